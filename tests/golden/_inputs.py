@@ -1,0 +1,40 @@
+"""Closed-form, seed-free input generators shared by make_golden.py and the tests.
+
+Golden fixtures store only expected OUTPUTS (and weights); the inputs are regenerated
+from these formulas on both sides, which keeps the fixtures small.
+"""
+import numpy as np
+
+
+def formula_tensor(shape, tag=0, dtype=np.float32):
+    """Deterministic pseudo-random-looking values in roughly [-1.5, 1.5] (float64 math)."""
+    n = int(np.prod(shape))
+    i = np.arange(n, dtype=np.float64)
+    v = np.sin(i * 0.7390851332151607 + 1.3 * tag + 0.25) + 0.5 * np.cos(i * 0.01170019 * (tag + 1) + 0.5 * tag)
+    v = v + 0.1 * np.sin(i * i * 1e-6 + tag)
+    return v.reshape(shape).astype(dtype)
+
+
+def formula_labels(shape, num_classes, tag=0):
+    """Integer labels in [0, num_classes) with spatial structure, shape (B,1,...)."""
+    n = int(np.prod(shape))
+    i = np.arange(n, dtype=np.float64)
+    v = np.floor((np.sin(i * 0.00931 + tag) * 0.5 + 0.5) * num_classes * 0.999 + 0.3 * np.sin(i * 0.7 + tag))
+    return np.clip(v, 0, num_classes - 1).reshape(shape).astype(np.float32)
+
+
+def sample_indices(n_total, n_samples, tag=0):
+    """Fixed, well-spread flat indices for storing a subset of a big output."""
+    step = 0.6180339887498949
+    return np.unique(np.floor(((np.arange(n_samples) * step + 0.1 * tag) % 1.0) * n_total).astype(np.int64))
+
+
+# (B, C, spatial, modes) cases shared by make_golden.py (G2) and the parity tests
+CROP_CASES = [
+    (1, 2, (13, 15, 11), (3, 4, 2)),
+    (1, 2, (33, 33, 33), (10, 14, 14)),
+    (1, 1, (65, 65, 65), (10, 14, 14)),
+    (1, 2, (61, 61, 40), (10, 14, 14)),
+    (2, 1, (9, 8, 7), (10, 14, 14)),       # clamped: m -> s // 2
+    (1, 3, (16, 12, 20), (8, 6, 10)),      # even sizes, 2m == N on every axis
+]

@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by importing the REFERENCE (build container only).
+
+    python tests/golden/make_golden.py [/root/reference]
+
+The reference tree never travels to the GPU box; only the .npz files written here do.
+Inputs come from the closed-form generators in _inputs.py, so fixtures hold weights and
+expected outputs only.  Re-running this script must reproduce the committed files
+(up to FFT-library rounding).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from _inputs import formula_tensor, formula_labels, sample_indices, CROP_CASES  # noqa: E402
+
+REF = sys.argv[1] if len(sys.argv) > 1 else '/root/reference'
+sys.path.insert(0, REF)
+import nets  # noqa: E402  (the reference package)
+from nets import custom_losses, dht, hnosegxs, nets_utils  # noqa: E402
+from nets.hartley_operator import HartleyOperator  # noqa: E402
+from nets.fourier_operator import FourierOperator  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(max(1, os.cpu_count() or 1))
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrays)} arrays')
+
+
+def grads_of(out, cot, wrt):
+    gs = torch.autograd.grad((out * cot).sum(), wrt, allow_unused=True)
+    return [None if g is None else g.detach().numpy() for g in gs]
+
+
+# ---------------------------------------------------------------------------- G1: dhtn
+def g1_dht():
+    out = {}
+    for tag, shape in enumerate([(2, 3, 13, 15, 11), (1, 2, 33, 33, 33)]):
+        for dt in (np.float32, np.float64):
+            x = T(formula_tensor(shape, tag, dt))
+            key = f's{tag}_{np.dtype(dt).name}'
+            f3 = dht.dht3(x)
+            i3 = dht.dht3(x, is_inverse=True)
+            f2 = dht.dht2(x)
+            i2 = dht.dht2(x, is_inverse=True)
+            if tag == 0:
+                out[f'{key}_fwd3'], out[f'{key}_inv3'] = f3.numpy(), i3.numpy()
+                out[f'{key}_fwd2'], out[f'{key}_inv2'] = f2.numpy(), i2.numpy()
+            else:
+                idx = sample_indices(x.numel(), 4096, tag)
+                out[f'{key}_idx'] = idx
+                out[f'{key}_fwd3'], out[f'{key}_inv3'] = f3.numpy().ravel()[idx], i3.numpy().ravel()[idx]
+                out[f'{key}_fwd2'] = f2.numpy().ravel()[idx]
+            rt = dht.dht3(dht.dht3(x), is_inverse=True)
+            out[f'{key}_roundtrip_err'] = np.array(float((rt - x).abs().max()))
+    save('g1_dht.npz', **out)
+
+
+# ------------------------------------------------------- G2: TransformCrop / PadInverse
+
+
+def g2_crop_pad():
+    out = {}
+    for ci, (b, c, sp, modes) in enumerate(CROP_CASES):
+        tc = hnosegxs.TransformCrop(modes, 5)
+        pi = hnosegxs.PadInverse(5)
+        x = T(formula_tensor((b, c) + sp, 10 + ci)).requires_grad_(True)
+        z = tc(x)
+        cot_z = T(formula_tensor(tuple(z.shape), 20 + ci))
+        (gx,) = grads_of(z, cot_z, [x])
+        zin = T(formula_tensor(tuple(z.shape), 30 + ci)).requires_grad_(True)
+        y = pi(zin, sp)
+        cot_y = T(formula_tensor(tuple(y.shape), 40 + ci))
+        (gz,) = grads_of(y, cot_y, [zin])
+        k = f'c{ci}'
+        out[f'{k}_zshape'] = np.array(z.shape)
+        out[f'{k}_crop'] = z.detach().numpy()
+        out[f'{k}_crop_gradx_idx'] = idx = sample_indices(x.numel(), 4096, ci)
+        out[f'{k}_crop_gradx'] = gx.ravel()[idx]
+        out[f'{k}_pad_idx'] = idy = sample_indices(y.numel(), 4096, ci + 1)
+        out[f'{k}_pad'] = y.detach().numpy().ravel()[idy]
+        out[f'{k}_pad_gradz'] = gz
+    save('g2_crop_pad.npz', **out)
+
+
+# ------------------------------------------------ G3: HartleyOperator / FourierOperator
+def g3_operators():
+    out = {}
+    ci_, co_, sp, modes = 3, 4, (12, 10, 14), (3, 2, 4)
+    x_np = formula_tensor((2, ci_) + sp, 50)
+    case = 0
+    for cls, name in ((HartleyOperator, 'hartley'), (FourierOperator, 'fourier')):
+        for wt in ('shared', 'individual'):
+            for use_transform in (True, False):
+                for use_bias in (False, True):
+                    torch.manual_seed(100 + case)
+                    op = cls(ci_, co_, modes, use_bias=use_bias, weights_type=wt, use_transform=use_transform)
+                    if use_bias:
+                        with torch.no_grad():
+                            op.bias.copy_(T(formula_tensor(tuple(op.bias.shape), 60 + case)) * 0.1)
+                    key = f'{name}_{wt}_t{int(use_transform)}_b{int(use_bias)}'
+                    if use_transform:
+                        x = T(x_np).requires_grad_(True)
+                    elif name == 'hartley':
+                        x = T(formula_tensor((2, ci_) + tuple(2 * m for m in modes), 70 + case)).requires_grad_(True)
+                    else:  # Fourier, already in the (complex) frequency domain
+                        shp = (2, ci_, 2 * modes[0], 2 * modes[1], modes[2])
+                        x = torch.complex(T(formula_tensor(shp, 70 + case)), T(formula_tensor(shp, 170 + case)))
+                        x = x.requires_grad_(True)
+                    y = op(x)
+                    params = dict(op.named_parameters())
+                    if y.is_complex():
+                        cot = torch.complex(T(formula_tensor(tuple(y.shape), 80 + case)),
+                                            T(formula_tensor(tuple(y.shape), 180 + case)))
+                        loss = (y * cot.conj()).real.sum()
+                        gs = torch.autograd.grad(loss, [x] + list(params.values()))
+                        gs = [g.detach().numpy() for g in gs]
+                    else:
+                        cot = T(formula_tensor(tuple(y.shape), 80 + case))
+                        gs = grads_of(y, cot, [x] + list(params.values()))
+                    out[f'{key}_case'] = np.array(case)
+                    out[f'{key}_y'] = y.detach().numpy()
+                    out[f'{key}_gx'] = gs[0]
+                    for (pn, p), g in zip(params.items(), gs[1:]):
+                        out[f'{key}_p_{pn}'] = p.detach().numpy()
+                        out[f'{key}_g_{pn}'] = g
+                    case += 1
+    save('g3_operators.npz', **out)
+
+
+# ---------------------------------------------------------------------- G5: losses
+def g5_losses():
+    out = {}
+    shape = (2, 4, 9, 10, 11)
+    logits = T(formula_tensor(shape, 90))
+    yp = torch.softmax(logits, dim=1).requires_grad_(True)
+    lab = formula_labels((2, 1, 9, 10, 11), 4, 3)
+    lab[1][lab[1] == 2] = 1  # sample 1 has an all-zero channel (label 2 absent): eps path
+    onehot = torch.movedim(torch.nn.functional.one_hot(T(lab)[:, 0].long(), 4).float(), -1, 1)
+    out['labels'] = lab
+    out['corrcoef'] = custom_losses.corrcoef(yp, onehot).detach().numpy()
+    out['dice_coef'] = custom_losses.dice_coef(yp, onehot).detach().numpy()
+    for name, fn in (('pcc', custom_losses.PCCLoss()), ('dice', custom_losses.DiceLoss()),
+                     ('expdice', custom_losses.ExpDiceLoss(0.3))):
+        val = fn(yp, onehot)
+        (g,) = torch.autograd.grad(val, [yp])
+        out[f'{name}_loss'] = val.detach().numpy()
+        out[f'{name}_grad'] = g.numpy()
+    save('g5_losses.npz', **out)
+
+
+# ----------------------------------------------------------- G6: full HNOSeg-XS (cfg1)
+def g6_hnosegxs():
+    torch.manual_seed(0)
+    model = nets.HNOSegXS(4, 4, 24, [3] * 8, (10, 14, 14))
+    n_params = sum(p.numel() for p in model.parameters())
+    assert n_params == 28248, n_params  # README.md:57-63 self check
+    sd = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+    out = {f'sd::{k}': v for k, v in sd.items()}
+    out['n_params'] = np.array(n_params)
+    for tag, shape in (('64', (1, 4, 64, 64, 64)), ('odd', (2, 4, 40, 36, 44))):
+        x = T(formula_tensor(shape, 7))
+        lab = formula_labels((shape[0], 1) + shape[2:], 4, 5)
+        onehot = torch.movedim(torch.nn.functional.one_hot(T(lab)[:, 0].long(), 4).float(), -1, 1)
+        model.zero_grad()
+        y = model(x)
+        loss = custom_losses.PCCLoss()(y, onehot)
+        loss.backward()
+        idx = sample_indices(y.numel(), 4096, 2)
+        out[f'{tag}_shape'] = np.array(shape)
+        out[f'{tag}_y_idx'] = idx
+        out[f'{tag}_y'] = y.detach().numpy().ravel()[idx]
+        out[f'{tag}_y_sum'] = np.array(y.detach().double().sum().item())
+        out[f'{tag}_loss'] = loss.detach().numpy()
+        for k, p in model.named_parameters():
+            out[f'{tag}_grad::{k}'] = p.grad.detach().numpy().copy()
+    save('g6_hnosegxs.npz', **out)
+
+
+# ------------------------------------------- G9: labels, padcrop, SNN init statistics
+def g9_misc():
+    sys.modules.setdefault('SimpleITK', type(sys)('SimpleITK'))
+    ti = type(sys)('torchinfo')
+    ti.summary = lambda *a, **k: 'summary'
+    sys.modules.setdefault('torchinfo', ti)
+    sys.modules.setdefault('torchview', type(sys)('torchview'))
+    from experiments import utils as ref_utils
+    out = {}
+    lab = formula_labels((2, 1, 5, 6, 7), 5, 1)
+    out['labels'] = lab
+    out['onehot5'] = ref_utils.to_categorical(T(lab), 5).numpy()
+    out['onehot_auto'] = ref_utils.to_categorical(T(lab)).numpy()
+    mapping = {4: 3, 3: 1, 1: 2}
+    out['remap_keys'] = np.array(list(mapping.keys()))
+    out['remap_vals'] = np.array(list(mapping.values()))
+    out['remapped'] = ref_utils.remap_labels(T(lab), mapping).numpy()
+    x = T(formula_tensor((1, 2, 7, 8, 9), 3))
+    targets = [(7, 8, 9), (10, 11, 12), (4, 5, 6), (9, 5, 9), (8, 8, 8)]
+    out['padcrop_targets'] = np.array(targets)
+    for i, t in enumerate(targets):
+        out[f'padcrop_{i}'] = nets_utils.spatial_padcrop(x, list(t)).numpy()
+    save('g9_misc.npz', **out)
+
+
+if __name__ == '__main__':
+    g1_dht()
+    g2_crop_pad()
+    g3_operators()
+    g5_losses()
+    g6_hnosegxs()
+    g9_misc()

@@ -1,0 +1,180 @@
+"""Pins the CPU oracle (oracle/hno_oracle.py) against golden vectors produced by the
+reference itself (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from _inputs import formula_tensor, formula_labels, CROP_CASES
+from oracle import hno_oracle as O
+
+TOL32 = 2e-5   # fp32 FFT vs fp32 FFT on identical op order: rounding only
+TOL64 = 1e-11
+# dense fp64 formulation vs the reference's fp32 FFT: the FFT's rounding error scales with
+# the FULL spectrum's energy while the kept block can be small, hence a looser bound
+TOLD = 1e-4
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def test_dht_against_reference():
+    g = load_golden('g1_dht.npz')
+    for tag, shape in enumerate([(2, 3, 13, 15, 11), (1, 2, 33, 33, 33)]):
+        for dt, tol in ((np.float32, TOL32), (np.float64, TOL64)):
+            x = T(formula_tensor(shape, tag, dt))
+            key = f's{tag}_{np.dtype(dt).name}'
+            f3, i3, f2 = O.dht3(x).numpy(), O.dht3(x, True).numpy(), O.dht2(x).numpy()
+            if tag == 0:
+                assert rel_err(f3, g[f'{key}_fwd3']) < tol
+                assert rel_err(i3, g[f'{key}_inv3']) < tol
+                assert rel_err(f2, g[f'{key}_fwd2']) < tol
+                assert rel_err(O.dht2(x, True).numpy(), g[f'{key}_inv2']) < tol
+            else:
+                idx = g[f'{key}_idx']
+                assert rel_err(f3.ravel()[idx], g[f'{key}_fwd3']) < tol
+                assert rel_err(i3.ravel()[idx], g[f'{key}_inv3']) < tol
+                assert rel_err(f2.ravel()[idx], g[f'{key}_fwd2']) < tol
+
+
+def test_dht_roundtrip_and_symmetry():
+    x = T(formula_tensor((1, 2, 9, 7, 10), 3, np.float64))
+    assert rel_err(O.dht3(O.dht3(x), True).numpy(), x.numpy()) < 1e-12
+    # dense cas-matrix form == FFT form
+    n = 10
+    c = O.cas_matrix(n)
+    assert torch.allclose(c, c.T)
+    v = T(formula_tensor((n,), 1, np.float64))
+    assert rel_err((c @ v / n).numpy(), O.dhtn(v, (-1,)).numpy()) < 1e-12
+
+
+@pytest.mark.parametrize('ci', range(len(CROP_CASES)))
+def test_transform_crop_pad_inverse(ci):
+    g = load_golden('g2_crop_pad.npz')
+    b, c, sp, modes = CROP_CASES[ci]
+    k = f'c{ci}'
+    x = T(formula_tensor((b, c) + sp, 10 + ci)).requires_grad_(True)
+    z = O.transform_crop(x, modes)
+    assert tuple(z.shape) == tuple(g[f'{k}_zshape'])
+    assert rel_err(z.detach().numpy(), g[f'{k}_crop']) < TOL32
+    cot = T(formula_tensor(tuple(z.shape), 20 + ci))
+    (gx,) = torch.autograd.grad((z * cot).sum(), [x])
+    assert rel_err(gx.numpy().ravel()[g[f'{k}_crop_gradx_idx']], g[f'{k}_crop_gradx']) < TOL32
+    zin = T(formula_tensor(tuple(z.shape), 30 + ci)).requires_grad_(True)
+    y = O.pad_inverse(zin, sp)
+    assert rel_err(y.detach().numpy().ravel()[g[f'{k}_pad_idx']], g[f'{k}_pad']) < TOL32
+    cot = T(formula_tensor(tuple(y.shape), 40 + ci))
+    (gz,) = torch.autograd.grad((y * cot).sum(), [zin])
+    assert rel_err(gz.numpy(), g[f'{k}_pad_gradz']) < TOL32
+    # the pruned separable (dense) formulation the HIP kernels implement agrees too
+    assert rel_err(O.dht_crop_dense(x.detach(), modes).numpy(), g[f'{k}_crop']) < TOLD
+    assert rel_err(O.pad_idht_dense(zin.detach(), sp).numpy().ravel()[g[f'{k}_pad_idx']], g[f'{k}_pad']) < TOLD
+    # adjoint identities used by the HIP backward
+    n3 = float(np.prod(sp))
+    assert rel_err((O.pad_idht_dense(cot_like(z, 20 + ci), sp) / n3).numpy().ravel()[g[f'{k}_crop_gradx_idx']],
+                   g[f'{k}_crop_gradx']) < TOLD
+    mm = O.clamp_modes(modes, sp)
+    assert rel_err(O.dht_crop_dense(cot_like(y, 40 + ci), mm, scale=1.0).numpy(), g[f'{k}_pad_gradz']) < TOLD
+
+
+def cot_like(t, tag):
+    return T(formula_tensor(tuple(t.shape), tag))
+
+
+def _operator_cases():
+    case = 0
+    for name in ('hartley', 'fourier'):
+        for wt in ('shared', 'individual'):
+            for use_transform in (True, False):
+                for use_bias in (False, True):
+                    yield name, wt, use_transform, use_bias, case
+                    case += 1
+
+
+@pytest.mark.parametrize('name,wt,use_transform,use_bias,case', list(_operator_cases()))
+def test_operators(name, wt, use_transform, use_bias, case):
+    g = load_golden('g3_operators.npz')
+    ci_, sp, modes = 3, (12, 10, 14), (3, 2, 4)
+    key = f'{name}_{wt}_t{int(use_transform)}_b{int(use_bias)}'
+    assert int(g[f'{key}_case']) == case
+    P = {k[len(key) + 3:]: T(g[k]).requires_grad_(True) for k in g.files if k.startswith(f'{key}_p_')}
+    bias = P.get('bias')
+    if use_transform:
+        x = T(formula_tensor((2, ci_) + sp, 50)).requires_grad_(True)
+    elif name == 'hartley':
+        x = T(formula_tensor((2, ci_) + tuple(2 * m for m in modes), 70 + case)).requires_grad_(True)
+    else:
+        shp = (2, ci_, 2 * modes[0], 2 * modes[1], modes[2])
+        x = torch.complex(T(formula_tensor(shp, 70 + case)), T(formula_tensor(shp, 170 + case))).requires_grad_(True)
+    if name == 'hartley':
+        y = O.hartley_operator(x, P['weight'], modes, bias, wt, use_transform)
+        plist = [('weight', P['weight'])]
+    else:
+        if use_transform:
+            y = O.fourier_operator(x, P['weight_real'], P['weight_imag'], modes, bias, wt)
+        else:
+            w = torch.complex(P['weight_real'], P['weight_imag'])
+            eq = 'oi,bidhw->bodhw' if wt == 'shared' else 'oidhw,bidhw->bodhw'
+            y = torch.einsum(eq, w, x)
+            if bias is not None:
+                y = y + bias
+        plist = [('weight_real', P['weight_real']), ('weight_imag', P['weight_imag'])]
+    if bias is not None:
+        plist.append(('bias', bias))
+    assert rel_err(_np(y), g[f'{key}_y']) < TOL32
+    if y.is_complex():
+        cot = torch.complex(T(formula_tensor(tuple(y.shape), 80 + case)), T(formula_tensor(tuple(y.shape), 180 + case)))
+        loss = (y * cot.conj()).real.sum()
+    else:
+        loss = (y * T(formula_tensor(tuple(y.shape), 80 + case))).sum()
+    gs = torch.autograd.grad(loss, [x] + [p for _, p in plist])
+    assert rel_err(_np(gs[0]), g[f'{key}_gx']) < 5e-5
+    for (pn, _), gp in zip(plist, gs[1:]):
+        assert rel_err(_np(gp), g[f'{key}_g_{pn}']) < 5e-5, pn
+
+
+def _np(t):
+    return t.detach().numpy()
+
+
+def test_losses():
+    g = load_golden('g5_losses.npz')
+    shape = (2, 4, 9, 10, 11)
+    yp = torch.softmax(T(formula_tensor(shape, 90)), dim=1).requires_grad_(True)
+    onehot = O.to_categorical(T(g['labels']), 4)
+    assert onehot[1, 2].sum() == 0  # the eps path is really exercised
+    assert rel_err(_np(O.corrcoef(yp, onehot)), g['corrcoef']) < 1e-5
+    assert rel_err(_np(O.dice_coef(yp, onehot)), g['dice_coef']) < 1e-5
+    for name, fn in (('pcc', O.pcc_loss), ('dice', O.dice_loss), ('expdice', O.exp_dice_loss)):
+        val = fn(yp, onehot)
+        (gr,) = torch.autograd.grad(val, [yp])
+        assert abs(float(val) - float(g[f'{name}_loss'])) < 1e-6
+        assert rel_err(gr.numpy(), g[f'{name}_grad']) < 1e-5
+
+
+@pytest.mark.parametrize('tag', ['64', 'odd'])
+def test_hnosegxs_full_model(tag):
+    g = load_golden('g6_hnosegxs.npz')
+    sd = {k[4:]: T(g[k]) for k in g.files if k.startswith('sd::')}
+    assert sum(v.numel() for v in sd.values()) == 28248 == int(g['n_params'])
+    shape = tuple(int(s) for s in g[f'{tag}_shape'])
+    x = T(formula_tensor(shape, 7))
+    lab = T(formula_labels((shape[0], 1) + shape[2:], 4, 5))
+    y, loss, grads = O.hnosegxs_step(sd, x, lab, [3] * 8, (10, 14, 14))
+    assert rel_err(y.numpy().ravel()[g[f'{tag}_y_idx']], g[f'{tag}_y']) < 1e-5
+    assert abs(float(loss) - float(g[f'{tag}_loss'])) < 1e-6
+    for k, gr in grads.items():
+        assert rel_err(gr.numpy(), g[f'{tag}_grad::{k}']) < 1e-4, k
+
+
+def test_labels_and_padcrop():
+    g = load_golden('g9_misc.npz')
+    lab = T(g['labels'])
+    assert np.array_equal(O.to_categorical(lab, 5).numpy(), g['onehot5'])
+    assert np.array_equal(O.to_categorical(lab).numpy(), g['onehot_auto'])
+    mapping = {int(k): int(v) for k, v in zip(g['remap_keys'], g['remap_vals'])}
+    assert np.array_equal(O.remap_labels(lab, mapping).numpy(), g['remapped'])
+    x = T(formula_tensor((1, 2, 7, 8, 9), 3))
+    for i, t in enumerate(g['padcrop_targets']):
+        assert np.array_equal(O.spatial_padcrop(x, tuple(int(v) for v in t)).numpy(), g[f'padcrop_{i}'])
