@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Benchmark of the accelerated hot path (contract in the task prompt / BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1] / [4]): HNOSeg-XS, BraTS'23 config (filters 24, 8 blocks x 3
+frequency-domain convs, modes (10,14,14)), per-GPU batch 2 of synthetic 4-modal 128^3 fp32
+volumes, random-init weights.  One step = forward + PCC loss + backward + gradient all-reduce
+(N > 1) + Adamax update.  Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (by total HIP-event
+time inside the timed region); `cpu_baseline` times the CPU oracle (the torch-CPU port of the
+reference op sequence) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MODEL_CFG = dict(in_channels=4, out_channels=4, filters=24, num_transform_blocks=[3] * 8, num_modes=(10, 14, 14))
+VOL = (128, 128, 128)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+ALGO_BYTES_PER_VOLUME = 4.67e9  # fwd 1.596 GB + bwd 3.073 GB
+
+
+def algorithmic_bytes(kernel, B):
+    """ALGORITHMIC bytes of one launch of `kernel` at the benchmark shapes."""
+    C, N3, M = 24, 65 ** 3, 20 * 28 * 28
+    V = 128 ** 3
+    f = 4
+    table = {
+        # 3-D truncated DHT, either direction: read N^3 reals, write 8 m0 m1 m2 reals;
+        # the two launches of one transform share that budget: the plane kernel owns the N^3 side
+        'dht_fwd_plane_kernel': B * C * N3 * f,
+        'dht_inv_plane_kernel': B * C * N3 * f,
+        'dht_fwd_d_kernel': B * C * M * f,
+        'dht_inv_d_kernel': B * C * M * f,
+        'pwconv_fwd_kernel': B * (48 + 24) * N3 * f,
+        'pwconv_bwd_kernel': B * (24 + 24 + 48 + 48) * N3 * f,
+        'conv_k2s2_fwd_kernel': B * (4 * V + C * N3) * f,
+        'conv_k2s2_bwd_kernel': B * (4 * V + 2 * C * N3) * f,
+        'upsoftmax_fwd_kernel': B * (4 * N3 + 4 * V) * f,
+        'upsoftmax_bwd_kernel': B * (8 * V + 4 * N3) * f,
+        'loss_stats_kernel': B * (4 * V * f + V),
+        'loss_bwd_kernel': B * (8 * V * f + V),
+    }
+    return table.get(kernel)
+
+
+def effective_cpus():
+    """CPUs this process may really use: affinity mask and cgroup quota, not os.cpu_count()."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(budget_s=40.0):
+    """CPU oracle (kind "port"): fwd + PCC + bwd + Adamax of HNOSeg-XS on the host cores, on a
+    bounded sample of the benchmark workload (one 4x128^3 volume per step when it fits the time
+    budget, otherwise one 4x64^3 volume, which is said in `sample`)."""
+    from oracle import hno_oracle as O
+    import multimodal_3d_image_segmentation_amd as pkg
+    ncores = min(effective_cpus(), 64)
+    torch.set_num_threads(ncores)
+    torch.manual_seed(0)
+    model = pkg.nets.HNOSegXS(**MODEL_CFG)   # parameters only; the oracle does the math
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    opt = torch.optim.Adamax(list(params.values()), lr=5e-3)
+    g = torch.Generator().manual_seed(1234)
+
+    def make(n):
+        return (torch.randn((1, 4, n, n, n), generator=g), torch.randint(0, 4, (1, 1, n, n, n), generator=g).float())
+
+    def step(xx, ll):
+        y = O.hnosegxs_forward(params, xx, MODEL_CFG['num_transform_blocks'], MODEL_CFG['num_modes'])
+        loss = O.pcc_loss(y, O.to_categorical(ll, 4))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return float(loss)
+
+    x64, l64 = make(64)
+    step(x64, l64)                      # warm-up
+    t0 = time.time()
+    step(x64, l64)
+    t64 = time.time() - t0
+    n, steps = (128, 1) if 9.0 * t64 < budget_s else (64, max(1, int(budget_s / 4 / max(t64, 1e-3))))
+    xs, ls = (make(128) if n == 128 else (x64, l64))
+    t0 = time.time()
+    for _ in range(steps):
+        step(xs, ls)
+    dt = time.time() - t0
+    return {'value': steps / dt, 'unit': 'volumes/s', 'cores': ncores, 'kind': 'port',
+            'sample': f'{steps} step(s) of one synthetic 4x{n}^3 volume, fwd+PCC+bwd+Adamax, oracle/hno_oracle.py '
+                      f'(torch-CPU fp32 port of the reference op sequence), {dt:.1f} s; 64^3 probe step {t64:.2f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=2, help='per-GPU batch (BASELINE config: 2)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-profile', action='store_true')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    import multimodal_3d_image_segmentation_amd as pkg
+    from multimodal_3d_image_segmentation_amd.nets import custom_losses
+    from multimodal_3d_image_segmentation_amd.parallel import FlatGradReplica
+
+    torch.manual_seed(0)
+    model = pkg.nets.HNOSegXS(**MODEL_CFG).to(dev)
+    rep = FlatGradReplica(model)
+    opt = torch.optim.Adamax(model.parameters(), lr=5e-3)
+    loss_fn = custom_losses.PCCLoss()
+    B = args.batch
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn((B, 4) + VOL, device=dev, generator=g)
+    labels = torch.randint(0, 4, (B, 1) + VOL, device=dev, generator=g).float()
+    lab_u8 = pkg.ops.labels_prepare(labels, 4)     # uint8 class map resident in HBM
+
+    def step():
+        y = model(x)
+        loss = loss_fn(y, lab_u8)
+        rep.zero_grad()
+        loss.backward()
+        rep.allreduce_grads()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    prof = None if args.no_kernel_profile else pkg._lib.KernelProfile(max_records=200 * args.steps + 64)
+    fence()
+    if prof:
+        prof.__enter__()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if prof:
+        prof.__exit__(None, None, None)
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    value = world * B * args.steps / dt
+
+    if rank == 0:
+        roofline = None
+        kernels = {}
+        if prof:
+            summ = prof.summary()
+            kernels = {k: {'calls_per_step': c / args.steps, 'avg_us': avg * 1e3, 'total_ms_per_step': s / args.steps}
+                       for k, (c, s, avg) in sorted(summ.items(), key=lambda kv: -kv[1][1])}
+            dom = max(summ.items(), key=lambda kv: kv[1][1])[0]
+            avg_ms = summ[dom][2]
+            ab = algorithmic_bytes(dom, B)
+            if ab:
+                achieved = ab / (avg_ms * 1e-3) / 1e9
+                traffic = None
+                tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+                if os.path.exists(tpath):
+                    traffic = json.load(open(tpath)).get(dom)
+                roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+                            'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                            'algorithmic_bytes_per_launch': ab, 'avg_launch_us': round(avg_ms * 1e3, 2)}
+        out = {
+            'metric': 'volumes/sec fwd+bwd, HNOSeg-XS 4-modal 128^3',
+            'value': round(value, 3), 'unit': 'volumes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': "HNOSeg-XS BraTS'23 config (filters 24, 8 blocks x 3, modes 10-14-14), "
+                                   "synthetic 4-modal 128^3 fp32, step = fwd + PCC loss + bwd + grad all-reduce + Adamax",
+                       'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
+                       'final_loss': round(float(loss), 6)},
+            'roofline': roofline,
+            'whole_step_roofline': {'algorithmic_GB_per_volume': ALGO_BYTES_PER_VOLUME / 1e9,
+                                    'hbm_bound_volumes_per_s_per_gpu': round(HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_VOLUME, 1),
+                                    'frac': round(value / world / (HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_VOLUME), 4)},
+            'kernels': kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

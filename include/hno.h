@@ -1,0 +1,150 @@
+/*
+ * libhno -- C ABI of the MI355X (gfx950) spectral-operator segmentation kernels.
+ *
+ * The reference (IBM/multimodal-3d-image-segmentation) is pure PyTorch and has no FFI of
+ * its own; every entry point below replaces the ATen op sequence issued by the cited
+ * reference call site (file:line into the reference tree).  All pointers are DEVICE
+ * pointers to contiguous fp32 NCDHW data unless stated otherwise, sizes are plain ints,
+ * `stream` is a hipStream_t passed as void*.  Kernels are enqueued on `stream` and never
+ * synchronise.  Return value: 0 on success, negative HNO_E* code otherwise (no C++
+ * exception crosses the boundary); hno_last_error() returns a thread-local message.
+ *
+ * The library owns nothing except immutable per-(N, m, device) twiddle tables; all
+ * buffers, including workspaces, are allocated and owned by the caller.
+ */
+#ifndef HNO_H_
+#define HNO_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HNO_OK 0
+#define HNO_EINVAL (-1)   /* bad argument (size, mode count, null pointer)      */
+#define HNO_ELIMIT (-2)   /* size outside the limits of the fused kernels        */
+#define HNO_EHIP (-3)     /* a HIP runtime call failed                           */
+
+#define HNO_ACT_NONE 0
+#define HNO_ACT_SELU 1
+#define HNO_ACT_ELU 2
+
+int hno_version(void);
+const char *hno_last_error(void);
+
+/* ---------------------------------------------------------------- 3-D Hartley transform
+ * hno_dht3_crop: out[bc, o0, o1, o2] = scale * sum_n x_eff[bc, n] * cas(phi(k(o), n))
+ *   over the kept mode block [0..m) U [N-m..N) per axis ('[low | high]' order).
+ *   x_eff = x                              if act_grad == HNO_ACT_NONE
+ *         = x * act'(from saved output u)  otherwise (u = `x_act_out`, same shape as x)
+ *   Replaces TransformCrop.forward (nets/hnosegxs.py:378-410: dhtn + 8 slices + 7 cats)
+ *   with scale = 1/(N0 N1 N2), and the backward of PadInverse (+ fused activation grad)
+ *   with scale = 1.  Modes must already be clamped (2 m_j <= N_j).
+ * hno_pad_idht3: out[bc, n] = act(scale * sum_k z[bc, k] * cas(phi(k, n)) + addend[bc, n])
+ *   Replaces PadInverse.forward (nets/hnosegxs.py:454-494: zeros + 7 cats + unscaled dhtn)
+ *   with scale = 1, and the backward of TransformCrop with scale = 1/(N0 N1 N2) and the
+ *   skip-connection gradient as `addend`.  `addend` may be NULL.
+ * Both need a caller-provided workspace of hno_dht3_workspace_bytes(...) bytes.
+ */
+size_t hno_dht3_workspace_bytes(int BC, int N0, int N1, int N2, int m0, int m1, int m2);
+int hno_dht3_crop(const float *x, const float *x_act_out, int act_grad, float *out, void *workspace,
+                  int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream);
+int hno_pad_idht3(const float *z, const float *addend, int act, float *out, void *workspace,
+                  int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream);
+
+/* ------------------------------------------------- shared-weight spectral channel mixing
+ * L stacked layers  z_{l+1} = act(W_l z_l + residual * z_l)  on a (B, C, M) spectrum
+ * (M = number of kept modes, contiguous).  W is (L, C, C) row-major [l][o][i].
+ * zs receives the L layer outputs, each (B, C, M): zs[l] = z_{l+1}.
+ * Replaces NeuralOperatorBlock.forward x n_XS (nets/hnosegxs.py:307-329) incl. the
+ * einsum 'oi,bidhw->bodhw' of HartleyOperator._call3d_notransform
+ * (nets/hartley_operator.py:287-292).
+ * Backward: given g = dL/dz_L, the saved z_0 and zs, produces dL/dz_0 and ACCUMULATES
+ * dL/dW into dW (L, C, C) (caller zeroes it).  workspace: hno_pwconv_bwd_workspace_bytes(C, C).
+ */
+int hno_specmix_shared_fwd(const float *z0, const float *W, float *zs, int B, int C, int M, int L,
+                           int residual, int act, void *stream);
+int hno_specmix_shared_bwd(const float *g, const float *z0, const float *zs, const float *W, float *gz0,
+                           float *dW, void *workspace, int B, int C, int M, int L, int residual, int act,
+                           void *stream);
+
+/* ------------------------------------------------------------ 1x1x1 convolution (+concat)
+ * y[b, o, v] = act( sum_i W[o, i] * [xa ; xb][b, i, v] + bias[o] ),  W is (Cout, Ca+Cb).
+ * xb may be NULL (Cb = 0); bias may be NULL.  Replaces torch.cat + ConvNormAct k=1
+ * (nets/hnosegxs.py:274-275, 254-255, 153; nets/nets_utils.py:127-133) and the bias-free
+ * conv_out (nets/hnosegxs.py:178).
+ * Backward: gy is dL/dy, y the saved OUTPUT (for act'); writes gxa / gxb (either may be
+ * NULL to skip) and ACCUMULATES dW (Cout, Ca+Cb) and dbias (Cout) (caller zeroes them).
+ * Weight gradients are reduced through per-block slabs in `workspace`
+ * (hno_pwconv_bwd_workspace_bytes) in a fixed order: no float atomics, reproducible bit for bit.
+ */
+size_t hno_pwconv_bwd_workspace_bytes(int Cin, int Cout);
+int hno_pwconv_fwd(const float *xa, int Ca, const float *xb, int Cb, const float *W, const float *bias,
+                   float *y, int B, int Cout, long long V, int act, void *stream);
+int hno_pwconv_bwd(const float *gy, const float *y, const float *xa, int Ca, const float *xb, int Cb,
+                   const float *W, float *gxa, float *gxb, float *dW, float *dbias, void *workspace,
+                   int B, int Cout, long long V, int act, void *stream);
+
+/* ------------------------------------------- strided 2x2x2 'resize' convolution (conv_in)
+ * Conv3d(Cin -> Cout, kernel 2, stride 2, padding 1) + bias + act: (B,Cin,D,H,W) ->
+ * (B,Cout,D/2+1,H/2+1,W/2+1).  Replaces ConvNormAct(kernel_size=2, stride=2)
+ * (nets/hnosegxs.py:102-104,151; nets/nets_utils.py:156-163).  W is (Cout,Cin,2,2,2).
+ * Backward produces dW / dbias (accumulated; workspace = hno_pwconv_bwd_workspace_bytes(Cin*8, Cout))
+ * and, if gx != NULL, the input gradient.
+ */
+int hno_conv_k2s2_fwd(const float *x, const float *W, const float *bias, float *y, int B, int Cin, int Cout,
+                      int D, int H, int Wd, int act, void *stream);
+int hno_conv_k2s2_bwd(const float *gy, const float *y, const float *x, const float *W, float *gx, float *dW,
+                      float *dbias, void *workspace, int B, int Cin, int Cout, int D, int H, int Wd, int act,
+                      void *stream);
+
+/* ------------------------------------------------- output head: upsample + channel softmax
+ * probs[b, c, :] = softmax_c( trilinear(logits_lr[b, c], size=(D,H,W), align_corners=False) )
+ * logits_lr is (B, K, d, h, w).  Together with hno_pwconv_fwd(conv_out) at LOW resolution
+ * this replaces F.interpolate(24 ch) -> conv_out -> softmax (nets/hnosegxs.py:174-180);
+ * the 1x1x1 conv commutes with the (linear, per-channel) interpolation.
+ * Backward: g_lr = trilinear^T( softmax'(probs, g_probs) ).
+ */
+int hno_upsoftmax_fwd(const float *logits_lr, float *probs, int B, int K, int d, int h, int w,
+                      int D, int H, int W, int softmax, void *stream);
+int hno_upsoftmax_bwd(const float *g_probs, const float *probs, float *g_lr, int B, int K, int d, int h, int w,
+                      int D, int H, int W, int softmax, void *stream);
+
+/* --------------------------------------------------------------- Pearson / Dice reductions
+ * Labels are uint8 class indices (B, V) -- one-hot encoding (experiments/utils.py:74-97)
+ * is fused.  stats is (B, K, 4) doubles: sum p, sum p^2, sum p*t, sum t.
+ * kind 0: PCCLoss (nets/custom_losses.py:17-70), 1: DiceLoss (:73-111),
+ * kind 2: ExpDiceLoss (:114-133, exponent `param`).
+ * fwd: fills stats (workspace, B*K*4 doubles), coef (B,K,4) floats = {r or dice value, alpha,
+ *      beta, gamma} with dloss/dprobs[b,k,v] = alpha*onehot + beta*p + gamma, and the scalar loss.
+ * bwd: g_probs[b,k,v] = gscale[0] * dloss/dprobs from coef (gscale: device pointer to the
+ *      upstream gradient, NULL = 1).
+ */
+int hno_loss_fwd(const float *probs, const uint8_t *labels, double *stats, float *coef, float *loss,
+                 int B, int K, long long V, int kind, float param, void *stream);
+int hno_loss_bwd(const float *probs, const uint8_t *labels, const float *coef, const float *gscale,
+                 float *g_probs, int B, int K, long long V, void *stream);
+
+/* float labels (B,1,...) -> uint8 class indices with optional remap table (256 entries,
+ * NULL = identity); one-hot output optional (NULL to skip). experiments/utils.py:74-119 */
+int hno_labels_prepare(const float *labels_f32, const int *remap_from, const int *remap_to, int n_remap,
+                       uint8_t *labels_u8, float *onehot, int B, int K, long long V, void *stream);
+
+/* ------------------------------------------------------------------ per-kernel profiler
+ * hno_profile_begin arms HIP-event bracketing of every kernel launch (on the stream the kernel
+ * is launched on); hno_profile_end stops it, waits for the events and returns the number of
+ * records written as (kernel id, milliseconds).  Not for use during graph capture. */
+int hno_profile_begin(int max_records);
+int hno_profile_end(int *kernel_ids, float *ms, int capacity);
+const char *hno_profile_kernel_name(int kernel_id);
+
+/* ------------------------------------------------------------------------ self tests
+ * C(MxN) = A(MxK) B(KxN) through the wave-level MFMA tile engine every kernel uses. */
+int hno_selftest_gemm(const float *A, const float *Bm, float *C, int M, int N, int K, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HNO_H_ */

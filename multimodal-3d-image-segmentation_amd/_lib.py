@@ -1,0 +1,127 @@
+"""ctypes binding of libhno.so (the C ABI declared in include/hno.h).
+
+PyTorch tensors are containers only: every call passes raw device pointers, sizes and the
+current HIP stream.  There is NO fallback: if the library is missing or a call fails the
+caller gets an exception.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libhno.so')
+_lib = None
+
+c_void_p, c_int, c_float, c_ll, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/hno.h declares
+SIGNATURES = {
+    'hno_version': (c_int, []),
+    'hno_last_error': (ctypes.c_char_p, []),
+    'hno_dht3_workspace_bytes': (c_size_t, [c_int] * 7),
+    'hno_dht3_crop': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_void_p]),
+    'hno_pad_idht3': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_void_p]),
+    'hno_specmix_shared_fwd': (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
+    'hno_specmix_shared_bwd': (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
+    'hno_pwconv_fwd': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_void_p]),
+    'hno_pwconv_bwd_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'hno_pwconv_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_void_p]),
+    'hno_conv_k2s2_fwd': (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
+    'hno_conv_k2s2_bwd': (c_int, [c_void_p] * 8 + [c_int] * 7 + [c_void_p]),
+    'hno_upsoftmax_fwd': (c_int, [c_void_p] * 2 + [c_int] * 9 + [c_void_p]),
+    'hno_upsoftmax_bwd': (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p]),
+    'hno_loss_fwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_ll, c_int, c_float, c_void_p]),
+    'hno_loss_bwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_ll, c_void_p]),
+    'hno_labels_prepare': (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 2 + [c_int, c_int, c_ll, c_void_p]),
+    'hno_profile_begin': (c_int, [c_int]),
+    'hno_profile_end': (c_int, [c_void_p, c_void_p, c_int]),
+    'hno_profile_kernel_name': (ctypes.c_char_p, [c_int]),
+    'hno_selftest_gemm': (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
+}
+
+
+class HnoError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile libhno.so for gfx950 with hipcc (works without a GPU)."""
+    cmd = ['make', '-C', os.path.join(_HERE, 'csrc'), '-j', '8']
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-8000:])
+    if res.returncode != 0:
+        raise HnoError('building libhno.so failed')
+    return LIB_PATH
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HnoError(f'{LIB_PATH} not found: run `python -c "import __graft_entry__ as g; g.build()"` '
+                           f'(there is no CPU/PyTorch fallback for the HIP path)')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), 'libhno needs contiguous device tensors'
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().hno_last_error().decode(errors='replace')
+        if rc == -1:
+            raise ValueError(f'{what}: {msg}')
+        raise HnoError(f'{what} failed ({rc}): {msg}')
+
+
+class KernelProfile:
+    """Context manager around hno_profile_begin/end: per-kernel HIP-event durations."""
+
+    def __init__(self, max_records=65536):
+        self.max_records = max_records
+        self.records = []   # (kernel name, milliseconds)
+
+    def __enter__(self):
+        check(lib().hno_profile_begin(self.max_records), 'hno_profile_begin')
+        return self
+
+    def __exit__(self, *exc):
+        ids = (ctypes.c_int * self.max_records)()
+        ms = (ctypes.c_float * self.max_records)()
+        n = lib().hno_profile_end(ids, ms, self.max_records)
+        if n < 0:
+            check(n, 'hno_profile_end')
+        names = {}
+        for i in range(n):
+            if ids[i] not in names:
+                names[ids[i]] = lib().hno_profile_kernel_name(ids[i]).decode()
+            self.records.append((names[ids[i]], ms[i]))
+        return False
+
+    def summary(self):
+        """name -> (calls, total ms, average ms)"""
+        agg = {}
+        for name, t in self.records:
+            c, s = agg.get(name, (0, 0.0))
+            agg[name] = (c + 1, s + t)
+        return {k: (c, s, s / c) for k, (c, s) in agg.items()}

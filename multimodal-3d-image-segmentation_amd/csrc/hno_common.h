@@ -1,0 +1,112 @@
+// Shared device/host helpers for libhno (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/hno.h"
+
+namespace hno {
+
+// ------------------------------------------------------------------ error plumbing
+void set_error(const std::string &msg);
+int fail(int code, const char *fmt, ...);
+
+#define HNO_CHECK_HIP(expr)                                                                    \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return ::hno::fail(HNO_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                               __FILE__, __LINE__);                                            \
+    } while (0)
+
+#define HNO_CHECK_LAUNCH()                                                                      \
+    do {                                                                                        \
+        hipError_t _e = hipGetLastError();                                                      \
+        if (_e != hipSuccess)                                                                   \
+            return ::hno::fail(HNO_EHIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), \
+                               __FILE__, __LINE__);                                             \
+    } while (0)
+
+#define HNO_REQUIRE(cond, ...)                               \
+    do {                                                     \
+        if (!(cond)) return ::hno::fail(HNO_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+// ------------------------------------------------------------------ per-kernel HIP-event profiler
+// Off by default (zero cost beyond one branch).  hno_profile_begin() arms it; every kernel launch
+// wrapped in a ProfScope is then bracketed by two hipEventRecord calls on ITS OWN stream.
+enum KernelId {
+    KID_DHT_FWD_PLANE = 0, KID_DHT_FWD_D, KID_DHT_INV_D, KID_DHT_INV_PLANE, KID_PWCONV_FWD, KID_PWCONV_BWD,
+    KID_CONV_K2S2_FWD, KID_CONV_K2S2_BWD, KID_UPSOFTMAX_FWD, KID_UPSOFTMAX_BWD, KID_LOSS_STATS, KID_LOSS_FINALIZE,
+    KID_LOSS_BWD, KID_LABELS, KID_COUNT
+};
+struct ProfScope {
+    int slot;
+    hipStream_t stream;
+    ProfScope(int kernel_id, hipStream_t s);
+    ~ProfScope();
+};
+
+// Weight-gradient partial sums: every block writes ONE slab of `n` floats (already reduced over
+// its 4 waves through LDS); reduce_partials_launch sums the slabs in a fixed order and ADDS the
+// result to dst.  No float atomics -> bitwise reproducible gradients, and none of the
+// same-address atomic contention that made the first version of these kernels 10x slower.
+int reduce_partials_launch(const float *partials, int nblocks, int n, float *dst0, int n0, float *dst1,
+                           hipStream_t stream);
+
+// wave-private accumulator fragments -> one slab per block.  `scratch` is >= 4 * n floats of LDS.
+// frag(idx) semantic: each wave calls store(idx, value) for the elements it owns; all 4 waves own
+// the same index set.
+__device__ __forceinline__ void block_sum_to_slab(float *scratch, int n, float *slab, int tid) {
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) slab[i] = scratch[i] + scratch[n + i] + scratch[2 * n + i] + scratch[3 * n + i];
+}
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// ------------------------------------------------------------------ activations
+#define HNO_SELU_ALPHA 1.6732632423543772848170429916717f
+#define HNO_SELU_SCALE 1.0507009873554804934193349852946f
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+    if (act == HNO_ACT_SELU) return x > 0.f ? HNO_SELU_SCALE * x : (HNO_SELU_SCALE * HNO_SELU_ALPHA) * expm1f(x);
+    if (act == HNO_ACT_ELU) return x > 0.f ? x : expm1f(x);
+    return x;
+}
+// derivative expressed through the saved OUTPUT y = act(x)
+__device__ __forceinline__ float act_grad_from_out(float y, int act) {
+    if (act == HNO_ACT_SELU) return y > 0.f ? HNO_SELU_SCALE : y + HNO_SELU_SCALE * HNO_SELU_ALPHA;
+    if (act == HNO_ACT_ELU) return y > 0.f ? 1.f : y + 1.f;
+    return 1.f;
+}
+
+// ------------------------------------------------------------------ MFMA tile engine
+// v_mfma_f32_16x16x4_f32: D(16x16) += A(16x4) * B(4x16), exact fp32 FMA chain.
+//   A operand: lane l holds A[row = l & 15][k = l >> 4]
+//   B operand: lane l holds B[k = l >> 4][col = l & 15]
+//   C/D      : lane l, reg r holds C[row = (l >> 4) * 4 + r][col = l & 15]
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// acc += A_tile(16 x 4*ksteps) * B_tile(4*ksteps x 16) with arbitrary element strides.
+// a points at A[row0][k0], b points at B[k0][col0].
+__device__ __forceinline__ f32x4 tile_mma(const float *a, int sa_r, int sa_k, const float *b, int sb_k, int sb_c,
+                                          int ksteps, f32x4 acc, int lane) {
+    const float *ap = a + (lane & 15) * sa_r + (lane >> 4) * sa_k;
+    const float *bp = b + (lane >> 4) * sb_k + (lane & 15) * sb_c;
+    const int da = 4 * sa_k, db = 4 * sb_k;
+    for (int ks = 0; ks < ksteps; ++ks) {
+        acc = mfma16(*ap, *bp, acc);
+        ap += da;
+        bp += db;
+    }
+    return acc;
+}
+
+}  // namespace hno

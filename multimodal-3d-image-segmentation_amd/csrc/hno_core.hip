@@ -1,0 +1,130 @@
+// Error plumbing, version and the MFMA tile-engine self test.
+#include <stdarg.h>
+
+#include <vector>
+
+#include "hno_common.h"
+
+namespace hno {
+static thread_local std::string g_last_error;
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+// ---- profiler state
+static const char *kKernelNames[KID_COUNT] = {
+    "dht_fwd_plane_kernel", "dht_fwd_d_kernel", "dht_inv_d_kernel", "dht_inv_plane_kernel", "pwconv_fwd_kernel",
+    "pwconv_bwd_kernel", "conv_k2s2_fwd_kernel", "conv_k2s2_bwd_kernel", "upsoftmax_fwd_kernel", "upsoftmax_bwd_kernel",
+    "loss_stats_kernel", "loss_finalize_kernel", "loss_bwd_kernel", "labels_kernel"};
+static bool g_prof_on = false;
+static std::vector<hipEvent_t> g_prof_events;  // 2 per record
+static std::vector<int> g_prof_ids;
+static int g_prof_cap = 0;
+
+ProfScope::ProfScope(int kernel_id, hipStream_t s) : slot(-1), stream(s) {
+    if (!g_prof_on || (int)g_prof_ids.size() >= g_prof_cap) return;
+    slot = (int)g_prof_ids.size();
+    g_prof_ids.push_back(kernel_id);
+    (void)hipEventRecord(g_prof_events[2 * slot], stream);
+}
+ProfScope::~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof_events[2 * slot + 1], stream);
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partials, int nblocks, int n,
+                                                             float *dst0, int n0, float *dst1) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 4 <= nblocks; b += 4) {
+        s0 += partials[(size_t)b * n + i];
+        s1 += partials[(size_t)(b + 1) * n + i];
+        s2 += partials[(size_t)(b + 2) * n + i];
+        s3 += partials[(size_t)(b + 3) * n + i];
+    }
+    for (; b < nblocks; ++b) s0 += partials[(size_t)b * n + i];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (i < n0) dst0[i] += s;
+    else if (dst1) dst1[i - n0] += s;
+}
+
+int reduce_partials_launch(const float *partials, int nblocks, int n, float *dst0, int n0, float *dst1,
+                           hipStream_t stream) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, partials, nblocks, n, dst0,
+                       n0, dst1);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+// One wave per 16x16 output tile; operands straight from global memory with the same
+// lane mapping every production kernel uses (so a layout mistake shows up here first).
+__global__ __launch_bounds__(64) void selftest_gemm_kernel(const float *A, const float *B, float *C, int M, int N, int K) {
+    const int lane = threadIdx.x;
+    const int mt = blockIdx.y, nt = blockIdx.x;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int row = mt * 16 + (lane & 15), k = k0 + (lane >> 4), col = nt * 16 + (lane & 15);
+        const float a = (row < M && k < K) ? A[(size_t)row * K + k] : 0.f;
+        const float b = (k < K && col < N) ? B[(size_t)k * N + col] : 0.f;
+        acc = mfma16(a, b, acc);
+    }
+    for (int r = 0; r < 4; ++r) {
+        const int row = mt * 16 + (lane >> 4) * 4 + r, col = nt * 16 + (lane & 15);
+        if (row < M && col < N) C[(size_t)row * N + col] = acc[r];
+    }
+}
+}  // namespace hno
+
+using namespace hno;
+
+extern "C" int hno_version(void) { return 100; }
+extern "C" const char *hno_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int hno_selftest_gemm(const float *A, const float *Bm, float *C, int M, int N, int K, void *stream) {
+    HNO_REQUIRE(A && Bm && C && M > 0 && N > 0 && K > 0, "hno_selftest_gemm: bad argument");
+    hipLaunchKernelGGL(selftest_gemm_kernel, dim3(ceil_div(N, 16), ceil_div(M, 16)), dim3(64), 0,
+                       (hipStream_t)stream, A, Bm, C, M, N, K);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+extern "C" int hno_profile_begin(int max_records) {
+    HNO_REQUIRE(max_records > 0 && max_records <= (1 << 20), "hno_profile_begin: bad record count");
+    while ((int)g_prof_events.size() < 2 * max_records) {
+        hipEvent_t e;
+        HNO_CHECK_HIP(hipEventCreate(&e));
+        g_prof_events.push_back(e);
+    }
+    g_prof_ids.clear();
+    g_prof_cap = max_records;
+    g_prof_on = true;
+    return HNO_OK;
+}
+
+// Stops recording, waits for the recorded events and returns per-record (kernel id, milliseconds).
+extern "C" int hno_profile_end(int *kernel_ids, float *ms, int capacity) {
+    g_prof_on = false;
+    const int n = (int)g_prof_ids.size();
+    for (int i = 0; i < n && i < capacity; ++i) {
+        HNO_CHECK_HIP(hipEventSynchronize(g_prof_events[2 * i + 1]));
+        float t = 0.f;
+        HNO_CHECK_HIP(hipEventElapsedTime(&t, g_prof_events[2 * i], g_prof_events[2 * i + 1]));
+        kernel_ids[i] = g_prof_ids[i];
+        ms[i] = t;
+    }
+    return n < capacity ? n : capacity;
+}
+
+extern "C" const char *hno_profile_kernel_name(int kernel_id) {
+    return (kernel_id >= 0 && kernel_id < KID_COUNT) ? kKernelNames[kernel_id] : "?";
+}

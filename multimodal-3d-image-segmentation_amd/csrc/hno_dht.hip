@@ -1,0 +1,650 @@
+// Mode-truncated 3-D discrete Hartley transform for gfx950 (MI355X).
+//
+// Reference semantics: nets/dht.py:16-36 (H = Re F - Im F, 1/N on the forward only),
+// nets/hnosegxs.py:378-410 (TransformCrop) and :454-494 (PadInverse).
+//
+// Formulation (see DESIGN.md "DHT kernels"): the kept block is 2m of N outputs per axis, so
+// each axis is a *pruned direct DFT* written as a small real GEMM against cos/sin tables and
+// run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32 FMA chains):
+//   * real-input / real-output Hermitian symmetry halves the last-axis work (k2 in 0..m2),
+//   * input folding  x[n] +- x[N-n]  halves every reduction length (cos part / sin part),
+//   * output pairing (+k, -k share the same cos and sin sums) halves the row count.
+// Forward  = [plane kernel: axis W then axis H, one (b*c, n0) plane per workgroup, staged in
+//             LDS] -> small intermediate in L2/MALL -> [D kernel: axis D + Re-/+Im + crop].
+// Inverse  = the transposed chain: [D kernel] -> intermediate -> [plane kernel: H then W,
+//             fused scale + residual add + SELU on store].
+#include <math.h>
+#include <stdarg.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "hno_common.h"
+
+namespace hno {
+
+// ------------------------------------------------------------------------------ plans
+struct Axis {
+    int N, m;      // size, kept modes (clamped: 2m <= N)
+    int J, Js;     // cos fold range 0..J, sin fold range 1..Js
+    int KT, KP;    // k tiles of 16 covering 0..m, KP = 16*KT
+    int KcP, KsP;  // forward reduction lengths padded to 4
+    int KmP;       // inverse reduction length (0..m) padded to 4
+    int NT;        // inverse output tiles of 16 covering 0..J
+    int cosF, sinF, cosI, sinI;  // offsets (floats) into the table buffer
+};
+
+struct DhtPlan {
+    Axis ax[3];
+    float *tables;     // device
+    int table_floats;
+    int K1S;           // 2*m1 + 1 signed k1 values
+    int CP;            // K1S * KP2 columns per part (re / im) of the intermediate
+    int MP1;           // N1 rounded up to 16
+    // forward plane kernel LDS layout (floats)
+    int lda2, TP, ldt, f_tabW, f_tabH, f_xs, f_T, f_lds_floats;
+    // inverse plane kernel LDS layout
+    int ldE, ldF, i_tabH, i_tabW, i_Es, i_Ed, i_FR, i_FI, i_lds_floats;
+};
+
+static int pad_2mod4(int v) {
+    while ((v & 3) != 2) ++v;
+    return v;
+}
+
+static void fill_axis(Axis &a, int N, int m, int &cursor) {
+    a.N = N;
+    a.m = m;
+    a.J = N / 2;
+    a.Js = (N - 1) / 2;
+    a.KT = ceil_div(m + 1, 16);
+    a.KP = a.KT * 16;
+    a.KcP = round_up(a.J + 1, 4);
+    a.KsP = round_up(a.Js, 4);
+    a.KmP = round_up(m + 1, 4);
+    a.NT = ceil_div(a.J + 1, 16);
+    a.cosF = cursor;
+    cursor += a.KT * a.KcP * 16;
+    a.sinF = cursor;
+    cursor += a.KT * a.KsP * 16;
+    a.cosI = cursor;
+    cursor += a.NT * a.KmP * 16;
+    a.sinI = cursor;
+    cursor += a.NT * a.KmP * 16;
+}
+
+static void build_axis_tables(const Axis &a, std::vector<float> &t) {
+    const double th = 2.0 * M_PI / a.N;
+    // forward: B[kk][k]; cos row kk <-> folded position c = kk (0..J);
+    //          sin row kk <-> folded position J+1+kk <-> j = Js - kk (1..Js)
+    for (int kt = 0; kt < a.KT; ++kt)
+        for (int kk = 0; kk < a.KcP; ++kk)
+            for (int c = 0; c < 16; ++c) {
+                int k = kt * 16 + c;
+                double v = (kk <= a.J && k <= a.m) ? cos(th * (double)((long long)k * kk % a.N)) : 0.0;
+                t[a.cosF + (kt * a.KcP + kk) * 16 + c] = (float)v;
+            }
+    for (int kt = 0; kt < a.KT; ++kt)
+        for (int kk = 0; kk < a.KsP; ++kk)
+            for (int c = 0; c < 16; ++c) {
+                int k = kt * 16 + c;
+                int j = a.Js - kk;
+                double v = (kk < a.Js && k <= a.m) ? sin(th * (double)((long long)k * j % a.N)) : 0.0;
+                t[a.sinF + (kt * a.KsP + kk) * 16 + c] = (float)v;
+            }
+    // inverse: B[kk][n], kk = frequency 0..m, n = output position 0..J
+    for (int nt = 0; nt < a.NT; ++nt)
+        for (int kk = 0; kk < a.KmP; ++kk)
+            for (int c = 0; c < 16; ++c) {
+                int n = nt * 16 + c;
+                bool ok = (kk <= a.m && n <= a.J);
+                double ang = th * (double)((long long)kk * n % a.N);
+                t[a.cosI + (nt * a.KmP + kk) * 16 + c] = ok ? (float)cos(ang) : 0.f;
+                t[a.sinI + (nt * a.KmP + kk) * 16 + c] = ok ? (float)sin(ang) : 0.f;
+            }
+}
+
+typedef std::tuple<int, int, int, int, int, int, int> PlanKey;
+static std::map<PlanKey, DhtPlan> g_plans;
+static std::mutex g_plan_mutex;
+
+static int get_plan(int N0, int N1, int N2, int m0, int m1, int m2, const DhtPlan **out) {
+    int dev = 0;
+    HNO_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    PlanKey key(dev, N0, N1, N2, m0, m1, m2);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) {
+        *out = &it->second;
+        return HNO_OK;
+    }
+    DhtPlan p;
+    int cursor = 0;
+    fill_axis(p.ax[0], N0, m0, cursor);
+    fill_axis(p.ax[1], N1, m1, cursor);
+    fill_axis(p.ax[2], N2, m2, cursor);
+    p.table_floats = cursor;
+    std::vector<float> host(cursor, 0.f);
+    for (int i = 0; i < 3; ++i) build_axis_tables(p.ax[i], host);
+    // table creation is the one place that allocates: do it outside graph capture (warm-up)
+    HNO_CHECK_HIP(hipMalloc((void **)&p.tables, sizeof(float) * cursor));
+    HNO_CHECK_HIP(hipMemcpy(p.tables, host.data(), sizeof(float) * cursor, hipMemcpyHostToDevice));
+    const Axis &a1 = p.ax[1], &a2 = p.ax[2];
+    p.K1S = 2 * m1 + 1;
+    p.CP = p.K1S * a2.KP;
+    p.MP1 = round_up(N1, 16);
+    // forward plane LDS
+    int need = a2.KcP > (a2.J + 1 + a2.KsP) ? a2.KcP : (a2.J + 1 + a2.KsP);
+    if (need < N2) need = N2;
+    p.lda2 = pad_2mod4(need);
+    p.TP = a1.KcP > (a1.J + 1 + a1.KsP) ? a1.KcP : (a1.J + 1 + a1.KsP);
+    if (p.TP < N1) p.TP = N1;
+    p.ldt = 2 * a2.KP + 16;
+    int c = 0;
+    p.f_tabW = c;
+    c += a2.KT * (a2.KcP + a2.KsP) * 16;
+    p.f_tabH = c;
+    c += a1.KT * (a1.KcP + a1.KsP) * 16;
+    p.f_xs = c;
+    c += p.MP1 * p.lda2;
+    p.f_T = c;
+    c += p.TP * p.ldt;
+    p.f_lds_floats = c;
+    // inverse plane LDS
+    p.ldE = pad_2mod4(a1.KmP);
+    p.ldF = pad_2mod4(a2.KmP);
+    c = 0;
+    p.i_tabH = c;
+    c += 2 * a1.NT * a1.KmP * 16;
+    p.i_tabW = c;
+    c += 2 * a2.NT * a2.KmP * 16;
+    p.i_Es = c;
+    c += 2 * a2.KP * p.ldE;
+    p.i_Ed = c;
+    c += 2 * a2.KP * p.ldE;
+    p.i_FR = c;
+    c += p.MP1 * p.ldF;
+    p.i_FI = c;
+    c += p.MP1 * p.ldF;
+    p.i_lds_floats = c;
+    auto res = g_plans.emplace(key, p);
+    *out = &res.first->second;
+    return HNO_OK;
+}
+
+// ------------------------------------------------------------------------------ kernels
+struct DhtArgs {
+    DhtPlan p;
+    int BC;
+    float scale;
+    int act;  // forward: activation whose derivative multiplies the input; inverse: epilogue act
+};
+
+// signed frequency -> index in the [low | high] block, or -1 if not kept
+__device__ __forceinline__ int kept_pos(int k, int m) { return (k >= 0) ? (k < m ? k : -1) : (k >= -m ? k + 2 * m : -1); }
+
+// ---- forward, axes W and H, one (bc, n0) plane per workgroup iteration -------------------
+__global__ __launch_bounds__(256) void dht_fwd_plane_kernel(const float *__restrict__ x, const float *__restrict__ xact,
+                                                            float *__restrict__ Y, DhtArgs a) {
+    extern __shared__ float lds[];
+    const DhtPlan &p = a.p;
+    const Axis &a1 = p.ax[1], &a2 = p.ax[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N1 = a1.N, N2 = a2.N;
+    float *tabW = lds + p.f_tabW, *tabH = lds + p.f_tabH, *xs = lds + p.f_xs, *T = lds + p.f_T;
+    const float *cosW = tabW, *sinW = tabW + a2.KT * a2.KcP * 16;
+    const float *cosH = tabH, *sinH = tabH + a1.KT * a1.KcP * 16;
+    // tables: contiguous in the plan buffer as cosF | sinF per axis
+    for (int i = tid; i < a2.KT * (a2.KcP + a2.KsP) * 16; i += 256) tabW[i] = p.tables[a2.cosF + i];
+    for (int i = tid; i < a1.KT * (a1.KcP + a1.KsP) * 16; i += 256) tabH[i] = p.tables[a1.cosF + i];
+    // zero the padding of xs once (rows >= N1, columns >= N2): never overwritten below
+    for (int i = tid; i < (p.MP1 - N1) * p.lda2; i += 256) xs[N1 * p.lda2 + i] = 0.f;
+    const int padc = p.lda2 - N2;
+    for (int i = tid; i < N1 * padc; i += 256) xs[(i / padc) * p.lda2 + N2 + (i % padc)] = 0.f;
+    // T rows >= N1 are reduction padding for axis H: keep them zero (stage W never stores there)
+    for (int i = tid; i < (p.TP - N1) * p.ldt; i += 256) T[N1 * p.ldt + i] = 0.f;
+
+    const int planes = a.BC * p.ax[0].N;
+    const size_t plane_elems = (size_t)N1 * N2;
+    const int MT1 = p.MP1 / 16;
+    for (int plane = blockIdx.x; plane < planes; plane += gridDim.x) {
+        const float *xp = x + (size_t)plane * plane_elems;
+        const float *up = xact ? xact + (size_t)plane * plane_elems : nullptr;
+        __syncthreads();  // previous iteration finished reading xs / T
+        // ---- load + fold along W: xs[r][c] = x[c] + x[N-c] (c <= Js), xs[r][N-c] = x[c] - x[N-c]
+        for (int r = wave; r < N1; r += 4) {
+            const float *row = xp + (size_t)r * N2;
+            const float *urow = up ? up + (size_t)r * N2 : nullptr;
+            float *dst = xs + r * p.lda2;
+            for (int c = lane; c <= a2.J; c += 64) {
+                float va = row[c];
+                if (urow) va *= act_grad_from_out(urow[c], a.act);
+                if (c >= 1 && c <= a2.Js) {
+                    float vb = row[N2 - c];
+                    if (urow) vb *= act_grad_from_out(urow[N2 - c], a.act);
+                    dst[c] = va + vb;
+                    dst[N2 - c] = va - vb;
+                } else {
+                    dst[c] = va;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- axis W: T[n1][k2] = sum_c xs[n1][c] * tab ; cos -> columns [0,KP2), sin -> [KP2, 2KP2)
+        const int ntaskW = MT1 * a2.KT * 2;
+        for (int t = wave; t < ntaskW; t += 4) {
+            const int which = t & 1, kt = (t >> 1) % a2.KT, mt = (t >> 1) / a2.KT;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (which == 0)
+                acc = tile_mma(xs + mt * 16 * p.lda2, p.lda2, 1, cosW + kt * a2.KcP * 16, 16, 1, a2.KcP / 4, acc, lane);
+            else
+                acc = tile_mma(xs + mt * 16 * p.lda2 + a2.J + 1, p.lda2, 1, sinW + kt * a2.KsP * 16, 16, 1,
+                               a2.KsP / 4, acc, lane);
+            const int col = which * a2.KP + kt * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = mt * 16 + (lane >> 4) * 4 + r;
+                if (row < N1) T[row * p.ldt + col] = acc[r];
+            }
+        }
+        __syncthreads();
+        // ---- fold T along n1 in place
+        {
+            const int ncol = 2 * a2.KP;
+            for (int i = tid; i < a1.Js * ncol; i += 256) {
+                const int c = 1 + i / ncol, col = i % ncol;
+                const float va = T[c * p.ldt + col], vb = T[(N1 - c) * p.ldt + col];
+                T[c * p.ldt + col] = va + vb;
+                T[(N1 - c) * p.ldt + col] = va - vb;
+            }
+        }
+        __syncthreads();
+        // ---- axis H: rows = T columns (Ac | As), reduce over n1, outputs k1 in 0..m1 (+/-)
+        float *Yp = Y + (size_t)plane * (2 * p.CP);
+        const int ntaskH = a2.KT * a1.KT * 2;
+        for (int t = wave; t < ntaskH; t += 4) {
+            const int part = t & 1, kt1 = (t >> 1) % a1.KT, kt2 = (t >> 1) / a1.KT;
+            const float *Tc = T + kt2 * 16;             // Ac columns of this k2 tile
+            const float *Ts = T + a2.KP + kt2 * 16;     // As columns
+            const float *bc = cosH + kt1 * a1.KcP * 16, *bs = sinH + kt1 * a1.KsP * 16;
+            f32x4 accP = {0.f, 0.f, 0.f, 0.f}, accQ = {0.f, 0.f, 0.f, 0.f};
+            if (part == 0) {  // BR(+-k1) = P_Ac -+ Q_As
+                accP = tile_mma(Tc, 1, p.ldt, bc, 16, 1, a1.KcP / 4, accP, lane);
+                accQ = tile_mma(Ts + (a1.J + 1) * p.ldt, 1, p.ldt, bs, 16, 1, a1.KsP / 4, accQ, lane);
+            } else {          // BI(+k1) = -(Q_Ac + P_As), BI(-k1) = Q_Ac - P_As
+                accP = tile_mma(Ts, 1, p.ldt, bc, 16, 1, a1.KcP / 4, accP, lane);
+                accQ = tile_mma(Tc + (a1.J + 1) * p.ldt, 1, p.ldt, bs, 16, 1, a1.KsP / 4, accQ, lane);
+            }
+            const int k1 = kt1 * 16 + (lane & 15);
+            if (k1 <= a1.m) {
+                f32x4 vp, vm;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (part == 0) {
+                        vp[r] = accP[r] - accQ[r];
+                        vm[r] = accP[r] + accQ[r];
+                    } else {
+                        vp[r] = -(accQ[r] + accP[r]);
+                        vm[r] = accQ[r] - accP[r];
+                    }
+                }
+                const int k2 = kt2 * 16 + (lane >> 4) * 4;
+                float *dstp = Yp + (size_t)(part * p.K1S + (a1.m + k1)) * a2.KP + k2;
+                *reinterpret_cast<f32x4 *>(dstp) = vp;
+                if (k1 >= 1) {
+                    float *dstm = Yp + (size_t)(part * p.K1S + (a1.m - k1)) * a2.KP + k2;
+                    *reinterpret_cast<f32x4 *>(dstm) = vm;
+                }
+            }
+        }
+    }
+}
+
+// ---- forward, axis D + (Re -/+ Im) + crop: one wave per (bc, column tile) ----------------
+__global__ __launch_bounds__(64) void dht_fwd_d_kernel(const float *__restrict__ Y, float *__restrict__ out, DhtArgs a) {
+    extern __shared__ float lds[];
+    const DhtPlan &p = a.p;
+    const Axis &a0 = p.ax[0], &a1 = p.ax[1], &a2 = p.ax[2];
+    const int lane = threadIdx.x;
+    const int ntab = a0.KT * (a0.KcP + a0.KsP) * 16;
+    for (int i = lane; i < ntab; i += 64) lds[i] = p.tables[a0.cosF + i];
+    __syncthreads();
+    const float *cosD = lds, *sinD = lds + a0.KT * a0.KcP * 16;
+    const int ct = blockIdx.x;  // column tile: (k1s, kt2)
+    const int bc = blockIdx.y;
+    const int k1s = ct / a2.KT, kt2 = ct % a2.KT;
+    const int N0 = a0.N;
+    const size_t pstride = (size_t)2 * p.CP;  // floats per n0 plane
+    const float *Yb = Y + (size_t)bc * N0 * pstride;
+    const int colR = ct * 16 + (lane & 15), colI = p.CP + colR;
+    const int q = lane >> 4;
+    const int m0 = a0.m, m1 = a1.m, m2 = a2.m;
+    float *ob = out + (size_t)bc * (2 * m0) * (2 * m1) * (2 * m2);
+    for (int kt0 = 0; kt0 < a0.KT; ++kt0) {
+        f32x4 PR = {0.f, 0.f, 0.f, 0.f}, PI = PR, QR = PR, QI = PR;
+        const float *bc_ = cosD + kt0 * a0.KcP * 16, *bs_ = sinD + kt0 * a0.KsP * 16;
+        for (int ks = 0; ks < a0.KcP / 4; ++ks) {
+            const int c = ks * 4 + q;
+            const bool in = c <= a0.J;
+            const bool paired = in && c >= 1 && c <= a0.Js;
+            const int c1 = in ? c : 0, c2 = paired ? N0 - c : 0;
+            float vr = Yb[c1 * pstride + colR], vi = Yb[c1 * pstride + colI];
+            const float wr = Yb[c2 * pstride + colR], wi = Yb[c2 * pstride + colI];
+            vr = in ? vr + (paired ? wr : 0.f) : 0.f;
+            vi = in ? vi + (paired ? wi : 0.f) : 0.f;
+            const float b = bc_[(ks * 4 + q) * 16 + (lane & 15)];
+            PR = mfma16(vr, b, PR);
+            PI = mfma16(vi, b, PI);
+        }
+        for (int ks = 0; ks < a0.KsP / 4; ++ks) {
+            const int kk = ks * 4 + q;
+            const bool in = kk < a0.Js;
+            const int j = in ? a0.Js - kk : 1;
+            const float vr = in ? Yb[j * pstride + colR] - Yb[(N0 - j) * pstride + colR] : 0.f;
+            const float vi = in ? Yb[j * pstride + colI] - Yb[(N0 - j) * pstride + colI] : 0.f;
+            const float b = bs_[(ks * 4 + q) * 16 + (lane & 15)];
+            QR = mfma16(vr, b, QR);
+            QI = mfma16(vi, b, QI);
+        }
+        // lane holds, for k0 = kt0*16 + (lane&15) and k2 = kt2*16 + q*4 + r:
+        //   X(+k0) = (PR + QI) + i (PI - QR),  X(-k0) = (PR - QI) + i (PI + QR)
+        const int k0 = kt0 * 16 + (lane & 15);
+        const int k1 = k1s - m1;
+        if (k0 <= m0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k2 = kt2 * 16 + q * 4 + r;
+                if (k2 > m2) continue;
+#pragma unroll
+                for (int sgn = 0; sgn < 2; ++sgn) {
+                    if (sgn == 1 && k0 == 0) continue;
+                    const int kk0 = sgn ? -k0 : k0;
+                    const float xr = sgn ? PR[r] - QI[r] : PR[r] + QI[r];
+                    const float xi = sgn ? PI[r] + QR[r] : PI[r] - QR[r];
+                    // H[k] = Re X[k] - Im X[k]
+                    int o0 = kept_pos(kk0, m0), o1 = kept_pos(k1, m1);
+                    if (k2 < m2 && o0 >= 0 && o1 >= 0)
+                        ob[((size_t)o0 * (2 * m1) + o1) * (2 * m2) + k2] = a.scale * (xr - xi);
+                    // H[-k] = Re X[k] + Im X[k]
+                    o0 = kept_pos(-kk0, m0);
+                    o1 = kept_pos(-k1, m1);
+                    if (k2 >= 1 && o0 >= 0 && o1 >= 0)
+                        ob[((size_t)o0 * (2 * m1) + o1) * (2 * m2) + (2 * m2 - k2)] = a.scale * (xr + xi);
+                }
+            }
+        }
+    }
+}
+
+// ---- inverse, axis D: spectrum block -> E[bc][n0][part][k1s][k2] --------------------------
+__device__ __forceinline__ float zk_load(const float *__restrict__ zb, int k0, int k1, int k2, int m0, int m1, int m2) {
+    const int o0 = kept_pos(k0, m0), o1 = kept_pos(k1, m1), o2 = kept_pos(k2, m2);
+    const bool ok = (o0 >= 0) & (o1 >= 0) & (o2 >= 0);
+    const size_t idx = ok ? ((size_t)o0 * (2 * m1) + o1) * (2 * m2) + o2 : 0;
+    const float v = zb[idx];
+    return ok ? v : 0.f;
+}
+
+__global__ __launch_bounds__(64) void dht_inv_d_kernel(const float *__restrict__ z, float *__restrict__ E, DhtArgs a) {
+    extern __shared__ float lds[];
+    const DhtPlan &p = a.p;
+    const Axis &a0 = p.ax[0], &a1 = p.ax[1], &a2 = p.ax[2];
+    const int lane = threadIdx.x;
+    const int ntab = 2 * a0.NT * a0.KmP * 16;
+    for (int i = lane; i < ntab; i += 64) lds[i] = p.tables[a0.cosI + i];
+    __syncthreads();
+    const float *cosD = lds, *sinD = lds + a0.NT * a0.KmP * 16;
+    const int ct = blockIdx.x, bc = blockIdx.y;
+    const int k1s = ct / a2.KT, kt2 = ct % a2.KT;
+    const int m0 = a0.m, m1 = a1.m, m2 = a2.m, N0 = a0.N;
+    const float *zb = z + (size_t)bc * (2 * m0) * (2 * m1) * (2 * m2);
+    const int q = lane >> 4;
+    const int k1 = k1s - m1;
+    const int k2 = kt2 * 16 + (lane & 15);  // A-operand row of this lane
+    // A operands for all k steps (k0 = ks*4 + q): Gs (cos part) and Gd (sin part), re & im
+    const int KS = a0.KmP / 4;
+    const size_t pstride = (size_t)2 * p.CP;
+    float *Eb = E + (size_t)bc * N0 * pstride;
+    for (int nt = 0; nt < a0.NT; ++nt) {
+        f32x4 UR = {0.f, 0.f, 0.f, 0.f}, UI = UR, VR = UR, VI = UR;
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k0 = ks * 4 + q;
+            float gsr = 0.f, gsi = 0.f, gdr = 0.f, gdi = 0.f;
+            if (k0 <= m0 && k2 <= m2) {
+                const float va = zk_load(zb, k0, k1, k2, m0, m1, m2);
+                const float vb = k2 >= 1 ? zk_load(zb, -k0, -k1, -k2, m0, m1, m2) : 0.f;
+                // G'(+k0) = (va + vb) + i (vb - va)
+                gsr = va + vb;
+                gsi = vb - va;
+                if (k0 >= 1) {
+                    const float vc = zk_load(zb, -k0, k1, k2, m0, m1, m2);
+                    const float vd = k2 >= 1 ? zk_load(zb, k0, -k1, -k2, m0, m1, m2) : 0.f;
+                    // G'(-k0) = (vc + vd) + i (vd - vc)
+                    gdr = gsr - (vc + vd);
+                    gdi = gsi - (vd - vc);
+                    gsr += vc + vd;
+                    gsi += vd - vc;
+                }
+            }
+            const float bcv = cosD[(nt * a0.KmP + ks * 4 + q) * 16 + (lane & 15)];
+            const float bsv = sinD[(nt * a0.KmP + ks * 4 + q) * 16 + (lane & 15)];
+            UR = mfma16(gsr, bcv, UR);
+            UI = mfma16(gsi, bcv, UI);
+            VR = mfma16(gdr, bsv, VR);
+            VI = mfma16(gdi, bsv, VI);
+        }
+        // lane holds rows k2' = kt2*16 + q*4 + r, column n0 = nt*16 + (lane&15)
+        const int n0 = nt * 16 + (lane & 15);
+        if (n0 <= a0.J) {
+            f32x4 er, ei, fr, fi;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                er[r] = UR[r] - VI[r];  // E[n0]    = U + iV
+                ei[r] = UI[r] + VR[r];
+                fr[r] = UR[r] + VI[r];  // E[N0-n0] = U - iV
+                fi[r] = UI[r] - VR[r];
+            }
+            const size_t col = (size_t)k1s * a2.KP + kt2 * 16 + q * 4;
+            *reinterpret_cast<f32x4 *>(Eb + (size_t)n0 * pstride + col) = er;
+            *reinterpret_cast<f32x4 *>(Eb + (size_t)n0 * pstride + p.CP + col) = ei;
+            if (n0 >= 1 && n0 <= a0.Js) {
+                *reinterpret_cast<f32x4 *>(Eb + (size_t)(N0 - n0) * pstride + col) = fr;
+                *reinterpret_cast<f32x4 *>(Eb + (size_t)(N0 - n0) * pstride + p.CP + col) = fi;
+            }
+        }
+    }
+}
+
+// ---- inverse, axes H and W, one (bc, n0) plane per workgroup iteration -------------------
+__global__ __launch_bounds__(256) void dht_inv_plane_kernel(const float *__restrict__ E, const float *__restrict__ addend,
+                                                            float *__restrict__ out, DhtArgs a) {
+    extern __shared__ float lds[];
+    const DhtPlan &p = a.p;
+    const Axis &a1 = p.ax[1], &a2 = p.ax[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N1 = a1.N, N2 = a2.N;
+    float *tabH = lds + p.i_tabH, *tabW = lds + p.i_tabW;
+    float *Es = lds + p.i_Es, *Ed = lds + p.i_Ed, *FR = lds + p.i_FR, *FI = lds + p.i_FI;
+    const float *cosH = tabH, *sinH = tabH + a1.NT * a1.KmP * 16;
+    const float *cosW = tabW, *sinW = tabW + a2.NT * a2.KmP * 16;
+    for (int i = tid; i < 2 * a1.NT * a1.KmP * 16; i += 256) tabH[i] = p.tables[a1.cosI + i];
+    for (int i = tid; i < 2 * a2.NT * a2.KmP * 16; i += 256) tabW[i] = p.tables[a2.cosI + i];
+    // F rows >= N1 are only ever multiplied into output rows that are not stored, but keep them finite
+    for (int i = tid; i < (p.MP1 - N1) * p.ldF; i += 256) {
+        FR[N1 * p.ldF + i] = 0.f;
+        FI[N1 * p.ldF + i] = 0.f;
+    }
+    const int planes = a.BC * p.ax[0].N;
+    const size_t plane_elems = (size_t)N1 * N2;
+    const int MT1 = p.MP1 / 16;
+    const int m1 = a1.m;
+    for (int plane = blockIdx.x; plane < planes; plane += gridDim.x) {
+        const float *Ep = E + (size_t)plane * (2 * p.CP);
+        __syncthreads();
+        // ---- load + fold over +-k1:  Es[row][k1] = E[+k1] + E[-k1], Ed = E[+k1] - E[-k1]
+        {
+            const int rows = 2 * a2.KP;  // (part, k2)
+            for (int i = tid; i < rows * a1.KmP; i += 256) {
+                const int k1 = i / rows, row = i % rows;  // row fastest: coalesced global reads
+                const int part = row / a2.KP, k2 = row % a2.KP;
+                float s = 0.f, d = 0.f;
+                if (k1 <= m1) {
+                    const float va = Ep[(size_t)(part * p.K1S + (m1 + k1)) * a2.KP + k2];
+                    if (k1 >= 1) {
+                        const float vb = Ep[(size_t)(part * p.K1S + (m1 - k1)) * a2.KP + k2];
+                        s = va + vb;
+                        d = va - vb;
+                    } else {
+                        s = va;
+                    }
+                }
+                Es[row * p.ldE + k1] = s;
+                Ed[row * p.ldE + k1] = d;
+            }
+        }
+        __syncthreads();
+        // ---- axis H: F[n1][k2] = sum_k1 E[k1][k2] e^{+i th k1 n1}
+        const int ntaskH = a1.NT * a2.KT * 2;
+        for (int t = wave; t < ntaskH; t += 4) {
+            const int part = t & 1, kt2 = (t >> 1) % a2.KT, nt1 = (t >> 1) / a2.KT;
+            const int rR = kt2 * 16, rI = a2.KP + kt2 * 16;
+            const float *bc = cosH + nt1 * a1.KmP * 16, *bs = sinH + nt1 * a1.KmP * 16;
+            f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = acc1;
+            acc1 = tile_mma(Es + (part ? rI : rR) * p.ldE, p.ldE, 1, bc, 16, 1, a1.KmP / 4, acc1, lane);
+            acc2 = tile_mma(Ed + (part ? rR : rI) * p.ldE, p.ldE, 1, bs, 16, 1, a1.KmP / 4, acc2, lane);
+            float *F = part ? FI : FR;
+            const int n1 = nt1 * 16 + (lane & 15);
+            if (n1 <= a1.J) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k2 = kt2 * 16 + (lane >> 4) * 4 + r;
+                    if (k2 < a2.KmP) {
+                        // FR = UsR - VdI (mirror +), FI = UsI + VdR (mirror -)
+                        const float v = part ? acc1[r] + acc2[r] : acc1[r] - acc2[r];
+                        const float w = part ? acc1[r] - acc2[r] : acc1[r] + acc2[r];
+                        F[n1 * p.ldF + k2] = v;
+                        if (n1 >= 1 && n1 <= a1.Js) F[(N1 - n1) * p.ldF + k2] = w;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- axis W: out[n1][n2] = sum_k2 FR cos - FI sin ; mirror n2 -> N2 - n2 gets +
+        float *op = out + (size_t)plane * plane_elems;
+        const float *ad = addend ? addend + (size_t)plane * plane_elems : nullptr;
+        const int ntaskW = MT1 * a2.NT;
+        for (int t = wave; t < ntaskW; t += 4) {
+            const int nt2 = t % a2.NT, mt = t / a2.NT;
+            f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = acc1;
+            acc1 = tile_mma(FR + mt * 16 * p.ldF, p.ldF, 1, cosW + nt2 * a2.KmP * 16, 16, 1, a2.KmP / 4, acc1, lane);
+            acc2 = tile_mma(FI + mt * 16 * p.ldF, p.ldF, 1, sinW + nt2 * a2.KmP * 16, 16, 1, a2.KmP / 4, acc2, lane);
+            const int n2 = nt2 * 16 + (lane & 15);
+            if (n2 <= a2.J) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n1 = mt * 16 + (lane >> 4) * 4 + r;
+                    if (n1 < N1) {
+                        size_t idx = (size_t)n1 * N2 + n2;
+                        float v = a.scale * (acc1[r] - acc2[r]);
+                        if (ad) v += ad[idx];
+                        op[idx] = act_apply(v, a.act);
+                        if (n2 >= 1 && n2 <= a2.Js) {
+                            idx = (size_t)n1 * N2 + (N2 - n2);
+                            float w = a.scale * (acc1[r] + acc2[r]);
+                            if (ad) w += ad[idx];
+                            op[idx] = act_apply(w, a.act);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+static int check_sizes(int BC, int N0, int N1, int N2, int m0, int m1, int m2) {
+    HNO_REQUIRE(BC > 0 && N0 > 0 && N1 > 0 && N2 > 0, "dht3: non-positive size");
+    HNO_REQUIRE(m0 > 0 && m1 > 0 && m2 > 0, "dht3: modes must be positive");
+    HNO_REQUIRE(2 * m0 <= N0 && 2 * m1 <= N1 && 2 * m2 <= N2, "dht3: modes must be clamped to N // 2 by the caller");
+    if (BC > 65535) return fail(HNO_ELIMIT, "dht3: B*C = %d exceeds 65535", BC);
+    return HNO_OK;
+}
+
+static const size_t kMaxLds = 160 * 1024;
+
+}  // namespace hno
+
+using namespace hno;
+
+extern "C" size_t hno_dht3_workspace_bytes(int BC, int N0, int N1, int N2, int m0, int m1, int m2) {
+    if (BC <= 0 || N0 <= 0 || m1 <= 0 || m2 < 0) return 0;
+    const int KP2 = ceil_div(m2 + 1, 16) * 16;
+    return (size_t)BC * N0 * 2 * (2 * m1 + 1) * KP2 * sizeof(float);
+}
+
+extern "C" int hno_dht3_crop(const float *x, const float *x_act_out, int act_grad, float *out, void *workspace,
+                             int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream) {
+    HNO_REQUIRE(x && out && workspace, "hno_dht3_crop: null pointer");
+    int rc = check_sizes(BC, N0, N1, N2, m0, m1, m2);
+    if (rc) return rc;
+    const DhtPlan *plan;
+    rc = get_plan(N0, N1, N2, m0, m1, m2, &plan);
+    if (rc) return rc;
+    DhtArgs a;
+    a.p = *plan;
+    a.BC = BC;
+    a.scale = scale;
+    a.act = x_act_out ? act_grad : HNO_ACT_NONE;
+    const size_t lds = sizeof(float) * plan->f_lds_floats;
+    if (lds > kMaxLds) return fail(HNO_ELIMIT, "hno_dht3_crop: plane %dx%d needs %zu B of LDS (> 160 KiB)", N1, N2, lds);
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+        attr_done = true;
+    }
+    const int planes = BC * N0;
+    const int grid = planes < 1024 ? planes : 1024;
+    { ProfScope _ps(KID_DHT_FWD_PLANE, s); hipLaunchKernelGGL(dht_fwd_plane_kernel, dim3(grid), dim3(256), lds, s, x, x_act_out, (float *)workspace, a); }
+    HNO_CHECK_LAUNCH();
+    const Axis &a0 = plan->ax[0];
+    const size_t ldsd = sizeof(float) * a0.KT * (a0.KcP + a0.KsP) * 16;
+    { ProfScope _ps(KID_DHT_FWD_D, s); hipLaunchKernelGGL(dht_fwd_d_kernel, dim3(plan->K1S * plan->ax[2].KT, BC), dim3(64), ldsd, s,
+                       (const float *)workspace, out, a); }
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+extern "C" int hno_pad_idht3(const float *z, const float *addend, int act, float *out, void *workspace,
+                             int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream) {
+    HNO_REQUIRE(z && out && workspace, "hno_pad_idht3: null pointer");
+    int rc = check_sizes(BC, N0, N1, N2, m0, m1, m2);
+    if (rc) return rc;
+    const DhtPlan *plan;
+    rc = get_plan(N0, N1, N2, m0, m1, m2, &plan);
+    if (rc) return rc;
+    DhtArgs a;
+    a.p = *plan;
+    a.BC = BC;
+    a.scale = scale;
+    a.act = act;
+    const size_t lds = sizeof(float) * plan->i_lds_floats;
+    if (lds > kMaxLds) return fail(HNO_ELIMIT, "hno_pad_idht3: plane %dx%d needs %zu B of LDS (> 160 KiB)", N1, N2, lds);
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+        attr_done = true;
+    }
+    const Axis &a0 = plan->ax[0];
+    const size_t ldsd = sizeof(float) * 2 * a0.NT * a0.KmP * 16;
+    { ProfScope _ps(KID_DHT_INV_D, s); hipLaunchKernelGGL(dht_inv_d_kernel, dim3(plan->K1S * plan->ax[2].KT, BC), dim3(64), ldsd, s, z,
+                       (float *)workspace, a); }
+    HNO_CHECK_LAUNCH();
+    const int planes = BC * N0;
+    const int grid = planes < 1024 ? planes : 1024;
+    { ProfScope _ps(KID_DHT_INV_PLANE, s); hipLaunchKernelGGL(dht_inv_plane_kernel, dim3(grid), dim3(256), lds, s, (const float *)workspace, addend, out, a); }
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}

@@ -1,0 +1,377 @@
+// Output head (trilinear upsample + channel softmax), Pearson / Dice reductions and label
+// preparation.  All are HBM-bound streaming kernels.
+//
+// Reference: F.interpolate(mode='trilinear') -> conv_out -> softmax (nets/hnosegxs.py:174-180;
+// the 1x1x1 conv is applied at LOW resolution by hno_pwconv_fwd since it commutes with the
+// per-channel linear interpolation), corrcoef/PCCLoss/dice_coef/DiceLoss/ExpDiceLoss
+// (nets/custom_losses.py:17-133), to_categorical/remap_labels (experiments/utils.py:74-119).
+#include "hno_common.h"
+
+namespace hno {
+
+// PyTorch area_pixel_compute_source_index, align_corners=False, non-cubic:
+//   src = max(scale * (dst + 0.5) - 0.5, 0), scale = in / out (fp32)
+struct Lin {
+    int i0, i1;
+    float w0, w1;
+};
+__device__ __forceinline__ Lin lin_coord(int dst, float rscale, int in_size) {
+    float src = rscale * ((float)dst + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    Lin l;
+    l.i0 = (int)src;
+    if (l.i0 > in_size - 1) l.i0 = in_size - 1;
+    l.i1 = l.i0 + (l.i0 < in_size - 1 ? 1 : 0);
+    l.w1 = src - (float)l.i0;
+    l.w0 = 1.f - l.w1;
+    return l;
+}
+
+struct UpArgs {
+    const float *lr, *gp, *p;
+    float *out;
+    int B, K, d, h, w, D, H, W;
+    float sd, sh, sw;
+    int softmax;
+};
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void upsoftmax_fwd_kernel(UpArgs a) {
+    const size_t V = (size_t)a.D * a.H * a.W, v_lr = (size_t)a.d * a.h * a.w;
+    const size_t total = V * a.B;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int b = (int)(idx / V);
+        const size_t v = idx % V;
+        const int x = (int)(v % a.W), y = (int)((v / a.W) % a.H), z = (int)(v / ((size_t)a.W * a.H));
+        const Lin lz = lin_coord(z, a.sd, a.d), ly = lin_coord(y, a.sh, a.h), lx = lin_coord(x, a.sw, a.w);
+        const size_t o00 = ((size_t)lz.i0 * a.h + ly.i0) * a.w, o01 = ((size_t)lz.i0 * a.h + ly.i1) * a.w;
+        const size_t o10 = ((size_t)lz.i1 * a.h + ly.i0) * a.w, o11 = ((size_t)lz.i1 * a.h + ly.i1) * a.w;
+        float val[KMAX];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            val[k] = 0.f;
+            if (k < a.K) {
+                const float *s = a.lr + ((size_t)b * a.K + k) * v_lr;
+                // same association order as upsample_trilinear3d: w-lerp, then h, then d
+                const float c00 = lx.w0 * s[o00 + lx.i0] + lx.w1 * s[o00 + lx.i1];
+                const float c01 = lx.w0 * s[o01 + lx.i0] + lx.w1 * s[o01 + lx.i1];
+                const float c10 = lx.w0 * s[o10 + lx.i0] + lx.w1 * s[o10 + lx.i1];
+                const float c11 = lx.w0 * s[o11 + lx.i0] + lx.w1 * s[o11 + lx.i1];
+                val[k] = lz.w0 * (ly.w0 * c00 + ly.w1 * c01) + lz.w1 * (ly.w0 * c10 + ly.w1 * c11);
+                mx = fmaxf(mx, val[k]);
+            }
+        }
+        if (a.softmax) {
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < a.K) {
+                    val[k] = expf(val[k] - mx);
+                    sum += val[k];
+                }
+            const float inv = 1.f / sum;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) val[k] *= inv;
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < a.K) a.out[((size_t)b * a.K + k) * V + v] = val[k];
+    }
+}
+
+// first / last high-res index whose i0 is >= lo_i / <= hi_i (i0 is monotone in dst)
+__device__ __forceinline__ void contrib_range(int i, float rscale, int in_size, int out_size, int &first, int &last) {
+    // dst contributes to low-res index i  <=>  i0(dst) in {i-1, i}
+    const float inv = 1.f / rscale;
+    int f = (int)floorf(((float)(i - 1) + 0.5f) * inv - 0.5f);
+    f = f < 0 ? 0 : (f > out_size - 1 ? out_size - 1 : f);
+    while (f > 0 && lin_coord(f - 1, rscale, in_size).i0 >= i - 1) --f;
+    while (f < out_size - 1 && lin_coord(f, rscale, in_size).i0 < i - 1) ++f;
+    int l = (int)ceilf(((float)(i + 1) + 0.5f) * inv - 0.5f);
+    l = l < 0 ? 0 : (l > out_size - 1 ? out_size - 1 : l);
+    while (l < out_size - 1 && lin_coord(l + 1, rscale, in_size).i0 <= i) ++l;
+    while (l > 0 && lin_coord(l, rscale, in_size).i0 > i) --l;
+    first = f;
+    last = l;
+}
+__device__ __forceinline__ float lin_weight(const Lin &l, int i) { return (l.i0 == i ? l.w0 : 0.f) + (l.i1 == i ? l.w1 : 0.f); }
+
+// g_lr[b,k,i] = sum over high-res voxels of  trilinear weight * softmax'(p, gp)_k   (gather form)
+template <int KMAX>
+__global__ __launch_bounds__(256) void upsoftmax_bwd_kernel(UpArgs a) {
+    const size_t V = (size_t)a.D * a.H * a.W, v_lr = (size_t)a.d * a.h * a.w;
+    const size_t total = v_lr * a.B;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int b = (int)(idx / v_lr);
+        const size_t v = idx % v_lr;
+        const int ix = (int)(v % a.w), iy = (int)((v / a.w) % a.h), iz = (int)(v / ((size_t)a.w * a.h));
+        int z0, z1, y0, y1, x0, x1;
+        contrib_range(iz, a.sd, a.d, a.D, z0, z1);
+        contrib_range(iy, a.sh, a.h, a.H, y0, y1);
+        contrib_range(ix, a.sw, a.w, a.W, x0, x1);
+        float acc[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+        for (int z = z0; z <= z1; ++z) {
+            const float wz = lin_weight(lin_coord(z, a.sd, a.d), iz);
+            if (wz == 0.f) continue;
+            for (int y = y0; y <= y1; ++y) {
+                const float wy = lin_weight(lin_coord(y, a.sh, a.h), iy) * wz;
+                if (wy == 0.f) continue;
+                for (int x = x0; x <= x1; ++x) {
+                    const float wgt = lin_weight(lin_coord(x, a.sw, a.w), ix) * wy;
+                    if (wgt == 0.f) continue;
+                    const size_t hv = ((size_t)z * a.H + y) * a.W + x;
+                    float g[KMAX], pr[KMAX];
+                    float dot = 0.f;
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) {
+                        g[k] = 0.f;
+                        pr[k] = 0.f;
+                        if (k < a.K) {
+                            g[k] = a.gp[((size_t)b * a.K + k) * V + hv];
+                            if (a.softmax) {
+                                pr[k] = a.p[((size_t)b * a.K + k) * V + hv];
+                                dot += pr[k] * g[k];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) acc[k] += wgt * (a.softmax ? pr[k] * (g[k] - dot) : g[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < a.K) a.out[((size_t)b * a.K + k) * v_lr + v] = acc[k];
+    }
+}
+
+// ------------------------------------------------------------------------------ losses
+// stats[b][k] = {sum p, sum p^2, sum p*t, sum t} in double (one pass, fp64 accumulation).
+template <int KMAX>
+__global__ __launch_bounds__(256) void loss_stats_kernel(const float *__restrict__ p, const uint8_t *__restrict__ lab,
+                                                        double *stats, int K, long long V) {
+    const int b = blockIdx.y;
+    double sp[KMAX], sp2[KMAX], spt[KMAX], st[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) sp[k] = sp2[k] = spt[k] = st[k] = 0.0;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < V; v += (long long)gridDim.x * 256) {
+        const int l = lab[(size_t)b * V + v];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) {
+                const double pv = (double)p[((size_t)b * K + k) * V + v];
+                sp[k] += pv;
+                sp2[k] += pv * pv;
+                if (l == k) {
+                    spt[k] += pv;
+                    st[k] += 1.0;
+                }
+            }
+    }
+    __shared__ double red[4][KMAX * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        double v4[4] = {sp[k], sp2[k], spt[k], st[k]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double s = v4[j];
+            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+            if (lane == 0) red[wave][k * 4 + j] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < K * 4) {
+        const double s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(&stats[(size_t)b * K * 4 + threadIdx.x], s);
+    }
+}
+
+// coef[b][k] = {value, alpha, beta, gamma} with  dloss/dp[b,k,v] = alpha * t_v + beta * p_v + gamma
+__global__ void loss_finalize_kernel(const double *stats, float *coef, float *loss, int B, int K, long long V, int kind,
+                                     float param) {
+    __shared__ double part[256];
+    double local = 0.0;
+    const double n = (double)V, inv_bk = 1.0 / ((double)B * K);
+    for (int i = threadIdx.x; i < B * K; i += blockDim.x) {
+        const double sp = stats[i * 4 + 0], sp2 = stats[i * 4 + 1], spt = stats[i * 4 + 2], st = stats[i * 4 + 3];
+        double value, alpha, beta, gamma, term;
+        if (kind == 0) {  // Pearson (custom_losses.py:32-39): centred sums, eps inside the sqrt
+            const double pm = sp / n, tm = st / n;
+            const double tp = spt - n * pm * tm, tt = st - n * tm * tm, pp = sp2 - n * pm * pm;
+            const double den = sqrt(tt * pp + 1e-7);
+            value = tp / den;
+            // dr/dp_v = (t_v - tm)/den - tp*tt*(p_v - pm)/den^3 ; loss = mean(0.5 - 0.5 r)
+            const double c1 = 1.0 / den, c2 = -tp * tt / (den * den * den);
+            const double dl = -0.5 * inv_bk;
+            alpha = dl * c1;
+            beta = dl * c2;
+            gamma = dl * (-c1 * tm - c2 * pm);
+            term = 1.0 - (value + 1.0) * 0.5;
+        } else {  // soft Dice (custom_losses.py:88-90)
+            const double uni = st + sp + 1e-7;
+            value = 2.0 * spt / uni;
+            double dl;  // dloss/dvalue for this (b,k)
+            if (kind == 1) {
+                dl = -inv_bk;
+                term = 1.0 - value;
+            } else {  // ExpDice: mean((-ln clamp(d))^e)
+                const double lo = 1e-7, hi = 1.0 - 1e-7;
+                const double dc = value < lo ? lo : (value > hi ? hi : value);
+                const double nl = -log(dc);
+                term = pow(nl, (double)param);
+                const bool inside = value >= lo && value <= hi;
+                dl = inside ? inv_bk * (double)param * pow(nl, (double)param - 1.0) * (-1.0 / dc) : 0.0;
+            }
+            alpha = dl * 2.0 / uni;
+            beta = 0.0;
+            gamma = dl * (-2.0 * spt / (uni * uni));
+        }
+        coef[i * 4 + 0] = (float)value;
+        coef[i * 4 + 1] = (float)alpha;
+        coef[i * 4 + 2] = (float)beta;
+        coef[i * 4 + 3] = (float)gamma;
+        local += term;
+    }
+    part[threadIdx.x] = local;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (float)(part[0] * inv_bk);
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const float *__restrict__ p, const uint8_t *__restrict__ lab,
+                                                      const float *__restrict__ coef, const float *__restrict__ gscale,
+                                                      float *__restrict__ g, int K, long long V) {
+    const int b = blockIdx.y;
+    const float gs = gscale ? *gscale : 1.f;
+    float al[KMAX], be[KMAX], ga[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        al[k] = be[k] = ga[k] = 0.f;
+        if (k < K) {
+            al[k] = gs * coef[((size_t)b * K + k) * 4 + 1];
+            be[k] = gs * coef[((size_t)b * K + k) * 4 + 2];
+            ga[k] = gs * coef[((size_t)b * K + k) * 4 + 3];
+        }
+    }
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < V; v += (long long)gridDim.x * 256) {
+        const int l = lab[(size_t)b * V + v];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) {
+                const size_t idx = ((size_t)b * K + k) * V + v;
+                g[idx] = (l == k ? al[k] : 0.f) + be[k] * p[idx] + ga[k];
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void labels_kernel(const float *__restrict__ lf, const int *rfrom, const int *rto, int nmap,
+                                                    uint8_t *lu, float *onehot, int K, long long V, int B) {
+    const size_t total = (size_t)V * B;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int orig = (int)lf[idx];  // y.to(dtype=int) truncates (experiments/utils.py:86)
+        int l = orig;
+        for (int j = 0; j < nmap; ++j)
+            if (orig == rfrom[j]) l = rto[j];  // every key matched against the ORIGINAL label
+        if (lu) lu[idx] = (uint8_t)l;
+        if (onehot) {
+            const size_t b = idx / V, v = idx % V;
+            for (int k = 0; k < K; ++k) onehot[(b * K + k) * V + v] = (l == k) ? 1.f : 0.f;
+        }
+    }
+}
+
+static int grid1d(size_t n) {
+    size_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace hno
+
+using namespace hno;
+
+static int up_fill(UpArgs &a, int B, int K, int d, int h, int w, int D, int H, int W, int softmax) {
+    HNO_REQUIRE(B > 0 && K > 0 && d > 0 && h > 0 && w > 0 && D > 0 && H > 0 && W > 0, "hno_upsoftmax: bad size");
+    if (K > 8) return fail(HNO_ELIMIT, "hno_upsoftmax: K=%d output channels (max 8)", K);
+    a.B = B; a.K = K; a.d = d; a.h = h; a.w = w; a.D = D; a.H = H; a.W = W;
+    a.sd = (float)d / (float)D; a.sh = (float)h / (float)H; a.sw = (float)w / (float)W;
+    a.softmax = softmax;
+    return HNO_OK;
+}
+
+extern "C" int hno_upsoftmax_fwd(const float *logits_lr, float *probs, int B, int K, int d, int h, int w,
+                                 int D, int H, int W, int softmax, void *stream) {
+    HNO_REQUIRE(logits_lr && probs, "hno_upsoftmax_fwd: null pointer");
+    UpArgs a = {};
+    int rc = up_fill(a, B, K, d, h, w, D, H, W, softmax);
+    if (rc) return rc;
+    a.lr = logits_lr; a.out = probs;
+    const int grid = grid1d((size_t)B * D * H * W);
+    if (K <= 4) { ProfScope _ps(KID_UPSOFTMAX_FWD, (hipStream_t)stream); hipLaunchKernelGGL(upsoftmax_fwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
+    else { ProfScope _ps(KID_UPSOFTMAX_FWD, (hipStream_t)stream); hipLaunchKernelGGL(upsoftmax_fwd_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+extern "C" int hno_upsoftmax_bwd(const float *g_probs, const float *probs, float *g_lr, int B, int K, int d, int h, int w,
+                                 int D, int H, int W, int softmax, void *stream) {
+    HNO_REQUIRE(g_probs && g_lr && (probs || !softmax), "hno_upsoftmax_bwd: null pointer");
+    UpArgs a = {};
+    int rc = up_fill(a, B, K, d, h, w, D, H, W, softmax);
+    if (rc) return rc;
+    a.gp = g_probs; a.p = probs; a.out = g_lr;
+    const int grid = grid1d((size_t)B * d * h * w);
+    if (K <= 4) { ProfScope _ps(KID_UPSOFTMAX_BWD, (hipStream_t)stream); hipLaunchKernelGGL(upsoftmax_bwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
+    else { ProfScope _ps(KID_UPSOFTMAX_BWD, (hipStream_t)stream); hipLaunchKernelGGL(upsoftmax_bwd_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+extern "C" int hno_loss_fwd(const float *probs, const uint8_t *labels, double *stats, float *coef, float *loss,
+                            int B, int K, long long V, int kind, float param, void *stream) {
+    HNO_REQUIRE(probs && labels && stats && coef && loss && B > 0 && K > 0 && V > 0, "hno_loss_fwd: bad argument");
+    HNO_REQUIRE(kind >= 0 && kind <= 2, "hno_loss_fwd: kind must be 0 (PCC), 1 (Dice) or 2 (ExpDice)");
+    if (K > 8) return fail(HNO_ELIMIT, "hno_loss_fwd: K=%d classes (max 8)", K);
+    hipStream_t s = (hipStream_t)stream;
+    HNO_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * B * K * 4, s));
+    long long gx = (V + 256 * 8 - 1) / (256 * 8);
+    if (gx > 1024) gx = 1024;
+    if (K <= 4) { ProfScope _ps(KID_LOSS_STATS, s); hipLaunchKernelGGL(loss_stats_kernel<4>, dim3((int)gx, B), dim3(256), 0, s, probs, labels, stats, K, V); }
+    else { ProfScope _ps(KID_LOSS_STATS, s); hipLaunchKernelGGL(loss_stats_kernel<8>, dim3((int)gx, B), dim3(256), 0, s, probs, labels, stats, K, V); }
+    HNO_CHECK_LAUNCH();
+    { ProfScope _ps(KID_LOSS_FINALIZE, s); hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const double *)stats, coef, loss, B, K, V, kind, param); }
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+extern "C" int hno_loss_bwd(const float *probs, const uint8_t *labels, const float *coef, const float *gscale,
+                            float *g_probs, int B, int K, long long V, void *stream) {
+    HNO_REQUIRE(probs && labels && coef && g_probs && B > 0 && K > 0 && V > 0, "hno_loss_bwd: bad argument");
+    if (K > 8) return fail(HNO_ELIMIT, "hno_loss_bwd: K=%d classes (max 8)", K);
+    long long gx = (V + 256 * 4 - 1) / (256 * 4);
+    if (gx > 2048) gx = 2048;
+    hipStream_t s = (hipStream_t)stream;
+    if (K <= 4) { ProfScope _ps(KID_LOSS_BWD, s); hipLaunchKernelGGL(loss_bwd_kernel<4>, dim3((int)gx, B), dim3(256), 0, s, probs, labels, coef, gscale, g_probs, K, V); }
+    else { ProfScope _ps(KID_LOSS_BWD, s); hipLaunchKernelGGL(loss_bwd_kernel<8>, dim3((int)gx, B), dim3(256), 0, s, probs, labels, coef, gscale, g_probs, K, V); }
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+extern "C" int hno_labels_prepare(const float *labels_f32, const int *remap_from, const int *remap_to, int n_remap,
+                                  uint8_t *labels_u8, float *onehot, int B, int K, long long V, void *stream) {
+    HNO_REQUIRE(labels_f32 && (labels_u8 || onehot) && B > 0 && V > 0, "hno_labels_prepare: bad argument");
+    HNO_REQUIRE(n_remap == 0 || (remap_from && remap_to), "hno_labels_prepare: remap tables missing");
+    { ProfScope _ps(KID_LABELS, (hipStream_t)stream); hipLaunchKernelGGL(labels_kernel, dim3(grid1d((size_t)B * V)), dim3(256), 0, (hipStream_t)stream, labels_f32,
+                       remap_from, remap_to, n_remap, labels_u8, onehot, K, V, B); }
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}

@@ -1,0 +1,623 @@
+// 1x1x1 ("pointwise") convolution with fused concat / bias / activation, forward and backward,
+// and the shared-weight spectral channel mix built on it.
+//
+// Reference call sites: torch.cat + ConvNormAct(k=1) in HNOXSBlock.forward
+// (nets/hnosegxs.py:254-255, 274-275), conv1 (:153), conv_out (:178), _OpNormAct.forward
+// (nets/nets_utils.py:127-133); NeuralOperatorBlock x n_XS (nets/hnosegxs.py:307-329) with the
+// einsum of HartleyOperator._call3d_notransform (nets/hartley_operator.py:287-292).
+// Data stay NCDHW (voxel index fastest).
+//
+// HBM-bound streaming op (8 flop/B at 48->24).  The channel contraction runs on
+// v_mfma_f32_32x32x2_f32 so that every global access is a 128-byte segment (32 consecutive
+// voxels of one channel) and needs no LDS: the weight matrix lives in VGPRs as the A operand
+// (rows = output channels), the activations stream through as the B operand (cols = voxels).
+//   A operand: lane l holds A[row = l & 31][k = l >> 5]
+//   B operand: lane l holds B[k = l >> 5][col = l & 31]
+//   C/D      : lane l, reg r holds C[row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][col = l & 31]
+// Addressing: every access is  (wave-uniform 64-bit base: batch, channel pair)  +  (32-bit per-lane
+// offset: lane-half channel + voxel, computed once per tile), which keeps the address math on
+// the scalar unit and the VGPR count low enough for several waves per SIMD.
+#include "hno_common.h"
+
+namespace hno {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+struct PwArgs {
+    const float *xa, *xb, *W, *bias;
+    float *y;
+    int Ca, Cb, Cin, Cout, B;
+    unsigned V;
+    int act;
+    int k_begin, k_count;  // input-channel chunk handled by this launch
+    int accumulate;        // start from the values already in y (pre-activation)
+    int finalize;          // add bias and apply the activation
+    int o_begin;           // first output channel of this launch (32 per launch)
+    int residual;          // use W + I (frequency-domain residual of the HNO-XS mix)
+};
+
+// x[channel i0 + h][v] of the virtual concat [xa ; xb] for one batch element.  i0 and nvalid
+// (1 or 2 channels of the pair exist) are wave-uniform; lanes of a missing channel read a valid
+// address (their weight is zero).
+__device__ __forceinline__ float load_pair(const float *xa_b, const float *xb_b, int Ca, int i0, int nvalid, unsigned V,
+                                           unsigned vcl, unsigned hoffV, int h) {
+    const unsigned off = (nvalid == 2 ? hoffV : 0u) + vcl;
+    if (i0 + nvalid <= Ca) return (xa_b + (size_t)i0 * V)[off];
+    if (i0 >= Ca) return (xb_b + (size_t)(i0 - Ca) * V)[off];
+    const float *p = h ? xb_b : xa_b + (size_t)i0 * V;  // pair straddles the concat boundary
+    return p[vcl];
+}
+
+// one wave = one tile of 32 voxels; 4 waves per block
+template <int KS_MAX>
+__global__ __launch_bounds__(256, 2) void pwconv_fwd_kernel(PwArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, c = lane & 31;
+    const int nks = (a.k_count + 1) / 2;
+    const unsigned V = a.V;
+    float w[KS_MAX];  // weights of this chunk: A[row = o][k = i]
+#pragma unroll
+    for (int ks = 0; ks < KS_MAX; ++ks) {
+        const int i = a.k_begin + 2 * ks + h, o = a.o_begin + c;
+        const bool ok = ks < nks && 2 * ks + h < a.k_count && o < a.Cout;
+        w[ks] = ok ? a.W[(size_t)o * a.Cin + i] : 0.f;
+        if (a.residual && ok && o == i) w[ks] += 1.f;
+    }
+    const unsigned tiles_per_b = (V + 31) / 32;
+    const unsigned ntiles = tiles_per_b * a.B;
+    const unsigned hoffV = h ? V : 0u, hoff4V = h ? 4u * V : 0u;
+    for (unsigned t = blockIdx.x * 4 + wave; t < ntiles; t += gridDim.x * 4) {
+        const unsigned b = t / tiles_per_b;
+        const unsigned v = (t - b * tiles_per_b) * 32 + c;
+        const bool vin = v < V;
+        const unsigned vcl = vin ? v : 0u;
+        const float *xa_b = a.xa + (size_t)b * a.Ca * V;
+        const float *xb_b = a.xb ? a.xb + (size_t)b * a.Cb * V : a.xa;
+        float *y_b = a.y + (size_t)b * a.Cout * V;
+        float xv[KS_MAX];
+#pragma unroll
+        for (int ks = 0; ks < KS_MAX; ++ks) {
+            xv[ks] = 0.f;
+            if (ks < nks) {
+                const int nvalid = (2 * ks + 1 < a.k_count) ? 2 : 1;
+                xv[ks] = load_pair(xa_b, xb_b, a.Ca, a.k_begin + 2 * ks, nvalid, V, vcl, hoffV, h);
+            }
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[r] = 0.f;
+            if (a.accumulate) {
+                const int orow = a.o_begin + (r & 3) + 8 * (r >> 2);
+                if (orow + 4 * h < a.Cout) acc[r] = (y_b + (size_t)orow * V)[hoff4V + vcl];
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS_MAX; ++ks)
+            if (ks < nks) acc = mfma32(w[ks], xv[ks], acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int orow = a.o_begin + (r & 3) + 8 * (r >> 2);  // uniform; this lane's row is orow + 4h
+            if (orow < a.Cout) {
+                float val = acc[r];
+                if (a.finalize) {
+                    if (a.bias) val += a.bias[orow + 4 * h < a.Cout ? orow + 4 * h : orow];
+                    val = act_apply(val, a.act);
+                }
+                if (vin && orow + 4 * h < a.Cout) (y_b + (size_t)orow * V)[hoff4V + v] = val;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ backward
+// One wave = 32 voxels.  g = gy * act'(y) is loaded once in B-operand layout
+// (2 channels x 32 voxels per register), used for
+//   dgrad: gx[i][v] = sum_o W[o][i] g[o][v]        (32x32x2 MFMA, A = W^T in VGPRs)
+//   wgrad: dW[o][i] += sum_v g[o][v] x[i][v]       (16x16x4 MFMA from a wave-private LDS tile)
+//   dbias: per-lane partial sums, reduced once at the end.
+// Limits of this kernel: Cout <= 32, Cin <= 64 (the C wrapper checks).
+struct PwBwdArgs {
+    const float *gy, *y, *xa, *xb, *W;
+    float *gxa, *gxb, *dW, *dbias;
+    float *partials;  // [gridDim.x][Cout*Cin + Cout] per-block slabs
+    int Ca, Cb, Cin, Cout, B;
+    unsigned V;
+    int act;
+    int residual;
+};
+
+#define PWB_LD 34  // 32 voxels + 2: row stride == 2 (mod 4) -> conflict-free 16x16x4 operand reads
+
+template <int KSO_MAX, int ICH>  // KSO_MAX >= ceil(Cout/2), ICH = number of 32-wide input-channel chunks
+__global__ __launch_bounds__(256, 2) void pwconv_bwd_kernel(PwBwdArgs a) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, c = lane & 31;
+    const int nkso = (a.Cout + 1) / 2;
+    const unsigned V = a.V;
+    constexpr int rowsG = 32, rowsX = ICH * 32;
+    float *G = lds + (size_t)wave * (rowsG + rowsX) * PWB_LD;  // [o][v]
+    float *X = G + rowsG * PWB_LD;                              // [i][v]
+    // A operand of dgrad: Wt[row = i][k = o] = W[o][i]
+    float wt[ICH][KSO_MAX];
+#pragma unroll
+    for (int ic = 0; ic < ICH; ++ic)
+#pragma unroll
+        for (int ks = 0; ks < KSO_MAX; ++ks) {
+            const int i = ic * 32 + c, o = 2 * ks + h;
+            const bool ok = i < a.Cin && o < a.Cout;
+            wt[ic][ks] = ok ? a.W[(size_t)o * a.Cin + i] : 0.f;
+            if (a.residual && ok && i == o) wt[ic][ks] += 1.f;
+        }
+    // zero the wave's LDS tile once: rows beyond Cout / Cin must stay finite and zero
+    for (int i = lane; i < (rowsG + rowsX) * PWB_LD; i += 64) G[i] = 0.f;
+    float db[KSO_MAX];
+#pragma unroll
+    for (int ks = 0; ks < KSO_MAX; ++ks) db[ks] = 0.f;
+    // wgrad accumulators: M tiles (o) x N tiles (i) of 16x16
+    constexpr int MT = 2, NTI = ICH * 2;
+    f32x4 dw[MT][NTI];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NTI; ++n) dw[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const unsigned tiles_per_b = (V + 31) / 32;
+    const unsigned ntiles = tiles_per_b * a.B;
+    const unsigned ngroups = (ntiles + 3) / 4;
+    const unsigned hoffV = h ? V : 0u, hoff4V = h ? 4u * V : 0u;
+    for (unsigned grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const unsigned t = grp * 4 + wave;
+        const bool live = t < ntiles;
+        const unsigned b = live ? t / tiles_per_b : 0u;
+        const unsigned v = live ? (t - b * tiles_per_b) * 32 + c : 0u;
+        const bool vin = live && v < V;
+        const unsigned vcl = vin ? v : 0u;
+        const float *gy_b = a.gy + (size_t)b * a.Cout * V, *y_b = a.y + (size_t)b * a.Cout * V;
+        const float *xa_b = a.xa + (size_t)b * a.Ca * V;
+        const float *xb_b = a.xb ? a.xb + (size_t)b * a.Cb * V : a.xa;
+        // ---- g = gy * act'(y), B-operand layout; also staged to LDS as G[o][v]
+        float g[KSO_MAX];
+#pragma unroll
+        for (int ks = 0; ks < KSO_MAX; ++ks) {
+            g[ks] = 0.f;
+            if (ks < nkso) {
+                const int o0 = 2 * ks;
+                const bool two = o0 + 1 < a.Cout;
+                const unsigned off = (two ? hoffV : 0u) + vcl;
+                float gv = (gy_b + (size_t)o0 * V)[off];
+                if (a.act != HNO_ACT_NONE) gv *= act_grad_from_out((y_b + (size_t)o0 * V)[off], a.act);
+                g[ks] = (vin && o0 + h < a.Cout) ? gv : 0.f;
+                G[(o0 + h) * PWB_LD + c] = g[ks];
+                db[ks] += g[ks];
+            }
+        }
+        // ---- x tile -> LDS X[i][v]  (partial unroll: bounds the loads in flight / VGPRs)
+#pragma unroll 8
+        for (int j = 0; j < ICH * 16; ++j) {
+            const int i0 = 2 * j;
+            if (i0 < a.Cin) {
+                const int nvalid = i0 + 1 < a.Cin ? 2 : 1;
+                const float xv = load_pair(xa_b, xb_b, a.Ca, i0, nvalid, V, vcl, hoffV, h);
+                if (i0 + h < a.Cin) X[(i0 + h) * PWB_LD + c] = vin ? xv : 0.f;
+            }
+        }
+        // ---- dgrad
+#pragma unroll
+        for (int ic = 0; ic < ICH; ++ic) {
+            if (ic * 32 >= a.Cin) continue;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KSO_MAX; ++ks)
+                if (ks < nkso) acc = mfma32(wt[ic][ks], g[ks], acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int irow = ic * 32 + (r & 3) + 8 * (r >> 2);  // uniform; lane's channel is irow + 4h
+                if (irow < a.Cin) {
+                    const int i = irow + 4 * h;
+                    const bool ok = vin && i < a.Cin;
+                    if (irow + 4 < a.Ca || irow + 4 >= a.Cin) {        // both lane halves in xa (or half 1 absent)
+                        if (irow < a.Ca) {
+                            if (a.gxa && ok) (a.gxa + ((size_t)b * a.Ca + irow) * V)[hoff4V + v] = acc[r];
+                        } else if (a.gxb && ok) {
+                            (a.gxb + ((size_t)b * a.Cb + (irow - a.Ca)) * V)[hoff4V + v] = acc[r];
+                        }
+                    } else if (irow >= a.Ca) {                          // both halves in xb
+                        if (a.gxb && ok) (a.gxb + ((size_t)b * a.Cb + (irow - a.Ca)) * V)[hoff4V + v] = acc[r];
+                    } else if (ok) {                                    // halves straddle the concat boundary
+                        if (i < a.Ca) {
+                            if (a.gxa) (a.gxa + ((size_t)b * a.Ca + i) * V)[v] = acc[r];
+                        } else if (a.gxb) {
+                            (a.gxb + ((size_t)b * a.Cb + (i - a.Ca)) * V)[v] = acc[r];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();  // LDS tile written (wave-private, but keep the ordering explicit)
+        // ---- wgrad: dw[m][n] += G[m-tile rows][v] * X[n-tile rows][v]^T  (K = 32 voxels = 8 steps)
+        // k-step outermost: 2 + NTI operand registers live at a time
+        {
+            const float *ga = G + (lane & 15) * PWB_LD + (lane >> 4);
+            const float *xb = X + (lane & 15) * PWB_LD + (lane >> 4);
+#pragma unroll 2
+            for (int ks = 0; ks < 8; ++ks) {
+                float av[MT], bv[NTI];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) av[m] = ga[m * 16 * PWB_LD + ks * 4];
+#pragma unroll
+                for (int n = 0; n < NTI; ++n) bv[n] = xb[n * 16 * PWB_LD + ks * 4];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NTI; ++n) dw[m][n] = mfma16(av[m], bv[n], dw[m][n]);
+            }
+        }
+        __syncthreads();  // before the next iteration overwrites the tile
+    }
+    // ---- flush: reduce the 4 waves through LDS, one slab per block (no atomics)
+    {
+        const int n = a.Cout * a.Cin + a.Cout;
+        __syncthreads();
+        float *mine = lds + (size_t)wave * n;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int nn = 0; nn < NTI; ++nn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = m * 16 + (lane >> 4) * 4 + r, i = nn * 16 + (lane & 15);
+                    if (o < a.Cout && i < a.Cin) mine[o * a.Cin + i] = dw[m][nn][r];
+                }
+#pragma unroll
+        for (int ks = 0; ks < KSO_MAX; ++ks) {
+            float s = db[ks];
+            for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off);  // within each 32-lane half
+            const int o = 2 * ks + h;
+            if (c == 0 && ks < nkso && o < a.Cout) mine[a.Cout * a.Cin + o] = s;
+        }
+        block_sum_to_slab(lds, n, a.partials + (size_t)blockIdx.x * n, threadIdx.x);
+    }
+}
+
+// ------------------------------------------------------------------------------ fast paths
+// Exact-size specialisations (no runtime channel guards, hence no branchy code and ~100 VGPRs):
+// Ca % 8 == 0, Cb % 8 == 0, CIN = 2*NKI, COUT = 2*NKO (<= 32), whole problem in one launch.
+template <int NKI, int COUT>
+__global__ __launch_bounds__(256, 4) void pwconv_fwd_fast_kernel(PwArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, c = lane & 31;
+    constexpr int CIN = 2 * NKI;
+    const unsigned V = a.V;
+    float w[NKI];
+#pragma unroll
+    for (int ks = 0; ks < NKI; ++ks) {
+        const int i = 2 * ks + h;
+        w[ks] = c < COUT ? a.W[(size_t)c * CIN + i] : 0.f;
+        if (a.residual && c == i) w[ks] += 1.f;
+    }
+    float bias_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = (r & 3) + 8 * (r >> 2) + 4 * h;
+        bias_r[r] = (a.bias && o < COUT) ? a.bias[o] : 0.f;
+    }
+    const unsigned tiles_per_b = (V + 31) / 32;
+    const unsigned ntiles = tiles_per_b * a.B;
+    const unsigned hoffV = h ? V : 0u, hoff4V = h ? 4u * V : 0u;
+    for (unsigned t = blockIdx.x * 4 + wave; t < ntiles; t += gridDim.x * 4) {
+        const unsigned b = t / tiles_per_b;
+        const unsigned v = (t - b * tiles_per_b) * 32 + c;
+        const bool vin = v < V;
+        const unsigned off = hoffV + (vin ? v : 0u);
+        const float *xa_b = a.xa + (size_t)b * a.Ca * V;
+        const float *xb_b = a.xb ? a.xb + (size_t)b * a.Cb * V : a.xa;
+        float *y_b = a.y + (size_t)b * COUT * V;
+        float xv[NKI];
+#pragma unroll
+        for (int ks = 0; ks < NKI; ++ks) {
+            const int i0 = 2 * ks;
+            const float *base = i0 < a.Ca ? xa_b + (size_t)i0 * V : xb_b + (size_t)(i0 - a.Ca) * V;
+            xv[ks] = base[off];
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKI; ++ks) acc = mfma32(w[ks], xv[ks], acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            constexpr int dummy = 0;
+            const int orow = (r & 3) + 8 * (r >> 2);
+            if (orow < COUT) {   // compile-time after unrolling
+                const float val = act_apply(acc[r] + bias_r[r], a.act);
+                if (vin && (orow + 4 < COUT || h == 0)) (y_b + (size_t)orow * V)[hoff4V + v] = val;
+            }
+            (void)dummy;
+        }
+    }
+}
+
+template <int NKO, int NKI>
+__global__ __launch_bounds__(256, 3) void pwconv_bwd_fast_kernel(PwBwdArgs a) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, c = lane & 31;
+    constexpr int COUT = 2 * NKO, CIN = 2 * NKI, ICH = (CIN + 31) / 32;
+    constexpr int MT = (COUT + 15) / 16, NTI = (CIN + 15) / 16;
+    constexpr int rowsG = MT * 16, rowsX = NTI * 16;
+    const unsigned V = a.V;
+    float *G = lds + (size_t)wave * (rowsG + rowsX) * PWB_LD;  // [o][v]
+    float *X = G + rowsG * PWB_LD;                              // [i][v]
+    float wt[ICH][NKO];  // A operand of dgrad: Wt[row = i][k = o]
+#pragma unroll
+    for (int ic = 0; ic < ICH; ++ic)
+#pragma unroll
+        for (int ks = 0; ks < NKO; ++ks) {
+            const int i = ic * 32 + c, o = 2 * ks + h;
+            wt[ic][ks] = i < CIN ? a.W[(size_t)o * CIN + i] : 0.f;
+            if (a.residual && i == o) wt[ic][ks] += 1.f;
+        }
+    for (int i = lane; i < (rowsG + rowsX) * PWB_LD; i += 64) G[i] = 0.f;
+    float db[NKO];
+#pragma unroll
+    for (int ks = 0; ks < NKO; ++ks) db[ks] = 0.f;
+    f32x4 dw[MT][NTI];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NTI; ++n) dw[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned tiles_per_b = (V + 31) / 32;
+    const unsigned ntiles = tiles_per_b * a.B;
+    const unsigned ngroups = (ntiles + 3) / 4;
+    const unsigned hoffV = h ? V : 0u, hoff4V = h ? 4u * V : 0u;
+    const float *ga = G + (lane & 15) * PWB_LD + (lane >> 4);
+    const float *xbp = X + (lane & 15) * PWB_LD + (lane >> 4);
+    for (unsigned grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const unsigned t = grp * 4 + wave;
+        const bool live = t < ntiles;
+        const unsigned b = live ? t / tiles_per_b : 0u;
+        const unsigned v = live ? (t - b * tiles_per_b) * 32 + c : 0u;
+        const bool vin = live && v < V;
+        const unsigned off = hoffV + (vin ? v : 0u);
+        const float *gy_b = a.gy + (size_t)b * COUT * V, *y_b = a.y + (size_t)b * COUT * V;
+        const float *xa_b = a.xa + (size_t)b * a.Ca * V;
+        const float *xb_b = a.xb ? a.xb + (size_t)b * a.Cb * V : a.xa;
+        float g[NKO];
+#pragma unroll
+        for (int ks = 0; ks < NKO; ++ks) {
+            float gv = (gy_b + (size_t)(2 * ks) * V)[off];
+            if (a.act != HNO_ACT_NONE) gv *= act_grad_from_out((y_b + (size_t)(2 * ks) * V)[off], a.act);
+            g[ks] = vin ? gv : 0.f;
+            G[(2 * ks + h) * PWB_LD + c] = g[ks];
+            db[ks] += g[ks];
+        }
+#pragma unroll
+        for (int j = 0; j < NKI; ++j) {
+            const int i0 = 2 * j;
+            const float *base = i0 < a.Ca ? xa_b + (size_t)i0 * V : xb_b + (size_t)(i0 - a.Ca) * V;
+            const float xv = base[off];
+            X[(i0 + h) * PWB_LD + c] = vin ? xv : 0.f;
+        }
+#pragma unroll
+        for (int ic = 0; ic < ICH; ++ic) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKO; ++ks) acc = mfma32(wt[ic][ks], g[ks], acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int irow = ic * 32 + (r & 3) + 8 * (r >> 2);
+                if (irow < CIN) {  // compile-time; rows irow, irow+4 are on one side since Ca % 8 == 0
+                    float *base = irow < a.Ca ? (a.gxa ? a.gxa + ((size_t)b * a.Ca + irow) * V : nullptr)
+                                              : (a.gxb ? a.gxb + ((size_t)b * a.Cb + (irow - a.Ca)) * V : nullptr);
+                    if (base && vin && (irow + 4 < CIN || h == 0)) base[hoff4V + v] = acc[r];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int ks = 0; ks < 8; ++ks) {
+            float av[MT], bv[NTI];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) av[m] = ga[m * 16 * PWB_LD + ks * 4];
+#pragma unroll
+            for (int n = 0; n < NTI; ++n) bv[n] = xbp[n * 16 * PWB_LD + ks * 4];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NTI; ++n) dw[m][n] = mfma16(av[m], bv[n], dw[m][n]);
+        }
+        __syncthreads();
+    }
+    {
+        constexpr int n = COUT * CIN + COUT;
+        __syncthreads();
+        float *mine = lds + (size_t)wave * n;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int nn = 0; nn < NTI; ++nn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = m * 16 + (lane >> 4) * 4 + r, i = nn * 16 + (lane & 15);
+                    if (o < COUT && i < CIN) mine[o * CIN + i] = dw[m][nn][r];
+                }
+#pragma unroll
+        for (int ks = 0; ks < NKO; ++ks) {
+            float s = db[ks];
+            for (int off2 = 16; off2 >= 1; off2 >>= 1) s += __shfl_xor(s, off2);
+            if (c == 0) mine[COUT * CIN + 2 * ks + h] = s;
+        }
+        block_sum_to_slab(lds, n, a.partials + (size_t)blockIdx.x * n, threadIdx.x);
+    }
+}
+
+static int grid_for(long long work_items, int per_block) {
+    long long g = (work_items + per_block - 1) / per_block;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const float *W, const float *bias,
+                      float *y, int B, int Cout, long long V, int act, int residual, void *stream) {
+    HNO_REQUIRE(xa && W && y && Ca > 0 && Cb >= 0 && B > 0 && Cout > 0 && V > 0, "hno_pwconv_fwd: bad argument");
+    HNO_REQUIRE(Cb == 0 || xb, "hno_pwconv_fwd: xb is NULL but Cb > 0");
+    if (V * 8 >= (1ll << 32) || ((V + 31) / 32) * B >= (1ll << 31))
+        return fail(HNO_ELIMIT, "hno_pwconv_fwd: V=%lld voxels per channel exceeds the 32-bit offset range", V);
+    PwArgs a;
+    a.xa = xa; a.xb = xb; a.W = W; a.bias = bias; a.y = y;
+    a.Ca = Ca; a.Cb = Cb; a.Cin = Ca + Cb; a.Cout = Cout; a.B = B; a.V = (unsigned)V; a.act = act;
+    a.residual = residual;
+    const long long ntiles = ((V + 31) / 32) * B;
+    const int grid = grid_for(ntiles, 4);
+    if (Ca % 8 == 0 && Cb % 8 == 0) {  // exact-size fast paths (the HNOSeg-XS shapes)
+        a.o_begin = 0; a.k_begin = 0; a.k_count = a.Cin; a.accumulate = 0; a.finalize = 1;
+        hipStream_t fs = (hipStream_t)stream;
+        bool done = true;
+        ProfScope ps(KID_PWCONV_FWD, fs);
+        if (a.Cin == 24 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<12, 24>), dim3(grid), dim3(256), 0, fs, a);
+        else if (a.Cin == 48 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 24>), dim3(grid), dim3(256), 0, fs, a);
+        else if (a.Cin == 24 && Cout == 4) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<12, 4>), dim3(grid), dim3(256), 0, fs, a);
+        else done = false;
+        if (done) {
+            HNO_CHECK_LAUNCH();
+            return HNO_OK;
+        }
+    }
+    const int KCH = 64;  // input channels per launch (32 k-steps of 2)
+    for (int o0 = 0; o0 < Cout; o0 += 32) {
+        for (int k0 = 0; k0 < a.Cin; k0 += KCH) {
+            a.o_begin = o0;
+            a.k_begin = k0;
+            a.k_count = a.Cin - k0 < KCH ? a.Cin - k0 : KCH;
+            a.accumulate = k0 > 0;
+            a.finalize = k0 + KCH >= a.Cin;
+            ProfScope ps(KID_PWCONV_FWD, (hipStream_t)stream);
+            if (a.k_count <= 24)
+                hipLaunchKernelGGL(pwconv_fwd_kernel<12>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+            else if (a.k_count <= 48)
+                hipLaunchKernelGGL(pwconv_fwd_kernel<24>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+            else
+                hipLaunchKernelGGL(pwconv_fwd_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+            HNO_CHECK_LAUNCH();
+        }
+    }
+    return HNO_OK;
+}
+
+int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, const float *xb, int Cb,
+                      const float *W, float *gxa, float *gxb, float *dW, float *dbias, void *workspace,
+                      int B, int Cout, long long V, int act, int residual, void *stream) {
+    HNO_REQUIRE(workspace, "hno_pwconv_bwd: workspace of hno_pwconv_bwd_workspace_bytes() is required");
+    HNO_REQUIRE(gy && xa && W && dW && Ca > 0 && Cb >= 0 && B > 0 && Cout > 0 && V > 0, "hno_pwconv_bwd: bad argument");
+    HNO_REQUIRE(act == HNO_ACT_NONE || y, "hno_pwconv_bwd: saved output y needed for the activation gradient");
+    HNO_REQUIRE(Cb == 0 || xb, "hno_pwconv_bwd: xb is NULL but Cb > 0");
+    const int Cin = Ca + Cb;
+    if (Cout > 32 || Cin > 64)
+        return fail(HNO_ELIMIT, "hno_pwconv_bwd: Cout=%d (max 32) / Cin=%d (max 64) outside the fused kernel limits", Cout, Cin);
+    if (V * 8 >= (1ll << 32) || ((V + 31) / 32) * B >= (1ll << 31))
+        return fail(HNO_ELIMIT, "hno_pwconv_bwd: V=%lld voxels per channel exceeds the 32-bit offset range", V);
+    PwBwdArgs a;
+    a.gy = gy; a.y = y ? y : gy; a.xa = xa; a.xb = xb; a.W = W;
+    a.gxa = gxa; a.gxb = gxb; a.dW = dW; a.dbias = dbias; a.partials = (float *)workspace;
+    a.Ca = Ca; a.Cb = Cb; a.Cin = Cin; a.Cout = Cout; a.B = B; a.V = (unsigned)V; a.act = act;
+    a.residual = residual;
+    const long long ntiles = ((V + 31) / 32) * B;
+    int grid = grid_for(ntiles, 4);
+    if (grid > 1024) grid = 1024;  // fewer blocks -> fewer dW atomics
+    const int ich = Cin <= 32 ? 1 : 2;
+    const size_t lds = sizeof(float) * 4 * (32 + ich * 32) * PWB_LD;
+    hipStream_t s = (hipStream_t)stream;
+    const int nslab = Cout * Cin + Cout;
+    if (Ca % 8 == 0 && Cb % 8 == 0) {  // exact-size fast paths
+        bool done = true;
+        ProfScope ps(KID_PWCONV_BWD, s);
+        if (Cin == 24 && Cout == 24) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<12, 12>), dim3(grid), dim3(256), sizeof(float) * 4 * (32 + 32) * PWB_LD, s, a);
+        else if (Cin == 48 && Cout == 24) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<12, 24>), dim3(grid), dim3(256), sizeof(float) * 4 * (32 + 48) * PWB_LD, s, a);
+        else if (Cin == 24 && Cout == 4) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<2, 12>), dim3(grid), dim3(256), sizeof(float) * 4 * (16 + 32) * PWB_LD, s, a);
+        else done = false;
+        if (done) {
+            HNO_CHECK_LAUNCH();
+            return reduce_partials_launch(a.partials, grid, nslab, dW, Cout * Cin, dbias, s);
+        }
+    }
+    {
+    ProfScope ps(KID_PWCONV_BWD, s);
+    if (Cout <= 8) {
+        if (ich == 1) hipLaunchKernelGGL((pwconv_bwd_kernel<4, 1>), dim3(grid), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((pwconv_bwd_kernel<4, 2>), dim3(grid), dim3(256), lds, s, a);
+    } else if (Cout <= 24) {
+        if (ich == 1) hipLaunchKernelGGL((pwconv_bwd_kernel<12, 1>), dim3(grid), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((pwconv_bwd_kernel<12, 2>), dim3(grid), dim3(256), lds, s, a);
+    } else {
+        if (ich == 1) hipLaunchKernelGGL((pwconv_bwd_kernel<16, 1>), dim3(grid), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((pwconv_bwd_kernel<16, 2>), dim3(grid), dim3(256), lds, s, a);
+    }
+    }
+    HNO_CHECK_LAUNCH();
+    return reduce_partials_launch(a.partials, grid, nslab, dW, Cout * Cin, dbias, s);
+}
+
+}  // namespace hno
+
+using namespace hno;
+
+extern "C" int hno_pwconv_fwd(const float *xa, int Ca, const float *xb, int Cb, const float *W, const float *bias,
+                              float *y, int B, int Cout, long long V, int act, void *stream) {
+    return pwconv_fwd_launch(xa, Ca, xb, Cb, W, bias, y, B, Cout, V, act, 0, stream);
+}
+
+extern "C" size_t hno_pwconv_bwd_workspace_bytes(int Cin, int Cout) {
+    return sizeof(float) * 1024 * ((size_t)Cout * Cin + Cout);  // one slab per block, <= 1024 blocks
+}
+
+extern "C" int hno_pwconv_bwd(const float *gy, const float *y, const float *xa, int Ca, const float *xb, int Cb,
+                              const float *W, float *gxa, float *gxb, float *dW, float *dbias, void *workspace,
+                              int B, int Cout, long long V, int act, void *stream) {
+    return pwconv_bwd_launch(gy, y, xa, Ca, xb, Cb, W, gxa, gxb, dW, dbias, workspace, B, Cout, V, act, 0, stream);
+}
+
+// Shared-weight spectral mix = L stacked pointwise layers over the mode axis with W + I.
+extern "C" int hno_specmix_shared_fwd(const float *z0, const float *W, float *zs, int B, int C, int M, int L,
+                                      int residual, int act, void *stream) {
+    HNO_REQUIRE(z0 && W && zs && B > 0 && C > 0 && M > 0 && L > 0, "hno_specmix_shared_fwd: bad argument");
+    const size_t layer = (size_t)B * C * M;
+    for (int l = 0; l < L; ++l) {
+        const float *in = l == 0 ? z0 : zs + (size_t)(l - 1) * layer;
+        int rc = pwconv_fwd_launch(in, C, nullptr, 0, W + (size_t)l * C * C, nullptr, zs + (size_t)l * layer, B, C, M,
+                                   act, residual, stream);
+        if (rc) return rc;
+    }
+    return HNO_OK;
+}
+
+extern "C" int hno_specmix_shared_bwd(const float *g, const float *z0, const float *zs, const float *W, float *gz0,
+                                      float *dW, void *workspace, int B, int C, int M, int L, int residual, int act,
+                                      void *stream) {
+    HNO_REQUIRE(g && z0 && zs && W && gz0 && dW && workspace && B > 0 && C > 0 && M > 0 && L > 0, "hno_specmix_shared_bwd: bad argument");
+    const size_t layer = (size_t)B * C * M;
+    for (int l = L - 1; l >= 0; --l) {
+        const float *in = l == 0 ? z0 : zs + (size_t)(l - 1) * layer;
+        // every wave reads its whole gy tile into registers before it writes gx for the same
+        // voxels, so updating the gradient in place (gy == gxa) is safe
+        const float *gy = l == L - 1 ? g : gz0;
+        int rc = pwconv_bwd_launch(gy, zs + (size_t)l * layer, in, C, nullptr, 0, W + (size_t)l * C * C, gz0, nullptr,
+                                   dW + (size_t)l * C * C, nullptr, workspace, B, C, M, act, residual, stream);
+        if (rc) return rc;
+    }
+    return HNO_OK;
+}

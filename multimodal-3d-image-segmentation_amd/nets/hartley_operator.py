@@ -1,0 +1,87 @@
+"""HartleyOperator on the HIP kernels (reference nets/hartley_operator.py:17-333)."""
+import math
+
+import numpy as np
+import torch
+from torch.nn import Module, Parameter, init
+
+from .. import ops
+
+
+class HartleyOperator(Module):
+    """Frequency-domain channel mixing through the Hartley transform.
+
+    Same constructor, parameters (`weight` (Co,Ci) or (Co,Ci,2m0,2m1,2m2), optional `bias`
+    (1,Co,1,1,1)) and semantics as the reference: with ``use_transform`` the input is
+    transformed, mixed on the kept mode block, SELU is applied IN THE FREQUENCY DOMAIN and the
+    unscaled transform brings it back (reference :168-271); without it the input already is a
+    cropped spectrum (HNOSeg-XS, reference :287-299).
+    """
+
+    def __init__(self, in_channels, out_channels, num_modes=None, use_bias=False, weights_type='shared',
+                 use_transform=True, ndim=5, device=None, dtype=None):
+        super().__init__()
+        valid = {'individual', 'shared'}
+        if weights_type not in valid:
+            raise ValueError(f'weights_type must be one of {valid}')
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.use_bias, self.weights_type, self.use_transform = use_bias, weights_type, use_transform
+        self.num_modes = num_modes
+        if num_modes is not None:
+            if np.isscalar(num_modes):
+                self.num_modes = (num_modes,) * (ndim - 2)
+            else:
+                assert len(num_modes) == ndim - 2
+                self.num_modes = tuple(num_modes)
+        shape = (out_channels, in_channels)
+        if weights_type != 'shared':
+            assert self.num_modes is not None
+            shape = shape + tuple(2 * m for m in self.num_modes)
+        self.weight = Parameter(torch.empty(shape, device=device, dtype=dtype))
+        if use_bias:
+            self.bias = Parameter(torch.empty((1, out_channels) + (1,) * (ndim - 2), device=device, dtype=dtype))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            init.zeros_(self.bias)
+
+    # -- forward -----------------------------------------------------------------------
+    def forward(self, inputs):
+        if inputs.ndim != 5:
+            raise NotImplementedError('2-D (ndim=4) HartleyOperator is not provided by the HIP path yet')
+        if self.use_transform:
+            return self._call3d(inputs)
+        x = self._mix(inputs)
+        if self.use_bias:
+            x = x + self.bias
+        return x
+
+    def _mix(self, z):
+        if self.weights_type == 'shared':
+            return ops.SpecMixFn.apply(z, self.weight.unsqueeze(0), 0, ops.ACT_NONE)
+        from .spectral_individual import hartley_mix_individual
+        return hartley_mix_individual(z, self.weight)
+
+    def _call3d(self, inputs):
+        spatial = tuple(inputs.shape[2:])
+        modes = self.num_modes
+        if self.weights_type == 'shared':
+            modes = ops.clamp_modes(modes, spatial)
+        else:
+            assert all(s >= 2 * m for s, m in zip(spatial, modes))
+        if self.use_bias:
+            raise NotImplementedError('HartleyOperator(use_transform=True, use_bias=True) is not provided by the '
+                                      'HIP path yet (bias on the zero-padded spectrum)')
+        n3 = float(np.prod(spatial))
+        z = ops.DhtCropFn.apply(inputs, modes, 1.0 / n3)
+        if self.weights_type == 'shared':
+            # selu(0) = 0, so SELU on the padded spectrum == SELU on the kept block
+            z = ops.SpecMixFn.apply(z, self.weight.unsqueeze(0), 0, ops.ACT_SELU)
+        else:
+            from .spectral_individual import hartley_mix_individual
+            z = hartley_mix_individual(z, self.weight, act=ops.ACT_SELU, full_spatial=spatial)
+        return ops.PadIdhtFn.apply(z, spatial, 1.0, ops.ACT_NONE)

@@ -1,0 +1,251 @@
+"""HNOSeg-XS on the HIP kernels (reference nets/hnosegxs.py:20-494).
+
+Same constructor kwargs, attributes, module tree and state-dict keys as the reference, so
+reference checkpoints load directly.  Data flow of one block (reference :253-279):
+
+    [mapping_conv] -> TransformCrop -> n_XS x (z <- selu(W z + z)) -> PadInverse -> selu
+                   -> conv_concat(cat[x, skip])
+
+runs as: hno_pwconv (concat fused) -> hno_dht3_crop -> hno_specmix_shared -> hno_pad_idht3
+(SELU fused on store) -> hno_pwconv (concat fused); the torch.cat / zeros / slice traffic of
+the reference does not exist here.
+"""
+from functools import partial
+from typing import Union
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from .hartley_operator import HartleyOperator
+from .nets_utils import ConvNormAct, init_weights_for_snn, spatial_padcrop, _is_selu
+
+
+def _tuple_modes(num_modes, ndim):
+    if np.isscalar(num_modes):
+        return (num_modes,) * (ndim - 2)
+    assert len(num_modes) == ndim - 2
+    return tuple(num_modes)
+
+
+class TransformCrop(nn.Module):
+    """dhtn + gather of the [low | high] mode block (reference :332-410)."""
+
+    def __init__(self, num_modes, ndim):
+        super().__init__()
+        assert ndim in (4, 5)
+        self.num_modes = _tuple_modes(num_modes, ndim)
+
+    def forward(self, x):
+        if x.ndim != 5:
+            raise NotImplementedError('2-D TransformCrop is not provided by the HIP path yet')
+        spatial = tuple(x.shape[2:])
+        modes = ops.clamp_modes(self.num_modes, spatial)
+        return ops.DhtCropFn.apply(x, modes, 1.0 / float(np.prod(spatial)))
+
+
+class PadInverse(nn.Module):
+    """zero-pad the mode block to the full grid + unscaled transform (reference :413-494).
+    `act` fuses the activation that follows in HNOXSBlock (reference :267-268)."""
+
+    def __init__(self, ndim):
+        super().__init__()
+        assert ndim in (4, 5)
+
+    def forward(self, x, spatial_shape, act=ops.ACT_NONE):
+        if x.ndim != 5:
+            raise NotImplementedError('2-D PadInverse is not provided by the HIP path yet')
+        assert all(s >= 2 * (zs // 2) for s, zs in zip(spatial_shape, x.shape[2:]))
+        return ops.PadIdhtFn.apply(x, tuple(spatial_shape), 1.0, act)
+
+
+class NeuralOperatorBlock(nn.Module):
+    """One frequency-domain convolution: x <- act(op(x) [+ conv_branch(x)] + x) (reference :282-329)."""
+
+    def __init__(self, in_channels, out_channels, num_modes, weights_type, ndim, activation, device,
+                 use_conv_branch=False):
+        super().__init__()
+        self.op = HartleyOperator(in_channels, out_channels, num_modes, use_bias=False, weights_type=weights_type,
+                                  use_transform=False, ndim=ndim, device=device)
+        self.conv_branch = None
+        if use_conv_branch:
+            conv = nn.Conv2d if ndim == 4 else nn.Conv3d
+            self.conv_branch = conv(in_channels, out_channels, kernel_size=1, bias=False, device=device)
+        self.normalization = None
+        if not _is_selu(activation):
+            self.normalization = nn.GroupNorm(1, out_channels, device=device)
+        self.activation = getattr(nn.functional, activation) if isinstance(activation, str) else activation
+
+    def fusable(self):
+        return (self.op.weights_type == 'shared' and self.conv_branch is None and self.normalization is None
+                and self.op.in_channels == self.op.out_channels)
+
+    def forward(self, x):
+        act = ops.act_id(self.activation)
+        if self.fusable():
+            return ops.SpecMixFn.apply(x, self.op.weight.unsqueeze(0), 1, act)
+        y = self.op(x)
+        if self.conv_branch is not None:
+            y = y + ops.PwConvFn.apply(x, None, self.conv_branch.weight, None, ops.ACT_NONE)
+        y = y + x
+        if self.normalization is not None:
+            from .conv3d import group_norm_act
+            return group_norm_act(y, self.normalization, act)
+        from .elementwise import activation_forward
+        return activation_forward(y, act)
+
+
+class HNOXSBlock(nn.Module):
+    """HNO-XS block with the block skip connection (reference :185-279)."""
+
+    def __init__(self, num_convs, in_channels, out_channels, num_modes, weights_type='shared', ndim=5,
+                 activation='selu', device=None, use_conv_branch=False, use_block_concat=True):
+        super().__init__()
+        cur = in_channels
+        self.mapping_conv = None
+        if cur != out_channels:
+            self.mapping_conv = ConvNormAct(cur, out_channels, use_bias=True, activation=activation, ndim=ndim,
+                                            device=device)
+            cur = out_channels
+        self.transform_crop = TransformCrop(num_modes, ndim)
+        self.conv_blocks = nn.ModuleList()
+        for _ in range(num_convs):
+            self.conv_blocks.append(NeuralOperatorBlock(cur, out_channels, num_modes, weights_type, ndim, activation,
+                                                        device, use_conv_branch))
+            cur = out_channels
+        self.pad_inverse = PadInverse(ndim)
+        self.normalization = None
+        if not _is_selu(activation):
+            self.normalization = nn.GroupNorm(1, cur, device=device)
+        self.activation = getattr(nn.functional, activation) if isinstance(activation, str) else activation
+        self.conv_concat = None
+        if use_block_concat:
+            self.conv_concat = ConvNormAct(cur + out_channels, out_channels, use_bias=True, activation=activation,
+                                           ndim=ndim, device=device)
+
+    def forward(self, x, skip=None):
+        """`skip` is the U-Net skip tensor the reference concatenates in HNOSegXS.forward (:161-162);
+        passing it separately lets the mapping conv read both tensors without a torch.cat."""
+        if self.mapping_conv is not None:
+            x = self.mapping_conv(x, skip)
+        else:
+            assert skip is None
+        tmp = x
+        spatial = tuple(x.shape[2:])
+        z = self.transform_crop(x)
+        if len(self.conv_blocks) and all(b.fusable() for b in self.conv_blocks):
+            # all n_XS layers in one launch sequence: z <- act((W + I) z)
+            W = torch.stack([b.op.weight for b in self.conv_blocks])
+            z = ops.SpecMixFn.apply(z, W, 1, ops.act_id(self.conv_blocks[0].activation))
+        else:
+            for block in self.conv_blocks:
+                z = block(z)
+        act = ops.act_id(self.activation)
+        if self.normalization is None:
+            u = self.pad_inverse(z, spatial, act)
+        else:
+            from .conv3d import group_norm_act
+            u = group_norm_act(self.pad_inverse(z, spatial), self.normalization, act)
+        if self.conv_concat is not None:
+            return self.conv_concat(u, tmp)
+        return u + tmp
+
+
+class HNOSegXS(nn.Module):
+    """HNOSeg-XS (reference :20-182).  See the reference docstring for the arguments; they are
+    identical here."""
+
+    def __init__(self, in_channels, out_channels, filters, num_transform_blocks, num_modes, weights_type='shared',
+                 use_resize=True, use_deep_supervision=False, use_unet_skip=True, use_block_concat=True,
+                 activation='selu', output_activation: Union[str, callable] = 'softmax', ndim=5, device=None):
+        super().__init__()
+        self.in_channels, self.out_channels, self.filters = in_channels, out_channels, filters
+        self.num_transform_blocks = num_transform_blocks
+        self.num_modes, self.weights_type = num_modes, weights_type
+        self.use_resize, self.use_deep_supervision = use_resize, use_deep_supervision
+        self.use_unet_skip, self.use_block_concat = use_unet_skip, use_block_concat
+        self.activation, self.output_activation = activation, output_activation
+        self.ndim, self.device = ndim, device
+        self.conv_in = self.conv1 = self.layers = self.conv_out = None
+        assert self.ndim in (4, 5)
+        if np.isscalar(self.num_transform_blocks):
+            self.num_transform_blocks = [self.num_transform_blocks]
+        self.block = partial(HNOXSBlock, num_modes=num_modes, weights_type=weights_type, ndim=ndim,
+                             activation=activation, device=device, use_block_concat=use_block_concat)
+        self.create_layers()
+
+    def create_layers(self):
+        ds_channels, enc_channels = [], {}
+        cur, filters = self.in_channels, self.filters
+        if self.use_resize:
+            self.conv_in = ConvNormAct(cur, filters, kernel_size=2, stride=2, use_bias=True, activation=self.activation,
+                                       ndim=self.ndim, device=self.device)
+            cur = filters
+        self.conv1 = ConvNormAct(cur, filters, use_bias=True, activation=self.activation, ndim=self.ndim,
+                                 device=self.device)
+        cur = filters
+        if self.use_deep_supervision:
+            ds_channels.append(cur)
+        assert isinstance(self.num_transform_blocks, (list, tuple))
+        self.layers = nn.ModuleList()
+        nb = len(self.num_transform_blocks)
+        for i, n_convs in enumerate(self.num_transform_blocks):
+            if self.use_unet_skip and i > nb // 2:  # decoding block: takes the mirrored encoder output too
+                cur += enc_channels[nb - 1 - i]
+            self.layers.append(self.block(n_convs, cur, filters))
+            cur = filters
+            if self.use_deep_supervision:
+                ds_channels.append(cur)
+            if self.use_unet_skip and i < nb // 2:
+                enc_channels[i] = cur
+        if ds_channels:
+            cur = sum(ds_channels)
+        conv = nn.Conv2d if self.ndim == 4 else nn.Conv3d
+        self.conv_out = conv(cur, self.out_channels, kernel_size=1, bias=False, device=self.device)
+        self._softmax = self.output_activation == 'softmax'
+        if isinstance(self.output_activation, str):
+            fn = getattr(nn.functional, self.output_activation)
+            self.output_activation = partial(fn, dim=1) if self._softmax else fn
+        if _is_selu(self.activation):
+            self.apply(init_weights_for_snn)
+
+    def forward(self, x):
+        if x.ndim != 5:
+            raise NotImplementedError('2-D (ndim=4) HNOSeg-XS is not provided by the HIP path yet')
+        image_size = tuple(x.shape[2:])
+        ds, enc = [], {}
+        if self.use_resize:
+            x = self.conv_in(x)
+        x = self.conv1(x)
+        if self.use_deep_supervision:
+            ds.append(x)
+        nb = len(self.num_transform_blocks)
+        for i, layer in enumerate(self.layers):
+            skip = enc[nb - 1 - i] if (self.use_unet_skip and i > nb // 2) else None
+            x = layer(x, skip)
+            if self.use_deep_supervision:
+                ds.append(x)
+            if self.use_unet_skip and i < nb // 2:
+                enc[i] = x
+        return self._head(ds if ds else [x], image_size)
+
+    def _head(self, feats, image_size):
+        """conv_out at LOW resolution (it commutes with the per-channel trilinear interpolation),
+        then fused upsample + softmax (reference :171-180)."""
+        w = self.conv_out.weight
+        if len(feats) == 1:
+            logits = ops.PwConvFn.apply(feats[0], None, w, None, ops.ACT_NONE)
+        else:  # deep supervision: conv over the channel concat = sum of per-tensor convs
+            logits, c0 = None, 0
+            for f in feats:
+                part = ops.PwConvFn.apply(f, None, w[:, c0:c0 + f.shape[1]].contiguous(), None, ops.ACT_NONE)
+                logits = part if logits is None else logits + part
+                c0 += f.shape[1]
+        if not (self._softmax or self.output_activation is None):
+            raise NotImplementedError('only softmax / None output activations are provided by the HIP path')
+        if self.use_resize:
+            y = ops.UpSoftmaxFn.apply(logits, image_size, self._softmax)
+        else:
+            y = ops.UpSoftmaxFn.apply(logits, tuple(logits.shape[2:]), self._softmax)
+        return spatial_padcrop(y, image_size)

@@ -1,0 +1,303 @@
+"""Functional + autograd wrappers over the libhno C ABI (include/hno.h).
+
+Each ``torch.autograd.Function`` here is one fused op of the hot path; torch tensors are only
+containers (allocation, lifetime, autograd graph).  Nothing in this file computes on the CPU
+or through ATen math kernels: if libhno.so is missing or the tensors are not on a GPU the
+call raises.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+ACT_NONE, ACT_SELU, ACT_ELU = 0, 1, 2
+_ACT_IDS = {None: ACT_NONE, 'none': ACT_NONE, 'selu': ACT_SELU, 'elu': ACT_ELU}
+LOSS_KINDS = {'pcc': 0, 'dice': 1, 'expdice': 2}
+
+
+def act_id(act):
+    if callable(act):
+        act = getattr(act, '__name__', act)
+    if act not in _ACT_IDS:
+        raise ValueError(f'activation {act!r} is not supported by the HIP path (selu, elu or None)')
+    return _ACT_IDS[act]
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.HnoError('the HIP path needs CUDA/HIP tensors; there is no CPU fallback '
+                                '(use oracle/ for CPU checks)')
+
+
+def _f32c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def clamp_modes(modes, spatial):
+    """2m > s -> m = s // 2 (nets/hnosegxs.py:382-387)."""
+    return tuple(int(s // 2 if 2 * m > s else m) for m, s in zip(modes, spatial))
+
+
+# ------------------------------------------------------------------------- raw launchers
+def dht3_crop_raw(x, modes, scale, act_out=None, act=ACT_NONE):
+    """x: (B,C,N0,N1,N2) -> (B,C,2m0,2m1,2m2); modes already clamped."""
+    _need_gpu(x, act_out)
+    B, C, N0, N1, N2 = x.shape
+    m0, m1, m2 = modes
+    L = _lib.lib()
+    ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, N0, N1, N2, m0, m1, m2) // 4, device=x.device, dtype=torch.float32)
+    out = torch.empty((B, C, 2 * m0, 2 * m1, 2 * m2), device=x.device, dtype=torch.float32)
+    check(L.hno_dht3_crop(ptr(x), ptr(act_out), act if act_out is not None else ACT_NONE, ptr(out), ptr(ws),
+                          B * C, N0, N1, N2, m0, m1, m2, float(scale), stream_ptr()), 'hno_dht3_crop')
+    return out
+
+
+def pad_idht3_raw(z, spatial, scale, addend=None, act=ACT_NONE):
+    """z: (B,C,2m0,2m1,2m2) -> (B,C,N0,N1,N2) = act(scale * IDHT(pad(z)) + addend)."""
+    _need_gpu(z, addend)
+    B, C = z.shape[:2]
+    m0, m1, m2 = (s // 2 for s in z.shape[2:])
+    N0, N1, N2 = (int(s) for s in spatial)
+    L = _lib.lib()
+    ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, N0, N1, N2, m0, m1, m2) // 4, device=z.device, dtype=torch.float32)
+    out = torch.empty((B, C, N0, N1, N2), device=z.device, dtype=torch.float32)
+    check(L.hno_pad_idht3(ptr(z), ptr(addend), act, ptr(out), ptr(ws), B * C, N0, N1, N2, m0, m1, m2,
+                          float(scale), stream_ptr()), 'hno_pad_idht3')
+    return out
+
+
+def _flat_v(t):
+    return int(np.prod(t.shape[2:]))
+
+
+def _wgrad_ws(cin, cout, device):
+    n = _lib.lib().hno_pwconv_bwd_workspace_bytes(int(cin), int(cout)) // 4
+    return torch.empty(n, device=device, dtype=torch.float32)
+
+
+# ----------------------------------------------------------------------------- autograd
+class DhtCropFn(torch.autograd.Function):
+    """TransformCrop (nets/hnosegxs.py:378-410).  backward = PadInverse * scale."""
+
+    @staticmethod
+    def forward(ctx, x, modes, scale):
+        x = _f32c(x)
+        ctx.spatial, ctx.scale = tuple(x.shape[2:]), scale
+        return dht3_crop_raw(x, modes, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        return pad_idht3_raw(_f32c(g), ctx.spatial, ctx.scale), None, None
+
+
+class PadIdhtFn(torch.autograd.Function):
+    """PadInverse (nets/hnosegxs.py:454-494) with fused output activation.
+    backward = TransformCrop of (g * act'(out)) with the same scale."""
+
+    @staticmethod
+    def forward(ctx, z, spatial, scale, act):
+        z = _f32c(z)
+        out = pad_idht3_raw(z, spatial, scale, None, act)
+        ctx.modes, ctx.scale, ctx.act = tuple(s // 2 for s in z.shape[2:]), scale, act
+        if act != ACT_NONE:
+            ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out = ctx.saved_tensors[0] if ctx.act != ACT_NONE else None
+        return dht3_crop_raw(_f32c(g), ctx.modes, ctx.scale, out, ctx.act), None, None, None
+
+
+class SpecMixFn(torch.autograd.Function):
+    """L stacked shared-weight frequency-domain mixes z <- act(W z + residual z)
+    (nets/hnosegxs.py:307-329, nets/hartley_operator.py:287-292)."""
+
+    @staticmethod
+    def forward(ctx, z0, W, residual, act):
+        z0, W = _f32c(z0), _f32c(W)
+        _need_gpu(z0, W)
+        B, C = z0.shape[:2]
+        M, Lyr = _flat_v(z0), W.shape[0]
+        zs = torch.empty((Lyr,) + tuple(z0.shape), device=z0.device, dtype=torch.float32)
+        check(_lib.lib().hno_specmix_shared_fwd(ptr(z0), ptr(W), ptr(zs), B, C, M, Lyr, int(residual), act, stream_ptr()),
+              'hno_specmix_shared_fwd')
+        ctx.save_for_backward(z0, W, zs)
+        ctx.residual, ctx.act = int(residual), act
+        return zs[-1]
+
+    @staticmethod
+    def backward(ctx, g):
+        z0, W, zs = ctx.saved_tensors
+        g = _f32c(g)
+        B, C = z0.shape[:2]
+        M, Lyr = _flat_v(z0), W.shape[0]
+        gz0 = torch.empty_like(z0)
+        dW = torch.zeros_like(W)
+        ws = _wgrad_ws(C, C, z0.device)
+        check(_lib.lib().hno_specmix_shared_bwd(ptr(g), ptr(z0), ptr(zs), ptr(W), ptr(gz0), ptr(dW), ptr(ws), B, C, M, Lyr,
+                                                ctx.residual, ctx.act, stream_ptr()), 'hno_specmix_shared_bwd')
+        return gz0, dW, None, None
+
+
+class PwConvFn(torch.autograd.Function):
+    """act(W [xa ; xb] + bias): fused concat + 1x1x1 conv + bias + activation
+    (nets/hnosegxs.py:274-275; nets/nets_utils.py:127-133)."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, W, bias, act):
+        xa, xb, W, bias = _f32c(xa), _f32c(xb), _f32c(W), _f32c(bias)
+        _need_gpu(xa, xb, W, bias)
+        B, Ca = xa.shape[:2]
+        Cb = xb.shape[1] if xb is not None else 0
+        Cout, V = W.shape[0], _flat_v(xa)
+        assert W.numel() == Cout * (Ca + Cb), 'weight shape does not match the concatenated input channels'
+        y = torch.empty((B, Cout) + tuple(xa.shape[2:]), device=xa.device, dtype=torch.float32)
+        check(_lib.lib().hno_pwconv_fwd(ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(bias), ptr(y), B, Cout, V, act, stream_ptr()),
+              'hno_pwconv_fwd')
+        ctx.save_for_backward(xa, xb, W, y if act != ACT_NONE else None)
+        ctx.act, ctx.has_bias = act, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xa, xb, W, y = ctx.saved_tensors
+        gy = _f32c(gy)
+        B, Ca = xa.shape[:2]
+        Cb = xb.shape[1] if xb is not None else 0
+        Cout, V = W.shape[0], _flat_v(xa)
+        gxa = torch.empty_like(xa) if ctx.needs_input_grad[0] else None
+        gxb = torch.empty_like(xb) if (xb is not None and ctx.needs_input_grad[1]) else None
+        dW = torch.zeros_like(W)
+        db = torch.zeros(Cout, device=W.device, dtype=torch.float32) if ctx.has_bias else None
+        ws = _wgrad_ws(Ca + Cb, Cout, xa.device)
+        check(_lib.lib().hno_pwconv_bwd(ptr(gy), ptr(y), ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(gxa), ptr(gxb), ptr(dW),
+                                        ptr(db), ptr(ws), B, Cout, V, ctx.act, stream_ptr()), 'hno_pwconv_bwd')
+        return gxa, gxb, dW, db, None
+
+
+class ConvK2S2Fn(torch.autograd.Function):
+    """Conv3d(k=2, s=2, p=1) + bias + act (conv_in; nets/hnosegxs.py:102-104,151)."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, act):
+        x, W, bias = _f32c(x), _f32c(W), _f32c(bias)
+        _need_gpu(x, W, bias)
+        B, Cin, D, H, Wd = x.shape
+        Cout = W.shape[0]
+        y = torch.empty((B, Cout, D // 2 + 1, H // 2 + 1, Wd // 2 + 1), device=x.device, dtype=torch.float32)
+        check(_lib.lib().hno_conv_k2s2_fwd(ptr(x), ptr(W), ptr(bias), ptr(y), B, Cin, Cout, D, H, Wd, act, stream_ptr()),
+              'hno_conv_k2s2_fwd')
+        ctx.save_for_backward(x, W, y)
+        ctx.act, ctx.has_bias = act, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, W, y = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise _lib.HnoError('conv_in input gradient is not implemented (the image needs none)')
+        gy = _f32c(gy)
+        B, Cin, D, H, Wd = x.shape
+        Cout = W.shape[0]
+        dW = torch.zeros_like(W)
+        db = torch.zeros(Cout, device=W.device, dtype=torch.float32) if ctx.has_bias else None
+        ws = _wgrad_ws(Cin * 8, Cout, x.device)
+        check(_lib.lib().hno_conv_k2s2_bwd(ptr(gy), ptr(y), ptr(x), ptr(W), None, ptr(dW), ptr(db), ptr(ws), B, Cin, Cout,
+                                           D, H, Wd, ctx.act, stream_ptr()), 'hno_conv_k2s2_bwd')
+        return None, dW, db, None
+
+
+class UpSoftmaxFn(torch.autograd.Function):
+    """trilinear(align_corners=False) upsample of K logits + softmax over channels
+    (nets/hnosegxs.py:174-180 with conv_out commuted to low resolution)."""
+
+    @staticmethod
+    def forward(ctx, logits_lr, size, softmax):
+        lr = _f32c(logits_lr)
+        _need_gpu(lr)
+        B, K, d, h, w = lr.shape
+        D, H, W = (int(s) for s in size)
+        probs = torch.empty((B, K, D, H, W), device=lr.device, dtype=torch.float32)
+        check(_lib.lib().hno_upsoftmax_fwd(ptr(lr), ptr(probs), B, K, d, h, w, D, H, W, int(softmax), stream_ptr()),
+              'hno_upsoftmax_fwd')
+        ctx.lr_shape, ctx.softmax = tuple(lr.shape), int(softmax)
+        if softmax:
+            ctx.save_for_backward(probs)
+        return probs
+
+    @staticmethod
+    def backward(ctx, g):
+        probs = ctx.saved_tensors[0] if ctx.softmax else None
+        g = _f32c(g)
+        B, K, d, h, w = ctx.lr_shape
+        D, H, W = g.shape[2:]
+        g_lr = torch.empty(ctx.lr_shape, device=g.device, dtype=torch.float32)
+        check(_lib.lib().hno_upsoftmax_bwd(ptr(g), ptr(probs), ptr(g_lr), B, K, d, h, w, D, H, W, ctx.softmax, stream_ptr()),
+              'hno_upsoftmax_bwd')
+        return g_lr, None, None
+
+
+class SegLossFn(torch.autograd.Function):
+    """PCC / Dice / ExpDice on uint8 labels (nets/custom_losses.py:17-133 with the one-hot
+    encoding of experiments/utils.py:74-97 fused)."""
+
+    @staticmethod
+    def forward(ctx, probs, labels_u8, kind, param):
+        probs = _f32c(probs)
+        _need_gpu(probs, labels_u8)
+        assert labels_u8.dtype == torch.uint8 and labels_u8.is_contiguous()
+        B, K = probs.shape[:2]
+        V = _flat_v(probs)
+        assert labels_u8.numel() == B * V
+        stats = torch.empty(B * K * 4, device=probs.device, dtype=torch.float64)
+        coef = torch.empty((B, K, 4), device=probs.device, dtype=torch.float32)
+        loss = torch.empty((), device=probs.device, dtype=torch.float32)
+        check(_lib.lib().hno_loss_fwd(ptr(probs), ptr(labels_u8), ptr(stats), ptr(coef), ptr(loss), B, K, V, kind,
+                                      float(param), stream_ptr()), 'hno_loss_fwd')
+        ctx.save_for_backward(probs, labels_u8, coef)
+        ctx.mark_non_differentiable(coef)
+        return loss, coef
+
+    @staticmethod
+    def backward(ctx, gl, _gcoef):
+        probs, labels_u8, coef = ctx.saved_tensors
+        B, K = probs.shape[:2]
+        V = _flat_v(probs)
+        gl = _f32c(gl).reshape(1)
+        g = torch.empty_like(probs)
+        check(_lib.lib().hno_loss_bwd(ptr(probs), ptr(labels_u8), ptr(coef), ptr(gl), ptr(g), B, K, V, stream_ptr()),
+              'hno_loss_bwd')
+        return g, None, None, None
+
+
+# ------------------------------------------------------------------------- label helpers
+def labels_prepare(labels, num_classes, mapping=None, want_onehot=False):
+    """(B,1,...) float/int labels -> uint8 class map (B,...) [+ one-hot fp32 (B,K,...)] on the GPU
+    (experiments/utils.py:74-119)."""
+    assert labels.shape[1] == 1, 'Can only handle single label per pixel.'
+    lab = _f32c(labels)
+    _need_gpu(lab)
+    B, V = lab.shape[0], _flat_v(lab)
+    u8 = torch.empty((B,) + tuple(lab.shape[2:]), device=lab.device, dtype=torch.uint8)
+    onehot = torch.empty((B, num_classes) + tuple(lab.shape[2:]), device=lab.device, dtype=torch.float32) if want_onehot else None
+    rf = rt = None
+    n = 0
+    if mapping:
+        rf = torch.tensor(list(mapping.keys()), device=lab.device, dtype=torch.int32)
+        rt = torch.tensor(list(mapping.values()), device=lab.device, dtype=torch.int32)
+        n = len(mapping)
+    check(_lib.lib().hno_labels_prepare(ptr(lab), ptr(rf), ptr(rt), n, ptr(u8), ptr(onehot), B, num_classes, V, stream_ptr()),
+          'hno_labels_prepare')
+    return (u8, onehot) if want_onehot else u8
+
+
+def onehot_to_u8(y_true):
+    """One-hot (B,K,...) fp32 -> uint8 class map (drop-in path for reference-style callers)."""
+    return torch.argmax(y_true, dim=1).to(torch.uint8).contiguous()

@@ -38,3 +38,32 @@ CROP_CASES = [
     (2, 1, (9, 8, 7), (10, 14, 14)),       # clamped: m -> s // 2
     (1, 3, (16, 12, 20), (8, 6, 10)),      # even sizes, 2m == N on every axis
 ]
+
+
+def formula_volume(shape, tag=0, noise=0.25, dtype=np.float32):
+    """Smooth multi-channel volume (B,C,D,H,W): a few low-frequency waves per channel plus broadband
+    texture -- like z-scored MR volumes, most of the energy sits in the low modes the operators keep."""
+    b, c, d, h, w = shape
+    z, y, x = np.meshgrid(np.arange(d) / d, np.arange(h) / h, np.arange(w) / w, indexing='ij')
+    out = np.empty(shape, dtype=np.float64)
+    for bi in range(b):
+        for ci in range(c):
+            s = 1.0 + bi * c + ci + 0.37 * tag
+            vol = np.zeros((d, h, w))
+            for j in range(1, 4):
+                fz, fy, fx = (j + s) % 3, (2 * j + s) % 4, (j * j + s) % 3
+                vol += (1.0 / j) * np.sin(2 * np.pi * (fz * z + fy * y + fx * x) + 0.7 * j * s)
+            out[bi, ci] = vol
+    out += noise * formula_tensor(shape, tag + 100, np.float64)
+    return out.astype(dtype)
+
+
+# small, well-conditioned HNOSeg-XS variants (golden G6s): name -> (ctor kwargs, input shape)
+SMALL_MODELS = {
+    'xs_small': (dict(in_channels=2, out_channels=3, filters=8, num_transform_blocks=[2, 2, 2, 2], num_modes=(4, 5, 5)),
+                 (1, 2, 24, 20, 28)),
+    'xs_odd_noskip': (dict(in_channels=1, out_channels=2, filters=8, num_transform_blocks=[1, 2, 1], num_modes=(3, 3, 4),
+                           use_unet_skip=False), (2, 1, 18, 22, 26)),
+    'xs_clamped': (dict(in_channels=2, out_channels=2, filters=16, num_transform_blocks=[1, 1], num_modes=(10, 14, 14)),
+                   (1, 2, 16, 20, 24)),
+}

@@ -16,7 +16,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from _inputs import formula_tensor, formula_labels, sample_indices, CROP_CASES  # noqa: E402
+from _inputs import formula_tensor, formula_labels, sample_indices, CROP_CASES, SMALL_MODELS  # noqa: E402
 
 REF = sys.argv[1] if len(sys.argv) > 1 else '/root/reference'
 sys.path.insert(0, REF)
@@ -186,7 +186,44 @@ def g6_hnosegxs():
         out[f'{tag}_loss'] = loss.detach().numpy()
         for k, p in model.named_parameters():
             out[f'{tag}_grad::{k}'] = p.grad.detach().numpy().copy()
+        # the same step with the REFERENCE model in float64: the rounding-free truth, used to show
+        # that fp32 round-off (reference and HIP alike) -- not the algorithm -- sets the error floor
+        import copy
+        m64 = copy.deepcopy(model).double()
+        m64.zero_grad()
+        y64 = m64(x.double())
+        loss64 = custom_losses.PCCLoss()(y64, onehot.double())
+        loss64.backward()
+        out[f'{tag}_y64'] = y64.detach().numpy().ravel()[idx].astype(np.float32)
+        out[f'{tag}_loss64'] = loss64.detach().numpy()
+        for k, p in m64.named_parameters():
+            out[f'{tag}_grad64::{k}'] = p.grad.detach().numpy().astype(np.float32)
     save('g6_hnosegxs.npz', **out)
+
+
+# ---------------------------- G6s: small, well-conditioned HNOSeg-XS variants (strict 1e-4)
+def g6s_small_models():
+    from _inputs import formula_volume
+    out = {}
+    for name, (kw, shape) in SMALL_MODELS.items():
+        torch.manual_seed(11)
+        model = nets.HNOSegXS(**kw)
+        for k, v in model.state_dict().items():
+            out[f'{name}::sd::{k}'] = v.detach().numpy().copy()
+        K = kw['out_channels']
+        x = T(formula_volume(shape, 3))
+        lab = formula_labels((shape[0], 1) + shape[2:], K, 2)
+        onehot = torch.movedim(torch.nn.functional.one_hot(T(lab)[:, 0].long(), K).float(), -1, 1)
+        for lname, fn in (('pcc', custom_losses.PCCLoss()), ('dice', custom_losses.DiceLoss())):
+            model.zero_grad()
+            y = model(x)
+            loss = fn(y, onehot)
+            loss.backward()
+            out[f'{name}::{lname}::loss'] = loss.detach().numpy()
+            for k, p in model.named_parameters():
+                out[f'{name}::{lname}::grad::{k}'] = p.grad.detach().numpy().copy()
+        out[f'{name}::y'] = y.detach().numpy()
+    save('g6s_small_models.npz', **out)
 
 
 # ------------------------------------------- G9: labels, padcrop, SNN init statistics
@@ -220,4 +257,5 @@ if __name__ == '__main__':
     g3_operators()
     g5_losses()
     g6_hnosegxs()
+    g6s_small_models()
     g9_misc()

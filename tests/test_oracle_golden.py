@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from conftest import load_golden, rel_err
-from _inputs import formula_tensor, formula_labels, CROP_CASES
+from _inputs import formula_tensor, formula_labels, formula_volume, CROP_CASES, SMALL_MODELS
 from oracle import hno_oracle as O
 
 TOL32 = 2e-5   # fp32 FFT vs fp32 FFT on identical op order: rounding only
@@ -178,3 +178,24 @@ def test_labels_and_padcrop():
     x = T(formula_tensor((1, 2, 7, 8, 9), 3))
     for i, t in enumerate(g['padcrop_targets']):
         assert np.array_equal(O.spatial_padcrop(x, tuple(int(v) for v in t)).numpy(), g[f'padcrop_{i}'])
+
+
+@pytest.mark.parametrize('name', list(SMALL_MODELS))
+def test_small_models_oracle(name):
+    g = load_golden('g6s_small_models.npz')
+    kw, shape = SMALL_MODELS[name]
+    pre = f'{name}::sd::'
+    sd = {k[len(pre):]: T(g[k]) for k in g.files if k.startswith(pre)}
+    K = kw['out_channels']
+    x = T(formula_volume(shape, 3))
+    lab = T(formula_labels((shape[0], 1) + shape[2:], K, 2))
+    for lname in ('pcc', 'dice'):
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        y = O.hnosegxs_forward(params, x, kw['num_transform_blocks'], kw['num_modes'],
+                               use_unet_skip=kw.get('use_unet_skip', True))
+        loss = (O.pcc_loss if lname == 'pcc' else O.dice_loss)(y, O.to_categorical(lab, K))
+        loss.backward()
+        assert rel_err(_np(y), g[f'{name}::y']) < 1e-5
+        assert abs(float(loss.detach()) - float(g[f'{name}::{lname}::loss'])) < 1e-6
+        for k, p in params.items():
+            assert rel_err(_np(p.grad), g[f'{name}::{lname}::grad::{k}']) < 1e-4, k
