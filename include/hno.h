@@ -61,8 +61,8 @@ int hno_pad_idht3(const float *z, const float *addend, int act, float *out, void
  * Replaces NeuralOperatorBlock.forward x n_XS (nets/hnosegxs.py:307-329) incl. the
  * einsum 'oi,bidhw->bodhw' of HartleyOperator._call3d_notransform
  * (nets/hartley_operator.py:287-292).
- * Backward: given g = dL/dz_L, the saved z_0 and zs, produces dL/dz_0 and ACCUMULATES
- * dL/dW into dW (L, C, C) (caller zeroes it).  workspace: hno_pwconv_bwd_workspace_bytes(C, C).
+ * Backward: given g = dL/dz_L, the saved z_0 and zs, produces dL/dz_0 and WRITES
+ * dL/dW into dW (L, C, C).  workspace: hno_pwconv_bwd_workspace_bytes(C, C).
  */
 int hno_specmix_shared_fwd(const float *z0, const float *W, float *zs, int B, int C, int M, int L,
                            int residual, int act, void *stream);
@@ -76,7 +76,7 @@ int hno_specmix_shared_bwd(const float *g, const float *z0, const float *zs, con
  * (nets/hnosegxs.py:274-275, 254-255, 153; nets/nets_utils.py:127-133) and the bias-free
  * conv_out (nets/hnosegxs.py:178).
  * Backward: gy is dL/dy, y the saved OUTPUT (for act'); writes gxa / gxb (either may be
- * NULL to skip) and ACCUMULATES dW (Cout, Ca+Cb) and dbias (Cout) (caller zeroes them).
+ * NULL to skip) and WRITES dW (Cout, Ca+Cb) and dbias (Cout).
  * Weight gradients are reduced through per-block slabs in `workspace`
  * (hno_pwconv_bwd_workspace_bytes) in a fixed order: no float atomics, reproducible bit for bit.
  */
@@ -91,7 +91,7 @@ int hno_pwconv_bwd(const float *gy, const float *y, const float *xa, int Ca, con
  * Conv3d(Cin -> Cout, kernel 2, stride 2, padding 1) + bias + act: (B,Cin,D,H,W) ->
  * (B,Cout,D/2+1,H/2+1,W/2+1).  Replaces ConvNormAct(kernel_size=2, stride=2)
  * (nets/hnosegxs.py:102-104,151; nets/nets_utils.py:156-163).  W is (Cout,Cin,2,2,2).
- * Backward produces dW / dbias (accumulated; workspace = hno_pwconv_bwd_workspace_bytes(Cin*8, Cout))
+ * Backward writes dW / dbias (workspace = hno_pwconv_bwd_workspace_bytes(Cin*8, Cout))
  * and, if gx != NULL, the input gradient.
  */
 int hno_conv_k2s2_fwd(const float *x, const float *W, const float *bias, float *y, int B, int Cin, int Cout,

@@ -50,18 +50,22 @@ struct ProfScope {
 };
 
 // Weight-gradient partial sums: every block writes ONE slab of `n` floats (already reduced over
-// its 4 waves through LDS); reduce_partials_launch sums the slabs in a fixed order and ADDS the
+// its waves through LDS); reduce_partials_launch sums the slabs in a fixed order and WRITES the
 // result to dst.  No float atomics -> bitwise reproducible gradients, and none of the
 // same-address atomic contention that made the first version of these kernels 10x slower.
 int reduce_partials_launch(const float *partials, int nblocks, int n, float *dst0, int n0, float *dst1,
                            hipStream_t stream);
 
-// wave-private accumulator fragments -> one slab per block.  `scratch` is >= 4 * n floats of LDS.
+// wave-private accumulator fragments -> one slab per block.  `scratch` is >= nwaves * n floats of LDS.
 // frag(idx) semantic: each wave calls store(idx, value) for the elements it owns; all 4 waves own
 // the same index set.
-__device__ __forceinline__ void block_sum_to_slab(float *scratch, int n, float *slab, int tid) {
+__device__ __forceinline__ void block_sum_to_slab(float *scratch, int n, float *slab, int tid, int nwaves = 4) {
     __syncthreads();
-    for (int i = tid; i < n; i += 256) slab[i] = scratch[i] + scratch[n + i] + scratch[2 * n + i] + scratch[3 * n + i];
+    for (int i = tid; i < n; i += 64 * nwaves) {
+        float s = 0.f;
+        for (int w = 0; w < nwaves; ++w) s += scratch[w * n + i];
+        slab[i] = s;
+    }
 }
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -95,18 +99,59 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 // acc += A_tile(16 x 4*ksteps) * B_tile(4*ksteps x 16) with arbitrary element strides.
-// a points at A[row0][k0], b points at B[k0][col0].
+// a points at A[row0][k0], b points at B[k0][col0].  Operand reads are batched four k-steps at a
+// time so the LDS latency overlaps the MFMA chain.
 __device__ __forceinline__ f32x4 tile_mma(const float *a, int sa_r, int sa_k, const float *b, int sb_k, int sb_c,
                                           int ksteps, f32x4 acc, int lane) {
     const float *ap = a + (lane & 15) * sa_r + (lane >> 4) * sa_k;
     const float *bp = b + (lane >> 4) * sb_k + (lane & 15) * sb_c;
     const int da = 4 * sa_k, db = 4 * sb_k;
-    for (int ks = 0; ks < ksteps; ++ks) {
+    int ks = 0;
+    for (; ks + 4 <= ksteps; ks += 4) {
+        const float a0 = ap[0], a1 = ap[da], a2 = ap[2 * da], a3 = ap[3 * da];
+        const float b0 = bp[0], b1 = bp[db], b2 = bp[2 * db], b3 = bp[3 * db];
+        acc = mfma16(a0, b0, acc);
+        acc = mfma16(a1, b1, acc);
+        acc = mfma16(a2, b2, acc);
+        acc = mfma16(a3, b3, acc);
+        ap += 4 * da;
+        bp += 4 * db;
+    }
+    for (; ks < ksteps; ++ks) {
         acc = mfma16(*ap, *bp, acc);
         ap += da;
         bp += db;
     }
     return acc;
+}
+
+// Two independent products sharing nothing: interleaved so the two MFMA dependency chains
+// (40-cycle latency, 32-cycle issue) fill each other's gaps.
+__device__ __forceinline__ void tile_mma2(const float *a1, const float *b1, int ks1, f32x4 &acc1, const float *a2,
+                                          const float *b2, int ks2, f32x4 &acc2, int sa_r, int sa_k, int sb_k, int sb_c,
+                                          int lane) {
+    const float *ap1 = a1 + (lane & 15) * sa_r + (lane >> 4) * sa_k, *ap2 = a2 + (lane & 15) * sa_r + (lane >> 4) * sa_k;
+    const float *bp1 = b1 + (lane >> 4) * sb_k + (lane & 15) * sb_c, *bp2 = b2 + (lane >> 4) * sb_k + (lane & 15) * sb_c;
+    const int da = 4 * sa_k, db = 4 * sb_k;
+    const int kmin = ks1 < ks2 ? ks1 : ks2;
+    int ks = 0;
+    for (; ks + 2 <= kmin; ks += 2) {
+        const float x0 = ap1[0], x1 = ap1[da], y0 = bp1[0], y1 = bp1[db];
+        const float u0 = ap2[0], u1 = ap2[da], v0 = bp2[0], v1 = bp2[db];
+        acc1 = mfma16(x0, y0, acc1);
+        acc2 = mfma16(u0, v0, acc2);
+        acc1 = mfma16(x1, y1, acc1);
+        acc2 = mfma16(u1, v1, acc2);
+        ap1 += 2 * da; bp1 += 2 * db; ap2 += 2 * da; bp2 += 2 * db;
+    }
+    for (int k = ks; k < ks1; ++k) {
+        acc1 = mfma16(*ap1, *bp1, acc1);
+        ap1 += da; bp1 += db;
+    }
+    for (int k = ks; k < ks2; ++k) {
+        acc2 = mfma16(*ap2, *bp2, acc2);
+        ap2 += da; bp2 += db;
+    }
 }
 
 }  // namespace hno

@@ -40,27 +40,37 @@ ProfScope::~ProfScope() {
     if (slot >= 0) (void)hipEventRecord(g_prof_events[2 * slot + 1], stream);
 }
 
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partials, int nblocks, int n,
-                                                             float *dst0, int n0, float *dst1) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+// 64 columns x 16 slab groups per block: every thread sums nblocks/16 slabs with independent
+// loads, then the 16 groups are combined through LDS in a fixed order.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__restrict__ partials, int nblocks, int n,
+                                                              float *dst0, int n0, float *dst1) {
+    __shared__ float red[16][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 4 <= nblocks; b += 4) {
-        s0 += partials[(size_t)b * n + i];
-        s1 += partials[(size_t)(b + 1) * n + i];
-        s2 += partials[(size_t)(b + 2) * n + i];
-        s3 += partials[(size_t)(b + 3) * n + i];
+    if (col < n) {
+        int b = grp;
+        for (; b + 48 < nblocks; b += 64) {
+            s0 += partials[(size_t)b * n + col];
+            s1 += partials[(size_t)(b + 16) * n + col];
+            s2 += partials[(size_t)(b + 32) * n + col];
+            s3 += partials[(size_t)(b + 48) * n + col];
+        }
+        for (; b < nblocks; b += 16) s0 += partials[(size_t)b * n + col];
     }
-    for (; b < nblocks; ++b) s0 += partials[(size_t)b * n + i];
-    const float s = (s0 + s1) + (s2 + s3);
-    if (i < n0) dst0[i] += s;
-    else if (dst1) dst1[i - n0] += s;
+    red[grp][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0 && col < n) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s += red[g][threadIdx.x];
+        if (col < n0) dst0[col] = s;
+        else if (dst1) dst1[col - n0] = s;
+    }
 }
 
 int reduce_partials_launch(const float *partials, int nblocks, int n, float *dst0, int n0, float *dst1,
                            hipStream_t stream) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, partials, nblocks, n, dst0,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(n, 64)), dim3(1024), 0, stream, partials, nblocks, n, dst0,
                        n0, dst1);
     HNO_CHECK_LAUNCH();
     return HNO_OK;

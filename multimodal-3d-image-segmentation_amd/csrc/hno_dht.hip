@@ -186,6 +186,10 @@ struct DhtArgs {
 __device__ __forceinline__ int kept_pos(int k, int m) { return (k >= 0) ? (k < m ? k : -1) : (k >= -m ? k + 2 * m : -1); }
 
 // ---- forward, axes W and H, one (bc, n0) plane per workgroup iteration -------------------
+// MAXE > 0: the whole plane (<= 256 * MAXE elements) is fetched into registers with fully
+// coalesced, independent loads, and the NEXT plane's fetch is issued before the current plane's
+// MFMA phases so HBM latency hides behind compute.  MAXE == 0: generic row-by-row path.
+template <int MAXE>
 __global__ __launch_bounds__(256) void dht_fwd_plane_kernel(const float *__restrict__ x, const float *__restrict__ xact,
                                                             float *__restrict__ Y, DhtArgs a) {
     extern __shared__ float lds[];
@@ -209,25 +213,67 @@ __global__ __launch_bounds__(256) void dht_fwd_plane_kernel(const float *__restr
     const int planes = a.BC * p.ax[0].N;
     const size_t plane_elems = (size_t)N1 * N2;
     const int MT1 = p.MP1 / 16;
-    for (int plane = blockIdx.x; plane < planes; plane += gridDim.x) {
+    constexpr int NE = MAXE > 0 ? MAXE : 1;
+    float rx[NE], ru[NE];
+    // (row, col) of element tid + 256 * j, advanced incrementally
+    const int r0 = tid / N2, c0 = tid - r0 * N2, dr = 256 / N2, dc = 256 - dr * N2;
+    auto fetch = [&](int plane) {
         const float *xp = x + (size_t)plane * plane_elems;
         const float *up = xact ? xact + (size_t)plane * plane_elems : nullptr;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const unsigned e = tid + 256u * j;
+            const bool in = e < plane_elems;
+            rx[j] = in ? xp[e] : 0.f;
+            ru[j] = (in && up) ? up[e] : 0.f;
+        }
+    };
+    if (MAXE > 0 && blockIdx.x < planes) fetch(blockIdx.x);
+    for (int plane = blockIdx.x; plane < planes; plane += gridDim.x) {
         __syncthreads();  // previous iteration finished reading xs / T
-        // ---- load + fold along W: xs[r][c] = x[c] + x[N-c] (c <= Js), xs[r][N-c] = x[c] - x[N-c]
-        for (int r = wave; r < N1; r += 4) {
-            const float *row = xp + (size_t)r * N2;
-            const float *urow = up ? up + (size_t)r * N2 : nullptr;
-            float *dst = xs + r * p.lda2;
-            for (int c = lane; c <= a2.J; c += 64) {
-                float va = row[c];
-                if (urow) va *= act_grad_from_out(urow[c], a.act);
-                if (c >= 1 && c <= a2.Js) {
-                    float vb = row[N2 - c];
-                    if (urow) vb *= act_grad_from_out(urow[N2 - c], a.act);
-                    dst[c] = va + vb;
-                    dst[N2 - c] = va - vb;
-                } else {
-                    dst[c] = va;
+        if (MAXE > 0) {
+            // ---- registers -> LDS (raw rows), activation gradient applied here
+            int r = r0, c = c0;
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                if (tid + 256u * j < plane_elems) xs[r * p.lda2 + c] = xact ? rx[j] * act_grad_from_out(ru[j], a.act) : rx[j];
+                r += dr;
+                c += dc;
+                if (c >= N2) {
+                    c -= N2;
+                    ++r;
+                }
+            }
+            const int next = plane + gridDim.x;
+            if (next < planes) fetch(next);  // in flight during this plane's compute
+            __syncthreads();
+            // ---- fold along W in place: xs[r][c] <- x[c] + x[N-c], xs[r][N-c] <- x[c] - x[N-c]
+            for (int i = tid; i < N1 * a2.Js; i += 256) {
+                const int rr = i / a2.Js, cc = 1 + (i - rr * a2.Js);
+                float *row = xs + rr * p.lda2;
+                const float va = row[cc], vb = row[N2 - cc];
+                row[cc] = va + vb;
+                row[N2 - cc] = va - vb;
+            }
+        } else {
+            const float *xp = x + (size_t)plane * plane_elems;
+            const float *up = xact ? xact + (size_t)plane * plane_elems : nullptr;
+            // ---- load + fold along W: xs[r][c] = x[c] + x[N-c] (c <= Js), xs[r][N-c] = x[c] - x[N-c]
+            for (int r = wave; r < N1; r += 4) {
+                const float *row = xp + (size_t)r * N2;
+                const float *urow = up ? up + (size_t)r * N2 : nullptr;
+                float *dst = xs + r * p.lda2;
+                for (int c = lane; c <= a2.J; c += 64) {
+                    float va = row[c];
+                    if (urow) va *= act_grad_from_out(urow[c], a.act);
+                    if (c >= 1 && c <= a2.Js) {
+                        float vb = row[N2 - c];
+                        if (urow) vb *= act_grad_from_out(urow[N2 - c], a.act);
+                        dst[c] = va + vb;
+                        dst[N2 - c] = va - vb;
+                    } else {
+                        dst[c] = va;
+                    }
                 }
             }
         }
@@ -270,13 +316,10 @@ __global__ __launch_bounds__(256) void dht_fwd_plane_kernel(const float *__restr
             const float *Ts = T + a2.KP + kt2 * 16;     // As columns
             const float *bc = cosH + kt1 * a1.KcP * 16, *bs = sinH + kt1 * a1.KsP * 16;
             f32x4 accP = {0.f, 0.f, 0.f, 0.f}, accQ = {0.f, 0.f, 0.f, 0.f};
-            if (part == 0) {  // BR(+-k1) = P_Ac -+ Q_As
-                accP = tile_mma(Tc, 1, p.ldt, bc, 16, 1, a1.KcP / 4, accP, lane);
-                accQ = tile_mma(Ts + (a1.J + 1) * p.ldt, 1, p.ldt, bs, 16, 1, a1.KsP / 4, accQ, lane);
-            } else {          // BI(+k1) = -(Q_Ac + P_As), BI(-k1) = Q_Ac - P_As
-                accP = tile_mma(Ts, 1, p.ldt, bc, 16, 1, a1.KcP / 4, accP, lane);
-                accQ = tile_mma(Tc + (a1.J + 1) * p.ldt, 1, p.ldt, bs, 16, 1, a1.KsP / 4, accQ, lane);
-            }
+            if (part == 0)    // BR(+-k1) = P_Ac -+ Q_As
+                tile_mma2(Tc, bc, a1.KcP / 4, accP, Ts + (a1.J + 1) * p.ldt, bs, a1.KsP / 4, accQ, 1, p.ldt, 16, 1, lane);
+            else              // BI(+k1) = -(Q_Ac + P_As), BI(-k1) = Q_Ac - P_As
+                tile_mma2(Ts, bc, a1.KcP / 4, accP, Tc + (a1.J + 1) * p.ldt, bs, a1.KsP / 4, accQ, 1, p.ldt, 16, 1, lane);
             const int k1 = kt1 * 16 + (lane & 15);
             if (k1 <= a1.m) {
                 f32x4 vp, vm;
@@ -325,28 +368,52 @@ __global__ __launch_bounds__(64) void dht_fwd_d_kernel(const float *__restrict__
     for (int kt0 = 0; kt0 < a0.KT; ++kt0) {
         f32x4 PR = {0.f, 0.f, 0.f, 0.f}, PI = PR, QR = PR, QI = PR;
         const float *bc_ = cosD + kt0 * a0.KcP * 16, *bs_ = sinD + kt0 * a0.KsP * 16;
-        for (int ks = 0; ks < a0.KcP / 4; ++ks) {
-            const int c = ks * 4 + q;
-            const bool in = c <= a0.J;
-            const bool paired = in && c >= 1 && c <= a0.Js;
-            const int c1 = in ? c : 0, c2 = paired ? N0 - c : 0;
-            float vr = Yb[c1 * pstride + colR], vi = Yb[c1 * pstride + colI];
-            const float wr = Yb[c2 * pstride + colR], wi = Yb[c2 * pstride + colI];
-            vr = in ? vr + (paired ? wr : 0.f) : 0.f;
-            vi = in ? vi + (paired ? wi : 0.f) : 0.f;
-            const float b = bc_[(ks * 4 + q) * 16 + (lane & 15)];
-            PR = mfma16(vr, b, PR);
-            PI = mfma16(vi, b, PI);
+        // operands are gathered four k-steps at a time (16 independent loads in flight)
+        for (int ks0 = 0; ks0 < a0.KcP / 4; ks0 += 4) {
+            float vr[4], vi[4], wr[4], wi[4], bb[4];
+            bool inn[4], prd[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ks = ks0 + u;
+                const int c = ks * 4 + q;
+                inn[u] = ks < a0.KcP / 4 && c <= a0.J;
+                prd[u] = inn[u] && c >= 1 && c <= a0.Js;
+                const int c1 = inn[u] ? c : 0, c2 = prd[u] ? N0 - c : 0;
+                vr[u] = Yb[c1 * pstride + colR];
+                vi[u] = Yb[c1 * pstride + colI];
+                wr[u] = Yb[c2 * pstride + colR];
+                wi[u] = Yb[c2 * pstride + colI];
+                bb[u] = ks < a0.KcP / 4 ? bc_[(ks * 4 + q) * 16 + (lane & 15)] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float ar = inn[u] ? vr[u] + (prd[u] ? wr[u] : 0.f) : 0.f;
+                const float ai = inn[u] ? vi[u] + (prd[u] ? wi[u] : 0.f) : 0.f;
+                PR = mfma16(ar, bb[u], PR);
+                PI = mfma16(ai, bb[u], PI);
+            }
         }
-        for (int ks = 0; ks < a0.KsP / 4; ++ks) {
-            const int kk = ks * 4 + q;
-            const bool in = kk < a0.Js;
-            const int j = in ? a0.Js - kk : 1;
-            const float vr = in ? Yb[j * pstride + colR] - Yb[(N0 - j) * pstride + colR] : 0.f;
-            const float vi = in ? Yb[j * pstride + colI] - Yb[(N0 - j) * pstride + colI] : 0.f;
-            const float b = bs_[(ks * 4 + q) * 16 + (lane & 15)];
-            QR = mfma16(vr, b, QR);
-            QI = mfma16(vi, b, QI);
+        for (int ks0 = 0; ks0 < a0.KsP / 4; ks0 += 4) {
+            float vr[4], vi[4], wr[4], wi[4], bb[4];
+            bool inn[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ks = ks0 + u;
+                const int kk = ks * 4 + q;
+                inn[u] = ks < a0.KsP / 4 && kk < a0.Js;
+                const int j = inn[u] ? a0.Js - kk : 0;
+                const int j2 = inn[u] ? N0 - j : 0;
+                vr[u] = Yb[j * pstride + colR];
+                vi[u] = Yb[j * pstride + colI];
+                wr[u] = Yb[j2 * pstride + colR];
+                wi[u] = Yb[j2 * pstride + colI];
+                bb[u] = ks < a0.KsP / 4 ? bs_[(ks * 4 + q) * 16 + (lane & 15)] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                QR = mfma16(inn[u] ? vr[u] - wr[u] : 0.f, bb[u], QR);
+                QI = mfma16(inn[u] ? vi[u] - wi[u] : 0.f, bb[u], QI);
+            }
         }
         // lane holds, for k0 = kt0*16 + (lane&15) and k2 = kt2*16 + q*4 + r:
         //   X(+k0) = (PR + QI) + i (PI - QR),  X(-k0) = (PR - QI) + i (PI + QR)
@@ -407,33 +474,42 @@ __global__ __launch_bounds__(64) void dht_inv_d_kernel(const float *__restrict__
     const int KS = a0.KmP / 4;
     const size_t pstride = (size_t)2 * p.CP;
     float *Eb = E + (size_t)bc * N0 * pstride;
+    // operands do not depend on the output tile: gather them once (up to 8 k-steps = m0 <= 31)
+    constexpr int KSM = 8;
+    float gsr[KSM], gsi[KSM], gdr[KSM], gdi[KSM];
+#pragma unroll
+    for (int ks = 0; ks < KSM; ++ks) {
+        gsr[ks] = gsi[ks] = gdr[ks] = gdi[ks] = 0.f;
+        const int k0 = ks * 4 + q;
+        if (ks < KS && k0 <= m0 && k2 <= m2) {
+            const float va = zk_load(zb, k0, k1, k2, m0, m1, m2);
+            const float vb = k2 >= 1 ? zk_load(zb, -k0, -k1, -k2, m0, m1, m2) : 0.f;
+            // G'(+k0) = (va + vb) + i (vb - va)
+            gsr[ks] = va + vb;
+            gsi[ks] = vb - va;
+            if (k0 >= 1) {
+                const float vc = zk_load(zb, -k0, k1, k2, m0, m1, m2);
+                const float vd = k2 >= 1 ? zk_load(zb, k0, -k1, -k2, m0, m1, m2) : 0.f;
+                // G'(-k0) = (vc + vd) + i (vd - vc)
+                gdr[ks] = gsr[ks] - (vc + vd);
+                gdi[ks] = gsi[ks] - (vd - vc);
+                gsr[ks] += vc + vd;
+                gsi[ks] += vd - vc;
+            }
+        }
+    }
     for (int nt = 0; nt < a0.NT; ++nt) {
         f32x4 UR = {0.f, 0.f, 0.f, 0.f}, UI = UR, VR = UR, VI = UR;
-        for (int ks = 0; ks < KS; ++ks) {
-            const int k0 = ks * 4 + q;
-            float gsr = 0.f, gsi = 0.f, gdr = 0.f, gdi = 0.f;
-            if (k0 <= m0 && k2 <= m2) {
-                const float va = zk_load(zb, k0, k1, k2, m0, m1, m2);
-                const float vb = k2 >= 1 ? zk_load(zb, -k0, -k1, -k2, m0, m1, m2) : 0.f;
-                // G'(+k0) = (va + vb) + i (vb - va)
-                gsr = va + vb;
-                gsi = vb - va;
-                if (k0 >= 1) {
-                    const float vc = zk_load(zb, -k0, k1, k2, m0, m1, m2);
-                    const float vd = k2 >= 1 ? zk_load(zb, k0, -k1, -k2, m0, m1, m2) : 0.f;
-                    // G'(-k0) = (vc + vd) + i (vd - vc)
-                    gdr = gsr - (vc + vd);
-                    gdi = gsi - (vd - vc);
-                    gsr += vc + vd;
-                    gsi += vd - vc;
-                }
+#pragma unroll
+        for (int ks = 0; ks < KSM; ++ks) {
+            if (ks < KS) {
+                const float bcv = cosD[(nt * a0.KmP + ks * 4 + q) * 16 + (lane & 15)];
+                const float bsv = sinD[(nt * a0.KmP + ks * 4 + q) * 16 + (lane & 15)];
+                UR = mfma16(gsr[ks], bcv, UR);
+                UI = mfma16(gsi[ks], bcv, UI);
+                VR = mfma16(gdr[ks], bsv, VR);
+                VI = mfma16(gdi[ks], bsv, VI);
             }
-            const float bcv = cosD[(nt * a0.KmP + ks * 4 + q) * 16 + (lane & 15)];
-            const float bsv = sinD[(nt * a0.KmP + ks * 4 + q) * 16 + (lane & 15)];
-            UR = mfma16(gsr, bcv, UR);
-            UI = mfma16(gsi, bcv, UI);
-            VR = mfma16(gdr, bsv, VR);
-            VI = mfma16(gdi, bsv, VI);
         }
         // lane holds rows k2' = kt2*16 + q*4 + r, column n0 = nt*16 + (lane&15)
         const int n0 = nt * 16 + (lane & 15);
@@ -512,8 +588,8 @@ __global__ __launch_bounds__(256) void dht_inv_plane_kernel(const float *__restr
             const int rR = kt2 * 16, rI = a2.KP + kt2 * 16;
             const float *bc = cosH + nt1 * a1.KmP * 16, *bs = sinH + nt1 * a1.KmP * 16;
             f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = acc1;
-            acc1 = tile_mma(Es + (part ? rI : rR) * p.ldE, p.ldE, 1, bc, 16, 1, a1.KmP / 4, acc1, lane);
-            acc2 = tile_mma(Ed + (part ? rR : rI) * p.ldE, p.ldE, 1, bs, 16, 1, a1.KmP / 4, acc2, lane);
+            tile_mma2(Es + (part ? rI : rR) * p.ldE, bc, a1.KmP / 4, acc1, Ed + (part ? rR : rI) * p.ldE, bs, a1.KmP / 4, acc2,
+                      p.ldE, 1, 16, 1, lane);
             float *F = part ? FI : FR;
             const int n1 = nt1 * 16 + (lane & 15);
             if (n1 <= a1.J) {
@@ -538,24 +614,26 @@ __global__ __launch_bounds__(256) void dht_inv_plane_kernel(const float *__restr
         for (int t = wave; t < ntaskW; t += 4) {
             const int nt2 = t % a2.NT, mt = t / a2.NT;
             f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = acc1;
-            acc1 = tile_mma(FR + mt * 16 * p.ldF, p.ldF, 1, cosW + nt2 * a2.KmP * 16, 16, 1, a2.KmP / 4, acc1, lane);
-            acc2 = tile_mma(FI + mt * 16 * p.ldF, p.ldF, 1, sinW + nt2 * a2.KmP * 16, 16, 1, a2.KmP / 4, acc2, lane);
             const int n2 = nt2 * 16 + (lane & 15);
-            if (n2 <= a2.J) {
+            const bool colok = n2 <= a2.J, mirror = n2 >= 1 && n2 <= a2.Js;
+            // residual values first: their latency hides behind the MFMA chain
+            float adv[4], adm[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n1 = mt * 16 + (lane >> 4) * 4 + r;
+                const bool ok = ad && colok && n1 < N1;
+                adv[r] = ok ? ad[(size_t)n1 * N2 + n2] : 0.f;
+                adm[r] = (ok && mirror) ? ad[(size_t)n1 * N2 + (N2 - n2)] : 0.f;
+            }
+            tile_mma2(FR + mt * 16 * p.ldF, cosW + nt2 * a2.KmP * 16, a2.KmP / 4, acc1, FI + mt * 16 * p.ldF,
+                      sinW + nt2 * a2.KmP * 16, a2.KmP / 4, acc2, p.ldF, 1, 16, 1, lane);
+            if (colok) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int n1 = mt * 16 + (lane >> 4) * 4 + r;
                     if (n1 < N1) {
-                        size_t idx = (size_t)n1 * N2 + n2;
-                        float v = a.scale * (acc1[r] - acc2[r]);
-                        if (ad) v += ad[idx];
-                        op[idx] = act_apply(v, a.act);
-                        if (n2 >= 1 && n2 <= a2.Js) {
-                            idx = (size_t)n1 * N2 + (N2 - n2);
-                            float w = a.scale * (acc1[r] + acc2[r]);
-                            if (ad) w += ad[idx];
-                            op[idx] = act_apply(w, a.act);
-                        }
+                        op[(size_t)n1 * N2 + n2] = act_apply(a.scale * (acc1[r] - acc2[r]) + adv[r], a.act);
+                        if (mirror) op[(size_t)n1 * N2 + (N2 - n2)] = act_apply(a.scale * (acc1[r] + acc2[r]) + adm[r], a.act);
                     }
                 }
             }
@@ -565,6 +643,7 @@ __global__ __launch_bounds__(256) void dht_inv_plane_kernel(const float *__restr
 
 static int check_sizes(int BC, int N0, int N1, int N2, int m0, int m1, int m2) {
     HNO_REQUIRE(BC > 0 && N0 > 0 && N1 > 0 && N2 > 0, "dht3: non-positive size");
+    if (m0 > 31) return fail(HNO_ELIMIT, "dht3: m0 = %d modes along the first axis (max 31)", m0);
     HNO_REQUIRE(m0 > 0 && m1 > 0 && m2 > 0, "dht3: modes must be positive");
     HNO_REQUIRE(2 * m0 <= N0 && 2 * m1 <= N1 && 2 * m2 <= N2, "dht3: modes must be clamped to N // 2 by the caller");
     if (BC > 65535) return fail(HNO_ELIMIT, "dht3: B*C = %d exceeds 65535", BC);
@@ -601,12 +680,27 @@ extern "C" int hno_dht3_crop(const float *x, const float *x_act_out, int act_gra
     hipStream_t s = (hipStream_t)stream;
     static bool attr_done = false;
     if (!attr_done) {
-        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         attr_done = true;
     }
     const int planes = BC * N0;
-    const int grid = planes < 1024 ? planes : 1024;
-    { ProfScope _ps(KID_DHT_FWD_PLANE, s); hipLaunchKernelGGL(dht_fwd_plane_kernel, dim3(grid), dim3(256), lds, s, x, x_act_out, (float *)workspace, a); }
+    // resident workgroups: LDS-limited; a grid of exactly that size lets every workgroup prefetch
+    int per_cu = (int)(kMaxLds / lds);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    const int grid = planes < 256 * per_cu ? planes : 256 * per_cu;
+    const int pe = N1 * N2;
+    {
+        ProfScope _ps(KID_DHT_FWD_PLANE, s);
+        if (pe <= 256 * 20)
+            hipLaunchKernelGGL(dht_fwd_plane_kernel<20>, dim3(grid), dim3(256), lds, s, x, x_act_out, (float *)workspace, a);
+        else if (pe <= 256 * 64)
+            hipLaunchKernelGGL(dht_fwd_plane_kernel<64>, dim3(grid), dim3(256), lds, s, x, x_act_out, (float *)workspace, a);
+        else
+            hipLaunchKernelGGL(dht_fwd_plane_kernel<0>, dim3(grid), dim3(256), lds, s, x, x_act_out, (float *)workspace, a);
+    }
     HNO_CHECK_LAUNCH();
     const Axis &a0 = plan->ax[0];
     const size_t ldsd = sizeof(float) * a0.KT * (a0.KcP + a0.KsP) * 16;

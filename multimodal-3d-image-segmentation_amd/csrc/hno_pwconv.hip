@@ -348,8 +348,10 @@ __global__ __launch_bounds__(256, 4) void pwconv_fwd_fast_kernel(PwArgs a) {
     }
 }
 
+#define PWB_FAST_WAVES 12  // 768-thread blocks, one per CU: 256 slabs instead of 1024
 template <int NKO, int NKI>
-__global__ __launch_bounds__(256, 3) void pwconv_bwd_fast_kernel(PwBwdArgs a) {
+__global__ __launch_bounds__(64 * PWB_FAST_WAVES) void pwconv_bwd_fast_kernel(PwBwdArgs a) {
+    constexpr int NW = PWB_FAST_WAVES;
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -380,12 +382,12 @@ __global__ __launch_bounds__(256, 3) void pwconv_bwd_fast_kernel(PwBwdArgs a) {
         for (int n = 0; n < NTI; ++n) dw[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     const unsigned tiles_per_b = (V + 31) / 32;
     const unsigned ntiles = tiles_per_b * a.B;
-    const unsigned ngroups = (ntiles + 3) / 4;
+    const unsigned ngroups = (ntiles + NW - 1) / NW;
     const unsigned hoffV = h ? V : 0u, hoff4V = h ? 4u * V : 0u;
     const float *ga = G + (lane & 15) * PWB_LD + (lane >> 4);
     const float *xbp = X + (lane & 15) * PWB_LD + (lane >> 4);
     for (unsigned grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const unsigned t = grp * 4 + wave;
+        const unsigned t = grp * NW + wave;
         const bool live = t < ntiles;
         const unsigned b = live ? t / tiles_per_b : 0u;
         const unsigned v = live ? (t - b * tiles_per_b) * 32 + c : 0u;
@@ -427,7 +429,10 @@ __global__ __launch_bounds__(256, 3) void pwconv_bwd_fast_kernel(PwBwdArgs a) {
                 }
             }
         }
-        __syncthreads();
+        // the LDS tile is wave-private: LDS ops of one wave execute in order, so only the compiler
+        // has to be kept from reordering the reads above the writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll 2
         for (int ks = 0; ks < 8; ++ks) {
             float av[MT], bv[NTI];
@@ -440,7 +445,8 @@ __global__ __launch_bounds__(256, 3) void pwconv_bwd_fast_kernel(PwBwdArgs a) {
 #pragma unroll
                 for (int n = 0; n < NTI; ++n) dw[m][n] = mfma16(av[m], bv[n], dw[m][n]);
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     {
         constexpr int n = COUT * CIN + COUT;
@@ -461,7 +467,7 @@ __global__ __launch_bounds__(256, 3) void pwconv_bwd_fast_kernel(PwBwdArgs a) {
             for (int off2 = 16; off2 >= 1; off2 >>= 1) s += __shfl_xor(s, off2);
             if (c == 0) mine[COUT * CIN + 2 * ks + h] = s;
         }
-        block_sum_to_slab(lds, n, a.partials + (size_t)blockIdx.x * n, threadIdx.x);
+        block_sum_to_slab(lds, n, a.partials + (size_t)blockIdx.x * n, threadIdx.x, NW);
     }
 }
 
@@ -545,14 +551,26 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
     const int nslab = Cout * Cin + Cout;
     if (Ca % 8 == 0 && Cb % 8 == 0) {  // exact-size fast paths
         bool done = true;
-        ProfScope ps(KID_PWCONV_BWD, s);
-        if (Cin == 24 && Cout == 24) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<12, 12>), dim3(grid), dim3(256), sizeof(float) * 4 * (32 + 32) * PWB_LD, s, a);
-        else if (Cin == 48 && Cout == 24) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<12, 24>), dim3(grid), dim3(256), sizeof(float) * 4 * (32 + 48) * PWB_LD, s, a);
-        else if (Cin == 24 && Cout == 4) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<2, 12>), dim3(grid), dim3(256), sizeof(float) * 4 * (16 + 32) * PWB_LD, s, a);
-        else done = false;
+        constexpr int NW = PWB_FAST_WAVES;
+        long long fg = (ntiles + NW - 1) / NW;
+        if (fg > 256) fg = 256;   // one 768-thread block per CU
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<12, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<12, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<2, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_done = true;
+        }
+        {
+            ProfScope ps(KID_PWCONV_BWD, s);
+            if (Cin == 24 && Cout == 24) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<12, 12>), dim3((int)fg), dim3(64 * NW), sizeof(float) * NW * (32 + 32) * PWB_LD, s, a);
+            else if (Cin == 48 && Cout == 24) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<12, 24>), dim3((int)fg), dim3(64 * NW), sizeof(float) * NW * (32 + 48) * PWB_LD, s, a);
+            else if (Cin == 24 && Cout == 4) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<2, 12>), dim3((int)fg), dim3(64 * NW), sizeof(float) * NW * (16 + 32) * PWB_LD, s, a);
+            else done = false;
+        }
         if (done) {
             HNO_CHECK_LAUNCH();
-            return reduce_partials_launch(a.partials, grid, nslab, dW, Cout * Cin, dbias, s);
+            return reduce_partials_launch(a.partials, (int)fg, nslab, dW, Cout * Cin, dbias, s);
         }
     }
     {

@@ -139,7 +139,7 @@ class SpecMixFn(torch.autograd.Function):
         B, C = z0.shape[:2]
         M, Lyr = _flat_v(z0), W.shape[0]
         gz0 = torch.empty_like(z0)
-        dW = torch.zeros_like(W)
+        dW = torch.empty_like(W)
         ws = _wgrad_ws(C, C, z0.device)
         check(_lib.lib().hno_specmix_shared_bwd(ptr(g), ptr(z0), ptr(zs), ptr(W), ptr(gz0), ptr(dW), ptr(ws), B, C, M, Lyr,
                                                 ctx.residual, ctx.act, stream_ptr()), 'hno_specmix_shared_bwd')
@@ -174,8 +174,8 @@ class PwConvFn(torch.autograd.Function):
         Cout, V = W.shape[0], _flat_v(xa)
         gxa = torch.empty_like(xa) if ctx.needs_input_grad[0] else None
         gxb = torch.empty_like(xb) if (xb is not None and ctx.needs_input_grad[1]) else None
-        dW = torch.zeros_like(W)
-        db = torch.zeros(Cout, device=W.device, dtype=torch.float32) if ctx.has_bias else None
+        dW = torch.empty_like(W)
+        db = torch.empty(Cout, device=W.device, dtype=torch.float32) if ctx.has_bias else None
         ws = _wgrad_ws(Ca + Cb, Cout, xa.device)
         check(_lib.lib().hno_pwconv_bwd(ptr(gy), ptr(y), ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(gxa), ptr(gxb), ptr(dW),
                                         ptr(db), ptr(ws), B, Cout, V, ctx.act, stream_ptr()), 'hno_pwconv_bwd')
@@ -206,8 +206,8 @@ class ConvK2S2Fn(torch.autograd.Function):
         gy = _f32c(gy)
         B, Cin, D, H, Wd = x.shape
         Cout = W.shape[0]
-        dW = torch.zeros_like(W)
-        db = torch.zeros(Cout, device=W.device, dtype=torch.float32) if ctx.has_bias else None
+        dW = torch.empty_like(W)
+        db = torch.empty(Cout, device=W.device, dtype=torch.float32) if ctx.has_bias else None
         ws = _wgrad_ws(Cin * 8, Cout, x.device)
         check(_lib.lib().hno_conv_k2s2_bwd(ptr(gy), ptr(y), ptr(x), ptr(W), None, ptr(dW), ptr(db), ptr(ws), B, Cin, Cout,
                                            D, H, Wd, ctx.act, stream_ptr()), 'hno_conv_k2s2_bwd')
