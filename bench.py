@@ -29,30 +29,6 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 ALGO_BYTES_PER_VOLUME = 4.67e9  # fwd 1.596 GB + bwd 3.073 GB
 
 
-def algorithmic_bytes(kernel, B):
-    """ALGORITHMIC bytes of one launch of `kernel` at the benchmark shapes."""
-    C, N3, M = 24, 65 ** 3, 20 * 28 * 28
-    V = 128 ** 3
-    f = 4
-    table = {
-        # 3-D truncated DHT, either direction: read N^3 reals, write 8 m0 m1 m2 reals (SURVEY 8d);
-        # the two launches of one transform share that budget: the plane kernel owns the N^3 side
-        'dht_fwd_plane_kernel': B * C * N3 * f,
-        'dht_inv_plane_kernel': B * C * N3 * f,
-        'dht_fwd_d_kernel': B * C * M * f,
-        'dht_inv_d_kernel': B * C * M * f,
-        'pwconv_fwd_kernel': B * (48 + 24) * N3 * f,
-        'pwconv_bwd_kernel': B * (24 + 24 + 48 + 48) * N3 * f,
-        'conv_k2s2_fwd_kernel': B * (4 * V + C * N3) * f,
-        'conv_k2s2_bwd_kernel': B * (4 * V + 2 * C * N3) * f,
-        'upsoftmax_fwd_kernel': B * (4 * N3 + 4 * V) * f,
-        'upsoftmax_bwd_kernel': B * (8 * V + 4 * N3) * f,
-        'loss_stats_kernel': B * (4 * V * f + V),
-        'loss_bwd_kernel': B * (8 * V * f + V),
-    }
-    return table.get(kernel)
-
-
 def effective_cpus():
     """CPUs this process may really use: affinity mask and cgroup quota, not os.cpu_count()."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -114,6 +90,7 @@ def main():
     ap.add_argument('--batch', type=int, default=2, help='per-GPU batch (BASELINE config: 2)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a HIP graph')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -143,14 +120,47 @@ def main():
     labels = torch.randint(0, 4, (B, 1) + VOL, device=dev, generator=g).float()
     lab_u8 = pkg.ops.labels_prepare(labels, 4)     # uint8 class map resident in HBM
 
-    def step():
+    def fwd_bwd():
         y = model(x)
         loss = loss_fn(y, lab_u8)
         rep.zero_grad()
         loss.backward()
+        return loss
+
+    def eager_step():
+        loss = fwd_bwd()
         rep.allreduce_grads()
         opt.step()
         return loss
+
+    for _ in range(max(args.warmup, 2)):   # also creates the twiddle tables / kernel attributes (not capturable)
+        eager_step()
+
+    # forward + loss + backward are captured ONCE into a HIP graph and replayed: ~150 kernel launches per
+    # step cost no host time, so the GPU is never launch-bound.  All-reduce and Adamax stay eager.
+    graph = None
+    if not args.no_graph:
+        try:
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    static_loss = fwd_bwd()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+        except Exception as exc:   # capture unsupported on this stack: run eagerly and say so
+            print(f'[bench] HIP graph capture failed ({exc!r}); running eagerly', file=sys.stderr)
+            graph = None
+
+    def step():
+        if graph is None:
+            return eager_step()
+        graph.replay()
+        rep.allreduce_grads()
+        opt.step()
+        return static_loss
 
     for _ in range(args.warmup):
         step()
@@ -161,17 +171,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    prof = None if args.no_kernel_profile else pkg._lib.KernelProfile(max_records=200 * args.steps + 64)
     fence()
-    if prof:
-        prof.__enter__()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    if prof:
-        prof.__exit__(None, None, None)
+    # per-kernel HIP-event durations: a few eager steps of the same workload right after the timed
+    # region (events cannot be recorded inside a graph replay)
+    prof = None
+    prof_steps = min(args.steps, 5)
+    if not args.no_kernel_profile:
+        prof = pkg._lib.KernelProfile(max_records=400 * prof_steps + 64)
+        with prof:
+            for _ in range(prof_steps):
+                eager_step()
+        fence()
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -183,13 +198,15 @@ def main():
         kernels = {}
         if prof:
             summ = prof.summary()
-            kernels = {k: {'calls_per_step': c / args.steps, 'avg_us': avg * 1e3, 'total_ms_per_step': s / args.steps}
-                       for k, (c, s, avg) in sorted(summ.items(), key=lambda kv: -kv[1][1])}
+            kernels = {k: {'calls_per_step': c / prof_steps, 'avg_us': round(avg * 1e3, 2),
+                           'total_ms_per_step': round(s / prof_steps, 4),
+                           'algorithmic_GBps': round(nb / (s * 1e-3) / 1e9, 1) if nb else None}
+                       for k, (c, s, avg, nb) in sorted(summ.items(), key=lambda kv: -kv[1][1])}
             dom = max(summ.items(), key=lambda kv: kv[1][1])[0]
-            avg_ms = summ[dom][2]
-            ab = algorithmic_bytes(dom, B)
+            calls, tot_ms, avg_ms, tot_bytes = summ[dom]
+            ab = tot_bytes / calls          # mean ALGORITHMIC bytes per launch (recorded by the launcher)
             if ab:
-                achieved = ab / (avg_ms * 1e-3) / 1e9
+                achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
                 traffic = None
                 tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
                 if os.path.exists(tpath):
@@ -205,6 +222,7 @@ def main():
             'config': {'workload': "HNOSeg-XS BraTS'23 config (filters 24, 8 blocks x 3, modes 10-14-14), "
                                    "synthetic 4-modal 128^3 fp32, step = fwd + PCC loss + bwd + grad all-reduce + Adamax",
                        'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
+                       'launch': 'hip-graph replay (fwd+loss+bwd) + eager all-reduce/Adamax' if graph is not None else 'eager',
                        'final_loss': round(float(loss), 6)},
             'roofline': roofline,
             'whole_step_roofline': {'algorithmic_GB_per_volume': ALGO_BYTES_PER_VOLUME / 1e9,

@@ -135,10 +135,13 @@ int hno_labels_prepare(const float *labels_f32, const int *remap_from, const int
 /* ------------------------------------------------------------------ per-kernel profiler
  * hno_profile_begin arms HIP-event bracketing of every kernel launch (on the stream the kernel
  * is launched on); hno_profile_end stops it, waits for the events and returns the number of
- * records written as (kernel id, milliseconds).  Not for use during graph capture. */
+ * records written as (kernel id, milliseconds, ALGORITHMIC bytes of that launch as defined in
+ * DESIGN.md section 4).  Not for use during graph capture. */
 int hno_profile_begin(int max_records);
-int hno_profile_end(int *kernel_ids, float *ms, int capacity);
+int hno_profile_end(int *kernel_ids, float *ms, double *algorithmic_bytes, int capacity);
 const char *hno_profile_kernel_name(int kernel_id);
+/* ablation switches for kernel tuning (timing only: results are wrong when non-zero) */
+int hno_set_debug(int flags);
 
 /* ------------------------------------------------------------------------ self tests
  * C(MxN) = A(MxK) B(KxN) through the wave-level MFMA tile engine every kernel uses. */

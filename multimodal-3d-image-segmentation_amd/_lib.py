@@ -37,8 +37,9 @@ SIGNATURES = {
     'hno_loss_bwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_ll, c_void_p]),
     'hno_labels_prepare': (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 2 + [c_int, c_int, c_ll, c_void_p]),
     'hno_profile_begin': (c_int, [c_int]),
-    'hno_profile_end': (c_int, [c_void_p, c_void_p, c_int]),
+    'hno_profile_end': (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
     'hno_profile_kernel_name': (ctypes.c_char_p, [c_int]),
+    'hno_set_debug': (c_int, [c_int]),
     'hno_selftest_gemm': (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
 }
 
@@ -99,7 +100,7 @@ class KernelProfile:
 
     def __init__(self, max_records=65536):
         self.max_records = max_records
-        self.records = []   # (kernel name, milliseconds)
+        self.records = []   # (kernel name, milliseconds, algorithmic bytes)
 
     def __enter__(self):
         check(lib().hno_profile_begin(self.max_records), 'hno_profile_begin')
@@ -108,20 +109,21 @@ class KernelProfile:
     def __exit__(self, *exc):
         ids = (ctypes.c_int * self.max_records)()
         ms = (ctypes.c_float * self.max_records)()
-        n = lib().hno_profile_end(ids, ms, self.max_records)
+        nbytes = (ctypes.c_double * self.max_records)()
+        n = lib().hno_profile_end(ids, ms, nbytes, self.max_records)
         if n < 0:
             check(n, 'hno_profile_end')
         names = {}
         for i in range(n):
             if ids[i] not in names:
                 names[ids[i]] = lib().hno_profile_kernel_name(ids[i]).decode()
-            self.records.append((names[ids[i]], ms[i]))
+            self.records.append((names[ids[i]], ms[i], nbytes[i]))
         return False
 
     def summary(self):
-        """name -> (calls, total ms, average ms)"""
+        """name -> (calls, total ms, average ms, total algorithmic bytes)"""
         agg = {}
-        for name, t in self.records:
-            c, s = agg.get(name, (0, 0.0))
-            agg[name] = (c + 1, s + t)
-        return {k: (c, s, s / c) for k, (c, s) in agg.items()}
+        for name, t, nb in self.records:
+            c, s, b = agg.get(name, (0, 0.0, 0.0))
+            agg[name] = (c + 1, s + t, b + nb)
+        return {k: (c, s, s / c, b) for k, (c, s, b) in agg.items()}

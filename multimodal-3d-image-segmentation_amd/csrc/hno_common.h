@@ -45,7 +45,7 @@ enum KernelId {
 struct ProfScope {
     int slot;
     hipStream_t stream;
-    ProfScope(int kernel_id, hipStream_t s);
+    ProfScope(int kernel_id, hipStream_t s, double algorithmic_bytes = 0.0);
     ~ProfScope();
 };
 
@@ -68,6 +68,9 @@ __device__ __forceinline__ void block_sum_to_slab(float *scratch, int n, float *
     }
 }
 
+// debug/ablation switches (hno_set_debug): timing-only builds of a kernel phase, results are WRONG
+int debug_flags();
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
@@ -75,9 +78,16 @@ inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 #define HNO_SELU_ALPHA 1.6732632423543772848170429916717f
 #define HNO_SELU_SCALE 1.0507009873554804934193349852946f
 
+// e^x - 1 for x <= 0, branch-free: 7-term Taylor series near zero (no cancellation), hardware exp2
+// elsewhere.  Absolute error < 1.5e-7, relative error < 6e-7 (libm expm1f costs ~10x more VALU).
+__device__ __forceinline__ float neg_expm1(float x) {
+    const float t = x * (1.f + x * (0.5f + x * (1.f / 6 + x * (1.f / 24 + x * (1.f / 120 + x * (1.f / 720 + x * (1.f / 5040)))))));
+    const float e = __expf(x) - 1.f;
+    return x > -0.25f ? t : e;
+}
 __device__ __forceinline__ float act_apply(float x, int act) {
-    if (act == HNO_ACT_SELU) return x > 0.f ? HNO_SELU_SCALE * x : (HNO_SELU_SCALE * HNO_SELU_ALPHA) * expm1f(x);
-    if (act == HNO_ACT_ELU) return x > 0.f ? x : expm1f(x);
+    if (act == HNO_ACT_SELU) return x > 0.f ? HNO_SELU_SCALE * x : (HNO_SELU_SCALE * HNO_SELU_ALPHA) * neg_expm1(x);
+    if (act == HNO_ACT_ELU) return x > 0.f ? x : neg_expm1(x);
     return x;
 }
 // derivative expressed through the saved OUTPUT y = act(x)
@@ -151,6 +161,41 @@ __device__ __forceinline__ void tile_mma2(const float *a1, const float *b1, int 
     for (int k = ks; k < ks2; ++k) {
         acc2 = mfma16(*ap2, *bp2, acc2);
         ap2 += da; bp2 += db;
+    }
+}
+
+// Folded pair of products used by the Hartley kernels: with s(i) = S[i * sk],
+//   accC += sum_c  (s(c) + s(N - c)) * Bc[c][.]      c = 0 .. 4*ksc-1   (cos part)
+//   accS += sum_kk (s(j) - s(N - j)) * Bs[kk][.]     j = Js - kk         (sin part)
+// The fold x[n] +- x[N-n] is applied while the operand is read, so no separate LDS pass is needed.
+// Positions outside 0..N multiply zero table rows; they are clamped so every read stays in range.
+// `ac` / `as_` point at the element (row0, position 0) of the cos / sin source rows.
+__device__ __forceinline__ void tile_mma_fold2(const float *ac, const float *as_, int sa_r, int sk, int N, int Js,
+                                               const float *bc, int ksc, const float *bs, int kss, f32x4 &accC,
+                                               f32x4 &accS, int lane) {
+    const int q = lane >> 4;
+    const float *pc = ac + (lane & 15) * sa_r, *ps = as_ + (lane & 15) * sa_r;
+    const float *bpc = bc + q * 16 + (lane & 15), *bps = bs + q * 16 + (lane & 15);
+    const int kmax = ksc > kss ? ksc : kss;
+    for (int ks = 0; ks < kmax; ks += 2) {
+        float ca[2], cb[2], sa[2], sb[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int kk = (ks + u) * 4 + q;
+            int c = kk < N ? kk : N;
+            int j = Js - kk;
+            j = j > 0 ? j : 0;
+            const bool oc = ks + u < ksc, os = ks + u < kss;
+            ca[u] = oc ? pc[c * sk] + pc[(N - c) * sk] : 0.f;
+            cb[u] = oc ? bpc[(ks + u) * 64] : 0.f;
+            sa[u] = os ? ps[j * sk] - ps[(N - j) * sk] : 0.f;
+            sb[u] = os ? bps[(ks + u) * 64] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (ks + u < ksc) accC = mfma16(ca[u], cb[u], accC);
+            if (ks + u < kss) accS = mfma16(sa[u], sb[u], accS);
+        }
     }
 }
 

@@ -212,9 +212,9 @@ extern "C" int hno_conv_k2s2_fwd(const float *x, const float *W, const float *bi
     long long grid = (ntiles + 3) / 4;
     if (grid > 4096) grid = 4096;
     if (Cin <= 4)
-        { ProfScope _ps(KID_CONV_K2S2_FWD, (hipStream_t)stream); hipLaunchKernelGGL(conv_k2s2_fwd_kernel<16>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a); }
+        { ProfScope _ps(KID_CONV_K2S2_FWD, (hipStream_t)stream, 4.0 * B * ((double)Cin * D * H * Wd + (double)Cout * a.Do * a.Ho * a.Wo)); hipLaunchKernelGGL(conv_k2s2_fwd_kernel<16>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a); }
     else
-        { ProfScope _ps(KID_CONV_K2S2_FWD, (hipStream_t)stream); hipLaunchKernelGGL(conv_k2s2_fwd_kernel<32>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a); }
+        { ProfScope _ps(KID_CONV_K2S2_FWD, (hipStream_t)stream, 4.0 * B * ((double)Cin * D * H * Wd + (double)Cout * a.Do * a.Ho * a.Wo)); hipLaunchKernelGGL(conv_k2s2_fwd_kernel<32>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a); }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }
@@ -236,11 +236,11 @@ extern "C" int hno_conv_k2s2_bwd(const float *gy, const float *y, const float *x
     const size_t lds = sizeof(float) * 4 * (32 + kch * 32) * K2_LD;
     hipStream_t s = (hipStream_t)stream;
     if (Cout <= 24) {
-        if (kch == 1) { ProfScope _ps(KID_CONV_K2S2_BWD, s); hipLaunchKernelGGL((conv_k2s2_bwd_kernel<12, 1>), dim3((int)grid), dim3(256), lds, s, a); }
-        else { ProfScope _ps(KID_CONV_K2S2_BWD, s); hipLaunchKernelGGL((conv_k2s2_bwd_kernel<12, 2>), dim3((int)grid), dim3(256), lds, s, a); }
+        if (kch == 1) { ProfScope _ps(KID_CONV_K2S2_BWD, s, 4.0 * B * ((double)Cin * D * H * Wd + 2.0 * Cout * a.Do * a.Ho * a.Wo)); hipLaunchKernelGGL((conv_k2s2_bwd_kernel<12, 1>), dim3((int)grid), dim3(256), lds, s, a); }
+        else { ProfScope _ps(KID_CONV_K2S2_BWD, s, 4.0 * B * ((double)Cin * D * H * Wd + 2.0 * Cout * a.Do * a.Ho * a.Wo)); hipLaunchKernelGGL((conv_k2s2_bwd_kernel<12, 2>), dim3((int)grid), dim3(256), lds, s, a); }
     } else {
-        if (kch == 1) { ProfScope _ps(KID_CONV_K2S2_BWD, s); hipLaunchKernelGGL((conv_k2s2_bwd_kernel<16, 1>), dim3((int)grid), dim3(256), lds, s, a); }
-        else { ProfScope _ps(KID_CONV_K2S2_BWD, s); hipLaunchKernelGGL((conv_k2s2_bwd_kernel<16, 2>), dim3((int)grid), dim3(256), lds, s, a); }
+        if (kch == 1) { ProfScope _ps(KID_CONV_K2S2_BWD, s, 4.0 * B * ((double)Cin * D * H * Wd + 2.0 * Cout * a.Do * a.Ho * a.Wo)); hipLaunchKernelGGL((conv_k2s2_bwd_kernel<16, 1>), dim3((int)grid), dim3(256), lds, s, a); }
+        else { ProfScope _ps(KID_CONV_K2S2_BWD, s, 4.0 * B * ((double)Cin * D * H * Wd + 2.0 * Cout * a.Do * a.Ho * a.Wo)); hipLaunchKernelGGL((conv_k2s2_bwd_kernel<16, 2>), dim3((int)grid), dim3(256), lds, s, a); }
     }
     HNO_CHECK_LAUNCH();
     return reduce_partials_launch(a.partials, (int)grid, Cout * Cin * 8 + Cout, dW, Cout * Cin * 8, dbias, s);

@@ -20,6 +20,9 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+static int g_debug_flags = 0;
+int debug_flags() { return g_debug_flags; }
+
 // ---- profiler state
 static const char *kKernelNames[KID_COUNT] = {
     "dht_fwd_plane_kernel", "dht_fwd_d_kernel", "dht_inv_d_kernel", "dht_inv_plane_kernel", "pwconv_fwd_kernel",
@@ -28,12 +31,14 @@ static const char *kKernelNames[KID_COUNT] = {
 static bool g_prof_on = false;
 static std::vector<hipEvent_t> g_prof_events;  // 2 per record
 static std::vector<int> g_prof_ids;
+static std::vector<double> g_prof_bytes;
 static int g_prof_cap = 0;
 
-ProfScope::ProfScope(int kernel_id, hipStream_t s) : slot(-1), stream(s) {
+ProfScope::ProfScope(int kernel_id, hipStream_t s, double algorithmic_bytes) : slot(-1), stream(s) {
     if (!g_prof_on || (int)g_prof_ids.size() >= g_prof_cap) return;
     slot = (int)g_prof_ids.size();
     g_prof_ids.push_back(kernel_id);
+    g_prof_bytes.push_back(algorithmic_bytes);
     (void)hipEventRecord(g_prof_events[2 * slot], stream);
 }
 ProfScope::~ProfScope() {
@@ -116,13 +121,14 @@ extern "C" int hno_profile_begin(int max_records) {
         g_prof_events.push_back(e);
     }
     g_prof_ids.clear();
+    g_prof_bytes.clear();
     g_prof_cap = max_records;
     g_prof_on = true;
     return HNO_OK;
 }
 
 // Stops recording, waits for the recorded events and returns per-record (kernel id, milliseconds).
-extern "C" int hno_profile_end(int *kernel_ids, float *ms, int capacity) {
+extern "C" int hno_profile_end(int *kernel_ids, float *ms, double *bytes, int capacity) {
     g_prof_on = false;
     const int n = (int)g_prof_ids.size();
     for (int i = 0; i < n && i < capacity; ++i) {
@@ -131,10 +137,16 @@ extern "C" int hno_profile_end(int *kernel_ids, float *ms, int capacity) {
         HNO_CHECK_HIP(hipEventElapsedTime(&t, g_prof_events[2 * i], g_prof_events[2 * i + 1]));
         kernel_ids[i] = g_prof_ids[i];
         ms[i] = t;
+        if (bytes) bytes[i] = g_prof_bytes[i];
     }
     return n < capacity ? n : capacity;
 }
 
 extern "C" const char *hno_profile_kernel_name(int kernel_id) {
     return (kernel_id >= 0 && kernel_id < KID_COUNT) ? kKernelNames[kernel_id] : "?";
+}
+
+extern "C" int hno_set_debug(int flags) {
+    g_debug_flags = flags;
+    return HNO_OK;
 }

@@ -46,7 +46,7 @@ struct DhtPlan {
     // forward plane kernel LDS layout (floats)
     int lda2, TP, ldt, f_tabW, f_tabH, f_xs, f_T, f_lds_floats;
     // inverse plane kernel LDS layout
-    int ldE, ldF, i_tabH, i_tabW, i_Es, i_Ed, i_FR, i_FI, i_lds_floats;
+    int ldE, ldF, ldo, i_tabH, i_tabW, i_Es, i_Ed, i_FR, i_FI, i_O, i_lds_floats;
 };
 
 static int pad_2mod4(int v) {
@@ -75,7 +75,10 @@ static void fill_axis(Axis &a, int N, int m, int &cursor) {
     cursor += a.NT * a.KmP * 16;
 }
 
-static void build_axis_tables(const Axis &a, std::vector<float> &t) {
+// plane_axis: the table is used by the plane kernels, which fold their operands on the fly as
+// s(c) + s(N-c); positions that are their own mirror (c = N/2 forward, frequency 0 inverse) would be
+// counted twice, so their cos rows are halved.  The D kernels fold explicitly and use plain tables.
+static void build_axis_tables(const Axis &a, std::vector<float> &t, bool plane_axis, bool inv_fold) {
     const double th = 2.0 * M_PI / a.N;
     // forward: B[kk][k]; cos row kk <-> folded position c = kk (0..J);
     //          sin row kk <-> folded position J+1+kk <-> j = Js - kk (1..Js)
@@ -84,6 +87,7 @@ static void build_axis_tables(const Axis &a, std::vector<float> &t) {
             for (int c = 0; c < 16; ++c) {
                 int k = kt * 16 + c;
                 double v = (kk <= a.J && k <= a.m) ? cos(th * (double)((long long)k * kk % a.N)) : 0.0;
+                if (plane_axis && 2 * kk == a.N) v *= 0.5;
                 t[a.cosF + (kt * a.KcP + kk) * 16 + c] = (float)v;
             }
     for (int kt = 0; kt < a.KT; ++kt)
@@ -101,7 +105,7 @@ static void build_axis_tables(const Axis &a, std::vector<float> &t) {
                 int n = nt * 16 + c;
                 bool ok = (kk <= a.m && n <= a.J);
                 double ang = th * (double)((long long)kk * n % a.N);
-                t[a.cosI + (nt * a.KmP + kk) * 16 + c] = ok ? (float)cos(ang) : 0.f;
+                t[a.cosI + (nt * a.KmP + kk) * 16 + c] = ok ? (float)(cos(ang) * ((inv_fold && kk == 0) ? 0.5 : 1.0)) : 0.f;
                 t[a.sinI + (nt * a.KmP + kk) * 16 + c] = ok ? (float)sin(ang) : 0.f;
             }
 }
@@ -127,7 +131,9 @@ static int get_plan(int N0, int N1, int N2, int m0, int m1, int m2, const DhtPla
     fill_axis(p.ax[2], N2, m2, cursor);
     p.table_floats = cursor;
     std::vector<float> host(cursor, 0.f);
-    for (int i = 0; i < 3; ++i) build_axis_tables(p.ax[i], host);
+    build_axis_tables(p.ax[0], host, false, false);
+    build_axis_tables(p.ax[1], host, false, false);
+    build_axis_tables(p.ax[2], host, false, false);
     // table creation is the one place that allocates: do it outside graph capture (warm-up)
     HNO_CHECK_HIP(hipMalloc((void **)&p.tables, sizeof(float) * cursor));
     HNO_CHECK_HIP(hipMemcpy(p.tables, host.data(), sizeof(float) * cursor, hipMemcpyHostToDevice));
@@ -137,10 +143,10 @@ static int get_plan(int N0, int N1, int N2, int m0, int m1, int m2, const DhtPla
     p.MP1 = round_up(N1, 16);
     // forward plane LDS
     int need = a2.KcP > (a2.J + 1 + a2.KsP) ? a2.KcP : (a2.J + 1 + a2.KsP);
-    if (need < N2) need = N2;
+    if (need < N2 + 1) need = N2 + 1;   // column N2 is the zero the c = 0 fold reads
     p.lda2 = pad_2mod4(need);
     p.TP = a1.KcP > (a1.J + 1 + a1.KsP) ? a1.KcP : (a1.J + 1 + a1.KsP);
-    if (p.TP < N1) p.TP = N1;
+    if (p.TP < N1 + 1) p.TP = N1 + 1;
     p.ldt = 2 * a2.KP + 16;
     int c = 0;
     p.f_tabW = c;
@@ -155,6 +161,8 @@ static int get_plan(int N0, int N1, int N2, int m0, int m1, int m2, const DhtPla
     // inverse plane LDS
     p.ldE = pad_2mod4(a1.KmP);
     p.ldF = pad_2mod4(a2.KmP);
+    p.ldo = N2;
+    while ((p.ldo & 7) != 4) ++p.ldo;   // 4 * ldo == 16 (mod 32): C-layout stores spread over banks
     c = 0;
     p.i_tabH = c;
     c += 2 * a1.NT * a1.KmP * 16;
@@ -168,6 +176,8 @@ static int get_plan(int N0, int N1, int N2, int m0, int m1, int m2, const DhtPla
     c += p.MP1 * p.ldF;
     p.i_FI = c;
     c += p.MP1 * p.ldF;
+    p.i_O = c;
+    c += N1 * p.ldo;
     p.i_lds_floats = c;
     auto res = g_plans.emplace(key, p);
     *out = &res.first->second;
@@ -180,6 +190,7 @@ struct DhtArgs {
     int BC;
     float scale;
     int act;  // forward: activation whose derivative multiplies the input; inverse: epilogue act
+    int dbg;  // ablation switches (timing only)
 };
 
 // signed frequency -> index in the [low | high] block, or -1 if not kept
@@ -189,6 +200,8 @@ __device__ __forceinline__ int kept_pos(int k, int m) { return (k >= 0) ? (k < m
 // MAXE > 0: the whole plane (<= 256 * MAXE elements) is fetched into registers with fully
 // coalesced, independent loads, and the NEXT plane's fetch is issued before the current plane's
 // MFMA phases so HBM latency hides behind compute.  MAXE == 0: generic row-by-row path.
+// The folds x[n] +- x[N-n] (axis W) and T[n1] +- T[N1-n1] (axis H) are cheap in-place LDS passes
+// (a wave per row, no integer division), so the MFMA loops read plain pre-folded operands.
 template <int MAXE>
 __global__ __launch_bounds__(256) void dht_fwd_plane_kernel(const float *__restrict__ x, const float *__restrict__ xact,
                                                             float *__restrict__ Y, DhtArgs a) {
@@ -232,7 +245,7 @@ __global__ __launch_bounds__(256) void dht_fwd_plane_kernel(const float *__restr
     for (int plane = blockIdx.x; plane < planes; plane += gridDim.x) {
         __syncthreads();  // previous iteration finished reading xs / T
         if (MAXE > 0) {
-            // ---- registers -> LDS (raw rows), activation gradient applied here
+            // ---- registers -> LDS rows, activation gradient applied here
             int r = r0, c = c0;
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
@@ -246,70 +259,59 @@ __global__ __launch_bounds__(256) void dht_fwd_plane_kernel(const float *__restr
             }
             const int next = plane + gridDim.x;
             if (next < planes) fetch(next);  // in flight during this plane's compute
-            __syncthreads();
-            // ---- fold along W in place: xs[r][c] <- x[c] + x[N-c], xs[r][N-c] <- x[c] - x[N-c]
-            for (int i = tid; i < N1 * a2.Js; i += 256) {
-                const int rr = i / a2.Js, cc = 1 + (i - rr * a2.Js);
-                float *row = xs + rr * p.lda2;
-                const float va = row[cc], vb = row[N2 - cc];
-                row[cc] = va + vb;
-                row[N2 - cc] = va - vb;
-            }
         } else {
             const float *xp = x + (size_t)plane * plane_elems;
             const float *up = xact ? xact + (size_t)plane * plane_elems : nullptr;
-            // ---- load + fold along W: xs[r][c] = x[c] + x[N-c] (c <= Js), xs[r][N-c] = x[c] - x[N-c]
-            for (int r = wave; r < N1; r += 4) {
-                const float *row = xp + (size_t)r * N2;
-                const float *urow = up ? up + (size_t)r * N2 : nullptr;
-                float *dst = xs + r * p.lda2;
-                for (int c = lane; c <= a2.J; c += 64) {
-                    float va = row[c];
-                    if (urow) va *= act_grad_from_out(urow[c], a.act);
-                    if (c >= 1 && c <= a2.Js) {
-                        float vb = row[N2 - c];
-                        if (urow) vb *= act_grad_from_out(urow[N2 - c], a.act);
-                        dst[c] = va + vb;
-                        dst[N2 - c] = va - vb;
-                    } else {
-                        dst[c] = va;
-                    }
+            for (int r = wave; r < N1; r += 4)
+                for (int c = lane; c < N2; c += 64) {
+                    float v = xp[(size_t)r * N2 + c];
+                    if (up) v *= act_grad_from_out(up[(size_t)r * N2 + c], a.act);
+                    xs[r * p.lda2 + c] = v;
+                }
+        }
+        __syncthreads();
+        // ---- fold along W in place (division-free: a wave per row, lanes over columns)
+        for (int r = wave; r < N1; r += 4) {
+            float *row = xs + r * p.lda2;
+            for (int c = 1 + lane; c <= a2.Js; c += 64) {
+                const float va = row[c], vb = row[N2 - c];
+                row[c] = va + vb;
+                row[N2 - c] = va - vb;
+            }
+        }
+        __syncthreads();
+        // ---- axis W: T[n1][k2]: cos part -> columns [0,KP2), sin part -> [KP2, 2KP2)
+        const int ntaskW = (a.dbg & 1) ? 0 : MT1 * a2.KT;
+        for (int t = wave; t < ntaskW; t += 4) {
+            const int kt = t % a2.KT, mt = t / a2.KT;
+            f32x4 accC = {0.f, 0.f, 0.f, 0.f}, accS = accC;
+            const float *rows = xs + mt * 16 * p.lda2;
+            tile_mma2(rows, cosW + kt * a2.KcP * 16, a2.KcP / 4, accC, rows + a2.J + 1, sinW + kt * a2.KsP * 16, a2.KsP / 4,
+                      accS, p.lda2, 1, 16, 1, lane);
+            const int col = kt * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = mt * 16 + (lane >> 4) * 4 + r;
+                if (row < N1) {
+                    T[row * p.ldt + col] = accC[r];
+                    T[row * p.ldt + a2.KP + col] = accS[r];
                 }
             }
         }
         __syncthreads();
-        // ---- axis W: T[n1][k2] = sum_c xs[n1][c] * tab ; cos -> columns [0,KP2), sin -> [KP2, 2KP2)
-        const int ntaskW = MT1 * a2.KT * 2;
-        for (int t = wave; t < ntaskW; t += 4) {
-            const int which = t & 1, kt = (t >> 1) % a2.KT, mt = (t >> 1) / a2.KT;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (which == 0)
-                acc = tile_mma(xs + mt * 16 * p.lda2, p.lda2, 1, cosW + kt * a2.KcP * 16, 16, 1, a2.KcP / 4, acc, lane);
-            else
-                acc = tile_mma(xs + mt * 16 * p.lda2 + a2.J + 1, p.lda2, 1, sinW + kt * a2.KsP * 16, 16, 1,
-                               a2.KsP / 4, acc, lane);
-            const int col = which * a2.KP + kt * 16 + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = mt * 16 + (lane >> 4) * 4 + r;
-                if (row < N1) T[row * p.ldt + col] = acc[r];
-            }
-        }
-        __syncthreads();
-        // ---- fold T along n1 in place
-        {
-            const int ncol = 2 * a2.KP;
-            for (int i = tid; i < a1.Js * ncol; i += 256) {
-                const int c = 1 + i / ncol, col = i % ncol;
-                const float va = T[c * p.ldt + col], vb = T[(N1 - c) * p.ldt + col];
-                T[c * p.ldt + col] = va + vb;
-                T[(N1 - c) * p.ldt + col] = va - vb;
+        // ---- fold T along n1 in place (a wave per row pair, lanes over the 2*KP2 columns)
+        for (int c = 1 + wave; c <= a1.Js; c += 4) {
+            float *ra_ = T + c * p.ldt, *rb_ = T + (N1 - c) * p.ldt;
+            for (int col = lane; col < 2 * a2.KP; col += 64) {
+                const float va = ra_[col], vb = rb_[col];
+                ra_[col] = va + vb;
+                rb_[col] = va - vb;
             }
         }
         __syncthreads();
         // ---- axis H: rows = T columns (Ac | As), reduce over n1, outputs k1 in 0..m1 (+/-)
         float *Yp = Y + (size_t)plane * (2 * p.CP);
-        const int ntaskH = a2.KT * a1.KT * 2;
+        const int ntaskH = (a.dbg & 2) ? 0 : a2.KT * a1.KT * 2;
         for (int t = wave; t < ntaskH; t += 4) {
             const int part = t & 1, kt1 = (t >> 1) % a1.KT, kt2 = (t >> 1) / a1.KT;
             const float *Tc = T + kt2 * 16;             // Ac columns of this k2 tile
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(256) void dht_fwd_plane_kernel(const float *__restr
             else              // BI(+k1) = -(Q_Ac + P_As), BI(-k1) = Q_Ac - P_As
                 tile_mma2(Ts, bc, a1.KcP / 4, accP, Tc + (a1.J + 1) * p.ldt, bs, a1.KsP / 4, accQ, 1, p.ldt, 16, 1, lane);
             const int k1 = kt1 * 16 + (lane & 15);
-            if (k1 <= a1.m) {
+            if (k1 <= a1.m && !((a.dbg & 4) && accP[0] != 12345.f)) {
                 f32x4 vp, vm;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -534,6 +536,11 @@ __global__ __launch_bounds__(64) void dht_inv_d_kernel(const float *__restrict__
 }
 
 // ---- inverse, axes H and W, one (bc, n0) plane per workgroup iteration -------------------
+// The intermediate plane is copied raw into LDS (prefetched one plane ahead); the +-k1 fold is
+// done while the axis-H operands are read.  The axis-W result goes to an LDS image of the output
+// plane, and a final flat pass applies scale / residual / activation with fully coalesced
+// loads and stores.
+template <int MAXE>
 __global__ __launch_bounds__(256) void dht_inv_plane_kernel(const float *__restrict__ E, const float *__restrict__ addend,
                                                             float *__restrict__ out, DhtArgs a) {
     extern __shared__ float lds[];
@@ -542,12 +549,11 @@ __global__ __launch_bounds__(256) void dht_inv_plane_kernel(const float *__restr
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N1 = a1.N, N2 = a2.N;
     float *tabH = lds + p.i_tabH, *tabW = lds + p.i_tabW;
-    float *Es = lds + p.i_Es, *Ed = lds + p.i_Ed, *FR = lds + p.i_FR, *FI = lds + p.i_FI;
+    float *Es = lds + p.i_Es, *Ed = lds + p.i_Ed, *FR = lds + p.i_FR, *FI = lds + p.i_FI, *O = lds + p.i_O;
     const float *cosH = tabH, *sinH = tabH + a1.NT * a1.KmP * 16;
     const float *cosW = tabW, *sinW = tabW + a2.NT * a2.KmP * 16;
     for (int i = tid; i < 2 * a1.NT * a1.KmP * 16; i += 256) tabH[i] = p.tables[a1.cosI + i];
     for (int i = tid; i < 2 * a2.NT * a2.KmP * 16; i += 256) tabW[i] = p.tables[a2.cosI + i];
-    // F rows >= N1 are only ever multiplied into output rows that are not stored, but keep them finite
     for (int i = tid; i < (p.MP1 - N1) * p.ldF; i += 256) {
         FR[N1 * p.ldF + i] = 0.f;
         FI[N1 * p.ldF + i] = 0.f;
@@ -556,38 +562,73 @@ __global__ __launch_bounds__(256) void dht_inv_plane_kernel(const float *__restr
     const size_t plane_elems = (size_t)N1 * N2;
     const int MT1 = p.MP1 / 16;
     const int m1 = a1.m;
+    const int ne = 2 * p.CP;                  // floats of one intermediate plane
+    const int rows = 2 * a2.KP;               // (part, k2)
+    const int nitem = rows * a1.KmP;          // folded operand entries Es/Ed[row][k1]
+    constexpr int NI = 4;                     // entries per thread held in registers (nitem <= 1024)
+    constexpr int NE = MAXE > 0 ? MAXE : 1;
+    float ea[NI], eb[NI], ra[NE];
+    const int r0 = tid / N2, c0 = tid - r0 * N2, dr = 256 / N2, dc = 256 - dr * N2;
+    // item i -> (k1 = i / rows, row = i % rows); rows is a multiple of 32
+    auto fetch_e = [&](int plane) {
+        const float *Ep = E + (size_t)plane * ne;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int i = tid + 256 * j;
+            const int k1 = i / rows, row = i - k1 * rows;
+            const int part = row / a2.KP, k2 = row - part * a2.KP;
+            const bool ok = i < nitem && k1 <= m1;
+            const int kc = ok ? k1 : 0;
+            ea[j] = ok ? Ep[(size_t)(part * p.K1S + (m1 + kc)) * a2.KP + k2] : 0.f;
+            eb[j] = (ok && k1 >= 1) ? Ep[(size_t)(part * p.K1S + (m1 - kc)) * a2.KP + k2] : 0.f;
+        }
+    };
+    if (blockIdx.x < planes) fetch_e(blockIdx.x);
     for (int plane = blockIdx.x; plane < planes; plane += gridDim.x) {
-        const float *Ep = E + (size_t)plane * (2 * p.CP);
         __syncthreads();
-        // ---- load + fold over +-k1:  Es[row][k1] = E[+k1] + E[-k1], Ed = E[+k1] - E[-k1]
-        {
-            const int rows = 2 * a2.KP;  // (part, k2)
-            for (int i = tid; i < rows * a1.KmP; i += 256) {
-                const int k1 = i / rows, row = i % rows;  // row fastest: coalesced global reads
-                const int part = row / a2.KP, k2 = row % a2.KP;
-                float s = 0.f, d = 0.f;
-                if (k1 <= m1) {
-                    const float va = Ep[(size_t)(part * p.K1S + (m1 + k1)) * a2.KP + k2];
-                    if (k1 >= 1) {
-                        const float vb = Ep[(size_t)(part * p.K1S + (m1 - k1)) * a2.KP + k2];
-                        s = va + vb;
-                        d = va - vb;
-                    } else {
-                        s = va;
-                    }
-                }
-                Es[row * p.ldE + k1] = s;
-                Ed[row * p.ldE + k1] = d;
+        // ---- Es[row][k1] = E[+k1] + E[-k1], Ed = E[+k1] - E[-k1] (k1 = 0: E[0], 0) from the prefetched pairs
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int i = tid + 256 * j;
+            if (i < nitem) {
+                const int k1 = i / rows, row = i - k1 * rows;
+                Es[row * p.ldE + k1] = ea[j] + eb[j];
+                Ed[row * p.ldE + k1] = (k1 >= 1 && k1 <= m1) ? ea[j] - eb[j] : 0.f;
+            }
+        }
+        for (int i = tid + 256 * NI; i < nitem; i += 256) {  // only for very large mode counts
+            const float *Ep = E + (size_t)plane * ne;
+            const int k1 = i / rows, row = i - k1 * rows;
+            const int part = row / a2.KP, k2 = row - part * a2.KP;
+            float sv = 0.f, dv = 0.f;
+            if (k1 <= m1) {
+                const float va = Ep[(size_t)(part * p.K1S + (m1 + k1)) * a2.KP + k2];
+                const float vb = k1 >= 1 ? Ep[(size_t)(part * p.K1S + (m1 - k1)) * a2.KP + k2] : 0.f;
+                sv = va + vb;
+                dv = k1 >= 1 ? va - vb : 0.f;
+            }
+            Es[row * p.ldE + k1] = sv;
+            Ed[row * p.ldE + k1] = dv;
+        }
+        if (plane + gridDim.x < planes) fetch_e(plane + gridDim.x);
+        // residual of THIS plane: issued now, consumed in the epilogue after both MFMA stages
+        const float *ad = addend ? addend + (size_t)plane * plane_elems : nullptr;
+        if (MAXE > 0 && ad) {
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const unsigned e = tid + 256u * j;
+                ra[j] = e < plane_elems ? ad[e] : 0.f;
             }
         }
         __syncthreads();
         // ---- axis H: F[n1][k2] = sum_k1 E[k1][k2] e^{+i th k1 n1}
-        const int ntaskH = a1.NT * a2.KT * 2;
+        const int ntaskH = (a.dbg & 1) ? 0 : a1.NT * a2.KT * 2;
         for (int t = wave; t < ntaskH; t += 4) {
             const int part = t & 1, kt2 = (t >> 1) % a2.KT, nt1 = (t >> 1) / a2.KT;
             const int rR = kt2 * 16, rI = a2.KP + kt2 * 16;
             const float *bc = cosH + nt1 * a1.KmP * 16, *bs = sinH + nt1 * a1.KmP * 16;
             f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = acc1;
+            // FR = cos * Es_R - sin * Ed_I ; FI = cos * Es_I + sin * Ed_R
             tile_mma2(Es + (part ? rI : rR) * p.ldE, bc, a1.KmP / 4, acc1, Ed + (part ? rR : rI) * p.ldE, bs, a1.KmP / 4, acc2,
                       p.ldE, 1, 16, 1, lane);
             float *F = part ? FI : FR;
@@ -597,7 +638,6 @@ __global__ __launch_bounds__(256) void dht_inv_plane_kernel(const float *__restr
                 for (int r = 0; r < 4; ++r) {
                     const int k2 = kt2 * 16 + (lane >> 4) * 4 + r;
                     if (k2 < a2.KmP) {
-                        // FR = UsR - VdI (mirror +), FI = UsI + VdR (mirror -)
                         const float v = part ? acc1[r] + acc2[r] : acc1[r] - acc2[r];
                         const float w = part ? acc1[r] - acc2[r] : acc1[r] + acc2[r];
                         F[n1 * p.ldF + k2] = v;
@@ -607,35 +647,55 @@ __global__ __launch_bounds__(256) void dht_inv_plane_kernel(const float *__restr
             }
         }
         __syncthreads();
-        // ---- axis W: out[n1][n2] = sum_k2 FR cos - FI sin ; mirror n2 -> N2 - n2 gets +
-        float *op = out + (size_t)plane * plane_elems;
-        const float *ad = addend ? addend + (size_t)plane * plane_elems : nullptr;
+        // ---- axis W: O[n1][n2] = sum_k2 FR cos - FI sin ; mirror n2 -> N2 - n2 gets +
         const int ntaskW = MT1 * a2.NT;
         for (int t = wave; t < ntaskW; t += 4) {
             const int nt2 = t % a2.NT, mt = t / a2.NT;
             f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = acc1;
+            if (!(a.dbg & 2))
+                tile_mma2(FR + mt * 16 * p.ldF, cosW + nt2 * a2.KmP * 16, a2.KmP / 4, acc1, FI + mt * 16 * p.ldF,
+                          sinW + nt2 * a2.KmP * 16, a2.KmP / 4, acc2, p.ldF, 1, 16, 1, lane);
             const int n2 = nt2 * 16 + (lane & 15);
-            const bool colok = n2 <= a2.J, mirror = n2 >= 1 && n2 <= a2.Js;
-            // residual values first: their latency hides behind the MFMA chain
-            float adv[4], adm[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n1 = mt * 16 + (lane >> 4) * 4 + r;
-                const bool ok = ad && colok && n1 < N1;
-                adv[r] = ok ? ad[(size_t)n1 * N2 + n2] : 0.f;
-                adm[r] = (ok && mirror) ? ad[(size_t)n1 * N2 + (N2 - n2)] : 0.f;
-            }
-            tile_mma2(FR + mt * 16 * p.ldF, cosW + nt2 * a2.KmP * 16, a2.KmP / 4, acc1, FI + mt * 16 * p.ldF,
-                      sinW + nt2 * a2.KmP * 16, a2.KmP / 4, acc2, p.ldF, 1, 16, 1, lane);
-            if (colok) {
+            if (n2 <= a2.J) {
+                const bool mirror = n2 >= 1 && n2 <= a2.Js;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int n1 = mt * 16 + (lane >> 4) * 4 + r;
                     if (n1 < N1) {
-                        op[(size_t)n1 * N2 + n2] = act_apply(a.scale * (acc1[r] - acc2[r]) + adv[r], a.act);
-                        if (mirror) op[(size_t)n1 * N2 + (N2 - n2)] = act_apply(a.scale * (acc1[r] + acc2[r]) + adm[r], a.act);
+                        O[n1 * p.ldo + n2] = acc1[r] - acc2[r];
+                        if (mirror) O[n1 * p.ldo + (N2 - n2)] = acc1[r] + acc2[r];
                     }
                 }
+            }
+        }
+        __syncthreads();
+        // ---- epilogue: out = act(scale * O + residual), flat and fully coalesced
+        float *op = out + (size_t)plane * plane_elems;
+        if (!(a.dbg & 4)) {
+            if (MAXE > 0) {
+                int r = r0, c = c0;
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    const unsigned e = tid + 256u * j;
+                    if (e < plane_elems) {
+                        float v = a.scale * O[r * p.ldo + c];
+                        if (ad) v += ra[j];
+                        op[e] = act_apply(v, a.act);
+                    }
+                    r += dr;
+                    c += dc;
+                    if (c >= N2) {
+                        c -= N2;
+                        ++r;
+                    }
+                }
+            } else {
+                for (int r = wave; r < N1; r += 4)
+                    for (int c = lane; c < N2; c += 64) {
+                        float v = a.scale * O[r * p.ldo + c];
+                        if (ad) v += ad[(size_t)r * N2 + c];
+                        op[(size_t)r * N2 + c] = act_apply(v, a.act);
+                    }
             }
         }
     }
@@ -675,6 +735,7 @@ extern "C" int hno_dht3_crop(const float *x, const float *x_act_out, int act_gra
     a.BC = BC;
     a.scale = scale;
     a.act = x_act_out ? act_grad : HNO_ACT_NONE;
+    a.dbg = debug_flags();
     const size_t lds = sizeof(float) * plan->f_lds_floats;
     if (lds > kMaxLds) return fail(HNO_ELIMIT, "hno_dht3_crop: plane %dx%d needs %zu B of LDS (> 160 KiB)", N1, N2, lds);
     hipStream_t s = (hipStream_t)stream;
@@ -693,7 +754,7 @@ extern "C" int hno_dht3_crop(const float *x, const float *x_act_out, int act_gra
     const int grid = planes < 256 * per_cu ? planes : 256 * per_cu;
     const int pe = N1 * N2;
     {
-        ProfScope _ps(KID_DHT_FWD_PLANE, s);
+        ProfScope _ps(KID_DHT_FWD_PLANE, s, 4.0 * BC * (double)N0 * N1 * N2 * (x_act_out ? 2 : 1));
         if (pe <= 256 * 20)
             hipLaunchKernelGGL(dht_fwd_plane_kernel<20>, dim3(grid), dim3(256), lds, s, x, x_act_out, (float *)workspace, a);
         else if (pe <= 256 * 64)
@@ -704,7 +765,7 @@ extern "C" int hno_dht3_crop(const float *x, const float *x_act_out, int act_gra
     HNO_CHECK_LAUNCH();
     const Axis &a0 = plan->ax[0];
     const size_t ldsd = sizeof(float) * a0.KT * (a0.KcP + a0.KsP) * 16;
-    { ProfScope _ps(KID_DHT_FWD_D, s); hipLaunchKernelGGL(dht_fwd_d_kernel, dim3(plan->K1S * plan->ax[2].KT, BC), dim3(64), ldsd, s,
+    { ProfScope _ps(KID_DHT_FWD_D, s, 4.0 * BC * 8.0 * m0 * m1 * m2); hipLaunchKernelGGL(dht_fwd_d_kernel, dim3(plan->K1S * plan->ax[2].KT, BC), dim3(64), ldsd, s,
                        (const float *)workspace, out, a); }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
@@ -723,22 +784,38 @@ extern "C" int hno_pad_idht3(const float *z, const float *addend, int act, float
     a.BC = BC;
     a.scale = scale;
     a.act = act;
+    a.dbg = debug_flags();
     const size_t lds = sizeof(float) * plan->i_lds_floats;
     if (lds > kMaxLds) return fail(HNO_ELIMIT, "hno_pad_idht3: plane %dx%d needs %zu B of LDS (> 160 KiB)", N1, N2, lds);
     hipStream_t s = (hipStream_t)stream;
+    if (a.dbg & 8) a.act = HNO_ACT_NONE;
     static bool attr_done = false;
     if (!attr_done) {
-        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         attr_done = true;
     }
     const Axis &a0 = plan->ax[0];
     const size_t ldsd = sizeof(float) * 2 * a0.NT * a0.KmP * 16;
-    { ProfScope _ps(KID_DHT_INV_D, s); hipLaunchKernelGGL(dht_inv_d_kernel, dim3(plan->K1S * plan->ax[2].KT, BC), dim3(64), ldsd, s, z,
+    { ProfScope _ps(KID_DHT_INV_D, s, 4.0 * BC * 8.0 * m0 * m1 * m2); hipLaunchKernelGGL(dht_inv_d_kernel, dim3(plan->K1S * plan->ax[2].KT, BC), dim3(64), ldsd, s, z,
                        (float *)workspace, a); }
     HNO_CHECK_LAUNCH();
     const int planes = BC * N0;
-    const int grid = planes < 1024 ? planes : 1024;
-    { ProfScope _ps(KID_DHT_INV_PLANE, s); hipLaunchKernelGGL(dht_inv_plane_kernel, dim3(grid), dim3(256), lds, s, (const float *)workspace, addend, out, a); }
+    int per_cu = (int)(kMaxLds / lds);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    const int grid = planes < 256 * per_cu ? planes : 256 * per_cu;
+    const int pe = N1 * N2;
+    {
+        ProfScope _ps(KID_DHT_INV_PLANE, s, 4.0 * BC * (double)N0 * N1 * N2 * (addend ? 2 : 1));
+        if (pe <= 256 * 20)
+            hipLaunchKernelGGL(dht_inv_plane_kernel<20>, dim3(grid), dim3(256), lds, s, (const float *)workspace, addend, out, a);
+        else if (pe <= 256 * 64)
+            hipLaunchKernelGGL(dht_inv_plane_kernel<64>, dim3(grid), dim3(256), lds, s, (const float *)workspace, addend, out, a);
+        else
+            hipLaunchKernelGGL(dht_inv_plane_kernel<0>, dim3(grid), dim3(256), lds, s, (const float *)workspace, addend, out, a);
+    }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }

@@ -316,8 +316,8 @@ extern "C" int hno_upsoftmax_fwd(const float *logits_lr, float *probs, int B, in
     if (rc) return rc;
     a.lr = logits_lr; a.out = probs;
     const int grid = grid1d((size_t)B * D * H * W);
-    if (K <= 4) { ProfScope _ps(KID_UPSOFTMAX_FWD, (hipStream_t)stream); hipLaunchKernelGGL(upsoftmax_fwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
-    else { ProfScope _ps(KID_UPSOFTMAX_FWD, (hipStream_t)stream); hipLaunchKernelGGL(upsoftmax_fwd_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
+    if (K <= 4) { ProfScope _ps(KID_UPSOFTMAX_FWD, (hipStream_t)stream, 4.0 * B * K * ((double)d * h * w + (double)D * H * W)); hipLaunchKernelGGL(upsoftmax_fwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
+    else { ProfScope _ps(KID_UPSOFTMAX_FWD, (hipStream_t)stream, 4.0 * B * K * ((double)d * h * w + (double)D * H * W)); hipLaunchKernelGGL(upsoftmax_fwd_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }
@@ -330,8 +330,8 @@ extern "C" int hno_upsoftmax_bwd(const float *g_probs, const float *probs, float
     if (rc) return rc;
     a.gp = g_probs; a.p = probs; a.out = g_lr;
     const int grid = grid1d((size_t)B * d * h * w);
-    if (K <= 4) { ProfScope _ps(KID_UPSOFTMAX_BWD, (hipStream_t)stream); hipLaunchKernelGGL(upsoftmax_bwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
-    else { ProfScope _ps(KID_UPSOFTMAX_BWD, (hipStream_t)stream); hipLaunchKernelGGL(upsoftmax_bwd_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
+    if (K <= 4) { ProfScope _ps(KID_UPSOFTMAX_BWD, (hipStream_t)stream, 4.0 * B * K * ((double)d * h * w + (softmax ? 2.0 : 1.0) * D * H * W)); hipLaunchKernelGGL(upsoftmax_bwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
+    else { ProfScope _ps(KID_UPSOFTMAX_BWD, (hipStream_t)stream, 4.0 * B * K * ((double)d * h * w + (softmax ? 2.0 : 1.0) * D * H * W)); hipLaunchKernelGGL(upsoftmax_bwd_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }
@@ -345,8 +345,8 @@ extern "C" int hno_loss_fwd(const float *probs, const uint8_t *labels, double *s
     HNO_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * B * K * 4, s));
     long long gx = (V + 256 * 8 - 1) / (256 * 8);
     if (gx > 1024) gx = 1024;
-    if (K <= 4) { ProfScope _ps(KID_LOSS_STATS, s); hipLaunchKernelGGL(loss_stats_kernel<4>, dim3((int)gx, B), dim3(256), 0, s, probs, labels, stats, K, V); }
-    else { ProfScope _ps(KID_LOSS_STATS, s); hipLaunchKernelGGL(loss_stats_kernel<8>, dim3((int)gx, B), dim3(256), 0, s, probs, labels, stats, K, V); }
+    if (K <= 4) { ProfScope _ps(KID_LOSS_STATS, s, (double)B * V * (4.0 * K + 1)); hipLaunchKernelGGL(loss_stats_kernel<4>, dim3((int)gx, B), dim3(256), 0, s, probs, labels, stats, K, V); }
+    else { ProfScope _ps(KID_LOSS_STATS, s, (double)B * V * (4.0 * K + 1)); hipLaunchKernelGGL(loss_stats_kernel<8>, dim3((int)gx, B), dim3(256), 0, s, probs, labels, stats, K, V); }
     HNO_CHECK_LAUNCH();
     { ProfScope _ps(KID_LOSS_FINALIZE, s); hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const double *)stats, coef, loss, B, K, V, kind, param); }
     HNO_CHECK_LAUNCH();
@@ -360,8 +360,8 @@ extern "C" int hno_loss_bwd(const float *probs, const uint8_t *labels, const flo
     long long gx = (V + 256 * 4 - 1) / (256 * 4);
     if (gx > 2048) gx = 2048;
     hipStream_t s = (hipStream_t)stream;
-    if (K <= 4) { ProfScope _ps(KID_LOSS_BWD, s); hipLaunchKernelGGL(loss_bwd_kernel<4>, dim3((int)gx, B), dim3(256), 0, s, probs, labels, coef, gscale, g_probs, K, V); }
-    else { ProfScope _ps(KID_LOSS_BWD, s); hipLaunchKernelGGL(loss_bwd_kernel<8>, dim3((int)gx, B), dim3(256), 0, s, probs, labels, coef, gscale, g_probs, K, V); }
+    if (K <= 4) { ProfScope _ps(KID_LOSS_BWD, s, (double)B * V * (8.0 * K + 1)); hipLaunchKernelGGL(loss_bwd_kernel<4>, dim3((int)gx, B), dim3(256), 0, s, probs, labels, coef, gscale, g_probs, K, V); }
+    else { ProfScope _ps(KID_LOSS_BWD, s, (double)B * V * (8.0 * K + 1)); hipLaunchKernelGGL(loss_bwd_kernel<8>, dim3((int)gx, B), dim3(256), 0, s, probs, labels, coef, gscale, g_probs, K, V); }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }

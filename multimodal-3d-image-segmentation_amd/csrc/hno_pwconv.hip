@@ -38,6 +38,7 @@ struct PwArgs {
     int finalize;          // add bias and apply the activation
     int o_begin;           // first output channel of this launch (32 per launch)
     int residual;          // use W + I (frequency-domain residual of the HNO-XS mix)
+    int dbg;
 };
 
 // x[channel i0 + h][v] of the virtual concat [xa ; xb] for one batch element.  i0 and nvalid
@@ -130,6 +131,7 @@ struct PwBwdArgs {
     unsigned V;
     int act;
     int residual;
+    int dbg;
 };
 
 #define PWB_LD 34  // 32 voxels + 2: row stride == 2 (mod 4) -> conflict-free 16x16x4 operand reads
@@ -315,36 +317,57 @@ __global__ __launch_bounds__(256, 4) void pwconv_fwd_fast_kernel(PwArgs a) {
     const unsigned tiles_per_b = (V + 31) / 32;
     const unsigned ntiles = tiles_per_b * a.B;
     const unsigned hoffV = h ? V : 0u, hoff4V = h ? 4u * V : 0u;
-    for (unsigned t = blockIdx.x * 4 + wave; t < ntiles; t += gridDim.x * 4) {
+    const unsigned stride = gridDim.x * 4;
+    // software pipeline: the loads of tile t + stride are in flight while tile t runs its MFMAs
+    float xv[NKI], xn[NKI];
+    auto fetch = [&](unsigned t, float (&dst)[NKI]) {
         const unsigned b = t / tiles_per_b;
         const unsigned v = (t - b * tiles_per_b) * 32 + c;
-        const bool vin = v < V;
-        const unsigned off = hoffV + (vin ? v : 0u);
+        const unsigned off = hoffV + (v < V ? v : 0u);
         const float *xa_b = a.xa + (size_t)b * a.Ca * V;
         const float *xb_b = a.xb ? a.xb + (size_t)b * a.Cb * V : a.xa;
-        float *y_b = a.y + (size_t)b * COUT * V;
-        float xv[NKI];
 #pragma unroll
         for (int ks = 0; ks < NKI; ++ks) {
             const int i0 = 2 * ks;
             const float *base = i0 < a.Ca ? xa_b + (size_t)i0 * V : xb_b + (size_t)(i0 - a.Ca) * V;
-            xv[ks] = base[off];
+            dst[ks] = base[off];
         }
+    };
+    unsigned t = blockIdx.x * 4 + wave;
+    if (t < ntiles) fetch(t, xv);
+    for (; t < ntiles; t += stride) {
+        const unsigned b = t / tiles_per_b;
+        const unsigned v = (t - b * tiles_per_b) * 32 + c;
+        const bool vin = v < V;
+        float *y_b = a.y + (size_t)b * COUT * V;
+        if (t + stride < ntiles) fetch(t + stride, xn);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (a.dbg & 1) {
 #pragma unroll
-        for (int ks = 0; ks < NKI; ++ks) acc = mfma32(w[ks], xv[ks], acc);
+            for (int ks = 0; ks < NKI; ++ks) acc[ks & 15] += xv[ks];
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            constexpr int dummy = 0;
-            const int orow = (r & 3) + 8 * (r >> 2);
-            if (orow < COUT) {   // compile-time after unrolling
-                const float val = act_apply(acc[r] + bias_r[r], a.act);
-                if (vin && (orow + 4 < COUT || h == 0)) (y_b + (size_t)orow * V)[hoff4V + v] = val;
-            }
-            (void)dummy;
+            for (int ks = 0; ks < NKI; ++ks) acc = mfma32(w[ks], xv[ks], acc);
         }
+        if (!(a.dbg & 2)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int orow = (r & 3) + 8 * (r >> 2);
+                if (orow < COUT) {   // compile-time after unrolling
+                    const float val = act_apply(acc[r] + bias_r[r], a.act);
+                    if (vin && (orow + 4 < COUT || h == 0)) (y_b + (size_t)orow * V)[hoff4V + v] = val;
+                }
+            }
+        } else {
+            float sacc = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc += acc[r];
+            if (sacc == 12345.678f) y_b[0] = sacc;
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKI; ++ks) xv[ks] = xn[ks];
     }
 }
 
@@ -386,46 +409,68 @@ __global__ __launch_bounds__(64 * PWB_FAST_WAVES) void pwconv_bwd_fast_kernel(Pw
     const unsigned hoffV = h ? V : 0u, hoff4V = h ? 4u * V : 0u;
     const float *ga = G + (lane & 15) * PWB_LD + (lane >> 4);
     const float *xbp = X + (lane & 15) * PWB_LD + (lane >> 4);
+    // software pipeline: raw loads of the NEXT tile (gy, y, x) are issued before this tile's
+    // LDS staging and MFMA work; activation gradient and masking happen when they are consumed
+    float pg[NKO], py[NKO], px[NKI];
+    auto fetch = [&](unsigned grp) {
+        const unsigned t = grp * NW + wave;
+        const bool live = t < ntiles;
+        const unsigned b = live ? t / tiles_per_b : 0u;
+        const unsigned v = live ? (t - b * tiles_per_b) * 32 + c : 0u;
+        const unsigned off = hoffV + ((live && v < V) ? v : 0u);
+        const float *gy_b = a.gy + (size_t)b * COUT * V, *y_b = a.y + (size_t)b * COUT * V;
+        const float *xa_b = a.xa + (size_t)b * a.Ca * V;
+        const float *xb_b = a.xb ? a.xb + (size_t)b * a.Cb * V : a.xa;
+#pragma unroll
+        for (int ks = 0; ks < NKO; ++ks) {
+            pg[ks] = (gy_b + (size_t)(2 * ks) * V)[off];
+            py[ks] = a.act != HNO_ACT_NONE ? (y_b + (size_t)(2 * ks) * V)[off] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NKI; ++j) {
+            const int i0 = 2 * j;
+            const float *base = i0 < a.Ca ? xa_b + (size_t)i0 * V : xb_b + (size_t)(i0 - a.Ca) * V;
+            px[j] = base[off];
+        }
+    };
+    if (blockIdx.x < ngroups) fetch(blockIdx.x);
     for (unsigned grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const unsigned t = grp * NW + wave;
         const bool live = t < ntiles;
         const unsigned b = live ? t / tiles_per_b : 0u;
         const unsigned v = live ? (t - b * tiles_per_b) * 32 + c : 0u;
         const bool vin = live && v < V;
-        const unsigned off = hoffV + (vin ? v : 0u);
-        const float *gy_b = a.gy + (size_t)b * COUT * V, *y_b = a.y + (size_t)b * COUT * V;
-        const float *xa_b = a.xa + (size_t)b * a.Ca * V;
-        const float *xb_b = a.xb ? a.xb + (size_t)b * a.Cb * V : a.xa;
         float g[NKO];
 #pragma unroll
         for (int ks = 0; ks < NKO; ++ks) {
-            float gv = (gy_b + (size_t)(2 * ks) * V)[off];
-            if (a.act != HNO_ACT_NONE) gv *= act_grad_from_out((y_b + (size_t)(2 * ks) * V)[off], a.act);
+            float gv = pg[ks];
+            if (a.act != HNO_ACT_NONE) gv *= act_grad_from_out(py[ks], a.act);
             g[ks] = vin ? gv : 0.f;
             G[(2 * ks + h) * PWB_LD + c] = g[ks];
             db[ks] += g[ks];
         }
 #pragma unroll
-        for (int j = 0; j < NKI; ++j) {
-            const int i0 = 2 * j;
-            const float *base = i0 < a.Ca ? xa_b + (size_t)i0 * V : xb_b + (size_t)(i0 - a.Ca) * V;
-            const float xv = base[off];
-            X[(i0 + h) * PWB_LD + c] = vin ? xv : 0.f;
-        }
+        for (int j = 0; j < NKI; ++j) X[(2 * j + h) * PWB_LD + c] = vin ? px[j] : 0.f;
+        if (grp + gridDim.x < ngroups) fetch(grp + gridDim.x);
 #pragma unroll
         for (int ic = 0; ic < ICH; ++ic) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            if (!(a.dbg & 1)) {
 #pragma unroll
-            for (int ks = 0; ks < NKO; ++ks) acc = mfma32(wt[ic][ks], g[ks], acc);
+                for (int ks = 0; ks < NKO; ++ks) acc = mfma32(wt[ic][ks], g[ks], acc);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < NKO; ++ks) acc[ks & 15] += g[ks];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int irow = ic * 32 + (r & 3) + 8 * (r >> 2);
                 if (irow < CIN) {  // compile-time; rows irow, irow+4 are on one side since Ca % 8 == 0
                     float *base = irow < a.Ca ? (a.gxa ? a.gxa + ((size_t)b * a.Ca + irow) * V : nullptr)
                                               : (a.gxb ? a.gxb + ((size_t)b * a.Cb + (irow - a.Ca)) * V : nullptr);
-                    if (base && vin && (irow + 4 < CIN || h == 0)) base[hoff4V + v] = acc[r];
+                    if (base && vin && (irow + 4 < CIN || h == 0) && !((a.dbg & 4) && acc[r] != 12345.678f)) base[hoff4V + v] = acc[r];
                 }
             }
         }
@@ -434,7 +479,7 @@ __global__ __launch_bounds__(64 * PWB_FAST_WAVES) void pwconv_bwd_fast_kernel(Pw
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll 2
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int ks = 0; ks < ((a.dbg & 2) ? 0 : 8); ++ks) {
             float av[MT], bv[NTI];
 #pragma unroll
             for (int m = 0; m < MT; ++m) av[m] = ga[m * 16 * PWB_LD + ks * 4];
@@ -488,13 +533,15 @@ int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const fl
     a.xa = xa; a.xb = xb; a.W = W; a.bias = bias; a.y = y;
     a.Ca = Ca; a.Cb = Cb; a.Cin = Ca + Cb; a.Cout = Cout; a.B = B; a.V = (unsigned)V; a.act = act;
     a.residual = residual;
+    a.dbg = debug_flags();
     const long long ntiles = ((V + 31) / 32) * B;
-    const int grid = grid_for(ntiles, 4);
+    int grid = grid_for(ntiles, 4);
+    if (a.dbg & 0xff00) grid = (a.dbg >> 8) & 0xffff;
     if (Ca % 8 == 0 && Cb % 8 == 0) {  // exact-size fast paths (the HNOSeg-XS shapes)
         a.o_begin = 0; a.k_begin = 0; a.k_count = a.Cin; a.accumulate = 0; a.finalize = 1;
         hipStream_t fs = (hipStream_t)stream;
         bool done = true;
-        ProfScope ps(KID_PWCONV_FWD, fs);
+        ProfScope ps(KID_PWCONV_FWD, fs, 4.0 * B * (double)V * (a.Cin + Cout));
         if (a.Cin == 24 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<12, 24>), dim3(grid), dim3(256), 0, fs, a);
         else if (a.Cin == 48 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 24>), dim3(grid), dim3(256), 0, fs, a);
         else if (a.Cin == 24 && Cout == 4) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<12, 4>), dim3(grid), dim3(256), 0, fs, a);
@@ -512,7 +559,7 @@ int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const fl
             a.k_count = a.Cin - k0 < KCH ? a.Cin - k0 : KCH;
             a.accumulate = k0 > 0;
             a.finalize = k0 + KCH >= a.Cin;
-            ProfScope ps(KID_PWCONV_FWD, (hipStream_t)stream);
+            ProfScope ps(KID_PWCONV_FWD, (hipStream_t)stream, 4.0 * B * (double)V * (a.k_count + (a.accumulate ? 2 : 1) * (Cout - o0 < 32 ? Cout - o0 : 32)));
             if (a.k_count <= 24)
                 hipLaunchKernelGGL(pwconv_fwd_kernel<12>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
             else if (a.k_count <= 48)
@@ -542,6 +589,7 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
     a.gxa = gxa; a.gxb = gxb; a.dW = dW; a.dbias = dbias; a.partials = (float *)workspace;
     a.Ca = Ca; a.Cb = Cb; a.Cin = Cin; a.Cout = Cout; a.B = B; a.V = (unsigned)V; a.act = act;
     a.residual = residual;
+    a.dbg = debug_flags();
     const long long ntiles = ((V + 31) / 32) * B;
     int grid = grid_for(ntiles, 4);
     if (grid > 1024) grid = 1024;  // fewer blocks -> fewer dW atomics
@@ -562,7 +610,7 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
             attr_done = true;
         }
         {
-            ProfScope ps(KID_PWCONV_BWD, s);
+            ProfScope ps(KID_PWCONV_BWD, s, 4.0 * B * (double)V * ((act != HNO_ACT_NONE ? 2 : 1) * Cout + Cin + (gxa ? Ca : 0) + (gxb ? Cb : 0)));
             if (Cin == 24 && Cout == 24) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<12, 12>), dim3((int)fg), dim3(64 * NW), sizeof(float) * NW * (32 + 32) * PWB_LD, s, a);
             else if (Cin == 48 && Cout == 24) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<12, 24>), dim3((int)fg), dim3(64 * NW), sizeof(float) * NW * (32 + 48) * PWB_LD, s, a);
             else if (Cin == 24 && Cout == 4) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<2, 12>), dim3((int)fg), dim3(64 * NW), sizeof(float) * NW * (16 + 32) * PWB_LD, s, a);
@@ -574,7 +622,7 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
         }
     }
     {
-    ProfScope ps(KID_PWCONV_BWD, s);
+    ProfScope ps(KID_PWCONV_BWD, s, 4.0 * B * (double)V * ((act != HNO_ACT_NONE ? 2 : 1) * Cout + Cin + (gxa ? Ca : 0) + (gxb ? Cb : 0)));
     if (Cout <= 8) {
         if (ich == 1) hipLaunchKernelGGL((pwconv_bwd_kernel<4, 1>), dim3(grid), dim3(256), lds, s, a);
         else hipLaunchKernelGGL((pwconv_bwd_kernel<4, 2>), dim3(grid), dim3(256), lds, s, a);

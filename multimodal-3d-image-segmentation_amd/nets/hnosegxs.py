@@ -124,9 +124,23 @@ class HNOXSBlock(nn.Module):
             self.conv_concat = ConvNormAct(cur + out_channels, out_channels, use_bias=True, activation=activation,
                                            ndim=ndim, device=device)
 
+    def _fused_ok(self):
+        return (len(self.conv_blocks) > 0 and all(b.fusable() for b in self.conv_blocks) and self.normalization is None
+                and self.conv_concat is not None and self.conv_concat.normalization is None
+                and (self.mapping_conv is None or self.mapping_conv.normalization is None))
+
     def forward(self, x, skip=None):
         """`skip` is the U-Net skip tensor the reference concatenates in HNOSegXS.forward (:161-162);
         passing it separately lets the mapping conv read both tensors without a torch.cat."""
+        if x.ndim == 5 and self._fused_ok():
+            # standard configuration: the whole block is one autograd node (ops.XSBlockFn)
+            act = ops.act_id(self.activation)
+            W = torch.stack([b.op.weight for b in self.conv_blocks])
+            mc = self.mapping_conv.op if self.mapping_conv is not None else None
+            assert mc is not None or skip is None
+            cc = self.conv_concat.op
+            return ops.XSBlockFn.apply(x, skip, mc.weight if mc is not None else None, mc.bias if mc is not None else None,
+                                       W, cc.weight, cc.bias, self.transform_crop.num_modes, act)
         if self.mapping_conv is not None:
             x = self.mapping_conv(x, skip)
         else:

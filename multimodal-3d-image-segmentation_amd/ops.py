@@ -81,6 +81,52 @@ def _wgrad_ws(cin, cout, device):
     return torch.empty(n, device=device, dtype=torch.float32)
 
 
+def pwconv_fwd_raw(xa, xb, W, bias, act):
+    B, Ca = xa.shape[:2]
+    Cb = xb.shape[1] if xb is not None else 0
+    Cout, V = W.shape[0], _flat_v(xa)
+    assert W.numel() == Cout * (Ca + Cb), 'weight shape does not match the concatenated input channels'
+    y = torch.empty((B, Cout) + tuple(xa.shape[2:]), device=xa.device, dtype=torch.float32)
+    check(_lib.lib().hno_pwconv_fwd(ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(bias), ptr(y), B, Cout, V, act, stream_ptr()),
+          'hno_pwconv_fwd')
+    return y
+
+
+def pwconv_bwd_raw(gy, y, xa, xb, W, act, has_bias, need_gxa=True, need_gxb=True):
+    """-> (gxa, gxb, dW, dbias); y is the saved output (None when act is NONE)."""
+    B, Ca = xa.shape[:2]
+    Cb = xb.shape[1] if xb is not None else 0
+    Cout, V = W.shape[0], _flat_v(xa)
+    gxa = torch.empty_like(xa) if need_gxa else None
+    gxb = torch.empty_like(xb) if (xb is not None and need_gxb) else None
+    dW = torch.empty_like(W)
+    db = torch.empty(Cout, device=W.device, dtype=torch.float32) if has_bias else None
+    ws = _wgrad_ws(Ca + Cb, Cout, xa.device)
+    check(_lib.lib().hno_pwconv_bwd(ptr(gy), ptr(y), ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(gxa), ptr(gxb), ptr(dW),
+                                    ptr(db), ptr(ws), B, Cout, V, act, stream_ptr()), 'hno_pwconv_bwd')
+    return gxa, gxb, dW, db
+
+
+def specmix_fwd_raw(z0, W, residual, act):
+    B, C = z0.shape[:2]
+    M, Lyr = _flat_v(z0), W.shape[0]
+    zs = torch.empty((Lyr,) + tuple(z0.shape), device=z0.device, dtype=torch.float32)
+    check(_lib.lib().hno_specmix_shared_fwd(ptr(z0), ptr(W), ptr(zs), B, C, M, Lyr, int(residual), act, stream_ptr()),
+          'hno_specmix_shared_fwd')
+    return zs
+
+
+def specmix_bwd_raw(g, z0, zs, W, residual, act):
+    B, C = z0.shape[:2]
+    M, Lyr = _flat_v(z0), W.shape[0]
+    gz0 = torch.empty_like(z0)
+    dW = torch.empty_like(W)
+    ws = _wgrad_ws(C, C, z0.device)
+    check(_lib.lib().hno_specmix_shared_bwd(ptr(g), ptr(z0), ptr(zs), ptr(W), ptr(gz0), ptr(dW), ptr(ws), B, C, M, Lyr,
+                                            int(residual), act, stream_ptr()), 'hno_specmix_shared_bwd')
+    return gz0, dW
+
+
 # ----------------------------------------------------------------------------- autograd
 class DhtCropFn(torch.autograd.Function):
     """TransformCrop (nets/hnosegxs.py:378-410).  backward = PadInverse * scale."""
@@ -123,11 +169,7 @@ class SpecMixFn(torch.autograd.Function):
     def forward(ctx, z0, W, residual, act):
         z0, W = _f32c(z0), _f32c(W)
         _need_gpu(z0, W)
-        B, C = z0.shape[:2]
-        M, Lyr = _flat_v(z0), W.shape[0]
-        zs = torch.empty((Lyr,) + tuple(z0.shape), device=z0.device, dtype=torch.float32)
-        check(_lib.lib().hno_specmix_shared_fwd(ptr(z0), ptr(W), ptr(zs), B, C, M, Lyr, int(residual), act, stream_ptr()),
-              'hno_specmix_shared_fwd')
+        zs = specmix_fwd_raw(z0, W, residual, act)
         ctx.save_for_backward(z0, W, zs)
         ctx.residual, ctx.act = int(residual), act
         return zs[-1]
@@ -135,14 +177,7 @@ class SpecMixFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         z0, W, zs = ctx.saved_tensors
-        g = _f32c(g)
-        B, C = z0.shape[:2]
-        M, Lyr = _flat_v(z0), W.shape[0]
-        gz0 = torch.empty_like(z0)
-        dW = torch.empty_like(W)
-        ws = _wgrad_ws(C, C, z0.device)
-        check(_lib.lib().hno_specmix_shared_bwd(ptr(g), ptr(z0), ptr(zs), ptr(W), ptr(gz0), ptr(dW), ptr(ws), B, C, M, Lyr,
-                                                ctx.residual, ctx.act, stream_ptr()), 'hno_specmix_shared_bwd')
+        gz0, dW = specmix_bwd_raw(_f32c(g), z0, zs, W, ctx.residual, ctx.act)
         return gz0, dW, None, None
 
 
@@ -154,13 +189,7 @@ class PwConvFn(torch.autograd.Function):
     def forward(ctx, xa, xb, W, bias, act):
         xa, xb, W, bias = _f32c(xa), _f32c(xb), _f32c(W), _f32c(bias)
         _need_gpu(xa, xb, W, bias)
-        B, Ca = xa.shape[:2]
-        Cb = xb.shape[1] if xb is not None else 0
-        Cout, V = W.shape[0], _flat_v(xa)
-        assert W.numel() == Cout * (Ca + Cb), 'weight shape does not match the concatenated input channels'
-        y = torch.empty((B, Cout) + tuple(xa.shape[2:]), device=xa.device, dtype=torch.float32)
-        check(_lib.lib().hno_pwconv_fwd(ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(bias), ptr(y), B, Cout, V, act, stream_ptr()),
-              'hno_pwconv_fwd')
+        y = pwconv_fwd_raw(xa, xb, W, bias, act)
         ctx.save_for_backward(xa, xb, W, y if act != ACT_NONE else None)
         ctx.act, ctx.has_bias = act, bias is not None
         return y
@@ -168,18 +197,53 @@ class PwConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         xa, xb, W, y = ctx.saved_tensors
-        gy = _f32c(gy)
-        B, Ca = xa.shape[:2]
-        Cb = xb.shape[1] if xb is not None else 0
-        Cout, V = W.shape[0], _flat_v(xa)
-        gxa = torch.empty_like(xa) if ctx.needs_input_grad[0] else None
-        gxb = torch.empty_like(xb) if (xb is not None and ctx.needs_input_grad[1]) else None
-        dW = torch.empty_like(W)
-        db = torch.empty(Cout, device=W.device, dtype=torch.float32) if ctx.has_bias else None
-        ws = _wgrad_ws(Ca + Cb, Cout, xa.device)
-        check(_lib.lib().hno_pwconv_bwd(ptr(gy), ptr(y), ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(gxa), ptr(gxb), ptr(dW),
-                                        ptr(db), ptr(ws), B, Cout, V, ctx.act, stream_ptr()), 'hno_pwconv_bwd')
+        gxa, gxb, dW, db = pwconv_bwd_raw(_f32c(gy), y, xa, xb, W, ctx.act, ctx.has_bias, ctx.needs_input_grad[0],
+                                          ctx.needs_input_grad[1])
         return gxa, gxb, dW, db, None
+
+
+class XSBlockFn(torch.autograd.Function):
+    """One whole HNO-XS block (nets/hnosegxs.py:253-279) as a single autograd node:
+
+        [mapping_conv(cat[x, skip])] -> TransformCrop -> n_XS x (z <- act((W + I) z)) -> PadInverse -> act
+                                     -> conv_concat(cat[., block input])
+
+    Owning the whole block lets the backward fuse the two gradients that meet at the block input
+    (through the transform and through the concat skip) into the inverse-transform store instead
+    of materialising both and adding them."""
+
+    @staticmethod
+    def forward(ctx, x, skip, map_w, map_b, mix_w, cat_w, cat_b, modes, act):
+        x, skip, map_w, map_b, mix_w, cat_w, cat_b = (_f32c(t) for t in (x, skip, map_w, map_b, mix_w, cat_w, cat_b))
+        _need_gpu(x, skip, mix_w, cat_w)
+        has_map = map_w is not None
+        xm = pwconv_fwd_raw(x, skip, map_w, map_b, act) if has_map else x
+        spatial = tuple(xm.shape[2:])
+        modes = clamp_modes(modes, spatial)
+        n3 = float(np.prod(spatial))
+        z0 = dht3_crop_raw(xm, modes, 1.0 / n3)
+        zs = specmix_fwd_raw(z0, mix_w, 1, act)
+        u = pad_idht3_raw(zs[-1], spatial, 1.0, None, act)
+        out = pwconv_fwd_raw(u, xm, cat_w, cat_b, act)
+        ctx.save_for_backward(x, skip, map_w, xm if has_map else None, z0, zs, mix_w, u, cat_w, out)
+        ctx.cfg = (has_map, modes, act, spatial, n3, map_b is not None, cat_b is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, skip, map_w, xm, z0, zs, mix_w, u, cat_w, out = ctx.saved_tensors
+        has_map, modes, act, spatial, n3, map_has_b, cat_has_b = ctx.cfg
+        if not has_map:
+            xm = x
+        g_u, g_skipin, d_cat_w, d_cat_b = pwconv_bwd_raw(_f32c(g_out), out, u, xm, cat_w, act, cat_has_b)
+        g_zl = dht3_crop_raw(g_u, modes, 1.0, u, act)                       # PadInverse^T with act'(u) fused
+        g_z0, d_mix = specmix_bwd_raw(g_zl, z0, zs, mix_w, 1, act)
+        g_xm = pad_idht3_raw(g_z0, spatial, 1.0 / n3, g_skipin, ACT_NONE)    # TransformCrop^T + skip gradient
+        if not has_map:
+            return g_xm, None, None, None, d_mix, d_cat_w, d_cat_b, None, None
+        g_x, g_skip, d_map_w, d_map_b = pwconv_bwd_raw(g_xm, xm, x, skip, map_w, act, map_has_b,
+                                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return g_x, g_skip, d_map_w, d_map_b, d_mix, d_cat_w, d_cat_b, None, None
 
 
 class ConvK2S2Fn(torch.autograd.Function):

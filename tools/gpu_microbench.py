@@ -1,0 +1,72 @@
+"""Ablation timings of single kernels on the GPU (tuning aid; results with debug flags are wrong)."""
+import sys, os, time, ctypes
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import multimodal_3d_image_segmentation_amd as pkg
+from multimodal_3d_image_segmentation_amd import ops
+L = pkg._lib.lib()
+dev = 'cuda'
+
+def timeit(fn, n=30, warm=5):
+    for _ in range(warm): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+B, C, N = 2, 24, 65
+xa = torch.randn(B, C, N, N, N, device=dev); xb = torch.randn_like(xa)
+W = torch.randn(C, 2 * C, device=dev) * 0.1; bias = torch.randn(C, device=dev) * 0.01
+which = sys.argv[1] if len(sys.argv) > 1 else 'all'
+if which in ('all', 'pwfwd'):
+    for dbg, name in ((0, 'full'), (1, 'no mfma'), (2, 'no stores'), (3, 'loads only')):
+        for grid in (0, 1024, 4096):
+            L.hno_set_debug(dbg | (grid << 8))
+            yy = torch.empty_like(xa)
+            PP, SS = pkg._lib.ptr, pkg._lib.stream_ptr
+            t = timeit(lambda: L.hno_pwconv_fwd(PP(xa), 24, PP(xb), 24, PP(W), PP(bias), PP(yy), B, 24, N ** 3, 1, SS()))
+            print(f'pwconv_fwd 48->24 [{name}] grid {grid or "default"}: {t:.1f} us  ({158.2e6 / t / 1e3:.0f} GB/s algorithmic)')
+    L.hno_set_debug(0)
+    # plain copy reference: torch copy of the same bytes
+    src = torch.randn(3 * 2 * 24 * N ** 3 // 2, device=dev); dst = torch.empty_like(src)
+    t = timeit(lambda: dst.copy_(src)); print(f'torch copy {src.numel() * 8 / 1e6:.0f} MB moved: {t:.1f} us ({src.numel() * 8 / t / 1e3:.0f} GB/s)')
+if which in ('all', 'pwbwd'):
+    y = ops.PwConvFn.apply(xa, xb, W, bias, ops.ACT_SELU)
+    gy = torch.randn_like(y)
+    gxa, gxb = torch.empty_like(xa), torch.empty_like(xb)
+    dW, db = torch.empty_like(W), torch.empty_like(bias)
+    ws = torch.empty(L.hno_pwconv_bwd_workspace_bytes(48, 24) // 4, device=dev)
+    P, S = pkg._lib.ptr, pkg._lib.stream_ptr
+    call = lambda: L.hno_pwconv_bwd(P(gy), P(y), P(xa), 24, P(xb), 24, P(W), P(gxa), P(gxb), P(dW), P(db), P(ws), B, 24, N ** 3, 1, S())
+    for dbg, name in ((0, 'full'), (1, 'no dgrad mfma'), (2, 'no wgrad mfma'), (3, 'no mfma'), (4, 'no gx stores'), (7, 'loads+lds only')):
+        L.hno_set_debug(dbg)
+        t = timeit(call)
+        print(f'pwconv_bwd 48->24 [{name}] (incl. slab reduce): {t:.1f} us ({316.4e6 / t / 1e3:.0f} GB/s algorithmic)')
+    L.hno_set_debug(0)
+if which in ('all', 'dhtab'):
+    x = torch.randn(B, C, N, N, N, device=dev); z = torch.randn(B, C, 20, 28, 28, device=dev)
+    BC, NN, mm = 48, (65, 65, 65), (10, 14, 14)
+    ws = torch.empty(L.hno_dht3_workspace_bytes(BC, *NN, *mm) // 4, device=dev)
+    out = torch.empty(B, C, 20, 28, 28, device=dev); yy = torch.empty_like(x)
+    P, S = pkg._lib.ptr, pkg._lib.stream_ptr
+    for dbg, name in ((0, 'full'), (1, 'no stage W'), (2, 'no stage H'), (3, 'no W,H'), (7, 'load+fold only')):
+        L.hno_set_debug(dbg)
+        with pkg._lib.KernelProfile() as kp:
+            for _ in range(20): L.hno_dht3_crop(P(x), None, 0, P(out), P(ws), BC, *NN, *mm, 1.0, S())
+        print(f'dht_fwd_plane [{name}]: {kp.summary()["dht_fwd_plane_kernel"][2] * 1e3:.1f} us')
+    for dbg, name in ((0, 'full'), (8, 'no SELU'), (1, 'no stage H'), (2, 'no stage W mma'), (4, 'no stores'), (6, 'no W mma, no stores'), (7, 'load only')):
+        L.hno_set_debug(dbg)
+        with pkg._lib.KernelProfile() as kp:
+            for _ in range(20): L.hno_pad_idht3(P(z), None, 1, P(yy), P(ws), BC, *NN, *mm, 1.0, S())
+        print(f'dht_inv_plane [{name}]: {kp.summary()["dht_inv_plane_kernel"][2] * 1e3:.1f} us')
+    L.hno_set_debug(0)
+if which in ('all', 'dht'):
+    x = torch.randn(B, C, N, N, N, device=dev)
+    z = torch.randn(B, C, 20, 28, 28, device=dev)
+    with pkg._lib.KernelProfile() as kp:
+        for _ in range(20):
+            ops.dht3_crop_raw(x, (10, 14, 14), 1.0); ops.dht3_crop_raw(x, (10, 14, 14), 1.0, x, 1)
+            ops.pad_idht3_raw(z, (N, N, N), 1.0, None, 1); ops.pad_idht3_raw(z, (N, N, N), 1.0, x, 0)
+    for k, (c, s, avg) in kp.summary().items(): print(f'{k}: {avg * 1e3:.1f} us avg over {c}')
