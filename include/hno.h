@@ -77,6 +77,8 @@ int hno_specmix_shared_bwd(const float *g, const float *z0, const float *zs, con
  * conv_out (nets/hnosegxs.py:178).
  * Backward: gy is dL/dy, y the saved OUTPUT (for act'); writes gxa / gxb (either may be
  * NULL to skip) and WRITES dW (Cout, Ca+Cb) and dbias (Cout).
+ * xa_act != HNO_ACT_NONE additionally multiplies gxa by act'(xa) where xa is itself the output of
+ * that activation (fuses the SELU backward of PadInverse into this kernel: HNOXSBlock :267-275).
  * Weight gradients are reduced through per-block slabs in `workspace`
  * (hno_pwconv_bwd_workspace_bytes) in a fixed order: no float atomics, reproducible bit for bit.
  */
@@ -85,7 +87,7 @@ int hno_pwconv_fwd(const float *xa, int Ca, const float *xb, int Cb, const float
                    float *y, int B, int Cout, long long V, int act, void *stream);
 int hno_pwconv_bwd(const float *gy, const float *y, const float *xa, int Ca, const float *xb, int Cb,
                    const float *W, float *gxa, float *gxb, float *dW, float *dbias, void *workspace,
-                   int B, int Cout, long long V, int act, void *stream);
+                   int B, int Cout, long long V, int act, int xa_act, void *stream);
 
 /* ------------------------------------------- strided 2x2x2 'resize' convolution (conv_in)
  * Conv3d(Cin -> Cout, kernel 2, stride 2, padding 1) + bias + act: (B,Cin,D,H,W) ->

@@ -143,10 +143,10 @@ static int get_plan(int N0, int N1, int N2, int m0, int m1, int m2, const DhtPla
     p.MP1 = round_up(N1, 16);
     // forward plane LDS
     int need = a2.KcP > (a2.J + 1 + a2.KsP) ? a2.KcP : (a2.J + 1 + a2.KsP);
-    if (need < N2 + 1) need = N2 + 1;   // column N2 is the zero the c = 0 fold reads
+    if (need < N2 + 4) need = N2 + 4;   // columns N2.. are zeros read by the folded operand fetch
     p.lda2 = pad_2mod4(need);
     p.TP = a1.KcP > (a1.J + 1 + a1.KsP) ? a1.KcP : (a1.J + 1 + a1.KsP);
-    if (p.TP < N1 + 1) p.TP = N1 + 1;
+    if (p.TP < N1 + 4) p.TP = N1 + 4;
     p.ldt = 2 * a2.KP + 16;
     int c = 0;
     p.f_tabW = c;
@@ -342,6 +342,145 @@ __global__ __launch_bounds__(256) void dht_fwd_plane_kernel(const float *__restr
                     float *dstm = Yp + (size_t)(part * p.K1S + (a1.m - k1)) * a2.KP + k2;
                     *reinterpret_cast<f32x4 *>(dstm) = vm;
                 }
+            }
+        }
+    }
+}
+
+// ---- forward plane kernel, specialised ------------------------------------------------------
+// Compile-time reduction lengths (KC/KS k-steps of 4 for the cos/sin parts of axis W = 2 and
+// axis H = 1), one k tile per axis (m + 1 <= 16).  Differences to the generic kernel:
+//   * the cos/sin tables live in VGPRs (34 registers for N = 65), not in LDS;
+//   * the folds x[c] +- x[N-c] happen while the MFMA operands are read, through two pointers
+//     (forward / mirrored) and compile-time LDS offsets: no fold passes, two barriers fewer;
+//   * every task issues all of its operand reads up front, then runs its two MFMA chains.
+template <int KC2, int KS2, int KC1, int KS1, bool HAS_ACT>
+__global__ __launch_bounds__(256, 3) void dht_fwd_plane_spec_kernel(const float *__restrict__ x, const float *__restrict__ xact,
+                                                                 float *__restrict__ Y, DhtArgs a) {
+    extern __shared__ float lds[];
+    constexpr int NE = 20;
+    const DhtPlan &p = a.p;
+    const Axis &a1 = p.ax[1], &a2 = p.ax[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, l15 = lane & 15;
+    const int N1 = a1.N, N2 = a2.N;
+    const int lda = p.lda2, ldt = p.ldt;
+    float *xs = lds + 16;                       // 16 zero floats in front: sin-part reads at j = -1..-3
+    float *T = xs + p.MP1 * lda;
+    // B operands (tables) in registers: lane holds B[k = ks*4 + q][col = l15]
+    float bwc[KC2], bws[KS2], bhc[KC1], bhs[KS1];
+#pragma unroll
+    for (int ks = 0; ks < KC2; ++ks) bwc[ks] = p.tables[a2.cosF + (ks * 4 + q) * 16 + l15];
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks) bws[ks] = p.tables[a2.sinF + (ks * 4 + q) * 16 + l15];
+#pragma unroll
+    for (int ks = 0; ks < KC1; ++ks) bhc[ks] = p.tables[a1.cosF + (ks * 4 + q) * 16 + l15];
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) bhs[ks] = p.tables[a1.sinF + (ks * 4 + q) * 16 + l15];
+    // zero: guard, xs padding (rows >= N1, columns >= N2), T rows >= N1
+    if (tid < 16) lds[tid] = 0.f;
+    for (int i = tid; i < (p.MP1 - N1) * lda; i += 256) xs[N1 * lda + i] = 0.f;
+    const int padc = lda - N2;
+    for (int i = tid; i < N1 * padc; i += 256) xs[(i / padc) * lda + N2 + (i % padc)] = 0.f;
+    for (int i = tid; i < (p.TP - N1) * ldt; i += 256) T[N1 * ldt + i] = 0.f;
+
+    const int planes = a.BC * p.ax[0].N;
+    const size_t plane_elems = (size_t)N1 * N2;
+    const int MT1 = p.MP1 / 16;
+    float rx[NE], ru[HAS_ACT ? NE : 1];
+    const int r0 = tid / N2, c0 = tid - r0 * N2, dr = 256 / N2, dc = 256 - dr * N2;
+    auto fetch = [&](int plane) {
+        const float *xp = x + (size_t)plane * plane_elems;
+        const float *up = xact ? xact + (size_t)plane * plane_elems : nullptr;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const unsigned e = tid + 256u * j;
+            const bool in = e < plane_elems;
+            rx[j] = in ? xp[e] : 0.f;
+            if (HAS_ACT) ru[j] = in ? up[e] : 0.f;
+        }
+    };
+    if (blockIdx.x < planes) fetch(blockIdx.x);
+    for (int plane = blockIdx.x; plane < planes; plane += gridDim.x) {
+        __syncthreads();  // previous iteration finished reading xs / T
+        {
+            int r = r0, c = c0;
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                if (tid + 256u * j < plane_elems) xs[r * lda + c] = HAS_ACT ? rx[j] * act_grad_from_out(ru[HAS_ACT ? j : 0], a.act) : rx[j];
+                r += dr;
+                c += dc;
+                if (c >= N2) {
+                    c -= N2;
+                    ++r;
+                }
+            }
+        }
+        if (plane + gridDim.x < planes) fetch(plane + gridDim.x);  // in flight during this plane's compute
+        __syncthreads();
+        // ---- axis W.  cos: (x[c] + x[N-c]) c = 4ks+q ; sin: (x[j] - x[N-j]) j = Js - (4ks+q)
+        if (!(a.dbg & 1)) {
+            for (int mt = wave; mt < MT1; mt += 4) {
+                const float *row = xs + (mt * 16 + l15) * lda;
+                const float *pf = row + q, *pb = row + N2 - q;
+                const float *sf = row + a2.Js - q, *sb = row + N2 - a2.Js + q;
+                float ac[KC2], as_[KS2];
+#pragma unroll
+                for (int ks = 0; ks < KC2; ++ks) ac[ks] = pf[4 * ks] + pb[-4 * ks];
+#pragma unroll
+                for (int ks = 0; ks < KS2; ++ks) as_[ks] = sf[-4 * ks] - sb[4 * ks];
+                f32x4 accC = {0.f, 0.f, 0.f, 0.f}, accS = accC;
+#pragma unroll
+                for (int ks = 0; ks < (KC2 > KS2 ? KC2 : KS2); ++ks) {
+                    if (ks < KC2) accC = mfma16(ac[ks], bwc[ks], accC);
+                    if (ks < KS2) accS = mfma16(as_[ks], bws[ks], accS);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = mt * 16 + q * 4 + r;
+                    if (rr < N1) {
+                        T[rr * ldt + l15] = accC[r];
+                        T[rr * ldt + 16 + l15] = accS[r];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- axis H (fold along n1 while reading).  wave 0: BR = P_Ac -+ Q_As ; wave 1: BI from Q_Ac, P_As
+        float *Yp = Y + (size_t)plane * (2 * p.CP);
+        if (wave < 2 && !(a.dbg & 2)) {
+            const int part = wave;
+            const float *cs = T + (part == 0 ? 0 : 16) + l15;   // source columns of the cos sum
+            const float *ss = T + (part == 0 ? 16 : 0) + l15;   // source columns of the sin sum
+            const float *pf = cs + q * ldt, *pb = cs + (N1 - q) * ldt;
+            const float *sf = ss + (a1.Js - q) * ldt, *sb = ss + (N1 - a1.Js + q) * ldt;
+            float ac[KC1], as_[KS1];
+#pragma unroll
+            for (int ks = 0; ks < KC1; ++ks) ac[ks] = pf[4 * ks * ldt] + pb[-4 * ks * ldt];
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) as_[ks] = sf[-4 * ks * ldt] - sb[4 * ks * ldt];
+            f32x4 accP = {0.f, 0.f, 0.f, 0.f}, accQ = accP;
+#pragma unroll
+            for (int ks = 0; ks < (KC1 > KS1 ? KC1 : KS1); ++ks) {
+                if (ks < KC1) accP = mfma16(ac[ks], bhc[ks], accP);
+                if (ks < KS1) accQ = mfma16(as_[ks], bhs[ks], accQ);
+            }
+            const int k1 = l15;
+            if (k1 <= a1.m && !((a.dbg & 4) && accP[0] != 12345.f)) {
+                f32x4 vp, vm;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (part == 0) {
+                        vp[r] = accP[r] - accQ[r];
+                        vm[r] = accP[r] + accQ[r];
+                    } else {
+                        vp[r] = -(accQ[r] + accP[r]);
+                        vm[r] = accQ[r] - accP[r];
+                    }
+                }
+                const int k2 = q * 4;
+                *reinterpret_cast<f32x4 *>(Yp + (size_t)(part * p.K1S + (a1.m + k1)) * a2.KP + k2) = vp;
+                if (k1 >= 1) *reinterpret_cast<f32x4 *>(Yp + (size_t)(part * p.K1S + (a1.m - k1)) * a2.KP + k2) = vm;
             }
         }
     }
@@ -701,6 +840,202 @@ __global__ __launch_bounds__(256) void dht_inv_plane_kernel(const float *__restr
     }
 }
 
+// ---- inverse plane kernel, specialised -------------------------------------------------------
+// Compile-time k-step counts (KM1, KM2) and output tile counts (NT1, NT2), one k tile per axis.
+// Tables in VGPRs, +-k1 fold fused into the operand reads of axis H (raw intermediate plane in LDS),
+// all operand reads of a task issued before its MFMA chains, LDS-staged coalesced epilogue.
+template <int KM1, int KM2, int NT1, int NT2, bool HAS_ADD>
+__global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float *__restrict__ E,
+                                                                    const float *__restrict__ addend,
+                                                                    float *__restrict__ out, DhtArgs a) {
+    extern __shared__ float lds[];
+    constexpr int NE = 20, NI = 4;
+    const DhtPlan &p = a.p;
+    const Axis &a1 = p.ax[1], &a2 = p.ax[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, l15 = lane & 15;
+    const int N1 = a1.N, N2 = a2.N, m1 = a1.m;
+    const int ldF = p.ldF, ldo = p.ldo;
+    const int ne = 2 * p.CP;
+    float *Er = lds + 16;                      // 16 zero floats in front (fold reads at k1s = -1)
+    float *FR = Er + ne + 16, *FI = FR + p.MP1 * ldF, *O = FI + p.MP1 * ldF;
+    // tables in registers: B[k = ks*4 + q][n = 1 + nt*16 + l15].  Output position 0 (cos = 1, sin = 0) is
+    // peeled off and computed as a plain sum, so positions 1..J fill whole 16-wide tiles (J = 32:
+    // 2 tiles instead of 3).  Frequency 0 is its own mirror in the +-k1 fold of axis H: cos row halved.
+    float bhc[NT1][KM1], bhs[NT1][KM1], bwc[NT2][KM2], bws[NT2][KM2];
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KM1; ++ks) {
+            const int n = 1 + nt * 16 + l15, kk = ks * 4 + q;
+            const bool ok = n <= a1.J;
+            const int idx = ((n >> 4) * a1.KmP + kk) * 16 + (n & 15);
+            bhc[nt][ks] = ok ? p.tables[a1.cosI + idx] * (kk == 0 ? 0.5f : 1.f) : 0.f;
+            bhs[nt][ks] = ok ? p.tables[a1.sinI + idx] : 0.f;
+        }
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KM2; ++ks) {
+            const int n = 1 + nt * 16 + l15, kk = ks * 4 + q;
+            const bool ok = n <= a2.J;
+            const int idx = ((n >> 4) * a2.KmP + kk) * 16 + (n & 15);
+            bwc[nt][ks] = ok ? p.tables[a2.cosI + idx] : 0.f;
+            bws[nt][ks] = ok ? p.tables[a2.sinI + idx] : 0.f;
+        }
+    if (tid < 16) {
+        lds[tid] = 0.f;
+        Er[ne + tid] = 0.f;
+    }
+    for (int i = tid; i < (p.MP1 - N1) * ldF; i += 256) {
+        FR[N1 * ldF + i] = 0.f;
+        FI[N1 * ldF + i] = 0.f;
+    }
+    const int planes = a.BC * p.ax[0].N;
+    const size_t plane_elems = (size_t)N1 * N2;
+    const int MT1 = p.MP1 / 16;
+    float re[NI], ra[HAS_ADD ? NE : 1];
+    const int r0 = tid / N2, c0 = tid - r0 * N2, dr = 256 / N2, dc = 256 - dr * N2;
+    auto fetch_e = [&](int plane) {
+        const float *Ep = E + (size_t)plane * ne;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int e = tid + 256 * j;
+            re[j] = e < ne ? Ep[e] : 0.f;
+        }
+    };
+    if (blockIdx.x < planes) fetch_e(blockIdx.x);
+    for (int plane = blockIdx.x; plane < planes; plane += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int e = tid + 256 * j;
+            if (e < ne) Er[e] = re[j];
+        }
+        if (plane + gridDim.x < planes) fetch_e(plane + gridDim.x);
+        if (HAS_ADD) {  // residual of THIS plane: consumed in the epilogue, after both MFMA stages
+            const float *ad = addend + (size_t)plane * plane_elems;
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const unsigned e = tid + 256u * j;
+                ra[HAS_ADD ? j : 0] = e < plane_elems ? ad[e] : 0.f;
+            }
+        }
+        __syncthreads();
+        // ---- axis H: F[n1][k2] = sum_k1 E[k1][k2] e^{+i th k1 n1}; E[+k1] +- E[-k1] formed while reading
+        if (!(a.dbg & 1)) {
+            for (int t = wave; t < NT1 * 2; t += 4) {
+                const int part = t & 1, nt1 = t >> 1;
+                // FR = cos * Es_R - sin * Ed_I ; FI = cos * Es_I + sin * Ed_R
+                const float *es = Er + (part ? p.CP : 0) + l15, *ed = Er + (part ? 0 : p.CP) + l15;
+                const float *sf = es + (m1 + q) * 16, *sb = es + (m1 - q) * 16;
+                const float *df = ed + (m1 + q) * 16, *db = ed + (m1 - q) * 16;
+                float as_[KM1], ad_[KM1];
+#pragma unroll
+                for (int ks = 0; ks < KM1; ++ks) {
+                    as_[ks] = sf[64 * ks] + sb[-64 * ks];
+                    ad_[ks] = df[64 * ks] - db[-64 * ks];
+                }
+                f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = acc1;
+#pragma unroll
+                for (int n = 0; n < NT1; ++n)
+                    if (n == nt1) {
+#pragma unroll
+                        for (int ks = 0; ks < KM1; ++ks) {
+                            acc1 = mfma16(as_[ks], bhc[n][ks], acc1);
+                            acc2 = mfma16(ad_[ks], bhs[n][ks], acc2);
+                        }
+                    }
+                float *F = part ? FI : FR;
+                const int n1 = 1 + nt1 * 16 + l15;
+                if (n1 <= a1.J) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k2 = q * 4 + r;
+                        const float v = part ? acc1[r] + acc2[r] : acc1[r] - acc2[r];
+                        const float w = part ? acc1[r] - acc2[r] : acc1[r] + acc2[r];
+                        F[n1 * ldF + k2] = v;
+                        if (n1 <= a1.Js) F[(N1 - n1) * ldF + k2] = w;
+                    }
+                }
+            }
+            // output row n1 = 0: every e^{i th k1 0} = 1, so F[0][k2] is the plain sum over all 2*m1+1 k1
+            if (wave == 3 && lane < 32) {
+                const float *src = Er + (lane >> 4) * p.CP + l15;
+                float sum = 0.f;
+                for (int k1s = 0; k1s < p.K1S; ++k1s) sum += src[k1s * 16];
+                ((lane >> 4) ? FI : FR)[l15] = sum;
+            }
+        }
+        __syncthreads();
+        // ---- axis W: O[n1][n2] = sum_k2 FR cos - FI sin ; mirror n2 -> N2 - n2 gets +
+        for (int t = wave; t < MT1 * NT2; t += 4) {
+            const int nt2 = t % NT2, mt = t / NT2;
+            const float *fr = FR + (mt * 16 + l15) * ldF + q, *fi = FI + (mt * 16 + l15) * ldF + q;
+            float ar[KM2], ai[KM2];
+#pragma unroll
+            for (int ks = 0; ks < KM2; ++ks) {
+                ar[ks] = fr[4 * ks];
+                ai[ks] = fi[4 * ks];
+            }
+            f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = acc1;
+            if (!(a.dbg & 2)) {
+#pragma unroll
+                for (int n = 0; n < NT2; ++n)
+                    if (n == nt2) {
+#pragma unroll
+                        for (int ks = 0; ks < KM2; ++ks) {
+                            acc1 = mfma16(ar[ks], bwc[n][ks], acc1);
+                            acc2 = mfma16(ai[ks], bws[n][ks], acc2);
+                        }
+                    }
+            }
+            const int n2 = 1 + nt2 * 16 + l15;
+            if (n2 <= a2.J) {
+                const bool mirror = n2 <= a2.Js;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n1 = mt * 16 + q * 4 + r;
+                    if (n1 < N1) {
+                        O[n1 * ldo + n2] = acc1[r] - acc2[r];
+                        if (mirror) O[n1 * ldo + (N2 - n2)] = acc1[r] + acc2[r];
+                    }
+                }
+            }
+        }
+        // output column n2 = 0: cos = 1, sin = 0 -> plain sum of FR over k2 (one lane per row)
+        if (wave == 3) {
+            for (int n1 = lane; n1 < N1; n1 += 64) {
+                float sum = 0.f;
+#pragma unroll
+                for (int k2 = 0; k2 < 4 * KM2; ++k2) sum += FR[n1 * ldF + k2];
+                O[n1 * ldo] = sum;
+            }
+        }
+        __syncthreads();
+        // ---- epilogue: out = act(scale * O + residual), flat and fully coalesced
+        if (!(a.dbg & 4)) {
+            float *op = out + (size_t)plane * plane_elems;
+            int r = r0, c = c0;
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const unsigned e = tid + 256u * j;
+                if (e < plane_elems) {
+                    float v = a.scale * O[r * ldo + c];
+                    if (HAS_ADD) v += ra[HAS_ADD ? j : 0];
+                    op[e] = act_apply(v, a.act);
+                }
+                r += dr;
+                c += dc;
+                if (c >= N2) {
+                    c -= N2;
+                    ++r;
+                }
+            }
+        }
+    }
+}
+
 static int check_sizes(int BC, int N0, int N1, int N2, int m0, int m1, int m2) {
     HNO_REQUIRE(BC > 0 && N0 > 0 && N1 > 0 && N2 > 0, "dht3: non-positive size");
     if (m0 > 31) return fail(HNO_ELIMIT, "dht3: m0 = %d modes along the first axis (max 31)", m0);
@@ -755,14 +1090,35 @@ extern "C" int hno_dht3_crop(const float *x, const float *x_act_out, int act_gra
     const int pe = N1 * N2;
     {
         ProfScope _ps(KID_DHT_FWD_PLANE, s, 4.0 * BC * (double)N0 * N1 * N2 * (x_act_out ? 2 : 1));
-        if (pe <= 256 * 20)
+        const Axis &b1 = plan->ax[1], &b2 = plan->ax[2];
+        const bool spec_ok = pe <= 256 * 20 && b1.KT == 1 && b2.KT == 1 && N1 >= 16 && N2 >= 16 && !(a.dbg & 16);
+        const size_t lds_spec = sizeof(float) * (16 + plan->MP1 * plan->lda2 + plan->TP * plan->ldt);
+        int g_spec = (int)(kMaxLds / lds_spec);
+        if (g_spec > 8) g_spec = 8;
+        g_spec = planes < 256 * g_spec ? planes : 256 * g_spec;
+        bool launched = false;
+#define HNO_SPEC(KC2, KS2, KC1, KS1)                                                                                      \
+    if (!launched && spec_ok && b2.KcP == 4 * KC2 && b2.KsP == 4 * KS2 && b1.KcP == 4 * KC1 && b1.KsP == 4 * KS1) {      \
+        if (x_act_out)                                                                                                    \
+            hipLaunchKernelGGL((dht_fwd_plane_spec_kernel<KC2, KS2, KC1, KS1, true>), dim3(g_spec), dim3(256), lds_spec,  \
+                               s, x, x_act_out, (float *)workspace, a);                                                   \
+        else                                                                                                              \
+            hipLaunchKernelGGL((dht_fwd_plane_spec_kernel<KC2, KS2, KC1, KS1, false>), dim3(g_spec), dim3(256), lds_spec, \
+                               s, x, x_act_out, (float *)workspace, a);                                                   \
+        launched = true;                                                                                                  \
+    }
+        HNO_SPEC(9, 8, 9, 8)   // 65 x 65 planes (128^3 inputs)
+        HNO_SPEC(5, 4, 5, 4)   // 33 x 33 planes (64^3 inputs)
+        HNO_SPEC(8, 8, 8, 8)   // 61 x 61 planes (120 x 120 inputs)
+#undef HNO_SPEC
+        if (launched) {
+        } else if (pe <= 256 * 20)
             hipLaunchKernelGGL(dht_fwd_plane_kernel<20>, dim3(grid), dim3(256), lds, s, x, x_act_out, (float *)workspace, a);
         else if (pe <= 256 * 64)
             hipLaunchKernelGGL(dht_fwd_plane_kernel<64>, dim3(grid), dim3(256), lds, s, x, x_act_out, (float *)workspace, a);
         else
             hipLaunchKernelGGL(dht_fwd_plane_kernel<0>, dim3(grid), dim3(256), lds, s, x, x_act_out, (float *)workspace, a);
     }
-    HNO_CHECK_LAUNCH();
     const Axis &a0 = plan->ax[0];
     const size_t ldsd = sizeof(float) * a0.KT * (a0.KcP + a0.KsP) * 16;
     { ProfScope _ps(KID_DHT_FWD_D, s, 4.0 * BC * 8.0 * m0 * m1 * m2); hipLaunchKernelGGL(dht_fwd_d_kernel, dim3(plan->K1S * plan->ax[2].KT, BC), dim3(64), ldsd, s,
@@ -809,7 +1165,30 @@ extern "C" int hno_pad_idht3(const float *z, const float *addend, int act, float
     const int pe = N1 * N2;
     {
         ProfScope _ps(KID_DHT_INV_PLANE, s, 4.0 * BC * (double)N0 * N1 * N2 * (addend ? 2 : 1));
-        if (pe <= 256 * 20)
+        const Axis &b1 = plan->ax[1], &b2 = plan->ax[2];
+        const bool spec_ok = pe <= 256 * 20 && b1.KT == 1 && b2.KT == 1 && 2 * plan->CP <= 1024 && N1 >= 16 && N2 >= 16 &&
+                             !(a.dbg & 16);
+        const size_t lds_spec = sizeof(float) * (16 + 2 * plan->CP + 16 + 2 * plan->MP1 * plan->ldF + N1 * plan->ldo);
+        int g_spec = (int)(kMaxLds / lds_spec);
+        if (g_spec > 8) g_spec = 8;
+        g_spec = planes < 256 * g_spec ? planes : 256 * g_spec;
+        bool launched = false;
+#define HNO_SPEC(KM1, KM2, NT1, NT2)                                                                                      \
+    if (!launched && spec_ok && b1.KmP == 4 * KM1 && b2.KmP == 4 * KM2 && (b1.J + 15) / 16 == NT1 &&                      \
+        (b2.J + 15) / 16 == NT2) {                                                                                        \
+        if (addend)                                                                                                       \
+            hipLaunchKernelGGL((dht_inv_plane_spec_kernel<KM1, KM2, NT1, NT2, true>), dim3(g_spec), dim3(256), lds_spec,  \
+                               s, (const float *)workspace, addend, out, a);                                              \
+        else                                                                                                              \
+            hipLaunchKernelGGL((dht_inv_plane_spec_kernel<KM1, KM2, NT1, NT2, false>), dim3(g_spec), dim3(256), lds_spec, \
+                               s, (const float *)workspace, addend, out, a);                                              \
+        launched = true;                                                                                                  \
+    }
+        HNO_SPEC(4, 4, 2, 2)   // 65 x 65 and 61 x 61 planes, modes (., 14, 14): positions 1..32 / 1..30
+        HNO_SPEC(4, 4, 1, 1)   // 33 x 33 planes: positions 1..16
+#undef HNO_SPEC
+        if (launched) {
+        } else if (pe <= 256 * 20)
             hipLaunchKernelGGL(dht_inv_plane_kernel<20>, dim3(grid), dim3(256), lds, s, (const float *)workspace, addend, out, a);
         else if (pe <= 256 * 64)
             hipLaunchKernelGGL(dht_inv_plane_kernel<64>, dim3(grid), dim3(256), lds, s, (const float *)workspace, addend, out, a);

@@ -92,8 +92,9 @@ def pwconv_fwd_raw(xa, xb, W, bias, act):
     return y
 
 
-def pwconv_bwd_raw(gy, y, xa, xb, W, act, has_bias, need_gxa=True, need_gxb=True):
-    """-> (gxa, gxb, dW, dbias); y is the saved output (None when act is NONE)."""
+def pwconv_bwd_raw(gy, y, xa, xb, W, act, has_bias, need_gxa=True, need_gxb=True, xa_act=ACT_NONE):
+    """-> (gxa, gxb, dW, dbias); y is the saved output (None when act is NONE).  xa_act: also multiply
+    gxa by act'(xa) (xa being the output of that activation)."""
     B, Ca = xa.shape[:2]
     Cb = xb.shape[1] if xb is not None else 0
     Cout, V = W.shape[0], _flat_v(xa)
@@ -103,7 +104,7 @@ def pwconv_bwd_raw(gy, y, xa, xb, W, act, has_bias, need_gxa=True, need_gxb=True
     db = torch.empty(Cout, device=W.device, dtype=torch.float32) if has_bias else None
     ws = _wgrad_ws(Ca + Cb, Cout, xa.device)
     check(_lib.lib().hno_pwconv_bwd(ptr(gy), ptr(y), ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(gxa), ptr(gxb), ptr(dW),
-                                    ptr(db), ptr(ws), B, Cout, V, act, stream_ptr()), 'hno_pwconv_bwd')
+                                    ptr(db), ptr(ws), B, Cout, V, act, xa_act, stream_ptr()), 'hno_pwconv_bwd')
     return gxa, gxb, dW, db
 
 
@@ -235,8 +236,9 @@ class XSBlockFn(torch.autograd.Function):
         has_map, modes, act, spatial, n3, map_has_b, cat_has_b = ctx.cfg
         if not has_map:
             xm = x
-        g_u, g_skipin, d_cat_w, d_cat_b = pwconv_bwd_raw(_f32c(g_out), out, u, xm, cat_w, act, cat_has_b)
-        g_zl = dht3_crop_raw(g_u, modes, 1.0, u, act)                       # PadInverse^T with act'(u) fused
+        # conv_concat backward; the SELU backward of PadInverse (g_u * act'(u)) is applied in its epilogue
+        g_u, g_skipin, d_cat_w, d_cat_b = pwconv_bwd_raw(_f32c(g_out), out, u, xm, cat_w, act, cat_has_b, xa_act=act)
+        g_zl = dht3_crop_raw(g_u, modes, 1.0)                               # PadInverse^T
         g_z0, d_mix = specmix_bwd_raw(g_zl, z0, zs, mix_w, 1, act)
         g_xm = pad_idht3_raw(g_z0, spatial, 1.0 / n3, g_skipin, ACT_NONE)    # TransformCrop^T + skip gradient
         if not has_map:
