@@ -1,0 +1,165 @@
+"""`training()` with the reference's signature and semantics (experiments/train_test.py:31-286).
+
+Kept: argument list, checkpoint/resume protocol and file names (`model/model.pt`,
+`model/checkpoint.pt`, `stdout.txt` with the `train_loss:` / `valid_loss:` line format), the order
+forward -> zero_grad -> backward -> step, the per-BATCH scheduler step, the mean of per-batch losses,
+the checkpoint cadence and the best-model selection rule.
+Changed on purpose: labels go to the loss kernels as uint8 class maps (no one-hot tensor), and the
+per-batch `loss.item()` host synchronisation (reference :162) is deferred to the end of the epoch.
+Out of scope: torchinfo/torchview summaries, matplotlib plots, autocast.
+"""
+import os
+import re
+import time
+from os.path import join
+
+import numpy as np
+import torch
+
+from .utils import labels_to_u8
+
+
+def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, label_mapping=None, num_epochs=100,
+             selection_epoch_portion=0.8, checkpoint_epoch=10, is_plot_model=False, is_print=True,
+             plot_epoch_portion=None, use_autocast=False, device=None, data_parallel=None):
+    """Trains a model; see the reference docstring (train_test.py:48-71).  `data_parallel` is an optional
+    parallel.FlatGradReplica for one-process-per-GPU training (not in the reference)."""
+    if use_autocast:
+        raise NotImplementedError('autocast is not provided by the fp32 HIP path')
+    model_dir = join(output_dir, 'model')
+    model_path, chkpt_path = join(model_dir, 'model.pt'), join(model_dir, 'checkpoint.pt')
+    stdout_file = join(output_dir, 'stdout.txt')
+    os.makedirs(model_dir, exist_ok=True)
+
+    def log(*lines, echo=True):
+        if is_print and echo:
+            for ln in lines:
+                print(ln)
+        with open(stdout_file, 'a') as f:
+            for ln in lines:
+                print(ln, file=f)
+
+    model.to(device)
+    if os.path.exists(chkpt_path):
+        start_epoch, min_loss, best_epoch = load_checkpoint(chkpt_path, model, optimizer, scheduler, None, device)
+        start_epoch += 1
+        if start_epoch >= num_epochs:
+            raise RuntimeError(f'Checkpoint detected, but start_epoch ({start_epoch}) >= num_epochs ({num_epochs})')
+        if is_print:
+            print(f'Checkpoint loaded for epoch {start_epoch}')
+        # drop what was logged after the last checkpoint (reference :92-102)
+        with open(stdout_file) as f:
+            lines = f.readlines()
+        last = max((i for i, ln in enumerate(lines) if 'checkpoint' in ln), default=len(lines) - 1)
+        with open(stdout_file, 'w') as f:
+            f.writelines(lines[:last + 1])
+    else:
+        start_epoch, min_loss, best_epoch = 0, float('inf'), None
+        log('', f'train_num_batches: {input_data.get_train_num_batches()}',
+            f'valid_num_batches: {input_data.get_valid_num_batches()}', '')
+        with open(join(output_dir, 'model_summary.txt'), 'w') as f:
+            print(model, file=f)
+            print(f'Total params: {sum(p.numel() for p in model.parameters())}', file=f)
+            print(f'Input size: {(1, model.in_channels) + tuple(input_data.get_train_image_size())}', file=f)
+
+    train_flow = input_data.get_train_flow(shuffle=True)
+    valid_flow = input_data.get_valid_flow()
+    num_labels = model.out_channels
+    if is_print:
+        print('Training started')
+        print(output_dir)
+    start_time = time.time()
+
+    def mean_loss(losses):
+        return float(np.mean([float(v) for v in torch.stack(losses).cpu()])) if losses else float('nan')
+
+    for epoch in range(start_epoch, num_epochs):
+        model.train()
+        losses = []
+        for x, y in train_flow:
+            x, y = x.to(device), y.to(device)
+            y = labels_to_u8(y, num_labels, label_mapping)
+            y_pred = model(x)
+            loss = loss_fn(y_pred, y)
+            losses.append(loss.detach())          # no host sync inside the step
+            if data_parallel is not None:
+                data_parallel.zero_grad()
+            else:
+                optimizer.zero_grad()
+            loss.backward()
+            if data_parallel is not None:
+                data_parallel.allreduce_grads()
+            optimizer.step()
+            if scheduler is not None:
+                scheduler.step()
+        train_loss = mean_loss(losses)
+        log('', '-------------------------', f'Epoch: {epoch}', f'train_loss: {train_loss}')
+
+        model.eval()
+        losses = []
+        with torch.no_grad():
+            for x, y in valid_flow:
+                x, y = x.to(device), y.to(device)
+                y = labels_to_u8(y, num_labels, label_mapping)
+                losses.append(loss_fn(model(x), y).detach())
+        valid_loss = mean_loss(losses)
+        log(f'valid_loss: {valid_loss}')
+
+        if (epoch + 1) % checkpoint_epoch == 0:
+            save_checkpoint(chkpt_path, epoch, model, optimizer, scheduler, min_loss, best_epoch, None)
+            log('Standard checkpoint saved.')
+        selection_epoch = int(num_epochs * selection_epoch_portion)
+        if (epoch > selection_epoch or epoch == num_epochs - 1) and valid_loss < min_loss:
+            min_loss, best_epoch = valid_loss, epoch
+            torch.save(model.state_dict(), model_path)
+            if (epoch + 1) % checkpoint_epoch != 0:  # avoid saving twice
+                save_checkpoint(chkpt_path, epoch, model, optimizer, scheduler, min_loss, best_epoch, None)
+                log('Best checkpoint saved.')
+    end_time = time.time()
+
+    if best_epoch is not None:
+        model.load_state_dict(torch.load(model_path, weights_only=True, map_location=device))
+    else:  # num_epochs == 0, i.e. no training
+        torch.save(model.state_dict(), model_path)
+    log('', f'Time used: {end_time - start_time:.2f} seconds.', f'Best epoch: {best_epoch}', f'Min loss: {min_loss}')
+    return model
+
+
+def save_checkpoint(chkpt_path, epoch, model, optimizer, scheduler, min_loss, best_epoch, scaler):
+    """Same dict keys as the reference (train_test.py:262-273)."""
+    checkpoint = {
+        'epoch': epoch,
+        'model_state_dict': model.state_dict(),
+        'optimizer_state_dict': optimizer.state_dict(),
+        'scheduler_state_dict': scheduler.state_dict() if scheduler is not None else None,
+        'min_loss': min_loss,
+        'best_epoch': best_epoch,
+    }
+    if scaler is not None:
+        checkpoint['scaler_state_dict'] = scaler.state_dict()
+    torch.save(checkpoint, chkpt_path)
+
+
+def load_checkpoint(chkpt_path, model, optimizer, scheduler, scaler, device):
+    """Reference train_test.py:276-286."""
+    checkpoint = torch.load(chkpt_path, weights_only=False, map_location=device)
+    model.load_state_dict(checkpoint['model_state_dict'])
+    optimizer.load_state_dict(checkpoint['optimizer_state_dict'])
+    if scheduler is not None and checkpoint.get('scheduler_state_dict') is not None:
+        scheduler.load_state_dict(checkpoint['scheduler_state_dict'])
+    if scaler is not None:
+        scaler.load_state_dict(checkpoint['scaler_state_dict'])
+    return checkpoint['epoch'], checkpoint['min_loss'], checkpoint['best_epoch']
+
+
+def get_losses_from_file(filename):
+    """Parses `train_loss:` / `valid_loss:` lines (reference train_test.py:289-302)."""
+    train_loss, valid_loss = [], []
+    with open(filename) as f:
+        for ln in f:
+            if 'train_loss' in ln:
+                train_loss.append(float(re.findall('train_loss: (.+)', ln)[0]))
+            elif 'valid_loss' in ln:
+                valid_loss.append(float(re.findall('valid_loss: (.+)', ln)[0]))
+    assert len(train_loss) == len(valid_loss)
+    return train_loss, valid_loss

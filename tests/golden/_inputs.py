@@ -67,3 +67,64 @@ SMALL_MODELS = {
     'xs_clamped': (dict(in_channels=2, out_channels=2, filters=16, num_transform_blocks=[1, 1], num_modes=(10, 14, 14)),
                    (1, 2, 16, 20, 24)),
 }
+
+
+# ---- training-loop trajectory case (golden G8), shared by make_golden.py and the tests
+TRAIN_CASE = {
+    'model': dict(in_channels=2, out_channels=3, filters=8, num_transform_blocks=[1, 1, 1, 1], num_modes=(3, 4, 4)),
+    'image_size': (16, 20, 24), 'batch_size': 2, 'num_train': 4, 'num_valid': 2,
+    'epochs': 4, 'lr': 5e-3, 'eta_min': 1e-3,
+    'mapping': {3: 2},           # labels are drawn from 0..3 and label 3 is merged into 2
+}
+
+
+class _TrainInput:
+    """Duck type of the reference's InputData (methods used by training()), deterministic data."""
+
+    def __init__(self):
+        c = TRAIN_CASE
+        self.batch_size = c['batch_size']
+        self._n = (c['num_train'], c['num_valid'])
+        self._size = c['image_size']
+
+    def _sample(self, i):
+        import torch
+        cin = TRAIN_CASE['model']['in_channels']
+        x = formula_volume((1, cin) + self._size, 50 + i)[0]
+        y = formula_labels((1, 1) + self._size, 4, 60 + i)[0]
+        return torch.from_numpy(x), torch.from_numpy(y)
+
+    def _flow(self, first, count):
+        import torch
+        for i in range(0, count, self.batch_size):
+            xs, ys = zip(*[self._sample(first + j) for j in range(i, min(i + self.batch_size, count))])
+            yield torch.stack(xs), torch.stack(ys)
+
+    def get_train_flow(self, shuffle=True):     # deterministic order: the trajectory must be reproducible
+        outer = self
+
+        class It:
+            def __iter__(self_inner):
+                return outer._flow(0, outer._n[0])
+        return It()
+
+    def get_valid_flow(self):
+        outer = self
+
+        class It:
+            def __iter__(self_inner):
+                return outer._flow(outer._n[0], outer._n[1])
+        return It()
+
+    def get_train_num_batches(self):
+        return -(-self._n[0] // self.batch_size)
+
+    def get_valid_num_batches(self):
+        return -(-self._n[1] // self.batch_size)
+
+    def get_train_image_size(self):
+        return self._size
+
+
+def make_train_input():
+    return _TrainInput()

@@ -251,6 +251,53 @@ def g9_misc():
     save('g9_misc.npz', **out)
 
 
+# ----------------------------------------------- G8: training-loop trajectory of the reference
+def _stub_missing_modules():
+    sys.modules.setdefault('SimpleITK', type(sys)('SimpleITK'))
+    ti = type(sys)('torchinfo')
+    ti.summary = lambda *a, **k: 'summary'
+    sys.modules.setdefault('torchinfo', ti)
+    sys.modules.setdefault('torchview', type(sys)('torchview'))
+    try:
+        import matplotlib  # noqa: F401
+    except ImportError:
+        mp = type(sys)('matplotlib')
+        mp.use = lambda *a, **k: None
+        sys.modules['matplotlib'] = mp
+        sys.modules['matplotlib.pyplot'] = type(sys)('matplotlib.pyplot')
+
+
+def g8_training():
+    import tempfile
+    _stub_missing_modules()
+    from experiments import train_test as ref_tt
+    ref_tt.plot_losses = lambda *a, **k: None        # plotting is out of scope
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), '..'))
+    from _inputs import TRAIN_CASE, make_train_input
+    data = make_train_input()
+    torch.manual_seed(5)
+    model = nets.HNOSegXS(**TRAIN_CASE['model'])
+    out = {f'sd0::{k}': v.detach().numpy().copy() for k, v in model.state_dict().items()}
+    opt = torch.optim.Adamax(model.parameters(), lr=TRAIN_CASE['lr'])
+    nb = data.get_train_num_batches()
+    sched = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=nb * TRAIN_CASE['epochs'], eta_min=TRAIN_CASE['eta_min'])
+    with tempfile.TemporaryDirectory() as d:
+        ref_tt.training(model, data, d, custom_losses.PCCLoss(), opt, sched, label_mapping=TRAIN_CASE['mapping'],
+                        num_epochs=TRAIN_CASE['epochs'], selection_epoch_portion=0.5, checkpoint_epoch=2,
+                        is_print=False, device='cpu')
+        tl, vl = ref_tt.get_losses_from_file(os.path.join(d, 'stdout.txt'))
+        ck = torch.load(os.path.join(d, 'model', 'checkpoint.pt'), weights_only=False)
+        out['files'] = np.array(sorted(os.listdir(os.path.join(d, 'model'))))
+    out['train_loss'], out['valid_loss'] = np.array(tl), np.array(vl)
+    out['checkpoint_keys'] = np.array(sorted(ck.keys()))
+    out['checkpoint_epoch'] = np.array(ck['epoch'])
+    out['best_epoch'] = np.array(-1 if ck['best_epoch'] is None else ck['best_epoch'])
+    out['final_lr'] = np.array(opt.param_groups[0]['lr'])
+    for k, v in model.state_dict().items():
+        out[f'sd1::{k}'] = v.detach().numpy().copy()
+    save('g8_training.npz', **out)
+
+
 if __name__ == '__main__':
     g1_dht()
     g2_crop_pad()
@@ -259,3 +306,4 @@ if __name__ == '__main__':
     g6_hnosegxs()
     g6s_small_models()
     g9_misc()
+    g8_training()
