@@ -54,6 +54,26 @@ int hno_dht3_crop(const float *x, const float *x_act_out, int act_grad, float *o
 int hno_pad_idht3(const float *z, const float *addend, int act, float *out, void *workspace,
                   int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream);
 
+/* ---------------------------------------------------- mode-truncated real FFT (FNO path)
+ * Same kernels as the Hartley pair with a different spectrum convention.  `spec` is the kept half
+ * spectrum as REAL data (B, 2, C, 2m0, 2m1, m2): re plane then im plane per batch element, i.e. a
+ * (B, 2C, ...) tensor whose channels are [re(0..C-1), im(0..C-1)], modes [low|high] on the first two
+ * axes and [0, m2) on the last.
+ * hno_rfft3_crop: spec = w(k2) * scale * sum_n x_eff[n] e^{-i phi(k, n)}.  k2_weights = 0 with scale
+ *   1/(N0 N1 N2) replaces torch.fft.rfftn(norm='forward') + the 4 corner slices of
+ *   FourierOperator._call3d (nets/fourier_operator.py:164-191); k2_weights = 1 (w = 1,2,2,...) with scale 1
+ *   is the backward of hno_irfft3_pad.
+ * hno_irfft3_pad: out = act(scale * sum_k w(k2) Re[spec[k] e^{+i phi(k, n)}] + addend).  k2_weights = 1,
+ *   scale 1 replaces the zero padding + torch.fft.irfftn(norm='forward') (:195-209); k2_weights = 0 with
+ *   scale 1/(N0 N1 N2) is the backward of hno_rfft3_crop.  Workspace: hno_dht3_workspace_bytes(B*C, ...).
+ */
+int hno_rfft3_crop(const float *x, const float *x_act_out, int act_grad, float *spec, void *workspace,
+                   int B, int C, int N0, int N1, int N2, int m0, int m1, int m2, float scale, int k2_weights,
+                   void *stream);
+int hno_irfft3_pad(const float *spec, const float *addend, int act, float *out, void *workspace,
+                   int B, int C, int N0, int N1, int N2, int m0, int m1, int m2, float scale, int k2_weights,
+                   void *stream);
+
 /* ------------------------------------------------- shared-weight spectral channel mixing
  * L stacked layers  z_{l+1} = act(W_l z_l + residual * z_l)  on a (B, C, M) spectrum
  * (M = number of kept modes, contiguous).  W is (L, C, C) row-major [l][o][i].
@@ -79,6 +99,7 @@ int hno_specmix_shared_bwd(const float *g, const float *z0, const float *zs, con
  * NULL to skip) and WRITES dW (Cout, Ca+Cb) and dbias (Cout).
  * xa_act != HNO_ACT_NONE additionally multiplies gxa by act'(xa) where xa is itself the output of
  * that activation (fuses the SELU backward of PadInverse into this kernel: HNOXSBlock :267-275).
+ * accumulate_gx != 0 adds the input gradients to the values already in gxa / gxb.
  * Weight gradients are reduced through per-block slabs in `workspace`
  * (hno_pwconv_bwd_workspace_bytes) in a fixed order: no float atomics, reproducible bit for bit.
  */
@@ -87,7 +108,7 @@ int hno_pwconv_fwd(const float *xa, int Ca, const float *xb, int Cb, const float
                    float *y, int B, int Cout, long long V, int act, void *stream);
 int hno_pwconv_bwd(const float *gy, const float *y, const float *xa, int Ca, const float *xb, int Cb,
                    const float *W, float *gxa, float *gxb, float *dW, float *dbias, void *workspace,
-                   int B, int Cout, long long V, int act, int xa_act, void *stream);
+                   int B, int Cout, long long V, int act, int xa_act, int accumulate_gx, void *stream);
 
 /* ------------------------------------------- strided 2x2x2 'resize' convolution (conv_in)
  * Conv3d(Cin -> Cout, kernel 2, stride 2, padding 1) + bias + act: (B,Cin,D,H,W) ->
@@ -113,6 +134,13 @@ int hno_upsoftmax_fwd(const float *logits_lr, float *probs, int B, int K, int d,
                       int D, int H, int W, int softmax, void *stream);
 int hno_upsoftmax_bwd(const float *g_probs, const float *probs, float *g_lr, int B, int K, int d, int h, int w,
                       int D, int H, int W, int softmax, void *stream);
+
+/* ------------------------------------------------------------------- elementwise helpers
+ * y = act(x) ; gx = g * act'(y) (y = saved output) ; out = a + b.  Used where the reference applies an
+ * activation or a residual add that no neighbouring kernel can absorb (nets/architectures.py:529-546). */
+int hno_act_fwd(const float *x, float *y, long long n, int act, void *stream);
+int hno_act_bwd(const float *g, const float *y, float *gx, long long n, int act, void *stream);
+int hno_add(const float *a, const float *b, float *out, long long n, void *stream);
 
 /* --------------------------------------------------------------- Pearson / Dice reductions
  * Labels are uint8 class indices (B, V) -- one-hot encoding (experiments/utils.py:74-97)

@@ -23,16 +23,21 @@ SIGNATURES = {
     'hno_dht3_workspace_bytes': (c_size_t, [c_int] * 7),
     'hno_dht3_crop': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_void_p]),
     'hno_pad_idht3': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_void_p]),
+    'hno_rfft3_crop': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_int, c_void_p]),
+    'hno_irfft3_pad': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_int, c_void_p]),
     'hno_specmix_shared_fwd': (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     'hno_specmix_shared_bwd': (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
     'hno_pwconv_fwd': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_void_p]),
     'hno_pwconv_bwd_workspace_bytes': (c_size_t, [c_int, c_int]),
     'hno_pwconv_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                               c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_int, c_void_p]),
+                               c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_int, c_int, c_void_p]),
     'hno_conv_k2s2_fwd': (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
     'hno_conv_k2s2_bwd': (c_int, [c_void_p] * 8 + [c_int] * 7 + [c_void_p]),
     'hno_upsoftmax_fwd': (c_int, [c_void_p] * 2 + [c_int] * 9 + [c_void_p]),
     'hno_upsoftmax_bwd': (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p]),
+    'hno_act_fwd': (c_int, [c_void_p, c_void_p, c_ll, c_int, c_void_p]),
+    'hno_act_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p]),
+    'hno_add': (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
     'hno_loss_fwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_ll, c_int, c_float, c_void_p]),
     'hno_loss_bwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_ll, c_void_p]),
     'hno_labels_prepare': (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 2 + [c_int, c_int, c_ll, c_void_p]),

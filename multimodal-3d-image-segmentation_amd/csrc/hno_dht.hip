@@ -191,6 +191,12 @@ struct DhtArgs {
     float scale;
     int act;  // forward: activation whose derivative multiplies the input; inverse: epilogue act
     int dbg;  // ablation switches (timing only)
+    // spectrum convention of the D kernels: 0 = Hartley block (real, [low|high] on all three axes);
+    // 1 / 2 = Fourier half spectrum (B, 2, C, 2m0, 2m1, m2) with re / im planes, k2 in [0, m2):
+    //   1: unit weights (rfftn forward, and the backward of rfftn)
+    //   2: weights (1, 2, 2, ...) along k2 (irfftn forward, and the backward of irfftn)
+    int mode;
+    int C;    // channels per batch element (Fourier layout only)
 };
 
 // signed frequency -> index in the [low | high] block, or -1 if not kept
@@ -560,7 +566,28 @@ __global__ __launch_bounds__(64) void dht_fwd_d_kernel(const float *__restrict__
         //   X(+k0) = (PR + QI) + i (PI - QR),  X(-k0) = (PR - QI) + i (PI + QR)
         const int k0 = kt0 * 16 + (lane & 15);
         const int k1 = k1s - m1;
-        if (k0 <= m0) {
+        if (k0 <= m0 && a.mode != 0) {
+            // Fourier half spectrum: S[b][re|im][c][o0][o1][k2], k2 in [0, m2)
+            const int b = bc / a.C, c = bc - b * a.C;
+            const size_t msz = (size_t)(2 * m0) * (2 * m1) * m2;
+            float *sr = out + ((size_t)(b * 2 + 0) * a.C + c) * msz, *si = out + ((size_t)(b * 2 + 1) * a.C + c) * msz;
+            const int o1 = kept_pos(k1, m1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k2 = kt2 * 16 + q * 4 + r;
+                if (k2 >= m2 || o1 < 0) continue;
+                const float w = a.scale * ((a.mode == 2 && k2 > 0) ? 2.f : 1.f);
+#pragma unroll
+                for (int sgn = 0; sgn < 2; ++sgn) {
+                    if (sgn == 1 && k0 == 0) continue;
+                    const int o0 = kept_pos(sgn ? -k0 : k0, m0);
+                    if (o0 < 0) continue;
+                    const size_t idx = ((size_t)o0 * (2 * m1) + o1) * m2 + k2;
+                    sr[idx] = w * (sgn ? PR[r] - QI[r] : PR[r] + QI[r]);
+                    si[idx] = w * (sgn ? PI[r] + QR[r] : PI[r] - QR[r]);
+                }
+            }
+        } else if (k0 <= m0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k2 = kt2 * 16 + q * 4 + r;
@@ -618,11 +645,31 @@ __global__ __launch_bounds__(64) void dht_inv_d_kernel(const float *__restrict__
     // operands do not depend on the output tile: gather them once (up to 8 k-steps = m0 <= 31)
     constexpr int KSM = 8;
     float gsr[KSM], gsi[KSM], gdr[KSM], gdi[KSM];
+    // Fourier layout: re / im planes of this (b, c)
+    const int fb = a.mode ? bc / a.C : 0, fc = a.mode ? bc - fb * a.C : 0;
+    const size_t msz = (size_t)(2 * m0) * (2 * m1) * m2;
+    const float *sr = z + ((size_t)(fb * 2 + 0) * a.C + fc) * msz, *si = z + ((size_t)(fb * 2 + 1) * a.C + fc) * msz;
 #pragma unroll
     for (int ks = 0; ks < KSM; ++ks) {
         gsr[ks] = gsi[ks] = gdr[ks] = gdi[ks] = 0.f;
         const int k0 = ks * 4 + q;
-        if (ks < KS && k0 <= m0 && k2 <= m2) {
+        if (a.mode != 0) {
+            // G'(k) = w(k2) * S[k] on kept (k0, k1), k2 in [0, m2); no conjugate partner (the c2r weights
+            // already account for the omitted half)
+            const int o1 = kept_pos(k1, m1);
+            if (ks < KS && k0 <= m0 && k2 < m2 && o1 >= 0) {
+                const float w = (a.mode == 2 && k2 > 0) ? 2.f : 1.f;
+                const int op = kept_pos(k0, m0), om = k0 >= 1 ? kept_pos(-k0, m0) : -1;
+                const size_t ip = ((size_t)(op >= 0 ? op : 0) * (2 * m1) + o1) * m2 + k2;
+                const size_t im = ((size_t)(om >= 0 ? om : 0) * (2 * m1) + o1) * m2 + k2;
+                const float pr = op >= 0 ? w * sr[ip] : 0.f, pi = op >= 0 ? w * si[ip] : 0.f;
+                const float mr = om >= 0 ? w * sr[im] : 0.f, mi = om >= 0 ? w * si[im] : 0.f;
+                gsr[ks] = pr + mr;
+                gsi[ks] = pi + mi;
+                gdr[ks] = k0 >= 1 ? pr - mr : 0.f;
+                gdi[ks] = k0 >= 1 ? pi - mi : 0.f;
+            }
+        } else if (ks < KS && k0 <= m0 && k2 <= m2) {
             const float va = zk_load(zb, k0, k1, k2, m0, m1, m2);
             const float vb = k2 >= 1 ? zk_load(zb, -k0, -k1, -k2, m0, m1, m2) : 0.f;
             // G'(+k0) = (va + vb) + i (vb - va)
@@ -1057,8 +1104,9 @@ extern "C" size_t hno_dht3_workspace_bytes(int BC, int N0, int N1, int N2, int m
     return (size_t)BC * N0 * 2 * (2 * m1 + 1) * KP2 * sizeof(float);
 }
 
-extern "C" int hno_dht3_crop(const float *x, const float *x_act_out, int act_grad, float *out, void *workspace,
-                             int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream) {
+static int dht_forward_launch(const float *x, const float *x_act_out, int act_grad, float *out, void *workspace,
+                              int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream,
+                              int mode, int C) {
     HNO_REQUIRE(x && out && workspace, "hno_dht3_crop: null pointer");
     int rc = check_sizes(BC, N0, N1, N2, m0, m1, m2);
     if (rc) return rc;
@@ -1071,6 +1119,8 @@ extern "C" int hno_dht3_crop(const float *x, const float *x_act_out, int act_gra
     a.scale = scale;
     a.act = x_act_out ? act_grad : HNO_ACT_NONE;
     a.dbg = debug_flags();
+    a.mode = mode;
+    a.C = C > 0 ? C : 1;
     const size_t lds = sizeof(float) * plan->f_lds_floats;
     if (lds > kMaxLds) return fail(HNO_ELIMIT, "hno_dht3_crop: plane %dx%d needs %zu B of LDS (> 160 KiB)", N1, N2, lds);
     hipStream_t s = (hipStream_t)stream;
@@ -1127,8 +1177,9 @@ extern "C" int hno_dht3_crop(const float *x, const float *x_act_out, int act_gra
     return HNO_OK;
 }
 
-extern "C" int hno_pad_idht3(const float *z, const float *addend, int act, float *out, void *workspace,
-                             int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream) {
+static int dht_inverse_launch(const float *z, const float *addend, int act, float *out, void *workspace,
+                              int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream,
+                              int mode, int C) {
     HNO_REQUIRE(z && out && workspace, "hno_pad_idht3: null pointer");
     int rc = check_sizes(BC, N0, N1, N2, m0, m1, m2);
     if (rc) return rc;
@@ -1141,6 +1192,8 @@ extern "C" int hno_pad_idht3(const float *z, const float *addend, int act, float
     a.scale = scale;
     a.act = act;
     a.dbg = debug_flags();
+    a.mode = mode;
+    a.C = C > 0 ? C : 1;
     const size_t lds = sizeof(float) * plan->i_lds_floats;
     if (lds > kMaxLds) return fail(HNO_ELIMIT, "hno_pad_idht3: plane %dx%d needs %zu B of LDS (> 160 KiB)", N1, N2, lds);
     hipStream_t s = (hipStream_t)stream;
@@ -1197,4 +1250,30 @@ extern "C" int hno_pad_idht3(const float *z, const float *addend, int act, float
     }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
+}
+
+extern "C" int hno_dht3_crop(const float *x, const float *x_act_out, int act_grad, float *out, void *workspace,
+                             int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream) {
+    return dht_forward_launch(x, x_act_out, act_grad, out, workspace, BC, N0, N1, N2, m0, m1, m2, scale, stream, 0, 1);
+}
+
+extern "C" int hno_pad_idht3(const float *z, const float *addend, int act, float *out, void *workspace,
+                             int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream) {
+    return dht_inverse_launch(z, addend, act, out, workspace, BC, N0, N1, N2, m0, m1, m2, scale, stream, 0, 1);
+}
+
+extern "C" int hno_rfft3_crop(const float *x, const float *x_act_out, int act_grad, float *spec, void *workspace,
+                              int B, int C, int N0, int N1, int N2, int m0, int m1, int m2, float scale, int k2_weights,
+                              void *stream) {
+    HNO_REQUIRE(B > 0 && C > 0, "hno_rfft3_crop: bad batch / channel count");
+    return dht_forward_launch(x, x_act_out, act_grad, spec, workspace, B * C, N0, N1, N2, m0, m1, m2, scale, stream,
+                              k2_weights ? 2 : 1, C);
+}
+
+extern "C" int hno_irfft3_pad(const float *spec, const float *addend, int act, float *out, void *workspace,
+                              int B, int C, int N0, int N1, int N2, int m0, int m1, int m2, float scale, int k2_weights,
+                              void *stream) {
+    HNO_REQUIRE(B > 0 && C > 0, "hno_irfft3_pad: bad batch / channel count");
+    return dht_inverse_launch(spec, addend, act, out, workspace, B * C, N0, N1, N2, m0, m1, m2, scale, stream,
+                              k2_weights ? 2 : 1, C);
 }

@@ -288,6 +288,17 @@ __global__ __launch_bounds__(256) void labels_kernel(const float *__restrict__ l
     }
 }
 
+__global__ __launch_bounds__(256) void eltwise_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                     float *__restrict__ out, size_t n, int op, int act) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v;
+        if (op == 0) v = act_apply(a[i], act);                       // y = act(x)
+        else if (op == 1) v = a[i] * act_grad_from_out(b[i], act);   // gx = g * act'(y)
+        else v = a[i] + b[i];
+        out[i] = v;
+    }
+}
+
 static int grid1d(size_t n) {
     size_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
@@ -372,6 +383,27 @@ extern "C" int hno_labels_prepare(const float *labels_f32, const int *remap_from
     HNO_REQUIRE(n_remap == 0 || (remap_from && remap_to), "hno_labels_prepare: remap tables missing");
     { ProfScope _ps(KID_LABELS, (hipStream_t)stream); hipLaunchKernelGGL(labels_kernel, dim3(grid1d((size_t)B * V)), dim3(256), 0, (hipStream_t)stream, labels_f32,
                        remap_from, remap_to, n_remap, labels_u8, onehot, K, V, B); }
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+extern "C" int hno_act_fwd(const float *x, float *y, long long n, int act, void *stream) {
+    HNO_REQUIRE(x && y && n > 0, "hno_act_fwd: bad argument");
+    hipLaunchKernelGGL(eltwise_kernel, dim3(grid1d((size_t)n)), dim3(256), 0, (hipStream_t)stream, x, (const float *)nullptr, y, (size_t)n, 0, act);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+extern "C" int hno_act_bwd(const float *g, const float *y, float *gx, long long n, int act, void *stream) {
+    HNO_REQUIRE(g && y && gx && n > 0, "hno_act_bwd: bad argument");
+    hipLaunchKernelGGL(eltwise_kernel, dim3(grid1d((size_t)n)), dim3(256), 0, (hipStream_t)stream, g, y, gx, (size_t)n, 1, act);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+extern "C" int hno_add(const float *a, const float *b, float *out, long long n, void *stream) {
+    HNO_REQUIRE(a && b && out && n > 0, "hno_add: bad argument");
+    hipLaunchKernelGGL(eltwise_kernel, dim3(grid1d((size_t)n)), dim3(256), 0, (hipStream_t)stream, a, b, out, (size_t)n, 2, 0);
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }

@@ -132,6 +132,7 @@ struct PwBwdArgs {
     int act;
     int residual;
     int dbg;
+    int accum;   // gxa / gxb += instead of = (gradient accumulation fused into the store)
     int xa_act;  // gxa *= act'(xa): xa is itself the OUTPUT of that activation (fuses PadInverse's SELU backward)
 };
 
@@ -230,17 +231,17 @@ __global__ __launch_bounds__(256, 2) void pwconv_bwd_kernel(PwBwdArgs a) {
                     const bool ok = vin && i < a.Cin;
                     if (irow + 4 < a.Ca || irow + 4 >= a.Cin) {        // both lane halves in xa (or half 1 absent)
                         if (irow < a.Ca) {
-                            if (a.gxa && ok) (a.gxa + ((size_t)b * a.Ca + irow) * V)[hoff4V + v] = acc[r] * (a.xa_act != HNO_ACT_NONE ? act_grad_from_out(X[i * PWB_LD + c], a.xa_act) : 1.f);
+                            if (a.gxa && ok) { float *q_ = a.gxa + ((size_t)b * a.Ca + irow) * V + hoff4V + v; *q_ = (acc[r] * (a.xa_act != HNO_ACT_NONE ? act_grad_from_out(X[i * PWB_LD + c], a.xa_act) : 1.f)) + (a.accum ? *q_ : 0.f); }
                         } else if (a.gxb && ok) {
-                            (a.gxb + ((size_t)b * a.Cb + (irow - a.Ca)) * V)[hoff4V + v] = acc[r];
+                            { float *q_ = a.gxb + ((size_t)b * a.Cb + (irow - a.Ca)) * V + hoff4V + v; *q_ = acc[r] + (a.accum ? *q_ : 0.f); }
                         }
                     } else if (irow >= a.Ca) {                          // both halves in xb
-                        if (a.gxb && ok) (a.gxb + ((size_t)b * a.Cb + (irow - a.Ca)) * V)[hoff4V + v] = acc[r];
+                        if (a.gxb && ok) { float *q_ = a.gxb + ((size_t)b * a.Cb + (irow - a.Ca)) * V + hoff4V + v; *q_ = acc[r] + (a.accum ? *q_ : 0.f); }
                     } else if (ok) {                                    // halves straddle the concat boundary
                         if (i < a.Ca) {
-                            if (a.gxa) (a.gxa + ((size_t)b * a.Ca + i) * V)[v] = acc[r] * (a.xa_act != HNO_ACT_NONE ? act_grad_from_out(X[i * PWB_LD + c], a.xa_act) : 1.f);
+                            if (a.gxa) { float *q_ = a.gxa + ((size_t)b * a.Ca + i) * V + v; *q_ = (acc[r] * (a.xa_act != HNO_ACT_NONE ? act_grad_from_out(X[i * PWB_LD + c], a.xa_act) : 1.f)) + (a.accum ? *q_ : 0.f); }
                         } else if (a.gxb) {
-                            (a.gxb + ((size_t)b * a.Cb + (i - a.Ca)) * V)[v] = acc[r];
+                            { float *q_ = a.gxb + ((size_t)b * a.Cb + (i - a.Ca)) * V + v; *q_ = acc[r] + (a.accum ? *q_ : 0.f); }
                         }
                     }
                 }
@@ -474,6 +475,7 @@ __global__ __launch_bounds__(64 * PWB_FAST_WAVES) void pwconv_bwd_fast_kernel(Pw
                     if (base && vin && (irow + 4 < CIN || h == 0) && !((a.dbg & 4) && acc[r] != 12345.678f)) {
                         float gv = acc[r];
                         if (a.xa_act != HNO_ACT_NONE && irow < a.Ca) gv *= act_grad_from_out(X[(irow + 4 * h) * PWB_LD + c], a.xa_act);
+                        if (a.accum) gv += base[hoff4V + v];
                         base[hoff4V + v] = gv;
                     }
                 }
@@ -579,7 +581,8 @@ int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const fl
 
 int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, const float *xb, int Cb,
                       const float *W, float *gxa, float *gxb, float *dW, float *dbias, void *workspace,
-                      int B, int Cout, long long V, int act, int residual, void *stream, int xa_act = HNO_ACT_NONE) {
+                      int B, int Cout, long long V, int act, int residual, void *stream, int xa_act = HNO_ACT_NONE,
+                      int accumulate_gx = 0) {
     HNO_REQUIRE(workspace, "hno_pwconv_bwd: workspace of hno_pwconv_bwd_workspace_bytes() is required");
     HNO_REQUIRE(gy && xa && W && dW && Ca > 0 && Cb >= 0 && B > 0 && Cout > 0 && V > 0, "hno_pwconv_bwd: bad argument");
     HNO_REQUIRE(act == HNO_ACT_NONE || y, "hno_pwconv_bwd: saved output y needed for the activation gradient");
@@ -596,6 +599,7 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
     a.residual = residual;
     a.dbg = debug_flags();
     a.xa_act = xa_act;
+    a.accum = accumulate_gx;
     const long long ntiles = ((V + 31) / 32) * B;
     int grid = grid_for(ntiles, 4);
     if (grid > 1024) grid = 1024;  // fewer blocks -> fewer dW atomics
@@ -659,8 +663,9 @@ extern "C" size_t hno_pwconv_bwd_workspace_bytes(int Cin, int Cout) {
 
 extern "C" int hno_pwconv_bwd(const float *gy, const float *y, const float *xa, int Ca, const float *xb, int Cb,
                               const float *W, float *gxa, float *gxb, float *dW, float *dbias, void *workspace,
-                              int B, int Cout, long long V, int act, int xa_act, void *stream) {
-    return pwconv_bwd_launch(gy, y, xa, Ca, xb, Cb, W, gxa, gxb, dW, dbias, workspace, B, Cout, V, act, 0, stream, xa_act);
+                              int B, int Cout, long long V, int act, int xa_act, int accumulate_gx, void *stream) {
+    return pwconv_bwd_launch(gy, y, xa, Ca, xb, Cb, W, gxa, gxb, dW, dbias, workspace, B, Cout, V, act, 0, stream, xa_act,
+                             accumulate_gx);
 }
 
 // Shared-weight spectral mix = L stacked pointwise layers over the mode axis with W + I.

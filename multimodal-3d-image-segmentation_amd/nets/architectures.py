@@ -33,16 +33,130 @@ class _TransBlock(nn.Module):
             # the operator adds the conv branch and applies the activation on store
             y = self.op.forward_fused(x, addend=x2, act=fuse_act)
         else:
-            from .elementwise import activation_forward
-            y = activation_forward(x2, fuse_act)
+            y = ops.ActFn.apply(x2, fuse_act) if fuse_act != ops.ACT_NONE else x2
         if self.normalization is not None:
             from .conv3d import group_norm_act
             y = group_norm_act(y, self.normalization, act)
         if self.use_block_skip:
             if self.conv_concat is not None:
                 return self.conv_concat(y, x)
-            return y + x
+            return ops.AddFn.apply(y, x)
         return y
+
+
+class NeuralOperatorBlock(_TransBlock):
+    """The FNO / HNO block (reference nets/architectures.py:551-608): spectral operator + 1x1x1 conv
+    branch -> activation -> block skip (concat conv, add, or none)."""
+
+    def __init__(self, in_channels, out_channels, num_modes, transform_type, weights_type='shared', ndim=5,
+                 activation='selu', device=None, use_conv_branch=True, use_bias_conv_branch=False, use_block_skip=True,
+                 use_block_concat=True):
+        super().__init__()
+        assert transform_type in ('Fourier', 'Hartley')
+        self.use_block_skip = use_block_skip
+        op = FourierOperator if transform_type == 'Fourier' else HartleyOperator
+        self.op = op(in_channels, out_channels, num_modes, use_bias=False, weights_type=weights_type, ndim=ndim,
+                     device=device)
+        if use_conv_branch:
+            conv = nn.Conv2d if ndim == 4 else nn.Conv3d
+            self.conv_branch = conv(in_channels, out_channels, kernel_size=1, bias=use_bias_conv_branch, device=device)
+        if not _is_selu(activation):
+            self.normalization = nn.GroupNorm(1, out_channels, device=device)
+        self.activation = getattr(nn.functional, activation) if isinstance(activation, str) else activation
+        if self.use_block_skip and use_block_concat:
+            self.conv_concat = ConvNormAct(in_channels + out_channels, out_channels, use_bias=True, activation=activation,
+                                           ndim=ndim, device=device)
+
+
+class _TransSeg(nn.Module):
+    """Common body of NeuralOperatorSeg and HartleyMHASeg (reference nets/architectures.py:255-353)."""
+
+    def __init__(self):
+        super().__init__()
+        self.in_channels = self.out_channels = self.filters = self.num_transform_blocks = None
+        self.use_resize = self.use_deep_supervision = self.activation = self.output_activation = None
+        self.ndim = self.device = self.block = None
+        self.conv_in = self.conv1 = self.layers = self.conv_out = self.conv_ds = None
+
+    def create_layers(self):
+        ds_channels = []
+        cur = self.in_channels
+        if self.use_resize:
+            self.conv_in = ConvNormAct(cur, self.filters, kernel_size=2, stride=2, use_bias=True,
+                                       activation=self.activation, ndim=self.ndim, device=self.device)
+            cur = self.filters
+        self.conv1 = ConvNormAct(cur, self.filters, use_bias=True, activation=self.activation, ndim=self.ndim,
+                                 device=self.device)
+        cur = self.filters
+        if self.use_deep_supervision:
+            ds_channels.append(cur)
+        self.layers = nn.ModuleList()
+        for _ in range(self.num_transform_blocks):
+            self.layers.append(self.block(cur, self.filters))
+            cur = self.filters
+            if self.use_deep_supervision:
+                ds_channels.append(cur)
+        if ds_channels:
+            cur = sum(ds_channels)
+            self.conv_ds = ConvNormAct(cur, self.out_channels, use_bias=True, activation=self.activation, ndim=self.ndim,
+                                       device=self.device)
+            cur = self.out_channels
+        conv = nn.Conv2d if self.ndim == 4 else nn.Conv3d
+        self.conv_out = conv(cur, self.out_channels, kernel_size=1, bias=False, device=self.device)
+        self._softmax = self.output_activation == 'softmax'
+        if isinstance(self.output_activation, str):
+            fn = getattr(nn.functional, self.output_activation)
+            self.output_activation = partial(fn, dim=1) if self._softmax else fn
+        if _is_selu(self.activation):
+            self.apply(init_weights_for_snn)
+
+    def forward(self, x):
+        if x.ndim != 5:
+            raise NotImplementedError('2-D (ndim=4) models are not provided by the HIP path yet')
+        image_size = tuple(x.shape[2:])
+        tensors = []
+        if self.use_resize:
+            x = self.conv_in(x)
+        x = self.conv1(x)
+        if self.use_deep_supervision:
+            tensors.append(x)
+        for layer in self.layers:
+            x = layer(x)
+            if self.use_deep_supervision:
+                tensors.append(x)
+        if tensors:
+            from .deep_supervision import conv_over_concat
+            x = conv_over_concat(self.conv_ds, tensors)
+        # conv_out commutes with the per-channel trilinear interpolation: run it at low resolution
+        logits = ops.PwConvFn.apply(x, None, self.conv_out.weight, None, ops.ACT_NONE)
+        if not (self._softmax or self.output_activation is None):
+            raise NotImplementedError('only softmax / None output activations are provided by the HIP path')
+        y = ops.UpSoftmaxFn.apply(logits, image_size if self.use_resize else tuple(logits.shape[2:]), self._softmax)
+        return spatial_padcrop(y, image_size)
+
+
+class NeuralOperatorSeg(_TransSeg):
+    """FNO / FNOSeg / HNOSeg by arguments (reference nets/architectures.py:356-429); same constructor."""
+
+    def __init__(self, in_channels, out_channels, filters, num_transform_blocks, num_modes, transform_type,
+                 weights_type='shared', use_resize=True, use_deep_supervision=False, use_bias_conv_branch=False,
+                 use_block_skip=True, use_block_concat=True, activation='selu',
+                 output_activation: Union[str, callable] = 'softmax', ndim=5, device=None):
+        super().__init__()
+        self.in_channels, self.out_channels, self.filters = in_channels, out_channels, filters
+        self.num_transform_blocks, self.num_modes = num_transform_blocks, num_modes
+        self.transform_type, self.weights_type = transform_type, weights_type
+        self.use_resize, self.use_deep_supervision = use_resize, use_deep_supervision
+        self.use_bias_conv_branch, self.use_block_skip, self.use_block_concat = use_bias_conv_branch, use_block_skip, use_block_concat
+        self.activation, self.output_activation = activation, output_activation
+        self.ndim, self.device = ndim, device
+        assert self.transform_type in ('Fourier', 'Hartley')
+        assert self.ndim in (4, 5)
+        self.block = partial(NeuralOperatorBlock, num_modes=num_modes, transform_type=transform_type,
+                             weights_type=weights_type, ndim=ndim, activation=activation, device=device,
+                             use_bias_conv_branch=use_bias_conv_branch, use_block_skip=use_block_skip,
+                             use_block_concat=use_block_concat)
+        self.create_layers()
 
 
 class _Pending(nn.Module):
@@ -50,10 +164,6 @@ class _Pending(nn.Module):
     def __init__(self, *args, **kwargs):
         super().__init__()
         raise NotImplementedError(f'{type(self).__name__} is not provided by the HIP path yet')
-
-
-class NeuralOperatorSeg(_Pending):
-    pass
 
 
 class HartleyMHASeg(_Pending):

@@ -49,3 +49,8 @@ class FourierOperator(Module):
     def forward(self, inputs):
         from .spectral_fourier import fourier_operator_forward
         return fourier_operator_forward(self, inputs)
+
+    def forward_fused(self, inputs, addend=None, act=ops.ACT_NONE):
+        """act(self(inputs) + addend), add and activation fused into the inverse transform's store."""
+        from .spectral_fourier import fourier_operator_forward
+        return fourier_operator_forward(self, inputs, addend, act)

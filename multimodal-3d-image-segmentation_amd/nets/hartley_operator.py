@@ -62,11 +62,21 @@ class HartleyOperator(Module):
 
     def _mix(self, z):
         if self.weights_type == 'shared':
-            return ops.SpecMixFn.apply(z, self.weight.unsqueeze(0), 0, ops.ACT_NONE)
+            return ops.PwConvFn.apply(z, None, self.weight, None, ops.ACT_NONE)   # 'oi,bidhw->bodhw'
         from .spectral_individual import hartley_mix_individual
         return hartley_mix_individual(z, self.weight)
 
-    def _call3d(self, inputs):
+    def forward_fused(self, inputs, addend=None, act=ops.ACT_NONE):
+        """act(self(inputs) + addend) with the add and the activation fused into the inverse transform's
+        store (the block pattern of nets/architectures.py:521-539)."""
+        if not self.use_transform or addend is None and act == ops.ACT_NONE:
+            y = self(inputs)
+            if addend is not None:
+                y = ops.AddFn.apply(y, addend)
+            return ops.ActFn.apply(y, act) if act != ops.ACT_NONE else y
+        return self._call3d(inputs, addend, act)
+
+    def _call3d(self, inputs, addend=None, act=ops.ACT_NONE):
         spatial = tuple(inputs.shape[2:])
         modes = self.num_modes
         if self.weights_type == 'shared':
@@ -80,8 +90,10 @@ class HartleyOperator(Module):
         z = ops.DhtCropFn.apply(inputs, modes, 1.0 / n3)
         if self.weights_type == 'shared':
             # selu(0) = 0, so SELU on the padded spectrum == SELU on the kept block
-            z = ops.SpecMixFn.apply(z, self.weight.unsqueeze(0), 0, ops.ACT_SELU)
+            z = ops.PwConvFn.apply(z, None, self.weight, None, ops.ACT_SELU)
         else:
             from .spectral_individual import hartley_mix_individual
             z = hartley_mix_individual(z, self.weight, act=ops.ACT_SELU, full_spatial=spatial)
-        return ops.PadIdhtFn.apply(z, spatial, 1.0, ops.ACT_NONE)
+        if addend is None:
+            return ops.PadIdhtFn.apply(z, spatial, 1.0, act)
+        return ops.PadIdhtAddFn.apply(z, addend, spatial, 1.0, act)

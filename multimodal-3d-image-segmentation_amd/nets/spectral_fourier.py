@@ -1,0 +1,36 @@
+"""FourierOperator forward on the HIP kernels (reference nets/fourier_operator.py:90-223).
+
+The kept half spectrum is carried as REAL data (B, 2C, 2m0, 2m1, m2) with channels [re | im], so
+the complex channel mix  Y = (Wr + i Wi) X  is two real pointwise convolutions over the mode axis:
+    Yr = [Wr, -Wi] [Xr ; Xi],   Yi = [Wi,  Wr] [Xr ; Xi]
+(the same MFMA kernels as every other 1x1x1 conv; autograd splits the weight gradients back into
+weight_real / weight_imag through the two tiny torch.cat nodes).
+"""
+import numpy as np
+import torch
+
+from .. import ops
+
+
+def complex_mix_shared(spec, weight_real, weight_imag):
+    w1 = torch.cat([weight_real, -weight_imag], dim=1)
+    w2 = torch.cat([weight_imag, weight_real], dim=1)
+    yr = ops.PwConvFn.apply(spec, None, w1, None, ops.ACT_NONE)
+    yi = ops.PwConvFn.apply(spec, None, w2, None, ops.ACT_NONE)
+    return torch.cat([yr, yi], dim=1)
+
+
+def fourier_operator_forward(op, inputs, addend=None, act=ops.ACT_NONE):
+    if inputs.ndim != 5:
+        raise NotImplementedError('2-D (ndim=4) FourierOperator is not provided by the HIP path yet')
+    if op.weights_type != 'shared':
+        raise NotImplementedError('FourierOperator(weights_type="individual") is not provided by the HIP path yet')
+    if not op.use_transform:
+        raise NotImplementedError('FourierOperator(use_transform=False) takes complex inputs; not provided by the HIP path')
+    if op.use_bias:
+        raise NotImplementedError('FourierOperator(use_bias=True) is not provided by the HIP path yet')
+    spatial = tuple(inputs.shape[2:])
+    modes = ops.clamp_modes(op.num_modes, spatial)
+    spec = ops.RfftCropFn.apply(inputs, modes)
+    spec = complex_mix_shared(spec, op.weight_real, op.weight_imag)
+    return ops.IrfftPadFn.apply(spec, addend, spatial, act)

@@ -72,6 +72,40 @@ def pad_idht3_raw(z, spatial, scale, addend=None, act=ACT_NONE):
     return out
 
 
+def rfft3_crop_raw(x, modes, scale, k2_weights=False, act_out=None, act=ACT_NONE):
+    """x (B,C,N0,N1,N2) -> kept half spectrum as real data (B, 2C, 2m0, 2m1, m2): channels [re | im]."""
+    _need_gpu(x, act_out)
+    B, C, N0, N1, N2 = x.shape
+    m0, m1, m2 = modes
+    L = _lib.lib()
+    ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, N0, N1, N2, m0, m1, m2) // 4, device=x.device, dtype=torch.float32)
+    out = torch.empty((B, 2 * C, 2 * m0, 2 * m1, m2), device=x.device, dtype=torch.float32)
+    check(L.hno_rfft3_crop(ptr(x), ptr(act_out), act if act_out is not None else ACT_NONE, ptr(out), ptr(ws), B, C,
+                           N0, N1, N2, m0, m1, m2, float(scale), int(k2_weights), stream_ptr()), 'hno_rfft3_crop')
+    return out
+
+
+def irfft3_pad_raw(spec, spatial, scale, k2_weights=True, addend=None, act=ACT_NONE):
+    """spec (B, 2C, 2m0, 2m1, m2) -> (B, C, N0, N1, N2) = act(scale * irfft-style inverse + addend)."""
+    _need_gpu(spec, addend)
+    B, C2 = spec.shape[:2]
+    C = C2 // 2
+    m0, m1, m2 = spec.shape[2] // 2, spec.shape[3] // 2, spec.shape[4]
+    N0, N1, N2 = (int(v) for v in spatial)
+    L = _lib.lib()
+    ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, N0, N1, N2, m0, m1, m2) // 4, device=spec.device, dtype=torch.float32)
+    out = torch.empty((B, C, N0, N1, N2), device=spec.device, dtype=torch.float32)
+    check(L.hno_irfft3_pad(ptr(spec), ptr(addend), act, ptr(out), ptr(ws), B, C, N0, N1, N2, m0, m1, m2, float(scale),
+                           int(k2_weights), stream_ptr()), 'hno_irfft3_pad')
+    return out
+
+
+def act_bwd_raw(g, y, act):
+    gx = torch.empty_like(g)
+    check(_lib.lib().hno_act_bwd(ptr(g), ptr(y), ptr(gx), g.numel(), act, stream_ptr()), 'hno_act_bwd')
+    return gx
+
+
 def _flat_v(t):
     return int(np.prod(t.shape[2:]))
 
@@ -92,19 +126,22 @@ def pwconv_fwd_raw(xa, xb, W, bias, act):
     return y
 
 
-def pwconv_bwd_raw(gy, y, xa, xb, W, act, has_bias, need_gxa=True, need_gxb=True, xa_act=ACT_NONE):
+def pwconv_bwd_raw(gy, y, xa, xb, W, act, has_bias, need_gxa=True, need_gxb=True, xa_act=ACT_NONE, accumulate_into=None):
     """-> (gxa, gxb, dW, dbias); y is the saved output (None when act is NONE).  xa_act: also multiply
     gxa by act'(xa) (xa being the output of that activation)."""
     B, Ca = xa.shape[:2]
     Cb = xb.shape[1] if xb is not None else 0
     Cout, V = W.shape[0], _flat_v(xa)
-    gxa = torch.empty_like(xa) if need_gxa else None
-    gxb = torch.empty_like(xb) if (xb is not None and need_gxb) else None
+    if accumulate_into is not None:      # (gxa, gxb) buffers that already hold a gradient: += fused into the store
+        gxa, gxb = accumulate_into
+    else:
+        gxa = torch.empty_like(xa) if need_gxa else None
+        gxb = torch.empty_like(xb) if (xb is not None and need_gxb) else None
     dW = torch.empty_like(W)
     db = torch.empty(Cout, device=W.device, dtype=torch.float32) if has_bias else None
     ws = _wgrad_ws(Ca + Cb, Cout, xa.device)
     check(_lib.lib().hno_pwconv_bwd(ptr(gy), ptr(y), ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(gxa), ptr(gxb), ptr(dW),
-                                    ptr(db), ptr(ws), B, Cout, V, act, xa_act, stream_ptr()), 'hno_pwconv_bwd')
+                                    ptr(db), ptr(ws), B, Cout, V, act, xa_act, int(accumulate_into is not None), stream_ptr()), 'hno_pwconv_bwd')
     return gxa, gxb, dW, db
 
 
@@ -160,6 +197,97 @@ class PadIdhtFn(torch.autograd.Function):
     def backward(ctx, g):
         out = ctx.saved_tensors[0] if ctx.act != ACT_NONE else None
         return dht3_crop_raw(_f32c(g), ctx.modes, ctx.scale, out, ctx.act), None, None, None
+
+
+class PadIdhtAddFn(torch.autograd.Function):
+    """act(scale * PadInverse(z) + addend): the operator output plus the spatial conv branch, activated
+    (nets/architectures.py:521-539 with HartleyOperator._call3d :243-269 feeding it)."""
+
+    @staticmethod
+    def forward(ctx, z, addend, spatial, scale, act):
+        z, addend = _f32c(z), _f32c(addend)
+        out = pad_idht3_raw(z, spatial, scale, addend, act)
+        ctx.modes, ctx.scale, ctx.act = tuple(s // 2 for s in z.shape[2:]), scale, act
+        ctx.save_for_backward(out if act != ACT_NONE else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        g = _f32c(g)
+        gz = dht3_crop_raw(g, ctx.modes, ctx.scale, out, ctx.act)
+        ga = None
+        if ctx.needs_input_grad[1]:
+            ga = act_bwd_raw(g, out, ctx.act) if ctx.act != ACT_NONE else g
+        return gz, ga, None, None, None
+
+
+class RfftCropFn(torch.autograd.Function):
+    """rfftn(norm='forward') + corner gather (nets/fourier_operator.py:164-191) -> (B, 2C, 2m0, 2m1, m2)."""
+
+    @staticmethod
+    def forward(ctx, x, modes):
+        x = _f32c(x)
+        ctx.spatial = tuple(x.shape[2:])
+        ctx.scale = 1.0 / float(np.prod(ctx.spatial))
+        return rfft3_crop_raw(x, modes, ctx.scale, False)
+
+    @staticmethod
+    def backward(ctx, g):
+        return irfft3_pad_raw(_f32c(g), ctx.spatial, ctx.scale, False), None
+
+
+class IrfftPadFn(torch.autograd.Function):
+    """act(zero-pad + irfftn(norm='forward') + addend) (nets/fourier_operator.py:195-209)."""
+
+    @staticmethod
+    def forward(ctx, spec, addend, spatial, act):
+        spec, addend = _f32c(spec), _f32c(addend)
+        out = irfft3_pad_raw(spec, spatial, 1.0, True, addend, act)
+        ctx.modes, ctx.act = (spec.shape[2] // 2, spec.shape[3] // 2, spec.shape[4]), act
+        ctx.save_for_backward(out if act != ACT_NONE else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        g = _f32c(g)
+        gs = rfft3_crop_raw(g, ctx.modes, 1.0, True, out, ctx.act)
+        ga = None
+        if ctx.needs_input_grad[1]:
+            ga = act_bwd_raw(g, out, ctx.act) if ctx.act != ACT_NONE else g
+        return gs, ga, None, None
+
+
+class ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        x = _f32c(x)
+        _need_gpu(x)
+        y = torch.empty_like(x)
+        check(_lib.lib().hno_act_fwd(ptr(x), ptr(y), x.numel(), act, stream_ptr()), 'hno_act_fwd')
+        ctx.act = act
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return act_bwd_raw(_f32c(g), y, ctx.act), None
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _f32c(a), _f32c(b)
+        _need_gpu(a, b)
+        out = torch.empty_like(a)
+        check(_lib.lib().hno_add(ptr(a), ptr(b), ptr(out), a.numel(), stream_ptr()), 'hno_add')
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
 
 
 class SpecMixFn(torch.autograd.Function):

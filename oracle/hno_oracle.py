@@ -344,6 +344,49 @@ def hnosegxs_forward(sd, x, num_transform_blocks, num_modes, use_resize=True, us
 
 
 # --------------------------------------------------------------------------------------
+# FNO / FNOSeg / HNOSeg (nets/architectures.py:255-429, 511-608)
+# --------------------------------------------------------------------------------------
+def neural_operator_block(sd, prefix, x, modes, transform_type, weights_type='shared', act='selu',
+                          use_block_skip=True):
+    """_TransBlock.forward (nets/architectures.py:521-548) for NeuralOperatorBlock (SELU: no normalisation)."""
+    if transform_type == 'Hartley':
+        x1 = hartley_operator(x, sd[f'{prefix}.op.weight'], modes, None, weights_type, True)
+    else:
+        x1 = fourier_operator(x, sd[f'{prefix}.op.weight_real'], sd[f'{prefix}.op.weight_imag'], modes, None, weights_type)
+    y = x1
+    if f'{prefix}.conv_branch.weight' in sd:
+        conv = F.conv3d if x.ndim == 5 else F.conv2d
+        y = y + conv(x, sd[f'{prefix}.conv_branch.weight'], sd.get(f'{prefix}.conv_branch.bias'))
+    y = _activate(y, act)
+    if use_block_skip:
+        if f'{prefix}.conv_concat.op.weight' in sd:
+            return conv_act(torch.cat([y, x], dim=1), sd[f'{prefix}.conv_concat.op.weight'],
+                            sd[f'{prefix}.conv_concat.op.bias'], act=act)
+        return y + x
+    return y
+
+
+def neural_operator_seg_forward(sd, x, num_transform_blocks, num_modes, transform_type, weights_type='shared',
+                                use_resize=True, use_block_skip=True, act='selu', output_activation='softmax'):
+    """_TransSeg.forward (nets/architectures.py:325-353) without deep supervision."""
+    nd = x.ndim - 2
+    image_size = tuple(x.shape[-nd:])
+    if np.isscalar(num_modes):
+        num_modes = (num_modes,) * nd
+    h = x
+    if use_resize:
+        h = conv_act(h, sd['conv_in.op.weight'], sd['conv_in.op.bias'], stride=2, act=act)
+    h = conv_act(h, sd['conv1.op.weight'], sd['conv1.op.bias'], act=act)
+    for i in range(num_transform_blocks):
+        h = neural_operator_block(sd, f'layers.{i}', h, num_modes, transform_type, weights_type, act, use_block_skip)
+    if use_resize:
+        h = F.interpolate(h, size=image_size, mode='trilinear' if nd == 3 else 'bilinear')
+    conv = F.conv3d if nd == 3 else F.conv2d
+    h = spatial_padcrop(conv(h, sd['conv_out.weight']), image_size)
+    return F.softmax(h, dim=1) if output_activation == 'softmax' else _activate(h, output_activation)
+
+
+# --------------------------------------------------------------------------------------
 # Losses (nets/custom_losses.py) and label handling (experiments/utils.py:74-119)
 # --------------------------------------------------------------------------------------
 def corrcoef(y_pred, y_true):

@@ -128,3 +128,18 @@ class _TrainInput:
 
 def make_train_input():
     return _TrainInput()
+
+
+# tiny NeuralOperatorSeg variants (golden G7): name -> (ctor kwargs, input shape)
+NOSEG_MODELS = {
+    'hnoseg': (dict(in_channels=2, out_channels=3, filters=8, num_transform_blocks=3, num_modes=(4, 5, 5),
+                    transform_type='Hartley'), (1, 2, 24, 20, 28)),
+    'fnoseg': (dict(in_channels=2, out_channels=3, filters=8, num_transform_blocks=3, num_modes=(4, 5, 5),
+                    transform_type='Fourier'), (1, 2, 24, 20, 28)),
+    'fnoseg_addskip_bias': (dict(in_channels=1, out_channels=2, filters=8, num_transform_blocks=2, num_modes=(3, 3, 4),
+                                 transform_type='Fourier', use_block_concat=False, use_bias_conv_branch=True),
+                            (2, 1, 18, 22, 26)),
+    'hnoseg_noskip_clamped': (dict(in_channels=2, out_channels=2, filters=8, num_transform_blocks=2,
+                                   num_modes=(10, 14, 14), transform_type='Hartley', use_block_skip=False),
+                              (1, 2, 16, 20, 24)),
+}

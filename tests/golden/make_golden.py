@@ -16,7 +16,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from _inputs import formula_tensor, formula_labels, sample_indices, CROP_CASES, SMALL_MODELS  # noqa: E402
+from _inputs import formula_tensor, formula_labels, sample_indices, CROP_CASES, SMALL_MODELS, NOSEG_MODELS  # noqa: E402
 
 REF = sys.argv[1] if len(sys.argv) > 1 else '/root/reference'
 sys.path.insert(0, REF)
@@ -251,6 +251,30 @@ def g9_misc():
     save('g9_misc.npz', **out)
 
 
+# ---------------------------------------------- G7: tiny FNOSeg / HNOSeg variants (strict 1e-4)
+def g7_noseg_models():
+    from _inputs import formula_volume
+    out = {}
+    for name, (kw, shape) in NOSEG_MODELS.items():
+        torch.manual_seed(21)
+        model = nets.NeuralOperatorSeg(**kw)
+        for k, v in model.state_dict().items():
+            out[f'{name}::sd::{k}'] = v.detach().numpy().copy()
+        K = kw['out_channels']
+        x = T(formula_volume(shape, 4))
+        lab = formula_labels((shape[0], 1) + shape[2:], K, 6)
+        onehot = torch.movedim(torch.nn.functional.one_hot(T(lab)[:, 0].long(), K).float(), -1, 1)
+        model.zero_grad()
+        y = model(x)
+        loss = custom_losses.PCCLoss()(y, onehot)
+        loss.backward()
+        out[f'{name}::y'] = y.detach().numpy()
+        out[f'{name}::loss'] = loss.detach().numpy()
+        for k, p in model.named_parameters():
+            out[f'{name}::grad::{k}'] = p.grad.detach().numpy().copy()
+    save('g7_noseg_models.npz', **out)
+
+
 # ----------------------------------------------- G8: training-loop trajectory of the reference
 def _stub_missing_modules():
     sys.modules.setdefault('SimpleITK', type(sys)('SimpleITK'))
@@ -305,5 +329,6 @@ if __name__ == '__main__':
     g5_losses()
     g6_hnosegxs()
     g6s_small_models()
+    g7_noseg_models()
     g9_misc()
     g8_training()

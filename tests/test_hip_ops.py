@@ -301,3 +301,68 @@ def test_small_models_strict_parity(pkg, name, loss_name):
     assert abs(float(loss.detach()) - float(g[f'{name}::{loss_name}::loss'])) < 1e-5
     for k, p in model.named_parameters():
         assert rel_err(p.grad.cpu().numpy(), g[f'{name}::{loss_name}::grad::{k}']) < TOL, k
+
+
+from _inputs import NOSEG_MODELS  # noqa: E402
+
+
+@pytest.mark.parametrize('name', list(NOSEG_MODELS))
+def test_noseg_models_strict_parity(pkg, name):
+    """FNOSeg / HNOSeg (NeuralOperatorSeg) variants -- Fourier and Hartley operators, concat / add / no
+    block skip, biased conv branch, clamped modes: outputs, loss, all gradients within 1e-4 of the
+    reference's fp32 results (golden G7)."""
+    from multimodal_3d_image_segmentation_amd.nets import custom_losses
+    g = load_golden('g7_noseg_models.npz')
+    kw, shape = NOSEG_MODELS[name]
+    model = pkg.nets.NeuralOperatorSeg(**kw)
+    pre = f'{name}::sd::'
+    model.load_state_dict({k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)})
+    model = model.cuda()
+    K = kw['out_channels']
+    x = T(formula_volume(shape, 4))
+    lab = T(formula_labels((shape[0], 1) + shape[2:], K, 6))
+    y = model(x)
+    loss = custom_losses.PCCLoss()(y, pkg.ops.labels_prepare(lab, K))
+    loss.backward()
+    assert rel_err(y.detach().cpu().numpy(), g[f'{name}::y']) < TOL
+    assert abs(float(loss.detach()) - float(g[f'{name}::loss'])) < 1e-5
+    for k, p in model.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), g[f'{name}::grad::{k}']) < TOL, k
+
+
+def _op_cases():
+    case = 0
+    for name in ('hartley', 'fourier'):
+        for wt in ('shared', 'individual'):
+            for use_transform in (True, False):
+                for use_bias in (False, True):
+                    yield name, wt, use_transform, use_bias, case
+                    case += 1
+
+
+@pytest.mark.parametrize('name,wt,use_transform,use_bias,case',
+                         [c for c in _op_cases() if c[1] == 'shared' and not c[3] and (c[2] or c[0] == 'hartley')])
+def test_operator_modules_vs_golden(pkg, name, wt, use_transform, use_bias, case):
+    """HartleyOperator / FourierOperator modules (shared weights) against the reference (golden G3)."""
+    from multimodal_3d_image_segmentation_amd.nets.hartley_operator import HartleyOperator
+    from multimodal_3d_image_segmentation_amd.nets.fourier_operator import FourierOperator
+    g = load_golden('g3_operators.npz')
+    ci_, co_, sp, modes = 3, 4, (12, 10, 14), (3, 2, 4)
+    key = f'{name}_{wt}_t{int(use_transform)}_b{int(use_bias)}'
+    cls = HartleyOperator if name == 'hartley' else FourierOperator
+    op = cls(ci_, co_, modes, use_bias=use_bias, weights_type=wt, use_transform=use_transform)
+    with torch.no_grad():
+        for pn, p in op.named_parameters():
+            p.copy_(torch.from_numpy(g[f'{key}_p_{pn}']))
+    op = op.cuda()
+    if use_transform:
+        x = T(formula_tensor((2, ci_) + sp, 50)).requires_grad_(True)
+    else:
+        x = T(formula_tensor((2, ci_) + tuple(2 * m for m in modes), 70 + case)).requires_grad_(True)
+    y = op(x)
+    assert rel_err(y.detach().cpu().numpy(), g[f'{key}_y']) < TOL
+    cot = T(formula_tensor(tuple(y.shape), 80 + case))
+    grads = torch.autograd.grad((y * cot).sum(), [x] + list(op.parameters()))
+    assert rel_err(grads[0].cpu().numpy(), g[f'{key}_gx']) < TOL
+    for (pn, _), gp in zip(op.named_parameters(), grads[1:]):
+        assert rel_err(gp.cpu().numpy(), g[f'{key}_g_{pn}']) < TOL, pn

@@ -199,3 +199,25 @@ def test_small_models_oracle(name):
         assert abs(float(loss.detach()) - float(g[f'{name}::{lname}::loss'])) < 1e-6
         for k, p in params.items():
             assert rel_err(_np(p.grad), g[f'{name}::{lname}::grad::{k}']) < 1e-4, k
+
+
+from _inputs import NOSEG_MODELS  # noqa: E402
+
+
+@pytest.mark.parametrize('name', list(NOSEG_MODELS))
+def test_noseg_models_oracle(name):
+    g = load_golden('g7_noseg_models.npz')
+    kw, shape = NOSEG_MODELS[name]
+    pre = f'{name}::sd::'
+    params = {k[len(pre):]: T(g[k]).requires_grad_(True) for k in g.files if k.startswith(pre)}
+    K = kw['out_channels']
+    x = T(formula_volume(shape, 4))
+    lab = T(formula_labels((shape[0], 1) + shape[2:], K, 6))
+    y = O.neural_operator_seg_forward(params, x, kw['num_transform_blocks'], kw['num_modes'], kw['transform_type'],
+                                      use_block_skip=kw.get('use_block_skip', True))
+    loss = O.pcc_loss(y, O.to_categorical(lab, K))
+    loss.backward()
+    assert rel_err(_np(y), g[f'{name}::y']) < 1e-5
+    assert abs(float(loss.detach()) - float(g[f'{name}::loss'])) < 1e-6
+    for k, p in params.items():
+        assert rel_err(_np(p.grad), g[f'{name}::grad::{k}']) < 1e-4, k

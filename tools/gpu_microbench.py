@@ -39,7 +39,7 @@ if which in ('all', 'pwbwd'):
     dW, db = torch.empty_like(W), torch.empty_like(bias)
     ws = torch.empty(L.hno_pwconv_bwd_workspace_bytes(48, 24) // 4, device=dev)
     P, S = pkg._lib.ptr, pkg._lib.stream_ptr
-    call = lambda: L.hno_pwconv_bwd(P(gy), P(y), P(xa), 24, P(xb), 24, P(W), P(gxa), P(gxb), P(dW), P(db), P(ws), B, 24, N ** 3, 1, 0, S())
+    call = lambda: L.hno_pwconv_bwd(P(gy), P(y), P(xa), 24, P(xb), 24, P(W), P(gxa), P(gxb), P(dW), P(db), P(ws), B, 24, N ** 3, 1, 0, 0, S())
     for dbg, name in ((0, 'full'), (1, 'no dgrad mfma'), (2, 'no wgrad mfma'), (3, 'no mfma'), (4, 'no gx stores'), (7, 'loads+lds only')):
         L.hno_set_debug(dbg)
         t = timeit(call)
