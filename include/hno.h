@@ -135,6 +135,13 @@ int hno_upsoftmax_fwd(const float *logits_lr, float *probs, int B, int K, int d,
 int hno_upsoftmax_bwd(const float *g_probs, const float *probs, float *g_lr, int B, int K, int d, int h, int w,
                       int D, int H, int W, int softmax, void *stream);
 
+/* ------------------------------------------------------------------------ batched GEMM
+ * C[b] = alpha * op(A[b]) * op(B[b]) for b < batch; contiguous row-major operands, op = transpose when
+ * the flag is set (A is M x K, or K x M when transA; B is K x N, or N x K when transB; C is M x N).
+ * Replaces the two einsums of the Hartley attention (nets/hartley_mha.py:196-201) and their backward. */
+int hno_bmm(const float *A, const float *B, float *C, int batch, int M, int N, int K, int transA, int transB,
+            float alpha, void *stream);
+
 /* ------------------------------------------------------------------- elementwise helpers
  * y = act(x) ; gx = g * act'(y) (y = saved output) ; out = a + b.  Used where the reference applies an
  * activation or a residual add that no neighbouring kernel can absorb (nets/architectures.py:529-546). */

@@ -10,6 +10,7 @@ from torch import nn
 from .. import ops
 from .fourier_operator import FourierOperator
 from .hartley_operator import HartleyOperator
+from .hartley_mha import HartleyMultiHeadAttention
 from .nets_utils import ConvNormAct, ConvTransposeNormAct, init_weights_for_snn, spatial_padcrop, _is_selu
 
 
@@ -166,8 +167,47 @@ class _Pending(nn.Module):
         raise NotImplementedError(f'{type(self).__name__} is not provided by the HIP path yet')
 
 
-class HartleyMHASeg(_Pending):
-    pass
+class HartleyMHABlock(_TransBlock):
+    """Hartley-MHA block (reference nets/architectures.py:611-635)."""
+
+    def __init__(self, in_channels, key_dim, num_heads, num_modes, patch_size, attention_activation, ndim, activation,
+                 device, use_conv_branch=True, use_bias_conv_branch=False, use_block_skip=True, use_block_concat=True):
+        super().__init__()
+        self.use_block_skip = use_block_skip
+        self.op = HartleyMultiHeadAttention(in_channels, key_dim, num_heads, num_modes, patch_size, attention_activation,
+                                            ndim=ndim, device=device)
+        if use_conv_branch:
+            conv = nn.Conv2d if ndim == 4 else nn.Conv3d
+            self.conv_branch = conv(in_channels, key_dim, kernel_size=1, bias=use_bias_conv_branch, device=device)
+        if not _is_selu(activation):
+            self.normalization = nn.GroupNorm(1, key_dim, device=device)
+        self.activation = getattr(nn.functional, activation) if isinstance(activation, str) else activation
+        if self.use_block_skip and use_block_concat:
+            self.conv_concat = ConvNormAct(in_channels + key_dim, key_dim, use_bias=True, activation=activation, ndim=ndim,
+                                           device=device)
+
+
+class HartleyMHASeg(_TransSeg):
+    """HartleyMHA architecture (reference nets/architectures.py:432-508); same constructor."""
+
+    def __init__(self, in_channels, out_channels, filters, num_transform_blocks, num_heads, num_modes, patch_size,
+                 attention_activation='selu', use_resize=True, use_deep_supervision=True, use_bias_conv_branch=False,
+                 use_block_skip=True, use_block_concat=True, activation='selu',
+                 output_activation: Union[str, callable] = 'softmax', ndim=5, device=None):
+        super().__init__()
+        self.in_channels, self.out_channels, self.filters = in_channels, out_channels, filters
+        self.num_transform_blocks, self.num_heads = num_transform_blocks, num_heads
+        self.num_modes, self.patch_size, self.attention_activation = num_modes, patch_size, attention_activation
+        self.use_resize, self.use_deep_supervision = use_resize, use_deep_supervision
+        self.use_bias_conv_branch, self.use_block_skip, self.use_block_concat = use_bias_conv_branch, use_block_skip, use_block_concat
+        self.activation, self.output_activation = activation, output_activation
+        self.ndim, self.device = ndim, device
+        assert self.ndim in (4, 5)
+        self.block = partial(HartleyMHABlock, num_heads=num_heads, num_modes=num_modes, patch_size=patch_size,
+                             attention_activation=attention_activation, ndim=ndim, activation=activation, device=device,
+                             use_bias_conv_branch=use_bias_conv_branch, use_block_skip=use_block_skip,
+                             use_block_concat=use_block_concat)
+        self.create_layers()
 
 
 class VNetDS(_Pending):

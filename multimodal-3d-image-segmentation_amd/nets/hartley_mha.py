@@ -1,0 +1,140 @@
+"""Hartley multi-head attention on the HIP kernels (reference nets/hartley_mha.py:18-524).
+
+Frequency-domain self-attention: Hartley transform + mode truncation (hno_dht3_crop), per-head
+query/key/value projections (pointwise MFMA convs over the mode axis), patch grouping (pure index
+permutation), att = act(Q^T K / sqrt(C)) and out = V att^T on the batched fp32 MFMA GEMM (hno_bmm),
+output projection, zero pad + unscaled inverse transform (hno_pad_idht3).  SELU, not softmax, is the
+default attention activation, so no online normalisation is needed.
+"""
+import math
+from typing import Union
+
+import numpy as np
+import torch
+from torch.nn import Module, Parameter, init
+
+from .. import ops
+
+
+def grouping3d(x, patch_size):
+    """(B,Z,C,D,H,W) -> (B,Z,C*pd*ph*pw, D/pd, H/ph, W/pw): each new voxel is a patch of the old ones
+    (reference :473-498).  Index permutation only."""
+    pd, ph, pw = patch_size
+    b, z, c, d, h, w = x.shape
+    assert d % pd == 0 and h % ph == 0 and w % pw == 0
+    nd_, nh, nw = d // pd, h // ph, w // pw
+    x = x.reshape(b, z, c, nd_, pd, nh, ph, nw, pw).permute(0, 1, 2, 4, 6, 8, 3, 5, 7)
+    return x.reshape(b, z, c * pd * ph * pw, nd_, nh, nw)
+
+
+def ungrouping3d(x, num_channels, patch_size):
+    """Inverse of grouping3d (reference :501-524)."""
+    pd, ph, pw = patch_size
+    b, z, _, nd_, nh, nw = x.shape
+    c = num_channels
+    x = x.reshape(b, z, c, pd, ph, pw, nd_, nh, nw).permute(0, 1, 2, 6, 3, 7, 4, 8, 5)
+    return x.reshape(b, z, c, nd_ * pd, nh * ph, nw * pw)
+
+
+class HartleyMultiHeadAttention(Module):
+    """Same constructor and parameters as the reference (:49-114): weight_query/key (Z,K,Ci),
+    weight_value (Z,V,Ci), weight_out (V, V*Z), optional biases."""
+
+    def __init__(self, in_channels, key_dim, num_heads, num_modes, patch_size=None,
+                 attention_activation: Union[str, callable] = 'selu', value_dim=None, key_in_channels=None,
+                 value_in_channels=None, use_bias=False, use_transform=True, ndim=5, device=None, dtype=None):
+        super().__init__()
+        fk = {'device': device, 'dtype': dtype}
+        self.in_channels, self.key_dim, self.num_heads = in_channels, key_dim, num_heads
+        self.num_modes, self.patch_size = num_modes, patch_size
+        self.attention_activation = attention_activation
+        self.value_dim = value_dim or key_dim
+        self.key_in_channels = key_in_channels or in_channels
+        self.value_in_channels = value_in_channels or self.key_in_channels
+        self.use_bias, self.use_transform = use_bias, use_transform
+        if np.isscalar(self.num_modes):
+            self.num_modes = (self.num_modes,) * (ndim - 2)
+        else:
+            assert len(self.num_modes) == ndim - 2
+            self.num_modes = tuple(self.num_modes)
+        if np.isscalar(self.patch_size):
+            self.patch_size = (self.patch_size,) * (ndim - 2)
+        if isinstance(self.attention_activation, str):
+            self.attention_activation = getattr(torch.nn.functional, self.attention_activation)
+        self.weight_query = Parameter(torch.empty((num_heads, key_dim, self.in_channels), **fk))
+        self.weight_key = Parameter(torch.empty((num_heads, key_dim, self.key_in_channels), **fk))
+        self.weight_value = Parameter(torch.empty((num_heads, self.value_dim, self.value_in_channels), **fk))
+        self.weight_out = Parameter(torch.empty((self.value_dim, self.value_dim * num_heads), **fk))
+        if use_bias:
+            ones = (1,) * (ndim - 2)
+            self.bias_query = Parameter(torch.empty((1, num_heads, key_dim) + ones, **fk))
+            self.bias_key = Parameter(torch.empty((1, num_heads, key_dim) + ones, **fk))
+            self.bias_value = Parameter(torch.empty((1, num_heads, self.value_dim) + ones, **fk))
+            self.bias_out = Parameter(torch.empty((1, self.value_dim) + ones, **fk))
+        else:
+            for n in ('bias_query', 'bias_key', 'bias_value', 'bias_out'):
+                self.register_parameter(n, None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for w, b in ((self.weight_query, self.bias_query), (self.weight_key, self.bias_key),
+                     (self.weight_value, self.bias_value), (self.weight_out, self.bias_out)):
+            init.kaiming_uniform_(w, a=math.sqrt(5))
+            if b is not None:
+                init.zeros_(b)
+
+    # ------------------------------------------------------------------------------------
+    def forward(self, inputs):
+        return self.forward_fused(inputs)
+
+    def forward_fused(self, inputs, addend=None, act=ops.ACT_NONE):
+        """act(attention(inputs) + addend); add and activation fused into the inverse transform's store."""
+        if isinstance(inputs, (tuple, list)):
+            if len(inputs) not in (2, 3):
+                raise ValueError('Invalid inputs.')
+            srcs = list(inputs)
+        else:
+            srcs = [inputs]
+        if srcs[0].ndim != 5:
+            raise NotImplementedError('2-D (ndim=4) Hartley attention is not provided by the HIP path yet')
+        if self.use_bias:
+            raise NotImplementedError('HartleyMultiHeadAttention(use_bias=True) is not provided by the HIP path yet')
+        spatial = tuple(srcs[0].shape[2:])
+        modes = self.num_modes
+        if self.use_transform:
+            assert all(s >= 2 * m for s, m in zip(spatial, modes))      # no clamping here (reference :159-163)
+            n3 = float(np.prod(spatial))
+            specs = [ops.DhtCropFn.apply(t, modes, 1.0 / n3) for t in srcs]
+        else:
+            specs = srcs
+        q_src, k_src, v_src = specs[0], specs[min(1, len(specs) - 1)], specs[-1]
+        act_att = ops.act_id(self.attention_activation)
+        Z = self.num_heads
+        heads = []
+        for z in range(Z):                                              # freq_conv3d 'zoi,bidhw->bzodhw'
+            q = ops.PwConvFn.apply(q_src, None, self.weight_query[z], None, ops.ACT_NONE)
+            k = ops.PwConvFn.apply(k_src, None, self.weight_key[z], None, ops.ACT_NONE)
+            v = ops.PwConvFn.apply(v_src, None, self.weight_value[z], None, ops.ACT_NONE)
+            heads.append((q, k, v))
+        q = torch.stack([h[0] for h in heads], dim=1)                   # (B, Z, K, d, h, w)
+        k = torch.stack([h[1] for h in heads], dim=1)
+        v = torch.stack([h[2] for h in heads], dim=1)
+        if self.patch_size is not None:
+            q, k, v = (grouping3d(t, self.patch_size) for t in (q, k, v))
+        freq_shape = tuple(q.shape[3:])
+        q, k, v = (t.reshape(t.shape[0], Z, t.shape[2], -1).contiguous() for t in (q, k, v))   # (B, Z, C', T)
+        att = ops.BmmFn.apply(q, k, True, False, 1.0 / math.sqrt(k.shape[2]))                  # (B, Z, Tq, Tk)
+        if act_att != ops.ACT_NONE:
+            att = ops.ActFn.apply(att, act_att)
+        out = ops.BmmFn.apply(v, att, False, True, 1.0)                                         # (B, Z, C', Tq)
+        out = out.reshape(out.shape[0], Z, out.shape[2], *freq_shape)
+        if self.patch_size is not None:
+            out = ungrouping3d(out, self.value_dim, self.patch_size)
+        out = out.reshape(out.shape[0], Z * self.value_dim, *out.shape[3:]).contiguous()
+        out = ops.PwConvFn.apply(out, None, self.weight_out, None, ops.ACT_NONE)               # 'oi,bidhw->bodhw'
+        if not self.use_transform:
+            assert addend is None and act == ops.ACT_NONE
+            return out
+        if addend is None:
+            return ops.PadIdhtFn.apply(out, spatial, 1.0, act)
+        return ops.PadIdhtAddFn.apply(out, addend, spatial, 1.0, act)

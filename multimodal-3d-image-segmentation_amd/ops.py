@@ -259,6 +259,47 @@ class IrfftPadFn(torch.autograd.Function):
         return gs, ga, None, None
 
 
+def bmm_raw(A, B, transA, transB, alpha=1.0):
+    """(batch..., M|K, K|M) x (batch..., K|N, N|K) -> (batch..., M, N) on the fp32 matrix cores."""
+    _need_gpu(A, B)
+    lead = A.shape[:-2]
+    batch = int(np.prod(lead)) if lead else 1
+    M, K = (A.shape[-1], A.shape[-2]) if transA else (A.shape[-2], A.shape[-1])
+    N = B.shape[-2] if transB else B.shape[-1]
+    assert (B.shape[-1] if transB else B.shape[-2]) == K and B.shape[:-2] == lead
+    C = torch.empty(tuple(lead) + (M, N), device=A.device, dtype=torch.float32)
+    check(_lib.lib().hno_bmm(ptr(A), ptr(B), ptr(C), batch, M, N, K, int(transA), int(transB), float(alpha), stream_ptr()),
+          'hno_bmm')
+    return C
+
+
+class BmmFn(torch.autograd.Function):
+    """C = alpha * op(A) op(B), batched (nets/hartley_mha.py:196-201)."""
+
+    @staticmethod
+    def forward(ctx, A, B, transA, transB, alpha):
+        A, B = _f32c(A), _f32c(B)
+        ctx.save_for_backward(A, B)
+        ctx.cfg = (bool(transA), bool(transB), float(alpha))
+        return bmm_raw(A, B, transA, transB, alpha)
+
+    @staticmethod
+    def backward(ctx, g):
+        A, B = ctx.saved_tensors
+        tA, tB, alpha = ctx.cfg
+        g = _f32c(g)
+        # C = op(A) op(B): d op(A) = g op(B)^T, d op(B) = op(A)^T g; transpose back where op is a transpose
+        if not tA:
+            dA = bmm_raw(g, B, False, not tB, alpha)            # (M,N) x op(B)^T -> (M,K)
+        else:
+            dA = bmm_raw(B, g, tB, True, alpha)                 # op(B) g^T -> (K,M)
+        if not tB:
+            dB = bmm_raw(A, g, not tA, False, alpha)            # op(A)^T g -> (K,N)
+        else:
+            dB = bmm_raw(g, A, True, tA, alpha)                 # g^T op(A) -> (N,K)
+        return dA, dB, None, None, None
+
+
 class ActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, act):

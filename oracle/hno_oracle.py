@@ -387,6 +387,50 @@ def neural_operator_seg_forward(sd, x, num_transform_blocks, num_modes, transfor
 
 
 # --------------------------------------------------------------------------------------
+# Hartley multi-head attention (nets/hartley_mha.py:136-222, 473-524)
+# --------------------------------------------------------------------------------------
+def _group3d(x, patch):
+    pd, ph, pw = patch
+    b, z, c, d, h, w = x.shape
+    x = x.reshape(b, z, c, d // pd, pd, h // ph, ph, w // pw, pw).permute(0, 1, 2, 4, 6, 8, 3, 5, 7)
+    return x.reshape(b, z, c * pd * ph * pw, d // pd, h // ph, w // pw)
+
+
+def _ungroup3d(x, c, patch):
+    pd, ph, pw = patch
+    b, z, _, nd_, nh, nw = x.shape
+    x = x.reshape(b, z, c, pd, ph, pw, nd_, nh, nw).permute(0, 1, 2, 6, 3, 7, 4, 8, 5)
+    return x.reshape(b, z, c, nd_ * pd, nh * ph, nw * pw)
+
+
+def hartley_mha(x, wq, wk, wv, wo, modes, patch=None, att_act='selu', x_key=None, x_value=None):
+    """HartleyMultiHeadAttention._call for 3-D inputs without biases.  x_key / x_value: the optional second
+    and third inputs (key = value = second input when only two are given)."""
+    spatial = x.shape[-3:]
+    assert all(s >= 2 * m for s, m in zip(spatial, modes))
+    dims = (-3, -2, -1)
+    q_s = crop_modes(dhtn(x, dims), modes)
+    k_s = q_s if x_key is None else crop_modes(dhtn(x_key, dims), modes)
+    v_s = k_s if x_value is None else crop_modes(dhtn(x_value, dims), modes)
+    q = torch.einsum('zoi,bidhw->bzodhw', wq, q_s)
+    k = torch.einsum('zoi,bidhw->bzodhw', wk, k_s)
+    v = torch.einsum('zoi,bidhw->bzodhw', wv, v_s)
+    if patch is not None:
+        q, k, v = _group3d(q, patch), _group3d(k, patch), _group3d(v, patch)
+    fshape = q.shape[3:]
+    q, k, v = (t.reshape(t.shape[0], t.shape[1], t.shape[2], -1) for t in (q, k, v))
+    att = torch.einsum('bzcq,bzck->bzqk', q, k) / math.sqrt(k.shape[2])
+    att = _activate(att, att_act)
+    out = torch.einsum('bzqk,bzck->bzcq', att, v)
+    out = out.reshape(out.shape[0], out.shape[1], out.shape[2], *fshape)
+    if patch is not None:
+        out = _ungroup3d(out, wv.shape[1], patch)
+    out = out.reshape(out.shape[0], out.shape[1] * out.shape[2], *out.shape[3:])
+    out = torch.einsum('oi,bidhw->bodhw', wo, out)
+    return pad_inverse(out, spatial)
+
+
+# --------------------------------------------------------------------------------------
 # Losses (nets/custom_losses.py) and label handling (experiments/utils.py:74-119)
 # --------------------------------------------------------------------------------------
 def corrcoef(y_pred, y_true):

@@ -143,3 +143,14 @@ NOSEG_MODELS = {
                                    num_modes=(10, 14, 14), transform_type='Hartley', use_block_skip=False),
                               (1, 2, 16, 20, 24)),
 }
+
+
+# Hartley MHA operator cases (golden G4): (in_ch, key_dim, heads, modes, patch, n_inputs) on (1, 6, 12, 14, 12)
+MHA_CASES = [
+    (6, 4, 2, (2, 3, 2), (2, 1, 2), 1),
+    (6, 4, 2, (2, 3, 2), None, 1),
+    (6, 4, 3, (2, 2, 2), (2, 2, 2), 2),
+    (6, 5, 2, (3, 3, 2), None, 3),
+]
+MHASEG_MODEL = (dict(in_channels=2, out_channels=3, filters=8, num_transform_blocks=2, num_heads=2, num_modes=(4, 4, 6),
+                     patch_size=(2, 2, 2)), (1, 2, 24, 20, 28))

@@ -275,6 +275,46 @@ def g7_noseg_models():
     save('g7_noseg_models.npz', **out)
 
 
+# --------------------------------------------------------- G4: Hartley multi-head attention
+def g4_mha():
+    from _inputs import MHA_CASES, MHASEG_MODEL, formula_volume
+    from nets.hartley_mha import HartleyMultiHeadAttention
+    out = {}
+    shape = (1, 6, 12, 14, 12)
+    for ci, (cin, kd, heads, modes, patch, nin) in enumerate(MHA_CASES):
+        torch.manual_seed(300 + ci)
+        op = HartleyMultiHeadAttention(cin, kd, heads, modes, patch)
+        xs = [T(formula_tensor(shape, 90 + ci + 7 * j)).requires_grad_(True) for j in range(nin)]
+        y = op(xs[0] if nin == 1 else xs)
+        cot = T(formula_tensor(tuple(y.shape), 95 + ci))
+        params = dict(op.named_parameters())
+        gs = grads_of(y, cot, xs + list(params.values()))
+        k = f'm{ci}'
+        out[f'{k}_y'] = y.detach().numpy()
+        for j in range(nin):
+            out[f'{k}_gx{j}'] = gs[j]
+        for (pn, p), g in zip(params.items(), gs[nin:]):
+            out[f'{k}_p_{pn}'] = p.detach().numpy()
+            out[f'{k}_g_{pn}'] = g
+    kw, mshape = MHASEG_MODEL
+    torch.manual_seed(31)
+    model = nets.HartleyMHASeg(**kw)
+    for k, v in model.state_dict().items():
+        out[f'seg::sd::{k}'] = v.detach().numpy().copy()
+    K = kw['out_channels']
+    x = T(formula_volume(mshape, 8))
+    lab = formula_labels((mshape[0], 1) + mshape[2:], K, 9)
+    onehot = torch.movedim(torch.nn.functional.one_hot(T(lab)[:, 0].long(), K).float(), -1, 1)
+    y = model(x)
+    loss = custom_losses.PCCLoss()(y, onehot)
+    loss.backward()
+    out['seg::y'] = y.detach().numpy()
+    out['seg::loss'] = loss.detach().numpy()
+    for k, p in model.named_parameters():
+        out[f'seg::grad::{k}'] = p.grad.detach().numpy().copy()
+    save('g4_mha.npz', **out)
+
+
 # ----------------------------------------------- G8: training-loop trajectory of the reference
 def _stub_missing_modules():
     sys.modules.setdefault('SimpleITK', type(sys)('SimpleITK'))
@@ -326,6 +366,7 @@ if __name__ == '__main__':
     g1_dht()
     g2_crop_pad()
     g3_operators()
+    g4_mha()
     g5_losses()
     g6_hnosegxs()
     g6s_small_models()

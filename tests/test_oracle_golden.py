@@ -221,3 +221,25 @@ def test_noseg_models_oracle(name):
     assert abs(float(loss.detach()) - float(g[f'{name}::loss'])) < 1e-6
     for k, p in params.items():
         assert rel_err(_np(p.grad), g[f'{name}::grad::{k}']) < 1e-4, k
+
+
+from _inputs import MHA_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize('ci', range(len(MHA_CASES)))
+def test_hartley_mha_oracle(ci):
+    g = load_golden('g4_mha.npz')
+    cin, kd, heads, modes, patch, nin = MHA_CASES[ci]
+    k = f'm{ci}'
+    shape = (1, 6, 12, 14, 12)
+    xs = [T(formula_tensor(shape, 90 + ci + 7 * j)).requires_grad_(True) for j in range(nin)]
+    P = {n: T(g[f'{k}_p_{n}']).requires_grad_(True) for n in ('weight_query', 'weight_key', 'weight_value', 'weight_out')}
+    y = O.hartley_mha(xs[0], P['weight_query'], P['weight_key'], P['weight_value'], P['weight_out'], modes, patch,
+                      x_key=xs[1] if nin >= 2 else None, x_value=xs[2] if nin == 3 else None)
+    assert rel_err(_np(y), g[f'{k}_y']) < 2e-5
+    cot = T(formula_tensor(tuple(y.shape), 95 + ci))
+    gs = torch.autograd.grad((y * cot).sum(), xs + list(P.values()))
+    for j in range(nin):
+        assert rel_err(_np(gs[j]), g[f'{k}_gx{j}']) < 1e-4
+    for (pn, _), gp in zip(P.items(), gs[nin:]):
+        assert rel_err(_np(gp), g[f'{k}_g_{pn}']) < 1e-4, pn
