@@ -135,6 +135,20 @@ int hno_upsoftmax_fwd(const float *logits_lr, float *probs, int B, int K, int d,
 int hno_upsoftmax_bwd(const float *g_probs, const float *probs, float *g_lr, int B, int K, int d, int h, int w,
                       int D, int H, int W, int softmax, void *stream);
 
+/* ------------------------------------------------------- per-mode ('individual') spectral weights
+ * Hartley (fourier = 0): y(k) = 1/2 [W(k)(x(k) + xr(k)) + W(-k)(x(k) - xr(k))] with xr = the frequency-
+ *   reversed copy of x supplied by the caller (on the cropped grid or taken from the full spectrum) and
+ *   W(-k) the reversal of W on its own (d0,d1,d2) = (2m0,2m1,2m2) grid.  x, xr (B,Ci,M); w (Co,Ci,M).
+ *   Replaces hartley_conv + get_reverse (nets/hartley_operator.py:302-333).
+ * Fourier (fourier = 1): complex y(k) = W(k) x(k); x / y hold [re | im] planes (B,2,C,M), w / wi the real
+ *   and imaginary weights (Co,Ci,M).  Replaces einsum('oidhw,bidhw->bodhw') (nets/fourier_operator.py:174-191).
+ * Backward writes gx (and gxr for Hartley), dw (and dwi for Fourier).  B <= 8 per call. */
+int hno_permode_fwd(const float *x, const float *xr, const float *w, const float *wi, float *y, int B, int Ci, int Co,
+                    int M, int d0, int d1, int d2, int fourier, void *stream);
+int hno_permode_bwd(const float *g, const float *x, const float *xr, const float *w, const float *wi, float *gx, float *gxr,
+                    float *dw, float *dwi, int B, int Ci, int Co, int M, int d0, int d1, int d2, int fourier,
+                    void *stream);
+
 /* ------------------------------------------------------------------------ batched GEMM
  * C[b] = alpha * op(A[b]) * op(B[b]) for b < batch; contiguous row-major operands, op = transpose when
  * the flag is set (A is M x K, or K x M when transA; B is K x N, or N x K when transB; C is M x N).

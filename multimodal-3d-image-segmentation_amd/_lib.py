@@ -35,6 +35,8 @@ SIGNATURES = {
     'hno_conv_k2s2_bwd': (c_int, [c_void_p] * 8 + [c_int] * 7 + [c_void_p]),
     'hno_upsoftmax_fwd': (c_int, [c_void_p] * 2 + [c_int] * 9 + [c_void_p]),
     'hno_upsoftmax_bwd': (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p]),
+    'hno_permode_fwd': (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
+    'hno_permode_bwd': (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_void_p]),
     'hno_bmm': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_float, c_void_p]),
     'hno_act_fwd': (c_int, [c_void_p, c_void_p, c_ll, c_int, c_void_p]),
     'hno_act_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p]),

@@ -87,13 +87,13 @@ class HartleyOperator(Module):
             raise NotImplementedError('HartleyOperator(use_transform=True, use_bias=True) is not provided by the '
                                       'HIP path yet (bias on the zero-padded spectrum)')
         n3 = float(np.prod(spatial))
-        z = ops.DhtCropFn.apply(inputs, modes, 1.0 / n3)
+        z = ops.DhtCropFn.apply(inputs, modes, 1.0 / n3) if self.weights_type == 'shared' else None
         if self.weights_type == 'shared':
             # selu(0) = 0, so SELU on the padded spectrum == SELU on the kept block
             z = ops.PwConvFn.apply(z, None, self.weight, None, ops.ACT_SELU)
         else:
             from .spectral_individual import hartley_mix_individual
-            z = hartley_mix_individual(z, self.weight, act=ops.ACT_SELU, full_spatial=spatial)
+            z = hartley_mix_individual(None, self.weight, act=ops.ACT_SELU, x_full=inputs, modes=modes)
         if addend is None:
             return ops.PadIdhtFn.apply(z, spatial, 1.0, act)
         return ops.PadIdhtAddFn.apply(z, addend, spatial, 1.0, act)

@@ -23,14 +23,16 @@ def complex_mix_shared(spec, weight_real, weight_imag):
 def fourier_operator_forward(op, inputs, addend=None, act=ops.ACT_NONE):
     if inputs.ndim != 5:
         raise NotImplementedError('2-D (ndim=4) FourierOperator is not provided by the HIP path yet')
-    if op.weights_type != 'shared':
-        raise NotImplementedError('FourierOperator(weights_type="individual") is not provided by the HIP path yet')
     if not op.use_transform:
         raise NotImplementedError('FourierOperator(use_transform=False) takes complex inputs; not provided by the HIP path')
     if op.use_bias:
         raise NotImplementedError('FourierOperator(use_bias=True) is not provided by the HIP path yet')
     spatial = tuple(inputs.shape[2:])
-    modes = ops.clamp_modes(op.num_modes, spatial)
+    modes = ops.clamp_modes(op.num_modes, spatial) if op.weights_type == 'shared' else tuple(op.num_modes)
     spec = ops.RfftCropFn.apply(inputs, modes)
-    spec = complex_mix_shared(spec, op.weight_real, op.weight_imag)
+    if op.weights_type == 'shared':
+        spec = complex_mix_shared(spec, op.weight_real, op.weight_imag)
+    else:
+        assert all(s >= 2 * m for s, m in zip(spatial, op.num_modes))
+        spec = ops.PerModeFourierFn.apply(spec, op.weight_real, op.weight_imag)
     return ops.IrfftPadFn.apply(spec, addend, spatial, act)

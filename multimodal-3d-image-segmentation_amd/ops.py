@@ -259,6 +259,64 @@ class IrfftPadFn(torch.autograd.Function):
         return gs, ga, None, None
 
 
+class PerModeHartleyFn(torch.autograd.Function):
+    """hartley_conv with per-mode weights (nets/hartley_operator.py:302-317): x, xr (B,Ci,d0,d1,d2), w (Co,Ci,d0,d1,d2)."""
+
+    @staticmethod
+    def forward(ctx, x, xr, w):
+        x, xr, w = _f32c(x), _f32c(xr), _f32c(w)
+        _need_gpu(x, xr, w)
+        B, Ci = x.shape[:2]
+        Co, (d0, d1, d2) = w.shape[0], w.shape[2:]
+        M = d0 * d1 * d2
+        y = torch.empty((B, Co, d0, d1, d2), device=x.device, dtype=torch.float32)
+        check(_lib.lib().hno_permode_fwd(ptr(x), ptr(xr), ptr(w), None, ptr(y), B, Ci, Co, M, d0, d1, d2, 0, stream_ptr()),
+              'hno_permode_fwd')
+        ctx.save_for_backward(x, xr, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, xr, w = ctx.saved_tensors
+        g = _f32c(g)
+        B, Ci = x.shape[:2]
+        Co, (d0, d1, d2) = w.shape[0], w.shape[2:]
+        gx, gxr, dw = torch.empty_like(x), torch.empty_like(xr), torch.empty_like(w)
+        check(_lib.lib().hno_permode_bwd(ptr(g), ptr(x), ptr(xr), ptr(w), None, ptr(gx), ptr(gxr), ptr(dw), None, B, Ci, Co,
+                                         d0 * d1 * d2, d0, d1, d2, 0, stream_ptr()), 'hno_permode_bwd')
+        return gx, gxr, dw
+
+
+class PerModeFourierFn(torch.autograd.Function):
+    """Complex per-mode mix 'oidhw,bidhw->bodhw' (nets/fourier_operator.py:174-191) on [re | im] planes:
+    spec (B, 2Ci, ...), wr / wi (Co, Ci, 2m0, 2m1, m2) -> (B, 2Co, ...)."""
+
+    @staticmethod
+    def forward(ctx, spec, wr, wi):
+        spec, wr, wi = _f32c(spec), _f32c(wr), _f32c(wi)
+        _need_gpu(spec, wr, wi)
+        B, Ci = spec.shape[0], spec.shape[1] // 2
+        Co = wr.shape[0]
+        M = int(np.prod(wr.shape[2:]))
+        y = torch.empty((B, 2 * Co) + tuple(spec.shape[2:]), device=spec.device, dtype=torch.float32)
+        check(_lib.lib().hno_permode_fwd(ptr(spec), None, ptr(wr), ptr(wi), ptr(y), B, Ci, Co, M, 1, 1, M, 1, stream_ptr()),
+              'hno_permode_fwd')
+        ctx.save_for_backward(spec, wr, wi)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        spec, wr, wi = ctx.saved_tensors
+        g = _f32c(g)
+        B, Ci = spec.shape[0], spec.shape[1] // 2
+        Co = wr.shape[0]
+        M = int(np.prod(wr.shape[2:]))
+        gx, dwr, dwi = torch.empty_like(spec), torch.empty_like(wr), torch.empty_like(wi)
+        check(_lib.lib().hno_permode_bwd(ptr(g), ptr(spec), None, ptr(wr), ptr(wi), ptr(gx), None, ptr(dwr), ptr(dwi), B, Ci,
+                                         Co, M, 1, 1, M, 1, stream_ptr()), 'hno_permode_bwd')
+        return gx, dwr, dwi
+
+
 def bmm_raw(A, B, transA, transB, alpha=1.0):
     """(batch..., M|K, K|M) x (batch..., K|N, N|K) -> (batch..., M, N) on the fp32 matrix cores."""
     _need_gpu(A, B)

@@ -386,6 +386,7 @@ def neural_operator_seg_forward(sd, x, num_transform_blocks, num_modes, transfor
     return F.softmax(h, dim=1) if output_activation == 'softmax' else _activate(h, output_activation)
 
 
+
 # --------------------------------------------------------------------------------------
 # Hartley multi-head attention (nets/hartley_mha.py:136-222, 473-524)
 # --------------------------------------------------------------------------------------

@@ -139,6 +139,11 @@ NOSEG_MODELS = {
     'fnoseg_addskip_bias': (dict(in_channels=1, out_channels=2, filters=8, num_transform_blocks=2, num_modes=(3, 3, 4),
                                  transform_type='Fourier', use_block_concat=False, use_bias_conv_branch=True),
                             (2, 1, 18, 22, 26)),
+    'fno_individual': (dict(in_channels=2, out_channels=3, filters=8, num_transform_blocks=2, num_modes=(3, 4, 4),
+                            transform_type='Fourier', weights_type='individual', use_bias_conv_branch=True,
+                            use_block_skip=False), (2, 2, 24, 20, 28)),          # the FNO configuration (config_fno.ini)
+    'hno_individual': (dict(in_channels=2, out_channels=2, filters=8, num_transform_blocks=2, num_modes=(3, 4, 4),
+                            transform_type='Hartley', weights_type='individual'), (1, 2, 24, 20, 28)),
     'hnoseg_noskip_clamped': (dict(in_channels=2, out_channels=2, filters=8, num_transform_blocks=2,
                                    num_modes=(10, 14, 14), transform_type='Hartley', use_block_skip=False),
                               (1, 2, 16, 20, 24)),
