@@ -135,6 +135,35 @@ int hno_upsoftmax_fwd(const float *logits_lr, float *probs, int B, int K, int d,
 int hno_upsoftmax_bwd(const float *g_probs, const float *probs, float *g_lr, int B, int K, int d, int h, int w,
                       int D, int H, int W, int softmax, void *stream);
 
+/* ------------------------------------------------------------------ V-Net-DS building blocks
+ * 3x3x3 convolutions as implicit GEMMs on the fp32 matrix cores (reference: ConvNormAct /
+ * ConvTransposeNormAct with kernel_size 3, nets/nets_utils.py:136-211, used by VNetDS
+ * nets/architectures.py:105-155).  hno_conv3d_k3 mode: 0 = Conv3d forward (W (Cout,Cin,3,3,3), stride 1 or 2,
+ * padding 1); 1 = its input gradient (x = dL/dy with the conv's OUTPUT dims as Di.., y = dL/dx); 2 =
+ * ConvTranspose3d forward (Wt (Cin,Cout,3,3,3), stride 2, padding 1, output_padding 1); 3 = its input
+ * gradient.  Cin / Cout always name the ORIGINAL operator's channels.  workspace:
+ * hno_conv3d_k3_workspace_bytes(Cin, Cout, 0).  hno_conv3d_k3_wgrad writes dW (same layout as the weight);
+ * Dx.. are the operator's input dims, Dg.. its output dims; workspace: ..._workspace_bytes(Cin, Cout, 1). */
+size_t hno_conv3d_k3_workspace_bytes(int Cin, int Cout, int for_wgrad);
+int hno_conv3d_k3(const float *x, const float *W, const float *bias, float *y, void *workspace, int mode, int B, int Cin,
+                  int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int stride, int pad, int act, void *stream);
+int hno_conv3d_k3_wgrad(const float *g, const float *x, float *dW, void *workspace, int transposed, int B, int Cin, int Cout,
+                        int Dx, int Hx, int Wx, int Dg, int Hg, int Wg, int stride, int pad, void *stream);
+/* GroupNorm(1, C) + activation (nn.GroupNorm(1, C) after every V-Net conv, nets/nets_utils.py:165-170).
+ * fwd saves mean_rstd (B,2); stats_ws: 2*B doubles.  bwd: sums_ws 2*B*C doubles, coef_ws 2*B floats. */
+int hno_groupnorm1_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean_rstd, double *stats_ws,
+                       int B, int C, long long V, float eps, int act, void *stream);
+int hno_groupnorm1_bwd(const float *g, const float *y, const float *x, const float *mean_rstd, const float *gamma, float *gx,
+                       float *dgamma, float *dbeta, double *sums_ws, float *coef_ws, int B, int C, long long V, int act,
+                       void *stream);
+/* nearest-neighbour resampling (F.interpolate default mode; `upsampling`, nets/architectures.py:638-653):
+ * adjoint = 0: dst (BC,D,H,W) = src (BC,d,h,w) upsampled (accumulate: dst += ...); adjoint = 1: src is the
+ * high-resolution gradient (BC,D,H,W), dst the low-resolution one (BC,d,h,w). */
+int hno_nearest3d(const float *src, float *dst, int BC, int d, int h, int w, int D, int H, int W, int adjoint, int accumulate,
+                  void *stream);
+/* out[c] = sum_{b,v} g[b][c][v] (bias gradient of the 3x3x3 convolutions) */
+int hno_channel_sum(const float *g, float *out, int B, int C, long long V, void *stream);
+
 /* ------------------------------------------------------- per-mode ('individual') spectral weights
  * Hartley (fourier = 0): y(k) = 1/2 [W(k)(x(k) + xr(k)) + W(-k)(x(k) - xr(k))] with xr = the frequency-
  *   reversed copy of x supplied by the caller (on the cropped grid or taken from the full spectrum) and

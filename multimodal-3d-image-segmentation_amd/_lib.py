@@ -35,6 +35,13 @@ SIGNATURES = {
     'hno_conv_k2s2_bwd': (c_int, [c_void_p] * 8 + [c_int] * 7 + [c_void_p]),
     'hno_upsoftmax_fwd': (c_int, [c_void_p] * 2 + [c_int] * 9 + [c_void_p]),
     'hno_upsoftmax_bwd': (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p]),
+    'hno_conv3d_k3_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'hno_conv3d_k3': (c_int, [c_void_p] * 5 + [c_int] * 13 + [c_void_p]),
+    'hno_conv3d_k3_wgrad': (c_int, [c_void_p] * 4 + [c_int] * 12 + [c_void_p]),
+    'hno_groupnorm1_fwd': (c_int, [c_void_p] * 6 + [c_int, c_int, c_ll, c_float, c_int, c_void_p]),
+    'hno_groupnorm1_bwd': (c_int, [c_void_p] * 10 + [c_int, c_int, c_ll, c_int, c_void_p]),
+    'hno_nearest3d': (c_int, [c_void_p] * 2 + [c_int] * 9 + [c_void_p]),
+    'hno_channel_sum': (c_int, [c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p]),
     'hno_permode_fwd': (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
     'hno_permode_bwd': (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_void_p]),
     'hno_bmm': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_float, c_void_p]),

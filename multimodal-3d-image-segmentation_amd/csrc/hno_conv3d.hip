@@ -1,0 +1,576 @@
+// 3x3x3 convolutions of the V-Net-DS path (reference nets/architectures.py:26-252 through
+// ConvNormAct / ConvTransposeNormAct, nets/nets_utils.py:136-211) as implicit GEMMs on the fp32 matrix
+// cores, plus GroupNorm(1, C) + activation and nearest-neighbour resampling.
+//
+// One gather-GEMM kernel serves four operators: the K index of the GEMM is (tap t, input channel i),
+// the B operand is x gathered at  in = s * out - pad + t  (stride-s convolution) or at
+// in = (out + pad - t) / s when divisible (fractionally strided: input gradient of a strided
+// convolution, and ConvTranspose3d forward), the A operand is the weight re-laid as [t][i][o] by a
+// small pre-pass so that its loads are coalesced over output channels:
+//   conv forward ............ conv mode,  weights W[o][i][t]
+//   conv input gradient ..... fractional mode, weights W[o][i][t] with roles of i and o swapped
+//   ConvTranspose3d forward . fractional mode, weights Wt[i][o][t]
+//   ConvTranspose3d dgrad ... conv mode, weights Wt[i][o][t] with roles swapped
+// Tile: one wave = 32 output channels x 32 consecutive output voxels of one row (v_mfma_f32_32x32x2_f32).
+#include "hno_common.h"
+
+namespace hno {
+
+typedef float f32x16c __attribute__((ext_vector_type(16)));
+
+struct C3Args {
+    const float *x, *wt, *bias;
+    float *y;
+    int B, Cin, Cout;
+    int Di, Hi, Wi, Do, Ho, Wo;
+    int stride, pad, frac;  // frac = 1: fractionally strided gather
+    int act;
+};
+
+// weight re-layout: dst[(t * Cin_g + i) * Cout_g + o] where the GEMM's "input" / "output" channels may be
+// either axis of the stored tensor and the taps may be flipped
+__global__ __launch_bounds__(256) void c3_relayout_kernel(const float *__restrict__ w, float *__restrict__ dst, int C0, int C1,
+                                                         int out_is_axis0, int flip) {
+    // w stored [C0][C1][27]
+    const int n = C0 * C1 * 27;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+        const int t = idx % 27, c1 = (idx / 27) % C1, c0 = idx / (27 * C1);
+        const int o = out_is_axis0 ? c0 : c1, i = out_is_axis0 ? c1 : c0;
+        const int Co = out_is_axis0 ? C0 : C1, Ci = out_is_axis0 ? C1 : C0;
+        const int tt = flip ? 26 - t : t;
+        dst[((size_t)tt * Ci + i) * Co + o] = w[idx];
+    }
+}
+
+__global__ __launch_bounds__(256) void c3_gemm_kernel(C3Args a) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, c = lane & 31;
+    const int o0 = blockIdx.y * 32;
+    const int wtiles = (a.Wo + 31) / 32;
+    const long long ntiles = (long long)a.B * a.Do * a.Ho * wtiles;
+    const size_t Vi = (size_t)a.Di * a.Hi * a.Wi, Vo = (size_t)a.Do * a.Ho * a.Wo;
+    const int nks = (a.Cin + 1) / 2;
+    for (long long t = (long long)blockIdx.x * 4 + wave; t < ntiles; t += (long long)gridDim.x * 4) {
+        const int wt_ = (int)(t % wtiles);
+        long long rem = t / wtiles;
+        const int oh = (int)(rem % a.Ho);
+        rem /= a.Ho;
+        const int od = (int)(rem % a.Do), b = (int)(rem / a.Do);
+        const int ow = wt_ * 32 + c;
+        const float *xb = a.x + (size_t)b * a.Cin * Vi;
+        f32x16c acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int tap = 0; tap < 27; ++tap) {
+            const int td = tap / 9, th = (tap / 3) % 3, tw = tap % 3;
+            int zi, yi, xi;
+            bool rowok, colok;
+            if (!a.frac) {
+                zi = a.stride * od - a.pad + td;
+                yi = a.stride * oh - a.pad + th;
+                xi = a.stride * ow - a.pad + tw;
+                rowok = zi >= 0 && zi < a.Di && yi >= 0 && yi < a.Hi;
+                colok = ow < a.Wo && xi >= 0 && xi < a.Wi;
+            } else {
+                const int nz = od + a.pad - td, ny = oh + a.pad - th, nx = ow + a.pad - tw;
+                rowok = nz >= 0 && ny >= 0 && nz % a.stride == 0 && ny % a.stride == 0;
+                zi = nz / a.stride;
+                yi = ny / a.stride;
+                rowok = rowok && zi < a.Di && yi < a.Hi;
+                xi = nx / a.stride;
+                colok = ow < a.Wo && nx >= 0 && nx % a.stride == 0 && xi < a.Wi;
+            }
+            if (!rowok) continue;  // wave-uniform
+            const float *xrow = xb + ((size_t)zi * a.Hi + yi) * a.Wi;
+            const float *wtap = a.wt + (size_t)tap * a.Cin * a.Cout;
+            const int xoff = colok ? xi : 0;
+#pragma unroll 4
+            for (int ks = 0; ks < nks; ++ks) {
+                const int i = 2 * ks + h;
+                const bool iok = i < a.Cin;
+                const int ic = iok ? i : 0;
+                const float bv = xrow[(size_t)ic * Vi + xoff];
+                const float av = (iok && o0 + c < a.Cout) ? wtap[(size_t)ic * a.Cout + o0 + c] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, (colok && iok) ? bv : 0.f, acc, 0, 0, 0);
+            }
+        }
+        if (ow < a.Wo) {
+            const size_t vo = ((size_t)od * a.Ho + oh) * a.Wo + ow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (o < a.Cout) a.y[((size_t)b * a.Cout + o) * Vo + vo] = act_apply(acc[r] + (a.bias ? a.bias[o] : 0.f), a.act);
+            }
+        }
+    }
+}
+
+// ---- weight gradient: dW[o][i][t] = sum_v g[o][v] * x[i][in(v, t)]  (g on the "output" grid) ----------------
+// One block = one (td, th) pair x one 32x32 (o, i) tile x a chunk of output rows; the three tw taps share
+// the loaded x row.  K = 32 output voxels per step on 16x16x4 MFMA from wave-private LDS tiles; partial
+// slabs are reduced in a fixed order by reduce_partials_launch.
+struct C3WArgs {
+    const float *g, *x;
+    float *partials;
+    int B, Cg, Cx;            // channels of g ("output" side) and x ("input" side)
+    int Dg, Hg, Wg, Dx, Hx, Wx;
+    int stride, pad, frac;
+    int nchunks;
+};
+
+#define C3W_LD 34
+__global__ __launch_bounds__(256) void c3_wgrad_kernel(C3WArgs a) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    float *G = lds + (size_t)wave * (32 + 96) * C3W_LD;  // [o][v]
+    float *X = G + 32 * C3W_LD;                           // [tw][i][v]
+    const int tdh = blockIdx.y, td = tdh / 3, th = tdh % 3;
+    const int ntile_i = (a.Cx + 31) / 32;
+    const int ot = blockIdx.z / ntile_i, it = blockIdx.z % ntile_i;
+    const int o0 = ot * 32, i0 = it * 32;
+    const size_t Vg = (size_t)a.Dg * a.Hg * a.Wg, Vx = (size_t)a.Dx * a.Hx * a.Wx;
+    f32x4 dw[3][2][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) dw[t][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int wtiles = (a.Wg + 31) / 32;
+    const long long ntiles = (long long)a.B * a.Dg * a.Hg * wtiles;
+    const long long ngroups = (ntiles + 3) / 4;
+    for (long long grp = blockIdx.x; grp < ngroups; grp += a.nchunks) {
+        const long long t = grp * 4 + wave;
+        const bool live = t < ntiles;
+        const int wt_ = live ? (int)(t % wtiles) : 0;
+        long long rem = live ? t / wtiles : 0;
+        const int gh = (int)(rem % a.Hg);
+        rem /= a.Hg;
+        const int gd = (int)(rem % a.Dg), b = (int)(rem / a.Dg);
+        const int gw = wt_ * 32 + c;
+        int zi, yi;
+        bool rowok;
+        if (!a.frac) {
+            zi = a.stride * gd - a.pad + td;
+            yi = a.stride * gh - a.pad + th;
+            rowok = zi >= 0 && zi < a.Dx && yi >= 0 && yi < a.Hx;
+        } else {
+            const int nz = gd + a.pad - td, ny = gh + a.pad - th;
+            rowok = nz >= 0 && ny >= 0 && nz % a.stride == 0 && ny % a.stride == 0;
+            zi = nz / a.stride;
+            yi = ny / a.stride;
+            rowok = rowok && zi < a.Dx && yi < a.Hx;
+        }
+        rowok = rowok && live;
+        // g tile and the three shifted x tiles (zeros where out of range)
+        for (int r = h; r < 32; r += 2) {
+            const int o = o0 + r;
+            float gv = 0.f;
+            if (rowok && o < a.Cg && gw < a.Wg) gv = a.g[((size_t)b * a.Cg + o) * Vg + ((size_t)gd * a.Hg + gh) * a.Wg + gw];
+            G[r * C3W_LD + c] = gv;
+        }
+#pragma unroll
+        for (int tw = 0; tw < 3; ++tw) {
+            int xi;
+            bool colok;
+            if (!a.frac) {
+                xi = a.stride * gw - a.pad + tw;
+                colok = gw < a.Wg && xi >= 0 && xi < a.Wx;
+            } else {
+                const int nx = gw + a.pad - tw;
+                xi = nx / a.stride;
+                colok = gw < a.Wg && nx >= 0 && nx % a.stride == 0 && xi < a.Wx;
+            }
+            for (int r = h; r < 32; r += 2) {
+                const int i = i0 + r;
+                float xv = 0.f;
+                if (rowok && colok && i < a.Cx) xv = a.x[((size_t)b * a.Cx + i) * Vx + ((size_t)zi * a.Hx + yi) * a.Wx + xi];
+                X[(tw * 32 + r) * C3W_LD + c] = xv;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float *ga = G + (lane & 15) * C3W_LD + (lane >> 4);
+        const float *xa = X + (lane & 15) * C3W_LD + (lane >> 4);
+#pragma unroll 2
+        for (int ks = 0; ks < 8; ++ks) {
+            float av[2], bv[3][2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) av[m] = ga[m * 16 * C3W_LD + ks * 4];
+#pragma unroll
+            for (int tw = 0; tw < 3; ++tw)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) bv[tw][n] = xa[(tw * 32 + n * 16) * C3W_LD + ks * 4];
+#pragma unroll
+            for (int tw = 0; tw < 3; ++tw)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) dw[tw][m][n] = mfma16(av[m], bv[tw][n], dw[tw][m][n]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // per-block slab: [tw][o 32][i 32] for this (td, th, ot, it)
+    constexpr int n = 3 * 32 * 32;
+    __syncthreads();
+    float *mine = lds + (size_t)wave * n;
+#pragma unroll
+    for (int tw = 0; tw < 3; ++tw)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = m * 16 + (lane >> 4) * 4 + r, i = nn * 16 + (lane & 15);
+                    mine[(tw * 32 + o) * 32 + i] = dw[tw][m][nn][r];
+                }
+    const size_t slab = ((size_t)(blockIdx.z * 9 + blockIdx.y) * a.nchunks + blockIdx.x) * n;
+    block_sum_to_slab(lds, n, a.partials + slab, threadIdx.x);
+}
+
+// scatter the reduced [tile][tdh][tw][o][i] sums into the stored weight layout [C0][C1][27]
+__global__ __launch_bounds__(256) void c3_wgrad_finish_kernel(const float *__restrict__ partials, float *__restrict__ dw, int nchunks,
+                                                             int Cg, int Cx, int g_is_axis0, int flip) {
+    const int ntile_i = (Cx + 31) / 32;
+    const int total = Cg * Cx * 27;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int tap = idx % 27, i = (idx / 27) % Cx, o = idx / (27 * Cx);
+        const int td = tap / 9, th = (tap / 3) % 3, tw = tap % 3;
+        const int tile = (o / 32) * ntile_i + (i / 32);
+        const size_t base = ((size_t)(tile * 9 + td * 3 + th) * nchunks) * (3 * 32 * 32) + ((size_t)tw * 32 + (o % 32)) * 32 + (i % 32);
+        float s = 0.f;
+        for (int ch = 0; ch < nchunks; ++ch) s += partials[base + (size_t)ch * (3 * 32 * 32)];
+        const int tt = flip ? 26 - tap : tap;
+        const size_t dst = g_is_axis0 ? ((size_t)o * Cx + i) * 27 + tt : ((size_t)i * Cg + o) * 27 + tt;
+        dw[dst] = s;
+    }
+}
+
+// ---- GroupNorm(1, C) + activation ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x, double *stats, long long n_per_sample) {
+    const int b = blockIdx.y;
+    const float *xb = x + (size_t)b * n_per_sample;
+    double s = 0.0, s2 = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_per_sample; i += (long long)gridDim.x * 256) {
+        const double v = xb[i];
+        s += v;
+        s2 += v * v;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        s += __shfl_xor(s, off);
+        s2 += __shfl_xor(s2, off);
+    }
+    __shared__ double red[8];
+    if ((threadIdx.x & 63) == 0) {
+        red[(threadIdx.x >> 6) * 2] = s;
+        red[(threadIdx.x >> 6) * 2 + 1] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[b * 2], red[0] + red[2] + red[4] + red[6]);
+        atomicAdd(&stats[b * 2 + 1], red[1] + red[3] + red[5] + red[7]);
+    }
+}
+
+// mean_rstd[b] = {mean, 1/sqrt(var + eps)} (biased variance, as nn.GroupNorm)
+__global__ void gn_finalize_kernel(const double *stats, float *mean_rstd, int B, long long n, float eps) {
+    const int b = threadIdx.x;
+    if (b < B) {
+        const double m = stats[b * 2] / n, var = stats[b * 2 + 1] / n - m * m;
+        mean_rstd[b * 2] = (float)m;
+        mean_rstd[b * 2 + 1] = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)eps));
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, const float *__restrict__ mean_rstd,
+                                                      const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                      float *__restrict__ y, int C, long long V, int act) {
+    const int bc = blockIdx.y, b = bc / C, c = bc % C;
+    const float m = mean_rstd[b * 2], r = mean_rstd[b * 2 + 1], gm = gamma[c], bt = beta[c];
+    const float *xp = x + (size_t)bc * V;
+    float *yp = y + (size_t)bc * V;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < V; i += (long long)gridDim.x * 256)
+        yp[i] = act_apply((xp[i] - m) * r * gm + bt, act);
+}
+
+// per-(b,c): sum_v ga and sum_v ga * xhat with ga = g * act'(y)
+__global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const float *__restrict__ g, const float *__restrict__ y,
+                                                         const float *__restrict__ x, const float *__restrict__ mean_rstd,
+                                                         double *sums, int C, long long V, int act) {
+    const int bc = blockIdx.y, b = bc / C;
+    const float m = mean_rstd[b * 2], r = mean_rstd[b * 2 + 1];
+    const size_t off = (size_t)bc * V;
+    double s0 = 0.0, s1 = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < V; i += (long long)gridDim.x * 256) {
+        const float ga = g[off + i] * act_grad_from_out(y[off + i], act);
+        s0 += ga;
+        s1 += (double)ga * ((x[off + i] - m) * r);
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        s0 += __shfl_xor(s0, o);
+        s1 += __shfl_xor(s1, o);
+    }
+    __shared__ double red[8];
+    if ((threadIdx.x & 63) == 0) {
+        red[(threadIdx.x >> 6) * 2] = s0;
+        red[(threadIdx.x >> 6) * 2 + 1] = s1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[bc * 2], red[0] + red[2] + red[4] + red[6]);
+        atomicAdd(&sums[bc * 2 + 1], red[1] + red[3] + red[5] + red[7]);
+    }
+}
+
+// coef[b] = {mean(g'), mean(g' xhat)} with g' = ga * gamma ; dgamma[c] = sum_b S1, dbeta[c] = sum_b S0
+__global__ void gn_bwd_finalize_kernel(const double *sums, const float *gamma, float *coef, float *dgamma, float *dbeta, int B,
+                                       int C, long long V) {
+    const int t = threadIdx.x;
+    if (t < B) {
+        double a0 = 0.0, a1 = 0.0;
+        for (int c = 0; c < C; ++c) {
+            a0 += (double)gamma[c] * sums[(t * C + c) * 2];
+            a1 += (double)gamma[c] * sums[(t * C + c) * 2 + 1];
+        }
+        coef[t * 2] = (float)(a0 / ((double)C * V));
+        coef[t * 2 + 1] = (float)(a1 / ((double)C * V));
+    }
+    for (int c = t; c < C; c += blockDim.x) {
+        double d0 = 0.0, d1 = 0.0;
+        for (int b = 0; b < B; ++b) {
+            d0 += sums[(b * C + c) * 2];
+            d1 += sums[(b * C + c) * 2 + 1];
+        }
+        dbeta[c] = (float)d0;
+        dgamma[c] = (float)d1;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *__restrict__ g, const float *__restrict__ y,
+                                                          const float *__restrict__ x, const float *__restrict__ mean_rstd,
+                                                          const float *__restrict__ gamma, const float *__restrict__ coef,
+                                                          float *__restrict__ gx, int C, long long V, int act) {
+    const int bc = blockIdx.y, b = bc / C, c = bc % C;
+    const float m = mean_rstd[b * 2], r = mean_rstd[b * 2 + 1], gm = gamma[c], k0 = coef[b * 2], k1 = coef[b * 2 + 1];
+    const size_t off = (size_t)bc * V;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < V; i += (long long)gridDim.x * 256) {
+        const float gp = g[off + i] * act_grad_from_out(y[off + i], act) * gm;
+        const float xh = (x[off + i] - m) * r;
+        gx[off + i] = r * (gp - k0 - xh * k1);
+    }
+}
+
+// ---- nearest-neighbour resampling (F.interpolate default mode) -------------------------------------------
+// src = min(floor(dst * in / out), in - 1) with the fp32 scale PyTorch uses
+__device__ __forceinline__ int nn_src(int dst, float scale, int in_size) {
+    const int s = (int)floorf(dst * scale);
+    return s < in_size - 1 ? s : in_size - 1;
+}
+struct NnArgs {
+    const float *src;
+    float *dst;
+    int BC, d, h, w, D, H, W;
+    float sd, sh, sw;
+    int accumulate;
+};
+__global__ __launch_bounds__(256) void nn_up_kernel(NnArgs a) {
+    const size_t V = (size_t)a.D * a.H * a.W, v_lr = (size_t)a.d * a.h * a.w;
+    const size_t total = V * a.BC;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const size_t bc = idx / V, v = idx % V;
+        const int x = (int)(v % a.W), y = (int)((v / a.W) % a.H), z = (int)(v / ((size_t)a.W * a.H));
+        const float val = a.src[bc * v_lr + ((size_t)nn_src(z, a.sd, a.d) * a.h + nn_src(y, a.sh, a.h)) * a.w + nn_src(x, a.sw, a.w)];
+        a.dst[idx] = a.accumulate ? a.dst[idx] + val : val;
+    }
+}
+// adjoint: every low-res voxel sums the high-res voxels that read it (contiguous index ranges per axis)
+__device__ __forceinline__ void nn_range(int i, float scale, int in_size, int out_size, int &lo, int &hi) {
+    int l = (int)ceilf(i / scale) - 1;
+    l = l < 0 ? 0 : l;
+    while (l < out_size && nn_src(l, scale, in_size) < i) ++l;
+    while (l > 0 && nn_src(l - 1, scale, in_size) >= i) --l;
+    int r = l;
+    while (r < out_size && nn_src(r, scale, in_size) == i) ++r;
+    lo = l;
+    hi = r;  // [lo, hi)
+}
+__global__ __launch_bounds__(256) void nn_down_kernel(NnArgs a) {  // src = high-res gradient, dst = low-res gradient
+    const size_t V = (size_t)a.D * a.H * a.W, v_lr = (size_t)a.d * a.h * a.w;
+    const size_t total = v_lr * a.BC;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const size_t bc = idx / v_lr, v = idx % v_lr;
+        const int x = (int)(v % a.w), y = (int)((v / a.w) % a.h), z = (int)(v / ((size_t)a.w * a.h));
+        int z0, z1, y0, y1, x0, x1;
+        nn_range(z, a.sd, a.d, a.D, z0, z1);
+        nn_range(y, a.sh, a.h, a.H, y0, y1);
+        nn_range(x, a.sw, a.w, a.W, x0, x1);
+        float s = 0.f;
+        for (int zz = z0; zz < z1; ++zz)
+            for (int yy = y0; yy < y1; ++yy)
+                for (int xx = x0; xx < x1; ++xx) s += a.src[bc * V + ((size_t)zz * a.H + yy) * a.W + xx];
+        a.dst[idx] = s;
+    }
+}
+
+// out[c] = sum over batch and voxels of g[b][c][v] (bias gradient of a convolution); one block per channel
+__global__ __launch_bounds__(256) void chan_sum_kernel(const float *__restrict__ g, float *__restrict__ out, int B, int C, long long V) {
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float *p = g + ((size_t)b * C + c) * V;
+        for (long long i = threadIdx.x; i < V; i += 256) s += p[i];
+    }
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[c] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
+static int g1(size_t n) {
+    size_t g = (n + 255) / 256;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+}  // namespace hno
+
+using namespace hno;
+
+extern "C" size_t hno_conv3d_k3_workspace_bytes(int Cin, int Cout, int for_wgrad) {
+    const size_t relayout = sizeof(float) * 27 * (size_t)Cin * Cout;
+    if (!for_wgrad) return relayout;
+    const size_t tiles = (size_t)((Cin + 31) / 32) * ((Cout + 31) / 32);
+    return sizeof(float) * tiles * 9 * 64 * (3 * 32 * 32);   // <= 64 chunks per (tile, td, th)
+}
+
+// mode 0: y = conv(x, W[Cout][Cin][27], stride, pad) ; mode 1: input gradient of that conv (x = dL/dy, y = dL/dx,
+// Cin/Cout are those of the ORIGINAL conv) ; mode 2: ConvTranspose3d forward with Wt[Cin][Cout][27] ;
+// mode 3: input gradient of that transposed conv.
+extern "C" int hno_conv3d_k3(const float *x, const float *W, const float *bias, float *y, void *workspace, int mode, int B,
+                             int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int stride, int pad, int act,
+                             void *stream) {
+    HNO_REQUIRE(x && W && y && workspace && B > 0 && Cin > 0 && Cout > 0, "hno_conv3d_k3: bad argument");
+    HNO_REQUIRE(mode >= 0 && mode <= 3 && (stride == 1 || stride == 2), "hno_conv3d_k3: bad mode / stride");
+    hipStream_t s = (hipStream_t)stream;
+    float *wt = (float *)workspace;
+    C3Args a = {};
+    a.x = x; a.wt = wt; a.bias = bias; a.y = y; a.B = B;
+    a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad = pad; a.act = act;
+    // GEMM channel roles and gather type per mode
+    if (mode == 0) { a.Cin = Cin; a.Cout = Cout; a.frac = 0; }
+    else if (mode == 1) { a.Cin = Cout; a.Cout = Cin; a.frac = 1; }
+    else if (mode == 2) { a.Cin = Cin; a.Cout = Cout; a.frac = 1; }
+    else { a.Cin = Cout; a.Cout = Cin; a.frac = 0; }
+    // stored tensors: conv W[Cout][Cin][27] (modes 0, 1), transposed conv Wt[Cin][Cout][27] (modes 2, 3)
+    const int C0 = (mode <= 1) ? Cout : Cin, C1 = (mode <= 1) ? Cin : Cout;
+    // the GEMM's output channel is tensor axis 0 for mode 0 (o) and mode 3 (Cin of Wt); axis 1 for modes 1 and 2
+    const int out_is_axis0 = (mode == 0 || mode == 3);
+    const int flip = 0;  // the fractional gather already pairs tap t with offset (+pad - t): no flip in any mode
+    hipLaunchKernelGGL(c3_relayout_kernel, dim3(g1((size_t)C0 * C1 * 27)), dim3(256), 0, s, W, wt, C0, C1, out_is_axis0, flip);
+    HNO_CHECK_LAUNCH();
+    const long long ntiles = (long long)B * Do * Ho * ((Wo + 31) / 32);
+    long long gx = (ntiles + 3) / 4;
+    if (gx > 8192) gx = 8192;
+    hipLaunchKernelGGL(c3_gemm_kernel, dim3((int)gx, (a.Cout + 31) / 32), dim3(256), 0, s, a);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+// dW of a conv (transposed = 0: W[Cout][Cin][27], g = dL/dy on the output grid, x = input) or of a
+// ConvTranspose3d (transposed = 1: Wt[Cin][Cout][27], g = dL/dy on the output grid, x = input).
+extern "C" int hno_conv3d_k3_wgrad(const float *g, const float *x, float *dW, void *workspace, int transposed, int B, int Cin,
+                                   int Cout, int Dx, int Hx, int Wx, int Dg, int Hg, int Wg, int stride, int pad,
+                                   void *stream) {
+    HNO_REQUIRE(g && x && dW && workspace && B > 0 && Cin > 0 && Cout > 0, "hno_conv3d_k3_wgrad: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    C3WArgs a = {};
+    a.B = B; a.stride = stride; a.pad = pad;
+    a.partials = (float *)workspace;
+    // The GEMM always reduces over the grid of the strided convolution's OUTPUT ("g side"):
+    //   conv:        g side = dL/dy (Cout), x side = input (Cin), gather in = s*out - pad + t
+    //   transposed:  the op is the adjoint of a strided conv from the OUTPUT grid to the INPUT grid, so the
+    //                "g side" is the transposed conv's input x (Cin, small grid) and the "x side" is dL/dy (Cout)
+    if (!transposed) {
+        a.g = g; a.x = x; a.Cg = Cout; a.Cx = Cin;
+        a.Dg = Dg; a.Hg = Hg; a.Wg = Wg; a.Dx = Dx; a.Hx = Hx; a.Wx = Wx; a.frac = 0;
+    } else {
+        a.g = x; a.x = g; a.Cg = Cin; a.Cx = Cout;
+        a.Dg = Dx; a.Hg = Hx; a.Wg = Wx; a.Dx = Dg; a.Hx = Hg; a.Wx = Wg; a.frac = 0;
+    }
+    const long long ntiles = (long long)B * a.Dg * a.Hg * ((a.Wg + 31) / 32);
+    long long nch = (ntiles + 3) / 4;
+    if (nch > 64) nch = 64;
+    a.nchunks = (int)nch;
+    const int tiles = ((a.Cg + 31) / 32) * ((a.Cx + 31) / 32);
+    const size_t lds = sizeof(float) * 4 * (32 + 96) * C3W_LD;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)c3_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(c3_wgrad_kernel, dim3(a.nchunks, 9, tiles), dim3(256), lds, s, a);
+    HNO_CHECK_LAUNCH();
+    // stored layout: conv W[Cg][Cx][27]; transposed Wt[Cin = Cg][Cout = Cx][27] -- both have the g side on axis 0
+    hipLaunchKernelGGL(c3_wgrad_finish_kernel, dim3(g1((size_t)a.Cg * a.Cx * 27)), dim3(256), 0, s, (const float *)a.partials, dW,
+                       a.nchunks, a.Cg, a.Cx, 1, 0);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+extern "C" int hno_groupnorm1_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean_rstd,
+                                  double *stats_ws, int B, int C, long long V, float eps, int act, void *stream) {
+    HNO_REQUIRE(x && gamma && beta && y && mean_rstd && stats_ws && B > 0 && B <= 256 && C > 0 && V > 0, "hno_groupnorm1_fwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    HNO_CHECK_HIP(hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * B, s));
+    const long long n = (long long)C * V;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(g1((size_t)n / 8 + 1) > 1024 ? 1024 : g1((size_t)n / 8 + 1), B), dim3(256), 0, s, x, stats_ws, n);
+    HNO_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, s, (const double *)stats_ws, mean_rstd, B, n, eps);
+    HNO_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(g1((size_t)V / 4 + 1) > 256 ? 256 : g1((size_t)V / 4 + 1), B * C), dim3(256), 0, s, x,
+                       (const float *)mean_rstd, gamma, beta, y, C, V, act);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+extern "C" int hno_groupnorm1_bwd(const float *g, const float *y, const float *x, const float *mean_rstd, const float *gamma,
+                                  float *gx, float *dgamma, float *dbeta, double *sums_ws, float *coef_ws, int B, int C,
+                                  long long V, int act, void *stream) {
+    HNO_REQUIRE(g && y && x && mean_rstd && gamma && gx && dgamma && dbeta && sums_ws && coef_ws && B > 0 && B <= 256,
+                "hno_groupnorm1_bwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    HNO_CHECK_HIP(hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * B * C, s));
+    const int gxn = g1((size_t)V / 4 + 1) > 256 ? 256 : g1((size_t)V / 4 + 1);
+    hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3(gxn, B * C), dim3(256), 0, s, g, y, x, mean_rstd, sums_ws, C, V, act);
+    HNO_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), 0, s, (const double *)sums_ws, gamma, coef_ws, dgamma, dbeta, B, C, V);
+    HNO_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(gxn, B * C), dim3(256), 0, s, g, y, x, mean_rstd, gamma, (const float *)coef_ws, gx, C, V, act);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+extern "C" int hno_nearest3d(const float *src, float *dst, int BC, int d, int h, int w, int D, int H, int W, int adjoint,
+                             int accumulate, void *stream) {
+    HNO_REQUIRE(src && dst && BC > 0, "hno_nearest3d: bad argument");
+    NnArgs a;
+    a.src = src; a.dst = dst; a.BC = BC; a.d = d; a.h = h; a.w = w; a.D = D; a.H = H; a.W = W;
+    a.sd = (float)d / D; a.sh = (float)h / H; a.sw = (float)w / W;
+    a.accumulate = accumulate;
+    if (!adjoint)
+        hipLaunchKernelGGL(nn_up_kernel, dim3(g1((size_t)BC * D * H * W)), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(nn_down_kernel, dim3(g1((size_t)BC * d * h * w)), dim3(256), 0, (hipStream_t)stream, a);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+extern "C" int hno_channel_sum(const float *g, float *out, int B, int C, long long V, void *stream) {
+    HNO_REQUIRE(g && out && B > 0 && C > 0 && V > 0, "hno_channel_sum: bad argument");
+    hipLaunchKernelGGL(chan_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, g, out, B, C, V);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}

@@ -210,5 +210,160 @@ class HartleyMHASeg(_TransSeg):
         self.create_layers()
 
 
-class VNetDS(_Pending):
-    pass
+def upsampling(tensors):
+    """Nearest-neighbour upsampling of a dict of tensors to the size of tensors[0]
+    (reference nets/architectures.py:638-653)."""
+    ref_size = tuple(tensors[0].shape[2:])
+    return [t if tuple(t.shape[2:]) == ref_size else ops.NearestUpFn.apply(t, ref_size) for t in tensors.values()]
+
+
+class VNetDS(nn.Module):
+    """V-Net with deep supervision (reference nets/architectures.py:26-252); same constructor, module tree
+    and state-dict keys.  3x3x3 convolutions run as implicit GEMMs on the fp32 matrix cores, every
+    GroupNorm(1, C) + ELU is one fused pass, and the right-leg deep supervision applies conv_ds to each
+    leg at its own resolution before the nearest-neighbour upsampling (the two commute), so the
+    744-channel concatenated tensor of the reference is never built."""
+
+    def __init__(self, in_channels, out_channels, base_num_filters, num_blocks, use_resize=True, right_leg_indexes=None,
+                 kernel_size=3, activation='elu', use_snn=False, output_activation='softmax', use_residual=True, ndim=5,
+                 device=None):
+        super().__init__()
+        assert isinstance(num_blocks, (list, tuple))
+        self.in_channels, self.out_channels, self.num_blocks = in_channels, out_channels, num_blocks
+        self.use_resize, self.right_leg_indexes = use_resize, right_leg_indexes
+        self.output_activation, self.use_residual, self.ndim = output_activation, use_residual, ndim
+        if self.right_leg_indexes is None:
+            self.right_leg_indexes = [0]
+        assert self.ndim in (4, 5)
+        nsec = len(self.num_blocks)
+        conv = partial(ConvNormAct, stride=1, use_bias=True, activation=activation, use_snn=use_snn, ndim=ndim, device=device)
+        cur = in_channels
+        self.conv_in = None
+        if self.use_resize:
+            self.conv_in = ConvNormAct(cur, base_num_filters, kernel_size=2, stride=2, use_bias=True, activation=activation,
+                                       use_snn=use_snn, ndim=ndim, device=device)
+            cur = base_num_filters
+        enc_ch, leg_ch = {}, {}
+        self.encode_layers = nn.ModuleDict()
+        for i in range(nsec):
+            layers = nn.ModuleList()
+            filters = base_num_filters * (2 ** i)
+            tmp_in = cur if self.use_residual else None
+            for _ in range(self.num_blocks[i]):
+                layers.append(conv(cur, filters, kernel_size=kernel_size))
+                cur = filters
+            if self.use_residual:
+                layers.append(conv(tmp_in, filters, kernel_size=1))
+                cur = filters
+            if i != nsec - 1:
+                enc_ch[i] = filters
+                layers.append(ConvNormAct(cur, filters, kernel_size=kernel_size, stride=2, use_bias=True, activation=activation,
+                                          use_snn=use_snn, ndim=ndim, device=device))
+                cur = filters
+            elif i in self.right_leg_indexes:
+                leg_ch[i] = cur
+            self.encode_layers[str(i)] = layers
+        self.decode_layers = nn.ModuleDict()
+        for i in reversed(range(nsec - 1)):
+            layers = nn.ModuleList()
+            filters = base_num_filters * (2 ** i)
+            layers.append(ConvTransposeNormAct(cur, filters, kernel_size=kernel_size, use_bias=True, activation=activation,
+                                               ndim=ndim, device=device))
+            cur = filters + enc_ch[i]
+            tmp_in = cur if self.use_residual else None
+            for _ in range(self.num_blocks[i]):
+                layers.append(conv(cur, filters, kernel_size=kernel_size))
+                cur = filters
+            if self.use_residual:
+                layers.append(conv(tmp_in, filters, kernel_size=1))
+                cur = filters
+            if i in self.right_leg_indexes:
+                leg_ch[i] = cur
+            self.decode_layers[str(i)] = layers
+        self.conv_ds = None
+        self._leg_channels = dict(leg_ch)
+        if len(leg_ch) == 1:
+            cur = leg_ch[0]
+        else:
+            cur = sum(leg_ch.values())
+            self.conv_ds = ConvNormAct(cur, self.out_channels, use_bias=True, activation=activation, use_snn=use_snn,
+                                       ndim=ndim, device=device)
+            cur = self.out_channels
+        convc = nn.Conv2d if ndim == 4 else nn.Conv3d
+        self.conv_out = convc(cur, self.out_channels, kernel_size=1, bias=False, device=device)
+        self._softmax = self.output_activation == 'softmax'
+        if isinstance(self.output_activation, str):
+            fn = getattr(nn.functional, self.output_activation)
+            self.output_activation = partial(fn, dim=1) if self._softmax else fn
+        self.encode_tensors = None
+        self.right_leg = None
+        if use_snn and _is_selu(activation):
+            self.apply(init_weights_for_snn)
+
+    def forward(self, x):
+        if x.ndim != 5:
+            raise NotImplementedError('2-D (ndim=4) V-Net-DS is not provided by the HIP path yet')
+        image_size = tuple(x.shape[2:])
+        self.encode_tensors, self.right_leg = {}, {}
+        if self.use_resize:
+            x = self.conv_in(x)
+        x = self.decode(self.encode(x))
+        logits = ops.PwConvFn.apply(x, None, self.conv_out.weight, None, ops.ACT_NONE)   # commutes with the upsampling
+        if not (self._softmax or self.output_activation is None):
+            raise NotImplementedError('only softmax / None output activations are provided by the HIP path')
+        y = ops.UpSoftmaxFn.apply(logits, image_size if self.use_resize else tuple(logits.shape[2:]), self._softmax)
+        return spatial_padcrop(y, image_size)
+
+    def _section(self, layers, x, nconv):
+        it = iter(layers)
+        tmp = x if self.use_residual else None
+        for _ in range(nconv):
+            x = next(it)(x)
+        if tmp is not None:
+            x = ops.AddFn.apply(x, next(it)(tmp))
+        return x, it
+
+    def encode(self, x):
+        nsec = len(self.num_blocks)
+        for i in range(nsec):
+            x, it = self._section(self.encode_layers[str(i)], x, self.num_blocks[i])
+            if i != nsec - 1:
+                self.encode_tensors[i] = x
+                x = next(it)(x)  # strided down-convolution
+            elif i in self.right_leg_indexes:
+                self.right_leg[i] = x
+        return x
+
+    def decode(self, x):
+        nsec = len(self.num_blocks)
+        for i in reversed(range(nsec - 1)):
+            layers = self.decode_layers[str(i)]
+            x = layers[0](x)                                            # transposed convolution
+            x = spatial_padcrop(x, tuple(self.encode_tensors[i].shape[2:]))
+            x = torch.cat([x.contiguous(), self.encode_tensors[i]], dim=1)
+            x, _ = self._section(list(layers)[1:], x, self.num_blocks[i])
+            if i in self.right_leg_indexes:
+                self.right_leg[i] = x
+        if len(self.right_leg) == 1:
+            return self.right_leg[0]
+        return self._deep_supervision()
+
+    def _deep_supervision(self):
+        """conv_ds(cat(upsampling(legs))) = act(norm(sum_legs up(W_leg . leg) + b)): the 1x1x1 conv is applied per
+        leg at its own resolution, only out_channels channels are upsampled and summed."""
+        op = self.conv_ds.op
+        w = op.weight.reshape(op.weight.shape[0], -1)
+        ref_size = tuple(self.right_leg[0].shape[2:])
+        acc, c0 = None, 0
+        for idx, (key, t) in enumerate(self.right_leg.items()):        # insertion order = concat order of the reference
+            c = t.shape[1]
+            part = ops.PwConvFn.apply(t, None, w[:, c0:c0 + c].contiguous(), op.bias if idx == 0 else None, ops.ACT_NONE)
+            if tuple(part.shape[2:]) != ref_size:
+                part = ops.NearestUpFn.apply(part, ref_size)
+            acc = part if acc is None else ops.AddFn.apply(acc, part)
+            c0 += c
+        act = ops.act_id(self.conv_ds.activation)
+        if self.conv_ds.normalization is not None:
+            from .conv3d import group_norm_act
+            return group_norm_act(acc, self.conv_ds.normalization, act)
+        return ops.ActFn.apply(acc, act) if act != ops.ACT_NONE else acc

@@ -259,6 +259,139 @@ class IrfftPadFn(torch.autograd.Function):
         return gs, ga, None, None
 
 
+def _conv_ws(cin, cout, wgrad, device):
+    n = _lib.lib().hno_conv3d_k3_workspace_bytes(int(cin), int(cout), int(wgrad)) // 4
+    return torch.empty(n, device=device, dtype=torch.float32)
+
+
+def _chan_sum(g):
+    B, C = g.shape[:2]
+    out = torch.empty(C, device=g.device, dtype=torch.float32)
+    check(_lib.lib().hno_channel_sum(ptr(g), ptr(out), B, C, _flat_v(g), stream_ptr()), 'hno_channel_sum')
+    return out
+
+
+def _conv3d_call(x, W, bias, out_shape, mode, cin, cout, stride, act=ACT_NONE):
+    y = torch.empty(out_shape, device=x.device, dtype=torch.float32)
+    ws = _conv_ws(cin, cout, False, x.device)
+    check(_lib.lib().hno_conv3d_k3(ptr(x), ptr(W), ptr(bias), ptr(y), ptr(ws), mode, x.shape[0], cin, cout, *x.shape[2:],
+                                   *out_shape[2:], stride, 1, act, stream_ptr()), 'hno_conv3d_k3')
+    return y
+
+
+class Conv3dK3Fn(torch.autograd.Function):
+    """Conv3d(kernel 3, stride 1 or 2, padding 1) + bias as an implicit GEMM (V-Net-DS convolutions)."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, stride):
+        x, W, bias = _f32c(x), _f32c(W), _f32c(bias)
+        _need_gpu(x, W, bias)
+        B, Cin = x.shape[:2]
+        Cout = W.shape[0]
+        osz = tuple((s - 1) // stride + 1 for s in x.shape[2:])
+        y = _conv3d_call(x, W, bias, (B, Cout) + osz, 0, Cin, Cout, stride)
+        ctx.save_for_backward(x, W)
+        ctx.stride, ctx.has_bias = stride, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        g = _f32c(g)
+        B, Cin = x.shape[:2]
+        Cout = W.shape[0]
+        gx = _conv3d_call(g, W, None, tuple(x.shape), 1, Cin, Cout, ctx.stride) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(W)
+        ws = _conv_ws(Cin, Cout, True, x.device)
+        check(_lib.lib().hno_conv3d_k3_wgrad(ptr(g), ptr(x), ptr(dW), ptr(ws), 0, B, Cin, Cout, *x.shape[2:], *g.shape[2:],
+                                             ctx.stride, 1, stream_ptr()), 'hno_conv3d_k3_wgrad')
+        return gx, dW, (_chan_sum(g) if ctx.has_bias else None), None
+
+
+class ConvT3dK3Fn(torch.autograd.Function):
+    """ConvTranspose3d(kernel 3, stride 2, padding 1, output_padding 1) + bias (V-Net-DS upsampling)."""
+
+    @staticmethod
+    def forward(ctx, x, Wt, bias):
+        x, Wt, bias = _f32c(x), _f32c(Wt), _f32c(bias)
+        _need_gpu(x, Wt, bias)
+        B, Cin = x.shape[:2]
+        Cout = Wt.shape[1]
+        osz = tuple(2 * s for s in x.shape[2:])
+        y = _conv3d_call(x, Wt, bias, (B, Cout) + osz, 2, Cin, Cout, 2)
+        ctx.save_for_backward(x, Wt)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, Wt = ctx.saved_tensors
+        g = _f32c(g)
+        B, Cin = x.shape[:2]
+        Cout = Wt.shape[1]
+        gx = _conv3d_call(g, Wt, None, tuple(x.shape), 3, Cin, Cout, 2) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(Wt)
+        ws = _conv_ws(Cin, Cout, True, x.device)
+        check(_lib.lib().hno_conv3d_k3_wgrad(ptr(g), ptr(x), ptr(dW), ptr(ws), 1, B, Cin, Cout, *x.shape[2:], *g.shape[2:],
+                                             2, 1, stream_ptr()), 'hno_conv3d_k3_wgrad')
+        return gx, dW, (_chan_sum(g) if ctx.has_bias else None)
+
+
+class GroupNormActFn(torch.autograd.Function):
+    """act(GroupNorm(1, C)(x)) (nets/nets_utils.py:127-133 with :165-170)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, act):
+        x, gamma, beta = _f32c(x), _f32c(gamma), _f32c(beta)
+        _need_gpu(x, gamma, beta)
+        B, C = x.shape[:2]
+        V = _flat_v(x)
+        y = torch.empty_like(x)
+        mr = torch.empty((B, 2), device=x.device, dtype=torch.float32)
+        ws = torch.empty(2 * B, device=x.device, dtype=torch.float64)
+        check(_lib.lib().hno_groupnorm1_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mr), ptr(ws), B, C, V, float(eps), act,
+                                            stream_ptr()), 'hno_groupnorm1_fwd')
+        ctx.save_for_backward(x, y, mr, gamma)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, mr, gamma = ctx.saved_tensors
+        g = _f32c(g)
+        B, C = x.shape[:2]
+        V = _flat_v(x)
+        gx, dg, db = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
+        sums = torch.empty(2 * B * C, device=x.device, dtype=torch.float64)
+        coef = torch.empty(2 * B, device=x.device, dtype=torch.float32)
+        check(_lib.lib().hno_groupnorm1_bwd(ptr(g), ptr(y), ptr(x), ptr(mr), ptr(gamma), ptr(gx), ptr(dg), ptr(db), ptr(sums),
+                                            ptr(coef), B, C, V, ctx.act, stream_ptr()), 'hno_groupnorm1_bwd')
+        return gx, dg, db, None, None
+
+
+class NearestUpFn(torch.autograd.Function):
+    """F.interpolate(x, size) with the default nearest mode (`upsampling`, nets/architectures.py:638-653)."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        x = _f32c(x)
+        _need_gpu(x)
+        B, C, d, h, w = x.shape
+        D, H, W = (int(s) for s in size)
+        y = torch.empty((B, C, D, H, W), device=x.device, dtype=torch.float32)
+        check(_lib.lib().hno_nearest3d(ptr(x), ptr(y), B * C, d, h, w, D, H, W, 0, 0, stream_ptr()), 'hno_nearest3d')
+        ctx.lr = (B, C, d, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _f32c(g)
+        B, C, d, h, w = ctx.lr
+        gx = torch.empty(ctx.lr, device=g.device, dtype=torch.float32)
+        check(_lib.lib().hno_nearest3d(ptr(g), ptr(gx), B * C, d, h, w, *g.shape[2:], 1, 0, stream_ptr()), 'hno_nearest3d')
+        return gx, None
+
+
 class PerModeHartleyFn(torch.autograd.Function):
     """hartley_conv with per-mode weights (nets/hartley_operator.py:302-317): x, xr (B,Ci,d0,d1,d2), w (Co,Ci,d0,d1,d2)."""
 

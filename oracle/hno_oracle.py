@@ -388,6 +388,68 @@ def neural_operator_seg_forward(sd, x, num_transform_blocks, num_modes, transfor
 
 
 # --------------------------------------------------------------------------------------
+# V-Net-DS (nets/architectures.py:26-252)
+# --------------------------------------------------------------------------------------
+def _cna(sd, prefix, x, stride=1, act='elu', transpose=False):
+    """ConvNormAct / ConvTransposeNormAct with GroupNorm(1, C) (use_snn=False path, nets/nets_utils.py:136-211)."""
+    w, b = sd[f'{prefix}.op.weight'], sd.get(f'{prefix}.op.bias')
+    k = w.shape[-1]
+    if transpose:
+        y = F.conv_transpose3d(x, w, b, stride=2, padding=k // 2, output_padding=1)
+    else:
+        y = F.conv3d(x, w, b, stride=stride, padding='same' if stride == 1 else k // 2)
+    if f'{prefix}.normalization.weight' in sd:
+        y = F.group_norm(y, 1, sd[f'{prefix}.normalization.weight'], sd[f'{prefix}.normalization.bias'])
+    return _activate(y, act)
+
+
+def vnetds_forward(sd, x, num_blocks, right_leg_indexes=None, use_resize=True, use_residual=True, act='elu'):
+    """VNetDS.forward / encode / decode (nets/architectures.py:184-252)."""
+    image_size = tuple(x.shape[2:])
+    legs_idx = right_leg_indexes if right_leg_indexes is not None else [0]
+    nsec = len(num_blocks)
+    h = x
+    if use_resize:
+        h = _cna(sd, 'conv_in', h, stride=2, act=act)
+    enc, legs = {}, {}
+    for i in range(nsec):
+        j, tmp = 0, h
+        for _ in range(num_blocks[i]):
+            h = _cna(sd, f'encode_layers.{i}.{j}', h, act=act)
+            j += 1
+        if use_residual:
+            h = h + _cna(sd, f'encode_layers.{i}.{j}', tmp, act=act)
+            j += 1
+        if i != nsec - 1:
+            enc[i] = h
+            h = _cna(sd, f'encode_layers.{i}.{j}', h, stride=2, act=act)
+        elif i in legs_idx:
+            legs[i] = h
+    for i in reversed(range(nsec - 1)):
+        h = _cna(sd, f'decode_layers.{i}.0', h, act=act, transpose=True)
+        h = spatial_padcrop(h, tuple(enc[i].shape[2:]))
+        h = torch.cat([h, enc[i]], dim=1)
+        j, tmp = 1, h
+        for _ in range(num_blocks[i]):
+            h = _cna(sd, f'decode_layers.{i}.{j}', h, act=act)
+            j += 1
+        if use_residual:
+            h = h + _cna(sd, f'decode_layers.{i}.{j}', tmp, act=act)
+        if i in legs_idx:
+            legs[i] = h
+    if len(legs) == 1:
+        h = legs[0]
+    else:
+        ref = tuple(legs[0].shape[2:])
+        h = torch.cat([F.interpolate(t, ref) for t in legs.values()], dim=1)
+        h = _cna(sd, 'conv_ds', h, act=act)
+    if use_resize:
+        h = F.interpolate(h, size=image_size, mode='trilinear')
+    h = spatial_padcrop(F.conv3d(h, sd['conv_out.weight']), image_size)
+    return F.softmax(h, dim=1)
+
+
+# --------------------------------------------------------------------------------------
 # Hartley multi-head attention (nets/hartley_mha.py:136-222, 473-524)
 # --------------------------------------------------------------------------------------
 def _group3d(x, patch):

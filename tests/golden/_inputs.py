@@ -159,3 +159,12 @@ MHA_CASES = [
 ]
 MHASEG_MODEL = (dict(in_channels=2, out_channels=3, filters=8, num_transform_blocks=2, num_heads=2, num_modes=(4, 4, 6),
                      patch_size=(2, 2, 2)), (1, 2, 24, 20, 28))
+
+
+# tiny V-Net-DS variants (golden G7v): name -> (ctor kwargs, input shape)
+VNET_MODELS = {
+    'vnet_ds': (dict(in_channels=2, out_channels=3, base_num_filters=4, num_blocks=[1, 2, 1], right_leg_indexes=[0, 1, 2]),
+                (1, 2, 20, 24, 28)),
+    'vnet_noresize_odd': (dict(in_channels=1, out_channels=2, base_num_filters=4, num_blocks=[1, 1], use_resize=False,
+                               right_leg_indexes=None), (2, 1, 9, 11, 13)),
+}

@@ -315,6 +315,29 @@ def g4_mha():
     save('g4_mha.npz', **out)
 
 
+# ------------------------------------------------------------- G7v: tiny V-Net-DS variants
+def g7v_vnet_models():
+    from _inputs import VNET_MODELS, formula_volume
+    out = {}
+    for name, (kw, shape) in VNET_MODELS.items():
+        torch.manual_seed(41)
+        model = nets.VNetDS(**kw)
+        for k, v in model.state_dict().items():
+            out[f'{name}::sd::{k}'] = v.detach().numpy().copy()
+        K = kw['out_channels']
+        x = T(formula_volume(shape, 5))
+        lab = formula_labels((shape[0], 1) + shape[2:], K, 7)
+        onehot = torch.movedim(torch.nn.functional.one_hot(T(lab)[:, 0].long(), K).float(), -1, 1)
+        y = model(x)
+        loss = custom_losses.DiceLoss()(y, onehot)
+        loss.backward()
+        out[f'{name}::y'] = y.detach().numpy()
+        out[f'{name}::loss'] = loss.detach().numpy()
+        for k, p in model.named_parameters():
+            out[f'{name}::grad::{k}'] = p.grad.detach().numpy().copy()
+    save('g7v_vnet_models.npz', **out)
+
+
 # ----------------------------------------------- G8: training-loop trajectory of the reference
 def _stub_missing_modules():
     sys.modules.setdefault('SimpleITK', type(sys)('SimpleITK'))
@@ -371,5 +394,6 @@ if __name__ == '__main__':
     g6_hnosegxs()
     g6s_small_models()
     g7_noseg_models()
+    g7v_vnet_models()
     g9_misc()
     g8_training()

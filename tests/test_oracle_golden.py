@@ -244,3 +244,24 @@ def test_hartley_mha_oracle(ci):
         assert rel_err(_np(gs[j]), g[f'{k}_gx{j}']) < 1e-4
     for (pn, _), gp in zip(P.items(), gs[nin:]):
         assert rel_err(_np(gp), g[f'{k}_g_{pn}']) < 1e-4, pn
+
+
+from _inputs import VNET_MODELS  # noqa: E402
+
+
+@pytest.mark.parametrize('name', list(VNET_MODELS))
+def test_vnet_models_oracle(name):
+    g = load_golden('g7v_vnet_models.npz')
+    kw, shape = VNET_MODELS[name]
+    pre = f'{name}::sd::'
+    params = {k[len(pre):]: T(g[k]).requires_grad_(True) for k in g.files if k.startswith(pre)}
+    K = kw['out_channels']
+    x = T(formula_volume(shape, 5))
+    lab = T(formula_labels((shape[0], 1) + shape[2:], K, 7))
+    y = O.vnetds_forward(params, x, kw['num_blocks'], kw.get('right_leg_indexes'), kw.get('use_resize', True))
+    loss = O.dice_loss(y, O.to_categorical(lab, K))
+    loss.backward()
+    assert rel_err(_np(y), g[f'{name}::y']) < 1e-5
+    assert abs(float(loss.detach()) - float(g[f'{name}::loss'])) < 1e-6
+    for k, p in params.items():
+        assert rel_err(_np(p.grad), g[f'{name}::grad::{k}']) < 1e-4, k
