@@ -48,7 +48,7 @@ ProfScope::~ProfScope() {
 // 64 columns x 16 slab groups per block: every thread sums nblocks/16 slabs with independent
 // loads, then the 16 groups are combined through LDS in a fixed order.
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__restrict__ partials, int nblocks, int n,
-                                                              float *dst0, int n0, float *dst1) {
+                                                              float *dst0, int n0, float *dst1, int cols, int ldd) {
     __shared__ float red[16][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -68,15 +68,16 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__re
         float s = 0.f;
 #pragma unroll
         for (int g = 0; g < 16; ++g) s += red[g][threadIdx.x];
-        if (col < n0) dst0[col] = s;
+        if (col < n0) dst0[(size_t)(col / cols) * ldd + (col % cols)] = s;   // row-strided sub-block of the weight
         else if (dst1) dst1[col - n0] = s;
     }
 }
 
 int reduce_partials_launch(const float *partials, int nblocks, int n, float *dst0, int n0, float *dst1,
-                           hipStream_t stream) {
+                           hipStream_t stream, int cols, int ldd) {
+    if (cols <= 0) cols = ldd = n0 > 0 ? n0 : 1;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(n, 64)), dim3(1024), 0, stream, partials, nblocks, n, dst0,
-                       n0, dst1);
+                       n0, dst1, cols, ldd);
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }

@@ -133,6 +133,10 @@ struct PwBwdArgs {
     int residual;
     int dbg;
     int accum;   // gxa / gxb += instead of = (gradient accumulation fused into the store)
+    // generic kernel only: element strides between batch items and between weight rows, so that channel
+    // sub-ranges of larger tensors can be processed in place (chunked launches for wide layers)
+    long long s_gy, s_xa, s_xb, s_gxa, s_gxb;
+    int ldw;
     int xa_act;  // gxa *= act'(xa): xa is itself the OUTPUT of that activation (fuses PadInverse's SELU backward)
 };
 
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void pwconv_bwd_kernel(PwBwdArgs a) {
         for (int ks = 0; ks < KSO_MAX; ++ks) {
             const int i = ic * 32 + c, o = 2 * ks + h;
             const bool ok = i < a.Cin && o < a.Cout;
-            wt[ic][ks] = ok ? a.W[(size_t)o * a.Cin + i] : 0.f;
+            wt[ic][ks] = ok ? a.W[(size_t)o * a.ldw + i] : 0.f;
             if (a.residual && ok && i == o) wt[ic][ks] += 1.f;
         }
     // zero the wave's LDS tile once: rows beyond Cout / Cin must stay finite and zero
@@ -184,9 +188,9 @@ __global__ __launch_bounds__(256, 2) void pwconv_bwd_kernel(PwBwdArgs a) {
         const unsigned v = live ? (t - b * tiles_per_b) * 32 + c : 0u;
         const bool vin = live && v < V;
         const unsigned vcl = vin ? v : 0u;
-        const float *gy_b = a.gy + (size_t)b * a.Cout * V, *y_b = a.y + (size_t)b * a.Cout * V;
-        const float *xa_b = a.xa + (size_t)b * a.Ca * V;
-        const float *xb_b = a.xb ? a.xb + (size_t)b * a.Cb * V : a.xa;
+        const float *gy_b = a.gy + (size_t)b * a.s_gy, *y_b = a.y + (size_t)b * a.s_gy;
+        const float *xa_b = a.xa + (size_t)b * a.s_xa;
+        const float *xb_b = a.xb ? a.xb + (size_t)b * a.s_xb : a.xa;
         // ---- g = gy * act'(y), B-operand layout; also staged to LDS as G[o][v]
         float g[KSO_MAX];
 #pragma unroll
@@ -231,17 +235,17 @@ __global__ __launch_bounds__(256, 2) void pwconv_bwd_kernel(PwBwdArgs a) {
                     const bool ok = vin && i < a.Cin;
                     if (irow + 4 < a.Ca || irow + 4 >= a.Cin) {        // both lane halves in xa (or half 1 absent)
                         if (irow < a.Ca) {
-                            if (a.gxa && ok) { float *q_ = a.gxa + ((size_t)b * a.Ca + irow) * V + hoff4V + v; *q_ = (acc[r] * (a.xa_act != HNO_ACT_NONE ? act_grad_from_out(X[i * PWB_LD + c], a.xa_act) : 1.f)) + (a.accum ? *q_ : 0.f); }
+                            if (a.gxa && ok) { float *q_ = a.gxa + (size_t)b * a.s_gxa + (size_t)irow * V + hoff4V + v; *q_ = (acc[r] * (a.xa_act != HNO_ACT_NONE ? act_grad_from_out(X[i * PWB_LD + c], a.xa_act) : 1.f)) + (a.accum ? *q_ : 0.f); }
                         } else if (a.gxb && ok) {
-                            { float *q_ = a.gxb + ((size_t)b * a.Cb + (irow - a.Ca)) * V + hoff4V + v; *q_ = acc[r] + (a.accum ? *q_ : 0.f); }
+                            { float *q_ = a.gxb + (size_t)b * a.s_gxb + (size_t)(irow - a.Ca) * V + hoff4V + v; *q_ = acc[r] + (a.accum ? *q_ : 0.f); }
                         }
                     } else if (irow >= a.Ca) {                          // both halves in xb
-                        if (a.gxb && ok) { float *q_ = a.gxb + ((size_t)b * a.Cb + (irow - a.Ca)) * V + hoff4V + v; *q_ = acc[r] + (a.accum ? *q_ : 0.f); }
+                        if (a.gxb && ok) { float *q_ = a.gxb + (size_t)b * a.s_gxb + (size_t)(irow - a.Ca) * V + hoff4V + v; *q_ = acc[r] + (a.accum ? *q_ : 0.f); }
                     } else if (ok) {                                    // halves straddle the concat boundary
                         if (i < a.Ca) {
-                            if (a.gxa) { float *q_ = a.gxa + ((size_t)b * a.Ca + i) * V + v; *q_ = (acc[r] * (a.xa_act != HNO_ACT_NONE ? act_grad_from_out(X[i * PWB_LD + c], a.xa_act) : 1.f)) + (a.accum ? *q_ : 0.f); }
+                            if (a.gxa) { float *q_ = a.gxa + (size_t)b * a.s_gxa + (size_t)i * V + v; *q_ = (acc[r] * (a.xa_act != HNO_ACT_NONE ? act_grad_from_out(X[i * PWB_LD + c], a.xa_act) : 1.f)) + (a.accum ? *q_ : 0.f); }
                         } else if (a.gxb) {
-                            { float *q_ = a.gxb + ((size_t)b * a.Cb + (i - a.Ca)) * V + v; *q_ = acc[r] + (a.accum ? *q_ : 0.f); }
+                            { float *q_ = a.gxb + (size_t)b * a.s_gxb + (size_t)(i - a.Ca) * V + v; *q_ = acc[r] + (a.accum ? *q_ : 0.f); }
                         }
                     }
                 }
@@ -588,8 +592,6 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
     HNO_REQUIRE(act == HNO_ACT_NONE || y, "hno_pwconv_bwd: saved output y needed for the activation gradient");
     HNO_REQUIRE(Cb == 0 || xb, "hno_pwconv_bwd: xb is NULL but Cb > 0");
     const int Cin = Ca + Cb;
-    if (Cout > 32 || Cin > 64)
-        return fail(HNO_ELIMIT, "hno_pwconv_bwd: Cout=%d (max 32) / Cin=%d (max 64) outside the fused kernel limits", Cout, Cin);
     if (V * 8 >= (1ll << 32) || ((V + 31) / 32) * B >= (1ll << 31))
         return fail(HNO_ELIMIT, "hno_pwconv_bwd: V=%lld voxels per channel exceeds the 32-bit offset range", V);
     PwBwdArgs a;
@@ -600,11 +602,13 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
     a.dbg = debug_flags();
     a.xa_act = xa_act;
     a.accum = accumulate_gx;
+    a.s_gy = (long long)Cout * V; a.s_xa = (long long)Ca * V; a.s_xb = (long long)Cb * V;
+    a.s_gxa = (long long)Ca * V; a.s_gxb = (long long)Cb * V; a.ldw = Cin;
     const long long ntiles = ((V + 31) / 32) * B;
     int grid = grid_for(ntiles, 4);
     if (grid > 1024) grid = 1024;  // fewer blocks -> fewer dW atomics
-    const int ich = Cin <= 32 ? 1 : 2;
-    const size_t lds = sizeof(float) * 4 * (32 + ich * 32) * PWB_LD;
+    if (residual && (Cout > 32 || Cin > 64 || Cb > 0))
+        return fail(HNO_ELIMIT, "hno_specmix_shared_bwd: the residual (W + I) form supports C <= 32 channels");
     hipStream_t s = (hipStream_t)stream;
     const int nslab = Cout * Cin + Cout;
     if (Ca % 8 == 0 && Cb % 8 == 0) {  // exact-size fast paths
@@ -631,21 +635,60 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
             return reduce_partials_launch(a.partials, (int)fg, nslab, dW, Cout * Cin, dbias, s);
         }
     }
-    {
-    ProfScope ps(KID_PWCONV_BWD, s, 4.0 * B * (double)V * ((act != HNO_ACT_NONE ? 2 : 1) * Cout + Cin + (gxa ? Ca : 0) + (gxb ? Cb : 0)));
-    if (Cout <= 8) {
-        if (ich == 1) hipLaunchKernelGGL((pwconv_bwd_kernel<4, 1>), dim3(grid), dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((pwconv_bwd_kernel<4, 2>), dim3(grid), dim3(256), lds, s, a);
-    } else if (Cout <= 24) {
-        if (ich == 1) hipLaunchKernelGGL((pwconv_bwd_kernel<12, 1>), dim3(grid), dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((pwconv_bwd_kernel<12, 2>), dim3(grid), dim3(256), lds, s, a);
-    } else {
-        if (ich == 1) hipLaunchKernelGGL((pwconv_bwd_kernel<16, 1>), dim3(grid), dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((pwconv_bwd_kernel<16, 2>), dim3(grid), dim3(256), lds, s, a);
+    // generic path: any channel counts, processed as (<= 32 output) x (<= 64 input) channel blocks of the
+    // concatenated input; input gradients accumulate over the output blocks, each weight block is reduced
+    // from its own slabs into the strided sub-block of dW
+    struct Seg { const float *x; float *gx; int C; int off; };
+    const Seg segs[2] = {{xa, gxa, Ca, 0}, {xb, gxb, Cb, Ca}};
+    bool first_block = true;
+    for (int sgi = 0; sgi < 2; ++sgi) {
+        const Seg &sg = segs[sgi];
+        for (int i0 = 0; i0 < sg.C; i0 += 64) {
+            const int ci = sg.C - i0 < 64 ? sg.C - i0 : 64;
+            for (int o0 = 0; o0 < Cout; o0 += 32) {
+                const int co = Cout - o0 < 32 ? Cout - o0 : 32;
+                PwBwdArgs c = a;
+                c.gy = gy + (size_t)o0 * V;
+                c.y = (y ? y : gy) + (size_t)o0 * V;
+                c.s_gy = (long long)Cout * V;
+                c.xa = sg.x + (size_t)i0 * V;
+                c.s_xa = (long long)sg.C * V;
+                c.xb = nullptr; c.s_xb = 0;
+                c.Ca = ci; c.Cb = 0; c.Cin = ci; c.Cout = co;
+                c.W = W + (size_t)o0 * Cin + sg.off + i0;
+                c.ldw = Cin;
+                c.gxa = sg.gx ? sg.gx + (size_t)i0 * V : nullptr;
+                c.s_gxa = (long long)sg.C * V;
+                c.gxb = nullptr; c.s_gxb = 0;
+                c.accum = (accumulate_gx || o0 > 0) ? 1 : 0;
+                c.xa_act = (sgi == 0) ? xa_act : HNO_ACT_NONE;
+                c.dbias = (dbias && first_block) ? dbias : nullptr;   // kernel only needs non-null to compute it
+                const int ich = ci <= 32 ? 1 : 2;
+                const size_t lds = sizeof(float) * 4 * (32 + ich * 32) * PWB_LD;
+                {
+                    ProfScope ps(KID_PWCONV_BWD, s, 4.0 * B * (double)V * ((act != HNO_ACT_NONE ? 2 : 1) * co + ci + (c.gxa ? ci : 0)));
+                    if (co <= 8) {
+                        if (ich == 1) hipLaunchKernelGGL((pwconv_bwd_kernel<4, 1>), dim3(grid), dim3(256), lds, s, c);
+                        else hipLaunchKernelGGL((pwconv_bwd_kernel<4, 2>), dim3(grid), dim3(256), lds, s, c);
+                    } else if (co <= 24) {
+                        if (ich == 1) hipLaunchKernelGGL((pwconv_bwd_kernel<12, 1>), dim3(grid), dim3(256), lds, s, c);
+                        else hipLaunchKernelGGL((pwconv_bwd_kernel<12, 2>), dim3(grid), dim3(256), lds, s, c);
+                    } else {
+                        if (ich == 1) hipLaunchKernelGGL((pwconv_bwd_kernel<16, 1>), dim3(grid), dim3(256), lds, s, c);
+                        else hipLaunchKernelGGL((pwconv_bwd_kernel<16, 2>), dim3(grid), dim3(256), lds, s, c);
+                    }
+                }
+                HNO_CHECK_LAUNCH();
+                // the bias gradient of an output block is the same in every input block: take it from the first
+                const bool want_bias = dbias && sgi == 0 && i0 == 0;
+                int rc = reduce_partials_launch(a.partials, grid, co * ci + co, dW + (size_t)o0 * Cin + sg.off + i0, co * ci,
+                                                want_bias ? dbias + o0 : nullptr, s, ci, Cin);
+                if (rc) return rc;
+                first_block = false;
+            }
+        }
     }
-    }
-    HNO_CHECK_LAUNCH();
-    return reduce_partials_launch(a.partials, grid, nslab, dW, Cout * Cin, dbias, s);
+    return HNO_OK;
 }
 
 }  // namespace hno

@@ -1,0 +1,46 @@
+"""fwd + loss + bwd time of every model family at the BASELINE.json config sizes (parity-test configs, not
+the headline bench line)."""
+import sys, os, time, json
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import multimodal_3d_image_segmentation_amd as pkg
+from multimodal_3d_image_segmentation_amd.nets import custom_losses
+nets = pkg.nets
+CASES = {
+    'hnosegxs_cfg2': (lambda: nets.HNOSegXS(4, 4, 24, [3] * 8, (10, 14, 14)), (2, 4, 128, 128, 128)),
+    'fnoseg_cfg3': (lambda: nets.NeuralOperatorSeg(4, 4, 24, 24, (10, 14, 14), 'Fourier'), (2, 4, 128, 128, 128)),
+    'hnoseg': (lambda: nets.NeuralOperatorSeg(4, 4, 24, 24, (10, 14, 14), 'Hartley'), (2, 4, 128, 128, 128)),
+    'fno_individual': (lambda: nets.NeuralOperatorSeg(4, 4, 12, 4, (10, 14, 14), 'Fourier', weights_type='individual',
+                                                      use_bias_conv_branch=True, use_block_skip=False), (2, 4, 128, 128, 128)),
+    'hartleymha': (lambda: nets.HartleyMHASeg(4, 4, 12, 16, 4, (10, 14, 14), (2, 2, 2)), (1, 4, 128, 128, 128)),
+    'vnetds_cfg4': (lambda: nets.VNetDS(4, 4, 24, [1, 2, 3, 3, 3], right_leg_indexes=[0, 1, 2, 3, 4]), (1, 4, 160, 192, 128)),
+}
+which = sys.argv[1:] or list(CASES)
+for name in which:
+    ctor, shape = CASES[name]
+    torch.manual_seed(0)
+    model = ctor().cuda()
+    x = torch.randn(shape, device='cuda')
+    lab = pkg.ops.labels_prepare(torch.randint(0, 4, (shape[0], 1) + shape[2:], device='cuda').float(), 4)
+    loss_fn = custom_losses.PCCLoss()
+    def step():
+        for p in model.parameters(): p.grad = None
+        loss = loss_fn(model(x), lab); loss.backward(); return loss
+    try:
+        step(); step()
+        torch.cuda.synchronize(); t0 = time.time(); n = 5
+        for _ in range(n): l = step()
+        torch.cuda.synchronize(); dt = (time.time() - t0) / n
+        with pkg._lib.KernelProfile() as kp:
+            step()
+        torch.cuda.synchronize()
+        top = sorted(kp.summary().items(), key=lambda kv: -kv[1][1])[:6]
+        print(json.dumps({'model': name, 'shape': shape, 'params': sum(p.numel() for p in model.parameters()),
+                          'ms_per_step': round(dt * 1e3, 2), 'volumes_per_s': round(shape[0] / dt, 2), 'loss': round(float(l), 5),
+                          'max_mem_GB': round(torch.cuda.max_memory_allocated() / 1e9, 2),
+                          'top_kernels_ms': {k: round(v[1], 2) for k, v in top}}))
+    except Exception as e:
+        print(json.dumps({'model': name, 'error': repr(e)[:300]}))
+    del model, x
+    torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
