@@ -154,11 +154,14 @@ def main():
             print(f'[bench] HIP graph capture failed ({exc!r}); running eagerly', file=sys.stderr)
             graph = None
 
+    # the gradient tensors the captured backward writes (replays refill them in place)
+    captured_grads = [p.grad for p in rep.params] if graph is not None else None
+
     def step():
         if graph is None:
             return eager_step()
         graph.replay()
-        rep.allreduce_grads()
+        rep.allreduce_grads(captured_grads)
         opt.step()
         return static_loss
 

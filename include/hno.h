@@ -82,13 +82,25 @@ int hno_irfft3_pad(const float *spec, const float *addend, int act, float *out, 
  * einsum 'oi,bidhw->bodhw' of HartleyOperator._call3d_notransform
  * (nets/hartley_operator.py:287-292).
  * Backward: given g = dL/dz_L, the saved z_0 and zs, produces dL/dz_0 and WRITES
- * dL/dW into dW (L, C, C).  workspace: hno_pwconv_bwd_workspace_bytes(C, C).
+ * dL/dW into dW (L, C, C).  workspace: hno_specmix_bwd_workspace_bytes(B, C, M, L).
  */
+size_t hno_specmix_bwd_workspace_bytes(int B, int C, int M, int L);
 int hno_specmix_shared_fwd(const float *z0, const float *W, float *zs, int B, int C, int M, int L,
                            int residual, int act, void *stream);
 int hno_specmix_shared_bwd(const float *g, const float *z0, const float *zs, const float *W, float *gz0,
                            float *dW, void *workspace, int B, int C, int M, int L, int residual, int act,
                            void *stream);
+/* Same, with the layer weights given as a HOST array of L device pointers, each (C, C): the
+ * form the model uses, because the reference keeps one Parameter per layer
+ * (state-dict keys layers.{i}.conv_blocks.{j}.op.weight) and stacking them would cost a copy per
+ * block and step.  dW stays one (L, C, C) block (a view per layer on the Python side).
+ * L <= 64.  Up to C = 32 the whole stack is ONE kernel each way (weights and the 32-mode tile stay
+ * in registers between layers); wider stacks run layer by layer through hno_pwconv. */
+int hno_specmix_layers_fwd(const float *z0, const float *const *W_layers, float *zs, int B, int C, int M,
+                           int L, int residual, int act, void *stream);
+int hno_specmix_layers_bwd(const float *g, const float *z0, const float *zs, const float *const *W_layers,
+                           float *gz0, float *dW, void *workspace, int B, int C, int M, int L, int residual,
+                           int act, void *stream);
 
 /* ------------------------------------------------------------ 1x1x1 convolution (+concat)
  * y[b, o, v] = act( sum_i W[o, i] * [xa ; xb][b, i, v] + bias[o] ),  W is (Cout, Ca+Cb).

@@ -27,6 +27,9 @@ SIGNATURES = {
     'hno_irfft3_pad': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_int, c_void_p]),
     'hno_specmix_shared_fwd': (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     'hno_specmix_shared_bwd': (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
+    'hno_specmix_bwd_workspace_bytes': (c_size_t, [c_int] * 4),
+    'hno_specmix_layers_fwd': (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
+    'hno_specmix_layers_bwd': (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
     'hno_pwconv_fwd': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_void_p]),
     'hno_pwconv_bwd_workspace_bytes': (c_size_t, [c_int, c_int]),
     'hno_pwconv_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

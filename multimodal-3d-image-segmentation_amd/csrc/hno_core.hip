@@ -27,7 +27,7 @@ int debug_flags() { return g_debug_flags; }
 static const char *kKernelNames[KID_COUNT] = {
     "dht_fwd_plane_kernel", "dht_fwd_d_kernel", "dht_inv_d_kernel", "dht_inv_plane_kernel", "pwconv_fwd_kernel",
     "pwconv_bwd_kernel", "conv_k2s2_fwd_kernel", "conv_k2s2_bwd_kernel", "upsoftmax_fwd_kernel", "upsoftmax_bwd_kernel",
-    "loss_stats_kernel", "loss_finalize_kernel", "loss_bwd_kernel", "labels_kernel"};
+    "loss_stats_kernel", "loss_finalize_kernel", "loss_bwd_kernel", "labels_kernel", "specmix_fwd_kernel", "specmix_bwd_kernel", "reduce_partials_kernel"};
 static bool g_prof_on = false;
 static std::vector<hipEvent_t> g_prof_events;  // 2 per record
 static std::vector<int> g_prof_ids;
@@ -76,6 +76,7 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__re
 int reduce_partials_launch(const float *partials, int nblocks, int n, float *dst0, int n0, float *dst1,
                            hipStream_t stream, int cols, int ldd) {
     if (cols <= 0) cols = ldd = n0 > 0 ? n0 : 1;
+    ProfScope ps(KID_REDUCE_PARTIALS, stream, 4.0 * n * ((double)nblocks + 1));
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(n, 64)), dim3(1024), 0, stream, partials, nblocks, n, dst0,
                        n0, dst1, cols, ldd);
     HNO_CHECK_LAUNCH();

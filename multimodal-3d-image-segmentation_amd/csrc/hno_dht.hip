@@ -492,6 +492,63 @@ __global__ __launch_bounds__(256, 3) void dht_fwd_plane_spec_kernel(const float 
     }
 }
 
+// Recombination + crop store of one (kt0, k1s, kt2) tile of the forward D transform.  The lane holds, for
+// k0 = kt0*16 + (lane&15) and k2 = kt2*16 + q*4 + r:
+//   X(+k0) = (PR + QI) + i (PI - QR),  X(-k0) = (PR - QI) + i (PI + QR)
+__device__ __forceinline__ void fwd_d_store(const DhtArgs &a, float *__restrict__ out, int bc, int k1s, int kt2, int kt0, int lane,
+                                            const f32x4 &PR, const f32x4 &PI, const f32x4 &QR, const f32x4 &QI) {
+    const DhtPlan &p = a.p;
+    const int m0 = p.ax[0].m, m1 = p.ax[1].m, m2 = p.ax[2].m;
+    const int q = lane >> 4;
+    float *ob = out + (size_t)bc * (2 * m0) * (2 * m1) * (2 * m2);
+    const int k0 = kt0 * 16 + (lane & 15);
+    const int k1 = k1s - m1;
+    if (k0 <= m0 && a.mode != 0) {
+        // Fourier half spectrum: S[b][re|im][c][o0][o1][k2], k2 in [0, m2)
+        const int b = bc / a.C, c = bc - b * a.C;
+        const size_t msz = (size_t)(2 * m0) * (2 * m1) * m2;
+        float *sr = out + ((size_t)(b * 2 + 0) * a.C + c) * msz, *si = out + ((size_t)(b * 2 + 1) * a.C + c) * msz;
+        const int o1 = kept_pos(k1, m1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k2 = kt2 * 16 + q * 4 + r;
+            if (k2 >= m2 || o1 < 0) continue;
+            const float w = a.scale * ((a.mode == 2 && k2 > 0) ? 2.f : 1.f);
+#pragma unroll
+            for (int sgn = 0; sgn < 2; ++sgn) {
+                if (sgn == 1 && k0 == 0) continue;
+                const int o0 = kept_pos(sgn ? -k0 : k0, m0);
+                if (o0 < 0) continue;
+                const size_t idx = ((size_t)o0 * (2 * m1) + o1) * m2 + k2;
+                sr[idx] = w * (sgn ? PR[r] - QI[r] : PR[r] + QI[r]);
+                si[idx] = w * (sgn ? PI[r] + QR[r] : PI[r] - QR[r]);
+            }
+        }
+    } else if (k0 <= m0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k2 = kt2 * 16 + q * 4 + r;
+            if (k2 > m2) continue;
+#pragma unroll
+            for (int sgn = 0; sgn < 2; ++sgn) {
+                if (sgn == 1 && k0 == 0) continue;
+                const int kk0 = sgn ? -k0 : k0;
+                const float xr = sgn ? PR[r] - QI[r] : PR[r] + QI[r];
+                const float xi = sgn ? PI[r] + QR[r] : PI[r] - QR[r];
+                // H[k] = Re X[k] - Im X[k]
+                int o0 = kept_pos(kk0, m0), o1 = kept_pos(k1, m1);
+                if (k2 < m2 && o0 >= 0 && o1 >= 0)
+                    ob[((size_t)o0 * (2 * m1) + o1) * (2 * m2) + k2] = a.scale * (xr - xi);
+                // H[-k] = Re X[k] + Im X[k]
+                o0 = kept_pos(-kk0, m0);
+                o1 = kept_pos(-k1, m1);
+                if (k2 >= 1 && o0 >= 0 && o1 >= 0)
+                    ob[((size_t)o0 * (2 * m1) + o1) * (2 * m2) + (2 * m2 - k2)] = a.scale * (xr + xi);
+            }
+        }
+    }
+}
+
 // ---- forward, axis D + (Re -/+ Im) + crop: one wave per (bc, column tile) ----------------
 __global__ __launch_bounds__(64) void dht_fwd_d_kernel(const float *__restrict__ Y, float *__restrict__ out, DhtArgs a) {
     extern __shared__ float lds[];
@@ -562,55 +619,65 @@ __global__ __launch_bounds__(64) void dht_fwd_d_kernel(const float *__restrict__
                 QI = mfma16(inn[u] ? vi[u] - wi[u] : 0.f, bb[u], QI);
             }
         }
-        // lane holds, for k0 = kt0*16 + (lane&15) and k2 = kt2*16 + q*4 + r:
-        //   X(+k0) = (PR + QI) + i (PI - QR),  X(-k0) = (PR - QI) + i (PI + QR)
-        const int k0 = kt0 * 16 + (lane & 15);
-        const int k1 = k1s - m1;
-        if (k0 <= m0 && a.mode != 0) {
-            // Fourier half spectrum: S[b][re|im][c][o0][o1][k2], k2 in [0, m2)
-            const int b = bc / a.C, c = bc - b * a.C;
-            const size_t msz = (size_t)(2 * m0) * (2 * m1) * m2;
-            float *sr = out + ((size_t)(b * 2 + 0) * a.C + c) * msz, *si = out + ((size_t)(b * 2 + 1) * a.C + c) * msz;
-            const int o1 = kept_pos(k1, m1);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k2 = kt2 * 16 + q * 4 + r;
-                if (k2 >= m2 || o1 < 0) continue;
-                const float w = a.scale * ((a.mode == 2 && k2 > 0) ? 2.f : 1.f);
-#pragma unroll
-                for (int sgn = 0; sgn < 2; ++sgn) {
-                    if (sgn == 1 && k0 == 0) continue;
-                    const int o0 = kept_pos(sgn ? -k0 : k0, m0);
-                    if (o0 < 0) continue;
-                    const size_t idx = ((size_t)o0 * (2 * m1) + o1) * m2 + k2;
-                    sr[idx] = w * (sgn ? PR[r] - QI[r] : PR[r] + QI[r]);
-                    si[idx] = w * (sgn ? PI[r] + QR[r] : PI[r] - QR[r]);
-                }
-            }
-        } else if (k0 <= m0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k2 = kt2 * 16 + q * 4 + r;
-                if (k2 > m2) continue;
-#pragma unroll
-                for (int sgn = 0; sgn < 2; ++sgn) {
-                    if (sgn == 1 && k0 == 0) continue;
-                    const int kk0 = sgn ? -k0 : k0;
-                    const float xr = sgn ? PR[r] - QI[r] : PR[r] + QI[r];
-                    const float xi = sgn ? PI[r] + QR[r] : PI[r] - QR[r];
-                    // H[k] = Re X[k] - Im X[k]
-                    int o0 = kept_pos(kk0, m0), o1 = kept_pos(k1, m1);
-                    if (k2 < m2 && o0 >= 0 && o1 >= 0)
-                        ob[((size_t)o0 * (2 * m1) + o1) * (2 * m2) + k2] = a.scale * (xr - xi);
-                    // H[-k] = Re X[k] + Im X[k]
-                    o0 = kept_pos(-kk0, m0);
-                    o1 = kept_pos(-k1, m1);
-                    if (k2 >= 1 && o0 >= 0 && o1 >= 0)
-                        ob[((size_t)o0 * (2 * m1) + o1) * (2 * m2) + (2 * m2 - k2)] = a.scale * (xr + xi);
-                }
-            }
-        }
+        fwd_d_store(a, out, bc, k1s, kt2, kt0, lane, PR, PI, QR, QI);
     }
+}
+
+// Fast form for m0 <= 15 (one k0 tile) and N0 <= 4*KCS - 1: every gather load of the wave (and its
+// table operands, straight from global memory) is issued before the first use, so the kernel is one
+// memory round trip instead of one per group of four k-steps, and needs neither LDS nor a barrier.
+template <int KCS, int KSS>
+__global__ __launch_bounds__(64) void dht_fwd_d_fast_kernel(const float *__restrict__ Y, float *__restrict__ out, DhtArgs a) {
+    const DhtPlan &p = a.p;
+    const Axis &a0 = p.ax[0], &a2 = p.ax[2];
+    const int lane = threadIdx.x;
+    const int ct = blockIdx.x, bc = blockIdx.y;
+    const int k1s = ct / a2.KT, kt2 = ct % a2.KT;
+    const int N0 = a0.N;
+    const size_t pstride = (size_t)2 * p.CP;
+    const float *Yb = Y + (size_t)bc * N0 * pstride;
+    const int colR = ct * 16 + (lane & 15), colI = p.CP + colR;
+    const int q = lane >> 4;
+    const float *__restrict__ tc = p.tables + a0.cosF, *__restrict__ ts = p.tables + a0.sinF;
+    const int nkc = a0.KcP / 4, nks = a0.KsP / 4;
+    float vr[KCS], vi[KCS], wr[KCS], wi[KCS], bcv[KCS];
+    float sr[KSS], si[KSS], tr[KSS], ti[KSS], bsv[KSS];
+    bool prd[KCS];
+#pragma unroll
+    for (int ks = 0; ks < KCS; ++ks) {
+        const int c = ks * 4 + q;
+        const bool inn = ks < nkc && c <= a0.J;
+        prd[ks] = inn && c >= 1 && c <= a0.Js;
+        const int c1 = inn ? c : 0, c2 = prd[ks] ? N0 - c : 0;
+        vr[ks] = Yb[c1 * pstride + colR];
+        vi[ks] = Yb[c1 * pstride + colI];
+        wr[ks] = Yb[c2 * pstride + colR];
+        wi[ks] = Yb[c2 * pstride + colI];
+        bcv[ks] = ks < nkc ? tc[(ks * 4 + q) * 16 + (lane & 15)] : 0.f;   // zero rows beyond J mask the operand
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSS; ++ks) {
+        const int kk = ks * 4 + q;
+        const bool inn = ks < nks && kk < a0.Js;
+        const int j = inn ? a0.Js - kk : 0, j2 = inn ? N0 - j : 0;
+        sr[ks] = Yb[j * pstride + colR];
+        si[ks] = Yb[j * pstride + colI];
+        tr[ks] = Yb[j2 * pstride + colR];
+        ti[ks] = Yb[j2 * pstride + colI];
+        bsv[ks] = ks < nks ? ts[(ks * 4 + q) * 16 + (lane & 15)] : 0.f;   // masked lanes: j = j2 = 0, so sr - tr = 0
+    }
+    f32x4 PR = {0.f, 0.f, 0.f, 0.f}, PI = PR, QR = PR, QI = PR;
+#pragma unroll
+    for (int ks = 0; ks < KCS; ++ks) {
+        PR = mfma16(vr[ks] + (prd[ks] ? wr[ks] : 0.f), bcv[ks], PR);
+        PI = mfma16(vi[ks] + (prd[ks] ? wi[ks] : 0.f), bcv[ks], PI);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSS; ++ks) {
+        QR = mfma16(sr[ks] - tr[ks], bsv[ks], QR);
+        QI = mfma16(si[ks] - ti[ks], bsv[ks], QI);
+    }
+    fwd_d_store(a, out, bc, k1s, kt2, 0, lane, PR, PI, QR, QI);
 }
 
 // ---- inverse, axis D: spectrum block -> E[bc][n0][part][k1s][k2] --------------------------
@@ -622,15 +689,35 @@ __device__ __forceinline__ float zk_load(const float *__restrict__ zb, int k0, i
     return ok ? v : 0.f;
 }
 
+// NTM > 0: fast form for NT <= NTM output tiles -- the table operands of every (tile, k-step) are loaded
+// straight from global memory into registers together with the spectrum gathers, so the wave makes
+// one memory round trip and needs neither LDS nor a barrier.  NTM == 0: tables staged in LDS.
+template <int NTM>
 __global__ __launch_bounds__(64) void dht_inv_d_kernel(const float *__restrict__ z, float *__restrict__ E, DhtArgs a) {
     extern __shared__ float lds[];
     const DhtPlan &p = a.p;
     const Axis &a0 = p.ax[0], &a1 = p.ax[1], &a2 = p.ax[2];
     const int lane = threadIdx.x;
-    const int ntab = 2 * a0.NT * a0.KmP * 16;
-    for (int i = lane; i < ntab; i += 64) lds[i] = p.tables[a0.cosI + i];
-    __syncthreads();
+    constexpr int KSM = 8;
+    constexpr int NTR = NTM > 0 ? NTM : 1;
+    float tcv[NTR][KSM], tsv[NTR][KSM];
     const float *cosD = lds, *sinD = lds + a0.NT * a0.KmP * 16;
+    if (NTM > 0) {
+        const float *__restrict__ tc = p.tables + a0.cosI, *__restrict__ ts = p.tables + a0.sinI;
+#pragma unroll
+        for (int nt = 0; nt < NTR; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < KSM; ++ks) {
+                const bool ok = nt < a0.NT && ks < a0.KmP / 4;
+                const int idx = ok ? (nt * a0.KmP + ks * 4 + (lane >> 4)) * 16 + (lane & 15) : 0;
+                tcv[nt][ks] = tc[idx];
+                tsv[nt][ks] = ts[idx];
+            }
+    } else {
+        const int ntab = 2 * a0.NT * a0.KmP * 16;
+        for (int i = lane; i < ntab; i += 64) lds[i] = p.tables[a0.cosI + i];
+        __syncthreads();
+    }
     const int ct = blockIdx.x, bc = blockIdx.y;
     const int k1s = ct / a2.KT, kt2 = ct % a2.KT;
     const int m0 = a0.m, m1 = a1.m, m2 = a2.m, N0 = a0.N;
@@ -643,7 +730,6 @@ __global__ __launch_bounds__(64) void dht_inv_d_kernel(const float *__restrict__
     const size_t pstride = (size_t)2 * p.CP;
     float *Eb = E + (size_t)bc * N0 * pstride;
     // operands do not depend on the output tile: gather them once (up to 8 k-steps = m0 <= 31)
-    constexpr int KSM = 8;
     float gsr[KSM], gsi[KSM], gdr[KSM], gdi[KSM];
     // Fourier layout: re / im planes of this (b, c)
     const int fb = a.mode ? bc / a.C : 0, fc = a.mode ? bc - fb * a.C : 0;
@@ -686,13 +772,15 @@ __global__ __launch_bounds__(64) void dht_inv_d_kernel(const float *__restrict__
             }
         }
     }
-    for (int nt = 0; nt < a0.NT; ++nt) {
+#pragma unroll
+    for (int nt = 0; nt < (NTM > 0 ? NTM : 64); ++nt) {
+        if (nt >= a0.NT) break;
         f32x4 UR = {0.f, 0.f, 0.f, 0.f}, UI = UR, VR = UR, VI = UR;
 #pragma unroll
         for (int ks = 0; ks < KSM; ++ks) {
             if (ks < KS) {
-                const float bcv = cosD[(nt * a0.KmP + ks * 4 + q) * 16 + (lane & 15)];
-                const float bsv = sinD[(nt * a0.KmP + ks * 4 + q) * 16 + (lane & 15)];
+                const float bcv = NTM > 0 ? tcv[nt < NTR ? nt : 0][ks] : cosD[(nt * a0.KmP + ks * 4 + q) * 16 + (lane & 15)];
+                const float bsv = NTM > 0 ? tsv[nt < NTR ? nt : 0][ks] : sinD[(nt * a0.KmP + ks * 4 + q) * 16 + (lane & 15)];
                 UR = mfma16(gsr[ks], bcv, UR);
                 UI = mfma16(gsi[ks], bcv, UI);
                 VR = mfma16(gdr[ks], bsv, VR);
@@ -1171,8 +1259,14 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
     }
     const Axis &a0 = plan->ax[0];
     const size_t ldsd = sizeof(float) * a0.KT * (a0.KcP + a0.KsP) * 16;
-    { ProfScope _ps(KID_DHT_FWD_D, s, 4.0 * BC * 8.0 * m0 * m1 * m2); hipLaunchKernelGGL(dht_fwd_d_kernel, dim3(plan->K1S * plan->ax[2].KT, BC), dim3(64), ldsd, s,
-                       (const float *)workspace, out, a); }
+    {
+        ProfScope _ps(KID_DHT_FWD_D, s, 4.0 * BC * 8.0 * m0 * m1 * m2);
+        const dim3 gd(plan->K1S * plan->ax[2].KT, BC);
+        if (a0.KT == 1 && a0.KcP <= 36 && a0.KsP <= 32 && !(a.dbg & 32))
+            hipLaunchKernelGGL((dht_fwd_d_fast_kernel<9, 8>), gd, dim3(64), 0, s, (const float *)workspace, out, a);
+        else
+            hipLaunchKernelGGL(dht_fwd_d_kernel, gd, dim3(64), ldsd, s, (const float *)workspace, out, a);
+    }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }
@@ -1207,8 +1301,14 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
     }
     const Axis &a0 = plan->ax[0];
     const size_t ldsd = sizeof(float) * 2 * a0.NT * a0.KmP * 16;
-    { ProfScope _ps(KID_DHT_INV_D, s, 4.0 * BC * 8.0 * m0 * m1 * m2); hipLaunchKernelGGL(dht_inv_d_kernel, dim3(plan->K1S * plan->ax[2].KT, BC), dim3(64), ldsd, s, z,
-                       (float *)workspace, a); }
+    {
+        ProfScope _ps(KID_DHT_INV_D, s, 4.0 * BC * 8.0 * m0 * m1 * m2);
+        const dim3 gd(plan->K1S * plan->ax[2].KT, BC);
+        if (a0.NT <= 3 && !(a.dbg & 32))
+            hipLaunchKernelGGL(dht_inv_d_kernel<3>, gd, dim3(64), 0, s, z, (float *)workspace, a);
+        else
+            hipLaunchKernelGGL(dht_inv_d_kernel<0>, gd, dim3(64), ldsd, s, z, (float *)workspace, a);
+    }
     HNO_CHECK_LAUNCH();
     const int planes = BC * N0;
     int per_cu = (int)(kMaxLds / lds);

@@ -300,12 +300,20 @@ __global__ __launch_bounds__(256, 2) void pwconv_bwd_kernel(PwBwdArgs a) {
 // ------------------------------------------------------------------------------ fast paths
 // Exact-size specialisations (no runtime channel guards, hence no branchy code and ~100 VGPRs):
 // Ca % 8 == 0, Cb % 8 == 0, CIN = 2*NKI, COUT = 2*NKO (<= 32), whole problem in one launch.
-template <int NKI, int COUT>
-__global__ __launch_bounds__(256, 4) void pwconv_fwd_fast_kernel(PwArgs a) {
+// Tuning notes (tools/pwbench.hip, 48->24 at 2 x 65^3): this streaming shape runs best with FEW waves
+// per CU (one 512-thread block per CU, grid = number of CUs, grid-stride over tiles): 37 us against
+// 42 us at 16 waves/CU and 46-50 us with one tile per wave; 8/16-byte-per-lane loads, explicit
+// software prefetch, XCD-contiguous tile order and non-temporal stores made no difference or hurt.
+#define PWF_FAST_WAVES 8
+template <int CA, int CB, int COUT>   // channel counts of xa / xb (both even) are compile-time: all address selects fold
+__global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_fast_kernel(PwArgs a) {
+    constexpr int NW = PWF_FAST_WAVES;
+    constexpr int NKI = (CA + CB) / 2;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, c = lane & 31;
     constexpr int CIN = 2 * NKI;
+    constexpr int NR = COUT > 28 ? 16 : (COUT > 20 ? 12 : (COUT > 12 ? 8 : 4));   // accumulator registers holding rows < COUT
     const unsigned V = a.V;
     float w[NKI];
 #pragma unroll
@@ -314,39 +322,33 @@ __global__ __launch_bounds__(256, 4) void pwconv_fwd_fast_kernel(PwArgs a) {
         w[ks] = c < COUT ? a.W[(size_t)c * CIN + i] : 0.f;
         if (a.residual && c == i) w[ks] += 1.f;
     }
-    float bias_r[16];
+    float bias_r[NR];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < NR; ++r) {
         const int o = (r & 3) + 8 * (r >> 2) + 4 * h;
         bias_r[r] = (a.bias && o < COUT) ? a.bias[o] : 0.f;
     }
+    // branch-free activation: act(x) = (x > 0 or linear) ? ap * x : aq * (e^x - 1)
+    const float ap = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f;
+    const float aq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
+    const bool lin = a.act == HNO_ACT_NONE;
     const unsigned tiles_per_b = (V + 31) / 32;
     const unsigned ntiles = tiles_per_b * a.B;
     const unsigned hoffV = h ? V : 0u, hoff4V = h ? 4u * V : 0u;
-    const unsigned stride = gridDim.x * 4;
-    // software pipeline: the loads of tile t + stride are in flight while tile t runs its MFMAs
-    float xv[NKI], xn[NKI];
-    auto fetch = [&](unsigned t, float (&dst)[NKI]) {
-        const unsigned b = t / tiles_per_b;
-        const unsigned v = (t - b * tiles_per_b) * 32 + c;
-        const unsigned off = hoffV + (v < V ? v : 0u);
-        const float *xa_b = a.xa + (size_t)b * a.Ca * V;
-        const float *xb_b = a.xb ? a.xb + (size_t)b * a.Cb * V : a.xa;
-#pragma unroll
-        for (int ks = 0; ks < NKI; ++ks) {
-            const int i0 = 2 * ks;
-            const float *base = i0 < a.Ca ? xa_b + (size_t)i0 * V : xb_b + (size_t)(i0 - a.Ca) * V;
-            dst[ks] = base[off];
-        }
-    };
-    unsigned t = blockIdx.x * 4 + wave;
-    if (t < ntiles) fetch(t, xv);
-    for (; t < ntiles; t += stride) {
+    for (unsigned t = blockIdx.x * NW + wave; t < ntiles; t += gridDim.x * NW) {
         const unsigned b = t / tiles_per_b;
         const unsigned v = (t - b * tiles_per_b) * 32 + c;
         const bool vin = v < V;
-        float *y_b = a.y + (size_t)b * COUT * V;
-        if (t + stride < ntiles) fetch(t + stride, xn);
+        const unsigned off = hoffV + (vin ? v : 0u);
+        const float *xa_b = a.xa + (size_t)b * CA * V;
+        const float *xb_b = CB > 0 ? a.xb + (size_t)b * CB * V : a.xa;
+        float xv[NKI];
+#pragma unroll
+        for (int ks = 0; ks < NKI; ++ks) {
+            const int i0 = 2 * ks;
+            const float *base = i0 < CA ? xa_b + (size_t)i0 * V : xb_b + (size_t)(i0 - CA) * V;
+            xv[ks] = base[off];
+        }
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -357,14 +359,14 @@ __global__ __launch_bounds__(256, 4) void pwconv_fwd_fast_kernel(PwArgs a) {
 #pragma unroll
             for (int ks = 0; ks < NKI; ++ks) acc = mfma32(w[ks], xv[ks], acc);
         }
+        float *y_b = a.y + (size_t)b * COUT * V;
         if (!(a.dbg & 2)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < NR; ++r) {
                 const int orow = (r & 3) + 8 * (r >> 2);
-                if (orow < COUT) {   // compile-time after unrolling
-                    const float val = act_apply(acc[r] + bias_r[r], a.act);
-                    if (vin && (orow + 4 < COUT || h == 0)) (y_b + (size_t)orow * V)[hoff4V + v] = val;
-                }
+                const float x = acc[r] + bias_r[r];
+                const float val = (x > 0.f || lin) ? ap * x : aq * neg_expm1(x);
+                if (vin && (orow + 4 < COUT || h == 0)) (y_b + (size_t)orow * V)[hoff4V + v] = val;
             }
         } else {
             float sacc = 0.f;
@@ -372,20 +374,17 @@ __global__ __launch_bounds__(256, 4) void pwconv_fwd_fast_kernel(PwArgs a) {
             for (int r = 0; r < 16; ++r) sacc += acc[r];
             if (sacc == 12345.678f) y_b[0] = sacc;
         }
-#pragma unroll
-        for (int ks = 0; ks < NKI; ++ks) xv[ks] = xn[ks];
     }
 }
 
-#define PWB_FAST_WAVES 12  // 768-thread blocks, one per CU: 256 slabs instead of 1024
-template <int NKO, int NKI>
-__global__ __launch_bounds__(64 * PWB_FAST_WAVES) void pwconv_bwd_fast_kernel(PwBwdArgs a) {
-    constexpr int NW = PWB_FAST_WAVES;
+#define PWB_FAST_WAVES 4   // 256-thread blocks, two per CU (512 slabs): measured best of {4, 8, 12} waves x {256, 512, 1024} blocks
+template <int COUT, int CA, int CB, int NW = PWB_FAST_WAVES>   // compile-time channel counts: every address select folds
+__global__ __launch_bounds__(64 * NW) void pwconv_bwd_fast_kernel(PwBwdArgs a) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, c = lane & 31;
-    constexpr int COUT = 2 * NKO, CIN = 2 * NKI, ICH = (CIN + 31) / 32;
+    constexpr int CIN = CA + CB, NKO = COUT / 2, NKI = CIN / 2, ICH = (CIN + 31) / 32;
     constexpr int MT = (COUT + 15) / 16, NTI = (CIN + 15) / 16;
     constexpr int rowsG = MT * 16, rowsX = NTI * 16;
     const unsigned V = a.V;
@@ -409,6 +408,11 @@ __global__ __launch_bounds__(64 * PWB_FAST_WAVES) void pwconv_bwd_fast_kernel(Pw
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NTI; ++n) dw[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // branch-free activation derivatives from the saved outputs: act'(y) = (y > 0 or linear) ? dp : y + dq
+    const float dp = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f, dq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
+    const bool lin = a.act == HNO_ACT_NONE;
+    const float xp = a.xa_act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f, xq = a.xa_act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
+    const bool xact = a.xa_act != HNO_ACT_NONE;
     const unsigned tiles_per_b = (V + 31) / 32;
     const unsigned ntiles = tiles_per_b * a.B;
     const unsigned ngroups = (ntiles + NW - 1) / NW;
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(64 * PWB_FAST_WAVES) void pwconv_bwd_fast_kernel(Pw
     const float *xbp = X + (lane & 15) * PWB_LD + (lane >> 4);
     // software pipeline: raw loads of the NEXT tile (gy, y, x) are issued before this tile's
     // LDS staging and MFMA work; activation gradient and masking happen when they are consumed
-    float pg[NKO], py[NKO], px[NKI];
+    float pg[NKO], py[NKO] = {}, px[NKI];
     auto fetch = [&](unsigned grp) {
         const unsigned t = grp * NW + wave;
         const bool live = t < ntiles;
@@ -425,17 +429,18 @@ __global__ __launch_bounds__(64 * PWB_FAST_WAVES) void pwconv_bwd_fast_kernel(Pw
         const unsigned v = live ? (t - b * tiles_per_b) * 32 + c : 0u;
         const unsigned off = hoffV + ((live && v < V) ? v : 0u);
         const float *gy_b = a.gy + (size_t)b * COUT * V, *y_b = a.y + (size_t)b * COUT * V;
-        const float *xa_b = a.xa + (size_t)b * a.Ca * V;
-        const float *xb_b = a.xb ? a.xb + (size_t)b * a.Cb * V : a.xa;
+        const float *xa_b = a.xa + (size_t)b * CA * V;
+        const float *xb_b = CB > 0 ? a.xb + (size_t)b * CB * V : a.xa;
 #pragma unroll
-        for (int ks = 0; ks < NKO; ++ks) {
-            pg[ks] = (gy_b + (size_t)(2 * ks) * V)[off];
-            py[ks] = a.act != HNO_ACT_NONE ? (y_b + (size_t)(2 * ks) * V)[off] : 0.f;
+        for (int ks = 0; ks < NKO; ++ks) pg[ks] = (gy_b + (size_t)(2 * ks) * V)[off];
+        if (!lin) {
+#pragma unroll
+            for (int ks = 0; ks < NKO; ++ks) py[ks] = (y_b + (size_t)(2 * ks) * V)[off];
         }
 #pragma unroll
         for (int j = 0; j < NKI; ++j) {
             const int i0 = 2 * j;
-            const float *base = i0 < a.Ca ? xa_b + (size_t)i0 * V : xb_b + (size_t)(i0 - a.Ca) * V;
+            const float *base = i0 < CA ? xa_b + (size_t)i0 * V : xb_b + (size_t)(i0 - CA) * V;
             px[j] = base[off];
         }
     };
@@ -449,8 +454,7 @@ __global__ __launch_bounds__(64 * PWB_FAST_WAVES) void pwconv_bwd_fast_kernel(Pw
         float g[NKO];
 #pragma unroll
         for (int ks = 0; ks < NKO; ++ks) {
-            float gv = pg[ks];
-            if (a.act != HNO_ACT_NONE) gv *= act_grad_from_out(py[ks], a.act);
+            const float gv = pg[ks] * ((lin || py[ks] > 0.f) ? dp : py[ks] + dq);
             g[ks] = vin ? gv : 0.f;
             G[(2 * ks + h) * PWB_LD + c] = g[ks];
             db[ks] += g[ks];
@@ -473,12 +477,15 @@ __global__ __launch_bounds__(64 * PWB_FAST_WAVES) void pwconv_bwd_fast_kernel(Pw
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int irow = ic * 32 + (r & 3) + 8 * (r >> 2);
-                if (irow < CIN) {  // compile-time; rows irow, irow+4 are on one side since Ca % 8 == 0
-                    float *base = irow < a.Ca ? (a.gxa ? a.gxa + ((size_t)b * a.Ca + irow) * V : nullptr)
-                                              : (a.gxb ? a.gxb + ((size_t)b * a.Cb + (irow - a.Ca)) * V : nullptr);
+                if (irow < CIN) {  // compile-time; rows irow, irow+4 are on one side since CA % 8 == 0
+                    float *base = irow < CA ? (a.gxa ? a.gxa + ((size_t)b * CA + irow) * V : nullptr)
+                                            : (a.gxb ? a.gxb + ((size_t)b * CB + (irow - CA)) * V : nullptr);
                     if (base && vin && (irow + 4 < CIN || h == 0) && !((a.dbg & 4) && acc[r] != 12345.678f)) {
                         float gv = acc[r];
-                        if (a.xa_act != HNO_ACT_NONE && irow < a.Ca) gv *= act_grad_from_out(X[(irow + 4 * h) * PWB_LD + c], a.xa_act);
+                        if (irow < CA && xact) {
+                            const float xo = X[(irow + 4 * h) * PWB_LD + c];
+                            gv *= xo > 0.f ? xp : xo + xq;
+                        }
                         if (a.accum) gv += base[hoff4V + v];
                         base[hoff4V + v] = gv;
                     }
@@ -547,15 +554,18 @@ int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const fl
     a.dbg = debug_flags();
     const long long ntiles = ((V + 31) / 32) * B;
     int grid = grid_for(ntiles, 4);
-    if (a.dbg & 0xff00) grid = (a.dbg >> 8) & 0xffff;
     if (Ca % 8 == 0 && Cb % 8 == 0) {  // exact-size fast paths (the HNOSeg-XS shapes)
         a.o_begin = 0; a.k_begin = 0; a.k_count = a.Cin; a.accumulate = 0; a.finalize = 1;
         hipStream_t fs = (hipStream_t)stream;
         bool done = true;
         ProfScope ps(KID_PWCONV_FWD, fs, 4.0 * B * (double)V * (a.Cin + Cout));
-        if (a.Cin == 24 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<12, 24>), dim3(grid), dim3(256), 0, fs, a);
-        else if (a.Cin == 48 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 24>), dim3(grid), dim3(256), 0, fs, a);
-        else if (a.Cin == 24 && Cout == 4) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<12, 4>), dim3(grid), dim3(256), 0, fs, a);
+        int fgrid = (int)((ntiles + PWF_FAST_WAVES - 1) / PWF_FAST_WAVES);
+        if (fgrid > 256) fgrid = 256;   // one block per CU
+        if (a.dbg >> 8) fgrid = a.dbg >> 8;
+        const dim3 fb(64 * PWF_FAST_WAVES);
+        if (Ca == 24 && Cb == 0 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 24>), dim3(fgrid), fb, 0, fs, a);
+        else if (Ca == 24 && Cb == 24 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 24, 24>), dim3(fgrid), fb, 0, fs, a);
+        else if (Ca == 24 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 4>), dim3(fgrid), fb, 0, fs, a);
         else done = false;
         if (done) {
             HNO_CHECK_LAUNCH();
@@ -613,21 +623,30 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
     const int nslab = Cout * Cin + Cout;
     if (Ca % 8 == 0 && Cb % 8 == 0) {  // exact-size fast paths
         bool done = true;
-        constexpr int NW = PWB_FAST_WAVES;
+        int NW = PWB_FAST_WAVES;
+        const bool s2424 = Ca == 24 && Cb == 24 && Cout == 24;
+        if (s2424 && (a.dbg & 64)) NW = 8;
+        if (s2424 && (a.dbg & 128)) NW = 12;
         long long fg = (ntiles + NW - 1) / NW;
-        if (fg > 256) fg = 256;   // one 768-thread block per CU
+        if (fg > 512) fg = 512;   // two blocks per CU
+        if (a.dbg >> 8) fg = a.dbg >> 8;
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<12, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<12, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<2, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 24, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 24, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<4, 24, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_done = true;
         }
         {
             ProfScope ps(KID_PWCONV_BWD, s, 4.0 * B * (double)V * ((act != HNO_ACT_NONE ? 2 : 1) * Cout + Cin + (gxa ? Ca : 0) + (gxb ? Cb : 0)));
-            if (Cin == 24 && Cout == 24) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<12, 12>), dim3((int)fg), dim3(64 * NW), sizeof(float) * NW * (32 + 32) * PWB_LD, s, a);
-            else if (Cin == 48 && Cout == 24) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<12, 24>), dim3((int)fg), dim3(64 * NW), sizeof(float) * NW * (32 + 48) * PWB_LD, s, a);
-            else if (Cin == 24 && Cout == 4) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<2, 12>), dim3((int)fg), dim3(64 * NW), sizeof(float) * NW * (16 + 32) * PWB_LD, s, a);
+            const dim3 g((int)fg), blk(64 * NW);
+            if (Ca == 24 && Cb == 0 && Cout == 24) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 0>), g, blk, sizeof(float) * NW * (32 + 32) * PWB_LD, s, a);
+            else if (s2424 && NW == 8) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 24, 8>), g, blk, sizeof(float) * NW * (32 + 48) * PWB_LD, s, a);
+            else if (s2424 && NW == 12) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 24, 12>), g, blk, sizeof(float) * NW * (32 + 48) * PWB_LD, s, a);
+            else if (s2424) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 24>), g, blk, sizeof(float) * NW * (32 + 48) * PWB_LD, s, a);
+            else if (Ca == 24 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<4, 24, 0>), g, blk, sizeof(float) * NW * (16 + 32) * PWB_LD, s, a);
             else done = false;
         }
         if (done) {
@@ -709,35 +728,4 @@ extern "C" int hno_pwconv_bwd(const float *gy, const float *y, const float *xa, 
                               int B, int Cout, long long V, int act, int xa_act, int accumulate_gx, void *stream) {
     return pwconv_bwd_launch(gy, y, xa, Ca, xb, Cb, W, gxa, gxb, dW, dbias, workspace, B, Cout, V, act, 0, stream, xa_act,
                              accumulate_gx);
-}
-
-// Shared-weight spectral mix = L stacked pointwise layers over the mode axis with W + I.
-extern "C" int hno_specmix_shared_fwd(const float *z0, const float *W, float *zs, int B, int C, int M, int L,
-                                      int residual, int act, void *stream) {
-    HNO_REQUIRE(z0 && W && zs && B > 0 && C > 0 && M > 0 && L > 0, "hno_specmix_shared_fwd: bad argument");
-    const size_t layer = (size_t)B * C * M;
-    for (int l = 0; l < L; ++l) {
-        const float *in = l == 0 ? z0 : zs + (size_t)(l - 1) * layer;
-        int rc = pwconv_fwd_launch(in, C, nullptr, 0, W + (size_t)l * C * C, nullptr, zs + (size_t)l * layer, B, C, M,
-                                   act, residual, stream);
-        if (rc) return rc;
-    }
-    return HNO_OK;
-}
-
-extern "C" int hno_specmix_shared_bwd(const float *g, const float *z0, const float *zs, const float *W, float *gz0,
-                                      float *dW, void *workspace, int B, int C, int M, int L, int residual, int act,
-                                      void *stream) {
-    HNO_REQUIRE(g && z0 && zs && W && gz0 && dW && workspace && B > 0 && C > 0 && M > 0 && L > 0, "hno_specmix_shared_bwd: bad argument");
-    const size_t layer = (size_t)B * C * M;
-    for (int l = L - 1; l >= 0; --l) {
-        const float *in = l == 0 ? z0 : zs + (size_t)(l - 1) * layer;
-        // every wave reads its whole gy tile into registers before it writes gx for the same
-        // voxels, so updating the gradient in place (gy == gxa) is safe
-        const float *gy = l == L - 1 ? g : gz0;
-        int rc = pwconv_bwd_launch(gy, zs + (size_t)l * layer, in, C, nullptr, 0, W + (size_t)l * C * C, gz0, nullptr,
-                                   dW + (size_t)l * C * C, nullptr, workspace, B, C, M, act, residual, stream);
-        if (rc) return rc;
-    }
-    return HNO_OK;
 }

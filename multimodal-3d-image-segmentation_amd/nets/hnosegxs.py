@@ -84,7 +84,7 @@ class NeuralOperatorBlock(nn.Module):
     def forward(self, x):
         act = ops.act_id(self.activation)
         if self.fusable():
-            return ops.SpecMixFn.apply(x, self.op.weight.unsqueeze(0), 1, act)
+            return ops.SpecMixFn.apply(x, 1, act, self.op.weight)
         y = self.op(x)
         if self.conv_branch is not None:
             y = y + ops.PwConvFn.apply(x, None, self.conv_branch.weight, None, ops.ACT_NONE)
@@ -135,12 +135,12 @@ class HNOXSBlock(nn.Module):
         if x.ndim == 5 and self._fused_ok():
             # standard configuration: the whole block is one autograd node (ops.XSBlockFn)
             act = ops.act_id(self.activation)
-            W = torch.stack([b.op.weight for b in self.conv_blocks])
             mc = self.mapping_conv.op if self.mapping_conv is not None else None
             assert mc is not None or skip is None
             cc = self.conv_concat.op
             return ops.XSBlockFn.apply(x, skip, mc.weight if mc is not None else None, mc.bias if mc is not None else None,
-                                       W, cc.weight, cc.bias, self.transform_crop.num_modes, act)
+                                       cc.weight, cc.bias, self.transform_crop.num_modes, act,
+                                       *[b.op.weight for b in self.conv_blocks])
         if self.mapping_conv is not None:
             x = self.mapping_conv(x, skip)
         else:
@@ -150,8 +150,7 @@ class HNOXSBlock(nn.Module):
         z = self.transform_crop(x)
         if len(self.conv_blocks) and all(b.fusable() for b in self.conv_blocks):
             # all n_XS layers in one launch sequence: z <- act((W + I) z)
-            W = torch.stack([b.op.weight for b in self.conv_blocks])
-            z = ops.SpecMixFn.apply(z, W, 1, ops.act_id(self.conv_blocks[0].activation))
+            z = ops.SpecMixFn.apply(z, 1, ops.act_id(self.conv_blocks[0].activation), *[b.op.weight for b in self.conv_blocks])
         else:
             for block in self.conv_blocks:
                 z = block(z)

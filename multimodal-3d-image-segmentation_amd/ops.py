@@ -145,23 +145,37 @@ def pwconv_bwd_raw(gy, y, xa, xb, W, act, has_bias, need_gxa=True, need_gxb=True
     return gxa, gxb, dW, db
 
 
+def _layer_ptrs(Ws):
+    import ctypes
+    return (ctypes.c_void_p * len(Ws))(*[w.data_ptr() for w in Ws])
+
+
+def _mix_layers(W):
+    """(L, C, C) tensor or a sequence of L (C, C) tensors -> list of contiguous fp32 (C, C) tensors."""
+    if torch.is_tensor(W):
+        W = W.unbind(0)
+    return [_f32c(w) for w in W]
+
+
 def specmix_fwd_raw(z0, W, residual, act):
+    Ws = _mix_layers(W)
     B, C = z0.shape[:2]
-    M, Lyr = _flat_v(z0), W.shape[0]
+    M, Lyr = _flat_v(z0), len(Ws)
     zs = torch.empty((Lyr,) + tuple(z0.shape), device=z0.device, dtype=torch.float32)
-    check(_lib.lib().hno_specmix_shared_fwd(ptr(z0), ptr(W), ptr(zs), B, C, M, Lyr, int(residual), act, stream_ptr()),
-          'hno_specmix_shared_fwd')
+    check(_lib.lib().hno_specmix_layers_fwd(ptr(z0), _layer_ptrs(Ws), ptr(zs), B, C, M, Lyr, int(residual), act, stream_ptr()),
+          'hno_specmix_layers_fwd')
     return zs
 
 
 def specmix_bwd_raw(g, z0, zs, W, residual, act):
+    Ws = _mix_layers(W)
     B, C = z0.shape[:2]
-    M, Lyr = _flat_v(z0), W.shape[0]
+    M, Lyr = _flat_v(z0), len(Ws)
     gz0 = torch.empty_like(z0)
-    dW = torch.empty_like(W)
-    ws = _wgrad_ws(C, C, z0.device)
-    check(_lib.lib().hno_specmix_shared_bwd(ptr(g), ptr(z0), ptr(zs), ptr(W), ptr(gz0), ptr(dW), ptr(ws), B, C, M, Lyr,
-                                            int(residual), act, stream_ptr()), 'hno_specmix_shared_bwd')
+    dW = torch.empty((Lyr, C, C), device=z0.device, dtype=torch.float32)
+    ws = torch.empty(_lib.lib().hno_specmix_bwd_workspace_bytes(B, C, M, Lyr) // 4, device=z0.device, dtype=torch.float32)
+    check(_lib.lib().hno_specmix_layers_bwd(ptr(g), ptr(z0), ptr(zs), _layer_ptrs(Ws), ptr(gz0), ptr(dW), ptr(ws), B, C, M, Lyr,
+                                            int(residual), act, stream_ptr()), 'hno_specmix_layers_bwd')
     return gz0, dW
 
 
@@ -524,22 +538,24 @@ class AddFn(torch.autograd.Function):
 
 class SpecMixFn(torch.autograd.Function):
     """L stacked shared-weight frequency-domain mixes z <- act(W z + residual z)
-    (nets/hnosegxs.py:307-329, nets/hartley_operator.py:287-292)."""
+    (nets/hnosegxs.py:307-329, nets/hartley_operator.py:287-292).  The layer weights are separate
+    (C, C) tensors (one Parameter per layer, as in the reference's state dict)."""
 
     @staticmethod
-    def forward(ctx, z0, W, residual, act):
-        z0, W = _f32c(z0), _f32c(W)
-        _need_gpu(z0, W)
-        zs = specmix_fwd_raw(z0, W, residual, act)
-        ctx.save_for_backward(z0, W, zs)
+    def forward(ctx, z0, residual, act, *Ws):
+        z0 = _f32c(z0)
+        Ws = [_f32c(w) for w in Ws]
+        _need_gpu(z0, *Ws)
+        zs = specmix_fwd_raw(z0, Ws, residual, act)
+        ctx.save_for_backward(z0, zs, *Ws)
         ctx.residual, ctx.act = int(residual), act
         return zs[-1]
 
     @staticmethod
     def backward(ctx, g):
-        z0, W, zs = ctx.saved_tensors
-        gz0, dW = specmix_bwd_raw(_f32c(g), z0, zs, W, ctx.residual, ctx.act)
-        return gz0, dW, None, None
+        z0, zs, *Ws = ctx.saved_tensors
+        gz0, dW = specmix_bwd_raw(_f32c(g), z0, zs, Ws, ctx.residual, ctx.act)
+        return (gz0, None, None) + tuple(dW.unbind(0))
 
 
 class PwConvFn(torch.autograd.Function):
@@ -574,38 +590,40 @@ class XSBlockFn(torch.autograd.Function):
     of materialising both and adding them."""
 
     @staticmethod
-    def forward(ctx, x, skip, map_w, map_b, mix_w, cat_w, cat_b, modes, act):
-        x, skip, map_w, map_b, mix_w, cat_w, cat_b = (_f32c(t) for t in (x, skip, map_w, map_b, mix_w, cat_w, cat_b))
-        _need_gpu(x, skip, mix_w, cat_w)
+    def forward(ctx, x, skip, map_w, map_b, cat_w, cat_b, modes, act, *mix_ws):
+        x, skip, map_w, map_b, cat_w, cat_b = (_f32c(t) for t in (x, skip, map_w, map_b, cat_w, cat_b))
+        mix_ws = [_f32c(w) for w in mix_ws]
+        _need_gpu(x, skip, cat_w, *mix_ws)
         has_map = map_w is not None
         xm = pwconv_fwd_raw(x, skip, map_w, map_b, act) if has_map else x
         spatial = tuple(xm.shape[2:])
         modes = clamp_modes(modes, spatial)
         n3 = float(np.prod(spatial))
         z0 = dht3_crop_raw(xm, modes, 1.0 / n3)
-        zs = specmix_fwd_raw(z0, mix_w, 1, act)
+        zs = specmix_fwd_raw(z0, mix_ws, 1, act)
         u = pad_idht3_raw(zs[-1], spatial, 1.0, None, act)
         out = pwconv_fwd_raw(u, xm, cat_w, cat_b, act)
-        ctx.save_for_backward(x, skip, map_w, xm if has_map else None, z0, zs, mix_w, u, cat_w, out)
+        ctx.save_for_backward(x, skip, map_w, xm if has_map else None, z0, zs, u, cat_w, out, *mix_ws)
         ctx.cfg = (has_map, modes, act, spatial, n3, map_b is not None, cat_b is not None)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        x, skip, map_w, xm, z0, zs, mix_w, u, cat_w, out = ctx.saved_tensors
+        x, skip, map_w, xm, z0, zs, u, cat_w, out, *mix_ws = ctx.saved_tensors
         has_map, modes, act, spatial, n3, map_has_b, cat_has_b = ctx.cfg
         if not has_map:
             xm = x
         # conv_concat backward; the SELU backward of PadInverse (g_u * act'(u)) is applied in its epilogue
         g_u, g_skipin, d_cat_w, d_cat_b = pwconv_bwd_raw(_f32c(g_out), out, u, xm, cat_w, act, cat_has_b, xa_act=act)
         g_zl = dht3_crop_raw(g_u, modes, 1.0)                               # PadInverse^T
-        g_z0, d_mix = specmix_bwd_raw(g_zl, z0, zs, mix_w, 1, act)
+        g_z0, d_mix = specmix_bwd_raw(g_zl, z0, zs, mix_ws, 1, act)
         g_xm = pad_idht3_raw(g_z0, spatial, 1.0 / n3, g_skipin, ACT_NONE)    # TransformCrop^T + skip gradient
+        d_mix = tuple(d_mix.unbind(0))
         if not has_map:
-            return g_xm, None, None, None, d_mix, d_cat_w, d_cat_b, None, None
+            return (g_xm, None, None, None, d_cat_w, d_cat_b, None, None) + d_mix
         g_x, g_skip, d_map_w, d_map_b = pwconv_bwd_raw(g_xm, xm, x, skip, map_w, act, map_has_b,
                                                        ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return g_x, g_skip, d_map_w, d_map_b, d_mix, d_cat_w, d_cat_b, None, None
+        return (g_x, g_skip, d_map_w, d_map_b, d_cat_w, d_cat_b, None, None) + d_mix
 
 
 class ConvK2S2Fn(torch.autograd.Function):

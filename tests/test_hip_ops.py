@@ -205,22 +205,29 @@ def test_labels_prepare(pkg):
     assert np.array_equal(u8m.cpu().numpy(), g['remapped'][:, 0].astype(np.uint8))
 
 
-def test_specmix_stack(pkg):
+@pytest.mark.parametrize('C,L,residual,shape', [(24, 3, 1, (6, 8, 10)), (24, 1, 1, (4, 4, 6)), (16, 2, 0, (3, 5, 7)),
+                                                 (20, 5, 1, (3, 5, 7)), (32, 4, 1, (2, 4, 8)), (7, 3, 1, (3, 3, 5)),
+                                                 (40, 2, 0, (3, 5, 7))])
+def test_specmix_stack(pkg, C, L, residual, shape):
+    """hno_specmix_layers_{fwd,bwd}: the fused register-resident stack (C <= 32; chunks of 4 layers, ragged
+    mode counts, odd channel counts) and the per-layer path (C > 32) against the einsum chain in float64."""
     from multimodal_3d_image_segmentation_amd import ops
     torch.manual_seed(0)
-    z = torch.randn(2, 24, 6, 8, 10, dtype=torch.float64, requires_grad=True)
-    W = (torch.randn(3, 24, 24, dtype=torch.float64) * 0.2).requires_grad_(True)
+    z = torch.randn(2, C, *shape, dtype=torch.float64, requires_grad=True)
+    W = [(torch.randn(C, C, dtype=torch.float64) * (0.2 if residual else 0.3)).requires_grad_(True) for _ in range(L)]
     cur = z
-    for l in range(3):
-        cur = F.selu(torch.einsum('oi,bidhw->bodhw', W[l], cur) + cur)
+    for l in range(L):
+        cur = F.selu(torch.einsum('oi,bidhw->bodhw', W[l], cur) + (cur if residual else 0))
     cot = torch.randn_like(cur)
-    gz, gW = torch.autograd.grad((cur * cot).sum(), [z, W])
-    zd, Wd = z.detach().float().cuda().requires_grad_(True), W.detach().float().cuda().requires_grad_(True)
-    out = ops.SpecMixFn.apply(zd, Wd, 1, ops.ACT_SELU)
+    gz, *gW = torch.autograd.grad((cur * cot).sum(), [z] + W)
+    zd = z.detach().float().cuda().requires_grad_(True)
+    Wd = [w.detach().float().cuda().requires_grad_(True) for w in W]
+    out = ops.SpecMixFn.apply(zd, residual, ops.ACT_SELU, *Wd)
     assert rel_err(out.detach().cpu().numpy(), cur.detach().numpy()) < 5e-6
-    gzd, gWd = torch.autograd.grad((out * cot.float().cuda()).sum(), [zd, Wd])
+    gzd, *gWd = torch.autograd.grad((out * cot.float().cuda()).sum(), [zd] + Wd)
     assert rel_err(gzd.cpu().numpy(), gz.numpy()) < 1e-5
-    assert rel_err(gWd.cpu().numpy(), gW.numpy()) < 1e-5
+    for a, b in zip(gWd, gW):
+        assert rel_err(a.cpu().numpy(), b.numpy()) < 1e-5
 
 
 @pytest.mark.parametrize('tag', ['64', 'odd'])

@@ -98,15 +98,31 @@ flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
 gathered = [torch.empty_like(flat) for _ in range(world)]
 dist.all_gather(gathered, flat)
 assert all(torch.equal(gathered[0], t) for t in gathered), 'parameters differ after broadcast'
-# fake per-rank gradients written through the .grad views (autograd accumulates the same way)
+# fake per-rank gradients installed as fresh tensors (what backward does after zero_grad)
 rep.zero_grad()
+assert all(p.grad is None for p in model.parameters())
 for i, p in enumerate(model.parameters()):
-    p.grad.add_(float(rank + 1) * (i + 1))
+    p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+if rank == 0:
+    list(model.parameters())[-1].grad = None        # a parameter without gradient counts as zero
 rep.allreduce_grads()
 want = sum(r + 1 for r in range(world)) / world
+nparam = len(list(model.parameters()))
 for i, p in enumerate(model.parameters()):
-    assert torch.allclose(p.grad, torch.full_like(p.grad, want * (i + 1))), (i, p.grad.flatten()[:3])
-    assert p.grad.data_ptr() >= rep.flat_grad.data_ptr()   # still a view of the flat buffer
+    w = want if i < nparam - 1 else sum(r + 1 for r in range(1, world)) / world
+    assert torch.allclose(p.grad, torch.full_like(p.grad, w * (i + 1))), (i, p.grad.flatten()[:3])
+    lo = rep.flat_grad.data_ptr()
+    assert lo <= p.grad.data_ptr() < lo + rep.flat_grad.numel() * 4   # a view of the flat buffer
+# a second round that accumulates INTO the views (no zero_grad in between) must also reduce correctly
+for i, p in enumerate(model.parameters()):
+    p.grad.add_(float(rank))
+before = [p.grad.clone() for p in model.parameters()]
+rep.allreduce_grads()
+gath = [[torch.empty_like(b) for _ in range(world)] for b in before]
+for b, gl in zip(before, gath):
+    dist.all_gather(gl, b)
+for p, gl in zip(model.parameters(), gath):
+    assert torch.allclose(p.grad, sum(gl) / world)
 opt = torch.optim.Adamax(model.parameters(), lr=1e-2)
 opt.step()
 flat2 = torch.cat([p.detach().reshape(-1) for p in model.parameters()])

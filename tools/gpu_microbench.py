@@ -8,13 +8,23 @@ from multimodal_3d_image_segmentation_amd import ops
 L = pkg._lib.lib()
 dev = 'cuda'
 
-def timeit(fn, n=30, warm=5):
+def timeit(fn, n=20, warm=3, reps=3):
+    """GPU time per call from replaying a HIP graph of n back-to-back calls (a Python launch loop is
+    host-bound below ~50 us per call)."""
     for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(n): fn()
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    g.replay(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n): fn()
+    for _ in range(reps): g.replay()
     e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
+    return e0.elapsed_time(e1) / (n * reps) * 1e3
 
 B, C, N = 2, 24, 65
 xa = torch.randn(B, C, N, N, N, device=dev); xb = torch.randn_like(xa)
@@ -22,7 +32,7 @@ W = torch.randn(C, 2 * C, device=dev) * 0.1; bias = torch.randn(C, device=dev) *
 which = sys.argv[1] if len(sys.argv) > 1 else 'all'
 if which in ('all', 'pwfwd'):
     for dbg, name in ((0, 'full'), (1, 'no mfma'), (2, 'no stores'), (3, 'loads only')):
-        for grid in (0, 1024, 4096):
+        for grid in (0, 128, 256, 512, 1024):
             L.hno_set_debug(dbg | (grid << 8))
             yy = torch.empty_like(xa)
             PP, SS = pkg._lib.ptr, pkg._lib.stream_ptr
@@ -40,7 +50,8 @@ if which in ('all', 'pwbwd'):
     ws = torch.empty(L.hno_pwconv_bwd_workspace_bytes(48, 24) // 4, device=dev)
     P, S = pkg._lib.ptr, pkg._lib.stream_ptr
     call = lambda: L.hno_pwconv_bwd(P(gy), P(y), P(xa), 24, P(xb), 24, P(W), P(gxa), P(gxb), P(dW), P(db), P(ws), B, 24, N ** 3, 1, 0, 0, S())
-    for dbg, name in ((0, 'full'), (1, 'no dgrad mfma'), (2, 'no wgrad mfma'), (3, 'no mfma'), (4, 'no gx stores'), (7, 'loads+lds only')):
+    for dbg, name in ((0, 'full nw12'), (64, 'full nw8'), (128, 'full nw4'), (64 | (512 << 8), 'nw8 grid512'), (128 | (512 << 8), 'nw4 grid512'), (128 | (1024 << 8), 'nw4 grid1024'),
+                      (1, 'no dgrad mfma'), (2, 'no wgrad mfma'), (3, 'no mfma'), (4, 'no gx stores'), (7, 'loads+lds only')):
         L.hno_set_debug(dbg)
         t = timeit(call)
         print(f'pwconv_bwd 48->24 [{name}] (incl. slab reduce): {t:.1f} us ({316.4e6 / t / 1e3:.0f} GB/s algorithmic)')

@@ -1,0 +1,41 @@
+"""GPU time of the small latency-bound kernels (spectral mix, D-axis transforms) measured by replaying a
+HIP graph of N back-to-back launches (no host launch overhead in the number)."""
+import sys, os, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import multimodal_3d_image_segmentation_amd as pkg
+from multimodal_3d_image_segmentation_amd import ops
+L = pkg._lib.lib()
+dev = 'cuda'
+
+def graph_time(fn, n=50, reps=5):
+    fn(); torch.cuda.synchronize()
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(n): fn()
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): g.replay()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (n * reps) * 1e3
+
+B, C = 2, 24
+z0 = torch.randn(B, C, 20, 28, 28, device=dev)
+Ws = [torch.randn(C, C, device=dev) * 0.1 for _ in range(3)]
+g = torch.randn_like(z0)
+zs = ops.specmix_fwd_raw(z0, Ws, 1, ops.ACT_SELU)
+for dbg in (0, 16):
+    L.hno_set_debug(dbg)
+    print(f'specmix fwd dbg={dbg}: {graph_time(lambda: ops.specmix_fwd_raw(z0, Ws, 1, ops.ACT_SELU)):.2f} us')
+    print(f'specmix bwd (+reduce) dbg={dbg}: {graph_time(lambda: ops.specmix_bwd_raw(g, z0, zs, Ws, 1, ops.ACT_SELU)):.2f} us')
+L.hno_set_debug(0)
+x = torch.randn(B, C, 65, 65, 65, device=dev)
+print(f'dht3_crop (plane + D): {graph_time(lambda: ops.dht3_crop_raw(x, (10, 14, 14), 1.0)):.2f} us')
+print(f'pad_idht3 (D + plane): {graph_time(lambda: ops.pad_idht3_raw(z0, (65, 65, 65), 1.0, None, ops.ACT_SELU)):.2f} us')
+y = torch.empty_like(z0)
+print(f'torch add 3 MB: {graph_time(lambda: torch.add(z0, g, out=y)):.2f} us')
+small = torch.randn(1024, device=dev); o = torch.empty_like(small)
+print(f'torch add 4 KB: {graph_time(lambda: torch.add(small, small, out=o)):.2f} us')
