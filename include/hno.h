@@ -140,12 +140,16 @@ int hno_conv_k2s2_bwd(const float *gy, const float *y, const float *x, const flo
  * logits_lr is (B, K, d, h, w).  Together with hno_pwconv_fwd(conv_out) at LOW resolution
  * this replaces F.interpolate(24 ch) -> conv_out -> softmax (nets/hnosegxs.py:174-180);
  * the 1x1x1 conv commutes with the (linear, per-channel) interpolation.
- * Backward: g_lr = trilinear^T( softmax'(probs, g_probs) ).
+ * Backward: g_lr = trilinear^T( softmax'(probs, g_probs) ).  With a workspace of
+ * hno_upsoftmax_bwd_workspace_bytes() the adjoint runs separably (W and H axes folded while the
+ * gradient streams through once, then the D axis); with workspace NULL, or for shapes the separable
+ * kernels do not cover (the size query returns 0), a gather kernel is used.
  */
 int hno_upsoftmax_fwd(const float *logits_lr, float *probs, int B, int K, int d, int h, int w,
                       int D, int H, int W, int softmax, void *stream);
-int hno_upsoftmax_bwd(const float *g_probs, const float *probs, float *g_lr, int B, int K, int d, int h, int w,
-                      int D, int H, int W, int softmax, void *stream);
+size_t hno_upsoftmax_bwd_workspace_bytes(int B, int K, int d, int h, int w, int D, int H, int W);
+int hno_upsoftmax_bwd(const float *g_probs, const float *probs, float *g_lr, void *workspace, int B, int K, int d,
+                      int h, int w, int D, int H, int W, int softmax, void *stream);
 
 /* ------------------------------------------------------------------ V-Net-DS building blocks
  * 3x3x3 convolutions as implicit GEMMs on the fp32 matrix cores (reference: ConvNormAct /

@@ -683,8 +683,10 @@ class UpSoftmaxFn(torch.autograd.Function):
         B, K, d, h, w = ctx.lr_shape
         D, H, W = g.shape[2:]
         g_lr = torch.empty(ctx.lr_shape, device=g.device, dtype=torch.float32)
-        check(_lib.lib().hno_upsoftmax_bwd(ptr(g), ptr(probs), ptr(g_lr), B, K, d, h, w, D, H, W, ctx.softmax, stream_ptr()),
-              'hno_upsoftmax_bwd')
+        nws = _lib.lib().hno_upsoftmax_bwd_workspace_bytes(B, K, d, h, w, D, H, W)
+        ws = torch.empty(nws // 4, device=g.device, dtype=torch.float32) if nws else None
+        check(_lib.lib().hno_upsoftmax_bwd(ptr(g), ptr(probs), ptr(g_lr), ptr(ws), B, K, d, h, w, D, H, W, ctx.softmax,
+                                           stream_ptr()), 'hno_upsoftmax_bwd')
         return g_lr, None, None
 
 

@@ -39,3 +39,20 @@ y = torch.empty_like(z0)
 print(f'torch add 3 MB: {graph_time(lambda: torch.add(z0, g, out=y)):.2f} us')
 small = torch.randn(1024, device=dev); o = torch.empty_like(small)
 print(f'torch add 4 KB: {graph_time(lambda: torch.add(small, small, out=o)):.2f} us')
+
+# head backward
+lr = torch.randn(2, 4, 65, 65, 65, device=dev)
+probs = ops.UpSoftmaxFn.apply(lr, (128, 128, 128), True)
+gp = torch.randn_like(probs)
+g_lr = torch.empty_like(lr)
+nws = L.hno_upsoftmax_bwd_workspace_bytes(2, 4, 65, 65, 65, 128, 128, 128)
+ws = torch.empty(nws // 4, device=dev)
+P, S = pkg._lib.ptr, pkg._lib.stream_ptr
+for dbg, name in ((0, 'full'), (1 << 8, 'nsplit 1'), (2 << 8, 'nsplit 2'), (3 << 8, 'nsplit 3'), (4 << 8, 'nsplit 4'), (8 << 8, 'nsplit 8'), (3, 'neither'), (0x20, 'return at start'), (0x40, 'return after taps'), (0x63, 'neither, no flush'), (0x60, 'no flush')):
+    L.hno_set_debug(dbg)
+    t = graph_time(lambda: L.hno_upsoftmax_bwd(P(gp), P(probs), P(g_lr), P(ws), 2, 4, 65, 65, 65, 128, 128, 128, 1, S()), n=10)
+    print(f'upsoftmax_bwd [{name}]: {t:.1f} us')
+L.hno_set_debug(0)
+with pkg._lib.KernelProfile() as kp:
+    for _ in range(20): L.hno_upsoftmax_bwd(P(gp), P(probs), P(g_lr), P(ws), 2, 4, 65, 65, 65, 128, 128, 128, 1, S())
+for k, v in kp.summary().items(): print(k, v)
