@@ -238,6 +238,9 @@ int hno_profile_end(int *kernel_ids, float *ms, double *algorithmic_bytes, int c
 const char *hno_profile_kernel_name(int kernel_id);
 /* ablation switches for kernel tuning (timing only: results are wrong when non-zero) */
 int hno_set_debug(int flags);
+/* with debug flag 64: clock64() stamps stored by thread 0 of workgroup 0 at the phase boundaries of the
+ * instrumented kernels (tuning aid; n <= 64) */
+int hno_debug_stamps(long long *out, int n);
 
 /* ------------------------------------------------------------------------ self tests
  * C(MxN) = A(MxK) B(KxN) through the wave-level MFMA tile engine every kernel uses. */

@@ -68,10 +68,22 @@ __device__ __forceinline__ void block_sum_to_slab(float *scratch, int n, float *
     }
 }
 
+// in-kernel phase stamps (debug flag 64): thread 0 of block 0 stores clock64() at phase boundaries into
+// the buffer returned by debug_stamp_buffer() (64 entries, allocated on first use)
+long long *debug_stamp_buffer();
+#define HNO_STAMP(buf, idx)                                                                         \
+    do {                                                                                            \
+        if ((buf) && blockIdx.x == 0 && threadIdx.x == 0 && (idx) < 64) (buf)[(idx)] = clock64();   \
+    } while (0)
+
 // debug/ablation switches (hno_set_debug): timing-only builds of a kernel phase, results are WRONG
 int debug_flags();
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+// Grid of a persistent (grid-stride) kernel: no more workgroups than are resident at once (occupancy from the
+// runtime, cached per kernel and LDS size -- a larger grid runs a second, mostly idle wave of workgroups), and
+// then the smallest grid that needs the same number of iterations, so every workgroup does equal work.
+int persistent_grid(const void *kernel, int block_threads, size_t dynamic_lds, int work_items);
 inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
 // ------------------------------------------------------------------ activations

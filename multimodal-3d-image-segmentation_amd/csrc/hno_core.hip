@@ -3,6 +3,10 @@
 
 #include <vector>
 
+#include <map>
+#include <mutex>
+#include <tuple>
+
 #include "hno_common.h"
 
 namespace hno {
@@ -18,6 +22,35 @@ int fail(int code, const char *fmt, ...) {
     va_end(ap);
     g_last_error = buf;
     return code;
+}
+
+static long long *g_stamps = nullptr;
+long long *debug_stamp_buffer() {
+    if (!g_stamps && hipMalloc((void **)&g_stamps, sizeof(long long) * 64) == hipSuccess) (void)hipMemset(g_stamps, 0, sizeof(long long) * 64);
+    return g_stamps;
+}
+
+int persistent_grid(const void *kernel, int block_threads, size_t dynamic_lds, int work_items) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, const void *, int, size_t>, int> cache;   // -> resident workgroups on the device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int slots = 0;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto key = std::make_tuple(dev, kernel, block_threads, dynamic_lds);
+        auto it = cache.find(key);
+        if (it == cache.end()) {
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, dynamic_lds) != hipSuccess || per_cu < 1) per_cu = 1;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+            it = cache.emplace(key, per_cu * cus).first;
+        }
+        slots = it->second;
+    }
+    if (work_items <= slots) return work_items < 1 ? 1 : work_items;
+    const int iters = ceil_div(work_items, slots);
+    return ceil_div(work_items, iters);
 }
 
 static int g_debug_flags = 0;
@@ -146,6 +179,15 @@ extern "C" int hno_profile_end(int *kernel_ids, float *ms, double *bytes, int ca
 
 extern "C" const char *hno_profile_kernel_name(int kernel_id) {
     return (kernel_id >= 0 && kernel_id < KID_COUNT) ? kKernelNames[kernel_id] : "?";
+}
+
+extern "C" int hno_debug_stamps(long long *out, int n) {
+    HNO_REQUIRE(out && n > 0 && n <= 64, "hno_debug_stamps: bad argument");
+    HNO_CHECK_HIP(hipDeviceSynchronize());
+    long long *buf = debug_stamp_buffer();
+    HNO_REQUIRE(buf, "hno_debug_stamps: no stamp buffer");
+    HNO_CHECK_HIP(hipMemcpy(out, buf, sizeof(long long) * n, hipMemcpyDeviceToHost));
+    return HNO_OK;
 }
 
 extern "C" int hno_set_debug(int flags) {

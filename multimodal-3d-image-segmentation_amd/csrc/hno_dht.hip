@@ -191,6 +191,7 @@ struct DhtArgs {
     float scale;
     int act;  // forward: activation whose derivative multiplies the input; inverse: epilogue act
     int dbg;  // ablation switches (timing only)
+    long long *stamps;  // phase stamps (debug flag 64), else NULL
     // spectrum convention of the D kernels: 0 = Hartley block (real, [low|high] on all three axes);
     // 1 / 2 = Fourier half spectrum (B, 2, C, 2m0, 2m1, m2) with re / im planes, k2 in [0, m2):
     //   1: unit weights (rfftn forward, and the backward of rfftn)
@@ -371,18 +372,26 @@ __global__ __launch_bounds__(256, 3) void dht_fwd_plane_spec_kernel(const float 
     const int q = lane >> 4, l15 = lane & 15;
     const int N1 = a1.N, N2 = a2.N;
     const int lda = p.lda2, ldt = p.ldt;
+    // Work roles instead of wave numbers: wave w of every workgroup sits on SIMD w, and the workgroups that
+    // share a CU differ by multiples of 256 in blockIdx, so rotating the roles by blockIdx / 256 spreads the
+    // heavier roles (0 and 1 also run the axis-H chains) over the four matrix pipes of the CU.
+    const int role = (a.dbg & 128) ? wave : ((wave + (int)(blockIdx.x >> 8)) & 3);
+    // one or two leftover rows (N1 = 16 t + 1: 65, 33, 97) are not worth a 16-row MFMA tile: VALU dot products
+    const int MTF = (N1 % 16 >= 1 && N1 % 16 <= 2 && !(a.dbg & 256)) ? N1 / 16 : p.MP1 / 16;
     float *xs = lds + 16;                       // 16 zero floats in front: sin-part reads at j = -1..-3
     float *T = xs + p.MP1 * lda;
     // B operands (tables) in registers: lane holds B[k = ks*4 + q][col = l15]
-    float bwc[KC2], bws[KS2], bhc[KC1], bhs[KS1];
+    // axis-W tables in registers (every wave uses them once per plane); the axis-H tables, used by two waves
+    // only, stay in LDS and are read together with the A operands (keeps the kernel at 3 workgroups per CU
+    // without spilling: a spill reload waits on vmcnt(0), i.e. on the prefetched plane)
+    float bwc[KC2], bws[KS2];
 #pragma unroll
     for (int ks = 0; ks < KC2; ++ks) bwc[ks] = p.tables[a2.cosF + (ks * 4 + q) * 16 + l15];
 #pragma unroll
     for (int ks = 0; ks < KS2; ++ks) bws[ks] = p.tables[a2.sinF + (ks * 4 + q) * 16 + l15];
-#pragma unroll
-    for (int ks = 0; ks < KC1; ++ks) bhc[ks] = p.tables[a1.cosF + (ks * 4 + q) * 16 + l15];
-#pragma unroll
-    for (int ks = 0; ks < KS1; ++ks) bhs[ks] = p.tables[a1.sinF + (ks * 4 + q) * 16 + l15];
+    float *tabH = T + p.TP * ldt;   // [KC1 + KS1][64]
+    for (int i = tid; i < (KC1 + KS1) * 64; i += 256) tabH[i] = i < KC1 * 64 ? p.tables[a1.cosF + i] : p.tables[a1.sinF + (i - KC1 * 64)];
+    const float *thc = tabH + lane, *ths = tabH + KC1 * 64 + lane;
     // zero: guard, xs padding (rows >= N1, columns >= N2), T rows >= N1
     if (tid < 16) lds[tid] = 0.f;
     for (int i = tid; i < (p.MP1 - N1) * lda; i += 256) xs[N1 * lda + i] = 0.f;
@@ -392,7 +401,6 @@ __global__ __launch_bounds__(256, 3) void dht_fwd_plane_spec_kernel(const float 
 
     const int planes = a.BC * p.ax[0].N;
     const size_t plane_elems = (size_t)N1 * N2;
-    const int MT1 = p.MP1 / 16;
     float rx[NE], ru[HAS_ACT ? NE : 1];
     const int r0 = tid / N2, c0 = tid - r0 * N2, dr = 256 / N2, dc = 256 - dr * N2;
     auto fetch = [&](int plane) {
@@ -406,9 +414,16 @@ __global__ __launch_bounds__(256, 3) void dht_fwd_plane_spec_kernel(const float 
             if (HAS_ACT) ru[j] = in ? up[e] : 0.f;
         }
     };
+    HNO_STAMP(a.stamps, 0);
+    if (a.stamps && blockIdx.x == 0 && tid == 0) { a.stamps[60] = wall_clock64(); a.stamps[62] = clock64(); }
+    if (a.stamps && blockIdx.x == gridDim.x - 1 && tid == 0) a.stamps[58] = wall_clock64();
+    if (a.stamps && blockIdx.x == 600 && tid == 0) a.stamps[56] = wall_clock64();
     if (blockIdx.x < planes) fetch(blockIdx.x);
-    for (int plane = blockIdx.x; plane < planes; plane += gridDim.x) {
+    int it = 0;
+    for (int plane = blockIdx.x; plane < planes; plane += gridDim.x, ++it) {
+        HNO_STAMP(a.stamps, 1 + it * 6);
         __syncthreads();  // previous iteration finished reading xs / T
+        HNO_STAMP(a.stamps, 2 + it * 6);
         {
             int r = r0, c = c0;
 #pragma unroll
@@ -423,23 +438,45 @@ __global__ __launch_bounds__(256, 3) void dht_fwd_plane_spec_kernel(const float 
             }
         }
         if (plane + gridDim.x < planes) fetch(plane + gridDim.x);  // in flight during this plane's compute
+        HNO_STAMP(a.stamps, 3 + it * 6);
         __syncthreads();
+        HNO_STAMP(a.stamps, 4 + it * 6);
         // ---- axis W.  cos: (x[c] + x[N-c]) c = 4ks+q ; sin: (x[j] - x[N-j]) j = Js - (4ks+q)
         if (!(a.dbg & 1)) {
-            for (int mt = wave; mt < MT1; mt += 4) {
+            for (int mt = role; mt < MTF; mt += 4) {
                 const float *row = xs + (mt * 16 + l15) * lda;
                 const float *pf = row + q, *pb = row + N2 - q;
                 const float *sf = row + a2.Js - q, *sb = row + N2 - a2.Js + q;
-                float ac[KC2], as_[KS2];
-#pragma unroll
-                for (int ks = 0; ks < KC2; ++ks) ac[ks] = pf[4 * ks] + pb[-4 * ks];
-#pragma unroll
-                for (int ks = 0; ks < KS2; ++ks) as_[ks] = sf[-4 * ks] - sb[4 * ks];
+                // one chain at a time: all raw LDS reads of the chain are issued, then folded, then the MFMAs run
+                // (left alone, the scheduler sinks each read next to its use and every MFMA waits for an LDS
+                // round trip; both chains at once need more registers than 3 workgroups per CU leave)
                 f32x4 accC = {0.f, 0.f, 0.f, 0.f}, accS = accC;
+                {
+                    float ac[KC2], cb[KC2];
 #pragma unroll
-                for (int ks = 0; ks < (KC2 > KS2 ? KC2 : KS2); ++ks) {
-                    if (ks < KC2) accC = mfma16(ac[ks], bwc[ks], accC);
-                    if (ks < KS2) accS = mfma16(as_[ks], bws[ks], accS);
+                    for (int ks = 0; ks < KC2; ++ks) {
+                        ac[ks] = pf[4 * ks];
+                        cb[ks] = pb[-4 * ks];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = 0; ks < KC2; ++ks) ac[ks] += cb[ks];
+#pragma unroll
+                    for (int ks = 0; ks < KC2; ++ks) accC = mfma16(ac[ks], bwc[ks], accC);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    float as_[KS2], sb_[KS2];
+#pragma unroll
+                    for (int ks = 0; ks < KS2; ++ks) {
+                        as_[ks] = sf[-4 * ks];
+                        sb_[ks] = sb[4 * ks];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = 0; ks < KS2; ++ks) as_[ks] -= sb_[ks];
+#pragma unroll
+                    for (int ks = 0; ks < KS2; ++ks) accS = mfma16(as_[ks], bws[ks], accS);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -450,26 +487,67 @@ __global__ __launch_bounds__(256, 3) void dht_fwd_plane_spec_kernel(const float 
                     }
                 }
             }
+            if (role == 3) {
+                for (int rr = MTF * 16; rr < N1; ++rr) {   // same operands as the MFMA path, k split over the 4 lane groups
+                    const float *row = xs + rr * lda;
+                    const float *pf = row + q, *pb = row + N2 - q;
+                    const float *sf = row + a2.Js - q, *sb = row + N2 - a2.Js + q;
+                    float pc = 0.f, ps = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < KC2; ++ks) pc += (pf[4 * ks] + pb[-4 * ks]) * bwc[ks];
+#pragma unroll
+                    for (int ks = 0; ks < KS2; ++ks) ps += (sf[-4 * ks] - sb[4 * ks]) * bws[ks];
+                    pc += __shfl_xor(pc, 16);
+                    ps += __shfl_xor(ps, 16);
+                    pc += __shfl_xor(pc, 32);
+                    ps += __shfl_xor(ps, 32);
+                    if (q == 0) {
+                        T[rr * ldt + l15] = pc;
+                        T[rr * ldt + 16 + l15] = ps;
+                    }
+                }
+            }
         }
+        HNO_STAMP(a.stamps, 5 + it * 6);
         __syncthreads();
+        HNO_STAMP(a.stamps, 6 + it * 6);
         // ---- axis H (fold along n1 while reading).  wave 0: BR = P_Ac -+ Q_As ; wave 1: BI from Q_Ac, P_As
         float *Yp = Y + (size_t)plane * (2 * p.CP);
-        if (wave < 2 && !(a.dbg & 2)) {
-            const int part = wave;
+        if (role < 2 && !(a.dbg & 2)) {
+            const int part = role;
             const float *cs = T + (part == 0 ? 0 : 16) + l15;   // source columns of the cos sum
             const float *ss = T + (part == 0 ? 16 : 0) + l15;   // source columns of the sin sum
             const float *pf = cs + q * ldt, *pb = cs + (N1 - q) * ldt;
             const float *sf = ss + (a1.Js - q) * ldt, *sb = ss + (N1 - a1.Js + q) * ldt;
-            float ac[KC1], as_[KS1];
-#pragma unroll
-            for (int ks = 0; ks < KC1; ++ks) ac[ks] = pf[4 * ks * ldt] + pb[-4 * ks * ldt];
-#pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) as_[ks] = sf[-4 * ks * ldt] - sb[4 * ks * ldt];
             f32x4 accP = {0.f, 0.f, 0.f, 0.f}, accQ = accP;
+            {
+                float ac[KC1], cb[KC1], bhc[KC1];
 #pragma unroll
-            for (int ks = 0; ks < (KC1 > KS1 ? KC1 : KS1); ++ks) {
-                if (ks < KC1) accP = mfma16(ac[ks], bhc[ks], accP);
-                if (ks < KS1) accQ = mfma16(as_[ks], bhs[ks], accQ);
+                for (int ks = 0; ks < KC1; ++ks) {
+                    ac[ks] = pf[4 * ks * ldt];
+                    cb[ks] = pb[-4 * ks * ldt];
+                    bhc[ks] = thc[64 * ks];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < KC1; ++ks) ac[ks] += cb[ks];
+#pragma unroll
+                for (int ks = 0; ks < KC1; ++ks) accP = mfma16(ac[ks], bhc[ks], accP);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                float as_[KS1], sb_[KS1], bhs[KS1];
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) {
+                    as_[ks] = sf[-4 * ks * ldt];
+                    sb_[ks] = sb[4 * ks * ldt];
+                    bhs[ks] = ths[64 * ks];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) as_[ks] -= sb_[ks];
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) accQ = mfma16(as_[ks], bhs[ks], accQ);
             }
             const int k1 = l15;
             if (k1 <= a1.m && !((a.dbg & 4) && accP[0] != 12345.f)) {
@@ -490,6 +568,9 @@ __global__ __launch_bounds__(256, 3) void dht_fwd_plane_spec_kernel(const float 
             }
         }
     }
+    if (a.stamps && blockIdx.x == 0 && tid == 0) { a.stamps[61] = wall_clock64(); a.stamps[63] = clock64(); }
+    if (a.stamps && blockIdx.x == gridDim.x - 1 && tid == 0) a.stamps[59] = wall_clock64();
+    if (a.stamps && blockIdx.x == 600 && tid == 0) a.stamps[57] = wall_clock64();
 }
 
 // Recombination + crop store of one (kt0, k1s, kt2) tile of the forward D transform.  The lane holds, for
@@ -501,6 +582,7 @@ __device__ __forceinline__ void fwd_d_store(const DhtArgs &a, float *__restrict_
     const int m0 = p.ax[0].m, m1 = p.ax[1].m, m2 = p.ax[2].m;
     const int q = lane >> 4;
     float *ob = out + (size_t)bc * (2 * m0) * (2 * m1) * (2 * m2);
+    (void)ob;
     const int k0 = kt0 * 16 + (lane & 15);
     const int k1 = k1s - m1;
     if (k0 <= m0 && a.mode != 0) {
@@ -569,6 +651,7 @@ __global__ __launch_bounds__(64) void dht_fwd_d_kernel(const float *__restrict__
     const int q = lane >> 4;
     const int m0 = a0.m, m1 = a1.m, m2 = a2.m;
     float *ob = out + (size_t)bc * (2 * m0) * (2 * m1) * (2 * m2);
+    (void)ob;
     for (int kt0 = 0; kt0 < a0.KT; ++kt0) {
         f32x4 PR = {0.f, 0.f, 0.f, 0.f}, PI = PR, QR = PR, QI = PR;
         const float *bc_ = cosD + kt0 * a0.KcP * 16, *bs_ = sinD + kt0 * a0.KsP * 16;
@@ -1065,12 +1148,21 @@ __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float 
                 const float *es = Er + (part ? p.CP : 0) + l15, *ed = Er + (part ? 0 : p.CP) + l15;
                 const float *sf = es + (m1 + q) * 16, *sb = es + (m1 - q) * 16;
                 const float *df = ed + (m1 + q) * 16, *db = ed + (m1 - q) * 16;
-                float as_[KM1], ad_[KM1];
+                float as_[KM1], ad_[KM1], asb[KM1], adb[KM1];
 #pragma unroll
                 for (int ks = 0; ks < KM1; ++ks) {
-                    as_[ks] = sf[64 * ks] + sb[-64 * ks];
-                    ad_[ks] = df[64 * ks] - db[-64 * ks];
+                    as_[ks] = sf[64 * ks];
+                    asb[ks] = sb[-64 * ks];
+                    ad_[ks] = df[64 * ks];
+                    adb[ks] = db[-64 * ks];
                 }
+                __builtin_amdgcn_sched_barrier(0);   // all raw reads in flight before the first fold
+#pragma unroll
+                for (int ks = 0; ks < KM1; ++ks) {
+                    as_[ks] += asb[ks];
+                    ad_[ks] -= adb[ks];
+                }
+                __builtin_amdgcn_sched_barrier(0);   // all operand reads before the MFMA chains
                 f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = acc1;
 #pragma unroll
                 for (int n = 0; n < NT1; ++n)
@@ -1113,6 +1205,7 @@ __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float 
                 ar[ks] = fr[4 * ks];
                 ai[ks] = fi[4 * ks];
             }
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = acc1;
             if (!(a.dbg & 2)) {
 #pragma unroll
@@ -1207,6 +1300,7 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
     a.scale = scale;
     a.act = x_act_out ? act_grad : HNO_ACT_NONE;
     a.dbg = debug_flags();
+    a.stamps = (a.dbg & 64) ? debug_stamp_buffer() : nullptr;
     a.mode = mode;
     a.C = C > 0 ? C : 1;
     const size_t lds = sizeof(float) * plan->f_lds_floats;
@@ -1230,19 +1324,22 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
         ProfScope _ps(KID_DHT_FWD_PLANE, s, 4.0 * BC * (double)N0 * N1 * N2 * (x_act_out ? 2 : 1));
         const Axis &b1 = plan->ax[1], &b2 = plan->ax[2];
         const bool spec_ok = pe <= 256 * 20 && b1.KT == 1 && b2.KT == 1 && N1 >= 16 && N2 >= 16 && !(a.dbg & 16);
-        const size_t lds_spec = sizeof(float) * (16 + plan->MP1 * plan->lda2 + plan->TP * plan->ldt);
+        const size_t lds_spec = sizeof(float) * (16 + plan->MP1 * plan->lda2 + plan->TP * plan->ldt + (b1.KcP + b1.KsP) * 16);
         int g_spec = (int)(kMaxLds / lds_spec);
         if (g_spec > 8) g_spec = 8;
         g_spec = planes < 256 * g_spec ? planes : 256 * g_spec;
         bool launched = false;
 #define HNO_SPEC(KC2, KS2, KC1, KS1)                                                                                      \
     if (!launched && spec_ok && b2.KcP == 4 * KC2 && b2.KsP == 4 * KS2 && b1.KcP == 4 * KC1 && b1.KsP == 4 * KS1) {      \
-        if (x_act_out)                                                                                                    \
-            hipLaunchKernelGGL((dht_fwd_plane_spec_kernel<KC2, KS2, KC1, KS1, true>), dim3(g_spec), dim3(256), lds_spec,  \
+        if (x_act_out) {                                                                                                  \
+            auto kern = dht_fwd_plane_spec_kernel<KC2, KS2, KC1, KS1, true>;                                              \
+            hipLaunchKernelGGL(kern, dim3(persistent_grid((const void *)kern, 256, lds_spec, planes)), dim3(256), lds_spec, \
                                s, x, x_act_out, (float *)workspace, a);                                                   \
-        else                                                                                                              \
-            hipLaunchKernelGGL((dht_fwd_plane_spec_kernel<KC2, KS2, KC1, KS1, false>), dim3(g_spec), dim3(256), lds_spec, \
+        } else {                                                                                                          \
+            auto kern = dht_fwd_plane_spec_kernel<KC2, KS2, KC1, KS1, false>;                                             \
+            hipLaunchKernelGGL(kern, dim3(persistent_grid((const void *)kern, 256, lds_spec, planes)), dim3(256), lds_spec, \
                                s, x, x_act_out, (float *)workspace, a);                                                   \
+        }                                                                                                                 \
         launched = true;                                                                                                  \
     }
         HNO_SPEC(9, 8, 9, 8)   // 65 x 65 planes (128^3 inputs)
@@ -1286,6 +1383,7 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
     a.scale = scale;
     a.act = act;
     a.dbg = debug_flags();
+    a.stamps = (a.dbg & 64) ? debug_stamp_buffer() : nullptr;
     a.mode = mode;
     a.C = C > 0 ? C : 1;
     const size_t lds = sizeof(float) * plan->i_lds_floats;
@@ -1330,10 +1428,10 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
     if (!launched && spec_ok && b1.KmP == 4 * KM1 && b2.KmP == 4 * KM2 && (b1.J + 15) / 16 == NT1 &&                      \
         (b2.J + 15) / 16 == NT2) {                                                                                        \
         if (addend)                                                                                                       \
-            hipLaunchKernelGGL((dht_inv_plane_spec_kernel<KM1, KM2, NT1, NT2, true>), dim3(g_spec), dim3(256), lds_spec,  \
+            hipLaunchKernelGGL((dht_inv_plane_spec_kernel<KM1, KM2, NT1, NT2, true>), dim3(persistent_grid((const void *)dht_inv_plane_spec_kernel<KM1, KM2, NT1, NT2, true>, 256, lds_spec, planes)), dim3(256), lds_spec,  \
                                s, (const float *)workspace, addend, out, a);                                              \
         else                                                                                                              \
-            hipLaunchKernelGGL((dht_inv_plane_spec_kernel<KM1, KM2, NT1, NT2, false>), dim3(g_spec), dim3(256), lds_spec, \
+            hipLaunchKernelGGL((dht_inv_plane_spec_kernel<KM1, KM2, NT1, NT2, false>), dim3(persistent_grid((const void *)dht_inv_plane_spec_kernel<KM1, KM2, NT1, NT2, false>, 256, lds_spec, planes)), dim3(256), lds_spec, \
                                s, (const float *)workspace, addend, out, a);                                              \
         launched = true;                                                                                                  \
     }

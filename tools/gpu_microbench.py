@@ -62,7 +62,7 @@ if which in ('all', 'dhtab'):
     ws = torch.empty(L.hno_dht3_workspace_bytes(BC, *NN, *mm) // 4, device=dev)
     out = torch.empty(B, C, 20, 28, 28, device=dev); yy = torch.empty_like(x)
     P, S = pkg._lib.ptr, pkg._lib.stream_ptr
-    for dbg, name in ((0, 'full'), (1, 'no stage W'), (2, 'no stage H'), (3, 'no W,H'), (7, 'load+fold only')):
+    for dbg, name in ((0, 'full'), (128, 'no role rotation'), (256, 'MFMA remainder tile'), (384, 'old assignment'), (0, 'full'), (384, 'old assignment'), (1, 'no stage W'), (2, 'no stage H'), (3, 'no W,H'), (7, 'load+fold only')):
         L.hno_set_debug(dbg)
         with pkg._lib.KernelProfile() as kp:
             for _ in range(20): L.hno_dht3_crop(P(x), None, 0, P(out), P(ws), BC, *NN, *mm, 1.0, S())
@@ -81,3 +81,25 @@ if which in ('all', 'dht'):
             ops.dht3_crop_raw(x, (10, 14, 14), 1.0); ops.dht3_crop_raw(x, (10, 14, 14), 1.0, x, 1)
             ops.pad_idht3_raw(z, (N, N, N), 1.0, None, 1); ops.pad_idht3_raw(z, (N, N, N), 1.0, x, 0)
     for k, (c, s, avg) in kp.summary().items(): print(f'{k}: {avg * 1e3:.1f} us avg over {c}')
+if which in ('stamps',):
+    import ctypes
+    x = torch.randn(B, C, N, N, N, device=dev)
+    BC, NN, mm = 48, (65, 65, 65), (10, 14, 14)
+    ws = torch.empty(L.hno_dht3_workspace_bytes(BC, *NN, *mm) // 4, device=dev)
+    out = torch.empty(B, C, 20, 28, 28, device=dev)
+    P, S = pkg._lib.ptr, pkg._lib.stream_ptr
+    L.hno_dht3_crop(P(x), None, 0, P(out), P(ws), BC, *NN, *mm, 1.0, S())
+    L.hno_set_debug(64)
+    L.hno_dht3_crop(P(x), None, 0, P(out), P(ws), BC, *NN, *mm, 1.0, S())
+    L.hno_set_debug(0)
+    buf = (ctypes.c_longlong * 64)()
+    L.hno_debug_stamps(buf, 64)
+    st = list(buf)
+    print(f'wall_clock64 (100 MHz) delta {st[61] - st[60]} -> {(st[61] - st[60]) / 100:.2f} us; clock64 delta {st[63] - st[62]} -> {(st[63] - st[62]) / max(1, st[61] - st[60]) * 100:.0f} MHz')
+    print(f'block 0: start 0, end {(st[61]-st[60])/100:.2f} us; block 600: start {(st[56]-st[60])/100:.2f}, end {(st[57]-st[60])/100:.2f} us; last block: start {(st[58]-st[60])/100:.2f}, end {(st[59]-st[60])/100:.2f} us')
+    print('fwd plane stamps (cycles since kernel-loop start; clock64 ticks):')
+    names = ['iter top', 'after sync0', 'after LDS write + fetch issue', 'after sync1', 'after W', 'after sync2 (H starts)']
+    for it in range(5):
+        row = st[1 + it * 6: 7 + it * 6]
+        if row[0] == 0: break
+        print(f'  iter {it}:', ', '.join(f'{n}: {v - st[0]}' for n, v in zip(names, row)))
