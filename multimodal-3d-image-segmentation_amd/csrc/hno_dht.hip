@@ -389,6 +389,10 @@ __global__ __launch_bounds__(256, 3) void dht_fwd_plane_spec_kernel(const float 
     for (int ks = 0; ks < KC2; ++ks) bwc[ks] = p.tables[a2.cosF + (ks * 4 + q) * 16 + l15];
 #pragma unroll
     for (int ks = 0; ks < KS2; ++ks) bws[ks] = p.tables[a2.sinF + (ks * 4 + q) * 16 + l15];
+#pragma unroll
+    for (int ks = 0; ks < KC2; ++ks) asm volatile("" : "+v"(bwc[ks]));   // keep in registers (no re-load inside the loop)
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks) asm volatile("" : "+v"(bws[ks]));
     float *tabH = T + p.TP * ldt;   // [KC1 + KS1][64]
     for (int i = tid; i < (KC1 + KS1) * 64; i += 256) tabH[i] = i < KC1 * 64 ? p.tables[a1.cosF + i] : p.tables[a1.sinF + (i - KC1 * 64)];
     const float *thc = tabH + lane, *ths = tabH + KC1 * 64 + lane;
@@ -1062,35 +1066,39 @@ __global__ __launch_bounds__(256) void dht_inv_plane_kernel(const float *__restr
 // Compile-time k-step counts (KM1, KM2) and output tile counts (NT1, NT2), one k tile per axis.
 // Tables in VGPRs, +-k1 fold fused into the operand reads of axis H (raw intermediate plane in LDS),
 // all operand reads of a task issued before its MFMA chains, LDS-staged coalesced epilogue.
-template <int KM1, int KM2, int NT1, int NT2, bool HAS_ADD>
+// NFULL = plane_elems / 256: epilogue elements j < NFULL exist for every thread (no guards, no exec juggling),
+// j == NFULL is the ragged tail, j > NFULL does not exist.
+template <int KM1, int KM2, int NT1, int NT2, bool HAS_ADD, int NFULL>
 __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float *__restrict__ E,
                                                                     const float *__restrict__ addend,
                                                                     float *__restrict__ out, DhtArgs a) {
     extern __shared__ float lds[];
-    constexpr int NE = 20, NI = 4;
+    constexpr int NE = NFULL + 1, NI = 4;
     const DhtPlan &p = a.p;
     const Axis &a1 = p.ax[1], &a2 = p.ax[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, l15 = lane & 15;
     const int N1 = a1.N, N2 = a2.N, m1 = a1.m;
-    const int ldF = p.ldF, ldo = p.ldo;
+    const int ldF = p.ldF;
+    const int ldo = N2;   // flat image of the output plane: the epilogue reads O[tid + 256 j] with immediate offsets
+                          // (C-layout stores then see 2-way bank conflicts on a few banks; they are 16 per task)
     const int ne = 2 * p.CP;
     float *Er = lds + 16;                      // 16 zero floats in front (fold reads at k1s = -1)
     float *FR = Er + ne + 16, *FI = FR + p.MP1 * ldF, *O = FI + p.MP1 * ldF;
     // tables in registers: B[k = ks*4 + q][n = 1 + nt*16 + l15].  Output position 0 (cos = 1, sin = 0) is
     // peeled off and computed as a plain sum, so positions 1..J fill whole 16-wide tiles (J = 32:
     // 2 tiles instead of 3).  Frequency 0 is its own mirror in the +-k1 fold of axis H: cos row halved.
-    float bhc[NT1][KM1], bhs[NT1][KM1], bwc[NT2][KM2], bws[NT2][KM2];
-#pragma unroll
-    for (int nt = 0; nt < NT1; ++nt)
-#pragma unroll
-        for (int ks = 0; ks < KM1; ++ks) {
-            const int n = 1 + nt * 16 + l15, kk = ks * 4 + q;
-            const bool ok = n <= a1.J;
-            const int idx = ((n >> 4) * a1.KmP + kk) * 16 + (n & 15);
-            bhc[nt][ks] = ok ? p.tables[a1.cosI + idx] * (kk == 0 ? 0.5f : 1.f) : 0.f;
-            bhs[nt][ks] = ok ? p.tables[a1.sinI + idx] : 0.f;
-        }
+    // axis-H tables: LDS image in operand order [nt][cos|sin][ks][lane] (used once per plane by each wave; keeping
+    // them out of the register file avoids spills -- a spill reload waits on vmcnt(0), i.e. on the prefetches)
+    float bwc[NT2][KM2], bws[NT2][KM2];
+    float *tabH = O + 256 * NE;
+    for (int i2 = tid; i2 < NT1 * 2 * KM1 * 64; i2 += 256) {
+        const int ln = i2 & 63, ks = (i2 >> 6) % KM1, cs = ((i2 >> 6) / KM1) & 1, nt = (i2 >> 6) / (2 * KM1);
+        const int n = 1 + nt * 16 + (ln & 15), kk = ks * 4 + (ln >> 4);
+        const bool ok = n <= a1.J;
+        const int idx = ((n >> 4) * a1.KmP + kk) * 16 + (n & 15);
+        tabH[i2] = !ok ? 0.f : (cs ? p.tables[a1.sinI + idx] : p.tables[a1.cosI + idx] * (kk == 0 ? 0.5f : 1.f));
+    }
 #pragma unroll
     for (int nt = 0; nt < NT2; ++nt)
 #pragma unroll
@@ -1100,6 +1108,15 @@ __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float 
             const int idx = ((n >> 4) * a2.KmP + kk) * 16 + (n & 15);
             bwc[nt][ks] = ok ? p.tables[a2.cosI + idx] : 0.f;
             bws[nt][ks] = ok ? p.tables[a2.sinI + idx] : 0.f;
+        }
+    // the tables must STAY in registers: left visible as loads from read-only memory, the compiler re-issues the
+    // global loads inside the plane loop (rematerialisation), and every MFMA chain then waits on vmcnt
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KM2; ++ks) {
+            asm volatile("" : "+v"(bwc[nt][ks]));
+            asm volatile("" : "+v"(bws[nt][ks]));
         }
     if (tid < 16) {
         lds[tid] = 0.f;
@@ -1113,7 +1130,6 @@ __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float 
     const size_t plane_elems = (size_t)N1 * N2;
     const int MT1 = p.MP1 / 16;
     float re[NI], ra[HAS_ADD ? NE : 1];
-    const int r0 = tid / N2, c0 = tid - r0 * N2, dr = 256 / N2, dc = 256 - dr * N2;
     auto fetch_e = [&](int plane) {
         const float *Ep = E + (size_t)plane * ne;
 #pragma unroll
@@ -1122,8 +1138,12 @@ __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float 
             re[j] = e < ne ? Ep[e] : 0.f;
         }
     };
+    HNO_STAMP(a.stamps, 0);
+    if (a.stamps && blockIdx.x == 0 && tid == 0) { a.stamps[60] = wall_clock64(); a.stamps[62] = clock64(); }
     if (blockIdx.x < planes) fetch_e(blockIdx.x);
-    for (int plane = blockIdx.x; plane < planes; plane += gridDim.x) {
+    int it = 0;
+    for (int plane = blockIdx.x; plane < planes; plane += gridDim.x, ++it) {
+        HNO_STAMP(a.stamps, 1 + it * 6);
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -1136,10 +1156,12 @@ __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float 
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
                 const unsigned e = tid + 256u * j;
-                ra[HAS_ADD ? j : 0] = e < plane_elems ? ad[e] : 0.f;
+                ra[HAS_ADD ? j : 0] = (j < NFULL || e < plane_elems) ? ad[e] : 0.f;
             }
         }
+        HNO_STAMP(a.stamps, 2 + it * 6);
         __syncthreads();
+        HNO_STAMP(a.stamps, 3 + it * 6);
         // ---- axis H: F[n1][k2] = sum_k1 E[k1][k2] e^{+i th k1 n1}; E[+k1] +- E[-k1] formed while reading
         if (!(a.dbg & 1)) {
             for (int t = wave; t < NT1 * 2; t += 4) {
@@ -1148,13 +1170,16 @@ __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float 
                 const float *es = Er + (part ? p.CP : 0) + l15, *ed = Er + (part ? 0 : p.CP) + l15;
                 const float *sf = es + (m1 + q) * 16, *sb = es + (m1 - q) * 16;
                 const float *df = ed + (m1 + q) * 16, *db = ed + (m1 - q) * 16;
-                float as_[KM1], ad_[KM1], asb[KM1], adb[KM1];
+                float as_[KM1], ad_[KM1], asb[KM1], adb[KM1], tc[KM1], ts[KM1];
+                const float *th = tabH + nt1 * 2 * KM1 * 64 + lane;
 #pragma unroll
                 for (int ks = 0; ks < KM1; ++ks) {
                     as_[ks] = sf[64 * ks];
                     asb[ks] = sb[-64 * ks];
                     ad_[ks] = df[64 * ks];
                     adb[ks] = db[-64 * ks];
+                    tc[ks] = th[64 * ks];
+                    ts[ks] = th[64 * (KM1 + ks)];
                 }
                 __builtin_amdgcn_sched_barrier(0);   // all raw reads in flight before the first fold
 #pragma unroll
@@ -1165,14 +1190,10 @@ __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float 
                 __builtin_amdgcn_sched_barrier(0);   // all operand reads before the MFMA chains
                 f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = acc1;
 #pragma unroll
-                for (int n = 0; n < NT1; ++n)
-                    if (n == nt1) {
-#pragma unroll
-                        for (int ks = 0; ks < KM1; ++ks) {
-                            acc1 = mfma16(as_[ks], bhc[n][ks], acc1);
-                            acc2 = mfma16(ad_[ks], bhs[n][ks], acc2);
-                        }
-                    }
+                for (int ks = 0; ks < KM1; ++ks) {
+                    acc1 = mfma16(as_[ks], tc[ks], acc1);
+                    acc2 = mfma16(ad_[ks], ts[ks], acc2);
+                }
                 float *F = part ? FI : FR;
                 const int n1 = 1 + nt1 * 16 + l15;
                 if (n1 <= a1.J) {
@@ -1187,46 +1208,109 @@ __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float 
                 }
             }
             // output row n1 = 0: every e^{i th k1 0} = 1, so F[0][k2] is the plain sum over all 2*m1+1 k1
-            if (wave == 3 && lane < 32) {
-                const float *src = Er + (lane >> 4) * p.CP + l15;
-                float sum = 0.f;
-                for (int k1s = 0; k1s < p.K1S; ++k1s) sum += src[k1s * 16];
-                ((lane >> 4) ? FI : FR)[l15] = sum;
+            if (wave == 3) {   // lanes 0..31: (part, k2) with k1s = 0, 4, 8, .. and 2, 6, ..; lanes 32..63: the odd k1s
+                const int o5 = lane & 31, g = lane >> 5;
+                const float *src = Er + (o5 >> 4) * p.CP + l15;
+                float s0 = 0.f, s1 = 0.f;
+                for (int k1s = g; k1s < p.K1S; k1s += 4) {
+                    s0 += src[k1s * 16];
+                    s1 += k1s + 2 < p.K1S ? src[(k1s + 2) * 16] : 0.f;
+                }
+                s0 += s1;
+                s0 += __shfl_xor(s0, 32);
+                if (g == 0) ((o5 >> 4) ? FI : FR)[l15] = s0;
             }
         }
+        HNO_STAMP(a.stamps, 4 + it * 6);
         __syncthreads();
         // ---- axis W: O[n1][n2] = sum_k2 FR cos - FI sin ; mirror n2 -> N2 - n2 gets +
-        for (int t = wave; t < MT1 * NT2; t += 4) {
-            const int nt2 = t % NT2, mt = t / NT2;
-            const float *fr = FR + (mt * 16 + l15) * ldF + q, *fi = FI + (mt * 16 + l15) * ldF + q;
-            float ar[KM2], ai[KM2];
+        // tasks = (16-row tile mt, 16-column tile nt2); a wave takes two tasks per round and issues the operand
+        // reads of both before the first MFMA.  One or two leftover rows (N1 = 16 t + 1) go to the VALU instead
+        // of a whole MFMA tile.
+        const int MTF = (N1 % 16 >= 1 && N1 % 16 <= 2) ? N1 / 16 : MT1;
+        for (int t0 = wave; t0 < MTF * NT2; t0 += 8) {
+            const int t1 = t0 + 4;
+            const bool two = t1 < MTF * NT2;
+            const int nt2a = t0 % NT2, mta = t0 / NT2, nt2b = two ? t1 % NT2 : nt2a, mtb = two ? t1 / NT2 : mta;
+            const float *fra = FR + (mta * 16 + l15) * ldF + q, *fia = FI + (mta * 16 + l15) * ldF + q;
+            const float *frb = FR + (mtb * 16 + l15) * ldF + q, *fib = FI + (mtb * 16 + l15) * ldF + q;
+            float ar[KM2], ai[KM2], br[KM2], bi[KM2];
 #pragma unroll
             for (int ks = 0; ks < KM2; ++ks) {
-                ar[ks] = fr[4 * ks];
-                ai[ks] = fi[4 * ks];
+                ar[ks] = fra[4 * ks];
+                ai[ks] = fia[4 * ks];
+                br[ks] = frb[4 * ks];
+                bi[ks] = fib[4 * ks];
             }
             __builtin_amdgcn_sched_barrier(0);
-            f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = acc1;
+            if (it == 1) HNO_STAMP(a.stamps, 40);
+            f32x4 a1_ = {0.f, 0.f, 0.f, 0.f}, a2_ = a1_, b1_ = a1_, b2_ = a1_;
             if (!(a.dbg & 2)) {
 #pragma unroll
-                for (int n = 0; n < NT2; ++n)
-                    if (n == nt2) {
+                for (int n = 0; n < NT2; ++n) {
+                    if (n == nt2a) {
 #pragma unroll
                         for (int ks = 0; ks < KM2; ++ks) {
-                            acc1 = mfma16(ar[ks], bwc[n][ks], acc1);
-                            acc2 = mfma16(ai[ks], bws[n][ks], acc2);
+                            a1_ = mfma16(ar[ks], bwc[n][ks], a1_);
+                            a2_ = mfma16(ai[ks], bws[n][ks], a2_);
                         }
                     }
-            }
-            const int n2 = 1 + nt2 * 16 + l15;
-            if (n2 <= a2.J) {
-                const bool mirror = n2 <= a2.Js;
+                    if (two && n == nt2b) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n1 = mt * 16 + q * 4 + r;
-                    if (n1 < N1) {
-                        O[n1 * ldo + n2] = acc1[r] - acc2[r];
-                        if (mirror) O[n1 * ldo + (N2 - n2)] = acc1[r] + acc2[r];
+                        for (int ks = 0; ks < KM2; ++ks) {
+                            b1_ = mfma16(br[ks], bwc[n][ks], b1_);
+                            b2_ = mfma16(bi[ks], bws[n][ks], b2_);
+                        }
+                    }
+                }
+            }
+            if (it == 1) { asm volatile("s_nop 0" :: "v"(a1_[0]), "v"(a2_[0]), "v"(b1_[0]), "v"(b2_[0])); HNO_STAMP(a.stamps, 41); }
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                if (h2 == 1 && !two) break;
+                const int nt2 = h2 ? nt2b : nt2a, mt = h2 ? mtb : mta;
+                const f32x4 acc1 = h2 ? b1_ : a1_, acc2 = h2 ? b2_ : a2_;
+                const int n2 = 1 + nt2 * 16 + l15;
+                if (nt2 * 16 + 16 <= a2.Js && mt * 16 + 16 <= N1) {   // whole tile inside the plane (wave-uniform): no lane masks
+                    float *o = O + (mt * 16 + q * 4) * ldo + n2, *om = O + (mt * 16 + q * 4) * ldo + (N2 - n2);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        o[r * ldo] = acc1[r] - acc2[r];
+                        om[r * ldo] = acc1[r] + acc2[r];
+                    }
+                } else if (n2 <= a2.J) {
+                    const bool mirror = n2 <= a2.Js;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n1 = mt * 16 + q * 4 + r;
+                        if (n1 < N1) {
+                            O[n1 * ldo + n2] = acc1[r] - acc2[r];
+                            if (mirror) O[n1 * ldo + (N2 - n2)] = acc1[r] + acc2[r];
+                        }
+                    }
+                }
+            }
+        }
+        if (it == 1) HNO_STAMP(a.stamps, 42);
+        if (wave == 2 && !(a.dbg & 2)) {
+            for (int n1 = MTF * 16; n1 < N1; ++n1) {   // leftover rows: the k2 sum is split over the 4 lane groups
+                const float *fr = FR + n1 * ldF + q, *fi = FI + n1 * ldF + q;
+#pragma unroll
+                for (int n = 0; n < NT2; ++n) {
+                    float pc = 0.f, ps = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < KM2; ++ks) {
+                        pc += fr[4 * ks] * bwc[n][ks];
+                        ps += fi[4 * ks] * bws[n][ks];
+                    }
+                    pc += __shfl_xor(pc, 16);
+                    ps += __shfl_xor(ps, 16);
+                    pc += __shfl_xor(pc, 32);
+                    ps += __shfl_xor(ps, 32);
+                    const int n2 = 1 + n * 16 + l15;
+                    if (q == 0 && n2 <= a2.J) {
+                        O[n1 * ldo + n2] = pc - ps;
+                        if (n2 <= a2.Js) O[n1 * ldo + (N2 - n2)] = pc + ps;
                     }
                 }
             }
@@ -1240,28 +1324,29 @@ __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float 
                 O[n1 * ldo] = sum;
             }
         }
+        HNO_STAMP(a.stamps, 5 + it * 6);
         __syncthreads();
+        HNO_STAMP(a.stamps, 6 + it * 6);
         // ---- epilogue: out = act(scale * O + residual), flat and fully coalesced
         if (!(a.dbg & 4)) {
+            const float ap = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f;
+            const float aq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
+            const bool lin = a.act == HNO_ACT_NONE;
             float *op = out + (size_t)plane * plane_elems;
-            int r = r0, c = c0;
+            float ov[NE];   // all LDS reads first (one wait), then the arithmetic and the stores
+#pragma unroll
+            for (int j = 0; j < NE; ++j) ov[j] = O[tid + 256 * j];   // the O region is padded to 256 * NE floats
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
-                const unsigned e = tid + 256u * j;
-                if (e < plane_elems) {
-                    float v = a.scale * O[r * ldo + c];
-                    if (HAS_ADD) v += ra[HAS_ADD ? j : 0];
-                    op[e] = act_apply(v, a.act);
-                }
-                r += dr;
-                c += dc;
-                if (c >= N2) {
-                    c -= N2;
-                    ++r;
-                }
+                float v = a.scale * ov[j];
+                if (HAS_ADD) v += ra[HAS_ADD ? j : 0];
+                v = (v > 0.f || lin) ? ap * v : aq * neg_expm1(v);
+                if (j < NFULL || tid + 256u * j < plane_elems) op[tid + 256 * j] = v;
             }
         }
     }
+    if (a.stamps && blockIdx.x == 0 && tid == 0) { a.stamps[61] = wall_clock64(); a.stamps[63] = clock64(); }
 }
 
 static int check_sizes(int BC, int N0, int N1, int N2, int m0, int m1, int m2) {
@@ -1419,24 +1504,28 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
         const Axis &b1 = plan->ax[1], &b2 = plan->ax[2];
         const bool spec_ok = pe <= 256 * 20 && b1.KT == 1 && b2.KT == 1 && 2 * plan->CP <= 1024 && N1 >= 16 && N2 >= 16 &&
                              !(a.dbg & 16);
-        const size_t lds_spec = sizeof(float) * (16 + 2 * plan->CP + 16 + 2 * plan->MP1 * plan->ldF + N1 * plan->ldo);
+        const size_t lds_spec = sizeof(float) * (16 + 2 * plan->CP + 16 + 2 * plan->MP1 * plan->ldF + 256 * (pe / 256 + 1) + 2 * ((b1.J + 15) / 16) * b1.KmP * 16);
         int g_spec = (int)(kMaxLds / lds_spec);
         if (g_spec > 8) g_spec = 8;
         g_spec = planes < 256 * g_spec ? planes : 256 * g_spec;
         bool launched = false;
-#define HNO_SPEC(KM1, KM2, NT1, NT2)                                                                                      \
+#define HNO_SPEC(KM1, KM2, NT1, NT2, NFULL)                                                                               \
     if (!launched && spec_ok && b1.KmP == 4 * KM1 && b2.KmP == 4 * KM2 && (b1.J + 15) / 16 == NT1 &&                      \
-        (b2.J + 15) / 16 == NT2) {                                                                                        \
-        if (addend)                                                                                                       \
-            hipLaunchKernelGGL((dht_inv_plane_spec_kernel<KM1, KM2, NT1, NT2, true>), dim3(persistent_grid((const void *)dht_inv_plane_spec_kernel<KM1, KM2, NT1, NT2, true>, 256, lds_spec, planes)), dim3(256), lds_spec,  \
+        (b2.J + 15) / 16 == NT2 && pe / 256 == NFULL) {                                                                   \
+        if (addend) {                                                                                                     \
+            auto kern = dht_inv_plane_spec_kernel<KM1, KM2, NT1, NT2, true, NFULL>;                                       \
+            hipLaunchKernelGGL(kern, dim3(persistent_grid((const void *)kern, 256, lds_spec, planes)), dim3(256), lds_spec, \
                                s, (const float *)workspace, addend, out, a);                                              \
-        else                                                                                                              \
-            hipLaunchKernelGGL((dht_inv_plane_spec_kernel<KM1, KM2, NT1, NT2, false>), dim3(persistent_grid((const void *)dht_inv_plane_spec_kernel<KM1, KM2, NT1, NT2, false>, 256, lds_spec, planes)), dim3(256), lds_spec, \
+        } else {                                                                                                          \
+            auto kern = dht_inv_plane_spec_kernel<KM1, KM2, NT1, NT2, false, NFULL>;                                      \
+            hipLaunchKernelGGL(kern, dim3(persistent_grid((const void *)kern, 256, lds_spec, planes)), dim3(256), lds_spec, \
                                s, (const float *)workspace, addend, out, a);                                              \
+        }                                                                                                                 \
         launched = true;                                                                                                  \
     }
-        HNO_SPEC(4, 4, 2, 2)   // 65 x 65 and 61 x 61 planes, modes (., 14, 14): positions 1..32 / 1..30
-        HNO_SPEC(4, 4, 1, 1)   // 33 x 33 planes: positions 1..16
+        HNO_SPEC(4, 4, 2, 2, 16)   // 65 x 65 planes, modes (., 14, 14): positions 1..32
+        HNO_SPEC(4, 4, 2, 2, 14)   // 61 x 61 planes: positions 1..30
+        HNO_SPEC(4, 4, 1, 1, 4)    // 33 x 33 planes: positions 1..16
 #undef HNO_SPEC
         if (launched) {
         } else if (pe <= 256 * 20)

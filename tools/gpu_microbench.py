@@ -103,3 +103,26 @@ if which in ('stamps',):
         row = st[1 + it * 6: 7 + it * 6]
         if row[0] == 0: break
         print(f'  iter {it}:', ', '.join(f'{n}: {v - st[0]}' for n, v in zip(names, row)))
+
+if which in ('stamps_inv',):
+    import ctypes
+    z = torch.randn(B, C, 20, 28, 28, device=dev); x = torch.randn(B, C, N, N, N, device=dev)
+    BC, NN, mm = 48, (65, 65, 65), (10, 14, 14)
+    ws = torch.empty(L.hno_dht3_workspace_bytes(BC, *NN, *mm) // 4, device=dev)
+    yy = torch.empty_like(x)
+    P, S = pkg._lib.ptr, pkg._lib.stream_ptr
+    for addend in (None, x):
+        L.hno_pad_idht3(P(z), P(addend), 1, P(yy), P(ws), BC, *NN, *mm, 1.0, S())
+        L.hno_set_debug(64)
+        L.hno_pad_idht3(P(z), P(addend), 1, P(yy), P(ws), BC, *NN, *mm, 1.0, S())
+        L.hno_set_debug(0)
+        buf = (ctypes.c_longlong * 64)()
+        L.hno_debug_stamps(buf, 64)
+        st = list(buf)
+        print(f'addend={addend is not None}: block 0 loop {(st[61] - st[60]) / 100:.2f} us, clock {(st[63] - st[62]) / max(1, st[61] - st[60]) * 100:.0f} MHz')
+        print('  W detail (iter 1): reads done', st[40] - st[0], 'mfma done', st[41] - st[0], 'writes done', st[42] - st[0])
+        names = ['iter top', 'Er written, fetches issued', 'after sync (H starts)', 'after H', 'after W', 'after sync (epilogue starts)']
+        for it in range(5):
+            row = st[1 + it * 6: 7 + it * 6]
+            if row[0] == 0: break
+            print(f'  iter {it}:', ', '.join(f'{n}: {v - st[0]}' for n, v in zip(names, row)))
