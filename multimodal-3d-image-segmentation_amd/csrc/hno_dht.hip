@@ -635,6 +635,273 @@ __device__ __forceinline__ void fwd_d_store(const DhtArgs &a, float *__restrict_
     }
 }
 
+// ---- forward plane kernel, one WAVE per plane ------------------------------------------------
+// The workgroup-per-plane kernels above spend most of their time in barriers and in the dependency chain of
+// one plane (load -> LDS -> GEMM -> barrier -> GEMM -> barrier, ~7 000 cycles, 3 planes in flight per CU).
+// Here every wave owns a plane: no workgroup barrier at all, 8 planes in flight per CU (two waves per SIMD keep
+// each matrix pipe fed while the other wave waits on LDS or HBM).
+//   * the plane is kept FLAT in the wave's LDS slice (row stride N2, odd), so staging it is a ds_write_b128 per
+//     four elements at an immediate offset; a 16-row MFMA tile takes every second row of a 32-row group
+//     (rows 32 g + 2 i + parity), which makes the operand reads bank-conflict free for any odd stride;
+//   * the axis-W result T[n1][0..31] overwrites the first 32 columns of row n1 in place (a tile's reads precede
+//     its writes, LDS operations of one wave execute in order), so the slice is 17 KB and 8 waves fit a CU;
+//   * the next plane is prefetched into registers with 16-byte loads during the GEMMs (2 waves per SIMD leave
+//     256 VGPRs each); two tiles (axis W) / both parts (axis H) run as four interleaved MFMA chains, which hides
+//     the 40-cycle dependent-accumulator latency that a single wave would otherwise expose.
+// Requires N1 % 32 == 1 (one leftover row, done on the VALU), odd N2, one k tile per axis, Js == KsP.
+struct __attribute__((packed, aligned(4))) f4u_t { float x, y, z, w; };
+
+template <int KC2, int KS2, int KC1, int KS1, int NV, int NWV>   // NV = N1 * N2 / 256 full 16-byte-per-lane iterations; NWV waves per workgroup
+__global__ __launch_bounds__(64 * NWV, 1) void dht_fwd_plane_wave_kernel(const float *__restrict__ x, float *__restrict__ Y, DhtArgs a) {
+    extern __shared__ float lds[];
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const DhtPlan &p = a.p;
+    const Axis &a1 = p.ax[1], &a2 = p.ax[2];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4, l15 = lane & 15;
+    const int N1 = a1.N, N2 = a2.N;
+    const int pe = N1 * N2;
+    const int LW = 16 + ((pe + 32 + 15) & ~15);   // guard | plane | 32 zeros (row N1 of T, mirror of column 0)
+    float *xs = lds + (size_t)wave * LW + 16;
+    // one 8-wave workgroup per CU; workgroup b owns the contiguous planes [b P / G, (b + 1) P / G), so every CU
+    // gets the same number of planes (+-1) and its waves share them round-robin
+    const int planes_all = a.BC * p.ax[0].N;
+    const int p_begin = (int)((long long)planes_all * blockIdx.x / gridDim.x);
+    const int planes = (int)((long long)planes_all * (blockIdx.x + 1) / gridDim.x);
+    constexpr int nwaves = NWV;
+    constexpr int NT = 4;   // scalar tail iterations: pe - 256 NV < 256 elements
+    f4v rv[NV];
+    float rt[NT];
+    auto fetch = [&](int plane) {
+        const float *xp = x + (size_t)plane * pe;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const f4u_t v = *reinterpret_cast<const f4u_t *>(xp + 4 * lane + 256 * j);
+            rv[j] = f4v{v.x, v.y, v.z, v.w};
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int e = 256 * NV + lane + 64 * j;
+            rt[j] = e < pe ? xp[e] : 0.f;
+        }
+    };
+    int plane = p_begin + wave;
+    if (plane < planes) fetch(plane);   // in flight while the tables load
+    float bwc[KC2], bws[KS2], bhc[KC1], bhs[KS1];
+#pragma unroll
+    for (int ks = 0; ks < KC2; ++ks) bwc[ks] = p.tables[a2.cosF + (ks * 4 + q) * 16 + l15];
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks) bws[ks] = p.tables[a2.sinF + (ks * 4 + q) * 16 + l15];
+#pragma unroll
+    for (int ks = 0; ks < KC1; ++ks) bhc[ks] = p.tables[a1.cosF + (ks * 4 + q) * 16 + l15];
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) bhs[ks] = p.tables[a1.sinF + (ks * 4 + q) * 16 + l15];
+#pragma unroll
+    for (int ks = 0; ks < KC2; ++ks) asm volatile("" : "+v"(bwc[ks]));   // stay in registers (no re-load in the loop)
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks) asm volatile("" : "+v"(bws[ks]));
+#pragma unroll
+    for (int ks = 0; ks < KC1; ++ks) asm volatile("" : "+v"(bhc[ks]));
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) asm volatile("" : "+v"(bhs[ks]));
+    if (lane < 16) xs[lane - 16] = 0.f;
+    if (lane < 32) xs[pe + lane] = 0.f;
+    const float cmask = q == 0 ? 0.f : 1.f;   // the c = 0 term of the cos fold has no mirror element
+    HNO_STAMP(a.stamps, 0);
+    if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) { a.stamps[60] = wall_clock64(); a.stamps[62] = clock64(); }
+    if (a.stamps && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a.stamps[58] = wall_clock64();
+    if (a.stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) a.stamps[56] = wall_clock64();
+    int it = 0;
+    for (; plane < planes; plane += nwaves, ++it) {
+        HNO_STAMP(a.stamps, 1 + it * 6);
+        // ---- stage the plane (flat image); the previous plane's axis-H reads are complete (in-order LDS)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) *reinterpret_cast<f4v *>(xs + 4 * lane + 256 * j) = rv[j];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int e = 256 * NV + lane + 64 * j;
+            if (e < pe) xs[e] = rt[j];
+        }
+        HNO_STAMP(a.stamps, 2 + it * 6);
+        if (plane + nwaves < planes) fetch(plane + nwaves);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        HNO_STAMP(a.stamps, 3 + it * 6);
+        // ---- axis W: tiles of 16 rows (rows 32 g + 2 i + parity), the two parities of a group together
+#pragma unroll 1
+        for (int g = 0; g < N1 / 32; ++g) {
+            const float *row0 = xs + (32 * g + 2 * l15) * N2, *row1 = row0 + N2;
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, s0 = c0, c1 = c0, s1 = c0;
+            // software pipeline: the LDS reads of k-steps [s + G, s + 2G) are in flight while the MFMAs of [s, s + G) run
+            constexpr int G = 3;
+            {
+                const float *pf0 = row0 + q, *pb0 = row0 + N2 - q, *pf1 = row1 + q, *pb1 = row1 + N2 - q;
+                float a0[KC2], b0[KC2], a1_[KC2], b1[KC2];
+                auto ld = [&](int ks) {
+                    a0[ks] = pf0[4 * ks];
+                    b0[ks] = pb0[-4 * ks];
+                    a1_[ks] = pf1[4 * ks];
+                    b1[ks] = pb1[-4 * ks];
+                };
+#pragma unroll
+                for (int ks = 0; ks < G && ks < KC2; ++ks) ld(ks);
+#pragma unroll
+                for (int s0_ = 0; s0_ < KC2; s0_ += G) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = s0_ + G; ks < s0_ + 2 * G && ks < KC2; ++ks) ld(ks);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = s0_; ks < s0_ + G && ks < KC2; ++ks) {
+                        const float m = ks == 0 ? cmask : 1.f;
+                        c0 = mfma16(a0[ks] + m * b0[ks], bwc[ks], c0);
+                        c1 = mfma16(a1_[ks] + m * b1[ks], bwc[ks], c1);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const float *sf0 = row0 + a2.Js - q, *sb0 = row0 + N2 - a2.Js + q, *sf1 = row1 + a2.Js - q, *sb1 = row1 + N2 - a2.Js + q;
+                float a0[KS2], b0[KS2], a1_[KS2], b1[KS2];
+                auto ld = [&](int ks) {
+                    a0[ks] = sf0[-4 * ks];
+                    b0[ks] = sb0[4 * ks];
+                    a1_[ks] = sf1[-4 * ks];
+                    b1[ks] = sb1[4 * ks];
+                };
+#pragma unroll
+                for (int ks = 0; ks < G && ks < KS2; ++ks) ld(ks);
+#pragma unroll
+                for (int s0_ = 0; s0_ < KS2; s0_ += G) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = s0_ + G; ks < s0_ + 2 * G && ks < KS2; ++ks) ld(ks);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = s0_; ks < s0_ + G && ks < KS2; ++ks) {
+                        s0 = mfma16(a0[ks] - b0[ks], bws[ks], s0);
+                        s1 = mfma16(a1_[ks] - b1[ks], bws[ks], s1);
+                    }
+                }
+            }
+            // T rows of the two tiles overwrite columns 0..31 of the same plane rows
+            float *t0 = xs + (32 * g + 2 * (q * 4)) * N2 + l15, *t1 = t0 + N2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                t0[2 * r * N2] = c0[r];
+                t0[2 * r * N2 + 16] = s0[r];
+                t1[2 * r * N2] = c1[r];
+                t1[2 * r * N2 + 16] = s1[r];
+            }
+        }
+        HNO_STAMP(a.stamps, 4 + it * 6);
+        {   // leftover row N1 - 1: same operands on the VALU, k split over the 4 lane groups
+            const float *row = xs + (N1 - 1) * N2;
+            const float *pf = row + q, *pb = row + N2 - q;
+            const float *sf = row + a2.Js - q, *sb = row + N2 - a2.Js + q;
+            float pc = (pf[0] + cmask * pb[0]) * bwc[0], ps = 0.f;
+#pragma unroll
+            for (int ks = 1; ks < KC2; ++ks) pc += (pf[4 * ks] + pb[-4 * ks]) * bwc[ks];
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) ps += (sf[-4 * ks] - sb[4 * ks]) * bws[ks];
+            pc += __shfl_xor(pc, 16);
+            ps += __shfl_xor(ps, 16);
+            pc += __shfl_xor(pc, 32);
+            ps += __shfl_xor(ps, 32);
+            __builtin_amdgcn_sched_barrier(0);   // every lane has read the row before lanes 0..15 overwrite it
+            if (q == 0) {
+                xs[(N1 - 1) * N2 + l15] = pc;
+                xs[(N1 - 1) * N2 + 16 + l15] = ps;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        HNO_STAMP(a.stamps, 5 + it * 6);
+        // ---- axis H (fold along n1 while reading), both parts at once: BR = P_Ac -+ Q_As ; BI from Q_Ac, P_As
+        {
+            float *Yp = Y + (size_t)plane * (2 * p.CP);
+            const float *cA = xs + l15, *cB = xs + 16 + l15;   // Ac and As columns
+            f32x4 pA = {0.f, 0.f, 0.f, 0.f}, pB = pA, qA = pA, qB = pA;   // P/Q sums of the Ac / As columns
+            constexpr int G = 3;
+            {
+                const float *fA = cA + q * N2, *bA = cA + (N1 - q) * N2, *fB = cB + q * N2, *bB = cB + (N1 - q) * N2;
+                float a0[KC1], b0[KC1], a1_[KC1], b1[KC1];
+                auto ld = [&](int ks) {
+                    a0[ks] = fA[4 * ks * N2];
+                    b0[ks] = bA[-4 * ks * N2];   // ks = 0, q = 0 reads the zero row N1
+                    a1_[ks] = fB[4 * ks * N2];
+                    b1[ks] = bB[-4 * ks * N2];
+                };
+#pragma unroll
+                for (int ks = 0; ks < G && ks < KC1; ++ks) ld(ks);
+#pragma unroll
+                for (int s0_ = 0; s0_ < KC1; s0_ += G) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = s0_ + G; ks < s0_ + 2 * G && ks < KC1; ++ks) ld(ks);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = s0_; ks < s0_ + G && ks < KC1; ++ks) {
+                        pA = mfma16(a0[ks] + b0[ks], bhc[ks], pA);
+                        pB = mfma16(a1_[ks] + b1[ks], bhc[ks], pB);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const float *fA = cA + (a1.Js - q) * N2, *bA = cA + (N1 - a1.Js + q) * N2;
+                const float *fB = cB + (a1.Js - q) * N2, *bB = cB + (N1 - a1.Js + q) * N2;
+                float a0[KS1], b0[KS1], a1_[KS1], b1[KS1];
+                auto ld = [&](int ks) {
+                    a0[ks] = fA[-4 * ks * N2];
+                    b0[ks] = bA[4 * ks * N2];
+                    a1_[ks] = fB[-4 * ks * N2];
+                    b1[ks] = bB[4 * ks * N2];
+                };
+#pragma unroll
+                for (int ks = 0; ks < G && ks < KS1; ++ks) ld(ks);
+#pragma unroll
+                for (int s0_ = 0; s0_ < KS1; s0_ += G) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = s0_ + G; ks < s0_ + 2 * G && ks < KS1; ++ks) ld(ks);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = s0_; ks < s0_ + G && ks < KS1; ++ks) {
+                        qA = mfma16(a0[ks] - b0[ks], bhs[ks], qA);
+                        qB = mfma16(a1_[ks] - b1[ks], bhs[ks], qB);
+                    }
+                }
+            }
+            const int k1 = l15;
+            if (k1 <= a1.m) {
+                // part 0: cos sum of Ac (pA), sin sum of As (qB);  part 1: cos sum of As (pB), sin sum of Ac (qA)
+                f32x4 vp0, vm0, vp1, vm1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    vp0[r] = pA[r] - qB[r];
+                    vm0[r] = pA[r] + qB[r];
+                    vp1[r] = -(qA[r] + pB[r]);
+                    vm1[r] = qA[r] - pB[r];
+                }
+                const int k2 = q * 4;
+                *reinterpret_cast<f32x4 *>(Yp + (size_t)(a1.m + k1) * a2.KP + k2) = vp0;
+                *reinterpret_cast<f32x4 *>(Yp + (size_t)(p.K1S + (a1.m + k1)) * a2.KP + k2) = vp1;
+                if (k1 >= 1) {
+                    *reinterpret_cast<f32x4 *>(Yp + (size_t)(a1.m - k1) * a2.KP + k2) = vm0;
+                    *reinterpret_cast<f32x4 *>(Yp + (size_t)(p.K1S + (a1.m - k1)) * a2.KP + k2) = vm1;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        HNO_STAMP(a.stamps, 6 + it * 6);
+    }
+    if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) { a.stamps[61] = wall_clock64(); a.stamps[63] = clock64(); }
+    if (a.stamps && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a.stamps[59] = wall_clock64();
+    if (a.stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) a.stamps[57] = wall_clock64();
+}
+
 // ---- forward, axis D + (Re -/+ Im) + crop: one wave per (bc, column tile) ----------------
 __global__ __launch_bounds__(64) void dht_fwd_d_kernel(const float *__restrict__ Y, float *__restrict__ out, DhtArgs a) {
     extern __shared__ float lds[];
@@ -1414,6 +1681,26 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
         if (g_spec > 8) g_spec = 8;
         g_spec = planes < 256 * g_spec ? planes : 256 * g_spec;
         bool launched = false;
+        // one wave per plane (no workgroup barriers): N1 = 32 g + 1, odd N2, no activation-gradient input
+#define HNO_WAVE(KC2, KS2, KC1, KS1, NEV)                                                                                  \
+    if (!launched && spec_ok && !x_act_out && !(a.dbg & 512) && N1 % 32 == 1 && (N2 & 1) && b2.KcP == 4 * KC2 &&           \
+        b2.KsP == 4 * KS2 && b1.KcP == 4 * KC1 && b1.KsP == 4 * KS1 && b1.Js == b1.KsP && b2.Js == b2.KsP &&              \
+        pe / 256 == NEV) {                                                                                                 \
+        constexpr int NWV = 8;   /* one 8-wave workgroup per CU (4 waves per CU measured 10 % slower) */                   \
+        auto kern = dht_fwd_plane_wave_kernel<KC2, KS2, KC1, KS1, NEV, NWV>;                                               \
+        const size_t lds_w = sizeof(float) * NWV * (16 + ((pe + 32 + 15) & ~15));                                          \
+        static bool attr = false;                                                                                          \
+        if (!attr) {                                                                                                       \
+            HNO_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds)); \
+            attr = true;                                                                                                   \
+        }                                                                                                                  \
+        const int gw = persistent_grid((const void *)kern, 64 * NWV, lds_w, (planes + NWV - 1) / NWV);                     \
+        hipLaunchKernelGGL(kern, dim3(gw), dim3(64 * NWV), lds_w, s, x, (float *)workspace, a);                            \
+        launched = true;                                                                                                   \
+    }
+        HNO_WAVE(9, 8, 9, 8, 16)   // 65 x 65 planes
+        HNO_WAVE(5, 4, 5, 4, 4)    // 33 x 33 planes
+#undef HNO_WAVE
 #define HNO_SPEC(KC2, KS2, KC1, KS1)                                                                                      \
     if (!launched && spec_ok && b2.KcP == 4 * KC2 && b2.KsP == 4 * KS2 && b1.KcP == 4 * KC1 && b1.KsP == 4 * KS1) {      \
         if (x_act_out) {                                                                                                  \

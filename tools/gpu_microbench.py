@@ -96,9 +96,9 @@ if which in ('stamps',):
     L.hno_debug_stamps(buf, 64)
     st = list(buf)
     print(f'wall_clock64 (100 MHz) delta {st[61] - st[60]} -> {(st[61] - st[60]) / 100:.2f} us; clock64 delta {st[63] - st[62]} -> {(st[63] - st[62]) / max(1, st[61] - st[60]) * 100:.0f} MHz')
-    print(f'block 0: start 0, end {(st[61]-st[60])/100:.2f} us; block 600: start {(st[56]-st[60])/100:.2f}, end {(st[57]-st[60])/100:.2f} us; last block: start {(st[58]-st[60])/100:.2f}, end {(st[59]-st[60])/100:.2f} us')
+    print(f'block 0: start 0, end {(st[61]-st[60])/100:.2f} us; middle block: start {(st[56]-st[60])/100:.2f}, end {(st[57]-st[60])/100:.2f} us; last block: start {(st[58]-st[60])/100:.2f}, end {(st[59]-st[60])/100:.2f} us')
     print('fwd plane stamps (cycles since kernel-loop start; clock64 ticks):')
-    names = ['iter top', 'after sync0', 'after LDS write + fetch issue', 'after sync1', 'after W', 'after sync2 (H starts)']
+    names = ['iter top', 'staged', 'fetch issued', 'after W tiles', 'after leftover row', 'after H']
     for it in range(5):
         row = st[1 + it * 6: 7 + it * 6]
         if row[0] == 0: break
