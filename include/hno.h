@@ -147,6 +147,11 @@ int hno_conv_k2s2_bwd(const float *gy, const float *y, const float *x, const flo
  */
 int hno_upsoftmax_fwd(const float *logits_lr, float *probs, int B, int K, int d, int h, int w,
                       int D, int H, int W, int softmax, void *stream);
+/* Inference head: labels[b, z, y, x] = argmax_c trilinear(logits_lr[b, c]) as uint8 -- the prediction of
+ * testing() (experiments/train_test.py:398-408: model(x) -> cpu -> argmax(1) -> uint8) without forming or moving
+ * the probabilities. */
+int hno_up_argmax(const float *logits_lr, unsigned char *labels, int B, int K, int d, int h, int w, int D, int H,
+                  int W, void *stream);
 size_t hno_upsoftmax_bwd_workspace_bytes(int B, int K, int d, int h, int w, int D, int H, int W);
 int hno_upsoftmax_bwd(const float *g_probs, const float *probs, float *g_lr, void *workspace, int B, int K, int d,
                       int h, int w, int D, int H, int W, int softmax, void *stream);

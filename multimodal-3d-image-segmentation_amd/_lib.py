@@ -37,6 +37,7 @@ SIGNATURES = {
     'hno_conv_k2s2_fwd': (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
     'hno_conv_k2s2_bwd': (c_int, [c_void_p] * 8 + [c_int] * 7 + [c_void_p]),
     'hno_upsoftmax_fwd': (c_int, [c_void_p] * 2 + [c_int] * 9 + [c_void_p]),
+    'hno_up_argmax': (c_int, [c_void_p] * 2 + [c_int] * 8 + [c_void_p]),
     'hno_upsoftmax_bwd_workspace_bytes': (c_size_t, [c_int] * 8),
     'hno_upsoftmax_bwd': (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
     'hno_conv3d_k3_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),

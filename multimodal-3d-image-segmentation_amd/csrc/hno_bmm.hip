@@ -97,6 +97,7 @@ extern "C" int hno_bmm(const float *A, const float *B, float *C, int batch, int 
     a.ldc = N;
     a.sA = (long long)M * K; a.sB = (long long)K * N; a.sC = (long long)M * N;
     a.transA = transA; a.transB = transB; a.alpha = alpha;
+    ProfScope _ps0(KID_BMM, (hipStream_t)stream, 4.0 * batch * ((double)M * K + (double)K * N + (double)M * N));
     hipLaunchKernelGGL(bmm_kernel, dim3(ceil_div(N, BMM_T), ceil_div(M, BMM_T), batch), dim3(256), 0, (hipStream_t)stream, a);
     HNO_CHECK_LAUNCH();
     return HNO_OK;

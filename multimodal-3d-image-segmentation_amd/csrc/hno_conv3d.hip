@@ -469,6 +469,7 @@ extern "C" int hno_conv3d_k3(const float *x, const float *W, const float *bias, 
     // the GEMM's output channel is tensor axis 0 for mode 0 (o) and mode 3 (Cin of Wt); axis 1 for modes 1 and 2
     const int out_is_axis0 = (mode == 0 || mode == 3);
     const int flip = 0;  // the fractional gather already pairs tap t with offset (+pad - t): no flip in any mode
+    ProfScope _ps(KID_CONV3D_GEMM, s);
     hipLaunchKernelGGL(c3_relayout_kernel, dim3(g1((size_t)C0 * C1 * 27)), dim3(256), 0, s, W, wt, C0, C1, out_is_axis0, flip);
     HNO_CHECK_LAUNCH();
     const long long ntiles = (long long)B * Do * Ho * ((Wo + 31) / 32);
@@ -511,6 +512,7 @@ extern "C" int hno_conv3d_k3_wgrad(const float *g, const float *x, float *dW, vo
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)c3_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
+    ProfScope _ps(KID_CONV3D_WGRAD, s);
     hipLaunchKernelGGL(c3_wgrad_kernel, dim3(a.nchunks, 9, tiles), dim3(256), lds, s, a);
     HNO_CHECK_LAUNCH();
     // stored layout: conv W[Cg][Cx][27]; transposed Wt[Cin = Cg][Cout = Cx][27] -- both have the g side on axis 0
@@ -526,6 +528,7 @@ extern "C" int hno_groupnorm1_fwd(const float *x, const float *gamma, const floa
     hipStream_t s = (hipStream_t)stream;
     HNO_CHECK_HIP(hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * B, s));
     const long long n = (long long)C * V;
+    ProfScope _ps(KID_GROUPNORM, s);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(g1((size_t)n / 8 + 1) > 1024 ? 1024 : g1((size_t)n / 8 + 1), B), dim3(256), 0, s, x, stats_ws, n);
     HNO_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, s, (const double *)stats_ws, mean_rstd, B, n, eps);
@@ -544,6 +547,7 @@ extern "C" int hno_groupnorm1_bwd(const float *g, const float *y, const float *x
     hipStream_t s = (hipStream_t)stream;
     HNO_CHECK_HIP(hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * B * C, s));
     const int gxn = g1((size_t)V / 4 + 1) > 256 ? 256 : g1((size_t)V / 4 + 1);
+    ProfScope _ps(KID_GROUPNORM, s);
     hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3(gxn, B * C), dim3(256), 0, s, g, y, x, mean_rstd, sums_ws, C, V, act);
     HNO_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), 0, s, (const double *)sums_ws, gamma, coef_ws, dgamma, dbeta, B, C, V);
@@ -560,6 +564,7 @@ extern "C" int hno_nearest3d(const float *src, float *dst, int BC, int d, int h,
     a.src = src; a.dst = dst; a.BC = BC; a.d = d; a.h = h; a.w = w; a.D = D; a.H = H; a.W = W;
     a.sd = (float)d / D; a.sh = (float)h / H; a.sw = (float)w / W;
     a.accumulate = accumulate;
+    ProfScope _ps(KID_RESAMPLE, (hipStream_t)stream, 4.0 * BC * ((double)d * h * w + (double)D * H * W));
     if (!adjoint)
         hipLaunchKernelGGL(nn_up_kernel, dim3(g1((size_t)BC * D * H * W)), dim3(256), 0, (hipStream_t)stream, a);
     else
@@ -570,6 +575,7 @@ extern "C" int hno_nearest3d(const float *src, float *dst, int BC, int d, int h,
 
 extern "C" int hno_channel_sum(const float *g, float *out, int B, int C, long long V, void *stream) {
     HNO_REQUIRE(g && out && B > 0 && C > 0 && V > 0, "hno_channel_sum: bad argument");
+    ProfScope _ps(KID_RESAMPLE, (hipStream_t)stream, 4.0 * B * C * (double)V);
     hipLaunchKernelGGL(chan_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, g, out, B, C, V);
     HNO_CHECK_LAUNCH();
     return HNO_OK;

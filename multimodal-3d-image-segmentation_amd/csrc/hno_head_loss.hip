@@ -82,6 +82,41 @@ __global__ __launch_bounds__(256) void upsoftmax_fwd_kernel(UpArgs a) {
     }
 }
 
+// Inference head: argmax over channels of the upsampled logits, written as uint8 class labels.  softmax is
+// monotone, so the probabilities (67 MB per 2 volumes, and their trip over PCIe in the reference's testing loop,
+// experiments/train_test.py:398-408) are never formed.  Ties resolve to the lowest index like numpy.argmax.
+template <int KMAX>
+__global__ __launch_bounds__(256) void upargmax_kernel(UpArgs a, unsigned char *__restrict__ labels) {
+    const size_t V = (size_t)a.D * a.H * a.W, v_lr = (size_t)a.d * a.h * a.w;
+    const size_t total = V * a.B;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int b = (int)(idx / V);
+        const size_t v = idx % V;
+        const int x = (int)(v % a.W), y = (int)((v / a.W) % a.H), z = (int)(v / ((size_t)a.W * a.H));
+        const Lin lz = lin_coord(z, a.sd, a.d), ly = lin_coord(y, a.sh, a.h), lx = lin_coord(x, a.sw, a.w);
+        const size_t o00 = ((size_t)lz.i0 * a.h + ly.i0) * a.w, o01 = ((size_t)lz.i0 * a.h + ly.i1) * a.w;
+        const size_t o10 = ((size_t)lz.i1 * a.h + ly.i0) * a.w, o11 = ((size_t)lz.i1 * a.h + ly.i1) * a.w;
+        float best = -3.0e38f;
+        int arg = 0;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (k < a.K) {
+                const float *s = a.lr + ((size_t)b * a.K + k) * v_lr;
+                const float c00 = lx.w0 * s[o00 + lx.i0] + lx.w1 * s[o00 + lx.i1];
+                const float c01 = lx.w0 * s[o01 + lx.i0] + lx.w1 * s[o01 + lx.i1];
+                const float c10 = lx.w0 * s[o10 + lx.i0] + lx.w1 * s[o10 + lx.i1];
+                const float c11 = lx.w0 * s[o11 + lx.i0] + lx.w1 * s[o11 + lx.i1];
+                const float val = lz.w0 * (ly.w0 * c00 + ly.w1 * c01) + lz.w1 * (ly.w0 * c10 + ly.w1 * c11);
+                if (val > best) {
+                    best = val;
+                    arg = k;
+                }
+            }
+        }
+        labels[idx] = (unsigned char)arg;
+    }
+}
+
 // first / last high-res index whose i0 is >= lo_i / <= hi_i (i0 is monotone in dst)
 __device__ __forceinline__ void contrib_range(int i, float rscale, int in_size, int out_size, int &first, int &last) {
     // dst contributes to low-res index i  <=>  i0(dst) in {i-1, i}
@@ -507,6 +542,21 @@ extern "C" int hno_upsoftmax_fwd(const float *logits_lr, float *probs, int B, in
     const int grid = grid1d((size_t)B * D * H * W);
     if (K <= 4) { ProfScope _ps(KID_UPSOFTMAX_FWD, (hipStream_t)stream, 4.0 * B * K * ((double)d * h * w + (double)D * H * W)); hipLaunchKernelGGL(upsoftmax_fwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
     else { ProfScope _ps(KID_UPSOFTMAX_FWD, (hipStream_t)stream, 4.0 * B * K * ((double)d * h * w + (double)D * H * W)); hipLaunchKernelGGL(upsoftmax_fwd_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+extern "C" int hno_up_argmax(const float *logits_lr, unsigned char *labels, int B, int K, int d, int h, int w, int D, int H,
+                             int W, void *stream) {
+    HNO_REQUIRE(logits_lr && labels, "hno_up_argmax: null pointer");
+    UpArgs a = {};
+    int rc = up_fill(a, B, K, d, h, w, D, H, W, 0);
+    if (rc) return rc;
+    a.lr = logits_lr;
+    const int grid = grid1d((size_t)B * D * H * W);
+    ProfScope _ps(KID_UPSOFTMAX_FWD, (hipStream_t)stream, 4.0 * B * K * (double)d * h * w + (double)B * D * H * W);
+    if (K <= 4) hipLaunchKernelGGL(upargmax_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, labels);
+    else hipLaunchKernelGGL(upargmax_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, labels);
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }

@@ -177,6 +177,7 @@ extern "C" int hno_permode_fwd(const float *x, const float *xr, const float *w, 
     a.B = B; a.Ci = Ci; a.Co = Co; a.M = M; a.d0 = d0; a.d1 = d1; a.d2 = d2; a.fourier = fourier;
     int rc = pm_check(a);
     if (rc) return rc;
+    ProfScope _ps(KID_PERMODE_FWD, (hipStream_t)stream);
     hipLaunchKernelGGL(permode_fwd_kernel<8>, dim3(ceil_div(M, 256), Co), dim3(256), 0, (hipStream_t)stream, a);
     HNO_CHECK_LAUNCH();
     return HNO_OK;
@@ -192,6 +193,7 @@ extern "C" int hno_permode_bwd(const float *g, const float *x, const float *xr, 
     int rc = pm_check(a);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    ProfScope _ps(KID_PERMODE_BWD, s);
     hipLaunchKernelGGL(permode_dgrad_kernel<8>, dim3(ceil_div(M, 256), Ci), dim3(256), 0, s, a);
     HNO_CHECK_LAUNCH();
     hipLaunchKernelGGL(permode_wgrad_kernel<8>, dim3(ceil_div(M, 256), Ci * Co), dim3(256), 0, s, a);

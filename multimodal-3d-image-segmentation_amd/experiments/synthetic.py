@@ -7,11 +7,13 @@ import torch
 
 class SyntheticInputData:
     def __init__(self, image_size, in_channels, num_labels, batch_size=1, num_train=4, num_valid=2, seed=1234,
-                 generator=None):
+                 generator=None, num_test=2):
         self.image_size = tuple(image_size)
         self.in_channels, self.num_labels = in_channels, num_labels
         self.batch_size, self.num_train, self.num_valid = batch_size, num_train, num_valid
         self.seed = seed
+        self.num_test = num_test
+        self.data_lists_test = [[f'synthetic_{i}'] for i in range(num_test)]
         self._make = generator or self._default_sample
 
     def _default_sample(self, index):
@@ -29,12 +31,18 @@ class SyntheticInputData:
             xs, ys = zip(*[self._make(j) for j in order[i:i + self.batch_size]])
             yield torch.stack(xs), torch.stack(ys)
 
-    # -- the part of the InputData interface used by training() ------------------------------
+    # -- the part of the InputData interface used by training() / testing() ------------------------------
     def get_train_flow(self, shuffle=True):
         return _Reiterable(lambda: self._flow(0, self.num_train, shuffle))
 
     def get_valid_flow(self):
         return _Reiterable(lambda: self._flow(self.num_train, self.num_valid, False))
+
+    def get_test_flow(self):
+        return _Reiterable(lambda: self._flow(self.num_train + self.num_valid, self.num_test, False))
+
+    def get_test_num_batches(self):
+        return int(math.ceil(self.num_test / self.batch_size))
 
     def get_train_num_batches(self):
         return int(math.ceil(self.num_train / self.batch_size))

@@ -125,6 +125,82 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
     return model
 
 
+def testing(model, input_data, output_dir, label_mapping=None, output_origin=None, is_print=True, use_autocast=False,
+            device=None, save_fn=None):
+    """Prediction on the testing data with the reference's signature and protocol (experiments/train_test.py:332-426):
+    batch size 1, `model.eval()`, per-sample wall time (first sample excluded from the average), label remapping,
+    `prediction_time_memory.txt`.
+
+    Changed on purpose: the class map is produced ON THE GPU (ops.label_output(): argmax fused into the upsampling
+    kernel), so one uint8 volume crosses PCIe per sample instead of K float32 probability volumes followed by a host
+    argmax (reference :398-408).  Writing NIfTI files needs SimpleITK (out of scope): predictions go
+    through `save_fn(array, data_lists_test, index, images_dir, output_origin, suffix)` when given, else to
+    `images/<index>_{true,pred}.npy`.  Returns (list of y_true or None, list of y_pred)."""
+    from .. import ops
+    from .utils import remap_labels
+    if use_autocast:
+        raise NotImplementedError('autocast is not provided by the fp32 HIP path')
+    assert input_data.batch_size == 1
+    os.makedirs(output_dir, exist_ok=True)
+    images_dir = join(output_dir, 'images')
+    os.makedirs(images_dir, exist_ok=True)
+    test_num_batches = input_data.get_test_num_batches()
+    data_lists_test = getattr(input_data, 'data_lists_test', None)
+    if is_print:
+        print('test_num_batches:', test_num_batches)
+        print()
+    test_flow = input_data.get_test_flow()
+    model.to(device)
+    model.eval()
+    if is_print:
+        print('Testing started')
+        print(output_dir)
+
+    def save(arr, i, suffix):
+        if save_fn is not None:
+            save_fn(arr, data_lists_test, i, images_dir, output_origin, suffix)
+        else:
+            np.save(join(images_dir, f'{i}{suffix}.npy'), arr)
+
+    start_time = time.time()
+    predict_times, y_trues, y_preds = [], [], []
+    for i, xy in enumerate(test_flow):
+        s_time = time.time()
+        y_true = None
+        if isinstance(xy, (tuple, list)):
+            x, y = xy
+            y_true = np.asarray(y, dtype=np.uint8)[0, 0]  # (1, 1, D, H, W) to (D, H, W)
+        else:
+            x = xy
+        x = x.to(device)
+        with torch.no_grad(), ops.label_output():
+            yp = model(x)                                   # (1, 1, D, H, W) uint8 labels
+        y_pred = np.asarray(yp.detach().to('cpu'))[0, 0]    # the .to('cpu') is the synchronisation point
+        e_time = time.time()
+        if y_true is not None:
+            save(y_true, i, '_true')
+        if label_mapping is not None:                       # outside the timed span, as in the reference (:409-410)
+            y_pred = np.asarray(remap_labels(yp, label_mapping).to('cpu'))[0, 0].astype(np.uint8)
+        save(y_pred, i, '_pred')
+        y_trues.append(y_true)
+        y_preds.append(y_pred)
+        if i != 0:  # Skip the first iteration which involves model initialization
+            predict_times.append(e_time - s_time)
+    end_time = time.time()
+    avg = float(np.mean(predict_times)) if predict_times else float('nan')
+    on_gpu = torch.cuda.is_available() and device is not None and torch.device(device).type == 'cuda'
+    lines = [f'Average prediction time: {avg}']
+    if on_gpu:
+        lines += [f'max_memory_reserved: {torch.cuda.max_memory_reserved(device) / 1024 ** 2:.2f} MiB',
+                  f'max_memory_allocated: {torch.cuda.max_memory_allocated(device) / 1024 ** 2:.2f} MiB']
+    if is_print:
+        print(f'\nTime used: {end_time - start_time:.2f} seconds.')
+        print('\n'.join(lines))
+    with open(join(output_dir, 'prediction_time_memory.txt'), 'w') as f:
+        print('\n'.join(lines), file=f)
+    return y_trues, y_preds
+
+
 def save_checkpoint(chkpt_path, epoch, model, optimizer, scheduler, min_loss, best_epoch, scaler):
     """Same dict keys as the reference (train_test.py:262-273)."""
     checkpoint = {

@@ -132,7 +132,7 @@ class _TransSeg(nn.Module):
         logits = ops.PwConvFn.apply(x, None, self.conv_out.weight, None, ops.ACT_NONE)
         if not (self._softmax or self.output_activation is None):
             raise NotImplementedError('only softmax / None output activations are provided by the HIP path')
-        y = ops.UpSoftmaxFn.apply(logits, image_size if self.use_resize else tuple(logits.shape[2:]), self._softmax)
+        y = ops.head_output(logits, image_size if self.use_resize else tuple(logits.shape[2:]), self._softmax)
         return spatial_padcrop(y, image_size)
 
 
@@ -311,7 +311,7 @@ class VNetDS(nn.Module):
         logits = ops.PwConvFn.apply(x, None, self.conv_out.weight, None, ops.ACT_NONE)   # commutes with the upsampling
         if not (self._softmax or self.output_activation is None):
             raise NotImplementedError('only softmax / None output activations are provided by the HIP path')
-        y = ops.UpSoftmaxFn.apply(logits, image_size if self.use_resize else tuple(logits.shape[2:]), self._softmax)
+        y = ops.head_output(logits, image_size if self.use_resize else tuple(logits.shape[2:]), self._softmax)
         return spatial_padcrop(y, image_size)
 
     def _section(self, layers, x, nconv):

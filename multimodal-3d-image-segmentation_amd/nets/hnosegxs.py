@@ -258,7 +258,7 @@ class HNOSegXS(nn.Module):
         if not (self._softmax or self.output_activation is None):
             raise NotImplementedError('only softmax / None output activations are provided by the HIP path')
         if self.use_resize:
-            y = ops.UpSoftmaxFn.apply(logits, image_size, self._softmax)
+            y = ops.head_output(logits, image_size, self._softmax)
         else:
-            y = ops.UpSoftmaxFn.apply(logits, tuple(logits.shape[2:]), self._softmax)
+            y = ops.head_output(logits, tuple(logits.shape[2:]), self._softmax)
         return spatial_padcrop(y, image_size)

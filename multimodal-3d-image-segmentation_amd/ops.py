@@ -690,6 +690,43 @@ class UpSoftmaxFn(torch.autograd.Function):
         return g_lr, None, None
 
 
+# ------------------------------------------------------------------------- inference head
+import contextlib
+import threading
+
+_HEAD_MODE = threading.local()
+
+
+@contextlib.contextmanager
+def label_output():
+    """Inside this context every model's output head returns uint8 class labels (B, 1, D, H, W) -- argmax over channels
+    of the upsampled logits, fused into the upsampling kernel -- instead of probabilities.  Used by
+    experiments.train_test.testing(); forward only (no autograd)."""
+    prev = getattr(_HEAD_MODE, 'labels', False)
+    _HEAD_MODE.labels = True
+    try:
+        yield
+    finally:
+        _HEAD_MODE.labels = prev
+
+
+def up_argmax(logits_lr, size):
+    lr = _f32c(logits_lr.detach())
+    _need_gpu(lr)
+    B, K, d, h, w = lr.shape
+    D, H, W = (int(s) for s in size)
+    labels = torch.empty((B, 1, D, H, W), device=lr.device, dtype=torch.uint8)
+    check(_lib.lib().hno_up_argmax(ptr(lr), ptr(labels), B, K, d, h, w, D, H, W, stream_ptr()), 'hno_up_argmax')
+    return labels
+
+
+def head_output(logits_lr, size, softmax):
+    """Output head shared by all model families: probabilities (training / evaluation) or labels (label_output())."""
+    if getattr(_HEAD_MODE, 'labels', False):
+        return up_argmax(logits_lr, size)
+    return UpSoftmaxFn.apply(logits_lr, size, softmax)
+
+
 class SegLossFn(torch.autograd.Function):
     """PCC / Dice / ExpDice on uint8 labels (nets/custom_losses.py:17-133 with the one-hot
     encoding of experiments/utils.py:74-97 fused)."""

@@ -67,3 +67,34 @@ def test_label_helpers_gpu():
     assert np.array_equal(utils.to_categorical(lab).cpu().numpy(), g['onehot_auto'])
     mapping = {int(k): int(v) for k, v in zip(g['remap_keys'], g['remap_vals'])}
     assert np.array_equal(utils.remap_labels(lab, mapping).cpu().numpy(), g['remapped'])
+
+
+@pytest.mark.parametrize('family', ['hnosegxs', 'fnoseg', 'vnetds'])
+def test_testing_labels_equal_argmax_of_probabilities(tmp_path, family):
+    """testing() (fused upsample + argmax on the GPU, uint8 over PCIe) must give exactly the class map the reference
+    protocol gives: argmax over channels of model(x) on the host (experiments/train_test.py:398-408)."""
+    import multimodal_3d_image_segmentation_amd as pkg
+    from multimodal_3d_image_segmentation_amd.experiments import train_test as tt
+    from multimodal_3d_image_segmentation_amd.experiments.synthetic import SyntheticInputData
+    torch.manual_seed(3)
+    nets = pkg.nets
+    if family == 'hnosegxs':
+        model, size = nets.HNOSegXS(2, 3, 8, [2, 2], (3, 4, 4)), (16, 20, 24)
+    elif family == 'fnoseg':
+        model, size = nets.NeuralOperatorSeg(2, 3, 8, 2, (3, 4, 4), 'Fourier'), (16, 20, 24)
+    else:
+        model, size = nets.VNetDS(2, 3, 4, [1, 1], right_leg_indexes=[0, 1]), (16, 16, 16)
+    model = model.cuda()
+    data = SyntheticInputData(size, 2, 3, batch_size=1, num_train=0, num_valid=0, num_test=3)
+    mapping = {0: 0, 1: 4, 2: 9}
+    y_true, y_pred = tt.testing(model, data, str(tmp_path / 'out'), label_mapping=mapping, is_print=False, device='cuda')
+    assert len(y_pred) == 3 and os.path.exists(tmp_path / 'out' / 'prediction_time_memory.txt')
+    model.eval()
+    for i, (x, y) in enumerate(data.get_test_flow()):
+        with torch.no_grad():
+            probs = model(x.cuda())
+        want = probs.argmax(1).cpu().numpy().astype(np.uint8)[0]
+        want = np.vectorize(mapping.get)(want).astype(want.dtype)
+        assert y_pred[i].shape == size and np.array_equal(y_pred[i], want)
+        assert np.array_equal(y_true[i], np.asarray(y, dtype=np.uint8)[0, 0])
+        assert np.array_equal(np.load(tmp_path / 'out' / 'images' / f'{i}_pred.npy'), want)
