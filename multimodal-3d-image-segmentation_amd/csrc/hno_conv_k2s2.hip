@@ -23,18 +23,46 @@ struct K2Args {
     float *y, *dW, *dbias, *partials;
     int B, Cin, Cout, D, H, Wd, Do, Ho, Wo;
     int act;
+    // tiling of one (b, od) slab: Ho * wtr row tiles (32 consecutive ow of one output row) followed by
+    // ncol * ctiles column tiles (32 consecutive oh at one of the last `ncol` columns).  Wo = 32 t + 1 (65, 33)
+    // would otherwise spend a whole 32-wide tile per row on its single leftover column: 3 tiles per row, not 2.
+    int wtr, ncol, ctiles, tiles_per_slab;
 };
+
+struct K2Tile {
+    int b, od, oh, ow;   // oh / ow are per-lane
+    bool live;
+};
+__device__ __forceinline__ K2Tile k2_tile(const K2Args &a, long long t, int c) {
+    K2Tile r;
+    const int idx = (int)(t % a.tiles_per_slab);
+    const long long slab = t / a.tiles_per_slab;
+    r.od = (int)(slab % a.Do);
+    r.b = (int)(slab / a.Do);
+    const int nrow = a.Ho * a.wtr;
+    if (idx < nrow) {
+        r.oh = idx / a.wtr;
+        r.ow = (idx - r.oh * a.wtr) * 32 + c;
+        r.live = r.ow < a.Wo - a.ncol;
+    } else {
+        const int j = idx - nrow, col = j / a.ctiles;
+        r.oh = (j - col * a.ctiles) * 32 + c;
+        r.ow = a.Wo - a.ncol + col;
+        r.live = r.oh < a.Ho;
+    }
+    return r;
+}
 
 // x[b, i, 2od-1+kd, 2oh-1+kh, 2ow-1+kw] (zero outside).  k>>1 = (i,kd,kh) is wave-uniform, the lane
 // half carries kw, so the address is  uniform row base + (2*ow - 1 + kw)  with a per-lane mask.
 __device__ __forceinline__ float k2_patch(const K2Args &a, const float *xb_, int kpair, int od, int oh, int wl, bool wok) {
     const int kh = kpair & 1, kd = (kpair >> 1) & 1, i = kpair >> 2;
-    const int d = 2 * od - 1 + kd, hh = 2 * oh - 1 + kh;
-    const bool rowok = i < a.Cin && d >= 0 && d < a.D && hh >= 0 && hh < a.H;  // uniform
-    if (!rowok) return 0.f;
-    const float *row = xb_ + (((size_t)i * a.D + d) * a.H + hh) * a.Wd;
-    const float v = row[wok ? wl : 0];
-    return wok ? v : 0.f;
+    const int d = 2 * od - 1 + kd, hh = 2 * oh - 1 + kh;       // oh (hence hh) is per-lane in column tiles
+    if (!(i < a.Cin && d >= 0 && d < a.D)) return 0.f;          // uniform
+    const bool ok = wok && hh >= 0 && hh < a.H;
+    const float *plane = xb_ + ((size_t)i * a.D + d) * a.H * a.Wd;
+    const float v = plane[ok ? hh * a.Wd + wl : 0];
+    return ok ? v : 0.f;
 }
 
 // tiles are 32 consecutive output voxels WITHIN one output row (ow), so the strided reads of a
@@ -50,17 +78,12 @@ __global__ __launch_bounds__(256) void conv_k2s2_fwd_kernel(K2Args a) {
         const int k = 2 * ks + h;
         w[ks] = (ks < nks && c < a.Cout) ? a.W[(size_t)c * (a.Cin * 8) + k] : 0.f;
     }
-    const int wtiles = (a.Wo + 31) / 32;
-    const long long ntiles = (long long)a.B * a.Do * a.Ho * wtiles;
+    const long long ntiles = (long long)a.B * a.Do * a.tiles_per_slab;
     const size_t Vo = (size_t)a.Do * a.Ho * a.Wo;
     for (long long t = (long long)blockIdx.x * 4 + wave; t < ntiles; t += (long long)gridDim.x * 4) {
-        const int wt = (int)(t % wtiles);
-        long long rem = t / wtiles;
-        const int oh = (int)(rem % a.Ho);
-        rem /= a.Ho;
-        const int od = (int)(rem % a.Do), b = (int)(rem / a.Do);
-        const int ow = wt * 32 + c;
-        const bool live = ow < a.Wo;
+        const K2Tile tl = k2_tile(a, t, c);
+        const int b = tl.b, od = tl.od, oh = tl.oh, ow = tl.ow;
+        const bool live = tl.live;
         const int wl = 2 * ow - 1 + h;                       // input column of this lane (kw = lane half)
         const bool wok = live && wl >= 0 && wl < a.Wd;
         const float *xb_ = a.x + (size_t)b * a.Cin * a.D * a.H * a.Wd;
@@ -109,21 +132,16 @@ __global__ __launch_bounds__(256) void conv_k2s2_bwd_kernel(K2Args a) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NTK; ++n) dw[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int wtiles = (a.Wo + 31) / 32;
-    const long long ntiles = (long long)a.B * a.Do * a.Ho * wtiles;
+    const long long ntiles = (long long)a.B * a.Do * a.tiles_per_slab;
     const long long ngroups = (ntiles + 3) / 4;
     const size_t Vo = (size_t)a.Do * a.Ho * a.Wo;
     for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const long long t = grp * 4 + wave;
-        const bool tl = t < ntiles;
-        const int wt = tl ? (int)(t % wtiles) : 0;
-        long long rem = tl ? t / wtiles : 0;
-        const int oh = (int)(rem % a.Ho);
-        rem /= a.Ho;
-        const int od = (int)(rem % a.Do), b = (int)(rem / a.Do);
-        const int ow = wt * 32 + c;
-        const bool live = tl && ow < a.Wo;
-        const unsigned vo = (unsigned)(((size_t)od * a.Ho + oh) * a.Wo + (live ? ow : 0));
+        const bool tlv = t < ntiles;
+        const K2Tile tl = k2_tile(a, tlv ? t : 0, c);
+        const int b = tl.b, od = tl.od, oh = tl.oh, ow = tl.ow;
+        const bool live = tlv && tl.live;
+        const unsigned vo = live ? (unsigned)(((size_t)od * a.Ho + oh) * a.Wo + ow) : 0u;
         const int wl = 2 * ow - 1 + h;
         const bool wok = live && wl >= 0 && wl < a.Wd;
         const float *xb_ = a.x + (size_t)b * a.Cin * a.D * a.H * a.Wd;
@@ -198,6 +216,11 @@ static int k2_fill(K2Args &a, int B, int Cin, int Cout, int D, int H, int Wd, in
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.Wd = Wd;
     a.Do = D / 2 + 1; a.Ho = H / 2 + 1; a.Wo = Wd / 2 + 1;
     a.act = act;
+    const int rem = a.Wo % 32;
+    a.ncol = (rem >= 1 && rem <= 4 && a.Wo > 32) ? rem : 0;      // few leftover columns: column tiles
+    a.wtr = (a.Wo - a.ncol + 31) / 32;
+    a.ctiles = (a.Ho + 31) / 32;
+    a.tiles_per_slab = a.Ho * a.wtr + a.ncol * a.ctiles;
     return HNO_OK;
 }
 
@@ -208,9 +231,10 @@ extern "C" int hno_conv_k2s2_fwd(const float *x, const float *W, const float *bi
     int rc = k2_fill(a, B, Cin, Cout, D, H, Wd, act);
     if (rc) return rc;
     a.x = x; a.W = W; a.bias = bias; a.y = y;
-    const long long ntiles = (long long)B * a.Do * a.Ho * ((a.Wo + 31) / 32);
+    const long long ntiles = (long long)B * a.Do * a.tiles_per_slab;
     long long grid = (ntiles + 3) / 4;
-    if (grid > 4096) grid = 4096;
+    if (grid > 1024) grid = 1024;   // 4 workgroups per CU; measured: 1024 -> 67 us, 2048 -> 71, 4096 -> 79, 512 -> 101
+    if (debug_flags() >> 8) grid = debug_flags() >> 8;
     if (Cin <= 4)
         { ProfScope _ps(KID_CONV_K2S2_FWD, (hipStream_t)stream, 4.0 * B * ((double)Cin * D * H * Wd + (double)Cout * a.Do * a.Ho * a.Wo)); hipLaunchKernelGGL(conv_k2s2_fwd_kernel<16>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a); }
     else
@@ -229,9 +253,10 @@ extern "C" int hno_conv_k2s2_bwd(const float *gy, const float *y, const float *x
     int rc = k2_fill(a, B, Cin, Cout, D, H, Wd, act);
     if (rc) return rc;
     a.x = x; a.gy = gy; a.y_saved = y; a.dW = dW; a.dbias = dbias; a.partials = (float *)workspace;
-    const long long ntiles = (long long)B * a.Do * a.Ho * ((a.Wo + 31) / 32);
+    const long long ntiles = (long long)B * a.Do * a.tiles_per_slab;
     long long grid = (ntiles + 3) / 4;
     if (grid > 1024) grid = 1024;
+    if (debug_flags() >> 8) grid = debug_flags() >> 8;
     const int kch = Cin * 8 <= 32 ? 1 : 2;
     const size_t lds = sizeof(float) * 4 * (32 + kch * 32) * K2_LD;
     hipStream_t s = (hipStream_t)stream;

@@ -56,3 +56,20 @@ L.hno_set_debug(0)
 with pkg._lib.KernelProfile() as kp:
     for _ in range(20): L.hno_upsoftmax_bwd(P(gp), P(probs), P(g_lr), P(ws), 2, 4, 65, 65, 65, 128, 128, 128, 1, S())
 for k, v in kp.summary().items(): print(k, v)
+
+# conv_in
+xin = torch.randn(2, 4, 128, 128, 128, device=dev)
+Wk = torch.randn(24, 4, 2, 2, 2, device=dev) * 0.1; bk = torch.randn(24, device=dev) * 0.01
+yk = ops.ConvK2S2Fn.apply(xin, Wk, bk, ops.ACT_SELU)
+gyk = torch.randn_like(yk); dWk = torch.empty_like(Wk); dbk = torch.empty_like(bk)
+wsk = torch.empty(L.hno_pwconv_bwd_workspace_bytes(32, 24) // 4, device=dev)
+for grid in (1280, 1536, 2048, 3072):
+    L.hno_set_debug(grid << 8)
+    tf = graph_time(lambda: L.hno_conv_k2s2_fwd(P(xin), P(Wk), P(bk), P(yk), 2, 4, 24, 128, 128, 128, 1, S()), n=10)
+    print(f'conv_k2s2 grid {grid}: fwd {tf:.1f} us')
+for grid in (0, 768, 1024):
+    L.hno_set_debug(grid << 8)
+    tf = graph_time(lambda: L.hno_conv_k2s2_fwd(P(xin), P(Wk), P(bk), P(yk), 2, 4, 24, 128, 128, 128, 1, S()), n=10)
+    tb = graph_time(lambda: L.hno_conv_k2s2_bwd(P(gyk), P(yk), P(xin), P(Wk), None, P(dWk), P(dbk), P(wsk), 2, 4, 24, 128, 128, 128, 1, S()), n=10)
+    print(f'conv_k2s2 grid {grid or "default"}: fwd {tf:.1f} us, bwd (+reduce) {tb:.1f} us')
+L.hno_set_debug(0)
