@@ -73,3 +73,14 @@ for grid in (0, 768, 1024):
     tb = graph_time(lambda: L.hno_conv_k2s2_bwd(P(gyk), P(yk), P(xin), P(Wk), None, P(dWk), P(dbk), P(wsk), 2, 4, 24, 128, 128, 128, 1, S()), n=10)
     print(f'conv_k2s2 grid {grid or "default"}: fwd {tf:.1f} us, bwd (+reduce) {tb:.1f} us')
 L.hno_set_debug(0)
+
+# loss statistics
+from multimodal_3d_image_segmentation_amd.nets import custom_losses
+pr = torch.softmax(torch.randn(2, 4, 128, 128, 128, device=dev), 1)
+lb = torch.randint(0, 4, (2, 128, 128, 128), device=dev, dtype=torch.uint8)
+stats = torch.empty(32, device=dev, dtype=torch.float64); coef = torch.empty(2, 4, 4, device=dev); lossv = torch.empty((), device=dev)
+for cfg in (16, 128 << 8, 256 << 8, 512 << 8, 1024 << 8, 2048 << 8):
+    L.hno_set_debug(cfg)
+    t = graph_time(lambda: L.hno_loss_fwd(P(pr), P(lb), P(stats), P(coef), P(lossv), 2, 4, 128 ** 3, 0, 0.0, S()), n=10)
+    print(f'loss_fwd cfg {cfg if cfg == 16 else cfg >> 8}: {t:.1f} us (stats + finalize + memset)')
+L.hno_set_debug(0)
