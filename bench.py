@@ -71,7 +71,12 @@ def cpu_baseline(budget_s=40.0):
     t0 = time.time()
     step(x64, l64)
     t64 = time.time() - t0
-    n, steps = (128, 1) if 9.0 * t64 < budget_s else (64, max(1, int(budget_s / 4 / max(t64, 1e-3))))
+    # a 128^3 step costs ~9-12x a 64^3 one: aim at ~12 s of CPU work (at least one step), never above the budget
+    est128 = 10.0 * t64
+    if est128 < budget_s:
+        n, steps = 128, max(1, min(8, int(12.0 / max(est128, 1e-3))))
+    else:
+        n, steps = 64, max(1, int(budget_s / 4 / max(t64, 1e-3)))
     xs, ls = (make(128) if n == 128 else (x64, l64))
     t0 = time.time()
     for _ in range(steps):

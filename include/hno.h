@@ -111,7 +111,8 @@ int hno_specmix_layers_bwd(const float *g, const float *z0, const float *zs, con
  * NULL to skip) and WRITES dW (Cout, Ca+Cb) and dbias (Cout).
  * xa_act != HNO_ACT_NONE additionally multiplies gxa by act'(xa) where xa is itself the output of
  * that activation (fuses the SELU backward of PadInverse into this kernel: HNOXSBlock :267-275).
- * accumulate_gx != 0 adds the input gradients to the values already in gxa / gxb.
+ * accumulate_gx: bit 0 adds the input gradient to the values already in gxa, bit 1 likewise for gxb (3 = both):
+ * gradient accumulation for a tensor with several consumers is fused into the store.
  * Weight gradients are reduced through per-block slabs in `workspace`
  * (hno_pwconv_bwd_workspace_bytes) in a fixed order: no float atomics, reproducible bit for bit.
  */

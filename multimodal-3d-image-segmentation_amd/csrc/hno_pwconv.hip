@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64 * NW) void pwconv_bwd_fast_kernel(PwBwdArgs a) {
                             const float xo = X[(irow + 4 * h) * PWB_LD + c];
                             gv *= xo > 0.f ? xp : xo + xq;
                         }
-                        if (a.accum) gv += base[hoff4V + v];
+                        if (a.accum & (irow < CA ? 1 : 2)) gv += base[hoff4V + v];
                         base[hoff4V + v] = gv;
                     }
                 }
@@ -679,7 +679,7 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
                 c.gxa = sg.gx ? sg.gx + (size_t)i0 * V : nullptr;
                 c.s_gxa = (long long)sg.C * V;
                 c.gxb = nullptr; c.s_gxb = 0;
-                c.accum = (accumulate_gx || o0 > 0) ? 1 : 0;
+                c.accum = ((accumulate_gx & (sgi == 0 ? 1 : 2)) || o0 > 0) ? 1 : 0;
                 c.xa_act = (sgi == 0) ? xa_act : HNO_ACT_NONE;
                 c.dbias = (dbias && first_block) ? dbias : nullptr;   // kernel only needs non-null to compute it
                 const int ich = ci <= 32 ? 1 : 2;

@@ -129,9 +129,11 @@ class HNOXSBlock(nn.Module):
                 and self.conv_concat is not None and self.conv_concat.normalization is None
                 and (self.mapping_conv is None or self.mapping_conv.normalization is None))
 
-    def forward(self, x, skip=None):
+    def forward(self, x, skip=None, passthrough=False):
         """`skip` is the U-Net skip tensor the reference concatenates in HNOSegXS.forward (:161-162);
-        passing it separately lets the mapping conv read both tensors without a torch.cat."""
+        passing it separately lets the mapping conv read both tensors without a torch.cat.
+        passthrough=True additionally returns the block INPUT (an alias) for use as a later block's skip, which
+        routes that block's skip gradient through this block's backward (see ops.XSBlockFn)."""
         if x.ndim == 5 and self._fused_ok():
             # standard configuration: the whole block is one autograd node (ops.XSBlockFn)
             act = ops.act_id(self.activation)
@@ -139,8 +141,10 @@ class HNOXSBlock(nn.Module):
             assert mc is not None or skip is None
             cc = self.conv_concat.op
             return ops.XSBlockFn.apply(x, skip, mc.weight if mc is not None else None, mc.bias if mc is not None else None,
-                                       cc.weight, cc.bias, self.transform_crop.num_modes, act,
+                                       cc.weight, cc.bias, self.transform_crop.num_modes, act, passthrough,
                                        *[b.op.weight for b in self.conv_blocks])
+        if passthrough:   # unfused configurations: plain autograd accumulates the two gradients of x
+            return self.forward(x, skip), x
         if self.mapping_conv is not None:
             x = self.mapping_conv(x, skip)
         else:
@@ -236,7 +240,12 @@ class HNOSegXS(nn.Module):
         nb = len(self.num_transform_blocks)
         for i, layer in enumerate(self.layers):
             skip = enc[nb - 1 - i] if (self.use_unet_skip and i > nb // 2) else None
-            x = layer(x, skip)
+            # the output of block i - 1 (this block's input) is a later block's skip: take the alias from this block
+            feeds_skip = self.use_unet_skip and 0 <= i - 1 < nb // 2 and (nb - 1 - (i - 1)) > nb // 2
+            if feeds_skip and torch.is_grad_enabled():
+                x, enc[i - 1] = layer(x, skip, passthrough=True)
+            else:
+                x = layer(x, skip)
             if self.use_deep_supervision:
                 ds.append(x)
             if self.use_unet_skip and i < nb // 2:

@@ -132,16 +132,20 @@ def pwconv_bwd_raw(gy, y, xa, xb, W, act, has_bias, need_gxa=True, need_gxb=True
     B, Ca = xa.shape[:2]
     Cb = xb.shape[1] if xb is not None else 0
     Cout, V = W.shape[0], _flat_v(xa)
-    if accumulate_into is not None:      # (gxa, gxb) buffers that already hold a gradient: += fused into the store
+    acc_bits = 0
+    gxa = gxb = None
+    if accumulate_into is not None:      # (gxa, gxb) buffers that already hold a gradient (None: fresh): += fused into the store
         gxa, gxb = accumulate_into
-    else:
-        gxa = torch.empty_like(xa) if need_gxa else None
-        gxb = torch.empty_like(xb) if (xb is not None and need_gxb) else None
+        acc_bits = (1 if gxa is not None else 0) | (2 if gxb is not None else 0)
+    if gxa is None and need_gxa:
+        gxa = torch.empty_like(xa)
+    if gxb is None and xb is not None and need_gxb:
+        gxb = torch.empty_like(xb)
     dW = torch.empty_like(W)
     db = torch.empty(Cout, device=W.device, dtype=torch.float32) if has_bias else None
     ws = _wgrad_ws(Ca + Cb, Cout, xa.device)
     check(_lib.lib().hno_pwconv_bwd(ptr(gy), ptr(y), ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(gxa), ptr(gxb), ptr(dW),
-                                    ptr(db), ptr(ws), B, Cout, V, act, xa_act, int(accumulate_into is not None), stream_ptr()), 'hno_pwconv_bwd')
+                                    ptr(db), ptr(ws), B, Cout, V, act, xa_act, acc_bits, stream_ptr()), 'hno_pwconv_bwd')
     return gxa, gxb, dW, db
 
 
@@ -590,7 +594,11 @@ class XSBlockFn(torch.autograd.Function):
     of materialising both and adding them."""
 
     @staticmethod
-    def forward(ctx, x, skip, map_w, map_b, cat_w, cat_b, modes, act, *mix_ws):
+    def forward(ctx, x, skip, map_w, map_b, cat_w, cat_b, modes, act, passthrough, *mix_ws):
+        """passthrough: also return the block input `x` as a second output.  A later block that takes this
+        tensor as its U-Net skip then sends its gradient HERE instead of to a second consumer edge of `x`, and
+        the backward below folds it into the store of the concat-path gradient -- autograd's separate
+        accumulation kernel (3 x 158 MB of traffic per step in HNOSeg-XS) disappears."""
         x, skip, map_w, map_b, cat_w, cat_b = (_f32c(t) for t in (x, skip, map_w, map_b, cat_w, cat_b))
         mix_ws = [_f32c(w) for w in mix_ws]
         _need_gpu(x, skip, cat_w, *mix_ws)
@@ -604,26 +612,37 @@ class XSBlockFn(torch.autograd.Function):
         u = pad_idht3_raw(zs[-1], spatial, 1.0, None, act)
         out = pwconv_fwd_raw(u, xm, cat_w, cat_b, act)
         ctx.save_for_backward(x, skip, map_w, xm if has_map else None, z0, zs, u, cat_w, out, *mix_ws)
-        ctx.cfg = (has_map, modes, act, spatial, n3, map_b is not None, cat_b is not None)
+        ctx.cfg = (has_map, modes, act, spatial, n3, map_b is not None, cat_b is not None, bool(passthrough))
+        ctx.set_materialize_grads(False)
+        if passthrough:
+            return out, x.view_as(x)
         return out
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, g_out, g_pass=None):
         x, skip, map_w, xm, z0, zs, u, cat_w, out, *mix_ws = ctx.saved_tensors
-        has_map, modes, act, spatial, n3, map_has_b, cat_has_b = ctx.cfg
+        has_map, modes, act, spatial, n3, map_has_b, cat_has_b, passthrough = ctx.cfg
         if not has_map:
             xm = x
-        # conv_concat backward; the SELU backward of PadInverse (g_u * act'(u)) is applied in its epilogue
-        g_u, g_skipin, d_cat_w, d_cat_b = pwconv_bwd_raw(_f32c(g_out), out, u, xm, cat_w, act, cat_has_b, xa_act=act)
+        if g_out is None:
+            raise _lib.HnoError('XSBlockFn.backward: no gradient for the block output')
+        g_pass = _f32c(g_pass) if g_pass is not None else None
+        # conv_concat backward; the SELU backward of PadInverse (g_u * act'(u)) is applied in its epilogue.  Without
+        # a mapping conv the block input IS xm: the passthrough gradient is accumulated into the concat-path
+        # gradient by the same kernel (gxb += ...), in the buffer autograd handed us.
+        fuse_pass = g_pass is not None and not has_map
+        g_u, g_skipin, d_cat_w, d_cat_b = pwconv_bwd_raw(_f32c(g_out), out, u, xm, cat_w, act, cat_has_b, xa_act=act,
+                                                         accumulate_into=(None, g_pass) if fuse_pass else None)
         g_zl = dht3_crop_raw(g_u, modes, 1.0)                               # PadInverse^T
         g_z0, d_mix = specmix_bwd_raw(g_zl, z0, zs, mix_ws, 1, act)
         g_xm = pad_idht3_raw(g_z0, spatial, 1.0 / n3, g_skipin, ACT_NONE)    # TransformCrop^T + skip gradient
         d_mix = tuple(d_mix.unbind(0))
         if not has_map:
-            return (g_xm, None, None, None, d_cat_w, d_cat_b, None, None) + d_mix
+            return (g_xm, None, None, None, d_cat_w, d_cat_b, None, None, None) + d_mix
         g_x, g_skip, d_map_w, d_map_b = pwconv_bwd_raw(g_xm, xm, x, skip, map_w, act, map_has_b,
-                                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return (g_x, g_skip, d_map_w, d_map_b, d_cat_w, d_cat_b, None, None) + d_mix
+                                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                                       accumulate_into=(g_pass, None) if g_pass is not None else None)
+        return (g_x, g_skip, d_map_w, d_map_b, d_cat_w, d_cat_b, None, None, None) + d_mix
 
 
 class ConvK2S2Fn(torch.autograd.Function):
