@@ -85,17 +85,33 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__re
                                                               float *dst0, int n0, float *dst1, int cols, int ldd) {
     __shared__ float red[16][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    // 8 independent loads in flight per thread (the kernel is a pure latency chain: 512 slabs = 4 rounds, not 8)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
     if (col < n) {
         int b = grp;
-        for (; b + 48 < nblocks; b += 64) {
-            s0 += partials[(size_t)b * n + col];
-            s1 += partials[(size_t)(b + 16) * n + col];
-            s2 += partials[(size_t)(b + 32) * n + col];
-            s3 += partials[(size_t)(b + 48) * n + col];
+        const float *pp = partials + col;
+        for (; b + 112 < nblocks; b += 128) {
+            s0 += pp[(size_t)b * n];
+            s1 += pp[(size_t)(b + 16) * n];
+            s2 += pp[(size_t)(b + 32) * n];
+            s3 += pp[(size_t)(b + 48) * n];
+            s4 += pp[(size_t)(b + 64) * n];
+            s5 += pp[(size_t)(b + 80) * n];
+            s6 += pp[(size_t)(b + 96) * n];
+            s7 += pp[(size_t)(b + 112) * n];
         }
-        for (; b < nblocks; b += 16) s0 += partials[(size_t)b * n + col];
+        for (; b + 48 < nblocks; b += 64) {
+            s0 += pp[(size_t)b * n];
+            s1 += pp[(size_t)(b + 16) * n];
+            s2 += pp[(size_t)(b + 32) * n];
+            s3 += pp[(size_t)(b + 48) * n];
+        }
+        for (; b < nblocks; b += 16) s0 += pp[(size_t)b * n];
     }
+    s0 += s4;
+    s1 += s5;
+    s2 += s6;
+    s3 += s7;
     red[grp][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (grp == 0 && col < n) {
