@@ -985,6 +985,10 @@ __global__ __launch_bounds__(64) void dht_fwd_d_fast_kernel(const float *__restr
     const DhtPlan &p = a.p;
     const Axis &a0 = p.ax[0], &a2 = p.ax[2];
     const int lane = threadIdx.x;
+    const bool st = a.stamps && blockIdx.x == 3 && blockIdx.y == 5 && lane == 0;
+    if (st) { a.stamps[0] = clock64(); a.stamps[10] = wall_clock64(); }
+    if (a.stamps && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) a.stamps[11] = wall_clock64();
+    if (a.stamps && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && lane == 0) a.stamps[12] = wall_clock64();
     const int ct = blockIdx.x, bc = blockIdx.y;
     const int k1s = ct / a2.KT, kt2 = ct % a2.KT;
     const int N0 = a0.N;
@@ -1020,6 +1024,7 @@ __global__ __launch_bounds__(64) void dht_fwd_d_fast_kernel(const float *__restr
         ti[ks] = Yb[j2 * pstride + colI];
         bsv[ks] = ks < nks ? ts[(ks * 4 + q) * 16 + (lane & 15)] : 0.f;   // masked lanes: j = j2 = 0, so sr - tr = 0
     }
+    if (st) a.stamps[1] = clock64();
     f32x4 PR = {0.f, 0.f, 0.f, 0.f}, PI = PR, QR = PR, QI = PR;
 #pragma unroll
     for (int ks = 0; ks < KCS; ++ks) {
@@ -1031,7 +1036,10 @@ __global__ __launch_bounds__(64) void dht_fwd_d_fast_kernel(const float *__restr
         QR = mfma16(sr[ks] - tr[ks], bsv[ks], QR);
         QI = mfma16(si[ks] - ti[ks], bsv[ks], QI);
     }
+    if (st) { asm volatile("s_nop 0" :: "v"(PR[0]), "v"(QI[0])); a.stamps[2] = clock64(); }
     fwd_d_store(a, out, bc, k1s, kt2, 0, lane, PR, PI, QR, QI);
+    if (st) { a.stamps[3] = clock64(); a.stamps[13] = wall_clock64(); }
+    if (a.stamps && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && lane == 0) a.stamps[14] = wall_clock64();
 }
 
 // ---- inverse, axis D: spectrum block -> E[bc][n0][part][k1s][k2] --------------------------

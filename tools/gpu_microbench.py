@@ -126,3 +126,19 @@ if which in ('stamps_inv',):
             row = st[1 + it * 6: 7 + it * 6]
             if row[0] == 0: break
             print(f'  iter {it}:', ', '.join(f'{n}: {v - st[0]}' for n, v in zip(names, row)))
+
+if which in ('stamps_d',):
+    import ctypes
+    x = torch.randn(B, C, N, N, N, device=dev)
+    BC, NN, mm = 48, (65, 65, 65), (10, 14, 14)
+    ws = torch.empty(L.hno_dht3_workspace_bytes(BC, *NN, *mm) // 4, device=dev)
+    out = torch.empty(B, C, 20, 28, 28, device=dev)
+    P, S = pkg._lib.ptr, pkg._lib.stream_ptr
+    L.hno_dht3_crop(P(x), None, 0, P(out), P(ws), BC, *NN, *mm, 1.0, S())
+    L.hno_set_debug(64)
+    L.hno_dht3_crop(P(x), None, 0, P(out), P(ws), BC, *NN, *mm, 1.0, S())
+    L.hno_set_debug(0)
+    buf = (ctypes.c_longlong * 64)()
+    L.hno_debug_stamps(buf, 64)
+    st = list(buf)
+    print(f'D fwd kernel, block (3,5): loads issued->arrived {st[1]-st[0]} cycles, mfma {st[2]-st[1]}, store {st[3]-st[2]}; wall: this block {(st[13]-st[10])*10} ns; first block start -> last block end {(st[14]-st[11])*10} ns; last block start {(st[12]-st[11])*10} ns after first')

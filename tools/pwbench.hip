@@ -119,6 +119,83 @@ __global__ __launch_bounds__(64 * NW) void pw_vec(Args a) {
     }
 }
 
+// Blocked layout [B][C/8][V][8]: the 8 channels of a group are 32 contiguous bytes per voxel.  One wave tile = 64
+// voxels: per input group two dwordx4 loads per lane (2 KB contiguous per instruction pair), v_permlane32_swap turns
+// (channel pair of voxel l) registers into the two MFMA B operands (voxels 0..31 / 32..63); outputs are stored as
+// dwordx4 per lane = 4 channels of one voxel, 1 KB contiguous per store instruction.
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void swap32(float &a, float &b) {
+    // a = [a.lo | b.lo], b = [a.hi | b.hi]   (lo = lanes 0..31)
+    asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+template <int GIN, int GOUT, int NW>   // channel groups of 8: inputs (xa then xb), outputs
+__global__ __launch_bounds__(64 * NW) void pw_blocked(Args a) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, c = lane & 31;
+    constexpr int CIN = 8 * GIN, COUT = 8 * GOUT, NKI = CIN / 2, GA = GIN / 2;
+    const unsigned V = a.V;
+    float w[NKI];
+#pragma unroll
+    for (int ks = 0; ks < NKI; ++ks) w[ks] = c < COUT ? a.W[c * CIN + 2 * ks + h] : 0.f;
+    float bias_r[4 * GOUT];
+#pragma unroll
+    for (int j = 0; j < 4 * GOUT; ++j) bias_r[j] = a.bias[(j & 3) + 8 * (j >> 2) + 4 * h];
+    const unsigned tiles_per_b = (V + 63) / 64, ntiles = tiles_per_b * a.B;
+    for (unsigned t = blockIdx.x * NW + wave; t < ntiles; t += gridDim.x * NW) {
+        const unsigned b = t / tiles_per_b;
+        const unsigned v = (t - b * tiles_per_b) * 64 + lane;
+        const bool vin = v < V;
+        const unsigned vl = vin ? v : 0u;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc0[j] = acc1[j] = 0.f;
+        f4 lo[GIN], hi[GIN];
+#pragma unroll
+        for (int g = 0; g < GIN; ++g) {
+            const float *base = (g < GA ? a.xa + ((size_t)b * GA + g) * V * 8 : a.xb + ((size_t)b * GA + (g - GA)) * V * 8) + (size_t)vl * 8;
+            lo[g] = *reinterpret_cast<const f4 *>(base);
+            hi[g] = *reinterpret_cast<const f4 *>(base + 4);
+        }
+#pragma unroll
+        for (int g = 0; g < GIN; ++g) {
+            float r[8] = {lo[g].x, lo[g].y, lo[g].z, lo[g].w, hi[g].x, hi[g].y, hi[g].z, hi[g].w};
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float e = r[2 * p], o = r[2 * p + 1];     // channels 8g+2p, 8g+2p+1 of voxel `lane`
+                if (!(a.mode & 1)) {
+                    swap32(e, o);                          // e: voxels 0..31 (k = h), o: voxels 32..63
+                    acc0 = mfma32(w[4 * g + p], e, acc0);
+                    acc1 = mfma32(w[4 * g + p], o, acc1);
+                } else {
+                    acc0[p] += e * w[4 * g + p];
+                    acc1[p] += o * w[4 * g + p];
+                }
+            }
+        }
+        if (a.mode & 2) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sacc += acc0[j] + acc1[j];
+            if (sacc == 12345.678f) a.y[0] = sacc;
+        } else {
+            // acc register 4g'+i of lane (h, c): channel 8g' + 4h + i of voxel c (acc0) / 32 + c (acc1)
+            const unsigned vb = (t - b * tiles_per_b) * 64;
+#pragma unroll
+            for (int g = 0; g < GOUT; ++g) {
+                f4 o0, o1;
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) {
+                    o0[i2] = selu(acc0[4 * g + i2] + bias_r[4 * g + i2]);
+                    o1[i2] = selu(acc1[4 * g + i2] + bias_r[4 * g + i2]);
+                }
+                float *yb = a.y + (((size_t)b * GOUT + g) * V) * 8 + 4 * h;
+                if (vb + c < V) *reinterpret_cast<f4 *>(yb + (size_t)(vb + c) * 8) = o0;
+                if (vb + 32 + c < V) *reinterpret_cast<f4 *>(yb + (size_t)(vb + 32 + c) * 8) = o1;
+            }
+        }
+    }
+}
+
 template <typename K>
 float timeit(K kern, int grid, int threads, Args a, int reps = 20) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -174,11 +251,44 @@ int main(int argc, char **argv) {
         printf("%-28s vec%d nw%2d pf%d grid %4d: full %6.1f us (%5.0f GB/s)  no-mfma %6.1f  no-store %6.1f  loads-only %6.1f", name, VEC, NW, (int)PF, grid, t, mb / t * 1e3, t1, t2, t3); \
         check(name);                                                                                   \
     }
-    RUN("", 1, 4, false, 256) RUN("", 1, 8, false, 256) RUN("", 1, 12, false, 256) RUN("", 1, 16, false, 256)
-    RUN("", 1, 4, true, 256) RUN("", 1, 8, true, 256) RUN("", 1, 12, true, 256) RUN("", 1, 16, true, 256)
-    RUN("", 2, 4, false, 256) RUN("", 2, 8, false, 256) RUN("", 2, 12, false, 256)
-    RUN("", 2, 4, true, 256) RUN("", 2, 8, true, 256)
-    RUN("", 4, 4, false, 256) RUN("", 4, 8, false, 256)
-    RUN("", 1, 4, false, 512) RUN("", 1, 4, true, 512) RUN("", 2, 4, false, 512) RUN("", 2, 4, true, 512) RUN("", 4, 4, false, 512)
+    RUN("", 1, 8, false, 256) RUN("", 1, 4, false, 512)
+    {
+        // blocked-layout copies of the inputs
+        std::vector<float> bxa(n), bxb(n);
+        for (int b2 = 0; b2 < B; ++b2)
+            for (int ch = 0; ch < C; ++ch)
+                for (unsigned v = 0; v < V; ++v) {
+                    bxa[(((size_t)b2 * 3 + ch / 8) * V + v) * 8 + ch % 8] = hxa[((size_t)b2 * C + ch) * V + v];
+                    bxb[(((size_t)b2 * 3 + ch / 8) * V + v) * 8 + ch % 8] = hxb[((size_t)b2 * C + ch) * V + v];
+                }
+        hipMemcpy(xa, bxa.data(), n * 4, hipMemcpyHostToDevice); hipMemcpy(xb, bxb.data(), n * 4, hipMemcpyHostToDevice);
+        auto checkb = [&]() {
+            std::vector<float> hy(n);
+            hipMemcpy(hy.data(), y, n * 4, hipMemcpyDeviceToHost);
+            double maxe = 0;
+            for (int s2 = 0; s2 < 4000; ++s2) {
+                const unsigned b2 = s2 & 1, v = (s2 < 200) ? V - 1 - s2 : (unsigned)((size_t)s2 * 7919 % V);
+                for (int o = 0; o < 24; ++o) {
+                    double acc = hb[o];
+                    for (int i2 = 0; i2 < 48; ++i2) acc += (double)hW[o * 48 + i2] * (i2 < 24 ? hxa[((size_t)b2 * 24 + i2) * V + v] : hxb[((size_t)b2 * 24 + i2 - 24) * V + v]);
+                    const double ref = acc > 0 ? 1.0507009873554805 * acc : 1.7580993408473766 * expm1(acc);
+                    maxe = fmax(maxe, fabs(ref - hy[(((size_t)b2 * 3 + o / 8) * V + v) * 8 + o % 8]));
+                }
+            }
+            printf("  err %.1e\n", maxe);
+        };
+#define RUNB(NW, grid)                                                                                 \
+    {                                                                                                  \
+        auto kern = pw_blocked<6, 3, NW>;                                                              \
+        a.mode = 0; float t = timeit(kern, grid, 64 * NW, a);                                          \
+        a.mode = 1; float t1 = timeit(kern, grid, 64 * NW, a);                                         \
+        a.mode = 2; float t2 = timeit(kern, grid, 64 * NW, a);                                         \
+        a.mode = 3; float t3 = timeit(kern, grid, 64 * NW, a);                                         \
+        a.mode = 0; hipMemset(y, 0, n * 4); hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), 0, 0, a);  \
+        printf("blocked layout nw%2d grid %4d: full %6.1f us (%5.0f GB/s)  no-mfma %6.1f  no-store %6.1f  loads-only %6.1f", NW, grid, t, mb / t * 1e3, t1, t2, t3); \
+        checkb();                                                                                      \
+    }
+        RUNB(4, 256) RUNB(8, 256) RUNB(4, 512) RUNB(4, 1024) RUNB(8, 512) RUNB(4, 2048) RUNB(16, 256)
+    }
     return 0;
 }
