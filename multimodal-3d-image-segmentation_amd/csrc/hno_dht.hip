@@ -1348,7 +1348,7 @@ __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float 
                                                                     const float *__restrict__ addend,
                                                                     float *__restrict__ out, DhtArgs a) {
     extern __shared__ float lds[];
-    constexpr int NE = NFULL + 1, NI = 4;
+    constexpr int NE = NFULL + 1, NI = 4, NV4 = NFULL / 4;
     const DhtPlan &p = a.p;
     const Axis &a1 = p.ax[1], &a2 = p.ax[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1429,7 +1429,16 @@ __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float 
         if (HAS_ADD) {  // residual of THIS plane: consumed in the epilogue, after both MFMA stages
             const float *ad = addend + (size_t)plane * plane_elems;
 #pragma unroll
-            for (int j = 0; j < NE; ++j) {
+            // elements [0, 1024 NV4) as 16-byte vectors (4 tid + 1024 jv + 0..3), the rest as scalars (tid + 256 j)
+            for (int jv = 0; jv < NV4; ++jv) {
+                const f4u_t v = *reinterpret_cast<const f4u_t *>(ad + 4 * tid + 1024 * jv);
+                ra[HAS_ADD ? 4 * jv : 0] = v.x;
+                ra[HAS_ADD ? 4 * jv + 1 : 0] = v.y;
+                ra[HAS_ADD ? 4 * jv + 2 : 0] = v.z;
+                ra[HAS_ADD ? 4 * jv + 3 : 0] = v.w;
+            }
+#pragma unroll
+            for (int j = 4 * NV4; j < NE; ++j) {
                 const unsigned e = tid + 256u * j;
                 ra[HAS_ADD ? j : 0] = (j < NFULL || e < plane_elems) ? ad[e] : 0.f;
             }
@@ -1609,16 +1618,37 @@ __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float 
             const bool lin = a.act == HNO_ACT_NONE;
             float *op = out + (size_t)plane * plane_elems;
             float ov[NE];   // all LDS reads first (one wait), then the arithmetic and the stores
+            typedef float f4v __attribute__((ext_vector_type(4)));
 #pragma unroll
-            for (int j = 0; j < NE; ++j) ov[j] = O[tid + 256 * j];   // the O region is padded to 256 * NE floats
+            for (int jv = 0; jv < NV4; ++jv) {
+                const f4v t = *reinterpret_cast<const f4v *>(O + 4 * tid + 1024 * jv);
+                ov[4 * jv] = t.x;
+                ov[4 * jv + 1] = t.y;
+                ov[4 * jv + 2] = t.z;
+                ov[4 * jv + 3] = t.w;
+            }
+#pragma unroll
+            for (int j = 4 * NV4; j < NE; ++j) ov[j] = O[tid + 256 * j];   // the O region is padded to 256 * NE floats
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
                 float v = a.scale * ov[j];
                 if (HAS_ADD) v += ra[HAS_ADD ? j : 0];
-                v = (v > 0.f || lin) ? ap * v : aq * neg_expm1(v);
-                if (j < NFULL || tid + 256u * j < plane_elems) op[tid + 256 * j] = v;
+                ov[j] = (v > 0.f || lin) ? ap * v : aq * neg_expm1(v);
             }
+            // 16-byte stores issue 4x fewer vector-memory instructions (the address path, not HBM, was the limit)
+#pragma unroll
+            for (int jv = 0; jv < NV4; ++jv) {
+                f4u_t t;
+                t.x = ov[4 * jv];
+                t.y = ov[4 * jv + 1];
+                t.z = ov[4 * jv + 2];
+                t.w = ov[4 * jv + 3];
+                *reinterpret_cast<f4u_t *>(op + 4 * tid + 1024 * jv) = t;
+            }
+#pragma unroll
+            for (int j = 4 * NV4; j < NE; ++j)
+                if (j < NFULL || tid + 256u * j < plane_elems) op[tid + 256 * j] = ov[j];
         }
     }
     if (a.stamps && blockIdx.x == 0 && tid == 0) { a.stamps[61] = wall_clock64(); a.stamps[63] = clock64(); }

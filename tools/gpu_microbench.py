@@ -121,7 +121,7 @@ if which in ('stamps_inv',):
         st = list(buf)
         print(f'addend={addend is not None}: block 0 loop {(st[61] - st[60]) / 100:.2f} us, clock {(st[63] - st[62]) / max(1, st[61] - st[60]) * 100:.0f} MHz')
         print('  W detail (iter 1): reads done', st[40] - st[0], 'mfma done', st[41] - st[0], 'writes done', st[42] - st[0])
-        names = ['iter top', 'Er written, fetches issued', 'after sync (H starts)', 'after H', 'after W', 'after sync (epilogue starts)']
+        names = ['iter top', 'staged', 'after H', 'chunk0 GEMM done', 'chunk0 epilogue done', '-']
         for it in range(5):
             row = st[1 + it * 6: 7 + it * 6]
             if row[0] == 0: break
