@@ -151,7 +151,8 @@ def main():
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=side):
+                # thread_local: the RCCL watchdog thread polls events while we capture; it must not invalidate the capture
+                with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
                     static_loss = fwd_bwd()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
