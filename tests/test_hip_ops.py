@@ -386,11 +386,12 @@ from _inputs import MHA_CASES, MHASEG_MODEL  # noqa: E402
 def test_bmm_all_transposes(pkg):
     from multimodal_3d_image_segmentation_amd import ops
     torch.manual_seed(0)
-    for (M, N, K) in [(70, 33, 45), (64, 64, 16), (5, 130, 7)]:
+    # the last case is large enough for the 128 x 128 tile kernels (ragged in M, N and K)
+    for (M, N, K, lead) in [(70, 33, 45, (2, 3)), (64, 64, 16, (2, 3)), (5, 130, 7, (2, 3)), (390, 517, 37, (2, 8))]:
         for tA in (False, True):
             for tB in (False, True):
-                A = torch.randn((2, 3) + ((K, M) if tA else (M, K)), dtype=torch.float64, requires_grad=True)
-                B = torch.randn((2, 3) + ((N, K) if tB else (K, N)), dtype=torch.float64, requires_grad=True)
+                A = torch.randn(lead + ((K, M) if tA else (M, K)), dtype=torch.float64, requires_grad=True)
+                B = torch.randn(lead + ((N, K) if tB else (K, N)), dtype=torch.float64, requires_grad=True)
                 C = 0.7 * (A.transpose(-1, -2) if tA else A) @ (B.transpose(-1, -2) if tB else B)
                 cot = torch.randn_like(C)
                 gA, gB = torch.autograd.grad((C * cot).sum(), [A, B])
