@@ -22,6 +22,7 @@ struct C3Args {
     const float *x, *wt, *bias;
     float *y;
     int B, Cin, Cout;
+    int CinP;   // rows per tap of the re-laid weights: Cin rounded up to 16 (zero rows), so a K-step of 16 never straddles taps
     int Di, Hi, Wi, Do, Ho, Wo;
     int stride, pad, frac;  // frac = 1: fractionally strided gather
     int act;
@@ -30,7 +31,7 @@ struct C3Args {
 // weight re-layout: dst[(t * Cin_g + i) * Cout_g + o] where the GEMM's "input" / "output" channels may be
 // either axis of the stored tensor and the taps may be flipped
 __global__ __launch_bounds__(256) void c3_relayout_kernel(const float *__restrict__ w, float *__restrict__ dst, int C0, int C1,
-                                                         int out_is_axis0, int flip) {
+                                                         int out_is_axis0, int flip, int CiP) {
     // w stored [C0][C1][27]
     const int n = C0 * C1 * 27;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
@@ -38,71 +39,226 @@ __global__ __launch_bounds__(256) void c3_relayout_kernel(const float *__restric
         const int o = out_is_axis0 ? c0 : c1, i = out_is_axis0 ? c1 : c0;
         const int Co = out_is_axis0 ? C0 : C1, Ci = out_is_axis0 ? C1 : C0;
         const int tt = flip ? 26 - t : t;
-        dst[((size_t)tt * Ci + i) * Co + o] = w[idx];
+        (void)Ci;
+        dst[((size_t)tt * CiP + i) * Co + o] = w[idx];
     }
 }
 
+// Tiles are 32 CONSECUTIVE output voxels of the flattened (od, oh, ow) grid of one sample (not 32 voxels of one row:
+// the V-Net grids are 65, 33, 17, 9 and 5 wide, which left 32 %, 48 %, 47 %, 72 % and 84 % of a row tile empty).  A
+// wave owns NT such tiles: one weight operand load feeds NT MFMAs and the NT accumulator chains are independent.
+template <int NT>
 __global__ __launch_bounds__(256) void c3_gemm_kernel(C3Args a) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, c = lane & 31;
     const int o0 = blockIdx.y * 32;
-    const int wtiles = (a.Wo + 31) / 32;
-    const long long ntiles = (long long)a.B * a.Do * a.Ho * wtiles;
     const size_t Vi = (size_t)a.Di * a.Hi * a.Wi, Vo = (size_t)a.Do * a.Ho * a.Wo;
-    const int nks = (a.Cin + 1) / 2;
+    const int vt = (int)((Vo + 32 * NT - 1) / (32 * NT));          // wave tiles per sample
+    const long long ntiles = (long long)a.B * vt;
+    const int nkf = a.Cin / 2;                                      // full channel pairs
+    const int oc = o0 + c < a.Cout ? o0 + c : a.Cout - 1;           // clamped output channel of this lane's A row
+    const int HWo = a.Ho * a.Wo;
     for (long long t = (long long)blockIdx.x * 4 + wave; t < ntiles; t += (long long)gridDim.x * 4) {
-        const int wt_ = (int)(t % wtiles);
-        long long rem = t / wtiles;
-        const int oh = (int)(rem % a.Ho);
-        rem /= a.Ho;
-        const int od = (int)(rem % a.Do), b = (int)(rem / a.Do);
-        const int ow = wt_ * 32 + c;
-        const float *xb = a.x + (size_t)b * a.Cin * Vi;
-        f32x16c acc;
+        const int b = (int)(t / vt);
+        const int v0 = (int)(t - (long long)b * vt) * 32 * NT;
+        int od[NT], oh[NT], ow[NT];
+        bool vok[NT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int n = 0; n < NT; ++n) {
+            const int v = v0 + 32 * n + c;
+            vok[n] = v < (int)Vo;
+            const int vv = vok[n] ? v : 0;
+            od[n] = vv / HWo;
+            const int r = vv - od[n] * HWo;
+            oh[n] = r / a.Wo;
+            ow[n] = r - oh[n] * a.Wo;
+        }
+        const float *xb = a.x + (size_t)b * a.Cin * Vi;
+        f32x16c acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
         for (int tap = 0; tap < 27; ++tap) {
             const int td = tap / 9, th = (tap / 3) % 3, tw = tap % 3;
-            int zi, yi, xi;
-            bool rowok, colok;
-            if (!a.frac) {
-                zi = a.stride * od - a.pad + td;
-                yi = a.stride * oh - a.pad + th;
-                xi = a.stride * ow - a.pad + tw;
-                rowok = zi >= 0 && zi < a.Di && yi >= 0 && yi < a.Hi;
-                colok = ow < a.Wo && xi >= 0 && xi < a.Wi;
-            } else {
-                const int nz = od + a.pad - td, ny = oh + a.pad - th, nx = ow + a.pad - tw;
-                rowok = nz >= 0 && ny >= 0 && nz % a.stride == 0 && ny % a.stride == 0;
-                zi = nz / a.stride;
-                yi = ny / a.stride;
-                rowok = rowok && zi < a.Di && yi < a.Hi;
-                xi = nx / a.stride;
-                colok = ow < a.Wo && nx >= 0 && nx % a.stride == 0 && xi < a.Wi;
-            }
-            if (!rowok) continue;  // wave-uniform
-            const float *xrow = xb + ((size_t)zi * a.Hi + yi) * a.Wi;
-            const float *wtap = a.wt + (size_t)tap * a.Cin * a.Cout;
-            const int xoff = colok ? xi : 0;
-#pragma unroll 4
-            for (int ks = 0; ks < nks; ++ks) {
-                const int i = 2 * ks + h;
-                const bool iok = i < a.Cin;
-                const int ic = iok ? i : 0;
-                const float bv = xrow[(size_t)ic * Vi + xoff];
-                const float av = (iok && o0 + c < a.Cout) ? wtap[(size_t)ic * a.Cout + o0 + c] : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, (colok && iok) ? bv : 0.f, acc, 0, 0, 0);
-            }
-        }
-        if (ow < a.Wo) {
-            const size_t vo = ((size_t)od * a.Ho + oh) * a.Wo + ow;
+            int xoff[NT];
+            bool ok[NT];
+            bool any = false;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (o < a.Cout) a.y[((size_t)b * a.Cout + o) * Vo + vo] = act_apply(acc[r] + (a.bias ? a.bias[o] : 0.f), a.act);
+            for (int n = 0; n < NT; ++n) {
+                int zi, yi, xi;
+                if (!a.frac) {
+                    zi = a.stride * od[n] - a.pad + td;
+                    yi = a.stride * oh[n] - a.pad + th;
+                    xi = a.stride * ow[n] - a.pad + tw;
+                    ok[n] = vok[n] && zi >= 0 && zi < a.Di && yi >= 0 && yi < a.Hi && xi >= 0 && xi < a.Wi;
+                } else {
+                    const int nz = od[n] + a.pad - td, ny = oh[n] + a.pad - th, nx = ow[n] + a.pad - tw;
+                    zi = nz / a.stride;
+                    yi = ny / a.stride;
+                    xi = nx / a.stride;
+                    ok[n] = vok[n] && nz >= 0 && ny >= 0 && nx >= 0 && nz % a.stride == 0 && ny % a.stride == 0 &&
+                            nx % a.stride == 0 && zi < a.Di && yi < a.Hi && xi < a.Wi;
+                }
+                xoff[n] = ok[n] ? (zi * a.Hi + yi) * a.Wi + xi : 0;
+                any = any || ok[n];
+            }
+            if (!__any(any)) continue;   // wave-uniform: the whole tile reads padding for this tap
+            // branch-free inner loop: every load is unconditional (clamped indices), padding taps are zeroed by a
+            // select on the loaded value, rows o >= Cout of the A operand may hold anything (never stored)
+            const float *wl = a.wt + (size_t)tap * a.CinP * a.Cout + (size_t)h * a.Cout + oc;   // + 2 ks Cout
+            const float *xl = xb + (size_t)h * Vi;                                              // + 2 ks Vi + xoff
+#pragma unroll 4
+            for (int ks = 0; ks < nkf; ++ks) {
+                const float av = wl[(size_t)2 * ks * a.Cout];
+                float bv[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bv[n] = xl[(size_t)2 * ks * Vi + xoff[n]];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, ok[n] ? bv[n] : 0.f, acc[n], 0, 0, 0);
+            }
+            if (a.Cin & 1) {   // odd channel count: the last k-step has one channel (lane half 0)
+                const float av = h == 0 ? wl[(size_t)2 * nkf * a.Cout - (size_t)h * a.Cout] : 0.f;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const float bv = h == 0 ? xl[(size_t)2 * nkf * Vi + xoff[n]] : 0.f;
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, ok[n] ? bv : 0.f, acc[n], 0, 0, 0);
+                }
             }
         }
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+            if (vok[n]) {
+                const size_t vo = (size_t)v0 + 32 * n + c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (o < a.Cout) a.y[((size_t)b * a.Cout + o) * Vo + vo] = act_apply(acc[n][r] + (a.bias ? a.bias[o] : 0.f), a.act);
+                }
+            }
     }
+}
+
+// ---- LDS-tiled implicit GEMM (the fast path of hno_conv3d_k3) -------------------------------------------------
+// C[o][v] = sum_k A[k][o] * Bg[k][v],  k = tap * Cin + i,  A = re-laid weights [k][Cout],  Bg[k][v] = x[i][in(v, tap)].
+// Workgroup tile (32 WM WR) output channels x (32 WN WC) consecutive voxels of one sample, K-steps of 16 double
+// buffered in LDS; every thread stages a fixed voxel column (its gather coordinates are computed once) and the
+// operands are reused by all four waves -- the gather-GEMM above re-loads both operands from global memory for every
+// single MFMA and reaches 9 TFLOP/s.
+#define C3I_K 16
+template <int WR, int WC, int WM, int WN>
+__global__ __launch_bounds__(256) void c3_igemm_kernel(C3Args a) {
+    constexpr int BM = 32 * WM * WR, BN = 32 * WN * WC, LDA = BM + 4, LDB = BN + 4;
+    constexpr int NA = (BM * C3I_K + 255) / 256, NB = BN * C3I_K / 256, RSTEP = 256 / BN;   // BN in {128, 256}
+    __shared__ float As[2][C3I_K * LDA], Bs[2][C3I_K * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t Vi = (size_t)a.Di * a.Hi * a.Wi, Vo = (size_t)a.Do * a.Ho * a.Wo;
+    const int vt = (int)((Vo + BN - 1) / BN);
+    const int b = blockIdx.x / vt, v0 = (blockIdx.x - b * vt) * BN, o0 = blockIdx.y * BM;
+    const int K = 27 * a.CinP;
+    // this thread's voxel column and its output coordinates
+    const int col = tid % BN, row0 = tid / BN;
+    const int v = v0 + col;
+    const bool vok = v < (int)Vo;
+    const int vv = vok ? v : 0;
+    const int HWo = a.Ho * a.Wo;
+    const int od = vv / HWo, rr = vv - od * HWo, oh = rr / a.Wo, ow = rr - oh * a.Wo;
+    const float *xb = a.x + (size_t)b * a.Cin * Vi;
+    float ra[NA], rb[NB];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int e = tid + 256 * j;
+            const int kk = e / BM, m = e - kk * BM;   // BM is a power of two
+            const int o = o0 + m;
+            const bool ok = e < BM * C3I_K && o < a.Cout;
+            const float val = a.wt[ok ? (size_t)(k0 + kk) * a.Cout + o : 0];
+            ra[j] = ok ? val : 0.f;
+        }
+        // the whole K-step lies inside one tap (CinP % 16 == 0): tap is wave-uniform, the gather offset of this
+        // thread's voxel is computed once per K-step, rows differ only by the channel
+        const int tap = k0 / a.CinP, i0 = k0 - tap * a.CinP;
+        const int td = tap / 9, th = (tap - 9 * td) / 3, tw = tap - 9 * td - 3 * th;
+        int zi, yi, xi;
+        bool ok;
+        if (!a.frac) {
+            zi = a.stride * od - a.pad + td;
+            yi = a.stride * oh - a.pad + th;
+            xi = a.stride * ow - a.pad + tw;
+            ok = zi >= 0 && zi < a.Di && yi >= 0 && yi < a.Hi && xi >= 0 && xi < a.Wi;
+        } else {
+            const int nz = od + a.pad - td, ny = oh + a.pad - th, nx = ow + a.pad - tw;
+            zi = nz / a.stride;
+            yi = ny / a.stride;
+            xi = nx / a.stride;
+            ok = nz >= 0 && ny >= 0 && nx >= 0 && nz % a.stride == 0 && ny % a.stride == 0 && nx % a.stride == 0 &&
+                 zi < a.Di && yi < a.Hi && xi < a.Wi;
+        }
+        ok = ok && vok;
+        const float *xp = xb + (ok ? ((size_t)zi * a.Hi + yi) * a.Wi + xi : 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int i = i0 + row0 + RSTEP * j;
+            const bool oki = ok && i < a.Cin;
+            const float val = xp[oki ? (size_t)i * Vi : 0];
+            rb[j] = oki ? val : 0.f;
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int e = tid + 256 * j;
+            const int kk = e / BM, m = e - kk * BM;
+            if (e < BM * C3I_K) As[buf][kk * LDA + m] = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) Bs[buf][(row0 + RSTEP * j) * LDB + col] = rb[j];
+    };
+    const int wm = (wave / WC) * 32 * WM, wn = (wave % WC) * 32 * WN;
+    f32x16c acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += C3I_K, buf ^= 1) {
+        const bool more = k0 + C3I_K < K;
+        if (more) fetch(k0 + C3I_K);
+        const float *Ac = As[buf] + (lane >> 5) * LDA + wm + (lane & 31);
+        const float *Bc = Bs[buf] + (lane >> 5) * LDB + wn + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < C3I_K; kk += 2) {
+            float av[WM], bv[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) av[i] = Ac[kk * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bv[j] = Bc[kk * LDB + 32 * j];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) stage(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int vcol = v0 + wn + 32 * j + (lane & 31);
+            if (vcol < (int)Vo) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = o0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (o < a.Cout) a.y[((size_t)b * a.Cout + o) * Vo + vcol] = act_apply(acc[i][j][r] + (a.bias ? a.bias[o] : 0.f), a.act);
+                }
+            }
+        }
 }
 
 // ---- weight gradient: dW[o][i][t] = sum_v g[o][v] * x[i][in(v, t)]  (g on the "output" grid) ----------------
@@ -137,18 +293,19 @@ __global__ __launch_bounds__(256) void c3_wgrad_kernel(C3WArgs a) {
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n) dw[t][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int wtiles = (a.Wg + 31) / 32;
-    const long long ntiles = (long long)a.B * a.Dg * a.Hg * wtiles;
+    // tiles: 32 consecutive voxels of the flattened g-side grid of one sample (see c3_gemm_kernel)
+    const int vt = (int)((Vg + 31) / 32);
+    const long long ntiles = (long long)a.B * vt;
     const long long ngroups = (ntiles + 3) / 4;
+    const int HWg = a.Hg * a.Wg;
     for (long long grp = blockIdx.x; grp < ngroups; grp += a.nchunks) {
         const long long t = grp * 4 + wave;
-        const bool live = t < ntiles;
-        const int wt_ = live ? (int)(t % wtiles) : 0;
-        long long rem = live ? t / wtiles : 0;
-        const int gh = (int)(rem % a.Hg);
-        rem /= a.Hg;
-        const int gd = (int)(rem % a.Dg), b = (int)(rem / a.Dg);
-        const int gw = wt_ * 32 + c;
+        const bool tlive = t < ntiles;
+        const int b = tlive ? (int)(t / vt) : 0;
+        const int v = tlive ? (int)(t - (long long)b * vt) * 32 + c : 0;
+        const bool live = tlive && v < (int)Vg;
+        const int vv = live ? v : 0;
+        const int gd = vv / HWg, rr = vv - gd * HWg, gh = rr / a.Wg, gw = rr - gh * a.Wg;
         int zi, yi;
         bool rowok;
         if (!a.frac) {
@@ -162,12 +319,13 @@ __global__ __launch_bounds__(256) void c3_wgrad_kernel(C3WArgs a) {
             yi = ny / a.stride;
             rowok = rowok && zi < a.Dx && yi < a.Hx;
         }
-        rowok = rowok && live;
+        rowok = rowok && live;   // per lane
         // g tile and the three shifted x tiles (zeros where out of range)
+        const size_t goff = (size_t)vv;
         for (int r = h; r < 32; r += 2) {
             const int o = o0 + r;
             float gv = 0.f;
-            if (rowok && o < a.Cg && gw < a.Wg) gv = a.g[((size_t)b * a.Cg + o) * Vg + ((size_t)gd * a.Hg + gh) * a.Wg + gw];
+            if (rowok && o < a.Cg) gv = a.g[((size_t)b * a.Cg + o) * Vg + goff];
             G[r * C3W_LD + c] = gv;
         }
 #pragma unroll
@@ -176,16 +334,18 @@ __global__ __launch_bounds__(256) void c3_wgrad_kernel(C3WArgs a) {
             bool colok;
             if (!a.frac) {
                 xi = a.stride * gw - a.pad + tw;
-                colok = gw < a.Wg && xi >= 0 && xi < a.Wx;
+                colok = xi >= 0 && xi < a.Wx;
             } else {
                 const int nx = gw + a.pad - tw;
                 xi = nx / a.stride;
-                colok = gw < a.Wg && nx >= 0 && nx % a.stride == 0 && xi < a.Wx;
+                colok = nx >= 0 && nx % a.stride == 0 && xi < a.Wx;
             }
+            const bool ok = rowok && colok;
+            const size_t xoff = ok ? ((size_t)zi * a.Hx + yi) * a.Wx + xi : 0;
             for (int r = h; r < 32; r += 2) {
                 const int i = i0 + r;
                 float xv = 0.f;
-                if (rowok && colok && i < a.Cx) xv = a.x[((size_t)b * a.Cx + i) * Vx + ((size_t)zi * a.Hx + yi) * a.Wx + xi];
+                if (ok && i < a.Cx) xv = a.x[((size_t)b * a.Cx + i) * Vx + xoff];
                 X[(tw * 32 + r) * C3W_LD + c] = xv;
             }
         }
@@ -440,7 +600,7 @@ static int g1(size_t n) {
 using namespace hno;
 
 extern "C" size_t hno_conv3d_k3_workspace_bytes(int Cin, int Cout, int for_wgrad) {
-    const size_t relayout = sizeof(float) * 27 * (size_t)Cin * Cout;
+    const size_t relayout = sizeof(float) * 27 * (size_t)(Cin + 15) * (Cout + 15);   // either role may be padded to 16
     if (!for_wgrad) return relayout;
     const size_t tiles = (size_t)((Cin + 31) / 32) * ((Cout + 31) / 32);
     return sizeof(float) * tiles * 9 * 64 * (3 * 32 * 32);   // <= 64 chunks per (tile, td, th)
@@ -470,12 +630,35 @@ extern "C" int hno_conv3d_k3(const float *x, const float *W, const float *bias, 
     const int out_is_axis0 = (mode == 0 || mode == 3);
     const int flip = 0;  // the fractional gather already pairs tap t with offset (+pad - t): no flip in any mode
     ProfScope _ps(KID_CONV3D_GEMM, s);
-    hipLaunchKernelGGL(c3_relayout_kernel, dim3(g1((size_t)C0 * C1 * 27)), dim3(256), 0, s, W, wt, C0, C1, out_is_axis0, flip);
+    a.CinP = (a.Cin + 15) / 16 * 16;
+    if (a.CinP != a.Cin) HNO_CHECK_HIP(hipMemsetAsync(wt, 0, sizeof(float) * 27 * (size_t)a.CinP * a.Cout, s));   // zero pad rows
+    hipLaunchKernelGGL(c3_relayout_kernel, dim3(g1((size_t)C0 * C1 * 27)), dim3(256), 0, s, W, wt, C0, C1, out_is_axis0, flip, a.CinP);
     HNO_CHECK_LAUNCH();
-    const long long ntiles = (long long)B * Do * Ho * ((Wo + 31) / 32);
-    long long gx = (ntiles + 3) / 4;
-    if (gx > 8192) gx = 8192;
-    hipLaunchKernelGGL(c3_gemm_kernel, dim3((int)gx, (a.Cout + 31) / 32), dim3(256), 0, s, a);
+    const long long Vo = (long long)Do * Ho * Wo;
+    if (!(debug_flags() & 16)) {
+        // output-channel tile 32 (1 x 4 waves, 128 voxels) up to 32 channels, else 64 (2 x 2 waves, 128 voxels)
+        if (a.Cout <= 32) {
+            const dim3 g((unsigned)(B * ((Vo + 127) / 128)), (a.Cout + 31) / 32);
+            hipLaunchKernelGGL((c3_igemm_kernel<1, 4, 1, 1>), g, dim3(256), 0, s, a);
+        } else {
+            const dim3 g((unsigned)(B * ((Vo + 127) / 128)), (a.Cout + 63) / 64);
+            hipLaunchKernelGGL((c3_igemm_kernel<2, 2, 1, 2>), g, dim3(256), 0, s, a);
+        }
+        HNO_CHECK_LAUNCH();
+        return HNO_OK;
+    }
+    const int octiles = (a.Cout + 31) / 32;
+    // two voxel tiles per wave when that still leaves >= 2 waves per SIMD's worth of work, else one
+    const long long nt2 = (long long)B * ((Vo + 63) / 64);
+    if (nt2 * octiles >= 2048) {
+        long long gx = (nt2 + 3) / 4;
+        if (gx > 8192) gx = 8192;
+        hipLaunchKernelGGL(c3_gemm_kernel<2>, dim3((int)gx, octiles), dim3(256), 0, s, a);
+    } else {
+        long long gx = ((long long)B * ((Vo + 31) / 32) + 3) / 4;
+        if (gx > 8192) gx = 8192;
+        hipLaunchKernelGGL(c3_gemm_kernel<1>, dim3((int)gx, octiles), dim3(256), 0, s, a);
+    }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }
@@ -501,7 +684,7 @@ extern "C" int hno_conv3d_k3_wgrad(const float *g, const float *x, float *dW, vo
         a.g = x; a.x = g; a.Cg = Cin; a.Cx = Cout;
         a.Dg = Dx; a.Hg = Hx; a.Wg = Wx; a.Dx = Dg; a.Hx = Hg; a.Wx = Wg; a.frac = 0;
     }
-    const long long ntiles = (long long)B * a.Dg * a.Hg * ((a.Wg + 31) / 32);
+    const long long ntiles = (long long)B * (((long long)a.Dg * a.Hg * a.Wg + 31) / 32);
     long long nch = (ntiles + 3) / 4;
     if (nch > 64) nch = 64;
     a.nchunks = (int)nch;
