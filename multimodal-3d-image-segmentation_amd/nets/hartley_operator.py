@@ -8,6 +8,13 @@ from torch.nn import Module, Parameter, init
 from .. import ops
 
 
+def _add_at_origin(y, per_channel):
+    """y[b, o, 0, 0, 0] += per_channel[o] (differentiable in both arguments)."""
+    onehot = torch.zeros(y.shape[2:], device=y.device, dtype=y.dtype)
+    onehot[(0,) * onehot.ndim] = 1.0
+    return y + per_channel.reshape(1, -1, *([1] * (y.ndim - 2))) * onehot
+
+
 class HartleyOperator(Module):
     """Frequency-domain channel mixing through the Hartley transform.
 
@@ -83,17 +90,33 @@ class HartleyOperator(Module):
             modes = ops.clamp_modes(modes, spatial)
         else:
             assert all(s >= 2 * m for s, m in zip(spatial, modes))
-        if self.use_bias:
-            raise NotImplementedError('HartleyOperator(use_transform=True, use_bias=True) is not provided by the '
-                                      'HIP path yet (bias on the zero-padded spectrum)')
         n3 = float(np.prod(spatial))
+        bias = self.bias.reshape(-1) if self.use_bias else None
         z = ops.DhtCropFn.apply(inputs, modes, 1.0 / n3) if self.weights_type == 'shared' else None
         if self.weights_type == 'shared':
-            # selu(0) = 0, so SELU on the padded spectrum == SELU on the kept block
-            z = ops.PwConvFn.apply(z, None, self.weight, None, ops.ACT_SELU)
+            # selu(0) = 0, so SELU on the padded spectrum == SELU on the kept block (without bias)
+            z = ops.PwConvFn.apply(z, None, self.weight, bias, ops.ACT_SELU)
         else:
             from .spectral_individual import hartley_mix_individual
-            z = hartley_mix_individual(None, self.weight, act=ops.ACT_SELU, x_full=inputs, modes=modes)
+            if bias is None:
+                z = hartley_mix_individual(None, self.weight, act=ops.ACT_SELU, x_full=inputs, modes=modes)
+            else:
+                z = hartley_mix_individual(None, self.weight, act=ops.ACT_NONE, x_full=inputs, modes=modes)
+                z = torch.nn.functional.selu(z + self.bias)
+        delta = None
+        if bias is not None:
+            # The reference adds the bias to the ZERO-PADDED spectrum (hartley_operator.py:262-263), so after SELU the
+            # whole padded region holds the constant selu(b).  The (unscaled) inverse transform of a constant spectrum is
+            # a delta at the origin, N^3 * selu(b): subtract the constant on the kept block, add the delta afterwards.
+            cb = torch.nn.functional.selu(self.bias)                       # (1, Co, 1, 1, 1)
+            z = z - cb
+            delta = cb.reshape(-1) * n3
+        if delta is not None:   # rare switch: unfused tail so that the delta lands before the residual add / activation
+            y = ops.PadIdhtFn.apply(z, spatial, 1.0, ops.ACT_NONE)
+            y = _add_at_origin(y, delta)
+            if addend is not None:
+                y = ops.AddFn.apply(y, addend)
+            return ops.ActFn.apply(y, act) if act != ops.ACT_NONE else y
         if addend is None:
             return ops.PadIdhtFn.apply(z, spatial, 1.0, act)
         return ops.PadIdhtAddFn.apply(z, addend, spatial, 1.0, act)

@@ -25,8 +25,6 @@ def fourier_operator_forward(op, inputs, addend=None, act=ops.ACT_NONE):
         raise NotImplementedError('2-D (ndim=4) FourierOperator is not provided by the HIP path yet')
     if not op.use_transform:
         raise NotImplementedError('FourierOperator(use_transform=False) takes complex inputs; not provided by the HIP path')
-    if op.use_bias:
-        raise NotImplementedError('FourierOperator(use_bias=True) is not provided by the HIP path yet')
     spatial = tuple(inputs.shape[2:])
     modes = ops.clamp_modes(op.num_modes, spatial) if op.weights_type == 'shared' else tuple(op.num_modes)
     spec = ops.RfftCropFn.apply(inputs, modes)
@@ -35,4 +33,21 @@ def fourier_operator_forward(op, inputs, addend=None, act=ops.ACT_NONE):
     else:
         assert all(s >= 2 * m for s, m in zip(spatial, op.num_modes))
         spec = ops.PerModeFourierFn.apply(spec, op.weight_real, op.weight_imag)
-    return ops.IrfftPadFn.apply(spec, addend, spatial, act)
+    if not op.use_bias:
+        return ops.IrfftPadFn.apply(spec, addend, spatial, act)
+    # The reference adds the (real) bias to the padded half spectrum, i.e. at every (k0, k1) and k2 < m2
+    # (fourier_operator.py:206-207), before the unscaled irfftn.  A constant over (k0, k1) is a delta at
+    # (n0, n1) = (0, 0) times N0 N1; along the last axis the c2r transform of [b] * m2 is b * (1 + 2 sum_k cos).
+    N0, N1, N2 = spatial
+    m2 = modes[2]
+    n2 = torch.arange(N2, device=inputs.device, dtype=torch.float64)
+    k = torch.arange(1, m2, device=inputs.device, dtype=torch.float64)
+    line = (1.0 + 2.0 * torch.cos(2.0 * np.pi * k[:, None] * n2[None, :] / N2).sum(0)).float() * float(N0 * N1)   # (N2,)
+    y = ops.IrfftPadFn.apply(spec, None, spatial, ops.ACT_NONE)
+    term = op.bias.reshape(1, -1, 1) * line.reshape(1, 1, -1)                                   # (1, Co, N2)
+    mask = torch.zeros((N0, N1, 1), device=inputs.device, dtype=y.dtype)
+    mask[0, 0, 0] = 1.0
+    y = y + term[:, :, None, None, :] * mask
+    if addend is not None:
+        y = ops.AddFn.apply(y, addend)
+    return ops.ActFn.apply(y, act) if act != ops.ACT_NONE else y
