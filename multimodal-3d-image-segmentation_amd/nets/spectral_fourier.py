@@ -24,7 +24,21 @@ def fourier_operator_forward(op, inputs, addend=None, act=ops.ACT_NONE):
     if inputs.ndim != 5:
         raise NotImplementedError('2-D (ndim=4) FourierOperator is not provided by the HIP path yet')
     if not op.use_transform:
-        raise NotImplementedError('FourierOperator(use_transform=False) takes complex inputs; not provided by the HIP path')
+        # complex spectrum in, complex spectrum out (fourier_operator.py:97-105, 212-223): the mix runs on the real
+        # [re | im] channel layout of the kernels; the bias is real and added to the result
+        assert addend is None and act == ops.ACT_NONE
+        if not inputs.is_complex():
+            raise ValueError('FourierOperator(use_transform=False) expects a complex input')
+        spec = torch.cat([inputs.real, inputs.imag], dim=1).float().contiguous()
+        if op.weights_type == 'shared':
+            y = complex_mix_shared(spec, op.weight_real, op.weight_imag)
+        else:
+            y = ops.PerModeFourierFn.apply(spec, op.weight_real, op.weight_imag)
+        co = y.shape[1] // 2
+        yr, yi = y[:, :co], y[:, co:]
+        if op.use_bias:
+            yr = yr + op.bias
+        return torch.complex(yr.contiguous(), yi.contiguous())
     spatial = tuple(inputs.shape[2:])
     modes = ops.clamp_modes(op.num_modes, spatial) if op.weights_type == 'shared' else tuple(op.num_modes)
     spec = ops.RfftCropFn.apply(inputs, modes)

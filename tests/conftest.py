@@ -26,6 +26,7 @@ def golden():
 
 def rel_err(a, b):
     """max |a-b| / max |b| -- the 'relative to max' error used for all fp parity checks."""
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
+    a, b = np.asarray(a), np.asarray(b)
+    dt = np.complex128 if (np.iscomplexobj(a) or np.iscomplexobj(b)) else np.float64   # complex spectra: modulus of the difference
+    a, b = a.astype(dt), b.astype(dt)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))

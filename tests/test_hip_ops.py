@@ -353,7 +353,7 @@ def _op_cases():
 
 
 @pytest.mark.parametrize('name,wt,use_transform,use_bias,case',
-                         [c for c in _op_cases() if c[2] or c[0] == 'hartley'])   # not built: Fourier on complex inputs
+                         list(_op_cases()))
 def test_operator_modules_vs_golden(pkg, name, wt, use_transform, use_bias, case):
     """HartleyOperator / FourierOperator modules (shared and per-mode weights) against the reference (golden G3)."""
     from multimodal_3d_image_segmentation_amd.nets.hartley_operator import HartleyOperator
@@ -369,12 +369,19 @@ def test_operator_modules_vs_golden(pkg, name, wt, use_transform, use_bias, case
     op = op.cuda()
     if use_transform:
         x = T(formula_tensor((2, ci_) + sp, 50)).requires_grad_(True)
-    else:
+    elif name == 'hartley':
         x = T(formula_tensor((2, ci_) + tuple(2 * m for m in modes), 70 + case)).requires_grad_(True)
+    else:   # Fourier without transform: complex spectrum in, complex spectrum out
+        shp = (2, ci_, 2 * modes[0], 2 * modes[1], modes[2])
+        x = torch.complex(T(formula_tensor(shp, 70 + case)), T(formula_tensor(shp, 170 + case))).requires_grad_(True)
     y = op(x)
     assert rel_err(y.detach().cpu().numpy(), g[f'{key}_y']) < TOL
-    cot = T(formula_tensor(tuple(y.shape), 80 + case))
-    grads = torch.autograd.grad((y * cot).sum(), [x] + list(op.parameters()))
+    if y.is_complex():
+        cot = torch.complex(T(formula_tensor(tuple(y.shape), 80 + case)), T(formula_tensor(tuple(y.shape), 180 + case)))
+        grads = torch.autograd.grad((y * cot.conj()).real.sum(), [x] + list(op.parameters()))
+    else:
+        cot = T(formula_tensor(tuple(y.shape), 80 + case))
+        grads = torch.autograd.grad((y * cot).sum(), [x] + list(op.parameters()))
     assert rel_err(grads[0].cpu().numpy(), g[f'{key}_gx']) < TOL
     for (pn, _), gp in zip(op.named_parameters(), grads[1:]):
         assert rel_err(gp.cpu().numpy(), g[f'{key}_g_{pn}']) < TOL, pn
