@@ -53,6 +53,16 @@ int hno_dht3_crop(const float *x, const float *x_act_out, int act_grad, float *o
                   int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream);
 int hno_pad_idht3(const float *z, const float *addend, int act, float *out, void *workspace,
                   int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream);
+/* hno_dht3_full: out[bc, k] = scale * sum_n x[bc, n] * cas(phi(k, n)) for EVERY frequency, natural order,
+ *   any (even or odd) sizes with N0 <= 63; out has the shape of x.  Replaces dht.dhtn / dht2 / dht3
+ *   (nets/dht.py:16-66; scale = 1/(N0 N1 N2) forward, 1 for is_inverse=True); N0 = 1 transforms each
+ *   (N1, N2) plane (dht2).  The transform matrix is symmetric, so its backward is the same call.
+ *   Workspace: hno_dht3_workspace_bytes(BC, N0, N1, N2, N0/2, N1/2, N2/2).
+ * 2-D data: hno_dht3_crop / hno_pad_idht3 (and the rfft pair below) accept N0 = 1 with m0 = 0; the mode
+ *   block then is (1, 2m1, 2m2) -- TransformCrop / PadInverse with ndim = 4 (nets/hnosegxs.py:361-376, :437-452).
+ */
+int hno_dht3_full(const float *x, float *out, void *workspace, int BC, int N0, int N1, int N2, float scale,
+                  void *stream);
 
 /* ---------------------------------------------------- mode-truncated real FFT (FNO path)
  * Same kernels as the Hartley pair with a different spectrum convention.  `spec` is the kept half

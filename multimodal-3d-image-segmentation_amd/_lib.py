@@ -22,6 +22,7 @@ SIGNATURES = {
     'hno_last_error': (ctypes.c_char_p, []),
     'hno_dht3_workspace_bytes': (c_size_t, [c_int] * 7),
     'hno_dht3_crop': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_void_p]),
+    'hno_dht3_full': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_float, c_void_p]),
     'hno_pad_idht3': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_void_p]),
     'hno_rfft3_crop': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_int, c_void_p]),
     'hno_irfft3_pad': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_int, c_void_p]),

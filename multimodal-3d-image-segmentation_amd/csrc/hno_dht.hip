@@ -198,10 +198,16 @@ struct DhtArgs {
     //   2: weights (1, 2, 2, ...) along k2 (irfftn forward, and the backward of irfftn)
     int mode;
     int C;    // channels per batch element (Fourier layout only)
+    // axis keeps ALL N = 2m + 1 frequencies k = -m..m (block size 2m + 1: k >= 0 at position k, k < 0 at
+    // 2m + 1 + k).  Used for un-truncated transforms of odd sizes (hno_dht3_full) and for a degenerate
+    // first axis (N0 = 1, m0 = 0: the 2-D transforms).  full1 / full2 are Hartley-layout only.
+    int full0, full1, full2;
 };
 
 // signed frequency -> index in the [low | high] block, or -1 if not kept
-__device__ __forceinline__ int kept_pos(int k, int m) { return (k >= 0) ? (k < m ? k : -1) : (k >= -m ? k + 2 * m : -1); }
+__device__ __forceinline__ int kept_pos(int k, int m, int full = 0) {
+    return (k >= 0) ? (k < m + full ? k : -1) : (k >= -m ? k + 2 * m + full : -1);
+}
 
 // ---- forward, axes W and H, one (bc, n0) plane per workgroup iteration -------------------
 // MAXE > 0: the whole plane (<= 256 * MAXE elements) is fetched into registers with fully
@@ -585,14 +591,15 @@ __device__ __forceinline__ void fwd_d_store(const DhtArgs &a, float *__restrict_
     const DhtPlan &p = a.p;
     const int m0 = p.ax[0].m, m1 = p.ax[1].m, m2 = p.ax[2].m;
     const int q = lane >> 4;
-    float *ob = out + (size_t)bc * (2 * m0) * (2 * m1) * (2 * m2);
+    const int s0 = 2 * m0 + a.full0, s1 = 2 * m1 + a.full1, s2 = 2 * m2 + a.full2;
+    float *ob = out + (size_t)bc * s0 * s1 * s2;
     (void)ob;
     const int k0 = kt0 * 16 + (lane & 15);
     const int k1 = k1s - m1;
     if (k0 <= m0 && a.mode != 0) {
         // Fourier half spectrum: S[b][re|im][c][o0][o1][k2], k2 in [0, m2)
         const int b = bc / a.C, c = bc - b * a.C;
-        const size_t msz = (size_t)(2 * m0) * (2 * m1) * m2;
+        const size_t msz = (size_t)s0 * (2 * m1) * m2;
         float *sr = out + ((size_t)(b * 2 + 0) * a.C + c) * msz, *si = out + ((size_t)(b * 2 + 1) * a.C + c) * msz;
         const int o1 = kept_pos(k1, m1);
 #pragma unroll
@@ -603,7 +610,7 @@ __device__ __forceinline__ void fwd_d_store(const DhtArgs &a, float *__restrict_
 #pragma unroll
             for (int sgn = 0; sgn < 2; ++sgn) {
                 if (sgn == 1 && k0 == 0) continue;
-                const int o0 = kept_pos(sgn ? -k0 : k0, m0);
+                const int o0 = kept_pos(sgn ? -k0 : k0, m0, a.full0);
                 if (o0 < 0) continue;
                 const size_t idx = ((size_t)o0 * (2 * m1) + o1) * m2 + k2;
                 sr[idx] = w * (sgn ? PR[r] - QI[r] : PR[r] + QI[r]);
@@ -622,14 +629,14 @@ __device__ __forceinline__ void fwd_d_store(const DhtArgs &a, float *__restrict_
                 const float xr = sgn ? PR[r] - QI[r] : PR[r] + QI[r];
                 const float xi = sgn ? PI[r] + QR[r] : PI[r] - QR[r];
                 // H[k] = Re X[k] - Im X[k]
-                int o0 = kept_pos(kk0, m0), o1 = kept_pos(k1, m1);
-                if (k2 < m2 && o0 >= 0 && o1 >= 0)
-                    ob[((size_t)o0 * (2 * m1) + o1) * (2 * m2) + k2] = a.scale * (xr - xi);
+                int o0 = kept_pos(kk0, m0, a.full0), o1 = kept_pos(k1, m1, a.full1);
+                if (k2 < m2 + a.full2 && o0 >= 0 && o1 >= 0)
+                    ob[((size_t)o0 * s1 + o1) * s2 + k2] = a.scale * (xr - xi);
                 // H[-k] = Re X[k] + Im X[k]
-                o0 = kept_pos(-kk0, m0);
-                o1 = kept_pos(-k1, m1);
+                o0 = kept_pos(-kk0, m0, a.full0);
+                o1 = kept_pos(-k1, m1, a.full1);
                 if (k2 >= 1 && o0 >= 0 && o1 >= 0)
-                    ob[((size_t)o0 * (2 * m1) + o1) * (2 * m2) + (2 * m2 - k2)] = a.scale * (xr + xi);
+                    ob[((size_t)o0 * s1 + o1) * s2 + (s2 - k2)] = a.scale * (xr + xi);
             }
         }
     }
@@ -906,7 +913,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void dht_fwd_plane_wave_kernel(const f
 __global__ __launch_bounds__(64) void dht_fwd_d_kernel(const float *__restrict__ Y, float *__restrict__ out, DhtArgs a) {
     extern __shared__ float lds[];
     const DhtPlan &p = a.p;
-    const Axis &a0 = p.ax[0], &a1 = p.ax[1], &a2 = p.ax[2];
+    const Axis &a0 = p.ax[0], &a2 = p.ax[2];
     const int lane = threadIdx.x;
     const int ntab = a0.KT * (a0.KcP + a0.KsP) * 16;
     for (int i = lane; i < ntab; i += 64) lds[i] = p.tables[a0.cosF + i];
@@ -920,9 +927,6 @@ __global__ __launch_bounds__(64) void dht_fwd_d_kernel(const float *__restrict__
     const float *Yb = Y + (size_t)bc * N0 * pstride;
     const int colR = ct * 16 + (lane & 15), colI = p.CP + colR;
     const int q = lane >> 4;
-    const int m0 = a0.m, m1 = a1.m, m2 = a2.m;
-    float *ob = out + (size_t)bc * (2 * m0) * (2 * m1) * (2 * m2);
-    (void)ob;
     for (int kt0 = 0; kt0 < a0.KT; ++kt0) {
         f32x4 PR = {0.f, 0.f, 0.f, 0.f}, PI = PR, QR = PR, QI = PR;
         const float *bc_ = cosD + kt0 * a0.KcP * 16, *bs_ = sinD + kt0 * a0.KsP * 16;
@@ -1043,10 +1047,11 @@ __global__ __launch_bounds__(64) void dht_fwd_d_fast_kernel(const float *__restr
 }
 
 // ---- inverse, axis D: spectrum block -> E[bc][n0][part][k1s][k2] --------------------------
-__device__ __forceinline__ float zk_load(const float *__restrict__ zb, int k0, int k1, int k2, int m0, int m1, int m2) {
-    const int o0 = kept_pos(k0, m0), o1 = kept_pos(k1, m1), o2 = kept_pos(k2, m2);
+__device__ __forceinline__ float zk_load(const float *__restrict__ zb, int k0, int k1, int k2, int m0, int m1, int m2,
+                                         const DhtArgs &a) {
+    const int o0 = kept_pos(k0, m0, a.full0), o1 = kept_pos(k1, m1, a.full1), o2 = kept_pos(k2, m2, a.full2);
     const bool ok = (o0 >= 0) & (o1 >= 0) & (o2 >= 0);
-    const size_t idx = ok ? ((size_t)o0 * (2 * m1) + o1) * (2 * m2) + o2 : 0;
+    const size_t idx = ok ? ((size_t)o0 * (2 * m1 + a.full1) + o1) * (2 * m2 + a.full2) + o2 : 0;
     const float v = zb[idx];
     return ok ? v : 0.f;
 }
@@ -1083,7 +1088,7 @@ __global__ __launch_bounds__(64) void dht_inv_d_kernel(const float *__restrict__
     const int ct = blockIdx.x, bc = blockIdx.y;
     const int k1s = ct / a2.KT, kt2 = ct % a2.KT;
     const int m0 = a0.m, m1 = a1.m, m2 = a2.m, N0 = a0.N;
-    const float *zb = z + (size_t)bc * (2 * m0) * (2 * m1) * (2 * m2);
+    const float *zb = z + (size_t)bc * (2 * m0 + a.full0) * (2 * m1 + a.full1) * (2 * m2 + a.full2);
     const int q = lane >> 4;
     const int k1 = k1s - m1;
     const int k2 = kt2 * 16 + (lane & 15);  // A-operand row of this lane
@@ -1095,7 +1100,7 @@ __global__ __launch_bounds__(64) void dht_inv_d_kernel(const float *__restrict__
     float gsr[KSM], gsi[KSM], gdr[KSM], gdi[KSM];
     // Fourier layout: re / im planes of this (b, c)
     const int fb = a.mode ? bc / a.C : 0, fc = a.mode ? bc - fb * a.C : 0;
-    const size_t msz = (size_t)(2 * m0) * (2 * m1) * m2;
+    const size_t msz = (size_t)(2 * m0 + a.full0) * (2 * m1) * m2;
     const float *sr = z + ((size_t)(fb * 2 + 0) * a.C + fc) * msz, *si = z + ((size_t)(fb * 2 + 1) * a.C + fc) * msz;
 #pragma unroll
     for (int ks = 0; ks < KSM; ++ks) {
@@ -1107,7 +1112,7 @@ __global__ __launch_bounds__(64) void dht_inv_d_kernel(const float *__restrict__
             const int o1 = kept_pos(k1, m1);
             if (ks < KS && k0 <= m0 && k2 < m2 && o1 >= 0) {
                 const float w = (a.mode == 2 && k2 > 0) ? 2.f : 1.f;
-                const int op = kept_pos(k0, m0), om = k0 >= 1 ? kept_pos(-k0, m0) : -1;
+                const int op = kept_pos(k0, m0, a.full0), om = k0 >= 1 ? kept_pos(-k0, m0, a.full0) : -1;
                 const size_t ip = ((size_t)(op >= 0 ? op : 0) * (2 * m1) + o1) * m2 + k2;
                 const size_t im = ((size_t)(om >= 0 ? om : 0) * (2 * m1) + o1) * m2 + k2;
                 const float pr = op >= 0 ? w * sr[ip] : 0.f, pi = op >= 0 ? w * si[ip] : 0.f;
@@ -1118,14 +1123,14 @@ __global__ __launch_bounds__(64) void dht_inv_d_kernel(const float *__restrict__
                 gdi[ks] = k0 >= 1 ? pi - mi : 0.f;
             }
         } else if (ks < KS && k0 <= m0 && k2 <= m2) {
-            const float va = zk_load(zb, k0, k1, k2, m0, m1, m2);
-            const float vb = k2 >= 1 ? zk_load(zb, -k0, -k1, -k2, m0, m1, m2) : 0.f;
+            const float va = zk_load(zb, k0, k1, k2, m0, m1, m2, a);
+            const float vb = k2 >= 1 ? zk_load(zb, -k0, -k1, -k2, m0, m1, m2, a) : 0.f;
             // G'(+k0) = (va + vb) + i (vb - va)
             gsr[ks] = va + vb;
             gsi[ks] = vb - va;
             if (k0 >= 1) {
-                const float vc = zk_load(zb, -k0, k1, k2, m0, m1, m2);
-                const float vd = k2 >= 1 ? zk_load(zb, k0, -k1, -k2, m0, m1, m2) : 0.f;
+                const float vc = zk_load(zb, -k0, k1, k2, m0, m1, m2, a);
+                const float vd = k2 >= 1 ? zk_load(zb, k0, -k1, -k2, m0, m1, m2, a) : 0.f;
                 // G'(-k0) = (vc + vd) + i (vd - vc)
                 gdr[ks] = gsr[ks] - (vc + vd);
                 gdi[ks] = gsi[ks] - (vd - vc);
@@ -1654,11 +1659,21 @@ __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float 
     if (a.stamps && blockIdx.x == 0 && tid == 0) { a.stamps[61] = wall_clock64(); a.stamps[63] = clock64(); }
 }
 
-static int check_sizes(int BC, int N0, int N1, int N2, int m0, int m1, int m2) {
+// full: bit i set = axis i keeps all N_i = 2 m_i + 1 frequencies (see DhtArgs).  A degenerate first axis
+// (N0 = 1, m0 = 0: 2-D data) is always "full".
+static int check_sizes(int BC, int N0, int N1, int N2, int m0, int m1, int m2, int &full, int mode) {
     HNO_REQUIRE(BC > 0 && N0 > 0 && N1 > 0 && N2 > 0, "dht3: non-positive size");
     if (m0 > 31) return fail(HNO_ELIMIT, "dht3: m0 = %d modes along the first axis (max 31)", m0);
-    HNO_REQUIRE(m0 > 0 && m1 > 0 && m2 > 0, "dht3: modes must be positive");
-    HNO_REQUIRE(2 * m0 <= N0 && 2 * m1 <= N1 && 2 * m2 <= N2, "dht3: modes must be clamped to N // 2 by the caller");
+    if (N0 == 1 && m0 == 0) full |= 1;
+    HNO_REQUIRE((m0 > 0 || (full & 1)) && m1 > 0 && m2 > 0, "dht3: modes must be positive");
+    const int N[3] = {N0, N1, N2}, m[3] = {m0, m1, m2};
+    for (int i = 0; i < 3; ++i) {
+        if ((full >> i) & 1)
+            HNO_REQUIRE(2 * m[i] + 1 == N[i], "dht3: a full axis needs N = 2 m + 1");
+        else
+            HNO_REQUIRE(2 * m[i] <= N[i], "dht3: modes must be clamped to N // 2 by the caller");
+    }
+    HNO_REQUIRE(mode == 0 || !(full & 6), "dht3: full axes 1 / 2 exist in the Hartley layout only");
     if (BC > 65535) return fail(HNO_ELIMIT, "dht3: B*C = %d exceeds 65535", BC);
     return HNO_OK;
 }
@@ -1677,9 +1692,9 @@ extern "C" size_t hno_dht3_workspace_bytes(int BC, int N0, int N1, int N2, int m
 
 static int dht_forward_launch(const float *x, const float *x_act_out, int act_grad, float *out, void *workspace,
                               int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream,
-                              int mode, int C) {
+                              int mode, int C, int full = 0) {
     HNO_REQUIRE(x && out && workspace, "hno_dht3_crop: null pointer");
-    int rc = check_sizes(BC, N0, N1, N2, m0, m1, m2);
+    int rc = check_sizes(BC, N0, N1, N2, m0, m1, m2, full, mode);
     if (rc) return rc;
     const DhtPlan *plan;
     rc = get_plan(N0, N1, N2, m0, m1, m2, &plan);
@@ -1693,6 +1708,9 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
     a.stamps = (a.dbg & 64) ? debug_stamp_buffer() : nullptr;
     a.mode = mode;
     a.C = C > 0 ? C : 1;
+    a.full0 = full & 1;
+    a.full1 = (full >> 1) & 1;
+    a.full2 = (full >> 2) & 1;
     const size_t lds = sizeof(float) * plan->f_lds_floats;
     if (lds > kMaxLds) return fail(HNO_ELIMIT, "hno_dht3_crop: plane %dx%d needs %zu B of LDS (> 160 KiB)", N1, N2, lds);
     hipStream_t s = (hipStream_t)stream;
@@ -1780,9 +1798,9 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
 
 static int dht_inverse_launch(const float *z, const float *addend, int act, float *out, void *workspace,
                               int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream,
-                              int mode, int C) {
+                              int mode, int C, int full = 0) {
     HNO_REQUIRE(z && out && workspace, "hno_pad_idht3: null pointer");
-    int rc = check_sizes(BC, N0, N1, N2, m0, m1, m2);
+    int rc = check_sizes(BC, N0, N1, N2, m0, m1, m2, full, mode);
     if (rc) return rc;
     const DhtPlan *plan;
     rc = get_plan(N0, N1, N2, m0, m1, m2, &plan);
@@ -1796,6 +1814,9 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
     a.stamps = (a.dbg & 64) ? debug_stamp_buffer() : nullptr;
     a.mode = mode;
     a.C = C > 0 ? C : 1;
+    a.full0 = full & 1;
+    a.full1 = (full >> 1) & 1;
+    a.full2 = (full >> 2) & 1;
     const size_t lds = sizeof(float) * plan->i_lds_floats;
     if (lds > kMaxLds) return fail(HNO_ELIMIT, "hno_pad_idht3: plane %dx%d needs %zu B of LDS (> 160 KiB)", N1, N2, lds);
     hipStream_t s = (hipStream_t)stream;
@@ -1867,6 +1888,15 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
 extern "C" int hno_dht3_crop(const float *x, const float *x_act_out, int act_grad, float *out, void *workspace,
                              int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream) {
     return dht_forward_launch(x, x_act_out, act_grad, out, workspace, BC, N0, N1, N2, m0, m1, m2, scale, stream, 0, 1);
+}
+
+extern "C" int hno_dht3_full(const float *x, float *out, void *workspace, int BC, int N0, int N1, int N2, float scale,
+                             void *stream) {
+    // every frequency of every axis: m = N / 2 keeps all of an even axis (the Nyquist term sits at -m), an
+    // odd axis additionally keeps +m
+    const int full = (N0 & 1) | ((N1 & 1) << 1) | ((N2 & 1) << 2);
+    return dht_forward_launch(x, nullptr, HNO_ACT_NONE, out, workspace, BC, N0, N1, N2, N0 / 2, N1 / 2, N2 / 2, scale,
+                              stream, 0, 1, full);
 }
 
 extern "C" int hno_pad_idht3(const float *z, const float *addend, int act, float *out, void *workspace,

@@ -58,14 +58,27 @@ class HartleyOperator(Module):
 
     # -- forward -----------------------------------------------------------------------
     def forward(self, inputs):
-        if inputs.ndim != 5:
-            raise NotImplementedError('2-D (ndim=4) HartleyOperator is not provided by the HIP path yet')
+        if inputs.ndim == 4:
+            return self._lifted()(inputs.unsqueeze(2)).squeeze(2)
         if self.use_transform:
             return self._call3d(inputs)
         x = self._mix(inputs)
         if self.use_bias:
             x = x + self.bias
         return x
+
+    def _lifted(self):
+        """2-D operator (reference _call2d :108-166, _call2d_notransform :273-285) as the 3-D one on
+        (B, C, 1, H, W): a size-1 axis has the single frequency 0, its reversal is the identity and its
+        transform is a copy, so the 3-D kernels compute exactly the 2-D result."""
+        view = object.__new__(HartleyOperator)
+        Module.__init__(view)
+        view.in_channels, view.out_channels = self.in_channels, self.out_channels
+        view.use_bias, view.weights_type, view.use_transform = self.use_bias, self.weights_type, self.use_transform
+        view.num_modes = None if self.num_modes is None else (0,) + tuple(self.num_modes)
+        view.__dict__['weight'] = self.weight if self.weights_type == 'shared' else self.weight.unsqueeze(2)
+        view.__dict__['bias'] = None if self.bias is None else self.bias.unsqueeze(2)
+        return view
 
     def _mix(self, z):
         if self.weights_type == 'shared':
@@ -76,6 +89,9 @@ class HartleyOperator(Module):
     def forward_fused(self, inputs, addend=None, act=ops.ACT_NONE):
         """act(self(inputs) + addend) with the add and the activation fused into the inverse transform's
         store (the block pattern of nets/architectures.py:521-539)."""
+        if inputs.ndim == 4:
+            return self._lifted().forward_fused(inputs.unsqueeze(2), None if addend is None else addend.unsqueeze(2),
+                                                act).squeeze(2)
         if not self.use_transform or addend is None and act == ops.ACT_NONE:
             y = self(inputs)
             if addend is not None:

@@ -38,8 +38,10 @@ class TransformCrop(nn.Module):
         self.num_modes = _tuple_modes(num_modes, ndim)
 
     def forward(self, x):
-        if x.ndim != 5:
-            raise NotImplementedError('2-D TransformCrop is not provided by the HIP path yet')
+        if x.ndim == 4:   # 2-D (reference _call2d :355-376): a degenerate leading axis through the same kernels
+            spatial = tuple(x.shape[2:])
+            modes = (0,) + ops.clamp_modes(self.num_modes, spatial)
+            return ops.DhtCropFn.apply(x.unsqueeze(2), modes, 1.0 / float(np.prod(spatial))).squeeze(2)
         spatial = tuple(x.shape[2:])
         modes = ops.clamp_modes(self.num_modes, spatial)
         return ops.DhtCropFn.apply(x, modes, 1.0 / float(np.prod(spatial)))
@@ -54,8 +56,9 @@ class PadInverse(nn.Module):
         assert ndim in (4, 5)
 
     def forward(self, x, spatial_shape, act=ops.ACT_NONE):
-        if x.ndim != 5:
-            raise NotImplementedError('2-D PadInverse is not provided by the HIP path yet')
+        if x.ndim == 4:   # 2-D (reference _call2d :437-452)
+            assert all(s >= 2 * (zs // 2) for s, zs in zip(spatial_shape, x.shape[2:]))
+            return ops.PadIdhtFn.apply(x.unsqueeze(2), (1,) + tuple(spatial_shape), 1.0, act).squeeze(2)
         assert all(s >= 2 * (zs // 2) for s, zs in zip(spatial_shape, x.shape[2:]))
         return ops.PadIdhtFn.apply(x, tuple(spatial_shape), 1.0, act)
 

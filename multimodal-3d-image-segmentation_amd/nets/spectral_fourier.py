@@ -21,8 +21,17 @@ def complex_mix_shared(spec, weight_real, weight_imag):
 
 
 def fourier_operator_forward(op, inputs, addend=None, act=ops.ACT_NONE):
-    if inputs.ndim != 5:
-        raise NotImplementedError('2-D (ndim=4) FourierOperator is not provided by the HIP path yet')
+    if inputs.ndim == 4:
+        # 2-D (reference _call2d :117-160): the same kernels on (B, C, 1, H, W) -- the transform of a size-1 axis is a copy
+        from types import SimpleNamespace
+        ind = op.weights_type != 'shared'
+        view = SimpleNamespace(use_transform=op.use_transform, weights_type=op.weights_type, use_bias=op.use_bias,
+                               num_modes=None if op.num_modes is None else (0,) + tuple(op.num_modes),
+                               weight_real=op.weight_real.unsqueeze(2) if ind else op.weight_real,
+                               weight_imag=op.weight_imag.unsqueeze(2) if ind else op.weight_imag,
+                               bias=None if op.bias is None else op.bias.unsqueeze(2))
+        y = fourier_operator_forward(view, inputs.unsqueeze(2), None if addend is None else addend.unsqueeze(2), act)
+        return y.squeeze(2)
     if not op.use_transform:
         # complex spectrum in, complex spectrum out (fourier_operator.py:97-105, 212-223): the mix runs on the real
         # [re | im] channel layout of the kernels; the bias is real and added to the result

@@ -20,22 +20,29 @@ def hartley_mix_individual(z, weight, act=ops.ACT_NONE, full_spatial=None, x_ful
         y = ops.PerModeHartleyFn.apply(z, _reverse_cropped(z).contiguous(), weight)
     else:
         spatial = tuple(x_full.shape[2:])
+        # 2m + 1 == N on some axis: +m is only available from the un-truncated transform
+        use_full = any(n > 1 and 2 * m + 1 == n for n, m in zip(spatial, modes))
         big, idx_k, idx_r = [], [], []
         for n, m in zip(spatial, modes):
-            if 2 * (m + 1) <= n:
-                mb = m + 1
-            elif 2 * m == n:
-                mb = m
-            else:
-                raise NotImplementedError('individual Hartley weights with 2m + 1 == N need the un-truncated transform, '
-                                          'which the HIP path does not provide')
+            if n == 1:                                                   # degenerate axis of 2-D data
+                big.append(0)
+                idx_k.append(torch.zeros(1, dtype=torch.long, device=x_full.device))
+                idx_r.append(idx_k[-1])
+                continue
+            mb = m + 1 if 2 * (m + 1) <= n else m
             big.append(mb)
             ks = list(range(m)) + list(range(-m, 0))                     # kept signed frequencies, [low | high]
-            pos = lambda k, mb=mb, n=n: (k if k >= 0 else k + 2 * mb) if 2 * mb < n else (k % n)   # noqa: E731
+            if use_full or 2 * mb == n:
+                pos = lambda k, n=n: k % n                               # noqa: E731  natural order
+            else:
+                pos = lambda k, mb=mb: k if k >= 0 else k + 2 * mb       # noqa: E731  [low | high] block of mb modes
             idx_k.append(torch.tensor([pos(k) for k in ks], device=x_full.device))
             idx_r.append(torch.tensor([pos(-k) for k in ks], device=x_full.device))
         import numpy as np
-        zb = ops.DhtCropFn.apply(x_full, tuple(big), 1.0 / float(np.prod(spatial)))
+        if use_full:
+            zb = ops.DhtFullFn.apply(x_full, 1.0 / float(np.prod(spatial)))
+        else:
+            zb = ops.DhtCropFn.apply(x_full, tuple(big), 1.0 / float(np.prod(spatial)))
         zk, zr = zb, zb
         for ax in range(3):
             zk = zk.index_select(2 + ax, idx_k[ax])

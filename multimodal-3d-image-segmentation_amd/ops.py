@@ -45,6 +45,12 @@ def clamp_modes(modes, spatial):
 
 
 # ------------------------------------------------------------------------- raw launchers
+def _block0(N0, m0):
+    """size of the kept block along the first axis: a degenerate axis (N0 = 1, m0 = 0; 2-D data viewed as
+    (B, C, 1, H, W)) keeps its single frequency."""
+    return 1 if (N0 == 1 and m0 == 0) else 2 * m0
+
+
 def dht3_crop_raw(x, modes, scale, act_out=None, act=ACT_NONE):
     """x: (B,C,N0,N1,N2) -> (B,C,2m0,2m1,2m2); modes already clamped."""
     _need_gpu(x, act_out)
@@ -52,9 +58,22 @@ def dht3_crop_raw(x, modes, scale, act_out=None, act=ACT_NONE):
     m0, m1, m2 = modes
     L = _lib.lib()
     ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, N0, N1, N2, m0, m1, m2) // 4, device=x.device, dtype=torch.float32)
-    out = torch.empty((B, C, 2 * m0, 2 * m1, 2 * m2), device=x.device, dtype=torch.float32)
+    out = torch.empty((B, C, _block0(N0, m0), 2 * m1, 2 * m2), device=x.device, dtype=torch.float32)
     check(L.hno_dht3_crop(ptr(x), ptr(act_out), act if act_out is not None else ACT_NONE, ptr(out), ptr(ws),
                           B * C, N0, N1, N2, m0, m1, m2, float(scale), stream_ptr()), 'hno_dht3_crop')
+    return out
+
+
+def dht3_full_raw(x, scale):
+    """x: (B,C,N0,N1,N2) -> every frequency of the 3-D Hartley transform in natural order, any sizes
+    (N0 = 1 gives the 2-D transform of each (N1, N2) plane)."""
+    _need_gpu(x)
+    B, C, N0, N1, N2 = x.shape
+    L = _lib.lib()
+    ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, N0, N1, N2, N0 // 2, N1 // 2, N2 // 2) // 4, device=x.device,
+                     dtype=torch.float32)
+    out = torch.empty_like(x)
+    check(L.hno_dht3_full(ptr(x), ptr(out), ptr(ws), B * C, N0, N1, N2, float(scale), stream_ptr()), 'hno_dht3_full')
     return out
 
 
@@ -79,7 +98,7 @@ def rfft3_crop_raw(x, modes, scale, k2_weights=False, act_out=None, act=ACT_NONE
     m0, m1, m2 = modes
     L = _lib.lib()
     ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, N0, N1, N2, m0, m1, m2) // 4, device=x.device, dtype=torch.float32)
-    out = torch.empty((B, 2 * C, 2 * m0, 2 * m1, m2), device=x.device, dtype=torch.float32)
+    out = torch.empty((B, 2 * C, _block0(N0, m0), 2 * m1, m2), device=x.device, dtype=torch.float32)
     check(L.hno_rfft3_crop(ptr(x), ptr(act_out), act if act_out is not None else ACT_NONE, ptr(out), ptr(ws), B, C,
                            N0, N1, N2, m0, m1, m2, float(scale), int(k2_weights), stream_ptr()), 'hno_rfft3_crop')
     return out
@@ -184,6 +203,19 @@ def specmix_bwd_raw(g, z0, zs, W, residual, act):
 
 
 # ----------------------------------------------------------------------------- autograd
+class DhtFullFn(torch.autograd.Function):
+    """Un-truncated dhtn (nets/dht.py:16-49).  The Hartley matrix is symmetric, so backward is the same transform."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return dht3_full_raw(_f32c(x), scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        return dht3_full_raw(_f32c(g), ctx.scale), None
+
+
 class DhtCropFn(torch.autograd.Function):
     """TransformCrop (nets/hnosegxs.py:378-410).  backward = PadInverse * scale."""
 

@@ -40,6 +40,15 @@ CROP_CASES = [
 ]
 
 
+# 2-D (ndim = 4) cases: (B, C, (H, W), modes)
+CROP_CASES_2D = [
+    (2, 3, (15, 11), (4, 2)),
+    (1, 2, (33, 65), (14, 14)),
+    (2, 1, (9, 8), (10, 14)),              # clamped
+    (1, 3, (16, 20), (8, 10)),             # 2m == N
+]
+
+
 def formula_volume(shape, tag=0, noise=0.25, dtype=np.float32):
     """Smooth multi-channel volume (B,C,D,H,W): a few low-frequency waves per channel plus broadband
     texture -- like z-scored MR volumes, most of the energy sits in the low modes the operators keep."""

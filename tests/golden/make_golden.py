@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate golden fixtures by importing the REFERENCE (build container only).
 
-    python tests/golden/make_golden.py [/root/reference]
+    python tests/golden/make_golden.py [/root/reference [fixture function names...]]
 
 The reference tree never travels to the GPU box; only the .npz files written here do.
 Inputs come from the closed-form generators in _inputs.py, so fixtures hold weights and
@@ -226,6 +226,62 @@ def g6s_small_models():
     save('g6s_small_models.npz', **out)
 
 
+# ------------------------------------------ G10: 2-D (ndim = 4) crop / pad and operators
+def g10_two_d():
+    from _inputs import CROP_CASES_2D
+    out = {}
+    for ci, (b, c, sp, modes) in enumerate(CROP_CASES_2D):
+        tc = hnosegxs.TransformCrop(modes, 4)
+        pi = hnosegxs.PadInverse(4)
+        x = T(formula_tensor((b, c) + sp, 210 + ci)).requires_grad_(True)
+        z = tc(x)
+        (gx,) = grads_of(z, T(formula_tensor(tuple(z.shape), 220 + ci)), [x])
+        zin = T(formula_tensor(tuple(z.shape), 230 + ci)).requires_grad_(True)
+        y = pi(zin, sp)
+        (gz,) = grads_of(y, T(formula_tensor(tuple(y.shape), 240 + ci)), [zin])
+        k = f'c{ci}'
+        out[f'{k}_crop'], out[f'{k}_crop_gradx'] = z.detach().numpy(), gx
+        out[f'{k}_pad'], out[f'{k}_pad_gradz'] = y.detach().numpy(), gz
+    ci_, co_, sp, modes = 3, 4, (12, 15), (3, 4)
+    x_np = formula_tensor((2, ci_) + sp, 250)
+    case = 0
+    for cls, name in ((HartleyOperator, 'hartley'), (FourierOperator, 'fourier')):
+        for wt in ('shared', 'individual'):
+            for use_transform in (True, False):
+                for use_bias in (False, True):
+                    torch.manual_seed(300 + case)
+                    op = cls(ci_, co_, modes, use_bias=use_bias, weights_type=wt, use_transform=use_transform, ndim=4)
+                    if use_bias:
+                        with torch.no_grad():
+                            op.bias.copy_(T(formula_tensor(tuple(op.bias.shape), 260 + case)) * 0.1)
+                    key = f'{name}_{wt}_t{int(use_transform)}_b{int(use_bias)}'
+                    if use_transform:
+                        x = T(x_np).requires_grad_(True)
+                    elif name == 'hartley':
+                        x = T(formula_tensor((2, ci_) + tuple(2 * m for m in modes), 270 + case)).requires_grad_(True)
+                    else:
+                        shp = (2, ci_, 2 * modes[0], modes[1])
+                        x = torch.complex(T(formula_tensor(shp, 270 + case)), T(formula_tensor(shp, 370 + case)))
+                        x = x.requires_grad_(True)
+                    y = op(x)
+                    params = dict(op.named_parameters())
+                    if y.is_complex():
+                        cot = torch.complex(T(formula_tensor(tuple(y.shape), 280 + case)),
+                                            T(formula_tensor(tuple(y.shape), 380 + case)))
+                        loss = (y * cot.conj()).real.sum()
+                        gs = [g.detach().numpy() for g in torch.autograd.grad(loss, [x] + list(params.values()))]
+                    else:
+                        gs = grads_of(y, T(formula_tensor(tuple(y.shape), 280 + case)), [x] + list(params.values()))
+                    out[f'{key}_case'] = np.array(case)
+                    out[f'{key}_y'] = y.detach().numpy()
+                    out[f'{key}_gx'] = gs[0]
+                    for (pn, p_), g in zip(params.items(), gs[1:]):
+                        out[f'{key}_p_{pn}'] = p_.detach().numpy()
+                        out[f'{key}_g_{pn}'] = g
+                    case += 1
+    save('g10_two_d.npz', **out)
+
+
 # ------------------------------------------- G9: labels, padcrop, SNN init statistics
 def g9_misc():
     sys.modules.setdefault('SimpleITK', type(sys)('SimpleITK'))
@@ -386,14 +442,9 @@ def g8_training():
 
 
 if __name__ == '__main__':
-    g1_dht()
-    g2_crop_pad()
-    g3_operators()
-    g4_mha()
-    g5_losses()
-    g6_hnosegxs()
-    g6s_small_models()
-    g7_noseg_models()
-    g7v_vnet_models()
-    g9_misc()
-    g8_training()
+    ALL = [g1_dht, g2_crop_pad, g3_operators, g4_mha, g5_losses, g6_hnosegxs, g6s_small_models, g7_noseg_models,
+           g7v_vnet_models, g9_misc, g10_two_d, g8_training]
+    only = set(sys.argv[2:])   # e.g. `make_golden.py /root/reference g10_two_d` regenerates one fixture
+    for fn in ALL:
+        if not only or fn.__name__ in only:
+            fn()
