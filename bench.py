@@ -117,7 +117,7 @@ def main():
     torch.manual_seed(0)
     model = pkg.nets.HNOSegXS(**MODEL_CFG).to(dev)
     rep = FlatGradReplica(model)
-    opt = torch.optim.Adamax(model.parameters(), lr=5e-3)
+    opt = pkg.optim.Adamax(model.parameters(), lr=5e-3)   # one-launch multi-tensor Adamax (hno_adamax_multi)
     loss_fn = custom_losses.PCCLoss()
     B = args.batch
     g = torch.Generator(device=dev).manual_seed(1234 + rank)

@@ -244,6 +244,18 @@ int hno_loss_bwd(const float *probs, const uint8_t *labels, const float *coef, c
 int hno_labels_prepare(const float *labels_f32, const int *remap_from, const int *remap_to, int n_remap,
                        uint8_t *labels_u8, float *onehot, int B, int K, long long V, void *stream);
 
+/* ------------------------------------------------------------------ optimizer
+ * Multi-tensor Adamax: ONE launch updates every parameter (replaces torch.optim.Adamax.step as driven by
+ * experiments/run.py:89-91 / train_test.py:171; arithmetic of torch/optim/adamax.py):
+ *   g = grad * grad_scale + weight_decay * p;  m += (1 - beta1)(g - m);  u = max(beta2 u, |g| + eps);
+ *   p -= lr / (1 - beta1^step) * m / u
+ * `table` is a DEVICE array of n_chunks rows of hno_adamax_chunk_rows() (= 5) 64-bit words:
+ *   { float *p, const float *grad, float *exp_avg, float *exp_inf, int64 n } -- a run of n elements of one tensor.
+ * `step` is the 1-based step count.  grad_scale folds the 1/world of a SUM all-reduce into the update. */
+int hno_adamax_chunk_rows(void);
+int hno_adamax_multi(const void *table, int n_chunks, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, long long step, float grad_scale, void *stream);
+
 /* ------------------------------------------------------------------ per-kernel profiler
  * hno_profile_begin arms HIP-event bracketing of every kernel launch (on the stream the kernel
  * is launched on); hno_profile_end stops it, waits for the events and returns the number of
