@@ -256,6 +256,22 @@ int hno_adamax_chunk_rows(void);
 int hno_adamax_multi(const void *table, int n_chunks, float lr, float beta1, float beta2, float eps,
                      float weight_decay, long long step, float grad_scale, void *stream);
 
+/* ------------------------------------------------------------------ input pipeline
+ * hno_zscore_modalities: x, out (C, V): per modality c, v = clip(x) if has_clip; statistics over v != mask_val if
+ *   has_mask; out = (v - mean) / std (population std), masked voxels -> 0.  Replaces normalize_modalities /
+ *   normalize_data (experiments/utils.py:25-71) as run.py:52-55 binds it (mask_val = 0).  mean_std (C, 2) receives the
+ *   statistics (may be NULL).  A batch is C = B * modalities.  Workspace: hno_zscore_workspace_bytes(C).
+ * hno_affine_nearest: x, out (C, D, H, W), out != x.  matrix12 is a HOST array, rows of [M | t] with
+ *   (x, y, z)_in = M (x, y, z)_out + t in voxel indices: nearest-neighbour resampling (round half up), `cval`
+ *   outside [-0.5, size - 0.5); then flips of the resampled image (bit 0 depth, bit 1 height, bit 2 width).
+ *   Replaces apply_transform + flip_axis (experiments/data_io/dataset.py:205-244; SimpleITK AffineTransform +
+ *   ResampleImageFilter with sitkNearestNeighbor).  2-D images: D = 1 and an identity z row. */
+size_t hno_zscore_workspace_bytes(int C);
+int hno_zscore_modalities(const float *x, float *out, float *mean_std, void *workspace, int C, long long V,
+                          int has_mask, float mask_val, int has_clip, float clip_lo, float clip_hi, void *stream);
+int hno_affine_nearest(const float *x, float *out, const double *matrix12, float cval, int flip_mask, int C, int D,
+                       int H, int W, void *stream);
+
 /* ------------------------------------------------------------------ per-kernel profiler
  * hno_profile_begin arms HIP-event bracketing of every kernel launch (on the stream the kernel
  * is launched on); hno_profile_end stops it, waits for the events and returns the number of

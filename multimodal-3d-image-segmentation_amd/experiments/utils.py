@@ -1,7 +1,7 @@
-"""Label helpers of the reference's experiments/utils.py (:74-119) on the HIP kernels."""
+"""Label and normalisation helpers of the reference's experiments/utils.py (:25-119) on the HIP kernels."""
 import torch
 
-from .. import ops
+from .. import _lib, ops
 
 
 def to_categorical(y, num_classes=None):
@@ -28,3 +28,32 @@ def remap_labels(label, mapping):
 def labels_to_u8(y, num_labels, mapping=None):
     """What the loop actually uses: (B,1,...) labels -> uint8 class map (B,...) with the optional remap fused."""
     return ops.labels_prepare(y, num_labels, mapping)
+
+
+def normalize_modalities(data, mask_val=None, clip_val=None, return_stats=False):
+    """Per-modality masked z-score on the GPU (reference utils.py:25-71; run.py:52-55 binds mask_val = 0).
+
+    data: (C, ...) one sample, or (B, C, ...) a batch -- every (sample, modality) volume is normalised on its
+    own, as the reference's per-sample ``x_processing`` does.  Values equal to ``mask_val`` (after clipping)
+    are left out of mean / std and come out as 0."""
+    if not isinstance(data, torch.Tensor):
+        data = torch.as_tensor(data)
+    if not data.is_cuda:
+        raise _lib.HnoError('normalize_modalities runs on the GPU; move the raw volume there first (no CPU fallback)')
+    x = data.float().contiguous()
+    C, V = x.shape[0], x[0].numel()
+    L = _lib.lib()
+    ws = torch.empty(L.hno_zscore_workspace_bytes(C) // 8, device=x.device, dtype=torch.float64)
+    out = torch.empty_like(x)
+    stats = torch.empty((C, 2), device=x.device, dtype=torch.float32) if return_stats else None
+    lo, hi = (float(clip_val[0]), float(clip_val[1])) if clip_val is not None else (0.0, 0.0)
+    _lib.check(L.hno_zscore_modalities(_lib.ptr(x), _lib.ptr(out), _lib.ptr(stats), _lib.ptr(ws), C, V,
+                                       int(mask_val is not None), float(mask_val if mask_val is not None else 0.0),
+                                       int(clip_val is not None), lo, hi, _lib.stream_ptr()), 'hno_zscore_modalities')
+    return (out, stats) if return_stats else out
+
+
+def normalize_batch(batch, mask_val=None, clip_val=None):
+    """(B, C, ...) raw batch -> normalised batch in one launch pair (B * C independent volumes)."""
+    flat = batch.reshape((batch.shape[0] * batch.shape[1],) + tuple(batch.shape[2:]))
+    return normalize_modalities(flat, mask_val, clip_val).reshape(batch.shape)

@@ -543,6 +543,69 @@ def remap_labels(label, mapping):
 
 
 # --------------------------------------------------------------------------------------
+# Input pipeline (experiments/utils.py:25-71, experiments/data_io/dataset.py:192-244)
+# --------------------------------------------------------------------------------------
+def normalize_modalities(data, mask_val=None, clip_val=None):
+    """utils.py:25-71: per modality (leading axis): clip, mean / population std over voxels != mask_val,
+    z-score, masked voxels -> 0.  float64 accumulation; pinned by golden G11 (reference output)."""
+    data = np.asarray(data, dtype=np.float32)
+    out = np.empty_like(data)
+    for c in range(data.shape[0]):
+        v = data[c]
+        if clip_val is not None:
+            v = np.clip(v, clip_val[0], clip_val[1])
+        keep = np.ones(v.shape, dtype=bool) if mask_val is None else (v != mask_val)
+        sel = v[keep].astype(np.float64)
+        mean = np.float32(sel.mean())
+        std = np.float32(np.sqrt(((sel - sel.mean()) ** 2).mean()))
+        out[c] = np.where(keep, (v - mean) / std, np.float32(0))
+    return out
+
+
+def centre_affine(matrix, spatial):
+    """dataset.py:192-199 + :218-221: homogeneous (x, y[, z]) matrix conjugated about size / 2 + 0.5 ->
+    3 x 4 rows [M | t] in (x, y, z) voxel indices (2-D: identity z row)."""
+    matrix = np.asarray(matrix, dtype=np.float64)
+    n = matrix.shape[0]
+    off = np.asarray(tuple(spatial)[::-1], dtype=np.float64) / 2.0 + 0.5
+    a, b = np.eye(n), np.eye(n)
+    a[:-1, -1], b[:-1, -1] = off, -off
+    full = a @ matrix @ b
+    if n == 3:
+        m = np.eye(4)
+        m[:2, :2], m[:2, 3] = full[:2, :2], full[:2, 2]
+        full = m
+    return full[:3, :4]
+
+
+def affine_nearest(x, m12, cval=0.0, flips=()):
+    """dataset.py:202-244 through ITK's published semantics (SimpleITK is NOT installed in this image, so this
+    function is NOT pinned by a reference run -- "parity unpinned"): ResampleImageFilter with an AffineTransform
+    (centre 0), unit spacing, zero origin, nearest-neighbour interpolation: the continuous input index of output
+    voxel p is M p + t; it is inside the buffer iff -0.5 <= c < size - 0.5 per axis; the nearest index is
+    floor(c + 0.5); outside voxels take `cval`.  `flips`: array axes (1-based spatial, axis 0 = channel) reversed
+    AFTER resampling.  x: (C, D, H, W) or (C, H, W) numpy."""
+    x = np.asarray(x)
+    sp = x.shape[1:]
+    D, H, W = ((1,) + tuple(sp)) if len(sp) == 2 else sp
+    x4 = x.reshape((x.shape[0], D, H, W))
+    z, y, xx = np.meshgrid(np.arange(D, dtype=np.float64), np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64),
+                           indexing='ij')
+    m = np.asarray(m12, dtype=np.float64)
+    cx = m[0, 0] * xx + m[0, 1] * y + m[0, 2] * z + m[0, 3]
+    cy = m[1, 0] * xx + m[1, 1] * y + m[1, 2] * z + m[1, 3]
+    cz = m[2, 0] * xx + m[2, 1] * y + m[2, 2] * z + m[2, 3]
+    inside = (cx >= -0.5) & (cx < W - 0.5) & (cy >= -0.5) & (cy < H - 0.5) & (cz >= -0.5) & (cz < D - 0.5)
+    ix = np.where(inside, np.floor(cx + 0.5), 0).astype(np.int64)
+    iy = np.where(inside, np.floor(cy + 0.5), 0).astype(np.int64)
+    iz = np.where(inside, np.floor(cz + 0.5), 0).astype(np.int64)
+    out = np.where(inside[None], x4[:, iz, iy, ix], np.asarray(cval, dtype=x.dtype)).reshape(x.shape)
+    for ax in flips:
+        out = np.flip(out, ax)
+    return np.ascontiguousarray(out)
+
+
+# --------------------------------------------------------------------------------------
 # Convenience: one fwd + loss + bwd step of HNOSeg-XS on CPU (the cpu_baseline "port")
 # --------------------------------------------------------------------------------------
 def hnosegxs_step(sd, x, labels, num_transform_blocks, num_modes, loss='pcc'):

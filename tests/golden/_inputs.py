@@ -177,3 +177,23 @@ VNET_MODELS = {
     'vnet_noresize_odd': (dict(in_channels=1, out_channels=2, base_num_filters=4, num_blocks=[1, 1], use_resize=False,
                                right_leg_indexes=None), (2, 1, 9, 11, 13)),
 }
+
+
+# ---- input pipeline (G11)
+AUG_CASES = {
+    'aug3d': (dict(rotation_range=[30, 10, 5], shift_range=[0.2, 0.1, 0.3], zoom_range=[0.8, 1.2], flip=[True, False, True],
+                   augmentation_probability=0.8, seed=7), (2, 6, 7, 9)),
+    'brats': (dict(rotation_range=[30, 0, 0], shift_range=[0.2, 0.2, 0.2], zoom_range=[0.8, 1.2],
+                   augmentation_probability=0.8, seed=11), (1, 8, 10, 12)),
+    'aug2d': (dict(rotation_range=25, shift_range=[0.1, 0.2], zoom_range=[0.7, 1.3], flip=[False, True],
+                   augmentation_probability=0.9, seed=3), (1, 9, 11)),
+}
+
+
+def raw_modalities():
+    """(3, 10, 12, 14) raw-MR-like volume: per-modality offset / scale and a zero background (the mask)."""
+    vol = formula_tensor((3, 10, 12, 14), 400).astype(np.float64)
+    vol = vol * np.array([300.0, 40.0, 1.0]).reshape(3, 1, 1, 1) + np.array([500.0, 90.0, 0.5]).reshape(3, 1, 1, 1)
+    vol[:, :2] = 0
+    vol[:, :, :3, :4] = 0
+    return vol.astype(np.float32)

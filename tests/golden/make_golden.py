@@ -282,6 +282,38 @@ def g10_two_d():
     save('g10_two_d.npz', **out)
 
 
+# ---------------------------- G11: input pipeline (normalisation values, augmentation random stream)
+def g11_input():
+    from _inputs import AUG_CASES, raw_modalities
+    _stub_missing_modules()
+    from experiments import utils as ref_utils
+    from experiments.data_io import dataset as ref_ds
+    out = {}
+    # normalisation: smooth volume with a zero background (the mask) -- raw-MR-like offsets and scales
+    vol = raw_modalities()
+    out['norm_masked'] = ref_utils.normalize_modalities(vol, mask_val=0)
+    out['norm_plain'] = ref_utils.normalize_modalities(vol)
+    out['norm_clip'] = ref_utils.normalize_modalities(vol, mask_val=0, clip_val=(0, 600))
+    # augmentation: the matrices ImageTransform hands to apply_transform and the flips it applies (SimpleITK itself is
+    # not installed, so the resampling cannot be run here: apply_transform is replaced by a recorder)
+    for name, (kw, shape) in AUG_CASES.items():
+        rec = []
+        ref_ds.apply_transform = lambda x, m, cval, rec=rec: (rec.append(np.array(m, dtype=np.float64)), x)[1]
+        tr = ref_ds.ImageTransform(**kw)
+        base = np.arange(int(np.prod(shape)), dtype=np.float32).reshape(shape)
+        mats, outs, had = [], [], []
+        for _ in range(12):
+            n0 = len(rec)
+            xo, yo = tr(base, base[:1])
+            had.append(len(rec) > n0)
+            mats.append(rec[n0] if len(rec) > n0 else np.eye(len(shape)))
+            outs.append(np.ascontiguousarray(xo))       # shows the flips (identity resampling)
+        out[f'{name}_had_matrix'] = np.array(had)
+        out[f'{name}_matrices'] = np.stack(mats)
+        out[f'{name}_flipped'] = np.stack(outs)
+    save('g11_input.npz', **out)
+
+
 # ------------------------------------------- G9: labels, padcrop, SNN init statistics
 def g9_misc():
     sys.modules.setdefault('SimpleITK', type(sys)('SimpleITK'))
@@ -443,7 +475,7 @@ def g8_training():
 
 if __name__ == '__main__':
     ALL = [g1_dht, g2_crop_pad, g3_operators, g4_mha, g5_losses, g6_hnosegxs, g6s_small_models, g7_noseg_models,
-           g7v_vnet_models, g9_misc, g10_two_d, g8_training]
+           g7v_vnet_models, g9_misc, g10_two_d, g11_input, g8_training]
     only = set(sys.argv[2:])   # e.g. `make_golden.py /root/reference g10_two_d` regenerates one fixture
     for fn in ALL:
         if not only or fn.__name__ in only:

@@ -142,3 +142,22 @@ def test_flat_grad_allreduce_gloo_world2(tmp_path):
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert res.stdout.count('ok') == 2
+
+
+def test_image_transform_random_stream_matches_reference():
+    """ImageTransform.draw (host side of the GPU augmentation) reproduces the reference's random stream: the same
+    matrices reach apply_transform and the same axes are flipped, call after call (golden G11)."""
+    from _inputs import AUG_CASES
+    from conftest import load_golden
+    from multimodal_3d_image_segmentation_amd.experiments.data_io.dataset import ImageTransform
+    g = load_golden('g11_input.npz')
+    for name, (kw, shape) in AUG_CASES.items():
+        tr = ImageTransform(**kw)
+        base = np.arange(int(np.prod(shape)), dtype=np.float32).reshape(shape)
+        for it in range(12):
+            mat, flips = tr.draw(shape)
+            assert (mat is not None) == bool(g[f'{name}_had_matrix'][it]), (name, it)
+            want = g[f'{name}_matrices'][it]
+            got = mat if mat is not None else np.eye(len(shape))
+            assert np.allclose(got, want, rtol=1e-13, atol=1e-13), (name, it)
+            assert np.array_equal(np.flip(base, flips) if flips else base, g[f'{name}_flipped'][it]), (name, it)

@@ -265,3 +265,31 @@ def test_vnet_models_oracle(name):
     assert abs(float(loss.detach()) - float(g[f'{name}::loss'])) < 1e-6
     for k, p in params.items():
         assert rel_err(_np(p.grad), g[f'{name}::grad::{k}']) < 1e-4, k
+
+
+def test_input_normalisation_oracle_vs_reference():
+    """oracle.normalize_modalities against the reference's numpy masked-array implementation (golden G11)."""
+    from _inputs import raw_modalities
+    g = load_golden('g11_input.npz')
+    vol = raw_modalities()
+    assert rel_err(O.normalize_modalities(vol, mask_val=0), g['norm_masked']) < 2e-6
+    assert rel_err(O.normalize_modalities(vol), g['norm_plain']) < 2e-6
+    assert rel_err(O.normalize_modalities(vol, mask_val=0, clip_val=(0, 600)), g['norm_clip']) < 2e-6
+    assert np.all(O.normalize_modalities(vol, mask_val=0)[vol == 0] == 0)
+
+
+def test_affine_nearest_oracle_properties():
+    """The resampling oracle is not pinned by a reference run (no SimpleITK here); check what must hold for any
+    nearest-neighbour resampler: identity, integer shifts, axis flips and the constant fill."""
+    x = formula_tensor((2, 5, 6, 7), 9)
+    eye = np.eye(4)
+    assert np.array_equal(O.affine_nearest(x, O.centre_affine(eye, x.shape[1:])), x)
+    sh = np.eye(4)
+    sh[:3, 3] = (2, -1, 1)          # (x, y, z): out[d, h, w] = in[d + 1, h - 1, w + 2]
+    got = O.affine_nearest(x, O.centre_affine(sh, x.shape[1:]), cval=-7.0)
+    want = np.full_like(x, -7.0)
+    want[:, :4, 1:, :5] = x[:, 1:, :5, 2:]
+    assert np.array_equal(got, want)
+    assert np.array_equal(O.affine_nearest(x, O.centre_affine(eye, x.shape[1:]), flips=(1, 3)), x[:, ::-1, :, ::-1])
+    x2 = formula_tensor((1, 6, 8), 2)
+    assert np.array_equal(O.affine_nearest(x2, O.centre_affine(np.eye(3), x2.shape[1:])), x2)
