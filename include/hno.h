@@ -133,6 +133,13 @@ int hno_pwconv_bwd(const float *gy, const float *y, const float *xa, int Ca, con
                    const float *W, float *gxa, float *gxb, float *dW, float *dbias, void *workspace,
                    int B, int Cout, long long V, int act, int xa_act, int accumulate_gx, void *stream);
 
+/* Complex shared-weight mix of the Fourier operator (nets/fourier_operator.py:164-172, complex 'oi,bi...->bo...') as ONE
+ * real pointwise conv on the [re | im] channel layout: hno_cmix_compose builds W2 = [[Wr, -Wi], [Wi, Wr]] (2Co x 2Ci) for
+ * hno_pwconv_fwd / hno_pwconv_bwd; hno_cmix_split_grad turns dW2 into dWr = dW2[re,re] + dW2[im,im], dWi = dW2[im,re] -
+ * dW2[re,im]. */
+int hno_cmix_compose(const float *w_real, const float *w_imag, float *w2, int Co, int Ci, void *stream);
+int hno_cmix_split_grad(const float *dw2, float *dw_real, float *dw_imag, int Co, int Ci, void *stream);
+
 /* ------------------------------------------- strided 2x2x2 'resize' convolution (conv_in)
  * Conv3d(Cin -> Cout, kernel 2, stride 2, padding 1) + bias + act: (B,Cin,D,H,W) ->
  * (B,Cout,D/2+1,H/2+1,W/2+1).  Replaces ConvNormAct(kernel_size=2, stride=2)

@@ -313,21 +313,27 @@ __global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_fast_kernel(Pw
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, c = lane & 31;
     constexpr int CIN = 2 * NKI;
-    constexpr int NR = COUT > 28 ? 16 : (COUT > 20 ? 12 : (COUT > 12 ? 8 : 4));   // accumulator registers holding rows < COUT
+    constexpr int OT = (COUT + 31) / 32;          // output tiles of 32 rows (COUT <= 64)
+    constexpr int CL = COUT - 32 * (OT - 1);      // rows of the last tile
+    constexpr int NRL = CL > 28 ? 16 : (CL > 20 ? 12 : (CL > 12 ? 8 : 4));   // accumulator registers holding rows < COUT
     const unsigned V = a.V;
-    float w[NKI];
+    float w[OT][NKI];
 #pragma unroll
-    for (int ks = 0; ks < NKI; ++ks) {
-        const int i = 2 * ks + h;
-        w[ks] = c < COUT ? a.W[(size_t)c * CIN + i] : 0.f;
-        if (a.residual && c == i) w[ks] += 1.f;
-    }
-    float bias_r[NR];
+    for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const int o = (r & 3) + 8 * (r >> 2) + 4 * h;
-        bias_r[r] = (a.bias && o < COUT) ? a.bias[o] : 0.f;
-    }
+        for (int ks = 0; ks < NKI; ++ks) {
+            const int i = 2 * ks + h, o = ot * 32 + c;
+            w[ot][ks] = o < COUT ? a.W[(size_t)o * CIN + i] : 0.f;
+            if (a.residual && o == i) w[ot][ks] += 1.f;
+        }
+    float bias_r[OT][16];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            bias_r[ot][r] = (a.bias && o < COUT) ? a.bias[o] : 0.f;
+        }
     // branch-free activation: act(x) = (x > 0 or linear) ? ap * x : aq * (e^x - 1)
     const float ap = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f;
     const float aq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
@@ -349,30 +355,33 @@ __global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_fast_kernel(Pw
             const float *base = i0 < CA ? xa_b + (size_t)i0 * V : xb_b + (size_t)(i0 - CA) * V;
             xv[ks] = base[off];
         }
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        if (a.dbg & 1) {
-#pragma unroll
-            for (int ks = 0; ks < NKI; ++ks) acc[ks & 15] += xv[ks];
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < NKI; ++ks) acc = mfma32(w[ks], xv[ks], acc);
-        }
         float *y_b = a.y + (size_t)b * COUT * V;
-        if (!(a.dbg & 2)) {
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const int orow = (r & 3) + 8 * (r >> 2);
-                const float x = acc[r] + bias_r[r];
-                const float val = (x > 0.f || lin) ? ap * x : aq * neg_expm1(x);
-                if (vin && (orow + 4 < COUT || h == 0)) (y_b + (size_t)orow * V)[hoff4V + v] = val;
+        for (int ot = 0; ot < OT; ++ot) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            if (a.dbg & 1) {
+#pragma unroll
+                for (int ks = 0; ks < NKI; ++ks) acc[ks & 15] += xv[ks];
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < NKI; ++ks) acc = mfma32(w[ot][ks], xv[ks], acc);
             }
-        } else {
-            float sacc = 0.f;
+            if (!(a.dbg & 2)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc += acc[r];
-            if (sacc == 12345.678f) y_b[0] = sacc;
+                for (int r = 0; r < (ot == OT - 1 ? NRL : 16); ++r) {
+                    const int orow = ot * 32 + (r & 3) + 8 * (r >> 2);
+                    const float x = acc[r] + bias_r[ot][r];
+                    const float val = (x > 0.f || lin) ? ap * x : aq * neg_expm1(x);
+                    if (vin && (orow + 4 < COUT || h == 0)) (y_b + (size_t)orow * V)[hoff4V + v] = val;
+                }
+            } else {
+                float sacc = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[r];
+                if (sacc == 12345.678f) y_b[0] = sacc;
+            }
         }
     }
 }
@@ -566,6 +575,7 @@ int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const fl
         if (Ca == 24 && Cb == 0 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 24>), dim3(fgrid), fb, 0, fs, a);
         else if (Ca == 24 && Cb == 24 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 24, 24>), dim3(fgrid), fb, 0, fs, a);
         else if (Ca == 24 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 4>), dim3(fgrid), fb, 0, fs, a);
+        else if (Ca == 48 && Cb == 0 && Cout == 48) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<48, 0, 48>), dim3(fgrid), fb, 0, fs, a);   // composed complex mix
         else done = false;
         if (done) {
             HNO_CHECK_LAUNCH();
@@ -637,6 +647,7 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 24, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<4, 24, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<48, 48, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_done = true;
         }
         {
@@ -647,6 +658,7 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
             else if (s2424 && NW == 12) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 24, 12>), g, blk, sizeof(float) * NW * (32 + 48) * PWB_LD, s, a);
             else if (s2424) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 24>), g, blk, sizeof(float) * NW * (32 + 48) * PWB_LD, s, a);
             else if (Ca == 24 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<4, 24, 0>), g, blk, sizeof(float) * NW * (16 + 32) * PWB_LD, s, a);
+            else if (Ca == 48 && Cb == 0 && Cout == 48) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<48, 48, 0>), g, blk, sizeof(float) * NW * (48 + 48) * PWB_LD, s, a);   // composed complex mix
             else done = false;
         }
         if (done) {
@@ -710,9 +722,48 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
     return HNO_OK;
 }
 
+// ---- complex shared mix of the Fourier operator as ONE real pointwise conv -----------------------------------
+// [Yr; Yi] = [[Wr, -Wi], [Wi, Wr]] [Xr; Xi] on the [re | im] channel layout of the kept half spectrum
+// (nets/fourier_operator.py:164-172 'oi,bi...->bo...' with complex weights).
+__global__ void cmix_compose_kernel(const float *__restrict__ wr, const float *__restrict__ wi, float *__restrict__ w2, int Co, int Ci) {
+    const int n = 4 * Co * Ci;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const int o = e / (2 * Ci), i = e - o * 2 * Ci;
+        const int oo = o < Co ? o : o - Co, ii = i < Ci ? i : i - Ci;
+        const float r = wr[oo * Ci + ii], im = wi[oo * Ci + ii];
+        w2[e] = (o < Co) == (i < Ci) ? r : (o < Co ? -im : im);
+    }
+}
+
+// dWr = dW2[re, re] + dW2[im, im];  dWi = dW2[im, re] - dW2[re, im]
+__global__ void cmix_split_kernel(const float *__restrict__ dw2, float *__restrict__ dwr, float *__restrict__ dwi, int Co, int Ci) {
+    const int n = Co * Ci;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const int o = e / Ci, i = e - o * Ci;
+        const float rr = dw2[(size_t)o * 2 * Ci + i], ri = dw2[(size_t)o * 2 * Ci + Ci + i];
+        const float ir = dw2[(size_t)(o + Co) * 2 * Ci + i], ii = dw2[(size_t)(o + Co) * 2 * Ci + Ci + i];
+        dwr[e] = rr + ii;
+        dwi[e] = ir - ri;
+    }
+}
+
 }  // namespace hno
 
 using namespace hno;
+
+extern "C" int hno_cmix_compose(const float *w_real, const float *w_imag, float *w2, int Co, int Ci, void *stream) {
+    HNO_REQUIRE(w_real && w_imag && w2 && Co > 0 && Ci > 0, "hno_cmix_compose: bad argument");
+    hipLaunchKernelGGL(cmix_compose_kernel, dim3(ceil_div(4 * Co * Ci, 256)), dim3(256), 0, (hipStream_t)stream, w_real, w_imag, w2, Co, Ci);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+extern "C" int hno_cmix_split_grad(const float *dw2, float *dw_real, float *dw_imag, int Co, int Ci, void *stream) {
+    HNO_REQUIRE(dw2 && dw_real && dw_imag && Co > 0 && Ci > 0, "hno_cmix_split_grad: bad argument");
+    hipLaunchKernelGGL(cmix_split_kernel, dim3(ceil_div(Co * Ci, 256)), dim3(256), 0, (hipStream_t)stream, dw2, dw_real, dw_imag, Co, Ci);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
 
 extern "C" int hno_pwconv_fwd(const float *xa, int Ca, const float *xb, int Cb, const float *W, const float *bias,
                               float *y, int B, int Cout, long long V, int act, void *stream) {

@@ -1,10 +1,10 @@
 """FourierOperator forward on the HIP kernels (reference nets/fourier_operator.py:90-223).
 
 The kept half spectrum is carried as REAL data (B, 2C, 2m0, 2m1, m2) with channels [re | im], so
-the complex channel mix  Y = (Wr + i Wi) X  is two real pointwise convolutions over the mode axis:
-    Yr = [Wr, -Wi] [Xr ; Xi],   Yi = [Wi,  Wr] [Xr ; Xi]
-(the same MFMA kernels as every other 1x1x1 conv; autograd splits the weight gradients back into
-weight_real / weight_imag through the two tiny torch.cat nodes).
+the complex channel mix  Y = (Wr + i Wi) X  is ONE real pointwise convolution over the mode axis:
+    [Yr ; Yi] = [[Wr, -Wi], [Wi, Wr]] [Xr ; Xi]
+(the same MFMA kernels as every other 1x1x1 conv; ops.ComplexMixFn composes the matrix and splits its
+gradient back into weight_real / weight_imag with two tiny kernels).
 """
 import numpy as np
 import torch
@@ -13,11 +13,7 @@ from .. import ops
 
 
 def complex_mix_shared(spec, weight_real, weight_imag):
-    w1 = torch.cat([weight_real, -weight_imag], dim=1)
-    w2 = torch.cat([weight_imag, weight_real], dim=1)
-    yr = ops.PwConvFn.apply(spec, None, w1, None, ops.ACT_NONE)
-    yi = ops.PwConvFn.apply(spec, None, w2, None, ops.ACT_NONE)
-    return torch.cat([yr, yi], dim=1)
+    return ops.ComplexMixFn.apply(spec, weight_real, weight_imag)
 
 
 def fourier_operator_forward(op, inputs, addend=None, act=ops.ACT_NONE):

@@ -615,6 +615,34 @@ class PwConvFn(torch.autograd.Function):
         return gxa, gxb, dW, db, None
 
 
+class ComplexMixFn(torch.autograd.Function):
+    """Complex shared-weight channel mix on the [re | im] layout (nets/fourier_operator.py:164-172):
+    spec (B, 2Ci, ...) -> (B, 2Co, ...) with W = weight_real + i weight_imag, as one real pointwise conv with the
+    composed matrix [[Wr, -Wi], [Wi, Wr]] (built and split back by two tiny kernels: no ATen cat / neg / slice)."""
+
+    @staticmethod
+    def forward(ctx, spec, wr, wi):
+        spec, wr, wi = _f32c(spec), _f32c(wr), _f32c(wi)
+        _need_gpu(spec, wr, wi)
+        Co, Ci = wr.shape
+        assert spec.shape[1] == 2 * Ci and wi.shape == wr.shape
+        w2 = torch.empty((2 * Co, 2 * Ci), device=spec.device, dtype=torch.float32)
+        check(_lib.lib().hno_cmix_compose(ptr(wr), ptr(wi), ptr(w2), Co, Ci, stream_ptr()), 'hno_cmix_compose')
+        y = pwconv_fwd_raw(spec, None, w2, None, ACT_NONE)
+        ctx.save_for_backward(spec, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        spec, w2 = ctx.saved_tensors
+        gx, _, dw2, _ = pwconv_bwd_raw(_f32c(g), None, spec, None, w2, ACT_NONE, False, ctx.needs_input_grad[0], False)
+        Co, Ci = w2.shape[0] // 2, w2.shape[1] // 2
+        dwr = torch.empty((Co, Ci), device=g.device, dtype=torch.float32)
+        dwi = torch.empty_like(dwr)
+        check(_lib.lib().hno_cmix_split_grad(ptr(dw2), ptr(dwr), ptr(dwi), Co, Ci, stream_ptr()), 'hno_cmix_split_grad')
+        return gx, dwr, dwi
+
+
 class XSBlockFn(torch.autograd.Function):
     """One whole HNO-XS block (nets/hnosegxs.py:253-279) as a single autograd node:
 
