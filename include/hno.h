@@ -133,6 +133,19 @@ int hno_pwconv_bwd(const float *gy, const float *y, const float *xa, int Ca, con
                    const float *W, float *gxa, float *gxb, float *dW, float *dbias, void *workspace,
                    int B, int Cout, long long V, int act, int xa_act, int accumulate_gx, void *stream);
 
+/* hno_pwconv_bwd with a FUSED CONV BRANCH (the FNOSeg / HNOSeg block, nets/architectures.py:521-546): the conv's first input
+ * xa = act(s + Wbr xb + bbr) was itself produced from xb by a second 1x1x1 conv (conv_branch) plus the operator output s.
+ * One pass over the voxels computes, with p = (W^T g)[xa rows] * act'(xa):
+ *   p_out (B, Ca, V) = p                     -- the gradient of the pre-activation sum: feeds the operator's backward
+ *   gxb   (B, Cb, V) = (W^T g)[xb rows] + Wbr^T p
+ *   dflat = [ dW (Cout x (Ca+Cb)) | dbias (Cout) | dWbr (Ca x Cb) | dbbr (Ca) ]   (one flat buffer)
+ * where g = gy * act'(y).  xa_act names the activation of xa (required).  Built for Ca = Cb = Cout = 24 (HNO_ELIMIT
+ * otherwise: call hno_pwconv_bwd twice).  Workspace: hno_pwconv_bwd_branch_workspace_bytes. */
+size_t hno_pwconv_bwd_branch_workspace_bytes(int Ca, int Cb, int Cout);
+int hno_pwconv_bwd_branch(const float *gy, const float *y, const float *xa, int Ca, const float *xb, int Cb,
+                          const float *W, const float *Wbr, float *p_out, float *gxb, float *dflat, void *workspace,
+                          int B, int Cout, long long V, int act, int xa_act, void *stream);
+
 /* Complex shared-weight mix of the Fourier operator (nets/fourier_operator.py:164-172, complex 'oi,bi...->bo...') as ONE
  * real pointwise conv on the [re | im] channel layout: hno_cmix_compose builds W2 = [[Wr, -Wi], [Wi, Wr]] (2Co x 2Ci) for
  * hno_pwconv_fwd / hno_pwconv_bwd; hno_cmix_split_grad turns dW2 into dWr = dW2[re,re] + dW2[im,im], dWi = dW2[im,re] -

@@ -138,6 +138,9 @@ struct PwBwdArgs {
     long long s_gy, s_xa, s_xb, s_gxa, s_gxb;
     int ldw;
     int xa_act;  // gxa *= act'(xa): xa is itself the OUTPUT of that activation (fuses PadInverse's SELU backward)
+    // fused conv branch (fast kernel, BR = 1): xa = act(s + Wbr xb + bbr) came from a second 1x1x1 conv of xb.  With
+    // p = gxa * act'(xa) (the xa_act product): gxb += Wbr^T p, dWbr = sum p xb^T, dbbr = sum p -- one pass instead of two
+    const float *Wbr;
 };
 
 #define PWB_LD 34  // 32 voxels + 2: row stride == 2 (mod 4) -> conflict-free 16x16x4 operand reads
@@ -387,18 +390,41 @@ __global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_fast_kernel(Pw
 }
 
 #define PWB_FAST_WAVES 4   // 256-thread blocks, two per CU (512 slabs): measured best of {4, 8, 12} waves x {256, 512, 1024} blocks
-template <int COUT, int CA, int CB, int NW = PWB_FAST_WAVES>   // compile-time channel counts: every address select folds
-__global__ __launch_bounds__(64 * NW) void pwconv_bwd_fast_kernel(PwBwdArgs a) {
+template <int COUT, int CA, int CB, int NW = PWB_FAST_WAVES, int BR = 0>   // compile-time channel counts: every address select folds
+__global__ __launch_bounds__(64 * NW, (BR && NW == 4) ? 2 : 1) void pwconv_bwd_fast_kernel(PwBwdArgs a) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, c = lane & 31;
     constexpr int CIN = CA + CB, NKO = COUT / 2, NKI = CIN / 2, ICH = (CIN + 31) / 32;
     constexpr int MT = (COUT + 15) / 16, NTI = (CIN + 15) / 16;
-    constexpr int rowsG = MT * 16, rowsX = NTI * 16;
+    // BR: the xa rows all sit in the first 32-row chunk; P holds p = gxa * act'(xa) as [o][v] for the branch weight gradient
+    static_assert(!BR || (CA % 8 == 0 && CA <= 32 && CB % 8 == 0 && CB > 0), "fused branch needs CA <= 32");
+    constexpr int RA = CA / 2;                          // accumulator registers of chunk 0 that hold xa rows
+    constexpr int MTP = BR ? (CA + 15) / 16 : 0, NTB = BR ? (CB + 15) / 16 : 0;
+    constexpr int rowsG = MT * 16, rowsX = BR ? (CA + NTB * 16 > NTI * 16 ? CA + NTB * 16 : NTI * 16) : NTI * 16, rowsP = MTP * 16;
     const unsigned V = a.V;
-    float *G = lds + (size_t)wave * (rowsG + rowsX) * PWB_LD;  // [o][v]
+    float *G = lds + (size_t)wave * (rowsG + rowsX + rowsP) * PWB_LD;  // [o][v]
     float *X = G + rowsG * PWB_LD;                              // [i][v]
+    float *P = X + rowsX * PWB_LD;                              // [o][v] of the branch (BR only)
+    float wbr[BR ? RA : 1];   // A operand of the branch dgrad: Wbr^T[row = i][k-slot ks -> channel (ks & 3) + 8 (ks >> 2) + 4 h]
+    if (BR) {
+#pragma unroll
+        for (int ks = 0; ks < RA; ++ks) {
+            const int o = (ks & 3) + 8 * (ks >> 2) + 4 * h;
+            wbr[ks] = c < CB ? a.Wbr[(size_t)o * CB + c] : 0.f;
+        }
+    }
+    f32x4 dwb[BR ? MTP : 1][BR ? NTB : 1];
+    float dbb[BR ? RA : 1];
+    if (BR) {
+#pragma unroll
+        for (int m = 0; m < MTP; ++m)
+#pragma unroll
+            for (int n = 0; n < NTB; ++n) dwb[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < RA; ++ks) dbb[ks] = 0.f;
+    }
     float wt[ICH][NKO];  // A operand of dgrad: Wt[row = i][k = o]
 #pragma unroll
     for (int ic = 0; ic < ICH; ++ic)
@@ -408,7 +434,7 @@ __global__ __launch_bounds__(64 * NW) void pwconv_bwd_fast_kernel(PwBwdArgs a) {
             wt[ic][ks] = i < CIN ? a.W[(size_t)o * CIN + i] : 0.f;
             if (a.residual && i == o) wt[ic][ks] += 1.f;
         }
-    for (int i = lane; i < (rowsG + rowsX) * PWB_LD; i += 64) G[i] = 0.f;
+    for (int i = lane; i < (rowsG + rowsX + rowsP) * PWB_LD; i += 64) G[i] = 0.f;
     float db[NKO];
 #pragma unroll
     for (int ks = 0; ks < NKO; ++ks) db[ks] = 0.f;
@@ -428,6 +454,7 @@ __global__ __launch_bounds__(64 * NW) void pwconv_bwd_fast_kernel(PwBwdArgs a) {
     const unsigned hoffV = h ? V : 0u, hoff4V = h ? 4u * V : 0u;
     const float *ga = G + (lane & 15) * PWB_LD + (lane >> 4);
     const float *xbp = X + (lane & 15) * PWB_LD + (lane >> 4);
+    const float *pa = P + (lane & 15) * PWB_LD + (lane >> 4);
     // software pipeline: raw loads of the NEXT tile (gy, y, x) are issued before this tile's
     // LDS staging and MFMA work; activation gradient and masking happen when they are consumed
     float pg[NKO], py[NKO] = {}, px[NKI];
@@ -471,6 +498,7 @@ __global__ __launch_bounds__(64 * NW) void pwconv_bwd_fast_kernel(PwBwdArgs a) {
 #pragma unroll
         for (int j = 0; j < NKI; ++j) X[(2 * j + h) * PWB_LD + c] = vin ? px[j] : 0.f;
         if (grp + gridDim.x < ngroups) fetch(grp + gridDim.x);
+        f32x16 acc2;   // BR: Wbr^T p, rows = xb channels
 #pragma unroll
         for (int ic = 0; ic < ICH; ++ic) {
             f32x16 acc;
@@ -483,22 +511,40 @@ __global__ __launch_bounds__(64 * NW) void pwconv_bwd_fast_kernel(PwBwdArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < NKO; ++ks) acc[ks & 15] += g[ks];
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            auto store_row = [&](int r) {
                 const int irow = ic * 32 + (r & 3) + 8 * (r >> 2);
                 if (irow < CIN) {  // compile-time; rows irow, irow+4 are on one side since CA % 8 == 0
                     float *base = irow < CA ? (a.gxa ? a.gxa + ((size_t)b * CA + irow) * V : nullptr)
                                             : (a.gxb ? a.gxb + ((size_t)b * CB + (irow - CA)) * V : nullptr);
+                    float gv = acc[r];
+                    if (irow < CA && xact) {
+                        const float xo = X[(irow + 4 * h) * PWB_LD + c];
+                        gv *= xo > 0.f ? xp : xo + xq;
+                    }
+                    if (BR && irow < CA) {   // p: B operand of the branch dgrad (k-slot r), A operand of its weight gradient
+                        acc[r] = gv;
+                        P[(irow + 4 * h) * PWB_LD + c] = gv;
+                        dbb[r < RA ? r : 0] += gv;
+                    }
+                    if (BR && irow >= CA) gv += acc2[(r + 16 * ic - RA) & 15];
                     if (base && vin && (irow + 4 < CIN || h == 0) && !((a.dbg & 4) && acc[r] != 12345.678f)) {
-                        float gv = acc[r];
-                        if (irow < CA && xact) {
-                            const float xo = X[(irow + 4 * h) * PWB_LD + c];
-                            gv *= xo > 0.f ? xp : xo + xq;
-                        }
                         if (a.accum & (irow < CA ? 1 : 2)) gv += base[hoff4V + v];
                         base[hoff4V + v] = gv;
                     }
                 }
+            };
+            if (BR && ic == 0) {
+#pragma unroll
+                for (int r = 0; r < RA; ++r) store_row(r);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < RA; ++ks) acc2 = mfma32(wbr[ks], acc[ks], acc2);
+#pragma unroll
+                for (int r = RA; r < 16; ++r) store_row(r);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) store_row(r);
             }
         }
         // the LDS tile is wave-private: LDS ops of one wave execute in order, so only the compiler
@@ -516,14 +562,43 @@ __global__ __launch_bounds__(64 * NW) void pwconv_bwd_fast_kernel(PwBwdArgs a) {
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < NTI; ++n) dw[m][n] = mfma16(av[m], bv[n], dw[m][n]);
+            if (BR) {   // dWbr[o][i] += p[o][v] xb[i][v]: the xb rows start at row CA of X
+                float pv[BR ? MTP : 1], xv2[BR ? NTB : 1];
+#pragma unroll
+                for (int m = 0; m < MTP; ++m) pv[m] = pa[m * 16 * PWB_LD + ks * 4];
+#pragma unroll
+                for (int n = 0; n < NTB; ++n) xv2[n] = xbp[(CA + n * 16) * PWB_LD + ks * 4];
+#pragma unroll
+                for (int m = 0; m < MTP; ++m)
+#pragma unroll
+                    for (int n = 0; n < NTB; ++n) dwb[m][n] = mfma16(pv[m], xv2[n], dwb[m][n]);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
     {
-        constexpr int n = COUT * CIN + COUT;
+        constexpr int n = COUT * CIN + COUT + (BR ? CA * CB + CA : 0);
         __syncthreads();
         float *mine = lds + (size_t)wave * n;
+        if (BR) {   // slab tail: dWbr [o][i], dbbr [o]
+            float *mb = mine + COUT * CIN + COUT;
+#pragma unroll
+            for (int m = 0; m < MTP; ++m)
+#pragma unroll
+                for (int nn = 0; nn < NTB; ++nn)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = m * 16 + (lane >> 4) * 4 + r, i = nn * 16 + (lane & 15);
+                        if (o < CA && i < CB) mb[o * CB + i] = dwb[m][nn][r];
+                    }
+#pragma unroll
+            for (int ks = 0; ks < RA; ++ks) {
+                float sb = dbb[ks];
+                for (int off2 = 16; off2 >= 1; off2 >>= 1) sb += __shfl_xor(sb, off2);
+                if (c == 0) mb[CA * CB + (ks & 3) + 8 * (ks >> 2) + 4 * h] = sb;
+            }
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -606,7 +681,7 @@ int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const fl
 int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, const float *xb, int Cb,
                       const float *W, float *gxa, float *gxb, float *dW, float *dbias, void *workspace,
                       int B, int Cout, long long V, int act, int residual, void *stream, int xa_act = HNO_ACT_NONE,
-                      int accumulate_gx = 0) {
+                      int accumulate_gx = 0, const float *Wbr = nullptr) {   // also declared in hno_specmix.hip
     HNO_REQUIRE(workspace, "hno_pwconv_bwd: workspace of hno_pwconv_bwd_workspace_bytes() is required");
     HNO_REQUIRE(gy && xa && W && dW && Ca > 0 && Cb >= 0 && B > 0 && Cout > 0 && V > 0, "hno_pwconv_bwd: bad argument");
     HNO_REQUIRE(act == HNO_ACT_NONE || y, "hno_pwconv_bwd: saved output y needed for the activation gradient");
@@ -622,6 +697,7 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
     a.dbg = debug_flags();
     a.xa_act = xa_act;
     a.accum = accumulate_gx;
+    a.Wbr = Wbr;
     a.s_gy = (long long)Cout * V; a.s_xa = (long long)Ca * V; a.s_xb = (long long)Cb * V;
     a.s_gxa = (long long)Ca * V; a.s_gxb = (long long)Cb * V; a.ldw = Cin;
     const long long ntiles = ((V + 31) / 32) * B;
@@ -635,6 +711,26 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
         bool done = true;
         int NW = PWB_FAST_WAVES;
         const bool s2424 = Ca == 24 && Cb == 24 && Cout == 24;
+        if (Wbr) {
+            // fused conv branch: dW is ONE flat buffer [dW (Cout x Cin) | dbias (Cout) | dWbr (Ca x Cb) | dbbr (Ca)]
+            if (!s2424) return fail(HNO_ELIMIT, "hno_pwconv_bwd_branch: only the 24 + 24 -> 24 block shape is built (got %d + %d -> %d)", Ca, Cb, Cout);
+            HNO_REQUIRE(xa_act != HNO_ACT_NONE && gxa && gxb && !residual, "hno_pwconv_bwd_branch: needs the activation of xa and both input gradients");
+            long long fgb = (ntiles + PWB_FAST_WAVES - 1) / PWB_FAST_WAVES;
+            if (fgb > 512) fgb = 512;
+            auto kern = pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 1>;
+            static bool battr = false;
+            if (!battr) {
+                (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                battr = true;
+            }
+            const int nb = Cout * Cin + Cout + Ca * Cb + Ca;
+            {
+                ProfScope ps(KID_PWCONV_BWD, s, 4.0 * B * (double)V * ((act != HNO_ACT_NONE ? 2 : 1) * Cout + Cin + Ca + Cb));
+                hipLaunchKernelGGL(kern, dim3((int)fgb), dim3(64 * PWB_FAST_WAVES), sizeof(float) * PWB_FAST_WAVES * (32 + 56 + 32) * PWB_LD, s, a);
+            }
+            HNO_CHECK_LAUNCH();
+            return reduce_partials_launch(a.partials, (int)fgb, nb, dW, nb, nullptr, s);
+        }
         if (s2424 && (a.dbg & 64)) NW = 8;
         if (s2424 && (a.dbg & 128)) NW = 12;
         long long fg = (ntiles + NW - 1) / NW;
@@ -666,6 +762,7 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
             return reduce_partials_launch(a.partials, (int)fg, nslab, dW, Cout * Cin, dbias, s);
         }
     }
+    if (Wbr) return fail(HNO_ELIMIT, "hno_pwconv_bwd_branch: only the 24 + 24 -> 24 block shape is built (got %d + %d -> %d)", Ca, Cb, Cout);
     // generic path: any channel counts, processed as (<= 32 output) x (<= 64 input) channel blocks of the
     // concatenated input; input gradients accumulate over the output blocks, each weight block is reduced
     // from its own slabs into the strided sub-block of dW
@@ -750,6 +847,17 @@ __global__ void cmix_split_kernel(const float *__restrict__ dw2, float *__restri
 }  // namespace hno
 
 using namespace hno;
+
+extern "C" size_t hno_pwconv_bwd_branch_workspace_bytes(int Ca, int Cb, int Cout) {
+    return sizeof(float) * 512 * ((size_t)Cout * (Ca + Cb) + Cout + (size_t)Ca * Cb + Ca);
+}
+
+extern "C" int hno_pwconv_bwd_branch(const float *gy, const float *y, const float *xa, int Ca, const float *xb, int Cb,
+                                     const float *W, const float *Wbr, float *p_out, float *gxb, float *dflat, void *workspace,
+                                     int B, int Cout, long long V, int act, int xa_act, void *stream) {
+    HNO_REQUIRE(Wbr && dflat, "hno_pwconv_bwd_branch: null pointer");
+    return pwconv_bwd_launch(gy, y, xa, Ca, xb, Cb, W, p_out, gxb, dflat, nullptr, workspace, B, Cout, V, act, 0, stream, xa_act, 0, Wbr);
+}
 
 extern "C" int hno_cmix_compose(const float *w_real, const float *w_imag, float *w2, int Co, int Ci, void *stream) {
     HNO_REQUIRE(w_real && w_imag && w2 && Co > 0 && Ci > 0, "hno_cmix_compose: bad argument");

@@ -441,7 +441,7 @@ int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const fl
                       int Cout, long long V, int act, int residual, void *stream);
 int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, const float *xb, int Cb, const float *W,
                       float *gxa, float *gxb, float *dW, float *dbias, void *workspace, int B, int Cout, long long V, int act,
-                      int residual, void *stream, int xa_act, int accumulate_gx);
+                      int residual, void *stream, int xa_act, int accumulate_gx, const float *Wbr = nullptr);
 
 static int specmix_fwd(const float *z0, const float *const *Wl, float *zs, int B, int C, int M, int L, int residual, int act,
                        void *stream) {

@@ -23,8 +23,27 @@ class _TransBlock(nn.Module):
         self.use_block_skip = None
         self.conv_concat = None
 
+    def _fused_block(self, x, act):
+        """The whole block as one autograd node (ops.NOBlockFn) when it has the FNOSeg / HNOSeg shape: shared-weight
+        Fourier / Hartley operator with transform and without bias, SELU (no GroupNorm), concat skip."""
+        op = self.op
+        if not (isinstance(op, (FourierOperator, HartleyOperator)) and x.ndim == 5 and self.normalization is None
+                and act != ops.ACT_NONE and self.use_block_skip and self.conv_concat is not None
+                and op.weights_type == 'shared' and op.use_transform and not op.use_bias
+                and self.conv_concat.normalization is None and ops.act_id(self.conv_concat.activation) == act):
+            return None
+        fourier = isinstance(op, FourierOperator)
+        op_ws = (op.weight_real, op.weight_imag) if fourier else (op.weight,)
+        br = self.conv_branch
+        cc = self.conv_concat.op
+        return ops.NOBlockFn.apply(x, fourier, tuple(op.num_modes), act, None if br is None else br.weight,
+                                   None if br is None else br.bias, cc.weight, cc.bias, *op_ws)
+
     def forward(self, x):
         act = ops.act_id(self.activation)
+        fused = self._fused_block(x, act)
+        if fused is not None:
+            return fused
         fuse_act = act if self.normalization is None else ops.ACT_NONE
         x2 = None
         if self.conv_branch is not None:

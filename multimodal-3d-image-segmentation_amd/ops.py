@@ -168,6 +168,26 @@ def pwconv_bwd_raw(gy, y, xa, xb, W, act, has_bias, need_gxa=True, need_gxb=True
     return gxa, gxb, dW, db
 
 
+def pwconv_bwd_branch_raw(gy, y, xa, xb, W, Wbr, act, xa_act):
+    """Backward of  act(W [xa ; xb] + b)  where xa = xa_act(s + Wbr xb + bbr): one pass (hno_pwconv_bwd_branch).
+    -> (p, gxb, dW, db, dWbr, dbbr) with p the gradient of the pre-activation sum s + Wbr xb + bbr."""
+    B, Ca = xa.shape[:2]
+    Cb, Cout, V = xb.shape[1], W.shape[0], _flat_v(xa)
+    L = _lib.lib()
+    p = torch.empty_like(xa)
+    gxb = torch.empty_like(xb)
+    n_w, n_br = Cout * (Ca + Cb), Ca * Cb
+    flat = torch.empty(n_w + Cout + n_br + Ca, device=xa.device, dtype=torch.float32)
+    ws = torch.empty(L.hno_pwconv_bwd_branch_workspace_bytes(Ca, Cb, Cout) // 4, device=xa.device, dtype=torch.float32)
+    check(L.hno_pwconv_bwd_branch(ptr(gy), ptr(y), ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(Wbr), ptr(p), ptr(gxb), ptr(flat),
+                                  ptr(ws), B, Cout, V, act, xa_act, stream_ptr()), 'hno_pwconv_bwd_branch')
+    dW = flat[:n_w].view_as(W)
+    db = flat[n_w:n_w + Cout]
+    dWbr = flat[n_w + Cout:n_w + Cout + n_br].view(Ca, Cb)
+    dbbr = flat[n_w + Cout + n_br:]
+    return p, gxb, dW, db, dWbr, dbbr
+
+
 def _layer_ptrs(Ws):
     import ctypes
     return (ctypes.c_void_p * len(Ws))(*[w.data_ptr() for w in Ws])
@@ -641,6 +661,80 @@ class ComplexMixFn(torch.autograd.Function):
         dwi = torch.empty_like(dwr)
         check(_lib.lib().hno_cmix_split_grad(ptr(dw2), ptr(dwr), ptr(dwi), Co, Ci, stream_ptr()), 'hno_cmix_split_grad')
         return gx, dwr, dwi
+
+
+class NOBlockFn(torch.autograd.Function):
+    """One FNOSeg / HNOSeg block (nets/architectures.py:511-608 with shared weights, SELU, concat skip) as a single
+    autograd node:
+
+        y   = act(op(x) + conv_branch(x))          op = Fourier / Hartley operator with use_transform (crop, mix, pad)
+        out = act(conv_concat(cat[y, x]))
+
+    The block input x has three consumers (operator, conv branch, concat skip).  Owning the block lets the backward
+    accumulate the three gradients inside the kernels that produce them -- the branch conv accumulates into the
+    concat-path gradient, the inverse transform adds that sum on its store -- and take the activation gradient of y
+    inside the forward transform and the branch conv instead of a separate elementwise pass."""
+
+    @staticmethod
+    def forward(ctx, x, fourier, modes, act, br_w, br_b, cat_w, cat_b, *op_ws):
+        x, br_w, br_b, cat_w, cat_b = (_f32c(t) for t in (x, br_w, br_b, cat_w, cat_b))
+        op_ws = [_f32c(w) for w in op_ws]
+        _need_gpu(x, cat_w, *op_ws)
+        spatial = tuple(x.shape[2:])
+        modes = clamp_modes(modes, spatial)
+        n3 = float(np.prod(spatial))
+        x2 = pwconv_fwd_raw(x, None, br_w, br_b, ACT_NONE) if br_w is not None else None
+        if fourier:
+            wr, wi = op_ws
+            Co, Ci = wr.shape
+            w = torch.empty((2 * Co, 2 * Ci), device=x.device, dtype=torch.float32)
+            check(_lib.lib().hno_cmix_compose(ptr(wr), ptr(wi), ptr(w), Co, Ci, stream_ptr()), 'hno_cmix_compose')
+            s0 = rfft3_crop_raw(x, modes, 1.0 / n3, False)
+            s1 = pwconv_fwd_raw(s0, None, w, None, ACT_NONE)
+            y = irfft3_pad_raw(s1, spatial, 1.0, True, x2, act)
+        else:
+            (w,) = op_ws
+            s0 = dht3_crop_raw(x, modes, 1.0 / n3)
+            s1 = pwconv_fwd_raw(s0, None, w, None, ACT_SELU)      # SELU in the frequency domain (hartley_operator.py:262-269)
+            y = pad_idht3_raw(s1, spatial, 1.0, x2, act)
+        out = pwconv_fwd_raw(y, x, cat_w, cat_b, act)
+        ctx.save_for_backward(x, br_w, cat_w, w, s0, s1 if not fourier else None, y, out)
+        ctx.cfg = (bool(fourier), modes, act, spatial, n3, br_b is not None, cat_b is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, br_w, cat_w, w, s0, s1, y, out = ctx.saved_tensors
+        fourier, modes, act, spatial, n3, br_has_b, cat_has_b = ctx.cfg
+        d_br_w = d_br_b = None
+        if br_w is not None and tuple(cat_w.shape[:2]) == (24, 48) and tuple(br_w.shape[:2]) == (24, 24):
+            # one pass: p = d loss / d (s + x2) = g_y * act'(y); g_x = concat-path gradient + Wbr^T p; all four parameter gradients
+            p, g_x, d_cat_w, d_cat_b, d_br_w, d_br_b = pwconv_bwd_branch_raw(_f32c(g_out), out, y, x, cat_w, br_w, act, act)
+            d_br_w = d_br_w.view_as(br_w)
+            if not cat_has_b:
+                d_cat_b = None
+            if not br_has_b:
+                d_br_b = None
+        else:
+            # p through the conv's xa_act product; the branch conv (its output gradient is p) adds its input gradient to g_x
+            p, g_x, d_cat_w, d_cat_b = pwconv_bwd_raw(_f32c(g_out), out, y, x, cat_w, act, cat_has_b, xa_act=act)
+            if br_w is not None:
+                _, _, d_br_w, d_br_b = pwconv_bwd_raw(p, None, x, None, br_w, ACT_NONE, br_has_b, accumulate_into=(g_x, None))
+        if fourier:
+            gs1 = rfft3_crop_raw(p, modes, 1.0, True)
+            gs0, _, dw2, _ = pwconv_bwd_raw(gs1, None, s0, None, w, ACT_NONE, False)
+            Co, Ci = w.shape[0] // 2, w.shape[1] // 2
+            dwr = torch.empty((Co, Ci), device=x.device, dtype=torch.float32)
+            dwi = torch.empty_like(dwr)
+            check(_lib.lib().hno_cmix_split_grad(ptr(dw2), ptr(dwr), ptr(dwi), Co, Ci, stream_ptr()), 'hno_cmix_split_grad')
+            gx = irfft3_pad_raw(gs0, spatial, 1.0 / n3, False, g_x, ACT_NONE)
+            d_ops = (dwr, dwi)
+        else:
+            gs1 = dht3_crop_raw(p, modes, 1.0)
+            gs0, _, dw, _ = pwconv_bwd_raw(gs1, s1, s0, None, w, ACT_SELU, False)
+            gx = pad_idht3_raw(gs0, spatial, 1.0 / n3, g_x, ACT_NONE)
+            d_ops = (dw,)
+        return (gx, None, None, None, d_br_w, d_br_b, d_cat_w, d_cat_b) + d_ops
 
 
 class XSBlockFn(torch.autograd.Function):

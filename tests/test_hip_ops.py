@@ -787,3 +787,30 @@ def test_input_data_flow_feeds_training(pkg, tmp_path):
     training(model, data, str(out_dir), custom_losses.PCCLoss(), opt, num_epochs=2, selection_epoch_portion=0.5, is_print=False,
              device='cuda')
     assert (out_dir / 'model' / 'model.pt').exists()
+
+
+@pytest.mark.parametrize('shape,act', [((2, 7, 9, 11), 'selu'), ((1, 5, 6, 33), 'elu'), ((3, 4, 4, 4), 'selu')])
+def test_pwconv_bwd_fused_branch(pkg, shape, act):
+    """hno_pwconv_bwd_branch (concat conv + conv branch backward in one pass) against torch autograd on the CPU in fp64:
+    y = act(s + Wbr x + bbr); out = act(Wcat [y ; x] + bcat)."""
+    from multimodal_3d_image_segmentation_amd import ops
+    B, sp = shape[0], shape[1:]
+    a = ops.act_id(act)
+    f = getattr(F, act)
+    torch.manual_seed(5)
+    x = torch.randn((B, 24) + sp, dtype=torch.float64, requires_grad=True)
+    s_ = torch.randn((B, 24) + sp, dtype=torch.float64, requires_grad=True)
+    wbr = (torch.randn(24, 24, dtype=torch.float64) * 0.2).requires_grad_(True)
+    bbr = (torch.randn(24, dtype=torch.float64) * 0.1).requires_grad_(True)
+    wcat = (torch.randn(24, 48, dtype=torch.float64) * 0.15).requires_grad_(True)
+    bcat = (torch.randn(24, dtype=torch.float64) * 0.1).requires_grad_(True)
+    bc = lambda t: t.reshape(1, -1, 1, 1, 1)   # noqa: E731
+    y = f(s_ + torch.einsum('oi,bidhw->bodhw', wbr, x) + bc(bbr))
+    out = f(torch.einsum('oi,bidhw->bodhw', wcat, torch.cat([y, x], 1)) + bc(bcat))
+    g = torch.randn_like(out)
+    want = torch.autograd.grad((out * g).sum(), [s_, x, wcat, bcat, wbr, bbr])
+    c = lambda t: t.detach().float().cuda().contiguous()   # noqa: E731
+    got = ops.pwconv_bwd_branch_raw(c(g), c(out), c(y), c(x), c(wcat), c(wbr), a, a)
+    names = ['p', 'gx', 'dWcat', 'dbcat', 'dWbr', 'dbbr']
+    for n, w_, g_ in zip(names, want, got):
+        assert rel_err(g_.cpu().numpy().reshape(w_.shape), w_.numpy()) < 2e-5, n
