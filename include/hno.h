@@ -141,6 +141,11 @@ int hno_pwconv_bwd(const float *gy, const float *y, const float *xa, int Ca, con
  *   dflat = [ dW (Cout x (Ca+Cb)) | dbias (Cout) | dWbr (Ca x Cb) | dbbr (Ca) ]   (one flat buffer)
  * where g = gy * act'(y).  xa_act names the activation of xa (required).  Built for Ca = Cb = Cout = 24 (HNO_ELIMIT
  * otherwise: call hno_pwconv_bwd twice).  Workspace: hno_pwconv_bwd_branch_workspace_bytes. */
+/* forward twin: y = act(s + Wbr xb + bbr); out = act(W [y ; xb] + bias) in one pass (y is written because the backward
+ * needs it).  s: the operator output (B, Ca, V).  Same shape limit. */
+int hno_pwconv_fwd_branch(const float *s, const float *xb, const float *Wbr, const float *bbr, const float *W,
+                          const float *bias, float *y, float *out, int B, int Ca, int Cb, int Cout, long long V,
+                          int act, void *stream);
 size_t hno_pwconv_bwd_branch_workspace_bytes(int Ca, int Cb, int Cout);
 int hno_pwconv_bwd_branch(const float *gy, const float *y, const float *xa, int Ca, const float *xb, int Cb,
                           const float *W, const float *Wbr, float *p_out, float *gxb, float *dflat, void *workspace,

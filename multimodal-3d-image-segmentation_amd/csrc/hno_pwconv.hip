@@ -389,6 +389,89 @@ __global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_fast_kernel(Pw
     }
 }
 
+// ---- forward of the FNOSeg / HNOSeg block tail in one pass (nets/architectures.py:521-546) -------------------
+//   y   = act(s + Wbr x + bbr)            s: operator output (inverse transform), x: block input, Wbr: conv_branch
+//   out = act(Wc [y ; x] + bc)            conv_concat over the virtual concat
+// The first product's accumulator rows are the second product's B operand: k-slot (r, h) of the y part carries channel
+// (r & 3) + 8 (r >> 2) + 4 h, and the y columns of Wc are loaded in that order, so y never leaves registers between the
+// two products.  Reads s, x; writes y (saved for the backward) and out: 4 streams instead of 8 for three separate kernels.
+struct PwBranchArgs {
+    const float *s, *x, *Wbr, *bbr, *W, *bias;
+    float *y, *out;
+    int B;
+    unsigned V;
+    int act;
+};
+
+template <int CA, int CB, int COUT>
+__global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_branch_kernel(PwBranchArgs a) {
+    static_assert(CA % 8 == 0 && CA <= 32 && CB % 8 == 0 && COUT <= 32 && COUT % 8 == 0, "one 32-row tile per product");
+    constexpr int NW = PWF_FAST_WAVES;
+    constexpr int RA = CA / 2, RO = COUT / 2, NKX = CB / 2, CIN = CA + CB;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, c = lane & 31;
+    const unsigned V = a.V;
+    float wbr[NKX], wcx[NKX], wcy[RA], bb[RA], bc[RO];
+#pragma unroll
+    for (int ks = 0; ks < NKX; ++ks) {
+        wbr[ks] = c < CA ? a.Wbr[(size_t)c * CB + 2 * ks + h] : 0.f;
+        wcx[ks] = c < COUT ? a.W[(size_t)c * CIN + CA + 2 * ks + h] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+        const int ch = (r & 3) + 8 * (r >> 2) + 4 * h;
+        wcy[r] = c < COUT ? a.W[(size_t)c * CIN + ch] : 0.f;
+        bb[r] = a.bbr ? a.bbr[ch] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < RO; ++r) bc[r] = a.bias ? a.bias[(r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+    const float ap = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f;
+    const float aq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
+    const bool lin = a.act == HNO_ACT_NONE;
+    const unsigned tiles_per_b = (V + 31) / 32;
+    const unsigned ntiles = tiles_per_b * a.B;
+    const unsigned hoffV = h ? V : 0u, hoff4V = h ? 4u * V : 0u;
+    for (unsigned t = blockIdx.x * NW + wave; t < ntiles; t += gridDim.x * NW) {
+        const unsigned b = t / tiles_per_b;
+        const unsigned v = (t - b * tiles_per_b) * 32 + c;
+        const bool vin = v < V;
+        const unsigned vc = vin ? v : 0u;
+        const float *x_b = a.x + (size_t)b * CB * V, *s_b = a.s + (size_t)b * CA * V;
+        float xv[NKX], sv[RA];
+#pragma unroll
+        for (int ks = 0; ks < NKX; ++ks) xv[ks] = (x_b + (size_t)(2 * ks) * V)[hoffV + vc];
+#pragma unroll
+        for (int r = 0; r < RA; ++r) sv[r] = (s_b + (size_t)((r & 3) + 8 * (r >> 2)) * V)[hoff4V + vc];
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKX; ++ks) acc = mfma32(wbr[ks], xv[ks], acc);
+        float *y_b = a.y + (size_t)b * CA * V;
+        float yv[RA];
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+            const float u = acc[r] + sv[r] + bb[r];
+            yv[r] = (u > 0.f || lin) ? ap * u : aq * neg_expm1(u);
+            if (vin) (y_b + (size_t)((r & 3) + 8 * (r >> 2)) * V)[hoff4V + v] = yv[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < RA; ++r) acc = mfma32(wcy[r], yv[r], acc);
+#pragma unroll
+        for (int ks = 0; ks < NKX; ++ks) acc = mfma32(wcx[ks], xv[ks], acc);
+        float *o_b = a.out + (size_t)b * COUT * V;
+#pragma unroll
+        for (int r = 0; r < RO; ++r) {
+            const float u = acc[r] + bc[r];
+            const float val = (u > 0.f || lin) ? ap * u : aq * neg_expm1(u);
+            if (vin) (o_b + (size_t)((r & 3) + 8 * (r >> 2)) * V)[hoff4V + v] = val;
+        }
+    }
+}
+
 #define PWB_FAST_WAVES 4   // 256-thread blocks, two per CU (512 slabs): measured best of {4, 8, 12} waves x {256, 512, 1024} blocks
 template <int COUT, int CA, int CB, int NW = PWB_FAST_WAVES, int BR = 0>   // compile-time channel counts: every address select folds
 __global__ __launch_bounds__(64 * NW, (BR && NW == 4) ? 2 : 1) void pwconv_bwd_fast_kernel(PwBwdArgs a) {
@@ -847,6 +930,27 @@ __global__ void cmix_split_kernel(const float *__restrict__ dw2, float *__restri
 }  // namespace hno
 
 using namespace hno;
+
+extern "C" int hno_pwconv_fwd_branch(const float *s_in, const float *x, const float *Wbr, const float *bbr, const float *W,
+                                     const float *bias, float *y, float *out, int B, int Ca, int Cb, int Cout, long long V,
+                                     int act, void *stream) {
+    HNO_REQUIRE(s_in && x && Wbr && W && y && out && B > 0 && V > 0, "hno_pwconv_fwd_branch: bad argument");
+    if (!(Ca == 24 && Cb == 24 && Cout == 24))
+        return fail(HNO_ELIMIT, "hno_pwconv_fwd_branch: only the 24 + 24 -> 24 block shape is built (got %d + %d -> %d)", Ca, Cb, Cout);
+    if (V * 8 >= (1ll << 32) || ((V + 31) / 32) * B >= (1ll << 31))
+        return fail(HNO_ELIMIT, "hno_pwconv_fwd_branch: V=%lld voxels per channel exceeds the 32-bit offset range", V);
+    PwBranchArgs a;
+    a.s = s_in; a.x = x; a.Wbr = Wbr; a.bbr = bbr; a.W = W; a.bias = bias; a.y = y; a.out = out;
+    a.B = B; a.V = (unsigned)V; a.act = act;
+    const long long ntiles = ((V + 31) / 32) * B;
+    long long grid = (ntiles + PWF_FAST_WAVES - 1) / PWF_FAST_WAVES;
+    if (grid > 256) grid = 256;   // one block per CU
+    hipStream_t fs = (hipStream_t)stream;
+    ProfScope ps(KID_PWCONV_FWD, fs, 4.0 * B * (double)V * (2 * Ca + Cb + Cout));
+    hipLaunchKernelGGL((pwconv_fwd_branch_kernel<24, 24, 24>), dim3((int)grid), dim3(64 * PWF_FAST_WAVES), 0, fs, a);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
 
 extern "C" size_t hno_pwconv_bwd_branch_workspace_bytes(int Ca, int Cb, int Cout) {
     return sizeof(float) * 512 * ((size_t)Cout * (Ca + Cb) + Cout + (size_t)Ca * Cb + Ca);

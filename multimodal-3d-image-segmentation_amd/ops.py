@@ -683,7 +683,10 @@ class NOBlockFn(torch.autograd.Function):
         spatial = tuple(x.shape[2:])
         modes = clamp_modes(modes, spatial)
         n3 = float(np.prod(spatial))
-        x2 = pwconv_fwd_raw(x, None, br_w, br_b, ACT_NONE) if br_w is not None else None
+        # 24 + 24 -> 24 with a conv branch: branch conv, add, activation and concat conv in one pass after the inverse
+        fuse_tail = br_w is not None and tuple(cat_w.shape[:2]) == (24, 48) and tuple(br_w.shape[:2]) == (24, 24)
+        x2 = pwconv_fwd_raw(x, None, br_w, br_b, ACT_NONE) if (br_w is not None and not fuse_tail) else None
+        inv_act = ACT_NONE if fuse_tail else act
         if fourier:
             wr, wi = op_ws
             Co, Ci = wr.shape
@@ -691,13 +694,18 @@ class NOBlockFn(torch.autograd.Function):
             check(_lib.lib().hno_cmix_compose(ptr(wr), ptr(wi), ptr(w), Co, Ci, stream_ptr()), 'hno_cmix_compose')
             s0 = rfft3_crop_raw(x, modes, 1.0 / n3, False)
             s1 = pwconv_fwd_raw(s0, None, w, None, ACT_NONE)
-            y = irfft3_pad_raw(s1, spatial, 1.0, True, x2, act)
+            y = irfft3_pad_raw(s1, spatial, 1.0, True, x2, inv_act)
         else:
             (w,) = op_ws
             s0 = dht3_crop_raw(x, modes, 1.0 / n3)
             s1 = pwconv_fwd_raw(s0, None, w, None, ACT_SELU)      # SELU in the frequency domain (hartley_operator.py:262-269)
-            y = pad_idht3_raw(s1, spatial, 1.0, x2, act)
-        out = pwconv_fwd_raw(y, x, cat_w, cat_b, act)
+            y = pad_idht3_raw(s1, spatial, 1.0, x2, inv_act)
+        if fuse_tail:
+            sop, y, out = y, torch.empty_like(x), torch.empty_like(x)
+            check(_lib.lib().hno_pwconv_fwd_branch(ptr(sop), ptr(x), ptr(br_w), ptr(br_b), ptr(cat_w), ptr(cat_b), ptr(y), ptr(out),
+                                                   x.shape[0], 24, 24, 24, _flat_v(x), act, stream_ptr()), 'hno_pwconv_fwd_branch')
+        else:
+            out = pwconv_fwd_raw(y, x, cat_w, cat_b, act)
         ctx.save_for_backward(x, br_w, cat_w, w, s0, s1 if not fourier else None, y, out)
         ctx.cfg = (bool(fourier), modes, act, spatial, n3, br_b is not None, cat_b is not None)
         return out

@@ -814,3 +814,11 @@ def test_pwconv_bwd_fused_branch(pkg, shape, act):
     names = ['p', 'gx', 'dWcat', 'dbcat', 'dWbr', 'dbbr']
     for n, w_, g_ in zip(names, want, got):
         assert rel_err(g_.cpu().numpy().reshape(w_.shape), w_.numpy()) < 2e-5, n
+    # forward twin: y and out from (s, x) in one pass
+    yk, ok = torch.empty_like(c(y)), torch.empty_like(c(out))
+    L, P = pkg._lib.lib(), pkg._lib.ptr
+    keep = [c(t) for t in (s_, x, wbr, bbr, wcat, bcat)]   # device copies must outlive the raw-pointer call
+    pkg._lib.check(L.hno_pwconv_fwd_branch(*[P(t) for t in keep], P(yk), P(ok), B, 24, 24, 24,
+                                           int(np.prod(sp)), a, pkg._lib.stream_ptr()), 'hno_pwconv_fwd_branch')
+    assert rel_err(yk.cpu().numpy(), y.detach().numpy()) < 2e-6
+    assert rel_err(ok.cpu().numpy(), out.detach().numpy()) < 2e-6
