@@ -616,7 +616,25 @@ __global__ __launch_bounds__(64 * NW, (BR && NW == 4) ? 2 : 1) void pwconv_bwd_f
                     }
                 }
             };
-            if (BR && ic == 0) {
+            if constexpr (BR == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int irow = ic * 32 + (r & 3) + 8 * (r >> 2);
+                    if (irow < CIN) {  // compile-time; rows irow, irow+4 are on one side since CA % 8 == 0
+                        float *base = irow < CA ? (a.gxa ? a.gxa + ((size_t)b * CA + irow) * V : nullptr)
+                                                : (a.gxb ? a.gxb + ((size_t)b * CB + (irow - CA)) * V : nullptr);
+                        if (base && vin && (irow + 4 < CIN || h == 0) && !((a.dbg & 4) && acc[r] != 12345.678f)) {
+                            float gv = acc[r];
+                            if (irow < CA && xact) {
+                                const float xo = X[(irow + 4 * h) * PWB_LD + c];
+                                gv *= xo > 0.f ? xp : xo + xq;
+                            }
+                            if (a.accum & (irow < CA ? 1 : 2)) gv += base[hoff4V + v];
+                            base[hoff4V + v] = gv;
+                        }
+                    }
+                }
+            } else if (ic == 0) {
 #pragma unroll
                 for (int r = 0; r < RA; ++r) store_row(r);
 #pragma unroll
