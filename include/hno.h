@@ -198,12 +198,16 @@ int hno_upsoftmax_bwd(const float *g_probs, const float *probs, float *g_lr, voi
  * nets/architectures.py:105-155).  hno_conv3d_k3 mode: 0 = Conv3d forward (W (Cout,Cin,3,3,3), stride 1 or 2,
  * padding 1); 1 = its input gradient (x = dL/dy with the conv's OUTPUT dims as Di.., y = dL/dx); 2 =
  * ConvTranspose3d forward (Wt (Cin,Cout,3,3,3), stride 2, padding 1, output_padding 1); 3 = its input
- * gradient.  Cin / Cout always name the ORIGINAL operator's channels.  workspace:
- * hno_conv3d_k3_workspace_bytes(Cin, Cout, 0).  hno_conv3d_k3_wgrad writes dW (same layout as the weight);
+ * gradient.  Cin / Cout always name the ORIGINAL operator's channels.  workspace: at least
+ * hno_conv3d_k3_workspace_bytes(Cin, Cout, 0) (weight re-layout); with hno_conv3d_k3_fwd_workspace_bytes(mode, B, ...,
+ * Do, Ho, Wo) bytes (Do.. = dims of THIS call's output y) small grids are additionally split over the 27 taps so that the
+ * deep V-Net levels fill the chip.  hno_conv3d_k3_wgrad writes dW (same layout as the weight);
  * Dx.. are the operator's input dims, Dg.. its output dims; workspace: ..._workspace_bytes(Cin, Cout, 1). */
 size_t hno_conv3d_k3_workspace_bytes(int Cin, int Cout, int for_wgrad);
-int hno_conv3d_k3(const float *x, const float *W, const float *bias, float *y, void *workspace, int mode, int B, int Cin,
-                  int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int stride, int pad, int act, void *stream);
+size_t hno_conv3d_k3_fwd_workspace_bytes(int mode, int B, int Cin, int Cout, int Do, int Ho, int Wo);
+int hno_conv3d_k3(const float *x, const float *W, const float *bias, float *y, void *workspace, size_t workspace_bytes,
+                  int mode, int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int stride, int pad,
+                  int act, void *stream);
 int hno_conv3d_k3_wgrad(const float *g, const float *x, float *dW, void *workspace, int transposed, int B, int Cin, int Cout,
                         int Dx, int Hx, int Wx, int Dg, int Hg, int Wg, int stride, int pad, void *stream);
 /* GroupNorm(1, C) + activation (nn.GroupNorm(1, C) after every V-Net conv, nets/nets_utils.py:165-170).
@@ -219,7 +223,8 @@ int hno_groupnorm1_bwd(const float *g, const float *y, const float *x, const flo
 int hno_nearest3d(const float *src, float *dst, int BC, int d, int h, int w, int D, int H, int W, int adjoint, int accumulate,
                   void *stream);
 /* out[c] = sum_{b,v} g[b][c][v] (bias gradient of the 3x3x3 convolutions) */
-int hno_channel_sum(const float *g, float *out, int B, int C, long long V, void *stream);
+size_t hno_channel_sum_workspace_bytes(int C);
+int hno_channel_sum(const float *g, float *out, void *workspace, int B, int C, long long V, void *stream);
 
 /* ------------------------------------------------------- per-mode ('individual') spectral weights
  * Hartley (fourier = 0): y(k) = 1/2 [W(k)(x(k) + xr(k)) + W(-k)(x(k) - xr(k))] with xr = the frequency-

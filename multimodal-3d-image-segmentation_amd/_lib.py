@@ -47,12 +47,14 @@ SIGNATURES = {
     'hno_upsoftmax_bwd_workspace_bytes': (c_size_t, [c_int] * 8),
     'hno_upsoftmax_bwd': (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
     'hno_conv3d_k3_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
-    'hno_conv3d_k3': (c_int, [c_void_p] * 5 + [c_int] * 13 + [c_void_p]),
+    'hno_conv3d_k3_fwd_workspace_bytes': (c_size_t, [c_int] * 7),
+    'hno_conv3d_k3': (c_int, [c_void_p] * 5 + [c_size_t] + [c_int] * 13 + [c_void_p]),
     'hno_conv3d_k3_wgrad': (c_int, [c_void_p] * 4 + [c_int] * 12 + [c_void_p]),
     'hno_groupnorm1_fwd': (c_int, [c_void_p] * 6 + [c_int, c_int, c_ll, c_float, c_int, c_void_p]),
     'hno_groupnorm1_bwd': (c_int, [c_void_p] * 10 + [c_int, c_int, c_ll, c_int, c_void_p]),
     'hno_nearest3d': (c_int, [c_void_p] * 2 + [c_int] * 9 + [c_void_p]),
-    'hno_channel_sum': (c_int, [c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p]),
+    'hno_channel_sum_workspace_bytes': (c_size_t, [c_int]),
+    'hno_channel_sum': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p]),
     'hno_permode_fwd': (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
     'hno_permode_bwd': (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_void_p]),
     'hno_bmm': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_float, c_void_p]),

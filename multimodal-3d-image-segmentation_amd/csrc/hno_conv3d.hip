@@ -26,6 +26,10 @@ struct C3Args {
     int Di, Hi, Wi, Do, Ho, Wo;
     int stride, pad, frac;  // frac = 1: fractionally strided gather
     int act;
+    // split-K over the taps for small grids (deep V-Net levels: a 6 x 7 x 5 grid is 2 voxel tiles): gridDim.z slices of
+    // 27 / ksplit taps write raw partial sums to `part` [z][b][o][v]; c3_splitk_finish_kernel adds them, bias and activation
+    int ksplit;
+    float *part;
 };
 
 // weight re-layout: dst[(t * Cin_g + i) * Cout_g + o] where the GEMM's "input" / "output" channels may be
@@ -155,7 +159,8 @@ __global__ __launch_bounds__(256) void c3_igemm_kernel(C3Args a) {
     const size_t Vi = (size_t)a.Di * a.Hi * a.Wi, Vo = (size_t)a.Do * a.Ho * a.Wo;
     const int vt = (int)((Vo + BN - 1) / BN);
     const int b = blockIdx.x / vt, v0 = (blockIdx.x - b * vt) * BN, o0 = blockIdx.y * BM;
-    const int K = 27 * a.CinP;
+    const int Kz = (27 / a.ksplit) * a.CinP;          // reduction range of this slice
+    const int kbeg = blockIdx.z * Kz, K = kbeg + Kz;
     // this thread's voxel column and its output coordinates
     const int col = tid % BN, row0 = tid / BN;
     const int v = v0 + col;
@@ -222,11 +227,11 @@ __global__ __launch_bounds__(256) void c3_igemm_kernel(C3Args a) {
         for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    fetch(0);
+    fetch(kbeg);
     stage(0);
     __syncthreads();
     int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += C3I_K, buf ^= 1) {
+    for (int k0 = kbeg; k0 < K; k0 += C3I_K, buf ^= 1) {
         const bool more = k0 + C3I_K < K;
         if (more) fetch(k0 + C3I_K);
         const float *Ac = As[buf] + (lane >> 5) * LDA + wm + (lane & 31);
@@ -255,10 +260,23 @@ __global__ __launch_bounds__(256) void c3_igemm_kernel(C3Args a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int o = o0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (o < a.Cout) a.y[((size_t)b * a.Cout + o) * Vo + vcol] = act_apply(acc[i][j][r] + (a.bias ? a.bias[o] : 0.f), a.act);
+                    if (o >= a.Cout) continue;
+                    const size_t idx = ((size_t)b * a.Cout + o) * Vo + vcol;
+                    if (a.ksplit > 1) a.part[(size_t)blockIdx.z * a.B * a.Cout * Vo + idx] = acc[i][j][r];
+                    else a.y[idx] = act_apply(acc[i][j][r] + (a.bias ? a.bias[o] : 0.f), a.act);
                 }
             }
         }
+}
+
+__global__ __launch_bounds__(256) void c3_splitk_finish_kernel(const float *__restrict__ part, const float *__restrict__ bias,
+                                                               float *__restrict__ y, int ksplit, int Cout, long long Vo, long long n, int act) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        float t = 0.f;
+        for (int z = 0; z < ksplit; ++z) t += part[(size_t)z * n + e];
+        const int o = (int)((e / Vo) % Cout);
+        y[e] = act_apply(t + (bias ? bias[o] : 0.f), act);
+    }
 }
 
 // ---- weight gradient: dW[o][i][t] = sum_v g[o][v] * x[i][in(v, t)]  (g on the "output" grid) ----------------
@@ -575,19 +593,33 @@ __global__ __launch_bounds__(256) void nn_down_kernel(NnArgs a) {  // src = high
     }
 }
 
-// out[c] = sum over batch and voxels of g[b][c][v] (bias gradient of a convolution); one block per channel
-__global__ __launch_bounds__(256) void chan_sum_kernel(const float *__restrict__ g, float *__restrict__ out, int B, int C, long long V) {
-    const int c = blockIdx.x;
+// out[c] = sum over batch and voxels of g[b][c][v] (bias gradient of a convolution): gridDim.y slices per channel write
+// fp64 partials (fixed order -> reproducible), a second tiny kernel adds them; one slice writes out[] directly
+__global__ __launch_bounds__(256) void chan_sum_kernel(const float *__restrict__ g, float *__restrict__ out, double *__restrict__ part,
+                                                       int B, int C, long long V) {
+    const int c = blockIdx.x, S = gridDim.y;
     double s = 0.0;
     for (int b = 0; b < B; ++b) {
         const float *p = g + ((size_t)b * C + c) * V;
-        for (long long i = threadIdx.x; i < V; i += 256) s += p[i];
+        for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < V; i += 256ll * S) s += p[i];
     }
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
     __shared__ double red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[c] = (float)(red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        const double t = red[0] + red[1] + red[2] + red[3];
+        if (S == 1) out[c] = (float)t;
+        else part[(size_t)c * S + blockIdx.y] = t;
+    }
+}
+
+__global__ void chan_sum_finish_kernel(const double *__restrict__ part, float *__restrict__ out, int C, int S) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double t = 0.0;
+    for (int j = 0; j < S; ++j) t += part[(size_t)c * S + j];
+    out[c] = (float)t;
 }
 
 static int g1(size_t n) {
@@ -609,9 +641,25 @@ extern "C" size_t hno_conv3d_k3_workspace_bytes(int Cin, int Cout, int for_wgrad
 // mode 0: y = conv(x, W[Cout][Cin][27], stride, pad) ; mode 1: input gradient of that conv (x = dL/dy, y = dL/dx,
 // Cin/Cout are those of the ORIGINAL conv) ; mode 2: ConvTranspose3d forward with Wt[Cin][Cout][27] ;
 // mode 3: input gradient of that transposed conv.
-extern "C" int hno_conv3d_k3(const float *x, const float *W, const float *bias, float *y, void *workspace, int mode, int B,
-                             int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int stride, int pad, int act,
-                             void *stream) {
+static int c3_pick_ksplit(int B, int gemm_cout, long long Vo) {
+    const long long blocks0 = (long long)B * ((Vo + 127) / 128) * (gemm_cout <= 32 ? (gemm_cout + 31) / 32 : (gemm_cout + 63) / 64);
+    if (blocks0 >= 384) return 1;
+    if (blocks0 * 3 >= 512) return 3;
+    if (blocks0 * 9 >= 512) return 9;
+    return 27;
+}
+
+extern "C" size_t hno_conv3d_k3_fwd_workspace_bytes(int mode, int B, int Cin, int Cout, int Do, int Ho, int Wo) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    const int gco = (mode == 0 || mode == 2) ? Cout : Cin;     // the GEMM's output channels (see hno_conv3d_k3)
+    const long long Vo = (long long)Do * Ho * Wo;
+    const int ks = c3_pick_ksplit(B, gco, Vo);
+    return hno_conv3d_k3_workspace_bytes(Cin, Cout, 0) + (ks > 1 ? sizeof(float) * ks * (size_t)B * gco * Vo : 0);
+}
+
+extern "C" int hno_conv3d_k3(const float *x, const float *W, const float *bias, float *y, void *workspace, size_t workspace_bytes,
+                             int mode, int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int stride,
+                             int pad, int act, void *stream) {
     HNO_REQUIRE(x && W && y && workspace && B > 0 && Cin > 0 && Cout > 0, "hno_conv3d_k3: bad argument");
     HNO_REQUIRE(mode >= 0 && mode <= 3 && (stride == 1 || stride == 2), "hno_conv3d_k3: bad mode / stride");
     hipStream_t s = (hipStream_t)stream;
@@ -635,16 +683,32 @@ extern "C" int hno_conv3d_k3(const float *x, const float *W, const float *bias, 
     hipLaunchKernelGGL(c3_relayout_kernel, dim3(g1((size_t)C0 * C1 * 27)), dim3(256), 0, s, W, wt, C0, C1, out_is_axis0, flip, a.CinP);
     HNO_CHECK_LAUNCH();
     const long long Vo = (long long)Do * Ho * Wo;
+    a.ksplit = 1;
+    a.part = nullptr;
     if (!(debug_flags() & 16)) {
+        // split-K when the grid alone cannot fill the chip and the caller's workspace has room for the partial sums
+        const size_t relayout = hno_conv3d_k3_workspace_bytes(Cin, Cout, 0);
+        const long long nout = (long long)B * a.Cout * Vo;
+        int ks = c3_pick_ksplit(B, a.Cout, Vo);
+        while (ks > 1 && workspace_bytes < relayout + sizeof(float) * ks * (size_t)nout) ks /= 3;
+        if (ks > 1) {
+            a.ksplit = ks;
+            a.part = (float *)((char *)workspace + relayout);
+        }
         // output-channel tile 32 (1 x 4 waves, 128 voxels) up to 32 channels, else 64 (2 x 2 waves, 128 voxels)
         if (a.Cout <= 32) {
-            const dim3 g((unsigned)(B * ((Vo + 127) / 128)), (a.Cout + 31) / 32);
+            const dim3 g((unsigned)(B * ((Vo + 127) / 128)), (a.Cout + 31) / 32, ks);
             hipLaunchKernelGGL((c3_igemm_kernel<1, 4, 1, 1>), g, dim3(256), 0, s, a);
         } else {
-            const dim3 g((unsigned)(B * ((Vo + 127) / 128)), (a.Cout + 63) / 64);
+            const dim3 g((unsigned)(B * ((Vo + 127) / 128)), (a.Cout + 63) / 64, ks);
             hipLaunchKernelGGL((c3_igemm_kernel<2, 2, 1, 2>), g, dim3(256), 0, s, a);
         }
         HNO_CHECK_LAUNCH();
+        if (ks > 1) {
+            hipLaunchKernelGGL(c3_splitk_finish_kernel, dim3(g1((size_t)nout)), dim3(256), 0, s, (const float *)a.part, a.bias, y, ks, a.Cout,
+                               Vo, nout, a.act);
+            HNO_CHECK_LAUNCH();
+        }
         return HNO_OK;
     }
     const int octiles = (a.Cout + 31) / 32;
@@ -756,10 +820,24 @@ extern "C" int hno_nearest3d(const float *src, float *dst, int BC, int d, int h,
     return HNO_OK;
 }
 
-extern "C" int hno_channel_sum(const float *g, float *out, int B, int C, long long V, void *stream) {
+extern "C" size_t hno_channel_sum_workspace_bytes(int C) { return C > 0 ? sizeof(double) * 64 * (size_t)C : 0; }
+
+extern "C" int hno_channel_sum(const float *g, float *out, void *workspace, int B, int C, long long V, void *stream) {
     HNO_REQUIRE(g && out && B > 0 && C > 0 && V > 0, "hno_channel_sum: bad argument");
-    ProfScope _ps(KID_RESAMPLE, (hipStream_t)stream, 4.0 * B * C * (double)V);
-    hipLaunchKernelGGL(chan_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, g, out, B, C, V);
+    if (C > 65535) return fail(HNO_ELIMIT, "hno_channel_sum: %d channels (max 65535)", C);
+    // enough slices to fill the chip (>= ~1024 workgroups), each with at least 16 K elements; without a workspace one slice
+    long long S = workspace ? (B * V) / 16384 : 1;
+    const long long want = (1024 + C - 1) / C;
+    if (S > want) S = want;
+    if (S > 64) S = 64;
+    if (S < 1) S = 1;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope _ps(KID_RESAMPLE, s, 4.0 * B * C * (double)V);
+    hipLaunchKernelGGL(chan_sum_kernel, dim3(C, (unsigned)S), dim3(256), 0, s, g, out, (double *)workspace, B, C, V);
     HNO_CHECK_LAUNCH();
+    if (S > 1) {
+        hipLaunchKernelGGL(chan_sum_finish_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, (const double *)workspace, out, C, (int)S);
+        HNO_CHECK_LAUNCH();
+    }
     return HNO_OK;
 }

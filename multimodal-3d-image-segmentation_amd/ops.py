@@ -337,15 +337,19 @@ def _conv_ws(cin, cout, wgrad, device):
 def _chan_sum(g):
     B, C = g.shape[:2]
     out = torch.empty(C, device=g.device, dtype=torch.float32)
-    check(_lib.lib().hno_channel_sum(ptr(g), ptr(out), B, C, _flat_v(g), stream_ptr()), 'hno_channel_sum')
+    L = _lib.lib()
+    ws = torch.empty(L.hno_channel_sum_workspace_bytes(C) // 8, device=g.device, dtype=torch.float64)
+    check(L.hno_channel_sum(ptr(g), ptr(out), ptr(ws), B, C, _flat_v(g), stream_ptr()), 'hno_channel_sum')
     return out
 
 
 def _conv3d_call(x, W, bias, out_shape, mode, cin, cout, stride, act=ACT_NONE):
     y = torch.empty(out_shape, device=x.device, dtype=torch.float32)
-    ws = _conv_ws(cin, cout, False, x.device)
-    check(_lib.lib().hno_conv3d_k3(ptr(x), ptr(W), ptr(bias), ptr(y), ptr(ws), mode, x.shape[0], cin, cout, *x.shape[2:],
-                                   *out_shape[2:], stride, 1, act, stream_ptr()), 'hno_conv3d_k3')
+    L = _lib.lib()
+    nbytes = L.hno_conv3d_k3_fwd_workspace_bytes(mode, x.shape[0], int(cin), int(cout), *out_shape[2:])
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    check(L.hno_conv3d_k3(ptr(x), ptr(W), ptr(bias), ptr(y), ptr(ws), nbytes, mode, x.shape[0], cin, cout, *x.shape[2:],
+                          *out_shape[2:], stride, 1, act, stream_ptr()), 'hno_conv3d_k3')
     return y
 
 

@@ -1,0 +1,39 @@
+"""Per-shape timing of the 3x3x3 convolution kernels at the V-Net-DS cfg4 layer shapes (fwd, dgrad, wgrad)."""
+import sys, os, time, json
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import multimodal_3d_image_segmentation_amd as pkg
+from multimodal_3d_image_segmentation_amd import ops
+
+SHAPES = [  # (Cin, Cout, (D, H, W))
+    (24, 24, (81, 97, 65)), (48, 24, (81, 97, 65)), (48, 48, (41, 49, 33)), (96, 48, (41, 49, 33)),
+    (96, 96, (21, 25, 17)), (192, 96, (21, 25, 17)), (192, 192, (11, 13, 9)), (384, 384, (6, 7, 5)),
+]
+
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.time() - t0) / n
+
+
+for cin, cout, sp in SHAPES:
+    x = torch.randn((1, cin) + sp, device='cuda', requires_grad=True)
+    w = (torch.randn(cout, cin, 3, 3, 3, device='cuda') * 0.05).requires_grad_(True)
+    b = torch.zeros(cout, device='cuda', requires_grad=True)
+    y = ops.Conv3dK3Fn.apply(x, w, b, 1)
+    g = torch.randn_like(y)
+    gf = 2.0 * cin * cout * 27 * y[0, 0].numel() / 1e9
+    t_f = timeit(lambda: ops.Conv3dK3Fn.apply(x, w, b, 1))
+    with pkg._lib.KernelProfile() as kp:
+        y = ops.Conv3dK3Fn.apply(x, w, b, 1)
+        torch.autograd.grad((y * g).sum(), [x, w, b])
+    torch.cuda.synchronize()
+    s = kp.summary()
+    print(json.dumps({'cin': cin, 'cout': cout, 'shape': sp, 'GF': round(gf, 2), 'fwd_ms': round(t_f * 1e3, 3),
+                      'fwd_TF': round(gf / t_f / 1e3, 1),
+                      'kernels_ms': {k: [v[0], round(v[1], 3)] for k, v in s.items()}}))
