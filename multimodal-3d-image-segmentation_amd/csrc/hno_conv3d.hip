@@ -316,7 +316,9 @@ __global__ __launch_bounds__(256) void c3_wgrad_kernel(C3WArgs a) {
     const long long ntiles = (long long)a.B * vt;
     const long long ngroups = (ntiles + 3) / 4;
     const int HWg = a.Hg * a.Wg;
-    for (long long grp = blockIdx.x; grp < ngroups; grp += a.nchunks) {
+    // software pipeline: the (masked) global loads of the NEXT tile are issued before this tile's LDS staging and MFMA work
+    float gq[16], xq[3][16];
+    auto fetch = [&](long long grp) {
         const long long t = grp * 4 + wave;
         const bool tlive = t < ntiles;
         const int b = tlive ? (int)(t / vt) : 0;
@@ -338,13 +340,12 @@ __global__ __launch_bounds__(256) void c3_wgrad_kernel(C3WArgs a) {
             rowok = rowok && zi < a.Dx && yi < a.Hx;
         }
         rowok = rowok && live;   // per lane
-        // g tile and the three shifted x tiles (zeros where out of range)
-        const size_t goff = (size_t)vv;
-        for (int r = h; r < 32; r += 2) {
-            const int o = o0 + r;
-            float gv = 0.f;
-            if (rowok && o < a.Cg) gv = a.g[((size_t)b * a.Cg + o) * Vg + goff];
-            G[r * C3W_LD + c] = gv;
+        const float *gp = a.g + ((size_t)b * a.Cg + o0 + h) * Vg + (size_t)vv;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const bool ok = rowok && o0 + h + 2 * j < a.Cg;
+            const float val = gp[ok ? (size_t)(2 * j) * Vg : 0];
+            gq[j] = ok ? val : 0.f;
         }
 #pragma unroll
         for (int tw = 0; tw < 3; ++tw) {
@@ -359,14 +360,24 @@ __global__ __launch_bounds__(256) void c3_wgrad_kernel(C3WArgs a) {
                 colok = nx >= 0 && nx % a.stride == 0 && xi < a.Wx;
             }
             const bool ok = rowok && colok;
-            const size_t xoff = ok ? ((size_t)zi * a.Hx + yi) * a.Wx + xi : 0;
-            for (int r = h; r < 32; r += 2) {
-                const int i = i0 + r;
-                float xv = 0.f;
-                if (ok && i < a.Cx) xv = a.x[((size_t)b * a.Cx + i) * Vx + xoff];
-                X[(tw * 32 + r) * C3W_LD + c] = xv;
+            const float *xp = a.x + ((size_t)b * a.Cx + i0 + h) * Vx + (ok ? ((size_t)zi * a.Hx + yi) * a.Wx + xi : 0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const bool oki = ok && i0 + h + 2 * j < a.Cx;
+                const float val = xp[oki ? (size_t)(2 * j) * Vx : 0];
+                xq[tw][j] = oki ? val : 0.f;
             }
         }
+    };
+    if ((long long)blockIdx.x < ngroups) fetch(blockIdx.x);
+    for (long long grp = blockIdx.x; grp < ngroups; grp += a.nchunks) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) G[(h + 2 * j) * C3W_LD + c] = gq[j];
+#pragma unroll
+        for (int tw = 0; tw < 3; ++tw)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) X[(tw * 32 + h + 2 * j) * C3W_LD + c] = xq[tw][j];
+        if (grp + a.nchunks < ngroups) fetch(grp + a.nchunks);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const float *ga = G + (lane & 15) * C3W_LD + (lane >> 4);
