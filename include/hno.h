@@ -252,6 +252,8 @@ int hno_bmm(const float *A, const float *B, float *C, int batch, int M, int N, i
  * activation or a residual add that no neighbouring kernel can absorb (nets/architectures.py:529-546). */
 int hno_act_fwd(const float *x, float *y, long long n, int act, void *stream);
 int hno_act_bwd(const float *g, const float *y, float *gx, long long n, int act, void *stream);
+/* y[b][c][v] = act(y[b][c][v] + bias[c]) in place: epilogue of 1x1x1 convolutions routed through hno_bmm (wide layers) */
+int hno_bias_act(float *y, const float *bias, int B, int C, long long V, int act, void *stream);
 int hno_add(const float *a, const float *b, float *out, long long n, void *stream);
 
 /* --------------------------------------------------------------- Pearson / Dice reductions

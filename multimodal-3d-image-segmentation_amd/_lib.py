@@ -60,6 +60,7 @@ SIGNATURES = {
     'hno_bmm': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_float, c_void_p]),
     'hno_act_fwd': (c_int, [c_void_p, c_void_p, c_ll, c_int, c_void_p]),
     'hno_act_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p]),
+    'hno_bias_act': (c_int, [c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_void_p]),
     'hno_add': (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
     'hno_loss_fwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_ll, c_int, c_float, c_void_p]),
     'hno_loss_bwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_ll, c_void_p]),

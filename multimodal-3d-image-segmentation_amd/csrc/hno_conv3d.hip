@@ -707,9 +707,15 @@ extern "C" int hno_conv3d_k3(const float *x, const float *W, const float *bias, 
             a.part = (float *)((char *)workspace + relayout);
         }
         // output-channel tile 32 (1 x 4 waves, 128 voxels) up to 32 channels, else 64 (2 x 2 waves, 128 voxels)
-        if (a.Cout <= 32) {
+        if (a.Cout <= 32 && (debug_flags() & 1024) && ks == 1) {
+            const dim3 g((unsigned)(B * ((Vo + 255) / 256)), (a.Cout + 31) / 32, ks);
+            hipLaunchKernelGGL((c3_igemm_kernel<1, 4, 1, 2>), g, dim3(256), 0, s, a);
+        } else if (a.Cout <= 32) {
             const dim3 g((unsigned)(B * ((Vo + 127) / 128)), (a.Cout + 31) / 32, ks);
             hipLaunchKernelGGL((c3_igemm_kernel<1, 4, 1, 1>), g, dim3(256), 0, s, a);
+        } else if ((debug_flags() & 2048) && ks == 1) {
+            const dim3 g((unsigned)(B * ((Vo + 255) / 256)), (a.Cout + 63) / 64, ks);
+            hipLaunchKernelGGL((c3_igemm_kernel<2, 2, 1, 4>), g, dim3(256), 0, s, a);
         } else {
             const dim3 g((unsigned)(B * ((Vo + 127) / 128)), (a.Cout + 63) / 64, ks);
             hipLaunchKernelGGL((c3_igemm_kernel<2, 2, 1, 2>), g, dim3(256), 0, s, a);

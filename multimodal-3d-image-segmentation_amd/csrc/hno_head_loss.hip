@@ -558,6 +558,14 @@ __global__ __launch_bounds__(256) void eltwise_kernel(const float *__restrict__ 
     }
 }
 
+// y[b][c][v] = act(y[b][c][v] + bias[c]) in place (epilogue of the GEMM-routed 1x1x1 convolutions)
+__global__ __launch_bounds__(256) void bias_act_kernel(float *__restrict__ y, const float *__restrict__ bias, int C, long long V, int act) {
+    const int bc = blockIdx.y;
+    const float bv = bias ? bias[bc % C] : 0.f;
+    float *p = y + (size_t)bc * V;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < V; i += (long long)gridDim.x * 256) p[i] = act_apply(p[i] + bv, act);
+}
+
 static int grid1d(size_t n) {
     size_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
@@ -730,6 +738,16 @@ extern "C" int hno_act_fwd(const float *x, float *y, long long n, int act, void 
 extern "C" int hno_act_bwd(const float *g, const float *y, float *gx, long long n, int act, void *stream) {
     HNO_REQUIRE(g && y && gx && n > 0, "hno_act_bwd: bad argument");
     hipLaunchKernelGGL(eltwise_kernel, dim3(grid1d((size_t)n)), dim3(256), 0, (hipStream_t)stream, g, y, gx, (size_t)n, 1, act);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+extern "C" int hno_bias_act(float *y, const float *bias, int B, int C, long long V, int act, void *stream) {
+    HNO_REQUIRE(y && B > 0 && C > 0 && V > 0, "hno_bias_act: bad argument");
+    if ((long long)B * C > 65535) return fail(HNO_ELIMIT, "hno_bias_act: B*C = %lld exceeds 65535", (long long)B * C);
+    int gx = (int)((V + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(bias_act_kernel, dim3(gx, B * C), dim3(256), 0, (hipStream_t)stream, y, bias, C, V, act);
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }

@@ -623,10 +623,25 @@ class PwConvFn(torch.autograd.Function):
     (nets/hnosegxs.py:274-275; nets/nets_utils.py:127-133)."""
 
     @staticmethod
+    def _wide(xa, xb, W):
+        """Wide layers on small grids (deep V-Net levels: 96 ... 384 channels, <= 16 K voxels) are plain GEMMs: the
+        streaming pointwise kernels would need (Cout / 32) x (Cin / 64) launches, the LDS-tiled batched GEMM needs one."""
+        return xb is None and (xa.shape[1] > 64 or W.shape[0] > 32) and W.shape[0] >= 16 and _flat_v(xa) <= 16384
+
+    @staticmethod
     def forward(ctx, xa, xb, W, bias, act):
         xa, xb, W, bias = _f32c(xa), _f32c(xb), _f32c(W), _f32c(bias)
         _need_gpu(xa, xb, W, bias)
-        y = pwconv_fwd_raw(xa, xb, W, bias, act)
+        ctx.wide = PwConvFn._wide(xa, xb, W)
+        if ctx.wide:
+            B, Cin = xa.shape[:2]
+            Cout, V = W.shape[0], _flat_v(xa)
+            w2 = W.reshape(1, Cout, Cin).expand(B, Cout, Cin).contiguous() if B > 1 else W.reshape(1, Cout, Cin)
+            y = bmm_raw(w2, xa.reshape(B, Cin, V), False, False).reshape((B, Cout) + tuple(xa.shape[2:]))
+            if bias is not None or act != ACT_NONE:
+                check(_lib.lib().hno_bias_act(ptr(y), ptr(bias), B, Cout, V, act, stream_ptr()), 'hno_bias_act')
+        else:
+            y = pwconv_fwd_raw(xa, xb, W, bias, act)
         ctx.save_for_backward(xa, xb, W, y if act != ACT_NONE else None)
         ctx.act, ctx.has_bias = act, bias is not None
         return y
@@ -634,6 +649,26 @@ class PwConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         xa, xb, W, y = ctx.saved_tensors
+        if ctx.wide:
+            g = _f32c(gy)
+            if ctx.act != ACT_NONE:
+                g = act_bwd_raw(g, y, ctx.act)
+            B, Cin = xa.shape[:2]
+            Cout, V = W.shape[0], _flat_v(xa)
+            g3, x3 = g.reshape(B, Cout, V), xa.reshape(B, Cin, V)
+            gxa = None
+            if ctx.needs_input_grad[0]:
+                w2 = W.reshape(1, Cout, Cin).expand(B, Cout, Cin).contiguous() if B > 1 else W.reshape(1, Cout, Cin)
+                gxa = bmm_raw(w2, g3, True, False).reshape(xa.shape)
+            dW = bmm_raw(g3, x3, False, True)                     # (B, Cout, Cin)
+            acc = dW[0]
+            for bi in range(1, B):       # batch > 1: fixed-order sum of the per-sample products (hno_add)
+                nxt = torch.empty_like(acc)
+                check(_lib.lib().hno_add(ptr(acc), ptr(dW[bi]), ptr(nxt), acc.numel(), stream_ptr()), 'hno_add')
+                acc = nxt
+            dW = acc.reshape(W.shape)
+            db = _chan_sum(g) if ctx.has_bias else None
+            return gxa, None, dW, db, None
         gxa, gxb, dW, db = pwconv_bwd_raw(_f32c(gy), y, xa, xb, W, ctx.act, ctx.has_bias, ctx.needs_input_grad[0],
                                           ctx.needs_input_grad[1])
         return gxa, gxb, dW, db, None
