@@ -110,15 +110,18 @@ class HartleyMultiHeadAttention(Module):
         q_src, k_src, v_src = specs[0], specs[min(1, len(specs) - 1)], specs[-1]
         act_att = ops.act_id(self.attention_activation)
         Z = self.num_heads
-        heads = []
-        for z in range(Z):                                              # freq_conv3d 'zoi,bidhw->bzodhw'
-            q = ops.PwConvFn.apply(q_src, None, self.weight_query[z], None, ops.ACT_NONE)
-            k = ops.PwConvFn.apply(k_src, None, self.weight_key[z], None, ops.ACT_NONE)
-            v = ops.PwConvFn.apply(v_src, None, self.weight_value[z], None, ops.ACT_NONE)
-            heads.append((q, k, v))
-        q = torch.stack([h[0] for h in heads], dim=1)                   # (B, Z, K, d, h, w)
-        k = torch.stack([h[1] for h in heads], dim=1)
-        v = torch.stack([h[2] for h in heads], dim=1)
+        # freq_conv3d 'zoi,bidhw->bzodhw' for all heads at once: the head axis folds into the output channels, and with a
+        # single source (self-attention) the three projections are ONE pointwise conv with the stacked weights
+        wq, wk, wv = (w.reshape(-1, w.shape[-1]) for w in (self.weight_query, self.weight_key, self.weight_value))
+        fsp = tuple(q_src.shape[2:])
+        if q_src is k_src and k_src is v_src:
+            y = ops.PwConvFn.apply(q_src, None, torch.cat([wq, wk, wv], dim=0), None, ops.ACT_NONE)
+            q, k, v = torch.split(y, [wq.shape[0], wk.shape[0], wv.shape[0]], dim=1)
+        else:
+            q = ops.PwConvFn.apply(q_src, None, wq, None, ops.ACT_NONE)
+            k = ops.PwConvFn.apply(k_src, None, wk, None, ops.ACT_NONE)
+            v = ops.PwConvFn.apply(v_src, None, wv, None, ops.ACT_NONE)
+        q, k, v = (t.reshape(t.shape[0], Z, t.shape[1] // Z, *fsp) for t in (q, k, v))   # (B, Z, K, d, h, w)
         if self.patch_size is not None:
             q, k, v = (grouping3d(t, self.patch_size) for t in (q, k, v))
         freq_shape = tuple(q.shape[3:])

@@ -626,7 +626,9 @@ class PwConvFn(torch.autograd.Function):
     def _wide(xa, xb, W):
         """Wide layers on small grids (deep V-Net levels: 96 ... 384 channels, <= 16 K voxels) are plain GEMMs: the
         streaming pointwise kernels would need (Cout / 32) x (Cin / 64) launches, the LDS-tiled batched GEMM needs one."""
-        return xb is None and (xa.shape[1] > 64 or W.shape[0] > 32) and W.shape[0] >= 16 and _flat_v(xa) <= 16384
+        launches = ((W.shape[0] + 31) // 32) * ((xa.shape[1] + 63) // 64)   # what the streaming path would need
+        # the GEMM's weight gradient reduces over V inside one tile (no split-K): only worth it when Cin is large too
+        return xb is None and launches >= 6 and xa.shape[1] >= 64 and _flat_v(xa) <= 16384
 
     @staticmethod
     def forward(ctx, xa, xb, W, bias, act):
