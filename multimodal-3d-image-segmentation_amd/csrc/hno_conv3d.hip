@@ -30,6 +30,7 @@ struct C3Args {
     // 27 / ksplit taps write raw partial sums to `part` [z][b][o][v]; c3_splitk_finish_kernel adds them, bias and activation
     int ksplit;
     float *part;
+    int dbg;
 };
 
 // weight re-layout: dst[(t * Cin_g + i) * Cout_g + o] where the GEMM's "input" / "output" channels may be
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(256) void c3_igemm_kernel(C3Args a) {
     constexpr int BM = 32 * WM * WR, BN = 32 * WN * WC, LDA = BM + 4, LDB = BN + 4;
     constexpr int NA = (BM * C3I_K + 255) / 256, NB = BN * C3I_K / 256, RSTEP = 256 / BN;   // BN in {128, 256}
     __shared__ float As[2][C3I_K * LDA], Bs[2][C3I_K * LDB];
+    __shared__ int Toff[27 * BN];   // gather offset of every (tap, voxel column) of this block, -1 = outside the input
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t Vi = (size_t)a.Di * a.Hi * a.Wi, Vo = (size_t)a.Do * a.Ho * a.Wo;
     const int vt = (int)((Vo + BN - 1) / BN);
@@ -171,6 +173,13 @@ __global__ __launch_bounds__(256) void c3_igemm_kernel(C3Args a) {
     const float *xb = a.x + (size_t)b * a.Cin * Vi;
     float ra[NA], rb[NB];
     auto fetch = [&](int k0) {
+        if (a.dbg & 4096) {   // ablation: no global loads
+#pragma unroll
+            for (int j = 0; j < NA; ++j) ra[j] = 1.f;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) rb[j] = 1.f;
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int e = tid + 256 * j;
@@ -180,9 +189,32 @@ __global__ __launch_bounds__(256) void c3_igemm_kernel(C3Args a) {
             const float val = a.wt[ok ? (size_t)(k0 + kk) * a.Cout + o : 0];
             ra[j] = ok ? val : 0.f;
         }
-        // the whole K-step lies inside one tap (CinP % 16 == 0): tap is wave-uniform, the gather offset of this
-        // thread's voxel is computed once per K-step, rows differ only by the channel
+        // the whole K-step lies inside one tap (CinP % 16 == 0): the gather offset of this thread's voxel comes from the
+        // table built once per block; rows differ only by the channel (32-bit element offsets from a uniform base)
         const int tap = k0 / a.CinP, i0 = k0 - tap * a.CinP;
+        const int off = Toff[tap * BN + col];
+        const bool ok = off >= 0;
+        const unsigned base = ok ? (unsigned)off : 0u;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int i = i0 + row0 + RSTEP * j;
+            const bool oki = ok && i < a.Cin;
+            const float val = xb[oki ? base + (unsigned)i * (unsigned)Vi : 0u];
+            rb[j] = oki ? val : 0.f;
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int e = tid + 256 * j;
+            const int kk = e / BM, m = e - kk * BM;
+            if (e < BM * C3I_K) As[buf][kk * LDA + m] = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) Bs[buf][(row0 + RSTEP * j) * LDB + col] = rb[j];
+    };
+    // gather-offset table: each thread fills the 27 taps of its own voxel column (all rows of the block share the columns)
+    for (int tap = row0; tap < 27; tap += RSTEP) {
         const int td = tap / 9, th = (tap - 9 * td) / 3, tw = tap - 9 * td - 3 * th;
         int zi, yi, xi;
         bool ok;
@@ -199,26 +231,9 @@ __global__ __launch_bounds__(256) void c3_igemm_kernel(C3Args a) {
             ok = nz >= 0 && ny >= 0 && nx >= 0 && nz % a.stride == 0 && ny % a.stride == 0 && nx % a.stride == 0 &&
                  zi < a.Di && yi < a.Hi && xi < a.Wi;
         }
-        ok = ok && vok;
-        const float *xp = xb + (ok ? ((size_t)zi * a.Hi + yi) * a.Wi + xi : 0);
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int i = i0 + row0 + RSTEP * j;
-            const bool oki = ok && i < a.Cin;
-            const float val = xp[oki ? (size_t)i * Vi : 0];
-            rb[j] = oki ? val : 0.f;
-        }
-    };
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int e = tid + 256 * j;
-            const int kk = e / BM, m = e - kk * BM;
-            if (e < BM * C3I_K) As[buf][kk * LDA + m] = ra[j];
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) Bs[buf][(row0 + RSTEP * j) * LDB + col] = rb[j];
-    };
+        Toff[tap * BN + col] = (ok && vok) ? (zi * a.Hi + yi) * a.Wi + xi : -1;
+    }
+    __syncthreads();
     const int wm = (wave / WC) * 32 * WM, wn = (wave % WC) * 32 * WN;
     f32x16c acc[WM][WN];
 #pragma unroll
@@ -237,7 +252,7 @@ __global__ __launch_bounds__(256) void c3_igemm_kernel(C3Args a) {
         const float *Ac = As[buf] + (lane >> 5) * LDA + wm + (lane & 31);
         const float *Bc = Bs[buf] + (lane >> 5) * LDB + wn + (lane & 31);
 #pragma unroll
-        for (int kk = 0; kk < C3I_K; kk += 2) {
+        for (int kk = 0; kk < ((a.dbg & 8192) ? 0 : C3I_K); kk += 2) {
             float av[WM], bv[WN];
 #pragma unroll
             for (int i = 0; i < WM; ++i) av[i] = Ac[kk * LDA + 32 * i];
@@ -673,6 +688,8 @@ extern "C" int hno_conv3d_k3(const float *x, const float *W, const float *bias, 
                              int pad, int act, void *stream) {
     HNO_REQUIRE(x && W && y && workspace && B > 0 && Cin > 0 && Cout > 0, "hno_conv3d_k3: bad argument");
     HNO_REQUIRE(mode >= 0 && mode <= 3 && (stride == 1 || stride == 2), "hno_conv3d_k3: bad mode / stride");
+    if ((long long)(Cin > Cout ? Cin : Cout) * Di * Hi * Wi >= (1ll << 31))
+        return fail(HNO_ELIMIT, "hno_conv3d_k3: input of %d x %d x %d x %d elements exceeds the 32-bit offset range", Cin > Cout ? Cin : Cout, Di, Hi, Wi);
     hipStream_t s = (hipStream_t)stream;
     float *wt = (float *)workspace;
     C3Args a = {};
@@ -696,6 +713,7 @@ extern "C" int hno_conv3d_k3(const float *x, const float *W, const float *bias, 
     const long long Vo = (long long)Do * Ho * Wo;
     a.ksplit = 1;
     a.part = nullptr;
+    a.dbg = debug_flags();
     if (!(debug_flags() & 16)) {
         // split-K when the grid alone cannot fill the chip and the caller's workspace has room for the partial sums
         const size_t relayout = hno_conv3d_k3_workspace_bytes(Cin, Cout, 0);
@@ -707,16 +725,10 @@ extern "C" int hno_conv3d_k3(const float *x, const float *W, const float *bias, 
             a.part = (float *)((char *)workspace + relayout);
         }
         // output-channel tile 32 (1 x 4 waves, 128 voxels) up to 32 channels, else 64 (2 x 2 waves, 128 voxels)
-        if (a.Cout <= 32 && (debug_flags() & 1024) && ks == 1) {
-            const dim3 g((unsigned)(B * ((Vo + 255) / 256)), (a.Cout + 31) / 32, ks);
-            hipLaunchKernelGGL((c3_igemm_kernel<1, 4, 1, 2>), g, dim3(256), 0, s, a);
-        } else if (a.Cout <= 32) {
+        if (a.Cout <= 32) {
             const dim3 g((unsigned)(B * ((Vo + 127) / 128)), (a.Cout + 31) / 32, ks);
             hipLaunchKernelGGL((c3_igemm_kernel<1, 4, 1, 1>), g, dim3(256), 0, s, a);
-        } else if ((debug_flags() & 2048) && ks == 1) {
-            const dim3 g((unsigned)(B * ((Vo + 255) / 256)), (a.Cout + 63) / 64, ks);
-            hipLaunchKernelGGL((c3_igemm_kernel<2, 2, 1, 4>), g, dim3(256), 0, s, a);
-        } else {
+        } else {   // 256-voxel tiles (<1,4,1,2> / <2,2,1,4>) were measured: +3 % / -20 %
             const dim3 g((unsigned)(B * ((Vo + 127) / 128)), (a.Cout + 63) / 64, ks);
             hipLaunchKernelGGL((c3_igemm_kernel<2, 2, 1, 2>), g, dim3(256), 0, s, a);
         }
