@@ -97,8 +97,6 @@ class HartleyMultiHeadAttention(Module):
             srcs = [inputs]
         if srcs[0].ndim != 5:
             raise NotImplementedError('2-D (ndim=4) Hartley attention is not provided by the HIP path yet')
-        if self.use_bias:
-            raise NotImplementedError('HartleyMultiHeadAttention(use_bias=True) is not provided by the HIP path yet')
         spatial = tuple(srcs[0].shape[2:])
         modes = self.num_modes
         if self.use_transform:
@@ -114,13 +112,18 @@ class HartleyMultiHeadAttention(Module):
         # single source (self-attention) the three projections are ONE pointwise conv with the stacked weights
         wq, wk, wv = (w.reshape(-1, w.shape[-1]) for w in (self.weight_query, self.weight_key, self.weight_value))
         fsp = tuple(q_src.shape[2:])
+        # biases (reference :174-177, :217-218) are per (head, channel) on the projections and per channel on the output,
+        # all on the CROPPED spectrum: they ride on the pointwise convs
+        bq, bk, bv, bo = ((b.reshape(-1) if b is not None else None)
+                          for b in (self.bias_query, self.bias_key, self.bias_value, self.bias_out))
         if q_src is k_src and k_src is v_src:
-            y = ops.PwConvFn.apply(q_src, None, torch.cat([wq, wk, wv], dim=0), None, ops.ACT_NONE)
+            b_all = torch.cat([bq, bk, bv]) if self.use_bias else None
+            y = ops.PwConvFn.apply(q_src, None, torch.cat([wq, wk, wv], dim=0), b_all, ops.ACT_NONE)
             q, k, v = torch.split(y, [wq.shape[0], wk.shape[0], wv.shape[0]], dim=1)
         else:
-            q = ops.PwConvFn.apply(q_src, None, wq, None, ops.ACT_NONE)
-            k = ops.PwConvFn.apply(k_src, None, wk, None, ops.ACT_NONE)
-            v = ops.PwConvFn.apply(v_src, None, wv, None, ops.ACT_NONE)
+            q = ops.PwConvFn.apply(q_src, None, wq, bq, ops.ACT_NONE)
+            k = ops.PwConvFn.apply(k_src, None, wk, bk, ops.ACT_NONE)
+            v = ops.PwConvFn.apply(v_src, None, wv, bv, ops.ACT_NONE)
         q, k, v = (t.reshape(t.shape[0], Z, t.shape[1] // Z, *fsp) for t in (q, k, v))   # (B, Z, K, d, h, w)
         if self.patch_size is not None:
             q, k, v = (grouping3d(t, self.patch_size) for t in (q, k, v))
@@ -134,7 +137,7 @@ class HartleyMultiHeadAttention(Module):
         if self.patch_size is not None:
             out = ungrouping3d(out, self.value_dim, self.patch_size)
         out = out.reshape(out.shape[0], Z * self.value_dim, *out.shape[3:]).contiguous()
-        out = ops.PwConvFn.apply(out, None, self.weight_out, None, ops.ACT_NONE)               # 'oi,bidhw->bodhw'
+        out = ops.PwConvFn.apply(out, None, self.weight_out, bo, ops.ACT_NONE)                 # 'oi,bidhw->bodhw' (+ bias_out)
         if not self.use_transform:
             assert addend is None and act == ops.ACT_NONE
             return out

@@ -166,6 +166,12 @@ MHA_CASES = [
     (6, 4, 3, (2, 2, 2), (2, 2, 2), 2),
     (6, 5, 2, (3, 3, 2), None, 3),
 ]
+# (in_channels, key_dim, heads, modes, patch, number of inputs, use_transform) with use_bias=True (golden G12)
+MHA_BIAS_CASES = [
+    (6, 4, 2, (2, 3, 2), (2, 1, 2), 1, True),
+    (6, 4, 3, (2, 2, 2), None, 2, True),
+    (6, 5, 2, (3, 3, 2), (2, 2, 2), 3, False),
+]
 MHASEG_MODEL = (dict(in_channels=2, out_channels=3, filters=8, num_transform_blocks=2, num_heads=2, num_modes=(4, 4, 6),
                      patch_size=(2, 2, 2)), (1, 2, 24, 20, 28))
 

@@ -403,6 +403,33 @@ def g4_mha():
     save('g4_mha.npz', **out)
 
 
+# ------------------------------------------- G12: HartleyMultiHeadAttention with biases (use_bias=True)
+def g12_mha_bias():
+    from _inputs import MHA_BIAS_CASES
+    from nets.hartley_mha import HartleyMultiHeadAttention
+    out = {}
+    for ci, (cin, kd, heads, modes, patch, nin, use_transform) in enumerate(MHA_BIAS_CASES):
+        torch.manual_seed(400 + ci)
+        op = HartleyMultiHeadAttention(cin, kd, heads, modes, patch, use_bias=True, use_transform=use_transform)
+        with torch.no_grad():
+            for j, (pn, p_) in enumerate(op.named_parameters()):
+                if pn.startswith('bias'):
+                    p_.copy_(T(formula_tensor(tuple(p_.shape), 410 + ci + j)) * 0.2)
+        shape = (1, cin, 12, 14, 12) if use_transform else (1, cin) + tuple(2 * m for m in modes)
+        xs = [T(formula_tensor(shape, 420 + ci + 7 * j)).requires_grad_(True) for j in range(nin)]
+        y = op(xs[0] if nin == 1 else xs)
+        params = dict(op.named_parameters())
+        gs = grads_of(y, T(formula_tensor(tuple(y.shape), 430 + ci)), xs + list(params.values()))
+        k = f'm{ci}'
+        out[f'{k}_y'] = y.detach().numpy()
+        for j in range(nin):
+            out[f'{k}_gx{j}'] = gs[j]
+        for (pn, p_), g in zip(params.items(), gs[nin:]):
+            out[f'{k}_p_{pn}'] = p_.detach().numpy()
+            out[f'{k}_g_{pn}'] = g
+    save('g12_mha_bias.npz', **out)
+
+
 # ------------------------------------------------------------- G7v: tiny V-Net-DS variants
 def g7v_vnet_models():
     from _inputs import VNET_MODELS, formula_volume
@@ -475,7 +502,7 @@ def g8_training():
 
 if __name__ == '__main__':
     ALL = [g1_dht, g2_crop_pad, g3_operators, g4_mha, g5_losses, g6_hnosegxs, g6s_small_models, g7_noseg_models,
-           g7v_vnet_models, g9_misc, g10_two_d, g11_input, g8_training]
+           g7v_vnet_models, g9_misc, g10_two_d, g11_input, g12_mha_bias, g8_training]
     only = set(sys.argv[2:])   # e.g. `make_golden.py /root/reference g10_two_d` regenerates one fixture
     for fn in ALL:
         if not only or fn.__name__ in only:

@@ -822,3 +822,30 @@ def test_pwconv_bwd_fused_branch(pkg, shape, act):
                                            int(np.prod(sp)), a, pkg._lib.stream_ptr()), 'hno_pwconv_fwd_branch')
     assert rel_err(yk.cpu().numpy(), y.detach().numpy()) < 2e-6
     assert rel_err(ok.cpu().numpy(), out.detach().numpy()) < 2e-6
+
+
+from _inputs import MHA_BIAS_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize('ci', range(len(MHA_BIAS_CASES)))
+def test_hartley_mha_bias_vs_golden(pkg, ci):
+    """HartleyMultiHeadAttention(use_bias=True) with non-zero biases; 1, 2 and 3 inputs; with and without the transform (G12)."""
+    from multimodal_3d_image_segmentation_amd.nets.hartley_mha import HartleyMultiHeadAttention
+    g = load_golden('g12_mha_bias.npz')
+    cin, kd, heads, modes, patch, nin, use_transform = MHA_BIAS_CASES[ci]
+    k = f'm{ci}'
+    op = HartleyMultiHeadAttention(cin, kd, heads, modes, patch, use_bias=True, use_transform=use_transform)
+    with torch.no_grad():
+        for pn, p in op.named_parameters():
+            p.copy_(torch.from_numpy(g[f'{k}_p_{pn}']))
+    op = op.cuda()
+    shape = (1, cin, 12, 14, 12) if use_transform else (1, cin) + tuple(2 * m for m in modes)
+    xs = [T(formula_tensor(shape, 420 + ci + 7 * j)).requires_grad_(True) for j in range(nin)]
+    y = op(xs[0] if nin == 1 else xs)
+    assert rel_err(y.detach().cpu().numpy(), g[f'{k}_y']) < TOL
+    gs = torch.autograd.grad((y * T(formula_tensor(tuple(y.shape), 430 + ci))).sum(), xs + list(op.parameters()))
+    for j in range(nin):
+        assert rel_err(gs[j].cpu().numpy(), g[f'{k}_gx{j}']) < TOL
+    for (pn, _), gp in zip(op.named_parameters(), gs[nin:]):
+        assert tuple(gp.shape) == g[f'{k}_g_{pn}'].shape
+        assert rel_err(gp.cpu().numpy(), g[f'{k}_g_{pn}']) < TOL, pn
