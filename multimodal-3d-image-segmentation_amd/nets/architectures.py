@@ -13,6 +13,9 @@ from .hartley_operator import HartleyOperator
 from .hartley_mha import HartleyMultiHeadAttention
 from .nets_utils import ConvNormAct, ConvTransposeNormAct, init_weights_for_snn, spatial_padcrop, _is_selu
 
+import os
+_NO_BLOCK_FUSION = bool(int(os.environ.get('HNO_NO_BLOCK_FUSION', '0')))   # A/B switch for the fused FNOSeg / HNOSeg block
+
 
 class _TransBlock(nn.Module):
     """x1 = op(x); x2 = conv_branch(x); x = act(norm(x1 + x2)); block skip (reference :511-548)."""
@@ -27,6 +30,8 @@ class _TransBlock(nn.Module):
         """The whole block as one autograd node (ops.NOBlockFn) when it has the FNOSeg / HNOSeg shape: shared-weight
         Fourier / Hartley operator with transform and without bias, SELU (no GroupNorm), concat skip."""
         op = self.op
+        if _NO_BLOCK_FUSION:
+            return None
         if not (isinstance(op, (FourierOperator, HartleyOperator)) and x.ndim == 5 and self.normalization is None
                 and act != ops.ACT_NONE and self.use_block_skip and self.conv_concat is not None
                 and op.weights_type == 'shared' and op.use_transform and not op.use_bias

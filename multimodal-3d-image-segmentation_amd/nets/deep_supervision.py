@@ -5,8 +5,6 @@ from .. import ops
 
 def conv_over_concat(conv_norm_act, tensors):
     op = conv_norm_act.op
-    if conv_norm_act.normalization is not None:
-        raise NotImplementedError('GroupNorm after conv_ds is not provided by the HIP path yet')
     w = op.weight.reshape(op.weight.shape[0], -1)
     acc, c0 = None, 0
     for i, t in enumerate(tensors):
@@ -15,4 +13,7 @@ def conv_over_concat(conv_norm_act, tensors):
         acc = part if acc is None else ops.AddFn.apply(acc, part)
         c0 += c
     act = ops.act_id(conv_norm_act.activation)
+    if conv_norm_act.normalization is not None:      # non-SELU activations: conv -> GroupNorm(1, C) -> activation (nets_utils.py:127-133)
+        from .conv3d import group_norm_act
+        return group_norm_act(acc, conv_norm_act.normalization, act)
     return ops.ActFn.apply(acc, act) if act != ops.ACT_NONE else acc

@@ -367,8 +367,10 @@ def neural_operator_block(sd, prefix, x, modes, transform_type, weights_type='sh
 
 
 def neural_operator_seg_forward(sd, x, num_transform_blocks, num_modes, transform_type, weights_type='shared',
-                                use_resize=True, use_block_skip=True, act='selu', output_activation='softmax'):
-    """_TransSeg.forward (nets/architectures.py:325-353) without deep supervision."""
+                                use_resize=True, use_block_skip=True, act='selu', output_activation='softmax',
+                                use_deep_supervision=False):
+    """_TransSeg.forward (nets/architectures.py:325-353); deep supervision: conv_ds over the concat of conv1's and every
+    block's output (:341-343)."""
     nd = x.ndim - 2
     image_size = tuple(x.shape[-nd:])
     if np.isscalar(num_modes):
@@ -377,8 +379,12 @@ def neural_operator_seg_forward(sd, x, num_transform_blocks, num_modes, transfor
     if use_resize:
         h = conv_act(h, sd['conv_in.op.weight'], sd['conv_in.op.bias'], stride=2, act=act)
     h = conv_act(h, sd['conv1.op.weight'], sd['conv1.op.bias'], act=act)
+    tensors = [h]
     for i in range(num_transform_blocks):
         h = neural_operator_block(sd, f'layers.{i}', h, num_modes, transform_type, weights_type, act, use_block_skip)
+        tensors.append(h)
+    if use_deep_supervision:
+        h = conv_act(torch.cat(tensors, dim=1), sd['conv_ds.op.weight'], sd['conv_ds.op.bias'], act=act)
     if use_resize:
         h = F.interpolate(h, size=image_size, mode='trilinear' if nd == 3 else 'bilinear')
     conv = F.conv3d if nd == 3 else F.conv2d

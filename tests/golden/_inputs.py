@@ -156,6 +156,10 @@ NOSEG_MODELS = {
     'hnoseg_noskip_clamped': (dict(in_channels=2, out_channels=2, filters=8, num_transform_blocks=2,
                                    num_modes=(10, 14, 14), transform_type='Hartley', use_block_skip=False),
                               (1, 2, 16, 20, 24)),
+    # (modes (3, 4, 4) puts one pre-activation of block 0 at 1e-7, on the SELU kink: the sign of a rounding error then
+    # decides between two derivatives and fp32 implementations legitimately disagree by 4e-3 -- not a usable fixture)
+    'hnoseg_deep_supervision': (dict(in_channels=2, out_channels=3, filters=8, num_transform_blocks=2, num_modes=(4, 4, 5),
+                                     transform_type='Hartley', use_deep_supervision=True), (1, 2, 24, 20, 28)),
 }
 
 

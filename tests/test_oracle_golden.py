@@ -215,7 +215,8 @@ def test_noseg_models_oracle(name):
     lab = T(formula_labels((shape[0], 1) + shape[2:], K, 6))
     y = O.neural_operator_seg_forward(params, x, kw['num_transform_blocks'], kw['num_modes'], kw['transform_type'],
                                       weights_type=kw.get('weights_type', 'shared'),
-                                      use_block_skip=kw.get('use_block_skip', True))
+                                      use_block_skip=kw.get('use_block_skip', True),
+                                      use_deep_supervision=kw.get('use_deep_supervision', False))
     loss = O.pcc_loss(y, O.to_categorical(lab, K))
     loss.backward()
     assert rel_err(_np(y), g[f'{name}::y']) < 1e-5
