@@ -304,6 +304,16 @@ int hno_zscore_modalities(const float *x, float *out, float *mean_std, void *wor
 int hno_affine_nearest(const float *x, float *out, const double *matrix12, float cval, int flip_mask, int C, int D,
                        int H, int W, void *stream);
 
+/* ------------------------------------------------------------------ deferred weight-gradient reduction
+ * Every *_bwd entry point that produces a weight gradient writes per-workgroup partial slabs into its workspace and then
+ * reduces them (fixed order, no atomics).  hno_set_defer_reduce(1) makes those calls RECORD the reduction instead (returns
+ * the previous setting); hno_flush_reduces launches ONE kernel for everything recorded (bit-identical results).  Between
+ * the call and the flush the caller must keep the workspace alive and must not read the gradient.  The Python layer turns
+ * it on during autograd's backward and flushes from the engine's end-of-backward callback. */
+int hno_set_defer_reduce(int on);
+int hno_pending_reduces(void);
+int hno_flush_reduces(void *stream);
+
 /* ------------------------------------------------------------------ per-kernel profiler
  * hno_profile_begin arms HIP-event bracketing of every kernel launch (on the stream the kernel
  * is launched on); hno_profile_end stops it, waits for the events and returns the number of

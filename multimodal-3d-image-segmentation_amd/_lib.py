@@ -70,6 +70,9 @@ SIGNATURES = {
     'hno_zscore_workspace_bytes': (c_size_t, [c_int]),
     'hno_zscore_modalities': (c_int, [c_void_p] * 4 + [c_int, c_ll, c_int, c_float, c_int, c_float, c_float, c_void_p]),
     'hno_affine_nearest': (c_int, [c_void_p, c_void_p, c_void_p, c_float] + [c_int] * 5 + [c_void_p]),
+    'hno_set_defer_reduce': (c_int, [c_int]),
+    'hno_pending_reduces': (c_int, []),
+    'hno_flush_reduces': (c_int, [c_void_p]),
     'hno_profile_begin': (c_int, [c_int]),
     'hno_profile_end': (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
     'hno_profile_kernel_name': (ctypes.c_char_p, [c_int]),

@@ -55,7 +55,7 @@ struct ProfScope {
 // result to dst.  No float atomics -> bitwise reproducible gradients, and none of the
 // same-address atomic contention that made the first version of these kernels 10x slower.
 int reduce_partials_launch(const float *partials, int nblocks, int n, float *dst0, int n0, float *dst1,
-                           hipStream_t stream, int cols = 0, int ldd = 0);   // cols/ldd: dst0 is a sub-block with row stride ldd
+                           hipStream_t stream, int cols = 0, int ldd = 0, bool allow_defer = true);   // allow_defer = false: callers that reuse the slab workspace for several rounds   // cols/ldd: dst0 is a sub-block with row stride ldd
 
 // wave-private accumulator fragments -> one slab per block.  `scratch` is >= nwaves * n floats of LDS.
 // frag(idx) semantic: each wave calls store(idx, value) for the elements it owns; all 4 waves own

@@ -123,9 +123,94 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__re
     }
 }
 
+// ---- deferred slab reduction: one launch for every weight gradient of a backward pass -------------------------------
+// With hno_set_defer_reduce(1) a reduce_partials_launch is only RECORDED (the slabs stay in the caller's workspace, which
+// the caller must keep alive); hno_flush_reduces launches one kernel over all recorded slab sets.  HNOSeg-XS: 22 launches of
+// ~4.8 us (latency-bound, 3 % of a step) -> 1.
+struct ReduceEntry {
+    const float *partials;
+    float *dst0, *dst1;
+    int nblocks, n, n0, cols, ldd, first_block;
+};
+#define HNO_MAX_DEFERRED 64   // 64 x 48 B of kernel arguments
+struct ReduceBatch {
+    ReduceEntry e[HNO_MAX_DEFERRED];
+    int count;
+};
+static bool g_defer_reduce = false;
+static std::vector<ReduceEntry> g_deferred;
+
+__global__ __launch_bounds__(1024) void reduce_partials_multi_kernel(ReduceBatch b) {
+    __shared__ float red[16][64];
+    int ei = 0;
+    while (ei + 1 < b.count && (int)blockIdx.x >= b.e[ei + 1].first_block) ++ei;   // block-uniform search
+    const ReduceEntry &e = b.e[ei];
+    const int col = ((int)blockIdx.x - e.first_block) * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    const int n = e.n, nblocks = e.nblocks;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+    if (col < n) {   // same summation order as reduce_partials_kernel: results are bit-identical to the eager path
+        int bb = grp;
+        const float *pp = e.partials + col;
+        for (; bb + 112 < nblocks; bb += 128) {
+            s0 += pp[(size_t)bb * n];
+            s1 += pp[(size_t)(bb + 16) * n];
+            s2 += pp[(size_t)(bb + 32) * n];
+            s3 += pp[(size_t)(bb + 48) * n];
+            s4 += pp[(size_t)(bb + 64) * n];
+            s5 += pp[(size_t)(bb + 80) * n];
+            s6 += pp[(size_t)(bb + 96) * n];
+            s7 += pp[(size_t)(bb + 112) * n];
+        }
+        for (; bb + 48 < nblocks; bb += 64) {
+            s0 += pp[(size_t)bb * n];
+            s1 += pp[(size_t)(bb + 16) * n];
+            s2 += pp[(size_t)(bb + 32) * n];
+            s3 += pp[(size_t)(bb + 48) * n];
+        }
+        for (; bb < nblocks; bb += 16) s0 += pp[(size_t)bb * n];
+    }
+    s0 += s4;
+    s1 += s5;
+    s2 += s6;
+    s3 += s7;
+    red[grp][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0 && col < n) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s += red[g][threadIdx.x];
+        if (col < e.n0) e.dst0[(size_t)(col / e.cols) * e.ldd + (col % e.cols)] = s;
+        else if (e.dst1) e.dst1[col - e.n0] = s;
+    }
+}
+
+int flush_reduces(hipStream_t stream) {
+    size_t i = 0;
+    while (i < g_deferred.size()) {
+        ReduceBatch b;
+        b.count = 0;
+        int blocks = 0;
+        while (i < g_deferred.size() && b.count < HNO_MAX_DEFERRED) {
+            ReduceEntry e = g_deferred[i++];
+            e.first_block = blocks;
+            blocks += ceil_div(e.n, 64);
+            b.e[b.count++] = e;
+        }
+        ProfScope ps(KID_REDUCE_PARTIALS, stream);
+        hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(blocks), dim3(1024), 0, stream, b);
+    }
+    g_deferred.clear();
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
 int reduce_partials_launch(const float *partials, int nblocks, int n, float *dst0, int n0, float *dst1,
-                           hipStream_t stream, int cols, int ldd) {
+                           hipStream_t stream, int cols, int ldd, bool allow_defer) {
     if (cols <= 0) cols = ldd = n0 > 0 ? n0 : 1;
+    if (g_defer_reduce && allow_defer) {
+        g_deferred.push_back(ReduceEntry{partials, dst0, dst1, nblocks, n, n0, cols, ldd, 0});
+        return HNO_OK;
+    }
     ProfScope ps(KID_REDUCE_PARTIALS, stream, 4.0 * n * ((double)nblocks + 1));
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(n, 64)), dim3(1024), 0, stream, partials, nblocks, n, dst0,
                        n0, dst1, cols, ldd);
@@ -155,6 +240,14 @@ __global__ __launch_bounds__(64) void selftest_gemm_kernel(const float *A, const
 using namespace hno;
 
 extern "C" int hno_version(void) { return 100; }
+
+extern "C" int hno_set_defer_reduce(int on) {
+    const int was = g_defer_reduce ? 1 : 0;
+    g_defer_reduce = on != 0;
+    return was;
+}
+extern "C" int hno_pending_reduces(void) { return (int)g_deferred.size(); }
+extern "C" int hno_flush_reduces(void *stream) { return flush_reduces((hipStream_t)stream); }
 extern "C" const char *hno_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" int hno_selftest_gemm(const float *A, const float *Bm, float *C, int M, int N, int K, void *stream) {

@@ -928,7 +928,7 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
                 // the bias gradient of an output block is the same in every input block: take it from the first
                 const bool want_bias = dbias && sgi == 0 && i0 == 0;
                 int rc = reduce_partials_launch(a.partials, grid, co * ci + co, dW + (size_t)o0 * Cin + sg.off + i0, co * ci,
-                                                want_bias ? dbias + o0 : nullptr, s, ci, Cin);
+                                                want_bias ? dbias + o0 : nullptr, s, ci, Cin, false);   // the slabs are reused by the next block
                 if (rc) return rc;
                 first_block = false;
             }

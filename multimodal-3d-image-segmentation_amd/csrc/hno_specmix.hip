@@ -493,6 +493,8 @@ static int specmix_bwd(const float *g, const float *z0, const float *zs, const f
         // once per block of 32 output channels, so the gradient ping-pongs between gz0 and a temporary
         // placed behind the slabs in the workspace (layer 0 lands in gz0)
         float *tmp = (float *)((char *)workspace + hno_pwconv_bwd_workspace_bytes(C, C));
+        const int was_deferring = hno_set_defer_reduce(0);   // the layers share one slab workspace: reduce each at once
+        struct Restore { int v; ~Restore() { hno_set_defer_reduce(v); } } restore{was_deferring};
         for (int l = L - 1; l >= 0; --l) {
             const float *in = l == 0 ? z0 : zs + (size_t)(l - 1) * layer;
             const float *gy = l == L - 1 ? g : ((l + 1) % 2 == 0 ? gz0 : tmp);
@@ -539,7 +541,7 @@ static int specmix_bwd(const float *g, const float *z0, const float *zs, const f
             }
         }
         HNO_CHECK_LAUNCH();
-        int rc = reduce_partials_launch(a.partials, grid, n, dW + (size_t)l0 * C * C, n, nullptr, s);
+        int rc = reduce_partials_launch(a.partials, grid, n, dW + (size_t)l0 * C * C, n, nullptr, s, 0, 0, L <= MIX_MAX_L);   // one round only
         if (rc) return rc;
     }
     return HNO_OK;

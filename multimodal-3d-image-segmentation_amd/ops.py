@@ -145,7 +145,8 @@ def pwconv_fwd_raw(xa, xb, W, bias, act):
     return y
 
 
-def pwconv_bwd_raw(gy, y, xa, xb, W, act, has_bias, need_gxa=True, need_gxb=True, xa_act=ACT_NONE, accumulate_into=None):
+def pwconv_bwd_raw(gy, y, xa, xb, W, act, has_bias, need_gxa=True, need_gxb=True, xa_act=ACT_NONE, accumulate_into=None,
+                   defer=False):
     """-> (gxa, gxb, dW, dbias); y is the saved output (None when act is NONE).  xa_act: also multiply
     gxa by act'(xa) (xa being the output of that activation)."""
     B, Ca = xa.shape[:2]
@@ -163,12 +164,14 @@ def pwconv_bwd_raw(gy, y, xa, xb, W, act, has_bias, need_gxa=True, need_gxb=True
     dW = torch.empty_like(W)
     db = torch.empty(Cout, device=W.device, dtype=torch.float32) if has_bias else None
     ws = _wgrad_ws(Ca + Cb, Cout, xa.device)
-    check(_lib.lib().hno_pwconv_bwd(ptr(gy), ptr(y), ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(gxa), ptr(gxb), ptr(dW),
-                                    ptr(db), ptr(ws), B, Cout, V, act, xa_act, acc_bits, stream_ptr()), 'hno_pwconv_bwd')
+    with _DeferReduce(defer) as d:
+        check(_lib.lib().hno_pwconv_bwd(ptr(gy), ptr(y), ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(gxa), ptr(gxb), ptr(dW),
+                                        ptr(db), ptr(ws), B, Cout, V, act, xa_act, acc_bits, stream_ptr()), 'hno_pwconv_bwd')
+        d.keep(ws)
     return gxa, gxb, dW, db
 
 
-def pwconv_bwd_branch_raw(gy, y, xa, xb, W, Wbr, act, xa_act):
+def pwconv_bwd_branch_raw(gy, y, xa, xb, W, Wbr, act, xa_act, defer=False):
     """Backward of  act(W [xa ; xb] + b)  where xa = xa_act(s + Wbr xb + bbr): one pass (hno_pwconv_bwd_branch).
     -> (p, gxb, dW, db, dWbr, dbbr) with p the gradient of the pre-activation sum s + Wbr xb + bbr."""
     B, Ca = xa.shape[:2]
@@ -179,13 +182,77 @@ def pwconv_bwd_branch_raw(gy, y, xa, xb, W, Wbr, act, xa_act):
     n_w, n_br = Cout * (Ca + Cb), Ca * Cb
     flat = torch.empty(n_w + Cout + n_br + Ca, device=xa.device, dtype=torch.float32)
     ws = torch.empty(L.hno_pwconv_bwd_branch_workspace_bytes(Ca, Cb, Cout) // 4, device=xa.device, dtype=torch.float32)
-    check(L.hno_pwconv_bwd_branch(ptr(gy), ptr(y), ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(Wbr), ptr(p), ptr(gxb), ptr(flat),
-                                  ptr(ws), B, Cout, V, act, xa_act, stream_ptr()), 'hno_pwconv_bwd_branch')
+    with _DeferReduce(defer) as d:
+        check(L.hno_pwconv_bwd_branch(ptr(gy), ptr(y), ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(Wbr), ptr(p), ptr(gxb), ptr(flat),
+                                      ptr(ws), B, Cout, V, act, xa_act, stream_ptr()), 'hno_pwconv_bwd_branch')
+        d.keep(ws)
     dW = flat[:n_w].view_as(W)
     db = flat[n_w:n_w + Cout]
     dWbr = flat[n_w + Cout:n_w + Cout + n_br].view(Ca, Cb)
     dbbr = flat[n_w + Cout + n_br:]
     return p, gxb, dW, db, dWbr, dbbr
+
+
+# ---- deferred slab reductions (include/hno.h: hno_set_defer_reduce) -------------------------------------------------
+# During autograd's backward the weight-gradient reductions of all layers are recorded and launched as ONE kernel from the
+# engine's end-of-backward callback; the slab workspaces are kept alive here until then.
+import os as _os
+_DEFER_ENABLED = bool(int(_os.environ.get('HNO_DEFER_REDUCE', '1')))
+_defer_state = {'active': False, 'keep': []}
+
+
+def _flush_deferred():
+    L = _lib.lib()
+    L.hno_set_defer_reduce(0)
+    try:
+        if L.hno_pending_reduces():
+            check(L.hno_flush_reduces(stream_ptr()), 'hno_flush_reduces')
+    finally:
+        _defer_state['active'] = False
+        _defer_state['keep'].clear()
+
+
+def _deferrable(*weights):
+    """A weight gradient may be produced late only if nothing reads it before the end of backward: the weight is a leaf
+    whose .grad is None (autograd then just installs the tensor), not a slice / cat / reshape of parameters (whose backward
+    nodes read the gradient) and not a gradient that will be accumulated into an existing .grad."""
+    return all(w is None or (w.is_leaf and w.grad is None) for w in weights)
+
+
+def _leaf_params(*ts):
+    """forward-time half of the check: the tensors handed in ARE leaves, used as they are (no fp32 / contiguous copy)."""
+    return all(t is None or (t.is_leaf and t.dtype == torch.float32 and t.is_contiguous()) for t in ts)
+
+
+class _DeferReduce:
+    """with _DeferReduce(ok) as d: <raw backward call>; d.keep(ws).  Defers only inside an autograd backward pass and only
+    when the caller vouches (``ok``) that the gradient is not read before the pass ends."""
+
+    def __init__(self, ok=False):
+        self.ok = ok
+
+    def __enter__(self):
+        self.on = False
+        if _DEFER_ENABLED and self.ok:
+            if not _defer_state['active']:
+                try:
+                    torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
+                    _defer_state['active'] = True
+                except RuntimeError:      # not inside backward(): reduce immediately
+                    pass
+            if _defer_state['active']:
+                _lib.lib().hno_set_defer_reduce(1)
+                self.on = True
+        return self
+
+    def keep(self, *tensors):
+        if self.on:
+            _defer_state['keep'].extend(tensors)
+
+    def __exit__(self, *exc):
+        if self.on:
+            _lib.lib().hno_set_defer_reduce(0)
+        return False
 
 
 def _layer_ptrs(Ws):
@@ -210,15 +277,17 @@ def specmix_fwd_raw(z0, W, residual, act):
     return zs
 
 
-def specmix_bwd_raw(g, z0, zs, W, residual, act):
+def specmix_bwd_raw(g, z0, zs, W, residual, act, defer=False):
     Ws = _mix_layers(W)
     B, C = z0.shape[:2]
     M, Lyr = _flat_v(z0), len(Ws)
     gz0 = torch.empty_like(z0)
     dW = torch.empty((Lyr, C, C), device=z0.device, dtype=torch.float32)
     ws = torch.empty(_lib.lib().hno_specmix_bwd_workspace_bytes(B, C, M, Lyr) // 4, device=z0.device, dtype=torch.float32)
-    check(_lib.lib().hno_specmix_layers_bwd(ptr(g), ptr(z0), ptr(zs), _layer_ptrs(Ws), ptr(gz0), ptr(dW), ptr(ws), B, C, M, Lyr,
-                                            int(residual), act, stream_ptr()), 'hno_specmix_layers_bwd')
+    with _DeferReduce(defer) as d:
+        check(_lib.lib().hno_specmix_layers_bwd(ptr(g), ptr(z0), ptr(zs), _layer_ptrs(Ws), ptr(gz0), ptr(dW), ptr(ws), B, C, M, Lyr,
+                                                int(residual), act, stream_ptr()), 'hno_specmix_layers_bwd')
+        d.keep(ws)
     return gz0, dW
 
 
@@ -632,6 +701,7 @@ class PwConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xa, xb, W, bias, act):
+        ctx.leaf_params = _leaf_params(W, bias)
         xa, xb, W, bias = _f32c(xa), _f32c(xb), _f32c(W), _f32c(bias)
         _need_gpu(xa, xb, W, bias)
         ctx.wide = PwConvFn._wide(xa, xb, W)
@@ -644,13 +714,13 @@ class PwConvFn(torch.autograd.Function):
                 check(_lib.lib().hno_bias_act(ptr(y), ptr(bias), B, Cout, V, act, stream_ptr()), 'hno_bias_act')
         else:
             y = pwconv_fwd_raw(xa, xb, W, bias, act)
-        ctx.save_for_backward(xa, xb, W, y if act != ACT_NONE else None)
+        ctx.save_for_backward(xa, xb, W, y if act != ACT_NONE else None, bias)
         ctx.act, ctx.has_bias = act, bias is not None
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        xa, xb, W, y = ctx.saved_tensors
+        xa, xb, W, y, bias = ctx.saved_tensors
         if ctx.wide:
             g = _f32c(gy)
             if ctx.act != ACT_NONE:
@@ -672,7 +742,7 @@ class PwConvFn(torch.autograd.Function):
             db = _chan_sum(g) if ctx.has_bias else None
             return gxa, None, dW, db, None
         gxa, gxb, dW, db = pwconv_bwd_raw(_f32c(gy), y, xa, xb, W, ctx.act, ctx.has_bias, ctx.needs_input_grad[0],
-                                          ctx.needs_input_grad[1])
+                                          ctx.needs_input_grad[1], defer=ctx.leaf_params and _deferrable(W, bias))
         return gxa, gxb, dW, db, None
 
 
@@ -718,6 +788,7 @@ class NOBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, fourier, modes, act, br_w, br_b, cat_w, cat_b, *op_ws):
+        ctx.leaf_params = _leaf_params(br_w, br_b, cat_w, cat_b, *op_ws)
         x, br_w, br_b, cat_w, cat_b = (_f32c(t) for t in (x, br_w, br_b, cat_w, cat_b))
         op_ws = [_f32c(w) for w in op_ws]
         _need_gpu(x, cat_w, *op_ws)
@@ -747,18 +818,19 @@ class NOBlockFn(torch.autograd.Function):
                                                    x.shape[0], 24, 24, 24, _flat_v(x), act, stream_ptr()), 'hno_pwconv_fwd_branch')
         else:
             out = pwconv_fwd_raw(y, x, cat_w, cat_b, act)
-        ctx.save_for_backward(x, br_w, cat_w, w, s0, s1 if not fourier else None, y, out)
+        ctx.save_for_backward(x, br_w, cat_w, w, s0, s1 if not fourier else None, y, out, br_b, cat_b, *op_ws)
         ctx.cfg = (bool(fourier), modes, act, spatial, n3, br_b is not None, cat_b is not None)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        x, br_w, cat_w, w, s0, s1, y, out = ctx.saved_tensors
+        x, br_w, cat_w, w, s0, s1, y, out, br_b, cat_b, *op_ws = ctx.saved_tensors
         fourier, modes, act, spatial, n3, br_has_b, cat_has_b = ctx.cfg
+        late = ctx.leaf_params and _deferrable(br_w, br_b, cat_w, cat_b, *op_ws)   # (the Fourier mix reads its dW2 at once: never late)
         d_br_w = d_br_b = None
         if br_w is not None and tuple(cat_w.shape[:2]) == (24, 48) and tuple(br_w.shape[:2]) == (24, 24):
             # one pass: p = d loss / d (s + x2) = g_y * act'(y); g_x = concat-path gradient + Wbr^T p; all four parameter gradients
-            p, g_x, d_cat_w, d_cat_b, d_br_w, d_br_b = pwconv_bwd_branch_raw(_f32c(g_out), out, y, x, cat_w, br_w, act, act)
+            p, g_x, d_cat_w, d_cat_b, d_br_w, d_br_b = pwconv_bwd_branch_raw(_f32c(g_out), out, y, x, cat_w, br_w, act, act, defer=late)
             d_br_w = d_br_w.view_as(br_w)
             if not cat_has_b:
                 d_cat_b = None
@@ -766,9 +838,10 @@ class NOBlockFn(torch.autograd.Function):
                 d_br_b = None
         else:
             # p through the conv's xa_act product; the branch conv (its output gradient is p) adds its input gradient to g_x
-            p, g_x, d_cat_w, d_cat_b = pwconv_bwd_raw(_f32c(g_out), out, y, x, cat_w, act, cat_has_b, xa_act=act)
+            p, g_x, d_cat_w, d_cat_b = pwconv_bwd_raw(_f32c(g_out), out, y, x, cat_w, act, cat_has_b, xa_act=act, defer=late)
             if br_w is not None:
-                _, _, d_br_w, d_br_b = pwconv_bwd_raw(p, None, x, None, br_w, ACT_NONE, br_has_b, accumulate_into=(g_x, None))
+                _, _, d_br_w, d_br_b = pwconv_bwd_raw(p, None, x, None, br_w, ACT_NONE, br_has_b, accumulate_into=(g_x, None),
+                                                      defer=late)
         if fourier:
             gs1 = rfft3_crop_raw(p, modes, 1.0, True)
             gs0, _, dw2, _ = pwconv_bwd_raw(gs1, None, s0, None, w, ACT_NONE, False)
@@ -780,7 +853,7 @@ class NOBlockFn(torch.autograd.Function):
             d_ops = (dwr, dwi)
         else:
             gs1 = dht3_crop_raw(p, modes, 1.0)
-            gs0, _, dw, _ = pwconv_bwd_raw(gs1, s1, s0, None, w, ACT_SELU, False)
+            gs0, _, dw, _ = pwconv_bwd_raw(gs1, s1, s0, None, w, ACT_SELU, False, defer=late)
             gx = pad_idht3_raw(gs0, spatial, 1.0 / n3, g_x, ACT_NONE)
             d_ops = (dw,)
         return (gx, None, None, None, d_br_w, d_br_b, d_cat_w, d_cat_b) + d_ops
@@ -802,6 +875,7 @@ class XSBlockFn(torch.autograd.Function):
         tensor as its U-Net skip then sends its gradient HERE instead of to a second consumer edge of `x`, and
         the backward below folds it into the store of the concat-path gradient -- autograd's separate
         accumulation kernel (3 x 158 MB of traffic per step in HNOSeg-XS) disappears."""
+        ctx.leaf_params = _leaf_params(map_w, map_b, cat_w, cat_b, *mix_ws)
         x, skip, map_w, map_b, cat_w, cat_b = (_f32c(t) for t in (x, skip, map_w, map_b, cat_w, cat_b))
         mix_ws = [_f32c(w) for w in mix_ws]
         _need_gpu(x, skip, cat_w, *mix_ws)
@@ -814,7 +888,7 @@ class XSBlockFn(torch.autograd.Function):
         zs = specmix_fwd_raw(z0, mix_ws, 1, act)
         u = pad_idht3_raw(zs[-1], spatial, 1.0, None, act)
         out = pwconv_fwd_raw(u, xm, cat_w, cat_b, act)
-        ctx.save_for_backward(x, skip, map_w, xm if has_map else None, z0, zs, u, cat_w, out, *mix_ws)
+        ctx.save_for_backward(x, skip, map_w, xm if has_map else None, z0, zs, u, cat_w, out, map_b, cat_b, *mix_ws)
         ctx.cfg = (has_map, modes, act, spatial, n3, map_b is not None, cat_b is not None, bool(passthrough))
         ctx.set_materialize_grads(False)
         if passthrough:
@@ -823,10 +897,13 @@ class XSBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out, g_pass=None):
-        x, skip, map_w, xm, z0, zs, u, cat_w, out, *mix_ws = ctx.saved_tensors
+        x, skip, map_w, xm, z0, zs, u, cat_w, out, map_b, cat_b, *mix_ws = ctx.saved_tensors
         has_map, modes, act, spatial, n3, map_has_b, cat_has_b, passthrough = ctx.cfg
         if not has_map:
             xm = x
+        # weight gradients of leaves with .grad None are not read before backward ends: their slab reductions are batched
+        lp = ctx.leaf_params
+        late_cat, late_mix, late_map = lp and _deferrable(cat_w, cat_b), lp and _deferrable(*mix_ws), lp and _deferrable(map_w, map_b)
         if g_out is None:
             raise _lib.HnoError('XSBlockFn.backward: no gradient for the block output')
         g_pass = _f32c(g_pass) if g_pass is not None else None
@@ -835,16 +912,17 @@ class XSBlockFn(torch.autograd.Function):
         # gradient by the same kernel (gxb += ...), in the buffer autograd handed us.
         fuse_pass = g_pass is not None and not has_map
         g_u, g_skipin, d_cat_w, d_cat_b = pwconv_bwd_raw(_f32c(g_out), out, u, xm, cat_w, act, cat_has_b, xa_act=act,
-                                                         accumulate_into=(None, g_pass) if fuse_pass else None)
+                                                         accumulate_into=(None, g_pass) if fuse_pass else None, defer=late_cat)
         g_zl = dht3_crop_raw(g_u, modes, 1.0)                               # PadInverse^T
-        g_z0, d_mix = specmix_bwd_raw(g_zl, z0, zs, mix_ws, 1, act)
+        g_z0, d_mix = specmix_bwd_raw(g_zl, z0, zs, mix_ws, 1, act, defer=late_mix)
         g_xm = pad_idht3_raw(g_z0, spatial, 1.0 / n3, g_skipin, ACT_NONE)    # TransformCrop^T + skip gradient
         d_mix = tuple(d_mix.unbind(0))
         if not has_map:
             return (g_xm, None, None, None, d_cat_w, d_cat_b, None, None, None) + d_mix
         g_x, g_skip, d_map_w, d_map_b = pwconv_bwd_raw(g_xm, xm, x, skip, map_w, act, map_has_b,
                                                        ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                                       accumulate_into=(g_pass, None) if g_pass is not None else None)
+                                                       accumulate_into=(g_pass, None) if g_pass is not None else None,
+                                                       defer=late_map)
         return (g_x, g_skip, d_map_w, d_map_b, d_cat_w, d_cat_b, None, None, None) + d_mix
 
 

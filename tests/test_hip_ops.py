@@ -849,3 +849,39 @@ def test_hartley_mha_bias_vs_golden(pkg, ci):
     for (pn, _), gp in zip(op.named_parameters(), gs[nin:]):
         assert tuple(gp.shape) == g[f'{k}_g_{pn}'].shape
         assert rel_err(gp.cpu().numpy(), g[f'{k}_g_{pn}']) < TOL, pn
+
+
+def test_deferred_weight_gradient_reduction(pkg):
+    """The weight-gradient slab reductions of a backward pass are batched into one launch (ops._DeferReduce).  Results must be
+    bit-identical to the eager reductions, accumulation into existing .grad must still work (no deferral then), and
+    gradients requested through torch.autograd.grad must be complete when it returns."""
+    from multimodal_3d_image_segmentation_amd import ops
+    from multimodal_3d_image_segmentation_amd.nets import custom_losses
+    torch.manual_seed(2)
+    model = pkg.nets.HNOSegXS(2, 3, 8, [2, 2], (3, 3, 3), device='cuda')
+    x = torch.randn(1, 2, 16, 16, 16, device='cuda')
+    lab = pkg.ops.labels_prepare(torch.randint(0, 3, (1, 1, 16, 16, 16), device='cuda').float(), 3)
+    loss_fn = custom_losses.PCCLoss()
+
+    def grads(defer, twice=False):
+        ops._DEFER_ENABLED = defer
+        for p in model.parameters():
+            p.grad = None
+        loss_fn(model(x), lab).backward()
+        if twice:                       # second backward accumulates into the existing .grad
+            loss_fn(model(x), lab).backward()
+        return [p.grad.clone() for p in model.parameters()]
+    try:
+        eager, late = grads(False), grads(True)
+        for a, b in zip(eager, late):
+            assert torch.equal(a, b)
+        twice = grads(True, twice=True)
+        for a, b in zip(eager, twice):
+            assert rel_err(b.cpu().numpy(), 2.0 * a.cpu().numpy()) < 1e-6
+        ops._DEFER_ENABLED = True
+        gs = torch.autograd.grad(loss_fn(model(x), lab), list(model.parameters()))
+        for a, b in zip(eager, gs):
+            assert torch.equal(a, b)
+        assert pkg._lib.lib().hno_pending_reduces() == 0
+    finally:
+        ops._DEFER_ENABLED = True
