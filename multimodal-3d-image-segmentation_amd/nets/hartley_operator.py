@@ -57,9 +57,15 @@ class HartleyOperator(Module):
             init.zeros_(self.bias)
 
     # -- forward -----------------------------------------------------------------------
+    def _is_lifted_2d(self, inputs):
+        """a 2-D operator (two mode counts / 4-D per-mode weights) fed the (B, C, 1, H, W) view of a 2-D model"""
+        return inputs.ndim == 5 and (self.weight.ndim == 4 or (self.num_modes is not None and len(self.num_modes) == 2))
+
     def forward(self, inputs):
         if inputs.ndim == 4:
             return self._lifted()(inputs.unsqueeze(2)).squeeze(2)
+        if self._is_lifted_2d(inputs):
+            return self._lifted()(inputs)
         if self.use_transform:
             return self._call3d(inputs)
         x = self._mix(inputs)
@@ -92,6 +98,8 @@ class HartleyOperator(Module):
         if inputs.ndim == 4:
             return self._lifted().forward_fused(inputs.unsqueeze(2), None if addend is None else addend.unsqueeze(2),
                                                 act).squeeze(2)
+        if self._is_lifted_2d(inputs):
+            return self._lifted().forward_fused(inputs, addend, act)
         if not self.use_transform or addend is None and act == ops.ACT_NONE:
             y = self(inputs)
             if addend is not None:

@@ -43,7 +43,8 @@ class TransformCrop(nn.Module):
             modes = (0,) + ops.clamp_modes(self.num_modes, spatial)
             return ops.DhtCropFn.apply(x.unsqueeze(2), modes, 1.0 / float(np.prod(spatial))).squeeze(2)
         spatial = tuple(x.shape[2:])
-        modes = ops.clamp_modes(self.num_modes, spatial)
+        nm = (0,) + tuple(self.num_modes) if len(self.num_modes) == 2 else self.num_modes   # 2-D model on a (B, C, 1, H, W) view
+        modes = ops.clamp_modes(nm, spatial)
         return ops.DhtCropFn.apply(x, modes, 1.0 / float(np.prod(spatial)))
 
 
@@ -231,8 +232,11 @@ class HNOSegXS(nn.Module):
             self.apply(init_weights_for_snn)
 
     def forward(self, x):
-        if x.ndim != 5:
-            raise NotImplementedError('2-D (ndim=4) HNOSeg-XS is not provided by the HIP path yet')
+        if x.ndim == 4:
+            # 2-D model (ndim = 4): the same kernels on a (B, C, 1, H, W) view.  A size-1 axis is transformed by a copy, the
+            # 2 x 2 / stride 2 / padding 1 stem is the 3-D kernel with its taps at kd = 1, trilinear resampling with depth
+            # 1 -> 1 is bilinear, and every other layer is pointwise.
+            return self.forward(x.unsqueeze(2)).squeeze(2)
         image_size = tuple(x.shape[2:])
         ds, enc = [], {}
         if self.use_resize:

@@ -67,18 +67,32 @@ def _is_selu(activation):
     return activation == 'selu' or activation is nn.functional.selu
 
 
+def _lib_error(msg):
+    from .. import _lib
+    return _lib.HnoError(msg)
+
+
 def conv_forward(op, x, act_id, xb=None):
     """Run a conv parameter container through the HIP kernels (optionally with a fused concat
     of a second input for 1x1x1 convs)."""
-    k = op.kernel_size if not np.isscalar(op.kernel_size) else (op.kernel_size,) * (x.ndim - 2)
-    s = op.stride if not np.isscalar(op.stride) else (op.stride,) * (x.ndim - 2)
+    nsp = op.weight.ndim - 2                       # 2 for nn.Conv2d parameters, 3 for nn.Conv3d
+    k = op.kernel_size if not np.isscalar(op.kernel_size) else (op.kernel_size,) * nsp
+    s = op.stride if not np.isscalar(op.stride) else (op.stride,) * nsp
     if x.ndim != 5:
-        raise NotImplementedError('2-D (ndim=4) models are not provided by the HIP path yet')
+        raise _lib_error('conv_forward expects (B, C, D, H, W); 2-D models lift their input to D = 1 first')
     if all(v == 1 for v in k) and all(v == 1 for v in s):
         return ops.PwConvFn.apply(x, xb, op.weight, op.bias, act_id)
     assert xb is None
     if all(v == 2 for v in k) and all(v == 2 for v in s):
-        return ops.ConvK2S2Fn.apply(x, op.weight, op.bias, act_id)
+        w = op.weight
+        if nsp == 2:
+            # 2-D model on a (B, C, 1, H, W) view: Conv2d(k 2, s 2, p 1) == the 3-D kernel with the 2-D taps at kd = 1 (the
+            # kd = 0 taps read the depth padding); autograd slices the weight gradient back
+            assert x.shape[2] == 1
+            w = torch.stack([torch.zeros_like(w), w], dim=2)
+        return ops.ConvK2S2Fn.apply(x, w, op.bias, act_id)
+    if nsp == 2:
+        raise NotImplementedError(f'Conv2d kernel {tuple(k)} stride {tuple(s)} is not provided by the HIP path (1x1, 2x2/s2)')
     from .conv3d import conv3d_forward  # general kernels (V-Net path)
     return conv3d_forward(op, x, act_id)
 

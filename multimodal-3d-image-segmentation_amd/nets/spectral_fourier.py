@@ -17,8 +17,10 @@ def complex_mix_shared(spec, weight_real, weight_imag):
 
 
 def fourier_operator_forward(op, inputs, addend=None, act=ops.ACT_NONE):
-    if inputs.ndim == 4:
+    lifted = inputs.ndim == 5 and (op.weight_real.ndim == 4 or (op.num_modes is not None and len(op.num_modes) == 2))
+    if inputs.ndim == 4 or lifted:
         # 2-D (reference _call2d :117-160): the same kernels on (B, C, 1, H, W) -- the transform of a size-1 axis is a copy
+        # (`lifted`: a 2-D operator inside a 2-D model that already runs on that view)
         from types import SimpleNamespace
         ind = op.weights_type != 'shared'
         view = SimpleNamespace(use_transform=op.use_transform, weights_type=op.weights_type, use_bias=op.use_bias,
@@ -26,6 +28,8 @@ def fourier_operator_forward(op, inputs, addend=None, act=ops.ACT_NONE):
                                weight_real=op.weight_real.unsqueeze(2) if ind else op.weight_real,
                                weight_imag=op.weight_imag.unsqueeze(2) if ind else op.weight_imag,
                                bias=None if op.bias is None else op.bias.unsqueeze(2))
+        if lifted:
+            return fourier_operator_forward(view, inputs, addend, act)
         y = fourier_operator_forward(view, inputs.unsqueeze(2), None if addend is None else addend.unsqueeze(2), act)
         return y.squeeze(2)
     if not op.use_transform:

@@ -793,6 +793,8 @@ class NOBlockFn(torch.autograd.Function):
         op_ws = [_f32c(w) for w in op_ws]
         _need_gpu(x, cat_w, *op_ws)
         spatial = tuple(x.shape[2:])
+        if len(modes) == 2:                      # 2-D model on a (B, C, 1, H, W) view
+            modes = (0,) + tuple(modes)
         modes = clamp_modes(modes, spatial)
         n3 = float(np.prod(spatial))
         # 24 + 24 -> 24 with a conv branch: branch conv, add, activation and concat conv in one pass after the inverse
@@ -882,6 +884,8 @@ class XSBlockFn(torch.autograd.Function):
         has_map = map_w is not None
         xm = pwconv_fwd_raw(x, skip, map_w, map_b, act) if has_map else x
         spatial = tuple(xm.shape[2:])
+        if len(modes) == 2:                      # 2-D model on a (B, C, 1, H, W) view
+            modes = (0,) + tuple(modes)
         modes = clamp_modes(modes, spatial)
         n3 = float(np.prod(spatial))
         z0 = dht3_crop_raw(xm, modes, 1.0 / n3)

@@ -207,3 +207,19 @@ def raw_modalities():
     vol[:, :2] = 0
     vol[:, :, :3, :4] = 0
     return vol.astype(np.float32)
+
+
+# tiny 2-D (ndim = 4) models (golden G13): name -> (class name, ctor kwargs, input shape)
+MODELS_2D = {
+    'xs2d': ('HNOSegXS', dict(in_channels=2, out_channels=3, filters=8, num_transform_blocks=[1, 2, 1, 1], num_modes=(4, 5), ndim=4),
+             (1, 2, 24, 28)),
+    'xs2d_ds_noskip': ('HNOSegXS', dict(in_channels=1, out_channels=2, filters=8, num_transform_blocks=[1, 1], num_modes=(3, 3),
+                                        use_deep_supervision=True, use_unet_skip=False, ndim=4), (2, 1, 17, 20)),
+    'hnoseg2d': ('NeuralOperatorSeg', dict(in_channels=2, out_channels=3, filters=8, num_transform_blocks=2, num_modes=(4, 5),
+                                           transform_type='Hartley', ndim=4), (1, 2, 24, 28)),
+    'fnoseg2d': ('NeuralOperatorSeg', dict(in_channels=2, out_channels=2, filters=8, num_transform_blocks=2, num_modes=(4, 5),
+                                           transform_type='Fourier', ndim=4), (1, 2, 24, 28)),
+    'fno2d_individual': ('NeuralOperatorSeg', dict(in_channels=2, out_channels=2, filters=8, num_transform_blocks=2, num_modes=(3, 4),
+                                                   transform_type='Fourier', weights_type='individual', use_bias_conv_branch=True,
+                                                   use_block_skip=False, ndim=4), (1, 2, 24, 28)),
+}

@@ -430,6 +430,29 @@ def g12_mha_bias():
     save('g12_mha_bias.npz', **out)
 
 
+# ------------------------------------------------------------- G13: tiny 2-D (ndim = 4) models
+def g13_models_2d():
+    from _inputs import MODELS_2D
+    out = {}
+    for name, (cls, kw, shape) in MODELS_2D.items():
+        torch.manual_seed(61)
+        model = getattr(nets, cls)(**kw)
+        for k, v in model.state_dict().items():
+            out[f'{name}::sd::{k}'] = v.detach().numpy().copy()
+        K = kw['out_channels']
+        x = T(formula_tensor(shape, 14))
+        lab = formula_labels((shape[0], 1) + shape[2:], K, 16)
+        onehot = torch.movedim(torch.nn.functional.one_hot(T(lab)[:, 0].long(), K).float(), -1, 1)
+        y = model(x)
+        loss = custom_losses.PCCLoss()(y, onehot)
+        loss.backward()
+        out[f'{name}::y'] = y.detach().numpy()
+        out[f'{name}::loss'] = loss.detach().numpy()
+        for k, p_ in model.named_parameters():
+            out[f'{name}::grad::{k}'] = p_.grad.detach().numpy().copy()
+    save('g13_models_2d.npz', **out)
+
+
 # ------------------------------------------------------------- G7v: tiny V-Net-DS variants
 def g7v_vnet_models():
     from _inputs import VNET_MODELS, formula_volume
@@ -502,7 +525,7 @@ def g8_training():
 
 if __name__ == '__main__':
     ALL = [g1_dht, g2_crop_pad, g3_operators, g4_mha, g5_losses, g6_hnosegxs, g6s_small_models, g7_noseg_models,
-           g7v_vnet_models, g9_misc, g10_two_d, g11_input, g12_mha_bias, g8_training]
+           g7v_vnet_models, g9_misc, g10_two_d, g11_input, g12_mha_bias, g13_models_2d, g8_training]
     only = set(sys.argv[2:])   # e.g. `make_golden.py /root/reference g10_two_d` regenerates one fixture
     for fn in ALL:
         if not only or fn.__name__ in only:

@@ -885,3 +885,31 @@ def test_deferred_weight_gradient_reduction(pkg):
         assert pkg._lib.lib().hno_pending_reduces() == 0
     finally:
         ops._DEFER_ENABLED = True
+
+
+from _inputs import MODELS_2D  # noqa: E402
+
+
+@pytest.mark.parametrize('name', list(MODELS_2D))
+def test_models_2d_vs_golden(pkg, name):
+    """2-D (ndim = 4) HNOSeg-XS / HNOSeg / FNOSeg / FNO: outputs, loss and every gradient within 1e-4 of the reference (golden
+    G13).  The 2-D models run the 3-D kernels on a (B, C, 1, H, W) view."""
+    from multimodal_3d_image_segmentation_amd.nets import custom_losses
+    g = load_golden('g13_models_2d.npz')
+    cls, kw, shape = MODELS_2D[name]
+    model = getattr(pkg.nets, cls)(**kw)
+    pre = f'{name}::sd::'
+    model.load_state_dict({k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)})
+    model = model.cuda()
+    K = kw['out_channels']
+    x = T(formula_tensor(shape, 14))
+    lab = T(formula_labels((shape[0], 1) + shape[2:], K, 16))
+    y = model(x)
+    assert tuple(y.shape) == g[f'{name}::y'].shape
+    loss = custom_losses.PCCLoss()(y, pkg.ops.labels_prepare(lab, K))
+    loss.backward()
+    assert rel_err(y.detach().cpu().numpy(), g[f'{name}::y']) < TOL
+    assert abs(float(loss.detach()) - float(g[f'{name}::loss'])) < 1e-5
+    for k, p in model.named_parameters():
+        assert tuple(p.grad.shape) == g[f'{name}::grad::{k}'].shape, k
+        assert rel_err(p.grad.cpu().numpy(), g[f'{name}::grad::{k}']) < TOL, k
