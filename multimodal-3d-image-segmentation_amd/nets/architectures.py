@@ -137,8 +137,6 @@ class _TransSeg(nn.Module):
 
     def forward(self, x):
         if x.ndim == 4:   # 2-D model (ndim = 4): the same kernels on a (B, C, 1, H, W) view (see HNOSegXS.forward)
-            if isinstance(self, HartleyMHASeg):
-                raise NotImplementedError('2-D (ndim=4) HartleyMHASeg is not provided by the HIP path yet')
             return self.forward(x.unsqueeze(2)).squeeze(2)
         image_size = tuple(x.shape[2:])
         tensors = []

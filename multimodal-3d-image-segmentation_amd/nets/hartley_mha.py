@@ -95,10 +95,17 @@ class HartleyMultiHeadAttention(Module):
             srcs = list(inputs)
         else:
             srcs = [inputs]
-        if srcs[0].ndim != 5:
-            raise NotImplementedError('2-D (ndim=4) Hartley attention is not provided by the HIP path yet')
+        if srcs[0].ndim == 4:
+            # 2-D (reference freq_conv2d / grouping2d :165-168, :180-184): the same kernels on (B, C, 1, H, W)
+            out = self.forward_fused([t.unsqueeze(2) for t in srcs] if len(srcs) > 1 else srcs[0].unsqueeze(2),
+                                     None if addend is None else addend.unsqueeze(2), act)
+            return out.squeeze(2)
         spatial = tuple(srcs[0].shape[2:])
         modes = self.num_modes
+        patch = self.patch_size
+        if len(modes) == 2:                     # a 2-D attention on the (B, C, 1, H, W) view: depth has one mode and patch 1
+            modes = (0,) + tuple(modes)
+            patch = None if patch is None else (1,) + tuple(patch)
         if self.use_transform:
             assert all(s >= 2 * m for s, m in zip(spatial, modes))      # no clamping here (reference :159-163)
             n3 = float(np.prod(spatial))
@@ -125,8 +132,8 @@ class HartleyMultiHeadAttention(Module):
             k = ops.PwConvFn.apply(k_src, None, wk, bk, ops.ACT_NONE)
             v = ops.PwConvFn.apply(v_src, None, wv, bv, ops.ACT_NONE)
         q, k, v = (t.reshape(t.shape[0], Z, t.shape[1] // Z, *fsp) for t in (q, k, v))   # (B, Z, K, d, h, w)
-        if self.patch_size is not None:
-            q, k, v = (grouping3d(t, self.patch_size) for t in (q, k, v))
+        if patch is not None:
+            q, k, v = (grouping3d(t, patch) for t in (q, k, v))
         freq_shape = tuple(q.shape[3:])
         q, k, v = (t.reshape(t.shape[0], Z, t.shape[2], -1).contiguous() for t in (q, k, v))   # (B, Z, C', T)
         att = ops.BmmFn.apply(q, k, True, False, 1.0 / math.sqrt(k.shape[2]))                  # (B, Z, Tq, Tk)
@@ -134,8 +141,8 @@ class HartleyMultiHeadAttention(Module):
             att = ops.ActFn.apply(att, act_att)
         out = ops.BmmFn.apply(v, att, False, True, 1.0)                                         # (B, Z, C', Tq)
         out = out.reshape(out.shape[0], Z, out.shape[2], *freq_shape)
-        if self.patch_size is not None:
-            out = ungrouping3d(out, self.value_dim, self.patch_size)
+        if patch is not None:
+            out = ungrouping3d(out, self.value_dim, patch)
         out = out.reshape(out.shape[0], Z * self.value_dim, *out.shape[3:]).contiguous()
         out = ops.PwConvFn.apply(out, None, self.weight_out, bo, ops.ACT_NONE)                 # 'oi,bidhw->bodhw' (+ bias_out)
         if not self.use_transform:

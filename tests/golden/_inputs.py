@@ -222,4 +222,6 @@ MODELS_2D = {
     'fno2d_individual': ('NeuralOperatorSeg', dict(in_channels=2, out_channels=2, filters=8, num_transform_blocks=2, num_modes=(3, 4),
                                                    transform_type='Fourier', weights_type='individual', use_bias_conv_branch=True,
                                                    use_block_skip=False, ndim=4), (1, 2, 24, 28)),
+    'mhaseg2d': ('HartleyMHASeg', dict(in_channels=2, out_channels=3, filters=8, num_transform_blocks=2, num_heads=2,
+                                       num_modes=(4, 6), patch_size=(2, 2), ndim=4), (1, 2, 24, 28)),
 }
