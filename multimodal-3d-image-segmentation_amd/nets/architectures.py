@@ -325,8 +325,8 @@ class VNetDS(nn.Module):
             self.apply(init_weights_for_snn)
 
     def forward(self, x):
-        if x.ndim != 5:
-            raise NotImplementedError('2-D (ndim=4) V-Net-DS is not provided by the HIP path yet')
+        if x.ndim == 4:   # 2-D model (ndim = 4): the same kernels on a (B, C, 1, H, W) view (see nets/conv3d.py for the 3x3 layers)
+            return self.forward(x.unsqueeze(2)).squeeze(2)
         image_size = tuple(x.shape[2:])
         self.encode_tensors, self.right_leg = {}, {}
         if self.use_resize:

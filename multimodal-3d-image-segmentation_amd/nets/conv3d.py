@@ -1,6 +1,7 @@
 """Dispatch of the V-Net-DS layer types to the HIP kernels (3x3x3 convolutions, transposed convolution,
 GroupNorm(1, C) + activation)."""
 import numpy as np
+import torch
 
 from .. import ops
 
@@ -9,20 +10,42 @@ def _k(op):
     return tuple(op.kernel_size) if not np.isscalar(op.kernel_size) else (op.kernel_size,) * 3
 
 
+def _embed_2d(w):
+    """(C0, C1, 3, 3) weights of a 2-D layer -> (C0, C1, 3, 3, 3) with the 2-D taps in the middle depth plane: on a
+    (B, C, 1, H, W) view with padding 1 the outer depth taps only ever meet the padding (autograd slices the gradient back)."""
+    z = torch.zeros_like(w)
+    return torch.stack([z, w, z], dim=2)
+
+
 def conv3d_forward(op, x, act_id):
-    """nn.Conv3d parameter container -> implicit-GEMM kernel (kernel 3, stride 1 'same' or stride 2 padding 1)."""
-    k, s = _k(op), tuple(op.stride) if not np.isscalar(op.stride) else (op.stride,) * 3
-    if k != (3, 3, 3) or s not in ((1, 1, 1), (2, 2, 2)):
-        raise NotImplementedError(f'Conv3d kernel {k} stride {s} is not provided by the HIP path (1x1x1, 2x2x2/s2, 3x3x3/s1|s2)')
-    y = ops.Conv3dK3Fn.apply(x, op.weight, op.bias, s[0])
+    """nn.Conv3d parameter container -> implicit-GEMM kernel (kernel 3, stride 1 'same' or stride 2 padding 1).  nn.Conv2d
+    containers (2-D models on a D = 1 view) go through the same kernel with embedded weights."""
+    nsp = op.weight.ndim - 2
+    k = tuple(op.kernel_size) if not np.isscalar(op.kernel_size) else (op.kernel_size,) * nsp
+    s = tuple(op.stride) if not np.isscalar(op.stride) else (op.stride,) * nsp
+    if k != (3,) * nsp or s not in ((1,) * nsp, (2,) * nsp):
+        raise NotImplementedError(f'Conv kernel {k} stride {s} is not provided by the HIP path (1x1x1, 2x2x2/s2, 3x3x3/s1|s2)')
+    w = op.weight
+    if nsp == 2:
+        assert x.shape[2] == 1
+        w = _embed_2d(w)
+    y = ops.Conv3dK3Fn.apply(x, w, op.bias, s[0])
     return ops.ActFn.apply(y, act_id) if act_id != ops.ACT_NONE else y
 
 
 def conv_transpose3d_forward(op, x, act_id):
-    k = _k(op)
-    if k != (3, 3, 3):
-        raise NotImplementedError(f'ConvTranspose3d kernel {k} is not provided by the HIP path (3x3x3, stride 2)')
-    y = ops.ConvT3dK3Fn.apply(x, op.weight, op.bias)
+    nsp = op.weight.ndim - 2
+    k = tuple(op.kernel_size) if not np.isscalar(op.kernel_size) else (op.kernel_size,) * nsp
+    if k != (3,) * nsp:
+        raise NotImplementedError(f'ConvTranspose kernel {k} is not provided by the HIP path (3x3x3, stride 2)')
+    w = op.weight
+    if nsp == 2:
+        # ConvTranspose2d on the D = 1 view: the 3-D kernel doubles the depth as well; with the taps in the middle depth plane
+        # output plane 0 is the 2-D result (plane 1 only holds the bias) -- keep plane 0
+        assert x.shape[2] == 1
+        y = ops.ConvT3dK3Fn.apply(x, _embed_2d(w), op.bias)[:, :, :1].contiguous()
+    else:
+        y = ops.ConvT3dK3Fn.apply(x, w, op.bias)
     return ops.ActFn.apply(y, act_id) if act_id != ops.ACT_NONE else y
 
 

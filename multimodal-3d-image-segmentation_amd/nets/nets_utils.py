@@ -91,8 +91,6 @@ def conv_forward(op, x, act_id, xb=None):
             assert x.shape[2] == 1
             w = torch.stack([torch.zeros_like(w), w], dim=2)
         return ops.ConvK2S2Fn.apply(x, w, op.bias, act_id)
-    if nsp == 2:
-        raise NotImplementedError(f'Conv2d kernel {tuple(k)} stride {tuple(s)} is not provided by the HIP path (1x1, 2x2/s2)')
     from .conv3d import conv3d_forward  # general kernels (V-Net path)
     return conv3d_forward(op, x, act_id)
 

@@ -224,4 +224,6 @@ MODELS_2D = {
                                                    use_block_skip=False, ndim=4), (1, 2, 24, 28)),
     'mhaseg2d': ('HartleyMHASeg', dict(in_channels=2, out_channels=3, filters=8, num_transform_blocks=2, num_heads=2,
                                        num_modes=(4, 6), patch_size=(2, 2), ndim=4), (1, 2, 24, 28)),
+    'vnet2d': ('VNetDS', dict(in_channels=2, out_channels=3, base_num_filters=4, num_blocks=[1, 2, 1], right_leg_indexes=[0, 1, 2],
+                              ndim=4), (1, 2, 40, 36)),
 }
