@@ -184,13 +184,6 @@ class NeuralOperatorSeg(_TransSeg):
         self.create_layers()
 
 
-class _Pending(nn.Module):
-    """Placeholder until the corresponding HIP path lands (later rows of SURVEY.md section 8)."""
-    def __init__(self, *args, **kwargs):
-        super().__init__()
-        raise NotImplementedError(f'{type(self).__name__} is not provided by the HIP path yet')
-
-
 class HartleyMHABlock(_TransBlock):
     """Hartley-MHA block (reference nets/architectures.py:611-635)."""
 
