@@ -30,6 +30,8 @@ extern "C" {
 #define HNO_ACT_NONE 0
 #define HNO_ACT_SELU 1
 #define HNO_ACT_ELU 2
+#define HNO_ACT_SIGMOID 3 /* hno_act_fwd / hno_act_bwd only (output activation of the models); the fused conv / transform
+                             epilogues take NONE, SELU or ELU */
 
 int hno_version(void);
 const char *hno_last_error(void);

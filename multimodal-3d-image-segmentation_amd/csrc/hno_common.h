@@ -107,12 +107,14 @@ __device__ __forceinline__ float neg_expm1(float x) {
 __device__ __forceinline__ float act_apply(float x, int act) {
     if (act == HNO_ACT_SELU) return x > 0.f ? HNO_SELU_SCALE * x : (HNO_SELU_SCALE * HNO_SELU_ALPHA) * neg_expm1(x);
     if (act == HNO_ACT_ELU) return x > 0.f ? x : neg_expm1(x);
+    if (act == HNO_ACT_SIGMOID) return 1.f / (1.f + __expf(-x));   // elementwise kernels only (hno_act_fwd / hno_act_bwd)
     return x;
 }
 // derivative expressed through the saved OUTPUT y = act(x)
 __device__ __forceinline__ float act_grad_from_out(float y, int act) {
     if (act == HNO_ACT_SELU) return y > 0.f ? HNO_SELU_SCALE : y + HNO_SELU_SCALE * HNO_SELU_ALPHA;
     if (act == HNO_ACT_ELU) return y > 0.f ? 1.f : y + 1.f;
+    if (act == HNO_ACT_SIGMOID) return y * (1.f - y);
     return 1.f;
 }
 

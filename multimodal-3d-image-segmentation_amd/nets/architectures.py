@@ -128,7 +128,7 @@ class _TransSeg(nn.Module):
             cur = self.out_channels
         conv = nn.Conv2d if self.ndim == 4 else nn.Conv3d
         self.conv_out = conv(cur, self.out_channels, kernel_size=1, bias=False, device=self.device)
-        self._softmax = self.output_activation == 'softmax'
+        self._softmax, self._out_act = ops.output_act(self.output_activation)
         if isinstance(self.output_activation, str):
             fn = getattr(nn.functional, self.output_activation)
             self.output_activation = partial(fn, dim=1) if self._softmax else fn
@@ -154,9 +154,7 @@ class _TransSeg(nn.Module):
             x = conv_over_concat(self.conv_ds, tensors)
         # conv_out commutes with the per-channel trilinear interpolation: run it at low resolution
         logits = ops.PwConvFn.apply(x, None, self.conv_out.weight, None, ops.ACT_NONE)
-        if not (self._softmax or self.output_activation is None):
-            raise NotImplementedError('only softmax / None output activations are provided by the HIP path')
-        y = ops.head_output(logits, image_size if self.use_resize else tuple(logits.shape[2:]), self._softmax)
+        y = ops.head_output(logits, image_size if self.use_resize else tuple(logits.shape[2:]), self._softmax, self._out_act)
         return spatial_padcrop(y, image_size)
 
 
@@ -308,7 +306,7 @@ class VNetDS(nn.Module):
             cur = self.out_channels
         convc = nn.Conv2d if ndim == 4 else nn.Conv3d
         self.conv_out = convc(cur, self.out_channels, kernel_size=1, bias=False, device=device)
-        self._softmax = self.output_activation == 'softmax'
+        self._softmax, self._out_act = ops.output_act(self.output_activation)
         if isinstance(self.output_activation, str):
             fn = getattr(nn.functional, self.output_activation)
             self.output_activation = partial(fn, dim=1) if self._softmax else fn
@@ -326,9 +324,7 @@ class VNetDS(nn.Module):
             x = self.conv_in(x)
         x = self.decode(self.encode(x))
         logits = ops.PwConvFn.apply(x, None, self.conv_out.weight, None, ops.ACT_NONE)   # commutes with the upsampling
-        if not (self._softmax or self.output_activation is None):
-            raise NotImplementedError('only softmax / None output activations are provided by the HIP path')
-        y = ops.head_output(logits, image_size if self.use_resize else tuple(logits.shape[2:]), self._softmax)
+        y = ops.head_output(logits, image_size if self.use_resize else tuple(logits.shape[2:]), self._softmax, self._out_act)
         return spatial_padcrop(y, image_size)
 
     def _section(self, layers, x, nconv):

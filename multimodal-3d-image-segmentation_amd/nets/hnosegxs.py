@@ -224,7 +224,7 @@ class HNOSegXS(nn.Module):
             cur = sum(ds_channels)
         conv = nn.Conv2d if self.ndim == 4 else nn.Conv3d
         self.conv_out = conv(cur, self.out_channels, kernel_size=1, bias=False, device=self.device)
-        self._softmax = self.output_activation == 'softmax'
+        self._softmax, self._out_act = ops.output_act(self.output_activation)
         if isinstance(self.output_activation, str):
             fn = getattr(nn.functional, self.output_activation)
             self.output_activation = partial(fn, dim=1) if self._softmax else fn
@@ -271,10 +271,8 @@ class HNOSegXS(nn.Module):
                 part = ops.PwConvFn.apply(f, None, w[:, c0:c0 + f.shape[1]].contiguous(), None, ops.ACT_NONE)
                 logits = part if logits is None else logits + part
                 c0 += f.shape[1]
-        if not (self._softmax or self.output_activation is None):
-            raise NotImplementedError('only softmax / None output activations are provided by the HIP path')
         if self.use_resize:
-            y = ops.head_output(logits, image_size, self._softmax)
+            y = ops.head_output(logits, image_size, self._softmax, self._out_act)
         else:
-            y = ops.head_output(logits, tuple(logits.shape[2:]), self._softmax)
+            y = ops.head_output(logits, tuple(logits.shape[2:]), self._softmax, self._out_act)
         return spatial_padcrop(y, image_size)

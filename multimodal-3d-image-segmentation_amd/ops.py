@@ -12,6 +12,7 @@ from . import _lib
 from ._lib import check, ptr, stream_ptr
 
 ACT_NONE, ACT_SELU, ACT_ELU = 0, 1, 2
+ACT_SIGMOID = 3     # elementwise ActFn only (model output activation); never passed to the fused conv / transform epilogues
 _ACT_IDS = {None: ACT_NONE, 'none': ACT_NONE, 'selu': ACT_SELU, 'elu': ACT_ELU}
 LOSS_KINDS = {'pcc': 0, 'dice': 1, 'expdice': 2}
 
@@ -1024,11 +1025,26 @@ def up_argmax(logits_lr, size):
     return labels
 
 
-def head_output(logits_lr, size, softmax):
+def output_act(output_activation):
+    """(softmax?, elementwise activation id) of a model's ``output_activation`` argument: 'softmax' (fused into the
+    upsampling kernel), None, or 'sigmoid' (multi-label outputs; an elementwise pass after the upsampling)."""
+    name = output_activation if isinstance(output_activation, str) or output_activation is None \
+        else getattr(output_activation, '__name__', None)
+    if name == 'softmax':
+        return True, ACT_NONE
+    if name is None and output_activation is None:
+        return False, ACT_NONE
+    if name == 'sigmoid':
+        return False, ACT_SIGMOID
+    raise NotImplementedError(f'output activation {output_activation!r} is not provided by the HIP path (softmax, sigmoid or None)')
+
+
+def head_output(logits_lr, size, softmax, out_act=ACT_NONE):
     """Output head shared by all model families: probabilities (training / evaluation) or labels (label_output())."""
     if getattr(_HEAD_MODE, 'labels', False):
-        return up_argmax(logits_lr, size)
-    return UpSoftmaxFn.apply(logits_lr, size, softmax)
+        return up_argmax(logits_lr, size)      # arg max of the logits == arg max after softmax / sigmoid
+    y = UpSoftmaxFn.apply(logits_lr, size, softmax)
+    return ActFn.apply(y, out_act) if out_act != ACT_NONE else y
 
 
 class SegLossFn(torch.autograd.Function):

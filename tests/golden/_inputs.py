@@ -224,6 +224,8 @@ MODELS_2D = {
                                                    use_block_skip=False, ndim=4), (1, 2, 24, 28)),
     'mhaseg2d': ('HartleyMHASeg', dict(in_channels=2, out_channels=3, filters=8, num_transform_blocks=2, num_heads=2,
                                        num_modes=(4, 6), patch_size=(2, 2), ndim=4), (1, 2, 24, 28)),
+    'xs2d_sigmoid': ('HNOSegXS', dict(in_channels=2, out_channels=2, filters=8, num_transform_blocks=[1, 1], num_modes=(3, 4),
+                                      output_activation='sigmoid', ndim=4), (1, 2, 20, 24)),      # multi-label style output
     'vnet2d': ('VNetDS', dict(in_channels=2, out_channels=3, base_num_filters=4, num_blocks=[1, 2, 1], right_leg_indexes=[0, 1, 2],
                               ndim=4), (1, 2, 40, 36)),
 }
