@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void c3_gemm_kernel(C3Args a) {
 // single MFMA and reaches 9 TFLOP/s.
 #define C3I_K 16
 template <int WR, int WC, int WM, int WN>
-__global__ __launch_bounds__(256) void c3_igemm_kernel(C3Args a) {
+__global__ __launch_bounds__(256, 4) void c3_igemm_kernel(C3Args a) {   // 4 blocks per CU (LDS): a 128-VGPR budget keeps the accumulators out of the AGPR shuffle
     constexpr int BM = 32 * WM * WR, BN = 32 * WN * WC, LDA = BM + 4, LDB = BN + 4;
     constexpr int NA = (BM * C3I_K + 255) / 256, NB = BN * C3I_K / 256, RSTEP = 256 / BN;   // BN in {128, 256}
     __shared__ float As[2][C3I_K * LDA], Bs[2][C3I_K * LDB];

@@ -474,7 +474,7 @@ __global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_branch_kernel(
 
 #define PWB_FAST_WAVES 4   // 256-thread blocks, two per CU (512 slabs): measured best of {4, 8, 12} waves x {256, 512, 1024} blocks
 template <int COUT, int CA, int CB, int NW = PWB_FAST_WAVES, int BR = 0>   // compile-time channel counts: every address select folds
-__global__ __launch_bounds__(64 * NW, (BR && NW == 4) ? 2 : 1) void pwconv_bwd_fast_kernel(PwBwdArgs a) {
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kernel(PwBwdArgs a) {   // 2 blocks per CU: a 256-register budget, all in VGPRs (no AGPR copies)
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
