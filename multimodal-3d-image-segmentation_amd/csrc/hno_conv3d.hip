@@ -180,27 +180,39 @@ __global__ __launch_bounds__(256, 4) void c3_igemm_kernel(C3Args a) {   // 4 blo
             for (int j = 0; j < NB; ++j) rb[j] = 1.f;
             return;
         }
+        // weights: rows beyond Cout of the last output tile read the neighbouring row (finite values that only reach output
+        // rows which are never stored; the re-laid weight buffer has slack behind its last row) -- no per-element predicate
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int e = tid + 256 * j;
             const int kk = e / BM, m = e - kk * BM;   // BM is a power of two
-            const int o = o0 + m;
-            const bool ok = e < BM * C3I_K && o < a.Cout;
-            const float val = a.wt[ok ? (size_t)(k0 + kk) * a.Cout + o : 0];
-            ra[j] = ok ? val : 0.f;
+            const bool ok = NA * 256 == BM * C3I_K || e < BM * C3I_K;
+            ra[j] = a.wt[ok ? (size_t)(k0 + kk) * a.Cout + (o0 + m) : 0];
         }
         // the whole K-step lies inside one tap (CinP % 16 == 0): the gather offset of this thread's voxel comes from the
-        // table built once per block; rows differ only by the channel (32-bit element offsets from a uniform base)
+        // table built once per block; rows differ only by the channel (32-bit element offsets from a uniform base).
+        // Out-of-range taps read element 0 and select zero; only the K-step that contains the zero-padded
+        // channels (Cin % 16 != 0) checks the channel index.
         const int tap = k0 / a.CinP, i0 = k0 - tap * a.CinP;
         const int off = Toff[tap * BN + col];
-        const bool ok = off >= 0;
-        const unsigned base = ok ? (unsigned)off : 0u;
+        const bool tap_ok = off >= 0;
+        const unsigned base = tap_ok ? (unsigned)off : 0u;
+        if (i0 + C3I_K <= a.Cin) {
+            unsigned idx = base + (unsigned)(i0 + row0) * (unsigned)Vi;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int i = i0 + row0 + RSTEP * j;
-            const bool oki = ok && i < a.Cin;
-            const float val = xb[oki ? base + (unsigned)i * (unsigned)Vi : 0u];
-            rb[j] = oki ? val : 0.f;
+            for (int j = 0; j < NB; ++j) {
+                const float val = xb[idx];
+                rb[j] = tap_ok ? val : 0.f;
+                idx += (unsigned)RSTEP * (unsigned)Vi;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int i = i0 + row0 + RSTEP * j;
+                const bool oki = off >= 0 && i < a.Cin;
+                const float val = xb[oki ? base + (unsigned)i * (unsigned)Vi : 0u];
+                rb[j] = oki ? val : 0.f;
+            }
         }
     };
     auto stage = [&](int buf) {
