@@ -26,7 +26,7 @@ def timeit(fn, n=20, warm=3, reps=3):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / (n * reps) * 1e3
 
-B, C, N = 2, 24, 65
+B, C, N = 2, 24, int(os.environ.get('MB_N', '65'))
 xa = torch.randn(B, C, N, N, N, device=dev); xb = torch.randn_like(xa)
 W = torch.randn(C, 2 * C, device=dev) * 0.1; bias = torch.randn(C, device=dev) * 0.01
 which = sys.argv[1] if len(sys.argv) > 1 else 'all'
@@ -37,7 +37,7 @@ if which in ('all', 'pwfwd'):
             yy = torch.empty_like(xa)
             PP, SS = pkg._lib.ptr, pkg._lib.stream_ptr
             t = timeit(lambda: L.hno_pwconv_fwd(PP(xa), 24, PP(xb), 24, PP(W), PP(bias), PP(yy), B, 24, N ** 3, 1, SS()))
-            print(f'pwconv_fwd 48->24 [{name}] grid {grid or "default"}: {t:.1f} us  ({158.2e6 / t / 1e3:.0f} GB/s algorithmic)')
+            print(f'pwconv_fwd 48->24 [{name}] grid {grid or "default"}: {t:.1f} us  ({72 * 2 * N ** 3 * 4 / t / 1e3:.0f} GB/s algorithmic)')
     L.hno_set_debug(0)
     # plain copy reference: torch copy of the same bytes
     src = torch.randn(3 * 2 * 24 * N ** 3 // 2, device=dev); dst = torch.empty_like(src)
