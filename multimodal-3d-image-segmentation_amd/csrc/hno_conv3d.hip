@@ -651,6 +651,30 @@ __global__ __launch_bounds__(256) void nn_down_kernel(NnArgs a) {  // src = high
     }
 }
 
+// the same with one WAVE per low-resolution voxel: for the deep V-Net legs a low-resolution voxel collects ~2 400 source
+// voxels (81 x 97 x 65 -> 6 x 7 x 5) and there are only a few hundred of them -- a serial loop per thread took 160 us
+__global__ __launch_bounds__(256) void nn_down_wave_kernel(NnArgs a) {
+    const size_t V = (size_t)a.D * a.H * a.W, v_lr = (size_t)a.d * a.h * a.w;
+    const size_t total = v_lr * a.BC;
+    const int lane = threadIdx.x & 63;
+    for (size_t idx = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); idx < total; idx += (size_t)gridDim.x * 4) {
+        const size_t bc = idx / v_lr, v = idx % v_lr;
+        const int x = (int)(v % a.w), y = (int)((v / a.w) % a.h), z = (int)(v / ((size_t)a.w * a.h));
+        int z0, z1, y0, y1, x0, x1;
+        nn_range(z, a.sd, a.d, a.D, z0, z1);
+        nn_range(y, a.sh, a.h, a.H, y0, y1);
+        nn_range(x, a.sw, a.w, a.W, x0, x1);
+        const int nx = x1 - x0, ny = y1 - y0, n = nx * ny * (z1 - z0);
+        float s = 0.f;
+        for (int e = lane; e < n; e += 64) {   // fixed assignment of elements to lanes -> reproducible
+            const int xx = x0 + e % nx, yy = y0 + (e / nx) % ny, zz = z0 + e / (nx * ny);
+            s += a.src[bc * V + ((size_t)zz * a.H + yy) * a.W + xx];
+        }
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) a.dst[idx] = s;
+    }
+}
+
 // out[c] = sum over batch and voxels of g[b][c][v] (bias gradient of a convolution): gridDim.y slices per channel write
 // fp64 partials (fixed order -> reproducible), a second tiny kernel adds them; one slice writes out[] directly
 __global__ __launch_bounds__(256) void chan_sum_kernel(const float *__restrict__ g, float *__restrict__ out, double *__restrict__ part,
@@ -876,7 +900,15 @@ extern "C" int hno_nearest3d(const float *src, float *dst, int BC, int d, int h,
     if (!adjoint)
         hipLaunchKernelGGL(nn_up_kernel, dim3(g1((size_t)BC * D * H * W)), dim3(256), 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(nn_down_kernel, dim3(g1((size_t)BC * d * h * w)), dim3(256), 0, (hipStream_t)stream, a);
+    {
+        const double box = ((double)D / d) * ((double)H / h) * ((double)W / w);   // source voxels per low-resolution voxel
+        if (box >= 48.0) {
+            size_t g = ((size_t)BC * d * h * w + 3) / 4;
+            if (g > 16384) g = 16384;
+            hipLaunchKernelGGL(nn_down_wave_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a);
+        } else
+            hipLaunchKernelGGL(nn_down_kernel, dim3(g1((size_t)BC * d * h * w)), dim3(256), 0, (hipStream_t)stream, a);
+    }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }
