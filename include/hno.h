@@ -314,6 +314,7 @@ int hno_affine_nearest(const float *x, float *out, const double *matrix12, float
  * it on during autograd's backward and flushes from the engine's end-of-backward callback. */
 int hno_set_defer_reduce(int on);
 int hno_pending_reduces(void);
+int hno_discard_reduces(void);   /* drop what was recorded (after an aborted backward pass); returns the count */
 int hno_flush_reduces(void *stream);
 
 /* ------------------------------------------------------------------ per-kernel profiler

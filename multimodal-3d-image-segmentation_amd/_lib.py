@@ -72,6 +72,7 @@ SIGNATURES = {
     'hno_affine_nearest': (c_int, [c_void_p, c_void_p, c_void_p, c_float] + [c_int] * 5 + [c_void_p]),
     'hno_set_defer_reduce': (c_int, [c_int]),
     'hno_pending_reduces': (c_int, []),
+    'hno_discard_reduces': (c_int, []),
     'hno_flush_reduces': (c_int, [c_void_p]),
     'hno_profile_begin': (c_int, [c_int]),
     'hno_profile_end': (c_int, [c_void_p, c_void_p, c_void_p, c_int]),

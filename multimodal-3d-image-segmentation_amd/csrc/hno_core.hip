@@ -247,6 +247,11 @@ extern "C" int hno_set_defer_reduce(int on) {
     return was;
 }
 extern "C" int hno_pending_reduces(void) { return (int)g_deferred.size(); }
+extern "C" int hno_discard_reduces(void) {   // forget recorded reductions (a backward pass that was aborted by an exception)
+    const int n = (int)g_deferred.size();
+    g_deferred.clear();
+    return n;
+}
 extern "C" int hno_flush_reduces(void *stream) { return flush_reduces((hipStream_t)stream); }
 extern "C" const char *hno_last_error(void) { return g_last_error.c_str(); }
 

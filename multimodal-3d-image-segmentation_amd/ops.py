@@ -199,7 +199,7 @@ def pwconv_bwd_branch_raw(gy, y, xa, xb, W, Wbr, act, xa_act, defer=False):
 # engine's end-of-backward callback; the slab workspaces are kept alive here until then.
 import os as _os
 _DEFER_ENABLED = bool(int(_os.environ.get('HNO_DEFER_REDUCE', '1')))
-_defer_state = {'active': False, 'keep': []}
+_defer_state = {'active': False, 'keep': [], 'task': None}
 
 
 def _flush_deferred():
@@ -210,6 +210,7 @@ def _flush_deferred():
             check(L.hno_flush_reduces(stream_ptr()), 'hno_flush_reduces')
     finally:
         _defer_state['active'] = False
+        _defer_state['task'] = None
         _defer_state['keep'].clear()
 
 
@@ -235,11 +236,19 @@ class _DeferReduce:
     def __enter__(self):
         self.on = False
         if _DEFER_ENABLED and self.ok:
-            if not _defer_state['active']:
+            task = torch._C._current_graph_task_id()      # -1 outside backward(); one id per backward pass
+            if task < 0:
+                return self                                # not inside backward(): reduce immediately
+            if _defer_state['task'] != task:
+                # first deferral of THIS backward pass.  Anything still recorded belongs to a pass that died with an
+                # exception before its callback ran: its workspaces are gone, drop the records
+                _lib.lib().hno_discard_reduces()
+                _defer_state['keep'].clear()
+                _defer_state['active'] = False
                 try:
                     torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
-                    _defer_state['active'] = True
-                except RuntimeError:      # not inside backward(): reduce immediately
+                    _defer_state['active'], _defer_state['task'] = True, task
+                except RuntimeError:
                     pass
             if _defer_state['active']:
                 _lib.lib().hno_set_defer_reduce(1)

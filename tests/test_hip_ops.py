@@ -883,6 +883,23 @@ def test_deferred_weight_gradient_reduction(pkg):
         for a, b in zip(eager, gs):
             assert torch.equal(a, b)
         assert pkg._lib.lib().hno_pending_reduces() == 0
+        # a backward pass that dies half way must not poison the next one
+        class Boom(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, t):
+                return t.clone()
+
+            @staticmethod
+            def backward(ctx, g):
+                raise RuntimeError('boom')
+        for p in model.parameters():
+            p.grad = None
+        x2 = x.clone().requires_grad_(True)
+        with pytest.raises(RuntimeError):
+            loss_fn(model(Boom.apply(x2)), lab).backward()     # conv_in needs no input gradient -> the failure comes late
+        late2 = grads(True)
+        for a, b in zip(eager, late2):
+            assert torch.equal(a, b)
     finally:
         ops._DEFER_ENABLED = True
 
