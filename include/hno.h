@@ -310,8 +310,10 @@ int hno_affine_nearest(const float *x, float *out, const double *matrix12, float
  * Every *_bwd entry point that produces a weight gradient writes per-workgroup partial slabs into its workspace and then
  * reduces them (fixed order, no atomics).  hno_set_defer_reduce(1) makes those calls RECORD the reduction instead (returns
  * the previous setting); hno_flush_reduces launches ONE kernel for everything recorded (bit-identical results).  Between
- * the call and the flush the caller must keep the workspace alive and must not read the gradient.  The Python layer turns
- * it on during autograd's backward and flushes from the engine's end-of-backward callback. */
+ * the call and the flush the caller must keep the workspace alive and must not read the gradient.  Per-call form: bit 8
+ * (0x100) of `accumulate_gx` (hno_pwconv_bwd), `xa_act` (hno_pwconv_bwd_branch) or `residual` (hno_specmix_layers_bwd)
+ * records just that call.  The Python layer uses the per-call bit during autograd's backward and flushes from the engine's
+ * end-of-backward callback. */
 int hno_set_defer_reduce(int on);
 int hno_pending_reduces(void);
 int hno_discard_reduces(void);   /* drop what was recorded (after an aborted backward pass); returns the count */

@@ -995,7 +995,11 @@ extern "C" int hno_pwconv_bwd_branch(const float *gy, const float *y, const floa
                                      const float *W, const float *Wbr, float *p_out, float *gxb, float *dflat, void *workspace,
                                      int B, int Cout, long long V, int act, int xa_act, void *stream) {
     HNO_REQUIRE(Wbr && dflat, "hno_pwconv_bwd_branch: null pointer");
-    return pwconv_bwd_launch(gy, y, xa, Ca, xb, Cb, W, p_out, gxb, dflat, nullptr, workspace, B, Cout, V, act, 0, stream, xa_act, 0, Wbr);
+    // bit 8 of xa_act: record the slab reduction for hno_flush_reduces
+    const int prev = hno_set_defer_reduce(0);
+    struct Restore { int v; ~Restore() { hno_set_defer_reduce(v); } } restore{prev};
+    hno_set_defer_reduce(((xa_act >> 8) & 1) ? 1 : prev);
+    return pwconv_bwd_launch(gy, y, xa, Ca, xb, Cb, W, p_out, gxb, dflat, nullptr, workspace, B, Cout, V, act, 0, stream, xa_act & 0xff, 0, Wbr);
 }
 
 extern "C" int hno_cmix_compose(const float *w_real, const float *w_imag, float *w2, int Co, int Ci, void *stream) {
@@ -1024,6 +1028,10 @@ extern "C" size_t hno_pwconv_bwd_workspace_bytes(int Cin, int Cout) {
 extern "C" int hno_pwconv_bwd(const float *gy, const float *y, const float *xa, int Ca, const float *xb, int Cb,
                               const float *W, float *gxa, float *gxb, float *dW, float *dbias, void *workspace,
                               int B, int Cout, long long V, int act, int xa_act, int accumulate_gx, void *stream) {
+    // bit 8 of accumulate_gx: record this call's slab reduction for hno_flush_reduces (per-call form of hno_set_defer_reduce)
+    const int prev = hno_set_defer_reduce(0);
+    struct Restore { int v; ~Restore() { hno_set_defer_reduce(v); } } restore{prev};
+    hno_set_defer_reduce(((accumulate_gx >> 8) & 1) ? 1 : prev);
     return pwconv_bwd_launch(gy, y, xa, Ca, xb, Cb, W, gxa, gxb, dW, dbias, workspace, B, Cout, V, act, 0, stream, xa_act,
-                             accumulate_gx);
+                             accumulate_gx & 0xff);
 }

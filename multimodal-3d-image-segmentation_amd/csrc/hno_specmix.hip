@@ -572,7 +572,11 @@ extern "C" int hno_specmix_layers_bwd(const float *g, const float *z0, const flo
     HNO_REQUIRE(g && z0 && zs && W_layers && gz0 && dW && workspace && B > 0 && C > 0 && M > 0 && L > 0,
                 "hno_specmix_layers_bwd: bad argument");
     for (int l = 0; l < L; ++l) HNO_REQUIRE(W_layers[l], "hno_specmix_layers_bwd: W_layers[%d] is NULL", l);
-    return specmix_bwd(g, z0, zs, W_layers, gz0, dW, workspace, B, C, M, L, residual, act, stream);
+    // bit 8 of residual: record the slab reduction for hno_flush_reduces
+    const int prev = hno_set_defer_reduce(0);
+    struct Restore { int v; ~Restore() { hno_set_defer_reduce(v); } } restore{prev};
+    hno_set_defer_reduce(((residual >> 8) & 1) ? 1 : prev);
+    return specmix_bwd(g, z0, zs, W_layers, gz0, dW, workspace, B, C, M, L, residual & 0xff, act, stream);
 }
 
 // Stacked-weight form: W is (L, C, C) contiguous.

@@ -167,7 +167,7 @@ def pwconv_bwd_raw(gy, y, xa, xb, W, act, has_bias, need_gxa=True, need_gxb=True
     ws = _wgrad_ws(Ca + Cb, Cout, xa.device)
     with _DeferReduce(defer) as d:
         check(_lib.lib().hno_pwconv_bwd(ptr(gy), ptr(y), ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(gxa), ptr(gxb), ptr(dW),
-                                        ptr(db), ptr(ws), B, Cout, V, act, xa_act, acc_bits, stream_ptr()), 'hno_pwconv_bwd')
+                                        ptr(db), ptr(ws), B, Cout, V, act, xa_act, acc_bits | d.bit, stream_ptr()), 'hno_pwconv_bwd')
         d.keep(ws)
     return gxa, gxb, dW, db
 
@@ -185,7 +185,7 @@ def pwconv_bwd_branch_raw(gy, y, xa, xb, W, Wbr, act, xa_act, defer=False):
     ws = torch.empty(L.hno_pwconv_bwd_branch_workspace_bytes(Ca, Cb, Cout) // 4, device=xa.device, dtype=torch.float32)
     with _DeferReduce(defer) as d:
         check(L.hno_pwconv_bwd_branch(ptr(gy), ptr(y), ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(Wbr), ptr(p), ptr(gxb), ptr(flat),
-                                      ptr(ws), B, Cout, V, act, xa_act, stream_ptr()), 'hno_pwconv_bwd_branch')
+                                      ptr(ws), B, Cout, V, act, xa_act | d.bit, stream_ptr()), 'hno_pwconv_bwd_branch')
         d.keep(ws)
     dW = flat[:n_w].view_as(W)
     db = flat[n_w:n_w + Cout]
@@ -251,17 +251,19 @@ class _DeferReduce:
                 except RuntimeError:
                     pass
             if _defer_state['active']:
-                _lib.lib().hno_set_defer_reduce(1)
                 self.on = True
         return self
+
+    @property
+    def bit(self):
+        """0x100 when this call's reduction is to be recorded (ORed into the int argument that carries it)"""
+        return 0x100 if self.on else 0
 
     def keep(self, *tensors):
         if self.on:
             _defer_state['keep'].extend(tensors)
 
     def __exit__(self, *exc):
-        if self.on:
-            _lib.lib().hno_set_defer_reduce(0)
         return False
 
 
@@ -296,7 +298,7 @@ def specmix_bwd_raw(g, z0, zs, W, residual, act, defer=False):
     ws = torch.empty(_lib.lib().hno_specmix_bwd_workspace_bytes(B, C, M, Lyr) // 4, device=z0.device, dtype=torch.float32)
     with _DeferReduce(defer) as d:
         check(_lib.lib().hno_specmix_layers_bwd(ptr(g), ptr(z0), ptr(zs), _layer_ptrs(Ws), ptr(gz0), ptr(dW), ptr(ws), B, C, M, Lyr,
-                                                int(residual), act, stream_ptr()), 'hno_specmix_layers_bwd')
+                                                int(residual) | d.bit, act, stream_ptr()), 'hno_specmix_layers_bwd')
         d.keep(ws)
     return gz0, dW
 
