@@ -37,15 +37,14 @@ struct C3Args {
 // either axis of the stored tensor and the taps may be flipped
 __global__ __launch_bounds__(256) void c3_relayout_kernel(const float *__restrict__ w, float *__restrict__ dst, int C0, int C1,
                                                          int out_is_axis0, int flip, int CiP) {
-    // w stored [C0][C1][27]
-    const int n = C0 * C1 * 27;
+    // w stored [C0][C1][27]; dst [tap][CiP][Co] -- every element of dst is written here, the pad rows (i >= Ci) as zeros
+    const int Co = out_is_axis0 ? C0 : C1, Ci = out_is_axis0 ? C1 : C0;
+    const int n = 27 * CiP * Co;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
-        const int t = idx % 27, c1 = (idx / 27) % C1, c0 = idx / (27 * C1);
-        const int o = out_is_axis0 ? c0 : c1, i = out_is_axis0 ? c1 : c0;
-        const int Co = out_is_axis0 ? C0 : C1, Ci = out_is_axis0 ? C1 : C0;
-        const int tt = flip ? 26 - t : t;
-        (void)Ci;
-        dst[((size_t)tt * CiP + i) * Co + o] = w[idx];
+        const int o = idx % Co, i = (idx / Co) % CiP, tt = idx / (Co * CiP);
+        const int t = flip ? 26 - tt : tt;
+        const int c0 = out_is_axis0 ? o : i, c1 = out_is_axis0 ? i : o;
+        dst[idx] = i < Ci ? w[((size_t)c0 * C1 + c1) * 27 + t] : 0.f;
     }
 }
 
@@ -763,8 +762,7 @@ extern "C" int hno_conv3d_k3(const float *x, const float *W, const float *bias, 
     const int flip = 0;  // the fractional gather already pairs tap t with offset (+pad - t): no flip in any mode
     ProfScope _ps(KID_CONV3D_GEMM, s);
     a.CinP = (a.Cin + 15) / 16 * 16;
-    if (a.CinP != a.Cin) HNO_CHECK_HIP(hipMemsetAsync(wt, 0, sizeof(float) * 27 * (size_t)a.CinP * a.Cout, s));   // zero pad rows
-    hipLaunchKernelGGL(c3_relayout_kernel, dim3(g1((size_t)C0 * C1 * 27)), dim3(256), 0, s, W, wt, C0, C1, out_is_axis0, flip, a.CinP);
+    hipLaunchKernelGGL(c3_relayout_kernel, dim3(g1((size_t)27 * a.CinP * a.Cout)), dim3(256), 0, s, W, wt, C0, C1, out_is_axis0, flip, a.CinP);
     HNO_CHECK_LAUNCH();
     const long long Vo = (long long)Do * Ho * Wo;
     a.ksplit = 1;
