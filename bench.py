@@ -87,6 +87,30 @@ def cpu_baseline(budget_s=40.0):
                       f'(torch-CPU fp32 port of the reference op sequence), {dt:.1f} s; 64^3 probe step {t64:.2f} s'}
 
 
+def launch_ranks(n):
+    """One child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, the same command line);
+    rank 0's stdout -- the JSON line -- passes through.  Returns the worst exit code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()       # does not initialise the GPU runtime
+    if have < n:
+        print(f'[bench] --gpus {n} requested but only {have} GPU(s) are visible', file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -98,12 +122,16 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a HIP graph')
     args = ap.parse_args()
 
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and world == 1 and 'RANK' not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves.  This process has not touched the GPU yet (nothing
+        # above initialises HIP) and never will: the ranks are fresh child processes, this one only waits for them.
+        raise SystemExit(launch_ranks(args.gpus))
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with {args.gpus} ranks')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
@@ -123,9 +151,12 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.randn((B, 4) + VOL, device=dev, generator=g)
     labels = torch.randint(0, 4, (B, 1) + VOL, device=dev, generator=g).float()
-    lab_u8 = pkg.ops.labels_prepare(labels, 4)     # uint8 class map resident in HBM
+    pkg.ops.set_defer_reduce(True)     # one batched weight-gradient slab reduction per backward (plain leaf parameters here)
 
     def fwd_bwd():
+        # the label conversion is part of every step, as in the reference loop (to_categorical, train_test.py:150-152);
+        # here it yields the uint8 class map the loss kernels read (the one-hot tensor never exists)
+        lab_u8 = pkg.ops.labels_prepare(labels, 4)
         y = model(x)
         loss = loss_fn(y, lab_u8)
         rep.zero_grad()

@@ -257,6 +257,9 @@ int hno_act_bwd(const float *g, const float *y, float *gx, long long n, int act,
 /* y[b][c][v] = act(y[b][c][v] + bias[c]) in place: epilogue of 1x1x1 convolutions routed through hno_bmm (wide layers) */
 int hno_bias_act(float *y, const float *bias, int B, int C, long long V, int act, void *stream);
 int hno_add(const float *a, const float *b, float *out, long long n, void *stream);
+/* out = alpha * a + beta * b (b may be NULL: out = alpha * a); the x +- x_reverse combinations of hartley_conv
+ * (nets/hartley_operator.py:315-317) and gradient scaling in the data-parallel path */
+int hno_axpby(float alpha, const float *a, float beta, const float *b, float *out, long long n, void *stream);
 
 /* --------------------------------------------------------------- Pearson / Dice reductions
  * Labels are uint8 class indices (B, V) -- one-hot encoding (experiments/utils.py:74-97)

@@ -62,6 +62,7 @@ SIGNATURES = {
     'hno_act_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p]),
     'hno_bias_act': (c_int, [c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_void_p]),
     'hno_add': (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
+    'hno_axpby': (c_int, [c_float, c_void_p, c_float, c_void_p, c_void_p, c_ll, c_void_p]),
     'hno_loss_fwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_ll, c_int, c_float, c_void_p]),
     'hno_loss_bwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_ll, c_void_p]),
     'hno_labels_prepare': (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 2 + [c_int, c_int, c_ll, c_void_p]),

@@ -548,12 +548,14 @@ __global__ __launch_bounds__(256) void labels_kernel(const float *__restrict__ l
 }
 
 __global__ __launch_bounds__(256) void eltwise_kernel(const float *__restrict__ a, const float *__restrict__ b,
-                                                     float *__restrict__ out, size_t n, int op, int act) {
+                                                     float *__restrict__ out, size_t n, int op, int act,
+                                                     float alpha = 1.f, float beta = 1.f) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float v;
         if (op == 0) v = act_apply(a[i], act);                       // y = act(x)
         else if (op == 1) v = a[i] * act_grad_from_out(b[i], act);   // gx = g * act'(y)
-        else v = a[i] + b[i];
+        else if (op == 2) v = a[i] + b[i];
+        else v = b ? fmaf(alpha, a[i], beta * b[i]) : alpha * a[i];  // out = alpha a + beta b
         out[i] = v;
     }
 }
@@ -755,6 +757,13 @@ extern "C" int hno_bias_act(float *y, const float *bias, int B, int C, long long
 extern "C" int hno_add(const float *a, const float *b, float *out, long long n, void *stream) {
     HNO_REQUIRE(a && b && out && n > 0, "hno_add: bad argument");
     hipLaunchKernelGGL(eltwise_kernel, dim3(grid1d((size_t)n)), dim3(256), 0, (hipStream_t)stream, a, b, out, (size_t)n, 2, 0);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+extern "C" int hno_axpby(float alpha, const float *a, float beta, const float *b, float *out, long long n, void *stream) {
+    HNO_REQUIRE(a && out && n > 0, "hno_axpby: bad argument");
+    hipLaunchKernelGGL(eltwise_kernel, dim3(grid1d((size_t)n)), dim3(256), 0, (hipStream_t)stream, a, b, out, (size_t)n, 3, 0, alpha, beta);
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }

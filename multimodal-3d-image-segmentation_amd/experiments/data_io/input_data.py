@@ -27,6 +27,16 @@ class _Flow:
     def __len__(self):
         return self.owner._get_num_batches(self.data_lists)
 
+    def _epoch_order(self):
+        """Sample order of one epoch for THIS process: the (shared-seed) permutation, sharded rank::world with the uneven
+        tail dropped so that every rank runs the same number of batches."""
+        o = self.owner
+        n = len(self.data_lists[0])
+        order = self._order_rng.permutation(n) if self.shuffle else np.arange(n)
+        if o.world > 1:
+            order = order[:(n // o.world) * o.world][o.rank::o.world]
+        return order
+
     def _read(self, idx):
         o = self.owner
         x = np.stack([np.asarray(o.reader(self.data_lists[m][idx])) for m in o.idx_x_modalities])
@@ -49,9 +59,8 @@ class _Flow:
 
     def __iter__(self):
         o = self.owner
-        n = len(self.data_lists[0])
-        order = self._order_rng.permutation(n) if self.shuffle else np.arange(n)
-        batches = [order[i:i + o.batch_size] for i in range(0, n, o.batch_size)]
+        order = self._epoch_order()
+        batches = [order[i:i + o.batch_size] for i in range(0, len(order), o.batch_size)]
         workers = max(1, int(o.num_workers))
         with ThreadPoolExecutor(workers) as pool:
             pending = []
@@ -80,7 +89,15 @@ class InputData:
         self.transform_kwargs = transform_kwargs
         self.device = torch.device(device)
         self.shuffle_seed = shuffle_seed
+        self.rank, self.world = 0, 1
         assert self.idx_x_modalities is not None
+
+    def set_shard(self, rank, world):
+        """One process per GPU: disjoint shards of every epoch.  The epoch permutations must be the same on every rank, so an
+        unseeded shuffle (shuffle_seed=None: fresh OS entropy per process) is pinned to seed 0 here."""
+        self.rank, self.world = int(rank), int(world)
+        if self.world > 1 and self.shuffle_seed is None:
+            self.shuffle_seed = 0
 
     def _get_flow(self, data_lists, shuffle=False, transform_kwargs=None):
         return _Flow(self, data_lists, shuffle, transform_kwargs)
@@ -95,7 +112,7 @@ class InputData:
         return self._get_flow(self.data_lists_test)
 
     def _get_num_batches(self, data):
-        return 0 if data is None else int(math.ceil(len(data[0]) / self.batch_size))
+        return 0 if data is None else int(math.ceil(len(data[0]) // self.world / self.batch_size))
 
     def get_train_num_batches(self):
         return self._get_num_batches(self.data_lists_train)

@@ -15,6 +15,13 @@ class SyntheticInputData:
         self.num_test = num_test
         self.data_lists_test = [[f'synthetic_{i}'] for i in range(num_test)]
         self._make = generator or self._default_sample
+        self.rank, self.world = 0, 1
+
+    def set_shard(self, rank, world):
+        """Data-parallel training: this process iterates samples rank, rank + world, ... of every epoch's order (the
+        permutation is drawn from the shared seed, so the shards are disjoint); the tail that does not divide evenly is
+        dropped so that every rank runs the same number of batches (a collective per batch would otherwise hang)."""
+        self.rank, self.world = int(rank), int(world)
 
     def _default_sample(self, index):
         g = torch.Generator().manual_seed(self.seed + index)
@@ -27,6 +34,9 @@ class SyntheticInputData:
         if shuffle:
             g = torch.Generator().manual_seed(self.seed + 7919 + epoch_seed)
             order = [order[i] for i in torch.randperm(count, generator=g).tolist()]
+        if self.world > 1:
+            order = order[:(count // self.world) * self.world][self.rank::self.world]
+            count = len(order)
         for i in range(0, count, self.batch_size):
             xs, ys = zip(*[self._make(j) for j in order[i:i + self.batch_size]])
             yield torch.stack(xs), torch.stack(ys)
@@ -45,10 +55,10 @@ class SyntheticInputData:
         return int(math.ceil(self.num_test / self.batch_size))
 
     def get_train_num_batches(self):
-        return int(math.ceil(self.num_train / self.batch_size))
+        return int(math.ceil(self.num_train // self.world / self.batch_size))
 
     def get_valid_num_batches(self):
-        return int(math.ceil(self.num_valid / self.batch_size))
+        return int(math.ceil(self.num_valid // self.world / self.batch_size))
 
     def get_train_image_size(self):
         return self.image_size

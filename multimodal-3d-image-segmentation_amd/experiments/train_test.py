@@ -16,7 +16,7 @@ from os.path import join
 import numpy as np
 import torch
 
-from .utils import labels_to_u8
+from .utils import labels_to_u8, save_model_summary
 
 
 def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, label_mapping=None, num_epochs=100,
@@ -26,12 +26,26 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
     parallel.FlatGradReplica for one-process-per-GPU training (not in the reference)."""
     if use_autocast:
         raise NotImplementedError('autocast is not provided by the fp32 HIP path')
+    import torch.distributed as dist
+    # one process per GPU (data_parallel given): rank 0 alone logs, writes the summary and saves; every rank resumes from the
+    # same checkpoint; the validation loss is averaged over ranks so that all ranks select the same best epoch
+    world = data_parallel.world if data_parallel is not None else 1
+    rank = dist.get_rank(data_parallel.group) if world > 1 else 0
+    is_main = rank == 0
+    is_print = is_print and is_main
     model_dir = join(output_dir, 'model')
     model_path, chkpt_path = join(model_dir, 'model.pt'), join(model_dir, 'checkpoint.pt')
     stdout_file = join(output_dir, 'stdout.txt')
-    os.makedirs(model_dir, exist_ok=True)
+    if is_main:
+        os.makedirs(model_dir, exist_ok=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(group=data_parallel.group)
 
     def log(*lines, echo=True):
+        if not is_main:
+            return
         if is_print and echo:
             for ln in lines:
                 print(ln)
@@ -40,6 +54,7 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
                 print(ln, file=f)
 
     model.to(device)
+    barrier()                       # the directory (and a checkpoint written by an earlier run) is visible to every rank
     if os.path.exists(chkpt_path):
         start_epoch, min_loss, best_epoch = load_checkpoint(chkpt_path, model, optimizer, scheduler, None, device)
         start_epoch += 1
@@ -47,20 +62,24 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
             raise RuntimeError(f'Checkpoint detected, but start_epoch ({start_epoch}) >= num_epochs ({num_epochs})')
         if is_print:
             print(f'Checkpoint loaded for epoch {start_epoch}')
-        # drop what was logged after the last checkpoint (reference :92-102)
-        with open(stdout_file) as f:
-            lines = f.readlines()
-        last = max((i for i, ln in enumerate(lines) if 'checkpoint' in ln), default=len(lines) - 1)
-        with open(stdout_file, 'w') as f:
-            f.writelines(lines[:last + 1])
+        barrier()                   # everyone has read the checkpoint before rank 0 rewrites files
+        if is_main:
+            # drop what was logged after the last checkpoint (reference :92-102)
+            with open(stdout_file) as f:
+                lines = f.readlines()
+            last = max((i for i, ln in enumerate(lines) if 'checkpoint' in ln), default=len(lines) - 1)
+            with open(stdout_file, 'w') as f:
+                f.writelines(lines[:last + 1])
     else:
         start_epoch, min_loss, best_epoch = 0, float('inf'), None
         log('', f'train_num_batches: {input_data.get_train_num_batches()}',
             f'valid_num_batches: {input_data.get_valid_num_batches()}', '')
-        with open(join(output_dir, 'model_summary.txt'), 'w') as f:
-            print(model, file=f)
-            print(f'Total params: {sum(p.numel() for p in model.parameters())}', file=f)
-            print(f'Input size: {(1, model.in_channels) + tuple(input_data.get_train_image_size())}', file=f)
+        if is_main:
+            # shape-only forward of a copy of the model on the meta device (reference :117-119)
+            input_size = (1, model.in_channels) + tuple(input_data.get_train_image_size())
+            save_model_summary(model, input_size, join(output_dir, 'model_summary.txt'))
+    if world > 1 and hasattr(input_data, 'set_shard'):
+        input_data.set_shard(rank, world)     # disjoint, equally sized shards of every epoch's (shared-seed) permutation
 
     train_flow = input_data.get_train_flow(shuffle=True)
     valid_flow = input_data.get_valid_flow()
@@ -103,24 +122,33 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
                 y = labels_to_u8(y, num_labels, label_mapping)
                 losses.append(loss_fn(model(x), y).detach())
         valid_loss = mean_loss(losses)
+        if world > 1:               # same number on every rank: they must agree on best_epoch / min_loss
+            t = torch.tensor([valid_loss if losses else 0.0, 1.0 if losses else 0.0], dtype=torch.float64,
+                             device=device if dist.get_backend(data_parallel.group) == 'nccl' else 'cpu')
+            dist.all_reduce(t, group=data_parallel.group)
+            valid_loss = float(t[0] / t[1]) if float(t[1]) > 0 else float('nan')
         log(f'valid_loss: {valid_loss}')
 
         if (epoch + 1) % checkpoint_epoch == 0:
-            save_checkpoint(chkpt_path, epoch, model, optimizer, scheduler, min_loss, best_epoch, None)
+            if is_main:
+                save_checkpoint(chkpt_path, epoch, model, optimizer, scheduler, min_loss, best_epoch, None)
             log('Standard checkpoint saved.')
         selection_epoch = int(num_epochs * selection_epoch_portion)
         if (epoch > selection_epoch or epoch == num_epochs - 1) and valid_loss < min_loss:
             min_loss, best_epoch = valid_loss, epoch
-            torch.save(model.state_dict(), model_path)
+            if is_main:
+                torch.save(model.state_dict(), model_path)
             if (epoch + 1) % checkpoint_epoch != 0:  # avoid saving twice
-                save_checkpoint(chkpt_path, epoch, model, optimizer, scheduler, min_loss, best_epoch, None)
+                if is_main:
+                    save_checkpoint(chkpt_path, epoch, model, optimizer, scheduler, min_loss, best_epoch, None)
                 log('Best checkpoint saved.')
     end_time = time.time()
 
+    if best_epoch is None and is_main:  # num_epochs == 0, i.e. no training
+        torch.save(model.state_dict(), model_path)
+    barrier()                       # model.pt is complete before any rank reads it
     if best_epoch is not None:
         model.load_state_dict(torch.load(model_path, weights_only=True, map_location=device))
-    else:  # num_epochs == 0, i.e. no training
-        torch.save(model.state_dict(), model_path)
     log('', f'Time used: {end_time - start_time:.2f} seconds.', f'Best epoch: {best_epoch}', f'Min loss: {min_loss}')
     return model
 

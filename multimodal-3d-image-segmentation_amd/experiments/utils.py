@@ -57,3 +57,50 @@ def normalize_batch(batch, mask_val=None, clip_val=None):
     """(B, C, ...) raw batch -> normalised batch in one launch pair (B * C independent volumes)."""
     flat = batch.reshape((batch.shape[0] * batch.shape[1],) + tuple(batch.shape[2:]))
     return normalize_modalities(flat, mask_val, clip_val).reshape(batch.shape)
+
+
+def save_model_summary(model, input_size, path=None):
+    """Layer table of `model` for an input of `input_size` (reference utils.py:122-134, which delegates to
+    ``torchinfo.summary(model, input_size=..., device='meta')``; torchinfo is not a dependency here).  Like the reference it
+    runs a SHAPE-ONLY forward of a copy of the model on the ``meta`` device -- no memory, no kernels (ops._HnoFunction.meta)
+    -- and lists every module with its output shape and parameter count."""
+    import copy
+    m = copy.deepcopy(model).to('meta')
+    rows, hooks = [], []
+
+    def shape_of(out):
+        if torch.is_tensor(out):
+            return list(out.shape)
+        if isinstance(out, (tuple, list)):
+            return [shape_of(o) for o in out]
+        return None
+
+    shapes = {}
+    for name, mod in m.named_modules():
+        def hook(mod, inp, out, name=name):
+            shapes[name] = shape_of(out)
+        hooks.append(mod.register_forward_hook(hook))
+    was_training = m.training
+    m.eval()
+    with torch.no_grad():
+        out = m(torch.empty(tuple(input_size), device='meta'))
+    m.train(was_training)
+    for h in hooks:
+        h.remove()
+    for name, mod in m.named_modules():      # modules whose kernels are fused into their parent's launch never run on their own
+        own = sum(p.numel() for p in mod.parameters(recurse=False))
+        rows.append((name or type(m).__name__, type(mod).__name__, shapes.get(name, '(fused into parent)'), own))
+    total = sum(p.numel() for p in m.parameters())
+    trainable = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    w = max([len(r[0]) for r in rows] + [10])
+    lines = ['=' * (w + 70), f'{"Layer":<{w}}  {"Type":<28}{"Output shape":<28}{"Param #":>10}', '=' * (w + 70)]
+    for name, typ, shp, own in rows:
+        lines.append(f'{name:<{w}}  {typ:<28}{str(shp):<28}{own:>10,}')
+    lines += ['=' * (w + 70), f'Total params: {total:,}', f'Trainable params: {trainable:,}',
+              f'Non-trainable params: {total - trainable:,}', f'Input size: {tuple(input_size)}',
+              f'Output size: {tuple(out.shape) if torch.is_tensor(out) else shape_of(out)}', '=' * (w + 70)]
+    text = '\n'.join(lines)
+    if path is not None:
+        with open(path, 'w') as f:
+            print(text, file=f)
+    return text

@@ -19,6 +19,7 @@ from .. import ops
 def grouping3d(x, patch_size):
     """(B,Z,C,D,H,W) -> (B,Z,C*pd*ph*pw, D/pd, H/ph, W/pw): each new voxel is a patch of the old ones
     (reference :473-498).  Index permutation only."""
+    assert len(patch_size) == 3
     pd, ph, pw = patch_size
     b, z, c, d, h, w = x.shape
     assert d % pd == 0 and h % ph == 0 and w % pw == 0
@@ -34,6 +35,18 @@ def ungrouping3d(x, num_channels, patch_size):
     c = num_channels
     x = x.reshape(b, z, c, pd, ph, pw, nd_, nh, nw).permute(0, 1, 2, 6, 3, 7, 4, 8, 5)
     return x.reshape(b, z, c, nd_ * pd, nh * ph, nw * pw)
+
+
+def grouping2d(x, patch_size):
+    """(B,Z,C,H,W) -> (B,Z,C*ph*pw, H/ph, W/pw) (reference :421-445).  Index permutation only."""
+    assert len(patch_size) == 2
+    return grouping3d(x.unsqueeze(3), (1,) + tuple(patch_size)).squeeze(3)
+
+
+def ungrouping2d(x, num_channels, patch_size):
+    """Inverse of grouping2d (reference :448-470)."""
+    assert len(patch_size) == 2
+    return ungrouping3d(x.unsqueeze(3), num_channels, (1,) + tuple(patch_size)).squeeze(3)
 
 
 class HartleyMultiHeadAttention(Module):

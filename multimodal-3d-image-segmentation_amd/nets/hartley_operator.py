@@ -144,3 +144,36 @@ class HartleyOperator(Module):
         if addend is None:
             return ops.PadIdhtFn.apply(z, spatial, 1.0, act)
         return ops.PadIdhtAddFn.apply(z, addend, spatial, 1.0, act)
+
+
+def get_reverse(x, dims):
+    """x[N - k] along `dims` by "flip, then roll by one" (reference nets/hartley_operator.py:320-333).  Pure index
+    permutation (no arithmetic)."""
+    assert isinstance(dims, (list, tuple))
+    return torch.roll(torch.flip(x, dims), [1] * len(dims), dims)
+
+
+def hartley_conv(equation, weight, weight_reverse, x, x_reverse):
+    """Hartley convolution theorem in the frequency domain (reference nets/hartley_operator.py:302-317):
+
+        1/2 [ einsum(equation, weight, x + x_reverse) + einsum(equation, weight_reverse, x - x_reverse) ]
+
+    for the equations the reference uses -- 'oi,bi...->bo...' (one matrix for all modes) and 'oi...,bi...->bo...'
+    (one matrix per mode), 2-D or 3-D.  The two combinations are formed by hno_axpby (with the 1/2 folded in); the shared
+    form is then ONE concat-fused pointwise conv [W | W_rev] . [s ; d], the per-mode form one complex per-mode mix
+    (W + i W_rev)(s + i d') whose real part is W s - W_rev d' with d' = (x_reverse - x)/2."""
+    lhs, rhs = equation.replace(' ', '').split('->')[0].split(',')
+    nsp = len(rhs) - 2
+    if nsp not in (2, 3) or len(lhs) not in (2, 2 + nsp) or x.ndim != nsp + 2:
+        raise ValueError(f'hartley_conv: unsupported equation {equation!r}')
+    if nsp == 2:        # 2-D: the same kernels on a (B, C, 1, H, W) view
+        eq3 = 'oi,bidhw->bodhw' if len(lhs) == 2 else 'oidhw,bidhw->bodhw'
+        lift = (lambda w: w) if len(lhs) == 2 else (lambda w: w.unsqueeze(2))
+        return hartley_conv(eq3, lift(weight), lift(weight_reverse), x.unsqueeze(2), x_reverse.unsqueeze(2)).squeeze(2)
+    s = ops.AxpbyFn.apply(x, x_reverse, 0.5, 0.5)
+    if len(lhs) == 2:
+        d = ops.AxpbyFn.apply(x, x_reverse, 0.5, -0.5)
+        return ops.PwConvFn.apply(s, d, torch.cat([weight, weight_reverse], dim=1), None, ops.ACT_NONE)
+    d = ops.AxpbyFn.apply(x_reverse, x, 0.5, -0.5)
+    y = ops.PerModeFourierFn.apply(torch.cat([s, d], dim=1), weight, weight_reverse)      # [re | im] channel halves
+    return y[:, :weight.shape[0]]

@@ -91,13 +91,12 @@ class NeuralOperatorBlock(nn.Module):
             return ops.SpecMixFn.apply(x, 1, act, self.op.weight)
         y = self.op(x)
         if self.conv_branch is not None:
-            y = y + ops.PwConvFn.apply(x, None, self.conv_branch.weight, None, ops.ACT_NONE)
-        y = y + x
+            y = ops.AddFn.apply(y, ops.PwConvFn.apply(x, None, self.conv_branch.weight, None, ops.ACT_NONE))
+        y = ops.AddFn.apply(y, x)
         if self.normalization is not None:
             from .conv3d import group_norm_act
             return group_norm_act(y, self.normalization, act)
-        from .elementwise import activation_forward
-        return activation_forward(y, act)
+        return ops.ActFn.apply(y, act) if act != ops.ACT_NONE else y
 
 
 class HNOXSBlock(nn.Module):
@@ -170,7 +169,7 @@ class HNOXSBlock(nn.Module):
             u = group_norm_act(self.pad_inverse(z, spatial), self.normalization, act)
         if self.conv_concat is not None:
             return self.conv_concat(u, tmp)
-        return u + tmp
+        return ops.AddFn.apply(u, tmp)
 
 
 class HNOSegXS(nn.Module):
@@ -269,7 +268,7 @@ class HNOSegXS(nn.Module):
             logits, c0 = None, 0
             for f in feats:
                 part = ops.PwConvFn.apply(f, None, w[:, c0:c0 + f.shape[1]].contiguous(), None, ops.ACT_NONE)
-                logits = part if logits is None else logits + part
+                logits = part if logits is None else ops.AddFn.apply(logits, part)
                 c0 += f.shape[1]
         if self.use_resize:
             y = ops.head_output(logits, image_size, self._softmax, self._out_act)

@@ -195,11 +195,24 @@ def pwconv_bwd_branch_raw(gy, y, xa, xb, W, Wbr, act, xa_act, defer=False):
 
 
 # ---- deferred slab reductions (include/hno.h: hno_set_defer_reduce) -------------------------------------------------
-# During autograd's backward the weight-gradient reductions of all layers are recorded and launched as ONE kernel from the
-# engine's end-of-backward callback; the slab workspaces are kept alive here until then.
+# During autograd's backward the weight-gradient reductions of all layers can be recorded and launched as ONE kernel from
+# the engine's end-of-backward callback; the slab workspaces are kept alive here until then.  The dW tensor handed to
+# autograd is uninitialised until that callback runs, so this is OPT-IN (set_defer_reduce(True) or HNO_DEFER_REDUCE=1;
+# bench.py and the training loop enable it) and guarded: a gradient is only deferred when nothing can read it before the
+# pass ends -- the weight is a leaf with .grad None, has no tensor / post-accumulate hooks, and feeds exactly ONE live
+# autograd node (a module applied twice, or tied weights, would make AccumulateGrad sum two unreduced tensors).
 import os as _os
-_DEFER_ENABLED = bool(int(_os.environ.get('HNO_DEFER_REDUCE', '1')))
-_defer_state = {'active': False, 'keep': [], 'task': None}
+_DEFER_ENABLED = bool(int(_os.environ.get('HNO_DEFER_REDUCE', '0')))
+_defer_state = {'active': False, 'keep': [], 'task': None, 'stream': None}
+_stats = {'pass_fused': 0, 'pass_unfused': 0}     # counters read by the tests
+_param_uses = {}     # id(parameter) -> [live autograd nodes holding it, poisoned]
+
+
+def set_defer_reduce(on=True):
+    """Enable / disable the batched end-of-backward weight-gradient reduction (see above).  Returns the old setting."""
+    global _DEFER_ENABLED
+    old, _DEFER_ENABLED = _DEFER_ENABLED, bool(on)
+    return old
 
 
 def _flush_deferred():
@@ -207,23 +220,82 @@ def _flush_deferred():
     L.hno_set_defer_reduce(0)
     try:
         if L.hno_pending_reduces():
-            check(L.hno_flush_reduces(stream_ptr()), 'hno_flush_reduces')
+            # on the stream the slab writers ran on (the engine may run this callback on another one)
+            st = _defer_state['stream']
+            if st is not None and st != torch.cuda.current_stream():
+                with torch.cuda.stream(st):
+                    check(L.hno_flush_reduces(stream_ptr()), 'hno_flush_reduces')
+                torch.cuda.current_stream().wait_stream(st)
+            else:
+                check(L.hno_flush_reduces(stream_ptr()), 'hno_flush_reduces')
     finally:
-        _defer_state['active'] = False
-        _defer_state['task'] = None
-        _defer_state['keep'].clear()
+        _defer_reset()
+
+
+def _defer_reset():
+    _defer_state['active'] = False
+    _defer_state['task'] = None
+    _defer_state['stream'] = None
+    _defer_state['keep'].clear()
+
+
+def _defer_drop_stale():
+    """Called outside any backward pass: records still pending belong to a pass that raised before its callback ran
+    (their workspaces are kept alive in 'keep', ~100 MB): drop both."""
+    if _defer_state['active'] and torch._C._current_graph_task_id() < 0:
+        _lib.lib().hno_discard_reduces()
+        _lib.lib().hno_set_defer_reduce(0)
+        _defer_reset()
+
+
+def _note_use(*weights):
+    """forward-time: these parameters are held by one more live autograd node"""
+    if not _DEFER_ENABLED or not torch.is_grad_enabled():
+        return
+    for w in weights:
+        if w is not None and w.requires_grad:
+            e = _param_uses.setdefault(id(w), [0, False])
+            e[0] += 1
+            if e[0] > 1:
+                e[1] = True
+
+
+def _release_use(*weights):
+    """backward-time: -> True when every one of these parameters fed only this node since it was last idle"""
+    ok = True
+    for w in weights:
+        if w is None:
+            continue
+        e = _param_uses.get(id(w))
+        if e is None:
+            ok = False
+            continue
+        ok = ok and not e[1]
+        e[0] -= 1
+        if e[0] <= 0:
+            del _param_uses[id(w)]
+    return ok
 
 
 def _deferrable(*weights):
     """A weight gradient may be produced late only if nothing reads it before the end of backward: the weight is a leaf
     whose .grad is None (autograd then just installs the tensor), not a slice / cat / reshape of parameters (whose backward
-    nodes read the gradient) and not a gradient that will be accumulated into an existing .grad."""
-    return all(w is None or (w.is_leaf and w.grad is None) for w in weights)
+    nodes read the gradient), has no hooks that would see the unreduced tensor, and is not accumulated with the gradient of
+    a second use (checked by the callers through _release_use)."""
+    for w in weights:
+        if w is None:
+            continue
+        if not (w.is_leaf and w.grad is None) or w._backward_hooks or getattr(w, '_post_accumulate_grad_hooks', None):
+            return False
+    return True
 
 
 def _leaf_params(*ts):
     """forward-time half of the check: the tensors handed in ARE leaves, used as they are (no fp32 / contiguous copy)."""
-    return all(t is None or (t.is_leaf and t.dtype == torch.float32 and t.is_contiguous()) for t in ts)
+    ok = all(t is None or (t.is_leaf and t.dtype == torch.float32 and t.is_contiguous()) for t in ts)
+    if ok:
+        _note_use(*ts)
+    return ok
 
 
 class _DeferReduce:
@@ -239,19 +311,16 @@ class _DeferReduce:
             task = torch._C._current_graph_task_id()      # -1 outside backward(); one id per backward pass
             if task < 0:
                 return self                                # not inside backward(): reduce immediately
-            if _defer_state['task'] != task:
-                # first deferral of THIS backward pass.  Anything still recorded belongs to a pass that died with an
-                # exception before its callback ran: its workspaces are gone, drop the records
-                _lib.lib().hno_discard_reduces()
-                _defer_state['keep'].clear()
-                _defer_state['active'] = False
+            if _defer_state['active'] and _defer_state['task'] != task:
+                return self                                # a nested (re-entrant) pass: leave the outer pass's records alone
+            if not _defer_state['active']:
                 try:
                     torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
                     _defer_state['active'], _defer_state['task'] = True, task
+                    _defer_state['stream'] = torch.cuda.current_stream()
                 except RuntimeError:
-                    pass
-            if _defer_state['active']:
-                self.on = True
+                    return self
+            self.on = True
         return self
 
     @property
@@ -304,8 +373,35 @@ def specmix_bwd_raw(g, z0, zs, W, residual, act, defer=False):
 
 
 # ----------------------------------------------------------------------------- autograd
-class DhtFullFn(torch.autograd.Function):
+class _HnoFunction(torch.autograd.Function):
+    """Base of every fused op.  Tensors on the ``meta`` device carry shapes only: ``apply`` then returns empty meta
+    tensors of the output shapes (``cls.meta``) without touching libhno -- this is what the reference's
+    ``save_model_summary(copy.deepcopy(model), input_size)`` / ``torchview.draw_graph(..., device='meta')`` need
+    (experiments/utils.py:122-134, train_test.py:117-122).  It is shape inference, not a compute path: any real CPU
+    tensor still raises (``_need_gpu``)."""
+
+    @classmethod
+    def apply(cls, *args):
+        if any(torch.is_tensor(a) and a.is_meta for a in args):
+            return cls.meta(*args)
+        if _defer_state['active']:
+            _defer_drop_stale()
+        return super().apply(*args)
+
+    @staticmethod
+    def meta(*args):
+        raise NotImplementedError
+
+
+def _m(shape, dtype=torch.float32):
+    return torch.empty(tuple(int(v) for v in shape), device='meta', dtype=dtype)
+
+class DhtFullFn(_HnoFunction):
     """Un-truncated dhtn (nets/dht.py:16-49).  The Hartley matrix is symmetric, so backward is the same transform."""
+
+    @staticmethod
+    def meta(x, scale):
+        return _m(x.shape)
 
     @staticmethod
     def forward(ctx, x, scale):
@@ -317,8 +413,12 @@ class DhtFullFn(torch.autograd.Function):
         return dht3_full_raw(_f32c(g), ctx.scale), None
 
 
-class DhtCropFn(torch.autograd.Function):
+class DhtCropFn(_HnoFunction):
     """TransformCrop (nets/hnosegxs.py:378-410).  backward = PadInverse * scale."""
+
+    @staticmethod
+    def meta(x, modes, scale):
+        return _m(tuple(x.shape[:2]) + (_block0(x.shape[2], modes[0]), 2 * modes[1], 2 * modes[2]))
 
     @staticmethod
     def forward(ctx, x, modes, scale):
@@ -331,9 +431,13 @@ class DhtCropFn(torch.autograd.Function):
         return pad_idht3_raw(_f32c(g), ctx.spatial, ctx.scale), None, None
 
 
-class PadIdhtFn(torch.autograd.Function):
+class PadIdhtFn(_HnoFunction):
     """PadInverse (nets/hnosegxs.py:454-494) with fused output activation.
     backward = TransformCrop of (g * act'(out)) with the same scale."""
+
+    @staticmethod
+    def meta(z, spatial, scale, act):
+        return _m(tuple(z.shape[:2]) + tuple(spatial))
 
     @staticmethod
     def forward(ctx, z, spatial, scale, act):
@@ -350,9 +454,13 @@ class PadIdhtFn(torch.autograd.Function):
         return dht3_crop_raw(_f32c(g), ctx.modes, ctx.scale, out, ctx.act), None, None, None
 
 
-class PadIdhtAddFn(torch.autograd.Function):
+class PadIdhtAddFn(_HnoFunction):
     """act(scale * PadInverse(z) + addend): the operator output plus the spatial conv branch, activated
     (nets/architectures.py:521-539 with HartleyOperator._call3d :243-269 feeding it)."""
+
+    @staticmethod
+    def meta(z, addend, spatial, scale, act):
+        return _m(tuple(z.shape[:2]) + tuple(spatial))
 
     @staticmethod
     def forward(ctx, z, addend, spatial, scale, act):
@@ -373,8 +481,12 @@ class PadIdhtAddFn(torch.autograd.Function):
         return gz, ga, None, None, None
 
 
-class RfftCropFn(torch.autograd.Function):
+class RfftCropFn(_HnoFunction):
     """rfftn(norm='forward') + corner gather (nets/fourier_operator.py:164-191) -> (B, 2C, 2m0, 2m1, m2)."""
+
+    @staticmethod
+    def meta(x, modes):
+        return _m((x.shape[0], 2 * x.shape[1], _block0(x.shape[2], modes[0]), 2 * modes[1], modes[2]))
 
     @staticmethod
     def forward(ctx, x, modes):
@@ -388,8 +500,12 @@ class RfftCropFn(torch.autograd.Function):
         return irfft3_pad_raw(_f32c(g), ctx.spatial, ctx.scale, False), None
 
 
-class IrfftPadFn(torch.autograd.Function):
+class IrfftPadFn(_HnoFunction):
     """act(zero-pad + irfftn(norm='forward') + addend) (nets/fourier_operator.py:195-209)."""
+
+    @staticmethod
+    def meta(spec, addend, spatial, act):
+        return _m((spec.shape[0], spec.shape[1] // 2) + tuple(spatial))
 
     @staticmethod
     def forward(ctx, spec, addend, spatial, act):
@@ -434,8 +550,12 @@ def _conv3d_call(x, W, bias, out_shape, mode, cin, cout, stride, act=ACT_NONE):
     return y
 
 
-class Conv3dK3Fn(torch.autograd.Function):
+class Conv3dK3Fn(_HnoFunction):
     """Conv3d(kernel 3, stride 1 or 2, padding 1) + bias as an implicit GEMM (V-Net-DS convolutions)."""
+
+    @staticmethod
+    def meta(x, W, bias, stride):
+        return _m((x.shape[0], W.shape[0]) + tuple((v - 1) // stride + 1 for v in x.shape[2:]))
 
     @staticmethod
     def forward(ctx, x, W, bias, stride):
@@ -463,8 +583,12 @@ class Conv3dK3Fn(torch.autograd.Function):
         return gx, dW, (_chan_sum(g) if ctx.has_bias else None), None
 
 
-class ConvT3dK3Fn(torch.autograd.Function):
+class ConvT3dK3Fn(_HnoFunction):
     """ConvTranspose3d(kernel 3, stride 2, padding 1, output_padding 1) + bias (V-Net-DS upsampling)."""
+
+    @staticmethod
+    def meta(x, Wt, bias):
+        return _m((x.shape[0], Wt.shape[1]) + tuple(2 * v for v in x.shape[2:]))
 
     @staticmethod
     def forward(ctx, x, Wt, bias):
@@ -492,8 +616,12 @@ class ConvT3dK3Fn(torch.autograd.Function):
         return gx, dW, (_chan_sum(g) if ctx.has_bias else None)
 
 
-class GroupNormActFn(torch.autograd.Function):
+class GroupNormActFn(_HnoFunction):
     """act(GroupNorm(1, C)(x)) (nets/nets_utils.py:127-133 with :165-170)."""
+
+    @staticmethod
+    def meta(x, gamma, beta, eps, act):
+        return _m(x.shape)
 
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, act):
@@ -524,8 +652,12 @@ class GroupNormActFn(torch.autograd.Function):
         return gx, dg, db, None, None
 
 
-class NearestUpFn(torch.autograd.Function):
+class NearestUpFn(_HnoFunction):
     """F.interpolate(x, size) with the default nearest mode (`upsampling`, nets/architectures.py:638-653)."""
+
+    @staticmethod
+    def meta(x, size):
+        return _m(tuple(x.shape[:2]) + tuple(size))
 
     @staticmethod
     def forward(ctx, x, size):
@@ -547,8 +679,12 @@ class NearestUpFn(torch.autograd.Function):
         return gx, None
 
 
-class PerModeHartleyFn(torch.autograd.Function):
+class PerModeHartleyFn(_HnoFunction):
     """hartley_conv with per-mode weights (nets/hartley_operator.py:302-317): x, xr (B,Ci,d0,d1,d2), w (Co,Ci,d0,d1,d2)."""
+
+    @staticmethod
+    def meta(x, xr, w):
+        return _m((x.shape[0], w.shape[0]) + tuple(w.shape[2:]))
 
     @staticmethod
     def forward(ctx, x, xr, w):
@@ -575,9 +711,13 @@ class PerModeHartleyFn(torch.autograd.Function):
         return gx, gxr, dw
 
 
-class PerModeFourierFn(torch.autograd.Function):
+class PerModeFourierFn(_HnoFunction):
     """Complex per-mode mix 'oidhw,bidhw->bodhw' (nets/fourier_operator.py:174-191) on [re | im] planes:
     spec (B, 2Ci, ...), wr / wi (Co, Ci, 2m0, 2m1, m2) -> (B, 2Co, ...)."""
+
+    @staticmethod
+    def meta(spec, wr, wi):
+        return _m((spec.shape[0], 2 * wr.shape[0]) + tuple(spec.shape[2:]))
 
     @staticmethod
     def forward(ctx, spec, wr, wi):
@@ -619,8 +759,14 @@ def bmm_raw(A, B, transA, transB, alpha=1.0):
     return C
 
 
-class BmmFn(torch.autograd.Function):
+class BmmFn(_HnoFunction):
     """C = alpha * op(A) op(B), batched (nets/hartley_mha.py:196-201)."""
+
+    @staticmethod
+    def meta(A, B, transA, transB, alpha):
+        M = A.shape[-1] if transA else A.shape[-2]
+        N = B.shape[-2] if transB else B.shape[-1]
+        return _m(tuple(A.shape[:-2]) + (M, N))
 
     @staticmethod
     def forward(ctx, A, B, transA, transB, alpha):
@@ -646,7 +792,11 @@ class BmmFn(torch.autograd.Function):
         return dA, dB, None, None, None
 
 
-class ActFn(torch.autograd.Function):
+class ActFn(_HnoFunction):
+
+    @staticmethod
+    def meta(x, act):
+        return _m(x.shape)
     @staticmethod
     def forward(ctx, x, act):
         x = _f32c(x)
@@ -663,7 +813,11 @@ class ActFn(torch.autograd.Function):
         return act_bwd_raw(_f32c(g), y, ctx.act), None
 
 
-class AddFn(torch.autograd.Function):
+class AddFn(_HnoFunction):
+
+    @staticmethod
+    def meta(a, b):
+        return _m(a.shape)
     @staticmethod
     def forward(ctx, a, b):
         a, b = _f32c(a), _f32c(b)
@@ -677,10 +831,44 @@ class AddFn(torch.autograd.Function):
         return g, g
 
 
-class SpecMixFn(torch.autograd.Function):
+class AxpbyFn(_HnoFunction):
+    """alpha * a + beta * b (hno_axpby)."""
+
+    @staticmethod
+    def meta(a, b, alpha, beta):
+        return _m(a.shape)
+
+    @staticmethod
+    def forward(ctx, a, b, alpha, beta):
+        a, b = _f32c(a), _f32c(b)
+        _need_gpu(a, b)
+        out = torch.empty_like(a)
+        check(_lib.lib().hno_axpby(float(alpha), ptr(a), float(beta), ptr(b), ptr(out), a.numel(), stream_ptr()), 'hno_axpby')
+        ctx.ab = (float(alpha), float(beta))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _f32c(g)
+
+        def scaled(c):
+            if c == 1.0:
+                return g
+            out = torch.empty_like(g)
+            check(_lib.lib().hno_axpby(c, ptr(g), 0.0, None, ptr(out), g.numel(), stream_ptr()), 'hno_axpby')
+            return out
+        return (scaled(ctx.ab[0]) if ctx.needs_input_grad[0] else None,
+                scaled(ctx.ab[1]) if ctx.needs_input_grad[1] else None, None, None)
+
+
+class SpecMixFn(_HnoFunction):
     """L stacked shared-weight frequency-domain mixes z <- act(W z + residual z)
     (nets/hnosegxs.py:307-329, nets/hartley_operator.py:287-292).  The layer weights are separate
     (C, C) tensors (one Parameter per layer, as in the reference's state dict)."""
+
+    @staticmethod
+    def meta(z0, residual, act, *Ws):
+        return _m(z0.shape)
 
     @staticmethod
     def forward(ctx, z0, residual, act, *Ws):
@@ -699,9 +887,13 @@ class SpecMixFn(torch.autograd.Function):
         return (gz0, None, None) + tuple(dW.unbind(0))
 
 
-class PwConvFn(torch.autograd.Function):
+class PwConvFn(_HnoFunction):
     """act(W [xa ; xb] + bias): fused concat + 1x1x1 conv + bias + activation
     (nets/hnosegxs.py:274-275; nets/nets_utils.py:127-133)."""
+
+    @staticmethod
+    def meta(xa, xb, W, bias, act):
+        return _m((xa.shape[0], W.shape[0]) + tuple(xa.shape[2:]))
 
     @staticmethod
     def _wide(xa, xb, W):
@@ -754,14 +946,18 @@ class PwConvFn(torch.autograd.Function):
             db = _chan_sum(g) if ctx.has_bias else None
             return gxa, None, dW, db, None
         gxa, gxb, dW, db = pwconv_bwd_raw(_f32c(gy), y, xa, xb, W, ctx.act, ctx.has_bias, ctx.needs_input_grad[0],
-                                          ctx.needs_input_grad[1], defer=ctx.leaf_params and _deferrable(W, bias))
+                                          ctx.needs_input_grad[1], defer=ctx.leaf_params and _release_use(W, bias) and _deferrable(W, bias))
         return gxa, gxb, dW, db, None
 
 
-class ComplexMixFn(torch.autograd.Function):
+class ComplexMixFn(_HnoFunction):
     """Complex shared-weight channel mix on the [re | im] layout (nets/fourier_operator.py:164-172):
     spec (B, 2Ci, ...) -> (B, 2Co, ...) with W = weight_real + i weight_imag, as one real pointwise conv with the
     composed matrix [[Wr, -Wi], [Wi, Wr]] (built and split back by two tiny kernels: no ATen cat / neg / slice)."""
+
+    @staticmethod
+    def meta(spec, wr, wi):
+        return _m((spec.shape[0], 2 * wr.shape[0]) + tuple(spec.shape[2:]))
 
     @staticmethod
     def forward(ctx, spec, wr, wi):
@@ -786,7 +982,7 @@ class ComplexMixFn(torch.autograd.Function):
         return gx, dwr, dwi
 
 
-class NOBlockFn(torch.autograd.Function):
+class NOBlockFn(_HnoFunction):
     """One FNOSeg / HNOSeg block (nets/architectures.py:511-608 with shared weights, SELU, concat skip) as a single
     autograd node:
 
@@ -797,6 +993,10 @@ class NOBlockFn(torch.autograd.Function):
     accumulate the three gradients inside the kernels that produce them -- the branch conv accumulates into the
     concat-path gradient, the inverse transform adds that sum on its store -- and take the activation gradient of y
     inside the forward transform and the branch conv instead of a separate elementwise pass."""
+
+    @staticmethod
+    def meta(x, fourier, modes, act, br_w, br_b, cat_w, cat_b, *op_ws):
+        return _m((x.shape[0], cat_w.shape[0]) + tuple(x.shape[2:]))
 
     @staticmethod
     def forward(ctx, x, fourier, modes, act, br_w, br_b, cat_w, cat_b, *op_ws):
@@ -840,7 +1040,7 @@ class NOBlockFn(torch.autograd.Function):
     def backward(ctx, g_out):
         x, br_w, cat_w, w, s0, s1, y, out, br_b, cat_b, *op_ws = ctx.saved_tensors
         fourier, modes, act, spatial, n3, br_has_b, cat_has_b = ctx.cfg
-        late = ctx.leaf_params and _deferrable(br_w, br_b, cat_w, cat_b, *op_ws)   # (the Fourier mix reads its dW2 at once: never late)
+        late = ctx.leaf_params and _release_use(br_w, br_b, cat_w, cat_b, *op_ws) and _deferrable(br_w, br_b, cat_w, cat_b, *op_ws)   # (the Fourier mix reads its dW2 at once: never late)
         d_br_w = d_br_b = None
         if br_w is not None and tuple(cat_w.shape[:2]) == (24, 48) and tuple(br_w.shape[:2]) == (24, 24):
             # one pass: p = d loss / d (s + x2) = g_y * act'(y); g_x = concat-path gradient + Wbr^T p; all four parameter gradients
@@ -873,7 +1073,7 @@ class NOBlockFn(torch.autograd.Function):
         return (gx, None, None, None, d_br_w, d_br_b, d_cat_w, d_cat_b) + d_ops
 
 
-class XSBlockFn(torch.autograd.Function):
+class XSBlockFn(_HnoFunction):
     """One whole HNO-XS block (nets/hnosegxs.py:253-279) as a single autograd node:
 
         [mapping_conv(cat[x, skip])] -> TransformCrop -> n_XS x (z <- act((W + I) z)) -> PadInverse -> act
@@ -882,6 +1082,11 @@ class XSBlockFn(torch.autograd.Function):
     Owning the whole block lets the backward fuse the two gradients that meet at the block input
     (through the transform and through the concat skip) into the inverse-transform store instead
     of materialising both and adding them."""
+
+    @staticmethod
+    def meta(x, skip, map_w, map_b, cat_w, cat_b, modes, act, passthrough, *mix_ws):
+        out = _m((x.shape[0], cat_w.shape[0]) + tuple(x.shape[2:]))
+        return (out, x) if passthrough else out
 
     @staticmethod
     def forward(ctx, x, skip, map_w, map_b, cat_w, cat_b, modes, act, passthrough, *mix_ws):
@@ -918,17 +1123,30 @@ class XSBlockFn(torch.autograd.Function):
         if not has_map:
             xm = x
         # weight gradients of leaves with .grad None are not read before backward ends: their slab reductions are batched
-        lp = ctx.leaf_params
+        lp = ctx.leaf_params and _release_use(map_w, map_b, cat_w, cat_b, *mix_ws)
         late_cat, late_mix, late_map = lp and _deferrable(cat_w, cat_b), lp and _deferrable(*mix_ws), lp and _deferrable(map_w, map_b)
         if g_out is None:
             raise _lib.HnoError('XSBlockFn.backward: no gradient for the block output')
+        # The passthrough gradient is accumulated IN PLACE into the buffer autograd handed us only when that buffer is
+        # provably private: produced by our own mapping-conv backward below (tagged), i.e. not summed by the engine, not
+        # captured by a hook, not shared with another consumer.  Anything else takes the out-of-place add.
+        private = g_pass is not None and getattr(g_pass, '_hno_private', False) and g_pass.dtype == torch.float32 \
+            and g_pass.is_contiguous()
         g_pass = _f32c(g_pass) if g_pass is not None else None
+        _stats['pass_fused' if private else 'pass_unfused'] += g_pass is not None
+
+        def plus_pass(t):
+            out = torch.empty_like(t)
+            check(_lib.lib().hno_add(ptr(t), ptr(g_pass), ptr(out), t.numel(), stream_ptr()), 'hno_add')
+            return out
         # conv_concat backward; the SELU backward of PadInverse (g_u * act'(u)) is applied in its epilogue.  Without
         # a mapping conv the block input IS xm: the passthrough gradient is accumulated into the concat-path
-        # gradient by the same kernel (gxb += ...), in the buffer autograd handed us.
-        fuse_pass = g_pass is not None and not has_map
+        # gradient by the same kernel (gxb += ...).
+        fuse_pass = private and not has_map
         g_u, g_skipin, d_cat_w, d_cat_b = pwconv_bwd_raw(_f32c(g_out), out, u, xm, cat_w, act, cat_has_b, xa_act=act,
                                                          accumulate_into=(None, g_pass) if fuse_pass else None, defer=late_cat)
+        if g_pass is not None and not has_map and not fuse_pass:
+            g_skipin = plus_pass(g_skipin)
         g_zl = dht3_crop_raw(g_u, modes, 1.0)                               # PadInverse^T
         g_z0, d_mix = specmix_bwd_raw(g_zl, z0, zs, mix_ws, 1, act, defer=late_mix)
         g_xm = pad_idht3_raw(g_z0, spatial, 1.0 / n3, g_skipin, ACT_NONE)    # TransformCrop^T + skip gradient
@@ -937,13 +1155,21 @@ class XSBlockFn(torch.autograd.Function):
             return (g_xm, None, None, None, d_cat_w, d_cat_b, None, None, None) + d_mix
         g_x, g_skip, d_map_w, d_map_b = pwconv_bwd_raw(g_xm, xm, x, skip, map_w, act, map_has_b,
                                                        ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                                       accumulate_into=(g_pass, None) if g_pass is not None else None,
+                                                       accumulate_into=(g_pass, None) if private else None,
                                                        defer=late_map)
+        if g_pass is not None and not private and g_x is not None:
+            g_x = plus_pass(g_x)
+        if g_skip is not None:
+            g_skip._hno_private = True          # fresh buffer of ours: a later consumer may accumulate into it
         return (g_x, g_skip, d_map_w, d_map_b, d_cat_w, d_cat_b, None, None, None) + d_mix
 
 
-class ConvK2S2Fn(torch.autograd.Function):
+class ConvK2S2Fn(_HnoFunction):
     """Conv3d(k=2, s=2, p=1) + bias + act (conv_in; nets/hnosegxs.py:102-104,151)."""
+
+    @staticmethod
+    def meta(x, W, bias, act):
+        return _m((x.shape[0], W.shape[0]) + tuple(v // 2 + 1 for v in x.shape[2:]))
 
     @staticmethod
     def forward(ctx, x, W, bias, act):
@@ -974,9 +1200,13 @@ class ConvK2S2Fn(torch.autograd.Function):
         return None, dW, db, None
 
 
-class UpSoftmaxFn(torch.autograd.Function):
+class UpSoftmaxFn(_HnoFunction):
     """trilinear(align_corners=False) upsample of K logits + softmax over channels
     (nets/hnosegxs.py:174-180 with conv_out commuted to low resolution)."""
+
+    @staticmethod
+    def meta(logits_lr, size, softmax):
+        return _m(tuple(logits_lr.shape[:2]) + tuple(size))
 
     @staticmethod
     def forward(ctx, logits_lr, size, softmax):
@@ -1028,6 +1258,8 @@ def label_output():
 
 def up_argmax(logits_lr, size):
     lr = _f32c(logits_lr.detach())
+    if lr.is_meta:
+        return _m((lr.shape[0], 1) + tuple(size), torch.uint8)
     _need_gpu(lr)
     B, K, d, h, w = lr.shape
     D, H, W = (int(s) for s in size)
@@ -1058,9 +1290,13 @@ def head_output(logits_lr, size, softmax, out_act=ACT_NONE):
     return ActFn.apply(y, out_act) if out_act != ACT_NONE else y
 
 
-class SegLossFn(torch.autograd.Function):
+class SegLossFn(_HnoFunction):
     """PCC / Dice / ExpDice on uint8 labels (nets/custom_losses.py:17-133 with the one-hot
     encoding of experiments/utils.py:74-97 fused)."""
+
+    @staticmethod
+    def meta(probs, labels_u8, kind, param):
+        return _m(()), _m(tuple(probs.shape[:2]) + (4,))
 
     @staticmethod
     def forward(ctx, probs, labels_u8, kind, param):
@@ -1097,6 +1333,9 @@ def labels_prepare(labels, num_classes, mapping=None, want_onehot=False):
     (experiments/utils.py:74-119)."""
     assert labels.shape[1] == 1, 'Can only handle single label per pixel.'
     lab = _f32c(labels)
+    if lab.is_meta:
+        u8 = _m((lab.shape[0],) + tuple(lab.shape[2:]), torch.uint8)
+        return (u8, _m((lab.shape[0], num_classes) + tuple(lab.shape[2:]))) if want_onehot else u8
     _need_gpu(lab)
     B, V = lab.shape[0], _flat_v(lab)
     u8 = torch.empty((B,) + tuple(lab.shape[2:]), device=lab.device, dtype=torch.uint8)

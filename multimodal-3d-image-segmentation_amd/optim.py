@@ -88,6 +88,10 @@ class Adamax(torch.optim.Optimizer):
                 for k in ('exp_avg', 'exp_inf'):   # e.g. after load_state_dict from a CPU checkpoint
                     if st[k].device != p.device or st[k].dtype != torch.float32 or not st[k].is_contiguous():
                         st[k] = st[k].to(device=p.device, dtype=torch.float32).contiguous()
+                if torch.is_tensor(st['step']) and st['step'].device.type != 'cpu':
+                    # after load_checkpoint(map_location=device) the counters sit on the GPU: `+= 1` would launch a kernel and
+                    # int() would synchronise, per parameter and step.  Keep them on the host (torch's non-capturable layout).
+                    st['step'] = st['step'].detach().to('cpu', torch.float32)
                 st['step'] += 1
                 by_step.setdefault(int(st['step']), []).append((p, p.grad, st['exp_avg'], st['exp_inf']))
             beta1, beta2 = group['betas']

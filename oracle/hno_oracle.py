@@ -301,7 +301,11 @@ def hnoxs_block(sd, prefix, x, modes, n_convs, act='selu', use_block_concat=True
     z = transform_crop(x, modes)
     for j in range(n_convs):  # NeuralOperatorBlock.forward, :307-329
         w = sd[f'{prefix}.conv_blocks.{j}.op.weight']
-        z = _activate(hartley_mix(w, z, weights_type) + z, act)
+        x1 = hartley_mix(w, z, weights_type)
+        wb = sd.get(f'{prefix}.conv_blocks.{j}.conv_branch.weight')   # use_conv_branch (:293-294, :308, :315-316)
+        if wb is not None:
+            x1 = x1 + (F.conv3d if nd == 3 else F.conv2d)(z, wb)
+        z = _activate(x1 + z, act)
     u = _activate(pad_inverse(z, spatial), act)
     if use_block_concat:
         return conv_act(torch.cat([u, skip], dim=1), sd[f'{prefix}.conv_concat.op.weight'],

@@ -75,7 +75,16 @@ SMALL_MODELS = {
                            use_unet_skip=False), (2, 1, 18, 22, 26)),
     'xs_clamped': (dict(in_channels=2, out_channels=2, filters=16, num_transform_blocks=[1, 1], num_modes=(10, 14, 14)),
                    (1, 2, 16, 20, 24)),
+    # per-mode weights (the unfused NeuralOperatorBlock path) and the add-skip / deep-supervision switches
+    'xs_individual': (dict(in_channels=2, out_channels=3, filters=8, num_transform_blocks=[1, 2, 1], num_modes=(3, 3, 4),
+                           weights_type='individual'), (1, 2, 20, 20, 24)),
+    'xs_add_ds': (dict(in_channels=2, out_channels=2, filters=8, num_transform_blocks=[2, 1, 2], num_modes=(3, 4, 4),
+                       use_block_concat=False, use_deep_supervision=True), (1, 2, 20, 24, 20)),
 }
+
+# HNOXSBlock with the spatial conv branch inside every frequency-domain layer (nets/hnosegxs.py:211,293-294): the
+# HNOSegXS constructor never sets it, so the block is pinned on its own (golden G6b).
+XSBLOCK_BRANCH = dict(num_convs=2, in_channels=8, out_channels=8, num_modes=(3, 4, 3), shape=(1, 8, 11, 12, 13))
 
 
 # ---- training-loop trajectory case (golden G8), shared by make_golden.py and the tests

@@ -201,6 +201,45 @@ def g6_hnosegxs():
     save('g6_hnosegxs.npz', **out)
 
 
+# ------------------------------- G6-128: HNOSeg-XS at the metric's own size (cfg2 grid, 128^3 -> 65^3)
+def g6_128():
+    """the reference HNOSeg-XS (same seed-0 weights as g6_hnosegxs.npz, not stored again) on one
+    (1, 4, 128^3) formula volume: 4 096 sampled outputs, output sum, loss, all 28 248 gradients, in fp32 and with the
+    reference run in float64.  A batch of 2 is the same volume stacked (PCC is a mean over (b, c): same loss, same grads)."""
+    import copy
+    torch.manual_seed(0)
+    model = nets.HNOSegXS(4, 4, 24, [3] * 8, (10, 14, 14))
+    out = {}
+    shape = (1, 4, 128, 128, 128)
+    x = T(formula_tensor(shape, 7))
+    lab = formula_labels((1, 1) + shape[2:], 4, 5)
+    onehot = torch.movedim(torch.nn.functional.one_hot(T(lab)[:, 0].long(), 4).float(), -1, 1)
+    model.zero_grad()
+    y = model(x)
+    loss = custom_losses.PCCLoss()(y, onehot)
+    loss.backward()
+    idx = sample_indices(y.numel(), 4096, 2)
+    out['shape'] = np.array(shape)
+    out['y_idx'] = idx
+    out['y'] = y.detach().numpy().ravel()[idx]
+    out['y_sum'] = np.array(y.detach().double().sum().item())
+    out['y_chan_sum'] = y.detach().double().sum(dim=(0, 2, 3, 4)).numpy()
+    out['loss'] = loss.detach().numpy()
+    for k, p in model.named_parameters():
+        out[f'grad::{k}'] = p.grad.detach().numpy().copy()
+    del y, loss
+    m64 = copy.deepcopy(model).double()
+    m64.zero_grad()
+    y64 = m64(x.double())
+    loss64 = custom_losses.PCCLoss()(y64, onehot.double())
+    loss64.backward()
+    out['y64'] = y64.detach().numpy().ravel()[idx].astype(np.float32)
+    out['loss64'] = loss64.detach().numpy()
+    for k, p in m64.named_parameters():
+        out[f'grad64::{k}'] = p.grad.detach().numpy().astype(np.float32)
+    save('g6_128.npz', **out)
+
+
 # ---------------------------- G6s: small, well-conditioned HNOSeg-XS variants (strict 1e-4)
 def g6s_small_models():
     from _inputs import formula_volume
@@ -224,6 +263,30 @@ def g6s_small_models():
                 out[f'{name}::{lname}::grad::{k}'] = p.grad.detach().numpy().copy()
         out[f'{name}::y'] = y.detach().numpy()
     save('g6s_small_models.npz', **out)
+
+
+# ------------------------------ G6b: one HNOXSBlock with use_conv_branch=True (nets/hnosegxs.py:185-329)
+def g6b_xsblock_branch():
+    from _inputs import XSBLOCK_BRANCH as cfg
+    torch.manual_seed(5)
+    blk = hnosegxs.HNOXSBlock(cfg['num_convs'], cfg['in_channels'], cfg['out_channels'], cfg['num_modes'],
+                              use_conv_branch=True)
+    blk.apply(nets_utils.init_weights_for_snn)
+    out = {f'sd::{k}': v.detach().numpy().copy() for k, v in blk.state_dict().items()}
+    x = T(formula_volume_small(cfg['shape'])).requires_grad_(True)
+    y = blk(x)
+    cot = T(formula_tensor(tuple(y.shape), 61))
+    gs = torch.autograd.grad((y * cot).sum(), [x] + list(blk.parameters()))
+    out['y'] = y.detach().numpy()
+    out['gx'] = gs[0].numpy()
+    for (k, _), g in zip(blk.named_parameters(), gs[1:]):
+        out[f'grad::{k}'] = g.numpy()
+    save('g6b_xsblock_branch.npz', **out)
+
+
+def formula_volume_small(shape):
+    from _inputs import formula_volume
+    return formula_volume(shape, 9)
 
 
 # ------------------------------------------ G10: 2-D (ndim = 4) crop / pad and operators
@@ -524,7 +587,7 @@ def g8_training():
 
 
 if __name__ == '__main__':
-    ALL = [g1_dht, g2_crop_pad, g3_operators, g4_mha, g5_losses, g6_hnosegxs, g6s_small_models, g7_noseg_models,
+    ALL = [g1_dht, g2_crop_pad, g3_operators, g4_mha, g5_losses, g6_hnosegxs, g6_128, g6s_small_models, g6b_xsblock_branch, g7_noseg_models,
            g7v_vnet_models, g9_misc, g10_two_d, g11_input, g12_mha_bias, g13_models_2d, g8_training]
     only = set(sys.argv[2:])   # e.g. `make_golden.py /root/reference g10_two_d` regenerates one fixture
     for fn in ALL:

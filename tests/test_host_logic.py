@@ -161,3 +161,110 @@ def test_image_transform_random_stream_matches_reference():
             got = mat if mat is not None else np.eye(len(shape))
             assert np.allclose(got, want, rtol=1e-13, atol=1e-13), (name, it)
             assert np.array_equal(np.flip(base, flips) if flips else base, g[f'{name}_flipped'][it]), (name, it)
+
+
+# ------------------------------------------------------------------ round 2: boundary truthfulness
+def test_meta_device_forward_and_model_summary(tmp_path):
+    """The reference's training() summarises a deep copy of the model on the meta device (train_test.py:117-119,
+    utils.py:122-134).  Every model family runs a shape-only forward there -- and real CPU tensors still raise."""
+    import copy
+    import multimodal_3d_image_segmentation_amd as pkg
+    from multimodal_3d_image_segmentation_amd.experiments.utils import save_model_summary
+    nets = pkg.nets
+    cases = [
+        (nets.HNOSegXS(4, 4, 24, [3] * 8, (10, 14, 14)), (1, 4, 128, 128, 128)),
+        (nets.HNOSegXS(2, 3, 8, [1, 2, 1], (3, 3, 4), weights_type='individual', use_deep_supervision=True), (2, 2, 20, 20, 24)),
+        (nets.NeuralOperatorSeg(4, 4, 24, 3, (10, 14, 14), 'Fourier'), (1, 4, 64, 64, 64)),
+        (nets.NeuralOperatorSeg(4, 4, 8, 2, (4, 4, 4), 'Hartley', weights_type='individual', use_bias_conv_branch=True,
+                                use_block_skip=False), (1, 4, 32, 32, 32)),
+        (nets.HartleyMHASeg(4, 4, 12, 2, 4, (10, 14, 14), (2, 2, 2)), (1, 4, 128, 128, 128)),
+        (nets.VNetDS(4, 4, 8, [1, 2, 2], right_leg_indexes=[0, 1, 2]), (1, 4, 32, 48, 32)),
+        (nets.HNOSegXS(4, 4, 8, [1, 1], (4, 4), ndim=4), (1, 4, 32, 48)),
+    ]
+    for model, shape in cases:
+        y = copy.deepcopy(model).to('meta')(torch.empty(shape, device='meta'))
+        assert y.is_meta and tuple(y.shape) == (shape[0], model.out_channels) + shape[2:], type(model).__name__
+    model, shape = cases[0]
+    text = save_model_summary(model, shape, str(tmp_path / 'model_summary.txt'))
+    assert 'Total params: 28,248' in text and 'layers.7.conv_concat' in text and '[1, 24, 65, 65, 65]' in text
+    assert (tmp_path / 'model_summary.txt').read_text().strip() == text.strip()
+    assert all(not p.is_meta for p in model.parameters())          # the model itself is untouched
+    with pytest.raises(pkg._lib.HnoError):                          # shape inference is not a CPU compute path
+        model(torch.zeros(1, 4, 16, 16, 16))
+
+
+def test_public_helper_functions_match_reference_semantics():
+    """get_reverse / grouping2d / ungrouping2d / grouping3d / ungrouping3d are pure index permutations
+    (reference nets/hartley_operator.py:320-333, nets/hartley_mha.py:421-524): checked against their definitions."""
+    from multimodal_3d_image_segmentation_amd.nets.hartley_operator import get_reverse, hartley_conv   # noqa: F401
+    from multimodal_3d_image_segmentation_amd.nets.hartley_mha import grouping2d, ungrouping2d, grouping3d, ungrouping3d
+    x = torch.arange(2 * 3 * 4 * 6 * 5, dtype=torch.float32).reshape(2, 3, 4, 6, 5)
+    r = get_reverse(x, [-3, -2, -1])
+    for (d, h, w) in [(0, 0, 0), (1, 2, 3), (3, 5, 4)]:
+        assert torch.equal(r[..., d, h, w], x[..., (4 - d) % 4, (6 - h) % 6, (5 - w) % 5])
+    x5 = torch.arange(2 * 2 * 3 * 4 * 6, dtype=torch.float32).reshape(2, 2, 3, 4, 6)      # (b, z, c, h, w)
+    g = grouping2d(x5, (2, 3))
+    assert g.shape == (2, 2, 3 * 6, 2, 2)
+    for c, ph, pw, nh, nw in [(0, 0, 0, 0, 0), (2, 1, 2, 1, 1), (1, 0, 1, 1, 0)]:
+        assert torch.equal(g[:, :, (c * 2 + ph) * 3 + pw, nh, nw], x5[:, :, c, nh * 2 + ph, nw * 3 + pw])
+    assert torch.equal(ungrouping2d(g, 3, (2, 3)), x5)
+    x6 = torch.arange(1 * 2 * 2 * 4 * 2 * 6, dtype=torch.float32).reshape(1, 2, 2, 4, 2, 6)
+    g3 = grouping3d(x6, (2, 1, 3))
+    assert g3.shape == (1, 2, 2 * 6, 2, 2, 2) and torch.equal(ungrouping3d(g3, 2, (2, 1, 3)), x6)
+    assert torch.equal(g3[:, :, (1 * 2 + 1) * 3 + 2, 1, 0, 1], x6[:, :, 1, 1 * 2 + 1, 0, 1 * 3 + 2])
+    with pytest.raises(AssertionError):
+        grouping2d(x5, (2, 2, 2))
+
+
+def test_deferred_reduction_guards():
+    """The batched end-of-backward weight-gradient reduction is opt-in and refuses parameters that feed two live autograd
+    nodes or carry hooks (AccumulateGrad would sum unreduced tensors)."""
+    import multimodal_3d_image_segmentation_amd as pkg
+    ops = pkg.ops
+    assert ops._DEFER_ENABLED is False or os.environ.get('HNO_DEFER_REDUCE') == '1'
+    old = ops.set_defer_reduce(True)
+    try:
+        w = torch.nn.Parameter(torch.zeros(4, 4))
+        v = torch.nn.Parameter(torch.zeros(4, 4))
+        ops._param_uses.clear()
+        assert ops._leaf_params(w, v)                    # node 1 holds w and v
+        assert ops._leaf_params(w)                       # node 2 holds w again (module applied twice / tied weights)
+        assert ops._release_use(w) is False              # backward of node 2: w is shared -> reduce immediately
+        assert ops._release_use(w, v) is False           # backward of node 1: still poisoned for this pass
+        assert not ops._param_uses                       # all uses released: the next pass starts clean
+        assert ops._leaf_params(w, v) and ops._release_use(w, v) is True
+        assert ops._deferrable(w, None, v)
+        h = w.register_hook(lambda g: g)
+        assert not ops._deferrable(w)                    # a tensor hook would read the unreduced gradient
+        h.remove()
+        w.grad = torch.zeros_like(w)
+        assert not ops._deferrable(w)                    # accumulation into an existing .grad reads it too
+        assert not ops._leaf_params(w[:2])               # slices / views of parameters are never deferred
+    finally:
+        ops.set_defer_reduce(old)
+        ops._param_uses.clear()
+
+
+def test_sharded_flows_are_disjoint_and_equal():
+    """Rank-aware input flows: shards of the shared-seed epoch order are disjoint and equally long."""
+    from multimodal_3d_image_segmentation_amd.experiments.synthetic import SyntheticInputData
+    from multimodal_3d_image_segmentation_amd.experiments.data_io.input_data import InputData
+    seen = []
+    for rank in range(2):
+        d = SyntheticInputData((4, 4, 4), 1, 2, batch_size=1, num_train=7, num_valid=2,
+                               generator=lambda i: (torch.full((1, 4, 4, 4), float(i)), torch.zeros(1, 4, 4, 4)))
+        d.set_shard(rank, 2)
+        ids = [int(x[0, 0, 0, 0, 0]) for x, _ in d.get_train_flow(shuffle=True)]
+        assert len(ids) == d.get_train_num_batches() == 3
+        seen.append(ids)
+    assert not set(seen[0]) & set(seen[1])
+    orders = []
+    for rank in range(2):
+        d = InputData(reader=lambda p: np.zeros((2, 2, 2)), data_lists_train=[[str(i) for i in range(9)]],
+                      idx_x_modalities=[0], batch_size=2, device='cpu')
+        d.set_shard(rank, 2)
+        assert d.shuffle_seed == 0 and d.get_train_num_batches() == 2
+        fl = d.get_train_flow(shuffle=True)
+        orders.append([fl._epoch_order().tolist() for _ in range(2)])
+    for e in range(2):
+        assert len(orders[0][e]) == len(orders[1][e]) == 4 and not set(orders[0][e]) & set(orders[1][e])

@@ -192,13 +192,38 @@ def test_small_models_oracle(name):
     for lname in ('pcc', 'dice'):
         params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
         y = O.hnosegxs_forward(params, x, kw['num_transform_blocks'], kw['num_modes'],
-                               use_unet_skip=kw.get('use_unet_skip', True))
+                               **{k: kw[k] for k in ('use_unet_skip', 'use_block_concat', 'use_deep_supervision', 'weights_type')
+                                  if k in kw})
         loss = (O.pcc_loss if lname == 'pcc' else O.dice_loss)(y, O.to_categorical(lab, K))
         loss.backward()
         assert rel_err(_np(y), g[f'{name}::y']) < 1e-5
         assert abs(float(loss.detach()) - float(g[f'{name}::{lname}::loss'])) < 1e-6
         for k, p in params.items():
             assert rel_err(_np(p.grad), g[f'{name}::{lname}::grad::{k}']) < 1e-4, k
+
+
+def test_xsblock_conv_branch_oracle():
+    """HNOXSBlock(use_conv_branch=True) (golden G6b; nets/hnosegxs.py:185-329)."""
+    from _inputs import XSBLOCK_BRANCH as cfg
+    g = load_golden('g6b_xsblock_branch.npz')
+    params = {'blk.' + k[4:]: T(g[k]).requires_grad_(True) for k in g.files if k.startswith('sd::')}
+    x = T(formula_volume(cfg['shape'], 9)).requires_grad_(True)
+    y = O.hnoxs_block(params, 'blk', x, cfg['num_modes'], cfg['num_convs'])
+    cot = T(formula_tensor(tuple(y.shape), 61))
+    (y * cot).sum().backward()
+    assert rel_err(_np(y), g['y']) < 1e-5
+    assert rel_err(_np(x.grad), g['gx']) < 1e-4
+    for k, p in params.items():
+        assert rel_err(_np(p.grad), g['grad::' + k[4:]]) < 1e-4, k
+
+
+def test_g6_128_fixture_is_selfconsistent():
+    """G6-128 (the metric's own grid): stored fp32 / float64 reference results agree to the fp32 noise floor."""
+    g = load_golden('g6_128.npz')
+    assert tuple(g['shape']) == (1, 4, 128, 128, 128) and g['y'].shape == g['y64'].shape
+    assert rel_err(g['y'], g['y64']) < 2e-4 and abs(float(g['loss']) - float(g['loss64'])) < 1e-6
+    n = sum(g[k].size for k in g.files if k.startswith('grad::'))
+    assert n == 28248
 
 
 from _inputs import NOSEG_MODELS  # noqa: E402
