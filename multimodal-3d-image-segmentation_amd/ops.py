@@ -250,7 +250,7 @@ def _defer_drop_stale():
 
 def _note_use(*weights):
     """forward-time: these parameters are held by one more live autograd node"""
-    if not _DEFER_ENABLED or not torch.is_grad_enabled():
+    if not _DEFER_ENABLED:
         return
     for w in weights:
         if w is not None and w.requires_grad:
@@ -290,12 +290,15 @@ def _deferrable(*weights):
     return True
 
 
-def _leaf_params(*ts):
-    """forward-time half of the check: the tensors handed in ARE leaves, used as they are (no fp32 / contiguous copy)."""
+def _leaf_params(ctx, *ts):
+    """forward-time half of the check: the tensors handed in ARE leaves, used as they are (no fp32 / contiguous copy).
+    When the node will run a backward (some input needs a gradient; Function.forward itself runs with grad mode off, so
+    ctx.needs_input_grad is the signal) the parameters are counted as held by one more live node (_note_use)."""
     ok = all(t is None or (t.is_leaf and t.dtype == torch.float32 and t.is_contiguous()) for t in ts)
-    if ok:
+    if ok and ctx is not None and any(ctx.needs_input_grad):
         _note_use(*ts)
-    return ok
+        return True
+    return False
 
 
 class _DeferReduce:
@@ -905,7 +908,7 @@ class PwConvFn(_HnoFunction):
 
     @staticmethod
     def forward(ctx, xa, xb, W, bias, act):
-        ctx.leaf_params = _leaf_params(W, bias)
+        ctx.leaf_params = _leaf_params(ctx, W, bias)
         xa, xb, W, bias = _f32c(xa), _f32c(xb), _f32c(W), _f32c(bias)
         _need_gpu(xa, xb, W, bias)
         ctx.wide = PwConvFn._wide(xa, xb, W)
@@ -1000,7 +1003,7 @@ class NOBlockFn(_HnoFunction):
 
     @staticmethod
     def forward(ctx, x, fourier, modes, act, br_w, br_b, cat_w, cat_b, *op_ws):
-        ctx.leaf_params = _leaf_params(br_w, br_b, cat_w, cat_b, *op_ws)
+        ctx.leaf_params = _leaf_params(ctx, br_w, br_b, cat_w, cat_b, *op_ws)
         x, br_w, br_b, cat_w, cat_b = (_f32c(t) for t in (x, br_w, br_b, cat_w, cat_b))
         op_ws = [_f32c(w) for w in op_ws]
         _need_gpu(x, cat_w, *op_ws)
@@ -1094,7 +1097,7 @@ class XSBlockFn(_HnoFunction):
         tensor as its U-Net skip then sends its gradient HERE instead of to a second consumer edge of `x`, and
         the backward below folds it into the store of the concat-path gradient -- autograd's separate
         accumulation kernel (3 x 158 MB of traffic per step in HNOSeg-XS) disappears."""
-        ctx.leaf_params = _leaf_params(map_w, map_b, cat_w, cat_b, *mix_ws)
+        ctx.leaf_params = _leaf_params(ctx, map_w, map_b, cat_w, cat_b, *mix_ws)
         x, skip, map_w, map_b, cat_w, cat_b = (_f32c(t) for t in (x, skip, map_w, map_b, cat_w, cat_b))
         mix_ws = [_f32c(w) for w in mix_ws]
         _need_gpu(x, skip, cat_w, *mix_ws)

@@ -227,19 +227,24 @@ def test_deferred_reduction_guards():
         w = torch.nn.Parameter(torch.zeros(4, 4))
         v = torch.nn.Parameter(torch.zeros(4, 4))
         ops._param_uses.clear()
-        assert ops._leaf_params(w, v)                    # node 1 holds w and v
-        assert ops._leaf_params(w)                       # node 2 holds w again (module applied twice / tied weights)
+        class Ctx:                                       # what autograd hands Function.forward
+            needs_input_grad = (True, False)
+        ctx = Ctx()
+        assert ops._leaf_params(ctx, w, v)               # node 1 holds w and v
+        assert ops._leaf_params(ctx, w)                  # node 2 holds w again (module applied twice / tied weights)
         assert ops._release_use(w) is False              # backward of node 2: w is shared -> reduce immediately
         assert ops._release_use(w, v) is False           # backward of node 1: still poisoned for this pass
         assert not ops._param_uses                       # all uses released: the next pass starts clean
-        assert ops._leaf_params(w, v) and ops._release_use(w, v) is True
+        assert ops._leaf_params(ctx, w, v) and ops._release_use(w, v) is True
         assert ops._deferrable(w, None, v)
         h = w.register_hook(lambda g: g)
         assert not ops._deferrable(w)                    # a tensor hook would read the unreduced gradient
         h.remove()
         w.grad = torch.zeros_like(w)
         assert not ops._deferrable(w)                    # accumulation into an existing .grad reads it too
-        assert not ops._leaf_params(w[:2])               # slices / views of parameters are never deferred
+        assert not ops._leaf_params(ctx, w[:2])          # slices / views of parameters are never deferred
+        Ctx.needs_input_grad = (False, False)
+        assert not ops._leaf_params(ctx, w) and not ops._param_uses     # inference (no backward will come): nothing is counted
     finally:
         ops.set_defer_reduce(old)
         ops._param_uses.clear()
