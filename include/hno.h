@@ -228,6 +228,42 @@ int hno_nearest3d(const float *src, float *dst, int BC, int d, int h, int w, int
 size_t hno_channel_sum_workspace_bytes(int C);
 int hno_channel_sum(const float *g, float *out, void *workspace, int B, int C, long long V, void *stream);
 
+/* ------------------------------------------------------- bf16 matrix-core path (autocast)
+ * The reference trains V-Net-DS / FNOSeg under torch.autocast(bfloat16) + GradScaler when `use_autocast` is set
+ * (experiments/train_test.py:79,154-168): nn.Conv3d / nn.ConvTranspose3d / einsum take bf16 operands, GroupNorm and the
+ * parameters stay fp32.  These entry points are that path: activations are CHANNELS-LAST bf16 (b, d, h, w, c), channel
+ * counts multiples of 8; accumulation is fp32 (v_mfma_f32_32x32x16_bf16 / _16x16x32_bf16); parameters, their gradients and
+ * the GroupNorm statistics are fp32.  `void *` tensors are bf16.  Replaces nets/nets_utils.py:127-211 (ConvNormAct /
+ * ConvTransposeNormAct forward + backward) for nets/architectures.py:26-252. */
+size_t hno_cb_packed_weight_bytes(int Cin, int Cout, int ks);
+/* role 0: conv forward W[Cout][Cin][ks^3]; 1: conv input gradient (same tensor); 2: ConvTranspose forward Wt[Cin][Cout][ks^3];
+ * 3: ConvTranspose input gradient.  dst: bf16 [tap * Ci/8 + c8][round_up(Co, 32)][8] of the GEMM's input (Ci) / output (Co) channels */
+int hno_cb_pack_weights(const float *W, void *dst, int role, int Cin, int Cout, int ks, void *stream);
+size_t hno_cb_conv_workspace_bytes(int B, int Cin, int Cout, int Do, int Ho, int Wo, int ks);
+/* y = conv([xa ; xb]) + bias as a gather GEMM.  mode 0: in = stride * out - pad + tap (Conv3d forward, ConvTranspose3d input
+ * gradient); mode 1: in = (out + pad - tap) / stride where divisible (ConvTranspose3d forward, Conv3d input gradient).
+ * mean_rstd (B, 2) != NULL: GroupNorm(1, Cout) statistics of the bf16-rounded output come out of the same pass. */
+int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const void *wpacked, const float *bias, void *y, float *mean_rstd,
+                float eps, void *workspace, size_t workspace_bytes, int mode, int B, int Cout, int Di, int Hi, int Wi, int Do, int Ho,
+                int Wo, int ks, int stride, int pad, void *stream);
+size_t hno_cb_wgrad_workspace_bytes(int Cin, int Cout, int ks);
+/* dW (fp32, the parameter's own layout) of a Conv3d (transposed = 0: g on the output grid (Dg, Hg, Wg), x = [xa ; xb] on the
+ * input grid (Dx, Hx, Wx)) or of a ConvTranspose3d (transposed = 1: x is ITS input on the small grid, g its output gradient). */
+int hno_cb_wgrad(const void *g, int Cg, const void *xa, int Ca, const void *xb, int Cb, float *dW, void *workspace, int transposed,
+                 int B, int Dx, int Hx, int Wx, int Dg, int Hg, int Wg, int ks, int stride, int pad, void *stream);
+/* z = act(GroupNorm(1, C)(y1)) [+ act(GroupNorm(1, C)(y2))]: the residual sum of a V-Net section fused (architectures.py:205-224) */
+int hno_cb_gn_apply(const void *y1, const float *mr1, const float *gamma1, const float *beta1, const void *y2, const float *mr2,
+                    const float *gamma2, const float *beta2, void *z, int B, int C, long long V, int act, void *stream);
+size_t hno_cb_gn_bwd_workspace_bytes(int B, int C);
+int hno_cb_gn_bwd(const void *dz, const void *y, const float *mr, const float *gamma, const float *beta, void *dy, float *dgamma,
+                  float *dbeta, void *workspace, int B, int C, long long V, int act, int accumulate, void *stream);
+/* fp32 NCDHW (C channels) -> bf16 channels-last with CP >= C channels (pad channels zero), and back */
+int hno_cb_pack_input(const float *x, void *y, int B, int C, int CP, long long V, void *stream);
+int hno_cb_unpack(const void *x, float *y, int B, int C, int CP, long long V, void *stream);
+/* out[c] = sum over rows of a (rows, C) bf16 tensor (bias gradients) */
+size_t hno_cb_colsum_workspace_bytes(int C);
+int hno_cb_colsum(const void *g, float *out, void *workspace, int C, long long rows, void *stream);
+
 /* ------------------------------------------------------- per-mode ('individual') spectral weights
  * Hartley (fourier = 0): y(k) = 1/2 [W(k)(x(k) + xr(k)) + W(-k)(x(k) - xr(k))] with xr = the frequency-
  *   reversed copy of x supplied by the caller (on the cropped grid or taken from the full spectrum) and

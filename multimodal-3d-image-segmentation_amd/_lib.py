@@ -55,6 +55,20 @@ SIGNATURES = {
     'hno_nearest3d': (c_int, [c_void_p] * 2 + [c_int] * 9 + [c_void_p]),
     'hno_channel_sum_workspace_bytes': (c_size_t, [c_int]),
     'hno_channel_sum': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p]),
+    'hno_cb_packed_weight_bytes': (c_size_t, [c_int] * 3),
+    'hno_cb_pack_weights': (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    'hno_cb_conv_workspace_bytes': (c_size_t, [c_int] * 7),
+    'hno_cb_conv': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_size_t]
+                    + [c_int] * 12 + [c_void_p]),
+    'hno_cb_wgrad_workspace_bytes': (c_size_t, [c_int] * 3),
+    'hno_cb_wgrad': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
+    'hno_cb_gn_apply': (c_int, [c_void_p] * 9 + [c_int, c_int, c_ll, c_int, c_void_p]),
+    'hno_cb_gn_bwd_workspace_bytes': (c_size_t, [c_int] * 2),
+    'hno_cb_gn_bwd': (c_int, [c_void_p] * 9 + [c_int, c_int, c_ll, c_int, c_int, c_void_p]),
+    'hno_cb_pack_input': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_ll, c_void_p]),
+    'hno_cb_unpack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_ll, c_void_p]),
+    'hno_cb_colsum_workspace_bytes': (c_size_t, [c_int]),
+    'hno_cb_colsum': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_ll, c_void_p]),
     'hno_permode_fwd': (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
     'hno_permode_bwd': (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_void_p]),
     'hno_bmm': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_float, c_void_p]),

@@ -1,0 +1,1040 @@
+// bf16 matrix-core path of the V-Net-DS convolutions (reference nets/architectures.py:26-252 run under
+// torch.autocast(bfloat16), experiments/train_test.py:79,154-168): convolutions and their gradients take bf16
+// operands and accumulate in fp32 on v_mfma_f32_32x32x16_bf16 / v_mfma_f32_16x16x32_bf16, GroupNorm statistics and
+// the normalisation arithmetic stay fp32, parameters and their gradients stay fp32.
+//
+// Layout: activations are CHANNELS-LAST bf16, x[b][d][h][w][c] ("NDHWC"), C a multiple of 8.  The K index of every
+// convolution GEMM is (tap, input channel), so with channels last one lane's MFMA operand -- 8 consecutive k -- is
+// one 16-byte load, and one lane's 16 accumulator rows store as channel-contiguous runs.  The weight gradient sums
+// over voxels instead: its operands are read from the same channels-last tiles in LDS with the transposing
+// ds_read_b64_tr_b16, so no second (channels-first) copy of any tensor exists.
+//
+//   hno_cb_pack_weights   fp32 parameter (any of the four operator roles) -> bf16 [q = tap * Cin/8 + c8][CoutP][8]
+//   hno_cb_conv           gather-GEMM: conv / strided conv / ConvTranspose / their input gradients, kernel 1, 2 or 3,
+//                         two concatenated inputs, fused bias, bf16 store, fused GroupNorm partial statistics,
+//                         split-K over taps for the deep (small-grid, wide-channel) levels
+//   hno_cb_wgrad          weight gradient, LDS halo tile + transposing reads, slab partials + ordered reduce
+//   hno_cb_gn_*           GroupNorm(1, C) + ELU/SELU forward (two-branch residual sum fused) and backward
+//   hno_cb_pack_input / hno_cb_unpack   fp32 NCDHW <-> bf16 NDHWC at the two ends of the network
+#include "hno_common.h"
+
+namespace hno {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16b __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;   // storage type (raw bits)
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    return __builtin_bit_cast(bf16_t, (__bf16)f);   // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+}
+__device__ __forceinline__ float bf2f(bf16_t v) {
+    return __builtin_bit_cast(float, (unsigned)v << 16);
+}
+
+// ------------------------------------------------------------------------------------------------ weights
+// src: fp32 [C0][C1][T] (T = ks^3 taps).  dst: bf16 [nq2][CoP][8], q = tap * nC8 + c8, element j = GEMM input channel
+// 8 c8 + j; nq2 = nq rounded up to even (a K-step is two chunks), CoP = Cout rounded up to 32; pads are zero.
+__global__ __launch_bounds__(256) void cb_pack_weights_kernel(const float *__restrict__ w, bf16_t *__restrict__ dst, int C0, int C1,
+                                                             int T, int out_is_axis0, int Ci, int Co, int CoP, int nq2) {
+    const int nC8 = Ci / 8;
+    const long long n = (long long)nq2 * CoP * 8;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
+        const int j = (int)(idx & 7);
+        const int o = (int)((idx >> 3) % CoP);
+        const int q = (int)((idx >> 3) / CoP);
+        const int t = q / nC8, i = (q % nC8) * 8 + j;
+        float v = 0.f;
+        if (t < T && o < Co) {
+            const int c0 = out_is_axis0 ? o : i, c1 = out_is_axis0 ? i : o;
+            v = w[((size_t)c0 * C1 + c1) * T + t];
+        }
+        dst[idx] = f2bf(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ gather GEMM
+struct CbArgs {
+    const bf16_t *xa, *xb;     // channels-last inputs; the GEMM input channels are [xa's Ca | xb's Cb] (fused concat)
+    int Ca, Cb;
+    const bf16_t *w;           // packed weights
+    const float *bias;         // fp32 per output channel or null
+    bf16_t *y;                 // channels-last output (null when split-K writes partials)
+    float *part;               // split-K: fp32 partials [z][b][v][Cout]
+    float *stats;              // per-block (sum, sum of squares) of the ROUNDED outputs: [b][gridDim.x * gridDim.y][2], or null
+    int B, Cout, CoP;
+    int Di, Hi, Wi, Do, Ho, Wo;
+    int ks, stride, pad, frac;
+    int ntaps, nq2;            // ks^3, padded chunk count
+    int ksplit;                // gridDim.z slices of the chunk range
+};
+
+// One wave = MT tiles of 32 consecutive output voxels (flattened d,h,w of one sample) x NT tiles of 32 output channels.
+// A operand (activations): lane (r = l & 31, h = l >> 5) holds voxel r's 8 channels of chunk q = 2 s + h: ONE 16-byte
+// load from the channels-last tensor at the tap's input voxel (zero when the tap falls into the padding).
+// B operand (weights): lane (r, h) holds output channel r's 8 k of chunk q: one 16-byte load from the packed array.
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void cb_gather_kernel(CbArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z / a.ksplit, kz = blockIdx.z % a.ksplit;
+    const int Vo = a.Do * a.Ho * a.Wo;
+    const int v0 = (blockIdx.x * 4 + wave) * 32 * MT;
+    const int n0 = blockIdx.y * 32 * NT;
+    const int Cin = a.Ca + a.Cb, nC8 = Cin >> 3, nCa8 = a.Ca >> 3;
+    const size_t Vi = (size_t)a.Di * a.Hi * a.Wi;
+    const bf16_t *xa = a.xa + (size_t)b * Vi * a.Ca;
+    const bf16_t *xb = a.xb ? a.xb + (size_t)b * Vi * a.Cb : nullptr;
+    const bool wave_active = v0 < Vo;
+
+    int od[MT], oh[MT], ow[MT];
+    bool vok[MT];
+    const int HWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int v = v0 + 32 * m + r;
+        vok[m] = v < Vo;
+        const int vv = vok[m] ? v : 0;
+        od[m] = vv / HWo;
+        const int rem = vv - od[m] * HWo;
+        oh[m] = rem / a.Wo;
+        ow[m] = rem - oh[m] * a.Wo;
+    }
+    f32x16b acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+    // chunk range of this K slice (whole K-steps)
+    const int nsteps = a.nq2 >> 1;
+    const int s_lo = (int)((long long)nsteps * kz / a.ksplit), s_hi = (int)((long long)nsteps * (kz + 1) / a.ksplit);
+    if (wave_active && s_lo < s_hi) {
+        int q = 2 * s_lo + h;
+        int tap = q / nC8, c8 = q - tap * nC8;
+        long long off[MT];    // element offset of the tap's input voxel (channel 0) in a tensor with 1 channel; < 0: padding
+        auto set_tap = [&](int t) {
+            const int ks2 = a.ks * a.ks;
+            const int td = t / ks2, th = (t / a.ks) % a.ks, tw = t % a.ks;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                int zi, yi, xi;
+                bool ok = vok[m] && t < a.ntaps;
+                if (!a.frac) {
+                    zi = a.stride * od[m] - a.pad + td;
+                    yi = a.stride * oh[m] - a.pad + th;
+                    xi = a.stride * ow[m] - a.pad + tw;
+                    ok = ok && zi >= 0 && zi < a.Di && yi >= 0 && yi < a.Hi && xi >= 0 && xi < a.Wi;
+                } else {
+                    const int nz = od[m] + a.pad - td, ny = oh[m] + a.pad - th, nx = ow[m] + a.pad - tw;
+                    ok = ok && nz >= 0 && ny >= 0 && nx >= 0;
+                    if (a.stride == 2) {
+                        ok = ok && !((nz | ny | nx) & 1);
+                        zi = nz >> 1; yi = ny >> 1; xi = nx >> 1;
+                    } else {
+                        zi = nz; yi = ny; xi = nx;
+                    }
+                    ok = ok && zi < a.Di && yi < a.Hi && xi < a.Wi;
+                }
+                off[m] = ok ? ((long long)zi * a.Hi + yi) * a.Wi + xi : -1;
+            }
+        };
+        set_tap(tap);
+        const uint4 zero4 = make_uint4(0, 0, 0, 0);
+        auto load_a = [&](int m) -> uint4 {
+            if (off[m] < 0) return zero4;
+            const bf16_t *p = c8 < nCa8 ? xa + (size_t)off[m] * a.Ca + c8 * 8 : xb + (size_t)off[m] * a.Cb + (c8 - nCa8) * 8;
+            return *reinterpret_cast<const uint4 *>(p);
+        };
+        auto load_b = [&](int n) -> uint4 {
+            return *reinterpret_cast<const uint4 *>(a.w + ((size_t)q * a.CoP + n0 + 32 * n + r) * 8);
+        };
+        uint4 av[MT], bv[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[m] = load_a(m);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bv[n] = load_b(n);
+        for (int s = s_lo; s < s_hi; ++s) {
+            uint4 an[MT], bn[NT];
+            const bool more = s + 1 < s_hi;
+            if (more) {     // next K-step's operands are in flight during this step's MFMAs
+                q += 2;
+                c8 += 2;
+                if (c8 >= nC8) {
+                    c8 -= nC8;
+                    ++tap;
+                    if (c8 >= nC8) { c8 -= nC8; ++tap; }      // nC8 == 1
+                    set_tap(tap);
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m) an[m] = load_a(m);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bn[n] = load_b(n);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[m]), __builtin_bit_cast(bf16x8, bv[n]),
+                                                                        acc[m][n], 0, 0, 0);
+            if (more) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) av[m] = an[m];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bv[n] = bn[n];
+            }
+        }
+    }
+    // epilogue.  C/D: column (lane & 31) = output channel, rows (i & 3) + 8 (i >> 2) + 4 h = voxels of the tile
+    float ssum = 0.f, ssq = 0.f;
+    if (wave_active) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int ch = n0 + 32 * n + r;
+            if (ch >= a.Cout) continue;
+            const float bias = (a.bias && kz == 0) ? a.bias[ch] : 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int v = v0 + 32 * m + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (v >= Vo) continue;
+                    const float val = acc[m][n][i] + bias;
+                    if (a.part) {
+                        a.part[(((size_t)kz * a.B + b) * Vo + v) * a.Cout + ch] = val;
+                    } else {
+                        const bf16_t o = f2bf(val);
+                        a.y[((size_t)b * Vo + v) * a.Cout + ch] = o;
+                        const float f = bf2f(o);
+                        ssum += f;
+                        ssq = fmaf(f, f, ssq);
+                    }
+                }
+        }
+    }
+    if (a.stats && !a.part) {
+        __shared__ float red[8];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ssum += __shfl_xor(ssum, o);
+            ssq += __shfl_xor(ssq, o);
+        }
+        if (lane == 0) { red[wave * 2] = ssum; red[wave * 2 + 1] = ssq; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int nblk = gridDim.x * gridDim.y;
+            float *dst = a.stats + ((size_t)b * nblk + blockIdx.y * gridDim.x + blockIdx.x) * 2;
+            dst[0] = red[0] + red[2] + red[4] + red[6];
+            dst[1] = red[1] + red[3] + red[5] + red[7];
+        }
+    }
+}
+
+// split-K finish: y = bf16(sum_z part[z] ) (bias was added by slice 0), + GroupNorm partial statistics
+__global__ __launch_bounds__(256) void cb_splitk_finish_kernel(const float *__restrict__ part, bf16_t *__restrict__ y, float *__restrict__ stats,
+                                                              int ksplit, long long per_sample, int B) {
+    const int b = blockIdx.y;
+    const size_t slice = (size_t)B * per_sample;
+    float ssum = 0.f, ssq = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (long long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int z = 0; z < ksplit; ++z) s += part[(size_t)z * slice + (size_t)b * per_sample + i];
+        const bf16_t o = f2bf(s);
+        y[(size_t)b * per_sample + i] = o;
+        const float f = bf2f(o);
+        ssum += f;
+        ssq = fmaf(f, f, ssq);
+    }
+    if (stats) {
+        __shared__ float red[8];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ssum += __shfl_xor(ssum, o);
+            ssq += __shfl_xor(ssq, o);
+        }
+        if (lane == 0) { red[wave * 2] = ssum; red[wave * 2 + 1] = ssq; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float *dst = stats + ((size_t)b * gridDim.x + blockIdx.x) * 2;
+            dst[0] = red[0] + red[2] + red[4] + red[6];
+            dst[1] = red[1] + red[3] + red[5] + red[7];
+        }
+    }
+}
+
+// (sum, sumsq) partials -> (mean, rstd) per sample; fp64 accumulation, fixed order
+__global__ __launch_bounds__(256) void cb_gn_finalize_kernel(const float *__restrict__ part, int nblk, double count, float eps,
+                                                            float *__restrict__ mr) {
+    const int b = blockIdx.x;
+    __shared__ double sh[512];
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+        s += (double)part[((size_t)b * nblk + i) * 2];
+        q += (double)part[((size_t)b * nblk + i) * 2 + 1];
+    }
+    sh[threadIdx.x] = s;
+    sh[256 + threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sh[threadIdx.x] += sh[threadIdx.x + o];
+            sh[256 + threadIdx.x] += sh[256 + threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mean = sh[0] / count;
+        double var = sh[256] / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mr[2 * b] = (float)mean;
+        mr[2 * b + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GroupNorm(1, C) + act
+// z = act(gamma1 (y1 - mean1) rstd1 + beta1) [+ act(gamma2 (y2 - mean2) rstd2 + beta2)], all tensors channels-last bf16,
+// arithmetic fp32.  8 channels (16 bytes) per thread and iteration; C % 8 == 0.
+__global__ __launch_bounds__(256) void cb_gn_apply_kernel(const bf16_t *__restrict__ y1, const float *__restrict__ mr1, const float *__restrict__ g1,
+                                                         const float *__restrict__ b1, const bf16_t *__restrict__ y2,
+                                                         const float *__restrict__ mr2, const float *__restrict__ g2,
+                                                         const float *__restrict__ b2, bf16_t *__restrict__ z, int C, long long per_sample,
+                                                         int act) {
+    const int b = blockIdx.y;
+    const float m1 = mr1[2 * b], r1 = mr1[2 * b + 1];
+    const float m2 = y2 ? mr2[2 * b] : 0.f, r2 = y2 ? mr2[2 * b + 1] : 0.f;
+    const long long n8 = per_sample >> 3;
+    const int C8 = C >> 3;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const int c0 = (int)(i % C8) * 8;
+        const size_t e = (size_t)b * per_sample + (size_t)i * 8;
+        const uint4 v1 = *reinterpret_cast<const uint4 *>(y1 + e);
+        uint4 v2 = make_uint4(0, 0, 0, 0);
+        if (y2) v2 = *reinterpret_cast<const uint4 *>(y2 + e);
+        const unsigned w1[4] = {v1.x, v1.y, v1.z, v1.w}, w2[4] = {v2.x, v2.y, v2.z, v2.w};
+        unsigned out[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float res[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int c = c0 + 2 * k + u;
+                const float a1 = bf2f((bf16_t)(u ? w1[k] >> 16 : w1[k] & 0xffff));
+                float t = act_apply(fmaf((a1 - m1) * r1, g1[c], b1[c]), act);
+                if (y2) {
+                    const float a2 = bf2f((bf16_t)(u ? w2[k] >> 16 : w2[k] & 0xffff));
+                    t += act_apply(fmaf((a2 - m2) * r2, g2[c], b2[c]), act);
+                }
+                res[u] = t;
+            }
+            out[k] = (unsigned)f2bf(res[0]) | ((unsigned)f2bf(res[1]) << 16);
+        }
+        *reinterpret_cast<uint4 *>(z + e) = make_uint4(out[0], out[1], out[2], out[3]);
+    }
+}
+
+// backward, pass 1: with u = gamma xhat + beta, t = dz act'(u):  per (block, channel) partial sums of t and t xhat.
+// Each block owns a contiguous run of voxels of ONE sample; thread t of 256 handles channel group (t % C8) of voxel
+// (t / C8) + k * (256 / C8) ... the partials go through LDS to one slab row per block: [b][blk][2][C].
+__global__ __launch_bounds__(256) void cb_gn_bwd_reduce_kernel(const bf16_t *__restrict__ dz, const bf16_t *__restrict__ y,
+                                                              const float *__restrict__ mr, const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta, float *__restrict__ slab, int C, long long V,
+                                                              int act) {
+    extern __shared__ float lds[];    // [2][C]
+    const int b = blockIdx.y, nblk = gridDim.x;
+    const float mean = mr[2 * b], rstd = mr[2 * b + 1];
+    const int C8 = C >> 3;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) lds[i] = 0.f;
+    __syncthreads();
+    const long long per_blk = (V + nblk - 1) / nblk;
+    const long long vlo = (long long)blockIdx.x * per_blk, vhi = vlo + per_blk < V ? vlo + per_blk : V;
+    const long long items = (vhi > vlo ? vhi - vlo : 0) * C8;
+    // a thread keeps ONE channel group when 256 % C8 == 0 (C = 8, 16, 32, 64 ...); otherwise (24, 48, 96 ...) the group
+    // changes per iteration and the sums go to LDS atomically per item -- use the general form for all
+    float s1[8], s2[8];
+    int cur = -1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    auto flush = [&]() {
+        if (cur >= 0)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                atomicAdd(&lds[cur * 8 + j], s1[j]);
+                atomicAdd(&lds[C + cur * 8 + j], s2[j]);
+                s1[j] = s2[j] = 0.f;
+            }
+    };
+    for (long long it = threadIdx.x; it < items; it += 256) {
+        const int cg = (int)(it % C8);
+        if (cg != cur) { flush(); cur = cg; }
+        const size_t e = ((size_t)b * V + vlo) * C + (size_t)it * 8;
+        const uint4 gv = *reinterpret_cast<const uint4 *>(dz + e), yv = *reinterpret_cast<const uint4 *>(y + e);
+        const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = 2 * k + u, c = cg * 8 + j;
+                const float g = bf2f((bf16_t)(u ? gw[k] >> 16 : gw[k] & 0xffff));
+                const float xh = (bf2f((bf16_t)(u ? yw[k] >> 16 : yw[k] & 0xffff)) - mean) * rstd;
+                const float out = act_apply(fmaf(xh, gamma[c], beta[c]), act);
+                const float t = g * act_grad_from_out(out, act);
+                s1[j] += t;
+                s2[j] = fmaf(t, xh, s2[j]);
+            }
+    }
+    flush();
+    __syncthreads();
+    float *dst = slab + ((size_t)b * nblk + blockIdx.x) * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) dst[i] = lds[i];
+}
+
+// pass 1b: slabs -> dgamma[c], dbeta[c] (summed over samples and blocks, fp64, fixed order) and per sample
+// k1 = sum_c gamma_c S1[b][c] / N,  k2 = sum_c gamma_c S2[b][c] / N   (N = C V)
+__global__ __launch_bounds__(256) void cb_gn_bwd_finalize_kernel(const float *__restrict__ slab, const float *__restrict__ gamma, int B, int nblk,
+                                                                int C, double count, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                                float *__restrict__ k12, int accumulate) {
+    __shared__ double sh[2][256];
+    double acc1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc2[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per sample, this thread's channels folded with gamma
+    // thread t owns channels t, t + 256, ...
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double dg = 0.0, db = 0.0;
+        for (int b = 0; b < B; ++b) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < nblk; ++k) {
+                const float *p = slab + ((size_t)b * nblk + k) * 2 * C;
+                s1 += (double)p[c];
+                s2 += (double)p[C + c];
+            }
+            db += s1;
+            dg += s2;
+            if (b < 8) {
+                acc1[b] += (double)gamma[c] * s1;
+                acc2[b] += (double)gamma[c] * s2;
+            }
+        }
+        if (accumulate) {
+            dgamma[c] += (float)dg;
+            dbeta[c] += (float)db;
+        } else {
+            dgamma[c] = (float)dg;
+            dbeta[c] = (float)db;
+        }
+    }
+    for (int b = 0; b < B && b < 8; ++b) {
+        sh[0][threadIdx.x] = acc1[b];
+        sh[1][threadIdx.x] = acc2[b];
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) {
+                sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+                sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            k12[2 * b] = (float)(sh[0][0] / count);
+            k12[2 * b + 1] = (float)(sh[1][0] / count);
+        }
+        __syncthreads();
+    }
+}
+
+// pass 2: dy = rstd (gamma t - k1 - xhat k2), bf16 channels-last
+__global__ __launch_bounds__(256) void cb_gn_bwd_apply_kernel(const bf16_t *__restrict__ dz, const bf16_t *__restrict__ y, const float *__restrict__ mr,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             const float *__restrict__ k12, bf16_t *__restrict__ dy, int C, long long per_sample,
+                                                             int act) {
+    const int b = blockIdx.y;
+    const float mean = mr[2 * b], rstd = mr[2 * b + 1], k1 = k12[2 * b], k2 = k12[2 * b + 1];
+    const long long n8 = per_sample >> 3;
+    const int C8 = C >> 3;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const int c0 = (int)(i % C8) * 8;
+        const size_t e = (size_t)b * per_sample + (size_t)i * 8;
+        const uint4 gv = *reinterpret_cast<const uint4 *>(dz + e), yv = *reinterpret_cast<const uint4 *>(y + e);
+        const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
+        unsigned out[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float res[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int c = c0 + 2 * k + u;
+                const float g = bf2f((bf16_t)(u ? gw[k] >> 16 : gw[k] & 0xffff));
+                const float xh = (bf2f((bf16_t)(u ? yw[k] >> 16 : yw[k] & 0xffff)) - mean) * rstd;
+                const float o = act_apply(fmaf(xh, gamma[c], beta[c]), act);
+                const float t = g * act_grad_from_out(o, act);
+                res[u] = rstd * (gamma[c] * t - k1 - xh * k2);
+            }
+            out[k] = (unsigned)f2bf(res[0]) | ((unsigned)f2bf(res[1]) << 16);
+        }
+        *reinterpret_cast<uint4 *>(dy + e) = make_uint4(out[0], out[1], out[2], out[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ layout / precision
+// fp32 NCDHW (C channels) -> bf16 NDHWC with CP >= C channels (pad channels zero).  One thread = one voxel.
+__global__ __launch_bounds__(256) void cb_pack_input_kernel(const float *__restrict__ x, bf16_t *__restrict__ y, int C, int CP, long long V) {
+    const int b = blockIdx.y;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < V; v += (long long)gridDim.x * 256) {
+        for (int c0 = 0; c0 < CP; c0 += 8) {
+            unsigned out[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + 2 * k;
+                const float f0 = c < C ? x[((size_t)b * C + c) * V + v] : 0.f;
+                const float f1 = c + 1 < C ? x[((size_t)b * C + c + 1) * V + v] : 0.f;
+                out[k] = (unsigned)f2bf(f0) | ((unsigned)f2bf(f1) << 16);
+            }
+            *reinterpret_cast<uint4 *>(y + ((size_t)b * V + v) * CP + c0) = make_uint4(out[0], out[1], out[2], out[3]);
+        }
+    }
+}
+
+// bf16 NDHWC (CP channels, the first C used) -> fp32 NCDHW
+__global__ __launch_bounds__(256) void cb_unpack_kernel(const bf16_t *__restrict__ x, float *__restrict__ y, int C, int CP, long long V) {
+    const int b = blockIdx.y;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < V; v += (long long)gridDim.x * 256) {
+        for (int c0 = 0; c0 < C; c0 += 8) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(x + ((size_t)b * V + v) * CP + c0);
+            const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + 2 * k;
+                if (c < C) y[((size_t)b * C + c) * V + v] = bf2f((bf16_t)(w[k] & 0xffff));
+                if (c + 1 < C) y[((size_t)b * C + c + 1) * V + v] = bf2f((bf16_t)(w[k] >> 16));
+            }
+        }
+    }
+}
+
+// per-channel sum over samples and voxels of a channels-last bf16 tensor (bias gradients): slab per block + ordered reduce
+__global__ __launch_bounds__(256) void cb_colsum_kernel(const bf16_t *__restrict__ g, float *__restrict__ slab, int C, long long rows) {
+    extern __shared__ float lds[];   // [C]
+    for (int i = threadIdx.x; i < C; i += 256) lds[i] = 0.f;
+    __syncthreads();
+    const int C8 = C >> 3;
+    const long long per_blk = (rows + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * per_blk, hi = lo + per_blk < rows ? lo + per_blk : rows;
+    const long long items = (hi > lo ? hi - lo : 0) * C8;
+    float s[8];
+    int cur = -1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    auto flush = [&]() {
+        if (cur >= 0)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                atomicAdd(&lds[cur * 8 + j], s[j]);
+                s[j] = 0.f;
+            }
+    };
+    for (long long it = threadIdx.x; it < items; it += 256) {
+        const int cg = (int)(it % C8);
+        if (cg != cur) { flush(); cur = cg; }
+        const uint4 gv = *reinterpret_cast<const uint4 *>(g + (size_t)lo * C + (size_t)it * 8);
+        const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s[2 * k] += bf2f((bf16_t)(gw[k] & 0xffff));
+            s[2 * k + 1] += bf2f((bf16_t)(gw[k] >> 16));
+        }
+    }
+    flush();
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) slab[(size_t)blockIdx.x * C + i] = lds[i];
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[t][o][i] = sum_{b, v} G[b][v][o] * X[b][in(v, t)][i].  The reduction index is the voxel, which channels-last tensors
+// do not have contiguous: the tiles are staged in LDS as they lie in memory ([voxel][channel] rows) and the MFMA
+// operands are read with ds_read_b64_tr_b16 (per 16-lane group: 4 voxel rows x 16 channels, delivered channel-major).
+//
+// Work decomposition.  A block owns (b, od, a band of TH output rows) per iteration and a (CO x CI) channel block
+// (CO, CI <= 48).  The G band is staged on a padded row pitch S (columns Wo .. S-1 are zero), the X halo -- the rows
+// and planes the band's taps reach -- on the same pitch, so that for output position p = hh * Sg + ww the tap
+// (td, th, tw) reads X-image element  base(tap) + stride * p : one flat shift per tap, no per-element index
+// arithmetic, and padding positions multiply zeros of G.  Each of the 4 waves accumulates ~ntaps / 4 taps in registers
+// across all the block's bands; the block then writes one slab [tap][CO][CI] and an ordered reduce sums the slabs.
+struct CwArgs {
+    const bf16_t *g, *xa, *xb;   // g: (B, Vo, Cg) output gradient; x = [xa | xb] (B, Vi, Ca / Cb) layer input
+    int Ca, Cb, Cg;
+    float *slab;                 // [nblk][ntaps][CO][CI] per (co block, ci block): see host
+    int B, Di, Hi, Wi, Do, Ho, Wo;
+    int ks, stride, pad, ntaps;
+    int TH, Sg, Sx, xrows, xplanes;   // band height; pitches; staged X rows per plane = stride * (TH - 1) + ks, planes = ks
+    int co0, ci0, CO, CI;        // channel block (multiples of 8; CO, CI <= 48)
+    int nbands;                  // bands per (b, od) = ceil(Ho / TH)
+    int swap;                    // 1: transposed-conv weight gradient (roles of g and x swapped by the host; informational)
+};
+
+// ds_read_b64_tr_b16 through the compiler builtin (it then places the lgkmcnt waits itself).  Per 16-lane group: lane 4q + p
+// supplies the address of row q, columns 4p .. 4p+3 of a 4 x 16 block; lane i receives column i of the 4 rows.
+__device__ __forceinline__ s16x4 lds_tr_read(const bf16_t *p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p));
+}
+
+// TA = ceil(CO / 16), TB = ceil(CI / 16) 16-channel tiles; TPW = taps per wave (ceil(ntaps / 4))
+template <int TA, int TB, int TPW>
+__global__ __launch_bounds__(256) void cb_wgrad_kernel(CwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int PG = TA * 16, PX = TB * 16;                 // channel pitch (elements) of the G / X images; pad channels zero
+    const int gpos = a.TH * a.Sg;                          // G image positions (rounded up to 32 below)
+    const int gpos32 = (gpos + 31) & ~31;
+    const int xpos = a.xplanes * a.xrows * a.Sx + 2 * a.Sx + 64;   // X image positions incl. slack on both ends
+    bf16_t *gi = reinterpret_cast<bf16_t *>(smem);                         // [gpos32][PG]
+    bf16_t *xi = gi + (size_t)gpos32 * PG;                                 // [xpos][PX], position 0 = slack
+    const int xorg = a.Sx + 32;                                            // image position of (plane 0, row 0, col -pad.. see below)
+    f32x4 acc[TPW][TA][TB];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int i = 0; i < TA; ++i)
+#pragma unroll
+            for (int j = 0; j < TB; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int Cx = a.Ca + a.Cb;
+    (void)Cx;
+    const long long nwork = (long long)a.B * a.Do * a.nbands;
+    const int grp = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
+    for (long long wk = blockIdx.x; wk < nwork; wk += gridDim.x) {
+        const int band = (int)(wk % a.nbands);
+        const int od = (int)((wk / a.nbands) % a.Do);
+        const int b = (int)(wk / ((long long)a.nbands * a.Do));
+        const int oh0 = band * a.TH;
+        __syncthreads();   // previous iteration's reads are done
+        // ---- stage G band: rows oh0 .. oh0+TH-1 (zero beyond Ho), columns 0 .. Sg-1 (zero beyond Wo), channels co0 .. co0+CO-1
+        {
+            const int c8n = PG >> 3;
+            const int items = gpos32 * c8n;
+            for (int it = threadIdx.x; it < items; it += 256) {
+                const int c8 = it % c8n, p = it / c8n;
+                const int hh = p / a.Sg, ww = p - hh * a.Sg;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                const int oh = oh0 + hh, ch = c8 * 8;
+                if (p < gpos && oh < a.Ho && ww < a.Wo && ch < a.CO) {
+                    const size_t vo = ((size_t)od * a.Ho + oh) * a.Wo + ww;
+                    v = *reinterpret_cast<const uint4 *>(a.g + ((size_t)b * a.Do * a.Ho * a.Wo + vo) * a.Cg + a.co0 + ch);
+                }
+                *reinterpret_cast<uint4 *>(gi + (size_t)p * PG + ch) = v;
+            }
+        }
+        // ---- stage X halo: planes id0 .. id0+ks-1, rows ih0 .. ih0+xrows-1, columns iw0 .. iw0+Sx-1 with
+        //      id0 = stride*od - pad, ih0 = stride*oh0 - pad, iw0 = -pad; out-of-range -> zero; the slack is zeroed too.
+        //      (pitch Sx == Sg, see wg_plan)
+        {
+            const int c8n = PX >> 3;
+            const int items = xpos * c8n;
+            const int id0 = a.stride * od - a.pad, ih0 = a.stride * oh0 - a.pad;
+            for (int it = threadIdx.x; it < items; it += 256) {
+                const int c8 = it % c8n, pp = it / c8n;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                const int p = pp - xorg;
+                const int ch = a.ci0 + c8 * 8;
+                if (p >= 0 && c8 * 8 < a.CI) {
+                    const int pl = p / (a.xrows * a.Sx), rem = p - pl * (a.xrows * a.Sx);
+                    const int rr = rem / a.Sx, cc = rem - rr * a.Sx;
+                    const int id = id0 + pl, ih = ih0 + rr, iw = cc - a.pad;
+                    if (pl < a.xplanes && id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi) {
+                        const size_t vi = ((size_t)b * a.Di + id) * a.Hi * a.Wi + (size_t)ih * a.Wi + iw;
+                        v = ch < a.Ca ? *reinterpret_cast<const uint4 *>(a.xa + vi * a.Ca + ch)
+                                      : *reinterpret_cast<const uint4 *>(a.xb + vi * a.Cb + (ch - a.Ca));
+                    }
+                }
+                *reinterpret_cast<uint4 *>(xi + (size_t)pp * PX + c8 * 8) = v;
+            }
+        }
+        __syncthreads();
+        // ---- K loop over the band's positions, 32 per step (v_mfma_f32_16x16x32_bf16: lane group grp holds k = 8 grp .. 8 grp + 7)
+        for (int p0 = 0; p0 < gpos32; p0 += 32) {
+            // A operand = G^T: rows = output channels (16 per tile), k = positions.  Two transposed reads per tile:
+            // positions p0 + 8 grp + {0..3} and + {4..7}; lane 4q+p supplies row q, channels 4p..4p+3 of the tile
+            s16x4 af[TA][2];
+#pragma unroll
+            for (int i = 0; i < TA; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int pos = p0 + 8 * grp + 4 * u + lq;
+                    af[i][u] = lds_tr_read(gi + (pos * PG + 16 * i + 4 * lp));
+                }
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int tap = wave + 4 * t;
+                if (tap < a.ntaps) {            // wave-uniform
+                    const int ks2 = a.ks * a.ks;
+                    const int td = tap / ks2, th = (tap / a.ks) % a.ks, tw = tap % a.ks;
+                    const int base = xorg + (td * a.xrows + th) * a.Sx + tw;
+                    s16x4 bfr[TB][2];
+#pragma unroll
+                    for (int j = 0; j < TB; ++j)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int pos = base + a.stride * (p0 + 8 * grp + 4 * u + lq);
+                            bfr[j][u] = lds_tr_read(xi + (pos * PX + 16 * j + 4 * lp));
+                        }
+#pragma unroll
+                    for (int i = 0; i < TA; ++i)
+#pragma unroll
+                        for (int j = 0; j < TB; ++j) {
+                            typedef short s16x8 __attribute__((ext_vector_type(8)));
+                            const s16x8 av = {af[i][0][0], af[i][0][1], af[i][0][2], af[i][0][3], af[i][1][0], af[i][1][1], af[i][1][2], af[i][1][3]};
+                            const s16x8 bv = {bfr[j][0][0], bfr[j][0][1], bfr[j][0][2], bfr[j][0][3], bfr[j][1][0], bfr[j][1][1], bfr[j][1][2], bfr[j][1][3]};
+                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                                                   acc[t][i][j], 0, 0, 0);
+                        }
+                }
+            }
+        }
+    }
+    // ---- slab: [tap][CO][CI] for this block.  C/D of 16x16x32: column (lane & 15) = input channel, rows 4 (lane >> 4) + e = output channel
+    float *dst = a.slab + (size_t)blockIdx.x * a.ntaps * a.CO * a.CI;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tap = wave + 4 * t;
+        if (tap >= a.ntaps) continue;
+#pragma unroll
+        for (int i = 0; i < TA; ++i)
+#pragma unroll
+            for (int j = 0; j < TB; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int o = 16 * i + 4 * grp + e, c = 16 * j + li;
+                    if (o < a.CO && c < a.CI) dst[((size_t)tap * a.CO + o) * a.CI + c] = acc[t][i][j][e];
+                }
+    }
+}
+
+// slabs [nblk][ntaps][CO][CI] -> dW fp32 in the parameter's own layout: element (o, i, tap) of the GEMM goes to
+// dW[(c0 * C1 + c1) * T + tap] with (c0, c1) = (o, i) or (i, o).  fp64-free ordered sum (fp32, fixed order).
+__global__ __launch_bounds__(256) void cb_wgrad_reduce_kernel(const float *__restrict__ slab, int nblk, int ntaps, int CO, int CI, int co0, int ci0,
+                                                             float *__restrict__ dW, int C1, int T, int out_is_axis0) {
+    const int n = ntaps * CO * CI;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nblk; ++k) s += slab[(size_t)k * n + idx];
+        const int c = idx % CI, o = (idx / CI) % CO, tap = idx / (CI * CO);
+        const int go = co0 + o, gc = ci0 + c;
+        const int c0 = out_is_axis0 ? go : gc, c1 = out_is_axis0 ? gc : go;
+        dW[((size_t)c0 * C1 + c1) * T + tap] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void cb_colsum_reduce_kernel(const float *__restrict__ slab, int nblk, int C, float *__restrict__ out) {
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nblk; ++k) s += slab[(size_t)k * C + c];
+        out[c] = s;
+    }
+}
+
+static int gsz(long long n, int per = 256, int cap = 4096) {
+    long long g = (n + per - 1) / per;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace hno
+
+using namespace hno;
+
+// ================================================================================================ C ABI
+extern "C" size_t hno_cb_packed_weight_bytes(int Cin, int Cout, int ks) {
+    const int nq = ks * ks * ks * (Cin / 8), nq2 = (nq + 1) & ~1;
+    const int CoP = (Cout + 31) / 32 * 32;
+    return (size_t)nq2 * CoP * 8 * sizeof(bf16_t);
+}
+
+// role: 0 conv forward (W[Cout][Cin][T]), 1 conv input gradient (same tensor, channel roles swapped),
+//       2 ConvTranspose forward (Wt[Cin][Cout][T]), 3 ConvTranspose input gradient.  Cin / Cout are the LAYER's.
+extern "C" int hno_cb_pack_weights(const float *W, void *dst, int role, int Cin, int Cout, int ks, void *stream) {
+    HNO_REQUIRE(W && dst && role >= 0 && role <= 3 && Cin > 0 && Cout > 0 && ks >= 1 && ks <= 3, "hno_cb_pack_weights: bad argument");
+    const int gi = (role == 0 || role == 2) ? Cin : Cout, go = (role == 0 || role == 2) ? Cout : Cin;   // GEMM in / out channels
+    if (gi % 8) return fail(HNO_ELIMIT, "hno_cb_pack_weights: %d GEMM input channels (must be a multiple of 8)", gi);
+    const int C0 = role <= 1 ? Cout : Cin, C1 = role <= 1 ? Cin : Cout;
+    const int out_is_axis0 = (role == 0 || role == 3);
+    const int T = ks * ks * ks;
+    const int nq = T * (gi / 8), nq2 = (nq + 1) & ~1, CoP = (go + 31) / 32 * 32;
+    hipLaunchKernelGGL(cb_pack_weights_kernel, dim3(gsz((long long)nq2 * CoP * 8)), dim3(256), 0, (hipStream_t)stream, W, (bf16_t *)dst, C0, C1, T,
+                       out_is_axis0, gi, go, CoP, nq2);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+static int cb_pick_ksplit(int B, int Cout, long long Vo, int nsteps) {
+    const long long waves = (long long)B * ((Vo + 63) / 64) * ((Cout + 95) / 96);
+    int ks = 1;
+    while (waves * ks < 2048 && ks * 2 <= nsteps && ks < 32) ks *= 2;
+    return ks;
+}
+
+extern "C" size_t hno_cb_conv_workspace_bytes(int B, int Cin, int Cout, int Do, int Ho, int Wo, int ks) {
+    const long long Vo = (long long)Do * Ho * Wo;
+    const int nq = ks * ks * ks * (Cin / 8), nsteps = ((nq + 1) & ~1) / 2;
+    const int kz = cb_pick_ksplit(B, Cout, Vo, nsteps);
+    size_t part = kz > 1 ? (size_t)kz * B * Vo * Cout * sizeof(float) : 0;
+    // statistics partials: at most one pair per 64-voxel x 32-channel block, or per finish block
+    size_t stats = (size_t)B * (((Vo + 63) / 64) * ((Cout + 31) / 32) + 4096) * 2 * sizeof(float);
+    return part + stats + 256;
+}
+
+// y = conv(x) (+ bias), channels-last bf16 in and out.  mode 0: correlation gather in = stride * out - pad + tap;
+// mode 1: fractional gather in = (out + pad - tap) / stride (ConvTranspose forward, input gradient of a conv).
+// wpacked: from hno_cb_pack_weights with the matching role.  Cin = Ca + Cb GEMM input channels, Cout GEMM output channels.
+// mean_rstd (B, 2) non-null: GroupNorm(1, Cout) statistics of the rounded output are produced in the same pass.
+extern "C" int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const void *wpacked, const float *bias, void *y,
+                           float *mean_rstd, float eps, void *workspace, size_t workspace_bytes, int mode, int B, int Cout,
+                           int Di, int Hi, int Wi, int Do, int Ho, int Wo, int ks, int stride, int pad, void *stream) {
+    HNO_REQUIRE(xa && wpacked && y && workspace && B > 0 && Cout > 0 && Ca > 0 && Cb >= 0, "hno_cb_conv: bad argument");
+    HNO_REQUIRE((mode == 0 || mode == 1) && (stride == 1 || stride == 2) && ks >= 1 && ks <= 3, "hno_cb_conv: bad mode / stride / kernel");
+    HNO_REQUIRE(Cb == 0 || xb, "hno_cb_conv: second input missing");
+    if ((Ca % 8) || (Cb % 8) || (Cout % 8)) return fail(HNO_ELIMIT, "hno_cb_conv: channel counts %d + %d -> %d must be multiples of 8", Ca, Cb, Cout);
+    const long long Vo = (long long)Do * Ho * Wo;
+    if ((long long)(Ca + Cb) * Di * Hi * Wi >= (1ll << 40) || Vo >= (1ll << 31)) return fail(HNO_ELIMIT, "hno_cb_conv: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    CbArgs a = {};
+    a.xa = (const bf16_t *)xa; a.xb = (const bf16_t *)xb; a.Ca = Ca; a.Cb = Cb; a.w = (const bf16_t *)wpacked; a.bias = bias;
+    a.y = (bf16_t *)y; a.B = B; a.Cout = Cout; a.CoP = (Cout + 31) / 32 * 32;
+    a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.ks = ks; a.stride = stride; a.pad = pad; a.frac = mode;
+    a.ntaps = ks * ks * ks;
+    const int nq = a.ntaps * ((Ca + Cb) / 8);
+    a.nq2 = (nq + 1) & ~1;
+    const int nsteps = a.nq2 / 2;
+    const int kz = cb_pick_ksplit(B, Cout, Vo, nsteps);
+    a.ksplit = kz;
+    const size_t part_bytes = kz > 1 ? (size_t)kz * B * Vo * Cout * sizeof(float) : 0;
+    HNO_REQUIRE(workspace_bytes >= hno_cb_conv_workspace_bytes(B, Ca + Cb, Cout, Do, Ho, Wo, ks), "hno_cb_conv: workspace too small");
+    a.part = kz > 1 ? (float *)workspace : nullptr;
+    float *stats = (float *)((char *)workspace + ((part_bytes + 255) & ~(size_t)255));
+    a.stats = mean_rstd ? stats : nullptr;
+    int nblk_stats;
+    const double flops = 2.0 * B * Vo * (double)Cout * a.ntaps * (Ca + Cb);
+    {
+        ProfScope _ps(KID_CB_CONV, s, flops);
+        if (Cout <= 32) {
+            const dim3 g((unsigned)((Vo + 4 * 32 * 4 - 1) / (4 * 32 * 4)), 1, B * kz);
+            hipLaunchKernelGGL((cb_gather_kernel<4, 1>), g, dim3(256), 0, s, a);
+            nblk_stats = g.x * g.y;
+        } else if (Cout <= 64) {
+            const dim3 g((unsigned)((Vo + 4 * 32 * 2 - 1) / (4 * 32 * 2)), 1, B * kz);
+            hipLaunchKernelGGL((cb_gather_kernel<2, 2>), g, dim3(256), 0, s, a);
+            nblk_stats = g.x * g.y;
+        } else {
+            const dim3 g((unsigned)((Vo + 4 * 32 * 2 - 1) / (4 * 32 * 2)), (Cout + 95) / 96, B * kz);
+            hipLaunchKernelGGL((cb_gather_kernel<2, 3>), g, dim3(256), 0, s, a);
+            nblk_stats = g.x * g.y;
+        }
+        HNO_CHECK_LAUNCH();
+    }
+    if (kz > 1) {
+        const long long per_sample = Vo * Cout;
+        const int gx = gsz(per_sample, 256, 1024);
+        hipLaunchKernelGGL(cb_splitk_finish_kernel, dim3(gx, B), dim3(256), 0, s, (const float *)a.part, (bf16_t *)y, mean_rstd ? stats : nullptr, kz,
+                           per_sample, B);
+        HNO_CHECK_LAUNCH();
+        nblk_stats = gx;
+    }
+    if (mean_rstd) {
+        hipLaunchKernelGGL(cb_gn_finalize_kernel, dim3(B), dim3(256), 0, s, (const float *)stats, nblk_stats, (double)Vo * Cout, eps, mean_rstd);
+        HNO_CHECK_LAUNCH();
+    }
+    return HNO_OK;
+}
+
+extern "C" int hno_cb_gn_apply(const void *y1, const float *mr1, const float *gamma1, const float *beta1, const void *y2,
+                               const float *mr2, const float *gamma2, const float *beta2, void *z, int B, int C, long long V, int act,
+                               void *stream) {
+    HNO_REQUIRE(y1 && mr1 && gamma1 && beta1 && z && B > 0 && C > 0 && V > 0, "hno_cb_gn_apply: bad argument");
+    HNO_REQUIRE(!y2 || (mr2 && gamma2 && beta2), "hno_cb_gn_apply: second branch incomplete");
+    if (C % 8) return fail(HNO_ELIMIT, "hno_cb_gn_apply: C = %d must be a multiple of 8", C);
+    hipStream_t s = (hipStream_t)stream;
+    const long long per_sample = V * C;
+    ProfScope _ps(KID_CB_GN, s, (double)B * per_sample * (y2 ? 6.0 : 4.0));
+    hipLaunchKernelGGL(cb_gn_apply_kernel, dim3(gsz(per_sample / 8, 256, 2048), B), dim3(256), 0, s, (const bf16_t *)y1, mr1, gamma1, beta1,
+                       (const bf16_t *)y2, mr2, gamma2, beta2, (bf16_t *)z, C, per_sample, act);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+#define CB_GN_BWD_BLOCKS 256
+extern "C" size_t hno_cb_gn_bwd_workspace_bytes(int B, int C) {
+    return ((size_t)B * CB_GN_BWD_BLOCKS * 2 * C + 2 * (size_t)(B > 8 ? B : 8)) * sizeof(float) + 256;
+}
+
+// backward of z = act(gamma (y - mean) rstd + beta) w.r.t. y, gamma, beta.  accumulate != 0: dgamma / dbeta += .
+extern "C" int hno_cb_gn_bwd(const void *dz, const void *y, const float *mr, const float *gamma, const float *beta, void *dy,
+                             float *dgamma, float *dbeta, void *workspace, int B, int C, long long V, int act, int accumulate,
+                             void *stream) {
+    HNO_REQUIRE(dz && y && mr && gamma && beta && dy && dgamma && dbeta && workspace && B > 0 && C > 0 && V > 0, "hno_cb_gn_bwd: bad argument");
+    if (C % 8 || C > 4096) return fail(HNO_ELIMIT, "hno_cb_gn_bwd: C = %d must be a multiple of 8 (<= 4096)", C);
+    if (B > 8) return fail(HNO_ELIMIT, "hno_cb_gn_bwd: batch %d > 8 per call", B);
+    hipStream_t s = (hipStream_t)stream;
+    float *slab = (float *)workspace;
+    float *k12 = slab + (size_t)B * CB_GN_BWD_BLOCKS * 2 * C;
+    int nblk = CB_GN_BWD_BLOCKS;
+    if (V < nblk) nblk = (int)V;
+    {
+        ProfScope _ps(KID_CB_GN, s, (double)B * V * C * 4.0);
+        hipLaunchKernelGGL(cb_gn_bwd_reduce_kernel, dim3(nblk, B), dim3(256), 2 * C * sizeof(float), s, (const bf16_t *)dz, (const bf16_t *)y, mr, gamma,
+                           beta, slab, C, V, act);
+        HNO_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(cb_gn_bwd_finalize_kernel, dim3(1), dim3(256), 0, s, (const float *)slab, gamma, B, nblk, C, (double)V * C, dgamma, dbeta, k12,
+                       accumulate);
+    HNO_CHECK_LAUNCH();
+    {
+        ProfScope _ps(KID_CB_GN, s, (double)B * V * C * 6.0);
+        hipLaunchKernelGGL(cb_gn_bwd_apply_kernel, dim3(gsz(V * C / 8, 256, 2048), B), dim3(256), 0, s, (const bf16_t *)dz, (const bf16_t *)y, mr, gamma,
+                           beta, (const float *)k12, (bf16_t *)dy, C, V * C, act);
+        HNO_CHECK_LAUNCH();
+    }
+    return HNO_OK;
+}
+
+extern "C" int hno_cb_pack_input(const float *x, void *y, int B, int C, int CP, long long V, void *stream) {
+    HNO_REQUIRE(x && y && B > 0 && C > 0 && CP >= C && CP % 8 == 0 && V > 0, "hno_cb_pack_input: bad argument");
+    hipLaunchKernelGGL(cb_pack_input_kernel, dim3(gsz(V, 256, 4096), B), dim3(256), 0, (hipStream_t)stream, x, (bf16_t *)y, C, CP, V);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+extern "C" int hno_cb_unpack(const void *x, float *y, int B, int C, int CP, long long V, void *stream) {
+    HNO_REQUIRE(x && y && B > 0 && C > 0 && CP >= C && CP % 8 == 0 && V > 0, "hno_cb_unpack: bad argument");
+    hipLaunchKernelGGL(cb_unpack_kernel, dim3(gsz(V, 256, 4096), B), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)x, y, C, CP, V);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+#define CB_COLSUM_BLOCKS 256
+extern "C" size_t hno_cb_colsum_workspace_bytes(int C) { return (size_t)CB_COLSUM_BLOCKS * C * sizeof(float); }
+
+extern "C" int hno_cb_colsum(const void *g, float *out, void *workspace, int C, long long rows, void *stream) {
+    HNO_REQUIRE(g && out && workspace && C > 0 && C % 8 == 0 && rows > 0, "hno_cb_colsum: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    int nblk = CB_COLSUM_BLOCKS;
+    if (rows < nblk) nblk = (int)rows;
+    hipLaunchKernelGGL(cb_colsum_kernel, dim3(nblk), dim3(256), C * sizeof(float), s, (const bf16_t *)g, (float *)workspace, C, rows);
+    HNO_CHECK_LAUNCH();
+    hipLaunchKernelGGL(cb_colsum_reduce_kernel, dim3(gsz(C)), dim3(256), 0, s, (const float *)workspace, nblk, C, out);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+// ---- weight gradient --------------------------------------------------------------------------------------------
+namespace {
+struct WgPlan {
+    int TH, Sg, Sx, xrows, gpos32, xpos, nblk;
+    size_t lds;
+};
+// band height: as many output rows as fit in LDS (G band + X halo at the block's channel pitches), at least 1
+WgPlan wg_plan(int B, int Do, int Ho, int Wo, int ks, int stride, int pad, int PG, int PX) {
+    WgPlan p = {};
+    // one pitch for both images: output position p = hh * S + ww reads X-image element base(tap) + stride * p, which is
+    // (row stride * hh + th, column stride * ww + tw) when the X rows have the SAME pitch S >= stride * (Wo - 1) + ks
+    p.Sg = stride * (Wo - 1) + ks;
+    p.Sx = p.Sg;
+    int best = 1;
+    for (int th = 1; th <= Ho; ++th) {
+        const int xrows = stride * (th - 1) + ks;
+        const int gpos32 = (th * p.Sg + 31) & ~31;
+        const int xpos = ks * xrows * p.Sx + 2 * p.Sx + 64 + stride * 32;
+        const size_t bytes = ((size_t)gpos32 * PG + (size_t)xpos * PX) * 2;
+        if (bytes <= 150 * 1024) best = th; else break;
+    }
+    p.TH = best;
+    p.xrows = stride * (best - 1) + ks;
+    p.gpos32 = (best * p.Sg + 31) & ~31;
+    p.xpos = ks * p.xrows * p.Sx + 2 * p.Sx + 64 + stride * 32;
+    p.lds = ((size_t)p.gpos32 * PG + (size_t)p.xpos * PX) * 2;
+    const long long nwork = (long long)B * Do * ((Ho + best - 1) / best);
+    p.nblk = (int)(nwork < 256 ? nwork : 256);
+    return p;
+}
+}  // namespace
+
+extern "C" size_t hno_cb_wgrad_workspace_bytes(int Cin, int Cout, int ks) {
+    // one slab set per (co block, ci block), processed one after the other: the workspace holds ONE set
+    const int CO = Cout < 48 ? Cout : 48, CI = Cin < 48 ? Cin : 48;
+    return (size_t)256 * ks * ks * ks * CO * CI * sizeof(float);
+}
+
+template <int TA, int TB>
+static int wg_launch(const CwArgs &a, int nblk, size_t lds, hipStream_t s) {
+    const int tpw = (a.ntaps + 3) / 4;
+    if (tpw <= 1) {
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)cb_wgrad_kernel<TA, TB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((cb_wgrad_kernel<TA, TB, 1>), dim3(nblk), dim3(256), lds, s, a);
+    } else if (tpw <= 2) {
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)cb_wgrad_kernel<TA, TB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((cb_wgrad_kernel<TA, TB, 2>), dim3(nblk), dim3(256), lds, s, a);
+    } else {
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)cb_wgrad_kernel<TA, TB, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((cb_wgrad_kernel<TA, TB, 7>), dim3(nblk), dim3(256), lds, s, a);
+    }
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+// dW (fp32, the parameter's layout) of a convolution (transposed = 0: W[Cout][Cin][T]; g on the OUTPUT grid (Dg..), x = [xa | xb]
+// on the input grid) or of a ConvTranspose (transposed = 1: Wt[Cin][Cout][T]; the transposed convolution's input x plays the
+// role of the "output gradient" operand and g of the gathered operand -- the host swaps them).
+extern "C" int hno_cb_wgrad(const void *g, int Cg, const void *xa, int Ca, const void *xb, int Cb, float *dW, void *workspace,
+                            int transposed, int B, int Dx, int Hx, int Wx, int Dg, int Hg, int Wg, int ks, int stride, int pad,
+                            void *stream) {
+    HNO_REQUIRE(g && xa && dW && workspace && B > 0 && Cg > 0 && Ca > 0 && Cb >= 0, "hno_cb_wgrad: bad argument");
+    HNO_REQUIRE((stride == 1 || stride == 2) && ks >= 1 && ks <= 3, "hno_cb_wgrad: bad stride / kernel");
+    if ((Cg % 8) || (Ca % 8) || (Cb % 8)) return fail(HNO_ELIMIT, "hno_cb_wgrad: channel counts must be multiples of 8");
+    hipStream_t s = (hipStream_t)stream;
+    // GEMM: rows = channels of the "positions" operand P (un-gathered, on the small grid), columns = channels of the gathered
+    // operand Q (on the grid the taps reach into).  conv: P = g (Cout), Q = x (Cin).  transposed conv: P = x (Cin), Q = g (Cout).
+    CwArgs a = {};
+    int CP, CQ;
+    if (!transposed) {
+        a.g = (const bf16_t *)g; a.Cg = Cg; a.xa = (const bf16_t *)xa; a.xb = (const bf16_t *)xb; a.Ca = Ca; a.Cb = Cb;
+        a.Do = Dg; a.Ho = Hg; a.Wo = Wg; a.Di = Dx; a.Hi = Hx; a.Wi = Wx;
+        CP = Cg; CQ = Ca + Cb;
+    } else {
+        HNO_REQUIRE(Cb == 0, "hno_cb_wgrad: transposed convolutions take one input");
+        a.g = (const bf16_t *)xa; a.Cg = Ca; a.xa = (const bf16_t *)g; a.xb = nullptr; a.Ca = Cg; a.Cb = 0;
+        a.Do = Dx; a.Ho = Hx; a.Wo = Wx; a.Di = Dg; a.Hi = Hg; a.Wi = Wg;
+        CP = Ca; CQ = Cg;
+    }
+    a.B = B; a.ks = ks; a.stride = stride; a.pad = pad; a.ntaps = ks * ks * ks; a.swap = transposed;
+    const int T = a.ntaps;
+    // parameter layout: conv W[Cout = P][Cin = Q][T]: out_is_axis0 = 1 with (o, i) = (P, Q); transposed Wt[Cin = P][Cout = Q][T] likewise
+    const int C1 = CQ;
+    for (int co0 = 0; co0 < CP; co0 += 48)
+        for (int ci0 = 0; ci0 < CQ; ci0 += 48) {
+            a.co0 = co0; a.ci0 = ci0;
+            a.CO = CP - co0 < 48 ? CP - co0 : 48;
+            a.CI = CQ - ci0 < 48 ? CQ - ci0 : 48;
+            // (a block may straddle the two concatenated inputs: the staging picks the tensor per 8-channel chunk)
+            const int TA = (a.CO + 15) / 16, TB = (a.CI + 15) / 16;
+            const WgPlan p = wg_plan(B, a.Do, a.Ho, a.Wo, ks, stride, pad, TA * 16, TB * 16);
+            a.TH = p.TH; a.Sg = p.Sg; a.Sx = p.Sx; a.xrows = p.xrows; a.xplanes = ks;
+            a.nbands = (a.Ho + p.TH - 1) / p.TH;
+            a.slab = (float *)workspace;
+            int rc;
+            {
+                ProfScope _ps(KID_CB_WGRAD, s, 2.0 * B * (double)a.Do * a.Ho * a.Wo * T * a.CO * a.CI);
+                if (TA == 1 && TB == 1) rc = wg_launch<1, 1>(a, p.nblk, p.lds, s);
+                else if (TA == 1 && TB == 2) rc = wg_launch<1, 2>(a, p.nblk, p.lds, s);
+                else if (TA == 1 && TB == 3) rc = wg_launch<1, 3>(a, p.nblk, p.lds, s);
+                else if (TA == 2 && TB == 1) rc = wg_launch<2, 1>(a, p.nblk, p.lds, s);
+                else if (TA == 2 && TB == 2) rc = wg_launch<2, 2>(a, p.nblk, p.lds, s);
+                else if (TA == 2 && TB == 3) rc = wg_launch<2, 3>(a, p.nblk, p.lds, s);
+                else if (TA == 3 && TB == 1) rc = wg_launch<3, 1>(a, p.nblk, p.lds, s);
+                else if (TA == 3 && TB == 2) rc = wg_launch<3, 2>(a, p.nblk, p.lds, s);
+                else rc = wg_launch<3, 3>(a, p.nblk, p.lds, s);
+            }
+            if (rc != HNO_OK) return rc;
+            hipLaunchKernelGGL(cb_wgrad_reduce_kernel, dim3(gsz((long long)T * a.CO * a.CI, 256, 256)), dim3(256), 0, s, (const float *)a.slab, p.nblk, T,
+                               a.CO, a.CI, co0, ci0, dW, C1, T, 1);
+            HNO_CHECK_LAUNCH();
+        }
+    return HNO_OK;
+}

@@ -1,0 +1,252 @@
+"""bf16 matrix-core path (the reference's ``use_autocast`` mode, experiments/train_test.py:79,154-168) over the
+``hno_cb_*`` entry points of include/hno.h.
+
+Activations are channels-last bf16 tensors (B, D, H, W, C) -- torch tensors as containers only; parameters, their
+gradients and the GroupNorm statistics are fp32.  Every Function here is one launch group of libhno; nothing
+computes through ATen, and there is no CPU path (meta tensors get shape inference only, see ops._HnoFunction).
+"""
+import torch
+
+from . import _lib, ops
+from ._lib import check, ptr, stream_ptr
+from .ops import _HnoFunction, _need_gpu, _m, ACT_NONE
+
+BF16 = torch.bfloat16
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), device=device, dtype=torch.uint8)
+
+
+def _cl(t):
+    """contiguous channels-last bf16 container check"""
+    assert t.dtype == BF16 and t.is_contiguous() and t.ndim == 5, 'expected a contiguous (B, D, H, W, C) bf16 tensor'
+    return t
+
+
+def _f32(t):
+    if t is None:
+        return None
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+# ----------------------------------------------------------------------------------------------- raw launchers
+def pack_weights(W, role, Cin, Cout, ks):
+    """fp32 parameter -> packed bf16 GEMM operand.  role 0 conv fwd, 1 conv dgrad, 2 ConvTranspose fwd, 3 ConvTranspose dgrad."""
+    L = _lib.lib()
+    W = _f32(W)
+    out = _ws(L.hno_cb_packed_weight_bytes(Cin if role in (0, 2) else Cout, Cout if role in (0, 2) else Cin, ks), W.device)
+    check(L.hno_cb_pack_weights(ptr(W), ptr(out), role, Cin, Cout, ks, stream_ptr()), 'hno_cb_pack_weights')
+    return out
+
+
+def conv_raw(xa, xb, wpacked, bias, Cout, out_spatial, mode, ks, stride, pad, want_stats, eps=1e-5):
+    """gather GEMM; -> (y (B, Do, Ho, Wo, Cout) bf16, mean_rstd (B, 2) fp32 or None)"""
+    _need_gpu(xa, xb)
+    xa = _cl(xa)
+    B, Di, Hi, Wi, Ca = xa.shape
+    Cb = 0
+    if xb is not None:
+        xb = _cl(xb)
+        assert xb.shape[:4] == xa.shape[:4]
+        Cb = xb.shape[4]
+    Do, Ho, Wo = (int(v) for v in out_spatial)
+    L = _lib.lib()
+    y = torch.empty((B, Do, Ho, Wo, Cout), device=xa.device, dtype=BF16)
+    mr = torch.empty((B, 2), device=xa.device, dtype=torch.float32) if want_stats else None
+    nws = L.hno_cb_conv_workspace_bytes(B, Ca + Cb, Cout, Do, Ho, Wo, ks)
+    ws = _ws(nws, xa.device)
+    check(L.hno_cb_conv(ptr(xa), Ca, ptr(xb), Cb, ptr(wpacked), ptr(_f32(bias)), ptr(y), ptr(mr), float(eps), ptr(ws), nws, mode, B, Cout,
+                        Di, Hi, Wi, Do, Ho, Wo, ks, stride, pad, stream_ptr()), 'hno_cb_conv')
+    return y, mr
+
+
+def wgrad_raw(g, xa, xb, w_shape, transposed, ks, stride, pad):
+    """dW (fp32, parameter layout).  conv: g on the output grid, x = [xa ; xb] its input.  transposed: x the ConvTranspose input."""
+    g, xa = _cl(g), _cl(xa)
+    L = _lib.lib()
+    Cb = 0 if xb is None else xb.shape[4]
+    dW = torch.empty(tuple(w_shape), device=g.device, dtype=torch.float32)
+    Cin, Cout = (xa.shape[4] + Cb, g.shape[4])
+    ws = _ws(L.hno_cb_wgrad_workspace_bytes(max(Cin, Cout), max(Cin, Cout), ks), g.device)
+    check(L.hno_cb_wgrad(ptr(g), g.shape[4], ptr(xa), xa.shape[4], ptr(xb), Cb, ptr(dW), ptr(ws), int(transposed), g.shape[0],
+                         xa.shape[1], xa.shape[2], xa.shape[3], g.shape[1], g.shape[2], g.shape[3], ks, stride, pad, stream_ptr()),
+          'hno_cb_wgrad')
+    return dW
+
+
+def colsum_raw(g):
+    C = g.shape[-1]
+    L = _lib.lib()
+    out = torch.empty(C, device=g.device, dtype=torch.float32)
+    ws = _ws(L.hno_cb_colsum_workspace_bytes(C), g.device)
+    check(L.hno_cb_colsum(ptr(g), ptr(out), ptr(ws), C, g.numel() // C, stream_ptr()), 'hno_cb_colsum')
+    return out
+
+
+def gn_apply_raw(y1, mr1, g1, b1, act, y2=None, mr2=None, g2=None, b2=None):
+    y1 = _cl(y1)
+    B, C = y1.shape[0], y1.shape[4]
+    V = y1.shape[1] * y1.shape[2] * y1.shape[3]
+    z = torch.empty_like(y1)
+    check(_lib.lib().hno_cb_gn_apply(ptr(y1), ptr(mr1), ptr(_f32(g1)), ptr(_f32(b1)), ptr(y2), ptr(mr2), ptr(_f32(g2)), ptr(_f32(b2)), ptr(z),
+                                     B, C, V, act, stream_ptr()), 'hno_cb_gn_apply')
+    return z
+
+
+def gn_bwd_raw(dz, y, mr, gamma, beta, act):
+    dz, y = _cl(dz), _cl(y)
+    B, C = y.shape[0], y.shape[4]
+    V = y.shape[1] * y.shape[2] * y.shape[3]
+    L = _lib.lib()
+    dy = torch.empty_like(y)
+    dg = torch.empty(C, device=y.device, dtype=torch.float32)
+    db = torch.empty(C, device=y.device, dtype=torch.float32)
+    ws = _ws(L.hno_cb_gn_bwd_workspace_bytes(B, C), y.device)
+    check(L.hno_cb_gn_bwd(ptr(dz), ptr(y), ptr(mr), ptr(_f32(gamma)), ptr(_f32(beta)), ptr(dy), ptr(dg), ptr(db), ptr(ws), B, C, V, act, 0,
+                          stream_ptr()), 'hno_cb_gn_bwd')
+    return dy, dg, db
+
+
+def pack_input_raw(x, CP=None):
+    """fp32 (B, C, D, H, W) -> bf16 (B, D, H, W, CP), pad channels zero"""
+    x = _f32(x)
+    _need_gpu(x)
+    B, C = x.shape[:2]
+    CP = CP or (C + 7) // 8 * 8
+    y = torch.empty((B,) + tuple(x.shape[2:]) + (CP,), device=x.device, dtype=BF16)
+    check(_lib.lib().hno_cb_pack_input(ptr(x), ptr(y), B, C, CP, x[0, 0].numel(), stream_ptr()), 'hno_cb_pack_input')
+    return y
+
+
+def unpack_raw(x, C=None):
+    """bf16 (B, D, H, W, CP) -> fp32 (B, C, D, H, W)"""
+    x = _cl(x)
+    B, CP = x.shape[0], x.shape[4]
+    C = C or CP
+    y = torch.empty((B, C) + tuple(x.shape[1:4]), device=x.device, dtype=torch.float32)
+    check(_lib.lib().hno_cb_unpack(ptr(x), ptr(y), B, C, CP, x.shape[1] * x.shape[2] * x.shape[3], stream_ptr()), 'hno_cb_unpack')
+    return y
+
+
+# ----------------------------------------------------------------------------------------------- autograd
+def _out_spatial(in_sp, ks, stride, transposed):
+    if transposed:
+        return tuple(2 * v for v in in_sp)                      # k 3, s 2, p 1, output_padding 1 (nets_utils.py:195-203)
+    if ks == 1:
+        return tuple(in_sp)
+    if ks == 2:
+        return tuple(v // 2 + 1 for v in in_sp)                 # k 2, s 2, p 1 (conv_in)
+    return tuple((v - 1) // stride + 1 for v in in_sp)          # k 3, p 1
+
+
+class ConvFn(_HnoFunction):
+    """Conv3d / ConvTranspose3d of ConvNormAct / ConvTransposeNormAct (nets/nets_utils.py:136-211) on channels-last bf16 with
+    the GroupNorm(1, C) statistics of the output produced in the same pass.
+
+        forward(xa, xb, W, bias, ks, stride, transposed, want_stats, eps) -> (y, mean_rstd)
+
+    xb: optional second input concatenated after xa along channels (the decoder's skip, architectures.py:236-240).
+    backward: input gradient = the same gather GEMM with the channel roles swapped; weight gradient = hno_cb_wgrad;
+    bias gradient = column sums."""
+
+    @staticmethod
+    def meta(xa, xb, W, bias, ks, stride, transposed, want_stats, eps):
+        Cout = W.shape[1] if transposed else W.shape[0]
+        osz = _out_spatial(tuple(xa.shape[1:4]), ks, stride, transposed)
+        return _m((xa.shape[0],) + osz + (Cout,), BF16), (_m((xa.shape[0], 2)) if want_stats else None)
+
+    @staticmethod
+    def forward(ctx, xa, xb, W, bias, ks, stride, transposed, want_stats, eps):
+        _need_gpu(xa, xb, W, bias)
+        Ca = xa.shape[4]
+        Cb = xb.shape[4] if xb is not None else 0
+        Cin = Ca + Cb
+        Cout = W.shape[1] if transposed else W.shape[0]
+        pad = 0 if ks == 1 else 1
+        osz = _out_spatial(tuple(xa.shape[1:4]), ks, stride, transposed)
+        wp = pack_weights(W, 2 if transposed else 0, Cin, Cout, ks)
+        y, mr = conv_raw(xa, xb, wp, bias, Cout, osz, 1 if transposed else 0, ks, stride, pad, want_stats, eps)
+        ctx.save_for_backward(xa, xb, W)
+        ctx.cfg = (ks, stride, bool(transposed), pad, bias is not None, Ca, Cb, Cout)
+        ctx.mark_non_differentiable(*([mr] if mr is not None else []))
+        return y, mr
+
+    @staticmethod
+    def backward(ctx, gy, _gmr):
+        xa, xb, W = ctx.saved_tensors
+        ks, stride, transposed, pad, has_bias, Ca, Cb, Cout = ctx.cfg
+        gy = gy.contiguous()
+        Cin = Ca + Cb
+        gxa = gxb = None
+        if ctx.needs_input_grad[0] or (xb is not None and ctx.needs_input_grad[1]):
+            wp = pack_weights(W, 3 if transposed else 1, Cin, Cout, ks)
+            gx, _ = conv_raw(gy, None, wp, None, Cin, tuple(xa.shape[1:4]), 0 if transposed else 1, ks, stride, pad, False)
+            if xb is None:
+                gxa = gx
+            else:   # split of the channel axis of a channels-last tensor (index op; only the decoder's two-input convs)
+                gxa, gxb = gx[..., :Ca].contiguous(), gx[..., Ca:].contiguous()
+        dW = wgrad_raw(gy, xa, xb, W.shape, transposed, ks, stride, pad)
+        db = colsum_raw(gy) if has_bias else None
+        return gxa, gxb, dW, db, None, None, None, None, None
+
+
+class GNActFn(_HnoFunction):
+    """z = act(GroupNorm(1, C)(y1)) [+ act(GroupNorm(1, C)(y2))] on channels-last bf16 with the statistics from ConvFn
+    (nets/nets_utils.py:127-133; the two-branch form is the residual sum of a V-Net section, architectures.py:205-224)."""
+
+    @staticmethod
+    def meta(y1, mr1, g1, b1, act, y2=None, mr2=None, g2=None, b2=None):
+        return _m(y1.shape, BF16)
+
+    @staticmethod
+    def forward(ctx, y1, mr1, g1, b1, act, y2=None, mr2=None, g2=None, b2=None):
+        _need_gpu(y1, y2)
+        z = gn_apply_raw(y1, mr1, g1, b1, act, y2, mr2, g2, b2)
+        ctx.save_for_backward(y1, mr1, g1, b1, y2, mr2, g2, b2)
+        ctx.act = act
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y1, mr1, g1, b1, y2, mr2, g2, b2 = ctx.saved_tensors
+        dz = dz.contiguous()
+        dy1, dg1, db1 = gn_bwd_raw(dz, y1, mr1, g1, b1, ctx.act)
+        dy2 = dg2 = db2 = None
+        if y2 is not None:
+            dy2, dg2, db2 = gn_bwd_raw(dz, y2, mr2, g2, b2, ctx.act)
+        return dy1, None, dg1, db1, None, dy2, None, dg2, db2
+
+
+class PackInputFn(_HnoFunction):
+    """fp32 NCDHW -> bf16 channels-last (the autocast cast of the first layer's input)."""
+
+    @staticmethod
+    def meta(x, CP):
+        return _m((x.shape[0],) + tuple(x.shape[2:]) + (CP,), BF16)
+
+    @staticmethod
+    def forward(ctx, x, CP):
+        ctx.C = x.shape[1]
+        return pack_input_raw(x, CP)
+
+    @staticmethod
+    def backward(ctx, g):
+        return unpack_raw(g.contiguous(), ctx.C), None
+
+
+class UnpackFn(_HnoFunction):
+    """bf16 channels-last -> fp32 NCDHW (where the bf16 region hands over to the fp32 head)."""
+
+    @staticmethod
+    def meta(x, C):
+        return _m((x.shape[0], C) + tuple(x.shape[1:4]))
+
+    @staticmethod
+    def forward(ctx, x, C):
+        ctx.CP = x.shape[4]
+        return unpack_raw(x, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        return pack_input_raw(g, ctx.CP), None
