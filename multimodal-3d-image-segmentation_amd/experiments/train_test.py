@@ -6,7 +6,7 @@ forward -> zero_grad -> backward -> step, the per-BATCH scheduler step, the mean
 the checkpoint cadence and the best-model selection rule.
 Changed on purpose: labels go to the loss kernels as uint8 class maps (no one-hot tensor), and the
 per-batch `loss.item()` host synchronisation (reference :162) is deferred to the end of the epoch.
-Out of scope: torchinfo/torchview summaries, matplotlib plots, autocast.
+Out of scope: torchview graph rendering, matplotlib plots.
 """
 import os
 import re
@@ -24,9 +24,15 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
              plot_epoch_portion=None, use_autocast=False, device=None, data_parallel=None):
     """Trains a model; see the reference docstring (train_test.py:48-71).  `data_parallel` is an optional
     parallel.FlatGradReplica for one-process-per-GPU training (not in the reference)."""
-    if use_autocast:
-        raise NotImplementedError('autocast is not provided by the fp32 HIP path')
+    import contextlib
     import torch.distributed as dist
+    # use_autocast (reference :79, :154-168): forward + loss under autocast, GradScaler around backward / step, its state in
+    # the checkpoint.  The matrix-core path here is bfloat16 (the reference leaves torch's per-device default dtype: float16
+    # on CUDA, bfloat16 on CPU); models switch to their bf16 kernels inside the context (ops_bf16.autocast_bf16()).
+    scaler = torch.amp.GradScaler(device='cuda') if use_autocast else None
+
+    def autocast():
+        return torch.autocast(device_type='cuda', dtype=torch.bfloat16) if use_autocast else contextlib.nullcontext()
     # one process per GPU (data_parallel given): rank 0 alone logs, writes the summary and saves; every rank resumes from the
     # same checkpoint; the validation loss is averaged over ranks so that all ranks select the same best epoch
     world = data_parallel.world if data_parallel is not None else 1
@@ -56,7 +62,7 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
     model.to(device)
     barrier()                       # the directory (and a checkpoint written by an earlier run) is visible to every rank
     if os.path.exists(chkpt_path):
-        start_epoch, min_loss, best_epoch = load_checkpoint(chkpt_path, model, optimizer, scheduler, None, device)
+        start_epoch, min_loss, best_epoch = load_checkpoint(chkpt_path, model, optimizer, scheduler, scaler, device)
         start_epoch += 1
         if start_epoch >= num_epochs:
             raise RuntimeError(f'Checkpoint detected, but start_epoch ({start_epoch}) >= num_epochs ({num_epochs})')
@@ -98,17 +104,25 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
         for x, y in train_flow:
             x, y = x.to(device), y.to(device)
             y = labels_to_u8(y, num_labels, label_mapping)
-            y_pred = model(x)
-            loss = loss_fn(y_pred, y)
+            with autocast():
+                y_pred = model(x)
+                loss = loss_fn(y_pred, y)
             losses.append(loss.detach())          # no host sync inside the step
             if data_parallel is not None:
                 data_parallel.zero_grad()
             else:
                 optimizer.zero_grad()
-            loss.backward()
-            if data_parallel is not None:
-                data_parallel.allreduce_grads()
-            optimizer.step()
+            if scaler is not None:
+                scaler.scale(loss).backward()
+                if data_parallel is not None:
+                    data_parallel.allreduce_grads()
+                scaler.step(optimizer)
+                scaler.update()
+            else:
+                loss.backward()
+                if data_parallel is not None:
+                    data_parallel.allreduce_grads()
+                optimizer.step()
             if scheduler is not None:
                 scheduler.step()
         train_loss = mean_loss(losses)
@@ -120,7 +134,8 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
             for x, y in valid_flow:
                 x, y = x.to(device), y.to(device)
                 y = labels_to_u8(y, num_labels, label_mapping)
-                losses.append(loss_fn(model(x), y).detach())
+                with autocast():
+                    losses.append(loss_fn(model(x), y).detach())
         valid_loss = mean_loss(losses)
         if world > 1:               # same number on every rank: they must agree on best_epoch / min_loss
             t = torch.tensor([valid_loss if losses else 0.0, 1.0 if losses else 0.0], dtype=torch.float64,
@@ -131,7 +146,7 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
 
         if (epoch + 1) % checkpoint_epoch == 0:
             if is_main:
-                save_checkpoint(chkpt_path, epoch, model, optimizer, scheduler, min_loss, best_epoch, None)
+                save_checkpoint(chkpt_path, epoch, model, optimizer, scheduler, min_loss, best_epoch, scaler)
             log('Standard checkpoint saved.')
         selection_epoch = int(num_epochs * selection_epoch_portion)
         if (epoch > selection_epoch or epoch == num_epochs - 1) and valid_loss < min_loss:
@@ -140,7 +155,7 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
                 torch.save(model.state_dict(), model_path)
             if (epoch + 1) % checkpoint_epoch != 0:  # avoid saving twice
                 if is_main:
-                    save_checkpoint(chkpt_path, epoch, model, optimizer, scheduler, min_loss, best_epoch, None)
+                    save_checkpoint(chkpt_path, epoch, model, optimizer, scheduler, min_loss, best_epoch, scaler)
                 log('Best checkpoint saved.')
     end_time = time.time()
 
@@ -166,8 +181,7 @@ def testing(model, input_data, output_dir, label_mapping=None, output_origin=Non
     `images/<index>_{true,pred}.npy`.  Returns (list of y_true or None, list of y_pred)."""
     from .. import ops
     from .utils import remap_labels
-    if use_autocast:
-        raise NotImplementedError('autocast is not provided by the fp32 HIP path')
+    import contextlib
     assert input_data.batch_size == 1
     os.makedirs(output_dir, exist_ok=True)
     images_dir = join(output_dir, 'images')
@@ -201,7 +215,7 @@ def testing(model, input_data, output_dir, label_mapping=None, output_origin=Non
         else:
             x = xy
         x = x.to(device)
-        with torch.no_grad(), ops.label_output():
+        with torch.no_grad(), ops.label_output(), (torch.autocast('cuda', dtype=torch.bfloat16) if use_autocast else contextlib.nullcontext()):
             yp = model(x)                                   # (1, 1, D, H, W) uint8 labels
         y_pred = np.asarray(yp.detach().to('cpu'))[0, 0]    # the .to('cpu') is the synchronisation point
         e_time = time.time()

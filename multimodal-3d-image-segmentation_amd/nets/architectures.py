@@ -316,6 +316,11 @@ class VNetDS(nn.Module):
             self.apply(init_weights_for_snn)
 
     def forward(self, x):
+        from .. import ops_bf16
+        if ops_bf16.autocast_bf16():
+            if x.ndim == 4:
+                raise NotImplementedError('the bf16 (autocast) path of V-Net-DS is 3-D only')
+            return self._forward_bf16(x)
         if x.ndim == 4:   # 2-D model (ndim = 4): the same kernels on a (B, C, 1, H, W) view (see nets/conv3d.py for the 3x3 layers)
             return self.forward(x.unsqueeze(2)).squeeze(2)
         image_size = tuple(x.shape[2:])
@@ -324,6 +329,77 @@ class VNetDS(nn.Module):
             x = self.conv_in(x)
         x = self.decode(self.encode(x))
         logits = ops.PwConvFn.apply(x, None, self.conv_out.weight, None, ops.ACT_NONE)   # commutes with the upsampling
+        y = ops.head_output(logits, image_size if self.use_resize else tuple(logits.shape[2:]), self._softmax, self._out_act)
+        return spatial_padcrop(y, image_size)
+
+    # ---- bf16 matrix-core path (torch.autocast(bfloat16); reference train_test.py:154-160) -------------------------------
+    def _forward_bf16(self, x):
+        """The same network on channels-last bf16 activations: every 3x3x3 / 2x2x2 / 1x1x1 convolution and transposed
+        convolution is a bf16 MFMA gather GEMM with fp32 accumulation (hno_cb_conv), GroupNorm statistics come out of the
+        convolution's epilogue, GroupNorm + ELU and the section's residual sum are one pass, the decoder's concat is fused
+        into the two-input convolutions.  The deep-supervision legs leave the bf16 body through their (C -> out_channels)
+        1x1x1 convolution; upsampling, the leg sum, conv_ds' GroupNorm, conv_out, trilinear + softmax and the loss stay fp32."""
+        from .. import ops_bf16 as ob
+        image_size = tuple(x.shape[2:])
+        nsec = len(self.num_blocks)
+        h = ob.PackInputFn.apply(x, (x.shape[1] + 7) // 8 * 8)
+        if self.use_resize:
+            h = ob.conv_norm_act(self.conv_in, h)
+        enc, legs = {}, {}
+
+        def section(layers, xa, xb, nconv):
+            it = iter(layers)
+            convs = [next(it) for _ in range(nconv)]
+            res = next(it) if self.use_residual else None
+            cur_a, cur_b = xa, xb
+            for k, layer in enumerate(convs):
+                last = k == nconv - 1
+                if last and res is not None:
+                    cur_a = ob.conv_norm_act(layer, cur_a, cur_b, residual=ob.conv_norm_act(res, xa, xb, residual='defer'))
+                else:
+                    cur_a = ob.conv_norm_act(layer, cur_a, cur_b)
+                cur_b = None
+            return cur_a, it
+        for i in range(nsec):
+            h, it = section(self.encode_layers[str(i)], h, None, self.num_blocks[i])
+            if i != nsec - 1:
+                enc[i] = h
+                h = ob.conv_norm_act(next(it), h)           # strided down-convolution
+            elif i in self.right_leg_indexes:
+                legs[i] = h
+        for i in reversed(range(nsec - 1)):
+            layers = self.decode_layers[str(i)]
+            up = ob.conv_norm_act(layers[0], h)             # transposed convolution (+ GroupNorm + act on its full output)
+            d, hh, w = enc[i].shape[1:4]
+            assert all(a >= b for a, b in zip(up.shape[1:4], (d, hh, w)))
+            lo = [(a - b) // 2 for a, b in zip(up.shape[1:4], (d, hh, w))]      # spatial_padcrop: the extra element goes high
+            if tuple(up.shape[1:4]) != (d, hh, w):
+                up = up[:, lo[0]:lo[0] + d, lo[1]:lo[1] + hh, lo[2]:lo[2] + w, :].contiguous()
+            h, _ = section(list(layers)[1:], up, enc[i], self.num_blocks[i])    # the concat is fused into the convolutions
+            if i in self.right_leg_indexes:
+                legs[i] = h
+        if len(legs) == 1:
+            feat = legs[0]
+            logits = ob.pointwise_to_f32(feat, self.conv_out.weight, None, self.out_channels)
+        else:
+            op = self.conv_ds.op
+            w = op.weight.reshape(op.weight.shape[0], -1)
+            ref_size = tuple(legs[0].shape[1:4])
+            acc, c0 = None, 0
+            for idx, (key, t) in enumerate(legs.items()):   # insertion order = concat order of the reference
+                c = t.shape[4]
+                part = ob.pointwise_to_f32(t, w[:, c0:c0 + c], op.bias if idx == 0 else None, w.shape[0])
+                if tuple(part.shape[2:]) != ref_size:
+                    part = ops.NearestUpFn.apply(part, ref_size)
+                acc = part if acc is None else ops.AddFn.apply(acc, part)
+                c0 += c
+            act = ops.act_id(self.conv_ds.activation)
+            if self.conv_ds.normalization is not None:
+                from .conv3d import group_norm_act
+                acc = group_norm_act(acc, self.conv_ds.normalization, act)
+            elif act != ops.ACT_NONE:
+                acc = ops.ActFn.apply(acc, act)
+            logits = ops.PwConvFn.apply(acc, None, self.conv_out.weight, None, ops.ACT_NONE)
         y = ops.head_output(logits, image_size if self.use_resize else tuple(logits.shape[2:]), self._softmax, self._out_act)
         return spatial_padcrop(y, image_size)
 

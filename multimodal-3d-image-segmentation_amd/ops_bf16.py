@@ -30,6 +30,17 @@ def _f32(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
 
 
+def autocast_bf16():
+    """True inside ``torch.autocast('cuda', dtype=torch.bfloat16)`` -- how the reference's ``use_autocast`` reaches the
+    model (train_test.py:154-160).  fp16 autocast (torch's CUDA default dtype) is refused: this path is bf16."""
+    if not torch.is_autocast_enabled('cuda'):
+        return False
+    dt = torch.get_autocast_dtype('cuda')
+    if dt != torch.bfloat16:
+        raise NotImplementedError(f'autocast dtype {dt} is not provided by the HIP path: use torch.autocast("cuda", dtype=torch.bfloat16)')
+    return True
+
+
 # ----------------------------------------------------------------------------------------------- raw launchers
 def pack_weights(W, role, Cin, Cout, ks):
     """fp32 parameter -> packed bf16 GEMM operand.  role 0 conv fwd, 1 conv dgrad, 2 ConvTranspose fwd, 3 ConvTranspose dgrad."""
@@ -250,3 +261,54 @@ class UnpackFn(_HnoFunction):
     @staticmethod
     def backward(ctx, g):
         return pack_input_raw(g, ctx.CP), None
+
+
+# ----------------------------------------------------------------------------------------------- layer helpers
+def conv_norm_act(layer, xa, xb=None, residual=None):
+    """ConvNormAct / ConvTransposeNormAct (nets/nets_utils.py:136-211) on channels-last bf16: conv (+ fused GroupNorm
+    statistics) then GroupNorm + activation.  `residual` = (y2, mr2, norm2): a second pre-normalisation branch whose activated
+    value is added (the V-Net section's residual sum).  -> activated tensor, or (y, mean_rstd) when `layer` is to be used as
+    the residual branch of another call (pass residual='defer')."""
+    op = layer.op
+    transposed = isinstance(op, torch.nn.ConvTranspose3d)
+    if op.weight.ndim != 5:
+        raise NotImplementedError('the bf16 path is 3-D only')
+    ks, stride = int(op.kernel_size[0]), int(op.stride[0])
+    norm = layer.normalization
+    act = ops.act_id(layer.activation)
+    W, b = op.weight, op.bias
+    Cin_w = W.shape[0] if transposed else W.shape[1]
+    Cin_x = xa.shape[4] + (xb.shape[4] if xb is not None else 0)
+    if Cin_w < Cin_x:          # first layer: image channels were padded to a multiple of 8 (zero channels, zero weights)
+        assert not transposed and xb is None
+        W = torch.nn.functional.pad(W, (0, 0, 0, 0, 0, 0, 0, Cin_x - Cin_w))
+    y, mr = ConvFn.apply(xa, xb, W, b, ks, stride, transposed, norm is not None, norm.eps if norm is not None else 1e-5)
+    if isinstance(residual, str):
+        return y, mr, norm
+    if norm is None:           # SNN configuration (SELU, no normalisation): identity statistics and affine
+        dev = y.device
+        mr = torch.tensor([[0.0, 1.0]] * y.shape[0], device=dev)
+        g, bt = torch.ones(y.shape[4], device=dev), torch.zeros(y.shape[4], device=dev)
+    else:
+        g, bt = norm.weight, norm.bias
+    if residual is None:
+        return GNActFn.apply(y, mr, g, bt, act)
+    y2, mr2, norm2 = residual
+    if norm2 is None:
+        dev = y.device
+        mr2 = torch.tensor([[0.0, 1.0]] * y.shape[0], device=dev)
+        g2, b2 = torch.ones(y.shape[4], device=dev), torch.zeros(y.shape[4], device=dev)
+    else:
+        g2, b2 = norm2.weight, norm2.bias
+    return GNActFn.apply(y, mr, g, bt, act, y2, mr2, g2, b2)
+
+
+def pointwise_to_f32(x, weight, bias, out_channels):
+    """1x1x1 conv of a channels-last bf16 tensor to a few (< 8) output channels, returned as fp32 NCDHW: where the bf16
+    body hands over to the fp32 head (deep-supervision legs, conv_out).  The output channels are padded to 8 for the GEMM."""
+    w2 = weight.reshape(weight.shape[0], -1)
+    pad_o = (-w2.shape[0]) % 8
+    W = torch.nn.functional.pad(w2, (0, 0, 0, pad_o)).reshape(w2.shape[0] + pad_o, w2.shape[1], 1, 1, 1)
+    b = torch.nn.functional.pad(bias, (0, pad_o)) if bias is not None else None
+    y, _ = ConvFn.apply(x, None, W, b, 1, 1, False, False, 1e-5)
+    return UnpackFn.apply(y, out_channels)

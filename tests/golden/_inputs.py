@@ -198,6 +198,19 @@ VNET_MODELS = {
 }
 
 
+# ---- bf16 autocast goldens (G7b): (class name, ctor kwargs, input shape); channel counts are multiples of 8 (the bf16 path's unit)
+BF16_MODELS = {
+    'vnet_ds_bf16': ('VNetDS', dict(in_channels=2, out_channels=3, base_num_filters=8, num_blocks=[1, 2, 1],
+                                    right_leg_indexes=[0, 1, 2]), (1, 2, 20, 24, 28)),
+    'vnet_oneleg_bf16': ('VNetDS', dict(in_channels=4, out_channels=2, base_num_filters=8, num_blocks=[1, 1],
+                                        right_leg_indexes=None), (2, 4, 18, 22, 14)),
+    'fnoseg_bf16': ('NeuralOperatorSeg', dict(in_channels=2, out_channels=3, filters=8, num_transform_blocks=3, num_modes=(4, 5, 5),
+                                             transform_type='Fourier'), (1, 2, 24, 20, 28)),
+    'hnoseg_bf16': ('NeuralOperatorSeg', dict(in_channels=2, out_channels=3, filters=8, num_transform_blocks=3, num_modes=(4, 5, 5),
+                                             transform_type='Hartley'), (1, 2, 24, 20, 28)),
+}
+
+
 # ---- input pipeline (G11)
 AUG_CASES = {
     'aug3d': (dict(rotation_range=[30, 10, 5], shift_range=[0.2, 0.1, 0.3], zoom_range=[0.8, 1.2], flip=[True, False, True],

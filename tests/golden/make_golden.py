@@ -539,6 +539,40 @@ def g7v_vnet_models():
     save('g7v_vnet_models.npz', **out)
 
 
+# ------------------------- G7b: the reference under torch.autocast(bfloat16) (train_test.py:154-160), beside its fp32 run
+def g7b_bf16_models():
+    """What `use_autocast` does to each model family on the reference itself (CPU autocast, bfloat16: convolutions take bf16
+    operands and return bf16, GroupNorm / FFT / complex einsum stay fp32): outputs, loss and all gradients, stored next to
+    the fp32 run of the same model so that the tests can state their tolerance as a multiple of the reference's own bf16-vs-fp32
+    distance."""
+    from _inputs import BF16_MODELS, formula_volume
+    out = {}
+    for name, (cls, kw, shape) in BF16_MODELS.items():
+        torch.manual_seed(43)
+        model = getattr(nets, cls)(**kw)
+        for k, v in model.state_dict().items():
+            out[f'{name}::sd::{k}'] = v.detach().numpy().copy()
+        K = kw['out_channels']
+        x = T(formula_volume(shape, 6))
+        lab = formula_labels((shape[0], 1) + shape[2:], K, 8)
+        onehot = torch.movedim(torch.nn.functional.one_hot(T(lab)[:, 0].long(), K).float(), -1, 1)
+        for tag in ('f32', 'bf16'):
+            model.zero_grad()
+            if tag == 'bf16':
+                with torch.autocast(device_type='cpu', dtype=torch.bfloat16):
+                    y = model(x)
+                    loss = custom_losses.PCCLoss()(y, onehot)
+            else:
+                y = model(x)
+                loss = custom_losses.PCCLoss()(y, onehot)
+            loss.backward()
+            out[f'{name}::{tag}::y'] = y.detach().float().numpy()
+            out[f'{name}::{tag}::loss'] = loss.detach().float().numpy()
+            for k, p in model.named_parameters():
+                out[f'{name}::{tag}::grad::{k}'] = p.grad.detach().float().numpy().copy()
+    save('g7b_bf16_models.npz', **out)
+
+
 # ----------------------------------------------- G8: training-loop trajectory of the reference
 def _stub_missing_modules():
     sys.modules.setdefault('SimpleITK', type(sys)('SimpleITK'))
@@ -588,7 +622,7 @@ def g8_training():
 
 if __name__ == '__main__':
     ALL = [g1_dht, g2_crop_pad, g3_operators, g4_mha, g5_losses, g6_hnosegxs, g6_128, g6s_small_models, g6b_xsblock_branch, g7_noseg_models,
-           g7v_vnet_models, g9_misc, g10_two_d, g11_input, g12_mha_bias, g13_models_2d, g8_training]
+           g7v_vnet_models, g7b_bf16_models, g9_misc, g10_two_d, g11_input, g12_mha_bias, g13_models_2d, g8_training]
     only = set(sys.argv[2:])   # e.g. `make_golden.py /root/reference g10_two_d` regenerates one fixture
     for fn in ALL:
         if not only or fn.__name__ in only:
