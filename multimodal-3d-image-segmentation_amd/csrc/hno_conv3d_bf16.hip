@@ -342,53 +342,55 @@ __global__ __launch_bounds__(256) void cb_gn_bwd_reduce_kernel(const bf16_t *__r
                                                               const float *__restrict__ mr, const float *__restrict__ gamma,
                                                               const float *__restrict__ beta, float *__restrict__ slab, int C, long long V,
                                                               int act) {
-    extern __shared__ float lds[];    // [2][C]
+    extern __shared__ float lds[];    // [256][16]
     const int b = blockIdx.y, nblk = gridDim.x;
     const float mean = mr[2 * b], rstd = mr[2 * b + 1];
     const int C8 = C >> 3;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) lds[i] = 0.f;
-    __syncthreads();
     const long long per_blk = (V + nblk - 1) / nblk;
     const long long vlo = (long long)blockIdx.x * per_blk, vhi = vlo + per_blk < V ? vlo + per_blk : V;
     const long long items = (vhi > vlo ? vhi - vlo : 0) * C8;
-    // a thread keeps ONE channel group when 256 % C8 == 0 (C = 8, 16, 32, 64 ...); otherwise (24, 48, 96 ...) the group
-    // changes per iteration and the sums go to LDS atomically per item -- use the general form for all
+    // threads 0 .. S-1 with S = the largest multiple of C8 <= 256 stride the items by S, so a thread keeps ONE channel
+    // group (it % C8 is constant) and its 16 sums stay in registers until the end
+    const int S = 256 - 256 % C8;
     float s1[8], s2[8];
-    int cur = -1;
 #pragma unroll
     for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
-    auto flush = [&]() {
-        if (cur >= 0)
+    const int cg = (int)(threadIdx.x % C8);
+    float gm[8], bt[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                atomicAdd(&lds[cur * 8 + j], s1[j]);
-                atomicAdd(&lds[C + cur * 8 + j], s2[j]);
-                s1[j] = s2[j] = 0.f;
-            }
-    };
-    for (long long it = threadIdx.x; it < items; it += 256) {
-        const int cg = (int)(it % C8);
-        if (cg != cur) { flush(); cur = cg; }
-        const size_t e = ((size_t)b * V + vlo) * C + (size_t)it * 8;
-        const uint4 gv = *reinterpret_cast<const uint4 *>(dz + e), yv = *reinterpret_cast<const uint4 *>(y + e);
-        const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
+    for (int j = 0; j < 8; ++j) { gm[j] = gamma[cg * 8 + j]; bt[j] = beta[cg * 8 + j]; }
+    if ((int)threadIdx.x < S)
+        for (long long it = threadIdx.x; it < items; it += S) {
+            const size_t e = ((size_t)b * V + vlo) * C + (size_t)it * 8;
+            const uint4 gv = *reinterpret_cast<const uint4 *>(dz + e), yv = *reinterpret_cast<const uint4 *>(y + e);
+            const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int j = 2 * k + u, c = cg * 8 + j;
-                const float g = bf2f((bf16_t)(u ? gw[k] >> 16 : gw[k] & 0xffff));
-                const float xh = (bf2f((bf16_t)(u ? yw[k] >> 16 : yw[k] & 0xffff)) - mean) * rstd;
-                const float out = act_apply(fmaf(xh, gamma[c], beta[c]), act);
-                const float t = g * act_grad_from_out(out, act);
-                s1[j] += t;
-                s2[j] = fmaf(t, xh, s2[j]);
-            }
+                for (int u = 0; u < 2; ++u) {
+                    const int j = 2 * k + u;
+                    const float g = bf2f((bf16_t)(u ? gw[k] >> 16 : gw[k] & 0xffff));
+                    const float xh = (bf2f((bf16_t)(u ? yw[k] >> 16 : yw[k] & 0xffff)) - mean) * rstd;
+                    const float out = act_apply(fmaf(xh, gm[j], bt[j]), act);
+                    const float t = g * act_grad_from_out(out, act);
+                    s1[j] += t;
+                    s2[j] = fmaf(t, xh, s2[j]);
+                }
+        }
+    // per-thread sums -> LDS [thread][16]; then channel c = 8 cg + j sums its S / C8 contributing threads in a fixed order
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        lds[threadIdx.x * 16 + j] = s1[j];
+        lds[threadIdx.x * 16 + 8 + j] = s2[j];
     }
-    flush();
     __syncthreads();
     float *dst = slab + ((size_t)b * nblk + blockIdx.x) * 2 * C;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) dst[i] = lds[i];
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int which = i / C, c = i - which * C, g8 = c >> 3, j = c & 7;
+        float acc = 0.f;
+        for (int t = g8; t < S; t += C8) acc += lds[t * 16 + which * 8 + j];
+        dst[i] = acc;
+    }
 }
 
 // pass 1b: slabs -> dgamma[c], dbeta[c] (summed over samples and blocks, fp64, fixed order) and per sample
@@ -513,39 +515,35 @@ __global__ __launch_bounds__(256) void cb_unpack_kernel(const bf16_t *__restrict
 
 // per-channel sum over samples and voxels of a channels-last bf16 tensor (bias gradients): slab per block + ordered reduce
 __global__ __launch_bounds__(256) void cb_colsum_kernel(const bf16_t *__restrict__ g, float *__restrict__ slab, int C, long long rows) {
-    extern __shared__ float lds[];   // [C]
-    for (int i = threadIdx.x; i < C; i += 256) lds[i] = 0.f;
-    __syncthreads();
+    extern __shared__ float lds[];   // [256][8]
     const int C8 = C >> 3;
     const long long per_blk = (rows + gridDim.x - 1) / gridDim.x;
     const long long lo = (long long)blockIdx.x * per_blk, hi = lo + per_blk < rows ? lo + per_blk : rows;
     const long long items = (hi > lo ? hi - lo : 0) * C8;
+    const int S = 256 - 256 % C8;       // see cb_gn_bwd_reduce_kernel
     float s[8];
-    int cur = -1;
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = 0.f;
-    auto flush = [&]() {
-        if (cur >= 0)
+    const int cg = (int)(threadIdx.x % C8);
+    if ((int)threadIdx.x < S) {
+        for (long long it = threadIdx.x; it < items; it += S) {
+            const uint4 gv = *reinterpret_cast<const uint4 *>(g + (size_t)lo * C + (size_t)it * 8);
+            const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                atomicAdd(&lds[cur * 8 + j], s[j]);
-                s[j] = 0.f;
+            for (int k = 0; k < 4; ++k) {
+                s[2 * k] += bf2f((bf16_t)(gw[k] & 0xffff));
+                s[2 * k + 1] += bf2f((bf16_t)(gw[k] >> 16));
             }
-    };
-    for (long long it = threadIdx.x; it < items; it += 256) {
-        const int cg = (int)(it % C8);
-        if (cg != cur) { flush(); cur = cg; }
-        const uint4 gv = *reinterpret_cast<const uint4 *>(g + (size_t)lo * C + (size_t)it * 8);
-        const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            s[2 * k] += bf2f((bf16_t)(gw[k] & 0xffff));
-            s[2 * k + 1] += bf2f((bf16_t)(gw[k] >> 16));
         }
     }
-    flush();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lds[threadIdx.x * 8 + j] = s[j];
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 256) slab[(size_t)blockIdx.x * C + i] = lds[i];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = 0.f;
+        for (int t = c >> 3; t < S; t += C8) acc += lds[t * 8 + (c & 7)];
+        slab[(size_t)blockIdx.x * C + c] = acc;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -566,7 +564,9 @@ struct CwArgs {
     int B, Di, Hi, Wi, Do, Ho, Wo;
     int ks, stride, pad, ntaps;
     int TH, Sg, Sx, xrows, xplanes;   // band height; pitches; staged X rows per plane = stride * (TH - 1) + ks, planes = ks
-    int co0, ci0, CO, CI;        // channel block (multiples of 8; CO, CI <= 48)
+    int xpos;                         // positions of the X image incl. slack (every one of them is written by the staging pass)
+    int co0, ci0, CO, CI;        // channel block (multiples of 8; CO, CI <= 48); with gridDim.y > 1: block y = (y / nci) , (y % nci)
+    int nci;                     // ci blocks per co block when the channel blocks ride on gridDim.y (all of size CO x CI)
     int nbands;                  // bands per (b, od) = ceil(Ho / TH)
     int swap;                    // 1: transposed-conv weight gradient (roles of g and x swapped by the host; informational)
 };
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void cb_wgrad_kernel(CwArgs a) {
     const int PG = TA * 16, PX = TB * 16;                 // channel pitch (elements) of the G / X images; pad channels zero
     const int gpos = a.TH * a.Sg;                          // G image positions (rounded up to 32 below)
     const int gpos32 = (gpos + 31) & ~31;
-    const int xpos = a.xplanes * a.xrows * a.Sx + 2 * a.Sx + 64;   // X image positions incl. slack on both ends
+    const int xpos = a.xpos;                               // X image positions incl. slack on both ends (host: wg_plan)
     bf16_t *gi = reinterpret_cast<bf16_t *>(smem);                         // [gpos32][PG]
     bf16_t *xi = gi + (size_t)gpos32 * PG;                                 // [xpos][PX], position 0 = slack
     const int xorg = a.Sx + 32;                                            // image position of (plane 0, row 0, col -pad.. see below)
@@ -597,8 +597,8 @@ __global__ __launch_bounds__(256) void cb_wgrad_kernel(CwArgs a) {
 #pragma unroll
             for (int j = 0; j < TB; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int Cx = a.Ca + a.Cb;
-    (void)Cx;
+    const int co0 = a.co0 + (gridDim.y > 1 ? (int)(blockIdx.y / a.nci) * a.CO : 0);
+    const int ci0 = a.ci0 + (gridDim.y > 1 ? (int)(blockIdx.y % a.nci) * a.CI : 0);
     const long long nwork = (long long)a.B * a.Do * a.nbands;
     const int grp = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
     for (long long wk = blockIdx.x; wk < nwork; wk += gridDim.x) {
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) void cb_wgrad_kernel(CwArgs a) {
                 const int oh = oh0 + hh, ch = c8 * 8;
                 if (p < gpos && oh < a.Ho && ww < a.Wo && ch < a.CO) {
                     const size_t vo = ((size_t)od * a.Ho + oh) * a.Wo + ww;
-                    v = *reinterpret_cast<const uint4 *>(a.g + ((size_t)b * a.Do * a.Ho * a.Wo + vo) * a.Cg + a.co0 + ch);
+                    v = *reinterpret_cast<const uint4 *>(a.g + ((size_t)b * a.Do * a.Ho * a.Wo + vo) * a.Cg + co0 + ch);
                 }
                 *reinterpret_cast<uint4 *>(gi + (size_t)p * PG + ch) = v;
             }
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void cb_wgrad_kernel(CwArgs a) {
                 const int c8 = it % c8n, pp = it / c8n;
                 uint4 v = make_uint4(0, 0, 0, 0);
                 const int p = pp - xorg;
-                const int ch = a.ci0 + c8 * 8;
+                const int ch = ci0 + c8 * 8;
                 if (p >= 0 && c8 * 8 < a.CI) {
                     const int pl = p / (a.xrows * a.Sx), rem = p - pl * (a.xrows * a.Sx);
                     const int rr = rem / a.Sx, cc = rem - rr * a.Sx;
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void cb_wgrad_kernel(CwArgs a) {
         }
     }
     // ---- slab: [tap][CO][CI] for this block.  C/D of 16x16x32: column (lane & 15) = input channel, rows 4 (lane >> 4) + e = output channel
-    float *dst = a.slab + (size_t)blockIdx.x * a.ntaps * a.CO * a.CI;
+    float *dst = a.slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * a.ntaps * a.CO * a.CI;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int tap = wave + 4 * t;
@@ -711,8 +711,13 @@ __global__ __launch_bounds__(256) void cb_wgrad_kernel(CwArgs a) {
 // slabs [nblk][ntaps][CO][CI] -> dW fp32 in the parameter's own layout: element (o, i, tap) of the GEMM goes to
 // dW[(c0 * C1 + c1) * T + tap] with (c0, c1) = (o, i) or (i, o).  fp64-free ordered sum (fp32, fixed order).
 __global__ __launch_bounds__(256) void cb_wgrad_reduce_kernel(const float *__restrict__ slab, int nblk, int ntaps, int CO, int CI, int co0, int ci0,
-                                                             float *__restrict__ dW, int C1, int T, int out_is_axis0) {
+                                                             float *__restrict__ dW, int C1, int T, int out_is_axis0, int nci) {
     const int n = ntaps * CO * CI;
+    slab += (size_t)blockIdx.y * nblk * n;
+    if (gridDim.y > 1) {
+        co0 += (int)(blockIdx.y / nci) * CO;
+        ci0 += (int)(blockIdx.y % nci) * CI;
+    }
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
         float s = 0.f;
         for (int k = 0; k < nblk; ++k) s += slab[(size_t)k * n + idx];
@@ -870,7 +875,7 @@ extern "C" int hno_cb_gn_bwd(const void *dz, const void *y, const float *mr, con
                              float *dgamma, float *dbeta, void *workspace, int B, int C, long long V, int act, int accumulate,
                              void *stream) {
     HNO_REQUIRE(dz && y && mr && gamma && beta && dy && dgamma && dbeta && workspace && B > 0 && C > 0 && V > 0, "hno_cb_gn_bwd: bad argument");
-    if (C % 8 || C > 4096) return fail(HNO_ELIMIT, "hno_cb_gn_bwd: C = %d must be a multiple of 8 (<= 4096)", C);
+    if (C % 8 || C > 2048) return fail(HNO_ELIMIT, "hno_cb_gn_bwd: C = %d must be a multiple of 8 (<= 2048)", C);
     if (B > 8) return fail(HNO_ELIMIT, "hno_cb_gn_bwd: batch %d > 8 per call", B);
     hipStream_t s = (hipStream_t)stream;
     float *slab = (float *)workspace;
@@ -879,7 +884,7 @@ extern "C" int hno_cb_gn_bwd(const void *dz, const void *y, const float *mr, con
     if (V < nblk) nblk = (int)V;
     {
         ProfScope _ps(KID_CB_GN, s, (double)B * V * C * 4.0);
-        hipLaunchKernelGGL(cb_gn_bwd_reduce_kernel, dim3(nblk, B), dim3(256), 2 * C * sizeof(float), s, (const bf16_t *)dz, (const bf16_t *)y, mr, gamma,
+        hipLaunchKernelGGL(cb_gn_bwd_reduce_kernel, dim3(nblk, B), dim3(256), 256 * 16 * sizeof(float), s, (const bf16_t *)dz, (const bf16_t *)y, mr, gamma,
                            beta, slab, C, V, act);
         HNO_CHECK_LAUNCH();
     }
@@ -917,7 +922,7 @@ extern "C" int hno_cb_colsum(const void *g, float *out, void *workspace, int C, 
     hipStream_t s = (hipStream_t)stream;
     int nblk = CB_COLSUM_BLOCKS;
     if (rows < nblk) nblk = (int)rows;
-    hipLaunchKernelGGL(cb_colsum_kernel, dim3(nblk), dim3(256), C * sizeof(float), s, (const bf16_t *)g, (float *)workspace, C, rows);
+    hipLaunchKernelGGL(cb_colsum_kernel, dim3(nblk), dim3(256), 256 * 8 * sizeof(float), s, (const bf16_t *)g, (float *)workspace, C, rows);
     HNO_CHECK_LAUNCH();
     hipLaunchKernelGGL(cb_colsum_reduce_kernel, dim3(gsz(C)), dim3(256), 0, s, (const float *)workspace, nblk, C, out);
     HNO_CHECK_LAUNCH();
@@ -931,7 +936,10 @@ struct WgPlan {
     size_t lds;
 };
 // band height: as many output rows as fit in LDS (G band + X halo at the block's channel pitches), at least 1
-WgPlan wg_plan(int B, int Do, int Ho, int Wo, int ks, int stride, int pad, int PG, int PX) {
+WgPlan wg_plan(int B, int Do, int Ho, int Wo, int ks, int stride, int pad, int PG, int PX, int ny) {
+    // two workgroups per CU (one stages while the other computes) when there is enough work: cap the LDS at half
+    // (measured: the one-channel-block layers of the two shallow levels are faster with one big band per CU, 228 vs 390 us)
+    const size_t cap = (ny == 1 || (debug_flags() & 128)) ? 150 * 1024 : 76 * 1024;
     WgPlan p = {};
     // one pitch for both images: output position p = hh * S + ww reads X-image element base(tap) + stride * p, which is
     // (row stride * hh + th, column stride * ww + tw) when the X rows have the SAME pitch S >= stride * (Wo - 1) + ks
@@ -943,7 +951,7 @@ WgPlan wg_plan(int B, int Do, int Ho, int Wo, int ks, int stride, int pad, int P
         const int gpos32 = (th * p.Sg + 31) & ~31;
         const int xpos = ks * xrows * p.Sx + 2 * p.Sx + 64 + stride * 32;
         const size_t bytes = ((size_t)gpos32 * PG + (size_t)xpos * PX) * 2;
-        if (bytes <= 150 * 1024) best = th; else break;
+        if (bytes <= cap || th == 1) best = th; else break;
     }
     p.TH = best;
     p.xrows = stride * (best - 1) + ks;
@@ -951,32 +959,39 @@ WgPlan wg_plan(int B, int Do, int Ho, int Wo, int ks, int stride, int pad, int P
     p.xpos = ks * p.xrows * p.Sx + 2 * p.Sx + 64 + stride * 32;
     p.lds = ((size_t)p.gpos32 * PG + (size_t)p.xpos * PX) * 2;
     const long long nwork = (long long)B * Do * ((Ho + best - 1) / best);
-    p.nblk = (int)(nwork < 256 ? nwork : 256);
+    long long want = 512 / (ny > 0 ? ny : 1);          // ~2 workgroups per CU over all channel blocks
+    if (want < 8) want = 8;
+    p.nblk = (int)(nwork < want ? nwork : want);
     return p;
 }
 }  // namespace
 
 extern "C" size_t hno_cb_wgrad_workspace_bytes(int Cin, int Cout, int ks) {
-    // one slab set per (co block, ci block), processed one after the other: the workspace holds ONE set
+    // slabs [channel block][workgroup][tap][<= 48][<= 48]: at most 512 workgroups over all channel blocks (>= 8 per block)
     const int CO = Cout < 48 ? Cout : 48, CI = Cin < 48 ? Cin : 48;
-    return (size_t)256 * ks * ks * ks * CO * CI * sizeof(float);
+    const int ny = ((Cout + CO - 1) / CO) * ((Cin + CI - 1) / CI);
+    long long per = 512 / ny;
+    if (per < 8) per = 8;
+    return (size_t)per * ny * ks * ks * ks * CO * CI * sizeof(float);
 }
 
-template <int TA, int TB>
-static int wg_launch(const CwArgs &a, int nblk, size_t lds, hipStream_t s) {
-    const int tpw = (a.ntaps + 3) / 4;
-    if (tpw <= 1) {
-        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)cb_wgrad_kernel<TA, TB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL((cb_wgrad_kernel<TA, TB, 1>), dim3(nblk), dim3(256), lds, s, a);
-    } else if (tpw <= 2) {
-        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)cb_wgrad_kernel<TA, TB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL((cb_wgrad_kernel<TA, TB, 2>), dim3(nblk), dim3(256), lds, s, a);
-    } else {
-        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)cb_wgrad_kernel<TA, TB, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL((cb_wgrad_kernel<TA, TB, 7>), dim3(nblk), dim3(256), lds, s, a);
+template <int TA, int TB, int TPW>
+static int wg_launch1(const CwArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+    static bool attr_set = false;       // once per instantiation (not a stream operation; kept out of graph captures after warm-up)
+    if (!attr_set) {
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)cb_wgrad_kernel<TA, TB, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
     }
+    hipLaunchKernelGGL((cb_wgrad_kernel<TA, TB, TPW>), grid, dim3(256), lds, s, a);
     HNO_CHECK_LAUNCH();
     return HNO_OK;
+}
+template <int TA, int TB>
+static int wg_launch(const CwArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+    const int tpw = (a.ntaps + 3) / 4;
+    if (tpw <= 1) return wg_launch1<TA, TB, 1>(a, grid, lds, s);
+    if (tpw <= 2) return wg_launch1<TA, TB, 2>(a, grid, lds, s);
+    return wg_launch1<TA, TB, 7>(a, grid, lds, s);
 }
 
 // dW (fp32, the parameter's layout) of a convolution (transposed = 0: W[Cout][Cin][T]; g on the OUTPUT grid (Dg..), x = [xa | xb]
@@ -1007,34 +1022,41 @@ extern "C" int hno_cb_wgrad(const void *g, int Cg, const void *xa, int Ca, const
     const int T = a.ntaps;
     // parameter layout: conv W[Cout = P][Cin = Q][T]: out_is_axis0 = 1 with (o, i) = (P, Q); transposed Wt[Cin = P][Cout = Q][T] likewise
     const int C1 = CQ;
-    for (int co0 = 0; co0 < CP; co0 += 48)
-        for (int ci0 = 0; ci0 < CQ; ci0 += 48) {
-            a.co0 = co0; a.ci0 = ci0;
-            a.CO = CP - co0 < 48 ? CP - co0 : 48;
-            a.CI = CQ - ci0 < 48 ? CQ - ci0 : 48;
-            // (a block may straddle the two concatenated inputs: the staging picks the tensor per 8-channel chunk)
-            const int TA = (a.CO + 15) / 16, TB = (a.CI + 15) / 16;
-            const WgPlan p = wg_plan(B, a.Do, a.Ho, a.Wo, ks, stride, pad, TA * 16, TB * 16);
-            a.TH = p.TH; a.Sg = p.Sg; a.Sx = p.Sx; a.xrows = p.xrows; a.xplanes = ks;
-            a.nbands = (a.Ho + p.TH - 1) / p.TH;
-            a.slab = (float *)workspace;
-            int rc;
-            {
-                ProfScope _ps(KID_CB_WGRAD, s, 2.0 * B * (double)a.Do * a.Ho * a.Wo * T * a.CO * a.CI);
-                if (TA == 1 && TB == 1) rc = wg_launch<1, 1>(a, p.nblk, p.lds, s);
-                else if (TA == 1 && TB == 2) rc = wg_launch<1, 2>(a, p.nblk, p.lds, s);
-                else if (TA == 1 && TB == 3) rc = wg_launch<1, 3>(a, p.nblk, p.lds, s);
-                else if (TA == 2 && TB == 1) rc = wg_launch<2, 1>(a, p.nblk, p.lds, s);
-                else if (TA == 2 && TB == 2) rc = wg_launch<2, 2>(a, p.nblk, p.lds, s);
-                else if (TA == 2 && TB == 3) rc = wg_launch<2, 3>(a, p.nblk, p.lds, s);
-                else if (TA == 3 && TB == 1) rc = wg_launch<3, 1>(a, p.nblk, p.lds, s);
-                else if (TA == 3 && TB == 2) rc = wg_launch<3, 2>(a, p.nblk, p.lds, s);
-                else rc = wg_launch<3, 3>(a, p.nblk, p.lds, s);
-            }
-            if (rc != HNO_OK) return rc;
-            hipLaunchKernelGGL(cb_wgrad_reduce_kernel, dim3(gsz((long long)T * a.CO * a.CI, 256, 256)), dim3(256), 0, s, (const float *)a.slab, p.nblk, T,
-                               a.CO, a.CI, co0, ci0, dW, C1, T, 1);
-            HNO_CHECK_LAUNCH();
+    // channel blocks of <= 48 x 48.  When every block has the same size (channel counts <= 48 or multiples of 48: all V-Net
+    // layers) they ride on gridDim.y of ONE launch; otherwise one launch per block.
+    const int CO = CP < 48 ? CP : 48, CI = CQ < 48 ? CQ : 48;
+    const bool uniform = CP % CO == 0 && CQ % CI == 0;
+    const int nco = (CP + CO - 1) / CO, nci = (CQ + CI - 1) / CI;
+    for (int bi = 0; bi < (uniform ? 1 : nco * nci); ++bi) {
+        a.co0 = uniform ? 0 : (bi / nci) * CO;
+        a.ci0 = uniform ? 0 : (bi % nci) * CI;
+        a.CO = uniform ? CO : (CP - a.co0 < CO ? CP - a.co0 : CO);
+        a.CI = uniform ? CI : (CQ - a.ci0 < CI ? CQ - a.ci0 : CI);
+        a.nci = nci;
+        const int ny = uniform ? nco * nci : 1;
+        const int TA = (a.CO + 15) / 16, TB = (a.CI + 15) / 16;
+        const WgPlan p = wg_plan(B, a.Do, a.Ho, a.Wo, ks, stride, pad, TA * 16, TB * 16, ny);
+        a.TH = p.TH; a.Sg = p.Sg; a.Sx = p.Sx; a.xrows = p.xrows; a.xplanes = ks; a.xpos = p.xpos;
+        a.nbands = (a.Ho + p.TH - 1) / p.TH;
+        a.slab = (float *)workspace;
+        int rc;
+        {
+            ProfScope _ps(KID_CB_WGRAD, s, 2.0 * B * (double)a.Do * a.Ho * a.Wo * T * a.CO * a.CI * ny);
+            const dim3 grid(p.nblk, ny);
+            if (TA == 1 && TB == 1) rc = wg_launch<1, 1>(a, grid, p.lds, s);
+            else if (TA == 1 && TB == 2) rc = wg_launch<1, 2>(a, grid, p.lds, s);
+            else if (TA == 1 && TB == 3) rc = wg_launch<1, 3>(a, grid, p.lds, s);
+            else if (TA == 2 && TB == 1) rc = wg_launch<2, 1>(a, grid, p.lds, s);
+            else if (TA == 2 && TB == 2) rc = wg_launch<2, 2>(a, grid, p.lds, s);
+            else if (TA == 2 && TB == 3) rc = wg_launch<2, 3>(a, grid, p.lds, s);
+            else if (TA == 3 && TB == 1) rc = wg_launch<3, 1>(a, grid, p.lds, s);
+            else if (TA == 3 && TB == 2) rc = wg_launch<3, 2>(a, grid, p.lds, s);
+            else rc = wg_launch<3, 3>(a, grid, p.lds, s);
         }
+        if (rc != HNO_OK) return rc;
+        hipLaunchKernelGGL(cb_wgrad_reduce_kernel, dim3(gsz((long long)T * a.CO * a.CI, 256, 64), ny), dim3(256), 0, s, (const float *)a.slab, p.nblk, T,
+                           a.CO, a.CI, a.co0, a.ci0, dW, C1, T, 1, nci);
+        HNO_CHECK_LAUNCH();
+    }
     return HNO_OK;
 }

@@ -16,9 +16,13 @@ CASES = {
     'hartleymha': (lambda: nets.HartleyMHASeg(4, 4, 12, 16, 4, (10, 14, 14), (2, 2, 2)), (1, 4, 128, 128, 128)),
     'vnetds_cfg4': (lambda: nets.VNetDS(4, 4, 24, [1, 2, 3, 3, 3], right_leg_indexes=[0, 1, 2, 3, 4]), (1, 4, 160, 192, 128)),
 }
+# a case name suffixed with ':bf16' runs the step under torch.autocast('cuda', dtype=torch.bfloat16) (the bf16 matrix-core path)
 which = sys.argv[1:] or list(CASES)
+import contextlib
 for name in which:
-    ctor, shape = CASES[name]
+    bf16 = name.endswith(':bf16')
+    ctor, shape = CASES[name.split(':')[0]]
+    ac = (lambda: torch.autocast('cuda', dtype=torch.bfloat16)) if bf16 else contextlib.nullcontext
     torch.manual_seed(0)
     model = ctor().cuda()
     x = torch.randn(shape, device='cuda')
@@ -26,7 +30,9 @@ for name in which:
     loss_fn = custom_losses.PCCLoss()
     def step():
         for p in model.parameters(): p.grad = None
-        loss = loss_fn(model(x), lab); loss.backward(); return loss
+        with ac():
+            loss = loss_fn(model(x), lab)
+        loss.backward(); return loss
     try:
         step(); step()
         torch.cuda.synchronize(); t0 = time.time(); n = 5
@@ -35,11 +41,12 @@ for name in which:
         with pkg._lib.KernelProfile() as kp:
             step()
         torch.cuda.synchronize()
-        top = sorted(kp.summary().items(), key=lambda kv: -kv[1][1])[:6]
+        top = sorted(kp.summary().items(), key=lambda kv: -kv[1][1])[:8]
         print(json.dumps({'model': name, 'shape': shape, 'params': sum(p.numel() for p in model.parameters()),
                           'ms_per_step': round(dt * 1e3, 2), 'volumes_per_s': round(shape[0] / dt, 2), 'loss': round(float(l), 5),
                           'max_mem_GB': round(torch.cuda.max_memory_allocated() / 1e9, 2),
-                          'top_kernels_ms': {k: round(v[1], 2) for k, v in top}}))
+                          'top_kernels_ms': {k: round(v[1], 2) for k, v in top},
+                          'algorithmic_TFLOPs_or_TBps': {k: round(v[3] / (v[1] * 1e-3) / 1e12, 1) for k, v in top if v[3]}}))
     except Exception as e:
         print(json.dumps({'model': name, 'error': repr(e)[:300]}))
     del model, x
