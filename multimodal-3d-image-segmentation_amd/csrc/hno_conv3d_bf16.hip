@@ -393,54 +393,65 @@ __global__ __launch_bounds__(256) void cb_gn_bwd_reduce_kernel(const bf16_t *__r
     }
 }
 
-// pass 1b: slabs -> dgamma[c], dbeta[c] (summed over samples and blocks, fp64, fixed order) and per sample
-// k1 = sum_c gamma_c S1[b][c] / N,  k2 = sum_c gamma_c S2[b][c] / N   (N = C V)
+// pass 1b: slabs -> dgamma[c], dbeta[c] (summed over samples and blocks, fixed order) and gS[b][which][c] = gamma_c S_which[b][c].
+// One workgroup per 8 channels: thread (slice = t >> 3, j = t & 7) sums every 32nd slab row of channel 8 blockIdx.x + j,
+// the 32 slices are then added in order.  (A single-workgroup version of this kernel -- 256 dependent loads per thread --
+// cost 0.2-0.5 ms per call, 10 ms of the 18 ms V-Net step.)
 __global__ __launch_bounds__(256) void cb_gn_bwd_finalize_kernel(const float *__restrict__ slab, const float *__restrict__ gamma, int B, int nblk,
-                                                                int C, double count, float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                                float *__restrict__ k12, int accumulate) {
-    __shared__ double sh[2][256];
-    double acc1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc2[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per sample, this thread's channels folded with gamma
-    // thread t owns channels t, t + 256, ...
-    for (int c = threadIdx.x; c < C; c += 256) {
-        double dg = 0.0, db = 0.0;
-        for (int b = 0; b < B; ++b) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int k = 0; k < nblk; ++k) {
-                const float *p = slab + ((size_t)b * nblk + k) * 2 * C;
-                s1 += (double)p[c];
-                s2 += (double)p[C + c];
-            }
-            db += s1;
-            dg += s2;
-            if (b < 8) {
-                acc1[b] += (double)gamma[c] * s1;
-                acc2[b] += (double)gamma[c] * s2;
-            }
+                                                                int C, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                                float *__restrict__ gS, int accumulate) {
+    __shared__ float sh[2][32][8];
+    const int j = threadIdx.x & 7, slice = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + j;
+    float dg = 0.f, db = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int k = slice; k < nblk; k += 32) {
+            const float *p = slab + ((size_t)b * nblk + k) * 2 * C;
+            s1 += p[c];
+            s2 += p[C + c];
         }
-        if (accumulate) {
-            dgamma[c] += (float)dg;
-            dbeta[c] += (float)db;
-        } else {
-            dgamma[c] = (float)dg;
-            dbeta[c] = (float)db;
+        sh[0][slice][j] = s1;
+        sh[1][slice][j] = s2;
+        __syncthreads();
+        if (slice == 0) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int q = 0; q < 32; ++q) { t1 += sh[0][q][j]; t2 += sh[1][q][j]; }
+            db += t1;
+            dg += t2;
+            gS[((size_t)b * 2) * C + c] = gamma[c] * t1;
+            gS[((size_t)b * 2 + 1) * C + c] = gamma[c] * t2;
         }
+        __syncthreads();
     }
-    for (int b = 0; b < B && b < 8; ++b) {
-        sh[0][threadIdx.x] = acc1[b];
-        sh[1][threadIdx.x] = acc2[b];
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) {
-                sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
-                sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
-            }
-            __syncthreads();
+    if (slice == 0) {
+        if (accumulate) { dgamma[c] += dg; dbeta[c] += db; }
+        else { dgamma[c] = dg; dbeta[c] = db; }
+    }
+}
+
+// k1[b] = sum_c gS[b][0][c] / N, k2[b] = sum_c gS[b][1][c] / N  (fp64, fixed order)
+__global__ __launch_bounds__(256) void cb_gn_bwd_k12_kernel(const float *__restrict__ gS, int C, double count, float *__restrict__ k12) {
+    __shared__ double sh[2][256];
+    const int b = blockIdx.x;
+    double a1 = 0.0, a2 = 0.0;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        a1 += (double)gS[((size_t)b * 2) * C + c];
+        a2 += (double)gS[((size_t)b * 2 + 1) * C + c];
+    }
+    sh[0][threadIdx.x] = a1;
+    sh[1][threadIdx.x] = a2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
         }
-        if (threadIdx.x == 0) {
-            k12[2 * b] = (float)(sh[0][0] / count);
-            k12[2 * b + 1] = (float)(sh[1][0] / count);
-        }
         __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        k12[2 * b] = (float)(sh[0][0] / count);
+        k12[2 * b + 1] = (float)(sh[1][0] / count);
     }
 }
 
@@ -709,30 +720,58 @@ __global__ __launch_bounds__(256) void cb_wgrad_kernel(CwArgs a) {
 }
 
 // slabs [nblk][ntaps][CO][CI] -> dW fp32 in the parameter's own layout: element (o, i, tap) of the GEMM goes to
-// dW[(c0 * C1 + c1) * T + tap] with (c0, c1) = (o, i) or (i, o).  fp64-free ordered sum (fp32, fixed order).
+// dW[(c0 * C1 + c1) * T + tap] with (c0, c1) = (o, i) or (i, o).  A workgroup = 64 consecutive elements x 4 slab slices
+// (slice q sums slabs q, q + 4, ...; four independent loads in flight per thread), the 4 slices are added in order.
+// (One thread walking all 256 slabs of its element -- 256 dependent-latency loads -- made this 3.5 ms of the V-Net step.)
 __global__ __launch_bounds__(256) void cb_wgrad_reduce_kernel(const float *__restrict__ slab, int nblk, int ntaps, int CO, int CI, int co0, int ci0,
                                                              float *__restrict__ dW, int C1, int T, int out_is_axis0, int nci) {
+    __shared__ float sh[4][64];
     const int n = ntaps * CO * CI;
     slab += (size_t)blockIdx.y * nblk * n;
     if (gridDim.y > 1) {
         co0 += (int)(blockIdx.y / nci) * CO;
         ci0 += (int)(blockIdx.y % nci) * CI;
     }
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < nblk; ++k) s += slab[(size_t)k * n + idx];
-        const int c = idx % CI, o = (idx / CI) % CO, tap = idx / (CI * CO);
-        const int go = co0 + o, gc = ci0 + c;
-        const int c0 = out_is_axis0 ? go : gc, c1 = out_is_axis0 ? gc : go;
-        dW[((size_t)c0 * C1 + c1) * T + tap] = s;
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    for (int base = blockIdx.x * 64; base < n; base += gridDim.x * 64) {
+        const int idx = base + e;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (idx < n) {
+            int k = q;
+            for (; k + 12 < nblk; k += 16) {
+                s0 += slab[(size_t)k * n + idx];
+                s1 += slab[(size_t)(k + 4) * n + idx];
+                s2 += slab[(size_t)(k + 8) * n + idx];
+                s3 += slab[(size_t)(k + 12) * n + idx];
+            }
+            for (; k < nblk; k += 4) s0 += slab[(size_t)k * n + idx];
+        }
+        sh[q][e] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (q == 0 && idx < n) {
+            const float s = (sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]);
+            const int c = idx % CI, o = (idx / CI) % CO, tap = idx / (CI * CO);
+            const int go = co0 + o, gc = ci0 + c;
+            const int c0 = out_is_axis0 ? go : gc, c1 = out_is_axis0 ? gc : go;
+            dW[((size_t)c0 * C1 + c1) * T + tap] = s;
+        }
+        __syncthreads();
     }
 }
 
+// per-channel slabs [nblk][C] -> out[C]: one workgroup per 8 channels, 32 slab slices per channel added in order
 __global__ __launch_bounds__(256) void cb_colsum_reduce_kernel(const float *__restrict__ slab, int nblk, int C, float *__restrict__ out) {
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < nblk; ++k) s += slab[(size_t)k * C + c];
-        out[c] = s;
+    __shared__ float sh[32][8];
+    const int j = threadIdx.x & 7, slice = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + j;
+    float s = 0.f;
+    for (int k = slice; k < nblk; k += 32) s += slab[(size_t)k * C + c];
+    sh[slice][j] = s;
+    __syncthreads();
+    if (slice == 0) {
+        float t = 0.f;
+        for (int q = 0; q < 32; ++q) t += sh[q][j];
+        out[c] = t;
     }
 }
 
@@ -867,7 +906,7 @@ extern "C" int hno_cb_gn_apply(const void *y1, const float *mr1, const float *ga
 
 #define CB_GN_BWD_BLOCKS 256
 extern "C" size_t hno_cb_gn_bwd_workspace_bytes(int B, int C) {
-    return ((size_t)B * CB_GN_BWD_BLOCKS * 2 * C + 2 * (size_t)(B > 8 ? B : 8)) * sizeof(float) + 256;
+    return ((size_t)B * CB_GN_BWD_BLOCKS * 2 * C + 2 * (size_t)B * C + 2 * (size_t)(B > 8 ? B : 8)) * sizeof(float) + 256;
 }
 
 // backward of z = act(gamma (y - mean) rstd + beta) w.r.t. y, gamma, beta.  accumulate != 0: dgamma / dbeta += .
@@ -876,10 +915,10 @@ extern "C" int hno_cb_gn_bwd(const void *dz, const void *y, const float *mr, con
                              void *stream) {
     HNO_REQUIRE(dz && y && mr && gamma && beta && dy && dgamma && dbeta && workspace && B > 0 && C > 0 && V > 0, "hno_cb_gn_bwd: bad argument");
     if (C % 8 || C > 2048) return fail(HNO_ELIMIT, "hno_cb_gn_bwd: C = %d must be a multiple of 8 (<= 2048)", C);
-    if (B > 8) return fail(HNO_ELIMIT, "hno_cb_gn_bwd: batch %d > 8 per call", B);
     hipStream_t s = (hipStream_t)stream;
     float *slab = (float *)workspace;
-    float *k12 = slab + (size_t)B * CB_GN_BWD_BLOCKS * 2 * C;
+    float *gS = slab + (size_t)B * CB_GN_BWD_BLOCKS * 2 * C;
+    float *k12 = gS + 2 * (size_t)B * C;
     int nblk = CB_GN_BWD_BLOCKS;
     if (V < nblk) nblk = (int)V;
     {
@@ -888,8 +927,9 @@ extern "C" int hno_cb_gn_bwd(const void *dz, const void *y, const float *mr, con
                            beta, slab, C, V, act);
         HNO_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(cb_gn_bwd_finalize_kernel, dim3(1), dim3(256), 0, s, (const float *)slab, gamma, B, nblk, C, (double)V * C, dgamma, dbeta, k12,
-                       accumulate);
+    hipLaunchKernelGGL(cb_gn_bwd_finalize_kernel, dim3(C / 8), dim3(256), 0, s, (const float *)slab, gamma, B, nblk, C, dgamma, dbeta, gS, accumulate);
+    HNO_CHECK_LAUNCH();
+    hipLaunchKernelGGL(cb_gn_bwd_k12_kernel, dim3(B), dim3(256), 0, s, (const float *)gS, C, (double)V * C, k12);
     HNO_CHECK_LAUNCH();
     {
         ProfScope _ps(KID_CB_GN, s, (double)B * V * C * 6.0);
@@ -924,7 +964,7 @@ extern "C" int hno_cb_colsum(const void *g, float *out, void *workspace, int C, 
     if (rows < nblk) nblk = (int)rows;
     hipLaunchKernelGGL(cb_colsum_kernel, dim3(nblk), dim3(256), 256 * 8 * sizeof(float), s, (const bf16_t *)g, (float *)workspace, C, rows);
     HNO_CHECK_LAUNCH();
-    hipLaunchKernelGGL(cb_colsum_reduce_kernel, dim3(gsz(C)), dim3(256), 0, s, (const float *)workspace, nblk, C, out);
+    hipLaunchKernelGGL(cb_colsum_reduce_kernel, dim3(C / 8), dim3(256), 0, s, (const float *)workspace, nblk, C, out);
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }
@@ -1054,7 +1094,7 @@ extern "C" int hno_cb_wgrad(const void *g, int Cg, const void *xa, int Ca, const
             else rc = wg_launch<3, 3>(a, grid, p.lds, s);
         }
         if (rc != HNO_OK) return rc;
-        hipLaunchKernelGGL(cb_wgrad_reduce_kernel, dim3(gsz((long long)T * a.CO * a.CI, 256, 64), ny), dim3(256), 0, s, (const float *)a.slab, p.nblk, T,
+        hipLaunchKernelGGL(cb_wgrad_reduce_kernel, dim3(gsz((long long)T * a.CO * a.CI, 64, 1024), ny), dim3(256), 0, s, (const float *)a.slab, p.nblk, T,
                            a.CO, a.CI, a.co0, a.ci0, dW, C1, T, 1, nci);
         HNO_CHECK_LAUNCH();
     }

@@ -38,12 +38,27 @@ for name in which:
         torch.cuda.synchronize(); t0 = time.time(); n = 5
         for _ in range(n): l = step()
         torch.cuda.synchronize(); dt = (time.time() - t0) / n
+        # the same step replayed from a HIP graph (no host launch cost: what bench.py does for the headline config)
+        dt_graph = None
+        try:
+            side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=side):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            gr.replay(); torch.cuda.synchronize(); t0 = time.time()
+            for _ in range(10): gr.replay()
+            torch.cuda.synchronize(); dt_graph = (time.time() - t0) / 10
+        except Exception as e:
+            print('graph capture failed:', repr(e)[:200], file=sys.stderr)
         with pkg._lib.KernelProfile() as kp:
             step()
         torch.cuda.synchronize()
         top = sorted(kp.summary().items(), key=lambda kv: -kv[1][1])[:8]
         print(json.dumps({'model': name, 'shape': shape, 'params': sum(p.numel() for p in model.parameters()),
-                          'ms_per_step': round(dt * 1e3, 2), 'volumes_per_s': round(shape[0] / dt, 2), 'loss': round(float(l), 5),
+                          'ms_per_step': round(dt * 1e3, 2), 'ms_per_step_graph': None if dt_graph is None else round(dt_graph * 1e3, 2),
+                          'volumes_per_s': round(shape[0] / (dt_graph or dt), 2), 'loss': round(float(l), 5),
                           'max_mem_GB': round(torch.cuda.max_memory_allocated() / 1e9, 2),
                           'top_kernels_ms': {k: round(v[1], 2) for k, v in top},
                           'algorithmic_TFLOPs_or_TBps': {k: round(v[3] / (v[1] * 1e-3) / 1e12, 1) for k, v in top if v[3]}}))
