@@ -232,6 +232,179 @@ __global__ __launch_bounds__(256) void cb_gather_kernel(CbArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ halo-tile GEMM
+// Stride-1 3x3x3 convolutions (and their input gradients: the same operator with the taps mirrored) on grids wide enough to
+// fill tiles: the shallow levels, where 85 % of the V-Net's flops are.  The gather kernel above re-reads every input
+// element once per tap through the texture path (27 x 16-byte gathers per element; measured 170 TFLOP/s, TA-bound).  Here a
+// workgroup owns (b, od, a band of TH output rows): the 3 planes x (TH + 2) rows x (W + 2) columns its taps reach are
+// staged ONCE per 24-channel chunk in LDS as [position][24 ch] (48-byte pitch: consecutive positions sit in consecutive
+// 16-byte bank slots 3 apart, so a ds_read_b128 of 32 positions is conflict-free), and tap (td, th, tw) of output position
+// p = hh * S + ww (S = W + 2) is image position  p + (td * (TH + 2) + th) * S + tw : a flat shift, no index arithmetic
+// per element.  Outputs at the two pad columns of each row are computed and dropped.  Weights stream from L2 in the packed
+// [chunk][CoP][8] layout (the same addresses in every workgroup), one K-step ahead.  LDS per workgroup <= 52 KB so that
+// three workgroups share a CU: one stages while the others multiply.
+struct ChArgs {
+    const bf16_t *xa, *xb;
+    int Ca, Cb;
+    const bf16_t *w;
+    const float *bias;
+    bf16_t *y;
+    float *stats;
+    int B, Cout, CoP, D, H, W;
+    int TH, S, nbands, npos;
+    int flip;                 // 1: input gradient (taps mirrored)
+    int dbg;                  // ablation switches (hno_set_debug): 512 skip the staging, 1024 skip the K loop (results WRONG)
+};
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void cb_halo_kernel(ChArgs a) {
+    extern __shared__ uint4 img[];                        // [npos][3] image, then the K-step table int2[96]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int band = blockIdx.x % a.nbands;
+    const int od = (blockIdx.x / a.nbands) % a.D;
+    const int b = blockIdx.x / (a.nbands * a.D);
+    const int oh0 = band * a.TH;
+    const int n0 = blockIdx.y * 32 * NT;
+    const int Cin = a.Ca + a.Cb, nC8 = Cin >> 3, nchunk = Cin / 24;
+    const int rows = a.TH + 2, S = a.S;
+    const int p0 = wave * 32 * MT;                         // this wave's first output position
+    // K-step table, the same for every wave: entry 2 s + h = (image offset in uint4 of the tap's shift and 8-channel part,
+    // weight offset in elements of chunk (tap, part); -1: padding step).  Keeps the K loop free of index arithmetic (the
+    // divisions by 3 / 9 per operand made the loop VALU-bound at 5x its MFMA time).
+    int2 *tab = reinterpret_cast<int2 *>(img + (size_t)a.npos * 3);
+    if (threadIdx.x < 96) {
+        const int ql = threadIdx.x;
+        int2 e = make_int2(0, -1);
+        if (ql < 81) {
+            const int tap = ql / 3, j = ql - tap * 3;
+            int td = tap / 9, th = (tap / 3) % 3, tw = tap % 3;
+            if (a.flip) { td = 2 - td; th = 2 - th; tw = 2 - tw; }
+            e.x = ((td * rows + th) * S + tw) * 3 + j;
+            e.y = (tap * nC8 + j) * a.CoP * 8;
+        }
+        tab[ql] = e;
+    }
+    f32x16b acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+    const size_t plane = (size_t)a.H * a.W;
+    const int row_items = 3 * S;                           // uint4 per image row
+    const int nrows_img = (a.npos + S - 1) / S;            // image rows incl. the zero slack behind the third plane
+    for (int cc = 0; cc < nchunk; ++cc) {
+        const bool from_a = cc * 24 < a.Ca;
+        const bf16_t *src = from_a ? a.xa + (size_t)b * a.D * plane * a.Ca + cc * 24 : a.xb + (size_t)b * a.D * plane * a.Cb + (cc * 24 - a.Ca);
+        const int Cs = from_a ? a.Ca : a.Cb;
+        __syncthreads();                                   // the previous chunk's reads are done
+        if (!(a.dbg & 512))
+            for (int row = wave; row < nrows_img; row += 4) {      // one wave per image row: row validity is wave-uniform
+                const int pl = row / rows, rr = row - pl * rows;
+                const int id = od - 1 + pl, ih = oh0 - 1 + rr;
+                const bool rok = pl < 3 && id >= 0 && id < a.D && ih >= 0 && ih < a.H;
+                const bf16_t *rsrc = src + ((size_t)(rok ? id : 0) * plane + (size_t)(rok ? ih : 0) * a.W) * Cs;
+                for (int it = lane; it < row_items; it += 64) {
+                    const int cx = it / 3, part = it - cx * 3;
+                    const int iw = cx - 1;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (rok && iw >= 0 && iw < a.W) v = *reinterpret_cast<const uint4 *>(rsrc + (size_t)iw * Cs + part * 8);
+                    const int dst = row * row_items + it;
+                    if (dst < a.npos * 3) img[dst] = v;
+                }
+            }
+        __syncthreads();
+        if (a.dbg & 1024) continue;
+        // 81 chunks of 8 k (27 taps x 3) -> 41 K-steps of 16 (padded to 48); lane half h takes chunk 2 s + h.  The weight
+        // operand streams from L2: a ring of PD K-steps of weight fragments is kept in flight.
+        constexpr int PD = 8;
+        const bf16_t *wl = a.w + ((size_t)cc * 3 * a.CoP + n0 + r) * 8;
+        const int lane_a = (p0 + r) * 3;
+        auto load_b = [&](int s, uint4 *bv) {
+            const int off = tab[2 * s + h].y;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bv[n] = off >= 0 ? *reinterpret_cast<const uint4 *>(wl + off + n * 256) : make_uint4(0, 0, 0, 0);
+        };
+        auto load_a = [&](int s, uint4 *av) {
+            const int off = tab[2 * s + h].x + lane_a;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) av[m] = img[off + 96 * m];
+        };
+        uint4 ring[PD][NT];
+#pragma unroll
+        for (int u = 0; u < PD; ++u) load_b(u, ring[u]);
+        uint4 av[MT];
+        load_a(0, av);
+        for (int s0 = 0; s0 < 48; s0 += PD) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int s = s0 + u;
+                uint4 an[MT];
+                load_a(s + 1 < 41 ? s + 1 : 40, an);
+                if (s < 41) {
+                    // A operand = weights (rows = output channels), B operand = activations (columns = positions)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[u][n]),
+                                                                                __builtin_bit_cast(bf16x8, av[m]), acc[m][n], 0, 0, 0);
+                }
+                if (s + PD < 41) load_b(s + PD, ring[u]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) av[m] = an[m];
+            }
+        }
+    }
+    // epilogue.  C/D: column (lane & 31) = position p0 + 32 m + r, rows (i & 3) + 8 (i >> 2) + 4 h = output channel within the
+    // 32-channel tile: registers 4 g .. 4 g + 3 are 4 CONSECUTIVE channels 8 g + 4 h .. + 3 of this lane's position: one
+    // 8-byte store each (the transposed orientation needed 2-byte stores: 35 us of a 220 us layer)
+    float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int p = p0 + 32 * m + r;
+        const int hh = p / S, ww = p - hh * S;
+        const int oh = oh0 + hh;
+        const bool pok = hh < a.TH && oh < a.H && ww < a.W;
+        bf16_t *yrow = a.y + (((size_t)b * a.D + od) * plane + (size_t)(pok ? oh : 0) * a.W + (pok ? ww : 0)) * a.Cout;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = n0 + 32 * n + 8 * g + 4 * h;
+                if (!pok || ch >= a.Cout) continue;          // Cout is a multiple of 8 and ch of 4: a group is all in or all out ... (ch + 3 < Cout when ch < Cout since Cout % 4 == 0)
+                bf16_t o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = f2bf(acc[m][n][4 * g + e] + (a.bias ? a.bias[ch + e] : 0.f));
+                    const float f = bf2f(o[e]);
+                    ssum += f;
+                    ssq = fmaf(f, f, ssq);
+                }
+                *reinterpret_cast<uint2 *>(yrow + ch) = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
+            }
+    }
+    if (a.stats) {
+        __shared__ float red[8];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ssum += __shfl_xor(ssum, o);
+            ssq += __shfl_xor(ssq, o);
+        }
+        if (lane == 0) { red[wave * 2] = ssum; red[wave * 2 + 1] = ssq; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int per_b = a.D * a.nbands;
+            const int nblk = per_b * gridDim.y;
+            float *dst = a.stats + ((size_t)b * nblk + blockIdx.y * per_b + (blockIdx.x % per_b)) * 2;
+            dst[0] = red[0] + red[2] + red[4] + red[6];
+            dst[1] = red[1] + red[3] + red[5] + red[7];
+        }
+    }
+}
+
 // split-K finish: y = bf16(sum_z part[z] ) (bias was added by slice 0), + GroupNorm partial statistics
 __global__ __launch_bounds__(256) void cb_splitk_finish_kernel(const float *__restrict__ part, bf16_t *__restrict__ y, float *__restrict__ stats,
                                                               int ksplit, long long per_sample, int B) {
@@ -857,6 +1030,44 @@ extern "C" int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const
     a.stats = mean_rstd ? stats : nullptr;
     int nblk_stats;
     const double flops = 2.0 * B * Vo * (double)Cout * a.ntaps * (Ca + Cb);
+    // halo-tile kernel: 3x3x3, stride 1, same grid in and out, channel chunks of 24, and a grid wide enough to fill the tiles
+    if (ks == 3 && stride == 1 && pad == 1 && Di == Do && Hi == Ho && Wi == Wo && Ca % 24 == 0 && Cb % 24 == 0 && !(debug_flags() & 256)) {
+        const int MT = 2;
+        const int S = Wo + 2;
+        int TH = (4 * MT * 32) / S;                      // the band's positions fill the 4 waves' tiles
+        if (TH > Ho) TH = Ho;
+        const int used = TH * S;
+        if (TH >= 1 && used * 10 >= 4 * MT * 32 * 6) {    // >= 60 % of the tile rows carry positions of the band
+            ChArgs h = {};
+            h.xa = a.xa; h.xb = a.xb; h.Ca = Ca; h.Cb = Cb; h.w = a.w; h.bias = bias; h.y = a.y; h.stats = mean_rstd ? stats : nullptr;
+            h.B = B; h.Cout = Cout; h.CoP = a.CoP; h.D = Do; h.H = Ho; h.W = Wo; h.TH = TH; h.S = S; h.flip = mode; h.dbg = debug_flags();
+            h.nbands = (Ho + TH - 1) / TH;
+            h.npos = (2 * (TH + 2) + 2) * S + 2 + 4 * MT * 32 + 8;
+            if (h.npos < 3 * (TH + 2) * S) h.npos = 3 * (TH + 2) * S;
+            const size_t lds = (size_t)h.npos * 48 + 96 * sizeof(int2);
+            const int NTsel = Cout <= 32 ? 1 : (Cout <= 64 ? 2 : 3);
+            const dim3 g((unsigned)(B * Do * h.nbands), (Cout + 32 * NTsel - 1) / (32 * NTsel));
+            ProfScope _ps(KID_CB_CONV, s, flops);
+            static bool attr[3] = {false, false, false};
+            if (NTsel == 1) {
+                if (lds > 48 * 1024 && !attr[0]) { HNO_CHECK_HIP(hipFuncSetAttribute((const void *)cb_halo_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); attr[0] = true; }
+                hipLaunchKernelGGL((cb_halo_kernel<2, 1>), g, dim3(256), lds, s, h);
+            } else if (NTsel == 2) {
+                if (lds > 48 * 1024 && !attr[1]) { HNO_CHECK_HIP(hipFuncSetAttribute((const void *)cb_halo_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); attr[1] = true; }
+                hipLaunchKernelGGL((cb_halo_kernel<2, 2>), g, dim3(256), lds, s, h);
+            } else {
+                if (lds > 48 * 1024 && !attr[2]) { HNO_CHECK_HIP(hipFuncSetAttribute((const void *)cb_halo_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); attr[2] = true; }
+                hipLaunchKernelGGL((cb_halo_kernel<2, 3>), g, dim3(256), lds, s, h);
+            }
+            HNO_CHECK_LAUNCH();
+            if (mean_rstd) {
+                hipLaunchKernelGGL(cb_gn_finalize_kernel, dim3(B), dim3(256), 0, s, (const float *)stats, (int)(Do * h.nbands * g.y), (double)Vo * Cout, eps,
+                                   mean_rstd);
+                HNO_CHECK_LAUNCH();
+            }
+            return HNO_OK;
+        }
+    }
     {
         ProfScope _ps(KID_CB_CONV, s, flops);
         if (Cout <= 32) {

@@ -60,6 +60,13 @@ CONV_CASES = [
     (2, 48, 0, 24, (6, 7, 9), 1, 1, False),         # 1x1x1 residual conv
     (1, 192, 0, 384, (3, 4, 3), 3, 1, False),       # deep level: split-K over taps
     (1, 96, 96, 96, (4, 5, 4), 3, 1, False),
+    # wide grids: the LDS halo-tile kernel (stride-1 3x3x3, 24-channel chunks), forward and input gradient
+    (1, 24, 0, 24, (4, 13, 30), 3, 1, False),
+    (1, 24, 24, 24, (3, 9, 33), 3, 1, False),
+    (1, 48, 0, 48, (3, 10, 31), 3, 1, False),
+    (2, 48, 0, 96, (2, 9, 30), 3, 1, False),
+    (1, 96, 96, 192, (2, 8, 30), 3, 1, False),
+    (1, 24, 0, 24, (3, 7, 65), 3, 1, False),        # the level-0 row width of BASELINE cfg4
 ]
 
 
