@@ -239,6 +239,8 @@ size_t hno_cb_packed_weight_bytes(int Cin, int Cout, int ks);
 /* role 0: conv forward W[Cout][Cin][ks^3]; 1: conv input gradient (same tensor); 2: ConvTranspose forward Wt[Cin][Cout][ks^3];
  * 3: ConvTranspose input gradient.  dst: bf16 [tap * Ci/8 + c8][round_up(Co, 32)][8] of the GEMM's input (Ci) / output (Co) channels */
 int hno_cb_pack_weights(const float *W, void *dst, int role, int Cin, int Cout, int ks, void *stream);
+/* roles 0 + 1 (transposed = 0) or 2 + 3 (transposed = 1) in ONE launch: the forward operand and the input-gradient operand */
+int hno_cb_pack_weights_both(const float *W, void *dst_fwd, void *dst_bwd, int transposed, int Cin, int Cout, int ks, void *stream);
 size_t hno_cb_conv_workspace_bytes(int B, int Cin, int Cout, int Do, int Ho, int Wo, int ks);
 /* y = conv([xa ; xb]) + bias as a gather GEMM.  mode 0: in = stride * out - pad + tap (Conv3d forward, ConvTranspose3d input
  * gradient); mode 1: in = (out + pad - tap) / stride where divisible (ConvTranspose3d forward, Conv3d input gradient).

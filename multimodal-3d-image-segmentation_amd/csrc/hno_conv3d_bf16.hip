@@ -603,38 +603,34 @@ __global__ __launch_bounds__(256) void cb_gn_bwd_finalize_kernel(const float *__
     }
 }
 
-// k1[b] = sum_c gS[b][0][c] / N, k2[b] = sum_c gS[b][1][c] / N  (fp64, fixed order)
-__global__ __launch_bounds__(256) void cb_gn_bwd_k12_kernel(const float *__restrict__ gS, int C, double count, float *__restrict__ k12) {
-    __shared__ double sh[2][256];
-    const int b = blockIdx.x;
-    double a1 = 0.0, a2 = 0.0;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        a1 += (double)gS[((size_t)b * 2) * C + c];
-        a2 += (double)gS[((size_t)b * 2 + 1) * C + c];
-    }
-    sh[0][threadIdx.x] = a1;
-    sh[1][threadIdx.x] = a2;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
-            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        k12[2 * b] = (float)(sh[0][0] / count);
-        k12[2 * b + 1] = (float)(sh[1][0] / count);
-    }
-}
-
 // pass 2: dy = rstd (gamma t - k1 - xhat k2), bf16 channels-last
 __global__ __launch_bounds__(256) void cb_gn_bwd_apply_kernel(const bf16_t *__restrict__ dz, const bf16_t *__restrict__ y, const float *__restrict__ mr,
                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                             const float *__restrict__ k12, bf16_t *__restrict__ dy, int C, long long per_sample,
+                                                             const float *__restrict__ gS, bf16_t *__restrict__ dy, int C, long long per_sample,
                                                              int act) {
     const int b = blockIdx.y;
-    const float mean = mr[2 * b], rstd = mr[2 * b + 1], k1 = k12[2 * b], k2 = k12[2 * b + 1];
+    // k1 = sum_c gS[b][0][c] / N, k2 = sum_c gS[b][1][c] / N: every workgroup re-reduces the <= 2 x 2048 values itself (fixed
+    // order, so all workgroups agree bit for bit) instead of waiting for one more tiny launch
+    __shared__ float kred[2][256];
+    {
+        float a1 = 0.f, a2 = 0.f;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            a1 += gS[((size_t)b * 2) * C + c];
+            a2 += gS[((size_t)b * 2 + 1) * C + c];
+        }
+        kred[0][threadIdx.x] = a1;
+        kred[1][threadIdx.x] = a2;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) {
+                kred[0][threadIdx.x] += kred[0][threadIdx.x + o];
+                kred[1][threadIdx.x] += kred[1][threadIdx.x + o];
+            }
+            __syncthreads();
+        }
+    }
+    const float inv_n = 1.0f / (float)per_sample;
+    const float mean = mr[2 * b], rstd = mr[2 * b + 1], k1 = kred[0][0] * inv_n, k2 = kred[1][0] * inv_n;
     const long long n8 = per_sample >> 3;
     const int C8 = C >> 3;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
@@ -968,6 +964,42 @@ extern "C" size_t hno_cb_packed_weight_bytes(int Cin, int Cout, int ks) {
 
 // role: 0 conv forward (W[Cout][Cin][T]), 1 conv input gradient (same tensor, channel roles swapped),
 //       2 ConvTranspose forward (Wt[Cin][Cout][T]), 3 ConvTranspose input gradient.  Cin / Cout are the LAYER's.
+// both GEMM operands of a layer in one launch: dst_fwd = role 0 (conv) / 2 (transposed), dst_bwd = role 1 / 3
+__global__ __launch_bounds__(256) void cb_pack_weights2_kernel(const float *__restrict__ w, bf16_t *__restrict__ d0, bf16_t *__restrict__ d1, int C0, int C1,
+                                                              int T, int oa0, int Ci0, int Co0, int CoP0, int nq20, int oa1, int Ci1, int Co1, int CoP1,
+                                                              int nq21) {
+    const long long n0 = (long long)nq20 * CoP0 * 8, n1 = (long long)nq21 * CoP1 * 8;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n0 + n1; idx += (long long)gridDim.x * 256) {
+        const bool second = idx >= n0;
+        const long long k = second ? idx - n0 : idx;
+        const int Ci = second ? Ci1 : Ci0, Co = second ? Co1 : Co0, CoP = second ? CoP1 : CoP0, oa = second ? oa1 : oa0;
+        const int nC8 = Ci / 8;
+        const int j = (int)(k & 7), o = (int)((k >> 3) % CoP), q = (int)((k >> 3) / CoP);
+        const int t = q / nC8, i = (q % nC8) * 8 + j;
+        float v = 0.f;
+        if (t < T && o < Co) {
+            const int c0 = oa ? o : i, c1 = oa ? i : o;
+            v = w[((size_t)c0 * C1 + c1) * T + t];
+        }
+        (second ? d1 : d0)[k] = f2bf(v);
+    }
+}
+
+extern "C" int hno_cb_pack_weights_both(const float *W, void *dst_fwd, void *dst_bwd, int transposed, int Cin, int Cout, int ks, void *stream) {
+    HNO_REQUIRE(W && dst_fwd && dst_bwd && Cin > 0 && Cout > 0 && ks >= 1 && ks <= 3, "hno_cb_pack_weights_both: bad argument");
+    if ((Cin % 8) || (Cout % 8)) return fail(HNO_ELIMIT, "hno_cb_pack_weights_both: %d -> %d channels (multiples of 8)", Cin, Cout);
+    const int T = ks * ks * ks;
+    const int C0 = transposed ? Cin : Cout, C1 = transposed ? Cout : Cin;
+    // forward: GEMM in = Cin, out = Cout; backward (input gradient): in = Cout, out = Cin
+    const int oa0 = transposed ? 0 : 1, oa1 = transposed ? 1 : 0;
+    const int nq0 = T * (Cin / 8), nq20 = (nq0 + 1) & ~1, CoP0 = (Cout + 31) / 32 * 32;
+    const int nq1 = T * (Cout / 8), nq21 = (nq1 + 1) & ~1, CoP1 = (Cin + 31) / 32 * 32;
+    hipLaunchKernelGGL(cb_pack_weights2_kernel, dim3(gsz((long long)nq20 * CoP0 * 8 + (long long)nq21 * CoP1 * 8)), dim3(256), 0, (hipStream_t)stream, W,
+                       (bf16_t *)dst_fwd, (bf16_t *)dst_bwd, C0, C1, T, oa0, Cin, Cout, CoP0, nq20, oa1, Cout, Cin, CoP1, nq21);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
 extern "C" int hno_cb_pack_weights(const float *W, void *dst, int role, int Cin, int Cout, int ks, void *stream) {
     HNO_REQUIRE(W && dst && role >= 0 && role <= 3 && Cin > 0 && Cout > 0 && ks >= 1 && ks <= 3, "hno_cb_pack_weights: bad argument");
     const int gi = (role == 0 || role == 2) ? Cin : Cout, go = (role == 0 || role == 2) ? Cout : Cin;   // GEMM in / out channels
@@ -1129,7 +1161,6 @@ extern "C" int hno_cb_gn_bwd(const void *dz, const void *y, const float *mr, con
     hipStream_t s = (hipStream_t)stream;
     float *slab = (float *)workspace;
     float *gS = slab + (size_t)B * CB_GN_BWD_BLOCKS * 2 * C;
-    float *k12 = gS + 2 * (size_t)B * C;
     int nblk = CB_GN_BWD_BLOCKS;
     if (V < nblk) nblk = (int)V;
     {
@@ -1140,12 +1171,10 @@ extern "C" int hno_cb_gn_bwd(const void *dz, const void *y, const float *mr, con
     }
     hipLaunchKernelGGL(cb_gn_bwd_finalize_kernel, dim3(C / 8), dim3(256), 0, s, (const float *)slab, gamma, B, nblk, C, dgamma, dbeta, gS, accumulate);
     HNO_CHECK_LAUNCH();
-    hipLaunchKernelGGL(cb_gn_bwd_k12_kernel, dim3(B), dim3(256), 0, s, (const float *)gS, C, (double)V * C, k12);
-    HNO_CHECK_LAUNCH();
     {
         ProfScope _ps(KID_CB_GN, s, (double)B * V * C * 6.0);
         hipLaunchKernelGGL(cb_gn_bwd_apply_kernel, dim3(gsz(V * C / 8, 256, 2048), B), dim3(256), 0, s, (const bf16_t *)dz, (const bf16_t *)y, mr, gamma,
-                           beta, (const float *)k12, (bf16_t *)dy, C, V * C, act);
+                           beta, (const float *)gS, (bf16_t *)dy, C, V * C, act);
         HNO_CHECK_LAUNCH();
     }
     return HNO_OK;

@@ -51,6 +51,16 @@ def pack_weights(W, role, Cin, Cout, ks):
     return out
 
 
+def pack_weights_both(W, transposed, Cin, Cout, ks):
+    """forward operand and input-gradient operand of one layer in one launch"""
+    L = _lib.lib()
+    W = _f32(W)
+    wf = _ws(L.hno_cb_packed_weight_bytes(Cin, Cout, ks), W.device)
+    wb = _ws(L.hno_cb_packed_weight_bytes(Cout, Cin, ks), W.device)
+    check(L.hno_cb_pack_weights_both(ptr(W), ptr(wf), ptr(wb), int(transposed), Cin, Cout, ks, stream_ptr()), 'hno_cb_pack_weights_both')
+    return wf, wb
+
+
 def conv_raw(xa, xb, wpacked, bias, Cout, out_spatial, mode, ks, stride, pad, want_stats, eps=1e-5):
     """gather GEMM; -> (y (B, Do, Ho, Wo, Cout) bf16, mean_rstd (B, 2) fp32 or None)"""
     _need_gpu(xa, xb)
@@ -176,7 +186,11 @@ class ConvFn(_HnoFunction):
         Cout = W.shape[1] if transposed else W.shape[0]
         pad = 0 if ks == 1 else 1
         osz = _out_spatial(tuple(xa.shape[1:4]), ks, stride, transposed)
-        wp = pack_weights(W, 2 if transposed else 0, Cin, Cout, ks)
+        need_dgrad = ctx.needs_input_grad[0] or (xb is not None and ctx.needs_input_grad[1])
+        if need_dgrad:      # the weights do not change between forward and backward: pack both GEMM operands now, in one launch
+            wp, ctx.wpd = pack_weights_both(W, transposed, Cin, Cout, ks)
+        else:
+            wp, ctx.wpd = pack_weights(W, 2 if transposed else 0, Cin, Cout, ks), None
         y, mr = conv_raw(xa, xb, wp, bias, Cout, osz, 1 if transposed else 0, ks, stride, pad, want_stats, eps)
         ctx.save_for_backward(xa, xb, W)
         ctx.cfg = (ks, stride, bool(transposed), pad, bias is not None, Ca, Cb, Cout)
@@ -191,7 +205,7 @@ class ConvFn(_HnoFunction):
         Cin = Ca + Cb
         gxa = gxb = None
         if ctx.needs_input_grad[0] or (xb is not None and ctx.needs_input_grad[1]):
-            wp = pack_weights(W, 3 if transposed else 1, Cin, Cout, ks)
+            wp = ctx.wpd if ctx.wpd is not None else pack_weights(W, 3 if transposed else 1, Cin, Cout, ks)
             gx, _ = conv_raw(gy, None, wp, None, Cin, tuple(xa.shape[1:4]), 0 if transposed else 1, ks, stride, pad, False)
             if xb is None:
                 gxa = gx
