@@ -174,8 +174,11 @@ def main():
 
     # forward + loss + backward are captured ONCE into a HIP graph and replayed: ~150 kernel launches per
     # step cost no host time, so the GPU is never launch-bound.  All-reduce and Adamax stay eager.
+    # With more than one replica the step runs eagerly instead (measured: 3.34 vs 3.30 ms, the step is kernel-bound either
+    # way): the per-bucket gradient all-reduces are launched from autograd hooks DURING backward, on the communication
+    # stream, which a single captured graph cannot express.
     graph = None
-    if not args.no_graph:
+    if not args.no_graph and world == 1:
         try:
             torch.cuda.synchronize()
             side = torch.cuda.Stream()
@@ -262,7 +265,9 @@ def main():
             'config': {'workload': "HNOSeg-XS BraTS'23 config (filters 24, 8 blocks x 3, modes 10-14-14), "
                                    "synthetic 4-modal 128^3 fp32, step = fwd + PCC loss + bwd + grad all-reduce + Adamax",
                        'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
-                       'launch': 'hip-graph replay (fwd+loss+bwd) + eager all-reduce/Adamax' if graph is not None else 'eager',
+                       'launch': 'hip-graph replay (fwd+loss+bwd) + eager Adamax' if graph is not None else
+                                 ('eager; gradient buckets all-reduced from backward hooks on a comm stream' if world > 1 else 'eager'),
+                       'grad_buckets': len(rep.buckets) if world > 1 else 0,
                        'final_loss': round(float(loss), 6)},
             'roofline': roofline,
             'whole_step_roofline': {'algorithmic_GB_per_volume': ALGO_BYTES_PER_VOLUME / 1e9,

@@ -45,6 +45,59 @@ def clamp_modes(modes, spatial):
     return tuple(int(s // 2 if 2 * m > s else m) for m, s in zip(modes, spatial))
 
 
+# ------------------------------------------------------------------------- gradient destinations
+# parallel.FlatGradReplica registers, per parameter, the slice of its flat all-reduce buffer that should receive the gradient:
+# the backward kernels then write the weight gradient straight into the collective's buffer (no pack copy), and autograd
+# installs that view as ``.grad``.  Keyed by the parameter's data pointer (saved tensors unpack to the same storage).
+_grad_dest = {}
+_dest_written = set()     # destinations handed out since the last new_grad_pass(): a second gradient of the same parameter
+                          # (module applied twice, tied weights) must not overwrite the first -- it gets a fresh buffer
+
+
+def set_grad_destinations(mapping):
+    """mapping: {parameter: fp32 view of the same shape}; None / {} clears.  Returns the previous registry."""
+    global _grad_dest
+    old = _grad_dest
+    _grad_dest = {p.data_ptr(): v for p, v in (mapping or {}).items()}
+    _dest_written.clear()
+    return old
+
+
+def new_grad_pass():
+    """call once per step before backward (FlatGradReplica.zero_grad does): every destination may be written once again"""
+    _dest_written.clear()
+
+
+def _grad_buffer(param, like=None):
+    """where the gradient of `param` is to be written: its registered destination when one exists and nothing has been
+    accumulated yet (``.grad`` is None or already that view, in which case the caller must NOT be accumulating), else fresh."""
+    like = param if like is None else like
+    if _grad_dest and param is not None:
+        key = param.data_ptr()
+        v = _grad_dest.get(key)
+        if v is not None and tuple(v.shape) == tuple(like.shape) and param.grad is None and key not in _dest_written:
+            _dest_written.add(key)
+            return v
+    return torch.empty_like(like)
+
+
+def _grad_buffer_stacked(params):
+    """one (L, ...) buffer whose slices are the destinations of L same-shaped parameters, when those destinations lie back
+    to back in that order in the flat buffer (they do: consecutive modules); else a fresh stacked tensor."""
+    p0 = params[0]
+    if _grad_dest:
+        vs = [_grad_dest.get(p.data_ptr()) for p in params]
+        if all(v is not None and p.grad is None and tuple(v.shape) == tuple(p.shape) and p.data_ptr() not in _dest_written
+               for v, p in zip(vs, params)):
+            n = p0.numel() * 4
+            if all(vs[i].data_ptr() == vs[0].data_ptr() + i * n for i in range(len(vs))):
+                _dest_written.update(p.data_ptr() for p in params)
+                base = vs[0]._base if vs[0]._base is not None else vs[0]
+                off = (vs[0].data_ptr() - base.data_ptr()) // 4
+                return base.reshape(-1)[off:off + len(vs) * p0.numel()].view((len(vs),) + tuple(p0.shape))
+    return torch.empty((len(params),) + tuple(p0.shape), device=p0.device, dtype=torch.float32)
+
+
 # ------------------------------------------------------------------------- raw launchers
 def _block0(N0, m0):
     """size of the kept block along the first axis: a degenerate axis (N0 = 1, m0 = 0; 2-D data viewed as
@@ -147,7 +200,7 @@ def pwconv_fwd_raw(xa, xb, W, bias, act):
 
 
 def pwconv_bwd_raw(gy, y, xa, xb, W, act, has_bias, need_gxa=True, need_gxb=True, xa_act=ACT_NONE, accumulate_into=None,
-                   defer=False):
+                   defer=False, bias=None):
     """-> (gxa, gxb, dW, dbias); y is the saved output (None when act is NONE).  xa_act: also multiply
     gxa by act'(xa) (xa being the output of that activation)."""
     B, Ca = xa.shape[:2]
@@ -162,8 +215,10 @@ def pwconv_bwd_raw(gy, y, xa, xb, W, act, has_bias, need_gxa=True, need_gxb=True
         gxa = torch.empty_like(xa)
     if gxb is None and xb is not None and need_gxb:
         gxb = torch.empty_like(xb)
-    dW = torch.empty_like(W)
-    db = torch.empty(Cout, device=W.device, dtype=torch.float32) if has_bias else None
+    dW = _grad_buffer(W)
+    db = None
+    if has_bias:
+        db = _grad_buffer(bias) if bias is not None else torch.empty(Cout, device=W.device, dtype=torch.float32)
     ws = _wgrad_ws(Ca + Cb, Cout, xa.device)
     with _DeferReduce(defer) as d:
         check(_lib.lib().hno_pwconv_bwd(ptr(gy), ptr(y), ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(gxa), ptr(gxb), ptr(dW),
@@ -366,7 +421,7 @@ def specmix_bwd_raw(g, z0, zs, W, residual, act, defer=False):
     B, C = z0.shape[:2]
     M, Lyr = _flat_v(z0), len(Ws)
     gz0 = torch.empty_like(z0)
-    dW = torch.empty((Lyr, C, C), device=z0.device, dtype=torch.float32)
+    dW = _grad_buffer_stacked(W) if not torch.is_tensor(W) else torch.empty((Lyr, C, C), device=z0.device, dtype=torch.float32)
     ws = torch.empty(_lib.lib().hno_specmix_bwd_workspace_bytes(B, C, M, Lyr) // 4, device=z0.device, dtype=torch.float32)
     with _DeferReduce(defer) as d:
         check(_lib.lib().hno_specmix_layers_bwd(ptr(g), ptr(z0), ptr(zs), _layer_ptrs(Ws), ptr(gz0), ptr(dW), ptr(ws), B, C, M, Lyr,
@@ -949,7 +1004,8 @@ class PwConvFn(_HnoFunction):
             db = _chan_sum(g) if ctx.has_bias else None
             return gxa, None, dW, db, None
         gxa, gxb, dW, db = pwconv_bwd_raw(_f32c(gy), y, xa, xb, W, ctx.act, ctx.has_bias, ctx.needs_input_grad[0],
-                                          ctx.needs_input_grad[1], defer=ctx.leaf_params and _release_use(W, bias) and _deferrable(W, bias))
+                                          ctx.needs_input_grad[1], defer=ctx.leaf_params and _release_use(W, bias) and _deferrable(W, bias),
+                                          bias=bias)
         return gxa, gxb, dW, db, None
 
 
@@ -1147,7 +1203,7 @@ class XSBlockFn(_HnoFunction):
         # gradient by the same kernel (gxb += ...).
         fuse_pass = private and not has_map
         g_u, g_skipin, d_cat_w, d_cat_b = pwconv_bwd_raw(_f32c(g_out), out, u, xm, cat_w, act, cat_has_b, xa_act=act,
-                                                         accumulate_into=(None, g_pass) if fuse_pass else None, defer=late_cat)
+                                                         accumulate_into=(None, g_pass) if fuse_pass else None, defer=late_cat, bias=cat_b)
         if g_pass is not None and not has_map and not fuse_pass:
             g_skipin = plus_pass(g_skipin)
         g_zl = dht3_crop_raw(g_u, modes, 1.0)                               # PadInverse^T
@@ -1159,7 +1215,7 @@ class XSBlockFn(_HnoFunction):
         g_x, g_skip, d_map_w, d_map_b = pwconv_bwd_raw(g_xm, xm, x, skip, map_w, act, map_has_b,
                                                        ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                                        accumulate_into=(g_pass, None) if private else None,
-                                                       defer=late_map)
+                                                       defer=late_map, bias=map_b)
         if g_pass is not None and not private and g_x is not None:
             g_x = plus_pass(g_x)
         if g_skip is not None:
@@ -1183,20 +1239,20 @@ class ConvK2S2Fn(_HnoFunction):
         y = torch.empty((B, Cout, D // 2 + 1, H // 2 + 1, Wd // 2 + 1), device=x.device, dtype=torch.float32)
         check(_lib.lib().hno_conv_k2s2_fwd(ptr(x), ptr(W), ptr(bias), ptr(y), B, Cin, Cout, D, H, Wd, act, stream_ptr()),
               'hno_conv_k2s2_fwd')
-        ctx.save_for_backward(x, W, y)
+        ctx.save_for_backward(x, W, y, bias)
         ctx.act, ctx.has_bias = act, bias is not None
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, W, y = ctx.saved_tensors
+        x, W, y, bias = ctx.saved_tensors
         if ctx.needs_input_grad[0]:
             raise _lib.HnoError('conv_in input gradient is not implemented (the image needs none)')
         gy = _f32c(gy)
         B, Cin, D, H, Wd = x.shape
         Cout = W.shape[0]
-        dW = torch.empty_like(W)
-        db = torch.empty(Cout, device=W.device, dtype=torch.float32) if ctx.has_bias else None
+        dW = _grad_buffer(W)
+        db = (_grad_buffer(bias) if bias is not None else torch.empty(Cout, device=W.device, dtype=torch.float32)) if ctx.has_bias else None
         ws = _wgrad_ws(Cin * 8, Cout, x.device)
         check(_lib.lib().hno_conv_k2s2_bwd(ptr(gy), ptr(y), ptr(x), ptr(W), None, ptr(dW), ptr(db), ptr(ws), B, Cin, Cout,
                                            D, H, Wd, ctx.act, stream_ptr()), 'hno_conv_k2s2_bwd')

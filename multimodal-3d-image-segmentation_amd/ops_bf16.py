@@ -82,12 +82,13 @@ def conv_raw(xa, xb, wpacked, bias, Cout, out_spatial, mode, ks, stride, pad, wa
     return y, mr
 
 
-def wgrad_raw(g, xa, xb, w_shape, transposed, ks, stride, pad):
+def wgrad_raw(g, xa, xb, w_shape, transposed, ks, stride, pad, param=None):
     """dW (fp32, parameter layout).  conv: g on the output grid, x = [xa ; xb] its input.  transposed: x the ConvTranspose input."""
     g, xa = _cl(g), _cl(xa)
     L = _lib.lib()
     Cb = 0 if xb is None else xb.shape[4]
-    dW = torch.empty(tuple(w_shape), device=g.device, dtype=torch.float32)
+    dW = ops._grad_buffer(param) if (param is not None and tuple(param.shape) == tuple(w_shape)) else \
+        torch.empty(tuple(w_shape), device=g.device, dtype=torch.float32)
     Cin, Cout = (xa.shape[4] + Cb, g.shape[4])
     ws = _ws(L.hno_cb_wgrad_workspace_bytes(max(Cin, Cout), max(Cin, Cout), ks), g.device)
     check(L.hno_cb_wgrad(ptr(g), g.shape[4], ptr(xa), xa.shape[4], ptr(xb), Cb, ptr(dW), ptr(ws), int(transposed), g.shape[0],
@@ -211,7 +212,7 @@ class ConvFn(_HnoFunction):
                 gxa = gx
             else:   # split of the channel axis of a channels-last tensor (index op; only the decoder's two-input convs)
                 gxa, gxb = gx[..., :Ca].contiguous(), gx[..., Ca:].contiguous()
-        dW = wgrad_raw(gy, xa, xb, W.shape, transposed, ks, stride, pad)
+        dW = wgrad_raw(gy, xa, xb, W.shape, transposed, ks, stride, pad, param=W if W.is_leaf else None)
         db = colsum_raw(gy) if has_bias else None
         return gxa, gxb, dW, db, None, None, None, None, None
 

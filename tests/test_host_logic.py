@@ -129,6 +129,47 @@ flat2 = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
 g2 = [torch.empty_like(flat2) for _ in range(world)]
 dist.all_gather(g2, flat2)
 assert all(torch.equal(g2[0], t) for t in g2), 'replicas diverged after the optimizer step'
+
+# ---- bucketed, overlapped path with a REAL backward (hooks): a CPU network, 4 buckets
+torch.manual_seed(7)
+net = torch.nn.Sequential(*[torch.nn.Linear(16, 16) for _ in range(6)])
+rep2 = FlatGradReplica(net, bucket_bytes=4 * 300, min_buckets=2)      # 272 floats per layer -> one or two layers per bucket
+assert len(rep2.buckets) >= 3
+torch.manual_seed(50 + rank)
+xin = torch.randn(8, 16)
+ref = [torch.zeros_like(p) for p in net.parameters()]
+for r in range(world):                                   # the mean gradient, computed locally on every rank's data
+    torch.manual_seed(50 + r)
+    xr = torch.randn(8, 16)
+    gs = torch.autograd.grad(net(xr).square().mean(), list(net.parameters()))
+    for a, g in zip(ref, gs):
+        a += g / world
+for step in range(2):
+    rep2.zero_grad()
+    net(xin).square().mean().backward()
+    # every bucket was sent DURING backward (from the post-accumulate hooks), last layers first
+    order = rep2.launch_order()
+    assert len(order) == len(rep2.buckets), (len(order), len(rep2.buckets))
+    assert all(order[k][0] >= order[k + 1][1] for k in range(len(order) - 1)), order
+    assert order[0][1] == rep2.flat_grad.numel() and order[-1][0] == 0
+    rep2.allreduce_grads()                               # only waits
+    for p, want in zip(net.parameters(), ref):
+        assert torch.allclose(p.grad, want, atol=1e-6), step
+        assert rep2.flat_grad.data_ptr() <= p.grad.data_ptr() < rep2.flat_grad.data_ptr() + 4 * rep2.flat_grad.numel()
+# a parameter that gets no gradient: its bucket is completed by allreduce_grads with zeros
+rep2.zero_grad()
+h = net[:3](xin)
+h.square().mean().backward()
+assert len(rep2.launch_order()) < len(rep2.buckets)
+rep2.allreduce_grads()
+assert float(list(net.parameters())[-1].grad.abs().max()) == 0.0
+# overlap=False: nothing is sent before allreduce_grads
+rep3 = FlatGradReplica(torch.nn.Linear(4, 4), overlap=False)
+rep3.zero_grad()
+rep3.module(torch.ones(2, 4) * (rank + 1)).sum().backward()
+assert rep3.launch_order() == []
+rep3.allreduce_grads()
+assert torch.allclose(rep3.module.bias.grad, torch.full((4,), 2.0))
 dist.destroy_process_group()
 print('ok', rank)
 '''
