@@ -148,6 +148,36 @@ def make_train_input():
     return _TrainInput()
 
 
+# ---- inference protocol case (golden G14): the reference's testing() on three deterministic samples, batch size 1
+TEST_CASE = {
+    'model': dict(in_channels=2, out_channels=3, filters=8, num_transform_blocks=[1, 1, 1, 1], num_modes=(3, 4, 4)),
+    'image_size': (20, 24, 28), 'num_test': 3, 'mapping': {1: 5, 2: 9},
+}
+
+
+class _TestInput:
+    """Duck type of the reference's InputData for testing() (train_test.py:359-366): batch size 1, (x, y) pairs."""
+    batch_size = 1
+
+    def __init__(self):
+        self.data_lists_test = [[f'case_{i}' for i in range(TEST_CASE['num_test'])]]
+
+    def get_test_num_batches(self):
+        return TEST_CASE['num_test']
+
+    def get_test_flow(self):
+        import torch
+        size, cin = TEST_CASE['image_size'], TEST_CASE['model']['in_channels']
+        for i in range(TEST_CASE['num_test']):
+            x = formula_volume((1, cin) + size, 70 + i)
+            y = formula_labels((1, 1) + size, TEST_CASE['model']['out_channels'], 80 + i)
+            yield torch.from_numpy(x), torch.from_numpy(y)
+
+
+def make_test_input():
+    return _TestInput()
+
+
 # tiny NeuralOperatorSeg variants (golden G7): name -> (ctor kwargs, input shape)
 NOSEG_MODELS = {
     'hnoseg': (dict(in_channels=2, out_channels=3, filters=8, num_transform_blocks=3, num_modes=(4, 5, 5),

@@ -620,9 +620,39 @@ def g8_training():
     save('g8_training.npz', **out)
 
 
+# --------------------------------------- G14: the reference's testing() protocol (train_test.py:332-426)
+def g14_testing():
+    """Class maps exactly as the reference's own ``testing()`` produces them (model.eval(), batch 1, host arg max, label
+    remapping), captured from its ``save_output`` calls, plus the top-2 probability margin per voxel so that the comparison
+    can leave out voxels that are numerically tied."""
+    import tempfile
+    _stub_missing_modules()
+    from experiments import train_test as ref_tt
+    from _inputs import TEST_CASE, make_test_input
+    captured = {}
+    ref_tt.save_output = lambda arr, lists, i, d, origin, suffix: captured.__setitem__((i, suffix), np.asarray(arr).copy())
+    torch.cuda.max_memory_reserved = lambda *a, **k: 0        # the reference prints CUDA statistics; there is no GPU here
+    torch.cuda.max_memory_allocated = lambda *a, **k: 0
+    torch.manual_seed(21)
+    model = nets.HNOSegXS(**TEST_CASE['model'])
+    out = {f'sd::{k}': v.detach().numpy().copy() for k, v in model.state_dict().items()}
+    with tempfile.TemporaryDirectory() as d:
+        ref_tt.testing(model, make_test_input(), d, label_mapping=TEST_CASE['mapping'], is_print=False, device='cpu')
+        out['files'] = np.array(sorted(os.listdir(d)))
+    model.eval()
+    for i, (x, y) in enumerate(make_test_input().get_test_flow()):
+        out[f'pred_{i}'] = captured[(i, '_pred')].astype(np.uint8)
+        out[f'true_{i}'] = captured[(i, '_true')].astype(np.uint8)
+        with torch.no_grad():
+            p = model(x).double()[0]
+        top2 = torch.topk(p, 2, dim=0).values
+        out[f'margin_{i}'] = (top2[0] - top2[1]).numpy().astype(np.float32)
+    save('g14_testing.npz', **out)
+
+
 if __name__ == '__main__':
     ALL = [g1_dht, g2_crop_pad, g3_operators, g4_mha, g5_losses, g6_hnosegxs, g6_128, g6s_small_models, g6b_xsblock_branch, g7_noseg_models,
-           g7v_vnet_models, g7b_bf16_models, g9_misc, g10_two_d, g11_input, g12_mha_bias, g13_models_2d, g8_training]
+           g7v_vnet_models, g7b_bf16_models, g9_misc, g10_two_d, g11_input, g12_mha_bias, g13_models_2d, g8_training, g14_testing]
     only = set(sys.argv[2:])   # e.g. `make_golden.py /root/reference g10_two_d` regenerates one fixture
     for fn in ALL:
         if not only or fn.__name__ in only:

@@ -38,6 +38,7 @@ for name in which:
         torch.cuda.synchronize(); t0 = time.time(); n = 5
         for _ in range(n): l = step()
         torch.cuda.synchronize(); dt = (time.time() - t0) / n
+        lval = float(l.detach()); del l      # a live loss keeps last step's AccumulateGrad nodes (default stream) alive: that breaks the capture below
         # the same step replayed from a HIP graph (no host launch cost: what bench.py does for the headline config)
         dt_graph = None
         try:
@@ -58,7 +59,7 @@ for name in which:
         top = sorted(kp.summary().items(), key=lambda kv: -kv[1][1])[:8]
         print(json.dumps({'model': name, 'shape': shape, 'params': sum(p.numel() for p in model.parameters()),
                           'ms_per_step': round(dt * 1e3, 2), 'ms_per_step_graph': None if dt_graph is None else round(dt_graph * 1e3, 2),
-                          'volumes_per_s': round(shape[0] / (dt_graph or dt), 2), 'loss': round(float(l), 5),
+                          'volumes_per_s': round(shape[0] / (dt_graph or dt), 2), 'loss': round(lval, 5),
                           'max_mem_GB': round(torch.cuda.max_memory_allocated() / 1e9, 2),
                           'top_kernels_ms': {k: round(v[1], 2) for k, v in top},
                           'algorithmic_TFLOPs_or_TBps': {k: round(v[3] / (v[1] * 1e-3) / 1e12, 1) for k, v in top if v[3]}}))
