@@ -287,6 +287,16 @@ int hno_permode_bwd(const float *g, const float *x, const float *xr, const float
 int hno_bmm(const float *A, const float *B, float *C, int batch, int M, int N, int K, int transA, int transB,
             float alpha, void *stream);
 
+/* Fused Hartley attention: out[c][q] = sum_k v[c][k] act(alpha sum_c' q[c'][q] k[c'][k]) per (batch, head) = BZ pairs, the
+ * T x T attention matrix never materialised (forward and backward recompute its 32 x 32 tiles on the fp32 matrix cores).
+ * q, k (BZ, Ck, T); v, out, dout (BZ, Cv, T); Ck, Cv <= 128 (hno_hmha_supported).  Replaces nets/hartley_mha.py:196-201
+ * (einsum 'bzcq,bzck->bzqk' / sqrt(C), attention activation -- SELU, not softmax --, einsum 'bzqk,bzck->bzcq') and its backward. */
+int hno_hmha_supported(int Ck, int Cv);
+int hno_hmha_fwd(const float *q, const float *k, const float *v, float *out, int BZ, int Ck, int Cv, int T, float alpha, int act,
+                 void *stream);
+int hno_hmha_bwd(const float *q, const float *k, const float *v, const float *dout, float *dq, float *dk, float *dv, int BZ, int Ck,
+                 int Cv, int T, float alpha, int act, void *stream);
+
 /* ------------------------------------------------------------------- elementwise helpers
  * y = act(x) ; gx = g * act'(y) (y = saved output) ; out = a + b.  Used where the reference applies an
  * activation or a residual add that no neighbouring kernel can absorb (nets/architectures.py:529-546). */

@@ -41,7 +41,7 @@ enum KernelId {
     KID_DHT_FWD_PLANE = 0, KID_DHT_FWD_D, KID_DHT_INV_D, KID_DHT_INV_PLANE, KID_PWCONV_FWD, KID_PWCONV_BWD,
     KID_CONV_K2S2_FWD, KID_CONV_K2S2_BWD, KID_UPSOFTMAX_FWD, KID_UPSOFTMAX_BWD, KID_LOSS_STATS, KID_LOSS_FINALIZE,
     KID_LOSS_BWD, KID_LABELS, KID_SPECMIX_FWD, KID_SPECMIX_BWD, KID_REDUCE_PARTIALS, KID_UPSOFTMAX_BWD_D, KID_BMM, KID_PERMODE_FWD, KID_PERMODE_BWD, KID_CONV3D_GEMM,
-    KID_CONV3D_WGRAD, KID_GROUPNORM, KID_RESAMPLE, KID_CB_CONV, KID_CB_WGRAD, KID_CB_GN, KID_COUNT
+    KID_CONV3D_WGRAD, KID_GROUPNORM, KID_RESAMPLE, KID_CB_CONV, KID_CB_WGRAD, KID_CB_GN, KID_HMHA, KID_COUNT
 };
 struct ProfScope {
     int slot;

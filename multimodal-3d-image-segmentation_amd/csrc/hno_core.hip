@@ -62,7 +62,7 @@ static const char *kKernelNames[KID_COUNT] = {
     "pwconv_bwd_kernel", "conv_k2s2_fwd_kernel", "conv_k2s2_bwd_kernel", "upsoftmax_fwd_kernel", "upsoftmax_bwd_kernel",
     "loss_stats_kernel", "loss_finalize_kernel", "loss_bwd_kernel", "labels_kernel", "specmix_fwd_kernel", "specmix_bwd_kernel", "reduce_partials_kernel", "upsoftmax_bwd_d_kernel", "bmm_kernel", "permode_fwd_kernel", "permode_bwd_kernels",
     "conv3d_gemm_kernel", "conv3d_wgrad_kernels", "groupnorm_kernels", "resample_kernels", "cb_conv_bf16_kernel", "cb_wgrad_bf16_kernel",
-    "cb_groupnorm_bf16_kernels"};
+    "cb_groupnorm_bf16_kernels", "hmha_kernel"};
 static bool g_prof_on = false;
 static std::vector<hipEvent_t> g_prof_events;  // 2 per record
 static std::vector<int> g_prof_ids;

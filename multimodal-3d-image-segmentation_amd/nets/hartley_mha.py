@@ -149,10 +149,15 @@ class HartleyMultiHeadAttention(Module):
             q, k, v = (grouping3d(t, patch) for t in (q, k, v))
         freq_shape = tuple(q.shape[3:])
         q, k, v = (t.reshape(t.shape[0], Z, t.shape[2], -1).contiguous() for t in (q, k, v))   # (B, Z, C', T)
-        att = ops.BmmFn.apply(q, k, True, False, 1.0 / math.sqrt(k.shape[2]))                  # (B, Z, Tq, Tk)
-        if act_att != ops.ACT_NONE:
-            att = ops.ActFn.apply(att, act_att)
-        out = ops.BmmFn.apply(v, att, False, True, 1.0)                                         # (B, Z, C', Tq)
+        alpha = 1.0 / math.sqrt(k.shape[2])
+        if q.is_meta or (q.shape[3] == k.shape[3] and ops.hmha_supported(q.shape[2], v.shape[2])):
+            # fused: QK^T -> scale -> activation -> .V in one kernel each way, the (T, T) matrix is never written
+            out = ops.HartleyAttentionFn.apply(q, k, v, alpha, act_att)                           # (B, Z, C', Tq)
+        else:   # > 128 grouped channels per head: batched GEMMs with the attention matrix in memory
+            att = ops.BmmFn.apply(q, k, True, False, alpha)                                      # (B, Z, Tq, Tk)
+            if act_att != ops.ACT_NONE:
+                att = ops.ActFn.apply(att, act_att)
+            out = ops.BmmFn.apply(v, att, False, True, 1.0)                                     # (B, Z, C', Tq)
         out = out.reshape(out.shape[0], Z, out.shape[2], *freq_shape)
         if patch is not None:
             out = ungrouping3d(out, self.value_dim, patch)

@@ -850,6 +850,44 @@ class BmmFn(_HnoFunction):
         return dA, dB, None, None, None
 
 
+class HartleyAttentionFn(_HnoFunction):
+    """out = V att^T, att = act(alpha Q^T K), per (batch, head): q, k (B, Z, Ck, T), v (B, Z, Cv, T) -> (B, Z, Cv, T)
+    (nets/hartley_mha.py:196-201).  One fused launch each way (hno_hmha_fwd / hno_hmha_bwd): the (B, Z, T, T) attention
+    matrix is never written, the backward recomputes it; only q, k, v are saved."""
+
+    @staticmethod
+    def meta(q, k, v, alpha, act):
+        return _m(v.shape)
+
+    @staticmethod
+    def forward(ctx, q, k, v, alpha, act):
+        q, k, v = _f32c(q), _f32c(k), _f32c(v)
+        _need_gpu(q, k, v)
+        B, Z, Ck, T = q.shape
+        Cv = v.shape[2]
+        assert k.shape == q.shape and v.shape[:2] == q.shape[:2] and v.shape[3] == T
+        out = torch.empty_like(v)
+        check(_lib.lib().hno_hmha_fwd(ptr(q), ptr(k), ptr(v), ptr(out), B * Z, Ck, Cv, T, float(alpha), act, stream_ptr()), 'hno_hmha_fwd')
+        ctx.save_for_backward(q, k, v)
+        ctx.cfg = (float(alpha), act)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v = ctx.saved_tensors
+        alpha, act = ctx.cfg
+        g = _f32c(g)
+        B, Z, Ck, T = q.shape
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        check(_lib.lib().hno_hmha_bwd(ptr(q), ptr(k), ptr(v), ptr(g), ptr(dq), ptr(dk), ptr(dv), B * Z, Ck, v.shape[2], T, alpha, act,
+                                      stream_ptr()), 'hno_hmha_bwd')
+        return dq, dk, dv, None, None
+
+
+def hmha_supported(Ck, Cv):
+    return bool(_lib.lib().hno_hmha_supported(int(Ck), int(Cv)))
+
+
 class ActFn(_HnoFunction):
 
     @staticmethod

