@@ -1147,7 +1147,7 @@ def test_fused_hartley_attention_vs_float64(pkg, shape, act):
             # 1.76 and an fp32 and a float64 evaluation legitimately pick different sides (each flip moves one dQ / dK entry
             # by O(1)).  Bound the error in norm and the number of such entries instead of the maximum.
             assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-3      # measured 1.9e-4 = one or two flipped entries
-            assert float((np.abs(a - b) > 1e-4 * np.abs(b).max()).mean()) < 1e-4
+            assert float((np.abs(a - b) > 1e-4 * np.abs(b).max()).mean()) < 1e-3          # a flip touches one 96-entry column
         else:
             assert rel_err(a, b) < 1e-4
 
