@@ -1147,7 +1147,7 @@ extern "C" int hno_cb_gn_apply(const void *y1, const float *mr1, const float *ga
     return HNO_OK;
 }
 
-#define CB_GN_BWD_BLOCKS 256
+#define CB_GN_BWD_BLOCKS 1024     // upper bound; small tensors use fewer (>= 64 voxels per workgroup)
 extern "C" size_t hno_cb_gn_bwd_workspace_bytes(int B, int C) {
     return ((size_t)B * CB_GN_BWD_BLOCKS * 2 * C + 2 * (size_t)B * C + 2 * (size_t)(B > 8 ? B : 8)) * sizeof(float) + 256;
 }
@@ -1161,8 +1161,10 @@ extern "C" int hno_cb_gn_bwd(const void *dz, const void *y, const float *mr, con
     hipStream_t s = (hipStream_t)stream;
     float *slab = (float *)workspace;
     float *gS = slab + (size_t)B * CB_GN_BWD_BLOCKS * 2 * C;
-    int nblk = CB_GN_BWD_BLOCKS;
-    if (V < nblk) nblk = (int)V;
+    // a streaming pass: enough workgroups to cover the latency (256 of them left one workgroup per CU: 0.9 TB/s)
+    int nblk = (int)((V + 63) / 64);
+    if (nblk > CB_GN_BWD_BLOCKS) nblk = CB_GN_BWD_BLOCKS;
+    if (nblk < 1) nblk = 1;
     {
         ProfScope _ps(KID_CB_GN, s, (double)B * V * C * 4.0);
         hipLaunchKernelGGL(cb_gn_bwd_reduce_kernel, dim3(nblk, B), dim3(256), 256 * 16 * sizeof(float), s, (const bf16_t *)dz, (const bf16_t *)y, mr, gamma,

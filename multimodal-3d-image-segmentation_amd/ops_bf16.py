@@ -196,10 +196,13 @@ class ConvFn(_HnoFunction):
         ctx.save_for_backward(xa, xb, W)
         ctx.cfg = (ks, stride, bool(transposed), pad, bias is not None, Ca, Cb, Cout)
         ctx.mark_non_differentiable(*([mr] if mr is not None else []))
+        ctx.set_materialize_grads(False)      # no zero tensor (one fill kernel per layer) for the statistics output's gradient
         return y, mr
 
     @staticmethod
     def backward(ctx, gy, _gmr):
+        if gy is None:
+            return (None,) * 9
         xa, xb, W = ctx.saved_tensors
         ks, stride, transposed, pad, has_bias, Ca, Cb, Cout = ctx.cfg
         gy = gy.contiguous()
