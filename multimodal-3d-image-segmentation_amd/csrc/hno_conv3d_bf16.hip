@@ -17,6 +17,7 @@
 //   hno_cb_gn_*           GroupNorm(1, C) + ELU/SELU forward (two-branch residual sum fused) and backward
 //   hno_cb_pack_input / hno_cb_unpack   fp32 NCDHW <-> bf16 NDHWC at the two ends of the network
 #include "hno_common.h"
+#include <stdlib.h>
 
 namespace hno {
 
@@ -253,6 +254,8 @@ struct ChArgs {
     int B, Cout, CoP, D, H, W;
     int TH, S, nbands, npos;
     int flip;                 // 1: input gradient (taps mirrored)
+    int ksplit;               // gridDim.z slices of the 24-channel chunks; > 1: fp32 partial sums to `part` [z][b][v][Cout]
+    float *part;
     int dbg;                  // ablation switches (hno_set_debug): 512 skip the staging, 1024 skip the K loop (results WRONG)
 };
 
@@ -295,7 +298,9 @@ __global__ __launch_bounds__(256) void cb_halo_kernel(ChArgs a) {
     const size_t plane = (size_t)a.H * a.W;
     const int row_items = 3 * S;                           // uint4 per image row
     const int nrows_img = (a.npos + S - 1) / S;            // image rows incl. the zero slack behind the third plane
-    for (int cc = 0; cc < nchunk; ++cc) {
+    const int kz = blockIdx.z;
+    const int cc_lo = nchunk * kz / a.ksplit, cc_hi = nchunk * (kz + 1) / a.ksplit;
+    for (int cc = cc_lo; cc < cc_hi; ++cc) {
         const bool from_a = cc * 24 < a.Ca;
         const bf16_t *src = from_a ? a.xa + (size_t)b * a.D * plane * a.Ca + cc * 24 : a.xb + (size_t)b * a.D * plane * a.Cb + (cc * 24 - a.Ca);
         const int Cs = from_a ? a.Ca : a.Cb;
@@ -375,6 +380,17 @@ __global__ __launch_bounds__(256) void cb_halo_kernel(ChArgs a) {
             for (int g = 0; g < 4; ++g) {
                 const int ch = n0 + 32 * n + 8 * g + 4 * h;
                 if (!pok || ch >= a.Cout) continue;          // Cout is a multiple of 8 and ch of 4: a group is all in or all out ... (ch + 3 < Cout when ch < Cout since Cout % 4 == 0)
+                if (a.part) {      // split-K: raw fp32 partial sums (bias from slice 0), finished by cb_splitk_finish_kernel
+                    float4 o;
+                    const bool wb = a.bias && kz == 0;
+                    o.x = acc[m][n][4 * g + 0] + (wb ? a.bias[ch + 0] : 0.f);
+                    o.y = acc[m][n][4 * g + 1] + (wb ? a.bias[ch + 1] : 0.f);
+                    o.z = acc[m][n][4 * g + 2] + (wb ? a.bias[ch + 2] : 0.f);
+                    o.w = acc[m][n][4 * g + 3] + (wb ? a.bias[ch + 3] : 0.f);
+                    const size_t v = ((size_t)b * a.D + od) * plane + (size_t)oh * a.W + ww;
+                    *reinterpret_cast<float4 *>(a.part + ((size_t)kz * a.B * a.D * plane + v) * a.Cout + ch) = o;
+                    continue;
+                }
                 bf16_t o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(256) void cb_halo_kernel(ChArgs a) {
                 *reinterpret_cast<uint2 *>(yrow + ch) = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
             }
     }
-    if (a.stats) {
+    if (a.stats && !a.part) {
         __shared__ float red[8];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -1026,8 +1042,12 @@ extern "C" size_t hno_cb_conv_workspace_bytes(int B, int Cin, int Cout, int Do, 
     const int nq = ks * ks * ks * (Cin / 8), nsteps = ((nq + 1) & ~1) / 2;
     const int kz = cb_pick_ksplit(B, Cout, Vo, nsteps);
     size_t part = kz > 1 ? (size_t)kz * B * Vo * Cout * sizeof(float) : 0;
+    if (ks == 3 && Cin % 24 == 0 && Cin >= 48) {             // the halo-tile kernel may slice the channel chunks 2 or 4 ways
+        const size_t halo_part = (size_t)4 * B * Vo * Cout * sizeof(float);
+        if (halo_part <= ((size_t)96 << 20) && halo_part > part) part = halo_part;
+    }
     // statistics partials: at most one pair per 64-voxel x 32-channel block, or per finish block
-    size_t stats = (size_t)B * (((Vo + 63) / 64) * ((Cout + 31) / 32) + 4096) * 2 * sizeof(float);
+    size_t stats = (size_t)B * (((Vo + 63) / 64) * ((Cout + 31) / 32) + (size_t)Do * Ho * ((Cout + 31) / 32) + 4096) * 2 * sizeof(float);
     return part + stats + 256;
 }
 
@@ -1062,39 +1082,83 @@ extern "C" int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const
     a.stats = mean_rstd ? stats : nullptr;
     int nblk_stats;
     const double flops = 2.0 * B * Vo * (double)Cout * a.ntaps * (Ca + Cb);
-    // halo-tile kernel: 3x3x3, stride 1, same grid in and out, channel chunks of 24, and a grid wide enough to fill the tiles
+    // halo-tile kernel: 3x3x3, stride 1, same grid in and out, channel chunks of 24, and a grid wide enough to fill the tiles.
+    // Tile shape per layer: MT position tiles per wave (band of 128 MT positions), NT channel tiles, and a split of the channel
+    // chunks over gridDim.z -- the largest tiles that still give every CU ~3 workgroups (a 21 x 25 x 17 level with 96 -> 96
+    // channels is 42 workgroups at <2, 3>: 72 TFLOP/s; at <1, 1> x 2 chunk slices 630).
     if (ks == 3 && stride == 1 && pad == 1 && Di == Do && Hi == Ho && Wi == Wo && Ca % 24 == 0 && Cb % 24 == 0 && !(debug_flags() & 256)) {
-        const int MT = 2;
         const int S = Wo + 2;
-        int TH = (4 * MT * 32) / S;                      // the band's positions fill the 4 waves' tiles
-        if (TH > Ho) TH = Ho;
-        const int used = TH * S;
-        if (TH >= 1 && used * 10 >= 4 * MT * 32 * 6) {    // >= 60 % of the tile rows carry positions of the band
-            ChArgs h = {};
-            h.xa = a.xa; h.xb = a.xb; h.Ca = Ca; h.Cb = Cb; h.w = a.w; h.bias = bias; h.y = a.y; h.stats = mean_rstd ? stats : nullptr;
-            h.B = B; h.Cout = Cout; h.CoP = a.CoP; h.D = Do; h.H = Ho; h.W = Wo; h.TH = TH; h.S = S; h.flip = mode; h.dbg = debug_flags();
-            h.nbands = (Ho + TH - 1) / TH;
-            h.npos = (2 * (TH + 2) + 2) * S + 2 + 4 * MT * 32 + 8;
-            if (h.npos < 3 * (TH + 2) * S) h.npos = 3 * (TH + 2) * S;
-            const size_t lds = (size_t)h.npos * 48 + 96 * sizeof(int2);
-            const int NTsel = Cout <= 32 ? 1 : (Cout <= 64 ? 2 : 3);
-            const dim3 g((unsigned)(B * Do * h.nbands), (Cout + 32 * NTsel - 1) / (32 * NTsel));
-            ProfScope _ps(KID_CB_CONV, s, flops);
-            static bool attr[3] = {false, false, false};
-            if (NTsel == 1) {
-                if (lds > 48 * 1024 && !attr[0]) { HNO_CHECK_HIP(hipFuncSetAttribute((const void *)cb_halo_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); attr[0] = true; }
-                hipLaunchKernelGGL((cb_halo_kernel<2, 1>), g, dim3(256), lds, s, h);
-            } else if (NTsel == 2) {
-                if (lds > 48 * 1024 && !attr[1]) { HNO_CHECK_HIP(hipFuncSetAttribute((const void *)cb_halo_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); attr[1] = true; }
-                hipLaunchKernelGGL((cb_halo_kernel<2, 2>), g, dim3(256), lds, s, h);
-            } else {
-                if (lds > 48 * 1024 && !attr[2]) { HNO_CHECK_HIP(hipFuncSetAttribute((const void *)cb_halo_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); attr[2] = true; }
-                hipLaunchKernelGGL((cb_halo_kernel<2, 3>), g, dim3(256), lds, s, h);
+        const int nchunk = (Ca + Cb) / 24;
+        const int ntmax = Cout <= 32 ? 1 : (Cout <= 64 ? 2 : 3);
+        int bMT = 0, bNT = 0, bKS = 0, bTH = 0;
+        double best = 0.0;
+        for (int MT = 2; MT >= 1; --MT)
+            for (int NT = ntmax; NT >= 1; --NT)
+                for (int ksp = 1; ksp <= 4 && ksp <= nchunk; ksp *= 2) {
+                    if (nchunk % ksp) continue;
+                    int TH = (4 * MT * 32) / S;
+                    if (TH > Ho) TH = Ho;
+                    if (TH < 1) continue;
+                    const double util = (double)TH * S / (4 * MT * 32);
+                    if (util < 0.6) continue;
+                    const long long blocks = (long long)B * Do * ((Ho + TH - 1) / TH) * ((Cout + 32 * NT - 1) / (32 * NT)) * ksp;
+                    const double fill = blocks >= 512 ? 1.0 : (double)blocks / 512.0;
+                    // shape factors fitted to a sweep of all shapes over the level-1 / level-2 layers (tools/bench_cb_conv.py with
+                    // HNO_HALO_SHAPE): small bands and many workgroups win (co-resident workgroups run in lockstep, so parallelism
+                    // has to come from the grid), fewer channel tiles re-stage the image, slices add the fp32 round trip
+                    const double shape = (MT == 2 ? 0.95 : 1.0) * (1.0 - 0.1 * (ntmax - NT)) * (ksp == 1 ? 1.0 : (ksp == 2 ? 0.8 : 0.65));
+                    const double score = fill * util * shape;
+                    if (score > best) { best = score; bMT = MT; bNT = NT; bKS = ksp; bTH = TH; }
+                }
+        if (const char *force = getenv("HNO_HALO_SHAPE")) {      // tuning aid: "MT,NT,KS"
+            int fm = 0, fn = 0, fk = 0;
+            if (sscanf(force, "%d,%d,%d", &fm, &fn, &fk) == 3 && fm >= 1 && fm <= 2 && fn >= 1 && fn <= ntmax && fk >= 1 && nchunk % fk == 0) {
+                int TH = (4 * fm * 32) / S;
+                if (TH > Ho) TH = Ho;
+                if (TH >= 1) { bMT = fm; bNT = fn; bKS = fk; bTH = TH; }
             }
-            HNO_CHECK_LAUNCH();
+        }
+        const size_t part_need = bKS > 1 ? (size_t)bKS * B * Vo * Cout * sizeof(float) : 0;
+        const size_t stat_need = (size_t)B * ((size_t)Do * ((Ho + (bTH ? bTH : 1) - 1) / (bTH ? bTH : 1)) * ((Cout + 32 * (bNT ? bNT : 1) - 1) / (32 * (bNT ? bNT : 1))) + 1024) * 2 * sizeof(float);
+        if (bMT && ((part_need + 255) & ~(size_t)255) + stat_need <= workspace_bytes) {
+            ChArgs h = {};
+            h.xa = a.xa; h.xb = a.xb; h.Ca = Ca; h.Cb = Cb; h.w = a.w; h.bias = bias; h.y = a.y;
+            h.B = B; h.Cout = Cout; h.CoP = a.CoP; h.D = Do; h.H = Ho; h.W = Wo; h.TH = bTH; h.S = S; h.flip = mode; h.dbg = debug_flags();
+            h.nbands = (Ho + bTH - 1) / bTH;
+            h.npos = (2 * (bTH + 2) + 2) * S + 2 + 4 * bMT * 32 + 8;
+            if (h.npos < 3 * (bTH + 2) * S) h.npos = 3 * (bTH + 2) * S;
+            h.ksplit = bKS;
+            h.part = bKS > 1 ? (float *)workspace : nullptr;
+            float *hstats = (float *)((char *)workspace + ((part_need + 255) & ~(size_t)255));
+            h.stats = mean_rstd ? hstats : nullptr;
+            const size_t lds = (size_t)h.npos * 48 + 96 * sizeof(int2);
+            const dim3 g((unsigned)(B * Do * h.nbands), (Cout + 32 * bNT - 1) / (32 * bNT), bKS);
+            {
+                ProfScope _ps(KID_CB_CONV, s, flops);
+#define HNO_HALO_CASE(MTv, NTv)                                                                                                              \
+    if (bMT == MTv && bNT == NTv) {                                                                                                          \
+        static bool attr_set = false;                                                                                                        \
+        if (lds > 48 * 1024 && !attr_set) {                                                                                                  \
+            HNO_CHECK_HIP(hipFuncSetAttribute((const void *)cb_halo_kernel<MTv, NTv>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); \
+            attr_set = true;                                                                                                                 \
+        }                                                                                                                                    \
+        hipLaunchKernelGGL((cb_halo_kernel<MTv, NTv>), g, dim3(256), lds, s, h);                                                             \
+    }
+                HNO_HALO_CASE(2, 1) HNO_HALO_CASE(2, 2) HNO_HALO_CASE(2, 3) HNO_HALO_CASE(1, 1) HNO_HALO_CASE(1, 2) HNO_HALO_CASE(1, 3)
+#undef HNO_HALO_CASE
+                HNO_CHECK_LAUNCH();
+            }
+            int nstat = (int)(Do * h.nbands * g.y);
+            if (bKS > 1) {
+                const long long per_sample = Vo * Cout;
+                const int gx = gsz(per_sample, 256, 1024);
+                hipLaunchKernelGGL(cb_splitk_finish_kernel, dim3(gx, B), dim3(256), 0, s, (const float *)h.part, (bf16_t *)y, mean_rstd ? hstats : nullptr,
+                                   bKS, per_sample, B);
+                HNO_CHECK_LAUNCH();
+                nstat = gx;
+            }
             if (mean_rstd) {
-                hipLaunchKernelGGL(cb_gn_finalize_kernel, dim3(B), dim3(256), 0, s, (const float *)stats, (int)(Do * h.nbands * g.y), (double)Vo * Cout, eps,
-                                   mean_rstd);
+                hipLaunchKernelGGL(cb_gn_finalize_kernel, dim3(B), dim3(256), 0, s, (const float *)hstats, nstat, (double)Vo * Cout, eps, mean_rstd);
                 HNO_CHECK_LAUNCH();
             }
             return HNO_OK;
