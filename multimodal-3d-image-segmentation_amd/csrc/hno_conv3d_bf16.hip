@@ -259,7 +259,7 @@ struct ChArgs {
     int dbg;                  // ablation switches (hno_set_debug): 512 skip the staging, 1024 skip the K loop (results WRONG)
 };
 
-template <int MT, int NT>
+template <int MT, int NT, bool WIDE>
 __global__ __launch_bounds__(256) void cb_halo_kernel(ChArgs a) {
     extern __shared__ uint4 img[];                        // [npos][3] image, then the K-step table int2[96]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -306,18 +306,56 @@ __global__ __launch_bounds__(256) void cb_halo_kernel(ChArgs a) {
         const int Cs = from_a ? a.Ca : a.Cb;
         __syncthreads();                                   // the previous chunk's reads are done
         if (!(a.dbg & 512))
-            for (int row = wave; row < nrows_img; row += 4) {      // one wave per image row: row validity is wave-uniform
-                const int pl = row / rows, rr = row - pl * rows;
-                const int id = od - 1 + pl, ih = oh0 - 1 + rr;
-                const bool rok = pl < 3 && id >= 0 && id < a.D && ih >= 0 && ih < a.H;
-                const bf16_t *rsrc = src + ((size_t)(rok ? id : 0) * plane + (size_t)(rok ? ih : 0) * a.W) * Cs;
-                for (int it = lane; it < row_items; it += 64) {
-                    const int cx = it / 3, part = it - cx * 3;
-                    const int iw = cx - 1;
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (rok && iw >= 0 && iw < a.W) v = *reinterpret_cast<const uint4 *>(rsrc + (size_t)iw * Cs + part * 8);
-                    const int dst = row * row_items + it;
-                    if (dst < a.npos * 3) img[dst] = v;
+            // one wave per image row (row validity is wave-uniform).  On the widest grid the loads of two rows (8 per lane) are
+            // issued back to back from clamped addresses and zeroed by a select afterwards: a load inside an `if` followed by
+            // its LDS store is one exposed global round trip per element (20 of that layer's 120 us)
+            if constexpr (WIDE) {
+                // wide rows (level 0): two rows of this wave per pass, 8 loads per lane in flight
+                for (int row0 = wave; row0 < nrows_img; row0 += 8) {
+                    uint4 v[2][4];
+                    bool okk[2][4];
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) {
+                        const int row = row0 + 4 * rb;
+                        const int pl = row / rows, rr = row - pl * rows;
+                        const int id = od - 1 + pl, ih = oh0 - 1 + rr;
+                        const bool rok = row < nrows_img && pl < 3 && id >= 0 && id < a.D && ih >= 0 && ih < a.H;
+                        const bf16_t *rsrc = src + ((size_t)(rok ? id : 0) * plane + (size_t)(rok ? ih : 0) * a.W) * Cs;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int it = lane + 64 * k;
+                            const int cx = it / 3, part = it - cx * 3;
+                            const int iw = cx - 1;
+                            okk[rb][k] = rok && it < row_items && iw >= 0 && iw < a.W;
+                            v[rb][k] = *reinterpret_cast<const uint4 *>(okk[rb][k] ? rsrc + (size_t)iw * Cs + part * 8 : src);
+                        }
+                    }
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) {
+                        const int row = row0 + 4 * rb;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int it = lane + 64 * k;
+                            const int dst = row * row_items + it;
+                            if (row < nrows_img && it < row_items && dst < a.npos * 3) img[dst] = okk[rb][k] ? v[rb][k] : make_uint4(0, 0, 0, 0);
+                        }
+                    }
+                }
+            } else {
+                // narrow rows (levels 1, 2; many small workgroups): one row per pass (measured faster there than the batched form)
+                for (int row = wave; row < nrows_img; row += 4) {
+                    const int pl = row / rows, rr = row - pl * rows;
+                    const int id = od - 1 + pl, ih = oh0 - 1 + rr;
+                    const bool rok = pl < 3 && id >= 0 && id < a.D && ih >= 0 && ih < a.H;
+                    const bf16_t *rsrc = src + ((size_t)(rok ? id : 0) * plane + (size_t)(rok ? ih : 0) * a.W) * Cs;
+                    for (int it = lane; it < row_items; it += 64) {
+                        const int cx = it / 3, part = it - cx * 3;
+                        const int iw = cx - 1;
+                        uint4 v = make_uint4(0, 0, 0, 0);
+                        if (rok && iw >= 0 && iw < a.W) v = *reinterpret_cast<const uint4 *>(rsrc + (size_t)iw * Cs + part * 8);
+                        const int dst = row * row_items + it;
+                        if (dst < a.npos * 3) img[dst] = v;
+                    }
                 }
             }
         __syncthreads();
@@ -765,6 +803,8 @@ struct CwArgs {
     int nci;                     // ci blocks per co block when the channel blocks ride on gridDim.y (all of size CO x CI)
     int nbands;                  // bands per (b, od) = ceil(Ho / TH)
     int swap;                    // 1: transposed-conv weight gradient (roles of g and x swapped by the host; informational)
+    int dbg;                     // ablation switches: 512 skip the staging, 1024 skip the K loop (results WRONG)
+    int slide, nseg;             // slide = 1: items are runs of output planes, the input planes slide through a 3-slot ring
 };
 
 // ds_read_b64_tr_b16 through the compiler builtin (it then places the lgkmcnt waits itself).  Per 16-lane group: lane 4q + p
@@ -795,56 +835,111 @@ __global__ __launch_bounds__(256) void cb_wgrad_kernel(CwArgs a) {
 
     const int co0 = a.co0 + (gridDim.y > 1 ? (int)(blockIdx.y / a.nci) * a.CO : 0);
     const int ci0 = a.ci0 + (gridDim.y > 1 ? (int)(blockIdx.y % a.nci) * a.CI : 0);
-    const long long nwork = (long long)a.B * a.Do * a.nbands;
     const int grp = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
-    for (long long wk = blockIdx.x; wk < nwork; wk += gridDim.x) {
-        const int band = (int)(wk % a.nbands);
-        const int od = (int)((wk / a.nbands) % a.Do);
-        const int b = (int)(wk / ((long long)a.nbands * a.Do));
-        const int oh0 = band * a.TH;
-        __syncthreads();   // previous iteration's reads are done
-        // ---- stage G band: rows oh0 .. oh0+TH-1 (zero beyond Ho), columns 0 .. Sg-1 (zero beyond Wo), channels co0 .. co0+CO-1
-        {
-            const int c8n = PG >> 3;
-            const int items = gpos32 * c8n;
-            for (int it = threadIdx.x; it < items; it += 256) {
-                const int c8 = it % c8n, p = it / c8n;
-                const int hh = p / a.Sg, ww = p - hh * a.Sg;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                const int oh = oh0 + hh, ch = c8 * 8;
-                if (p < gpos && oh < a.Ho && ww < a.Wo && ch < a.CO) {
-                    const size_t vo = ((size_t)od * a.Ho + oh) * a.Wo + ww;
-                    v = *reinterpret_cast<const uint4 *>(a.g + ((size_t)b * a.Do * a.Ho * a.Wo + vo) * a.Cg + co0 + ch);
-                }
-                *reinterpret_cast<uint4 *>(gi + (size_t)p * PG + ch) = v;
-            }
-        }
-        // ---- stage X halo: planes id0 .. id0+ks-1, rows ih0 .. ih0+xrows-1, columns iw0 .. iw0+Sx-1 with
-        //      id0 = stride*od - pad, ih0 = stride*oh0 - pad, iw0 = -pad; out-of-range -> zero; the slack is zeroed too.
-        //      (pitch Sx == Sg, see wg_plan)
-        {
-            const int c8n = PX >> 3;
-            const int items = xpos * c8n;
-            const int id0 = a.stride * od - a.pad, ih0 = a.stride * oh0 - a.pad;
-            for (int it = threadIdx.x; it < items; it += 256) {
-                const int c8 = it % c8n, pp = it / c8n;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                const int p = pp - xorg;
-                const int ch = ci0 + c8 * 8;
-                if (p >= 0 && c8 * 8 < a.CI) {
-                    const int pl = p / (a.xrows * a.Sx), rem = p - pl * (a.xrows * a.Sx);
-                    const int rr = rem / a.Sx, cc = rem - rr * a.Sx;
-                    const int id = id0 + pl, ih = ih0 + rr, iw = cc - a.pad;
-                    if (pl < a.xplanes && id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi) {
-                        const size_t vi = ((size_t)b * a.Di + id) * a.Hi * a.Wi + (size_t)ih * a.Wi + iw;
-                        v = ch < a.Ca ? *reinterpret_cast<const uint4 *>(a.xa + vi * a.Ca + ch)
-                                      : *reinterpret_cast<const uint4 *>(a.xb + vi * a.Cb + (ch - a.Ca));
+    // the whole X image once: the slack positions behind the last plane are read (against zeros of G) and never staged again
+    for (int i = threadIdx.x; i < xpos * (PX >> 3); i += 256) reinterpret_cast<uint4 *>(xi)[i] = make_uint4(0, 0, 0, 0);
+    // stage input plane `id` (rows ih0 .. ih0 + xrows - 1, columns -pad .. Sx - pad - 1) into plane slot `slot`: one wave per image
+    // row (the row's validity is wave-uniform), a lane per position, 16-byte loads of the channel block; out of range -> zero
+    auto stage_plane = [&](int b, int id, int ih0, int slot) {
+        const int c8n = (a.CI + 7) >> 3;
+        const bool pok = id >= 0 && id < a.Di;
+        for (int rr = wave; rr < a.xrows; rr += 4) {
+            const int ih = ih0 + rr;
+            const bool rok = pok && ih >= 0 && ih < a.Hi;
+            const size_t vrow = (((size_t)b * a.Di + (rok ? id : 0)) * a.Hi + (rok ? ih : 0)) * a.Wi;
+            bf16_t *drow = xi + ((size_t)xorg + (size_t)(slot * a.xrows + rr) * a.Sx) * PX;
+            for (int cc0 = 0; cc0 < a.Sx; cc0 += 128) {          // two positions per lane and pass, all their loads in flight
+                uint4 v[2][TB * 2];
+                bool okk[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int cc = cc0 + lane + 64 * u;
+                    const int iw = cc - a.pad;
+                    okk[u] = rok && cc < a.Sx && iw >= 0 && iw < a.Wi;
+#pragma unroll
+                    for (int c8 = 0; c8 < TB * 2; ++c8) {
+                        const int ch = ci0 + c8 * 8;
+                        const bool ok = okk[u] && c8 < c8n;
+                        const bf16_t *ptr = !ok ? a.xa : (ch < a.Ca ? a.xa + (vrow + iw) * a.Ca + ch : a.xb + (vrow + iw) * a.Cb + (ch - a.Ca));
+                        v[u][c8] = *reinterpret_cast<const uint4 *>(ptr);
+                        if (!ok) v[u][c8] = make_uint4(0, 0, 0, 0);
                     }
                 }
-                *reinterpret_cast<uint4 *>(xi + (size_t)pp * PX + c8 * 8) = v;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int cc = cc0 + lane + 64 * u;
+                    if (cc < a.Sx)
+#pragma unroll
+                        for (int c8 = 0; c8 < TB * 2; ++c8) *reinterpret_cast<uint4 *>(drow + (size_t)cc * PX + c8 * 8) = v[u][c8];
+                }
             }
         }
+    };
+    auto stage_g = [&](int b, int od, int oh0) {
+        const int c8n = (a.CO + 7) >> 3;
+        const int rows_img = gpos32 / a.Sg + 1;
+        for (int hh = wave; hh < rows_img; hh += 4) {
+            const int oh = oh0 + hh;
+            const bool rok = hh < a.TH && oh < a.Ho;
+            const size_t vrow = (((size_t)b * a.Do + od) * a.Ho + (rok ? oh : 0)) * a.Wo;
+            for (int ww0 = 0; ww0 < a.Sg; ww0 += 128) {
+                uint4 v[2][TA * 2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int ww = ww0 + lane + 64 * u;
+#pragma unroll
+                    for (int c8 = 0; c8 < TA * 2; ++c8) {
+                        const bool ok = rok && ww < a.Wo && c8 < c8n;
+                        v[u][c8] = *reinterpret_cast<const uint4 *>(ok ? a.g + (vrow + ww) * a.Cg + co0 + c8 * 8 : a.g);
+                        if (!ok) v[u][c8] = make_uint4(0, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int ww = ww0 + lane + 64 * u;
+                    const int p = hh * a.Sg + ww;
+                    if (ww < a.Sg && p < gpos32)
+#pragma unroll
+                        for (int c8 = 0; c8 < TA * 2; ++c8) *reinterpret_cast<uint4 *>(gi + (size_t)p * PG + c8 * 8) = v[u][c8];
+                }
+            }
+        }
+    };
+    // work items.  slide = 1 (3x3x3, stride 1): an item is (b, band, a run of consecutive output planes); the three input planes
+    // of a run live in a ring of plane slots and every step stages ONE new plane (the first version staged all three planes of
+    // every (od, band): 155 of 254 us on the largest layer).  slide = 0: an item is one (b, od, band).
+    const long long nwork = a.slide ? (long long)a.B * a.nbands * a.nseg : (long long)a.B * a.Do * a.nbands;
+    for (long long wk = blockIdx.x; wk < nwork; wk += gridDim.x) {
+        int b, band, od_lo, od_hi;
+        if (a.slide) {
+            const int seg = (int)(wk % a.nseg);
+            band = (int)((wk / a.nseg) % a.nbands);
+            b = (int)(wk / ((long long)a.nseg * a.nbands));
+            od_lo = (int)((long long)a.Do * seg / a.nseg);
+            od_hi = (int)((long long)a.Do * (seg + 1) / a.nseg);
+        } else {
+            band = (int)(wk % a.nbands);
+            od_lo = (int)((wk / a.nbands) % a.Do);
+            od_hi = od_lo + 1;
+            b = (int)(wk / ((long long)a.nbands * a.Do));
+        }
+        const int oh0 = band * a.TH;
+        const int ih0 = a.stride * oh0 - a.pad;
+      for (int od = od_lo; od < od_hi; ++od) {
+        __syncthreads();   // previous step's reads are done
+        if (!(a.dbg & 512)) {
+            stage_g(b, od, oh0);
+            if (a.slide) {
+                // input planes od - 1, od, od + 1 live in slots (plane + 1) % 3
+                if (od == od_lo) { stage_plane(b, od - 1, ih0, od % 3); stage_plane(b, od, ih0, (od + 1) % 3); }
+                stage_plane(b, od + 1, ih0, (od + 2) % 3);
+            } else {
+                for (int pl = 0; pl < a.xplanes; ++pl) stage_plane(b, a.stride * od - a.pad + pl, ih0, pl);
+            }
+        }
+        const int slot_rot = a.slide ? od % 3 : 0;         // input plane od - 1 + td sits in slot (od + td) % 3
         __syncthreads();
+        if (a.dbg & 1024) continue;
         // ---- K loop over the band's positions, 32 per step (v_mfma_f32_16x16x32_bf16: lane group grp holds k = 8 grp .. 8 grp + 7)
         for (int p0 = 0; p0 < gpos32; p0 += 32) {
             // A operand = G^T: rows = output channels (16 per tile), k = positions.  Two transposed reads per tile:
@@ -863,7 +958,9 @@ __global__ __launch_bounds__(256) void cb_wgrad_kernel(CwArgs a) {
                 if (tap < a.ntaps) {            // wave-uniform
                     const int ks2 = a.ks * a.ks;
                     const int td = tap / ks2, th = (tap / a.ks) % a.ks, tw = tap % a.ks;
-                    const int base = xorg + (td * a.xrows + th) * a.Sx + tw;
+                    int slot = td + slot_rot;
+                    slot = slot >= 3 ? slot - 3 : slot;
+                    const int base = xorg + (slot * a.xrows + th) * a.Sx + tw;
                     s16x4 bfr[TB][2];
 #pragma unroll
                     for (int j = 0; j < TB; ++j)
@@ -885,6 +982,7 @@ __global__ __launch_bounds__(256) void cb_wgrad_kernel(CwArgs a) {
                 }
             }
         }
+      }
     }
     // ---- slab: [tap][CO][CI] for this block.  C/D of 16x16x32: column (lane & 15) = input channel, rows 4 (lane >> 4) + e = output channel
     float *dst = a.slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * a.ntaps * a.CO * a.CI;
@@ -1135,16 +1233,18 @@ extern "C" int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const
             const dim3 g((unsigned)(B * Do * h.nbands), (Cout + 32 * bNT - 1) / (32 * bNT), bKS);
             {
                 ProfScope _ps(KID_CB_CONV, s, flops);
-#define HNO_HALO_CASE(MTv, NTv)                                                                                                              \
-    if (bMT == MTv && bNT == NTv) {                                                                                                          \
+                const bool wide = 3 * S > 128;      // staging variant (template: the batched form's registers stay out of the narrow kernels)
+#define HNO_HALO_CASE(MTv, NTv, WIDEv)                                                                                                       \
+    if (bMT == MTv && bNT == NTv && wide == WIDEv) {                                                                                         \
         static bool attr_set = false;                                                                                                        \
         if (lds > 48 * 1024 && !attr_set) {                                                                                                  \
-            HNO_CHECK_HIP(hipFuncSetAttribute((const void *)cb_halo_kernel<MTv, NTv>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); \
+            HNO_CHECK_HIP(hipFuncSetAttribute((const void *)cb_halo_kernel<MTv, NTv, WIDEv>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); \
             attr_set = true;                                                                                                                 \
         }                                                                                                                                    \
-        hipLaunchKernelGGL((cb_halo_kernel<MTv, NTv>), g, dim3(256), lds, s, h);                                                             \
+        hipLaunchKernelGGL((cb_halo_kernel<MTv, NTv, WIDEv>), g, dim3(256), lds, s, h);                                                      \
     }
-                HNO_HALO_CASE(2, 1) HNO_HALO_CASE(2, 2) HNO_HALO_CASE(2, 3) HNO_HALO_CASE(1, 1) HNO_HALO_CASE(1, 2) HNO_HALO_CASE(1, 3)
+                HNO_HALO_CASE(2, 1, true) HNO_HALO_CASE(2, 2, true) HNO_HALO_CASE(2, 3, true) HNO_HALO_CASE(1, 1, true) HNO_HALO_CASE(1, 2, true) HNO_HALO_CASE(1, 3, true)
+                HNO_HALO_CASE(2, 1, false) HNO_HALO_CASE(2, 2, false) HNO_HALO_CASE(2, 3, false) HNO_HALO_CASE(1, 1, false) HNO_HALO_CASE(1, 2, false) HNO_HALO_CASE(1, 3, false)
 #undef HNO_HALO_CASE
                 HNO_CHECK_LAUNCH();
             }
@@ -1278,7 +1378,7 @@ extern "C" int hno_cb_colsum(const void *g, float *out, void *workspace, int C, 
 // ---- weight gradient --------------------------------------------------------------------------------------------
 namespace {
 struct WgPlan {
-    int TH, Sg, Sx, xrows, gpos32, xpos, nblk;
+    int TH, Sg, Sx, xrows, gpos32, xpos, nblk, slide, nseg;
     size_t lds;
 };
 // band height: as many output rows as fit in LDS (G band + X halo at the block's channel pitches), at least 1
@@ -1304,9 +1404,19 @@ WgPlan wg_plan(int B, int Do, int Ho, int Wo, int ks, int stride, int pad, int P
     p.gpos32 = (best * p.Sg + 31) & ~31;
     p.xpos = ks * p.xrows * p.Sx + 2 * p.Sx + 64 + stride * 32;
     p.lds = ((size_t)p.gpos32 * PG + (size_t)p.xpos * PX) * 2;
-    const long long nwork = (long long)B * Do * ((Ho + best - 1) / best);
     long long want = 512 / (ny > 0 ? ny : 1);          // ~2 workgroups per CU over all channel blocks
     if (want < 8) want = 8;
+    const int nbands = (Ho + best - 1) / best;
+    p.slide = (ks == 3 && stride == 1) ? 1 : 0;
+    p.nseg = 1;
+    long long nwork = (long long)B * Do * nbands;
+    if (p.slide) {       // runs of output planes: as long as the grid allows (each run re-stages 2 planes at its start)
+        long long nseg = (want + (long long)B * nbands - 1) / ((long long)B * nbands);
+        if (nseg < 1) nseg = 1;
+        if (nseg > Do) nseg = Do;
+        p.nseg = (int)nseg;
+        nwork = (long long)B * nbands * nseg;
+    }
     p.nblk = (int)(nwork < want ? nwork : want);
     return p;
 }
@@ -1364,7 +1474,7 @@ extern "C" int hno_cb_wgrad(const void *g, int Cg, const void *xa, int Ca, const
         a.Do = Dx; a.Ho = Hx; a.Wo = Wx; a.Di = Dg; a.Hi = Hg; a.Wi = Wg;
         CP = Ca; CQ = Cg;
     }
-    a.B = B; a.ks = ks; a.stride = stride; a.pad = pad; a.ntaps = ks * ks * ks; a.swap = transposed;
+    a.B = B; a.ks = ks; a.stride = stride; a.pad = pad; a.ntaps = ks * ks * ks; a.swap = transposed; a.dbg = debug_flags();
     const int T = a.ntaps;
     // parameter layout: conv W[Cout = P][Cin = Q][T]: out_is_axis0 = 1 with (o, i) = (P, Q); transposed Wt[Cin = P][Cout = Q][T] likewise
     const int C1 = CQ;
@@ -1382,7 +1492,7 @@ extern "C" int hno_cb_wgrad(const void *g, int Cg, const void *xa, int Ca, const
         const int ny = uniform ? nco * nci : 1;
         const int TA = (a.CO + 15) / 16, TB = (a.CI + 15) / 16;
         const WgPlan p = wg_plan(B, a.Do, a.Ho, a.Wo, ks, stride, pad, TA * 16, TB * 16, ny);
-        a.TH = p.TH; a.Sg = p.Sg; a.Sx = p.Sx; a.xrows = p.xrows; a.xplanes = ks; a.xpos = p.xpos;
+        a.TH = p.TH; a.Sg = p.Sg; a.Sx = p.Sx; a.xrows = p.xrows; a.xplanes = ks; a.xpos = p.xpos; a.slide = p.slide; a.nseg = p.nseg;
         a.nbands = (a.Ho + p.TH - 1) / p.TH;
         a.slab = (float *)workspace;
         int rc;
