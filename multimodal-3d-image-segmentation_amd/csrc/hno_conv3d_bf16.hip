@@ -1404,8 +1404,11 @@ WgPlan wg_plan(int B, int Do, int Ho, int Wo, int ks, int stride, int pad, int P
     p.gpos32 = (best * p.Sg + 31) & ~31;
     p.xpos = ks * p.xrows * p.Sx + 2 * p.Sx + 64 + stride * 32;
     p.lds = ((size_t)p.gpos32 * PG + (size_t)p.xpos * PX) * 2;
-    long long want = 512 / (ny > 0 ? ny : 1);          // ~2 workgroups per CU over all channel blocks
-    if (want < 8) want = 8;
+    // workgroups per channel block: ~one per CU over all channel blocks.  Every workgroup writes a slab of ntaps x 48 x 48 floats
+    // that the reduce kernel reads back: with 512 / ny (>= 8) workgroups the slabs of a 384 x 384 layer were 127 MB, more traffic
+    // than everything else in that layer
+    long long want = ny <= 1 ? 512 : 256 / ny;        // (single-channel-block layers: measured faster with two rounds of workgroups)
+    if (want < 1) want = 1;
     const int nbands = (Ho + best - 1) / best;
     p.slide = (ks == 3 && stride == 1) ? 1 : 0;
     p.nseg = 1;
@@ -1426,8 +1429,8 @@ extern "C" size_t hno_cb_wgrad_workspace_bytes(int Cin, int Cout, int ks) {
     // slabs [channel block][workgroup][tap][<= 48][<= 48]: at most 512 workgroups over all channel blocks (>= 8 per block)
     const int CO = Cout < 48 ? Cout : 48, CI = Cin < 48 ? Cin : 48;
     const int ny = ((Cout + CO - 1) / CO) * ((Cin + CI - 1) / CI);
-    long long per = 512 / ny;
-    if (per < 8) per = 8;
+    long long per = ny <= 1 ? 512 : 256 / ny;
+    if (per < 1) per = 1;
     return (size_t)per * ny * ks * ks * ks * CO * CI * sizeof(float);
 }
 
