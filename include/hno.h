@@ -241,6 +241,11 @@ size_t hno_cb_packed_weight_bytes(int Cin, int Cout, int ks);
 int hno_cb_pack_weights(const float *W, void *dst, int role, int Cin, int Cout, int ks, void *stream);
 /* roles 0 + 1 (transposed = 0) or 2 + 3 (transposed = 1) in ONE launch: the forward operand and the input-gradient operand */
 int hno_cb_pack_weights_both(const float *W, void *dst_fwd, void *dst_bwd, int transposed, int Cin, int Cout, int ks, void *stream);
+/* all layers of a model in one launch: `table_dev` is an (nrows, 16) int64 device array whose rows were filled on the host by
+ * hno_cb_pack_table_row (parameter pointer, the two destination buffers, layer shape) */
+int hno_cb_pack_table_row(long long *row, const float *W, void *dst_fwd, void *dst_bwd, int transposed, int Cin, int Cout, int ks);
+/* total_chunks = sum over rows of ceil((row[10] * row[9] + row[15] * row[14]) * 8 / 2048): one workgroup per 2048 packed elements */
+int hno_cb_pack_weights_multi(const void *table_dev, int nrows, long long total_chunks, void *stream);
 size_t hno_cb_conv_workspace_bytes(int B, int Cin, int Cout, int Do, int Ho, int Wo, int ks);
 /* y = conv([xa ; xb]) + bias as a gather GEMM.  mode 0: in = stride * out - pad + tap (Conv3d forward, ConvTranspose3d input
  * gradient); mode 1: in = (out + pad - tap) / stride where divisible (ConvTranspose3d forward, Conv3d input gradient).

@@ -521,6 +521,14 @@ __global__ __launch_bounds__(256) void cb_gn_finalize_kernel(const float *__rest
     }
 }
 
+// act'(u) from the PRE-activation u (one exponential; the forward's polynomial expm1 and the output form are not needed here)
+__device__ __forceinline__ float act_grad_from_pre(float u, int act) {
+    const float e = __builtin_amdgcn_exp2f(fminf(u, 0.f) * 1.4426950408889634f);
+    if (act == HNO_ACT_SELU) return u > 0.f ? HNO_SELU_SCALE : (HNO_SELU_SCALE * HNO_SELU_ALPHA) * e;
+    if (act == HNO_ACT_ELU) return u > 0.f ? 1.f : e;
+    return 1.f;
+}
+
 // ------------------------------------------------------------------------------------------------ GroupNorm(1, C) + act
 // z = act(gamma1 (y1 - mean1) rstd1 + beta1) [+ act(gamma2 (y2 - mean2) rstd2 + beta2)], all tensors channels-last bf16,
 // arithmetic fp32.  8 channels (16 bytes) per thread and iteration; C % 8 == 0.
@@ -598,8 +606,7 @@ __global__ __launch_bounds__(256) void cb_gn_bwd_reduce_kernel(const bf16_t *__r
                     const int j = 2 * k + u;
                     const float g = bf2f((bf16_t)(u ? gw[k] >> 16 : gw[k] & 0xffff));
                     const float xh = (bf2f((bf16_t)(u ? yw[k] >> 16 : yw[k] & 0xffff)) - mean) * rstd;
-                    const float out = act_apply(fmaf(xh, gm[j], bt[j]), act);
-                    const float t = g * act_grad_from_out(out, act);
+                    const float t = g * act_grad_from_pre(fmaf(xh, gm[j], bt[j]), act);
                     s1[j] += t;
                     s2[j] = fmaf(t, xh, s2[j]);
                 }
@@ -701,8 +708,7 @@ __global__ __launch_bounds__(256) void cb_gn_bwd_apply_kernel(const bf16_t *__re
                 const int c = c0 + 2 * k + u;
                 const float g = bf2f((bf16_t)(u ? gw[k] >> 16 : gw[k] & 0xffff));
                 const float xh = (bf2f((bf16_t)(u ? yw[k] >> 16 : yw[k] & 0xffff)) - mean) * rstd;
-                const float o = act_apply(fmaf(xh, gamma[c], beta[c]), act);
-                const float t = g * act_grad_from_out(o, act);
+                const float t = g * act_grad_from_pre(fmaf(xh, gamma[c], beta[c]), act);
                 res[u] = rstd * (gamma[c] * t - k1 - xh * k2);
             }
             out[k] = (unsigned)f2bf(res[0]) | ((unsigned)f2bf(res[1]) << 16);
@@ -1110,6 +1116,64 @@ extern "C" int hno_cb_pack_weights_both(const float *W, void *dst_fwd, void *dst
     const int nq1 = T * (Cout / 8), nq21 = (nq1 + 1) & ~1, CoP1 = (Cin + 31) / 32 * 32;
     hipLaunchKernelGGL(cb_pack_weights2_kernel, dim3(gsz((long long)nq20 * CoP0 * 8 + (long long)nq21 * CoP1 * 8)), dim3(256), 0, (hipStream_t)stream, W,
                        (bf16_t *)dst_fwd, (bf16_t *)dst_bwd, C0, C1, T, oa0, Cin, Cout, CoP0, nq20, oa1, Cout, Cin, CoP1, nq21);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+// every layer of a model in ONE launch: `table` is (nrows, 16) int64 on the device:
+//   [W, dst_fwd, dst_bwd, C0, C1, T, oa0, Ci0, Co0, CoP0, nq20, oa1, Ci1, Co1, CoP1, nq21]  (see hno_cb_pack_weights_both)
+__global__ __launch_bounds__(256) void cb_pack_weights_multi_kernel(const long long *__restrict__ table, int nrows) {
+    // workgroup -> (row, chunk of 2048 elements): walk the rows' chunk counts (a few dozen rows)
+    int row_id = 0;
+    long long first = 0;
+    for (; row_id < nrows; ++row_id) {
+        const long long *r = table + (size_t)row_id * 16;
+        const long long n = r[10] * r[9] * 8 + r[15] * r[14] * 8;
+        const long long nb = (n + 2047) / 2048;
+        if ((long long)blockIdx.x < first + nb) break;
+        first += nb;
+    }
+    if (row_id >= nrows) return;
+    const long long *row = table + (size_t)row_id * 16;
+    const float *w = reinterpret_cast<const float *>(row[0]);
+    bf16_t *d0 = reinterpret_cast<bf16_t *>(row[1]), *d1 = reinterpret_cast<bf16_t *>(row[2]);
+    const int C1 = (int)row[4], T = (int)row[5];
+    const int oa0 = (int)row[6], Ci0 = (int)row[7], Co0 = (int)row[8], CoP0 = (int)row[9], nq20 = (int)row[10];
+    const int oa1 = (int)row[11], Ci1 = (int)row[12], Co1 = (int)row[13], CoP1 = (int)row[14], nq21 = (int)row[15];
+    const long long n0 = (long long)nq20 * CoP0 * 8, n1 = (long long)nq21 * CoP1 * 8;
+    const long long lo = ((long long)blockIdx.x - first) * 2048;
+    for (long long idx = lo + threadIdx.x; idx < lo + 2048 && idx < n0 + n1; idx += 256) {
+        const bool second = idx >= n0;
+        const long long k = second ? idx - n0 : idx;
+        const int Ci = second ? Ci1 : Ci0, Co = second ? Co1 : Co0, CoP = second ? CoP1 : CoP0, oa = second ? oa1 : oa0;
+        const int nC8 = Ci / 8;
+        const int j = (int)(k & 7), o = (int)((k >> 3) % CoP), q = (int)((k >> 3) / CoP);
+        const int t = q / nC8, i = (q % nC8) * 8 + j;
+        float v = 0.f;
+        if (t < T && o < Co) {
+            const int c0 = oa ? o : i, c1 = oa ? i : o;
+            v = w[((size_t)c0 * C1 + c1) * T + t];
+        }
+        (second ? d1 : d0)[k] = f2bf(v);
+    }
+}
+
+// fills row `r` (16 int64, HOST memory) of the table of hno_cb_pack_weights_multi for one layer
+extern "C" int hno_cb_pack_table_row(long long *row, const float *W, void *dst_fwd, void *dst_bwd, int transposed, int Cin, int Cout, int ks) {
+    HNO_REQUIRE(row && W && dst_fwd && dst_bwd && Cin > 0 && Cout > 0 && ks >= 1 && ks <= 3, "hno_cb_pack_table_row: bad argument");
+    if ((Cin % 8) || (Cout % 8)) return fail(HNO_ELIMIT, "hno_cb_pack_table_row: %d -> %d channels (multiples of 8)", Cin, Cout);
+    const int T = ks * ks * ks;
+    row[0] = (long long)(size_t)W; row[1] = (long long)(size_t)dst_fwd; row[2] = (long long)(size_t)dst_bwd;
+    row[3] = transposed ? Cin : Cout; row[4] = transposed ? Cout : Cin; row[5] = T;
+    const int nq0 = T * (Cin / 8), nq1 = T * (Cout / 8);
+    row[6] = transposed ? 0 : 1; row[7] = Cin; row[8] = Cout; row[9] = (Cout + 31) / 32 * 32; row[10] = (nq0 + 1) & ~1;
+    row[11] = transposed ? 1 : 0; row[12] = Cout; row[13] = Cin; row[14] = (Cin + 31) / 32 * 32; row[15] = (nq1 + 1) & ~1;
+    return HNO_OK;
+}
+
+extern "C" int hno_cb_pack_weights_multi(const void *table_dev, int nrows, long long total_chunks, void *stream) {
+    HNO_REQUIRE(table_dev && nrows > 0 && total_chunks > 0 && total_chunks < (1ll << 31), "hno_cb_pack_weights_multi: bad argument");
+    hipLaunchKernelGGL(cb_pack_weights_multi_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)stream, (const long long *)table_dev, nrows);
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }

@@ -61,6 +61,48 @@ def pack_weights_both(W, transposed, Cin, Cout, ks):
     return wf, wb
 
 
+class PackedWeights:
+    """Packed bf16 GEMM operands (forward + input gradient) of a set of conv layers, refreshed by ONE launch per step
+    (hno_cb_pack_weights_multi) instead of one per layer: buffers and the device table are built once per (layer set, weight
+    storage) and reused; `refresh()` re-reads the current fp32 weights.  ConvFn looks the buffers up by the weight's storage."""
+    _current = None          # the instance whose buffers ConvFn may use (set by refresh(), valid for this forward + backward)
+
+    def __init__(self, layers):
+        import ctypes
+        import numpy as np
+        L = _lib.lib()
+        self.entries = {}
+        rows = []
+        for op in layers:
+            W = op.weight
+            transposed = isinstance(op, torch.nn.ConvTranspose3d)
+            Cin, Cout = (W.shape[0], W.shape[1]) if transposed else (W.shape[1], W.shape[0])
+            ks = int(op.kernel_size[0])
+            if Cin % 8 or Cout % 8 or W.dtype != torch.float32 or not W.is_contiguous():
+                continue
+            wf = _ws(L.hno_cb_packed_weight_bytes(Cin, Cout, ks), W.device)
+            wb = _ws(L.hno_cb_packed_weight_bytes(Cout, Cin, ks), W.device)
+            row = np.zeros(16, dtype=np.int64)
+            check(L.hno_cb_pack_table_row(row.ctypes.data_as(ctypes.c_void_p), ptr(W), ptr(wf), ptr(wb), int(transposed), Cin, Cout, ks),
+                  'hno_cb_pack_table_row')
+            rows.append(row)
+            self.entries[W.data_ptr()] = (wf, wb)
+        self.key = tuple(self.entries)
+        self.table = torch.from_numpy(np.stack(rows)).to(layers[0].weight.device) if rows else None
+        self.chunks = int(sum((int(r[10] * r[9] * 8 + r[15] * r[14] * 8) + 2047) // 2048 for r in rows))
+
+    def refresh(self):
+        if self.table is not None:
+            check(_lib.lib().hno_cb_pack_weights_multi(ptr(self.table), self.table.shape[0], self.chunks, stream_ptr()),
+                  'hno_cb_pack_weights_multi')
+        PackedWeights._current = self
+
+    @staticmethod
+    def lookup(W):
+        cur = PackedWeights._current
+        return cur.entries.get(W.data_ptr()) if cur is not None else None
+
+
 def conv_raw(xa, xb, wpacked, bias, Cout, out_spatial, mode, ks, stride, pad, want_stats, eps=1e-5):
     """gather GEMM; -> (y (B, Do, Ho, Wo, Cout) bf16, mean_rstd (B, 2) fp32 or None)"""
     _need_gpu(xa, xb)
@@ -188,7 +230,10 @@ class ConvFn(_HnoFunction):
         pad = 0 if ks == 1 else 1
         osz = _out_spatial(tuple(xa.shape[1:4]), ks, stride, transposed)
         need_dgrad = ctx.needs_input_grad[0] or (xb is not None and ctx.needs_input_grad[1])
-        if need_dgrad:      # the weights do not change between forward and backward: pack both GEMM operands now, in one launch
+        pre = PackedWeights.lookup(W)
+        if pre is not None:   # packed with every other layer by this forward's PackedWeights.refresh()
+            wp, ctx.wpd = pre
+        elif need_dgrad:      # the weights do not change between forward and backward: pack both GEMM operands now, in one launch
             wp, ctx.wpd = pack_weights_both(W, transposed, Cin, Cout, ks)
         else:
             wp, ctx.wpd = pack_weights(W, 2 if transposed else 0, Cin, Cout, ks), None
