@@ -340,17 +340,24 @@ class VNetDS(nn.Module):
         into the two-input convolutions.  The deep-supervision legs leave the bf16 body through their (C -> out_channels)
         1x1x1 convolution; upsampling, the leg sum, conv_ds' GroupNorm, conv_out, trilinear + softmax and the loss stay fp32."""
         from .. import ops_bf16 as ob
-        image_size = tuple(x.shape[2:])
-        nsec = len(self.num_blocks)
         # bf16 GEMM operands of every convolution, packed by one launch (the table is rebuilt if the parameters moved)
+        if x.is_meta:
+            return self._forward_bf16_body(x, ob)
         ops_ = [m.op for m in self.modules() if hasattr(m, 'op') and isinstance(m.op, (nn.Conv3d, nn.ConvTranspose3d))]
         pk = getattr(self, '_packed', None)
         if pk is None or pk.key != tuple(o.weight.data_ptr() for o in ops_ if o.weight.data_ptr() in pk.entries) or \
                 any(o.weight.data_ptr() not in pk.entries for o in ops_ if o.weight.shape[0] % 8 == 0 and o.weight.shape[1] % 8 == 0):
             pk = ob.PackedWeights(ops_)
             object.__setattr__(self, '_packed', pk)
-        if not x.is_meta:
-            pk.refresh()
+        pk.refresh()
+        try:
+            return self._forward_bf16_body(x, ob)
+        finally:
+            ob.PackedWeights.release()
+
+    def _forward_bf16_body(self, x, ob):
+        image_size = tuple(x.shape[2:])
+        nsec = len(self.num_blocks)
         h = ob.PackInputFn.apply(x, (x.shape[1] + 7) // 8 * 8)
         if self.use_resize:
             h = ob.conv_norm_act(self.conv_in, h)

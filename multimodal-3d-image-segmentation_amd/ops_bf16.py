@@ -69,6 +69,7 @@ class PackedWeights:
 
     def __init__(self, layers):
         import ctypes
+        import weakref
         import numpy as np
         L = _lib.lib()
         self.entries = {}
@@ -86,7 +87,7 @@ class PackedWeights:
             check(L.hno_cb_pack_table_row(row.ctypes.data_as(ctypes.c_void_p), ptr(W), ptr(wf), ptr(wb), int(transposed), Cin, Cout, ks),
                   'hno_cb_pack_table_row')
             rows.append(row)
-            self.entries[W.data_ptr()] = (wf, wb)
+            self.entries[W.data_ptr()] = (weakref.ref(W), wf, wb)
         self.key = tuple(self.entries)
         self.table = torch.from_numpy(np.stack(rows)).to(layers[0].weight.device) if rows else None
         self.chunks = int(sum((int(r[10] * r[9] * 8 + r[15] * r[14] * 8) + 2047) // 2048 for r in rows))
@@ -98,9 +99,20 @@ class PackedWeights:
         PackedWeights._current = self
 
     @staticmethod
+    def release():
+        """end of the owning model's forward: no other caller may pick these buffers up (a later tensor can reuse a freed
+        parameter's address)"""
+        PackedWeights._current = None
+
+    @staticmethod
     def lookup(W):
         cur = PackedWeights._current
-        return cur.entries.get(W.data_ptr()) if cur is not None else None
+        if cur is None:
+            return None
+        e = cur.entries.get(W.data_ptr())
+        if e is None or e[0]() is not W:          # the very Parameter object the table was built from, not just its address
+            return None
+        return e[1], e[2]
 
 
 def conv_raw(xa, xb, wpacked, bias, Cout, out_spatial, mode, ks, stride, pad, want_stats, eps=1e-5):

@@ -614,7 +614,7 @@ def test_vnet_models_vs_golden(pkg, name):
     assert rel_err(y.detach().cpu().numpy(), g[f'{name}::y']) < TOL
     assert abs(float(loss.detach()) - float(g[f'{name}::loss'])) < 1e-5
     for k, p in model.named_parameters():
-        assert rel_err(p.grad.cpu().numpy(), g[f'{name}::grad::{k}']) < 2 * TOL, k
+        assert rel_err(p.grad.cpu().numpy(), g[f"{name}::grad::{k}"]) < TOL, k          # measured <= 4e-6
 
 
 # ------------------------------------------------------ un-truncated dhtn and the 2-D (ndim = 4) paths
