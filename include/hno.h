@@ -32,6 +32,12 @@ extern "C" {
 #define HNO_ACT_ELU 2
 #define HNO_ACT_SIGMOID 3 /* hno_act_fwd / hno_act_bwd only (output activation of the models); the fused conv / transform
                              epilogues take NONE, SELU or ELU */
+/* ORed into the `act` argument of hno_pwconv_fwd / hno_pwconv_bwd / hno_pwconv_fwd_branch / hno_pwconv_bwd_branch: run the channel
+ * contraction on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulation) with the operands rounded to bf16 and the
+ * convolution output rounded to bf16 -- what torch.autocast(bfloat16) makes of nn.Conv3d (reference experiments/train_test.py:154-160).
+ * Tensors stay fp32 in memory.  Built for the 24- and 48-channel shapes of the BASELINE configurations (24 -> 24, 24 + 24 -> 24,
+ * 24 -> 4, the fused block tail); other shapes ignore the flag and keep fp32 arithmetic.  The weight gradient keeps its fp32 tiles. */
+#define HNO_ACT_BF16 0x1000
 
 int hno_version(void);
 const char *hno_last_error(void);

@@ -27,6 +27,24 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// ---- bf16 matrix-core variants (torch.autocast(bfloat16): nn.Conv3d takes bf16 operands, accumulates in fp32 and returns bf16;
+// reference experiments/train_test.py:154-160).  The kernels keep their fp32 load / store structure: a lane still holds
+// channel 2 ks + h of its voxel for ks = 0 .. NK-1; six consecutive ks (+ two zero slots) are ONE fragment of
+// v_mfma_f32_32x32x16_bf16 (k-slot 8 h + j  <->  channel 2 (6 s + j) + h), so 12 fp32 MFMAs of 64 cycles become 2 of 32.
+typedef __bf16 pw_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ pw_bf16x8 pack6(const float *v) {
+    pw_bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) f[j] = (__bf16)v[j];
+    f[6] = (__bf16)0.f;
+    f[7] = (__bf16)0.f;
+    return f;
+}
+__device__ __forceinline__ f32x16 mfma_bf(pw_bf16x8 a, pw_bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; }
+
 struct PwArgs {
     const float *xa, *xb, *W, *bias;
     float *y;
@@ -308,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void pwconv_bwd_kernel(PwBwdArgs a) {
 // 42 us at 16 waves/CU and 46-50 us with one tile per wave; 8/16-byte-per-lane loads, explicit
 // software prefetch, XCD-contiguous tile order and non-temporal stores made no difference or hurt.
 #define PWF_FAST_WAVES 8
-template <int CA, int CB, int COUT>   // channel counts of xa / xb (both even) are compile-time: all address selects fold
+template <int CA, int CB, int COUT, bool BF16 = false>   // channel counts of xa / xb (both even) are compile-time: all address selects fold
 __global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_fast_kernel(PwArgs a) {
     constexpr int NW = PWF_FAST_WAVES;
     constexpr int NKI = (CA + CB) / 2;
@@ -329,6 +347,14 @@ __global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_fast_kernel(Pw
             w[ot][ks] = o < COUT ? a.W[(size_t)o * CIN + i] : 0.f;
             if (a.residual && o == i) w[ot][ks] += 1.f;
         }
+    static_assert(!BF16 || NKI % 6 == 0, "bf16 fragments take six channel pairs");
+    pw_bf16x8 wf[OT][BF16 ? NKI / 6 : 1];
+    if constexpr (BF16) {
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+            for (int s6 = 0; s6 < NKI / 6; ++s6) wf[ot][s6] = pack6(&w[ot][6 * s6]);
+    }
     float bias_r[OT][16];
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot)
@@ -367,6 +393,9 @@ __global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_fast_kernel(Pw
             if (a.dbg & 1) {
 #pragma unroll
                 for (int ks = 0; ks < NKI; ++ks) acc[ks & 15] += xv[ks];
+            } else if constexpr (BF16) {
+#pragma unroll
+                for (int s6 = 0; s6 < NKI / 6; ++s6) acc = mfma_bf(wf[ot][s6], pack6(&xv[6 * s6]), acc);
             } else {
 #pragma unroll
                 for (int ks = 0; ks < NKI; ++ks) acc = mfma32(w[ot][ks], xv[ks], acc);
@@ -375,8 +404,10 @@ __global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_fast_kernel(Pw
 #pragma unroll
                 for (int r = 0; r < (ot == OT - 1 ? NRL : 16); ++r) {
                     const int orow = ot * 32 + (r & 3) + 8 * (r >> 2);
-                    const float x = acc[r] + bias_r[ot][r];
-                    const float val = (x > 0.f || lin) ? ap * x : aq * neg_expm1(x);
+                    float x = acc[r] + bias_r[ot][r];
+                    if constexpr (BF16) x = bf16_round(x);      // the convolution's output dtype under autocast
+                    float val = (x > 0.f || lin) ? ap * x : aq * neg_expm1(x);
+                    if constexpr (BF16) val = bf16_round(val);
                     if (vin && (orow + 4 < COUT || h == 0)) (y_b + (size_t)orow * V)[hoff4V + v] = val;
                 }
             } else {
@@ -403,7 +434,7 @@ struct PwBranchArgs {
     int act;
 };
 
-template <int CA, int CB, int COUT>
+template <int CA, int CB, int COUT, bool BF16 = false>
 __global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_branch_kernel(PwBranchArgs a) {
     static_assert(CA % 8 == 0 && CA <= 32 && CB % 8 == 0 && COUT <= 32 && COUT % 8 == 0, "one 32-row tile per product");
     constexpr int NW = PWF_FAST_WAVES;
@@ -426,6 +457,14 @@ __global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_branch_kernel(
     }
 #pragma unroll
     for (int r = 0; r < RO; ++r) bc[r] = a.bias ? a.bias[(r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+    static_assert(!BF16 || (NKX % 6 == 0 && RA % 6 == 0), "bf16 fragments take six k-slots");
+    pw_bf16x8 fbr[BF16 ? NKX / 6 : 1], fcx[BF16 ? NKX / 6 : 1], fcy[BF16 ? RA / 6 : 1];
+    if constexpr (BF16) {
+#pragma unroll
+        for (int s6 = 0; s6 < NKX / 6; ++s6) { fbr[s6] = pack6(&wbr[6 * s6]); fcx[s6] = pack6(&wcx[6 * s6]); }
+#pragma unroll
+        for (int s6 = 0; s6 < RA / 6; ++s6) fcy[s6] = pack6(&wcy[6 * s6]);
+    }
     const float ap = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f;
     const float aq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
     const bool lin = a.act == HNO_ACT_NONE;
@@ -446,34 +485,51 @@ __global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_branch_kernel(
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        pw_bf16x8 xf[BF16 ? NKX / 6 : 1];
+        if constexpr (BF16) {
 #pragma unroll
-        for (int ks = 0; ks < NKX; ++ks) acc = mfma32(wbr[ks], xv[ks], acc);
+            for (int s6 = 0; s6 < NKX / 6; ++s6) { xf[s6] = pack6(&xv[6 * s6]); acc = mfma_bf(fbr[s6], xf[s6], acc); }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < NKX; ++ks) acc = mfma32(wbr[ks], xv[ks], acc);
+        }
         float *y_b = a.y + (size_t)b * CA * V;
         float yv[RA];
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
-            const float u = acc[r] + sv[r] + bb[r];
+            // autocast: the branch convolution returns bf16 (bias included), the sum with the fp32 operator output and the
+            // activation are fp32 (nets/architectures.py:521-539)
+            const float u = BF16 ? bf16_round(acc[r] + bb[r]) + sv[r] : acc[r] + sv[r] + bb[r];
             yv[r] = (u > 0.f || lin) ? ap * u : aq * neg_expm1(u);
             if (vin) (y_b + (size_t)((r & 3) + 8 * (r >> 2)) * V)[hoff4V + v] = yv[r];
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if constexpr (BF16) {
 #pragma unroll
-        for (int r = 0; r < RA; ++r) acc = mfma32(wcy[r], yv[r], acc);
+            for (int s6 = 0; s6 < RA / 6; ++s6) acc = mfma_bf(fcy[s6], pack6(&yv[6 * s6]), acc);
 #pragma unroll
-        for (int ks = 0; ks < NKX; ++ks) acc = mfma32(wcx[ks], xv[ks], acc);
+            for (int s6 = 0; s6 < NKX / 6; ++s6) acc = mfma_bf(fcx[s6], xf[s6], acc);
+        } else {
+#pragma unroll
+            for (int r = 0; r < RA; ++r) acc = mfma32(wcy[r], yv[r], acc);
+#pragma unroll
+            for (int ks = 0; ks < NKX; ++ks) acc = mfma32(wcx[ks], xv[ks], acc);
+        }
         float *o_b = a.out + (size_t)b * COUT * V;
 #pragma unroll
         for (int r = 0; r < RO; ++r) {
-            const float u = acc[r] + bc[r];
-            const float val = (u > 0.f || lin) ? ap * u : aq * neg_expm1(u);
+            float u = acc[r] + bc[r];
+            if constexpr (BF16) u = bf16_round(u);
+            float val = (u > 0.f || lin) ? ap * u : aq * neg_expm1(u);
+            if constexpr (BF16) val = bf16_round(val);
             if (vin) (o_b + (size_t)((r & 3) + 8 * (r >> 2)) * V)[hoff4V + v] = val;
         }
     }
 }
 
 #define PWB_FAST_WAVES 4   // 256-thread blocks, two per CU (512 slabs): measured best of {4, 8, 12} waves x {256, 512, 1024} blocks
-template <int COUT, int CA, int CB, int NW = PWB_FAST_WAVES, int BR = 0>   // compile-time channel counts: every address select folds
+template <int COUT, int CA, int CB, int NW = PWB_FAST_WAVES, int BR = 0, bool BF16 = false>   // compile-time channel counts: every address select folds
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kernel(PwBwdArgs a) {   // 2 blocks per CU: a 256-register budget, all in VGPRs (no AGPR copies)
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63;
@@ -517,6 +573,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kern
             wt[ic][ks] = i < CIN ? a.W[(size_t)o * CIN + i] : 0.f;
             if (a.residual && i == o) wt[ic][ks] += 1.f;
         }
+    // bf16 (autocast): the input-gradient products run on v_mfma_f32_32x32x16_bf16 (six k-slots per fragment, see pack6); the
+    // weight gradient below keeps its fp32 tiles (more accurate than the reference's bf16 weight gradient, same cost as before)
+    static_assert(!BF16 || (NKO % 6 == 0 && (!BR || RA % 6 == 0)), "bf16 fragments take six k-slots");
+    pw_bf16x8 wtf[ICH][BF16 ? NKO / 6 : 1], wbrf[(BF16 && BR) ? RA / 6 : 1];
+    if constexpr (BF16) {
+#pragma unroll
+        for (int ic = 0; ic < ICH; ++ic)
+#pragma unroll
+            for (int s6 = 0; s6 < NKO / 6; ++s6) wtf[ic][s6] = pack6(&wt[ic][6 * s6]);
+        if constexpr (BR != 0) {
+#pragma unroll
+            for (int s6 = 0; s6 < RA / 6; ++s6) wbrf[s6] = pack6(&wbr[6 * s6]);
+        }
+    }
     for (int i = lane; i < (rowsG + rowsX + rowsP) * PWB_LD; i += 64) G[i] = 0.f;
     float db[NKO];
 #pragma unroll
@@ -601,7 +671,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kern
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            if (!(a.dbg & 1)) {
+            if constexpr (BF16) {
+#pragma unroll
+                for (int s6 = 0; s6 < NKO / 6; ++s6) acc = mfma_bf(wtf[ic][s6], pack6(&g[6 * s6]), acc);
+            } else if (!(a.dbg & 1)) {
 #pragma unroll
                 for (int ks = 0; ks < NKO; ++ks) acc = mfma32(wt[ic][ks], g[ks], acc);
             } else {
@@ -656,8 +729,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kern
                 for (int r = 0; r < RA; ++r) store_row(r);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+                if constexpr (BF16) {
+                    float pr[RA];
 #pragma unroll
-                for (int ks = 0; ks < RA; ++ks) acc2 = mfma32(wbr[ks], acc[ks], acc2);
+                    for (int ks = 0; ks < RA; ++ks) pr[ks] = acc[ks];
+#pragma unroll
+                    for (int s6 = 0; s6 < RA / 6; ++s6) acc2 = mfma_bf(wbrf[s6], pack6(&pr[6 * s6]), acc2);
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < RA; ++ks) acc2 = mfma32(wbr[ks], acc[ks], acc2);
+                }
 #pragma unroll
                 for (int r = RA; r < 16; ++r) store_row(r);
             } else {
@@ -745,6 +826,8 @@ static int grid_for(long long work_items, int per_block) {
 
 int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const float *W, const float *bias,
                       float *y, int B, int Cout, long long V, int act, int residual, void *stream) {
+    const int bf16 = (act >> 12) & 1;      // HNO_ACT_BF16: bf16 matrix-core arithmetic (autocast); built for the 24 / 48-channel shapes
+    act &= 0xfff;
     HNO_REQUIRE(xa && W && y && Ca > 0 && Cb >= 0 && B > 0 && Cout > 0 && V > 0, "hno_pwconv_fwd: bad argument");
     HNO_REQUIRE(Cb == 0 || xb, "hno_pwconv_fwd: xb is NULL but Cb > 0");
     if (V * 8 >= (1ll << 32) || ((V + 31) / 32) * B >= (1ll << 31))
@@ -765,7 +848,10 @@ int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const fl
         if (fgrid > 256) fgrid = 256;   // one block per CU
         if (a.dbg >> 8) fgrid = a.dbg >> 8;
         const dim3 fb(64 * PWF_FAST_WAVES);
-        if (Ca == 24 && Cb == 0 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 24>), dim3(fgrid), fb, 0, fs, a);
+        if (bf16 && Ca == 24 && Cb == 0 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 24, true>), dim3(fgrid), fb, 0, fs, a);
+        else if (bf16 && Ca == 24 && Cb == 24 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 24, 24, true>), dim3(fgrid), fb, 0, fs, a);
+        else if (bf16 && Ca == 24 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 4, true>), dim3(fgrid), fb, 0, fs, a);
+        else if (Ca == 24 && Cb == 0 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 24>), dim3(fgrid), fb, 0, fs, a);
         else if (Ca == 24 && Cb == 24 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 24, 24>), dim3(fgrid), fb, 0, fs, a);
         else if (Ca == 24 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 4>), dim3(fgrid), fb, 0, fs, a);
         else if (Ca == 48 && Cb == 0 && Cout == 48) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<48, 0, 48>), dim3(fgrid), fb, 0, fs, a);   // composed complex mix
@@ -800,6 +886,8 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
                       const float *W, float *gxa, float *gxb, float *dW, float *dbias, void *workspace,
                       int B, int Cout, long long V, int act, int residual, void *stream, int xa_act = HNO_ACT_NONE,
                       int accumulate_gx = 0, const float *Wbr = nullptr) {   // also declared in hno_specmix.hip
+    const int bf16 = (act >> 12) & 1;      // HNO_ACT_BF16 (see pwconv_fwd_launch)
+    act &= 0xfff;
     HNO_REQUIRE(workspace, "hno_pwconv_bwd: workspace of hno_pwconv_bwd_workspace_bytes() is required");
     HNO_REQUIRE(gy && xa && W && dW && Ca > 0 && Cb >= 0 && B > 0 && Cout > 0 && V > 0, "hno_pwconv_bwd: bad argument");
     HNO_REQUIRE(act == HNO_ACT_NONE || y, "hno_pwconv_bwd: saved output y needed for the activation gradient");
@@ -835,10 +923,11 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
             HNO_REQUIRE(xa_act != HNO_ACT_NONE && gxa && gxb && !residual, "hno_pwconv_bwd_branch: needs the activation of xa and both input gradients");
             long long fgb = (ntiles + PWB_FAST_WAVES - 1) / PWB_FAST_WAVES;
             if (fgb > 512) fgb = 512;
-            auto kern = pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 1>;
+            auto kern = bf16 ? pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 1, true> : pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 1>;
             static bool battr = false;
             if (!battr) {
-                (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 battr = true;
             }
             const int nb = Cout * Cin + Cout + Ca * Cb + Ca;
@@ -862,12 +951,18 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<4, 24, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<48, 48, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 0, PWB_FAST_WAVES, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_done = true;
         }
         {
             ProfScope ps(KID_PWCONV_BWD, s, 4.0 * B * (double)V * ((act != HNO_ACT_NONE ? 2 : 1) * Cout + Cin + (gxa ? Ca : 0) + (gxb ? Cb : 0)));
             const dim3 g((int)fg), blk(64 * NW);
-            if (Ca == 24 && Cb == 0 && Cout == 24) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 0>), g, blk, sizeof(float) * NW * (32 + 32) * PWB_LD, s, a);
+            if (bf16 && NW == PWB_FAST_WAVES && Ca == 24 && Cb == 0 && Cout == 24)
+                hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 0, PWB_FAST_WAVES, 0, true>), g, blk, sizeof(float) * NW * (32 + 32) * PWB_LD, s, a);
+            else if (bf16 && NW == PWB_FAST_WAVES && s2424)
+                hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 0, true>), g, blk, sizeof(float) * NW * (32 + 48) * PWB_LD, s, a);
+            else if (Ca == 24 && Cb == 0 && Cout == 24) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 0>), g, blk, sizeof(float) * NW * (32 + 32) * PWB_LD, s, a);
             else if (s2424 && NW == 8) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 24, 8>), g, blk, sizeof(float) * NW * (32 + 48) * PWB_LD, s, a);
             else if (s2424 && NW == 12) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 24, 12>), g, blk, sizeof(float) * NW * (32 + 48) * PWB_LD, s, a);
             else if (s2424) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 24>), g, blk, sizeof(float) * NW * (32 + 48) * PWB_LD, s, a);
@@ -969,6 +1064,8 @@ using namespace hno;
 extern "C" int hno_pwconv_fwd_branch(const float *s_in, const float *x, const float *Wbr, const float *bbr, const float *W,
                                      const float *bias, float *y, float *out, int B, int Ca, int Cb, int Cout, long long V,
                                      int act, void *stream) {
+    const int bf16 = (act >> 12) & 1;
+    act &= 0xfff;
     HNO_REQUIRE(s_in && x && Wbr && W && y && out && B > 0 && V > 0, "hno_pwconv_fwd_branch: bad argument");
     if (!(Ca == 24 && Cb == 24 && Cout == 24))
         return fail(HNO_ELIMIT, "hno_pwconv_fwd_branch: only the 24 + 24 -> 24 block shape is built (got %d + %d -> %d)", Ca, Cb, Cout);
@@ -982,7 +1079,8 @@ extern "C" int hno_pwconv_fwd_branch(const float *s_in, const float *x, const fl
     if (grid > 256) grid = 256;   // one block per CU
     hipStream_t fs = (hipStream_t)stream;
     ProfScope ps(KID_PWCONV_FWD, fs, 4.0 * B * (double)V * (2 * Ca + Cb + Cout));
-    hipLaunchKernelGGL((pwconv_fwd_branch_kernel<24, 24, 24>), dim3((int)grid), dim3(64 * PWF_FAST_WAVES), 0, fs, a);
+    if (bf16) hipLaunchKernelGGL((pwconv_fwd_branch_kernel<24, 24, 24, true>), dim3((int)grid), dim3(64 * PWF_FAST_WAVES), 0, fs, a);
+    else hipLaunchKernelGGL((pwconv_fwd_branch_kernel<24, 24, 24>), dim3((int)grid), dim3(64 * PWF_FAST_WAVES), 0, fs, a);
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }

@@ -12,6 +12,7 @@ from . import _lib
 from ._lib import check, ptr, stream_ptr
 
 ACT_NONE, ACT_SELU, ACT_ELU = 0, 1, 2
+ACT_BF16 = 0x1000   # ORed into the `act` argument of the pointwise entry points: bf16 matrix-core arithmetic (autocast)
 ACT_SIGMOID = 3     # elementwise ActFn only (model output activation); never passed to the fused conv / transform epilogues
 _ACT_IDS = {None: ACT_NONE, 'none': ACT_NONE, 'selu': ACT_SELU, 'elu': ACT_ELU}
 LOSS_KINDS = {'pcc': 0, 'dice': 1, 'expdice': 2}
@@ -188,19 +189,28 @@ def _wgrad_ws(cin, cout, device):
     return torch.empty(n, device=device, dtype=torch.float32)
 
 
-def pwconv_fwd_raw(xa, xb, W, bias, act):
+def _autocast_bf16():
+    """True inside torch.autocast('cuda', dtype=bfloat16): the pointwise kernels then run their channel contraction on the bf16
+    matrix cores (24 / 48-channel shapes; see ops_bf16.autocast_bf16)"""
+    if not torch.is_autocast_enabled('cuda'):
+        return False
+    from . import ops_bf16
+    return ops_bf16.autocast_bf16()
+
+
+def pwconv_fwd_raw(xa, xb, W, bias, act, bf16=False):
     B, Ca = xa.shape[:2]
     Cb = xb.shape[1] if xb is not None else 0
     Cout, V = W.shape[0], _flat_v(xa)
     assert W.numel() == Cout * (Ca + Cb), 'weight shape does not match the concatenated input channels'
     y = torch.empty((B, Cout) + tuple(xa.shape[2:]), device=xa.device, dtype=torch.float32)
-    check(_lib.lib().hno_pwconv_fwd(ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(bias), ptr(y), B, Cout, V, act, stream_ptr()),
+    check(_lib.lib().hno_pwconv_fwd(ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(bias), ptr(y), B, Cout, V, act | (ACT_BF16 if bf16 else 0), stream_ptr()),
           'hno_pwconv_fwd')
     return y
 
 
 def pwconv_bwd_raw(gy, y, xa, xb, W, act, has_bias, need_gxa=True, need_gxb=True, xa_act=ACT_NONE, accumulate_into=None,
-                   defer=False, bias=None):
+                   defer=False, bias=None, bf16=False):
     """-> (gxa, gxb, dW, dbias); y is the saved output (None when act is NONE).  xa_act: also multiply
     gxa by act'(xa) (xa being the output of that activation)."""
     B, Ca = xa.shape[:2]
@@ -222,12 +232,12 @@ def pwconv_bwd_raw(gy, y, xa, xb, W, act, has_bias, need_gxa=True, need_gxb=True
     ws = _wgrad_ws(Ca + Cb, Cout, xa.device)
     with _DeferReduce(defer) as d:
         check(_lib.lib().hno_pwconv_bwd(ptr(gy), ptr(y), ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(gxa), ptr(gxb), ptr(dW),
-                                        ptr(db), ptr(ws), B, Cout, V, act, xa_act, acc_bits | d.bit, stream_ptr()), 'hno_pwconv_bwd')
+                                        ptr(db), ptr(ws), B, Cout, V, act | (ACT_BF16 if bf16 else 0), xa_act, acc_bits | d.bit, stream_ptr()), 'hno_pwconv_bwd')
         d.keep(ws)
     return gxa, gxb, dW, db
 
 
-def pwconv_bwd_branch_raw(gy, y, xa, xb, W, Wbr, act, xa_act, defer=False):
+def pwconv_bwd_branch_raw(gy, y, xa, xb, W, Wbr, act, xa_act, defer=False, bf16=False):
     """Backward of  act(W [xa ; xb] + b)  where xa = xa_act(s + Wbr xb + bbr): one pass (hno_pwconv_bwd_branch).
     -> (p, gxb, dW, db, dWbr, dbbr) with p the gradient of the pre-activation sum s + Wbr xb + bbr."""
     B, Ca = xa.shape[:2]
@@ -240,7 +250,7 @@ def pwconv_bwd_branch_raw(gy, y, xa, xb, W, Wbr, act, xa_act, defer=False):
     ws = torch.empty(L.hno_pwconv_bwd_branch_workspace_bytes(Ca, Cb, Cout) // 4, device=xa.device, dtype=torch.float32)
     with _DeferReduce(defer) as d:
         check(L.hno_pwconv_bwd_branch(ptr(gy), ptr(y), ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(Wbr), ptr(p), ptr(gxb), ptr(flat),
-                                      ptr(ws), B, Cout, V, act, xa_act | d.bit, stream_ptr()), 'hno_pwconv_bwd_branch')
+                                      ptr(ws), B, Cout, V, act | (ACT_BF16 if bf16 else 0), xa_act | d.bit, stream_ptr()), 'hno_pwconv_bwd_branch')
         d.keep(ws)
     dW = flat[:n_w].view_as(W)
     db = flat[n_w:n_w + Cout]
@@ -1013,7 +1023,8 @@ class PwConvFn(_HnoFunction):
             if bias is not None or act != ACT_NONE:
                 check(_lib.lib().hno_bias_act(ptr(y), ptr(bias), B, Cout, V, act, stream_ptr()), 'hno_bias_act')
         else:
-            y = pwconv_fwd_raw(xa, xb, W, bias, act)
+            ctx.bf16 = _autocast_bf16()
+            y = pwconv_fwd_raw(xa, xb, W, bias, act, ctx.bf16)
         ctx.save_for_backward(xa, xb, W, y if act != ACT_NONE else None, bias)
         ctx.act, ctx.has_bias = act, bias is not None
         return y
@@ -1043,7 +1054,7 @@ class PwConvFn(_HnoFunction):
             return gxa, None, dW, db, None
         gxa, gxb, dW, db = pwconv_bwd_raw(_f32c(gy), y, xa, xb, W, ctx.act, ctx.has_bias, ctx.needs_input_grad[0],
                                           ctx.needs_input_grad[1], defer=ctx.leaf_params and _release_use(W, bias) and _deferrable(W, bias),
-                                          bias=bias)
+                                          bias=bias, bf16=getattr(ctx, 'bf16', False))
         return gxa, gxb, dW, db, None
 
 
@@ -1108,7 +1119,8 @@ class NOBlockFn(_HnoFunction):
         n3 = float(np.prod(spatial))
         # 24 + 24 -> 24 with a conv branch: branch conv, add, activation and concat conv in one pass after the inverse
         fuse_tail = br_w is not None and tuple(cat_w.shape[:2]) == (24, 48) and tuple(br_w.shape[:2]) == (24, 24)
-        x2 = pwconv_fwd_raw(x, None, br_w, br_b, ACT_NONE) if (br_w is not None and not fuse_tail) else None
+        bf = _autocast_bf16()       # autocast: the spatial 1x1x1 convolutions take bf16 operands; transform and spectral mix stay fp32
+        x2 = pwconv_fwd_raw(x, None, br_w, br_b, ACT_NONE, bf) if (br_w is not None and not fuse_tail) else None
         inv_act = ACT_NONE if fuse_tail else act
         if fourier:
             wr, wi = op_ws
@@ -1126,9 +1138,10 @@ class NOBlockFn(_HnoFunction):
         if fuse_tail:
             sop, y, out = y, torch.empty_like(x), torch.empty_like(x)
             check(_lib.lib().hno_pwconv_fwd_branch(ptr(sop), ptr(x), ptr(br_w), ptr(br_b), ptr(cat_w), ptr(cat_b), ptr(y), ptr(out),
-                                                   x.shape[0], 24, 24, 24, _flat_v(x), act, stream_ptr()), 'hno_pwconv_fwd_branch')
+                                                   x.shape[0], 24, 24, 24, _flat_v(x), act | (ACT_BF16 if bf else 0), stream_ptr()), 'hno_pwconv_fwd_branch')
         else:
-            out = pwconv_fwd_raw(y, x, cat_w, cat_b, act)
+            out = pwconv_fwd_raw(y, x, cat_w, cat_b, act, bf)
+        ctx.bf16 = bf
         ctx.save_for_backward(x, br_w, cat_w, w, s0, s1 if not fourier else None, y, out, br_b, cat_b, *op_ws)
         ctx.cfg = (bool(fourier), modes, act, spatial, n3, br_b is not None, cat_b is not None)
         return out
@@ -1141,7 +1154,7 @@ class NOBlockFn(_HnoFunction):
         d_br_w = d_br_b = None
         if br_w is not None and tuple(cat_w.shape[:2]) == (24, 48) and tuple(br_w.shape[:2]) == (24, 24):
             # one pass: p = d loss / d (s + x2) = g_y * act'(y); g_x = concat-path gradient + Wbr^T p; all four parameter gradients
-            p, g_x, d_cat_w, d_cat_b, d_br_w, d_br_b = pwconv_bwd_branch_raw(_f32c(g_out), out, y, x, cat_w, br_w, act, act, defer=late)
+            p, g_x, d_cat_w, d_cat_b, d_br_w, d_br_b = pwconv_bwd_branch_raw(_f32c(g_out), out, y, x, cat_w, br_w, act, act, defer=late, bf16=ctx.bf16)
             d_br_w = d_br_w.view_as(br_w)
             if not cat_has_b:
                 d_cat_b = None
@@ -1149,10 +1162,10 @@ class NOBlockFn(_HnoFunction):
                 d_br_b = None
         else:
             # p through the conv's xa_act product; the branch conv (its output gradient is p) adds its input gradient to g_x
-            p, g_x, d_cat_w, d_cat_b = pwconv_bwd_raw(_f32c(g_out), out, y, x, cat_w, act, cat_has_b, xa_act=act, defer=late)
+            p, g_x, d_cat_w, d_cat_b = pwconv_bwd_raw(_f32c(g_out), out, y, x, cat_w, act, cat_has_b, xa_act=act, defer=late, bf16=ctx.bf16)
             if br_w is not None:
                 _, _, d_br_w, d_br_b = pwconv_bwd_raw(p, None, x, None, br_w, ACT_NONE, br_has_b, accumulate_into=(g_x, None),
-                                                      defer=late)
+                                                      defer=late, bf16=ctx.bf16)
         if fourier:
             gs1 = rfft3_crop_raw(p, modes, 1.0, True)
             gs0, _, dw2, _ = pwconv_bwd_raw(gs1, None, s0, None, w, ACT_NONE, False)
@@ -1196,7 +1209,9 @@ class XSBlockFn(_HnoFunction):
         mix_ws = [_f32c(w) for w in mix_ws]
         _need_gpu(x, skip, cat_w, *mix_ws)
         has_map = map_w is not None
-        xm = pwconv_fwd_raw(x, skip, map_w, map_b, act) if has_map else x
+        bf = _autocast_bf16()       # autocast: bf16 operands for the two spatial convolutions of the block
+        ctx.bf16 = bf
+        xm = pwconv_fwd_raw(x, skip, map_w, map_b, act, bf) if has_map else x
         spatial = tuple(xm.shape[2:])
         if len(modes) == 2:                      # 2-D model on a (B, C, 1, H, W) view
             modes = (0,) + tuple(modes)
@@ -1205,7 +1220,7 @@ class XSBlockFn(_HnoFunction):
         z0 = dht3_crop_raw(xm, modes, 1.0 / n3)
         zs = specmix_fwd_raw(z0, mix_ws, 1, act)
         u = pad_idht3_raw(zs[-1], spatial, 1.0, None, act)
-        out = pwconv_fwd_raw(u, xm, cat_w, cat_b, act)
+        out = pwconv_fwd_raw(u, xm, cat_w, cat_b, act, bf)
         ctx.save_for_backward(x, skip, map_w, xm if has_map else None, z0, zs, u, cat_w, out, map_b, cat_b, *mix_ws)
         ctx.cfg = (has_map, modes, act, spatial, n3, map_b is not None, cat_b is not None, bool(passthrough))
         ctx.set_materialize_grads(False)
@@ -1241,7 +1256,7 @@ class XSBlockFn(_HnoFunction):
         # gradient by the same kernel (gxb += ...).
         fuse_pass = private and not has_map
         g_u, g_skipin, d_cat_w, d_cat_b = pwconv_bwd_raw(_f32c(g_out), out, u, xm, cat_w, act, cat_has_b, xa_act=act,
-                                                         accumulate_into=(None, g_pass) if fuse_pass else None, defer=late_cat, bias=cat_b)
+                                                         accumulate_into=(None, g_pass) if fuse_pass else None, defer=late_cat, bias=cat_b, bf16=ctx.bf16)
         if g_pass is not None and not has_map and not fuse_pass:
             g_skipin = plus_pass(g_skipin)
         g_zl = dht3_crop_raw(g_u, modes, 1.0)                               # PadInverse^T
@@ -1253,7 +1268,7 @@ class XSBlockFn(_HnoFunction):
         g_x, g_skip, d_map_w, d_map_b = pwconv_bwd_raw(g_xm, xm, x, skip, map_w, act, map_has_b,
                                                        ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                                        accumulate_into=(g_pass, None) if private else None,
-                                                       defer=late_map, bias=map_b)
+                                                       defer=late_map, bias=map_b, bf16=ctx.bf16)
         if g_pass is not None and not private and g_x is not None:
             g_x = plus_pass(g_x)
         if g_skip is not None:

@@ -238,6 +238,13 @@ BF16_MODELS = {
                                              transform_type='Fourier'), (1, 2, 24, 20, 28)),
     'hnoseg_bf16': ('NeuralOperatorSeg', dict(in_channels=2, out_channels=3, filters=8, num_transform_blocks=3, num_modes=(4, 5, 5),
                                              transform_type='Hartley'), (1, 2, 24, 20, 28)),
+    # 24 filters: the channel counts of the BASELINE configurations, for which the pointwise kernels have bf16 matrix-core variants
+    'fnoseg24_bf16': ('NeuralOperatorSeg', dict(in_channels=2, out_channels=3, filters=24, num_transform_blocks=3, num_modes=(4, 5, 5),
+                                               transform_type='Fourier'), (1, 2, 24, 20, 28)),
+    'hnoseg24_bf16': ('NeuralOperatorSeg', dict(in_channels=2, out_channels=3, filters=24, num_transform_blocks=2, num_modes=(4, 5, 5),
+                                               transform_type='Hartley'), (1, 2, 24, 20, 28)),
+    'xs24_bf16': ('HNOSegXS', dict(in_channels=2, out_channels=3, filters=24, num_transform_blocks=[1, 2, 1, 1], num_modes=(4, 5, 5)),
+                  (1, 2, 24, 20, 28)),
 }
 
 

@@ -87,6 +87,60 @@ def test_vnet_bf16_vs_reference_autocast_golden(pkg, name):
     assert ops_bf16.PackedWeights.lookup(next(model.parameters())) is None
 
 
+@pytest.mark.parametrize('name', [n for n in BF16_MODELS if not n.startswith('vnet')])
+def test_spectral_models_bf16_vs_reference_autocast_golden(pkg, name):
+    """FNOSeg / HNOSeg / HNOSeg-XS under autocast (BASELINE cfg3's family): the reference keeps transforms and the complex mix in fp32
+    and runs the spatial 1x1x1 convolutions in bf16; here those convolutions take the bf16 matrix-core variants of the pointwise
+    kernels at the BASELINE channel count (24; other widths keep fp32 arithmetic, i.e. are closer to the fp32 run).  Same bars
+    as the V-Net test: outputs no further from the reference's fp32 outputs than 2x its own bf16 run, whole-gradient L2 error
+    <= max(5e-2, 2x the reference's own bf16-vs-fp32 distance)."""
+    g, model, y, loss = _run(pkg, name)
+    yv = y.detach().float().cpu().numpy()
+    d_ref = rel_err(g[f'{name}::bf16::y'], g[f'{name}::f32::y'])
+    d = rel_err(yv, g[f'{name}::f32::y'])
+    l2, l2_ref = _l2(model, g, name), _l2_ref(g, name)
+    print(f'{name}: outputs vs reference fp32 {d:.2e} (reference bf16: {d_ref:.2e}); loss {float(loss.detach()):.6f} vs '
+          f'{float(g[f"{name}::f32::loss"]):.6f}; gradient L2 vs reference fp32 {l2:.2e} (reference bf16: {l2_ref:.2e})')
+    assert np.isfinite(yv).all()
+    assert d < 2.5e-2 and d < max(5e-3, 2.0 * d_ref)
+    assert abs(float(loss.detach()) - float(g[f'{name}::f32::loss'])) < 2e-3
+    assert l2 < max(5e-2, 2.0 * l2_ref)
+    if '24' in name:      # the bf16 kernels really ran: the result differs from the fp32 kernels' by bf16-sized amounts
+        g2, model2, y2, loss2 = _run(pkg, name, autocast=False)
+        assert rel_err(y2.detach().cpu().numpy(), g[f'{name}::f32::y']) < 1e-4
+        assert rel_err(yv, y2.detach().cpu().numpy()) > 1e-4
+
+
+def test_fnoseg_cfg3_full_size_bf16_step(pkg):
+    """BASELINE cfg3 at its real size (FNOSeg, 24 blocks, 2 x 4 x 128^3) under autocast: finite, loss within 2e-3 of the fp32
+    kernels' loss, gradient cosine with the fp32 gradient > 0.96."""
+    from multimodal_3d_image_segmentation_amd.nets import custom_losses
+    import contextlib
+    torch.manual_seed(0)
+    model = pkg.nets.NeuralOperatorSeg(4, 4, 24, 24, (10, 14, 14), 'Fourier').cuda()
+    gen = torch.Generator(device='cuda').manual_seed(6)
+    x = torch.randn((2, 4, 128, 128, 128), device='cuda', generator=gen)
+    lab = torch.randint(0, 4, (2, 1, 128, 128, 128), device='cuda', generator=gen).float()
+    u8 = pkg.ops.labels_prepare(lab, 4)
+    res = {}
+    for tag in ('bf16', 'f32'):
+        for p in model.parameters():
+            p.grad = None
+        with (torch.autocast('cuda', dtype=torch.bfloat16) if tag == 'bf16' else contextlib.nullcontext()):
+            y = model(x)
+            loss = custom_losses.PCCLoss()(y, u8)
+        loss.backward()
+        assert torch.isfinite(y).all()
+        res[tag] = (float(loss.detach()), torch.cat([p.grad.reshape(-1) for p in model.parameters()]).double())
+        del y, loss
+    (lb, gb), (lf, gf) = res['bf16'], res['f32']
+    cos = float((gb * gf).sum() / (gb.norm() * gf.norm()))
+    print(f'cfg3 full size: loss bf16 {lb:.6f} fp32 {lf:.6f}; gradient cosine {cos:.5f}, norm ratio {float(gb.norm() / gf.norm()):.4f}')
+    assert torch.isfinite(gb).all() and abs(lb - lf) < 2e-3
+    # 24 blocks of bf16 convolutions between fp32 transforms: measured cosine 0.981, norm ratio 0.981
+    assert cos > 0.96 and 0.9 < float(gb.norm() / gf.norm()) < 1.1 and float((gb - gf).abs().max()) > 0.0
+
+
 def test_vnet_fp32_path_unchanged_outside_autocast(pkg):
     """the same model without autocast still runs the fp32 kernels and matches the reference's fp32 run at 1e-4 / 2e-4"""
     name = 'vnet_ds_bf16'

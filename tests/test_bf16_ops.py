@@ -154,3 +154,55 @@ def test_groupnorm_act_vs_float64(ob, two, act):
             assert rel_err(from_cl(a).numpy(), b.numpy()) < BF16_TOL, k
         else:
             assert rel_err(a.cpu().numpy(), b.numpy()) < 1e-4, k
+
+
+@pytest.mark.parametrize('shape', ['24+24->24', '24->24', 'branch'])
+def test_pointwise_bf16_variants_vs_float64(shape):
+    """bf16 matrix-core variants of the planar pointwise kernels (hno_pwconv_fwd / _bwd / _fwd_branch / _bwd_branch with
+    HNO_ACT_BF16): operands rounded to bf16, fp32 accumulation, the convolution output rounded to bf16 -- against float64 on
+    the same bf16-rounded operands.  Outputs within one bf16 rounding (4e-3), input gradients within 1.2e-2 (their operand,
+    g * act'(y), is itself rounded to bf16), weight gradients (kept in fp32 tiles) within 1e-4 of the float64 ones."""
+    import multimodal_3d_image_segmentation_amd as pkg
+    ops = pkg.ops
+    torch.manual_seed(3)
+    B, V3 = 2, (5, 6, 7)
+    xa = rb(torch.randn(B, 24, *V3)); xb = rb(torch.randn(B, 24, *V3))
+    W = rb(torch.randn(24, 48 if shape != '24->24' else 24) * 0.2); bias = torch.randn(24) * 0.1
+    if shape == 'branch':
+        # y = selu(s + bf16(Wbr x + bbr)); out = selu(bf16(Wc [bf16(y) ; x] + bc))
+        sop = torch.randn(B, 24, *V3); Wbr = rb(torch.randn(24, 24) * 0.2); bbr = torch.randn(24) * 0.1
+        L = pkg._lib.lib()
+        P, S = pkg._lib.ptr, pkg._lib.stream_ptr
+        d = [t.cuda().contiguous() for t in (sop, xb, Wbr, bbr, W, bias)]
+        y = torch.empty(B, 24, *V3, device='cuda'); out = torch.empty_like(y)
+        pkg._lib.check(L.hno_pwconv_fwd_branch(P(d[0]), P(d[1]), P(d[2]), P(d[3]), P(d[4]), P(d[5]), P(y), P(out), B, 24, 24, 24,
+                                               int(np.prod(V3)), ops.ACT_SELU | ops.ACT_BF16, S()), 'fwd_branch')
+        br = rb(torch.einsum('oi,bidhw->bodhw', Wbr.double(), xb.double()).float() + bbr.view(1, -1, 1, 1, 1))
+        y64 = F.selu(sop.double() + br.double())
+        pre = torch.einsum('oi,bidhw->bodhw', W.double(), torch.cat([rb(y64.float()).double(), xb.double()], 1)) + bias.double().view(1, -1, 1, 1, 1)
+        out64 = F.selu(rb(pre.float()).double())
+        assert rel_err(y.cpu().numpy(), y64.numpy()) < BF16_TOL
+        assert rel_err(out.cpu().numpy(), out64.numpy()) < 2 * BF16_TOL      # two roundings on the way
+        return
+    two = shape == '24+24->24'
+    x64 = (torch.cat([xa, xb], 1) if two else xa).double().requires_grad_(True)
+    W64, b64 = W.double().requires_grad_(True), bias.double().requires_grad_(True)
+    ref = F.selu(torch.einsum('oi,bidhw->bodhw', W64, x64) + b64.view(1, -1, 1, 1, 1))
+    cot = rb(torch.randn(ref.shape))
+    gx64, gW64, gb64 = torch.autograd.grad((ref * cot.double()).sum(), [x64, W64, b64])
+    xad = xa.cuda().requires_grad_(True)
+    xbd = xb.cuda().requires_grad_(True) if two else None
+    Wd, bd = W.cuda().requires_grad_(True), bias.cuda().requires_grad_(True)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        y = ops.PwConvFn.apply(xad, xbd, Wd, bd, ops.ACT_SELU)
+    assert y.dtype == torch.float32
+    assert rel_err(y.detach().cpu().numpy(), ref.detach().numpy()) < 2 * BF16_TOL     # pre-activation and output are both rounded
+    y32 = ops.PwConvFn.apply(xad, xbd, Wd, bd, ops.ACT_SELU)
+    assert rel_err(y32.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5 and not torch.equal(y, y32)   # the flag switched kernels
+    gs = torch.autograd.grad((y * cot.cuda()).sum(), [xad] + ([xbd] if two else []) + [Wd, bd])
+    assert rel_err(gs[0].cpu().numpy(), gx64[:, :24].numpy()) < 1.2e-2
+    if two:
+        assert rel_err(gs[1].cpu().numpy(), gx64[:, 24:].numpy()) < 1.2e-2
+    # the weight gradient multiplies g * act'(y) (y here = the bf16-rounded output) by the inputs in fp32
+    assert rel_err(gs[-2].cpu().numpy(), gW64.numpy()) < 1e-2
+    assert rel_err(gs[-1].cpu().numpy(), gb64.numpy()) < 1e-2
