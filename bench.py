@@ -111,6 +111,76 @@ def launch_ranks(n):
     return rc
 
 
+def secondary_configs(pkg, dev):
+    """BASELINE cfg3 / cfg4 and the inference protocol, timed by the same process after the headline (N = 1 only; each wrapped so
+    that a failure cannot take the headline line down).  ms per fwd + PCC + bwd step, HIP-graph replay, synthetic data."""
+    import contextlib
+    from multimodal_3d_image_segmentation_amd.nets import custom_losses
+    nets = pkg.nets
+    out = {}
+
+    def time_step(ctor, shape, bf16, replays=10):
+        torch.manual_seed(0)
+        model = ctor().to(dev)
+        x = torch.randn(shape, device=dev)
+        lab = pkg.ops.labels_prepare(torch.randint(0, 4, (shape[0], 1) + shape[2:], device=dev).float(), 4)
+        loss_fn = custom_losses.PCCLoss()
+        ac = (lambda: torch.autocast('cuda', dtype=torch.bfloat16)) if bf16 else contextlib.nullcontext
+
+        def step():
+            for p in model.parameters():
+                p.grad = None
+            with ac():
+                loss = loss_fn(model(x), lab)
+            loss.backward()
+        step(); step()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=side):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        gr.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(replays):
+            gr.replay()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / replays * 1e3
+        del gr, model, x
+        torch.cuda.empty_cache()
+        return round(ms, 3)
+    cases = {
+        'cfg3_fnoseg_2x4x128^3_bf16_autocast_ms_per_step': (lambda: nets.NeuralOperatorSeg(4, 4, 24, 24, (10, 14, 14), 'Fourier'), (2, 4, 128, 128, 128), True),
+        'cfg3_fnoseg_2x4x128^3_fp32_ms_per_step': (lambda: nets.NeuralOperatorSeg(4, 4, 24, 24, (10, 14, 14), 'Fourier'), (2, 4, 128, 128, 128), False),
+        'cfg4_vnetds_1x4x160x192x128_bf16_autocast_ms_per_step': (lambda: nets.VNetDS(4, 4, 24, [1, 2, 3, 3, 3], right_leg_indexes=[0, 1, 2, 3, 4]), (1, 4, 160, 192, 128), True),
+        'cfg4_vnetds_1x4x160x192x128_fp32_ms_per_step': (lambda: nets.VNetDS(4, 4, 24, [1, 2, 3, 3, 3], right_leg_indexes=[0, 1, 2, 3, 4]), (1, 4, 160, 192, 128), False),
+    }
+    for key, (ctor, shape, bf16) in cases.items():
+        try:
+            out[key] = time_step(ctor, shape, bf16)
+        except Exception as exc:   # noqa: BLE001
+            out[key] = f'failed: {exc!r}'[:200]
+    try:    # the reference's published metric: single-image inference at 240 x 240 x 155 incl. host copies (README.md:10: V100 < 0.24 s)
+        model = nets.HNOSegXS(**MODEL_CFG).to(dev).eval()
+        xh = torch.randn((1, 4, 240, 240, 155)).pin_memory()
+        ts = []
+        for i in range(6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.no_grad(), pkg.ops.label_output():
+                yp = model(xh.to(dev, non_blocking=True))
+            _ = yp.to('cpu')
+            if i:
+                ts.append(time.perf_counter() - t0)
+        out['hnosegxs_inference_240x240x155_seconds_per_image'] = round(sum(ts) / len(ts), 5)
+    except Exception as exc:   # noqa: BLE001
+        out['hnosegxs_inference_240x240x155_seconds_per_image'] = f'failed: {exc!r}'[:200]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -120,6 +190,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a HIP graph')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the cfg3 / cfg4 / inference timings appended to the line')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -275,6 +346,9 @@ def main():
                                     'frac': round(value / world / (HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_VOLUME), 4)},
             'kernels': kernels,
         }
+        if world == 1 and not args.no_secondary:
+            del graph
+            out['secondary'] = secondary_configs(pkg, dev)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
