@@ -326,9 +326,28 @@ __global__ __launch_bounds__(256, 2) void pwconv_bwd_kernel(PwBwdArgs a) {
 // 42 us at 16 waves/CU and 46-50 us with one tile per wave; 8/16-byte-per-lane loads, explicit
 // software prefetch, XCD-contiguous tile order and non-temporal stores made no difference or hurt.
 #define PWF_FAST_WAVES 8
+#define PWF_DMA_WAVES 4      // fast forward kernel: 4 waves (one per SIMD), each with a private two-slot LDS ring
+
+// One LDS-DMA instruction: 64 lanes x 4 bytes from (wave-uniform base + per-lane byte offset) to 256 contiguous LDS bytes at `lds_dst`
+// (wave-uniform).  No VGPR destination: the load is in flight while the wave multiplies the previous tile; it is retired by a counted
+// s_waitcnt vmcnt(N) (hipcc does not count asm memory operations -- see dma_wait).  M0 (the destination base) is saved and restored:
+// it is compiler-reserved.
+__device__ __forceinline__ void dma_row_pair(const float *base, unsigned lane_byte_off, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_byte_off), "s"(base), "s"(lds_dst) : "memory");
+}
+// At most N vector-memory operations stay in flight (DMA, loads and stores share one in-order counter).  N must not exceed the number
+// of operations CERTAINLY issued after the ones waited for: a larger N would let them stay in flight.
+template <int N>
+__device__ __forceinline__ void dma_wait() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 template <int CA, int CB, int COUT, bool BF16 = false>   // channel counts of xa / xb (both even) are compile-time: all address selects fold
-__global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_fast_kernel(PwArgs a) {
-    constexpr int NW = PWF_FAST_WAVES;
+__global__ __launch_bounds__(64 * PWF_DMA_WAVES) void pwconv_fwd_fast_kernel(PwArgs a) {
+    constexpr int NW = PWF_DMA_WAVES;
+    extern __shared__ float pwf_ring[];      // NW x 2 slots x NKI x 64 floats
     constexpr int NKI = (CA + CB) / 2;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -370,20 +389,42 @@ __global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_fast_kernel(Pw
     const unsigned tiles_per_b = (V + 31) / 32;
     const unsigned ntiles = tiles_per_b * a.B;
     const unsigned hoffV = h ? V : 0u, hoff4V = h ? 4u * V : 0u;
-    for (unsigned t = blockIdx.x * NW + wave; t < ntiles; t += gridDim.x * NW) {
+    // The input rows arrive by LDS-DMA, one tile ahead of the products: slot layout [k-step][h][32 voxels] is exactly the MFMA B operand
+    // order (lane (c, h) reads its own 4 bytes), so the B operands are conflict-free ds_read_b32.  Loads never wait behind the MFMA chain
+    // and the stores of tile t overlap the loads of tile t + 1 (DESIGN.md lesson 27).
+    float *ring = pwf_ring + wave * (2 * NKI * 64);
+    const unsigned ring_b = (unsigned)(size_t)ring;      // LDS byte address
+    const unsigned stride = gridDim.x * NW;
+    auto issue = [&](unsigned t, int slot) {
         const unsigned b = t / tiles_per_b;
         const unsigned v = (t - b * tiles_per_b) * 32 + c;
-        const bool vin = v < V;
-        const unsigned off = hoffV + (vin ? v : 0u);
+        const unsigned boff = (hoffV + (v < V ? v : 0u)) * 4u;     // V * 8 < 2^32 (host check)
         const float *xa_b = a.xa + (size_t)b * CA * V;
         const float *xb_b = CB > 0 ? a.xb + (size_t)b * CB * V : a.xa;
-        float xv[NKI];
 #pragma unroll
         for (int ks = 0; ks < NKI; ++ks) {
             const int i0 = 2 * ks;
             const float *base = i0 < CA ? xa_b + (size_t)i0 * V : xb_b + (size_t)(i0 - CA) * V;
-            xv[ks] = base[off];
+            dma_row_pair(base, boff, __builtin_amdgcn_readfirstlane(ring_b + (slot * NKI + ks) * 256));
         }
+    };
+    unsigned t = blockIdx.x * NW + wave;
+    if (t < ntiles) issue(t, 0);
+    for (int slot = 0; t < ntiles; t += stride, slot ^= 1) {
+        static_assert(NKI <= 63, "the DMA of one tile must fit the vmcnt counter");
+        if (t + stride < ntiles) {
+            issue(t + stride, slot ^ 1);
+            dma_wait<NKI>();      // only the next tile's DMA stays in flight (counting the previous tile's stores too would be wrong on the first pass)
+        } else {
+            dma_wait<0>();
+        }
+        const unsigned b = t / tiles_per_b;
+        const unsigned v0 = (t - b * tiles_per_b) * 32, v = v0 + c;
+        const bool vin = v < V, full = v0 + 32 <= V;      // `full` is wave-uniform
+        const float *sl = ring + slot * NKI * 64 + lane;
+        float xv[NKI];
+#pragma unroll
+        for (int ks = 0; ks < NKI; ++ks) xv[ks] = sl[ks * 64];
         float *y_b = a.y + (size_t)b * COUT * V;
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) {
@@ -401,14 +442,39 @@ __global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_fast_kernel(Pw
                 for (int ks = 0; ks < NKI; ++ks) acc = mfma32(w[ot][ks], xv[ks], acc);
             }
             if (!(a.dbg & 2)) {
+                // epilogue without divergent control flow: the activation is computed for every lane and selected (a branch per output
+                // register costs more than the ~12 instructions it skips), and whole tiles (all but the last of a batch) store unpredicated
+                float val[16];
 #pragma unroll
                 for (int r = 0; r < (ot == OT - 1 ? NRL : 16); ++r) {
-                    const int orow = ot * 32 + (r & 3) + 8 * (r >> 2);
                     float x = acc[r] + bias_r[ot][r];
                     if constexpr (BF16) x = bf16_round(x);      // the convolution's output dtype under autocast
-                    float val = (x > 0.f || lin) ? ap * x : aq * neg_expm1(x);
-                    if constexpr (BF16) val = bf16_round(val);
-                    if (vin && (orow + 4 < COUT || h == 0)) (y_b + (size_t)orow * V)[hoff4V + v] = val;
+                    val[r] = x;
+                }
+                if (!lin) {
+#pragma unroll
+                    for (int r = 0; r < (ot == OT - 1 ? NRL : 16); ++r) {
+                        float e = neg_expm1(val[r]);
+                        asm volatile("" : "+v"(e));             // keeps the compiler from sinking the computation into a branch
+                        val[r] = val[r] > 0.f ? ap * val[r] : aq * e;
+                    }
+                }
+                float *y_l = y_b + (hoff4V + v);
+                if (full) {
+#pragma unroll
+                    for (int r = 0; r < (ot == OT - 1 ? NRL : 16); ++r) {
+                        const int orow = ot * 32 + (r & 3) + 8 * (r >> 2);
+                        const float o = BF16 ? bf16_round(val[r]) : val[r];
+                        if (orow + 4 < COUT) y_l[(size_t)orow * V] = o;
+                        else if (h == 0) y_l[(size_t)orow * V] = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < (ot == OT - 1 ? NRL : 16); ++r) {
+                        const int orow = ot * 32 + (r & 3) + 8 * (r >> 2);
+                        const float o = BF16 ? bf16_round(val[r]) : val[r];
+                        if (vin && (orow + 4 < COUT || h == 0)) y_l[(size_t)orow * V] = o;
+                    }
                 }
             } else {
                 float sacc = 0.f;
@@ -844,17 +910,18 @@ int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const fl
         hipStream_t fs = (hipStream_t)stream;
         bool done = true;
         ProfScope ps(KID_PWCONV_FWD, fs, 4.0 * B * (double)V * (a.Cin + Cout));
-        int fgrid = (int)((ntiles + PWF_FAST_WAVES - 1) / PWF_FAST_WAVES);
+        int fgrid = (int)((ntiles + PWF_DMA_WAVES - 1) / PWF_DMA_WAVES);
         if (fgrid > 256) fgrid = 256;   // one block per CU
         if (a.dbg >> 8) fgrid = a.dbg >> 8;
-        const dim3 fb(64 * PWF_FAST_WAVES);
-        if (bf16 && Ca == 24 && Cb == 0 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 24, true>), dim3(fgrid), fb, 0, fs, a);
-        else if (bf16 && Ca == 24 && Cb == 24 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 24, 24, true>), dim3(fgrid), fb, 0, fs, a);
-        else if (bf16 && Ca == 24 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 4, true>), dim3(fgrid), fb, 0, fs, a);
-        else if (Ca == 24 && Cb == 0 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 24>), dim3(fgrid), fb, 0, fs, a);
-        else if (Ca == 24 && Cb == 24 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 24, 24>), dim3(fgrid), fb, 0, fs, a);
-        else if (Ca == 24 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 4>), dim3(fgrid), fb, 0, fs, a);
-        else if (Ca == 48 && Cb == 0 && Cout == 48) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<48, 0, 48>), dim3(fgrid), fb, 0, fs, a);   // composed complex mix
+        const dim3 fb(64 * PWF_DMA_WAVES);
+        const size_t fl = (size_t)PWF_DMA_WAVES * 2 * (a.Cin / 2) * 256;      // the waves' DMA rings
+        if (bf16 && Ca == 24 && Cb == 0 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 24, true>), dim3(fgrid), fb, fl, fs, a);
+        else if (bf16 && Ca == 24 && Cb == 24 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 24, 24, true>), dim3(fgrid), fb, fl, fs, a);
+        else if (bf16 && Ca == 24 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 4, true>), dim3(fgrid), fb, fl, fs, a);
+        else if (Ca == 24 && Cb == 0 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 24>), dim3(fgrid), fb, fl, fs, a);
+        else if (Ca == 24 && Cb == 24 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 24, 24>), dim3(fgrid), fb, fl, fs, a);
+        else if (Ca == 24 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 4>), dim3(fgrid), fb, fl, fs, a);
+        else if (Ca == 48 && Cb == 0 && Cout == 48) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<48, 0, 48>), dim3(fgrid), fb, fl, fs, a);   // composed complex mix
         else done = false;
         if (done) {
             HNO_CHECK_LAUNCH();
