@@ -162,6 +162,7 @@ struct PwBwdArgs {
 };
 
 #define PWB_LD 34  // 32 voxels + 2: row stride == 2 (mod 4) -> conflict-free 16x16x4 operand reads
+#define PWB_XP 68  // floats between DMA'd row pairs of the fast backward kernel's x ring (see there)
 
 template <int KSO_MAX, int ICH>  // KSO_MAX >= ceil(Cout/2), ICH = number of 32-wide input-channel chunks
 __global__ __launch_bounds__(256, 2) void pwconv_bwd_kernel(PwBwdArgs a) {
@@ -609,9 +610,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kern
     constexpr int MTP = BR ? (CA + 15) / 16 : 0, NTB = BR ? (CB + 15) / 16 : 0;
     constexpr int rowsG = MT * 16, rowsX = BR ? (CA + NTB * 16 > NTI * 16 ? CA + NTB * 16 : NTI * 16) : NTI * 16, rowsP = MTP * 16;
     const unsigned V = a.V;
-    float *G = lds + (size_t)wave * (rowsG + rowsX + rowsP) * PWB_LD;  // [o][v]
-    float *X = G + rowsG * PWB_LD;                              // [i][v]
-    float *P = X + rowsX * PWB_LD;                              // [o][v] of the branch (BR only)
+    // DMA (all but the fused-branch variant): the x rows of the NEXT tile arrive by LDS-DMA into a two-slot ring while this tile is
+    // multiplied -- no registers, no ds_write pass, and the loads never queue behind the MFMA chains.  A DMA instruction fills 256
+    // contiguous bytes (row pair 2j, 2j + 1 x 32 voxels); pairs are PWB_XP = 68 floats apart, which makes the 16x16x4 operand reads of
+    // the weight gradient (16 rows x 4 voxels per instruction) hit 64 different banks: bank = 4 (row >> 1) + 32 (row & 1) + voxel.
+    constexpr bool DMA = BR == 0;
+    constexpr int XS = DMA ? (rowsX / 2) * PWB_XP : rowsX * PWB_LD;   // floats per x slot
+    constexpr int WAVE_FLOATS = rowsG * PWB_LD + (DMA ? 2 : 1) * XS + rowsP * PWB_LD;
+    float *G = lds + (size_t)wave * WAVE_FLOATS;                // [o][v]
+    float *X = G + rowsG * PWB_LD;                              // [i][v] (DMA: two slots of [i / 2][i & 1][v])
+    float *P = X + (DMA ? 2 : 1) * XS;                          // [o][v] of the branch (BR only)
     float wbr[BR ? RA : 1];   // A operand of the branch dgrad: Wbr^T[row = i][k-slot ks -> channel (ks & 3) + 8 (ks >> 2) + 4 h]
     if (BR) {
 #pragma unroll
@@ -653,7 +661,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kern
             for (int s6 = 0; s6 < RA / 6; ++s6) wbrf[s6] = pack6(&wbr[6 * s6]);
         }
     }
-    for (int i = lane; i < (rowsG + rowsX + rowsP) * PWB_LD; i += 64) G[i] = 0.f;
+    for (int i = lane; i < WAVE_FLOATS; i += 64) G[i] = 0.f;
     float db[NKO];
 #pragma unroll
     for (int ks = 0; ks < NKO; ++ks) db[ks] = 0.f;
@@ -672,18 +680,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kern
     const unsigned ngroups = (ntiles + NW - 1) / NW;
     const unsigned hoffV = h ? V : 0u, hoff4V = h ? 4u * V : 0u;
     const float *ga = G + (lane & 15) * PWB_LD + (lane >> 4);
-    const float *xbp = X + (lane & 15) * PWB_LD + (lane >> 4);
+    const float *xbp = DMA ? X + ((lane & 15) >> 1) * PWB_XP + (lane & 1) * 32 + (lane >> 4) : X + (lane & 15) * PWB_LD + (lane >> 4);
+    constexpr int XT = DMA ? 8 * PWB_XP : 16 * PWB_LD;          // 16 rows further
     const float *pa = P + (lane & 15) * PWB_LD + (lane >> 4);
+    const unsigned x_lds = (unsigned)(size_t)X;                 // LDS byte address of the ring
     // software pipeline: raw loads of the NEXT tile (gy, y, x) are issued before this tile's
     // LDS staging and MFMA work; activation gradient and masking happen when they are consumed
-    float pg[NKO], py[NKO] = {}, px[NKI];
+    float pg[NKO], py[NKO] = {}, px[DMA ? 1 : NKI];
     // gradient already stored in gxb (accumulate bit 1 << 1: the U-Net skip consumer arrived first): prefetched with the tile --
     // read inside the store loop instead, every row is a dependent load -> add -> store round trip (the compiler cannot move a
     // load above the previous row's store): 130 us instead of 95 per call
     constexpr int NQ = (!BR && CB > 0) ? CB / 2 : 1;
     float pq[NQ] = {};
     const bool accb = !BR && CB > 0 && (a.accum & 2) && a.gxb;
-    auto fetch = [&](unsigned grp) {
+    auto fetch = [&](unsigned grp, int slot) {
         const unsigned t = grp * NW + wave;
         const bool live = t < ntiles;
         const unsigned b = live ? t / tiles_per_b : 0u;
@@ -692,17 +702,29 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kern
         const float *gy_b = a.gy + (size_t)b * COUT * V, *y_b = a.y + (size_t)b * COUT * V;
         const float *xa_b = a.xa + (size_t)b * CA * V;
         const float *xb_b = CB > 0 ? a.xb + (size_t)b * CB * V : a.xa;
+        if constexpr (DMA) {
+            // issued BEFORE the register loads below: vector-memory loads complete in order, so the wait hipcc places in front of the
+            // first use of pg / py (younger loads) also retires these; out-of-range lanes repeat voxel 0 (finite, and g is 0 there)
+#pragma unroll
+            for (int j = 0; j < NKI; ++j) {
+                const int i0 = 2 * j;
+                const float *base = i0 < CA ? xa_b + (size_t)i0 * V : xb_b + (size_t)(i0 - CA) * V;
+                dma_row_pair(base, off * 4u, __builtin_amdgcn_readfirstlane(x_lds + (slot * XS + j * PWB_XP) * 4));
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < NKO; ++ks) pg[ks] = (gy_b + (size_t)(2 * ks) * V)[off];
         if (!lin) {
 #pragma unroll
             for (int ks = 0; ks < NKO; ++ks) py[ks] = (y_b + (size_t)(2 * ks) * V)[off];
         }
+        if constexpr (!DMA) {
 #pragma unroll
-        for (int j = 0; j < NKI; ++j) {
-            const int i0 = 2 * j;
-            const float *base = i0 < CA ? xa_b + (size_t)i0 * V : xb_b + (size_t)(i0 - CA) * V;
-            px[j] = base[off];
+            for (int j = 0; j < NKI; ++j) {
+                const int i0 = 2 * j;
+                const float *base = i0 < CA ? xa_b + (size_t)i0 * V : xb_b + (size_t)(i0 - CA) * V;
+                px[j] = base[off];
+            }
         }
         if (accb) {
             const float *q_b = a.gxb + (size_t)b * CB * V + (h ? 4u * V : 0u) + ((live && v < V) ? v : 0u);
@@ -710,8 +732,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kern
             for (int j = 0; j < NQ; ++j) pq[j] = q_b[(size_t)((j & 3) + 8 * (j >> 2)) * V];   // rows (j & 3) + 8 (j >> 2) + 4 h
         }
     };
-    if (blockIdx.x < ngroups) fetch(blockIdx.x);
-    for (unsigned grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    unsigned bid = blockIdx.x;
+    if ((a.dbg & 32) && (gridDim.x & 7) == 0) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    unsigned g_begin = bid, g_end = ngroups, g_step = gridDim.x;
+    if (a.dbg & 16) {
+        const unsigned per = (ngroups + gridDim.x - 1) / gridDim.x;
+        g_begin = bid * per; g_end = g_begin + per < ngroups ? g_begin + per : ngroups; g_step = 1;
+    }
+    if (g_begin < g_end) fetch(g_begin, 0);
+    int slot = 0;
+    for (unsigned grp = g_begin; grp < g_end; grp += g_step, slot ^= 1) {
+        const float *Xc = X + (DMA ? slot * XS : 0);            // this tile's x rows
+        const unsigned tu = grp * NW + wave;                    // wave-uniform copies of the tile coordinates
+        const unsigned bu = tu < ntiles ? tu / tiles_per_b : 0u;
+        const bool fast_store = BR == 0 && tu < ntiles && (tu - bu * tiles_per_b) * 32 + 32 <= V && a.gxa && (CB == 0 || a.gxb) &&
+                                !(a.accum & 1) && !(a.dbg & 4);
         const unsigned t = grp * NW + wave;
         const bool live = t < ntiles;
         const unsigned b = live ? t / tiles_per_b : 0u;
@@ -725,12 +760,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kern
             G[(2 * ks + h) * PWB_LD + c] = g[ks];
             db[ks] += g[ks];
         }
+        if constexpr (!DMA) {
 #pragma unroll
-        for (int j = 0; j < NKI; ++j) X[(2 * j + h) * PWB_LD + c] = vin ? px[j] : 0.f;
+            for (int j = 0; j < NKI; ++j) X[(2 * j + h) * PWB_LD + c] = vin ? px[j] : 0.f;
+        }
         float qc[NQ];
 #pragma unroll
         for (int j = 0; j < NQ; ++j) qc[j] = pq[j];
-        if (grp + gridDim.x < ngroups) fetch(grp + gridDim.x);
+        if (grp + g_step < g_end) fetch(grp + g_step, slot ^ 1);
         f32x16 acc2;   // BR: Wbr^T p, rows = xb channels
 #pragma unroll
         for (int ic = 0; ic < ICH; ++ic) {
@@ -770,6 +807,35 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kern
                 }
             };
             if constexpr (BR == 0) {
+              if (fast_store) {
+                // whole tile, both gradients wanted, nothing to accumulate from memory: no per-row control flow.  The activation
+                // derivative's x values are read from LDS in one batch (a dependent ds_read + wait per row otherwise).
+                float xo[16];
+                if (xact) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int irow = ic * 32 + (r & 3) + 8 * (r >> 2);
+                        if (irow < CA) xo[r] = DMA ? Xc[((irow >> 1) + 2 * h) * PWB_XP + (irow & 1) * 32 + c] : X[(irow + 4 * h) * PWB_LD + c];
+                    }
+                }
+                float *ga_l = a.gxa + (size_t)b * CA * V + (hoff4V + v);
+                float *gb_l = CB > 0 ? a.gxb + (size_t)b * CB * V + (hoff4V + v) : nullptr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int irow = ic * 32 + (r & 3) + 8 * (r >> 2);
+                    if (irow < CIN) {
+                        float gv = acc[r];
+                        if (irow < CA && xact) gv *= xo[r] > 0.f ? xp : xo[r] + xq;
+                        if (irow >= CA && CB > 0 && accb) {
+                            const int i = irow - CA;
+                            gv += qc[((i >> 3) << 2) + (i & 3) < NQ ? ((i >> 3) << 2) + (i & 3) : 0];
+                        }
+                        float *dst = irow < CA ? ga_l + (size_t)irow * V : gb_l + (size_t)(irow - CA) * V;
+                        if (irow + 4 < CIN) *dst = gv;
+                        else if (h == 0) *dst = gv;
+                    }
+                }
+              } else
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int irow = ic * 32 + (r & 3) + 8 * (r >> 2);
@@ -779,7 +845,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kern
                         if (base && vin && (irow + 4 < CIN || h == 0) && !((a.dbg & 4) && acc[r] != 12345.678f)) {
                             float gv = acc[r];
                             if (irow < CA && xact) {
-                                const float xo = X[(irow + 4 * h) * PWB_LD + c];
+                                const float xo = DMA ? Xc[((irow >> 1) + 2 * h) * PWB_XP + (irow & 1) * 32 + c] : X[(irow + 4 * h) * PWB_LD + c];
                                 gv *= xo > 0.f ? xp : xo + xq;
                             }
                             if (irow >= CA && CB > 0) {
@@ -822,7 +888,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kern
 #pragma unroll
             for (int m = 0; m < MT; ++m) av[m] = ga[m * 16 * PWB_LD + ks * 4];
 #pragma unroll
-            for (int n = 0; n < NTI; ++n) bv[n] = xbp[n * 16 * PWB_LD + ks * 4];
+            for (int n = 0; n < NTI; ++n) bv[n] = xbp[(DMA ? slot * XS : 0) + n * XT + ks * 4];
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -881,6 +947,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kern
         }
         block_sum_to_slab(lds, n, a.partials + (size_t)blockIdx.x * n, threadIdx.x, NW);
     }
+}
+
+// dynamic LDS of pwconv_bwd_fast_kernel<COUT, CA, CB, NW, BR>: per wave G (rows of 16) + x (ring of two DMA slots, or one padded tile with
+// the fused branch) + P; never less than the slab staging of its epilogue
+template <int COUT, int CA, int CB, int BR>
+static size_t pwb_fast_lds_bytes(int nw) {
+    constexpr int CIN = CA + CB, MT = (COUT + 15) / 16, NTI = (CIN + 15) / 16;
+    constexpr int MTP = BR ? (CA + 15) / 16 : 0, NTB = BR ? (CB + 15) / 16 : 0;
+    constexpr int rowsG = MT * 16, rowsX = BR ? (CA + NTB * 16 > NTI * 16 ? CA + NTB * 16 : NTI * 16) : NTI * 16, rowsP = MTP * 16;
+    constexpr int xs = BR ? rowsX * PWB_LD : 2 * (rowsX / 2) * PWB_XP;
+    constexpr int slab = COUT * CIN + COUT + (BR ? CA * CB + CA : 0);
+    constexpr int per_wave = rowsG * PWB_LD + xs + rowsP * PWB_LD;
+    return sizeof(float) * (size_t)nw * (per_wave > slab ? per_wave : slab);
 }
 
 static int grid_for(long long work_items, int per_block) {
@@ -1000,13 +1079,12 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
             const int nb = Cout * Cin + Cout + Ca * Cb + Ca;
             {
                 ProfScope ps(KID_PWCONV_BWD, s, 4.0 * B * (double)V * ((act != HNO_ACT_NONE ? 2 : 1) * Cout + Cin + Ca + Cb));
-                hipLaunchKernelGGL(kern, dim3((int)fgb), dim3(64 * PWB_FAST_WAVES), sizeof(float) * PWB_FAST_WAVES * (32 + 56 + 32) * PWB_LD, s, a);
+                hipLaunchKernelGGL(kern, dim3((int)fgb), dim3(64 * PWB_FAST_WAVES), (pwb_fast_lds_bytes<24, 24, 24, 1>(PWB_FAST_WAVES)), s, a);
             }
             HNO_CHECK_LAUNCH();
             return reduce_partials_launch(a.partials, (int)fgb, nb, dW, nb, nullptr, s);
         }
         if (s2424 && (a.dbg & 64)) NW = 8;
-        if (s2424 && (a.dbg & 128)) NW = 12;
         long long fg = (ntiles + NW - 1) / NW;
         if (fg > 512) fg = 512;   // two blocks per CU
         if (a.dbg >> 8) fg = a.dbg >> 8;
@@ -1014,7 +1092,6 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
         if (!attr_done) {
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 24, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 24, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<4, 24, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<48, 48, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1026,15 +1103,14 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
             ProfScope ps(KID_PWCONV_BWD, s, 4.0 * B * (double)V * ((act != HNO_ACT_NONE ? 2 : 1) * Cout + Cin + (gxa ? Ca : 0) + (gxb ? Cb : 0)));
             const dim3 g((int)fg), blk(64 * NW);
             if (bf16 && NW == PWB_FAST_WAVES && Ca == 24 && Cb == 0 && Cout == 24)
-                hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 0, PWB_FAST_WAVES, 0, true>), g, blk, sizeof(float) * NW * (32 + 32) * PWB_LD, s, a);
+                hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 0, PWB_FAST_WAVES, 0, true>), g, blk, (pwb_fast_lds_bytes<24, 24, 0, 0>(NW)), s, a);
             else if (bf16 && NW == PWB_FAST_WAVES && s2424)
-                hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 0, true>), g, blk, sizeof(float) * NW * (32 + 48) * PWB_LD, s, a);
-            else if (Ca == 24 && Cb == 0 && Cout == 24) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 0>), g, blk, sizeof(float) * NW * (32 + 32) * PWB_LD, s, a);
-            else if (s2424 && NW == 8) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 24, 8>), g, blk, sizeof(float) * NW * (32 + 48) * PWB_LD, s, a);
-            else if (s2424 && NW == 12) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 24, 12>), g, blk, sizeof(float) * NW * (32 + 48) * PWB_LD, s, a);
-            else if (s2424) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 24>), g, blk, sizeof(float) * NW * (32 + 48) * PWB_LD, s, a);
-            else if (Ca == 24 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<4, 24, 0>), g, blk, sizeof(float) * NW * (16 + 32) * PWB_LD, s, a);
-            else if (Ca == 48 && Cb == 0 && Cout == 48) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<48, 48, 0>), g, blk, sizeof(float) * NW * (48 + 48) * PWB_LD, s, a);   // composed complex mix
+                hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 0, true>), g, blk, (pwb_fast_lds_bytes<24, 24, 24, 0>(NW)), s, a);
+            else if (Ca == 24 && Cb == 0 && Cout == 24) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 0>), g, blk, (pwb_fast_lds_bytes<24, 24, 0, 0>(NW)), s, a);
+            else if (s2424 && NW == 8) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 24, 8>), g, blk, (pwb_fast_lds_bytes<24, 24, 24, 0>(NW)), s, a);
+            else if (s2424) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 24>), g, blk, (pwb_fast_lds_bytes<24, 24, 24, 0>(NW)), s, a);
+            else if (Ca == 24 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<4, 24, 0>), g, blk, (pwb_fast_lds_bytes<4, 24, 0, 0>(NW)), s, a);
+            else if (Ca == 48 && Cb == 0 && Cout == 48) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<48, 48, 0>), g, blk, (pwb_fast_lds_bytes<48, 48, 0, 0>(NW)), s, a);   // composed complex mix
             else done = false;
         }
         if (done) {

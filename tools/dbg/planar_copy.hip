@@ -300,6 +300,147 @@ static float run_dma16(const float *x, const float *W, float *y, int B, unsigned
     return ms * 1e3f / reps;
 }
 
+// mode 8: the planar copy of mode 0 with NM MFMAs per tile that do NOT touch the copied data (own registers): does matrix-core
+// activity by itself slow the streaming (clocks / issue), or is it the dependence chain load -> MFMA -> store?
+template <int NM, int NW>
+__global__ __launch_bounds__(64 * NW) void planar_copy_mfma_kernel(const float *__restrict__ x, float *__restrict__ y, int B, unsigned V, float seed) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const unsigned tpb = (V + 31) / 32, nt = tpb * B;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = seed;
+    float wa = seed * lane, wb = seed + lane;
+    for (unsigned t = blockIdx.x * NW + wave; t < nt; t += gridDim.x * NW) {
+        const unsigned b = t / tpb, v = (t - b * tpb) * 32 + c;
+        const bool in = v < V;
+        const float *xb = x + (size_t)b * CIN * V + (in ? v : 0u) + (h ? V : 0u);
+        float xv[CIN / 2];
+#pragma unroll
+        for (int k = 0; k < CIN / 2; ++k) xv[k] = xb[(size_t)2 * k * V];
+#pragma unroll
+        for (int k = 0; k < NM; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, wb, acc, 0, 0, 0);
+        float *yb = y + (size_t)b * COUT * V + v + (h ? V : 0u);
+#pragma unroll
+        for (int o = 0; o < COUT / 2; ++o) {
+            const float s = xv[2 * o] + xv[2 * o + 1];
+            if (in) yb[(size_t)2 * o * V] = s;
+        }
+    }
+    float sacc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc += acc[r];
+    if (sacc == 12345.678f) y[0] = sacc;
+}
+
+template <int NM, int NW>
+static float run_copy_mfma(const float *x, float *y, int B, unsigned V, int grid, int reps) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((planar_copy_mfma_kernel<NM, NW>), dim3(grid), dim3(64 * NW), 0, 0, x, y, B, V, 0.5f);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((planar_copy_mfma_kernel<NM, NW>), dim3(grid), dim3(64 * NW), 0, 0, x, y, B, V, 0.5f);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e3f / reps;
+}
+
+// mode 9: register double buffering, unrolled by two (no register copies): loads(t+1) -> MFMA(t) -> stores(t) -> loads(t+2) -> MFMA(t+1) -> ...
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void planar_regpf_kernel(const float *__restrict__ x, const float *__restrict__ W, float *__restrict__ y, int B, unsigned V) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, c = lane & 31;
+    constexpr int NKI = CIN / 2;
+    float w[NKI];
+#pragma unroll
+    for (int k = 0; k < NKI; ++k) w[k] = c < COUT ? W[c * CIN + 2 * k + h] : 0.f;
+    const unsigned tpb = (V + 31) / 32, nt = tpb * B;
+    const unsigned stride = gridDim.x * NW;
+    auto load = [&](unsigned t, float (&xv)[NKI]) {
+        const unsigned tt = t < nt ? t : nt - 1;
+        const unsigned b = tt / tpb, v = (tt - b * tpb) * 32 + c;
+        const float *xb = x + (size_t)b * CIN * V + (v < V ? v : 0u) + (h ? V : 0u);
+#pragma unroll
+        for (int k = 0; k < NKI; ++k) xv[k] = xb[(size_t)2 * k * V];
+    };
+    auto compute = [&](unsigned t, const float (&xv)[NKI]) {
+        if (t >= nt) return;
+        const unsigned b = t / tpb, v = (t - b * tpb) * 32 + c;
+        const bool in = v < V;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NKI; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[k], xv[k], acc, 0, 0, 0);
+        float *yb = y + (size_t)b * COUT * V + v + (h ? 4 * V : 0u);
+#pragma unroll
+        for (int r = 0; r < 12; ++r)
+            if (in) yb[(size_t)((r & 3) + 8 * (r >> 2)) * V] = acc[r];
+    };
+    float xa[NKI], xb2[NKI];
+    unsigned t = blockIdx.x * NW + wave;
+    load(t, xa);
+    for (; t < nt; t += 2 * stride) {
+        load(t + stride, xb2);
+        compute(t, xa);
+        load(t + 2 * stride, xa);
+        compute(t + stride, xb2);
+    }
+}
+
+template <int NW>
+static float run_regpf(const float *x, const float *W, float *y, int B, unsigned V, int grid, int reps) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((planar_regpf_kernel<NW>), dim3(grid), dim3(64 * NW), 0, 0, x, W, y, B, V);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((planar_regpf_kernel<NW>), dim3(grid), dim3(64 * NW), 0, 0, x, W, y, B, V);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e3f / reps;
+}
+
+// mode 11: planar copy where every output depends on ALL loads of the tile (so the 12 stores leave as one burst after the last load
+// has landed, as after an MFMA chain) -- against mode 0 where each store leaves as soon as its two inputs are there.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void planar_burst_kernel(const float *__restrict__ x, float *__restrict__ y, int B, unsigned V) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const unsigned tpb = (V + 31) / 32, nt = tpb * B;
+    for (unsigned t = blockIdx.x * NW + wave; t < nt; t += gridDim.x * NW) {
+        const unsigned b = t / tpb, v = (t - b * tpb) * 32 + c;
+        const bool in = v < V;
+        const float *xb = x + (size_t)b * CIN * V + (in ? v : 0u) + (h ? V : 0u);
+        float xv[CIN / 2];
+#pragma unroll
+        for (int k = 0; k < CIN / 2; ++k) xv[k] = xb[(size_t)2 * k * V];
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < CIN / 2; ++k) tot += xv[k];
+        float *yb = y + (size_t)b * COUT * V + v + (h ? V : 0u);
+#pragma unroll
+        for (int o = 0; o < COUT / 2; ++o)
+            if (in) yb[(size_t)2 * o * V] = tot + xv[o];
+    }
+}
+template <int NW>
+static float run_burst(const float *x, float *y, int B, unsigned V, int grid, int reps) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((planar_burst_kernel<NW>), dim3(grid), dim3(64 * NW), 0, 0, x, y, B, V);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((planar_burst_kernel<NW>), dim3(grid), dim3(64 * NW), 0, 0, x, y, B, V);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e3f / reps;
+}
+
 template <int MODE, int NW>
 static float run(const float *x, float *y, int B, unsigned V, int grid, int reps) {
     hipEvent_t e0, e1;
@@ -330,6 +471,18 @@ int main(int argc, char **argv) {
             if (N % 4 == 0) { t = run<2, 4>(x, y, B, V, grid, 20); printf("N=%d mode2 (1x1KB aligned)  nw4 grid %4d: %6.1f us %5.0f GB/s\n", N, grid, t, bytes / t / 1e3); }
             t = run<3, 4>(x, y, B, V, grid, 20); printf("N=%d mode3 (1x1KB row-aligned) nw4 grid %4d: %6.1f us %5.0f GB/s\n", N, grid, t, bytes / t / 1e3);
         }
+        for (int grid : {256, 512, 1024}) {
+            float t;
+            t = run_burst<8>(x, y, B, V, grid, 20); printf("N=%d mode11 copy, stores after all loads nw8 grid %d: %6.1f us\n", N, grid, t);
+            t = run_burst<4>(x, y, B, V, grid, 20); printf("N=%d mode11 copy, stores after all loads nw4 grid %d: %6.1f us\n", N, grid, t);
+        }
+        for (int grid : {256, 512}) {
+            float t;
+            t = run_copy_mfma<0, 8>(x, y, B, V, grid, 20); printf("N=%d mode8 copy +  0 independent MFMA nw8 grid %d: %6.1f us\n", N, grid, t);
+            t = run_copy_mfma<12, 8>(x, y, B, V, grid, 20); printf("N=%d mode8 copy + 12 independent MFMA nw8 grid %d: %6.1f us\n", N, grid, t);
+            t = run_copy_mfma<24, 8>(x, y, B, V, grid, 20); printf("N=%d mode8 copy + 24 independent MFMA nw8 grid %d: %6.1f us\n", N, grid, t);
+            t = run_copy_mfma<48, 8>(x, y, B, V, grid, 20); printf("N=%d mode8 copy + 48 independent MFMA nw8 grid %d: %6.1f us\n", N, grid, t);
+        }
         {
             float *W, *y2;
             CK(hipMalloc(&W, COUT * CIN * 4)); CK(hipMalloc(&y2, (size_t)B * COUT * V * 4 + 64));
@@ -356,6 +509,17 @@ int main(int argc, char **argv) {
                 t = run_dma16<3, 4>(x, W, y, B, V, grid, 20); printf("N=%d mode7 (16B DMA, D=3) nw4 grid %4d: %6.1f us %5.0f GB/s\n", N, grid, t, bytes / t / 1e3);
                 t = run_dma16<4, 4>(x, W, y, B, V, grid, 20); printf("N=%d mode7 (16B DMA, D=4) nw4 grid %4d: %6.1f us %5.0f GB/s\n", N, grid, t, bytes / t / 1e3);
                 t = run_dma16<2, 8>(x, W, y, B, V, grid, 20); printf("N=%d mode7 (16B DMA, D=2) nw8 grid %4d: %6.1f us %5.0f GB/s\n", N, grid, t, bytes / t / 1e3);
+            }
+            CK(hipMemset(y2, 0, a.size() * 4));
+            run_regpf<8>(x, W, y2, B, V, 256, 1);
+            CK(hipMemcpy(bb.data(), y2, a.size() * 4, hipMemcpyDeviceToHost));
+            bad = 0;
+            for (size_t i = 0; i < a.size(); ++i) if (a[i] != bb[i]) ++bad;
+            printf("N=%d mode9 vs mode4: %zu of %zu differ\n", N, bad, a.size());
+            for (int grid : {256, 512, 1024}) {
+                float t;
+                t = run_regpf<4>(x, W, y, B, V, grid, 20); printf("N=%d mode9 (register double buffer) nw4 grid %4d: %6.1f us\n", N, grid, t);
+                t = run_regpf<8>(x, W, y, B, V, grid, 20); printf("N=%d mode9 (register double buffer) nw8 grid %4d: %6.1f us\n", N, grid, t);
             }
             for (int abl : {1, 2, 3}) {
                 float t = run_mfma<5, 4>(x, W, y2, B, V, 256, 20, abl); printf("N=%d mode5 nw4 grid 256 ablation %d (1 = no MFMA, 2 = no stores): %6.1f us\n", N, abl, t);
