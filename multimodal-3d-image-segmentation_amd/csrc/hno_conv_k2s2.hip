@@ -29,46 +29,22 @@ struct K2Args {
     int wtr, ncol, ctiles, tiles_per_slab;
 };
 
-struct K2Tile {
-    int b, od, oh, ow;   // oh / ow are per-lane
-    bool live;
-};
-__device__ __forceinline__ K2Tile k2_tile(const K2Args &a, long long t, int c) {
-    K2Tile r;
-    const int idx = (int)(t % a.tiles_per_slab);
-    const long long slab = t / a.tiles_per_slab;
-    r.od = (int)(slab % a.Do);
-    r.b = (int)(slab / a.Do);
-    const int nrow = a.Ho * a.wtr;
-    if (idx < nrow) {
-        r.oh = idx / a.wtr;
-        r.ow = (idx - r.oh * a.wtr) * 32 + c;
-        r.live = r.ow < a.Wo - a.ncol;
-    } else {
-        const int j = idx - nrow, col = j / a.ctiles;
-        r.oh = (j - col * a.ctiles) * 32 + c;
-        r.ow = a.Wo - a.ncol + col;
-        r.live = r.oh < a.Ho;
-    }
-    return r;
-}
-
-// x[b, i, 2od-1+kd, 2oh-1+kh, 2ow-1+kw] (zero outside).  k>>1 = (i,kd,kh) is wave-uniform, the lane
-// half carries kw, so the address is  uniform row base + (2*ow - 1 + kw)  with a per-lane mask.
-__device__ __forceinline__ float k2_patch(const K2Args &a, const float *xb_, int kpair, int od, int oh, int wl, bool wok) {
-    const int kh = kpair & 1, kd = (kpair >> 1) & 1, i = kpair >> 2;
-    const int d = 2 * od - 1 + kd, hh = 2 * oh - 1 + kh;       // oh (hence hh) is per-lane in column tiles
-    if (!(i < a.Cin && d >= 0 && d < a.D)) return 0.f;          // uniform
-    const bool ok = wok && hh >= 0 && hh < a.H;
-    const float *plane = xb_ + ((size_t)i * a.D + d) * a.H * a.Wd;
-    const float v = plane[ok ? hh * a.Wd + wl : 0];
-    return ok ? v : 0.f;
-}
-
 // tiles are 32 consecutive output voxels WITHIN one output row (ow), so the strided reads of a
-// tile are one contiguous run; rows are enumerated as (b, od, oh)
+// tile are one contiguous run; rows are enumerated as (b, od, oh).
+// The patch rows arrive by LDS-DMA into a wave-private two-slot ring, one tile ahead of the products (hno_pwconv.hip's forward
+// kernel, DESIGN.md lesson 27): a DMA instruction moves one k-step's operand (64 lanes x 4 bytes = taps kw = 0 / 1 of 32 output
+// voxels, one contiguous 256-byte run in a row tile), the lane reads back its own 4 bytes.  A DMA cannot mask, so lanes outside
+// the image (padding = 1) read a valid dummy element and are zeroed when the operand is read; ALWAYS KS_MAX instructions per
+// tile, so that the counted wait is exact.  All tile arithmetic is 32-bit and wave-uniform where the tile allows it.
+struct K2TileState {
+    unsigned b, vo;       // batch index (uniform), output voxel offset of this lane
+    bool live;            // lane has an output voxel
+    bool ok[2][2];        // [kd][kh]: the tap row of this lane is inside the image
+};
+
 template <int KS_MAX>  // >= Cin * 4 k-steps
 __global__ __launch_bounds__(256) void conv_k2s2_fwd_kernel(K2Args a) {
+    extern __shared__ float k2_ring[];                  // 4 waves x 2 slots x KS_MAX x 64 floats
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, c = lane & 31;
     const int nks = a.Cin * 4;
@@ -78,41 +54,131 @@ __global__ __launch_bounds__(256) void conv_k2s2_fwd_kernel(K2Args a) {
         const int k = 2 * ks + h;
         w[ks] = (ks < nks && c < a.Cout) ? a.W[(size_t)c * (a.Cin * 8) + k] : 0.f;
     }
-    const long long ntiles = (long long)a.B * a.Do * a.tiles_per_slab;
-    const size_t Vo = (size_t)a.Do * a.Ho * a.Wo;
-    for (long long t = (long long)blockIdx.x * 4 + wave; t < ntiles; t += (long long)gridDim.x * 4) {
-        const K2Tile tl = k2_tile(a, t, c);
-        const int b = tl.b, od = tl.od, oh = tl.oh, ow = tl.ow;
-        const bool live = tl.live;
-        const int wl = 2 * ow - 1 + h;                       // input column of this lane (kw = lane half)
-        const bool wok = live && wl >= 0 && wl < a.Wd;
-        const float *xb_ = a.x + (size_t)b * a.Cin * a.D * a.H * a.Wd;
-        float xv[KS_MAX];
+    float bias_r[16];
 #pragma unroll
-        for (int ks = 0; ks < KS_MAX; ++ks) xv[ks] = ks < nks ? k2_patch(a, xb_, ks, od, oh, wl, wok) : 0.f;
+    for (int r = 0; r < 16; ++r) {
+        const int o = crow32k(r, lane);
+        bias_r[r] = (a.bias && o < a.Cout) ? a.bias[o] : 0.f;
+    }
+    const bool lin = a.act == HNO_ACT_NONE, exp_act = a.act == HNO_ACT_SELU || a.act == HNO_ACT_ELU;
+    const float ap = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f;
+    const float aq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
+    const unsigned ntiles = (unsigned)a.B * a.Do * a.tiles_per_slab;
+    const unsigned Vo = (unsigned)a.Do * a.Ho * a.Wo, HW = (unsigned)a.H * a.Wd, DHW = (unsigned)a.D * HW;
+    const unsigned nrow = (unsigned)a.Ho * a.wtr;
+    float *ring = k2_ring + wave * (2 * KS_MAX * 64);
+    const unsigned ring_b = (unsigned)(size_t)ring;
+    const unsigned stride = gridDim.x * 4;
+    auto issue = [&](unsigned t, int slot) {
+        K2TileState ts;
+        const unsigned slab = t / a.tiles_per_slab, idx = t - slab * a.tiles_per_slab;      // wave-uniform
+        const unsigned b = slab / a.Do, od = slab - b * a.Do;
+        int oh, ow;
+        if (idx < nrow) {                  // row tile: 32 consecutive ow of output row oh
+            const unsigned ohu = idx / a.wtr;
+            oh = (int)ohu;
+            ow = (int)(idx - ohu * a.wtr) * 32 + c;
+            ts.live = ow < a.Wo - a.ncol;
+        } else {                           // column tile: 32 consecutive oh at one of the last columns
+            const unsigned j = idx - nrow, col = j / a.ctiles;
+            oh = (int)(j - col * a.ctiles) * 32 + c;
+            ow = a.Wo - a.ncol + (int)col;
+            ts.live = oh < a.Ho;
+        }
+        ts.b = b;
+        ts.vo = ts.live ? ((unsigned)od * a.Ho + oh) * a.Wo + ow : 0u;
+        const int wl = 2 * ow - 1 + h;                               // input column of this lane (kw = lane half)
+        const bool wok = ts.live && wl >= 0 && wl < a.Wd;
+        unsigned rowoff[2];
+        bool okh[2];
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            const int hh = 2 * oh - 1 + kh;
+            okh[kh] = wok && hh >= 0 && hh < a.H;
+            rowoff[kh] = okh[kh] ? (unsigned)(hh * a.Wd + wl) * 4u : 0u;
+        }
+        const float *xb_ = a.x + (size_t)b * a.Cin * DHW;
+        unsigned doff[2];                                           // element offset of depth plane d inside a channel (uniform)
+        bool okd[2];
+#pragma unroll
+        for (int kd = 0; kd < 2; ++kd) {
+            const int d = 2 * (int)od - 1 + kd;
+            okd[kd] = d >= 0 && d < a.D;                             // uniform
+            doff[kd] = okd[kd] ? (unsigned)d * HW : 0u;
+            ts.ok[kd][0] = okd[kd] && okh[0];
+            ts.ok[kd][1] = okd[kd] && okh[1];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS_MAX; ++ks) {
+            const int kh = ks & 1, kd = (ks >> 1) & 1, i = ks >> 2;
+            const bool oku = i < a.Cin && okd[kd];                   // uniform; otherwise a dummy row of channel 0
+            const float *base = xb_ + (oku ? (unsigned)i * DHW + doff[kd] : 0u);      // < 2^29 elements (host check)
+            dma_row_pair(base, rowoff[kh], __builtin_amdgcn_readfirstlane(ring_b + (slot * KS_MAX + ks) * 256));
+        }
+        return ts;
+    };
+    unsigned t = blockIdx.x * 4 + wave;
+    K2TileState cur = {}, nxt = {};
+    if (t < ntiles) cur = issue(t, 0);
+    for (int slot = 0; t < ntiles; t += stride, slot ^= 1, cur = nxt) {
+        static_assert(KS_MAX <= 63, "the DMA of one tile must fit the vmcnt counter");
+        if (t + stride < ntiles) {
+            nxt = issue(t + stride, slot ^ 1);
+            dma_wait<KS_MAX>();            // only the next tile's DMA stays in flight
+        } else {
+            dma_wait<0>();
+        }
+        const float *sl = ring + slot * KS_MAX * 64 + lane;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS_MAX; ++ks)
-            if (ks < nks) acc = mfma32k(w[ks], xv[ks], acc);
-        if (live) {
-            const size_t vo = ((size_t)od * a.Ho + oh) * a.Wo + ow;
+            if (ks < nks) {
+                const float xv = sl[ks * 64];
+                acc = mfma32k(w[ks], cur.ok[(ks >> 1) & 1][ks & 1] ? xv : 0.f, acc);
+            }
+        float val[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) val[r] = acc[r] + bias_r[r];
+        if (exp_act) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int o = crow32k(r, lane);
-                if (o < a.Cout) {
-                    float val = acc[r] + (a.bias ? a.bias[o] : 0.f);
-                    a.y[((size_t)b * a.Cout + o) * Vo + vo] = act_apply(val, a.act);
-                }
+                float e = neg_expm1(val[r]);
+                asm volatile("" : "+v"(e));             // computed for every lane and selected: no branch per register
+                val[r] = val[r] > 0.f ? ap * val[r] : aq * e;
+            }
+        } else if (!lin) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) val[r] = act_apply(val[r], a.act);
+        }
+        float *y_l = a.y + (size_t)cur.b * a.Cout * Vo + cur.vo + (h ? 4u * Vo : 0u);
+        const bool full = __builtin_amdgcn_ballot_w64(cur.live) == ~0ull;
+        if (full) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o0 = (r & 3) + 8 * (r >> 2);
+                if (o0 + 4 < a.Cout) y_l[(size_t)o0 * Vo] = val[r];                 // uniform conditions
+                else if (o0 < a.Cout) { if (h == 0) y_l[(size_t)o0 * Vo] = val[r]; }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o0 = (r & 3) + 8 * (r >> 2);
+                if (cur.live && o0 + 4 * h < a.Cout) y_l[(size_t)o0 * Vo] = val[r];
             }
         }
     }
 }
 
-// weight / bias gradient: dW[o][k] += sum_v g[o][v] * patch[k][v] with 16x16x4 MFMA from a
-// wave-private LDS tile (K = 32 output voxels per tile).  The input image needs no gradient.
+// weight / bias gradient: dW[o][k] += sum_v g[o][v] * patch[k][v] with 16x16x4 MFMA from wave-private LDS tiles
+// (K = 32 output voxels per tile).  The input image needs no gradient.
+//   * the patch rows of the NEXT tile arrive by LDS-DMA (two-slot ring, row pairs K2_XP = 68 floats apart: conflict-free 16 x 4 operand
+//     reads, see hno_pwconv.hip), gy / y of the next tile are register-prefetched behind the DMA; no workgroup barrier;
+//   * padding taps are real zeros in this product (g is not zero there), so a lane whose tap lies outside the image overwrites its own
+//     DMA'd element with 0 before the tile is read (every second row tile has one such lane: input column -1).
 #define K2_LD 34
+#define K2_XP 68
 template <int KSO_MAX, int KCH>  // KSO_MAX >= ceil(Cout/2); KCH = 32-wide chunks of k = Cin*8
 __global__ __launch_bounds__(256) void conv_k2s2_bwd_kernel(K2Args a) {
     extern __shared__ float lds[];
@@ -120,9 +186,13 @@ __global__ __launch_bounds__(256) void conv_k2s2_bwd_kernel(K2Args a) {
     const int h = lane >> 5, c = lane & 31;
     const int nkso = (a.Cout + 1) / 2;
     const int K = a.Cin * 8;
-    float *G = lds + (size_t)wave * (32 + KCH * 32) * K2_LD;
-    float *P = G + 32 * K2_LD;
-    for (int i = lane; i < (32 + KCH * 32) * K2_LD; i += 64) G[i] = 0.f;
+    constexpr int KS = KCH * 16;                       // DMA instructions (k pairs) per tile
+    constexpr int XS = KS * K2_XP;                     // floats per ring slot
+    constexpr int WAVE_FLOATS = 32 * K2_LD + 2 * XS;
+    float *G = lds + (size_t)wave * WAVE_FLOATS;       // [o][v]
+    float *P = G + 32 * K2_LD;                         // two slots of [k / 2][k & 1][v]
+    const unsigned p_lds = (unsigned)(size_t)P;
+    for (int i = lane; i < WAVE_FLOATS; i += 64) G[i] = 0.f;
     float db[KSO_MAX];
 #pragma unroll
     for (int ks = 0; ks < KSO_MAX; ++ks) db[ks] = 0.f;
@@ -132,54 +202,119 @@ __global__ __launch_bounds__(256) void conv_k2s2_bwd_kernel(K2Args a) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NTK; ++n) dw[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const long long ntiles = (long long)a.B * a.Do * a.tiles_per_slab;
-    const long long ngroups = (ntiles + 3) / 4;
-    const size_t Vo = (size_t)a.Do * a.Ho * a.Wo;
-    for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const long long t = grp * 4 + wave;
-        const bool tlv = t < ntiles;
-        const K2Tile tl = k2_tile(a, tlv ? t : 0, c);
-        const int b = tl.b, od = tl.od, oh = tl.oh, ow = tl.ow;
-        const bool live = tlv && tl.live;
-        const unsigned vo = live ? (unsigned)(((size_t)od * a.Ho + oh) * a.Wo + ow) : 0u;
+    const unsigned ntiles = (unsigned)a.B * a.Do * a.tiles_per_slab;
+    const unsigned ngroups = (ntiles + 3) / 4;
+    const unsigned Vo = (unsigned)a.Do * a.Ho * a.Wo, HW = (unsigned)a.H * a.Wd, DHW = (unsigned)a.D * HW;
+    const unsigned nrow = (unsigned)a.Ho * a.wtr;
+    const unsigned hoffV = h ? Vo : 0u;
+    float pg[KSO_MAX], py[KSO_MAX];
+    struct St { bool live; bool ok[2][2]; bool any_bad; };
+    auto fetch = [&](unsigned grp, int slot) {
+        St st;
+        const unsigned t0 = grp * 4 + wave;
+        const bool tlv = t0 < ntiles;                                            // uniform
+        const unsigned t = tlv ? t0 : 0u;
+        const unsigned slab = t / a.tiles_per_slab, idx = t - slab * a.tiles_per_slab;
+        const unsigned b = slab / a.Do, od = slab - b * a.Do;
+        int oh, ow;
+        if (idx < nrow) {
+            const unsigned ohu = idx / a.wtr;
+            oh = (int)ohu;
+            ow = (int)(idx - ohu * a.wtr) * 32 + c;
+            st.live = tlv && ow < a.Wo - a.ncol;
+        } else {
+            const unsigned j = idx - nrow, col = j / a.ctiles;
+            oh = (int)(j - col * a.ctiles) * 32 + c;
+            ow = a.Wo - a.ncol + (int)col;
+            st.live = tlv && oh < a.Ho;
+        }
+        const unsigned vo = st.live ? ((unsigned)od * a.Ho + oh) * a.Wo + ow : 0u;
         const int wl = 2 * ow - 1 + h;
-        const bool wok = live && wl >= 0 && wl < a.Wd;
-        const float *xb_ = a.x + (size_t)b * a.Cin * a.D * a.H * a.Wd;
+        const bool wok = st.live && wl >= 0 && wl < a.Wd;
+        unsigned rowoff[2];
+        bool okh[2];
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            const int hh = 2 * oh - 1 + kh;
+            okh[kh] = wok && hh >= 0 && hh < a.H;
+            rowoff[kh] = okh[kh] ? (unsigned)(hh * a.Wd + wl) * 4u : 0u;
+        }
+        bool bad = false;
+        unsigned doff[2];
+        bool okd[2];
+#pragma unroll
+        for (int kd = 0; kd < 2; ++kd) {
+            const int d = 2 * (int)od - 1 + kd;
+            okd[kd] = d >= 0 && d < a.D;
+            doff[kd] = okd[kd] ? (unsigned)d * HW : 0u;
+            st.ok[kd][0] = okd[kd] && okh[0];
+            st.ok[kd][1] = okd[kd] && okh[1];
+            bad = bad || !st.ok[kd][0] || !st.ok[kd][1];
+        }
+        st.any_bad = __builtin_amdgcn_ballot_w64(bad) != 0ull;                   // uniform
+        const float *xb_ = a.x + (size_t)b * a.Cin * DHW;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int kd = (ks >> 1) & 1, i = ks >> 2;
+            const bool oku = i < a.Cin && okd[kd];
+            const float *base = xb_ + (oku ? (unsigned)i * DHW + doff[kd] : 0u);
+            dma_row_pair(base, rowoff[ks & 1], __builtin_amdgcn_readfirstlane(p_lds + (slot * XS + ks * K2_XP) * 4));
+        }
+        // younger register loads: in-order completion makes hipcc's wait for them retire the DMA above as well
         const float *gy_b = a.gy + (size_t)b * a.Cout * Vo, *y_b = a.y_saved + (size_t)b * a.Cout * Vo;
-        const unsigned hoffV = h ? (unsigned)Vo : 0u;
 #pragma unroll
         for (int ks = 0; ks < KSO_MAX; ++ks) {
-            float g = 0.f;
+            pg[ks] = 0.f; py[ks] = 0.f;
             if (ks < nkso) {
                 const int o0 = 2 * ks;
                 const unsigned off = (o0 + 1 < a.Cout ? hoffV : 0u) + vo;
-                g = (gy_b + (size_t)o0 * Vo)[off] * act_grad_from_out((y_b + (size_t)o0 * Vo)[off], a.act);
-                g = (live && o0 + h < a.Cout) ? g : 0.f;
-                G[(o0 + h) * K2_LD + c] = g;
+                pg[ks] = (gy_b + (size_t)o0 * Vo)[off];
+                py[ks] = (y_b + (size_t)o0 * Vo)[off];
             }
-            db[ks] += g;
         }
-#pragma unroll 8
-        for (int j = 0; j < KCH * 16; ++j)
-            if (2 * j < K) P[(2 * j + h) * K2_LD + c] = k2_patch(a, xb_, j, od, oh, wl, wok);
-        __syncthreads();
+        return st;
+    };
+    St cur = {}, nxt = {};
+    if (blockIdx.x < ngroups) cur = fetch(blockIdx.x, 0);
+    int slot = 0;
+    for (unsigned grp = blockIdx.x; grp < ngroups; grp += gridDim.x, slot ^= 1, cur = nxt) {
+        float *Pc = P + slot * XS;
+        dma_wait<0>();              // this tile's DMA and register loads are the only operations in flight (the kernel stores nothing)
+#pragma unroll
+        for (int ks = 0; ks < KSO_MAX; ++ks) {
+            if (ks < nkso) {
+                float g = pg[ks] * act_grad_from_out(py[ks], a.act);
+                g = (cur.live && 2 * ks + h < a.Cout) ? g : 0.f;
+                G[(2 * ks + h) * K2_LD + c] = g;
+                db[ks] += g;
+            }
+        }
+        if (cur.any_bad) {          // zero padding taps (the DMA put a dummy element there)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                if (!cur.ok[(ks >> 1) & 1][ks & 1]) Pc[ks * K2_XP + lane] = 0.f;
+        }
+        if (grp + gridDim.x < ngroups) nxt = fetch(grp + gridDim.x, slot ^ 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         {
             const float *ga = G + (lane & 15) * K2_LD + (lane >> 4);
-            const float *pb = P + (lane & 15) * K2_LD + (lane >> 4);
+            const float *pb = Pc + ((lane & 15) >> 1) * K2_XP + (lane & 1) * 32 + (lane >> 4);
 #pragma unroll 2
             for (int ks = 0; ks < 8; ++ks) {
                 float av[MT], bv[NTK];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) av[m] = ga[m * 16 * K2_LD + ks * 4];
 #pragma unroll
-                for (int n = 0; n < NTK; ++n) bv[n] = pb[n * 16 * K2_LD + ks * 4];
+                for (int n = 0; n < NTK; ++n) bv[n] = pb[n * 8 * K2_XP + ks * 4];
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NTK; ++n) dw[m][n] = mfma16(av[m], bv[n], dw[m][n]);
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     {
         const int n = a.Cout * K + a.Cout;
@@ -232,13 +367,20 @@ extern "C" int hno_conv_k2s2_fwd(const float *x, const float *W, const float *bi
     if (rc) return rc;
     a.x = x; a.W = W; a.bias = bias; a.y = y;
     const long long ntiles = (long long)B * a.Do * a.tiles_per_slab;
+    if (ntiles >= (1ll << 31) || (long long)Cin * D * H * Wd >= (1ll << 29) || (long long)Cout * a.Do * a.Ho * a.Wo >= (1ll << 29))
+        return fail(HNO_ELIMIT, "hno_conv_k2s2_fwd: image of %d x %d x %d x %d exceeds the 32-bit offset range", Cin, D, H, Wd);
     long long grid = (ntiles + 3) / 4;
-    if (grid > 1024) grid = 1024;   // 4 workgroups per CU; measured: 1024 -> 67 us, 2048 -> 71, 4096 -> 79, 512 -> 101
+    if (grid > 1024) grid = 1024;   // four 4-wave workgroups per CU (measured: 256 -> 56 us, 512 -> 44, 1024 -> 40)
     if (debug_flags() >> 8) grid = debug_flags() >> 8;
-    if (Cin <= 4)
-        { ProfScope _ps(KID_CONV_K2S2_FWD, (hipStream_t)stream, 4.0 * B * ((double)Cin * D * H * Wd + (double)Cout * a.Do * a.Ho * a.Wo)); hipLaunchKernelGGL(conv_k2s2_fwd_kernel<16>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a); }
-    else
-        { ProfScope _ps(KID_CONV_K2S2_FWD, (hipStream_t)stream, 4.0 * B * ((double)Cin * D * H * Wd + (double)Cout * a.Do * a.Ho * a.Wo)); hipLaunchKernelGGL(conv_k2s2_fwd_kernel<32>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a); }
+    {
+        ProfScope _ps(KID_CONV_K2S2_FWD, (hipStream_t)stream, 4.0 * B * ((double)Cin * D * H * Wd + (double)Cout * a.Do * a.Ho * a.Wo));
+        if (Cin <= 4) hipLaunchKernelGGL(conv_k2s2_fwd_kernel<16>, dim3((int)grid), dim3(256), 4 * 2 * 16 * 256, (hipStream_t)stream, a);
+        else {
+            static bool attr = false;
+            if (!attr) { (void)hipFuncSetAttribute((const void *)conv_k2s2_fwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr = true; }
+            hipLaunchKernelGGL(conv_k2s2_fwd_kernel<32>, dim3((int)grid), dim3(256), 4 * 2 * 32 * 256, (hipStream_t)stream, a);
+        }
+    }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }
@@ -254,11 +396,13 @@ extern "C" int hno_conv_k2s2_bwd(const float *gy, const float *y, const float *x
     if (rc) return rc;
     a.x = x; a.gy = gy; a.y_saved = y; a.dW = dW; a.dbias = dbias; a.partials = (float *)workspace;
     const long long ntiles = (long long)B * a.Do * a.tiles_per_slab;
+    if (ntiles >= (1ll << 31) || (long long)Cin * D * H * Wd >= (1ll << 29) || (long long)Cout * a.Do * a.Ho * a.Wo >= (1ll << 29))
+        return fail(HNO_ELIMIT, "hno_conv_k2s2_bwd: image of %d x %d x %d x %d exceeds the 32-bit offset range", Cin, D, H, Wd);
     long long grid = (ntiles + 3) / 4;
-    if (grid > 1024) grid = 1024;
+    if (grid > 512) grid = 512;     // two workgroups per CU (measured: 256 -> 79 us, 512 -> 61, 1024 -> 68 incl. the slab reduce)
     if (debug_flags() >> 8) grid = debug_flags() >> 8;
     const int kch = Cin * 8 <= 32 ? 1 : 2;
-    const size_t lds = sizeof(float) * 4 * (32 + kch * 32) * K2_LD;
+    const size_t lds = sizeof(float) * 4 * (32 * K2_LD + 2 * kch * 16 * K2_XP);
     hipStream_t s = (hipStream_t)stream;
     if (Cout <= 24) {
         if (kch == 1) { ProfScope _ps(KID_CONV_K2S2_BWD, s, 4.0 * B * ((double)Cin * D * H * Wd + 2.0 * Cout * a.Do * a.Ho * a.Wo)); hipLaunchKernelGGL((conv_k2s2_bwd_kernel<12, 1>), dim3((int)grid), dim3(256), lds, s, a); }

@@ -329,22 +329,6 @@ __global__ __launch_bounds__(256, 2) void pwconv_bwd_kernel(PwBwdArgs a) {
 #define PWF_FAST_WAVES 8
 #define PWF_DMA_WAVES 4      // fast forward kernel: 4 waves (one per SIMD), each with a private two-slot LDS ring
 
-// One LDS-DMA instruction: 64 lanes x 4 bytes from (wave-uniform base + per-lane byte offset) to 256 contiguous LDS bytes at `lds_dst`
-// (wave-uniform).  No VGPR destination: the load is in flight while the wave multiplies the previous tile; it is retired by a counted
-// s_waitcnt vmcnt(N) (hipcc does not count asm memory operations -- see dma_wait).  M0 (the destination base) is saved and restored:
-// it is compiler-reserved.
-__device__ __forceinline__ void dma_row_pair(const float *base, unsigned lane_byte_off, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(lane_byte_off), "s"(base), "s"(lds_dst) : "memory");
-}
-// At most N vector-memory operations stay in flight (DMA, loads and stores share one in-order counter).  N must not exceed the number
-// of operations CERTAINLY issued after the ones waited for: a larger N would let them stay in flight.
-template <int N>
-__device__ __forceinline__ void dma_wait() {
-    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 template <int CA, int CB, int COUT, bool BF16 = false>   // channel counts of xa / xb (both even) are compile-time: all address selects fold
 __global__ __launch_bounds__(64 * PWF_DMA_WAVES) void pwconv_fwd_fast_kernel(PwArgs a) {
     constexpr int NW = PWF_DMA_WAVES;
