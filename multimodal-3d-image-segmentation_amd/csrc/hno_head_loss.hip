@@ -82,6 +82,68 @@ __global__ __launch_bounds__(256) void upsoftmax_fwd_kernel(UpArgs a) {
     }
 }
 
+// Wave-per-row-segment form of the two head kernels (probabilities / arg max): a wave owns 64 consecutive x of one output row, so
+// (b, z, y), the row offsets and the y / z interpolation weights are wave-uniform -- the one-thread-per-voxel form above spends most of
+// its instructions on five 64-bit divisions per voxel.  Same loads (consecutive lanes -> consecutive x: one or two cache lines per
+// gather), same arithmetic and association order.
+template <int KMAX, bool ARGMAX>
+__global__ __launch_bounds__(256) void uphead_seg_kernel(UpArgs a, unsigned char *__restrict__ labels) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned nseg = (unsigned)(a.W + 63) / 64, items = (unsigned)a.B * a.D * a.H * nseg;
+    const unsigned v_lr = (unsigned)a.d * a.h * a.w;
+    const size_t V = (size_t)a.D * a.H * a.W;
+    for (unsigned item = blockIdx.x * 4 + wave; item < items; item += gridDim.x * 4) {
+        const unsigned row = item / nseg, seg = item - row * nseg;             // wave-uniform
+        const unsigned bz = row / a.H, y = row - bz * a.H, b = bz / a.D, z = bz - b * a.D;
+        const int x = (int)seg * 64 + lane;
+        const bool in = x < a.W;
+        const Lin lz = lin_coord((int)z, a.sd, a.d), ly = lin_coord((int)y, a.sh, a.h), lx = lin_coord(in ? x : a.W - 1, a.sw, a.w);
+        const unsigned o00 = ((unsigned)lz.i0 * a.h + ly.i0) * a.w, o01 = ((unsigned)lz.i0 * a.h + ly.i1) * a.w;
+        const unsigned o10 = ((unsigned)lz.i1 * a.h + ly.i0) * a.w, o11 = ((unsigned)lz.i1 * a.h + ly.i1) * a.w;
+        float val[KMAX];
+        float mx = -3.0e38f;
+        int arg = 0;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            val[k] = 0.f;
+            if (k < a.K) {
+                const float *s = a.lr + ((size_t)b * a.K + k) * v_lr;
+                // same association order as upsample_trilinear3d: w-lerp, then h, then d
+                const float c00 = lx.w0 * s[o00 + lx.i0] + lx.w1 * s[o00 + lx.i1];
+                const float c01 = lx.w0 * s[o01 + lx.i0] + lx.w1 * s[o01 + lx.i1];
+                const float c10 = lx.w0 * s[o10 + lx.i0] + lx.w1 * s[o10 + lx.i1];
+                const float c11 = lx.w0 * s[o11 + lx.i0] + lx.w1 * s[o11 + lx.i1];
+                val[k] = lz.w0 * (ly.w0 * c00 + ly.w1 * c01) + lz.w1 * (ly.w0 * c10 + ly.w1 * c11);
+                if (ARGMAX) {
+                    if (val[k] > mx) { mx = val[k]; arg = k; }
+                } else {
+                    mx = fmaxf(mx, val[k]);
+                }
+            }
+        }
+        const size_t vo = ((size_t)z * a.H + y) * a.W + x;
+        if constexpr (ARGMAX) {
+            if (in) labels[(size_t)b * V + vo] = (unsigned char)arg;
+        } else {
+            if (a.softmax) {
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+                    if (k < a.K) {
+                        val[k] = expf(val[k] - mx);
+                        sum += val[k];
+                    }
+                const float inv = 1.f / sum;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) val[k] *= inv;
+            }
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < a.K && in) a.out[((size_t)b * a.K + k) * V + vo] = val[k];
+        }
+    }
+}
+
 // Inference head: argmax over channels of the upsampled logits, written as uint8 class labels.  softmax is
 // monotone, so the probabilities (67 MB per 2 volumes, and their trip over PCIe in the reference's testing loop,
 // experiments/train_test.py:398-408) are never formed.  Ties resolve to the lowest index like numpy.argmax.
@@ -595,9 +657,19 @@ extern "C" int hno_upsoftmax_fwd(const float *logits_lr, float *probs, int B, in
     int rc = up_fill(a, B, K, d, h, w, D, H, W, softmax);
     if (rc) return rc;
     a.lr = logits_lr; a.out = probs;
-    const int grid = grid1d((size_t)B * D * H * W);
-    if (K <= 4) { ProfScope _ps(KID_UPSOFTMAX_FWD, (hipStream_t)stream, 4.0 * B * K * ((double)d * h * w + (double)D * H * W)); hipLaunchKernelGGL(upsoftmax_fwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
-    else { ProfScope _ps(KID_UPSOFTMAX_FWD, (hipStream_t)stream, 4.0 * B * K * ((double)d * h * w + (double)D * H * W)); hipLaunchKernelGGL(upsoftmax_fwd_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
+    ProfScope _ps(KID_UPSOFTMAX_FWD, (hipStream_t)stream, 4.0 * B * K * ((double)d * h * w + (double)D * H * W));
+    const long long items = (long long)B * D * H * ((W + 63) / 64);
+    if (items < (1ll << 31) && (long long)d * h * w < (1ll << 31) && !(debug_flags() & 16)) {
+        long long grid = (items + 3) / 4;
+        if (grid > 8192) grid = 8192;
+        if (debug_flags() >> 8) grid = debug_flags() >> 8;
+        if (K <= 4) hipLaunchKernelGGL((uphead_seg_kernel<4, false>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a, nullptr);
+        else hipLaunchKernelGGL((uphead_seg_kernel<8, false>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a, nullptr);
+    } else {
+        const int grid = grid1d((size_t)B * D * H * W);
+        if (K <= 4) hipLaunchKernelGGL(upsoftmax_fwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(upsoftmax_fwd_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }
@@ -609,10 +681,19 @@ extern "C" int hno_up_argmax(const float *logits_lr, unsigned char *labels, int 
     int rc = up_fill(a, B, K, d, h, w, D, H, W, 0);
     if (rc) return rc;
     a.lr = logits_lr;
-    const int grid = grid1d((size_t)B * D * H * W);
     ProfScope _ps(KID_UPSOFTMAX_FWD, (hipStream_t)stream, 4.0 * B * K * (double)d * h * w + (double)B * D * H * W);
-    if (K <= 4) hipLaunchKernelGGL(upargmax_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, labels);
-    else hipLaunchKernelGGL(upargmax_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, labels);
+    const long long items = (long long)B * D * H * ((W + 63) / 64);
+    if (items < (1ll << 31) && (long long)d * h * w < (1ll << 31) && !(debug_flags() & 16)) {
+        long long grid = (items + 3) / 4;
+        if (grid > 8192) grid = 8192;
+        if (debug_flags() >> 8) grid = debug_flags() >> 8;
+        if (K <= 4) hipLaunchKernelGGL((uphead_seg_kernel<4, true>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a, labels);
+        else hipLaunchKernelGGL((uphead_seg_kernel<8, true>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a, labels);
+    } else {
+        const int grid = grid1d((size_t)B * D * H * W);
+        if (K <= 4) hipLaunchKernelGGL(upargmax_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, labels);
+        else hipLaunchKernelGGL(upargmax_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, labels);
+    }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }
