@@ -268,8 +268,10 @@ int hno_cb_wgrad(const void *g, int Cg, const void *xa, int Ca, const void *xb, 
 int hno_cb_gn_apply(const void *y1, const float *mr1, const float *gamma1, const float *beta1, const void *y2, const float *mr2,
                     const float *gamma2, const float *beta2, void *z, int B, int C, long long V, int act, void *stream);
 size_t hno_cb_gn_bwd_workspace_bytes(int B, int C);
+/* dy_colsum (C floats, may be NULL): sum over samples and voxels of dy per channel = the bias gradient of the convolution that produced
+ * y, obtained from the per-channel reductions the backward already makes (no pass over dy: see cb_gn_bwd_apply_kernel). */
 int hno_cb_gn_bwd(const void *dz, const void *y, const float *mr, const float *gamma, const float *beta, void *dy, float *dgamma,
-                  float *dbeta, void *workspace, int B, int C, long long V, int act, int accumulate, void *stream);
+                  float *dbeta, float *dy_colsum, void *workspace, int B, int C, long long V, int act, int accumulate, void *stream);
 /* fp32 NCDHW (C channels) -> bf16 channels-last with CP >= C channels (pad channels zero), and back */
 int hno_cb_pack_input(const float *x, void *y, int B, int C, int CP, long long V, void *stream);
 int hno_cb_unpack(const void *x, float *y, int B, int C, int CP, long long V, void *stream);

@@ -67,7 +67,7 @@ SIGNATURES = {
     'hno_cb_wgrad': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
     'hno_cb_gn_apply': (c_int, [c_void_p] * 9 + [c_int, c_int, c_ll, c_int, c_void_p]),
     'hno_cb_gn_bwd_workspace_bytes': (c_size_t, [c_int] * 2),
-    'hno_cb_gn_bwd': (c_int, [c_void_p] * 9 + [c_int, c_int, c_ll, c_int, c_int, c_void_p]),
+    'hno_cb_gn_bwd': (c_int, [c_void_p] * 10 + [c_int, c_int, c_ll, c_int, c_int, c_void_p]),
     'hno_cb_pack_input': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_ll, c_void_p]),
     'hno_cb_unpack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_ll, c_void_p]),
     'hno_cb_colsum_workspace_bytes': (c_size_t, [c_int]),

@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void cb_gn_bwd_reduce_kernel(const bf16_t *__r
                                                               const float *__restrict__ mr, const float *__restrict__ gamma,
                                                               const float *__restrict__ beta, float *__restrict__ slab, int C, long long V,
                                                               int act) {
-    extern __shared__ float lds[];    // [256][16]
+    extern __shared__ float lds[];    // [256][24]
     const int b = blockIdx.y, nblk = gridDim.x;
     const float mean = mr[2 * b], rstd = mr[2 * b + 1];
     const int C8 = C >> 3;
@@ -587,9 +587,9 @@ __global__ __launch_bounds__(256) void cb_gn_bwd_reduce_kernel(const bf16_t *__r
     // threads 0 .. S-1 with S = the largest multiple of C8 <= 256 stride the items by S, so a thread keeps ONE channel
     // group (it % C8 is constant) and its 16 sums stay in registers until the end
     const int S = 256 - 256 % C8;
-    float s1[8], s2[8];
+    float s1[8], s2[8], s3[8];      // sums of t, t xhat and xhat (the last one gives the convolution's bias gradient, see finalize)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = s3[j] = 0.f;
     const int cg = (int)(threadIdx.x % C8);
     float gm[8], bt[8];
 #pragma unroll
@@ -609,20 +609,22 @@ __global__ __launch_bounds__(256) void cb_gn_bwd_reduce_kernel(const bf16_t *__r
                     const float t = g * act_grad_from_pre(fmaf(xh, gm[j], bt[j]), act);
                     s1[j] += t;
                     s2[j] = fmaf(t, xh, s2[j]);
+                    s3[j] += xh;
                 }
         }
-    // per-thread sums -> LDS [thread][16]; then channel c = 8 cg + j sums its S / C8 contributing threads in a fixed order
+    // per-thread sums -> LDS [thread][24]; then channel c = 8 cg + j sums its S / C8 contributing threads in a fixed order
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        lds[threadIdx.x * 16 + j] = s1[j];
-        lds[threadIdx.x * 16 + 8 + j] = s2[j];
+        lds[threadIdx.x * 24 + j] = s1[j];
+        lds[threadIdx.x * 24 + 8 + j] = s2[j];
+        lds[threadIdx.x * 24 + 16 + j] = s3[j];
     }
     __syncthreads();
-    float *dst = slab + ((size_t)b * nblk + blockIdx.x) * 2 * C;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float *dst = slab + ((size_t)b * nblk + blockIdx.x) * 3 * C;
+    for (int i = threadIdx.x; i < 3 * C; i += 256) {
         const int which = i / C, c = i - which * C, g8 = c >> 3, j = c & 7;
         float acc = 0.f;
-        for (int t = g8; t < S; t += C8) acc += lds[t * 16 + which * 8 + j];
+        for (int t = g8; t < S; t += C8) acc += lds[t * 24 + which * 8 + j];
         dst[i] = acc;
     }
 }
@@ -634,27 +636,30 @@ __global__ __launch_bounds__(256) void cb_gn_bwd_reduce_kernel(const bf16_t *__r
 __global__ __launch_bounds__(256) void cb_gn_bwd_finalize_kernel(const float *__restrict__ slab, const float *__restrict__ gamma, int B, int nblk,
                                                                 int C, float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                                 float *__restrict__ gS, int accumulate) {
-    __shared__ float sh[2][32][8];
+    __shared__ float sh[3][32][8];
     const int j = threadIdx.x & 7, slice = threadIdx.x >> 3;
     const int c = blockIdx.x * 8 + j;
     float dg = 0.f, db = 0.f;
     for (int b = 0; b < B; ++b) {
-        float s1 = 0.f, s2 = 0.f;
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
         for (int k = slice; k < nblk; k += 32) {
-            const float *p = slab + ((size_t)b * nblk + k) * 2 * C;
+            const float *p = slab + ((size_t)b * nblk + k) * 3 * C;
             s1 += p[c];
             s2 += p[C + c];
+            s3 += p[2 * C + c];
         }
         sh[0][slice][j] = s1;
         sh[1][slice][j] = s2;
+        sh[2][slice][j] = s3;
         __syncthreads();
         if (slice == 0) {
-            float t1 = 0.f, t2 = 0.f;
-            for (int q = 0; q < 32; ++q) { t1 += sh[0][q][j]; t2 += sh[1][q][j]; }
+            float t1 = 0.f, t2 = 0.f, t3 = 0.f;
+            for (int q = 0; q < 32; ++q) { t1 += sh[0][q][j]; t2 += sh[1][q][j]; t3 += sh[2][q][j]; }
             db += t1;
             dg += t2;
-            gS[((size_t)b * 2) * C + c] = gamma[c] * t1;
-            gS[((size_t)b * 2 + 1) * C + c] = gamma[c] * t2;
+            gS[((size_t)b * 4) * C + c] = gamma[c] * t1;
+            gS[((size_t)b * 4 + 1) * C + c] = gamma[c] * t2;
+            gS[((size_t)b * 4 + 2) * C + c] = t3;          // sum_v xhat[c][v]
         }
         __syncthreads();
     }
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(256) void cb_gn_bwd_finalize_kernel(const float *__
 __global__ __launch_bounds__(256) void cb_gn_bwd_apply_kernel(const bf16_t *__restrict__ dz, const bf16_t *__restrict__ y, const float *__restrict__ mr,
                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
                                                              const float *__restrict__ gS, bf16_t *__restrict__ dy, int C, long long per_sample,
-                                                             int act) {
+                                                             int act, float *__restrict__ dcolsum, int B) {
     const int b = blockIdx.y;
     // k1 = sum_c gS[b][0][c] / N, k2 = sum_c gS[b][1][c] / N: every workgroup re-reduces the <= 2 x 2048 values itself (fixed
     // order, so all workgroups agree bit for bit) instead of waiting for one more tiny launch
@@ -676,8 +681,8 @@ __global__ __launch_bounds__(256) void cb_gn_bwd_apply_kernel(const bf16_t *__re
     {
         float a1 = 0.f, a2 = 0.f;
         for (int c = threadIdx.x; c < C; c += 256) {
-            a1 += gS[((size_t)b * 2) * C + c];
-            a2 += gS[((size_t)b * 2 + 1) * C + c];
+            a1 += gS[((size_t)b * 4) * C + c];
+            a2 += gS[((size_t)b * 4 + 1) * C + c];
         }
         kred[0][threadIdx.x] = a1;
         kred[1][threadIdx.x] = a2;
@@ -692,6 +697,39 @@ __global__ __launch_bounds__(256) void cb_gn_bwd_apply_kernel(const bf16_t *__re
     }
     const float inv_n = 1.0f / (float)per_sample;
     const float mean = mr[2 * b], rstd = mr[2 * b + 1], k1 = kred[0][0] * inv_n, k2 = kred[1][0] * inv_n;
+    // Column sums of dy = the bias gradient of the convolution that produced y, without another pass over dy:
+    //   sum_v dy[c][v] = rstd (gamma_c S1_c - V k1 - k2 S3_c),  S1 = sum_v t, S3 = sum_v xhat  (both already reduced per channel).
+    // Workgroup (0, 0) does it for every sample (k1, k2 of the other samples re-reduced the same way), fixed order.
+    if (dcolsum && blockIdx.x == 0 && blockIdx.y == 0) {
+        const float Vf = (float)(per_sample / C);
+        for (int c = threadIdx.x; c < C; c += 256) dcolsum[c] = 0.f;
+        for (int bb = 0; bb < B; ++bb) {
+            float q1 = k1, q2 = k2;
+            if (bb != b) {                       // uniform branch (b == 0 here)
+                __syncthreads();
+                float a1 = 0.f, a2 = 0.f;
+                for (int c = threadIdx.x; c < C; c += 256) {
+                    a1 += gS[((size_t)bb * 4) * C + c];
+                    a2 += gS[((size_t)bb * 4 + 1) * C + c];
+                }
+                kred[0][threadIdx.x] = a1;
+                kred[1][threadIdx.x] = a2;
+                __syncthreads();
+                for (int o = 128; o > 0; o >>= 1) {
+                    if ((int)threadIdx.x < o) {
+                        kred[0][threadIdx.x] += kred[0][threadIdx.x + o];
+                        kred[1][threadIdx.x] += kred[1][threadIdx.x + o];
+                    }
+                    __syncthreads();
+                }
+                q1 = kred[0][0] * inv_n;
+                q2 = kred[1][0] * inv_n;
+            }
+            const float rs = mr[2 * bb + 1];
+            for (int c = threadIdx.x; c < C; c += 256)
+                dcolsum[c] += rs * (gS[((size_t)bb * 4) * C + c] - Vf * q1 - q2 * gS[((size_t)bb * 4 + 2) * C + c]);
+        }
+    }
     const long long n8 = per_sample >> 3;
     const int C8 = C >> 3;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
@@ -1377,25 +1415,25 @@ extern "C" int hno_cb_gn_apply(const void *y1, const float *mr1, const float *ga
 
 #define CB_GN_BWD_BLOCKS 1024     // upper bound; small tensors use fewer (>= 64 voxels per workgroup)
 extern "C" size_t hno_cb_gn_bwd_workspace_bytes(int B, int C) {
-    return ((size_t)B * CB_GN_BWD_BLOCKS * 2 * C + 2 * (size_t)B * C + 2 * (size_t)(B > 8 ? B : 8)) * sizeof(float) + 256;
+    return ((size_t)B * CB_GN_BWD_BLOCKS * 3 * C + 4 * (size_t)B * C + 2 * (size_t)(B > 8 ? B : 8)) * sizeof(float) + 256;
 }
 
 // backward of z = act(gamma (y - mean) rstd + beta) w.r.t. y, gamma, beta.  accumulate != 0: dgamma / dbeta += .
 extern "C" int hno_cb_gn_bwd(const void *dz, const void *y, const float *mr, const float *gamma, const float *beta, void *dy,
-                             float *dgamma, float *dbeta, void *workspace, int B, int C, long long V, int act, int accumulate,
-                             void *stream) {
+                             float *dgamma, float *dbeta, float *dy_colsum, void *workspace, int B, int C, long long V, int act,
+                             int accumulate, void *stream) {
     HNO_REQUIRE(dz && y && mr && gamma && beta && dy && dgamma && dbeta && workspace && B > 0 && C > 0 && V > 0, "hno_cb_gn_bwd: bad argument");
     if (C % 8 || C > 2048) return fail(HNO_ELIMIT, "hno_cb_gn_bwd: C = %d must be a multiple of 8 (<= 2048)", C);
     hipStream_t s = (hipStream_t)stream;
     float *slab = (float *)workspace;
-    float *gS = slab + (size_t)B * CB_GN_BWD_BLOCKS * 2 * C;
+    float *gS = slab + (size_t)B * CB_GN_BWD_BLOCKS * 3 * C;
     // a streaming pass: enough workgroups to cover the latency (256 of them left one workgroup per CU: 0.9 TB/s)
     int nblk = (int)((V + 63) / 64);
     if (nblk > CB_GN_BWD_BLOCKS) nblk = CB_GN_BWD_BLOCKS;
     if (nblk < 1) nblk = 1;
     {
         ProfScope _ps(KID_CB_GN, s, (double)B * V * C * 4.0);
-        hipLaunchKernelGGL(cb_gn_bwd_reduce_kernel, dim3(nblk, B), dim3(256), 256 * 16 * sizeof(float), s, (const bf16_t *)dz, (const bf16_t *)y, mr, gamma,
+        hipLaunchKernelGGL(cb_gn_bwd_reduce_kernel, dim3(nblk, B), dim3(256), 256 * 24 * sizeof(float), s, (const bf16_t *)dz, (const bf16_t *)y, mr, gamma,
                            beta, slab, C, V, act);
         HNO_CHECK_LAUNCH();
     }
@@ -1404,7 +1442,7 @@ extern "C" int hno_cb_gn_bwd(const void *dz, const void *y, const float *mr, con
     {
         ProfScope _ps(KID_CB_GN, s, (double)B * V * C * 6.0);
         hipLaunchKernelGGL(cb_gn_bwd_apply_kernel, dim3(gsz(V * C / 8, 256, 2048), B), dim3(256), 0, s, (const bf16_t *)dz, (const bf16_t *)y, mr, gamma,
-                           beta, (const float *)gS, (bf16_t *)dy, C, V * C, act);
+                           beta, (const float *)gS, (bf16_t *)dy, C, V * C, act, dy_colsum, B);
         HNO_CHECK_LAUNCH();
     }
     return HNO_OK;

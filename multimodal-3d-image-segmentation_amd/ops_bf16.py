@@ -170,7 +170,12 @@ def gn_apply_raw(y1, mr1, g1, b1, act, y2=None, mr2=None, g2=None, b2=None):
     return z
 
 
-def gn_bwd_raw(dz, y, mr, gamma, beta, act):
+_stats = {'colsum_fused': 0, 'colsum_pass': 0}      # how ConvFn.backward got its bias gradient (tests)
+
+
+def gn_bwd_raw(dz, y, mr, gamma, beta, act, colsum=False):
+    """colsum: also return sum_{b, v} dy[b, v, c] (the bias gradient of the convolution that produced y), which the kernels get from
+    their per-channel reductions without another pass over dy."""
     dz, y = _cl(dz), _cl(y)
     B, C = y.shape[0], y.shape[4]
     V = y.shape[1] * y.shape[2] * y.shape[3]
@@ -178,10 +183,11 @@ def gn_bwd_raw(dz, y, mr, gamma, beta, act):
     dy = torch.empty_like(y)
     dg = torch.empty(C, device=y.device, dtype=torch.float32)
     db = torch.empty(C, device=y.device, dtype=torch.float32)
+    cs = torch.empty(C, device=y.device, dtype=torch.float32) if colsum else None
     ws = _ws(L.hno_cb_gn_bwd_workspace_bytes(B, C), y.device)
-    check(L.hno_cb_gn_bwd(ptr(dz), ptr(y), ptr(mr), ptr(_f32(gamma)), ptr(_f32(beta)), ptr(dy), ptr(dg), ptr(db), ptr(ws), B, C, V, act, 0,
-                          stream_ptr()), 'hno_cb_gn_bwd')
-    return dy, dg, db
+    check(L.hno_cb_gn_bwd(ptr(dz), ptr(y), ptr(mr), ptr(_f32(gamma)), ptr(_f32(beta)), ptr(dy), ptr(dg), ptr(db), ptr(cs), ptr(ws), B, C, V,
+                          act, 0, stream_ptr()), 'hno_cb_gn_bwd')
+    return (dy, dg, db, cs) if colsum else (dy, dg, db)
 
 
 def pack_input_raw(x, CP=None):
@@ -262,6 +268,7 @@ class ConvFn(_HnoFunction):
             return (None,) * 9
         xa, xb, W = ctx.saved_tensors
         ks, stride, transposed, pad, has_bias, Ca, Cb, Cout = ctx.cfg
+        cs = getattr(gy, '_hno_colsum', None)        # left by GNActFn.backward: the column sums of this very tensor
         gy = gy.contiguous()
         Cin = Ca + Cb
         gxa = gxb = None
@@ -273,7 +280,10 @@ class ConvFn(_HnoFunction):
             else:   # split of the channel axis of a channels-last tensor (index op; only the decoder's two-input convs)
                 gxa, gxb = gx[..., :Ca].contiguous(), gx[..., Ca:].contiguous()
         dW = wgrad_raw(gy, xa, xb, W.shape, transposed, ks, stride, pad, param=W if W.is_leaf else None)
-        db = colsum_raw(gy) if has_bias else None
+        db = None
+        if has_bias:
+            db = cs if (cs is not None and cs.numel() == Cout) else colsum_raw(gy)
+            _stats['colsum_fused' if db is cs else 'colsum_pass'] += 1
         return gxa, gxb, dW, db, None, None, None, None, None
 
 
@@ -297,10 +307,14 @@ class GNActFn(_HnoFunction):
     def backward(ctx, dz):
         y1, mr1, g1, b1, y2, mr2, g2, b2 = ctx.saved_tensors
         dz = dz.contiguous()
-        dy1, dg1, db1 = gn_bwd_raw(dz, y1, mr1, g1, b1, ctx.act)
+        # the column sums ride on the gradient tensor: the producing ConvFn's backward takes them as its bias gradient when autograd
+        # hands it this very tensor (one consumer; a summed gradient is a new tensor without the attribute)
+        dy1, dg1, db1, cs1 = gn_bwd_raw(dz, y1, mr1, g1, b1, ctx.act, colsum=True)
+        dy1._hno_colsum = cs1
         dy2 = dg2 = db2 = None
         if y2 is not None:
-            dy2, dg2, db2 = gn_bwd_raw(dz, y2, mr2, g2, b2, ctx.act)
+            dy2, dg2, db2, cs2 = gn_bwd_raw(dz, y2, mr2, g2, b2, ctx.act, colsum=True)
+            dy2._hno_colsum = cs2
         return dy1, None, dg1, db1, None, dy2, None, dg2, db2
 
 

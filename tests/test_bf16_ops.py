@@ -154,6 +154,12 @@ def test_groupnorm_act_vs_float64(ob, two, act):
             assert rel_err(from_cl(a).numpy(), b.numpy()) < BF16_TOL, k
         else:
             assert rel_err(a.cpu().numpy(), b.numpy()) < 1e-4, k
+    # the per-channel column sums of dy that ride on the gradient tensor (the producing convolution's bias gradient, taken from the
+    # backward's own reductions instead of a pass over dy): against the float64 sums of the float64 gradient
+    dy, dg, db, cs = ob.gn_bwd_raw(to_cl(cot), d1[0].detach(), d1[1], d1[2].detach(), d1[3].detach(), aid, colsum=True)
+    want = gref[0].sum(dim=(0, 2, 3, 4)).numpy()
+    assert rel_err(cs.cpu().numpy(), want) < 1e-4
+    assert rel_err(from_cl(dy).double().sum(dim=(0, 2, 3, 4)).numpy(), want) < BF16_TOL     # what a pass over the bf16 dy gives
 
 
 @pytest.mark.parametrize('shape', ['24+24->24', '24->24', 'branch'])
