@@ -278,7 +278,7 @@ class ConvFn(_HnoFunction):
             if xb is None:
                 gxa = gx
             else:   # split of the channel axis of a channels-last tensor (index op; only the decoder's two-input convs)
-                gxa, gxb = gx[..., :Ca].contiguous(), gx[..., Ca:].contiguous()
+                gxa, gxb = gx[..., :Ca], gx[..., Ca:]      # views: the consumers (crop backward, gradient sums, .contiguous() of the next op) copy at most once
         dW = wgrad_raw(gy, xa, xb, W.shape, transposed, ks, stride, pad, param=W if W.is_leaf else None)
         db = None
         if has_bias:
