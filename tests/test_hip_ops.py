@@ -1213,3 +1213,50 @@ def test_overlapped_bucket_allreduce_on_rccl_single_rank(pkg, tmp_path):
     res = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert 'ok nccl1' in res.stdout
+
+
+@pytest.mark.parametrize('grid', [1, 3])
+def test_dma_ring_kernels_many_tiles_per_wave(pkg, grid):
+    """The pointwise and conv_in kernels stream their operands through two-slot LDS-DMA rings, one tile ahead (counted
+    s_waitcnt vmcnt).  The op tests above give every wave at most one tile; here the launch is forced down to `grid`
+    workgroups (debug grid override), so every wave walks through many tiles, both ring slots and ragged tail tiles --
+    against float64."""
+    from multimodal_3d_image_segmentation_amd import ops
+    L = pkg._lib.lib()
+    torch.manual_seed(5)
+    try:
+        L.hno_set_debug(grid << 8)
+        for (Ca, Cb, Cout, V, act) in ((24, 24, 24, (9, 11, 13), 'selu'), (24, 0, 24, (10, 10, 10), 'selu'), (24, 0, 4, (7, 9, 11), None),
+                                       (48, 0, 48, (6, 7, 9), 'selu')):
+            B = 2
+            xa = torch.randn((B, Ca) + V, dtype=torch.float64)
+            xb = torch.randn((B, Cb) + V, dtype=torch.float64) if Cb else None
+            W = torch.randn(Cout, Ca + Cb, dtype=torch.float64) * 0.2
+            bs = torch.randn(Cout, dtype=torch.float64) * 0.1
+            ins = [t.clone().requires_grad_(True) for t in (xa, xb, W, bs) if t is not None]
+            cat = torch.cat([ins[0], ins[1]], 1) if Cb else ins[0]
+            y = F.conv3d(cat, ins[-2][:, :, None, None, None], ins[-1])
+            y = getattr(F, act)(y) if act else y
+            cot = torch.randn_like(y)
+            gref = torch.autograd.grad((y * cot).sum(), ins)
+            dins = [t.detach().float().cuda().requires_grad_(True) for t in ins]
+            yd = ops.PwConvFn.apply(dins[0], dins[1] if Cb else None, dins[-2], dins[-1], ops.act_id(act))
+            assert rel_err(yd.detach().cpu().numpy(), y.detach().numpy()) < 2e-6, (Ca, Cb, Cout)
+            gd = torch.autograd.grad((yd * cot.float().cuda()).sum(), dins)
+            for a, b_ in zip(gd, gref):
+                assert rel_err(a.cpu().numpy(), b_.numpy()) < 5e-6, (Ca, Cb, Cout)
+        for shape, Cin, Cout in (((8, 10, 70), 4, 24), ((6, 6, 130), 3, 8)):
+            x = torch.randn((2, Cin) + shape, dtype=torch.float64)
+            W = (torch.randn(Cout, Cin, 2, 2, 2, dtype=torch.float64) * 0.3).requires_grad_(True)
+            b = (torch.randn(Cout, dtype=torch.float64) * 0.1).requires_grad_(True)
+            y = F.selu(F.conv3d(x, W, b, stride=2, padding=1))
+            cot = torch.randn_like(y)
+            gW, gb = torch.autograd.grad((y * cot).sum(), [W, b])
+            Wd, bd = W.detach().float().cuda().requires_grad_(True), b.detach().float().cuda().requires_grad_(True)
+            yd = ops.ConvK2S2Fn.apply(x.float().cuda(), Wd, bd, ops.ACT_SELU)
+            assert rel_err(yd.detach().cpu().numpy(), y.detach().numpy()) < 2e-6
+            gWd, gbd = torch.autograd.grad((yd * cot.float().cuda()).sum(), [Wd, bd])
+            assert rel_err(gWd.cpu().numpy(), gW.numpy()) < 5e-6
+            assert rel_err(gbd.cpu().numpy(), gb.numpy()) < 5e-6
+    finally:
+        L.hno_set_debug(0)
