@@ -340,7 +340,7 @@ __global__ __launch_bounds__(64 * PWF_DMA_WAVES) void pwconv_fwd_fast_kernel(PwA
     constexpr int CIN = 2 * NKI;
     constexpr int OT = (COUT + 31) / 32;          // output tiles of 32 rows (COUT <= 64)
     constexpr int CL = COUT - 32 * (OT - 1);      // rows of the last tile
-    constexpr int NRL = CL > 28 ? 16 : (CL > 20 ? 12 : (CL > 12 ? 8 : 4));   // accumulator registers holding rows < COUT
+    constexpr int NRL = CL > 24 ? 16 : (CL > 16 ? 12 : (CL > 8 ? 8 : 4));    // accumulator registers holding rows < COUT (register r: rows (r & 3) + 8 (r >> 2) + 4 h)
     const unsigned V = a.V;
     float w[OT][NKI];
 #pragma unroll
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kern
     // load above the previous row's store): 130 us instead of 95 per call
     constexpr int NQ = (!BR && CB > 0) ? CB / 2 : 1;
     float pq[NQ] = {};
-    const bool accb = !BR && CB > 0 && (a.accum & 2) && a.gxb;
+    const bool accb = !BR && CB > 0 && CA % 8 == 0 && (a.accum & 2) && a.gxb;      // (straddling rows take the read-modify-write path)
     auto fetch = [&](unsigned grp, int slot) {
         const unsigned t = grp * NW + wave;
         const bool live = t < ntiles;
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kern
         const unsigned tu = grp * NW + wave;                    // wave-uniform copies of the tile coordinates
         const unsigned bu = tu < ntiles ? tu / tiles_per_b : 0u;
         const bool fast_store = BR == 0 && tu < ntiles && (tu - bu * tiles_per_b) * 32 + 32 <= V && a.gxa && (CB == 0 || a.gxb) &&
-                                !(a.accum & 1) && !(a.dbg & 4);
+                                !(a.accum & 1) && !(CA % 8 != 0 && (a.accum & 2)) && !(a.dbg & 4);
         const unsigned t = grp * NW + wave;
         const bool live = t < ntiles;
         const unsigned b = live ? t / tiles_per_b : 0u;
@@ -808,13 +808,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kern
                 for (int r = 0; r < 16; ++r) {
                     const int irow = ic * 32 + (r & 3) + 8 * (r >> 2);
                     if (irow < CIN) {
+                        // register r holds row irow (h = 0 lanes) and irow + 4 (h = 1 lanes): both xa rows, both xb rows, or -- when CA is
+                        // not a multiple of 8 (12 + 12 channels) -- an xa row and an xb row
+                        const bool a0 = irow < CA, a1 = irow + 4 < CA;         // fold after unrolling
                         float gv = acc[r];
-                        if (irow < CA && xact) gv *= xo[r] > 0.f ? xp : xo[r] + xq;
+                        if (a0 && xact) {
+                            const float f = xo[r] > 0.f ? xp : xo[r] + xq;
+                            gv *= (a1 || h == 0) ? f : 1.f;
+                        }
                         if (irow >= CA && CB > 0 && accb) {
                             const int i = irow - CA;
                             gv += qc[((i >> 3) << 2) + (i & 3) < NQ ? ((i >> 3) << 2) + (i & 3) : 0];
                         }
-                        float *dst = irow < CA ? ga_l + (size_t)irow * V : gb_l + (size_t)(irow - CA) * V;
+                        float *dst;
+                        if (a0 == a1) dst = a0 ? ga_l + (size_t)irow * V : gb_l + (size_t)(irow - CA) * V;
+                        else dst = h ? a.gxb + ((size_t)b * CB + (irow + 4 - CA)) * V + v : a.gxa + ((size_t)b * CA + irow) * V + v;
                         if (irow + 4 < CIN) *dst = gv;
                         else if (h == 0) *dst = gv;
                     }
@@ -823,20 +831,24 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kern
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int irow = ic * 32 + (r & 3) + 8 * (r >> 2);
-                    if (irow < CIN) {  // compile-time; rows irow, irow+4 are on one side since CA % 8 == 0
-                        float *base = irow < CA ? (a.gxa ? a.gxa + ((size_t)b * CA + irow) * V : nullptr)
-                                                : (a.gxb ? a.gxb + ((size_t)b * CB + (irow - CA)) * V : nullptr);
+                    if (irow < CIN) {  // compile-time
+                        const bool a0 = irow < CA, a1 = irow + 4 < CA;          // see the whole-tile path above
+                        const bool on_a = (a0 == a1) ? a0 : h == 0;           // this lane's row is an xa row
+                        const int lrow = irow + 4 * h;                          // this lane's row of [xa ; xb]
+                        float *base = on_a ? (a.gxa ? a.gxa + ((size_t)b * CA + lrow) * V : nullptr)
+                                           : (a.gxb ? a.gxb + ((size_t)b * CB + (lrow - CA)) * V : nullptr);
                         if (base && vin && (irow + 4 < CIN || h == 0) && !((a.dbg & 4) && acc[r] != 12345.678f)) {
                             float gv = acc[r];
-                            if (irow < CA && xact) {
+                            if (a0 && xact && on_a) {
                                 const float xo = DMA ? Xc[((irow >> 1) + 2 * h) * PWB_XP + (irow & 1) * 32 + c] : X[(irow + 4 * h) * PWB_LD + c];
                                 gv *= xo > 0.f ? xp : xo + xq;
                             }
                             if (irow >= CA && CB > 0) {
                                 const int i = irow - CA;                       // compile-time: xb row (of the h = 0 half)
                                 if (accb) gv += qc[((i >> 3) << 2) + (i & 3) < NQ ? ((i >> 3) << 2) + (i & 3) : 0];
-                            } else if (a.accum & 1) gv += base[hoff4V + v];
-                            base[hoff4V + v] = gv;
+                                else if (CA % 8 != 0 && (a.accum & 2)) gv += base[v];
+                            } else if (a.accum & (on_a ? 1 : 2)) gv += base[v];
+                            base[v] = gv;
                         }
                     }
                 }
@@ -961,6 +973,16 @@ int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const fl
     HNO_REQUIRE(Cb == 0 || xb, "hno_pwconv_fwd: xb is NULL but Cb > 0");
     if (V * 8 >= (1ll << 32) || ((V + 31) / 32) * B >= (1ll << 31))
         return fail(HNO_ELIMIT, "hno_pwconv_fwd: V=%lld voxels per channel exceeds the 32-bit offset range", V);
+    if (B == 1 && Ca == 12 && Cb == 0 && Cout > 48 && Cout % 48 == 0 && !residual) {
+        // HartleyMHASeg's fused q / k / v projection (12 -> 144 on the kept spectrum): three launches of the 12 -> 48 fast kernel on
+        // output-channel thirds instead of five of the generic one (one sample: the thirds are contiguous blocks of y)
+        for (int o0 = 0; o0 < Cout; o0 += 48) {
+            const int rc = pwconv_fwd_launch(xa, Ca, nullptr, 0, W + (size_t)o0 * Ca, bias ? bias + o0 : nullptr, y + (size_t)o0 * V, 1, 48, V,
+                                             act | (bf16 ? HNO_ACT_BF16 : 0), 0, stream);
+            if (rc) return rc;
+        }
+        return HNO_OK;
+    }
     PwArgs a;
     a.xa = xa; a.xb = xb; a.W = W; a.bias = bias; a.y = y;
     a.Ca = Ca; a.Cb = Cb; a.Cin = Ca + Cb; a.Cout = Cout; a.B = B; a.V = (unsigned)V; a.act = act;
@@ -968,7 +990,7 @@ int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const fl
     a.dbg = debug_flags();
     const long long ntiles = ((V + 31) / 32) * B;
     int grid = grid_for(ntiles, 4);
-    if (Ca % 8 == 0 && Cb % 8 == 0) {  // exact-size fast paths (the HNOSeg-XS shapes)
+    if (Ca % 4 == 0 && Cb % 4 == 0) {  // exact-size fast paths (the HNOSeg-XS shapes; 12 channels: HartleyMHASeg)
         a.o_begin = 0; a.k_begin = 0; a.k_count = a.Cin; a.accumulate = 0; a.finalize = 1;
         hipStream_t fs = (hipStream_t)stream;
         bool done = true;
@@ -985,6 +1007,11 @@ int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const fl
         else if (Ca == 24 && Cb == 24 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 24, 24>), dim3(fgrid), fb, fl, fs, a);
         else if (Ca == 24 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 4>), dim3(fgrid), fb, fl, fs, a);
         else if (Ca == 48 && Cb == 0 && Cout == 48) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<48, 0, 48>), dim3(fgrid), fb, fl, fs, a);   // composed complex mix
+        else if (Ca == 12 && Cb == 0 && Cout == 12) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<12, 0, 12>), dim3(fgrid), fb, fl, fs, a);
+        else if (Ca == 12 && Cb == 12 && Cout == 12) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<12, 12, 12>), dim3(fgrid), fb, fl, fs, a);
+        else if (Ca == 12 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<12, 0, 4>), dim3(fgrid), fb, fl, fs, a);
+        else if (Ca == 12 && Cb == 0 && Cout == 48) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<12, 0, 48>), dim3(fgrid), fb, fl, fs, a);     // a third of the attention's q / k / v projection
+        else if (Ca == 48 && Cb == 0 && Cout == 12) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<48, 0, 12>), dim3(fgrid), fb, fl, fs, a);     // attention output projection
         else done = false;
         if (done) {
             HNO_CHECK_LAUNCH();
@@ -1025,6 +1052,19 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
     const int Cin = Ca + Cb;
     if (V * 8 >= (1ll << 32) || ((V + 31) / 32) * B >= (1ll << 31))
         return fail(HNO_ELIMIT, "hno_pwconv_bwd: V=%lld voxels per channel exceeds the 32-bit offset range", V);
+    if (B == 1 && Ca == 12 && Cb == 0 && Cout > 48 && Cout % 48 == 0 && !residual && !Wbr) {
+        // see pwconv_fwd_launch: output-channel thirds on the 48 <- 12 fast kernel; the input gradient accumulates over the thirds
+        // each third keeps its own slab region (a deferred slab reduction reads it after the next third has run): the workspace of
+        // (12, Cout) is 1024 slabs of Cout (12 + 1) floats = Cout / 48 regions of 1024 slabs of 48 (12 + 1)
+        for (int o0 = 0; o0 < Cout; o0 += 48) {
+            float *ws_k = (float *)workspace + (size_t)(o0 / 48) * 1024 * (48 * Ca + 48);
+            const int rc = pwconv_bwd_launch(gy + (size_t)o0 * V, y ? y + (size_t)o0 * V : nullptr, xa, Ca, nullptr, 0, W + (size_t)o0 * Ca, gxa,
+                                             nullptr, dW + (size_t)o0 * Ca, dbias ? dbias + o0 : nullptr, ws_k, 1, 48, V,
+                                             act | (bf16 ? HNO_ACT_BF16 : 0), 0, stream, xa_act, o0 > 0 ? (accumulate_gx | 1) : accumulate_gx, nullptr);
+            if (rc) return rc;
+        }
+        return HNO_OK;
+    }
     PwBwdArgs a;
     a.gy = gy; a.y = y ? y : gy; a.xa = xa; a.xb = xb; a.W = W;
     a.gxa = gxa; a.gxb = gxb; a.dW = dW; a.dbias = dbias; a.partials = (float *)workspace;
@@ -1043,7 +1083,7 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
         return fail(HNO_ELIMIT, "hno_specmix_shared_bwd: the residual (W + I) form supports C <= 32 channels");
     hipStream_t s = (hipStream_t)stream;
     const int nslab = Cout * Cin + Cout;
-    if (Ca % 8 == 0 && Cb % 8 == 0) {  // exact-size fast paths
+    if (Ca % 4 == 0 && Cb % 4 == 0) {  // exact-size fast paths
         bool done = true;
         int NW = PWB_FAST_WAVES;
         const bool s2424 = Ca == 24 && Cb == 24 && Cout == 24;
@@ -1095,6 +1135,11 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
             else if (s2424) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<24, 24, 24>), g, blk, (pwb_fast_lds_bytes<24, 24, 24, 0>(NW)), s, a);
             else if (Ca == 24 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<4, 24, 0>), g, blk, (pwb_fast_lds_bytes<4, 24, 0, 0>(NW)), s, a);
             else if (Ca == 48 && Cb == 0 && Cout == 48) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<48, 48, 0>), g, blk, (pwb_fast_lds_bytes<48, 48, 0, 0>(NW)), s, a);   // composed complex mix
+            else if (Ca == 12 && Cb == 0 && Cout == 12) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<12, 12, 0>), g, blk, (pwb_fast_lds_bytes<12, 12, 0, 0>(NW)), s, a);   // HartleyMHASeg
+            else if (Ca == 12 && Cb == 12 && Cout == 12) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<12, 12, 12>), g, blk, (pwb_fast_lds_bytes<12, 12, 12, 0>(NW)), s, a);
+            else if (Ca == 12 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<4, 12, 0>), g, blk, (pwb_fast_lds_bytes<4, 12, 0, 0>(NW)), s, a);
+            else if (Ca == 12 && Cb == 0 && Cout == 48) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<48, 12, 0>), g, blk, (pwb_fast_lds_bytes<48, 12, 0, 0>(NW)), s, a);
+            else if (Ca == 48 && Cb == 0 && Cout == 12) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<12, 48, 0>), g, blk, (pwb_fast_lds_bytes<12, 48, 0, 0>(NW)), s, a);
             else done = false;
         }
         if (done) {

@@ -111,6 +111,11 @@ def test_pad_idht_fused_epilogue(pkg):
     (72, 50, 45, (2, 3, 33), 'elu', True),     # wide concat, > 32 outputs
     (48, 0, 48, (5, 7, 9), None, False),       # composed complex mix (two 32-row output tiles in the fast kernel)
     (48, 0, 48, (6, 6, 6), 'selu', True),
+    (12, 12, 12, (9, 10, 11), 'selu', True),   # HartleyMHASeg shapes on the fast kernels: an accumulator register straddles xa / xb rows
+    (12, 0, 12, (7, 9, 11), 'selu', True),
+    (12, 0, 4, (6, 7, 33), None, True),
+    (12, 0, 48, (5, 7, 9), None, True),        # a third of the attention's q / k / v projection
+    (48, 0, 12, (5, 7, 9), 'selu', True),      # attention output projection (two 32-row input chunks in the backward)
 ])
 def test_pwconv(pkg, Ca, Cb, Cout, V, act, bias):
     from multimodal_3d_image_segmentation_amd import ops
@@ -1227,7 +1232,7 @@ def test_dma_ring_kernels_many_tiles_per_wave(pkg, grid):
     try:
         L.hno_set_debug(grid << 8)
         for (Ca, Cb, Cout, V, act) in ((24, 24, 24, (9, 11, 13), 'selu'), (24, 0, 24, (10, 10, 10), 'selu'), (24, 0, 4, (7, 9, 11), None),
-                                       (48, 0, 48, (6, 7, 9), 'selu')):
+                                       (48, 0, 48, (6, 7, 9), 'selu'), (12, 12, 12, (9, 9, 11), 'selu'), (12, 0, 4, (7, 7, 9), None)):
             B = 2
             xa = torch.randn((B, Ca) + V, dtype=torch.float64)
             xb = torch.randn((B, Cb) + V, dtype=torch.float64) if Cb else None
@@ -1260,3 +1265,29 @@ def test_dma_ring_kernels_many_tiles_per_wave(pkg, grid):
             assert rel_err(gbd.cpu().numpy(), gb.numpy()) < 5e-6
     finally:
         L.hno_set_debug(0)
+
+
+def test_pwconv_qkv_projection_thirds(pkg):
+    """12 -> 144 channels on one sample (HartleyMHASeg's fused q / k / v projection on the kept spectrum) runs as three launches
+    of the 12 -> 48 fast kernels on output-channel thirds, the input gradient accumulating over them -- against float64,
+    also with the weight-gradient slab reductions deferred to the end of backward."""
+    from multimodal_3d_image_segmentation_amd import ops
+    torch.manual_seed(2)
+    V = (6, 9, 11)
+    x = torch.randn((1, 12) + V, dtype=torch.float64, requires_grad=True)
+    W = (torch.randn(144, 12, dtype=torch.float64) * 0.2).requires_grad_(True)
+    b = (torch.randn(144, dtype=torch.float64) * 0.1).requires_grad_(True)
+    y = F.conv3d(x, W[:, :, None, None, None], b)
+    cot = torch.randn_like(y)
+    gref = torch.autograd.grad((y * cot).sum(), [x, W, b])
+    for defer in (False, True):
+        ops.set_defer_reduce(defer)
+        try:
+            d = [t.detach().float().cuda().requires_grad_(True) for t in (x, W, b)]
+            yd = ops.PwConvFn.apply(d[0], None, d[1], d[2], ops.ACT_NONE)
+            assert rel_err(yd.detach().cpu().numpy(), y.detach().numpy()) < 2e-6
+            (yd * cot.float().cuda()).sum().backward()
+            for a, r in zip(d, gref):
+                assert rel_err(a.grad.cpu().numpy(), r.numpy()) < 5e-6, defer
+        finally:
+            ops.set_defer_reduce(False)
