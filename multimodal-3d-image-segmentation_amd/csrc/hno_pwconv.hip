@@ -486,9 +486,10 @@ struct PwBranchArgs {
 };
 
 template <int CA, int CB, int COUT, bool BF16 = false>
-__global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_branch_kernel(PwBranchArgs a) {
+__global__ __launch_bounds__(64 * PWF_DMA_WAVES) void pwconv_fwd_branch_kernel(PwBranchArgs a) {
     static_assert(CA % 8 == 0 && CA <= 32 && CB % 8 == 0 && COUT <= 32 && COUT % 8 == 0, "one 32-row tile per product");
-    constexpr int NW = PWF_FAST_WAVES;
+    constexpr int NW = PWF_DMA_WAVES;
+    extern __shared__ float pwf_ring[];      // NW x 2 slots x (NKX + RA) x 64 floats: see pwconv_fwd_fast_kernel
     constexpr int RA = CA / 2, RO = COUT / 2, NKX = CB / 2, CIN = CA + CB;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -522,17 +523,44 @@ __global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_branch_kernel(
     const unsigned tiles_per_b = (V + 31) / 32;
     const unsigned ntiles = tiles_per_b * a.B;
     const unsigned hoffV = h ? V : 0u, hoff4V = h ? 4u * V : 0u;
-    for (unsigned t = blockIdx.x * NW + wave; t < ntiles; t += gridDim.x * NW) {
+    // both inputs arrive by LDS-DMA one tile ahead (pwconv_fwd_fast_kernel): x as B-operand row pairs (2 ks, 2 ks + 1), s in the
+    // accumulator layout (rows r' and r' + 4 per instruction); a lane reads back its own 4 bytes
+    constexpr int NDMA = NKX + RA;
+    static_assert(NDMA <= 63, "the DMA of one tile must fit the vmcnt counter");
+    float *ring = pwf_ring + wave * (2 * NDMA * 64);
+    const unsigned ring_b = (unsigned)(size_t)ring;
+    const unsigned stride = gridDim.x * NW;
+    auto issue = [&](unsigned t, int slot) {
         const unsigned b = t / tiles_per_b;
         const unsigned v = (t - b * tiles_per_b) * 32 + c;
-        const bool vin = v < V;
-        const unsigned vc = vin ? v : 0u;
+        const unsigned vc = v < V ? v : 0u;
         const float *x_b = a.x + (size_t)b * CB * V, *s_b = a.s + (size_t)b * CA * V;
+#pragma unroll
+        for (int ks = 0; ks < NKX; ++ks)
+            dma_row_pair(x_b + (size_t)(2 * ks) * V, (hoffV + vc) * 4u, __builtin_amdgcn_readfirstlane(ring_b + (slot * NDMA + ks) * 256));
+#pragma unroll
+        for (int r = 0; r < RA; ++r)
+            dma_row_pair(s_b + (size_t)((r & 3) + 8 * (r >> 2)) * V, (hoff4V + vc) * 4u,
+                         __builtin_amdgcn_readfirstlane(ring_b + (slot * NDMA + NKX + r) * 256));
+    };
+    unsigned t = blockIdx.x * NW + wave;
+    if (t < ntiles) issue(t, 0);
+    for (int slot = 0; t < ntiles; t += stride, slot ^= 1) {
+        if (t + stride < ntiles) {
+            issue(t + stride, slot ^ 1);
+            dma_wait<NDMA>();
+        } else {
+            dma_wait<0>();
+        }
+        const unsigned b = t / tiles_per_b;
+        const unsigned v0 = (t - b * tiles_per_b) * 32, v = v0 + c;
+        const bool vin = v < V, full = v0 + 32 <= V;
+        const float *sl = ring + slot * NDMA * 64 + lane;
         float xv[NKX], sv[RA];
 #pragma unroll
-        for (int ks = 0; ks < NKX; ++ks) xv[ks] = (x_b + (size_t)(2 * ks) * V)[hoffV + vc];
+        for (int ks = 0; ks < NKX; ++ks) xv[ks] = sl[ks * 64];
 #pragma unroll
-        for (int r = 0; r < RA; ++r) sv[r] = (s_b + (size_t)((r & 3) + 8 * (r >> 2)) * V)[hoff4V + vc];
+        for (int r = 0; r < RA; ++r) sv[r] = sl[(NKX + r) * 64];
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -544,15 +572,29 @@ __global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_branch_kernel(
 #pragma unroll
             for (int ks = 0; ks < NKX; ++ks) acc = mfma32(wbr[ks], xv[ks], acc);
         }
-        float *y_b = a.y + (size_t)b * CA * V;
+        float *y_l = a.y + (size_t)b * CA * V + (hoff4V + v);
         float yv[RA];
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
             // autocast: the branch convolution returns bf16 (bias included), the sum with the fp32 operator output and the
             // activation are fp32 (nets/architectures.py:521-539)
-            const float u = BF16 ? bf16_round(acc[r] + bb[r]) + sv[r] : acc[r] + sv[r] + bb[r];
-            yv[r] = (u > 0.f || lin) ? ap * u : aq * neg_expm1(u);
-            if (vin) (y_b + (size_t)((r & 3) + 8 * (r >> 2)) * V)[hoff4V + v] = yv[r];
+            yv[r] = BF16 ? bf16_round(acc[r] + bb[r]) + sv[r] : acc[r] + sv[r] + bb[r];
+        }
+        if (!lin) {             // no branch per register (see pwconv_fwd_fast_kernel)
+#pragma unroll
+            for (int r = 0; r < RA; ++r) {
+                float e = neg_expm1(yv[r]);
+                asm volatile("" : "+v"(e));
+                yv[r] = yv[r] > 0.f ? ap * yv[r] : aq * e;
+            }
+        }
+        if (full) {
+#pragma unroll
+            for (int r = 0; r < RA; ++r) y_l[(size_t)((r & 3) + 8 * (r >> 2)) * V] = yv[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < RA; ++r)
+                if (vin) y_l[(size_t)((r & 3) + 8 * (r >> 2)) * V] = yv[r];
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -567,14 +609,26 @@ __global__ __launch_bounds__(64 * PWF_FAST_WAVES) void pwconv_fwd_branch_kernel(
 #pragma unroll
             for (int ks = 0; ks < NKX; ++ks) acc = mfma32(wcx[ks], xv[ks], acc);
         }
-        float *o_b = a.out + (size_t)b * COUT * V;
+        float *o_l = a.out + (size_t)b * COUT * V + (hoff4V + v);
+        float ov[RO];
 #pragma unroll
         for (int r = 0; r < RO; ++r) {
-            float u = acc[r] + bc[r];
-            if constexpr (BF16) u = bf16_round(u);
-            float val = (u > 0.f || lin) ? ap * u : aq * neg_expm1(u);
-            if constexpr (BF16) val = bf16_round(val);
-            if (vin) (o_b + (size_t)((r & 3) + 8 * (r >> 2)) * V)[hoff4V + v] = val;
+            ov[r] = acc[r] + bc[r];
+            if constexpr (BF16) ov[r] = bf16_round(ov[r]);
+        }
+        if (!lin) {
+#pragma unroll
+            for (int r = 0; r < RO; ++r) {
+                float e = neg_expm1(ov[r]);
+                asm volatile("" : "+v"(e));
+                ov[r] = ov[r] > 0.f ? ap * ov[r] : aq * e;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RO; ++r) {
+            const float val = BF16 ? bf16_round(ov[r]) : ov[r];
+            if (full) o_l[(size_t)((r & 3) + 8 * (r >> 2)) * V] = val;
+            else if (vin) o_l[(size_t)((r & 3) + 8 * (r >> 2)) * V] = val;
         }
     }
 }
@@ -1247,12 +1301,14 @@ extern "C" int hno_pwconv_fwd_branch(const float *s_in, const float *x, const fl
     a.s = s_in; a.x = x; a.Wbr = Wbr; a.bbr = bbr; a.W = W; a.bias = bias; a.y = y; a.out = out;
     a.B = B; a.V = (unsigned)V; a.act = act;
     const long long ntiles = ((V + 31) / 32) * B;
-    long long grid = (ntiles + PWF_FAST_WAVES - 1) / PWF_FAST_WAVES;
-    if (grid > 256) grid = 256;   // one block per CU
+    long long grid = (ntiles + PWF_DMA_WAVES - 1) / PWF_DMA_WAVES;
+    if (grid > 512) grid = 512;   // two 4-wave blocks per CU (each wave one tile ahead through its LDS ring; 256: 62 us, 512: 57)
+    if (debug_flags() >> 8) grid = debug_flags() >> 8;
     hipStream_t fs = (hipStream_t)stream;
     ProfScope ps(KID_PWCONV_FWD, fs, 4.0 * B * (double)V * (2 * Ca + Cb + Cout));
-    if (bf16) hipLaunchKernelGGL((pwconv_fwd_branch_kernel<24, 24, 24, true>), dim3((int)grid), dim3(64 * PWF_FAST_WAVES), 0, fs, a);
-    else hipLaunchKernelGGL((pwconv_fwd_branch_kernel<24, 24, 24>), dim3((int)grid), dim3(64 * PWF_FAST_WAVES), 0, fs, a);
+    const size_t fl = (size_t)PWF_DMA_WAVES * 2 * (12 + 12) * 256;
+    if (bf16) hipLaunchKernelGGL((pwconv_fwd_branch_kernel<24, 24, 24, true>), dim3((int)grid), dim3(64 * PWF_DMA_WAVES), fl, fs, a);
+    else hipLaunchKernelGGL((pwconv_fwd_branch_kernel<24, 24, 24>), dim3((int)grid), dim3(64 * PWF_DMA_WAVES), fl, fs, a);
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }
