@@ -1178,15 +1178,18 @@ __global__ __launch_bounds__(256) void cb_pack_weights_multi_kernel(const long l
     const int C1 = (int)row[4], T = (int)row[5];
     const int oa0 = (int)row[6], Ci0 = (int)row[7], Co0 = (int)row[8], CoP0 = (int)row[9], nq20 = (int)row[10];
     const int oa1 = (int)row[11], Ci1 = (int)row[12], Co1 = (int)row[13], CoP1 = (int)row[14], nq21 = (int)row[15];
-    const long long n0 = (long long)nq20 * CoP0 * 8, n1 = (long long)nq21 * CoP1 * 8;
-    const long long lo = ((long long)blockIdx.x - first) * 2048;
-    for (long long idx = lo + threadIdx.x; idx < lo + 2048 && idx < n0 + n1; idx += 256) {
+    // 32-bit element arithmetic (a layer's packed weights are far below 2^31 elements: checked by the host when the row is built);
+    // the 64-bit divisions of the first version were most of this kernel's time
+    const unsigned n0 = (unsigned)nq20 * CoP0 * 8u, n1 = (unsigned)nq21 * CoP1 * 8u;
+    const unsigned lo = (unsigned)((long long)blockIdx.x - first) * 2048u;
+    for (unsigned idx = lo + threadIdx.x; idx < lo + 2048u && idx < n0 + n1; idx += 256u) {
         const bool second = idx >= n0;
-        const long long k = second ? idx - n0 : idx;
+        const unsigned k = second ? idx - n0 : idx;
         const int Ci = second ? Ci1 : Ci0, Co = second ? Co1 : Co0, CoP = second ? CoP1 : CoP0, oa = second ? oa1 : oa0;
-        const int nC8 = Ci / 8;
-        const int j = (int)(k & 7), o = (int)((k >> 3) % CoP), q = (int)((k >> 3) / CoP);
-        const int t = q / nC8, i = (q % nC8) * 8 + j;
+        const unsigned nC8 = (unsigned)Ci / 8u;
+        const unsigned k8 = k >> 3, qq = k8 / (unsigned)CoP;
+        const int j = (int)(k & 7u), o = (int)(k8 - qq * (unsigned)CoP), q = (int)qq;
+        const int t = (int)(qq / nC8), i = (int)(qq - (qq / nC8) * nC8) * 8 + j;
         float v = 0.f;
         if (t < T && o < Co) {
             const int c0 = oa ? o : i, c1 = oa ? i : o;
@@ -1201,6 +1204,8 @@ extern "C" int hno_cb_pack_table_row(long long *row, const float *W, void *dst_f
     HNO_REQUIRE(row && W && dst_fwd && dst_bwd && Cin > 0 && Cout > 0 && ks >= 1 && ks <= 3, "hno_cb_pack_table_row: bad argument");
     if ((Cin % 8) || (Cout % 8)) return fail(HNO_ELIMIT, "hno_cb_pack_table_row: %d -> %d channels (multiples of 8)", Cin, Cout);
     const int T = ks * ks * ks;
+    if ((long long)T * Cin * ((Cout + 31) / 32 * 32) + (long long)T * Cout * ((Cin + 31) / 32 * 32) >= (1ll << 30))
+        return fail(HNO_ELIMIT, "hno_cb_pack_table_row: %d -> %d channels exceed the pack kernel's 32-bit element range", Cin, Cout);
     row[0] = (long long)(size_t)W; row[1] = (long long)(size_t)dst_fwd; row[2] = (long long)(size_t)dst_bwd;
     row[3] = transposed ? Cin : Cout; row[4] = transposed ? Cout : Cin; row[5] = T;
     const int nq0 = T * (Cin / 8), nq1 = T * (Cout / 8);
