@@ -251,6 +251,8 @@ int hno_cb_pack_weights_both(const float *W, void *dst_fwd, void *dst_bwd, int t
  * hno_cb_pack_table_row (parameter pointer, the two destination buffers, layer shape) */
 int hno_cb_pack_table_row(long long *row, const float *W, void *dst_fwd, void *dst_bwd, int transposed, int Cin, int Cout, int ks);
 /* total_chunks = sum over rows of ceil((row[10] * row[9] + row[15] * row[14]) * 8 / 2048): one workgroup per 2048 packed elements */
+long long hno_cb_pack_row_chunks(const long long *row);   /* workgroups of hno_cb_pack_weights_multi for this (host) row; total_chunks = their sum.
+                                                             The destination buffers must be zeroed once by the caller: padding is not rewritten. */
 int hno_cb_pack_weights_multi(const void *table_dev, int nrows, long long total_chunks, void *stream);
 size_t hno_cb_conv_workspace_bytes(int B, int Cin, int Cout, int Do, int Ho, int Wo, int ks);
 /* y = conv([xa ; xb]) + bias as a gather GEMM.  mode 0: in = stride * out - pad + tap (Conv3d forward, ConvTranspose3d input

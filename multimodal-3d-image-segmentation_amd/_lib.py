@@ -59,6 +59,7 @@ SIGNATURES = {
     'hno_cb_pack_weights': (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     'hno_cb_pack_weights_both': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     'hno_cb_pack_table_row': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 4),
+    'hno_cb_pack_row_chunks': (c_ll, [c_void_p]),
     'hno_cb_pack_weights_multi': (c_int, [c_void_p, c_int, c_ll, c_void_p]),
     'hno_cb_conv_workspace_bytes': (c_size_t, [c_int] * 7),
     'hno_cb_conv': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_size_t]

@@ -1160,6 +1160,68 @@ extern "C" int hno_cb_pack_weights_both(const float *W, void *dst_fwd, void *dst
 
 // every layer of a model in ONE launch: `table` is (nrows, 16) int64 on the device:
 //   [W, dst_fwd, dst_bwd, C0, C1, T, oa0, Ci0, Co0, CoP0, nq20, oa1, Ci1, Co1, CoP1, nq21]  (see hno_cb_pack_weights_both)
+// Tiled form of cb_pack_weights_multi_kernel: a workgroup takes the weights of 8 values of the parameter's first channel index and 32
+// of its second one, all taps -- 8 contiguous runs of 32 T floats -- through LDS, and writes both packed images in whole 16-byte rows
+// (8 consecutive GEMM input channels of one output channel): 128- or 512-byte contiguous pieces.  The element-wise kernel below reads the
+// parameter with a stride of T floats (one 4-byte gather per element: 184 us for the 22.5 M weights of V-Net-DS).  Padding (output channels
+// Co .. CoP, the odd q row) is NOT written here: the buffers are zeroed once when they are allocated.
+#define CB_PT_C0 8
+#define CB_PT_C1 32
+__global__ __launch_bounds__(256) void cb_pack_weights_tiled_kernel(const long long *__restrict__ table, int nrows) {
+    __shared__ float wt[CB_PT_C0][CB_PT_C1 * 27];
+    int row_id = 0;
+    long long first = 0;
+    int g1n = 1;
+    for (; row_id < nrows; ++row_id) {
+        const long long *r = table + (size_t)row_id * 16;
+        g1n = (int)((r[4] + CB_PT_C1 - 1) / CB_PT_C1);
+        const long long nb = (r[3] / CB_PT_C0) * g1n;
+        if ((long long)blockIdx.x < first + nb) break;
+        first += nb;
+    }
+    if (row_id >= nrows) return;
+    const long long *row = table + (size_t)row_id * 16;
+    const float *w = reinterpret_cast<const float *>(row[0]);
+    const int C1 = (int)row[4], T = (int)row[5];
+    const int local = (int)((long long)blockIdx.x - first);
+    const int g0 = local / g1n, g1 = local - g0 * g1n;
+    const int c0_0 = g0 * CB_PT_C0, c1_0 = g1 * CB_PT_C1;
+    const int c1n = C1 - c1_0 < CB_PT_C1 ? C1 - c1_0 : CB_PT_C1;       // a multiple of 8
+    for (int c0l = 0; c0l < CB_PT_C0; ++c0l) {
+        const float *src = w + ((size_t)(c0_0 + c0l) * C1 + c1_0) * T;
+        for (int e = threadIdx.x; e < c1n * T; e += 256) wt[c0l][e] = src[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        bf16_t *d = reinterpret_cast<bf16_t *>(row[1 + which]);
+        const int oa = (int)row[6 + 5 * which], Ci = (int)row[7 + 5 * which], CoP = (int)row[9 + 5 * which];
+        const int nC8 = Ci / 8;
+        if (oa) {            // first index = output channel o, second = input channel i
+            const int ng = c1n / 8, nchunk = T * ng * CB_PT_C0;
+            for (int ch = threadIdx.x; ch < nchunk; ch += 256) {
+                const int ol = ch & 7, rest = ch >> 3, gi = rest % ng, t = rest / ng;
+                const int q = t * nC8 + c1_0 / 8 + gi, o = c0_0 + ol;
+                unsigned out[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    out[k] = (unsigned)f2bf(wt[ol][(gi * 8 + 2 * k) * T + t]) | ((unsigned)f2bf(wt[ol][(gi * 8 + 2 * k + 1) * T + t]) << 16);
+                *reinterpret_cast<uint4 *>(d + ((size_t)q * CoP + o) * 8) = make_uint4(out[0], out[1], out[2], out[3]);
+            }
+        } else {             // first index = input channel i (one group of 8), second = output channel o
+            const int nchunk = T * c1n;
+            for (int ch = threadIdx.x; ch < nchunk; ch += 256) {
+                const int ol = ch % c1n, t = ch / c1n;
+                const int q = t * nC8 + c0_0 / 8, o = c1_0 + ol;
+                unsigned out[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) out[k] = (unsigned)f2bf(wt[2 * k][ol * T + t]) | ((unsigned)f2bf(wt[2 * k + 1][ol * T + t]) << 16);
+                *reinterpret_cast<uint4 *>(d + ((size_t)q * CoP + o) * 8) = make_uint4(out[0], out[1], out[2], out[3]);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void cb_pack_weights_multi_kernel(const long long *__restrict__ table, int nrows) {
     // workgroup -> (row, chunk of 2048 elements): walk the rows' chunk counts (a few dozen rows)
     int row_id = 0;
@@ -1214,9 +1276,14 @@ extern "C" int hno_cb_pack_table_row(long long *row, const float *W, void *dst_f
     return HNO_OK;
 }
 
+// workgroups hno_cb_pack_weights_multi needs for this row (sum them over the table for its `total_chunks`)
+extern "C" long long hno_cb_pack_row_chunks(const long long *row) {
+    return row ? (row[3] / CB_PT_C0) * ((row[4] + CB_PT_C1 - 1) / CB_PT_C1) : 0;
+}
+
 extern "C" int hno_cb_pack_weights_multi(const void *table_dev, int nrows, long long total_chunks, void *stream) {
     HNO_REQUIRE(table_dev && nrows > 0 && total_chunks > 0 && total_chunks < (1ll << 31), "hno_cb_pack_weights_multi: bad argument");
-    hipLaunchKernelGGL(cb_pack_weights_multi_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)stream, (const long long *)table_dev, nrows);
+    hipLaunchKernelGGL(cb_pack_weights_tiled_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)stream, (const long long *)table_dev, nrows);
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }

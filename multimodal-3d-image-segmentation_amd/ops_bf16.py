@@ -81,8 +81,8 @@ class PackedWeights:
             ks = int(op.kernel_size[0])
             if Cin % 8 or Cout % 8 or W.dtype != torch.float32 or not W.is_contiguous():
                 continue
-            wf = _ws(L.hno_cb_packed_weight_bytes(Cin, Cout, ks), W.device)
-            wb = _ws(L.hno_cb_packed_weight_bytes(Cout, Cin, ks), W.device)
+            wf = _ws(L.hno_cb_packed_weight_bytes(Cin, Cout, ks), W.device).zero_()     # padding rows / channels stay zero:
+            wb = _ws(L.hno_cb_packed_weight_bytes(Cout, Cin, ks), W.device).zero_()     # the refresh kernel only writes real weights
             row = np.zeros(16, dtype=np.int64)
             check(L.hno_cb_pack_table_row(row.ctypes.data_as(ctypes.c_void_p), ptr(W), ptr(wf), ptr(wb), int(transposed), Cin, Cout, ks),
                   'hno_cb_pack_table_row')
@@ -90,7 +90,7 @@ class PackedWeights:
             self.entries[W.data_ptr()] = (weakref.ref(W), wf, wb)
         self.key = tuple(self.entries)
         self.table = torch.from_numpy(np.stack(rows)).to(layers[0].weight.device) if rows else None
-        self.chunks = int(sum((int(r[10] * r[9] * 8 + r[15] * r[14] * 8) + 2047) // 2048 for r in rows))
+        self.chunks = int(sum(L.hno_cb_pack_row_chunks(r.ctypes.data_as(ctypes.c_void_p)) for r in rows))
 
     def refresh(self):
         if self.table is not None:
