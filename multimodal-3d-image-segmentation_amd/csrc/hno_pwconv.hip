@@ -783,6 +783,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kern
         const float *Xc = X + (DMA ? slot * XS : 0);            // this tile's x rows
         const unsigned tu = grp * NW + wave;                    // wave-uniform copies of the tile coordinates
         const unsigned bu = tu < ntiles ? tu / tiles_per_b : 0u;
+        const bool br_fast = BR != 0 && tu < ntiles && (tu - bu * tiles_per_b) * 32 + 32 <= V && a.gxa && a.gxb && !a.accum && !(a.dbg & 4);
         const bool fast_store = BR == 0 && tu < ntiles && (tu - bu * tiles_per_b) * 32 + 32 <= V && a.gxa && (CB == 0 || a.gxb) &&
                                 !(a.accum & 1) && !(CA % 8 != 0 && (a.accum & 2)) && !(a.dbg & 4);
         const unsigned t = grp * NW + wave;
@@ -905,6 +906,45 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kern
                             base[v] = gv;
                         }
                     }
+                }
+            } else if (br_fast) {
+                // whole tile, both gradients stored, nothing accumulated from memory: the rows of store_row without per-row control flow,
+                // the activation derivative's x values read from LDS in one batch
+                float *ga_l = a.gxa + (size_t)b * CA * V + (hoff4V + v);
+                float *gb_l = a.gxb + (size_t)b * CB * V + (hoff4V + v);
+                if (ic == 0) {
+                    float xo[RA];
+                    if (xact) {
+#pragma unroll
+                        for (int r = 0; r < RA; ++r) xo[r] = X[((r & 3) + 8 * (r >> 2) + 4 * h) * PWB_LD + c];
+                    }
+#pragma unroll
+                    for (int r = 0; r < RA; ++r) {
+                        const int irow = (r & 3) + 8 * (r >> 2);
+                        float gv = acc[r];
+                        if (xact) gv *= xo[r] > 0.f ? xp : xo[r] + xq;
+                        acc[r] = gv;
+                        P[(irow + 4 * h) * PWB_LD + c] = gv;
+                        dbb[r] += gv;
+                        ga_l[(size_t)irow * V] = gv;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+                    if constexpr (BF16) {
+                        float pr[RA];
+#pragma unroll
+                        for (int ks = 0; ks < RA; ++ks) pr[ks] = acc[ks];
+#pragma unroll
+                        for (int s6 = 0; s6 < RA / 6; ++s6) acc2 = mfma_bf(wbrf[s6], pack6(&pr[6 * s6]), acc2);
+                    } else {
+#pragma unroll
+                        for (int ks = 0; ks < RA; ++ks) acc2 = mfma32(wbr[ks], acc[ks], acc2);
+                    }
+                }
+#pragma unroll
+                for (int r = (ic == 0 ? RA : 0); r < 16; ++r) {
+                    const int irow = ic * 32 + (r & 3) + 8 * (r >> 2);
+                    if (irow < CIN) gb_l[(size_t)(irow - CA) * V] = acc[r] + acc2[(r + 16 * ic - RA) & 15];
                 }
             } else if (ic == 0) {
 #pragma unroll
