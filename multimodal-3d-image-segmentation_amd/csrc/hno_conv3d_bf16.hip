@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void cb_gn_apply_kernel(const bf16_t *__restri
     const long long n8 = per_sample >> 3;
     const int C8 = C >> 3;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
-        const int c0 = (int)(i % C8) * 8;
+        const int c0 = (int)((unsigned)i % (unsigned)C8) * 8;      // i < 2^32 (host check): a 64-bit modulo per item costs more than the item
         const size_t e = (size_t)b * per_sample + (size_t)i * 8;
         const uint4 v1 = *reinterpret_cast<const uint4 *>(y1 + e);
         uint4 v2 = make_uint4(0, 0, 0, 0);
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256) void cb_gn_bwd_apply_kernel(const bf16_t *__re
     const long long n8 = per_sample >> 3;
     const int C8 = C >> 3;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
-        const int c0 = (int)(i % C8) * 8;
+        const int c0 = (int)((unsigned)i % (unsigned)C8) * 8;      // i < 2^32 (host check): a 64-bit modulo per item costs more than the item
         const size_t e = (size_t)b * per_sample + (size_t)i * 8;
         const uint4 gv = *reinterpret_cast<const uint4 *>(dz + e), yv = *reinterpret_cast<const uint4 *>(y + e);
         const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
@@ -1478,6 +1478,7 @@ extern "C" int hno_cb_gn_apply(const void *y1, const float *mr1, const float *ga
     if (C % 8) return fail(HNO_ELIMIT, "hno_cb_gn_apply: C = %d must be a multiple of 8", C);
     hipStream_t s = (hipStream_t)stream;
     const long long per_sample = V * C;
+    if (per_sample >= (1ll << 34)) return fail(HNO_ELIMIT, "hno_cb_gn_apply: %lld elements per sample exceed the kernel's 32-bit item index", per_sample);
     ProfScope _ps(KID_CB_GN, s, (double)B * per_sample * (y2 ? 6.0 : 4.0));
     hipLaunchKernelGGL(cb_gn_apply_kernel, dim3(gsz(per_sample / 8, 256, 2048), B), dim3(256), 0, s, (const bf16_t *)y1, mr1, gamma1, beta1,
                        (const bf16_t *)y2, mr2, gamma2, beta2, (bf16_t *)z, C, per_sample, act);
@@ -1496,6 +1497,7 @@ extern "C" int hno_cb_gn_bwd(const void *dz, const void *y, const float *mr, con
                              int accumulate, void *stream) {
     HNO_REQUIRE(dz && y && mr && gamma && beta && dy && dgamma && dbeta && workspace && B > 0 && C > 0 && V > 0, "hno_cb_gn_bwd: bad argument");
     if (C % 8 || C > 2048) return fail(HNO_ELIMIT, "hno_cb_gn_bwd: C = %d must be a multiple of 8 (<= 2048)", C);
+    if (V * C >= (1ll << 34)) return fail(HNO_ELIMIT, "hno_cb_gn_bwd: %lld elements per sample exceed the kernels' 32-bit item index", V * C);
     hipStream_t s = (hipStream_t)stream;
     float *slab = (float *)workspace;
     float *gS = slab + (size_t)B * CB_GN_BWD_BLOCKS * 3 * C;
