@@ -298,6 +298,7 @@ __global__ __launch_bounds__(UPB_THREADS) void upsoftmax_bwd_plane_kernel(UpBwdA
         const int j = col % w;
         int x0 = (int)floorf(((float)(j - 1) + 0.5f) / a.sw - 0.5f) - 1;
         x0 = x0 < 0 ? 0 : (x0 > W - UPB_MAXT ? (W - UPB_MAXT > 0 ? W - UPB_MAXT : 0) : x0);
+        x0 &= ~1;      // even first tap (W % 4 == 0, the window has one spare tap): the fold reads its taps as 8-byte pairs, conflict-free
         tap0[c] = x0;
 #pragma unroll
         for (int t = 0; t < UPB_MAXT; ++t) tapw[c][t] = (x0 + t < W && col < K * w) ? lin_weight(lin_coord(x0 + t, a.sw, w), j) : 0.f;
@@ -379,8 +380,15 @@ __global__ __launch_bounds__(UPB_THREADS) void upsoftmax_bwd_plane_kernel(UpBwdA
                 if (col < K * w) {
                     const int k = col / w;
                     float v = 0.f;
+                    // lanes own consecutive low-res columns, i.e. taps two floats apart: single-float reads were 2-way bank conflicts
+                    // on every tap; tap0 is even and tap0 + UPB_MAXT <= W (clamped above, W >= UPB_MAXT), so pairs are aligned and in range
+                    const float2 *sp = reinterpret_cast<const float2 *>(sr + k * W + tap0[c]);
 #pragma unroll
-                    for (int t = 0; t < UPB_MAXT; ++t) v += tapw[c][t] * sr[k * W + (tap0[c] + t < W ? tap0[c] + t : W - 1)];
+                    for (int t = 0; t < UPB_MAXT; t += 2) {
+                        const float2 pr = sp[t >> 1];
+                        v += tapw[c][t] * pr.x;
+                        v += tapw[c][t + 1] * pr.y;
+                    }
                     const float c0 = (ly.i0 == cur ? ly.w0 : 0.f) + (ly.i1 == cur ? ly.w1 : 0.f);
                     const float c1 = (ly.i0 == cur + 1 ? ly.w0 : 0.f) + (ly.i1 == cur + 1 ? ly.w1 : 0.f);
                     a0[c] += c0 * v;
