@@ -1583,7 +1583,8 @@ WgPlan wg_plan(int B, int Do, int Ho, int Wo, int ks, int stride, int pad, int P
     // workgroups per channel block: ~one per CU over all channel blocks.  Every workgroup writes a slab of ntaps x 48 x 48 floats
     // that the reduce kernel reads back: with 512 / ny (>= 8) workgroups the slabs of a 384 x 384 layer were 127 MB, more traffic
     // than everything else in that layer
-    long long want = ny <= 1 ? 512 : 256 / ny;        // (single-channel-block layers: measured faster with two rounds of workgroups)
+    static const int want1 = getenv("HNO_WGRAD_WANT1") ? atoi(getenv("HNO_WGRAD_WANT1")) : 256, wantn = getenv("HNO_WGRAD_WANTN") ? atoi(getenv("HNO_WGRAD_WANTN")) : 256;   // tuning aids
+    long long want = ny <= 1 ? want1 : wantn / ny;        // workgroups (= slabs to reduce); cfg4 step: 256 -> 8.34 ms, 384 -> 8.37, 512 -> 8.39, 128 -> 8.89; more than 256 / ny does not fit the workspace
     if (want < 1) want = 1;
     const int nbands = (Ho + best - 1) / best;
     p.slide = (ks == 3 && stride == 1) ? 1 : 0;
