@@ -261,11 +261,13 @@ size_t hno_cb_conv_workspace_bytes(int B, int Cin, int Cout, int Do, int Ho, int
 int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const void *wpacked, const float *bias, void *y, float *mean_rstd,
                 float eps, void *workspace, size_t workspace_bytes, int mode, int B, int Cout, int Di, int Hi, int Wi, int Do, int Ho,
                 int Wo, int ks, int stride, int pad, void *stream);
+/* upper bound of the slab workspace hno_cb_wgrad writes for a layer with these (total input, output) channel counts */
 size_t hno_cb_wgrad_workspace_bytes(int Cin, int Cout, int ks);
 /* dW (fp32, the parameter's own layout) of a Conv3d (transposed = 0: g on the output grid (Dg, Hg, Wg), x = [xa ; xb] on the
  * input grid (Dx, Hx, Wx)) or of a ConvTranspose3d (transposed = 1: x is ITS input on the small grid, g its output gradient). */
-int hno_cb_wgrad(const void *g, int Cg, const void *xa, int Ca, const void *xb, int Cb, float *dW, void *workspace, int transposed,
-                 int B, int Dx, int Hx, int Wx, int Dg, int Hg, int Wg, int ks, int stride, int pad, void *stream);
+int hno_cb_wgrad(const void *g, int Cg, const void *xa, int Ca, const void *xb, int Cb, float *dW, void *workspace,
+                 size_t workspace_bytes, int transposed, int B, int Dx, int Hx, int Wx, int Dg, int Hg, int Wg, int ks, int stride,
+                 int pad, void *stream);
 /* z = act(GroupNorm(1, C)(y1)) [+ act(GroupNorm(1, C)(y2))]: the residual sum of a V-Net section fused (architectures.py:205-224) */
 int hno_cb_gn_apply(const void *y1, const float *mr1, const float *gamma1, const float *beta1, const void *y2, const float *mr2,
                     const float *gamma2, const float *beta2, void *z, int B, int C, long long V, int act, void *stream);

@@ -1557,6 +1557,28 @@ struct WgPlan {
     int TH, Sg, Sx, xrows, gpos32, xpos, nblk, slide, nseg;
     size_t lds;
 };
+// workgroups per channel block (= slabs the reduce kernel reads back) of a launch with ny channel blocks on gridDim.y; shared by
+// wg_plan and hno_cb_wgrad_workspace_bytes so that the workspace bound follows the tuning aids.
+// cfg4 step: 256 -> 8.34 ms, 384 -> 8.37, 512 -> 8.39, 128 -> 8.89
+long long wg_want(int ny) {
+    static const int want1 = getenv("HNO_WGRAD_WANT1") ? atoi(getenv("HNO_WGRAD_WANT1")) : 256, wantn = getenv("HNO_WGRAD_WANTN") ? atoi(getenv("HNO_WGRAD_WANTN")) : 256;   // tuning aids
+    long long want = ny <= 1 ? want1 : wantn / ny;
+    return want < 1 ? 1 : want;
+}
+// channel blocking of the weight-gradient GEMM (rows CP, columns CQ): blocks of <= 48 x 48; equal-sized blocks ride on gridDim.y
+struct WgBlocks {
+    int CO, CI, nco, nci;
+    bool uniform;
+};
+WgBlocks wg_blocks(int CP, int CQ) {
+    WgBlocks b;
+    b.CO = CP < 48 ? CP : 48;
+    b.CI = CQ < 48 ? CQ : 48;
+    b.uniform = CP % b.CO == 0 && CQ % b.CI == 0;
+    b.nco = (CP + b.CO - 1) / b.CO;
+    b.nci = (CQ + b.CI - 1) / b.CI;
+    return b;
+}
 // band height: as many output rows as fit in LDS (G band + X halo at the block's channel pitches), at least 1
 WgPlan wg_plan(int B, int Do, int Ho, int Wo, int ks, int stride, int pad, int PG, int PX, int ny) {
     // two workgroups per CU (one stages while the other computes) when there is enough work: cap the LDS at half
@@ -1583,9 +1605,7 @@ WgPlan wg_plan(int B, int Do, int Ho, int Wo, int ks, int stride, int pad, int P
     // workgroups per channel block: ~one per CU over all channel blocks.  Every workgroup writes a slab of ntaps x 48 x 48 floats
     // that the reduce kernel reads back: with 512 / ny (>= 8) workgroups the slabs of a 384 x 384 layer were 127 MB, more traffic
     // than everything else in that layer
-    static const int want1 = getenv("HNO_WGRAD_WANT1") ? atoi(getenv("HNO_WGRAD_WANT1")) : 256, wantn = getenv("HNO_WGRAD_WANTN") ? atoi(getenv("HNO_WGRAD_WANTN")) : 256;   // tuning aids
-    long long want = ny <= 1 ? want1 : wantn / ny;        // workgroups (= slabs to reduce); cfg4 step: 256 -> 8.34 ms, 384 -> 8.37, 512 -> 8.39, 128 -> 8.89; more than 256 / ny does not fit the workspace
-    if (want < 1) want = 1;
+    const long long want = wg_want(ny);
     const int nbands = (Ho + best - 1) / best;
     p.slide = (ks == 3 && stride == 1) ? 1 : 0;
     p.nseg = 1;
@@ -1603,12 +1623,13 @@ WgPlan wg_plan(int B, int Do, int Ho, int Wo, int ks, int stride, int pad, int P
 }  // namespace
 
 extern "C" size_t hno_cb_wgrad_workspace_bytes(int Cin, int Cout, int ks) {
-    // slabs [channel block][workgroup][tap][<= 48][<= 48]: at most 512 workgroups over all channel blocks (>= 8 per block)
-    const int CO = Cout < 48 ? Cout : 48, CI = Cin < 48 ? Cin : 48;
-    const int ny = ((Cout + CO - 1) / CO) * ((Cin + CI - 1) / CI);
-    long long per = ny <= 1 ? 512 : 256 / ny;
-    if (per < 1) per = 1;
-    return (size_t)per * ny * ks * ks * ks * CO * CI * sizeof(float);
+    // slabs [channel block][workgroup][tap][<= 48][<= 48] of ONE launch (the launches of a non-uniform blocking reuse the workspace):
+    // the true upper bound of what hno_cb_wgrad writes for these channel counts (symmetric in Cin / Cout, so it holds for the
+    // transposed form too); hno_cb_wgrad checks its plan against the size it is handed
+    if (Cin < 1 || Cout < 1 || ks < 1) return 0;
+    const WgBlocks b = wg_blocks(Cout, Cin);
+    const int ny = b.uniform ? b.nco * b.nci : 1;
+    return (size_t)wg_want(ny) * ny * ks * ks * ks * b.CO * b.CI * sizeof(float);
 }
 
 template <int TA, int TB, int TPW>
@@ -1634,8 +1655,8 @@ static int wg_launch(const CwArgs &a, dim3 grid, size_t lds, hipStream_t s) {
 // on the input grid) or of a ConvTranspose (transposed = 1: Wt[Cin][Cout][T]; the transposed convolution's input x plays the
 // role of the "output gradient" operand and g of the gathered operand -- the host swaps them).
 extern "C" int hno_cb_wgrad(const void *g, int Cg, const void *xa, int Ca, const void *xb, int Cb, float *dW, void *workspace,
-                            int transposed, int B, int Dx, int Hx, int Wx, int Dg, int Hg, int Wg, int ks, int stride, int pad,
-                            void *stream) {
+                            size_t workspace_bytes, int transposed, int B, int Dx, int Hx, int Wx, int Dg, int Hg, int Wg, int ks,
+                            int stride, int pad, void *stream) {
     HNO_REQUIRE(g && xa && dW && workspace && B > 0 && Cg > 0 && Ca > 0 && Cb >= 0, "hno_cb_wgrad: bad argument");
     HNO_REQUIRE((stride == 1 || stride == 2) && ks >= 1 && ks <= 3, "hno_cb_wgrad: bad stride / kernel");
     if ((Cg % 8) || (Ca % 8) || (Cb % 8)) return fail(HNO_ELIMIT, "hno_cb_wgrad: channel counts must be multiples of 8");
@@ -1660,9 +1681,9 @@ extern "C" int hno_cb_wgrad(const void *g, int Cg, const void *xa, int Ca, const
     const int C1 = CQ;
     // channel blocks of <= 48 x 48.  When every block has the same size (channel counts <= 48 or multiples of 48: all V-Net
     // layers) they ride on gridDim.y of ONE launch; otherwise one launch per block.
-    const int CO = CP < 48 ? CP : 48, CI = CQ < 48 ? CQ : 48;
-    const bool uniform = CP % CO == 0 && CQ % CI == 0;
-    const int nco = (CP + CO - 1) / CO, nci = (CQ + CI - 1) / CI;
+    const WgBlocks blk = wg_blocks(CP, CQ);
+    const int CO = blk.CO, CI = blk.CI, nco = blk.nco, nci = blk.nci;
+    const bool uniform = blk.uniform;
     for (int bi = 0; bi < (uniform ? 1 : nco * nci); ++bi) {
         a.co0 = uniform ? 0 : (bi / nci) * CO;
         a.ci0 = uniform ? 0 : (bi % nci) * CI;
@@ -1675,6 +1696,9 @@ extern "C" int hno_cb_wgrad(const void *g, int Cg, const void *xa, int Ca, const
         a.TH = p.TH; a.Sg = p.Sg; a.Sx = p.Sx; a.xrows = p.xrows; a.xplanes = ks; a.xpos = p.xpos; a.slide = p.slide; a.nseg = p.nseg;
         a.nbands = (a.Ho + p.TH - 1) / p.TH;
         a.slab = (float *)workspace;
+        // every workgroup (blockIdx.y * gridDim.x + blockIdx.x) writes one slab of T x CO x CI floats
+        HNO_REQUIRE((size_t)p.nblk * ny * T * a.CO * a.CI * sizeof(float) <= workspace_bytes,
+                    "hno_cb_wgrad: workspace too small (size it with hno_cb_wgrad_workspace_bytes(Cin, Cout, ks))");
         int rc;
         {
             ProfScope _ps(KID_CB_WGRAD, s, 2.0 * B * (double)a.Do * a.Ho * a.Wo * T * a.CO * a.CI * ny);

@@ -303,6 +303,7 @@ extern "C" int hno_debug_stamps(long long *out, int n) {
     long long *buf = debug_stamp_buffer();
     HNO_REQUIRE(buf, "hno_debug_stamps: no stamp buffer");
     HNO_CHECK_HIP(hipMemcpy(out, buf, sizeof(long long) * n, hipMemcpyDeviceToHost));
+    HNO_CHECK_HIP(hipMemset(buf, 0, sizeof(long long) * 64));   // the next reader sees only its own kernel's stamps
     return HNO_OK;
 }
 

@@ -15,6 +15,8 @@
 //             fused scale + residual add + SELU on store].
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <map>
 #include <mutex>
@@ -41,6 +43,8 @@ struct DhtPlan {
     float *tables;     // device
     int table_floats;
     int K1S;           // 2*m1 + 1 signed k1 values
+    int hperm, NP1;    // axis-H tables in accumulator order for the DMA forward plane kernel (odd N1, one k1 tile): offset, row-pair tiles
+    int dmatab, dmatab_stride;   // kDmaTabCopies copies of [axis-W cos | axis-W sin | hperm] in lane order (one 256-byte row per register)
     int CP;            // K1S * KP2 columns per part (re / im) of the intermediate
     int MP1;           // N1 rounded up to 16
     // forward plane kernel LDS layout (floats)
@@ -110,6 +114,10 @@ static void build_axis_tables(const Axis &a, std::vector<float> &t, bool plane_a
             }
 }
 
+// Every wave of the DMA plane kernel loads the same ~8 KB of table rows at its start; with one copy, 2 048 waves queue on the same L2
+// lines (5 us before the first MFMA, measured with in-kernel stamps).  Workgroup b reads copy b % kDmaTabCopies.
+static const int kDmaTabCopies = 32;
+
 typedef std::tuple<int, int, int, int, int, int, int> PlanKey;
 static std::map<PlanKey, DhtPlan> g_plans;
 static std::mutex g_plan_mutex;
@@ -129,11 +137,45 @@ static int get_plan(int N0, int N1, int N2, int m0, int m1, int m2, const DhtPla
     fill_axis(p.ax[0], N0, m0, cursor);
     fill_axis(p.ax[1], N1, m1, cursor);
     fill_axis(p.ax[2], N2, m2, cursor);
+    // dht_fwd_plane_dma_kernel keeps the axis-W result in its MFMA accumulators and feeds them to the axis-H product as they
+    // lie: tile X (0..NP1-1) holds plane row n1 = 1 + 16 X + i in accumulator row i = 4 q + r (lane group q, register r), its
+    // partner tile the mirror row N1 - n1.  K-step (X, r) of the axis-H product therefore sums over n1(X, 4 q + r), q = 0..3:
+    // table [X][r][cos | sin][q][k1]
+    p.NP1 = ceil_div(p.ax[1].Js, 16);
+    p.hperm = cursor;
+    if ((N1 & 1) && p.ax[1].KT == 1) cursor += p.NP1 * 4 * 2 * 4 * 16;
+    const bool dma_tab = (N1 & 1) && p.ax[1].KT == 1 && p.ax[2].KT == 1;
+    p.dmatab = cursor;
+    p.dmatab_stride = round_up((p.ax[2].KcP / 4 + p.ax[2].KsP / 4 + p.NP1 * 8) * 64, 64);
+    if (dma_tab) cursor += kDmaTabCopies * p.dmatab_stride;
     p.table_floats = cursor;
     std::vector<float> host(cursor, 0.f);
     build_axis_tables(p.ax[0], host, false, false);
     build_axis_tables(p.ax[1], host, false, false);
     build_axis_tables(p.ax[2], host, false, false);
+    if ((N1 & 1) && p.ax[1].KT == 1) {
+        const double th1 = 2.0 * M_PI / N1;
+        for (int X = 0; X < p.NP1; ++X)
+            for (int r = 0; r < 4; ++r)
+                for (int q = 0; q < 4; ++q)
+                    for (int k1 = 0; k1 < 16; ++k1) {
+                        const int n1 = 1 + 16 * X + 4 * q + r;
+                        const bool ok = n1 <= p.ax[1].Js && k1 <= p.ax[1].m;
+                        const double ang = th1 * (double)((long long)k1 * n1 % N1);
+                        float *t = host.data() + p.hperm + ((X * 4 + r) * 2) * 64 + q * 16 + k1;
+                        t[0] = ok ? (float)cos(ang) : 0.f;
+                        t[64] = ok ? (float)sin(ang) : 0.f;
+                    }
+    }
+    if (dma_tab) {
+        // row ks of the axis-W tables in lane order: lane (q, l15) <-> table element (4 ks + q, l15) = cosF[ks * 64 + lane]
+        const Axis &w = p.ax[2];
+        std::vector<float> blk;
+        blk.insert(blk.end(), host.begin() + w.cosF, host.begin() + w.cosF + (w.KcP / 4) * 64);
+        blk.insert(blk.end(), host.begin() + w.sinF, host.begin() + w.sinF + (w.KsP / 4) * 64);
+        blk.insert(blk.end(), host.begin() + p.hperm, host.begin() + p.hperm + p.NP1 * 8 * 64);
+        for (int c = 0; c < kDmaTabCopies; ++c) std::copy(blk.begin(), blk.end(), host.begin() + p.dmatab + c * p.dmatab_stride);
+    }
     // table creation is the one place that allocates: do it outside graph capture (warm-up)
     HNO_CHECK_HIP(hipMalloc((void **)&p.tables, sizeof(float) * cursor));
     HNO_CHECK_HIP(hipMemcpy(p.tables, host.data(), sizeof(float) * cursor, hipMemcpyHostToDevice));
@@ -909,6 +951,387 @@ __global__ __launch_bounds__(64 * NWV, 1) void dht_fwd_plane_wave_kernel(const f
     if (a.stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) a.stamps[57] = wall_clock64();
 }
 
+// ---- forward plane kernel, one wave per plane, planes streamed into LDS by DMA, axis-W result kept in registers ------------
+// What bounded the kernel above (profiles/r02_d_pmc_sq_per_kernel.json, in-kernel wall-clock stamps): all 2 048 waves fetch their first
+// plane at once (35 MB in flight, ~6 us with no arithmetic running), the prefetch of the next plane costs 64 VGPRs of 16-byte loads
+// at 4-byte alignment (split requests), the axis-W result goes through LDS (16 stores + 68 conflicting reads + a fence per plane), and
+// every MFMA waits for the VALU fold that writes its A operand into the register the previous MFMA is still reading.
+// Here:
+//   * a plane reaches LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per instruction, no VGPRs).  Every source range starts at the
+//     16-byte boundary below the data (which then sits 0..3 floats into its LDS image), so all requests are aligned;
+//   * the unit of work is an ITEM = the rows of one row-pair tile: item X of a plane holds rows n1 = 1 + 16 X + i (i = 0..15) and their
+//     mirror rows N1 - n1 (item 0 also row 0, which is its own mirror and runs on the VALU).  For N1 = 65 that is rows [0, 17) + [49, 65)
+//     and rows [17, 49): contiguous chunks of <= 10 KiB, so 8 waves x 2 item slots fill the 160 KiB of a CU, two waves share a SIMD and
+//     every wave has its next item in flight behind the one it multiplies (counted vmcnt) -- 76 KB in flight per CU all the time;
+//   * the C layout of v_mfma_f32_16x16x4_f32 (column k2 on the lane, rows 4 q + r in register r) IS the A-operand layout of the axis-H
+//     product when its K index is the tile row: lane group q supplies row 4 q + r at k-step r, and the tables are stored in that order
+//     (DhtPlan::hperm).  The fold T[n1] +- T[N1 - n1] is an add / subtract of the two tiles' registers: the axis-W result never touches
+//     LDS, the axis-H sums run across the items of a plane in registers;
+//   * folds are formed for a whole burst into distinct registers before its MFMAs issue back to back;
+//   * nothing is multiplied by bytes outside a row (the c = 0 mirror term is selected away, not masked by a product): slots need no
+//     zero guards and a DMA may over-read into the neighbouring rows (the tail pieces of the last plane are clamped into the tensor).
+// Requires N1 = 32 NP + 1 (NP = 1, 2), odd N2 with Js2 == 4 KS2 (65 x 65 and 33 x 33 planes), one k tile per axis, x 4-byte aligned.
+__device__ __forceinline__ void dma_piece16(const float *base, unsigned lane_byte_off, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane_byte_off), "s"(base), "s"(lds_dst) : "memory");
+}
+// four consecutive KiB: the instruction offset advances the global and the LDS address alike
+__device__ __forceinline__ void dma_piece16x4(const float *base, unsigned lane_byte_off, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
+                 : : "v"(lane_byte_off), "s"(base), "s"(lds_dst) : "memory");
+}
+
+// 16-byte store that goes through to memory (agent scope): no dirty line stays behind in the XCD's L2
+__device__ __forceinline__ void store16_wt(float *ptr, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(ptr), "v"(v) : "memory");
+}
+
+// ABL: timing ablations (results wrong): 1 = a VALU op in place of every MFMA, 2 = no LDS operand reads
+template <int KC2, int KS2, int NP, int NWV, int ABL = 0>
+__global__ __launch_bounds__(64 * NWV, 2) void dht_fwd_plane_dma_kernel(const float *__restrict__ xal, float *__restrict__ Y, DhtArgs a,
+                                                                        unsigned shift0, unsigned max_off, int pl_base, int pl_rem) {
+    extern __shared__ float lds[];
+    auto MM = [](float av, float bv, f32x4 c) -> f32x4 {
+        if (ABL == 1) {
+            c[0] = fmaf(av, bv, c[0]);
+            return c;
+        }
+        return mfma16(av, bv, c);
+    };
+    const DhtPlan &p = a.p;
+    const Axis &a1 = p.ax[1], &a2 = p.ax[2];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4, l15 = lane & 15;
+    const int N2 = a2.N;
+    constexpr int N1 = 32 * NP + 1;
+    const unsigned pe = (unsigned)(N1 * N2);
+    // chunks of an item (rows [r0, r1) of the plane) and their KiB pieces; item slot = SLOTP pieces
+    constexpr int SLOTP = NP == 2 ? 10 : 5;
+    constexpr int SLOTF = SLOTP * 256;
+    float *ring = lds + (size_t)wave * 2 * SLOTF;
+    const unsigned ring_b = (unsigned)(size_t)ring;
+    // one workgroup per CU owns a contiguous range of planes: P / G each (pl_base), the first P % G (pl_rem) workgroups one more (the
+    // host divides: a 64-bit division here costs every wave ~2 000 cycles before its first load); its waves take them round-robin
+    const int bid = blockIdx.x;
+    const int p_begin = bid * pl_base + (bid < pl_rem ? bid : pl_rem);
+    const int p_end = p_begin + pl_base + (bid < pl_rem ? 1 : 0);
+    HNO_STAMP(a.stamps, 20);
+    if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[60] = wall_clock64();
+    if (a.stamps && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a.stamps[58] = wall_clock64();
+    if (a.stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 64 * (NWV - 1)) a.stamps[56] = wall_clock64();
+    // rows [r0, r0 + nr) of `plane` -> LDS at byte address dst, NPC pieces
+    auto issue_chunk = [&](int plane, int r0, int NPC, unsigned dst) {
+        const unsigned f0 = shift0 + (unsigned)plane * pe + (unsigned)(r0 * N2);   // float index of the chunk from the aligned base
+        const unsigned boff = (f0 & ~3u) * 4u + (unsigned)lane * 16u;
+        const unsigned first = __builtin_amdgcn_readfirstlane(boff);
+        if (first + (unsigned)NPC * 1024u <= max_off) {   // wave-uniform: every piece inside the tensor
+            int j = 0;
+            for (; j + 4 <= NPC; j += 4) dma_piece16x4(xal, boff + 1024u * j, __builtin_amdgcn_readfirstlane(dst + 1024u * j));
+            for (; j < NPC; ++j) dma_piece16(xal, boff + 1024u * j, __builtin_amdgcn_readfirstlane(dst + 1024u * j));
+        } else {
+            for (int j = 0; j < NPC; ++j) {
+                unsigned off = boff + 1024u * j;
+                off = off < max_off ? off : max_off;                 // the last plane's tail pieces stay inside the tensor
+                dma_piece16(xal, off, __builtin_amdgcn_readfirstlane(dst + 1024u * j));
+            }
+        }
+    };
+    auto issue_item = [&](int plane, int X) {
+        const unsigned dst = ring_b + (unsigned)(X & 1) * (SLOTF * 4);
+        if (NP == 1) issue_chunk(plane, 0, 5, dst);
+        else if (X == 0) {
+            issue_chunk(plane, 0, 5, dst);
+            issue_chunk(plane, 49, 5, dst + 5 * 1024);
+        } else
+            issue_chunk(plane, 17, 9, dst);
+    };
+    // Start-up: the table rows (lane order, copy b % kDmaTabCopies: see get_plan) are requested first, the first two items right behind
+    // them.  The table loads are asm loads hipcc does not count: an ordinary load would make it drain the whole vector-memory queue
+    // (vmcnt(0), both items) at the tables' first use; here the wait leaves the NPRO younger DMA pieces in flight.
+    int plane = p_begin + wave;
+    float bwc[KC2], bws[KS2], bhc[NP][4], bhs[NP][4];
+    {
+        const float *tb = p.tables + p.dmatab + (size_t)(blockIdx.x % kDmaTabCopies) * p.dmatab_stride;
+        const unsigned lo = (unsigned)lane * 4u;
+#define HNO_TLOAD(dst, row) asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(dst) : "v"(lo + ((row) >> 4) * 4096u), "s"(tb), "n"(((row) & 15) * 256))
+#pragma unroll
+        for (int ks = 0; ks < KC2; ++ks) HNO_TLOAD(bwc[ks], ks);
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) HNO_TLOAD(bws[ks], KC2 + ks);
+#pragma unroll
+        for (int X = 0; X < NP; ++X)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                HNO_TLOAD(bhc[X][r], KC2 + KS2 + (X * 4 + r) * 2);
+                HNO_TLOAD(bhs[X][r], KC2 + KS2 + (X * 4 + r) * 2 + 1);
+            }
+#undef HNO_TLOAD
+    }
+    HNO_STAMP(a.stamps, 21);
+    int npro = 0;   // DMA pieces issued behind the table loads
+    if (plane < p_end) {
+        issue_item(plane, 0);
+        npro = NP == 2 ? 10 : 5;
+        if (NP == 2) {
+            issue_item(plane, 1);
+            npro += 9;
+        } else if (plane + NWV < p_end) {
+            issue_item(plane + NWV, 1);   // NP == 1: slot parity alternates between planes
+            npro += 5;
+        }
+    }
+    if (npro == 19) dma_wait<19>();
+    else if (npro == 10) dma_wait<10>();
+    else if (npro == 5) dma_wait<5>();
+    else dma_wait<0>();
+#pragma unroll
+    for (int ks = 0; ks < KC2; ++ks) asm volatile("" : "+v"(bwc[ks]));
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks) asm volatile("" : "+v"(bws[ks]));
+#pragma unroll
+    for (int X = 0; X < NP; ++X)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            asm volatile("" : "+v"(bhc[X][r]));
+            asm volatile("" : "+v"(bhs[X][r]));
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    HNO_STAMP(a.stamps, 22);
+    const bool q0 = q == 0;
+    // plane rows of item (plane, X) in its slot: row r of the plane at rowsP + r N2 (rows of the tile) / rowsM + r N2 (mirror rows)
+    auto item_rows = [&](int pl, int X, int slot, const float *&rowsP, const float *&rowsM) {
+        const unsigned g0 = shift0 + (unsigned)pl * pe;
+        const float *sl = ring + slot * SLOTF;
+        if (NP == 1) rowsP = rowsM = sl + (g0 & 3u);
+        else if (X == 0) {
+            rowsP = sl + (g0 & 3u);
+            rowsM = sl + 5 * 256 + ((g0 + 49u * N2) & 3u) - 49 * N2;
+        } else
+            rowsP = rowsM = sl + ((g0 + 17u * N2) & 3u) - 17 * N2;
+    };
+    // cosine-part operands of the two tiles of an item (column c = 4 ks + q and its mirror N2 - c)
+    auto read_cos = [&](int pl, int X, int slot, float (&ra0)[KC2], float (&rb0)[KC2], float (&ra1)[KC2], float (&rb1)[KC2]) {
+        if (ABL == 2) {
+#pragma unroll
+            for (int ks = 0; ks < KC2; ++ks) ra0[ks] = rb0[ks] = ra1[ks] = rb1[ks] = bwc[ks];
+            return;
+        }
+        const float *rowsP, *rowsM;
+        item_rows(pl, X, slot, rowsP, rowsM);
+        const int rp = 1 + 16 * X + l15;
+        const float *row0 = rowsP + rp * N2, *row1 = rowsM + (N1 - rp) * N2;
+        const float *pf0 = row0 + q, *pb0 = row0 + N2 - q - 4 * (KC2 - 1), *pf1 = row1 + q, *pb1 = row1 + N2 - q - 4 * (KC2 - 1);
+#pragma unroll
+        for (int ks = 0; ks < KC2; ++ks) {
+            ra0[ks] = pf0[4 * ks];
+            rb0[ks] = pb0[4 * (KC2 - 1 - ks)];
+            ra1[ks] = pf1[4 * ks];
+            rb1[ks] = pb1[4 * (KC2 - 1 - ks)];
+        }
+    };
+    // The loop is software-pipelined over items: the cosine operands of item t + 1 are read from LDS (its DMA has landed: counted wait)
+    // before the sine / axis-H MFMAs of item t are issued, so an item starts on operands that are already in registers.
+    float a0[KC2], b0[KC2], a1_[KC2], b1[KC2];
+    if (plane < p_end) {
+        if (NP == 2) dma_wait<9>();
+        else if (plane + NWV < p_end) dma_wait<5>();
+        else dma_wait<0>();
+        if (!(a.dbg & 1)) read_cos(plane, 0, 0, a0, b0, a1_, b1);
+    }
+    int it = 0;
+    for (; plane < p_end; plane += NWV, ++it) {
+        const bool more = plane + NWV < p_end;
+        f32x4 pA = {0.f, 0.f, 0.f, 0.f}, pB = pA, qA = pA, qB = pA;   // axis-H sums of the plane
+#pragma unroll
+        for (int X = 0; X < NP; ++X) {
+            HNO_STAMP(a.stamps, 24 + (it * NP + X) * 6);
+            const int slot = NP == 2 ? X : (it & 1);
+            const bool refill = NP == 2 ? more : (plane + 2 * NWV < p_end);
+            const int rf_plane = NP == 2 ? plane + NWV : plane + 2 * NWV;
+            if (a.dbg & 1) {   // timing aid: DMA stream and waits only
+                if (refill) issue_item(rf_plane, slot);
+                if (refill) {
+                    if (NP == 2 && X == 0) dma_wait<10>();
+                    else if (NP == 2) dma_wait<9>();
+                    else dma_wait<5>();
+                } else
+                    dma_wait<0>();
+                continue;
+            }
+            const float *rowsP, *rowsM;
+            item_rows(plane, X, slot, rowsP, rowsM);
+            const int rp = 1 + 16 * X + l15;
+            const float *row0 = rowsP + rp * N2, *row1 = rowsM + (N1 - rp) * N2;
+            // ---- the item's remaining operand reads (sine part, row 0) go out first: they land behind the cosine part's MFMAs
+            float sa0[KS2], sb0[KS2], sa1[KS2], sb1[KS2];
+            if (ABL == 2) {
+#pragma unroll
+                for (int ks = 0; ks < KS2; ++ks) sa0[ks] = sb0[ks] = sa1[ks] = sb1[ks] = bws[ks];
+            } else {
+                const float *sf0 = row0 + a2.Js - q - 4 * (KS2 - 1), *sb0_ = row0 + N2 - a2.Js + q;
+                const float *sf1 = row1 + a2.Js - q - 4 * (KS2 - 1), *sb1_ = row1 + N2 - a2.Js + q;
+#pragma unroll
+                for (int ks = 0; ks < KS2; ++ks) {
+                    sa0[ks] = sf0[4 * (KS2 - 1 - ks)];
+                    sb0[ks] = sb0_[4 * ks];
+                    sa1[ks] = sf1[4 * (KS2 - 1 - ks)];
+                    sb1[ks] = sb1_[4 * ks];
+                }
+            }
+            float r0a[KC2], r0b[KC2], r0c[KS2], r0d[KS2];   // row 0 (item 0 only)
+            if (X == 0 && ABL == 2) {
+#pragma unroll
+                for (int ks = 0; ks < KC2; ++ks) r0a[ks] = r0b[ks] = bwc[ks];
+#pragma unroll
+                for (int ks = 0; ks < KS2; ++ks) r0c[ks] = r0d[ks] = bws[ks];
+            } else if (X == 0) {
+                const float *rz = rowsP;
+                const float *pf = rz + q, *pb = rz + N2 - q - 4 * (KC2 - 1), *sf = rz + a2.Js - q - 4 * (KS2 - 1), *sb = rz + N2 - a2.Js + q;
+#pragma unroll
+                for (int ks = 0; ks < KC2; ++ks) {
+                    r0a[ks] = pf[4 * ks];
+                    r0b[ks] = pb[4 * (KC2 - 1 - ks)];
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS2; ++ks) {
+                    r0c[ks] = sf[4 * (KS2 - 1 - ks)];
+                    r0d[ks] = sb[4 * ks];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // c = 0 has no mirror element: what was read there (the next row's first element, or bytes outside the chunk) is dropped
+            // by a select, so no garbage is ever multiplied
+            b0[0] = q0 ? 0.f : b0[0];
+            b1[0] = q0 ? 0.f : b1[0];
+#pragma unroll
+            for (int ks = 0; ks < KC2; ++ks) {
+                a0[ks] += b0[ks];
+                a1_[ks] += b1[ks];
+            }
+            // ---- cosine part.  Its first MFMAs cover the latency of the reads just issued; as soon as those have returned the slot is
+            //      refilled (the earlier a slot is free, the more bytes the wave keeps in flight: with the refill behind the whole
+            //      cosine part the kernel was latency-bound at 4.2 TB/s).  The VALU work of the next bursts (sine folds, row 0) rides
+            //      between the remaining MFMAs: an MFMA holds the matrix pipe for 32 cycles but the issue port only for 8
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, s0 = c0, c1 = c0, s1 = c0;
+            float pc = 0.f, ps = 0.f;   // row 0: this lane group's share of the sums over the folded columns
+            constexpr int KSPLIT = KC2 / 2;
+#pragma unroll
+            for (int ks = 0; ks < KSPLIT; ++ks) {
+                c0 = MM(a0[ks], bwc[ks], c0);
+                c1 = MM(a1_[ks], bwc[ks], c1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of the item has returned
+            HNO_STAMP(a.stamps, 25 + (it * NP + X) * 6);
+            if (refill) issue_item(rf_plane, slot);
+            HNO_STAMP(a.stamps, 26 + (it * NP + X) * 6);
+#pragma unroll
+            for (int ks = KSPLIT; ks < KC2; ++ks) {
+                __builtin_amdgcn_sched_barrier(0);
+                c0 = MM(a0[ks], bwc[ks], c0);
+                c1 = MM(a1_[ks], bwc[ks], c1);
+#pragma unroll
+                for (int j = 2 * (ks - KSPLIT); j < 2 * (ks - KSPLIT) + 2; ++j) {
+                    if (j < KS2) {
+                        sa0[j] -= sb0[j];
+                        sa1[j] -= sb1[j];
+                    }
+                    if (X == 0) {
+                        if (j < KC2) pc = fmaf(r0a[j] + ((j == 0 && q0) ? 0.f : r0b[j]), bwc[j], pc);
+                        if (j < KS2) ps = fmaf(r0c[j] - r0d[j], bws[j], ps);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- sine part, with the axis-H products of the finished cosine part between its MFMAs (four independent chains).
+            //      Axis H, this item's 16 row pairs: P = cos sums of the folded rows, Q = sin sums of the row differences
+            float fa[4], fb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                fa[r] = c0[r] + c1[r];
+                fb[r] = c0[r] - c1[r];
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {
+                __builtin_amdgcn_sched_barrier(0);
+                s0 = MM(sa0[ks], bws[ks], s0);
+                s1 = MM(sa1[ks], bws[ks], s1);
+                if ((ks & 1) == 0 && ks / 2 < 4) pA = MM(fa[ks / 2], bhc[X][ks / 2], pA);
+                if ((ks & 1) == 1 && ks / 2 < 4) qA = MM(fb[ks / 2], bhs[X][ks / 2], qA);
+            }
+            if (KS2 < 8) {
+#pragma unroll
+                for (int r = KS2 / 2; r < 4; ++r) {
+                    pA = MM(fa[r], bhc[X][r], pA);
+                    qA = MM(fb[r], bhs[X][r], qA);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- the next item has landed when at most the pieces of the refill just issued are outstanding (vector memory completes
+            //      in order; Y stores in between only make the wait a little longer than necessary): fetch its cosine operands now
+            {
+                const bool have_next = X + 1 < NP || more;
+                if (have_next) {
+                    if (refill) {
+                        if (NP == 2 && X == 0) dma_wait<10>();
+                        else if (NP == 2) dma_wait<9>();
+                        else dma_wait<5>();
+                    } else
+                        dma_wait<0>();
+                    if (X + 1 < NP) read_cos(plane, X + 1, X + 1, a0, b0, a1_, b1);
+                    else read_cos(plane + NWV, 0, NP == 2 ? 0 : ((it + 1) & 1), a0, b0, a1_, b1);
+                }
+            }
+            HNO_STAMP(a.stamps, 27 + (it * NP + X) * 6);
+            // row 0: the sum over the four lane groups is the K sum of an MFMA against ones
+            if (X == 0) {
+                pA = MM(pc, 1.f, pA);
+                pB = MM(ps, 1.f, pB);
+            }
+            float fc[4], fd[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                fc[r] = s0[r] + s1[r];
+                fd[r] = s0[r] - s1[r];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pB = MM(fc[r], bhc[X][r], pB);
+                qB = MM(fd[r], bhs[X][r], qB);
+            }
+            HNO_STAMP(a.stamps, 28 + (it * NP + X) * 6);
+        }
+        if (!(a.dbg & 1)) {
+            float *Yp = Y + (size_t)plane * (2 * p.CP);
+            const int k1 = l15;
+            if (k1 <= a1.m) {
+                // part 0: cos sum of Ac (pA), sin sum of As (qB);  part 1: cos sum of As (pB), sin sum of Ac (qA)
+                f32x4 vp0, vm0, vp1, vm1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    vp0[r] = pA[r] - qB[r];
+                    vm0[r] = pA[r] + qB[r];
+                    vp1[r] = -(qA[r] + pB[r]);
+                    vm1[r] = qA[r] - pB[r];
+                }
+                const int k2 = q * 4;
+                // write-through stores: the 11.6 MB of Y would otherwise sit dirty in the L2s until the end-of-kernel write-back
+                store16_wt(Yp + (size_t)(a1.m + k1) * a2.KP + k2, vp0);
+                store16_wt(Yp + (size_t)(p.K1S + (a1.m + k1)) * a2.KP + k2, vp1);
+                if (k1 >= 1) {
+                    store16_wt(Yp + (size_t)(a1.m - k1) * a2.KP + k2, vm0);
+                    store16_wt(Yp + (size_t)(p.K1S + (a1.m - k1)) * a2.KP + k2, vm1);
+                }
+            }
+        }
+    }
+    HNO_STAMP(a.stamps, 23);
+    if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[61] = wall_clock64();
+    if (a.stamps && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a.stamps[59] = wall_clock64();
+    if (a.stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 64 * (NWV - 1)) a.stamps[57] = wall_clock64();
+}
+
 // ---- forward, axis D + (Re -/+ Im) + crop: one wave per (bc, column tile) ----------------
 __global__ __launch_bounds__(64) void dht_fwd_d_kernel(const float *__restrict__ Y, float *__restrict__ out, DhtArgs a) {
     extern __shared__ float lds[];
@@ -1675,6 +2098,19 @@ static int check_sizes(int BC, int N0, int N1, int N2, int m0, int m1, int m2, i
 
 static const size_t kMaxLds = 160 * 1024;
 
+// HNO_FWD_PLANE: "wave" = 1 (round-2 kernel: register prefetch, axis-W result through LDS), "dma8" = 2 (DMA kernel, 8 waves x 1 slot),
+// default 0 = DMA kernel with 4 waves x 2 slots.  A/B aid; read once.
+static int fwd_plane_variant() {
+    static const int v = [] {
+        const char *e = getenv("HNO_FWD_PLANE");
+        if (!e) return 0;
+        if (!strcmp(e, "wave")) return 1;
+        if (!strcmp(e, "dma8")) return 2;
+        return 0;
+    }();
+    return v;
+}
+
 }  // namespace hno
 
 using namespace hno;
@@ -1749,6 +2185,31 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
         hipLaunchKernelGGL(kern, dim3(gw), dim3(64 * NWV), lds_w, s, x, (float *)workspace, a);                            \
         launched = true;                                                                                                   \
     }
+        // planes by LDS-DMA, axis-W result in registers (see dht_fwd_plane_dma_kernel); HNO_FWD_PLANE=wave selects the older kernel
+#define HNO_DMA(KC2, KS2, NP)                                                                                              \
+    if (!launched && spec_ok && !x_act_out && !(a.dbg & 512) && fwd_plane_variant() != 1 && N1 == 32 * NP + 1 && (N2 & 1) && \
+        b2.KcP == 4 * KC2 && b2.KsP == 4 * KS2 && b2.Js == b2.KsP && plan->NP1 == NP && b1.KT == 1 &&                      \
+        (NP == 2 ? N2 == 65 : N2 <= 37) && (double)planes * pe < 1.0e9 && ((size_t)x & 3) == 0) {                          \
+        const unsigned shift0 = (unsigned)(((size_t)x >> 2) & 3);                                                          \
+        const float *xal = x - shift0;                                                                                     \
+        const unsigned max_off = (unsigned)((((size_t)shift0 + (size_t)planes * pe) * 4 - 1) & ~(size_t)15);               \
+        constexpr int NWV = 8;                                                                                             \
+        auto kern = (a.dbg & 2) ? dht_fwd_plane_dma_kernel<KC2, KS2, NP, NWV, 1>                                          \
+                                : (a.dbg & 4) ? dht_fwd_plane_dma_kernel<KC2, KS2, NP, NWV, 2> : dht_fwd_plane_dma_kernel<KC2, KS2, NP, NWV, 0>; \
+        const size_t lds_w = (size_t)NWV * 2 * (NP == 2 ? 10 : 5) * 1024;                                                  \
+        static bool attr = false;                                                                                          \
+        if (!attr || (a.dbg & 6)) {                                                                                        \
+            HNO_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds)); \
+            attr = true;                                                                                                   \
+        }                                                                                                                  \
+        const int gw = persistent_grid((const void *)kern, 64 * NWV, lds_w, (planes + NWV - 1) / NWV);                     \
+        hipLaunchKernelGGL(kern, dim3(gw), dim3(64 * NWV), lds_w, s, xal, (float *)workspace, a, shift0, max_off,          \
+                           planes / gw, planes % gw);                                                                      \
+        launched = true;                                                                                                   \
+    }
+        HNO_DMA(9, 8, 2)           // 65 x 65 planes
+        HNO_DMA(5, 4, 1)           // 33 x 33 planes
+#undef HNO_DMA
         HNO_WAVE(9, 8, 9, 8, 16)   // 65 x 65 planes
         HNO_WAVE(5, 4, 5, 4, 4)    // 33 x 33 planes
 #undef HNO_WAVE

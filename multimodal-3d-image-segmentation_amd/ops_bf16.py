@@ -144,8 +144,9 @@ def wgrad_raw(g, xa, xb, w_shape, transposed, ks, stride, pad, param=None):
     dW = ops._grad_buffer(param) if (param is not None and tuple(param.shape) == tuple(w_shape)) else \
         torch.empty(tuple(w_shape), device=g.device, dtype=torch.float32)
     Cin, Cout = (xa.shape[4] + Cb, g.shape[4])
-    ws = _ws(L.hno_cb_wgrad_workspace_bytes(max(Cin, Cout), max(Cin, Cout), ks), g.device)
-    check(L.hno_cb_wgrad(ptr(g), g.shape[4], ptr(xa), xa.shape[4], ptr(xb), Cb, ptr(dW), ptr(ws), int(transposed), g.shape[0],
+    nws = L.hno_cb_wgrad_workspace_bytes(Cin, Cout, ks)
+    ws = _ws(nws, g.device)
+    check(L.hno_cb_wgrad(ptr(g), g.shape[4], ptr(xa), xa.shape[4], ptr(xb), Cb, ptr(dW), ptr(ws), nws, int(transposed), g.shape[0],
                          xa.shape[1], xa.shape[2], xa.shape[3], g.shape[1], g.shape[2], g.shape[3], ks, stride, pad, stream_ptr()),
           'hno_cb_wgrad')
     return dW

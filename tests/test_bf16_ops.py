@@ -67,6 +67,10 @@ CONV_CASES = [
     (2, 48, 0, 96, (2, 9, 30), 3, 1, False),
     (1, 96, 96, 192, (2, 8, 30), 3, 1, False),
     (1, 24, 0, 24, (3, 7, 65), 3, 1, False),        # the level-0 row width of BASELINE cfg4
+    # channel counts that are not multiples of 48 (one weight-gradient launch per 48 x 48 block) on grids with >= 256 work
+    # items per launch: every launch fills all 256 slabs of the workspace (round-2 advisor finding: the bound was 252)
+    (4, 128, 0, 128, (64, 4, 4), 3, 1, False),
+    (2, 128, 0, 128, (128, 4, 4), 1, 1, False),
 ]
 
 

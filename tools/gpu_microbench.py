@@ -104,6 +104,30 @@ if which in ('stamps',):
         if row[0] == 0: break
         print(f'  iter {it}:', ', '.join(f'{n}: {v - st[0]}' for n, v in zip(names, row)))
 
+if which in ('stamps_dma',):
+    import ctypes
+    x = torch.randn(B, C, N, N, N, device=dev)
+    BC, NN, mm = 48, (65, 65, 65), (10, 14, 14)
+    ws = torch.empty(L.hno_dht3_workspace_bytes(BC, *NN, *mm) // 4, device=dev)
+    out = torch.empty(B, C, 20, 28, 28, device=dev)
+    P, S = pkg._lib.ptr, pkg._lib.stream_ptr
+    for _ in range(3): L.hno_dht3_crop(P(x), None, 0, P(out), P(ws), BC, *NN, *mm, 1.0, S())
+    buf = (ctypes.c_longlong * 64)()
+    L.hno_debug_stamps(buf, 64)   # allocate + clear
+    L.hno_set_debug(64)
+    L.hno_dht3_crop(P(x), None, 0, P(out), P(ws), BC, *NN, *mm, 1.0, S())
+    L.hno_set_debug(0)
+    L.hno_debug_stamps(buf, 64)
+    st = list(buf)
+    t0 = st[0]
+    base = st[20]
+    print(f'cycles from kernel top: table loads issued {st[21] - base}, DMAs issued + tables landed {st[22] - base}, end {st[23] - base}; wall: block 0 wave 0 {(st[61] - st[60]) * 10} ns, last block start +{(st[58] - st[60]) * 10} ns end +{(st[59] - st[60]) * 10} ns, middle block wave 7 start +{(st[56] - st[60]) * 10} end +{(st[57] - st[60]) * 10} ns')
+    names = ['top', 'reads back (4 cos steps)', 'refill issued', 'sin loop done, next landed, cos prefetch issued', 'item done']
+    for it in range(5):
+        row = st[24 + it * 6: 29 + it * 6]
+        if row[0] == 0: break
+        print(f'  item {it}:', ', '.join(f'{n}: {v - base}' for n, v in zip(names, row)))
+
 if which in ('stamps_inv',):
     import ctypes
     z = torch.randn(B, C, 20, 28, 28, device=dev); x = torch.randn(B, C, N, N, N, device=dev)
