@@ -45,6 +45,7 @@ struct DhtPlan {
     int K1S;           // 2*m1 + 1 signed k1 values
     int hperm, NP1;    // axis-H tables in accumulator order for the DMA forward plane kernel (odd N1, one k1 tile): offset, row-pair tiles
     int dmatab, dmatab_stride;   // kDmaTabCopies copies of [axis-W cos | axis-W sin | hperm] in lane order (one 256-byte row per register)
+    int itab, itab_stride;       // inverse item kernel: copies of [axis-H: tile X][cos | sin][ks] then [axis-W: tile nt2][cos | sin][r], lane order
     int CP;            // K1S * KP2 columns per part (re / im) of the intermediate
     int MP1;           // N1 rounded up to 16
     // forward plane kernel LDS layout (floats)
@@ -148,6 +149,10 @@ static int get_plan(int N0, int N1, int N2, int m0, int m1, int m2, const DhtPla
     p.dmatab = cursor;
     p.dmatab_stride = round_up((p.ax[2].KcP / 4 + p.ax[2].KsP / 4 + p.NP1 * 8) * 64, 64);
     if (dma_tab) cursor += kDmaTabCopies * p.dmatab_stride;
+    p.itab = cursor;
+    const int i_nt2 = ceil_div(p.ax[2].J, 16);
+    p.itab_stride = (p.NP1 * 2 * (p.ax[1].KmP / 4) + i_nt2 * 8) * 64;
+    if (dma_tab) cursor += kDmaTabCopies * p.itab_stride;
     p.table_floats = cursor;
     std::vector<float> host(cursor, 0.f);
     build_axis_tables(p.ax[0], host, false, false);
@@ -175,6 +180,31 @@ static int get_plan(int N0, int N1, int N2, int m0, int m1, int m2, const DhtPla
         blk.insert(blk.end(), host.begin() + w.sinF, host.begin() + w.sinF + (w.KsP / 4) * 64);
         blk.insert(blk.end(), host.begin() + p.hperm, host.begin() + p.hperm + p.NP1 * 8 * 64);
         for (int c = 0; c < kDmaTabCopies; ++c) std::copy(blk.begin(), blk.end(), host.begin() + p.dmatab + c * p.dmatab_stride);
+        // inverse item kernel (dht_inv_item_kernel).  Axis H: output column n1 = 1 + 16 X + l15 against frequency kk = 4 ks + q (kk = 0
+        // is its own mirror in the +-k1 fold: cosine halved).  Axis W: the A operand is the axis-H accumulator as it lies, so k-step r
+        // of lane group q is frequency k2 = 4 q + r; output column n2 = 1 + 16 nt2 + l15.
+        const Axis &h = p.ax[1];
+        const double thH = 2.0 * M_PI / h.N, thW = 2.0 * M_PI / w.N;
+        std::vector<float> ib;
+        for (int X = 0; X < p.NP1; ++X)
+            for (int cs = 0; cs < 2; ++cs)
+                for (int ks = 0; ks < h.KmP / 4; ++ks)
+                    for (int ln = 0; ln < 64; ++ln) {
+                        const int n = 1 + 16 * X + (ln & 15), kk = 4 * ks + (ln >> 4);
+                        const bool ok = n <= h.J && kk <= h.m;
+                        const double ang = thH * (double)((long long)kk * n % h.N);
+                        ib.push_back(!ok ? 0.f : (float)(cs ? sin(ang) : cos(ang) * (kk == 0 ? 0.5 : 1.0)));
+                    }
+        for (int nt = 0; nt < i_nt2; ++nt)
+            for (int cs = 0; cs < 2; ++cs)
+                for (int r = 0; r < 4; ++r)
+                    for (int ln = 0; ln < 64; ++ln) {
+                        const int n = 1 + 16 * nt + (ln & 15), kk = 4 * (ln >> 4) + r;
+                        const bool ok = n <= w.J && kk <= w.m;
+                        const double ang = thW * (double)((long long)kk * n % w.N);
+                        ib.push_back(!ok ? 0.f : (float)(cs ? sin(ang) : cos(ang)));
+                    }
+        for (int c = 0; c < kDmaTabCopies; ++c) std::copy(ib.begin(), ib.end(), host.begin() + p.itab + c * p.itab_stride);
     }
     // table creation is the one place that allocates: do it outside graph capture (warm-up)
     HNO_CHECK_HIP(hipMalloc((void **)&p.tables, sizeof(float) * cursor));
@@ -245,6 +275,8 @@ struct DhtArgs {
     // first axis (N0 = 1, m0 = 0: the 2-D transforms).  full1 / full2 are Hartley-layout only.
     int full0, full1, full2;
 };
+
+constexpr int round_up_c(int a, int b) { return (a + b - 1) / b * b; }
 
 // signed frequency -> index in the [low | high] block, or -1 if not kept
 __device__ __forceinline__ int kept_pos(int k, int m, int full = 0) {
@@ -2077,6 +2109,301 @@ __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float 
     if (a.stamps && blockIdx.x == 0 && tid == 0) { a.stamps[61] = wall_clock64(); a.stamps[63] = clock64(); }
 }
 
+// ---- inverse plane kernel, one wave per ITEM (half plane), no workgroup barrier, both GEMMs chained in registers ---------------
+// What bounded the kernel above (profiles/r02_d_pmc_sq_per_kernel.json): three workgroup barriers per plane, the axis-H result through
+// LDS, 3 300 instructions per wave of which ~1 000 are the SELU epilogue, and fp32 MFMAs that do not overlap VALU work of the same wave.
+// Here an item = the output rows of one row-pair tile: rows n1 = 1 + 16 X + i and their mirrors N1 - n1 (item 0 also row 0), i.e. rows
+// [0, 17) + [49, 65) and rows [17, 49) of a 65-row plane -- items are independent, so 6 240 of them spread evenly over all SIMDs:
+//   * axis H reads its operands (the +-k1 rows of the 3.7 KB intermediate plane) straight from global memory / L2, 16 dwords per lane;
+//   * its accumulators (column n1 on the lane, rows k2 = 4 q + r in register r) ARE the A operands of the axis-W product when the
+//     tables are stored with k-step r <-> k2 = 4 q + r (DhtPlan::itab): no LDS between the two GEMMs;
+//   * the axis-W result goes to a wave-private LDS image of the item's rows, laid out at the 16-byte phase of the global destination,
+//     so the epilogue (scale, residual, activation) reads ds_read_b128 and writes aligned 16-byte rows; only the first and last
+//     group of a chunk are written element-wise;
+//   * twelve waves per CU (three per SIMD): while one wave's MFMAs hold the matrix pipe the others run their epilogues.
+// Requires N1 = 32 NP + 1 (NP = 1, 2), N2 = 16 NT2 * 2 + 1, one k tile per axis, out (and addend) 4-byte aligned with equal 16-byte phase.
+template <int NP, int N2c, int KM1, int NT2, bool HAS_ADD, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const float *__restrict__ E, const float *__restrict__ add_al,
+                                                              float *__restrict__ out_al, DhtArgs a, unsigned shift0, int it_base,
+                                                              int it_rem) {
+    extern __shared__ float lds[];
+    HNO_STAMP(a.stamps, 20);
+    if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[60] = wall_clock64();
+    if (a.stamps && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a.stamps[58] = wall_clock64();
+    if (a.stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 64 * (NWV - 1)) a.stamps[56] = wall_clock64();
+    constexpr int N1 = 32 * NP + 1, N2 = N2c;
+    constexpr int OBUF = NP == 2 ? 2176 : round_up_c(N1 * N2 + 4, 64);   // floats per wave: the item's rows (+ phase slack)
+    constexpr int WSTRIDE = OBUF + 64;                                    // + scratch for row 0
+    const DhtPlan &p = a.p;
+    const Axis &a1 = p.ax[1];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4, l15 = lane & 15;
+    const int m1 = a1.m;
+    float *obuf = lds + (size_t)wave * WSTRIDE, *scr = obuf + OBUF;
+    const int bid = blockIdx.x;
+    const int t_begin = bid * it_base + (bid < it_rem ? bid : it_rem);
+    const int t_end = t_begin + it_base + (bid < it_rem ? 1 : 0);
+    // the items of a wave all have the same X (NWV is even): X = parity of its first item
+    int t = t_begin + wave;
+    const int X = NP == 2 ? (t & 1) : 0;
+    // ---- tables (lane order, copy b % kDmaTabCopies): axis H of tile X, axis W of both column tiles
+    float thc[KM1], ths[KM1], bwc[NT2][4], bws[NT2][4];
+    {
+        const float *tb = p.tables + p.itab + (size_t)(bid % kDmaTabCopies) * p.itab_stride + lane;
+#pragma unroll
+        for (int ks = 0; ks < KM1; ++ks) {
+            thc[ks] = tb[((X * 2 + 0) * KM1 + ks) * 64];
+            ths[ks] = tb[((X * 2 + 1) * KM1 + ks) * 64];
+        }
+        const float *tw = tb + NP * 2 * KM1 * 64;
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bwc[nt][r] = tw[((nt * 2 + 0) * 4 + r) * 64];
+                bws[nt][r] = tw[((nt * 2 + 1) * 4 + r) * 64];
+            }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KM1; ++ks) {
+        asm volatile("" : "+v"(thc[ks]));
+        asm volatile("" : "+v"(ths[ks]));
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            asm volatile("" : "+v"(bwc[nt][r]));
+            asm volatile("" : "+v"(bws[nt][r]));
+        }
+    const unsigned pe = N1 * N2;
+    const int ne = 2 * p.CP;                                   // floats per intermediate plane
+    const float ap = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f;
+    const float aq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
+    const bool lin = a.act == HNO_ACT_NONE;
+    const bool q0 = q == 0;
+    // chunk geometry of this wave's items: rows [R0, R0 + NR) at LDS float offset LO (a second chunk for X = 0 of a 65-row plane)
+    // X = 0: rows [0, 17) (+ [49, 65));  X = 1: rows [17, 49);  NP = 1: rows [0, 33)
+    // axis-H operands of an item: rows k1s = m1 +- (4 ks + q) of the re / im parts (out-of-range rows are selected away: the last
+    // k-step may reach |k1| = m1 + 1, whose table entries are zero but whose bytes are arbitrary).  Four waves per SIMD cover the
+    // L2 round trip; prefetching the next item's operands was measured and changed nothing at three waves per SIMD.
+    float erp[KM1], erm[KM1], eip[KM1], eim[KM1];
+    auto load_e = [&](int tt) {
+        const int pl = NP == 2 ? (tt >> 1) : tt;
+        const float *Ep = E + (size_t)pl * ne;
+#pragma unroll
+        for (int ks = 0; ks < KM1; ++ks) {
+            const int k1 = 4 * ks + q;
+            const bool ok = k1 <= m1;
+            const int rp = ok ? m1 + k1 : m1, rm = ok ? m1 - k1 : m1;
+            erp[ks] = Ep[rp * 16 + l15];
+            erm[ks] = Ep[rm * 16 + l15];
+            eip[ks] = Ep[p.CP + rp * 16 + l15];
+            eim[ks] = Ep[p.CP + rm * 16 + l15];
+        }
+    };
+    HNO_STAMP(a.stamps, 21);
+    int it = 0;
+    for (; t < t_end; t += NWV, ++it) {
+        HNO_STAMP(a.stamps, 24 + it * 6);
+        const int plane = NP == 2 ? (t >> 1) : t;
+        load_e(t);
+        // ---- folds of the +-k1 rows
+        float sR[KM1], dR[KM1], sI[KM1], dI[KM1];
+#pragma unroll
+        for (int ks = 0; ks < KM1; ++ks) {
+            const bool ok = 4 * ks + q <= m1;
+            sR[ks] = ok ? erp[ks] + erm[ks] : 0.f;
+            dR[ks] = ok ? erp[ks] - erm[ks] : 0.f;
+            sI[ks] = ok ? eip[ks] + eim[ks] : 0.f;
+            dI[ks] = ok ? eip[ks] - eim[ks] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- chunk geometry of the item (rows [r0, r0 + nr) of the plane, LDS float offset): X = 0: rows [0, 17) (+ [49, 65) at 1112);
+        //      X = 1: rows [17, 49);  NP = 1: rows [0, 33)
+        const unsigned f0 = shift0 + (unsigned)plane * pe;     // float index of the plane from the aligned base
+        constexpr int NG0 = NP == 2 ? 5 : (N1 * N2 + 3 + 255) / 256, NG1 = NP == 2 ? 5 : 0, NGB = 9;
+        const int c0_r0 = NP == 2 ? (X == 0 ? 0 : 17) : 0;
+        const int c1_r0 = 49, c1_lo = 1112;
+        const unsigned fA = f0 + (unsigned)(c0_r0 * N2), fC = f0 + 49u * N2;
+        const unsigned shA = fA & 3u, shC = fC & 3u;
+        if (a.stamps) asm volatile("s_nop 0" ::"v"(sR[0]), "v"(dI[KM1 - 1]));
+        HNO_STAMP(a.stamps, 25 + it * 6);
+        // ---- axis H, tile X: F[n1][k2] = sum_k1 E[k1][k2] e^{+i th k1 n1}: cR, cI = cosine sums of re / im, sR_, sI_ = sine sums
+        f32x4 cRe = {0.f, 0.f, 0.f, 0.f}, cIm = cRe, sRe = cRe, sIm = cRe;
+        if (!(a.dbg & 8))   // timing aid: no MFMA
+#pragma unroll
+        for (int ks = 0; ks < KM1; ++ks) {
+            cRe = mfma16(sR[ks], thc[ks], cRe);
+            sIm = mfma16(dI[ks], ths[ks], sIm);
+            cIm = mfma16(sI[ks], thc[ks], cIm);
+            sRe = mfma16(dR[ks], ths[ks], sRe);
+        }
+        // row n1: FR = cRe - sIm, FI = cIm + sRe;  mirror row N1 - n1: FR = cRe + sIm, FI = cIm - sRe
+        float FRp[4], FIp[4], FRm[4], FIm[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            FRp[r] = cRe[r] - sIm[r];
+            FRm[r] = cRe[r] + sIm[r];
+            FIp[r] = cIm[r] + sRe[r];
+            FIm[r] = cIm[r] - sRe[r];
+        }
+        if (a.stamps) asm volatile("s_nop 0" ::"v"(FRp[0]), "v"(FIm[3]));
+        HNO_STAMP(a.stamps, 26 + it * 6);
+        // ---- LDS image of the item's rows: plane row n1 of chunk 0 at img0 + n1 N2, of chunk 1 at img1 + n1 N2
+        float *img0 = obuf + shA - c0_r0 * N2, *img1 = obuf + c1_lo + shC - c1_r0 * N2;
+        const int n1p = 1 + 16 * X + 4 * q, n1m = N1 - n1p;     // rows of accumulator register 0 (plus tile ascending, mirror descending)
+        float *rowP = img0 + n1p * N2, *rowM = ((NP == 2 && X == 0) ? img1 : img0) + n1m * N2;
+        // ---- axis W: O[n1][n2] = sum_k2 FR cos - FI sin, mirror column N2 - n2 gets +; the A operands are the F registers
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+            f32x4 pc = {0.f, 0.f, 0.f, 0.f}, ps = pc, mc = pc, ms = pc;
+            if (!(a.dbg & 8))
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pc = mfma16(FRp[r], bwc[nt][r], pc);
+                ps = mfma16(FIp[r], bws[nt][r], ps);
+                mc = mfma16(FRm[r], bwc[nt][r], mc);
+                ms = mfma16(FIm[r], bws[nt][r], ms);
+            }
+            const int n2 = 1 + 16 * nt + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                rowP[r * N2 + n2] = pc[r] - ps[r];
+                rowP[r * N2 + N2 - n2] = pc[r] + ps[r];
+                rowM[-r * N2 + n2] = mc[r] - ms[r];
+                rowM[-r * N2 + N2 - n2] = mc[r] + ms[r];
+            }
+        }
+        HNO_STAMP(a.stamps, 27 + it * 6);
+        // ---- output column n2 = 0: cos = 1, sin = 0 -> the plain sum of FR over k2 = over (q, r): row i = l15 of each tile
+        {
+            float zp = (FRp[0] + FRp[1]) + (FRp[2] + FRp[3]), zm = (FRm[0] + FRm[1]) + (FRm[2] + FRm[3]);
+            zp += __shfl_xor(zp, 16);
+            zm += __shfl_xor(zm, 16);
+            zp += __shfl_xor(zp, 32);
+            zm += __shfl_xor(zm, 32);
+            // ... but the lane layout of F is (column n1 index = l15, k2 group q): the sum over q is the row's value
+            if (q0) {
+                img0[(1 + 16 * X + l15) * N2] = zp;
+                ((NP == 2 && X == 0) ? img1 : img0)[(N1 - 1 - 16 * X - l15) * N2] = zm;
+            }
+        }
+        // ---- output row 0 (item 0): F[0][k2] = plain sum over all k1 (the k1 = 0 row was doubled by the fold)
+        if (X == 0) {
+            float f0r = q0 ? 0.5f * sR[0] : sR[0], f0i = q0 ? 0.5f * sI[0] : sI[0];
+#pragma unroll
+            for (int ks = 1; ks < KM1; ++ks) {
+                f0r += sR[ks];
+                f0i += sI[ks];
+            }
+            f0r += __shfl_xor(f0r, 16);
+            f0i += __shfl_xor(f0i, 16);
+            f0r += __shfl_xor(f0r, 32);
+            f0i += __shfl_xor(f0i, 32);
+            // every lane group holds F0[k2 = l15]; the axis-W tables want k2 = 4 q + r: through the wave's scratch
+            if (q0) {
+                scr[l15] = f0r;
+                scr[16 + l15] = f0i;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const f32x4 gr = *reinterpret_cast<const f32x4 *>(scr + 4 * q), gi = *reinterpret_cast<const f32x4 *>(scr + 16 + 4 * q);
+            float z0 = (gr[0] + gr[1]) + (gr[2] + gr[3]);
+            z0 += __shfl_xor(z0, 16);
+            z0 += __shfl_xor(z0, 32);
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) {
+                float c = 0.f, s_ = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    c = fmaf(gr[r], bwc[nt][r], c);
+                    s_ = fmaf(gi[r], bws[nt][r], s_);
+                }
+                c += __shfl_xor(c, 16);
+                s_ += __shfl_xor(s_, 16);
+                c += __shfl_xor(c, 32);
+                s_ += __shfl_xor(s_, 32);
+                const int n2 = 1 + 16 * nt + l15;
+                if (q0) {
+                    img0[n2] = c - s_;
+                    img0[N2 - n2] = c + s_;
+                }
+            }
+            if (lane == 0) img0[0] = z0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        HNO_STAMP(a.stamps, 28 + it * 6);
+        // ---- epilogue: out = act(scale * O + residual) in aligned 16-byte groups; group g of a chunk covers chunk elements
+        //      4 g - sh .. 4 g - sh + 3 (element e at LDS float lo + sh + e and at global float (f & ~3) + sh + e)
+        auto chunk_out = [&](const int NG, const unsigned fch, const unsigned n, const float *limg) {
+            const unsigned sh = fch & 3u;
+            float *gbase = out_al + (fch & ~3u);
+            const float *abase = HAS_ADD ? add_al + (fch & ~3u) : nullptr;
+            // residual: aligned 16-byte loads of the same groups, two groups ahead of their use (a group that straddles a chunk end
+            // also holds neighbouring rows of the same tensor; groups beyond the chunk are not touched)
+            constexpr int AHEAD = 2;
+            f32x4 rq[AHEAD + 1];
+            auto ld_add = [&](int j) -> f32x4 {
+                const unsigned g = 64u * j + lane;
+                return (4 * g < sh + n) ? *reinterpret_cast<const f32x4 *>(abase + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+            };
+            if (HAS_ADD) {
+#pragma unroll
+                for (int j = 0; j < AHEAD && j < NG; ++j) rq[j] = ld_add(j);
+            }
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                const unsigned g = 64u * j + lane;
+                const int e0 = (int)(4 * g) - (int)sh;
+                if (HAS_ADD && j + AHEAD < NG) rq[(j + AHEAD) % (AHEAD + 1)] = ld_add(j + AHEAD);
+                f32x4 o = *reinterpret_cast<const f32x4 *>(limg + 4 * g);
+                f32x4 v;
+                {   // scale, residual and activation on the packed fp32 pipe, two elements per instruction
+                    const f32x2 sc = {a.scale, a.scale};
+                    f32x2 x0 = f32x2{o[0], o[1]} * sc, x1 = f32x2{o[2], o[3]} * sc;
+                    if (HAS_ADD) {
+                        const f32x4 r = rq[j % (AHEAD + 1)];
+                        x0 = __builtin_elementwise_fma(f32x2{o[0], o[1]}, sc, f32x2{r[0], r[1]});
+                        x1 = __builtin_elementwise_fma(f32x2{o[2], o[3]}, sc, f32x2{r[2], r[3]});
+                    }
+                    if (!lin) {   // wave-uniform
+                        x0 = selu_like_pk(x0, ap, aq);
+                        x1 = selu_like_pk(x1, ap, aq);
+                    }
+                    v = f32x4{x0[0], x0[1], x1[0], x1[1]};
+                }
+                if (a.dbg & 2) {   // timing aid: no stores
+                    asm volatile("" ::"v"(v));
+                } else if (j > 0 && j < NG - 1) {
+                    *reinterpret_cast<f32x4 *>(gbase + 4 * g) = v;          // wholly inside the chunk
+                } else if (e0 >= 0 && e0 + 3 < (int)n) {
+                    *reinterpret_cast<f32x4 *>(gbase + 4 * g) = v;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (e0 + c >= 0 && e0 + c < (int)n) gbase[4 * g + c] = v[c];
+                }
+            }
+        };
+        if (a.dbg & 4) {   // timing aid: no epilogue
+        } else if (NP == 1) chunk_out(NG0, fA, (unsigned)(N1 * N2), obuf);
+        else if (X == 0) {
+            chunk_out(NG0, fA, 17u * N2, obuf);
+            chunk_out(NG1, fC, 16u * N2, obuf + c1_lo);
+        } else
+            chunk_out(NGB, fA, 32u * N2, obuf);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        HNO_STAMP(a.stamps, 29 + it * 6);
+    }
+    HNO_STAMP(a.stamps, 23);
+    if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[61] = wall_clock64();
+    if (a.stamps && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a.stamps[59] = wall_clock64();
+    if (a.stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 64 * (NWV - 1)) a.stamps[57] = wall_clock64();
+}
+
 // full: bit i set = axis i keeps all N_i = 2 m_i + 1 frequencies (see DhtArgs).  A degenerate first axis
 // (N0 = 1, m0 = 0: 2-D data) is always "full".
 static int check_sizes(int BC, int N0, int N1, int N2, int m0, int m1, int m2, int &full, int mode) {
@@ -2097,6 +2424,15 @@ static int check_sizes(int BC, int N0, int N1, int N2, int m0, int m1, int m2, i
 }
 
 static const size_t kMaxLds = 160 * 1024;
+
+// HNO_INV_PLANE: "spec" = 1 (round-2 kernel: a workgroup per plane, axis-H result through LDS), default 0 = item kernel.  A/B aid.
+static int inv_plane_variant() {
+    static const int v = [] {
+        const char *e = getenv("HNO_INV_PLANE");
+        return (e && !strcmp(e, "spec")) ? 1 : 0;
+    }();
+    return v;
+}
 
 // HNO_FWD_PLANE: "wave" = 1 (round-2 kernel: register prefetch, axis-W result through LDS), "dma8" = 2 (DMA kernel, 8 waves x 1 slot),
 // default 0 = DMA kernel with 4 waves x 2 slots.  A/B aid; read once.
@@ -2202,7 +2538,9 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
             HNO_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds)); \
             attr = true;                                                                                                   \
         }                                                                                                                  \
-        const int gw = persistent_grid((const void *)kern, 64 * NWV, lds_w, (planes + NWV - 1) / NWV);                     \
+        static const int gforce = getenv("HNO_FWD_GRID") ? atoi(getenv("HNO_FWD_GRID")) : 0;                               \
+        int gw = persistent_grid((const void *)kern, 64 * NWV, lds_w, (planes + NWV - 1) / NWV);                           \
+        if (gforce > 0) gw = gforce < planes ? gforce : planes;                                                            \
         hipLaunchKernelGGL(kern, dim3(gw), dim3(64 * NWV), lds_w, s, xal, (float *)workspace, a, shift0, max_off,          \
                            planes / gw, planes % gw);                                                                      \
         launched = true;                                                                                                   \
@@ -2311,6 +2649,43 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
         if (g_spec > 8) g_spec = 8;
         g_spec = planes < 256 * g_spec ? planes : 256 * g_spec;
         bool launched = false;
+        // one wave per half-plane item, GEMMs chained in registers (dht_inv_item_kernel); HNO_INV_PLANE=spec selects the older kernel
+#define HNO_ITEM(NP, N2c, KM1, NT2)                                                                                        \
+    if (!launched && spec_ok && !(a.dbg & 512) && inv_plane_variant() != 1 && N1 == 32 * NP + 1 && N2 == N2c && b1.KT == 1 && \
+        b2.KT == 1 && b1.KmP == 4 * KM1 && b2.KmP <= 16 && plan->NP1 == NP && (b2.J + 15) / 16 == NT2 &&                   \
+        (double)planes * pe < 1.0e9 && ((size_t)out & 3) == 0 && (!addend || ((size_t)addend & 15) == ((size_t)out & 15))) { \
+        const unsigned shift0 = (unsigned)(((size_t)out >> 2) & 3);                                                        \
+        float *out_al = out - shift0;                                                                                      \
+        const float *add_al = addend ? addend - shift0 : nullptr;                                                          \
+        constexpr int NWV = 16;                                                                                            \
+        const size_t lds_w = sizeof(float) * NWV * ((NP == 2 ? 2176 : round_up_c((32 * NP + 1) * N2c + 4, 64)) + 64);     \
+        const int items = planes * NP;                                                                                     \
+        if (addend) {                                                                                                      \
+            auto kern = dht_inv_item_kernel<NP, N2c, KM1, NT2, true, NWV>;                                                      \
+            static bool attr = false;                                                                                      \
+            if (!attr) {                                                                                                   \
+                HNO_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds)); \
+                attr = true;                                                                                               \
+            }                                                                                                              \
+            const int gw = items < 256 * NWV ? (items + NWV - 1) / NWV : 256;                                              \
+            hipLaunchKernelGGL(kern, dim3(gw), dim3(64 * NWV), lds_w, s, (const float *)workspace, add_al, out_al, a, shift0, \
+                               items / gw, items % gw);                                                                    \
+        } else {                                                                                                           \
+            auto kern = dht_inv_item_kernel<NP, N2c, KM1, NT2, false, NWV>;                                                     \
+            static bool attr = false;                                                                                      \
+            if (!attr) {                                                                                                   \
+                HNO_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds)); \
+                attr = true;                                                                                               \
+            }                                                                                                              \
+            const int gw = items < 256 * NWV ? (items + NWV - 1) / NWV : 256;                                              \
+            hipLaunchKernelGGL(kern, dim3(gw), dim3(64 * NWV), lds_w, s, (const float *)workspace, add_al, out_al, a, shift0, \
+                               items / gw, items % gw);                                                                    \
+        }                                                                                                                  \
+        launched = true;                                                                                                   \
+    }
+        HNO_ITEM(2, 65, 4, 2)      // 65 x 65 planes, modes (., 14, 14)
+        HNO_ITEM(1, 33, 4, 1)      // 33 x 33 planes
+#undef HNO_ITEM
 #define HNO_SPEC(KM1, KM2, NT1, NT2, NFULL)                                                                               \
     if (!launched && spec_ok && b1.KmP == 4 * KM1 && b2.KmP == 4 * KM2 && (b1.J + 15) / 16 == NT1 &&                      \
         (b2.J + 15) / 16 == NT2 && pe / 256 == NFULL) {                                                                   \

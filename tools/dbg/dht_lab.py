@@ -105,3 +105,15 @@ if what == 'stream':
         t = timeit(lambda: L.hno_dht3_crop(P(x), None, 0, P(out), P(ws), BC, N, N, N, *modes, 1.0, S()))
         print(f'[{tag}] N={N} dht3_crop (plane + D), debug {dbg}: {t:.2f} us')
     L.hno_set_debug(0)
+if what == 'invabl':
+    L = pkg._lib.lib()
+    P, S = pkg._lib.ptr, pkg._lib.stream_ptr
+    BC = B * C
+    ws = torch.empty(L.hno_dht3_workspace_bytes(BC, N, N, N, *modes) // 4, device=dev)
+    yy = torch.empty_like(x)
+    for dbg, act, ad, name in ((0, 1, None, 'selu'), (12, 1, None, 'no epilogue, no MFMA'), (8, 1, None, 'no MFMA'), (0, 0, None, 'no activation'), (2, 1, None, 'selu, no stores'), (4, 1, None, 'no epilogue'),
+                               (0, 1, add, 'addend + selu'), (0, 0, add, 'addend, no activation'), (2, 1, add, 'addend + selu, no stores')):
+        L.hno_set_debug(dbg)
+        t = timeit(lambda: L.hno_pad_idht3(P(z), P(ad), act, P(yy), P(ws), BC, N, N, N, *modes, 1.0, S()))
+        print(f'[{tag}] N={N} pad_idht3 (D + plane) [{name}]: {t:.2f} us')
+    L.hno_set_debug(0)

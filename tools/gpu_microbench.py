@@ -128,6 +128,30 @@ if which in ('stamps_dma',):
         if row[0] == 0: break
         print(f'  item {it}:', ', '.join(f'{n}: {v - base}' for n, v in zip(names, row)))
 
+if which in ('stamps_item',):
+    import ctypes
+    z = torch.randn(B, C, 20, 28, 28, device=dev); x = torch.randn(B, C, N, N, N, device=dev)
+    BC, NN, mm = 48, (65, 65, 65), (10, 14, 14)
+    ws = torch.empty(L.hno_dht3_workspace_bytes(BC, *NN, *mm) // 4, device=dev)
+    yy = torch.empty_like(x)
+    P, S = pkg._lib.ptr, pkg._lib.stream_ptr
+    for addend in (None, x):
+        for _ in range(3): L.hno_pad_idht3(P(z), P(addend), 1, P(yy), P(ws), BC, *NN, *mm, 1.0, S())
+        buf = (ctypes.c_longlong * 64)()
+        L.hno_debug_stamps(buf, 64)
+        L.hno_set_debug(64)
+        L.hno_pad_idht3(P(z), P(addend), 1, P(yy), P(ws), BC, *NN, *mm, 1.0, S())
+        L.hno_set_debug(0)
+        L.hno_debug_stamps(buf, 64)
+        st = list(buf)
+        base = st[20]
+        print(f'addend={addend is not None}: cycles from kernel top: tables {st[21] - base}, end {st[23] - base}; wall: block 0 wave 0 {(st[61] - st[60]) * 10} ns, last block start +{(st[58] - st[60]) * 10} end +{(st[59] - st[60]) * 10} ns, middle block wave 11 start +{(st[56] - st[60]) * 10} end +{(st[57] - st[60]) * 10} ns')
+        names = ['top', 'E landed + folds', 'H done', 'W done + stored to LDS', 'col 0 / row 0 done', 'epilogue done']
+        for it in range(5):
+            row = st[24 + it * 6: 30 + it * 6]
+            if row[0] == 0: break
+            print(f'  item {it}:', ', '.join(f'{n}: {v - base}' for n, v in zip(names, row)))
+
 if which in ('stamps_inv',):
     import ctypes
     z = torch.randn(B, C, 20, 28, 28, device=dev); x = torch.randn(B, C, N, N, N, device=dev)
