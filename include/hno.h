@@ -114,6 +114,21 @@ int hno_specmix_shared_bwd(const float *g, const float *z0, const float *zs, con
  * block and step.  dW stays one (L, C, C) block (a view per layer on the Python side).
  * L <= 64.  Up to C = 32 the whole stack is ONE kernel each way (weights and the 32-mode tile stay
  * in registers between layers); wider stacks run layer by layer through hno_pwconv. */
+/* ------------------------------------------------------------ fused spectral middle of an HNO-XS block
+ * TransformCrop's axis-D step + the n_XS frequency-domain layers + PadInverse's axis-D step in one kernel, between the two plane
+ * transforms (nets/hnosegxs.py:378-410, 307-329, 454-494):
+ *     hno_dht3_planes(x, ws)  ->  hno_spec_mid_fwd(ws, W, zs)  ->  hno_idht3_planes(ws, addend, act, out)
+ * computes what hno_dht3_crop -> hno_specmix_layers_fwd -> hno_pad_idht3 compute.  The workspace (hno_dht3_workspace_bytes) is
+ * transformed in place.  zs: (L + 1, B, C, 2 m0, 2 m1, 2 m2) = cropped spectrum z0 followed by the L layer outputs (what
+ * the backward needs).  hno_spec_mid_supported says whether the fused kernels exist for a configuration (24 channels, N0 in
+ * {65, 33}, m0 = 10, m1, m2 <= 15); callers use the three-kernel path otherwise. */
+int hno_spec_mid_supported(int C, int N0, int m0, int m1, int m2, int L);
+int hno_dht3_planes(const float *x, void *workspace, int BC, int N0, int N1, int N2, int m0, int m1, int m2, void *stream);
+int hno_spec_mid_fwd(void *workspace, const float *const *W_layers, float *zs, int B, int C, int N0, int m0, int m1, int m2, int L,
+                     int residual, int act, float scale, void *stream);
+int hno_idht3_planes(const void *workspace, const float *addend, int act, float *out, int BC, int N0, int N1, int N2, int m0, int m1,
+                     int m2, float scale, void *stream);
+
 int hno_specmix_layers_fwd(const float *z0, const float *const *W_layers, float *zs, int B, int C, int M,
                            int L, int residual, int act, void *stream);
 int hno_specmix_layers_bwd(const float *g, const float *z0, const float *zs, const float *const *W_layers,

@@ -29,6 +29,10 @@ SIGNATURES = {
     'hno_specmix_shared_fwd': (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     'hno_specmix_shared_bwd': (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
     'hno_specmix_bwd_workspace_bytes': (c_size_t, [c_int] * 4),
+    'hno_spec_mid_supported': (c_int, [c_int] * 6),
+    'hno_dht3_planes': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    'hno_spec_mid_fwd': (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_float, c_void_p]),
+    'hno_idht3_planes': (c_int, [c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 7 + [c_float, c_void_p]),
     'hno_specmix_layers_fwd': (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     'hno_specmix_layers_bwd': (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
     'hno_pwconv_fwd': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_void_p]),

@@ -2337,63 +2337,58 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const f
         HNO_STAMP(a.stamps, 28 + it * 6);
         // ---- epilogue: out = act(scale * O + residual) in aligned 16-byte groups; group g of a chunk covers chunk elements
         //      4 g - sh .. 4 g - sh + 3 (element e at LDS float lo + sh + e and at global float (f & ~3) + sh + e)
-        auto chunk_out = [&](const int NG, const unsigned fch, const unsigned n, const float *limg) {
+        // A LOOP, not an unrolled sequence: every kernel starts with a cold instruction cache and a wave runs this code once or twice
+        // per launch, so straight-line code is paid for in instruction fetches (~0.4 us per KB, DESIGN lesson 1); unrolled, the
+        // epilogue of the two item kinds was 20 KB.
+        const int nchunk = (a.dbg & 4) ? 0 : ((NP == 2 && X == 0) ? 2 : 1);
+#pragma unroll 1
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const unsigned fch = ch ? fC : fA;
+            const unsigned n = NP == 1 ? (unsigned)(N1 * N2) : (X == 0 ? (ch ? 16u : 17u) : 32u) * N2;
+            const int ng = NP == 1 ? NG0 : (X == 0 ? NG0 : NGB);
+            const float *limg = obuf + (ch ? c1_lo : 0);
             const unsigned sh = fch & 3u;
-            float *gbase = out_al + (fch & ~3u);
-            const float *abase = HAS_ADD ? add_al + (fch & ~3u) : nullptr;
+            float *gbase = out_al + (fch & ~3u) + 4 * lane;
+            const float *abase = HAS_ADD ? add_al + (fch & ~3u) + 4 * lane : nullptr;
             // residual: aligned 16-byte loads of the same groups, two groups ahead of their use (a group that straddles a chunk end
             // also holds neighbouring rows of the same tensor; groups beyond the chunk are not touched)
-            constexpr int AHEAD = 2;
-            f32x4 rq[AHEAD + 1];
             auto ld_add = [&](int j) -> f32x4 {
-                const unsigned g = 64u * j + lane;
-                return (4 * g < sh + n) ? *reinterpret_cast<const f32x4 *>(abase + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+                return (j < ng && 4 * (64u * j + lane) < sh + n) ? *reinterpret_cast<const f32x4 *>(abase + 256 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
             };
+            f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
             if (HAS_ADD) {
-#pragma unroll
-                for (int j = 0; j < AHEAD && j < NG; ++j) rq[j] = ld_add(j);
+                r0 = ld_add(0);
+                r1 = ld_add(1);
             }
-#pragma unroll
-            for (int j = 0; j < NG; ++j) {
-                const unsigned g = 64u * j + lane;
-                const int e0 = (int)(4 * g) - (int)sh;
-                if (HAS_ADD && j + AHEAD < NG) rq[(j + AHEAD) % (AHEAD + 1)] = ld_add(j + AHEAD);
-                f32x4 o = *reinterpret_cast<const f32x4 *>(limg + 4 * g);
-                f32x4 v;
-                {   // scale, residual and activation on the packed fp32 pipe, two elements per instruction
-                    const f32x2 sc = {a.scale, a.scale};
-                    f32x2 x0 = f32x2{o[0], o[1]} * sc, x1 = f32x2{o[2], o[3]} * sc;
-                    if (HAS_ADD) {
-                        const f32x4 r = rq[j % (AHEAD + 1)];
-                        x0 = __builtin_elementwise_fma(f32x2{o[0], o[1]}, sc, f32x2{r[0], r[1]});
-                        x1 = __builtin_elementwise_fma(f32x2{o[2], o[3]}, sc, f32x2{r[2], r[3]});
-                    }
-                    if (!lin) {   // wave-uniform
-                        x0 = selu_like_pk(x0, ap, aq);
-                        x1 = selu_like_pk(x1, ap, aq);
-                    }
-                    v = f32x4{x0[0], x0[1], x1[0], x1[1]};
+#pragma unroll 1
+            for (int j = 0; j < ng; ++j) {
+                const int e0 = (int)(4 * (64u * j + lane)) - (int)sh;
+                const f32x4 r = r0;
+                if (HAS_ADD) {
+                    r0 = r1;
+                    r1 = ld_add(j + 2);
                 }
+                const f32x4 o = *reinterpret_cast<const f32x4 *>(limg + 256 * j + 4 * lane);
+                // scale, residual and activation on the packed fp32 pipe, two elements per instruction
+                const f32x2 sc = {a.scale, a.scale};
+                f32x2 x0 = __builtin_elementwise_fma(f32x2{o[0], o[1]}, sc, f32x2{r[0], r[1]});
+                f32x2 x1 = __builtin_elementwise_fma(f32x2{o[2], o[3]}, sc, f32x2{r[2], r[3]});
+                if (!lin) {   // wave-uniform
+                    x0 = selu_like_pk(x0, ap, aq);
+                    x1 = selu_like_pk(x1, ap, aq);
+                }
+                const f32x4 v = {x0[0], x0[1], x1[0], x1[1]};
                 if (a.dbg & 2) {   // timing aid: no stores
                     asm volatile("" ::"v"(v));
-                } else if (j > 0 && j < NG - 1) {
-                    *reinterpret_cast<f32x4 *>(gbase + 4 * g) = v;          // wholly inside the chunk
                 } else if (e0 >= 0 && e0 + 3 < (int)n) {
-                    *reinterpret_cast<f32x4 *>(gbase + 4 * g) = v;
+                    *reinterpret_cast<f32x4 *>(gbase + 256 * j) = v;          // wholly inside the chunk
                 } else {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        if (e0 + c >= 0 && e0 + c < (int)n) gbase[4 * g + c] = v[c];
+                        if (e0 + c >= 0 && e0 + c < (int)n) gbase[256 * j + c] = v[c];
                 }
             }
-        };
-        if (a.dbg & 4) {   // timing aid: no epilogue
-        } else if (NP == 1) chunk_out(NG0, fA, (unsigned)(N1 * N2), obuf);
-        else if (X == 0) {
-            chunk_out(NG0, fA, 17u * N2, obuf);
-            chunk_out(NG1, fC, 16u * N2, obuf + c1_lo);
-        } else
-            chunk_out(NGB, fA, 32u * N2, obuf);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         HNO_STAMP(a.stamps, 29 + it * 6);
@@ -2457,10 +2452,12 @@ extern "C" size_t hno_dht3_workspace_bytes(int BC, int N0, int N1, int N2, int m
     return (size_t)BC * N0 * 2 * (2 * m1 + 1) * KP2 * sizeof(float);
 }
 
+// planes_only: stop after the plane kernel (the workspace then holds the axis-W / axis-H transform of every plane: the operand of
+// dht_fwd_d_kernel or of the fused spectral middle, hno_specmid.hip)
 static int dht_forward_launch(const float *x, const float *x_act_out, int act_grad, float *out, void *workspace,
                               int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream,
-                              int mode, int C, int full = 0) {
-    HNO_REQUIRE(x && out && workspace, "hno_dht3_crop: null pointer");
+                              int mode, int C, int full = 0, bool planes_only = false) {
+    HNO_REQUIRE(x && (out || planes_only) && workspace, "hno_dht3_crop: null pointer");
     int rc = check_sizes(BC, N0, N1, N2, m0, m1, m2, full, mode);
     if (rc) return rc;
     const DhtPlan *plan;
@@ -2576,6 +2573,10 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
         else
             hipLaunchKernelGGL(dht_fwd_plane_kernel<0>, dim3(grid), dim3(256), lds, s, x, x_act_out, (float *)workspace, a);
     }
+    if (planes_only) {
+        HNO_CHECK_LAUNCH();
+        return HNO_OK;
+    }
     const Axis &a0 = plan->ax[0];
     const size_t ldsd = sizeof(float) * a0.KT * (a0.KcP + a0.KsP) * 16;
     {
@@ -2590,10 +2591,11 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
     return HNO_OK;
 }
 
+// planes_only: the workspace already holds the axis-D step's output (written by the fused spectral middle): plane kernel only
 static int dht_inverse_launch(const float *z, const float *addend, int act, float *out, void *workspace,
                               int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream,
-                              int mode, int C, int full = 0) {
-    HNO_REQUIRE(z && out && workspace, "hno_pad_idht3: null pointer");
+                              int mode, int C, int full = 0, bool planes_only = false) {
+    HNO_REQUIRE((z || planes_only) && out && workspace, "hno_pad_idht3: null pointer");
     int rc = check_sizes(BC, N0, N1, N2, m0, m1, m2, full, mode);
     if (rc) return rc;
     const DhtPlan *plan;
@@ -2624,7 +2626,7 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
     }
     const Axis &a0 = plan->ax[0];
     const size_t ldsd = sizeof(float) * 2 * a0.NT * a0.KmP * 16;
-    {
+    if (!planes_only) {
         ProfScope _ps(KID_DHT_INV_D, s, 4.0 * BC * 8.0 * m0 * m1 * m2);
         const dim3 gd(plan->K1S * plan->ax[2].KT, BC);
         if (a0.NT <= 3 && !(a.dbg & 32))
@@ -2719,6 +2721,16 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
 extern "C" int hno_dht3_crop(const float *x, const float *x_act_out, int act_grad, float *out, void *workspace,
                              int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream) {
     return dht_forward_launch(x, x_act_out, act_grad, out, workspace, BC, N0, N1, N2, m0, m1, m2, scale, stream, 0, 1);
+}
+
+// The two plane transforms alone, around the fused spectral middle (hno_spec_mid_fwd / _bwd, hno_specmid.hip)
+extern "C" int hno_dht3_planes(const float *x, void *workspace, int BC, int N0, int N1, int N2, int m0, int m1, int m2, void *stream) {
+    return dht_forward_launch(x, nullptr, HNO_ACT_NONE, nullptr, workspace, BC, N0, N1, N2, m0, m1, m2, 1.f, stream, 0, 1, 0, true);
+}
+
+extern "C" int hno_idht3_planes(const void *workspace, const float *addend, int act, float *out, int BC, int N0, int N1, int N2, int m0,
+                                int m1, int m2, float scale, void *stream) {
+    return dht_inverse_launch(nullptr, addend, act, out, (void *)workspace, BC, N0, N1, N2, m0, m1, m2, scale, stream, 0, 1, 0, true);
 }
 
 extern "C" int hno_dht3_full(const float *x, float *out, void *workspace, int BC, int N0, int N1, int N2, float scale,

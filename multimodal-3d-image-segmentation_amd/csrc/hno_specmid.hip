@@ -1,0 +1,398 @@
+// The spectral middle of an HNO-XS block in ONE kernel per direction:
+//
+//   forward :  axis-D transform + Re -/+ Im + crop  ->  L x ( z <- act((W + I) z) )  ->  pad + axis-D inverse transform
+//
+// i.e. what dht_fwd_d_kernel, specmix_fwd_loop_kernel and dht_inv_d_kernel (hno_dht.hip, hno_specmix.hip) do in three launches
+// between the two plane transforms.  Reference: TransformCrop.forward (nets/hnosegxs.py:378-410, axis D of dhtn, nets/dht.py:16-36),
+// NeuralOperatorBlock.forward x n_XS (nets/hnosegxs.py:307-329, HartleyOperator._call3d_notransform, nets/hartley_operator.py:287-292),
+// PadInverse.forward (nets/hnosegxs.py:454-494).
+//
+// Why: each of the three kernels is one memory round trip plus a launch (10 + 12 + 10 us for ~1 us of arithmetic each, 16 chains per
+// HNOSeg-XS step = 17 % of the step, profiles/r02_d_*).  The chain is closed per COLUMN of the intermediate: column (k1, k2 >= 0) of
+// the plane-transform output, all N0 planes and all channels of one sample, determines the 40 kept modes (+-k0, k1, k2) and
+// (+-k0, -k1, -k2), the channel mix is pointwise over modes, and the inverse D step of the same column reads exactly those 40 modes.
+// A workgroup owns 4 adjacent k2 columns of one (sample, k1): 2 x 29 x 4 = 232 workgroups at the benchmark size.
+//   * the D steps run on the VALU: 65 -> 11 cos / 10 sin sums per (channel, part, column) is 683 FMAs, far too little per column for
+//     a 16-column MFMA tile (round 2's fused attempt kept the MFMA tiles and ended with 58 workgroups, DESIGN lesson 29); the twiddles
+//     are wave-uniform, i.e. scalar operands;
+//   * the channel mix is the register-chained v_mfma_f32_32x32x2_f32 stack of hno_specmix.hip on the 160 modes of the tile;
+//   * the workgroup reads its columns of the plane-transform output and overwrites the same addresses with the inverse D step's
+//     output: the workspace is transformed in place, no second buffer.
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "hno_common.h"
+
+namespace hno {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct MidArgs {
+    float *ws;                 // [b * C + c][n0][part 2][k1s (2 m1 + 1)][16]: in = forward plane transform, out = inverse D step
+    const float *W[4];         // (C, C) per layer
+    float *zs;                 // (L + 1) stacked (B, C, 2 m0, 2 m1, 2 m2): z0 = cropped spectrum, z_l = output of layer l
+    const float *tw;           // twiddle A operands of the two D steps in lane order (mid_twiddles)
+    int B, L, residual, act;
+    int m1, m2;
+    float scale;
+    long long *stamps;         // phase stamps of workgroup 0, wave 0 (debug flag 1024)
+    int dbg;                   // timing aids (results wrong): 1 = no forward D arithmetic, 2 = no layers, 4 = no inverse D step, 8 = no loads
+};
+
+__device__ __forceinline__ int mid_chan(int ks, int h) { return (ks & 3) + 8 * (ks >> 2) + 4 * h; }
+
+// N0: planes (odd), M0: kept modes along D (frequencies k0 = 0..M0 are computed; +M0 itself is not kept, -M0 is)
+//
+// Both D steps are small GEMMs on v_mfma_f32_16x16x4_f32 whose 16 COLUMNS are (column j of the tile, re / im part, 2 channels): the
+// N dimension of the MFMA is filled by batching over parts and channels, not by widening the k2 tile, so 4-column tiles cost no
+// matrix-core work.  Twiddles are the A operands (registers, loaded once in lane order).
+//   forward : rows k0 = 0..15, K = n (folded: f[n] = v[n] + v[N0 - n] against cos, d[n] = v[n] - v[N0 - n] against sin), 9 k-steps
+//   inverse : rows n = 1 + 16 mt + i, K = k0 (3 k-steps); n = 0 is the plain sum of the cosine coefficients
+template <int N0, int M0>
+__global__ __launch_bounds__(512, 2) void spec_mid_fwd_kernel(MidArgs a) {
+    constexpr int C = 24, NK = 12, J = N0 / 2, K0 = M0 + 1;
+    constexpr int KC = (J + 1 + 3) / 4;               // k-steps of the forward D step (n = 0 .. 4 KC - 1)
+    constexpr int KI = (K0 + 3) / 4;                   // k-steps of the inverse D step (k0 = 0 .. 4 KI - 1)
+    constexpr int NMT = J / 16;                        // 16-row output tiles of the inverse D step (n = 1 .. 16 NMT)
+    constexpr int NMODE = 2 * 2 * M0 * 4;              // modes of the tile: (sign of (k1, k2), o0, column)
+    constexpr int NT = (NMODE + 31) / 32;             // 32-mode MFMA tiles
+    constexpr int NCT = C / 2;                         // column tiles of the D steps: 2 channels x 2 parts x 4 columns
+    static_assert(J % 16 == 0 && K0 <= 16, "tile shapes");
+    __shared__ float PQ[C * 2 * 2 * K0 * 4];          // [c][part][P | Q][k0][column]
+    __shared__ float ZL[C * NT * 32];                 // [c][mode]: output of the last layer
+    if (a.dbg & 16) return;
+    HNO_STAMP(a.stamps, 0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, l15 = lane & 15;
+    // workgroup -> (sample, k1 row, k2 tile).  The 8 workgroups that share the 128-byte lines of a k1 row pair get ids that are
+    // equal mod 8, i.e. the same XCD under round-robin dispatch: each line then crosses the fabric once instead of eight times
+    // (speed only; nothing depends on the placement)
+    const int m1 = a.m1, m2 = a.m2, K1S = 2 * m1 + 1, CP = K1S * 16;
+    const int pairs = (K1S + 1) / 2, G8 = (a.B * pairs + 7) & ~7;
+    const int w8 = blockIdx.x / G8, gidx = blockIdx.x - w8 * G8;
+    const int b = gidx / pairs, k1s = 2 * (gidx - b * pairs) + (w8 >> 2), kt2 = w8 & 3;
+    if (b >= a.B || k1s >= K1S) return;
+    const int k1 = k1s - m1;
+    const size_t pstride = (size_t)2 * CP;            // floats per n0 plane
+    // column of the D-step tiles held by this lane: j = column of the k2 tile, re / im part, channel within the pair
+    const int j = l15 & 3, part = (l15 >> 2) & 1, cloc = l15 >> 3;
+    // twiddle A operands in lane order: forward cos / sin [ks], inverse cos / sin [mt][ks]
+    float tcF[KC], tsF[KC], tcI[NMT][KI], tsI[NMT][KI];
+    {
+        const float *tb = a.tw + lane;
+#pragma unroll
+        for (int ks = 0; ks < KC; ++ks) {
+            tcF[ks] = tb[ks * 64];
+            tsF[ks] = tb[(KC + ks) * 64];
+        }
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < KI; ++ks) {
+                tcI[mt][ks] = tb[(2 * KC + (mt * 2 + 0) * KI + ks) * 64];
+                tsI[mt][ks] = tb[(2 * KC + (mt * 2 + 1) * KI + ks) * 64];
+            }
+    }
+    // ---------------- layer weights as the A operand of the 32x32x2 MFMA: lane (row cl, k-slot half h) holds W'[cl][chan(ks, h)].
+    // Rows >= C of the 32-row tile are zero: they LOAD row 0 and select it away -- a load under a lane condition compiles to a branch
+    // with its own vmcnt(0), i.e. twelve dependent L2 round trips per layer (3 us per layer, seen in the ISA).  The first layer's
+    // weights are requested here, ahead of the forward D step.
+    const int h = lane >> 5, cl = lane & 31;
+    const bool wrow = cl < C;
+    const unsigned wl = (unsigned)(wrow ? cl : 0) * C + 4 * h;
+    const int dsel = cl - 4 * h;
+    const float res = a.residual ? 1.f : 0.f;
+    auto load_w_raw = [&](const float *Wp, float (&w)[NK]) {
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) w[ks] = Wp[wl + (ks & 3) + 8 * (ks >> 2)];
+    };
+    auto fin_w = [&](const float (&raw)[NK], float (&w)[NK]) {
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const int row = (ks & 3) + 8 * (ks >> 2);
+            w[ks] = wrow ? raw[ks] + ((dsel == row) ? res : 0.f) : 0.f;
+        }
+    };
+    float wraw[NK];
+    if (wave < NT) load_w_raw(a.W[0], wraw);
+    // ---------------- phase 1: forward D step.  A wave owns the column tiles wave and wave + 8; the loads of BOTH are issued before the
+    //                  first product (one memory round trip per wave instead of two: the columns come from another XCD's writes)
+    {
+        constexpr int TPW = (NCT + 7) / 8;
+        float va[TPW][KC], vb[TPW][KC];
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const int t = wave + 8 * u;
+            const int c = 2 * (t < NCT ? t : 0) + cloc;
+            const float *src = a.ws + ((size_t)(b * C + c) * N0) * pstride + (size_t)part * CP + k1s * 16 + kt2 * 4 + j;
+#pragma unroll
+            for (int ks = 0; ks < KC; ++ks) {
+                const int n = 4 * ks + q;
+                const bool in = n <= J, mir = n >= 1 && n <= J;
+                va[u][ks] = (a.dbg & 8) ? 1.f : src[(size_t)(in ? n : 0) * pstride];
+                vb[u][ks] = (a.dbg & 8) ? 1.f : src[(size_t)(mir ? N0 - n : 0) * pstride];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const int t = wave + 8 * u;
+            if (t >= NCT) break;
+            const int c = 2 * t + cloc;
+            f32x4 P = {0.f, 0.f, 0.f, 0.f}, Q = P;
+            if (!(a.dbg & 1)) {
+#pragma unroll
+                for (int ks = 0; ks < KC; ++ks) {
+                    const int n = 4 * ks + q;
+                    const float fa = n <= J ? va[u][ks] : 0.f, fb = (n >= 1 && n <= J) ? vb[u][ks] : 0.f;
+                    P = mfma16(tcF[ks], fa + fb, P);
+                    Q = mfma16(tsF[ks], fa - fb, Q);
+                }
+            }
+            // accumulator row 4 q + r = k0
+            float *dst = PQ + (((c * 2 + part) * 2) * K0) * 4 + j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k0 = 4 * q + r;
+                if (k0 < K0) {
+                    dst[k0 * 4] = P[r];
+                    dst[(K0 + k0) * 4] = Q[r];
+                }
+            }
+        }
+    }
+    HNO_STAMP(a.stamps, 1);
+    __syncthreads();
+    HNO_STAMP(a.stamps, 2);
+    if (a.dbg & 32) return;
+    // ---------------- phase 2 + 3: Hartley values of the tile's modes, then the layer stack (waves 0 .. NT - 1, one 32-mode tile each)
+    const int S0 = 2 * M0, S1 = 2 * m1, S2 = 2 * m2;
+    const size_t sample = (size_t)C * S0 * S1 * S2, layer = sample * a.B;
+    if (wave < NT) {
+        const int mi = wave * 32 + cl;                // mode index: column fastest, then o0, then the sign of (k1, k2)
+        const int jm = mi & 3, rest = mi >> 2, s12 = rest / S0, o0 = rest - s12 * S0;
+        const int k2 = kt2 * 4 + jm;
+        const int kk = o0 < M0 ? o0 : o0 - S0;        // signed k0 of this position
+        const int kap = s12 ? -kk : kk;               // the frequency whose X gives the value: H[k] = Re X[k] - Im X[k], H[-k] = Re X[k] + Im X[k]
+        const int ka = kap < 0 ? -kap : kap;
+        // kept positions along k1 / k2 ([low | high] block): + : (k1, k2), - : (-k1, -k2)
+        const int kk1 = s12 ? -k1 : k1;
+        const int o1 = kk1 >= 0 ? (kk1 < m1 ? kk1 : -1) : (kk1 >= -m1 ? kk1 + S1 : -1);
+        const int o2 = s12 ? (k2 >= 1 && k2 <= m2 ? S2 - k2 : -1) : (k2 < m2 ? k2 : -1);
+        const bool valid = mi < NMODE && o1 >= 0 && o2 >= 0;
+        const size_t zoff = valid ? ((size_t)o0 * S1 + o1) * S2 + o2 : 0;
+        float z[NK];
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const int c = mid_chan(ks, h);
+            const float *pq = PQ + ((c * 2) * 2 * K0 + ka) * 4 + jm;
+            const float PR = pq[0], QR = pq[K0 * 4], PI = pq[2 * K0 * 4], QI = pq[3 * K0 * 4];
+            const float xr = kap >= 0 ? PR + QI : PR - QI, xi = kap >= 0 ? PI - QR : PI + QR;
+            const float hv = a.scale * (s12 ? xr + xi : xr - xi);
+            z[ks] = valid ? hv : 0.f;
+        }
+        float *ob = a.zs + (size_t)b * sample;
+        if (valid) {
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) ob[(size_t)mid_chan(ks, h) * (S0 * S1 * S2) + zoff] = z[ks];
+        }
+        const float ap = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f;
+        const float aq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
+        const bool lin = a.act == HNO_ACT_NONE;
+        float w[NK];
+        fin_w(wraw, w);
+        HNO_STAMP(a.stamps, 3);
+#pragma unroll 1
+        for (int l = 0; l < ((a.dbg & 2) ? 0 : a.L); ++l) {
+            // the next layer's weights are requested before this layer's products and finished (residual identity, zero rows) after
+            // its activation: the loads are in flight behind the MFMAs instead of in front of them
+            HNO_STAMP(a.stamps, 4 + 4 * l);
+            float nraw[NK];
+            if (l + 1 < a.L) load_w_raw(l == 0 ? a.W[1] : (l == 1 ? a.W[2] : a.W[3]), nraw);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ks], z[ks], acc, 0, 0, 0);
+            if (a.stamps) asm volatile("s_nop 0" ::"v"(acc[0]));
+            HNO_STAMP(a.stamps, 5 + 4 * l);
+            if (a.dbg & 512) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = z[r % NK] + w[r % NK];
+            }
+            ob += layer;
+            if (lin) {
+#pragma unroll
+                for (int ks = 0; ks < NK; ++ks) z[ks] = acc[ks];
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < NK; ks += 2) {
+                    const f32x2 y = selu_like_pk(f32x2{acc[ks], acc[ks + 1]}, ap, aq);
+                    z[ks] = y[0];
+                    z[ks + 1] = y[1];
+                }
+            }
+            if (a.stamps) asm volatile("s_nop 0" ::"v"(z[0]), "v"(z[11]));
+            HNO_STAMP(a.stamps, 6 + 4 * l);
+            if (valid && !(a.dbg & 256)) {
+#pragma unroll
+                for (int ks = 0; ks < NK; ++ks) ob[(size_t)mid_chan(ks, h) * (S0 * S1 * S2) + zoff] = z[ks];
+            }
+            HNO_STAMP(a.stamps, 7 + 4 * l);
+            __builtin_amdgcn_sched_barrier(0);
+            if (l + 1 < a.L) fin_w(nraw, w);
+        }
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) ZL[mid_chan(ks, h) * (NT * 32) + mi] = valid ? z[ks] : 0.f;
+    }
+    HNO_STAMP(a.stamps, 20);
+    __syncthreads();
+    HNO_STAMP(a.stamps, 21);
+    if (a.dbg & 64) return;
+    // ---------------- phase 4: pad + inverse D step
+    for (int t = wave; t < NCT; t += 8) {
+        if (a.dbg & 4) break;
+        const int c = 2 * t + cloc;
+        // z(+-, kappa) of this channel and column; positions outside the kept block are zero
+        const float *zc = ZL + c * (NT * 32) + j;
+        auto zz = [&](int s12, int kap) -> float {
+            const bool ok = kap >= -M0 && kap < M0;
+            const int o0 = kap >= 0 ? kap : kap + S0;
+            const float v = zc[(s12 * S0 + (ok ? o0 : 0)) * 4];
+            return ok ? v : 0.f;
+        };
+        // G'(+k0) = (va + vb) + i (vb - va), G'(-k0) = (vc + vd) + i (vd - vc);  gs = G'(+) + G'(-), gd = G'(+) - G'(-)
+        float gs[KI], gd[KI];
+#pragma unroll
+        for (int ks = 0; ks < KI; ++ks) {
+            const int k = 4 * ks + q;
+            const bool in = k <= M0;
+            const float va = zz(0, k), vb = zz(1, -k), vc = k ? zz(0, -k) : 0.f, vd = k ? zz(1, k) : 0.f;
+            const float pr = va + vb, pi = vb - va, mr = vc + vd, mi_ = vd - vc;
+            // re part: E = U_re - V_im -> gs = Re sums, gd = Im differences;  im part: E = U_im + V_re
+            gs[ks] = in ? (part ? pi + mi_ : pr + mr) : 0.f;
+            gd[ks] = in ? (part ? pr - mr : pi - mi_) : 0.f;
+        }
+        float *dst = a.ws + ((size_t)(b * C + c) * N0) * pstride + (size_t)part * CP + k1s * 16 + kt2 * 4 + j;
+        {   // n = 0: cos = 1, sin = 0 -> the plain sum of the cosine coefficients over k0 = over (ks, q)
+            float u0 = gs[0];
+#pragma unroll
+            for (int ks = 1; ks < KI; ++ks) u0 += gs[ks];
+            u0 += __shfl_xor(u0, 16);
+            u0 += __shfl_xor(u0, 32);
+            if (q == 0) dst[0] = u0;
+        }
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) {
+            f32x4 U = {0.f, 0.f, 0.f, 0.f}, V = U;
+#pragma unroll
+            for (int ks = 0; ks < KI; ++ks) {
+                U = mfma16(tcI[mt][ks], gs[ks], U);
+                V = mfma16(tsI[mt][ks], gd[ks], V);
+            }
+            // accumulator row 4 q + r <-> n = 1 + 16 mt + 4 q + r;  re part: E[n] = U - V, E[N0 - n] = U + V;  im part: the opposite signs
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = 1 + 16 * mt + 4 * q + r;
+                const float en = part ? U[r] + V[r] : U[r] - V[r], em = part ? U[r] - V[r] : U[r] + V[r];
+                dst[(size_t)n * pstride] = en;
+                dst[(size_t)(N0 - n) * pstride] = em;
+            }
+        }
+    }
+    HNO_STAMP(a.stamps, 22);
+}
+
+// ---- twiddle tables, cached per (device, N0, M0)
+static std::map<std::tuple<int, int, int>, float *> g_mid_tw;
+static std::mutex g_mid_mutex;
+
+static int mid_twiddles(int N0, int M0, const float **out) {
+    int dev = 0;
+    HNO_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_mid_mutex);
+    auto key = std::make_tuple(dev, N0, M0);
+    auto it = g_mid_tw.find(key);
+    if (it != g_mid_tw.end()) {
+        *out = it->second;
+        return HNO_OK;
+    }
+    // A operands of v_mfma_f32_16x16x4_f32 in lane order (lane = 16 q + i holds A[row i][k = q] of its k-step):
+    //   forward D step, k-step ks: row i = k0, k = n = 4 ks + q:  cos | sin (2 pi k0 n / N0), zero for k0 > M0 or n > J
+    //   inverse D step, tile mt, k-step ks: row i <-> n = 1 + 16 mt + i, k = k0 = 4 ks + q, zero for n > J or k0 > M0
+    const int J = N0 / 2, K0 = M0 + 1, KC = (J + 1 + 3) / 4, KI = (K0 + 3) / 4, NMT = J / 16;
+    std::vector<float> h((size_t)(2 * KC + NMT * 2 * KI) * 64, 0.f);
+    const double th = 2.0 * M_PI / N0;
+    for (int ks = 0; ks < KC; ++ks)
+        for (int ln = 0; ln < 64; ++ln) {
+            const int k0 = ln & 15, n = 4 * ks + (ln >> 4);
+            if (k0 > M0 || n > J) continue;
+            const double ang = th * (double)((long long)k0 * n % N0);
+            h[(size_t)ks * 64 + ln] = (float)cos(ang);
+            h[(size_t)(KC + ks) * 64 + ln] = (float)sin(ang);
+        }
+    for (int mt = 0; mt < NMT; ++mt)
+        for (int ks = 0; ks < KI; ++ks)
+            for (int ln = 0; ln < 64; ++ln) {
+                const int n = 1 + 16 * mt + (ln & 15), k0 = 4 * ks + (ln >> 4);
+                if (k0 > M0 || n > J) continue;
+                const double ang = th * (double)((long long)k0 * n % N0);
+                h[(size_t)(2 * KC + (mt * 2 + 0) * KI + ks) * 64 + ln] = (float)cos(ang);
+                h[(size_t)(2 * KC + (mt * 2 + 1) * KI + ks) * 64 + ln] = (float)sin(ang);
+            }
+    float *d = nullptr;
+    // allocated once per size, outside graph capture (first call = warm-up)
+    HNO_CHECK_HIP(hipMalloc((void **)&d, h.size() * sizeof(float)));
+    HNO_CHECK_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    g_mid_tw[key] = d;
+    *out = d;
+    return HNO_OK;
+}
+
+}  // namespace hno
+
+using namespace hno;
+
+// 1 if the fused kernels exist for this configuration (Hartley layout, 24 channels, odd N0 in {65, 33} with m0 = 10, one k tile per
+// plane axis); the caller falls back to hno_dht3_crop / hno_specmix_layers_* / hno_pad_idht3 otherwise.
+extern "C" int hno_spec_mid_supported(int C, int N0, int m0, int m1, int m2, int L) {
+    return C == 24 && (N0 == 65 || N0 == 33) && m0 == 10 && 2 * m0 <= N0 && m1 >= 1 && m1 <= 15 && m2 >= 1 && m2 <= 15 && L >= 1 && L <= 4;
+}
+
+// workspace: the forward plane transform of x (hno_dht3_planes) on entry, the operand of the inverse plane transform
+// (hno_idht3_planes) on return.  zs: (L + 1, B, C, 2 m0, 2 m1, 2 m2), z0 first.
+extern "C" int hno_spec_mid_fwd(void *workspace, const float *const *W_layers, float *zs, int B, int C, int N0, int m0, int m1, int m2,
+                                int L, int residual, int act, float scale, void *stream) {
+    HNO_REQUIRE(workspace && W_layers && zs && B > 0, "hno_spec_mid_fwd: bad argument");
+    if (!hno_spec_mid_supported(C, N0, m0, m1, m2, L)) return fail(HNO_ELIMIT, "hno_spec_mid_fwd: unsupported configuration");
+    MidArgs a = {};
+    a.ws = (float *)workspace;
+    for (int l = 0; l < L; ++l) {
+        HNO_REQUIRE(W_layers[l], "hno_spec_mid_fwd: W_layers[%d] is NULL", l);
+        a.W[l] = W_layers[l];
+    }
+    a.zs = zs;
+    a.B = B;
+    a.L = L;
+    a.residual = residual;
+    a.act = act;
+    a.m1 = m1;
+    a.m2 = m2;
+    a.scale = scale;
+    a.dbg = debug_flags();
+    a.stamps = (a.dbg & 1024) ? debug_stamp_buffer() : nullptr;
+    int rc = mid_twiddles(N0, m0, &a.tw);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int pairs = (2 * m1 + 1 + 1) / 2, G8 = (B * pairs + 7) & ~7;
+    const dim3 grid(8 * G8);
+    {
+        ProfScope _ps(KID_SPECMIX_FWD, s, 4.0 * B * C * (2.0 * N0 * 2 * (2 * m1 + 1) * 16 + (L + 1) * 8.0 * m0 * m1 * m2));
+        if (N0 == 65) hipLaunchKernelGGL((spec_mid_fwd_kernel<65, 10>), grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((spec_mid_fwd_kernel<33, 10>), grid, dim3(512), 0, s, a);
+    }
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}

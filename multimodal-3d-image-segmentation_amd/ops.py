@@ -5,6 +5,8 @@ containers (allocation, lifetime, autograd graph).  Nothing in this file compute
 or through ATen math kernels: if libhno.so is missing or the tensors are not on a GPU the
 call raises.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -424,6 +426,32 @@ def specmix_fwd_raw(z0, W, residual, act):
     check(_lib.lib().hno_specmix_layers_fwd(ptr(z0), _layer_ptrs(Ws), ptr(zs), B, C, M, Lyr, int(residual), act, stream_ptr()),
           'hno_specmix_layers_fwd')
     return zs
+
+
+def spectral_chain_supported(x, modes, n_layers):
+    """fused spectral middle (hno_spec_mid_*): HNOSeg-XS shapes on 65^3 / 33^3 grids; HNO_FUSED_MID=0 switches it off (A/B)."""
+    if os.environ.get('HNO_FUSED_MID', '1') == '0' or x.dim() != 5:
+        return False
+    m0, m1, m2 = modes
+    return bool(_lib.lib().hno_spec_mid_supported(int(x.shape[1]), int(x.shape[2]), int(m0), int(m1), int(m2), int(n_layers)))
+
+
+def spectral_chain_fwd_raw(x, W, modes, act, scale_fwd, inv_act):
+    """TransformCrop -> n_XS frequency-domain layers -> PadInverse (+ activation) with the fused middle:
+    -> (z0, zs, u): what dht3_crop_raw / specmix_fwd_raw / pad_idht3_raw return."""
+    _need_gpu(x)
+    Ws = _mix_layers(W)
+    B, C, N0, N1, N2 = x.shape
+    m0, m1, m2 = modes
+    L, Lyr = _lib.lib(), len(Ws)
+    ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, N0, N1, N2, m0, m1, m2) // 4, device=x.device, dtype=torch.float32)
+    zall = torch.empty((Lyr + 1, B, C, 2 * m0, 2 * m1, 2 * m2), device=x.device, dtype=torch.float32)
+    u = torch.empty_like(x)
+    check(L.hno_dht3_planes(ptr(x), ptr(ws), B * C, N0, N1, N2, m0, m1, m2, stream_ptr()), 'hno_dht3_planes')
+    check(L.hno_spec_mid_fwd(ptr(ws), _layer_ptrs(Ws), ptr(zall), B, C, N0, m0, m1, m2, Lyr, 1, act, float(scale_fwd), stream_ptr()),
+          'hno_spec_mid_fwd')
+    check(L.hno_idht3_planes(ptr(ws), None, inv_act, ptr(u), B * C, N0, N1, N2, m0, m1, m2, 1.0, stream_ptr()), 'hno_idht3_planes')
+    return zall[0], zall[1:], u
 
 
 def specmix_bwd_raw(g, z0, zs, W, residual, act, defer=False):
@@ -1217,9 +1245,12 @@ class XSBlockFn(_HnoFunction):
             modes = (0,) + tuple(modes)
         modes = clamp_modes(modes, spatial)
         n3 = float(np.prod(spatial))
-        z0 = dht3_crop_raw(xm, modes, 1.0 / n3)
-        zs = specmix_fwd_raw(z0, mix_ws, 1, act)
-        u = pad_idht3_raw(zs[-1], spatial, 1.0, None, act)
+        if spectral_chain_supported(xm, modes, len(mix_ws)):
+            z0, zs, u = spectral_chain_fwd_raw(xm, mix_ws, modes, act, 1.0 / n3, act)
+        else:
+            z0 = dht3_crop_raw(xm, modes, 1.0 / n3)
+            zs = specmix_fwd_raw(z0, mix_ws, 1, act)
+            u = pad_idht3_raw(zs[-1], spatial, 1.0, None, act)
         out = pwconv_fwd_raw(u, xm, cat_w, cat_b, act, bf)
         ctx.save_for_backward(x, skip, map_w, xm if has_map else None, z0, zs, u, cat_w, out, map_b, cat_b, *mix_ws)
         ctx.cfg = (has_map, modes, act, spatial, n3, map_b is not None, cat_b is not None, bool(passthrough))
