@@ -181,6 +181,25 @@ def secondary_configs(pkg, dev):
     return out
 
 
+def dp_path_secondary(headline_ms):
+    """The full-size cfg2 step through the N > 1 code path on ONE rank (a fresh child process: its own RCCL group of one rank,
+    `--dp-path`), next to the headline: ms per step, the ratio, and the host time the step's launches take."""
+    import subprocess
+    out = {}
+    try:
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), '--dp-path', '--steps', '30', '--warmup', '5', '--no-secondary',
+                              '--no-cpu-baseline', '--no-kernel-profile'], capture_output=True, text=True, timeout=600)
+        line = [ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1]
+        d = json.loads(line)
+        out['dp_path_1rank_ms_per_step'] = d['ms_per_step']
+        out['dp_path_1rank_over_headline'] = round(d['ms_per_step'] / headline_ms, 4)
+        out['dp_path_1rank_host_us_per_step'] = d['config'].get('host_us_per_step')
+        out['dp_path_1rank_launch'] = d['config'].get('launch')
+    except Exception as exc:
+        out['dp_path_1rank_ms_per_step'] = f'failed: {exc!r}'[:200]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -191,6 +210,10 @@ def main():
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a HIP graph')
     ap.add_argument('--no-secondary', action='store_true', help='skip the cfg3 / cfg4 / inference timings appended to the line')
+    ap.add_argument('--dp-path', action='store_true',
+                    help='one rank, but through the data-parallel step as N > 1 ranks run it: RCCL group of one rank, flat gradient '
+                         'buffer written by the backward kernels, bucket all-reduces on the communication stream behind the graph '
+                         'replay (what `secondary.dp_path_1rank_ms_per_step` reports)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -208,6 +231,15 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    elif args.dp_path:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    distributed = world > 1 or args.dp_path
 
     import multimodal_3d_image_segmentation_amd as pkg
     from multimodal_3d_image_segmentation_amd.nets import custom_losses
@@ -215,14 +247,16 @@ def main():
 
     torch.manual_seed(0)
     model = pkg.nets.HNOSegXS(**MODEL_CFG).to(dev)
-    rep = FlatGradReplica(model)
+    rep = FlatGradReplica(model, force_distributed=args.dp_path and world == 1)
     opt = pkg.optim.Adamax(model.parameters(), lr=5e-3)   # one-launch multi-tensor Adamax (hno_adamax_multi)
     loss_fn = custom_losses.PCCLoss()
     B = args.batch
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.randn((B, 4) + VOL, device=dev, generator=g)
     labels = torch.randint(0, 4, (B, 1) + VOL, device=dev, generator=g).float()
-    pkg.ops.set_defer_reduce(True)     # one batched weight-gradient slab reduction per backward (plain leaf parameters here)
+    # one batched weight-gradient slab reduction per backward (plain leaf parameters here).  Not in eager data-parallel steps: the
+    # buckets leave from hooks DURING backward, a reduction deferred to its end would land after its bucket was sent
+    pkg.ops.set_defer_reduce(not distributed)
 
     def fwd_bwd():
         # the label conversion is part of every step, as in the reference loop (to_categorical, train_test.py:150-152);
@@ -243,15 +277,19 @@ def main():
     for _ in range(max(args.warmup, 2)):   # also creates the twiddle tables / kernel attributes (not capturable)
         eager_step()
 
-    # forward + loss + backward are captured ONCE into a HIP graph and replayed: ~150 kernel launches per
-    # step cost no host time, so the GPU is never launch-bound.  All-reduce and Adamax stay eager.
-    # With more than one replica the step runs eagerly instead (measured: 3.34 vs 3.30 ms, the step is kernel-bound either
-    # way): the per-bucket gradient all-reduces are launched from autograd hooks DURING backward, on the communication
-    # stream, which a single captured graph cannot express.
+    # forward + loss + backward are captured ONCE into a HIP graph and replayed: ~120 kernel launches per step cost no host
+    # time, so the GPU is never launch-bound.  Adamax stays an eager launch behind the replay.
+    # Data-parallel runs replay the same graph: the backward kernels write their weight gradients straight into the flat
+    # gradient buffer (the few that cannot are copied there by kernels inside the graph, rep.finish_capture()), and the bucket
+    # all-reduces are launched on the communication stream behind the replay (rep.allreduce_flat(): two RCCL launches for
+    # HNOSeg-XS's 113 KB, no Python per parameter).  Round 2 ran N > 1 eagerly with ~60 Python hooks per backward; the hooks
+    # remain the path of `training()` for models whose gradients are worth overlapping (V-Net-DS: 90 MB).
     graph = None
-    if not args.no_graph and world == 1:
+    if not args.no_graph:
         try:
             torch.cuda.synchronize()
+            rep.set_hooks_enabled(False)
+            pkg.ops.set_defer_reduce(True)     # inside a captured step nothing is sent before backward ends: batch the reductions
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -259,21 +297,28 @@ def main():
                 # thread_local: the RCCL watchdog thread polls events while we capture; it must not invalidate the capture
                 with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
                     static_loss = fwd_bwd()
+                    if distributed:
+                        rep.finish_capture()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
         except Exception as exc:   # capture unsupported on this stack: run eagerly and say so
             print(f'[bench] HIP graph capture failed ({exc!r}); running eagerly', file=sys.stderr)
             graph = None
+            rep.set_hooks_enabled(True)
+            if distributed:
+                pkg.ops.set_defer_reduce(False)
 
-    # the gradient tensors the captured backward writes (replays refill them in place)
-    captured_grads = [p.grad for p in rep.params] if graph is not None else None
+    host_s = [0.0]
 
     def step():
         if graph is None:
             return eager_step()
+        t_h = time.perf_counter()
         graph.replay()
-        rep.allreduce_grads(captured_grads)
+        if distributed:
+            rep.allreduce_flat()
         opt.step()
+        host_s[0] += time.perf_counter() - t_h
         return static_loss
 
     for _ in range(args.warmup):
@@ -286,11 +331,13 @@ def main():
         torch.cuda.synchronize()
 
     fence()
+    host_s[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    host_us_per_step = host_s[0] / args.steps * 1e6 if graph is not None else None
     # per-kernel HIP-event durations: a few eager steps of the same workload right after the timed
     # region (events cannot be recorded inside a graph replay)
     prof = None
@@ -336,9 +383,12 @@ def main():
             'config': {'workload': "HNOSeg-XS BraTS'23 config (filters 24, 8 blocks x 3, modes 10-14-14), "
                                    "synthetic 4-modal 128^3 fp32, step = fwd + PCC loss + bwd + grad all-reduce + Adamax",
                        'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
-                       'launch': 'hip-graph replay (fwd+loss+bwd) + eager Adamax' if graph is not None else
-                                 ('eager; gradient buckets all-reduced from backward hooks on a comm stream' if world > 1 else 'eager'),
-                       'grad_buckets': len(rep.buckets) if world > 1 else 0,
+                       'launch': ('hip-graph replay (fwd+loss+bwd)' + (' + bucket all-reduces on the comm stream' if distributed else '')
+                                  + ' + eager Adamax') if graph is not None else
+                                 ('eager; gradient buckets all-reduced from backward hooks on a comm stream' if distributed else 'eager'),
+                       'grad_buckets': len(rep.buckets) if distributed else 0,
+                       'dp_path_on_one_rank': bool(args.dp_path and world == 1),
+                       'host_us_per_step': None if host_us_per_step is None else round(host_us_per_step, 1),
                        'final_loss': round(float(loss), 6)},
             'roofline': roofline,
             'whole_step_roofline': {'algorithmic_GB_per_volume': ALGO_BYTES_PER_VOLUME / 1e9,
@@ -346,13 +396,14 @@ def main():
                                     'frac': round(value / world / (HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_VOLUME), 4)},
             'kernels': kernels,
         }
-        if world == 1 and not args.no_secondary:
+        if world == 1 and not args.no_secondary and not args.dp_path:
             del graph
             out['secondary'] = secondary_configs(pkg, dev)
+            out['secondary'].update(dp_path_secondary(out['ms_per_step']))
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.dp_path:
         dist.destroy_process_group()
 
 

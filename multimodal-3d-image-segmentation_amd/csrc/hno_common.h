@@ -77,6 +77,11 @@ long long *debug_stamp_buffer();
         if ((buf) && blockIdx.x == 0 && threadIdx.x == 0 && (idx) < 64) (buf)[(idx)] = clock64();   \
     } while (0)
 
+// Zero `n` doubles by a KERNEL.  Not hipMemsetAsync: as a memset NODE of a captured graph the clear of the loss statistics was lost
+// in the first replay that followed an eager kernel launch of another library (that replay's loss came out NaN, every later replay
+// was right; tools/dbg/graph_first_replay.py, DESIGN lesson 36).
+int clear_doubles(double *p, int n, hipStream_t s);
+
 // debug/ablation switches (hno_set_debug): timing-only builds of a kernel phase, results are WRONG
 int debug_flags();
 

@@ -856,7 +856,7 @@ extern "C" int hno_groupnorm1_fwd(const float *x, const float *gamma, const floa
                                   double *stats_ws, int B, int C, long long V, float eps, int act, void *stream) {
     HNO_REQUIRE(x && gamma && beta && y && mean_rstd && stats_ws && B > 0 && B <= 256 && C > 0 && V > 0, "hno_groupnorm1_fwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    HNO_CHECK_HIP(hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * B, s));
+    if (int rc = clear_doubles((double *)stats_ws, 2 * B, s)) return rc;
     const long long n = (long long)C * V;
     ProfScope _ps(KID_GROUPNORM, s);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(g1((size_t)n / 8 + 1) > 1024 ? 1024 : g1((size_t)n / 8 + 1), B), dim3(256), 0, s, x, stats_ws, n);
@@ -875,7 +875,7 @@ extern "C" int hno_groupnorm1_bwd(const float *g, const float *y, const float *x
     HNO_REQUIRE(g && y && x && mean_rstd && gamma && gx && dgamma && dbeta && sums_ws && coef_ws && B > 0 && B <= 256,
                 "hno_groupnorm1_bwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    HNO_CHECK_HIP(hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * B * C, s));
+    if (int rc = clear_doubles((double *)sums_ws, 2 * B * C, s)) return rc;
     const int gxn = g1((size_t)V / 4 + 1) > 256 ? 256 : g1((size_t)V / 4 + 1);
     ProfScope _ps(KID_GROUPNORM, s);
     hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3(gxn, B * C), dim3(256), 0, s, g, y, x, mean_rstd, sums_ws, C, V, act);

@@ -53,6 +53,17 @@ int persistent_grid(const void *kernel, int block_threads, size_t dynamic_lds, i
     return ceil_div(work_items, iters);
 }
 
+__global__ void clear_doubles_kernel(double *p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0;
+}
+int clear_doubles(double *p, int n, hipStream_t s) {
+    if (n <= 0) return HNO_OK;
+    hipLaunchKernelGGL(clear_doubles_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, n);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
 static int g_debug_flags = 0;
 int debug_flags() { return g_debug_flags; }
 

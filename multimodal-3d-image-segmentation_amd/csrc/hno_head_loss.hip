@@ -773,7 +773,10 @@ extern "C" int hno_loss_fwd(const float *probs, const uint8_t *labels, double *s
     HNO_REQUIRE(kind >= 0 && kind <= 2, "hno_loss_fwd: kind must be 0 (PCC), 1 (Dice) or 2 (ExpDice)");
     if (K > 8) return fail(HNO_ELIMIT, "hno_loss_fwd: K=%d classes (max 8)", K);
     hipStream_t s = (hipStream_t)stream;
-    HNO_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * B * K * 4, s));
+    {   // accumulators of the statistics kernels (see clear_doubles: not a memset node)
+        const int rc = clear_doubles(stats, B * K * 4, s);
+        if (rc) return rc;
+    }
     if (V % 4 == 0 && ((size_t)labels & 3) == 0 && ((size_t)probs & 15) == 0 && !(debug_flags() & 16)) {
         long long gq = (V / 4 + 255) / 256;
         if (gq > 256) gq = 256;   // measured (stats + finalize): 128 -> 37 us, 256 -> 29, 512 -> 32, 2048 -> 67 (atomic contention)

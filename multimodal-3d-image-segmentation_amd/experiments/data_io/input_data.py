@@ -19,13 +19,14 @@ from .dataset import ImageTransform
 class _Flow:
     """Re-iterable like a DataLoader: every ``iter()`` starts a new epoch (train_test.py:146,189)."""
 
-    def __init__(self, owner, data_lists, shuffle, transform_kwargs):
+    def __init__(self, owner, data_lists, shuffle, transform_kwargs, sharded=False):
         self.owner, self.data_lists, self.shuffle = owner, data_lists, shuffle
+        self.sharded = sharded      # train / validation flows only: testing() predicts every sample on the rank that runs it
         self.transform = ImageTransform(**transform_kwargs) if transform_kwargs is not None else None
         self._order_rng = np.random.default_rng(owner.shuffle_seed)
 
     def __len__(self):
-        return self.owner._get_num_batches(self.data_lists)
+        return self.owner._get_num_batches(self.data_lists, self.sharded)
 
     def _epoch_order(self):
         """Sample order of one epoch for THIS process: the (shared-seed) permutation, sharded rank::world with the uneven
@@ -33,7 +34,7 @@ class _Flow:
         o = self.owner
         n = len(self.data_lists[0])
         order = self._order_rng.permutation(n) if self.shuffle else np.arange(n)
-        if o.world > 1:
+        if self.sharded and o.world > 1:
             order = order[:(n // o.world) * o.world][o.rank::o.world]
         return order
 
@@ -93,32 +94,35 @@ class InputData:
         assert self.idx_x_modalities is not None
 
     def set_shard(self, rank, world):
-        """One process per GPU: disjoint shards of every epoch.  The epoch permutations must be the same on every rank, so an
-        unseeded shuffle (shuffle_seed=None: fresh OS entropy per process) is pinned to seed 0 here."""
+        """One process per GPU: disjoint shards of every TRAINING and VALIDATION epoch.  The epoch permutations must be the same on
+        every rank, so an unseeded shuffle (shuffle_seed=None: fresh OS entropy per process) is pinned to seed 0 here.  The test
+        flow is never sharded: testing() names its outputs by the position in the test list (train_test.py:383-426), so a rank
+        that runs it must see the whole list."""
         self.rank, self.world = int(rank), int(world)
         if self.world > 1 and self.shuffle_seed is None:
             self.shuffle_seed = 0
 
-    def _get_flow(self, data_lists, shuffle=False, transform_kwargs=None):
-        return _Flow(self, data_lists, shuffle, transform_kwargs)
+    def _get_flow(self, data_lists, shuffle=False, transform_kwargs=None, sharded=False):
+        return _Flow(self, data_lists, shuffle, transform_kwargs, sharded)
 
     def get_train_flow(self, shuffle=True):
-        return self._get_flow(self.data_lists_train, shuffle=shuffle, transform_kwargs=self.transform_kwargs)
+        return self._get_flow(self.data_lists_train, shuffle=shuffle, transform_kwargs=self.transform_kwargs, sharded=True)
 
     def get_valid_flow(self):
-        return self._get_flow(self.data_lists_valid)
+        return self._get_flow(self.data_lists_valid, sharded=True)
 
     def get_test_flow(self):
         return self._get_flow(self.data_lists_test)
 
-    def _get_num_batches(self, data):
-        return 0 if data is None else int(math.ceil(len(data[0]) // self.world / self.batch_size))
+    def _get_num_batches(self, data, sharded=False):
+        world = self.world if sharded else 1
+        return 0 if data is None else int(math.ceil(len(data[0]) // world / self.batch_size))
 
     def get_train_num_batches(self):
-        return self._get_num_batches(self.data_lists_train)
+        return self._get_num_batches(self.data_lists_train, True)
 
     def get_valid_num_batches(self):
-        return self._get_num_batches(self.data_lists_valid)
+        return self._get_num_batches(self.data_lists_valid, True)
 
     def get_test_num_batches(self):
         return self._get_num_batches(self.data_lists_test)

@@ -20,7 +20,8 @@ class SyntheticInputData:
     def set_shard(self, rank, world):
         """Data-parallel training: this process iterates samples rank, rank + world, ... of every epoch's order (the
         permutation is drawn from the shared seed, so the shards are disjoint); the tail that does not divide evenly is
-        dropped so that every rank runs the same number of batches (a collective per batch would otherwise hang)."""
+        dropped so that every rank runs the same number of batches (a collective per batch would otherwise hang).  Training and
+        validation flows only: the test flow always yields every sample (testing() names outputs by list position)."""
         self.rank, self.world = int(rank), int(world)
 
     def _default_sample(self, index):
@@ -29,12 +30,12 @@ class SyntheticInputData:
         y = torch.randint(0, self.num_labels, (1,) + self.image_size, generator=g).float()
         return x, y
 
-    def _flow(self, first, count, shuffle, epoch_seed=0):
+    def _flow(self, first, count, shuffle, epoch_seed=0, sharded=True):
         order = list(range(first, first + count))
         if shuffle:
             g = torch.Generator().manual_seed(self.seed + 7919 + epoch_seed)
             order = [order[i] for i in torch.randperm(count, generator=g).tolist()]
-        if self.world > 1:
+        if sharded and self.world > 1:
             order = order[:(count // self.world) * self.world][self.rank::self.world]
             count = len(order)
         for i in range(0, count, self.batch_size):
@@ -49,7 +50,7 @@ class SyntheticInputData:
         return _Reiterable(lambda: self._flow(self.num_train, self.num_valid, False))
 
     def get_test_flow(self):
-        return _Reiterable(lambda: self._flow(self.num_train + self.num_valid, self.num_test, False))
+        return _Reiterable(lambda: self._flow(self.num_train + self.num_valid, self.num_test, False, sharded=False))
 
     def get_test_num_batches(self):
         return int(math.ceil(self.num_test / self.batch_size))

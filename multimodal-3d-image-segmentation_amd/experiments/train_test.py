@@ -139,7 +139,7 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
         valid_loss = mean_loss(losses)
         if world > 1:               # same number on every rank: they must agree on best_epoch / min_loss
             t = torch.tensor([valid_loss if losses else 0.0, 1.0 if losses else 0.0], dtype=torch.float64,
-                             device=device if dist.get_backend(data_parallel.group) == 'nccl' else 'cpu')
+                             device=data_parallel.device if dist.get_backend(data_parallel.group) == 'nccl' else 'cpu')
             dist.all_reduce(t, group=data_parallel.group)
             valid_loss = float(t[0] / t[1]) if float(t[1]) > 0 else float('nan')
         log(f'valid_loss: {valid_loss}')

@@ -265,7 +265,8 @@ def pwconv_bwd_branch_raw(gy, y, xa, xb, W, Wbr, act, xa_act, defer=False, bf16=
 # During autograd's backward the weight-gradient reductions of all layers can be recorded and launched as ONE kernel from
 # the engine's end-of-backward callback; the slab workspaces are kept alive here until then.  The dW tensor handed to
 # autograd is uninitialised until that callback runs, so this is OPT-IN (set_defer_reduce(True) or HNO_DEFER_REDUCE=1;
-# bench.py and the training loop enable it) and guarded: a gradient is only deferred when nothing can read it before the
+# bench.py enables it; training() leaves the setting alone, and FlatGradReplica switches it off while its per-bucket hooks send
+# gradients during backward) and guarded: a gradient is only deferred when nothing can read it before the
 # pass ends -- the weight is a leaf with .grad None, has no tensor / post-accumulate hooks, and feeds exactly ONE live
 # autograd node (a module applied twice, or tied weights, would make AccumulateGrad sum two unreduced tensors).
 import os as _os

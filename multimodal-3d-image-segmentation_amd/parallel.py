@@ -29,7 +29,11 @@ class FlatGradReplica:
     usage per step:  rep.zero_grad(); loss = ...; loss.backward(); rep.allreduce_grads(); opt.step()
     """
 
-    def __init__(self, module, process_group=None, bucket_bytes=8 << 20, broadcast=True, overlap=True, min_buckets=2):
+    def __init__(self, module, process_group=None, bucket_bytes=8 << 20, broadcast=True, overlap=True, min_buckets=2,
+                 force_distributed=False):
+        """force_distributed: take the world > 1 code paths on a group of ONE rank (all-reduce with AVG over one rank is the
+        identity): how the data-parallel step is exercised and timed on a single-GPU box (bench.py `dp_path_1rank_ms_per_step`,
+        tests)."""
         self.module = module
         self.group = process_group
         self.params = [p for p in module.parameters() if p.requires_grad]
@@ -43,7 +47,11 @@ class FlatGradReplica:
             self.offsets.append(off)
             off += p.numel()
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if force_distributed and dist.is_initialized() and self.world == 1:
+            self.world = 2       # branch selector only: the collectives still run over the real (one-rank) group
+        self.forced = bool(force_distributed)
         self._avg = self.world > 1 and dist.get_backend(process_group) == 'nccl'   # RCCL reduces with AVG directly
+        self._flat_ready = False
         self.overlap = bool(overlap) and self.world > 1
         # ---- buckets: contiguous parameter ranges, cut from the end; at least `min_buckets` so that even a 113 KB model
         # sends its first half while the second half of backward still runs
@@ -66,12 +74,13 @@ class FlatGradReplica:
         self._comm_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
         self._hooks = []
         if self.world > 1:
-            if broadcast:
+            if broadcast and not self.forced:
                 self.broadcast_parameters()
             from . import ops
             if dev.type == 'cuda':
                 ops.set_grad_destinations(dict(zip(self.params, self.views)))
-                ops.set_defer_reduce(False)      # a deferred (end-of-backward) reduction would land after the bucket was sent
+                # a deferred (end-of-backward) reduction would land after the bucket was sent; close() restores the setting
+                self._prev_defer = ops.set_defer_reduce(False)
             if self.overlap:
                 for i, p in enumerate(self.params):
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
@@ -109,6 +118,8 @@ class FlatGradReplica:
 
     def _make_hook(self, i):
         def hook(param):
+            if not getattr(self, '_hooks_on', True):
+                return
             self._settle(i)
             b = self.bucket_of[i]
             self._pending[b] -= 1
@@ -161,6 +172,44 @@ class FlatGradReplica:
         self._launched = [False] * len(self.buckets)
         return None
 
+    # ---- captured steps (HIP graph): no Python per parameter in the hot loop ---------------------------------------------
+    def set_hooks_enabled(self, on):
+        """the per-bucket hooks launch collectives from inside backward: switch them off while a step is captured into a graph
+        (the collectives then run after the replay, allreduce_flat) and on again for eager steps"""
+        self._hooks_on = bool(on)
+
+    def finish_capture(self):
+        """Call INSIDE the capture, after backward: gradients that did not arrive in their flat-buffer view (ops without a
+        destination, summed gradients) are copied there by kernels that become part of the graph; afterwards every ``.grad`` IS its
+        view, so an optimizer reads the averaged values and a replay needs no per-parameter work."""
+        for i in range(len(self.params)):
+            self._settle(i)
+        self._flat_ready = True
+
+    def allreduce_flat(self):
+        """After a graph replay whose kernels filled ``flat_grad`` (finish_capture): launch every bucket's all-reduce on the
+        communication stream behind the replay and make the compute stream wait for them.  Host cost: one collective launch per
+        bucket (two for HNOSeg-XS's 113 KB)."""
+        if self.world == 1:
+            return
+        assert self._flat_ready, 'allreduce_flat() needs finish_capture() in the captured step'
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        works = []
+        if self._comm_stream is not None:
+            self._comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._comm_stream):
+                for lo, hi, _ in self.buckets:
+                    works.append(dist.all_reduce(self.flat_grad[lo:hi], op=op, group=self.group, async_op=True))
+        else:
+            for lo, hi, _ in self.buckets:
+                works.append(dist.all_reduce(self.flat_grad[lo:hi], op=op, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+        if self._comm_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._comm_stream)
+        if not self._avg:
+            self.flat_grad.mul_(1.0 / self.world)
+
     def close(self):
         for h in self._hooks:
             h.remove()
@@ -168,6 +217,7 @@ class FlatGradReplica:
         if self.world > 1 and self.device.type == 'cuda':
             from . import ops
             ops.set_grad_destinations(None)
+            ops.set_defer_reduce(self._prev_defer)
 
     def __call__(self, *a, **k):
         return self.module(*a, **k)

@@ -163,6 +163,23 @@ h.square().mean().backward()
 assert len(rep2.launch_order()) < len(rep2.buckets)
 rep2.allreduce_grads()
 assert float(list(net.parameters())[-1].grad.abs().max()) == 0.0
+# ---- the captured-step path (bench.py, round 3): hooks off during the (graph-captured) backward, finish_capture() settles every
+#      gradient into its flat-buffer view, allreduce_flat() sends all buckets behind the replay -- no per-parameter work per step
+rep2.set_hooks_enabled(False)
+rep2.zero_grad()
+net(xin).square().mean().backward()
+assert rep2.launch_order() == []                         # nothing left the rank during backward
+rep2.finish_capture()
+lo = rep2.flat_grad.data_ptr()
+assert all(lo <= p.grad.data_ptr() < lo + 4 * rep2.flat_grad.numel() for p in net.parameters())
+for replay in range(2):                                  # a "replay" refills the flat buffer in place, then the collectives run
+    gs = torch.autograd.grad(net(xin).square().mean(), list(net.parameters()))
+    for v, g in zip(rep2.views, gs):
+        v.copy_(g)
+    rep2.allreduce_flat()
+    for p, want in zip(net.parameters(), ref):
+        assert torch.allclose(p.grad, want, atol=1e-6), replay
+rep2.set_hooks_enabled(True)
 # overlap=False: nothing is sent before allreduce_grads
 rep3 = FlatGradReplica(torch.nn.Linear(4, 4), overlap=False)
 rep3.zero_grad()
@@ -314,3 +331,24 @@ def test_sharded_flows_are_disjoint_and_equal():
         orders.append([fl._epoch_order().tolist() for _ in range(2)])
     for e in range(2):
         assert len(orders[0][e]) == len(orders[1][e]) == 4 and not set(orders[0][e]) & set(orders[1][e])
+
+
+def test_test_flow_is_never_sharded():
+    """`training()` leaves its shard on the input data; a later `testing()` on that rank must still see EVERY test
+    sample, in list order (it names its outputs by position, train_test.py:383-426): only train / validation flows shard."""
+    from multimodal_3d_image_segmentation_amd.experiments.synthetic import SyntheticInputData
+    from multimodal_3d_image_segmentation_amd.experiments.data_io.input_data import InputData
+    d = SyntheticInputData((4, 4, 4), 1, 2, batch_size=1, num_train=4, num_valid=2, num_test=5,
+                           generator=lambda i: (torch.full((1, 4, 4, 4), float(i)), torch.zeros(1, 4, 4, 4)))
+    d.set_shard(1, 2)
+    ids = [int(x[0, 0, 0, 0, 0]) for x, _ in d.get_test_flow()]
+    assert ids == [6, 7, 8, 9, 10] and d.get_test_num_batches() == 5
+    assert d.get_valid_num_batches() == 1 and len(list(d.get_valid_flow())) == 1
+    r = InputData(reader=lambda p: np.full((2, 2, 2), float(p)), data_lists_train=[[str(i) for i in range(8)]],
+                  data_lists_valid=[[str(i) for i in range(4)]], data_lists_test=[[str(i) for i in range(5)]],
+                  idx_x_modalities=[0], batch_size=2, device='cpu')
+    r.set_shard(1, 2)
+    assert r.get_test_num_batches() == 3 and r.get_valid_num_batches() == 1 and r.get_train_num_batches() == 2
+    fl = r.get_test_flow()
+    assert len(fl) == 3 and fl._epoch_order().tolist() == [0, 1, 2, 3, 4]
+    assert r.get_valid_flow()._epoch_order().tolist() == [1, 3]
