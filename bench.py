@@ -281,7 +281,7 @@ def main():
     # time, so the GPU is never launch-bound.  Adamax stays an eager launch behind the replay.
     # Data-parallel runs replay the same graph: the backward kernels write their weight gradients straight into the flat
     # gradient buffer (the few that cannot are copied there by kernels inside the graph, rep.finish_capture()), and the bucket
-    # all-reduces are launched on the communication stream behind the replay (rep.allreduce_flat(): two RCCL launches for
+    # gradient all-reduce is launched on the communication stream behind the replay (rep.allreduce_flat(): one RCCL launch for
     # HNOSeg-XS's 113 KB, no Python per parameter).  Round 2 ran N > 1 eagerly with ~60 Python hooks per backward; the hooks
     # remain the path of `training()` for models whose gradients are worth overlapping (V-Net-DS: 90 MB).
     graph = None
@@ -383,7 +383,7 @@ def main():
             'config': {'workload': "HNOSeg-XS BraTS'23 config (filters 24, 8 blocks x 3, modes 10-14-14), "
                                    "synthetic 4-modal 128^3 fp32, step = fwd + PCC loss + bwd + grad all-reduce + Adamax",
                        'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
-                       'launch': ('hip-graph replay (fwd+loss+bwd)' + (' + bucket all-reduces on the comm stream' if distributed else '')
+                       'launch': ('hip-graph replay (fwd+loss+bwd)' + (' + one flat gradient all-reduce on the comm stream' if distributed else '')
                                   + ' + eager Adamax') if graph is not None else
                                  ('eager; gradient buckets all-reduced from backward hooks on a comm stream' if distributed else 'eager'),
                        'grad_buckets': len(rep.buckets) if distributed else 0,
