@@ -33,6 +33,28 @@ __global__ __launch_bounds__(64 * NW) void planar_kernel(const float *__restrict
                 if (in) yb[(size_t)2 * o * V] = s;
             }
         }
+    } else if constexpr (MODE == 12) {
+        // mode 0's access shape, but every wave walks a CONTIGUOUS range of tiles: the 32-byte sectors at the two ends of a
+        // misaligned 128-byte run are shared with the neighbouring tiles, which the same wave requests next (round 3, pmc_planar.sh)
+        const int h = lane >> 5, c = lane & 31;
+        const unsigned tpb = (V + 31) / 32, nt = tpb * B;
+        const unsigned gw = blockIdx.x * NW + wave, nwv = gridDim.x * NW;
+        const unsigned per = nt / nwv, rem = nt - per * nwv;
+        const unsigned t0 = gw * per + (gw < rem ? gw : rem), t1 = t0 + per + (gw < rem ? 1u : 0u);
+        for (unsigned t = t0; t < t1; ++t) {
+            const unsigned b = t / tpb, v = (t - b * tpb) * 32 + c;
+            const bool in = v < V;
+            const float *xb = x + (size_t)b * CIN * V + (in ? v : 0u) + (h ? V : 0u);
+            float xv[CIN / 2];
+#pragma unroll
+            for (int k = 0; k < CIN / 2; ++k) xv[k] = xb[(size_t)2 * k * V];
+            float *yb = y + (size_t)b * COUT * V + v + (h ? V : 0u);
+#pragma unroll
+            for (int o = 0; o < COUT / 2; ++o) {
+                const float s = xv[2 * o] + xv[2 * o + 1];
+                if (in) yb[(size_t)2 * o * V] = s;
+            }
+        }
     } else if constexpr (MODE == 1) {
         const unsigned tpb = (V + 63) / 64, nt = tpb * B;
         for (unsigned t = blockIdx.x * NW + wave; t < nt; t += gridDim.x * NW) {
@@ -468,6 +490,8 @@ int main(int argc, char **argv) {
             t = run<0, 8>(x, y, B, V, grid, 20); printf("N=%d mode0 (2x128B/instr) nw8 grid %4d: %6.1f us %5.0f GB/s\n", N, grid, t, bytes / t / 1e3);
             t = run<0, 4>(x, y, B, V, grid, 20); printf("N=%d mode0 (2x128B/instr) nw4 grid %4d: %6.1f us %5.0f GB/s\n", N, grid, t, bytes / t / 1e3);
             t = run<1, 4>(x, y, B, V, grid, 20); printf("N=%d mode1 (1x256B/instr) nw4 grid %4d: %6.1f us %5.0f GB/s\n", N, grid, t, bytes / t / 1e3);
+            t = run<12, 8>(x, y, B, V, grid, 20); printf("N=%d mode12 (mode 0, contiguous tiles per wave) nw8 grid %4d: %6.1f us %5.0f GB/s\n", N, grid, t, bytes / t / 1e3);
+            t = run<12, 4>(x, y, B, V, grid, 20); printf("N=%d mode12 (mode 0, contiguous tiles per wave) nw4 grid %4d: %6.1f us %5.0f GB/s\n", N, grid, t, bytes / t / 1e3);
             if (N % 4 == 0) { t = run<2, 4>(x, y, B, V, grid, 20); printf("N=%d mode2 (1x1KB aligned)  nw4 grid %4d: %6.1f us %5.0f GB/s\n", N, grid, t, bytes / t / 1e3); }
             t = run<3, 4>(x, y, B, V, grid, 20); printf("N=%d mode3 (1x1KB row-aligned) nw4 grid %4d: %6.1f us %5.0f GB/s\n", N, grid, t, bytes / t / 1e3);
         }
