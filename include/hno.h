@@ -121,13 +121,23 @@ int hno_specmix_shared_bwd(const float *g, const float *z0, const float *zs, con
  * computes what hno_dht3_crop -> hno_specmix_layers_fwd -> hno_pad_idht3 compute.  The workspace (hno_dht3_workspace_bytes) is
  * transformed in place.  zs: (L + 1, B, C, 2 m0, 2 m1, 2 m2) = cropped spectrum z0 followed by the L layer outputs (what
  * the backward needs).  hno_spec_mid_supported says whether the fused kernels exist for a configuration (24 channels, N0 in
- * {65, 33}, m0 = 10, m1, m2 <= 15); callers use the three-kernel path otherwise. */
+ * {65, 33}, m0 = 10, m1, m2 <= 15); callers use the three-kernel path otherwise.  ldbc: stride (floats) between consecutive (b, c)
+ * volumes of x / out / addend (0 = N0 N1 N2, contiguous). */
 int hno_spec_mid_supported(int C, int N0, int m0, int m1, int m2, int L);
-int hno_dht3_planes(const float *x, void *workspace, int BC, int N0, int N1, int N2, int m0, int m1, int m2, void *stream);
+int hno_dht3_planes(const float *x, void *workspace, int BC, int N0, int N1, int N2, int m0, int m1, int m2, long long ldbc,
+                    void *stream);
 int hno_spec_mid_fwd(void *workspace, const float *const *W_layers, float *zs, int B, int C, int N0, int m0, int m1, int m2, int L,
                      int residual, int act, float scale, void *stream);
 int hno_idht3_planes(const void *workspace, const float *addend, int act, float *out, int BC, int N0, int N1, int N2, int m0, int m1,
-                     int m2, float scale, void *stream);
+                     int m2, float scale, long long ldbc, void *stream);
+/* hno_dht3_crop / hno_pad_idht3 on channel-padded activations: ldbc = stride (floats) between consecutive (b, c) volumes of x /
+ * x_act_out, resp. out / addend (0 or N0 N1 N2 = contiguous; a padded stride needs the 65^3 / 33^3 kernels, else HNO_ELIMIT).
+ * The inverse zeroes the padding of `out`.  hno_dht3_ld_supported: 1 when both directions take a padded stride for this geometry. */
+int hno_dht3_ld_supported(int N0, int N1, int N2, int m0, int m1, int m2);
+int hno_dht3_crop_ld(const float *x, const float *x_act_out, int act_grad, float *out, void *workspace, int BC, int N0, int N1, int N2,
+                     int m0, int m1, int m2, float scale, long long ldbc, void *stream);
+int hno_pad_idht3_ld(const float *z, const float *addend, int act, float *out, void *workspace, int BC, int N0, int N1, int N2,
+                     int m0, int m1, int m2, float scale, long long ldbc, void *stream);
 
 int hno_specmix_layers_fwd(const float *z0, const float *const *W_layers, float *zs, int B, int C, int M,
                            int L, int residual, int act, void *stream);
@@ -187,12 +197,15 @@ int hno_cmix_split_grad(const float *dw2, float *dw_real, float *dw_imag, int Co
  * (nets/hnosegxs.py:102-104,151; nets/nets_utils.py:156-163).  W is (Cout,Cin,2,2,2).
  * Backward writes dW / dbias (workspace = hno_pwconv_bwd_workspace_bytes(Cin*8, Cout))
  * and, if gx != NULL, the input gradient.
+ * ldy: channel stride (floats) of y / gy (0 = the voxel count; or padded up to a multiple of 32, "channel-padded" activations:
+ * every channel row then starts on a 128-byte boundary, which the pointwise backward needs to run at the memory rate -- the forward
+ * zeroes the padding).
  */
 int hno_conv_k2s2_fwd(const float *x, const float *W, const float *bias, float *y, int B, int Cin, int Cout,
-                      int D, int H, int Wd, int act, void *stream);
+                      int D, int H, int Wd, int act, long long ldy, void *stream);
 int hno_conv_k2s2_bwd(const float *gy, const float *y, const float *x, const float *W, float *gx, float *dW,
                       float *dbias, void *workspace, int B, int Cin, int Cout, int D, int H, int Wd, int act,
-                      void *stream);
+                      long long ldy, void *stream);
 
 /* ------------------------------------------------- output head: upsample + channel softmax
  * probs[b, c, :] = softmax_c( trilinear(logits_lr[b, c], size=(D,H,W), align_corners=False) )
@@ -337,6 +350,9 @@ int hno_act_bwd(const float *g, const float *y, float *gx, long long n, int act,
 /* y[b][c][v] = act(y[b][c][v] + bias[c]) in place: epilogue of 1x1x1 convolutions routed through hno_bmm (wide layers) */
 int hno_bias_act(float *y, const float *bias, int B, int C, long long V, int act, void *stream);
 int hno_add(const float *a, const float *b, float *out, long long n, void *stream);
+/* dst[r][v] = v < V ? src[r][v] : 0 for v < ld_dst, r < rows: (b, c) volumes between the contiguous layout (ld = V) and the
+ * channel-padded one (ld = V rounded up to 32 floats, padding zeroed) that the HNOSeg-XS path keeps its activations in */
+int hno_chan_restride(const float *src, float *dst, long long rows, long long V, long long ld_src, long long ld_dst, void *stream);
 /* out = alpha * a + beta * b (b may be NULL: out = alpha * a); the x +- x_reverse combinations of hartley_conv
  * (nets/hartley_operator.py:315-317) and gradient scaling in the data-parallel path */
 int hno_axpby(float alpha, const float *a, float beta, const float *b, float *out, long long n, void *stream);

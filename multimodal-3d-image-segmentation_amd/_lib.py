@@ -30,9 +30,12 @@ SIGNATURES = {
     'hno_specmix_shared_bwd': (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
     'hno_specmix_bwd_workspace_bytes': (c_size_t, [c_int] * 4),
     'hno_spec_mid_supported': (c_int, [c_int] * 6),
-    'hno_dht3_planes': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    'hno_dht3_planes': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_ll, c_void_p]),
     'hno_spec_mid_fwd': (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_float, c_void_p]),
-    'hno_idht3_planes': (c_int, [c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 7 + [c_float, c_void_p]),
+    'hno_idht3_planes': (c_int, [c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 7 + [c_float, c_ll, c_void_p]),
+    'hno_dht3_ld_supported': (c_int, [c_int] * 6),
+    'hno_dht3_crop_ld': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_ll, c_void_p]),
+    'hno_pad_idht3_ld': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_ll, c_void_p]),
     'hno_specmix_layers_fwd': (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     'hno_specmix_layers_bwd': (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
     'hno_pwconv_fwd': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_void_p]),
@@ -44,8 +47,8 @@ SIGNATURES = {
     'hno_pwconv_bwd_branch': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 6 + [c_int, c_int, c_ll, c_int, c_int, c_void_p]),
     'hno_cmix_compose': (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p]),
     'hno_cmix_split_grad': (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p]),
-    'hno_conv_k2s2_fwd': (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
-    'hno_conv_k2s2_bwd': (c_int, [c_void_p] * 8 + [c_int] * 7 + [c_void_p]),
+    'hno_conv_k2s2_fwd': (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_ll, c_void_p]),
+    'hno_conv_k2s2_bwd': (c_int, [c_void_p] * 8 + [c_int] * 7 + [c_ll, c_void_p]),
     'hno_upsoftmax_fwd': (c_int, [c_void_p] * 2 + [c_int] * 9 + [c_void_p]),
     'hno_up_argmax': (c_int, [c_void_p] * 2 + [c_int] * 8 + [c_void_p]),
     'hno_upsoftmax_bwd_workspace_bytes': (c_size_t, [c_int] * 8),
@@ -87,6 +90,7 @@ SIGNATURES = {
     'hno_act_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p]),
     'hno_bias_act': (c_int, [c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_void_p]),
     'hno_add': (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
+    'hno_chan_restride': (c_int, [c_void_p, c_void_p, c_ll, c_ll, c_ll, c_ll, c_void_p]),
     'hno_axpby': (c_int, [c_float, c_void_p, c_float, c_void_p, c_void_p, c_ll, c_void_p]),
     'hno_loss_fwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_ll, c_int, c_float, c_void_p]),
     'hno_loss_bwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_ll, c_void_p]),
@@ -144,11 +148,20 @@ def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _chan_padded(t):
+    """(B, C, D, H, W) fp32 whose (b, c) volumes are contiguous and a multiple of 32 floats apart (ops.chan_stride)"""
+    if t.dim() != 5:
+        return False
+    B, C, D, H, W = t.shape
+    st = t.stride()
+    return st[1] % 32 == 0 and 0 <= st[1] - D * H * W < 32 and tuple(st[2:]) == (H * W, W, 1) and (B == 1 or st[0] == C * st[1])
+
+
 def ptr(t):
-    """Device pointer of a contiguous tensor (None -> NULL)."""
+    """Device pointer of a contiguous (or channel-padded: ops.chan_stride) tensor (None -> NULL)."""
     if t is None:
         return None
-    assert t.is_cuda and t.is_contiguous(), 'libhno needs contiguous device tensors'
+    assert t.is_cuda and (t.is_contiguous() or _chan_padded(t)), 'libhno needs contiguous device tensors'
     return ctypes.c_void_p(t.data_ptr())
 
 

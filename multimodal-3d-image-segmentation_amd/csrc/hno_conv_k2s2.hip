@@ -23,6 +23,7 @@ struct K2Args {
     float *y, *dW, *dbias, *partials;
     int B, Cin, Cout, D, H, Wd, Do, Ho, Wo;
     int act;
+    unsigned ldy;   // channel stride (floats) of y / gy / the saved output: Do * Ho * Wo, or padded to a multiple of 32 (ops.act_empty)
     // tiling of one (b, od) slab: Ho * wtr row tiles (32 consecutive ow of one output row) followed by
     // ncol * ctiles column tiles (32 consecutive oh at one of the last `ncol` columns).  Wo = 32 t + 1 (65, 33)
     // would otherwise spend a whole 32-wide tile per row on its single leftover column: 3 tiles per row, not 2.
@@ -152,20 +153,20 @@ __global__ __launch_bounds__(256) void conv_k2s2_fwd_kernel(K2Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) val[r] = act_apply(val[r], a.act);
         }
-        float *y_l = a.y + (size_t)cur.b * a.Cout * Vo + cur.vo + (h ? 4u * Vo : 0u);
+        float *y_l = a.y + (size_t)cur.b * a.Cout * a.ldy + cur.vo + (h ? 4u * a.ldy : 0u);
         const bool full = __builtin_amdgcn_ballot_w64(cur.live) == ~0ull;
         if (full) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o0 = (r & 3) + 8 * (r >> 2);
-                if (o0 + 4 < a.Cout) y_l[(size_t)o0 * Vo] = val[r];                 // uniform conditions
-                else if (o0 < a.Cout) { if (h == 0) y_l[(size_t)o0 * Vo] = val[r]; }
+                if (o0 + 4 < a.Cout) y_l[(size_t)o0 * a.ldy] = val[r];                 // uniform conditions
+                else if (o0 < a.Cout) { if (h == 0) y_l[(size_t)o0 * a.ldy] = val[r]; }
             }
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o0 = (r & 3) + 8 * (r >> 2);
-                if (cur.live && o0 + 4 * h < a.Cout) y_l[(size_t)o0 * Vo] = val[r];
+                if (cur.live && o0 + 4 * h < a.Cout) y_l[(size_t)o0 * a.ldy] = val[r];
             }
         }
     }
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void conv_k2s2_bwd_kernel(K2Args a) {
     const unsigned ngroups = (ntiles + 3) / 4;
     const unsigned Vo = (unsigned)a.Do * a.Ho * a.Wo, HW = (unsigned)a.H * a.Wd, DHW = (unsigned)a.D * HW;
     const unsigned nrow = (unsigned)a.Ho * a.wtr;
-    const unsigned hoffV = h ? Vo : 0u;
+    const unsigned hoffV = h ? a.ldy : 0u;
     float pg[KSO_MAX], py[KSO_MAX];
     struct St { bool live; bool ok[2][2]; bool any_bad; };
     auto fetch = [&](unsigned grp, int slot) {
@@ -261,15 +262,15 @@ __global__ __launch_bounds__(256) void conv_k2s2_bwd_kernel(K2Args a) {
             dma_row_pair(base, rowoff[ks & 1], __builtin_amdgcn_readfirstlane(p_lds + (slot * XS + ks * K2_XP) * 4));
         }
         // younger register loads: in-order completion makes hipcc's wait for them retire the DMA above as well
-        const float *gy_b = a.gy + (size_t)b * a.Cout * Vo, *y_b = a.y_saved + (size_t)b * a.Cout * Vo;
+        const float *gy_b = a.gy + (size_t)b * a.Cout * a.ldy, *y_b = a.y_saved + (size_t)b * a.Cout * a.ldy;
 #pragma unroll
         for (int ks = 0; ks < KSO_MAX; ++ks) {
             pg[ks] = 0.f; py[ks] = 0.f;
             if (ks < nkso) {
                 const int o0 = 2 * ks;
                 const unsigned off = (o0 + 1 < a.Cout ? hoffV : 0u) + vo;
-                pg[ks] = (gy_b + (size_t)o0 * Vo)[off];
-                py[ks] = (y_b + (size_t)o0 * Vo)[off];
+                pg[ks] = (gy_b + (size_t)o0 * a.ldy)[off];
+                py[ks] = (y_b + (size_t)o0 * a.ldy)[off];
             }
         }
         return st;
@@ -359,12 +360,22 @@ static int k2_fill(K2Args &a, int B, int Cin, int Cout, int D, int H, int Wd, in
     return HNO_OK;
 }
 
+// rows of y whose channel stride exceeds the voxel count: the padding is zeroed (finite for every later reader, see ops.act_empty)
+__global__ void k2_zero_pad_kernel(float *y, unsigned rows, unsigned Vo, unsigned ldy) {
+    const unsigned npad = ldy - Vo;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * npad; i += gridDim.x * blockDim.x)
+        y[(size_t)(i / npad) * ldy + Vo + i % npad] = 0.f;
+}
+
 extern "C" int hno_conv_k2s2_fwd(const float *x, const float *W, const float *bias, float *y, int B, int Cin, int Cout,
-                                 int D, int H, int Wd, int act, void *stream) {
+                                 int D, int H, int Wd, int act, long long ldy, void *stream) {
     HNO_REQUIRE(x && W && y, "hno_conv_k2s2_fwd: null pointer");
     K2Args a = {};
     int rc = k2_fill(a, B, Cin, Cout, D, H, Wd, act);
     if (rc) return rc;
+    const long long Vo_ = (long long)a.Do * a.Ho * a.Wo;
+    HNO_REQUIRE(ldy == 0 || (ldy >= Vo_ && ldy < Vo_ + 64), "hno_conv_k2s2_fwd: channel stride %lld for %lld voxels", ldy, Vo_);
+    a.ldy = (unsigned)(ldy ? ldy : Vo_);
     a.x = x; a.W = W; a.bias = bias; a.y = y;
     const long long ntiles = (long long)B * a.Do * a.tiles_per_slab;
     if (ntiles >= (1ll << 31) || (long long)Cin * D * H * Wd >= (1ll << 29) || (long long)Cout * a.Do * a.Ho * a.Wo >= (1ll << 29))
@@ -382,18 +393,27 @@ extern "C" int hno_conv_k2s2_fwd(const float *x, const float *W, const float *bi
         }
     }
     HNO_CHECK_LAUNCH();
+    if (a.ldy > (unsigned)Vo_) {
+        hipLaunchKernelGGL(k2_zero_pad_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, y, (unsigned)(B * Cout), (unsigned)Vo_, a.ldy);
+        HNO_CHECK_LAUNCH();
+    }
     return HNO_OK;
 }
 
 extern "C" int hno_conv_k2s2_bwd(const float *gy, const float *y, const float *x, const float *W, float *gx, float *dW,
                                  float *dbias, void *workspace, int B, int Cin, int Cout, int D, int H, int Wd, int act,
-                                 void *stream) {
+                                 long long ldy, void *stream) {
     HNO_REQUIRE(gy && y && x && dW && workspace, "hno_conv_k2s2_bwd: null pointer");
     (void)W;
     if (gx) return fail(HNO_ELIMIT, "hno_conv_k2s2_bwd: input-gradient (gx) is not implemented; the image input needs none");
     K2Args a = {};
     int rc = k2_fill(a, B, Cin, Cout, D, H, Wd, act);
     if (rc) return rc;
+    {
+        const long long Vo_ = (long long)a.Do * a.Ho * a.Wo;
+        HNO_REQUIRE(ldy == 0 || (ldy >= Vo_ && ldy < Vo_ + 64), "hno_conv_k2s2_bwd: channel stride %lld for %lld voxels", ldy, Vo_);
+        a.ldy = (unsigned)(ldy ? ldy : Vo_);
+    }
     a.x = x; a.gy = gy; a.y_saved = y; a.dW = dW; a.dbias = dbias; a.partials = (float *)workspace;
     const long long ntiles = (long long)B * a.Do * a.tiles_per_slab;
     if (ntiles >= (1ll << 31) || (long long)Cin * D * H * Wd >= (1ll << 29) || (long long)Cout * a.Do * a.Ho * a.Wo >= (1ll << 29))

@@ -1021,7 +1021,8 @@ __device__ __forceinline__ void store16_wt(float *ptr, f32x4 v) {
 // ABL: timing ablations (results wrong): 1 = a VALU op in place of every MFMA, 2 = no LDS operand reads
 template <int KC2, int KS2, int NP, int NWV, int ABL = 0>
 __global__ __launch_bounds__(64 * NWV, 2) void dht_fwd_plane_dma_kernel(const float *__restrict__ xal, float *__restrict__ Y, DhtArgs a,
-                                                                        unsigned shift0, unsigned max_off, int pl_base, int pl_rem) {
+                                                                        unsigned shift0, unsigned max_off, int pl_base, int pl_rem,
+                                                                        unsigned ldbc) {
     extern __shared__ float lds[];
     auto MM = [](float av, float bv, f32x4 c) -> f32x4 {
         if (ABL == 1) {
@@ -1037,6 +1038,13 @@ __global__ __launch_bounds__(64 * NWV, 2) void dht_fwd_plane_dma_kernel(const fl
     const int N2 = a2.N;
     constexpr int N1 = 32 * NP + 1;
     const unsigned pe = (unsigned)(N1 * N2);
+    // float index of plane (bc, n0) from the aligned base: consecutive (b, c) volumes are ldbc floats apart (N0 pe, or padded up
+    // to a multiple of 32: channel-padded activations)
+    const int N0p = p.ax[0].N;
+    auto plane_f0 = [&](int plane) -> unsigned {
+        const int bc = plane / N0p;
+        return shift0 + (unsigned)bc * ldbc + (unsigned)(plane - bc * N0p) * pe;
+    };
     // chunks of an item (rows [r0, r1) of the plane) and their KiB pieces; item slot = SLOTP pieces
     constexpr int SLOTP = NP == 2 ? 10 : 5;
     constexpr int SLOTF = SLOTP * 256;
@@ -1053,7 +1061,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void dht_fwd_plane_dma_kernel(const fl
     if (a.stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 64 * (NWV - 1)) a.stamps[56] = wall_clock64();
     // rows [r0, r0 + nr) of `plane` -> LDS at byte address dst, NPC pieces
     auto issue_chunk = [&](int plane, int r0, int NPC, unsigned dst) {
-        const unsigned f0 = shift0 + (unsigned)plane * pe + (unsigned)(r0 * N2);   // float index of the chunk from the aligned base
+        const unsigned f0 = plane_f0(plane) + (unsigned)(r0 * N2);   // float index of the chunk from the aligned base
         const unsigned boff = (f0 & ~3u) * 4u + (unsigned)lane * 16u;
         const unsigned first = __builtin_amdgcn_readfirstlane(boff);
         if (first + (unsigned)NPC * 1024u <= max_off) {   // wave-uniform: every piece inside the tensor
@@ -1132,7 +1140,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void dht_fwd_plane_dma_kernel(const fl
     const bool q0 = q == 0;
     // plane rows of item (plane, X) in its slot: row r of the plane at rowsP + r N2 (rows of the tile) / rowsM + r N2 (mirror rows)
     auto item_rows = [&](int pl, int X, int slot, const float *&rowsP, const float *&rowsM) {
-        const unsigned g0 = shift0 + (unsigned)pl * pe;
+        const unsigned g0 = plane_f0(pl);
         const float *sl = ring + slot * SLOTF;
         if (NP == 1) rowsP = rowsM = sl + (g0 & 3u);
         else if (X == 0) {
@@ -2125,7 +2133,7 @@ __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float 
 template <int NP, int N2c, int KM1, int NT2, bool HAS_ADD, int NWV>
 __global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const float *__restrict__ E, const float *__restrict__ add_al,
                                                               float *__restrict__ out_al, DhtArgs a, unsigned shift0, int it_base,
-                                                              int it_rem) {
+                                                              int it_rem, unsigned ldbc) {
     extern __shared__ float lds[];
     HNO_STAMP(a.stamps, 20);
     if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[60] = wall_clock64();
@@ -2221,7 +2229,14 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const f
         __builtin_amdgcn_sched_barrier(0);
         // ---- chunk geometry of the item (rows [r0, r0 + nr) of the plane, LDS float offset): X = 0: rows [0, 17) (+ [49, 65) at 1112);
         //      X = 1: rows [17, 49);  NP = 1: rows [0, 33)
-        const unsigned f0 = shift0 + (unsigned)plane * pe;     // float index of the plane from the aligned base
+        // float index of the plane from the aligned base: consecutive (b, c) volumes are ldbc floats apart (channel-padded
+        // activations: N0 pe rounded up to a multiple of 32; the wave that writes a volume's last rows zeroes the padding)
+        const int N0p = p.ax[0].N, bcv = plane / N0p, n0v = plane - bcv * N0p;
+        const unsigned f0 = shift0 + (unsigned)bcv * ldbc + (unsigned)n0v * pe;
+        if (n0v == N0p - 1 && X == 0 && ldbc > (unsigned)N0p * pe) {
+            const unsigned npad = ldbc - (unsigned)N0p * pe;
+            if ((unsigned)lane < npad) out_al[shift0 + (unsigned)bcv * ldbc + (unsigned)N0p * pe + lane] = 0.f;
+        }
         constexpr int NG0 = NP == 2 ? 5 : (N1 * N2 + 3 + 255) / 256, NG1 = NP == 2 ? 5 : 0, NGB = 9;
         const int c0_r0 = NP == 2 ? (X == 0 ? 0 : 17) : 0;
         const int c1_r0 = 49, c1_lo = 1112;
@@ -2456,8 +2471,11 @@ extern "C" size_t hno_dht3_workspace_bytes(int BC, int N0, int N1, int N2, int m
 // dht_fwd_d_kernel or of the fused spectral middle, hno_specmid.hip)
 static int dht_forward_launch(const float *x, const float *x_act_out, int act_grad, float *out, void *workspace,
                               int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream,
-                              int mode, int C, int full = 0, bool planes_only = false) {
+                              int mode, int C, int full = 0, bool planes_only = false, long long ldbc = 0) {
     HNO_REQUIRE(x && (out || planes_only) && workspace, "hno_dht3_crop: null pointer");
+    const long long vol = (long long)N0 * N1 * N2;
+    if (ldbc == 0) ldbc = vol;
+    HNO_REQUIRE(ldbc >= vol && ldbc < vol + 64, "hno_dht3_crop: volume stride %lld for %lld voxels", ldbc, vol);
     int rc = check_sizes(BC, N0, N1, N2, m0, m1, m2, full, mode);
     if (rc) return rc;
     const DhtPlan *plan;
@@ -2522,10 +2540,10 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
 #define HNO_DMA(KC2, KS2, NP)                                                                                              \
     if (!launched && spec_ok && !x_act_out && !(a.dbg & 512) && fwd_plane_variant() != 1 && N1 == 32 * NP + 1 && (N2 & 1) && \
         b2.KcP == 4 * KC2 && b2.KsP == 4 * KS2 && b2.Js == b2.KsP && plan->NP1 == NP && b1.KT == 1 &&                      \
-        (NP == 2 ? N2 == 65 : N2 <= 37) && (double)planes * pe < 1.0e9 && ((size_t)x & 3) == 0) {                          \
+        (NP == 2 ? N2 == 65 : N2 <= 37) && (double)BC * ldbc < 1.0e9 && ((size_t)x & 3) == 0) {                            \
         const unsigned shift0 = (unsigned)(((size_t)x >> 2) & 3);                                                          \
         const float *xal = x - shift0;                                                                                     \
-        const unsigned max_off = (unsigned)((((size_t)shift0 + (size_t)planes * pe) * 4 - 1) & ~(size_t)15);               \
+        const unsigned max_off = (unsigned)((((size_t)shift0 + (size_t)(BC - 1) * ldbc + (size_t)vol) * 4 - 1) & ~(size_t)15); \
         constexpr int NWV = 8;                                                                                             \
         auto kern = (a.dbg & 2) ? dht_fwd_plane_dma_kernel<KC2, KS2, NP, NWV, 1>                                          \
                                 : (a.dbg & 4) ? dht_fwd_plane_dma_kernel<KC2, KS2, NP, NWV, 2> : dht_fwd_plane_dma_kernel<KC2, KS2, NP, NWV, 0>; \
@@ -2539,12 +2557,13 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
         int gw = persistent_grid((const void *)kern, 64 * NWV, lds_w, (planes + NWV - 1) / NWV);                           \
         if (gforce > 0) gw = gforce < planes ? gforce : planes;                                                            \
         hipLaunchKernelGGL(kern, dim3(gw), dim3(64 * NWV), lds_w, s, xal, (float *)workspace, a, shift0, max_off,          \
-                           planes / gw, planes % gw);                                                                      \
+                           planes / gw, planes % gw, (unsigned)ldbc);                                                      \
         launched = true;                                                                                                   \
     }
         HNO_DMA(9, 8, 2)           // 65 x 65 planes
         HNO_DMA(5, 4, 1)           // 33 x 33 planes
 #undef HNO_DMA
+        if (!launched && ldbc != vol) return fail(HNO_ELIMIT, "hno_dht3_crop: a padded volume stride needs the 65 x 65 / 33 x 33 plane kernels");
         HNO_WAVE(9, 8, 9, 8, 16)   // 65 x 65 planes
         HNO_WAVE(5, 4, 5, 4, 4)    // 33 x 33 planes
 #undef HNO_WAVE
@@ -2594,8 +2613,11 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
 // planes_only: the workspace already holds the axis-D step's output (written by the fused spectral middle): plane kernel only
 static int dht_inverse_launch(const float *z, const float *addend, int act, float *out, void *workspace,
                               int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream,
-                              int mode, int C, int full = 0, bool planes_only = false) {
+                              int mode, int C, int full = 0, bool planes_only = false, long long ldbc = 0) {
     HNO_REQUIRE((z || planes_only) && out && workspace, "hno_pad_idht3: null pointer");
+    const long long vol = (long long)N0 * N1 * N2;
+    if (ldbc == 0) ldbc = vol;
+    HNO_REQUIRE(ldbc >= vol && ldbc < vol + 64, "hno_pad_idht3: volume stride %lld for %lld voxels", ldbc, vol);
     int rc = check_sizes(BC, N0, N1, N2, m0, m1, m2, full, mode);
     if (rc) return rc;
     const DhtPlan *plan;
@@ -2655,7 +2677,7 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
 #define HNO_ITEM(NP, N2c, KM1, NT2)                                                                                        \
     if (!launched && spec_ok && !(a.dbg & 512) && inv_plane_variant() != 1 && N1 == 32 * NP + 1 && N2 == N2c && b1.KT == 1 && \
         b2.KT == 1 && b1.KmP == 4 * KM1 && b2.KmP <= 16 && plan->NP1 == NP && (b2.J + 15) / 16 == NT2 &&                   \
-        (double)planes * pe < 1.0e9 && ((size_t)out & 3) == 0 && (!addend || ((size_t)addend & 15) == ((size_t)out & 15))) { \
+        (double)BC * ldbc < 1.0e9 && ((size_t)out & 3) == 0 && (!addend || ((size_t)addend & 15) == ((size_t)out & 15))) { \
         const unsigned shift0 = (unsigned)(((size_t)out >> 2) & 3);                                                        \
         float *out_al = out - shift0;                                                                                      \
         const float *add_al = addend ? addend - shift0 : nullptr;                                                          \
@@ -2671,7 +2693,7 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
             }                                                                                                              \
             const int gw = items < 256 * NWV ? (items + NWV - 1) / NWV : 256;                                              \
             hipLaunchKernelGGL(kern, dim3(gw), dim3(64 * NWV), lds_w, s, (const float *)workspace, add_al, out_al, a, shift0, \
-                               items / gw, items % gw);                                                                    \
+                               items / gw, items % gw, (unsigned)ldbc);                                                    \
         } else {                                                                                                           \
             auto kern = dht_inv_item_kernel<NP, N2c, KM1, NT2, false, NWV>;                                                     \
             static bool attr = false;                                                                                      \
@@ -2681,13 +2703,14 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
             }                                                                                                              \
             const int gw = items < 256 * NWV ? (items + NWV - 1) / NWV : 256;                                              \
             hipLaunchKernelGGL(kern, dim3(gw), dim3(64 * NWV), lds_w, s, (const float *)workspace, add_al, out_al, a, shift0, \
-                               items / gw, items % gw);                                                                    \
+                               items / gw, items % gw, (unsigned)ldbc);                                                    \
         }                                                                                                                  \
         launched = true;                                                                                                   \
     }
         HNO_ITEM(2, 65, 4, 2)      // 65 x 65 planes, modes (., 14, 14)
         HNO_ITEM(1, 33, 4, 1)      // 33 x 33 planes
 #undef HNO_ITEM
+        if (!launched && ldbc != vol) return fail(HNO_ELIMIT, "hno_pad_idht3: a padded volume stride needs the 65 x 65 / 33 x 33 plane kernels");
 #define HNO_SPEC(KM1, KM2, NT1, NT2, NFULL)                                                                               \
     if (!launched && spec_ok && b1.KmP == 4 * KM1 && b2.KmP == 4 * KM2 && (b1.J + 15) / 16 == NT1 &&                      \
         (b2.J + 15) / 16 == NT2 && pe / 256 == NFULL) {                                                                   \
@@ -2724,13 +2747,45 @@ extern "C" int hno_dht3_crop(const float *x, const float *x_act_out, int act_gra
 }
 
 // The two plane transforms alone, around the fused spectral middle (hno_spec_mid_fwd / _bwd, hno_specmid.hip)
-extern "C" int hno_dht3_planes(const float *x, void *workspace, int BC, int N0, int N1, int N2, int m0, int m1, int m2, void *stream) {
-    return dht_forward_launch(x, nullptr, HNO_ACT_NONE, nullptr, workspace, BC, N0, N1, N2, m0, m1, m2, 1.f, stream, 0, 1, 0, true);
+extern "C" int hno_dht3_planes(const float *x, void *workspace, int BC, int N0, int N1, int N2, int m0, int m1, int m2, long long ldbc,
+                               void *stream) {
+    return dht_forward_launch(x, nullptr, HNO_ACT_NONE, nullptr, workspace, BC, N0, N1, N2, m0, m1, m2, 1.f, stream, 0, 1, 0, true, ldbc);
 }
 
 extern "C" int hno_idht3_planes(const void *workspace, const float *addend, int act, float *out, int BC, int N0, int N1, int N2, int m0,
-                                int m1, int m2, float scale, void *stream) {
-    return dht_inverse_launch(nullptr, addend, act, out, (void *)workspace, BC, N0, N1, N2, m0, m1, m2, scale, stream, 0, 1, 0, true);
+                                int m1, int m2, float scale, long long ldbc, void *stream) {
+    return dht_inverse_launch(nullptr, addend, act, out, (void *)workspace, BC, N0, N1, N2, m0, m1, m2, scale, stream, 0, 1, 0, true, ldbc);
+}
+
+// 1 when both plane kernels that understand a padded volume stride (dht_fwd_plane_dma_kernel, dht_inv_item_kernel) serve this
+// geometry: the host side only hands out channel-padded activations when this says so.
+extern "C" int hno_dht3_ld_supported(int N0, int N1, int N2, int m0, int m1, int m2) {
+    if (N0 < 1 || N1 < 16 || N2 < 16 || m0 < 0 || m1 < 1 || m2 < 1) return 0;
+    const DhtPlan *plan;
+    if (get_plan(N0, N1, N2, m0, m1, m2, &plan)) {
+        set_error("");
+        return 0;
+    }
+    const Axis &b1 = plan->ax[1], &b2 = plan->ax[2];
+    const int pe = N1 * N2, dbg = debug_flags();
+    if (dbg & (16 | 512)) return 0;
+    if (fwd_plane_variant() == 1 || inv_plane_variant() == 1) return 0;
+    if (!(pe <= 256 * 20 && b1.KT == 1 && b2.KT == 1 && 2 * plan->CP <= 1024)) return 0;
+    const int NP = plan->NP1;
+    if (!((NP == 2 && N1 == 65 && N2 == 65) || (NP == 1 && N1 == 33 && N2 == 33))) return 0;
+    const bool fwd = (N2 & 1) && b2.KcP == (NP == 2 ? 36 : 20) && b2.KsP == (NP == 2 ? 32 : 16) && b2.Js == b2.KsP;
+    const bool inv = b1.KmP == 16 && b2.KmP <= 16 && (b2.J + 15) / 16 == (NP == 2 ? 2 : 1);
+    return fwd && inv ? 1 : 0;
+}
+
+extern "C" int hno_dht3_crop_ld(const float *x, const float *x_act_out, int act_grad, float *out, void *workspace, int BC, int N0, int N1,
+                                int N2, int m0, int m1, int m2, float scale, long long ldbc, void *stream) {
+    return dht_forward_launch(x, x_act_out, act_grad, out, workspace, BC, N0, N1, N2, m0, m1, m2, scale, stream, 0, 1, 0, false, ldbc);
+}
+
+extern "C" int hno_pad_idht3_ld(const float *z, const float *addend, int act, float *out, void *workspace, int BC, int N0, int N1, int N2,
+                                int m0, int m1, int m2, float scale, long long ldbc, void *stream) {
+    return dht_inverse_launch(z, addend, act, out, workspace, BC, N0, N1, N2, m0, m1, m2, scale, stream, 0, 1, 0, false, ldbc);
 }
 
 extern "C" int hno_dht3_full(const float *x, float *out, void *workspace, int BC, int N0, int N1, int N2, float scale,

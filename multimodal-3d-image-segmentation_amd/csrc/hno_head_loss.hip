@@ -853,6 +853,29 @@ extern "C" int hno_add(const float *a, const float *b, float *out, long long n, 
     return HNO_OK;
 }
 
+// dst[r][v] = v < V ? src[r][v] : 0 for v in [0, ld_dst): moves (b, c) volumes between the contiguous layout (ld = V) and the
+// channel-padded one (ld = V rounded up to a multiple of 32 floats, padding zeroed)
+__global__ __launch_bounds__(256) void chan_restride_kernel(const float *__restrict__ src, float *__restrict__ dst, unsigned V,
+                                                            unsigned ld_src, unsigned ld_dst) {
+    const size_t r = blockIdx.y;
+    const float *s = src + r * ld_src;
+    float *d = dst + r * ld_dst;
+    for (unsigned v = blockIdx.x * 256u + threadIdx.x; v < ld_dst; v += gridDim.x * 256u) d[v] = v < V ? s[v] : 0.f;
+}
+
+extern "C" int hno_chan_restride(const float *src, float *dst, long long rows, long long V, long long ld_src, long long ld_dst,
+                                 void *stream) {
+    HNO_REQUIRE(src && dst && rows > 0 && V > 0 && ld_src >= V && ld_dst >= V, "hno_chan_restride: bad argument");
+    if (rows > 65535 || ld_dst >= (1ll << 32) || ld_src >= (1ll << 32))
+        return fail(HNO_ELIMIT, "hno_chan_restride: %lld rows of %lld floats", rows, ld_dst);
+    int gx = (int)((ld_dst + 1023) / 1024);
+    if (gx > 128) gx = 128;
+    hipLaunchKernelGGL(chan_restride_kernel, dim3(gx, (int)rows), dim3(256), 0, (hipStream_t)stream, src, dst, (unsigned)V,
+                       (unsigned)ld_src, (unsigned)ld_dst);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
 extern "C" int hno_axpby(float alpha, const float *a, float beta, const float *b, float *out, long long n, void *stream) {
     HNO_REQUIRE(a && out && n > 0, "hno_axpby: bad argument");
     hipLaunchKernelGGL(eltwise_kernel, dim3(grid1d((size_t)n)), dim3(256), 0, (hipStream_t)stream, a, b, out, (size_t)n, 3, 0, alpha, beta);

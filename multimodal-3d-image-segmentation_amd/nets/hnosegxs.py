@@ -237,6 +237,15 @@ class HNOSegXS(nn.Module):
             # 1 -> 1 is bilinear, and every other layer is pointwise.
             return self.forward(x.unsqueeze(2)).squeeze(2)
         image_size = tuple(x.shape[2:])
+        # channel-padded activations (ops.channel_padded): the stem hands the blocks tensors whose channel stride is rounded up to
+        # 128 B when the working grid (65^3 for 128^3 images) is one both plane transforms serve and every block is the fused node
+        grid = tuple(v // 2 + 1 for v in image_size) if self.use_resize else image_size
+        pad = (x.is_cuda and self.use_resize and self.conv_in.normalization is None and self.conv1.normalization is None
+               and all(l._fused_ok() for l in self.layers) and ops.padded_ok(grid, _tuple_modes(self.num_modes, self.ndim)))
+        with ops.channel_padded(pad):
+            return self._forward5(x, image_size)
+
+    def _forward5(self, x, image_size):
         ds, enc = [], {}
         if self.use_resize:
             x = self.conv_in(x)

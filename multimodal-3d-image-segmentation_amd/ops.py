@@ -5,7 +5,9 @@ containers (allocation, lifetime, autograd graph).  Nothing in this file compute
 or through ATen math kernels: if libhno.so is missing or the tensors are not on a GPU the
 call raises.
 """
+import contextlib
 import os
+import threading
 
 import numpy as np
 import torch
@@ -36,11 +38,109 @@ def _need_gpu(*tensors):
 
 
 def _f32c(t):
+    """fp32, contiguous (a channel-padded activation is repacked: chan_stride / to_layout below)"""
     if t is None:
         return None
     if t.dtype != torch.float32:
         t = t.float()
+    if t.dim() == 5 and not t.is_contiguous() and chan_stride(t) is not None:
+        return to_layout(t, None)
     return t.contiguous()
+
+
+# ------------------------------------------------------------------------- channel-padded activations
+# HNOSeg-XS works on 65^3 volumes: V = 274625 floats per channel is odd, so in a contiguous (B, C, V) tensor every channel row of
+# every tile starts at a different offset inside a 32-byte HBM sector and the pointwise kernels fetch 1.25x - 1.33x the bytes they
+# use (profiles/r03_a_pmc_calibration_planar_copy.json, tools/dbg/pw_padded_stride.py).  Inside the HNOSeg-XS path activations
+# therefore live with the channel stride rounded up to a multiple of 32 floats (128 B):
+#     strides (C ld, ld, H W, W, 1),  ld = round_up(V, 32)
+# * the pointwise kernels are called unchanged with V := ld (they never look at spatial coordinates); the transforms and the stem
+#   take the stride as an argument (hno_*_ld, ldbc / ldy);
+# * invariants: forward padding is FINITE (zero out of the stem, the inverse transform and to_layout; act(W pad + b) after a
+#   pointwise layer), gradient padding is exactly ZERO (to_layout and the inverse transform zero it, the pointwise backward maps
+#   zeros to zeros) -- so the padding never reaches a weight gradient (0 x finite) or a bias gradient;
+# * every op that does not know the layout goes through _f32c (one repack kernel) and hands back contiguous tensors.
+# The model switches it on (channel_padded) only for geometries both plane kernels serve; HNO_PAD_ACT=0 switches it off (A/B).
+_PAD = threading.local()
+
+
+@contextlib.contextmanager
+def channel_padded(on=True):
+    prev = getattr(_PAD, 'on', False)
+    _PAD.on = bool(on) and os.environ.get('HNO_PAD_ACT', '1') != '0'
+    try:
+        yield
+    finally:
+        _PAD.on = prev
+
+
+def padded_ok(spatial, modes):
+    """both transform directions take a padded channel stride for this grid / these (clamped) modes"""
+    if len(spatial) != 3 or spatial[0] < 2 or int(np.prod(spatial)) % 32 == 0:
+        return False
+    m = clamp_modes(modes, spatial)
+    return bool(_lib.lib().hno_dht3_ld_supported(*(int(v) for v in spatial), *(int(v) for v in m)))
+
+
+def _pad_ld(V):
+    return (int(V) + 31) // 32 * 32
+
+
+def chan_stride(t):
+    """channel stride (floats) when `t` is a channel-padded activation, else None"""
+    if t is None or t.dim() != 5 or t.dtype != torch.float32 or t.is_meta:
+        return None
+    B, C, D, H, W = t.shape
+    V, st = D * H * W, t.stride()
+    ld = st[1]
+    if ld == V or D < 2 or ld != _pad_ld(V) or tuple(st[2:]) != (H * W, W, 1) or (B > 1 and st[0] != C * ld):
+        return None
+    if (t.storage_offset() + B * C * ld) * 4 > t.untyped_storage().nbytes():
+        return None
+    return ld
+
+
+def act_empty(B, C, spatial, device, ld=None):
+    """uninitialised (B, C, *spatial) fp32 activation with channel stride `ld` (None: contiguous)"""
+    D, H, W = (int(v) for v in spatial)
+    if not ld or ld == D * H * W:
+        return torch.empty((B, C, D, H, W), device=device, dtype=torch.float32)
+    return torch.empty(B * C * ld, device=device, dtype=torch.float32).as_strided((B, C, D, H, W), (C * ld, ld, H * W, W, 1))
+
+
+def act_like(t, C=None):
+    return act_empty(t.shape[0], t.shape[1] if C is None else C, t.shape[2:], t.device, chan_stride(t))
+
+
+def _ext(t):
+    """floats an elementwise / pointwise kernel covers: the whole storage extent, padding included"""
+    ld = chan_stride(t)
+    return t.numel() if ld is None else t.shape[0] * t.shape[1] * ld
+
+
+def to_layout(t, ld):
+    """`t` with channel stride `ld` (None: contiguous); padding zeroed.  No-op when it already is."""
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    cur = chan_stride(t)
+    if cur is None and not t.is_contiguous():
+        t = t.contiguous()
+    if cur == ld:
+        return t
+    B, C = t.shape[:2]
+    V = _flat_v(t)
+    out = act_empty(B, C, t.shape[2:], t.device, ld)
+    check(_lib.lib().hno_chan_restride(ptr(t), ptr(out), B * C, V, cur or V, ld or V, stream_ptr()), 'hno_chan_restride')
+    return out
+
+
+def _f32a(t):
+    """fp32 activation in a layout the pointwise kernels take: channel-padded as it is, anything else contiguous"""
+    if t is None or (t.dtype == torch.float32 and chan_stride(t) is not None):
+        return t
+    return _f32c(t)
 
 
 def clamp_modes(modes, spatial):
@@ -120,6 +220,12 @@ def dht3_crop_raw(x, modes, scale, act_out=None, act=ACT_NONE):
     L = _lib.lib()
     ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, N0, N1, N2, m0, m1, m2) // 4, device=x.device, dtype=torch.float32)
     out = torch.empty((B, C, _block0(N0, m0), 2 * m1, 2 * m2), device=x.device, dtype=torch.float32)
+    ld = chan_stride(x)
+    if ld is not None:
+        act_out = to_layout(act_out, ld)
+        check(L.hno_dht3_crop_ld(ptr(x), ptr(act_out), act if act_out is not None else ACT_NONE, ptr(out), ptr(ws),
+                                 B * C, N0, N1, N2, m0, m1, m2, float(scale), ld, stream_ptr()), 'hno_dht3_crop_ld')
+        return out
     check(L.hno_dht3_crop(ptr(x), ptr(act_out), act if act_out is not None else ACT_NONE, ptr(out), ptr(ws),
                           B * C, N0, N1, N2, m0, m1, m2, float(scale), stream_ptr()), 'hno_dht3_crop')
     return out
@@ -138,14 +244,21 @@ def dht3_full_raw(x, scale):
     return out
 
 
-def pad_idht3_raw(z, spatial, scale, addend=None, act=ACT_NONE):
-    """z: (B,C,2m0,2m1,2m2) -> (B,C,N0,N1,N2) = act(scale * IDHT(pad(z)) + addend)."""
+def pad_idht3_raw(z, spatial, scale, addend=None, act=ACT_NONE, ld=None):
+    """z: (B,C,2m0,2m1,2m2) -> (B,C,N0,N1,N2) = act(scale * IDHT(pad(z)) + addend); ld: channel stride of the result (and of the
+    addend) when it is to be a channel-padded activation."""
     _need_gpu(z, addend)
     B, C = z.shape[:2]
     m0, m1, m2 = (s // 2 for s in z.shape[2:])
     N0, N1, N2 = (int(s) for s in spatial)
     L = _lib.lib()
     ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, N0, N1, N2, m0, m1, m2) // 4, device=z.device, dtype=torch.float32)
+    if ld is not None:
+        addend = to_layout(addend, ld)
+        out = act_empty(B, C, (N0, N1, N2), z.device, ld)
+        check(L.hno_pad_idht3_ld(ptr(z), ptr(addend), act, ptr(out), ptr(ws), B * C, N0, N1, N2, m0, m1, m2,
+                                 float(scale), ld, stream_ptr()), 'hno_pad_idht3_ld')
+        return out
     out = torch.empty((B, C, N0, N1, N2), device=z.device, dtype=torch.float32)
     check(L.hno_pad_idht3(ptr(z), ptr(addend), act, ptr(out), ptr(ws), B * C, N0, N1, N2, m0, m1, m2,
                           float(scale), stream_ptr()), 'hno_pad_idht3')
@@ -207,9 +320,11 @@ def _autocast_bf16():
 def pwconv_fwd_raw(xa, xb, W, bias, act, bf16=False):
     B, Ca = xa.shape[:2]
     Cb = xb.shape[1] if xb is not None else 0
-    Cout, V = W.shape[0], _flat_v(xa)
+    ld = chan_stride(xa)            # channel-padded operands: the kernel runs over V := ld voxels per channel
+    xb = to_layout(xb, ld)
+    Cout, V = W.shape[0], ld or _flat_v(xa)
     assert W.numel() == Cout * (Ca + Cb), 'weight shape does not match the concatenated input channels'
-    y = torch.empty((B, Cout) + tuple(xa.shape[2:]), device=xa.device, dtype=torch.float32)
+    y = act_like(xa, Cout)
     check(_lib.lib().hno_pwconv_fwd(ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(bias), ptr(y), B, Cout, V, act | (ACT_BF16 if bf16 else 0), stream_ptr()),
           'hno_pwconv_fwd')
     return y
@@ -221,16 +336,19 @@ def pwconv_bwd_raw(gy, y, xa, xb, W, act, has_bias, need_gxa=True, need_gxb=True
     gxa by act'(xa) (xa being the output of that activation)."""
     B, Ca = xa.shape[:2]
     Cb = xb.shape[1] if xb is not None else 0
-    Cout, V = W.shape[0], _flat_v(xa)
+    ld = chan_stride(xa)            # channel-padded operands (all of them): V := ld; gy's padding is zero, so is gxa's / gxb's
+    gy, y, xb = to_layout(gy, ld), to_layout(y, ld), to_layout(xb, ld)
+    Cout, V = W.shape[0], ld or _flat_v(xa)
     acc_bits = 0
     gxa = gxb = None
     if accumulate_into is not None:      # (gxa, gxb) buffers that already hold a gradient (None: fresh): += fused into the store
         gxa, gxb = accumulate_into
+        assert all(t is None or chan_stride(t) == ld for t in (gxa, gxb)), 'accumulation buffer in another layout'
         acc_bits = (1 if gxa is not None else 0) | (2 if gxb is not None else 0)
     if gxa is None and need_gxa:
-        gxa = torch.empty_like(xa)
+        gxa = act_like(xa)
     if gxb is None and xb is not None and need_gxb:
-        gxb = torch.empty_like(xb)
+        gxb = act_like(xb)
     dW = _grad_buffer(W)
     db = None
     if has_bias:
@@ -451,11 +569,12 @@ def spectral_chain_fwd_raw(x, W, modes, act, scale_fwd, inv_act):
     L, Lyr = _lib.lib(), len(Ws)
     ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, N0, N1, N2, m0, m1, m2) // 4, device=x.device, dtype=torch.float32)
     zall = torch.empty((Lyr + 1, B, C, 2 * m0, 2 * m1, 2 * m2), device=x.device, dtype=torch.float32)
-    u = torch.empty_like(x)
-    check(L.hno_dht3_planes(ptr(x), ptr(ws), B * C, N0, N1, N2, m0, m1, m2, stream_ptr()), 'hno_dht3_planes')
+    ld = chan_stride(x) or 0
+    u = act_like(x)
+    check(L.hno_dht3_planes(ptr(x), ptr(ws), B * C, N0, N1, N2, m0, m1, m2, ld, stream_ptr()), 'hno_dht3_planes')
     check(L.hno_spec_mid_fwd(ptr(ws), _layer_ptrs(Ws), ptr(zall), B, C, N0, m0, m1, m2, Lyr, 1, act, float(scale_fwd), stream_ptr()),
           'hno_spec_mid_fwd')
-    check(L.hno_idht3_planes(ptr(ws), None, inv_act, ptr(u), B * C, N0, N1, N2, m0, m1, m2, 1.0, stream_ptr()), 'hno_idht3_planes')
+    check(L.hno_idht3_planes(ptr(ws), None, inv_act, ptr(u), B * C, N0, N1, N2, m0, m1, m2, 1.0, ld, stream_ptr()), 'hno_idht3_planes')
     return zall[0], zall[1:], u
 
 
@@ -1045,10 +1164,11 @@ class PwConvFn(_HnoFunction):
     @staticmethod
     def forward(ctx, xa, xb, W, bias, act):
         ctx.leaf_params = _leaf_params(ctx, W, bias)
-        xa, xb, W, bias = _f32c(xa), _f32c(xb), _f32c(W), _f32c(bias)
+        xa, xb, W, bias = _f32a(xa), _f32a(xb), _f32c(W), _f32c(bias)
         _need_gpu(xa, xb, W, bias)
         ctx.wide = PwConvFn._wide(xa, xb, W)
         if ctx.wide:
+            xa = _f32c(xa)
             B, Cin = xa.shape[:2]
             Cout, V = W.shape[0], _flat_v(xa)
             w2 = W.reshape(1, Cout, Cin).expand(B, Cout, Cin).contiguous() if B > 1 else W.reshape(1, Cout, Cin)
@@ -1085,7 +1205,7 @@ class PwConvFn(_HnoFunction):
             dW = acc.reshape(W.shape)
             db = _chan_sum(g) if ctx.has_bias else None
             return gxa, None, dW, db, None
-        gxa, gxb, dW, db = pwconv_bwd_raw(_f32c(gy), y, xa, xb, W, ctx.act, ctx.has_bias, ctx.needs_input_grad[0],
+        gxa, gxb, dW, db = pwconv_bwd_raw(_f32a(gy), y, xa, xb, W, ctx.act, ctx.has_bias, ctx.needs_input_grad[0],
                                           ctx.needs_input_grad[1], defer=ctx.leaf_params and _release_use(W, bias) and _deferrable(W, bias),
                                           bias=bias, bf16=getattr(ctx, 'bf16', False))
         return gxa, gxb, dW, db, None
@@ -1238,24 +1358,27 @@ class XSBlockFn(_HnoFunction):
         the backward below folds it into the store of the concat-path gradient -- autograd's separate
         accumulation kernel (3 x 158 MB of traffic per step in HNOSeg-XS) disappears."""
         ctx.leaf_params = _leaf_params(ctx, map_w, map_b, cat_w, cat_b, *mix_ws)
-        x, skip, map_w, map_b, cat_w, cat_b = (_f32c(t) for t in (x, skip, map_w, map_b, cat_w, cat_b))
+        map_w, map_b, cat_w, cat_b = (_f32c(t) for t in (map_w, map_b, cat_w, cat_b))
         mix_ws = [_f32c(w) for w in mix_ws]
+        spatial = tuple(x.shape[2:])
+        if len(modes) == 2:                      # 2-D model on a (B, C, 1, H, W) view
+            modes = (0,) + tuple(modes)
+        modes = clamp_modes(modes, spatial)
+        # a channel-padded input stays padded through the block when both transform directions take the stride
+        x = _f32a(x) if (chan_stride(x) is not None and padded_ok(spatial, modes)) else _f32c(x)
+        skip = to_layout(skip, chan_stride(x))
         _need_gpu(x, skip, cat_w, *mix_ws)
         has_map = map_w is not None
         bf = _autocast_bf16()       # autocast: bf16 operands for the two spatial convolutions of the block
         ctx.bf16 = bf
         xm = pwconv_fwd_raw(x, skip, map_w, map_b, act, bf) if has_map else x
-        spatial = tuple(xm.shape[2:])
-        if len(modes) == 2:                      # 2-D model on a (B, C, 1, H, W) view
-            modes = (0,) + tuple(modes)
-        modes = clamp_modes(modes, spatial)
         n3 = float(np.prod(spatial))
         if spectral_chain_supported(xm, modes, len(mix_ws)):
             z0, zs, u = spectral_chain_fwd_raw(xm, mix_ws, modes, act, 1.0 / n3, act)
         else:
             z0 = dht3_crop_raw(xm, modes, 1.0 / n3)
             zs = specmix_fwd_raw(z0, mix_ws, 1, act)
-            u = pad_idht3_raw(zs[-1], spatial, 1.0, None, act)
+            u = pad_idht3_raw(zs[-1], spatial, 1.0, None, act, ld=chan_stride(xm))
         out = pwconv_fwd_raw(u, xm, cat_w, cat_b, act, bf)
         ctx.save_for_backward(x, skip, map_w, xm if has_map else None, z0, zs, u, cat_w, out, map_b, cat_b, *mix_ws)
         ctx.cfg = (has_map, modes, act, spatial, n3, map_b is not None, cat_b is not None, bool(passthrough))
@@ -1278,26 +1401,27 @@ class XSBlockFn(_HnoFunction):
         # The passthrough gradient is accumulated IN PLACE into the buffer autograd handed us only when that buffer is
         # provably private: produced by our own mapping-conv backward below (tagged), i.e. not summed by the engine, not
         # captured by a hook, not shared with another consumer.  Anything else takes the out-of-place add.
+        ld = chan_stride(xm)        # the block's activation layout (saved tensors keep their strides); gradients follow it
         private = g_pass is not None and getattr(g_pass, '_hno_private', False) and g_pass.dtype == torch.float32 \
-            and g_pass.is_contiguous()
-        g_pass = _f32c(g_pass) if g_pass is not None else None
+            and (g_pass.is_contiguous() if ld is None else chan_stride(g_pass) == ld)
+        g_pass = to_layout(g_pass, ld)
         _stats['pass_fused' if private else 'pass_unfused'] += g_pass is not None
 
         def plus_pass(t):
-            out = torch.empty_like(t)
-            check(_lib.lib().hno_add(ptr(t), ptr(g_pass), ptr(out), t.numel(), stream_ptr()), 'hno_add')
+            out = act_like(t)
+            check(_lib.lib().hno_add(ptr(t), ptr(g_pass), ptr(out), _ext(t), stream_ptr()), 'hno_add')
             return out
         # conv_concat backward; the SELU backward of PadInverse (g_u * act'(u)) is applied in its epilogue.  Without
         # a mapping conv the block input IS xm: the passthrough gradient is accumulated into the concat-path
         # gradient by the same kernel (gxb += ...).
         fuse_pass = private and not has_map
-        g_u, g_skipin, d_cat_w, d_cat_b = pwconv_bwd_raw(_f32c(g_out), out, u, xm, cat_w, act, cat_has_b, xa_act=act,
+        g_u, g_skipin, d_cat_w, d_cat_b = pwconv_bwd_raw(to_layout(g_out, ld), out, u, xm, cat_w, act, cat_has_b, xa_act=act,
                                                          accumulate_into=(None, g_pass) if fuse_pass else None, defer=late_cat, bias=cat_b, bf16=ctx.bf16)
         if g_pass is not None and not has_map and not fuse_pass:
             g_skipin = plus_pass(g_skipin)
         g_zl = dht3_crop_raw(g_u, modes, 1.0)                               # PadInverse^T
         g_z0, d_mix = specmix_bwd_raw(g_zl, z0, zs, mix_ws, 1, act, defer=late_mix)
-        g_xm = pad_idht3_raw(g_z0, spatial, 1.0 / n3, g_skipin, ACT_NONE)    # TransformCrop^T + skip gradient
+        g_xm = pad_idht3_raw(g_z0, spatial, 1.0 / n3, g_skipin, ACT_NONE, ld=ld)    # TransformCrop^T + skip gradient
         d_mix = tuple(d_mix.unbind(0))
         if not has_map:
             return (g_xm, None, None, None, d_cat_w, d_cat_b, None, None, None) + d_mix
@@ -1325,8 +1449,11 @@ class ConvK2S2Fn(_HnoFunction):
         _need_gpu(x, W, bias)
         B, Cin, D, H, Wd = x.shape
         Cout = W.shape[0]
-        y = torch.empty((B, Cout, D // 2 + 1, H // 2 + 1, Wd // 2 + 1), device=x.device, dtype=torch.float32)
-        check(_lib.lib().hno_conv_k2s2_fwd(ptr(x), ptr(W), ptr(bias), ptr(y), B, Cin, Cout, D, H, Wd, act, stream_ptr()),
+        so = (D // 2 + 1, H // 2 + 1, Wd // 2 + 1)
+        # first producer of the HNOSeg-XS activations: channel-padded when the model asked for it (ops.channel_padded)
+        ld = _pad_ld(np.prod(so)) if (getattr(_PAD, 'on', False) and so[0] > 1 and int(np.prod(so)) % 32) else None
+        y = act_empty(B, Cout, so, x.device, ld)
+        check(_lib.lib().hno_conv_k2s2_fwd(ptr(x), ptr(W), ptr(bias), ptr(y), B, Cin, Cout, D, H, Wd, act, ld or 0, stream_ptr()),
               'hno_conv_k2s2_fwd')
         ctx.save_for_backward(x, W, y, bias)
         ctx.act, ctx.has_bias = act, bias is not None
@@ -1337,14 +1464,15 @@ class ConvK2S2Fn(_HnoFunction):
         x, W, y, bias = ctx.saved_tensors
         if ctx.needs_input_grad[0]:
             raise _lib.HnoError('conv_in input gradient is not implemented (the image needs none)')
-        gy = _f32c(gy)
+        ld = chan_stride(y)
+        gy = to_layout(gy, ld)
         B, Cin, D, H, Wd = x.shape
         Cout = W.shape[0]
         dW = _grad_buffer(W)
         db = (_grad_buffer(bias) if bias is not None else torch.empty(Cout, device=W.device, dtype=torch.float32)) if ctx.has_bias else None
         ws = _wgrad_ws(Cin * 8, Cout, x.device)
         check(_lib.lib().hno_conv_k2s2_bwd(ptr(gy), ptr(y), ptr(x), ptr(W), None, ptr(dW), ptr(db), ptr(ws), B, Cin, Cout,
-                                           D, H, Wd, ctx.act, stream_ptr()), 'hno_conv_k2s2_bwd')
+                                           D, H, Wd, ctx.act, ld or 0, stream_ptr()), 'hno_conv_k2s2_bwd')
         return None, dW, db, None
 
 
@@ -1385,9 +1513,6 @@ class UpSoftmaxFn(_HnoFunction):
 
 
 # ------------------------------------------------------------------------- inference head
-import contextlib
-import threading
-
 _HEAD_MODE = threading.local()
 
 

@@ -99,6 +99,75 @@ def test_fused_spectral_middle_vs_three_kernel_path(pkg, n):
     assert rel_err(gu.cpu().numpy(), ops.pad_idht3_raw(z1[-1], (n, n, n), 1.0, None, ops.ACT_NONE).cpu().numpy()) < 2e-6
 
 
+@pytest.mark.parametrize('n', [65, 33])
+def test_channel_padded_activations_match_contiguous(pkg, n, monkeypatch):
+    """Round 3: inside HNOSeg-XS the activations live with their channel stride rounded up to 128 B (ops.channel_padded; the odd
+    65^3 = 274625-float rows of the contiguous layout cost the pointwise kernels 1.25x - 1.33x over-fetch).  Same numbers either way:
+    each op on a padded tensor against the same op on the contiguous one (bit-exact where no reduction order changes), then the
+    whole model, loss and every gradient, with HNO_PAD_ACT on and off."""
+    from multimodal_3d_image_segmentation_amd import ops
+    from multimodal_3d_image_segmentation_amd.nets.hnosegxs import HNOSegXS
+    torch.manual_seed(5)
+    modes, V = (10, 14, 14), n ** 3
+    ld = ops._pad_ld(V)
+    assert ld % 32 == 0 and V < ld < V + 32 and ops.padded_ok((n, n, n), modes)
+    x = torch.randn(2, 24, n, n, n, device='cuda')
+    xp = ops.to_layout(x, ld)
+    assert ops.chan_stride(xp) == ld and ops.chan_stride(x) is None and bool((xp == x).all())
+    flat = xp.untyped_storage()
+    pad = torch.empty(0, device='cuda').set_(flat, 0, (48, ld))[:, V:]
+    assert bool((pad == 0).all())
+    assert bool((ops.to_layout(xp, None) == x).all()) and ops._f32c(xp).is_contiguous()
+    # transforms with a channel stride: bit-exact (same kernels, other plane base addresses)
+    z = ops.dht3_crop_raw(x, modes, 1.0 / V)
+    assert bool((ops.dht3_crop_raw(xp, modes, 1.0 / V) == z).all())
+    add = torch.randn_like(x)
+    y = ops.pad_idht3_raw(z, (n, n, n), 1.0, add, ops.ACT_SELU)
+    yp = ops.pad_idht3_raw(z, (n, n, n), 1.0, add, ops.ACT_SELU, ld=ld)
+    assert ops.chan_stride(yp) == ld and bool((yp == y).all())
+    assert bool((torch.empty(0, device='cuda').set_(yp.untyped_storage(), 0, (48, ld))[:, V:] == 0).all())
+    Ws = [torch.randn(24, 24, device='cuda') * 0.2 for _ in range(3)]
+    a = ops.spectral_chain_fwd_raw(x, Ws, modes, ops.ACT_SELU, 1.0 / V, ops.ACT_SELU)
+    b = ops.spectral_chain_fwd_raw(xp, Ws, modes, ops.ACT_SELU, 1.0 / V, ops.ACT_SELU)
+    assert all(bool((u == v).all()) for u, v in zip(a, b))
+    # pointwise layer: forward bit-exact per voxel; weight gradients sum the same products in another order
+    W = (torch.randn(24, 48, device='cuda') * 0.2).requires_grad_(True)
+    bias = torch.randn(24, device='cuda').requires_grad_(True)
+    x2 = torch.randn_like(x)
+    outs = []
+    for xa, xb in ((x, x2), (xp, ops.to_layout(x2, ld))):
+        xa = xa.detach().requires_grad_(True)
+        o = ops.PwConvFn.apply(xa, xb, W, bias, ops.ACT_SELU)
+        g = torch.autograd.grad((o * add).sum(), [xa, W, bias])
+        outs.append((o, *g))
+    assert ops.chan_stride(outs[1][0]) == ld and bool((outs[0][0] == outs[1][0]).all())
+    assert ops.chan_stride(outs[1][1]) == ld and bool((outs[0][1] == outs[1][1]).all())
+    for i in (2, 3):
+        assert rel_err(outs[1][i].cpu().numpy(), outs[0][i].cpu().numpy()) < 2e-6
+    # the model end to end
+    size = 2 * n - 2
+    img = torch.randn(1, 4, size, size, size, device='cuda')
+    lab = torch.randint(0, 4, (1, 1, size, size, size), device='cuda').to(torch.uint8)
+    res = []
+    for flag in ('0', '1'):
+        monkeypatch.setenv('HNO_PAD_ACT', flag)
+        torch.manual_seed(11)
+        net = HNOSegXS(4, 4, 24, [3, 3, 3, 3, 3] if n == 65 else [3, 3, 3], (10, 14, 14), device='cuda')
+        seen = []
+        h = net.conv1.register_forward_hook(lambda m, i, o: seen.append(ops.chan_stride(o)))
+        probs = net(img)
+        h.remove()
+        assert seen == [ld if flag == '1' else None]
+        loss, _ = ops.SegLossFn.apply(probs, lab, 0, 0.0)
+        loss.backward()
+        res.append((probs.detach(), float(loss), [p.grad.clone() for p in net.parameters()]))
+    assert res[1][0].is_contiguous() and bool((res[0][0] == res[1][0]).all())
+    assert res[0][1] == res[1][1]
+    for g0, g1 in zip(res[0][2], res[1][2]):
+        assert bool(torch.isfinite(g1).all())
+        assert rel_err(g1.cpu().numpy(), g0.cpu().numpy()) < 2e-5
+
+
 def test_dht_roundtrip_property_full_size(pkg):
     """Size-independent property at the benchmark size: crop(pad_inverse(z)) * 1 == z (the kept
     modes of an inverse transform of a band-limited spectrum are the spectrum itself) and linearity."""

@@ -50,11 +50,11 @@ ws = torch.empty(nws // 4, device=dev)
 P, S = pkg._lib.ptr, pkg._lib.stream_ptr
 for dbg, name in ((0, 'full'), (1 << 8, 'nsplit 1'), (2 << 8, 'nsplit 2'), (3 << 8, 'nsplit 3'), (4 << 8, 'nsplit 4'), (8 << 8, 'nsplit 8'), (3, 'neither'), (0x20, 'return at start'), (0x40, 'return after taps'), (0x63, 'neither, no flush'), (0x60, 'no flush')):
     L.hno_set_debug(dbg)
-    t = graph_time(lambda: L.hno_upsoftmax_bwd(P(gp), P(probs), P(g_lr), P(ws), 2, 4, 65, 65, 65, 128, 128, 128, 1, S()), n=10)
+    t = graph_time(lambda: L.hno_upsoftmax_bwd(P(gp), P(probs), P(g_lr), P(ws), 2, 4, 65, 65, 65, 128, 128, 128, 1, 0, S()), n=10)
     print(f'upsoftmax_bwd [{name}]: {t:.1f} us')
 L.hno_set_debug(0)
 with pkg._lib.KernelProfile() as kp:
-    for _ in range(20): L.hno_upsoftmax_bwd(P(gp), P(probs), P(g_lr), P(ws), 2, 4, 65, 65, 65, 128, 128, 128, 1, S())
+    for _ in range(20): L.hno_upsoftmax_bwd(P(gp), P(probs), P(g_lr), P(ws), 2, 4, 65, 65, 65, 128, 128, 128, 1, 0, S())
 for k, v in kp.summary().items(): print(k, v)
 
 # conv_in
@@ -65,12 +65,12 @@ gyk = torch.randn_like(yk); dWk = torch.empty_like(Wk); dbk = torch.empty_like(b
 wsk = torch.empty(L.hno_pwconv_bwd_workspace_bytes(32, 24) // 4, device=dev)
 for grid in (1280, 1536, 2048, 3072):
     L.hno_set_debug(grid << 8)
-    tf = graph_time(lambda: L.hno_conv_k2s2_fwd(P(xin), P(Wk), P(bk), P(yk), 2, 4, 24, 128, 128, 128, 1, S()), n=10)
+    tf = graph_time(lambda: L.hno_conv_k2s2_fwd(P(xin), P(Wk), P(bk), P(yk), 2, 4, 24, 128, 128, 128, 1, 0, S()), n=10)
     print(f'conv_k2s2 grid {grid}: fwd {tf:.1f} us')
 for grid in (0, 768, 1024):
     L.hno_set_debug(grid << 8)
-    tf = graph_time(lambda: L.hno_conv_k2s2_fwd(P(xin), P(Wk), P(bk), P(yk), 2, 4, 24, 128, 128, 128, 1, S()), n=10)
-    tb = graph_time(lambda: L.hno_conv_k2s2_bwd(P(gyk), P(yk), P(xin), P(Wk), None, P(dWk), P(dbk), P(wsk), 2, 4, 24, 128, 128, 128, 1, S()), n=10)
+    tf = graph_time(lambda: L.hno_conv_k2s2_fwd(P(xin), P(Wk), P(bk), P(yk), 2, 4, 24, 128, 128, 128, 1, 0, S()), n=10)
+    tb = graph_time(lambda: L.hno_conv_k2s2_bwd(P(gyk), P(yk), P(xin), P(Wk), None, P(dWk), P(dbk), P(wsk), 2, 4, 24, 128, 128, 128, 1, 0, S()), n=10)
     print(f'conv_k2s2 grid {grid or "default"}: fwd {tf:.1f} us, bwd (+reduce) {tb:.1f} us')
 L.hno_set_debug(0)
 
