@@ -2215,18 +2215,6 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const f
     for (; t < t_end; t += NWV, ++it) {
         HNO_STAMP(a.stamps, 24 + it * 6);
         const int plane = NP == 2 ? (t >> 1) : t;
-        load_e(t);
-        // ---- folds of the +-k1 rows
-        float sR[KM1], dR[KM1], sI[KM1], dI[KM1];
-#pragma unroll
-        for (int ks = 0; ks < KM1; ++ks) {
-            const bool ok = 4 * ks + q <= m1;
-            sR[ks] = ok ? erp[ks] + erm[ks] : 0.f;
-            dR[ks] = ok ? erp[ks] - erm[ks] : 0.f;
-            sI[ks] = ok ? eip[ks] + eim[ks] : 0.f;
-            dI[ks] = ok ? eip[ks] - eim[ks] : 0.f;
-        }
-        __builtin_amdgcn_sched_barrier(0);
         // ---- chunk geometry of the item (rows [r0, r0 + nr) of the plane, LDS float offset): X = 0: rows [0, 17) (+ [49, 65) at 1112);
         //      X = 1: rows [17, 49);  NP = 1: rows [0, 33)
         // float index of the plane from the aligned base: consecutive (b, c) volumes are ldbc floats apart (channel-padded
@@ -2242,7 +2230,42 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const f
         const int c1_r0 = 49, c1_lo = 1112;
         const unsigned fA = f0 + (unsigned)(c0_r0 * N2), fC = f0 + 49u * N2;
         const unsigned shA = fA & 3u, shC = fC & 3u;
+        load_e(t);
+        // ---- folds of the +-k1 rows
+        float sR[KM1], dR[KM1], sI[KM1], dI[KM1];
+#pragma unroll
+        for (int ks = 0; ks < KM1; ++ks) {
+            const bool ok = 4 * ks + q <= m1;
+            sR[ks] = ok ? erp[ks] + erm[ks] : 0.f;
+            dR[ks] = ok ? erp[ks] - erm[ks] : 0.f;
+            sI[ks] = ok ? eip[ks] + eim[ks] : 0.f;
+            dI[ks] = ok ? eip[ks] - eim[ks] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (a.stamps) asm volatile("s_nop 0" ::"v"(sR[0]), "v"(dI[KM1 - 1]));
+        if (HAS_ADD) {
+            // The residual rows go by LDS-DMA straight into the item's image -- the same aligned 16-byte groups the epilogue reads --
+            // at the TOP of the item, ahead of the operand loads: one HBM round trip per item, overlapped with the operands' L2 round
+            // trip and covered by the other waves of the SIMD.  The GEMM results are then added into the image (read - add - write;
+            // ds_add_f32 was measured at ~0.4 lanes per cycle and CU: 93 us per launch) and the epilogue is the one without a
+            // residual.  Loading the residual in the epilogue (two groups ahead) paid the HBM latency five times per item: 37 us
+            // per launch inside a training step against 23.5 us without residual (in isolation the 53 MB residual sat in the MALL).
+            // Lanes beyond the chunk are masked: they would overwrite the neighbouring chunk's image.
+            const unsigned ob = (unsigned)(size_t)obuf;
+            const int nch = (NP == 2 && X == 0) ? 2 : 1;
+#pragma unroll 1
+            for (int ch = 0; ch < nch; ++ch) {
+                const unsigned fch = ch ? fC : fA;
+                const unsigned n = NP == 1 ? (unsigned)(N1 * N2) : (X == 0 ? (ch ? 16u : 17u) : 32u) * N2;
+                const int ng = NP == 1 ? NG0 : (X == 0 ? NG0 : NGB);
+                const unsigned lim = (fch & 3u) + n, lo = ch ? (unsigned)c1_lo : 0u;
+                const unsigned goff = ((fch & ~3u) + 4u * lane) * 4u;
+#pragma unroll 1
+                for (int j = 0; j < ng; ++j)
+                    if (4u * (64u * j + lane) < lim)
+                        dma_piece16(add_al, goff + 1024u * j, __builtin_amdgcn_readfirstlane(ob + (lo + 256u * j) * 4u));
+            }
+        }
         HNO_STAMP(a.stamps, 25 + it * 6);
         // ---- axis H, tile X: F[n1][k2] = sum_k1 E[k1][k2] e^{+i th k1 n1}: cR, cI = cosine sums of re / im, sR_, sI_ = sine sums
         f32x4 cRe = {0.f, 0.f, 0.f, 0.f}, cIm = cRe, sRe = cRe, sIm = cRe;
@@ -2269,6 +2292,11 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const f
         float *img0 = obuf + shA - c0_r0 * N2, *img1 = obuf + c1_lo + shC - c1_r0 * N2;
         const int n1p = 1 + 16 * X + 4 * q, n1m = N1 - n1p;     // rows of accumulator register 0 (plus tile ascending, mirror descending)
         float *rowP = img0 + n1p * N2, *rowM = ((NP == 2 && X == 0) ? img1 : img0) + n1m * N2;
+        // image element <- v (no residual) or += scale v on top of the residual the DMA put there
+        auto put = [&](float *dst, float v) {
+            if (HAS_ADD) *dst = fmaf(v, a.scale, *dst);
+            else *dst = v;
+        };
         // ---- axis W: O[n1][n2] = sum_k2 FR cos - FI sin, mirror column N2 - n2 gets +; the A operands are the F registers
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
@@ -2282,12 +2310,25 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const f
                 ms = mfma16(FIm[r], bws[nt][r], ms);
             }
             const int n2 = 1 + 16 * nt + l15;
+            if (HAS_ADD) {
+                if (nt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the residual is in the image (long since: in-order
+                                                                                // return behind the operand loads)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                rowP[r * N2 + n2] = pc[r] - ps[r];
-                rowP[r * N2 + N2 - n2] = pc[r] + ps[r];
-                rowM[-r * N2 + n2] = mc[r] - ms[r];
-                rowM[-r * N2 + N2 - n2] = mc[r] + ms[r];
+                for (int r = 0; r < 4; ++r) {   // four at a time: sixteen residual values in flight spilled registers
+                    const float v0 = rowP[r * N2 + n2], v1 = rowP[r * N2 + N2 - n2], v2 = rowM[-r * N2 + n2], v3 = rowM[-r * N2 + N2 - n2];
+                    rowP[r * N2 + n2] = fmaf(pc[r] - ps[r], a.scale, v0);
+                    rowP[r * N2 + N2 - n2] = fmaf(pc[r] + ps[r], a.scale, v1);
+                    rowM[-r * N2 + n2] = fmaf(mc[r] - ms[r], a.scale, v2);
+                    rowM[-r * N2 + N2 - n2] = fmaf(mc[r] + ms[r], a.scale, v3);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    rowP[r * N2 + n2] = pc[r] - ps[r];
+                    rowP[r * N2 + N2 - n2] = pc[r] + ps[r];
+                    rowM[-r * N2 + n2] = mc[r] - ms[r];
+                    rowM[-r * N2 + N2 - n2] = mc[r] + ms[r];
+                }
             }
         }
         HNO_STAMP(a.stamps, 27 + it * 6);
@@ -2300,8 +2341,8 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const f
             zm += __shfl_xor(zm, 32);
             // ... but the lane layout of F is (column n1 index = l15, k2 group q): the sum over q is the row's value
             if (q0) {
-                img0[(1 + 16 * X + l15) * N2] = zp;
-                ((NP == 2 && X == 0) ? img1 : img0)[(N1 - 1 - 16 * X - l15) * N2] = zm;
+                put(img0 + (1 + 16 * X + l15) * N2, zp);
+                put(((NP == 2 && X == 0) ? img1 : img0) + (N1 - 1 - 16 * X - l15) * N2, zm);
             }
         }
         // ---- output row 0 (item 0): F[0][k2] = plain sum over all k1 (the k1 = 0 row was doubled by the fold)
@@ -2341,11 +2382,11 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const f
                 s_ += __shfl_xor(s_, 32);
                 const int n2 = 1 + 16 * nt + l15;
                 if (q0) {
-                    img0[n2] = c - s_;
-                    img0[N2 - n2] = c + s_;
+                    put(img0 + n2, c - s_);
+                    put(img0 + N2 - n2, c + s_);
                 }
             }
-            if (lane == 0) img0[0] = z0;
+            if (lane == 0) put(img0, z0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -2364,30 +2405,15 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const f
             const float *limg = obuf + (ch ? c1_lo : 0);
             const unsigned sh = fch & 3u;
             float *gbase = out_al + (fch & ~3u) + 4 * lane;
-            const float *abase = HAS_ADD ? add_al + (fch & ~3u) + 4 * lane : nullptr;
-            // residual: aligned 16-byte loads of the same groups, two groups ahead of their use (a group that straddles a chunk end
-            // also holds neighbouring rows of the same tensor; groups beyond the chunk are not touched)
-            auto ld_add = [&](int j) -> f32x4 {
-                return (j < ng && 4 * (64u * j + lane) < sh + n) ? *reinterpret_cast<const f32x4 *>(abase + 256 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
-            };
-            f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
-            if (HAS_ADD) {
-                r0 = ld_add(0);
-                r1 = ld_add(1);
-            }
+            // (with a residual the image already holds scale * O + residual: see the DMA above)
+            const f32x2 sc = {HAS_ADD ? 1.f : a.scale, HAS_ADD ? 1.f : a.scale};
 #pragma unroll 1
             for (int j = 0; j < ng; ++j) {
                 const int e0 = (int)(4 * (64u * j + lane)) - (int)sh;
-                const f32x4 r = r0;
-                if (HAS_ADD) {
-                    r0 = r1;
-                    r1 = ld_add(j + 2);
-                }
                 const f32x4 o = *reinterpret_cast<const f32x4 *>(limg + 256 * j + 4 * lane);
-                // scale, residual and activation on the packed fp32 pipe, two elements per instruction
-                const f32x2 sc = {a.scale, a.scale};
-                f32x2 x0 = __builtin_elementwise_fma(f32x2{o[0], o[1]}, sc, f32x2{r[0], r[1]});
-                f32x2 x1 = __builtin_elementwise_fma(f32x2{o[2], o[3]}, sc, f32x2{r[2], r[3]});
+                // scale and activation on the packed fp32 pipe, two elements per instruction
+                f32x2 x0 = f32x2{o[0], o[1]} * sc;
+                f32x2 x1 = f32x2{o[2], o[3]} * sc;
                 if (!lin) {   // wave-uniform
                     x0 = selu_like_pk(x0, ap, aq);
                     x1 = selu_like_pk(x1, ap, aq);

@@ -199,6 +199,39 @@ def test_pad_idht_fused_epilogue(pkg):
     assert rel_err(got.cpu().numpy(), want.numpy()) < 5e-6
 
 
+@pytest.mark.parametrize('n', [65, 33])
+def test_pad_idht_residual_at_benchmark_planes_vs_float64(pkg, n):
+    """The 65 x 65 / 33 x 33 inverse plane kernel takes its residual by LDS-DMA into the output image and adds the GEMM results on
+    top (round 3): scale, residual and activation against the float64 dense formulation, on contiguous and on channel-padded
+    tensors, and with the base pointer 1 .. 3 floats off a 16-byte boundary (equal phase of residual and output is required)."""
+    from multimodal_3d_image_segmentation_amd import ops
+    torch.manual_seed(7)
+    B, C, modes = 2, 24, (10, 14, 14)
+    z = torch.randn(B, C, 20, 28, 28, device='cuda')
+    add = torch.randn(B, C, n, n, n, device='cuda')
+    sel = [(0, 0), (1, C - 1), (1, 5)]
+    dense = {bc: O().pad_idht_dense(z[bc].cpu().double()[None, None], (n, n, n))[0, 0] for bc in sel}
+    for scale, act, fn in ((0.5, ops.ACT_SELU, F.selu), (1.0 / n ** 3, ops.ACT_NONE, lambda t: t)):
+        out = ops.pad_idht3_raw(z, (n, n, n), scale, add, act)
+        for bc in sel:
+            want = fn(scale * dense[bc] + add[bc].cpu().double())
+            assert rel_err(out[bc].cpu().numpy(), want.numpy()) < 5e-6
+        ld = ops._pad_ld(n ** 3)
+        outp = ops.pad_idht3_raw(z, (n, n, n), scale, ops.to_layout(add, ld), act, ld=ld)
+        assert ops.chan_stride(outp) == ld and bool((outp == out).all())
+    for shift in (1, 2, 3):
+        abuf, obuf = torch.randn(B * C * n ** 3 + 8, device='cuda'), torch.full((B * C * n ** 3 + 8,), 7.0, device='cuda')
+        a_s, o_s = abuf[shift:shift + B * C * n ** 3].view(B, C, n, n, n), obuf[shift:shift + B * C * n ** 3].view(B, C, n, n, n)
+        L = pkg._lib.lib()
+        ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, n, n, n, *modes) // 4, device='cuda')
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        pkg._lib.check(L.hno_pad_idht3(P(z), P(a_s), ops.ACT_SELU, P(o_s), P(ws), B * C, n, n, n, *modes, 0.5, pkg._lib.stream_ptr()), 'x')
+        for bc in sel[:2]:
+            want = F.selu(0.5 * dense[bc] + a_s[bc].cpu().double())
+            assert rel_err(o_s[bc].cpu().numpy(), want.numpy()) < 5e-6
+        assert bool((obuf[:shift] == 7.0).all()) and bool((obuf[shift + B * C * n ** 3:] == 7.0).all())   # nothing outside the view
+
+
 @pytest.mark.parametrize('Ca,Cb,Cout,V,act,bias', [
     (24, 24, 24, (9, 10, 11), 'selu', True),   # conv_concat
     (24, 0, 24, (7, 7, 7), 'selu', True),      # conv1
