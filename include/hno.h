@@ -128,6 +128,11 @@ int hno_dht3_planes(const float *x, void *workspace, int BC, int N0, int N1, int
                     void *stream);
 int hno_spec_mid_fwd(void *workspace, const float *const *W_layers, float *zs, int B, int C, int N0, int m0, int m1, int m2, int L,
                      int residual, int act, float scale, void *stream);
+/* backward of the same chain: workspace = hno_dht3_planes of the block-output gradient on entry, operand of hno_idht3_planes (which
+ * yields the block-input gradient) on return; zs as written by hno_spec_mid_fwd; dW (L, C, C); slab_workspace of
+ * hno_specmix_bwd_workspace_bytes(B, C, M, L) bytes; bit 8 of `residual` defers the slab reduction (hno_set_defer_reduce). */
+int hno_spec_mid_bwd(void *workspace, const float *const *W_layers, const float *zs, float *dW, void *slab_workspace, int B, int C,
+                     int N0, int m0, int m1, int m2, int L, int residual, int act, float scale, void *stream);
 int hno_idht3_planes(const void *workspace, const float *addend, int act, float *out, int BC, int N0, int N1, int N2, int m0, int m1,
                      int m2, float scale, long long ldbc, void *stream);
 /* hno_dht3_crop / hno_pad_idht3 on channel-padded activations: ldbc = stride (floats) between consecutive (b, c) volumes of x /

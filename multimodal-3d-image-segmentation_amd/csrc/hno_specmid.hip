@@ -1,6 +1,8 @@
 // The spectral middle of an HNO-XS block in ONE kernel per direction:
 //
 //   forward :  axis-D transform + Re -/+ Im + crop  ->  L x ( z <- act((W + I) z) )  ->  pad + axis-D inverse transform
+//   backward:  the same two D steps (PadInverse^T = TransformCrop and vice versa) around the BACKWARD of the layer stack: per layer
+//              g <- g * act'(z_l), dW_l += g z_{l-1}^T, g <- (W_l + I)^T g; the gradients of the cropped spectra never reach memory
 //
 // i.e. what dht_fwd_d_kernel, specmix_fwd_loop_kernel and dht_inv_d_kernel (hno_dht.hip, hno_specmix.hip) do in three launches
 // between the two plane transforms.  Reference: TransformCrop.forward (nets/hnosegxs.py:378-410, axis D of dhtn, nets/dht.py:16-36),
@@ -37,6 +39,7 @@ struct MidArgs {
     int B, L, residual, act;
     int m1, m2;
     float scale;
+    float *partials;           // backward: one slab of L x C x C weight-gradient partial sums per workgroup
     long long *stamps;         // phase stamps of workgroup 0, wave 0 (debug flag 1024)
     int dbg;                   // timing aids (results wrong): 1 = no forward D arithmetic, 2 = no layers, 4 = no inverse D step, 8 = no loads
 };
@@ -50,8 +53,8 @@ __device__ __forceinline__ int mid_chan(int ks, int h) { return (ks & 3) + 8 * (
 // matrix-core work.  Twiddles are the A operands (registers, loaded once in lane order).
 //   forward : rows k0 = 0..15, K = n (folded: f[n] = v[n] + v[N0 - n] against cos, d[n] = v[n] - v[N0 - n] against sin), 9 k-steps
 //   inverse : rows n = 1 + 16 mt + i, K = k0 (3 k-steps); n = 0 is the plain sum of the cosine coefficients
-template <int N0, int M0>
-__global__ __launch_bounds__(512, 2) void spec_mid_fwd_kernel(MidArgs a) {
+template <int N0, int M0, bool BWD>
+__global__ __launch_bounds__(512, BWD ? 1 : 2) void spec_mid_kernel(MidArgs a) {
     constexpr int C = 24, NK = 12, J = N0 / 2, K0 = M0 + 1;
     constexpr int KC = (J + 1 + 3) / 4;               // k-steps of the forward D step (n = 0 .. 4 KC - 1)
     constexpr int KI = (K0 + 3) / 4;                   // k-steps of the inverse D step (k0 = 0 .. 4 KI - 1)
@@ -60,8 +63,14 @@ __global__ __launch_bounds__(512, 2) void spec_mid_fwd_kernel(MidArgs a) {
     constexpr int NT = (NMODE + 31) / 32;             // 32-mode MFMA tiles
     constexpr int NCT = C / 2;                         // column tiles of the D steps: 2 channels x 2 parts x 4 columns
     static_assert(J % 16 == 0 && K0 <= 16, "tile shapes");
-    __shared__ float PQ[C * 2 * 2 * K0 * 4];          // [c][part][P | Q][k0][column]
-    __shared__ float ZL[C * NT * 32];                 // [c][mode]: output of the last layer
+    constexpr int NPQ = C * 2 * 2 * K0 * 4, NZL = C * NT * 32;
+    constexpr int GLD = 34;                            // row stride of the G / Z tiles: == 2 (mod 4), conflict-free 16x16x4 operand reads
+    constexpr int TILE = 2 * 32 * GLD;                 // backward: [o][mode] and [i][mode] tiles of one wave
+    extern __shared__ float lds[];
+    float *PQ = lds;                                   // [c][part][P | Q][k0][column]
+    float *ZL = lds + NPQ;                             // [c][mode]: output of the last layer (backward: gradient of the first layer's input)
+    float *GZ = ZL + NZL;                              // backward: NT tiles
+    float *MINE = GZ + NT * TILE;                      // backward: per-wave weight-gradient fragments [wave][l][o][i]
     if (a.dbg & 16) return;
     HNO_STAMP(a.stamps, 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -73,7 +82,11 @@ __global__ __launch_bounds__(512, 2) void spec_mid_fwd_kernel(MidArgs a) {
     const int pairs = (K1S + 1) / 2, G8 = (a.B * pairs + 7) & ~7;
     const int w8 = blockIdx.x / G8, gidx = blockIdx.x - w8 * G8;
     const int b = gidx / pairs, k1s = 2 * (gidx - b * pairs) + (w8 >> 2), kt2 = w8 & 3;
-    if (b >= a.B || k1s >= K1S) return;
+    if (b >= a.B || k1s >= K1S) {
+        if (BWD)
+            for (int i = tid; i < a.L * C * C; i += 512) a.partials[(size_t)blockIdx.x * (a.L * C * C) + i] = 0.f;
+        return;
+    }
     const int k1 = k1s - m1;
     const size_t pstride = (size_t)2 * CP;            // floats per n0 plane
     // column of the D-step tiles held by this lane: j = column of the k2 tile, re / im part, channel within the pair
@@ -115,8 +128,18 @@ __global__ __launch_bounds__(512, 2) void spec_mid_fwd_kernel(MidArgs a) {
             w[ks] = wrow ? raw[ks] + ((dsel == row) ? res : 0.f) : 0.f;
         }
     };
+    // backward: A operand of g <- W'^T g: lane (row cl = input channel, k-slot half h) holds W'[chan(ks, h)][cl]
+    const unsigned wlt = 4u * h * C + (unsigned)(wrow ? cl : 0);
+    auto load_wt_raw = [&](const float *Wp, float (&w)[NK]) {
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) w[ks] = Wp[wlt + ((ks & 3) + 8 * (ks >> 2)) * C];
+    };
+    auto wsel = [&](int l) -> const float * { return l == 0 ? a.W[0] : (l == 1 ? a.W[1] : (l == 2 ? a.W[2] : a.W[3])); };
     float wraw[NK];
-    if (wave < NT) load_w_raw(a.W[0], wraw);
+    if (wave < NT) {
+        if (BWD) load_wt_raw(wsel(a.L - 1), wraw);
+        else load_w_raw(a.W[0], wraw);
+    }
     // ---------------- phase 1: forward D step.  A wave owns the column tiles wave and wave + 8; the loads of BOTH are issued before the
     //                  first product (one memory round trip per wave instead of two: the columns come from another XCD's writes)
     {
@@ -193,15 +216,98 @@ __global__ __launch_bounds__(512, 2) void spec_mid_fwd_kernel(MidArgs a) {
             z[ks] = valid ? hv : 0.f;
         }
         float *ob = a.zs + (size_t)b * sample;
-        if (valid) {
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks) ob[(size_t)mid_chan(ks, h) * (S0 * S1 * S2) + zoff] = z[ks];
-        }
         const float ap = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f;
         const float aq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
         const bool lin = a.act == HNO_ACT_NONE;
         float w[NK];
-        fin_w(wraw, w);
+        fin_w(wraw, w);      // (residual identity on the diagonal, zero rows >= C: the same for W' and W'^T)
+        if (BWD) {
+            // ---- backward of the layer stack on this wave's 32 modes; z holds the incoming gradient (the cropped spectrum of g_u).
+            // Saved activations come from zs (z_0 .. z_L; loads unconditional at offset 0 for unkept positions and selected away),
+            // one layer ahead of their use; the weight gradient of a layer is a 32 x 32 x 32 product of the G / Z tiles the wave
+            // stages through its own LDS (channels become MFMA rows), stored once per layer into the wave's fragment area.
+            float *G = GZ + wave * TILE, *Z = G + 32 * GLD;
+            const int nslab = a.L * C * C;
+            float *mine = MINE + wave * nslab;
+            const float *ga = G + l15 * GLD + q, *za = Z + l15 * GLD + q;
+            auto load_z = [&](const float *base, float (&v)[NK]) {
+#pragma unroll
+                for (int ks = 0; ks < NK; ++ks) v[ks] = base[(size_t)mid_chan(ks, h) * (S0 * S1 * S2) + zoff];
+            };
+            float zo[NK], zi[NK];
+            load_z(ob + (size_t)a.L * layer, zo);
+            load_z(ob + (size_t)(a.L - 1) * layer, zi);
+            HNO_STAMP(a.stamps, 3);
+#pragma unroll 1
+            for (int l = ((a.dbg & 2) ? -1 : a.L - 1); l >= 0; --l) {
+                float zn[NK], nraw[NK];
+                if (l > 0) {
+                    load_z(ob + (size_t)(l - 1) * layer, zn);
+                    load_wt_raw(wsel(l - 1), nraw);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < NK; ++ks) {
+                    const int ch = mid_chan(ks, h);
+                    const float y = valid ? zo[ks] : 0.f;
+                    z[ks] *= (y > 0.f || lin) ? ap : y + aq;
+                    G[ch * GLD + cl] = z[ks];
+                    Z[ch * GLD + cl] = valid ? zi[ks] : 0.f;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                f32x4 dw[2][2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < 2; ++nn) dw[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    float av[2], bv[2];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        av[m] = ga[m * 16 * GLD + kk * 4];
+                        bv[m] = za[m * 16 * GLD + kk * 4];
+                    }
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int nn = 0; nn < 2; ++nn) dw[m][nn] = mfma16(av[m], bv[nn], dw[m][nn]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                float *dst = mine + l * C * C;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int o = m * 16 + q * 4 + r, i = nn * 16 + l15;
+                            if (o < C && i < C) dst[o * C + i] = dw[m][nn][r];
+                        }
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < NK; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ks], z[ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int ks = 0; ks < NK; ++ks) {
+                    z[ks] = acc[ks];
+                    zo[ks] = zi[ks];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (l > 0) {
+                    fin_w(nraw, w);
+#pragma unroll
+                    for (int ks = 0; ks < NK; ++ks) zi[ks] = zn[ks];
+                }
+            }
+        } else {
+        if (valid) {
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) ob[(size_t)mid_chan(ks, h) * (S0 * S1 * S2) + zoff] = z[ks];
+        }
         HNO_STAMP(a.stamps, 3);
 #pragma unroll 1
         for (int l = 0; l < ((a.dbg & 2) ? 0 : a.L); ++l) {
@@ -244,12 +350,23 @@ __global__ __launch_bounds__(512, 2) void spec_mid_fwd_kernel(MidArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             if (l + 1 < a.L) fin_w(nraw, w);
         }
+        }
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) ZL[mid_chan(ks, h) * (NT * 32) + mi] = valid ? z[ks] : 0.f;
     }
     HNO_STAMP(a.stamps, 20);
     __syncthreads();
     HNO_STAMP(a.stamps, 21);
+    if (BWD) {   // the NT waves' weight-gradient fragments -> this workgroup's slab (fixed order: bit-reproducible)
+        const int nslab = a.L * C * C;
+        float *slab = a.partials + (size_t)blockIdx.x * nslab;
+        for (int i = tid; i < nslab; i += 512) {
+            float sum = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NT; ++wv) sum += MINE[wv * nslab + i];
+            slab[i] = sum;
+        }
+    }
     if (a.dbg & 64) return;
     // ---------------- phase 4: pad + inverse D step
     for (int t = wave; t < NCT; t += 8) {
@@ -351,6 +468,14 @@ static int mid_twiddles(int N0, int M0, const float **out) {
     return HNO_OK;
 }
 
+// dynamic LDS of spec_mid_kernel (floats): PQ + ZL (+ backward: NT G / Z tiles and NT x L x C x C weight-gradient fragments)
+static size_t mid_lds_floats(int M0, int L, bool bwd) {
+    const int C = 24, K0 = M0 + 1, NT = (2 * 2 * M0 * 4 + 31) / 32;
+    size_t n = (size_t)C * 2 * 2 * K0 * 4 + (size_t)C * NT * 32;
+    if (bwd) n += (size_t)NT * 2 * 32 * 34 + (size_t)NT * L * C * C;
+    return n;
+}
+
 }  // namespace hno
 
 using namespace hno;
@@ -388,11 +513,63 @@ extern "C" int hno_spec_mid_fwd(void *workspace, const float *const *W_layers, f
     hipStream_t s = (hipStream_t)stream;
     const int pairs = (2 * m1 + 1 + 1) / 2, G8 = (B * pairs + 7) & ~7;
     const dim3 grid(8 * G8);
+    const size_t lds = sizeof(float) * mid_lds_floats(m0, 0, false);
     {
         ProfScope _ps(KID_SPECMIX_FWD, s, 4.0 * B * C * (2.0 * N0 * 2 * (2 * m1 + 1) * 16 + (L + 1) * 8.0 * m0 * m1 * m2));
-        if (N0 == 65) hipLaunchKernelGGL((spec_mid_fwd_kernel<65, 10>), grid, dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((spec_mid_fwd_kernel<33, 10>), grid, dim3(512), 0, s, a);
+        if (N0 == 65) hipLaunchKernelGGL((spec_mid_kernel<65, 10, false>), grid, dim3(512), lds, s, a);
+        else hipLaunchKernelGGL((spec_mid_kernel<33, 10, false>), grid, dim3(512), lds, s, a);
     }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
+}
+
+// Backward of the same chain.  workspace: the forward plane transform of the block-output gradient (hno_dht3_planes of g_u) on entry,
+// the operand of the inverse plane transform that yields the block-input gradient (hno_idht3_planes) on return.  zs: what the
+// forward wrote (z_0 .. z_L).  dW: (L, C, C) weight gradients (written, or recorded for the batched end-of-backward reduction when
+// bit 8 of `residual` is set: hno_set_defer_reduce); slab_workspace: hno_specmix_bwd_workspace_bytes(B, C, M, L) bytes.
+extern "C" int hno_spec_mid_bwd(void *workspace, const float *const *W_layers, const float *zs, float *dW, void *slab_workspace, int B,
+                                int C, int N0, int m0, int m1, int m2, int L, int residual, int act, float scale, void *stream) {
+    HNO_REQUIRE(workspace && W_layers && zs && dW && slab_workspace && B > 0, "hno_spec_mid_bwd: bad argument");
+    if (!hno_spec_mid_supported(C, N0, m0, m1, m2, L)) return fail(HNO_ELIMIT, "hno_spec_mid_bwd: unsupported configuration");
+    MidArgs a = {};
+    a.ws = (float *)workspace;
+    for (int l = 0; l < L; ++l) {
+        HNO_REQUIRE(W_layers[l], "hno_spec_mid_bwd: W_layers[%d] is NULL", l);
+        a.W[l] = W_layers[l];
+    }
+    a.zs = const_cast<float *>(zs);
+    a.partials = (float *)slab_workspace;
+    a.B = B;
+    a.L = L;
+    a.residual = residual & 0xff;
+    a.act = act;
+    a.m1 = m1;
+    a.m2 = m2;
+    a.scale = scale;
+    a.dbg = debug_flags();
+    a.stamps = (a.dbg & 1024) ? debug_stamp_buffer() : nullptr;
+    int rc = mid_twiddles(N0, m0, &a.tw);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int pairs = (2 * m1 + 1 + 1) / 2, G8 = (B * pairs + 7) & ~7, nwg = 8 * G8, n = L * C * C;
+    if ((size_t)nwg * n * sizeof(float) > hno_pwconv_bwd_workspace_bytes(C, C))
+        return fail(HNO_ELIMIT, "hno_spec_mid_bwd: %d workgroups x %d floats exceed the slab workspace", nwg, n);
+    const size_t lds = sizeof(float) * mid_lds_floats(m0, L, true);
+    static bool attr_done = false;
+    if (!attr_done) {
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)spec_mid_kernel<65, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)spec_mid_kernel<33, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    {
+        ProfScope _ps(KID_SPECMIX_BWD, s, 4.0 * B * C * (2.0 * N0 * 2 * (2 * m1 + 1) * 16 + (L + 1) * 8.0 * m0 * m1 * m2));
+        if (N0 == 65) hipLaunchKernelGGL((spec_mid_kernel<65, 10, true>), dim3(nwg), dim3(512), lds, s, a);
+        else hipLaunchKernelGGL((spec_mid_kernel<33, 10, true>), dim3(nwg), dim3(512), lds, s, a);
+    }
+    HNO_CHECK_LAUNCH();
+    // bit 8 of residual: record the slab reduction for hno_flush_reduces (per-call form of hno_set_defer_reduce)
+    const int prev = hno_set_defer_reduce(0);
+    struct Restore { int v; ~Restore() { hno_set_defer_reduce(v); } } restore{prev};
+    hno_set_defer_reduce(((residual >> 8) & 1) ? 1 : prev);
+    return reduce_partials_launch(a.partials, nwg, n, dW, n, nullptr, s);
 }

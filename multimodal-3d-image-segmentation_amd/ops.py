@@ -578,6 +578,38 @@ def spectral_chain_fwd_raw(x, W, modes, act, scale_fwd, inv_act):
     return zall[0], zall[1:], u
 
 
+def spectral_chain_bwd_ok(xm, modes, z0, zs):
+    """backward of the fused spectral middle: same configurations as the forward, and z_0 .. z_L stacked in one buffer (what
+    spectral_chain_fwd_raw returns); HNO_FUSED_MID_BWD=0 switches it off (A/B)."""
+    return (os.environ.get('HNO_FUSED_MID_BWD', '1') != '0' and spectral_chain_supported(xm, modes, zs.shape[0])
+            and zs.is_contiguous() and z0.is_contiguous() and zs.data_ptr() == z0.data_ptr() + 4 * z0.numel())
+
+
+def spectral_chain_bwd_raw(g_u, z0, W, modes, act, scale_out, addend, defer=False):
+    """PadInverse^T -> backward of the n_XS frequency-domain layers -> TransformCrop^T (+ addend) with the fused middle: g_u is the
+    gradient of PadInverse's pre-activation output, z0 the base of the stacked z_0 .. z_L of the forward; -> (g_xm, dW (L, C, C)).
+    The gradients of the cropped spectra never reach memory."""
+    _need_gpu(g_u, addend)
+    Ws = _mix_layers(W)
+    B, C, N0, N1, N2 = g_u.shape
+    m0, m1, m2 = modes
+    L, Lyr = _lib.lib(), len(Ws)
+    ld = chan_stride(g_u)
+    addend = to_layout(addend, ld)
+    ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, N0, N1, N2, m0, m1, m2) // 4, device=g_u.device, dtype=torch.float32)
+    slab = torch.empty(L.hno_specmix_bwd_workspace_bytes(B, C, 8 * m0 * m1 * m2, Lyr) // 4, device=g_u.device, dtype=torch.float32)
+    dW = _grad_buffer_stacked(W) if not torch.is_tensor(W) else torch.empty((Lyr, C, C), device=g_u.device, dtype=torch.float32)
+    g_xm = act_like(g_u)
+    check(L.hno_dht3_planes(ptr(g_u), ptr(ws), B * C, N0, N1, N2, m0, m1, m2, ld or 0, stream_ptr()), 'hno_dht3_planes')
+    with _DeferReduce(defer) as d:
+        check(L.hno_spec_mid_bwd(ptr(ws), _layer_ptrs(Ws), ptr(z0), ptr(dW), ptr(slab), B, C, N0, m0, m1, m2, Lyr, 1 | d.bit, act, 1.0,
+                                 stream_ptr()), 'hno_spec_mid_bwd')
+        d.keep(slab)
+    check(L.hno_idht3_planes(ptr(ws), ptr(addend), ACT_NONE, ptr(g_xm), B * C, N0, N1, N2, m0, m1, m2, float(scale_out), ld or 0,
+                             stream_ptr()), 'hno_idht3_planes')
+    return g_xm, dW
+
+
 def specmix_bwd_raw(g, z0, zs, W, residual, act, defer=False):
     Ws = _mix_layers(W)
     B, C = z0.shape[:2]
@@ -1419,9 +1451,12 @@ class XSBlockFn(_HnoFunction):
                                                          accumulate_into=(None, g_pass) if fuse_pass else None, defer=late_cat, bias=cat_b, bf16=ctx.bf16)
         if g_pass is not None and not has_map and not fuse_pass:
             g_skipin = plus_pass(g_skipin)
-        g_zl = dht3_crop_raw(g_u, modes, 1.0)                               # PadInverse^T
-        g_z0, d_mix = specmix_bwd_raw(g_zl, z0, zs, mix_ws, 1, act, defer=late_mix)
-        g_xm = pad_idht3_raw(g_z0, spatial, 1.0 / n3, g_skipin, ACT_NONE, ld=ld)    # TransformCrop^T + skip gradient
+        if spectral_chain_bwd_ok(xm, modes, z0, zs):     # PadInverse^T, the layers' backward and TransformCrop^T + skip gradient
+            g_xm, d_mix = spectral_chain_bwd_raw(g_u, z0, mix_ws, modes, act, 1.0 / n3, g_skipin, defer=late_mix)
+        else:
+            g_zl = dht3_crop_raw(g_u, modes, 1.0)                               # PadInverse^T
+            g_z0, d_mix = specmix_bwd_raw(g_zl, z0, zs, mix_ws, 1, act, defer=late_mix)
+            g_xm = pad_idht3_raw(g_z0, spatial, 1.0 / n3, g_skipin, ACT_NONE, ld=ld)    # TransformCrop^T + skip gradient
         d_mix = tuple(d_mix.unbind(0))
         if not has_map:
             return (g_xm, None, None, None, d_cat_w, d_cat_b, None, None, None) + d_mix

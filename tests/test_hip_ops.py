@@ -100,6 +100,38 @@ def test_fused_spectral_middle_vs_three_kernel_path(pkg, n):
 
 
 @pytest.mark.parametrize('n', [65, 33])
+@pytest.mark.parametrize('act', ['selu', None])
+def test_fused_spectral_middle_backward_vs_three_kernel_path(pkg, n, act):
+    """hno_dht3_planes -> hno_spec_mid_bwd -> hno_idht3_planes (PadInverse^T, the backward of the n_XS frequency-domain layers incl.
+    their weight gradients, TransformCrop^T + skip gradient; nets/hnosegxs.py:307-329,378-410,454-494 differentiated) against
+    hno_dht3_crop -> hno_specmix_layers_bwd -> hno_pad_idht3, which the G2 / G3 / G6 goldens pin: block-input gradient and all layers'
+    weight gradients, 3 layers and 1 layer, contiguous and channel-padded."""
+    from multimodal_3d_image_segmentation_amd import ops
+    torch.manual_seed(4)
+    modes, sp, a = (10, 14, 14), (n, n, n), ops.act_id(act)
+    x = torch.randn(2, 24, n, n, n, device='cuda')
+    g_u, add = torch.randn_like(x), torch.randn_like(x)
+    for nl in (3, 1):
+        Ws = [torch.randn(24, 24, device='cuda') * 0.2 for _ in range(nl)]
+        z0, zs, _ = ops.spectral_chain_fwd_raw(x, Ws, modes, a, 1.0 / n ** 3, a)
+        assert ops.spectral_chain_bwd_ok(x, modes, z0, zs)
+        g_zl = ops.dht3_crop_raw(g_u, modes, 1.0)
+        g_z0, dW = ops.specmix_bwd_raw(g_zl, z0, zs, Ws, 1, a)
+        want = ops.pad_idht3_raw(g_z0, sp, 1.0 / n ** 3, add, ops.ACT_NONE)
+        got, dW2 = ops.spectral_chain_bwd_raw(g_u, z0, Ws, modes, a, 1.0 / n ** 3, add)
+        assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 2e-6
+        assert tuple(dW2.shape) == (nl, 24, 24)
+        for l in range(nl):
+            assert rel_err(dW2[l].cpu().numpy(), dW[l].cpu().numpy()) < 1e-5
+        ld = ops._pad_ld(n ** 3)
+        gotp, dWp = ops.spectral_chain_bwd_raw(ops.to_layout(g_u, ld), z0, Ws, modes, a, 1.0 / n ** 3, ops.to_layout(add, ld))
+        assert ops.chan_stride(gotp) == ld and bool((gotp == got).all()) and bool((dWp == dW2).all())
+    # without a skip gradient
+    got, _ = ops.spectral_chain_bwd_raw(g_u, z0, Ws, modes, a, 1.0, None)
+    assert rel_err(got.cpu().numpy(), ops.pad_idht3_raw(g_z0, sp, 1.0, None, ops.ACT_NONE).cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize('n', [65, 33])
 def test_channel_padded_activations_match_contiguous(pkg, n, monkeypatch):
     """Round 3: inside HNOSeg-XS the activations live with their channel stride rounded up to 128 B (ops.channel_padded; the odd
     65^3 = 274625-float rows of the contiguous layout cost the pointwise kernels 1.25x - 1.33x over-fetch).  Same numbers either way:
