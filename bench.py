@@ -281,10 +281,13 @@ def main():
     # time, so the GPU is never launch-bound.  Adamax stays an eager launch behind the replay.
     # Data-parallel runs replay the same graph: the backward kernels write their weight gradients straight into the flat
     # gradient buffer (the few that cannot are copied there by kernels inside the graph, rep.finish_capture()), and the bucket
-    # gradient all-reduce is launched on the communication stream behind the replay (rep.allreduce_flat(): one RCCL launch for
+    # gradient all-reduce is launched from the compute stream behind the replay (rep.allreduce_flat(): one RCCL launch for
     # HNOSeg-XS's 113 KB, no Python per parameter).  Round 2 ran N > 1 eagerly with ~60 Python hooks per backward; the hooks
     # remain the path of `training()` for models whose gradients are worth overlapping (V-Net-DS: 90 MB).
     graph = None
+    # HNO_DP_CAPTURE_ALLREDUCE=1: also capture the gradient all-reduce into the graph (measured on one rank only; the default keeps it an
+    # eager launch behind the replay because a capture of RCCL collectives across several GPUs could not be tested from here)
+    capture_allreduce = distributed and os.environ.get('HNO_DP_CAPTURE_ALLREDUCE', '0') == '1'
     if not args.no_graph:
         try:
             torch.cuda.synchronize()
@@ -299,6 +302,8 @@ def main():
                     static_loss = fwd_bwd()
                     if distributed:
                         rep.finish_capture()
+                        if capture_allreduce:      # the collective becomes a node of the graph (RCCL kernels are capturable)
+                            rep.allreduce_flat()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
         except Exception as exc:   # capture unsupported on this stack: run eagerly and say so
@@ -315,7 +320,7 @@ def main():
             return eager_step()
         t_h = time.perf_counter()
         graph.replay()
-        if distributed:
+        if distributed and not capture_allreduce:
             rep.allreduce_flat()
         opt.step()
         host_s[0] += time.perf_counter() - t_h
@@ -383,7 +388,7 @@ def main():
             'config': {'workload': "HNOSeg-XS BraTS'23 config (filters 24, 8 blocks x 3, modes 10-14-14), "
                                    "synthetic 4-modal 128^3 fp32, step = fwd + PCC loss + bwd + grad all-reduce + Adamax",
                        'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
-                       'launch': ('hip-graph replay (fwd+loss+bwd)' + (' + one flat gradient all-reduce on the comm stream' if distributed else '')
+                       'launch': ('hip-graph replay (fwd+loss+bwd)' + ((' + one flat gradient all-reduce ' + ('inside the graph' if capture_allreduce else 'behind the replay')) if distributed else '')
                                   + ' + eager Adamax') if graph is not None else
                                  ('eager; gradient buckets all-reduced from backward hooks on a comm stream' if distributed else 'eager'),
                        'grad_buckets': len(rep.buckets) if distributed else 0,

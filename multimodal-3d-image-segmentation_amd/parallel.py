@@ -194,23 +194,17 @@ class FlatGradReplica:
         self._flat_ready = True
 
     def allreduce_flat(self):
-        """After a graph replay whose kernels filled ``flat_grad`` (finish_capture): ONE all-reduce of the whole flat buffer on the
-        communication stream behind the replay (nothing is left to overlap with, so buckets would only multiply the launch and
-        synchronisation cost: two collectives cost 0.12 ms of a 3 ms HNOSeg-XS step on one rank, one costs half), then the compute
-        stream waits for it.  No Python per parameter."""
+        """After a graph replay whose kernels filled ``flat_grad`` (finish_capture) -- or INSIDE the capture, where the collective
+        becomes a node of the graph: ONE all-reduce of the whole flat buffer, launched from the compute stream.  Nothing is left to
+        overlap with, so buckets and the communication stream only add cross-stream hops: RCCL runs on the process group's own
+        stream either way (compute -> RCCL -> compute, two event hops of ~10-15 us each on this stack); going through the
+        communication stream as the overlapped buckets do made it four (measured on one rank at the HNOSeg-XS step: 2.745 ms against
+        2.638 ms for the step without the collective; captured into the graph: 2.638 ms).  No Python per parameter."""
         if self.world == 1:
             return
         assert self._flat_ready, 'allreduce_flat() needs finish_capture() in the captured step'
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        if self._comm_stream is not None:
-            self._comm_stream.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(self._comm_stream):
-                work = dist.all_reduce(self.flat_grad, op=op, group=self.group, async_op=True)
-        else:
-            work = dist.all_reduce(self.flat_grad, op=op, group=self.group, async_op=True)
-        work.wait()
-        if self._comm_stream is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self._comm_stream)
+        dist.all_reduce(self.flat_grad, op=op, group=self.group)      # synchronous form: the compute stream waits for the collective
         if not self._avg:
             self.flat_grad.mul_(1.0 / self.world)
 
