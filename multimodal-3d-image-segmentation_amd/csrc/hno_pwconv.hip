@@ -326,12 +326,20 @@ __global__ __launch_bounds__(256, 2) void pwconv_bwd_kernel(PwBwdArgs a) {
 // per CU (one 512-thread block per CU, grid = number of CUs, grid-stride over tiles): 37 us against
 // 42 us at 16 waves/CU and 46-50 us with one tile per wave; 8/16-byte-per-lane loads, explicit
 // software prefetch, XCD-contiguous tile order and non-temporal stores made no difference or hurt.
+// waves per workgroup of the 24 + 24 -> 24 forward kernel (one workgroup per CU).  Round 3, with channel-padded (128-byte aligned) rows:
+// 8 waves = two per SIMD, so one wave's bias + SELU epilogue (~1 200 VALU cycles per tile) runs under the other's MFMA chain
+// (they do not overlap within a wave, DESIGN lesson 34): 39.0 -> 36.4 us isolated, 2.686 -> 2.667 ms per step; 12 waves: the same.
+// With the misaligned rows of rounds 1-2 four waves were best.  HNO_PWF_WAVES=4 / 12 select the others (A/B).
+static int pwf_waves() {
+    static const int v = getenv("HNO_PWF_WAVES") ? atoi(getenv("HNO_PWF_WAVES")) : 8;
+    return v;
+}
 #define PWF_FAST_WAVES 8
 #define PWF_DMA_WAVES 4      // fast forward kernel: 4 waves (one per SIMD), each with a private two-slot LDS ring
 
-template <int CA, int CB, int COUT, bool BF16 = false>   // channel counts of xa / xb (both even) are compile-time: all address selects fold
-__global__ __launch_bounds__(64 * PWF_DMA_WAVES) void pwconv_fwd_fast_kernel(PwArgs a) {
-    constexpr int NW = PWF_DMA_WAVES;
+template <int CA, int CB, int COUT, bool BF16 = false, int NWV = PWF_DMA_WAVES>   // channel counts of xa / xb (both even) are compile-time: all address selects fold
+__global__ __launch_bounds__(64 * NWV) void pwconv_fwd_fast_kernel(PwArgs a) {
+    constexpr int NW = NWV;
     extern __shared__ float pwf_ring[];      // NW x 2 slots x NKI x 64 floats
     constexpr int NKI = (CA + CB) / 2;
     const int lane = threadIdx.x & 63;
@@ -1098,6 +1106,19 @@ int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const fl
         else if (bf16 && Ca == 24 && Cb == 24 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 24, 24, true>), dim3(fgrid), fb, fl, fs, a);
         else if (bf16 && Ca == 24 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 4, true>), dim3(fgrid), fb, fl, fs, a);
         else if (Ca == 24 && Cb == 0 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 24>), dim3(fgrid), fb, fl, fs, a);
+        else if (Ca == 24 && Cb == 24 && Cout == 24 && (pwf_waves() == 8 || pwf_waves() == 12)) {   // 2 (default) / 3 waves per SIMD
+            const int nw = pwf_waves();
+            int g8 = (int)((ntiles + nw - 1) / nw);
+            if (g8 > 256) g8 = 256;
+            static bool attr8 = false;
+            if (!attr8) {
+                (void)hipFuncSetAttribute((const void *)pwconv_fwd_fast_kernel<24, 24, 24, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)pwconv_fwd_fast_kernel<24, 24, 24, false, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr8 = true;
+            }
+            if (nw == 8) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 24, 24, false, 8>), dim3(g8), dim3(512), (size_t)8 * 2 * 24 * 256, fs, a);
+            else hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 24, 24, false, 12>), dim3(g8), dim3(768), (size_t)12 * 2 * 24 * 256, fs, a);
+        }
         else if (Ca == 24 && Cb == 24 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 24, 24>), dim3(fgrid), fb, fl, fs, a);
         else if (Ca == 24 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 4>), dim3(fgrid), fb, fl, fs, a);
         else if (Ca == 48 && Cb == 0 && Cout == 48) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<48, 0, 48>), dim3(fgrid), fb, fl, fs, a);   // composed complex mix
