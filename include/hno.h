@@ -91,6 +91,11 @@ int hno_rfft3_crop(const float *x, const float *x_act_out, int act_grad, float *
 int hno_irfft3_pad(const float *spec, const float *addend, int act, float *out, void *workspace,
                    int B, int C, int N0, int N1, int N2, int m0, int m1, int m2, float scale, int k2_weights,
                    void *stream);
+/* the same pair on channel-padded activations (see hno_dht3_crop_ld): ldbc = floats between consecutive (b, c) volumes */
+int hno_rfft3_crop_ld(const float *x, const float *x_act_out, int act_grad, float *spec, void *workspace, int B, int C, int N0, int N1,
+                      int N2, int m0, int m1, int m2, float scale, int k2_weights, long long ldbc, void *stream);
+int hno_irfft3_pad_ld(const float *spec, const float *addend, int act, float *out, void *workspace, int B, int C, int N0, int N1, int N2,
+                      int m0, int m1, int m2, float scale, int k2_weights, long long ldbc, void *stream);
 
 /* ------------------------------------------------- shared-weight spectral channel mixing
  * L stacked layers  z_{l+1} = act(W_l z_l + residual * z_l)  on a (B, C, M) spectrum

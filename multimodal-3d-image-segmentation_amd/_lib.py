@@ -26,6 +26,8 @@ SIGNATURES = {
     'hno_pad_idht3': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_void_p]),
     'hno_rfft3_crop': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_int, c_void_p]),
     'hno_irfft3_pad': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_int, c_void_p]),
+    'hno_rfft3_crop_ld': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_int, c_ll, c_void_p]),
+    'hno_irfft3_pad_ld': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_int, c_ll, c_void_p]),
     'hno_specmix_shared_fwd': (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     'hno_specmix_shared_bwd': (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
     'hno_specmix_bwd_workspace_bytes': (c_size_t, [c_int] * 4),

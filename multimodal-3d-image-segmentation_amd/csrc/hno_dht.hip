@@ -2843,3 +2843,18 @@ extern "C" int hno_irfft3_pad(const float *spec, const float *addend, int act, f
     return dht_inverse_launch(spec, addend, act, out, workspace, B * C, N0, N1, N2, m0, m1, m2, scale, stream,
                               k2_weights ? 2 : 1, C);
 }
+
+// the Fourier pair on channel-padded activations (ldbc: floats between consecutive (b, c) volumes of x, resp. out / addend)
+extern "C" int hno_rfft3_crop_ld(const float *x, const float *x_act_out, int act_grad, float *spec, void *workspace, int B, int C, int N0,
+                                 int N1, int N2, int m0, int m1, int m2, float scale, int k2_weights, long long ldbc, void *stream) {
+    HNO_REQUIRE(B > 0 && C > 0, "hno_rfft3_crop: bad batch / channel count");
+    return dht_forward_launch(x, x_act_out, act_grad, spec, workspace, B * C, N0, N1, N2, m0, m1, m2, scale, stream, k2_weights ? 2 : 1, C,
+                              0, false, ldbc);
+}
+
+extern "C" int hno_irfft3_pad_ld(const float *spec, const float *addend, int act, float *out, void *workspace, int B, int C, int N0, int N1,
+                                 int N2, int m0, int m1, int m2, float scale, int k2_weights, long long ldbc, void *stream) {
+    HNO_REQUIRE(B > 0 && C > 0, "hno_irfft3_pad: bad batch / channel count");
+    return dht_inverse_launch(spec, addend, act, out, workspace, B * C, N0, N1, N2, m0, m1, m2, scale, stream, k2_weights ? 2 : 1, C, 0,
+                              false, ldbc);
+}

@@ -26,16 +26,18 @@ class _TransBlock(nn.Module):
         self.use_block_skip = None
         self.conv_concat = None
 
+    def _fusable(self, act):
+        op = self.op
+        return (not _NO_BLOCK_FUSION and isinstance(op, (FourierOperator, HartleyOperator)) and self.normalization is None
+                and act != ops.ACT_NONE and self.use_block_skip and self.conv_concat is not None
+                and op.weights_type == 'shared' and op.use_transform and not op.use_bias
+                and self.conv_concat.normalization is None and ops.act_id(self.conv_concat.activation) == act)
+
     def _fused_block(self, x, act):
         """The whole block as one autograd node (ops.NOBlockFn) when it has the FNOSeg / HNOSeg shape: shared-weight
         Fourier / Hartley operator with transform and without bias, SELU (no GroupNorm), concat skip."""
         op = self.op
-        if _NO_BLOCK_FUSION:
-            return None
-        if not (isinstance(op, (FourierOperator, HartleyOperator)) and x.ndim == 5 and self.normalization is None
-                and act != ops.ACT_NONE and self.use_block_skip and self.conv_concat is not None
-                and op.weights_type == 'shared' and op.use_transform and not op.use_bias
-                and self.conv_concat.normalization is None and ops.act_id(self.conv_concat.activation) == act):
+        if x.ndim != 5 or not self._fusable(act):
             return None
         fourier = isinstance(op, FourierOperator)
         op_ws = (op.weight_real, op.weight_imag) if fourier else (op.weight,)
@@ -139,6 +141,18 @@ class _TransSeg(nn.Module):
         if x.ndim == 4:   # 2-D model (ndim = 4): the same kernels on a (B, C, 1, H, W) view (see HNOSegXS.forward)
             return self.forward(x.unsqueeze(2)).squeeze(2)
         image_size = tuple(x.shape[2:])
+        # channel-padded activations (ops.channel_padded, see HNOSegXS.forward): every block the fused node, both plane transforms
+        # serve the working grid
+        grid = tuple(v // 2 + 1 for v in image_size) if self.use_resize else image_size
+        blocks = list(self.layers)
+        pad = (x.is_cuda and self.use_resize and not self.use_deep_supervision and self.conv_in.normalization is None
+               and self.conv1.normalization is None and len(blocks) > 0
+               and all(isinstance(l, _TransBlock) and l._fusable(ops.act_id(l.activation)) for l in blocks)
+               and len(blocks[0].op.num_modes) == 3 and ops.padded_ok(grid, tuple(blocks[0].op.num_modes)))
+        with ops.channel_padded(pad):
+            return self._forward5(x, image_size)
+
+    def _forward5(self, x, image_size):
         tensors = []
         if self.use_resize:
             x = self.conv_in(x)

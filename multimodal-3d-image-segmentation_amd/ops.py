@@ -273,12 +273,18 @@ def rfft3_crop_raw(x, modes, scale, k2_weights=False, act_out=None, act=ACT_NONE
     L = _lib.lib()
     ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, N0, N1, N2, m0, m1, m2) // 4, device=x.device, dtype=torch.float32)
     out = torch.empty((B, 2 * C, _block0(N0, m0), 2 * m1, m2), device=x.device, dtype=torch.float32)
+    ld = chan_stride(x)
+    if ld is not None:
+        act_out = to_layout(act_out, ld)
+        check(L.hno_rfft3_crop_ld(ptr(x), ptr(act_out), act if act_out is not None else ACT_NONE, ptr(out), ptr(ws), B, C,
+                                  N0, N1, N2, m0, m1, m2, float(scale), int(k2_weights), ld, stream_ptr()), 'hno_rfft3_crop_ld')
+        return out
     check(L.hno_rfft3_crop(ptr(x), ptr(act_out), act if act_out is not None else ACT_NONE, ptr(out), ptr(ws), B, C,
                            N0, N1, N2, m0, m1, m2, float(scale), int(k2_weights), stream_ptr()), 'hno_rfft3_crop')
     return out
 
 
-def irfft3_pad_raw(spec, spatial, scale, k2_weights=True, addend=None, act=ACT_NONE):
+def irfft3_pad_raw(spec, spatial, scale, k2_weights=True, addend=None, act=ACT_NONE, ld=None):
     """spec (B, 2C, 2m0, 2m1, m2) -> (B, C, N0, N1, N2) = act(scale * irfft-style inverse + addend)."""
     _need_gpu(spec, addend)
     B, C2 = spec.shape[:2]
@@ -287,6 +293,12 @@ def irfft3_pad_raw(spec, spatial, scale, k2_weights=True, addend=None, act=ACT_N
     N0, N1, N2 = (int(v) for v in spatial)
     L = _lib.lib()
     ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, N0, N1, N2, m0, m1, m2) // 4, device=spec.device, dtype=torch.float32)
+    if ld is not None:
+        addend = to_layout(addend, ld)
+        out = act_empty(B, C, (N0, N1, N2), spec.device, ld)
+        check(L.hno_irfft3_pad_ld(ptr(spec), ptr(addend), act, ptr(out), ptr(ws), B, C, N0, N1, N2, m0, m1, m2, float(scale),
+                                  int(k2_weights), ld, stream_ptr()), 'hno_irfft3_pad_ld')
+        return out
     out = torch.empty((B, C, N0, N1, N2), device=spec.device, dtype=torch.float32)
     check(L.hno_irfft3_pad(ptr(spec), ptr(addend), act, ptr(out), ptr(ws), B, C, N0, N1, N2, m0, m1, m2, float(scale),
                            int(k2_weights), stream_ptr()), 'hno_irfft3_pad')
@@ -365,10 +377,12 @@ def pwconv_bwd_branch_raw(gy, y, xa, xb, W, Wbr, act, xa_act, defer=False, bf16=
     """Backward of  act(W [xa ; xb] + b)  where xa = xa_act(s + Wbr xb + bbr): one pass (hno_pwconv_bwd_branch).
     -> (p, gxb, dW, db, dWbr, dbbr) with p the gradient of the pre-activation sum s + Wbr xb + bbr."""
     B, Ca = xa.shape[:2]
-    Cb, Cout, V = xb.shape[1], W.shape[0], _flat_v(xa)
+    ld = chan_stride(xa)            # channel-padded operands: V := ld (pwconv_bwd_raw)
+    gy, y, xb = to_layout(gy, ld), to_layout(y, ld), to_layout(xb, ld)
+    Cb, Cout, V = xb.shape[1], W.shape[0], ld or _flat_v(xa)
     L = _lib.lib()
-    p = torch.empty_like(xa)
-    gxb = torch.empty_like(xb)
+    p = act_like(xa)
+    gxb = act_like(xb)
     n_w, n_br = Cout * (Ca + Cb), Ca * Cb
     flat = torch.empty(n_w + Cout + n_br + Ca, device=xa.device, dtype=torch.float32)
     ws = torch.empty(L.hno_pwconv_bwd_branch_workspace_bytes(Ca, Cb, Cout) // 4, device=xa.device, dtype=torch.float32)
@@ -1294,13 +1308,16 @@ class NOBlockFn(_HnoFunction):
     @staticmethod
     def forward(ctx, x, fourier, modes, act, br_w, br_b, cat_w, cat_b, *op_ws):
         ctx.leaf_params = _leaf_params(ctx, br_w, br_b, cat_w, cat_b, *op_ws)
-        x, br_w, br_b, cat_w, cat_b = (_f32c(t) for t in (x, br_w, br_b, cat_w, cat_b))
+        br_w, br_b, cat_w, cat_b = (_f32c(t) for t in (br_w, br_b, cat_w, cat_b))
         op_ws = [_f32c(w) for w in op_ws]
-        _need_gpu(x, cat_w, *op_ws)
         spatial = tuple(x.shape[2:])
         if len(modes) == 2:                      # 2-D model on a (B, C, 1, H, W) view
             modes = (0,) + tuple(modes)
         modes = clamp_modes(modes, spatial)
+        # a channel-padded input stays padded through the block when both transform directions take the stride (XSBlockFn)
+        x = _f32a(x) if (chan_stride(x) is not None and padded_ok(spatial, modes)) else _f32c(x)
+        ld = chan_stride(x)
+        _need_gpu(x, cat_w, *op_ws)
         n3 = float(np.prod(spatial))
         # 24 + 24 -> 24 with a conv branch: branch conv, add, activation and concat conv in one pass after the inverse
         fuse_tail = br_w is not None and tuple(cat_w.shape[:2]) == (24, 48) and tuple(br_w.shape[:2]) == (24, 24)
@@ -1314,16 +1331,16 @@ class NOBlockFn(_HnoFunction):
             check(_lib.lib().hno_cmix_compose(ptr(wr), ptr(wi), ptr(w), Co, Ci, stream_ptr()), 'hno_cmix_compose')
             s0 = rfft3_crop_raw(x, modes, 1.0 / n3, False)
             s1 = pwconv_fwd_raw(s0, None, w, None, ACT_NONE)
-            y = irfft3_pad_raw(s1, spatial, 1.0, True, x2, inv_act)
+            y = irfft3_pad_raw(s1, spatial, 1.0, True, x2, inv_act, ld=ld)
         else:
             (w,) = op_ws
             s0 = dht3_crop_raw(x, modes, 1.0 / n3)
             s1 = pwconv_fwd_raw(s0, None, w, None, ACT_SELU)      # SELU in the frequency domain (hartley_operator.py:262-269)
-            y = pad_idht3_raw(s1, spatial, 1.0, x2, inv_act)
+            y = pad_idht3_raw(s1, spatial, 1.0, x2, inv_act, ld=ld)
         if fuse_tail:
-            sop, y, out = y, torch.empty_like(x), torch.empty_like(x)
+            sop, y, out = y, act_like(x), act_like(x)
             check(_lib.lib().hno_pwconv_fwd_branch(ptr(sop), ptr(x), ptr(br_w), ptr(br_b), ptr(cat_w), ptr(cat_b), ptr(y), ptr(out),
-                                                   x.shape[0], 24, 24, 24, _flat_v(x), act | (ACT_BF16 if bf else 0), stream_ptr()), 'hno_pwconv_fwd_branch')
+                                                   x.shape[0], 24, 24, 24, ld or _flat_v(x), act | (ACT_BF16 if bf else 0), stream_ptr()), 'hno_pwconv_fwd_branch')
         else:
             out = pwconv_fwd_raw(y, x, cat_w, cat_b, act, bf)
         ctx.bf16 = bf
@@ -1339,7 +1356,7 @@ class NOBlockFn(_HnoFunction):
         d_br_w = d_br_b = None
         if br_w is not None and tuple(cat_w.shape[:2]) == (24, 48) and tuple(br_w.shape[:2]) == (24, 24):
             # one pass: p = d loss / d (s + x2) = g_y * act'(y); g_x = concat-path gradient + Wbr^T p; all four parameter gradients
-            p, g_x, d_cat_w, d_cat_b, d_br_w, d_br_b = pwconv_bwd_branch_raw(_f32c(g_out), out, y, x, cat_w, br_w, act, act, defer=late, bf16=ctx.bf16)
+            p, g_x, d_cat_w, d_cat_b, d_br_w, d_br_b = pwconv_bwd_branch_raw(_f32a(g_out), out, y, x, cat_w, br_w, act, act, defer=late, bf16=ctx.bf16)
             d_br_w = d_br_w.view_as(br_w)
             if not cat_has_b:
                 d_cat_b = None
@@ -1347,7 +1364,7 @@ class NOBlockFn(_HnoFunction):
                 d_br_b = None
         else:
             # p through the conv's xa_act product; the branch conv (its output gradient is p) adds its input gradient to g_x
-            p, g_x, d_cat_w, d_cat_b = pwconv_bwd_raw(_f32c(g_out), out, y, x, cat_w, act, cat_has_b, xa_act=act, defer=late, bf16=ctx.bf16)
+            p, g_x, d_cat_w, d_cat_b = pwconv_bwd_raw(_f32a(g_out), out, y, x, cat_w, act, cat_has_b, xa_act=act, defer=late, bf16=ctx.bf16)
             if br_w is not None:
                 _, _, d_br_w, d_br_b = pwconv_bwd_raw(p, None, x, None, br_w, ACT_NONE, br_has_b, accumulate_into=(g_x, None),
                                                       defer=late, bf16=ctx.bf16)
@@ -1358,12 +1375,12 @@ class NOBlockFn(_HnoFunction):
             dwr = torch.empty((Co, Ci), device=x.device, dtype=torch.float32)
             dwi = torch.empty_like(dwr)
             check(_lib.lib().hno_cmix_split_grad(ptr(dw2), ptr(dwr), ptr(dwi), Co, Ci, stream_ptr()), 'hno_cmix_split_grad')
-            gx = irfft3_pad_raw(gs0, spatial, 1.0 / n3, False, g_x, ACT_NONE)
+            gx = irfft3_pad_raw(gs0, spatial, 1.0 / n3, False, g_x, ACT_NONE, ld=chan_stride(x))
             d_ops = (dwr, dwi)
         else:
             gs1 = dht3_crop_raw(p, modes, 1.0)
             gs0, _, dw, _ = pwconv_bwd_raw(gs1, s1, s0, None, w, ACT_SELU, False, defer=late)
-            gx = pad_idht3_raw(gs0, spatial, 1.0 / n3, g_x, ACT_NONE)
+            gx = pad_idht3_raw(gs0, spatial, 1.0 / n3, g_x, ACT_NONE, ld=chan_stride(x))
             d_ops = (dw,)
         return (gx, None, None, None, d_br_w, d_br_b, d_cat_w, d_cat_b) + d_ops
 

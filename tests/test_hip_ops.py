@@ -231,6 +231,34 @@ def test_pad_idht_fused_epilogue(pkg):
     assert rel_err(got.cpu().numpy(), want.numpy()) < 5e-6
 
 
+@pytest.mark.parametrize('transform', ['Fourier', 'Hartley'])
+def test_channel_padded_activations_fnoseg_hnoseg(pkg, transform, monkeypatch):
+    """The channel-padded layout through the FNOSeg / HNOSeg block (ops.NOBlockFn: fused branch + concat convolutions, rfft / Hartley
+    transforms with a channel stride): outputs bit-identical, every gradient as close as two summation orders, HNO_PAD_ACT on / off."""
+    from multimodal_3d_image_segmentation_amd import ops
+    from multimodal_3d_image_segmentation_amd.nets import NeuralOperatorSeg
+    torch.manual_seed(6)
+    img = torch.randn(2, 4, 64, 64, 64, device='cuda')
+    lab = torch.randint(0, 4, (2, 1, 64, 64, 64), device='cuda').to(torch.uint8)
+    res = []
+    for flag in ('0', '1'):
+        monkeypatch.setenv('HNO_PAD_ACT', flag)
+        torch.manual_seed(12)
+        net = NeuralOperatorSeg(4, 4, 24, 3, (10, 14, 14), transform, device='cuda')
+        seen = []
+        h = net.layers[1].register_forward_hook(lambda m, i, o: seen.append(ops.chan_stride(o)))
+        probs = net(img)
+        h.remove()
+        assert seen == [ops._pad_ld(33 ** 3) if flag == '1' else None]
+        loss, _ = ops.SegLossFn.apply(probs, lab, 0, 0.0)
+        loss.backward()
+        res.append((probs.detach(), float(loss.detach()), [p.grad.clone() for p in net.parameters()]))
+    assert bool((res[0][0] == res[1][0]).all()) and res[0][1] == res[1][1]
+    for g0, g1 in zip(res[0][2], res[1][2]):
+        assert bool(torch.isfinite(g1).all())
+        assert rel_err(g1.cpu().numpy(), g0.cpu().numpy()) < 2e-5
+
+
 @pytest.mark.parametrize('n', [65, 33])
 def test_pad_idht_residual_at_benchmark_planes_vs_float64(pkg, n):
     """The 65 x 65 / 33 x 33 inverse plane kernel takes its residual by LDS-DMA into the output image and adds the GEMM results on
