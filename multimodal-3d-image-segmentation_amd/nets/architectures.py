@@ -259,6 +259,7 @@ class VNetDS(nn.Module):
         super().__init__()
         assert isinstance(num_blocks, (list, tuple))
         self.in_channels, self.out_channels, self.num_blocks = in_channels, out_channels, num_blocks
+        self.base_num_filters = base_num_filters
         self.use_resize, self.right_leg_indexes = use_resize, right_leg_indexes
         self.output_activation, self.use_residual, self.ndim = output_activation, use_residual, ndim
         if self.right_leg_indexes is None:
@@ -331,7 +332,9 @@ class VNetDS(nn.Module):
 
     def forward(self, x):
         from .. import ops_bf16
-        if ops_bf16.autocast_bf16():
+        # bf16 matrix-core path under autocast when every hidden channel count (base_num_filters 2^k) is a multiple of 8 -- the bf16
+        # kernels' fragment width; other widths run the fp32 kernels (still on the GPU: autocast only ever lowers precision)
+        if ops_bf16.autocast_bf16() and self.base_num_filters % 8 == 0:
             if x.ndim == 4:
                 raise NotImplementedError('the bf16 (autocast) path of V-Net-DS is 3-D only')
             return self._forward_bf16(x)

@@ -93,6 +93,7 @@ class PackedWeights:
         self.chunks = int(sum(L.hno_cb_pack_row_chunks(r.ctypes.data_as(ctypes.c_void_p)) for r in rows))
 
     def refresh(self):
+        self.generation = getattr(self, 'generation', 0) + 1    # ConvFn.backward re-packs when the buffers were rewritten since its forward
         if self.table is not None:
             check(_lib.lib().hno_cb_pack_weights_multi(ptr(self.table), self.table.shape[0], self.chunks, stream_ptr()),
                   'hno_cb_pack_weights_multi')
@@ -250,8 +251,10 @@ class ConvFn(_HnoFunction):
         osz = _out_spatial(tuple(xa.shape[1:4]), ks, stride, transposed)
         need_dgrad = ctx.needs_input_grad[0] or (xb is not None and ctx.needs_input_grad[1])
         pre = PackedWeights.lookup(W)
+        ctx.wp_owner = None
         if pre is not None:   # packed with every other layer by this forward's PackedWeights.refresh()
             wp, ctx.wpd = pre
+            ctx.wp_owner = (PackedWeights._current, PackedWeights._current.generation)
         elif need_dgrad:      # the weights do not change between forward and backward: pack both GEMM operands now, in one launch
             wp, ctx.wpd = pack_weights_both(W, transposed, Cin, Cout, ks)
         else:
@@ -269,12 +272,18 @@ class ConvFn(_HnoFunction):
             return (None,) * 9
         xa, xb, W = ctx.saved_tensors
         ks, stride, transposed, pad, has_bias, Ca, Cb, Cout = ctx.cfg
-        cs = getattr(gy, '_hno_colsum', None)        # left by GNActFn.backward: the column sums of this very tensor
+        # left by GNActFn.backward: the column sums of this very tensor -- valid only while nobody wrote into it (the autograd engine
+        # may accumulate a second consumer's gradient IN PLACE into the first-arrived tensor: that bumps its version counter)
+        tag = getattr(gy, '_hno_colsum', None)
+        cs = tag[0] if (tag is not None and gy._version == tag[1]) else None
         gy = gy.contiguous()
         Cin = Ca + Cb
         gxa = gxb = None
         if ctx.needs_input_grad[0] or (xb is not None and ctx.needs_input_grad[1]):
-            wp = ctx.wpd if ctx.wpd is not None else pack_weights(W, 3 if transposed else 1, Cin, Cout, ks)
+            # the shared packed buffers are rewritten by every forward of the owning model: a backward that runs after ANOTHER forward
+            # (two graphs alive, a validation forward in between, gradient accumulation) packs its own operand from the saved weights
+            stale = ctx.wp_owner is not None and ctx.wp_owner[0].generation != ctx.wp_owner[1]
+            wp = ctx.wpd if (ctx.wpd is not None and not stale) else pack_weights(W, 3 if transposed else 1, Cin, Cout, ks)
             gx, _ = conv_raw(gy, None, wp, None, Cin, tuple(xa.shape[1:4]), 0 if transposed else 1, ks, stride, pad, False)
             if xb is None:
                 gxa = gx
@@ -311,11 +320,11 @@ class GNActFn(_HnoFunction):
         # the column sums ride on the gradient tensor: the producing ConvFn's backward takes them as its bias gradient when autograd
         # hands it this very tensor (one consumer; a summed gradient is a new tensor without the attribute)
         dy1, dg1, db1, cs1 = gn_bwd_raw(dz, y1, mr1, g1, b1, ctx.act, colsum=True)
-        dy1._hno_colsum = cs1
+        dy1._hno_colsum = (cs1, dy1._version)
         dy2 = dg2 = db2 = None
         if y2 is not None:
             dy2, dg2, db2, cs2 = gn_bwd_raw(dz, y2, mr2, g2, b2, ctx.act, colsum=True)
-            dy2._hno_colsum = cs2
+            dy2._hno_colsum = (cs2, dy2._version)
         return dy1, None, dg1, db1, None, dy2, None, dg2, db2
 
 
