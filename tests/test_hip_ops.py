@@ -1312,7 +1312,27 @@ def test_limits_fail_loudly(pkg):
     with pytest.raises(Err):                           # the fused branch backward is built for 24 + 24 -> 24 only
         t = torch.randn(1, 8, 4, 4, 4, device='cuda')
         ops.pwconv_bwd_branch_raw(t, t, t, t, torch.randn(8, 16, device='cuda'), torch.randn(8, 8, device='cuda'), ops.ACT_SELU, ops.ACT_SELU)
-    assert 'hno_' in pkg._lib.lib().hno_last_error().decode() or True
+    # round 3: a padded channel stride is only understood by the 65 x 65 / 33 x 33 plane kernels; other grids refuse it, and the host
+    # side never hands them one (padded_ok); the fused spectral middle refuses configurations it was not built for
+    L = pkg._lib.lib()
+    assert L.hno_dht3_ld_supported(65, 65, 65, 10, 14, 14) == 1 and L.hno_dht3_ld_supported(33, 33, 33, 10, 14, 14) == 1
+    assert L.hno_dht3_ld_supported(61, 61, 61, 10, 14, 14) == 0 and L.hno_dht3_ld_supported(24, 24, 24, 4, 4, 4) == 0
+    assert not ops.padded_ok((61, 61, 61), (10, 14, 14)) and not ops.padded_ok((64, 64, 64), (10, 14, 14))
+    V, ld = 21 ** 3, ops._pad_ld(21 ** 3)
+    xp = ops.to_layout(torch.randn(1, 2, 21, 21, 21, device='cuda'), ld)
+    assert ops.chan_stride(xp) == ld
+    with pytest.raises(Err):
+        ops.dht3_crop_raw(xp, (4, 4, 4), 1.0)
+    with pytest.raises(Err):
+        ops.pad_idht3_raw(torch.randn(1, 2, 8, 8, 8, device='cuda'), (21, 21, 21), 1.0, None, ops.ACT_NONE, ld=ld)
+    assert L.hno_spec_mid_supported(24, 65, 10, 14, 14, 3) == 1 and L.hno_spec_mid_supported(16, 65, 10, 14, 14, 3) == 0
+    assert L.hno_spec_mid_supported(24, 61, 10, 14, 14, 3) == 0 and L.hno_spec_mid_supported(24, 65, 10, 14, 14, 5) == 0
+    assert not ops.spectral_chain_supported(torch.empty(1, 16, 65, 65, 65, device='cuda'), (10, 14, 14), 3)
+    # the repack kernel: contiguous <-> padded, padding zeroed, values untouched
+    t = torch.randn(2, 3, 5, 7, 9, device='cuda')
+    tp = ops.to_layout(t, ops._pad_ld(5 * 7 * 9))
+    assert ops.chan_stride(tp) == 320 and bool((tp == t).all()) and bool((ops._f32c(tp) == t).all())
+    assert bool((torch.empty(0, device='cuda').set_(tp.untyped_storage(), 0, (6, 320))[:, 315:] == 0).all())
 
 
 
