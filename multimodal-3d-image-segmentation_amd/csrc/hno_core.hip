@@ -7,6 +7,8 @@
 #include <mutex>
 #include <tuple>
 
+#include <stdlib.h>
+
 #include "hno_common.h"
 
 namespace hno {
@@ -64,7 +66,8 @@ int clear_doubles(double *p, int n, hipStream_t s) {
     return HNO_OK;
 }
 
-static int g_debug_flags = 0;
+// HNO_DEBUG_FLAGS=<int> presets the ablation / variant switches of hno_set_debug for a whole process (A/B runs of bench.py)
+static int g_debug_flags = getenv("HNO_DEBUG_FLAGS") ? atoi(getenv("HNO_DEBUG_FLAGS")) : 0;
 int debug_flags() { return g_debug_flags; }
 
 // ---- profiler state

@@ -2422,7 +2422,8 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const f
                 if (a.dbg & 2) {   // timing aid: no stores
                     asm volatile("" ::"v"(v));
                 } else if (e0 >= 0 && e0 + 3 < (int)n) {
-                    *reinterpret_cast<f32x4 *>(gbase + 256 * j) = v;          // wholly inside the chunk
+                    *reinterpret_cast<f32x4 *>(gbase + 256 * j) = v;          // wholly inside the chunk (write-through `sc1` stores, which
+                                                                              // pay in the forward kernel, cost 5 us here: 40.5 vs 35.2 us)
                 } else {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
