@@ -2211,6 +2211,8 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const f
         }
     };
     HNO_STAMP(a.stamps, 21);
+    // (Staggering the four waves of a SIMD by n x 1 024 cycles -- one computes while the others store -- was measured: 34.7 us at
+    // n = 0, 35.3 / 36.1 / 38.2 at n = 1 / 3 / 8 without residual; with residual 38.5 -> 36.9 at n = 3.  Not kept.)
     int it = 0;
     for (; t < t_end; t += NWV, ++it) {
         HNO_STAMP(a.stamps, 24 + it * 6);
@@ -2407,10 +2409,14 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const f
             float *gbase = out_al + (fch & ~3u) + 4 * lane;
             // (with a residual the image already holds scale * O + residual: see the DMA above)
             const f32x2 sc = {HAS_ADD ? 1.f : a.scale, HAS_ADD ? 1.f : a.scale};
+            // the image read of group j + 1 is issued before group j is worked on (reads past the last group stay inside the wave's own
+            // LDS area or the next wave's, values unused)
+            f32x4 onext = *reinterpret_cast<const f32x4 *>(limg + 4 * lane);
 #pragma unroll 1
             for (int j = 0; j < ng; ++j) {
                 const int e0 = (int)(4 * (64u * j + lane)) - (int)sh;
-                const f32x4 o = *reinterpret_cast<const f32x4 *>(limg + 256 * j + 4 * lane);
+                const f32x4 o = onext;
+                if (j + 1 < ng) onext = *reinterpret_cast<const f32x4 *>(limg + 256 * (j + 1) + 4 * lane);
                 // scale and activation on the packed fp32 pipe, two elements per instruction
                 f32x2 x0 = f32x2{o[0], o[1]} * sc;
                 f32x2 x1 = f32x2{o[2], o[3]} * sc;
