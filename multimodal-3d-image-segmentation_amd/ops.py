@@ -573,10 +573,10 @@ def spectral_chain_supported(x, modes, n_layers):
     return bool(_lib.lib().hno_spec_mid_supported(int(x.shape[1]), int(x.shape[2]), int(m0), int(m1), int(m2), int(n_layers)))
 
 
-def spectral_chain_fwd_raw(x, W, modes, act, scale_fwd, inv_act):
-    """TransformCrop -> n_XS frequency-domain layers -> PadInverse (+ activation) with the fused middle:
-    -> (z0, zs, u): what dht3_crop_raw / specmix_fwd_raw / pad_idht3_raw return."""
-    _need_gpu(x)
+def spectral_chain_fwd_raw(x, W, modes, act, scale_fwd, inv_act, residual=1, addend=None):
+    """TransformCrop -> n_XS frequency-domain layers z <- act((W [+ I]) z) -> PadInverse (+ addend, + activation) with the fused
+    middle: -> (z0, zs, u): what dht3_crop_raw / specmix_fwd_raw / pad_idht3_raw return."""
+    _need_gpu(x, addend)
     Ws = _mix_layers(W)
     B, C, N0, N1, N2 = x.shape
     m0, m1, m2 = modes
@@ -586,9 +586,10 @@ def spectral_chain_fwd_raw(x, W, modes, act, scale_fwd, inv_act):
     ld = chan_stride(x) or 0
     u = act_like(x)
     check(L.hno_dht3_planes(ptr(x), ptr(ws), B * C, N0, N1, N2, m0, m1, m2, ld, stream_ptr()), 'hno_dht3_planes')
-    check(L.hno_spec_mid_fwd(ptr(ws), _layer_ptrs(Ws), ptr(zall), B, C, N0, m0, m1, m2, Lyr, 1, act, float(scale_fwd), stream_ptr()),
+    addend = to_layout(addend, ld or None)
+    check(L.hno_spec_mid_fwd(ptr(ws), _layer_ptrs(Ws), ptr(zall), B, C, N0, m0, m1, m2, Lyr, int(residual), act, float(scale_fwd), stream_ptr()),
           'hno_spec_mid_fwd')
-    check(L.hno_idht3_planes(ptr(ws), None, inv_act, ptr(u), B * C, N0, N1, N2, m0, m1, m2, 1.0, ld, stream_ptr()), 'hno_idht3_planes')
+    check(L.hno_idht3_planes(ptr(ws), ptr(addend), inv_act, ptr(u), B * C, N0, N1, N2, m0, m1, m2, 1.0, ld, stream_ptr()), 'hno_idht3_planes')
     return zall[0], zall[1:], u
 
 
@@ -599,7 +600,7 @@ def spectral_chain_bwd_ok(xm, modes, z0, zs):
             and zs.is_contiguous() and z0.is_contiguous() and zs.data_ptr() == z0.data_ptr() + 4 * z0.numel())
 
 
-def spectral_chain_bwd_raw(g_u, z0, W, modes, act, scale_out, addend, defer=False):
+def spectral_chain_bwd_raw(g_u, z0, W, modes, act, scale_out, addend, defer=False, residual=1):
     """PadInverse^T -> backward of the n_XS frequency-domain layers -> TransformCrop^T (+ addend) with the fused middle: g_u is the
     gradient of PadInverse's pre-activation output, z0 the base of the stacked z_0 .. z_L of the forward; -> (g_xm, dW (L, C, C)).
     The gradients of the cropped spectra never reach memory."""
@@ -616,7 +617,7 @@ def spectral_chain_bwd_raw(g_u, z0, W, modes, act, scale_out, addend, defer=Fals
     g_xm = act_like(g_u)
     check(L.hno_dht3_planes(ptr(g_u), ptr(ws), B * C, N0, N1, N2, m0, m1, m2, ld or 0, stream_ptr()), 'hno_dht3_planes')
     with _DeferReduce(defer) as d:
-        check(L.hno_spec_mid_bwd(ptr(ws), _layer_ptrs(Ws), ptr(z0), ptr(dW), ptr(slab), B, C, N0, m0, m1, m2, Lyr, 1 | d.bit, act, 1.0,
+        check(L.hno_spec_mid_bwd(ptr(ws), _layer_ptrs(Ws), ptr(z0), ptr(dW), ptr(slab), B, C, N0, m0, m1, m2, Lyr, int(residual) | d.bit, act, 1.0,
                                  stream_ptr()), 'hno_spec_mid_bwd')
         d.keep(slab)
     check(L.hno_idht3_planes(ptr(ws), ptr(addend), ACT_NONE, ptr(g_xm), B * C, N0, N1, N2, m0, m1, m2, float(scale_out), ld or 0,
@@ -1334,9 +1335,14 @@ class NOBlockFn(_HnoFunction):
             y = irfft3_pad_raw(s1, spatial, 1.0, True, x2, inv_act, ld=ld)
         else:
             (w,) = op_ws
-            s0 = dht3_crop_raw(x, modes, 1.0 / n3)
-            s1 = pwconv_fwd_raw(s0, None, w, None, ACT_SELU)      # SELU in the frequency domain (hartley_operator.py:262-269)
-            y = pad_idht3_raw(s1, spatial, 1.0, x2, inv_act, ld=ld)
+            if spectral_chain_supported(x, modes, 1) and tuple(w.shape) == (x.shape[1], x.shape[1]):
+                # the fused middle with one layer and no residual identity: z1 = selu(W z0) (hartley_operator.py:262-269)
+                s0, zs, y = spectral_chain_fwd_raw(x, [w], modes, ACT_SELU, 1.0 / n3, inv_act, residual=0, addend=x2)
+                s1 = zs[0]
+            else:
+                s0 = dht3_crop_raw(x, modes, 1.0 / n3)
+                s1 = pwconv_fwd_raw(s0, None, w, None, ACT_SELU)      # SELU in the frequency domain (hartley_operator.py:262-269)
+                y = pad_idht3_raw(s1, spatial, 1.0, x2, inv_act, ld=ld)
         if fuse_tail:
             sop, y, out = y, act_like(x), act_like(x)
             check(_lib.lib().hno_pwconv_fwd_branch(ptr(sop), ptr(x), ptr(br_w), ptr(br_b), ptr(cat_w), ptr(cat_b), ptr(y), ptr(out),
@@ -1378,9 +1384,13 @@ class NOBlockFn(_HnoFunction):
             gx = irfft3_pad_raw(gs0, spatial, 1.0 / n3, False, g_x, ACT_NONE, ld=chan_stride(x))
             d_ops = (dwr, dwi)
         else:
-            gs1 = dht3_crop_raw(p, modes, 1.0)
-            gs0, _, dw, _ = pwconv_bwd_raw(gs1, s1, s0, None, w, ACT_SELU, False, defer=late)
-            gx = pad_idht3_raw(gs0, spatial, 1.0 / n3, g_x, ACT_NONE, ld=chan_stride(x))
+            if s1.dim() == 5 and spectral_chain_bwd_ok(x, modes, s0, s1.unsqueeze(0)):
+                gx, dW = spectral_chain_bwd_raw(p, s0, op_ws, modes, ACT_SELU, 1.0 / n3, g_x, defer=late, residual=0)
+                dw = dW[0]
+            else:
+                gs1 = dht3_crop_raw(p, modes, 1.0)
+                gs0, _, dw, _ = pwconv_bwd_raw(gs1, s1, s0, None, w, ACT_SELU, False, defer=late)
+                gx = pad_idht3_raw(gs0, spatial, 1.0 / n3, g_x, ACT_NONE, ld=chan_stride(x))
             d_ops = (dw,)
         return (gx, None, None, None, d_br_w, d_br_b, d_cat_w, d_cat_b) + d_ops
 

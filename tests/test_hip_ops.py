@@ -257,6 +257,18 @@ def test_channel_padded_activations_fnoseg_hnoseg(pkg, transform, monkeypatch):
     for g0, g1 in zip(res[0][2], res[1][2]):
         assert bool(torch.isfinite(g1).all())
         assert rel_err(g1.cpu().numpy(), g0.cpu().numpy()) < 2e-5
+    # the Hartley block runs its one frequency-domain layer through the fused spectral middle (L = 1, no residual identity,
+    # the conv branch as the inverse transform's residual): against the three-kernel path, which the G7 goldens pin
+    monkeypatch.setenv('HNO_FUSED_MID', '0')
+    monkeypatch.setenv('HNO_FUSED_MID_BWD', '0')
+    torch.manual_seed(12)
+    net = NeuralOperatorSeg(4, 4, 24, 3, (10, 14, 14), transform, device='cuda')
+    probs = net(img)
+    loss, _ = ops.SegLossFn.apply(probs, lab, 0, 0.0)
+    loss.backward()
+    assert rel_err(probs.detach().cpu().numpy(), res[1][0].cpu().numpy()) < 5e-6
+    for p_, g1 in zip(net.parameters(), res[1][2]):
+        assert rel_err(g1.cpu().numpy(), p_.grad.cpu().numpy()) < 1e-4      # (bias gradients are cancelling sums: 3e-5 measured)
 
 
 @pytest.mark.parametrize('n', [65, 33])
