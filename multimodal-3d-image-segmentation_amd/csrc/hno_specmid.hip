@@ -422,6 +422,277 @@ __global__ __launch_bounds__(512, BWD ? 1 : 2) void spec_mid_kernel(MidArgs a) {
     HNO_STAMP(a.stamps, 22);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The same chain for the FOURIER block (FNOSeg: nets/fourier_operator.py:117-223 inside nets/architectures.py:511-608): axis D of the
+// rfft + mode selection -> complex channel mix (ONE real 2C x 2C product on [re | im] channels, hno_cmix_compose) -> zero pad + axis D
+// of the inverse; and its backward (the transposed D steps around  g <- W2^T g,  dW2 = g s0^T).  Differences to the Hartley kernel:
+// the spectrum is the HALF spectrum (k2 in [0, m2)), stored as real data (B, 2C, 2 m0, 2 m1, m2); a (k1, k2) column yields the 2 m0
+// complex modes (+-k0, k1, k2) only (no mirrored family); no activation, no residual; the c2r weights (1, 2, 2, ...) over k2 sit on
+// the forward D step of the backward and on the inverse D step of the forward.
+struct MidFArgs {
+    float *ws;                 // as MidArgs.ws
+    const float *W2;           // (2C, 2C) composed real form of the complex weights
+    float *s0;                 // (B, 2C, 2 m0, 2 m1, m2): forward: written (the cropped spectrum); backward: read
+    const float *tw;
+    float *partials;           // backward: one (2C x 2C) slab per workgroup
+    int B, m1, m2;
+    float scale;               // of the forward D step
+    int w_fwd, w_inv;          // c2r weights (2 for k2 > 0) on the forward / inverse D step
+    int dbg;
+};
+
+template <int N0, int M0, bool BWD>
+__global__ __launch_bounds__(512, 1) void spec_mid_fourier_kernel(MidFArgs a) {
+    constexpr int C = 24, C2 = 48, NK = 24, J = N0 / 2, K0 = M0 + 1;
+    constexpr int KC = (J + 1 + 3) / 4, KI = (K0 + 3) / 4, NMT = J / 16;
+    constexpr int S0 = 2 * M0;
+    constexpr int NMODE = S0 * 4;                      // (o0, column)
+    constexpr int NT = (NMODE + 31) / 32;
+    constexpr int NCT = C / 2;
+    constexpr int NPQ = C * 2 * 2 * K0 * 4, NZL = C2 * NT * 32;
+    constexpr int GLD = 34, TILE = 2 * C2 * GLD;
+    static_assert(J % 16 == 0 && K0 <= 16, "tile shapes");
+    extern __shared__ float lds[];
+    float *PQ = lds, *ZL = lds + NPQ, *GZ = ZL + NZL, *MINE = GZ + NT * TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, l15 = lane & 15;
+    const int m1 = a.m1, m2 = a.m2, K1S = 2 * m1 + 1, CP = K1S * 16;
+    const int pairs = (K1S + 1) / 2, G8 = (a.B * pairs + 7) & ~7;
+    const int w8 = blockIdx.x / G8, gidx = blockIdx.x - w8 * G8;
+    const int b = gidx / pairs, k1s = 2 * (gidx - b * pairs) + (w8 >> 2), kt2 = w8 & 3;
+    if (b >= a.B || k1s >= K1S) {
+        if (BWD)
+            for (int i = tid; i < C2 * C2; i += 512) a.partials[(size_t)blockIdx.x * (C2 * C2) + i] = 0.f;
+        return;
+    }
+    const int k1 = k1s - m1;
+    const size_t pstride = (size_t)2 * CP;
+    const int j = l15 & 3, part = (l15 >> 2) & 1, cloc = l15 >> 3;
+    float tcF[KC], tsF[KC], tcI[NMT][KI], tsI[NMT][KI];
+    {
+        const float *tb = a.tw + lane;
+#pragma unroll
+        for (int ks = 0; ks < KC; ++ks) {
+            tcF[ks] = tb[ks * 64];
+            tsF[ks] = tb[(KC + ks) * 64];
+        }
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < KI; ++ks) {
+                tcI[mt][ks] = tb[(2 * KC + (mt * 2 + 0) * KI + ks) * 64];
+                tsI[mt][ks] = tb[(2 * KC + (mt * 2 + 1) * KI + ks) * 64];
+            }
+    }
+    // ---- weights of the channel product as A operands of the 32x32x2 MFMA, two 32-row tiles (rows 48 .. 63 are zero):
+    //      forward: lane (row cl, half h), tile ot: W2[32 ot + cl][chan(ks, h)];  backward: the transpose, W2[chan(ks, h)][32 ot + cl].
+    //      Rows beyond 2C load row 0 and are selected away (no load under a lane condition, lesson 38).
+    const int h = lane >> 5, cl = lane & 31;
+    float wA[2][NK];
+    if (wave < NT) {
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+            const int row = ot * 32 + cl;
+            const bool ok = row < C2;
+            const int rs = ok ? row : 0;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const int ch = mid_chan(ks, h);
+                const float v = BWD ? a.W2[ch * C2 + rs] : a.W2[rs * C2 + ch];
+                wA[ot][ks] = ok ? v : 0.f;
+            }
+        }
+    }
+    // ---- phase 1: forward D step (identical to the Hartley kernel: the plane transform's output does not depend on the layout)
+    {
+        constexpr int TPW = (NCT + 7) / 8;
+        float va[TPW][KC], vb[TPW][KC];
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const int t = wave + 8 * u;
+            const int c = 2 * (t < NCT ? t : 0) + cloc;
+            const float *src = a.ws + ((size_t)(b * C + c) * N0) * pstride + (size_t)part * CP + k1s * 16 + kt2 * 4 + j;
+#pragma unroll
+            for (int ks = 0; ks < KC; ++ks) {
+                const int n = 4 * ks + q;
+                const bool in = n <= J, mir = n >= 1 && n <= J;
+                va[u][ks] = src[(size_t)(in ? n : 0) * pstride];
+                vb[u][ks] = src[(size_t)(mir ? N0 - n : 0) * pstride];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const int t = wave + 8 * u;
+            if (t >= NCT) break;
+            const int c = 2 * t + cloc;
+            f32x4 P = {0.f, 0.f, 0.f, 0.f}, Q = P;
+#pragma unroll
+            for (int ks = 0; ks < KC; ++ks) {
+                const int n = 4 * ks + q;
+                const float fa = n <= J ? va[u][ks] : 0.f, fb = (n >= 1 && n <= J) ? vb[u][ks] : 0.f;
+                P = mfma16(tcF[ks], fa + fb, P);
+                Q = mfma16(tsF[ks], fa - fb, Q);
+            }
+            float *dst = PQ + (((c * 2 + part) * 2) * K0) * 4 + j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k0 = 4 * q + r;
+                if (k0 < K0) {
+                    dst[k0 * 4] = P[r];
+                    dst[(K0 + k0) * 4] = Q[r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2 + 3: complex spectrum of the tile's modes as 2C real channel values per mode, then the channel product
+    const int S1 = 2 * m1;
+    const size_t chs = (size_t)S0 * S1 * m2;          // floats per real channel of the spectrum
+    if (wave < NT) {
+        const int mi = wave * 32 + cl;                // mode index: column fastest, then o0
+        const int jm = mi & 3, o0 = mi >> 2;
+        const int k2 = kt2 * 4 + jm;
+        const int kk = o0 < M0 ? o0 : o0 - S0;        // signed k0 of this position
+        const int ka = kk < 0 ? -kk : kk;
+        const int o1 = k1 < m1 ? (k1 >= 0 ? k1 : k1 + S1) : -1;      // kept position of k1 in [-m1, m1)
+        const bool valid = mi < NMODE && k2 < m2 && o1 >= 0;
+        const size_t zoff = valid ? ((size_t)o0 * S1 + o1) * m2 + k2 : 0;
+        const float wf = a.scale * ((a.w_fwd && k2 > 0) ? 2.f : 1.f);
+        float z[NK];
+#pragma unroll
+        for (int ks = 0; ks < NK / 2; ++ks) {
+            const int c = mid_chan(ks, h);
+            const float *pq = PQ + ((c * 2) * 2 * K0 + (valid ? ka : 0)) * 4 + jm;
+            const float PR = pq[0], QR = pq[K0 * 4], PI = pq[2 * K0 * 4], QI = pq[3 * K0 * 4];
+            // X(+k0) = (PR + QI) + i (PI - QR),  X(-k0) = (PR - QI) + i (PI + QR)
+            const float xr = kk >= 0 ? PR + QI : PR - QI, xi = kk >= 0 ? PI - QR : PI + QR;
+            z[ks] = valid ? wf * xr : 0.f;            // real channels chan(ks, h)      (ks < 12: the re block)
+            z[ks + NK / 2] = valid ? wf * xi : 0.f;   //               chan(ks + 12, h) = C + chan(ks, h): the im block
+        }
+        float *sb = a.s0 + (size_t)b * C2 * chs;
+        f32x16 acc[2];
+        if (!BWD) {
+            if (valid) {
+#pragma unroll
+                for (int ks = 0; ks < NK; ++ks) sb[(size_t)mid_chan(ks, h) * chs + zoff] = z[ks];
+            }
+        } else {
+            // weight gradient of the product: dW2[o][i] = sum over modes of g[o] s0[i]; channels become MFMA rows through the wave's LDS
+            float zi[NK];
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) zi[ks] = sb[(size_t)mid_chan(ks, h) * chs + zoff];
+            float *G = GZ + wave * TILE, *Z = G + C2 * GLD;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const int ch = mid_chan(ks, h);
+                G[ch * GLD + cl] = z[ks];
+                Z[ch * GLD + cl] = valid ? zi[ks] : 0.f;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float *ga = G + l15 * GLD + q, *za = Z + l15 * GLD + q;
+            f32x4 dw[3][3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int nn = 0; nn < 3; ++nn) dw[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+            for (int kq = 0; kq < 8; ++kq) {
+                float av[3], bv[3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    av[m] = ga[m * 16 * GLD + kq * 4];
+                    bv[m] = za[m * 16 * GLD + kq * 4];
+                }
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < 3; ++nn) dw[m][nn] = mfma16(av[m], bv[nn], dw[m][nn]);
+            }
+            float *mine = MINE + wave * (C2 * C2);
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int nn = 0; nn < 3; ++nn)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mine[(m * 16 + q * 4 + r) * C2 + nn * 16 + l15] = dw[m][nn][r];
+        }
+        // the channel product (forward: s1 = W2 s0; backward: g0 = W2^T g1)
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ot][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[ot][ks], z[ks], acc[ot], 0, 0, 0);
+        }
+        // accumulator register r of tile ot, lane (mode cl, half h): output channel 32 ot + (r & 3) + 8 (r >> 2) + 4 h
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (ot == 0 || r < 8) ZL[row * (NT * 32) + mi] = valid ? acc[ot][r] : 0.f;
+            }
+    }
+    __syncthreads();
+    if (BWD) {
+        float *slab = a.partials + (size_t)blockIdx.x * (C2 * C2);
+        for (int i = tid; i < C2 * C2; i += 512) {
+            float sum = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NT; ++wv) sum += MINE[wv * (C2 * C2) + i];
+            slab[i] = sum;
+        }
+    }
+    // ---- phase 4: zero pad + inverse D step of column (k1s, 4 kt2 + j), channel c, re / im part
+    for (int t = wave; t < NCT; t += 8) {
+        const int c = 2 * t + cloc;
+        const int k2 = kt2 * 4 + j;
+        const float wi = (a.w_inv && k2 > 0) ? 2.f : 1.f;
+        auto zz = [&](int isim, int kap) -> float {
+            const bool ok = kap >= -M0 && kap < M0;
+            const int o0 = kap >= 0 ? kap : kap + S0;
+            const float v = ZL[(isim * C + c) * (NT * 32) + (ok ? o0 : 0) * 4 + j];
+            return ok ? wi * v : 0.f;
+        };
+        float gs[KI], gd[KI];
+#pragma unroll
+        for (int ks = 0; ks < KI; ++ks) {
+            const int k = 4 * ks + q;
+            const bool in = k <= M0;
+            // G'(+k0) = pr + i pi, G'(-k0) = mr + i mi  (positions outside the kept block are zero; ZL holds zeros for unkept columns)
+            const float pr = zz(0, k), pi = zz(1, k), mr = k ? zz(0, -k) : 0.f, mi_ = k ? zz(1, -k) : 0.f;
+            gs[ks] = in ? (part ? pi + mi_ : pr + mr) : 0.f;
+            gd[ks] = in ? (part ? pr - mr : pi - mi_) : 0.f;
+        }
+        float *dst = a.ws + ((size_t)(b * C + c) * N0) * pstride + (size_t)part * CP + k1s * 16 + kt2 * 4 + j;
+        {
+            float u0 = gs[0];
+#pragma unroll
+            for (int ks = 1; ks < KI; ++ks) u0 += gs[ks];
+            u0 += __shfl_xor(u0, 16);
+            u0 += __shfl_xor(u0, 32);
+            if (q == 0) dst[0] = u0;
+        }
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) {
+            f32x4 U = {0.f, 0.f, 0.f, 0.f}, V = U;
+#pragma unroll
+            for (int ks = 0; ks < KI; ++ks) {
+                U = mfma16(tcI[mt][ks], gs[ks], U);
+                V = mfma16(tsI[mt][ks], gd[ks], V);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = 1 + 16 * mt + 4 * q + r;
+                const float en = part ? U[r] + V[r] : U[r] - V[r], em = part ? U[r] - V[r] : U[r] + V[r];
+                dst[(size_t)n * pstride] = en;
+                dst[(size_t)(N0 - n) * pstride] = em;
+            }
+        }
+    }
+}
+
 // ---- twiddle tables, cached per (device, N0, M0)
 static std::map<std::tuple<int, int, int>, float *> g_mid_tw;
 static std::mutex g_mid_mutex;
@@ -572,4 +843,73 @@ extern "C" int hno_spec_mid_bwd(void *workspace, const float *const *W_layers, c
     struct Restore { int v; ~Restore() { hno_set_defer_reduce(v); } } restore{prev};
     hno_set_defer_reduce(((residual >> 8) & 1) ? 1 : prev);
     return reduce_partials_launch(a.partials, nwg, n, dW, n, nullptr, s);
+}
+
+// ---- Fourier block (spec_mid_fourier_kernel) ---------------------------------------------------------------------------------------
+extern "C" int hno_spec_mid_fourier_supported(int C, int N0, int m0, int m1, int m2) {
+    return C == 24 && (N0 == 65 || N0 == 33) && m0 == 10 && 2 * m0 <= N0 && m1 >= 1 && m1 <= 15 && m2 >= 1 && m2 <= 15;
+}
+
+static int mid_fourier_launch(bool bwd, void *workspace, const float *W2, float *s0, float *dW2, void *slab_workspace, int B, int C, int N0,
+                              int m0, int m1, int m2, float scale, int w_fwd, int w_inv, void *stream) {
+    if (!hno_spec_mid_fourier_supported(C, N0, m0, m1, m2)) return fail(HNO_ELIMIT, "hno_spec_mid_fourier: unsupported configuration");
+    MidFArgs a = {};
+    a.ws = (float *)workspace;
+    a.W2 = W2;
+    a.s0 = s0;
+    a.partials = (float *)slab_workspace;
+    a.B = B;
+    a.m1 = m1;
+    a.m2 = m2;
+    a.scale = scale;
+    a.w_fwd = w_fwd;
+    a.w_inv = w_inv;
+    a.dbg = debug_flags();
+    int rc = mid_twiddles(N0, m0, &a.tw);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int pairs = (2 * m1 + 1 + 1) / 2, G8 = (B * pairs + 7) & ~7, nwg = 8 * G8, n = 4 * C * C;
+    const int K0 = m0 + 1, NT = (2 * m0 * 4 + 31) / 32;
+    size_t lds = (size_t)C * 2 * 2 * K0 * 4 + (size_t)2 * C * NT * 32;
+    if (bwd) lds += (size_t)NT * 2 * 2 * C * 34 + (size_t)NT * n;
+    lds *= sizeof(float);
+    if (bwd && (size_t)nwg * n * sizeof(float) > hno_pwconv_bwd_workspace_bytes(2 * C, 2 * C))
+        return fail(HNO_ELIMIT, "hno_spec_mid_fourier_bwd: %d workgroups x %d floats exceed the slab workspace", nwg, n);
+    static bool attr_done = false;
+    if (!attr_done) {
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)spec_mid_fourier_kernel<65, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)spec_mid_fourier_kernel<33, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    {
+        ProfScope _ps(bwd ? KID_SPECMIX_BWD : KID_SPECMIX_FWD, s, 4.0 * B * C * (2.0 * N0 * 2 * (2 * m1 + 1) * 16 + 2 * 8.0 * m0 * m1 * m2));
+        if (N0 == 65 && bwd) hipLaunchKernelGGL((spec_mid_fourier_kernel<65, 10, true>), dim3(nwg), dim3(512), lds, s, a);
+        else if (N0 == 65) hipLaunchKernelGGL((spec_mid_fourier_kernel<65, 10, false>), dim3(nwg), dim3(512), lds, s, a);
+        else if (bwd) hipLaunchKernelGGL((spec_mid_fourier_kernel<33, 10, true>), dim3(nwg), dim3(512), lds, s, a);
+        else hipLaunchKernelGGL((spec_mid_fourier_kernel<33, 10, false>), dim3(nwg), dim3(512), lds, s, a);
+    }
+    HNO_CHECK_LAUNCH();
+    if (!bwd) return HNO_OK;
+    const int prev = hno_set_defer_reduce(0);      // the caller splits dW2 into its real / imaginary parts right away: reduce now
+    struct Restore { int v; ~Restore() { hno_set_defer_reduce(v); } } restore{prev};
+    return reduce_partials_launch(a.partials, nwg, n, dW2, n, nullptr, s);
+}
+
+// workspace: hno_dht3_planes of x on entry, the operand of hno_idht3_planes on return.  W2: (2C, 2C) from hno_cmix_compose.
+// s0 (B, 2C, 2 m0, 2 m1, m2): the cropped half spectrum, scaled by `scale` (and by the c2r weights when w_fwd), is written (it is what
+// hno_rfft3_crop returns); the mixed spectrum goes straight into the inverse D step (weights w_inv: 1 = the irfft's 1, 2, 2, ...).
+extern "C" int hno_spec_mid_fourier_fwd(void *workspace, const float *W2, float *s0, int B, int C, int N0, int m0, int m1, int m2, float scale,
+                                        int w_fwd, int w_inv, void *stream) {
+    HNO_REQUIRE(workspace && W2 && s0 && B > 0, "hno_spec_mid_fourier_fwd: bad argument");
+    return mid_fourier_launch(false, workspace, W2, s0, nullptr, nullptr, B, C, N0, m0, m1, m2, scale, w_fwd, w_inv, stream);
+}
+
+// backward: workspace = hno_dht3_planes of the gradient of the inverse transform's output; s0 as written by the forward;
+// dW2 (2C, 2C) <- sum over modes of g s0^T (hno_cmix_split_grad turns it into the gradients of the real / imaginary weights);
+// slab_workspace: hno_pwconv_bwd_workspace_bytes(2C, 2C) bytes.  On return the workspace is the operand of hno_idht3_planes.
+extern "C" int hno_spec_mid_fourier_bwd(void *workspace, const float *W2, const float *s0, float *dW2, void *slab_workspace, int B, int C,
+                                        int N0, int m0, int m1, int m2, float scale, int w_fwd, int w_inv, void *stream) {
+    HNO_REQUIRE(workspace && W2 && s0 && dW2 && slab_workspace && B > 0, "hno_spec_mid_fourier_bwd: bad argument");
+    return mid_fourier_launch(true, workspace, W2, const_cast<float *>(s0), dW2, slab_workspace, B, C, N0, m0, m1, m2, scale, w_fwd, w_inv,
+                              stream);
 }

@@ -625,6 +625,54 @@ def spectral_chain_bwd_raw(g_u, z0, W, modes, act, scale_out, addend, defer=Fals
     return g_xm, dW
 
 
+def fourier_chain_supported(x, modes):
+    """fused middle of the Fourier block (hno_spec_mid_fourier_*): 24 channels on 65^3 / 33^3 grids; HNO_FUSED_MID=0 switches it off."""
+    if os.environ.get('HNO_FUSED_MID', '1') == '0' or x.dim() != 5:
+        return False
+    m0, m1, m2 = modes
+    return bool(_lib.lib().hno_spec_mid_fourier_supported(int(x.shape[1]), int(x.shape[2]), int(m0), int(m1), int(m2)))
+
+
+def fourier_chain_fwd_raw(x, w2, modes, scale_fwd, addend, inv_act):
+    """rfftn + mode selection -> complex channel mix (w2: the composed real (2C, 2C) form) -> zero pad + irfftn (+ addend, + activation)
+    with the fused middle: -> (s0, y) = what rfft3_crop_raw returns and irfft3_pad_raw(pwconv(s0, w2), ...) returns."""
+    _need_gpu(x, addend)
+    B, C, N0, N1, N2 = x.shape
+    m0, m1, m2 = modes
+    L = _lib.lib()
+    ld = chan_stride(x) or 0
+    addend = to_layout(addend, ld or None)
+    ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, N0, N1, N2, m0, m1, m2) // 4, device=x.device, dtype=torch.float32)
+    s0 = torch.empty((B, 2 * C, 2 * m0, 2 * m1, m2), device=x.device, dtype=torch.float32)
+    y = act_like(x)
+    check(L.hno_dht3_planes(ptr(x), ptr(ws), B * C, N0, N1, N2, m0, m1, m2, ld, stream_ptr()), 'hno_dht3_planes')
+    check(L.hno_spec_mid_fourier_fwd(ptr(ws), ptr(w2), ptr(s0), B, C, N0, m0, m1, m2, float(scale_fwd), 0, 1, stream_ptr()),
+          'hno_spec_mid_fourier_fwd')
+    check(L.hno_idht3_planes(ptr(ws), ptr(addend), inv_act, ptr(y), B * C, N0, N1, N2, m0, m1, m2, 1.0, ld, stream_ptr()), 'hno_idht3_planes')
+    return s0, y
+
+
+def fourier_chain_bwd_raw(p, s0, w2, modes, scale_out, addend):
+    """backward of the same chain: p = gradient of the inverse transform's (pre-activation) output -> (gx, dW2 (2C, 2C)); the gradients
+    of the spectra never reach memory."""
+    _need_gpu(p, addend)
+    B, C, N0, N1, N2 = p.shape
+    m0, m1, m2 = modes
+    L = _lib.lib()
+    ld = chan_stride(p) or 0
+    addend = to_layout(addend, ld or None)
+    ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, N0, N1, N2, m0, m1, m2) // 4, device=p.device, dtype=torch.float32)
+    slab = torch.empty(L.hno_pwconv_bwd_workspace_bytes(2 * C, 2 * C) // 4, device=p.device, dtype=torch.float32)
+    dw2 = torch.empty((2 * C, 2 * C), device=p.device, dtype=torch.float32)
+    gx = act_like(p)
+    check(L.hno_dht3_planes(ptr(p), ptr(ws), B * C, N0, N1, N2, m0, m1, m2, ld, stream_ptr()), 'hno_dht3_planes')
+    check(L.hno_spec_mid_fourier_bwd(ptr(ws), ptr(w2), ptr(s0), ptr(dw2), ptr(slab), B, C, N0, m0, m1, m2, 1.0, 1, 0, stream_ptr()),
+          'hno_spec_mid_fourier_bwd')
+    check(L.hno_idht3_planes(ptr(ws), ptr(addend), ACT_NONE, ptr(gx), B * C, N0, N1, N2, m0, m1, m2, float(scale_out), ld, stream_ptr()),
+          'hno_idht3_planes')
+    return gx, dw2
+
+
 def specmix_bwd_raw(g, z0, zs, W, residual, act, defer=False):
     Ws = _mix_layers(W)
     B, C = z0.shape[:2]
@@ -1330,9 +1378,12 @@ class NOBlockFn(_HnoFunction):
             Co, Ci = wr.shape
             w = torch.empty((2 * Co, 2 * Ci), device=x.device, dtype=torch.float32)
             check(_lib.lib().hno_cmix_compose(ptr(wr), ptr(wi), ptr(w), Co, Ci, stream_ptr()), 'hno_cmix_compose')
-            s0 = rfft3_crop_raw(x, modes, 1.0 / n3, False)
-            s1 = pwconv_fwd_raw(s0, None, w, None, ACT_NONE)
-            y = irfft3_pad_raw(s1, spatial, 1.0, True, x2, inv_act, ld=ld)
+            if Co == Ci == x.shape[1] and fourier_chain_supported(x, modes):
+                s0, y = fourier_chain_fwd_raw(x, w, modes, 1.0 / n3, x2, inv_act)
+            else:
+                s0 = rfft3_crop_raw(x, modes, 1.0 / n3, False)
+                s1 = pwconv_fwd_raw(s0, None, w, None, ACT_NONE)
+                y = irfft3_pad_raw(s1, spatial, 1.0, True, x2, inv_act, ld=ld)
         else:
             (w,) = op_ws
             if spectral_chain_supported(x, modes, 1) and tuple(w.shape) == (x.shape[1], x.shape[1]):
@@ -1375,13 +1426,18 @@ class NOBlockFn(_HnoFunction):
                 _, _, d_br_w, d_br_b = pwconv_bwd_raw(p, None, x, None, br_w, ACT_NONE, br_has_b, accumulate_into=(g_x, None),
                                                       defer=late, bf16=ctx.bf16)
         if fourier:
-            gs1 = rfft3_crop_raw(p, modes, 1.0, True)
-            gs0, _, dw2, _ = pwconv_bwd_raw(gs1, None, s0, None, w, ACT_NONE, False)
             Co, Ci = w.shape[0] // 2, w.shape[1] // 2
+            fused = Co == Ci == x.shape[1] and fourier_chain_supported(x, modes) and os.environ.get('HNO_FUSED_MID_BWD', '1') != '0'
+            if fused:
+                gx, dw2 = fourier_chain_bwd_raw(p, s0, w, modes, 1.0 / n3, g_x)
+            else:
+                gs1 = rfft3_crop_raw(p, modes, 1.0, True)
+                gs0, _, dw2, _ = pwconv_bwd_raw(gs1, None, s0, None, w, ACT_NONE, False)
             dwr = torch.empty((Co, Ci), device=x.device, dtype=torch.float32)
             dwi = torch.empty_like(dwr)
             check(_lib.lib().hno_cmix_split_grad(ptr(dw2), ptr(dwr), ptr(dwi), Co, Ci, stream_ptr()), 'hno_cmix_split_grad')
-            gx = irfft3_pad_raw(gs0, spatial, 1.0 / n3, False, g_x, ACT_NONE, ld=chan_stride(x))
+            if not fused:
+                gx = irfft3_pad_raw(gs0, spatial, 1.0 / n3, False, g_x, ACT_NONE, ld=chan_stride(x))
             d_ops = (dwr, dwi)
         else:
             if s1.dim() == 5 and spectral_chain_bwd_ok(x, modes, s0, s1.unsqueeze(0)):

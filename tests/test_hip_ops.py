@@ -132,6 +132,40 @@ def test_fused_spectral_middle_backward_vs_three_kernel_path(pkg, n, act):
 
 
 @pytest.mark.parametrize('n', [65, 33])
+def test_fused_fourier_middle_vs_three_kernel_path(pkg, n):
+    """hno_dht3_planes -> hno_spec_mid_fourier_fwd / _bwd -> hno_idht3_planes (the D step of the rfft + crop, the complex channel mix and
+    the zero pad + D step of the inverse of a FNOSeg block, nets/fourier_operator.py:117-223, in one kernel each way) against
+    hno_rfft3_crop -> hno_pwconv -> hno_irfft3_pad, which the G3 / G7 goldens pin: cropped spectrum, block output with the conv branch as
+    residual, input gradient and the (2C, 2C) weight gradient; contiguous and channel-padded."""
+    from multimodal_3d_image_segmentation_amd import ops
+    torch.manual_seed(8)
+    modes, sp, C = (10, 14, 14), (n, n, n), 24
+    x = torch.randn(2, C, n, n, n, device='cuda')
+    add, p = torch.randn_like(x), torch.randn_like(x)
+    wr, wi = torch.randn(C, C, device='cuda') * 0.2, torch.randn(C, C, device='cuda') * 0.2
+    w2 = torch.empty(2 * C, 2 * C, device='cuda')
+    pkg._lib.check(pkg._lib.lib().hno_cmix_compose(pkg._lib.ptr(wr), pkg._lib.ptr(wi), pkg._lib.ptr(w2), C, C, pkg._lib.stream_ptr()), 'c')
+    assert ops.fourier_chain_supported(x, modes)
+    s0 = ops.rfft3_crop_raw(x, modes, 1.0 / n ** 3, False)
+    s1 = ops.pwconv_fwd_raw(s0, None, w2, None, ops.ACT_NONE)
+    y = ops.irfft3_pad_raw(s1, sp, 1.0, True, add, ops.ACT_SELU)
+    f0, fy = ops.fourier_chain_fwd_raw(x, w2, modes, 1.0 / n ** 3, add, ops.ACT_SELU)
+    assert rel_err(f0.cpu().numpy(), s0.cpu().numpy()) < 1e-6 and bool(((f0 == 0) == (s0 == 0)).all())
+    assert rel_err(fy.cpu().numpy(), y.cpu().numpy()) < 2e-6
+    gs1 = ops.rfft3_crop_raw(p, modes, 1.0, True)
+    gs0, _, dw2, _ = ops.pwconv_bwd_raw(gs1, None, s0, None, w2, ops.ACT_NONE, False)
+    gx = ops.irfft3_pad_raw(gs0, sp, 1.0 / n ** 3, False, add, ops.ACT_NONE)
+    fgx, fdw2 = ops.fourier_chain_bwd_raw(p, f0, w2, modes, 1.0 / n ** 3, add)
+    assert rel_err(fgx.cpu().numpy(), gx.cpu().numpy()) < 2e-6
+    assert rel_err(fdw2.cpu().numpy(), dw2.cpu().numpy()) < 1e-5
+    ld = ops._pad_ld(n ** 3)
+    p0, py = ops.fourier_chain_fwd_raw(ops.to_layout(x, ld), w2, modes, 1.0 / n ** 3, ops.to_layout(add, ld), ops.ACT_SELU)
+    assert ops.chan_stride(py) == ld and bool((py == fy).all()) and bool((p0 == f0).all())
+    pgx, pdw2 = ops.fourier_chain_bwd_raw(ops.to_layout(p, ld), f0, w2, modes, 1.0 / n ** 3, ops.to_layout(add, ld))
+    assert bool((pgx == fgx).all()) and bool((pdw2 == fdw2).all())
+
+
+@pytest.mark.parametrize('n', [65, 33])
 def test_channel_padded_activations_match_contiguous(pkg, n, monkeypatch):
     """Round 3: inside HNOSeg-XS the activations live with their channel stride rounded up to 128 B (ops.channel_padded; the odd
     65^3 = 274625-float rows of the contiguous layout cost the pointwise kernels 1.25x - 1.33x over-fetch).  Same numbers either way:
