@@ -1719,6 +1719,9 @@ class SegLossFn(_HnoFunction):
 
 
 # ------------------------------------------------------------------------- label helpers
+_label_maps = {}
+
+
 def labels_prepare(labels, num_classes, mapping=None, want_onehot=False):
     """(B,1,...) float/int labels -> uint8 class map (B,...) [+ one-hot fp32 (B,K,...)] on the GPU
     (experiments/utils.py:74-119)."""
@@ -1734,8 +1737,16 @@ def labels_prepare(labels, num_classes, mapping=None, want_onehot=False):
     rf = rt = None
     n = 0
     if mapping:
-        rf = torch.tensor(list(mapping.keys()), device=lab.device, dtype=torch.int32)
-        rt = torch.tensor(list(mapping.values()), device=lab.device, dtype=torch.int32)
+        # the two small tables go to the device ONCE per (mapping, device): a host-to-device copy per step is a synchronising copy in the
+        # reference's loop and is not allowed inside a captured step (experiments.train_test.CapturedStep)
+        key = (tuple(mapping.items()), str(lab.device))
+        hit = _label_maps.get(key)
+        if hit is None:
+            if len(_label_maps) > 16:
+                _label_maps.clear()
+            hit = _label_maps[key] = (torch.tensor(list(mapping.keys()), device=lab.device, dtype=torch.int32),
+                                      torch.tensor(list(mapping.values()), device=lab.device, dtype=torch.int32))
+        rf, rt = hit
         n = len(mapping)
     check(_lib.lib().hno_labels_prepare(ptr(lab), ptr(rf), ptr(rt), n, ptr(u8), ptr(onehot), B, num_classes, V, stream_ptr()),
           'hno_labels_prepare')

@@ -43,6 +43,27 @@ def test_training_matches_reference_trajectory(tmp_path):
         assert rel_err(v.cpu().numpy(), g[f'sd1::{k}']) < 2e-3, k
 
 
+def test_training_graph_replay_equals_eager(tmp_path):
+    """training() replays forward + loss + backward of recurring batch shapes from a HIP graph (CapturedStep, round 3): the same
+    kernels, so the same trajectory as eager launches -- and the first batch of a shape still runs eagerly."""
+    from multimodal_3d_image_segmentation_amd.experiments import train_test as tt
+    g = load_golden('g8_training.npz')
+    runs = {}
+    for tag, flag in (('graph', True), ('eager', False)):
+        model, opt, sched, data, loss_fn = _setup(g)
+        before = dict(tt.step_stats)
+        tt.training(model, data, str(tmp_path / tag), loss_fn, opt, sched, label_mapping=TRAIN_CASE['mapping'],
+                    num_epochs=TRAIN_CASE['epochs'], selection_epoch_portion=0.5, checkpoint_epoch=2, is_print=False,
+                    device='cuda', use_graph=flag)
+        n_rep, n_eag = tt.step_stats['replayed'] - before['replayed'], tt.step_stats['eager'] - before['eager']
+        assert ((n_rep > 0 and n_eag == 1) if flag else (n_rep == 0 and n_eag > 1)), (tag, n_rep, n_eag)
+        runs[tag] = (tt.get_losses_from_file(os.path.join(tmp_path / tag, 'stdout.txt')), [v.clone() for v in model.state_dict().values()])
+    assert np.abs(np.array(runs['graph'][0][0]) - np.array(runs['eager'][0][0])).max() < 2e-6
+    assert np.abs(np.array(runs['graph'][0][1]) - np.array(runs['eager'][0][1])).max() < 2e-6
+    for a, b in zip(runs['graph'][1], runs['eager'][1]):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-4
+
+
 def test_training_resume_from_checkpoint(tmp_path):
     from multimodal_3d_image_segmentation_amd.experiments import train_test as tt
     g = load_golden('g8_training.npz')
