@@ -246,6 +246,14 @@ int hno_up_argmax(const float *logits_lr, unsigned char *labels, int B, int K, i
 size_t hno_upsoftmax_bwd_workspace_bytes(int B, int K, int d, int h, int w, int D, int H, int W);
 int hno_upsoftmax_bwd(const float *g_probs, const float *probs, float *g_lr, void *workspace, int B, int K, int d,
                       int h, int w, int D, int H, int W, int softmax, void *stream);
+/* the head on a channel-padded low-resolution tensor (ldlr = floats between consecutive (b, k) volumes of logits_lr / g_lr, 0 = d h w;
+ * the backward zeroes the padding of g_lr and needs the separable form: workspace > 0) */
+int hno_upsoftmax_fwd_ld(const float *logits_lr, float *probs, int B, int K, int d, int h, int w, int D, int H, int W, int softmax,
+                         long long ldlr, void *stream);
+int hno_up_argmax_ld(const float *logits_lr, unsigned char *labels, int B, int K, int d, int h, int w, int D, int H, int W, long long ldlr,
+                     void *stream);
+int hno_upsoftmax_bwd_ld(const float *g_probs, const float *probs, float *g_lr, void *workspace, int B, int K, int d, int h, int w, int D,
+                         int H, int W, int softmax, long long ldlr, void *stream);
 
 /* ------------------------------------------------------------------ V-Net-DS building blocks
  * 3x3x3 convolutions as implicit GEMMs on the fp32 matrix cores (reference: ConvNormAct /

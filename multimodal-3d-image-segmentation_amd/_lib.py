@@ -59,6 +59,9 @@ SIGNATURES = {
     'hno_up_argmax': (c_int, [c_void_p] * 2 + [c_int] * 8 + [c_void_p]),
     'hno_upsoftmax_bwd_workspace_bytes': (c_size_t, [c_int] * 8),
     'hno_upsoftmax_bwd': (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
+    'hno_upsoftmax_fwd_ld': (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_ll, c_void_p]),
+    'hno_up_argmax_ld': (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_ll, c_void_p]),
+    'hno_upsoftmax_bwd_ld': (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_ll, c_void_p]),
     'hno_conv3d_k3_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'hno_conv3d_k3_fwd_workspace_bytes': (c_size_t, [c_int] * 7),
     'hno_conv3d_k3': (c_int, [c_void_p] * 5 + [c_size_t] + [c_int] * 13 + [c_void_p]),

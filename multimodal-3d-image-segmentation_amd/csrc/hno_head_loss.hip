@@ -35,6 +35,7 @@ struct UpArgs {
     int B, K, d, h, w, D, H, W;
     float sd, sh, sw;
     int softmax;
+    unsigned ldlr;     // floats between consecutive (b, k) volumes of the low-resolution tensor: d h w, or a channel-padded stride
 };
 
 template <int KMAX>
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void upsoftmax_fwd_kernel(UpArgs a) {
         for (int k = 0; k < KMAX; ++k) {
             val[k] = 0.f;
             if (k < a.K) {
-                const float *s = a.lr + ((size_t)b * a.K + k) * v_lr;
+                const float *s = a.lr + ((size_t)b * a.K + k) * a.ldlr;
                 // same association order as upsample_trilinear3d: w-lerp, then h, then d
                 const float c00 = lx.w0 * s[o00 + lx.i0] + lx.w1 * s[o00 + lx.i1];
                 const float c01 = lx.w0 * s[o01 + lx.i0] + lx.w1 * s[o01 + lx.i1];
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void uphead_seg_kernel(UpArgs a, unsigned char
         for (int k = 0; k < KMAX; ++k) {
             val[k] = 0.f;
             if (k < a.K) {
-                const float *s = a.lr + ((size_t)b * a.K + k) * v_lr;
+                const float *s = a.lr + ((size_t)b * a.K + k) * a.ldlr;
                 // same association order as upsample_trilinear3d: w-lerp, then h, then d
                 const float c00 = lx.w0 * s[o00 + lx.i0] + lx.w1 * s[o00 + lx.i1];
                 const float c01 = lx.w0 * s[o01 + lx.i0] + lx.w1 * s[o01 + lx.i1];
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void upargmax_kernel(UpArgs a, unsigned char *
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             if (k < a.K) {
-                const float *s = a.lr + ((size_t)b * a.K + k) * v_lr;
+                const float *s = a.lr + ((size_t)b * a.K + k) * a.ldlr;
                 const float c00 = lx.w0 * s[o00 + lx.i0] + lx.w1 * s[o00 + lx.i1];
                 const float c01 = lx.w0 * s[o01 + lx.i0] + lx.w1 * s[o01 + lx.i1];
                 const float c10 = lx.w0 * s[o10 + lx.i0] + lx.w1 * s[o10 + lx.i1];
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256) void upsoftmax_bwd_kernel(UpArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
-            if (k < a.K) a.out[((size_t)b * a.K + k) * v_lr + v] = acc[k];
+            if (k < a.K) a.out[((size_t)b * a.K + k) * a.ldlr + v] = acc[k];
     }
 }
 
@@ -268,6 +269,7 @@ struct UpBwdArgs {
     int B, K, d, h, w, D, H, W;
     float sd, sh, sw;
     int softmax, nsplit, dbg;
+    unsigned ldlr;     // channel stride of the low-resolution gradient (padding zeroed by upsoftmax_bwd_d_kernel)
 };
 
 template <int KMAX, int NC, int NI>   // NI: (row, quad) items per thread, UPB_ROWS * W / 4 <= NI * UPB_THREADS
@@ -427,7 +429,11 @@ __global__ __launch_bounds__(256) void upsoftmax_bwd_d_kernel(UpBwdArgs a) {
             const int z = z0 + t <= z1 ? z0 + t : z1;   // weight 0 beyond the range
             acc += wz[t] * Tb[(size_t)z * hw + i];
         }
-        a.out[((size_t)bk * a.d + iz) * hw + i] = acc;
+        a.out[(size_t)bk * a.ldlr + (size_t)iz * hw + i] = acc;
+    }
+    if (iz == 0 && blockIdx.x == 0 && a.ldlr > (unsigned)(a.d * hw)) {     // channel-padded gradient: the padding is zero (ops.chan_stride)
+        const unsigned npad = a.ldlr - (unsigned)(a.d * hw);
+        if (threadIdx.x < npad) a.out[(size_t)bk * a.ldlr + (size_t)a.d * hw + threadIdx.x] = 0.f;
     }
 }
 
@@ -655,14 +661,26 @@ static int up_fill(UpArgs &a, int B, int K, int d, int h, int w, int D, int H, i
     a.B = B; a.K = K; a.d = d; a.h = h; a.w = w; a.D = D; a.H = H; a.W = W;
     a.sd = (float)d / (float)D; a.sh = (float)h / (float)H; a.sw = (float)w / (float)W;
     a.softmax = softmax;
+    a.ldlr = (unsigned)((long long)d * h * w);
     return HNO_OK;
 }
 
-extern "C" int hno_upsoftmax_fwd(const float *logits_lr, float *probs, int B, int K, int d, int h, int w,
-                                 int D, int H, int W, int softmax, void *stream) {
+static int up_set_ld(UpArgs &a, long long ldlr) {
+    const long long v = (long long)a.d * a.h * a.w;
+    if (ldlr == 0) ldlr = v;
+    HNO_REQUIRE(ldlr >= v && ldlr < v + 64 && ldlr < (1ll << 31), "hno_upsoftmax: channel stride %lld for %lld low-resolution voxels", ldlr, v);
+    a.ldlr = (unsigned)ldlr;
+    return HNO_OK;
+}
+
+// ldlr: floats between consecutive (b, k) volumes of logits_lr (0 = d h w; a channel-padded stride: ops.chan_stride)
+extern "C" int hno_upsoftmax_fwd_ld(const float *logits_lr, float *probs, int B, int K, int d, int h, int w,
+                                    int D, int H, int W, int softmax, long long ldlr, void *stream) {
     HNO_REQUIRE(logits_lr && probs, "hno_upsoftmax_fwd: null pointer");
     UpArgs a = {};
     int rc = up_fill(a, B, K, d, h, w, D, H, W, softmax);
+    if (rc) return rc;
+    rc = up_set_ld(a, ldlr);
     if (rc) return rc;
     a.lr = logits_lr; a.out = probs;
     ProfScope _ps(KID_UPSOFTMAX_FWD, (hipStream_t)stream, 4.0 * B * K * ((double)d * h * w + (double)D * H * W));
@@ -682,11 +700,18 @@ extern "C" int hno_upsoftmax_fwd(const float *logits_lr, float *probs, int B, in
     return HNO_OK;
 }
 
-extern "C" int hno_up_argmax(const float *logits_lr, unsigned char *labels, int B, int K, int d, int h, int w, int D, int H,
-                             int W, void *stream) {
+extern "C" int hno_upsoftmax_fwd(const float *logits_lr, float *probs, int B, int K, int d, int h, int w,
+                                 int D, int H, int W, int softmax, void *stream) {
+    return hno_upsoftmax_fwd_ld(logits_lr, probs, B, K, d, h, w, D, H, W, softmax, 0, stream);
+}
+
+extern "C" int hno_up_argmax_ld(const float *logits_lr, unsigned char *labels, int B, int K, int d, int h, int w, int D, int H,
+                                int W, long long ldlr, void *stream) {
     HNO_REQUIRE(logits_lr && labels, "hno_up_argmax: null pointer");
     UpArgs a = {};
     int rc = up_fill(a, B, K, d, h, w, D, H, W, 0);
+    if (rc) return rc;
+    rc = up_set_ld(a, ldlr);
     if (rc) return rc;
     a.lr = logits_lr;
     ProfScope _ps(KID_UPSOFTMAX_FWD, (hipStream_t)stream, 4.0 * B * K * (double)d * h * w + (double)B * D * H * W);
@@ -706,6 +731,11 @@ extern "C" int hno_up_argmax(const float *logits_lr, unsigned char *labels, int 
     return HNO_OK;
 }
 
+extern "C" int hno_up_argmax(const float *logits_lr, unsigned char *labels, int B, int K, int d, int h, int w, int D, int H,
+                             int W, void *stream) {
+    return hno_up_argmax_ld(logits_lr, labels, B, K, d, h, w, D, H, W, 0, stream);
+}
+
 static bool upb_separable_ok(int K, int d, int h, int w, int D, int H, int W) {
     if (W % 4 != 0 || W > 4 * UPB_THREADS / UPB_ROWS * 2 || K * w > UPB_NC * UPB_THREADS) return false;
     if (w > W || h > H || d > D) return false;                       // taps bound assumes upsampling
@@ -718,20 +748,26 @@ extern "C" size_t hno_upsoftmax_bwd_workspace_bytes(int B, int K, int d, int h, 
     return sizeof(float) * (size_t)B * K * D * h * w;
 }
 
-extern "C" int hno_upsoftmax_bwd(const float *g_probs, const float *probs, float *g_lr, void *workspace, int B, int K, int d,
-                                 int h, int w, int D, int H, int W, int softmax, void *stream) {
+// ldlr: floats between consecutive (b, k) volumes of g_lr (0 = d h w; channel-padded: the padding is zeroed)
+extern "C" int hno_upsoftmax_bwd_ld(const float *g_probs, const float *probs, float *g_lr, void *workspace, int B, int K, int d,
+                                    int h, int w, int D, int H, int W, int softmax, long long ldlr, void *stream) {
     HNO_REQUIRE(g_probs && g_lr && (probs || !softmax), "hno_upsoftmax_bwd: null pointer");
     UpArgs a = {};
     int rc = up_fill(a, B, K, d, h, w, D, H, W, softmax);
     if (rc) return rc;
+    rc = up_set_ld(a, ldlr);
+    if (rc) return rc;
+    if (a.ldlr != (unsigned)((long long)d * h * w) && !(workspace && upb_separable_ok(K, d, h, w, D, H, W)))
+        return fail(HNO_ELIMIT, "hno_upsoftmax_bwd: a channel-padded gradient needs the separable form");
     a.gp = g_probs; a.p = probs; a.out = g_lr;
     hipStream_t s = (hipStream_t)stream;
     const double abytes = 4.0 * B * K * ((double)d * h * w + (softmax ? 2.0 : 1.0) * D * H * W);
-    if (workspace && upb_separable_ok(K, d, h, w, D, H, W) && !(debug_flags() & 16)) {
+    if (workspace && upb_separable_ok(K, d, h, w, D, H, W) && (!(debug_flags() & 16) || a.ldlr != (unsigned)((long long)d * h * w))) {
         UpBwdArgs u = {};
         u.gp = g_probs; u.p = probs; u.T = (float *)workspace; u.out = g_lr;
         u.B = B; u.K = K; u.d = d; u.h = h; u.w = w; u.D = D; u.H = H; u.W = W;
         u.sd = a.sd; u.sh = a.sh; u.sw = a.sw; u.softmax = softmax;
+        u.ldlr = a.ldlr;
         const int planes = B * D;
         int nsplit = (1024 + planes - 1) / planes;
         if (nsplit > h / 8) nsplit = h / 8;
@@ -765,6 +801,11 @@ extern "C" int hno_upsoftmax_bwd(const float *g_probs, const float *probs, float
     else { ProfScope _ps(KID_UPSOFTMAX_BWD, s, abytes); hipLaunchKernelGGL(upsoftmax_bwd_kernel<8>, dim3(grid), dim3(256), 0, s, a); }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
+}
+
+extern "C" int hno_upsoftmax_bwd(const float *g_probs, const float *probs, float *g_lr, void *workspace, int B, int K, int d,
+                                 int h, int w, int D, int H, int W, int softmax, void *stream) {
+    return hno_upsoftmax_bwd_ld(g_probs, probs, g_lr, workspace, B, K, d, h, w, D, H, W, softmax, 0, stream);
 }
 
 extern "C" int hno_loss_fwd(const float *probs, const uint8_t *labels, double *stats, float *coef, float *loss,

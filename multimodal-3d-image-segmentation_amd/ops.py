@@ -1604,14 +1604,15 @@ class UpSoftmaxFn(_HnoFunction):
 
     @staticmethod
     def forward(ctx, logits_lr, size, softmax):
-        lr = _f32c(logits_lr)
+        lr = _f32a(logits_lr)         # channel-padded logits are read in place (no repack kernel): the stride goes to the kernel
         _need_gpu(lr)
         B, K, d, h, w = lr.shape
         D, H, W = (int(s) for s in size)
         probs = torch.empty((B, K, D, H, W), device=lr.device, dtype=torch.float32)
-        check(_lib.lib().hno_upsoftmax_fwd(ptr(lr), ptr(probs), B, K, d, h, w, D, H, W, int(softmax), stream_ptr()),
+        ld = chan_stride(lr)
+        check(_lib.lib().hno_upsoftmax_fwd_ld(ptr(lr), ptr(probs), B, K, d, h, w, D, H, W, int(softmax), ld or 0, stream_ptr()),
               'hno_upsoftmax_fwd')
-        ctx.lr_shape, ctx.softmax = tuple(lr.shape), int(softmax)
+        ctx.lr_shape, ctx.softmax, ctx.lr_ld = tuple(lr.shape), int(softmax), ld
         if softmax:
             ctx.save_for_backward(probs)
         return probs
@@ -1622,11 +1623,12 @@ class UpSoftmaxFn(_HnoFunction):
         g = _f32c(g)
         B, K, d, h, w = ctx.lr_shape
         D, H, W = g.shape[2:]
-        g_lr = torch.empty(ctx.lr_shape, device=g.device, dtype=torch.float32)
         nws = _lib.lib().hno_upsoftmax_bwd_workspace_bytes(B, K, d, h, w, D, H, W)
         ws = torch.empty(nws // 4, device=g.device, dtype=torch.float32) if nws else None
-        check(_lib.lib().hno_upsoftmax_bwd(ptr(g), ptr(probs), ptr(g_lr), ptr(ws), B, K, d, h, w, D, H, W, ctx.softmax,
-                                           stream_ptr()), 'hno_upsoftmax_bwd')
+        ld = ctx.lr_ld if nws else None      # the gradient in the logits' own layout (padding zeroed by the kernel): separable form only
+        g_lr = act_empty(B, K, (d, h, w), g.device, ld)
+        check(_lib.lib().hno_upsoftmax_bwd_ld(ptr(g), ptr(probs), ptr(g_lr), ptr(ws), B, K, d, h, w, D, H, W, ctx.softmax, ld or 0,
+                                              stream_ptr()), 'hno_upsoftmax_bwd')
         return g_lr, None, None
 
 
@@ -1648,14 +1650,14 @@ def label_output():
 
 
 def up_argmax(logits_lr, size):
-    lr = _f32c(logits_lr.detach())
+    lr = _f32a(logits_lr.detach())
     if lr.is_meta:
         return _m((lr.shape[0], 1) + tuple(size), torch.uint8)
     _need_gpu(lr)
     B, K, d, h, w = lr.shape
     D, H, W = (int(s) for s in size)
     labels = torch.empty((B, 1, D, H, W), device=lr.device, dtype=torch.uint8)
-    check(_lib.lib().hno_up_argmax(ptr(lr), ptr(labels), B, K, d, h, w, D, H, W, stream_ptr()), 'hno_up_argmax')
+    check(_lib.lib().hno_up_argmax_ld(ptr(lr), ptr(labels), B, K, d, h, w, D, H, W, chan_stride(lr) or 0, stream_ptr()), 'hno_up_argmax')
     return labels
 
 

@@ -426,6 +426,26 @@ def test_upsoftmax(pkg, lr, hr, K, softmax):
     assert rel_err(gxd.cpu().numpy(), gx.numpy()) < 1e-5
 
 
+def test_head_on_channel_padded_logits(pkg):
+    """The head reads channel-padded low-resolution logits in place and returns their gradient in the same layout, padding zeroed
+    (hno_upsoftmax_fwd_ld / _bwd_ld / hno_up_argmax_ld): bit-identical to the contiguous tensors."""
+    from multimodal_3d_image_segmentation_amd import ops
+    torch.manual_seed(10)
+    lr, hr, K = (33, 33, 33), (64, 64, 64), 4
+    a = torch.randn((2, K) + lr, device='cuda')
+    ld = ops._pad_ld(33 ** 3)
+    cot = torch.randn((2, K) + hr, device='cuda')
+    res = []
+    for t in (a, ops.to_layout(a, ld)):
+        t = t.detach().requires_grad_(True)
+        probs = ops.UpSoftmaxFn.apply(t, hr, True)
+        (g,) = torch.autograd.grad((probs * cot).sum(), [t])
+        res.append((probs.detach(), g, ops.up_argmax(t, hr)))
+    assert ops.chan_stride(res[1][1]) == ld and ops.chan_stride(res[0][1]) is None
+    assert bool((res[0][0] == res[1][0]).all()) and bool((res[0][1] == res[1][1]).all()) and bool((res[0][2] == res[1][2]).all())
+    assert bool((torch.empty(0, device='cuda').set_(res[1][1].untyped_storage(), 0, (2 * K, ld))[:, 33 ** 3:] == 0).all())
+
+
 def test_losses_vs_golden(pkg):
     from multimodal_3d_image_segmentation_amd.nets import custom_losses as CL
     g = load_golden('g5_losses.npz')
