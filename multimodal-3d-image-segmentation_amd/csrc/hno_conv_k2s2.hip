@@ -48,6 +48,13 @@ __global__ __launch_bounds__(256) void conv_k2s2_fwd_kernel(K2Args a) {
     extern __shared__ float k2_ring[];                  // 4 waves x 2 slots x KS_MAX x 64 floats
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, c = lane & 31;
+    {   // channel-padded output: the last workgroup zeroes the (< 32-float) padding behind every (b, c) volume -- nobody else writes it
+        const unsigned Vo_ = (unsigned)a.Do * a.Ho * a.Wo;
+        if (a.ldy > Vo_ && blockIdx.x == gridDim.x - 1) {
+            const unsigned npad = a.ldy - Vo_, tot = (unsigned)(a.B * a.Cout) * npad;
+            for (unsigned i = threadIdx.x; i < tot; i += 256) a.y[(size_t)(i / npad) * a.ldy + Vo_ + i % npad] = 0.f;
+        }
+    }
     const int nks = a.Cin * 4;
     float w[KS_MAX];
 #pragma unroll
@@ -360,13 +367,6 @@ static int k2_fill(K2Args &a, int B, int Cin, int Cout, int D, int H, int Wd, in
     return HNO_OK;
 }
 
-// rows of y whose channel stride exceeds the voxel count: the padding is zeroed (finite for every later reader, see ops.act_empty)
-__global__ void k2_zero_pad_kernel(float *y, unsigned rows, unsigned Vo, unsigned ldy) {
-    const unsigned npad = ldy - Vo;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * npad; i += gridDim.x * blockDim.x)
-        y[(size_t)(i / npad) * ldy + Vo + i % npad] = 0.f;
-}
-
 extern "C" int hno_conv_k2s2_fwd(const float *x, const float *W, const float *bias, float *y, int B, int Cin, int Cout,
                                  int D, int H, int Wd, int act, long long ldy, void *stream) {
     HNO_REQUIRE(x && W && y, "hno_conv_k2s2_fwd: null pointer");
@@ -393,10 +393,6 @@ extern "C" int hno_conv_k2s2_fwd(const float *x, const float *W, const float *bi
         }
     }
     HNO_CHECK_LAUNCH();
-    if (a.ldy > (unsigned)Vo_) {
-        hipLaunchKernelGGL(k2_zero_pad_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, y, (unsigned)(B * Cout), (unsigned)Vo_, a.ldy);
-        HNO_CHECK_LAUNCH();
-    }
     return HNO_OK;
 }
 
