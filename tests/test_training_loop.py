@@ -64,6 +64,30 @@ def test_training_graph_replay_equals_eager(tmp_path):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-4
 
 
+def test_training_graph_replay_with_ragged_last_batch(tmp_path):
+    """Five samples in batches of two: shapes (2, ...) and (1, ...) alternate.  Each shape runs eagerly once, then from its own graph;
+    gradients written by one form must never leak into a step of the other (CapturedStep re-installs .grad after every replay)."""
+    import multimodal_3d_image_segmentation_amd as pkg
+    from multimodal_3d_image_segmentation_amd.experiments import train_test as tt
+    from multimodal_3d_image_segmentation_amd.experiments.synthetic import SyntheticInputData
+    from multimodal_3d_image_segmentation_amd.nets import custom_losses
+    runs = {}
+    for tag, flag in (('graph', True), ('eager', False)):
+        torch.manual_seed(2)
+        model = pkg.nets.HNOSegXS(2, 3, 8, [1, 1, 1], (3, 3, 3))
+        opt = pkg.optim.Adamax(model.parameters(), lr=5e-3)
+        data = SyntheticInputData((16, 16, 16), 2, 3, batch_size=2, num_train=5, num_valid=2, seed=5)
+        before = dict(tt.step_stats)
+        tt.training(model, data, str(tmp_path / tag), custom_losses.DiceLoss(), opt, None, num_epochs=4, selection_epoch_portion=0.5,
+                    checkpoint_epoch=2, is_print=False, device='cuda', use_graph=flag)
+        n_rep, n_eag = tt.step_stats['replayed'] - before['replayed'], tt.step_stats['eager'] - before['eager']
+        assert (n_rep, n_eag) == ((10, 2) if flag else (0, 12)), (tag, n_rep, n_eag)
+        runs[tag] = (tt.get_losses_from_file(os.path.join(tmp_path / tag, 'stdout.txt')), [v.clone() for v in model.state_dict().values()])
+    assert np.abs(np.array(runs['graph'][0][0]) - np.array(runs['eager'][0][0])).max() < 2e-6
+    for a, b in zip(runs['graph'][1], runs['eager'][1]):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-4
+
+
 def test_training_resume_from_checkpoint(tmp_path):
     from multimodal_3d_image_segmentation_amd.experiments import train_test as tt
     g = load_golden('g8_training.npz')
