@@ -16,6 +16,7 @@ from os.path import join
 import numpy as np
 import torch
 
+from ..ops import backward_from
 from .utils import labels_to_u8, save_model_summary
 
 
@@ -59,7 +60,7 @@ class CapturedStep:
                     else:
                         for p in self.params:
                             p.grad = None
-                    loss.backward()
+                    ops.backward_from(loss)
                     if self.dp is not None:
                         self.dp.finish_capture()
             cur.wait_stream(side)
@@ -266,7 +267,7 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
                 scaler.step(optimizer)
                 scaler.update()
             else:
-                loss.backward()
+                backward_from(loss)            # loss.backward() with a cached root gradient (no fill kernel per step)
                 if data_parallel is not None:
                     data_parallel.allreduce_grads()
                 optimizer.step()

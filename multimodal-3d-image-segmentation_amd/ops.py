@@ -1706,10 +1706,13 @@ class SegLossFn(_HnoFunction):
                                       float(param), stream_ptr()), 'hno_loss_fwd')
         ctx.save_for_backward(probs, labels_u8, coef)
         ctx.mark_non_differentiable(coef)
+        ctx.set_materialize_grads(False)      # no zero tensor (a fill kernel per step) for the coefficient output's gradient
         return loss, coef
 
     @staticmethod
     def backward(ctx, gl, _gcoef):
+        if gl is None:
+            return None, None, None, None
         probs, labels_u8, coef = ctx.saved_tensors
         B, K = probs.shape[:2]
         V = _flat_v(probs)
@@ -1722,6 +1725,19 @@ class SegLossFn(_HnoFunction):
 
 # ------------------------------------------------------------------------- label helpers
 _label_maps = {}
+
+
+_ones = {}
+
+
+def backward_from(loss):
+    """``loss.backward()`` without the fill kernel autograd launches for its root gradient (``torch.ones_like(loss)`` every step): the
+    same d loss / d loss = 1, from a tensor kept per (device, dtype)."""
+    key = (loss.device, loss.dtype)
+    one = _ones.get(key)
+    if one is None:
+        one = _ones[key] = torch.ones((), device=loss.device, dtype=loss.dtype)
+    loss.backward(gradient=one.expand_as(loss) if loss.dim() else one)
 
 
 def labels_prepare(labels, num_classes, mapping=None, want_onehot=False):
