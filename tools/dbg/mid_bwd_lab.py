@@ -1,0 +1,52 @@
+"""Backward fused middle alone: time per call from a graph replay, debug ablations, phase stamps.  python tools/dbg/mid_bwd_lab.py"""
+import ctypes, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import multimodal_3d_image_segmentation_amd as pkg
+from multimodal_3d_image_segmentation_amd import ops
+sys.path.insert(0, os.path.join(ROOT, 'tools', 'dbg'))
+L = pkg._lib.lib()
+P, S = pkg._lib.ptr, pkg._lib.stream_ptr
+dev, N, B, C, modes = 'cuda', 65, 2, 24, (10, 14, 14)
+
+
+def timeit(fn, n=20, reps=5):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(n):
+                fn()
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / n * 1e3)
+    return best
+
+
+torch.manual_seed(0)
+Ws = [torch.randn(C, C, device=dev) * 0.2 for _ in range(3)]
+wp = ops._layer_ptrs(Ws)
+ws = torch.randn(L.hno_dht3_workspace_bytes(B * C, N, N, N, *modes) // 4, device=dev)
+zall = torch.randn((4, B, C, 20, 28, 28), device=dev)
+dW = torch.empty(3, C, C, device=dev)
+slab = torch.empty(L.hno_specmix_bwd_workspace_bytes(B, C, 8 * 10 * 14 * 14, 3) // 4, device=dev)
+call = lambda: L.hno_spec_mid_bwd(P(ws), wp, P(zall), P(dW), P(slab), B, C, N, *modes, 3, 1, 1, 1.0, S())
+for dbg, name in ((0, 'full'), (16, 'return at top'), (32, 'return after phase 1'), (64, 'return before phase 4'), (64 + 2, 'before phase 4, no layers'), (2, 'no layers'), (4, 'no inverse D')):
+    L.hno_set_debug(dbg)
+    print(f'hno_spec_mid_bwd alone [{name}]: {timeit(call):.1f} us (incl. the slab reduction launch)')
+L.hno_set_debug(0)
+fw = lambda: L.hno_spec_mid_fwd(P(ws), wp, P(zall), B, C, N, *modes, 3, 1, 1, 1.0 / N ** 3, S())
+print(f'hno_spec_mid_fwd alone: {timeit(fw):.1f} us')
+buf = (ctypes.c_longlong * 64)()
+call(); L.hno_debug_stamps(buf, 64)
+L.hno_set_debug(1024); call(); L.hno_set_debug(0); L.hno_debug_stamps(buf, 64)
+st = list(buf)
+print('stamps (cycles from kernel top): phase 1 done', st[1] - st[0], 'barrier', st[2] - st[0], 'first loads issued', st[3] - st[0],
+      'ZL written', st[20] - st[0], 'barrier', st[21] - st[0], 'end', st[22] - st[0])
