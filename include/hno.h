@@ -396,6 +396,12 @@ int hno_axpby(float alpha, const float *a, float beta, const float *b, float *ou
  */
 int hno_loss_fwd(const float *probs, const uint8_t *labels, double *stats, float *coef, float *loss,
                  int B, int K, long long V, int kind, float param, void *stream);
+/* the same with the statistics summed through per-workgroup rows instead of double atomics: no clear kernel, bit-reproducible loss.
+ * workspace: hno_loss_workspace_doubles(B, K, V) doubles; its first B K 4 doubles hold the statistics afterwards.  Falls back to the
+ * accumulating form when V % 4 != 0 or the pointers are not 16-byte aligned. */
+size_t hno_loss_workspace_doubles(int B, int K, long long V);
+int hno_loss_fwd_ws(const float *probs, const uint8_t *labels, double *workspace, size_t workspace_doubles, float *coef, float *loss,
+                    int B, int K, long long V, int kind, float param, void *stream);
 int hno_loss_bwd(const float *probs, const uint8_t *labels, const float *coef, const float *gscale,
                  float *g_probs, int B, int K, long long V, void *stream);
 

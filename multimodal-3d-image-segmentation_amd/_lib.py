@@ -102,6 +102,8 @@ SIGNATURES = {
     'hno_chan_restride': (c_int, [c_void_p, c_void_p, c_ll, c_ll, c_ll, c_ll, c_void_p]),
     'hno_axpby': (c_int, [c_float, c_void_p, c_float, c_void_p, c_void_p, c_ll, c_void_p]),
     'hno_loss_fwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_ll, c_int, c_float, c_void_p]),
+    'hno_loss_workspace_doubles': (c_size_t, [c_int, c_int, c_ll]),
+    'hno_loss_fwd_ws': (c_int, [c_void_p] * 3 + [c_size_t, c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_float, c_void_p]),
     'hno_loss_bwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_ll, c_void_p]),
     'hno_labels_prepare': (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 2 + [c_int, c_int, c_ll, c_void_p]),
     'hno_adamax_chunk_rows': (c_int, []),

@@ -6,6 +6,7 @@
 // per-channel linear interpolation), corrcoef/PCCLoss/dice_coef/DiceLoss/ExpDiceLoss
 // (nets/custom_losses.py:17-133), to_categorical/remap_labels (experiments/utils.py:74-119).
 #include <math.h>
+#include <stdlib.h>
 
 #include "hno_common.h"
 
@@ -482,7 +483,10 @@ __global__ __launch_bounds__(256) void loss_stats_kernel(const float *__restrict
 // Vectorised form for V % 4 == 0: 16-byte loads of the probabilities, 4 labels per 32-bit load, fp32 sums of each
 // quad promoted to the fp64 accumulators, and FEW workgroups (128 per sample): the first version launched 2 048
 // workgroups whose 32 k same-address double atomics dominated its 46 us.
-template <int KMAX>
+// PART: every workgroup stores its sums to its own row of `stats` ([b][workgroup][K * 4]) instead of adding them to shared
+// accumulators: no same-address double atomics (256 per address and launch serialise in the L2), no clear kernel, and a loss that
+// is bit-reproducible; loss_finalize_kernel adds the rows in a fixed order.
+template <int KMAX, bool PART = false>
 __global__ __launch_bounds__(256) void loss_stats_vec_kernel(const float *__restrict__ p, const uint8_t *__restrict__ lab,
                                                             double *stats, int K, long long V) {
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -521,14 +525,45 @@ __global__ __launch_bounds__(256) void loss_stats_vec_kernel(const float *__rest
     __syncthreads();
     if (threadIdx.x < K * 4) {
         const double sv = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        atomicAdd(&stats[(size_t)b * K * 4 + threadIdx.x], sv);
+        if (PART) stats[((size_t)b * gridDim.x + blockIdx.x) * K * 4 + threadIdx.x] = sv;
+        else atomicAdd(&stats[(size_t)b * K * 4 + threadIdx.x], sv);
     }
 }
 
 // coef[b][k] = {value, alpha, beta, gamma} with  dloss/dp[b,k,v] = alpha * t_v + beta * p_v + gamma
 __global__ void loss_finalize_kernel(const double *stats, float *coef, float *loss, int B, int K, long long V, int kind,
-                                     float param) {
+                                     float param, const double *rows = nullptr, int nrows = 0, double *stats_out = nullptr) {
     __shared__ double part[256];
+    if (rows) {   // per-workgroup rows [b][nrows][K * 4] -> stats_out[b][K * 4], every sum in the same fixed order on every run:
+                  // n = K * 4 consecutive threads read one row (coalesced), G = 256 / n rows per pass; the G partial sums of a
+                  // statistic are then added in order
+        const int n = K * 4, G = (int)blockDim.x / n;
+        const int g = threadIdx.x / n, i = threadIdx.x - g * n;
+        for (int b = 0; b < B; ++b) {
+            double acc = 0.0;
+            if (g < G) {
+                const double *rb = rows + (size_t)b * nrows * n + i;
+                int w = g;
+                for (; w + 7 * G < nrows; w += 8 * G) {     // eight independent loads in flight, added in row order
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = rb[(size_t)(w + u * G) * n];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += v[u];
+                }
+                for (; w < nrows; w += G) acc += rb[(size_t)w * n];
+            }
+            part[threadIdx.x] = acc;
+            __syncthreads();
+            if ((int)threadIdx.x < n) {
+                double t = part[threadIdx.x];
+                for (int u = 1; u < G; ++u) t += part[u * n + threadIdx.x];
+                stats_out[b * n + threadIdx.x] = t;
+            }
+            __syncthreads();
+        }
+        stats = stats_out;
+    }
     double local = 0.0;
     const double n = (double)V, inv_bk = 1.0 / ((double)B * K);
     for (int i = threadIdx.x; i < B * K; i += blockDim.x) {
@@ -836,6 +871,49 @@ extern "C" int hno_loss_fwd(const float *probs, const uint8_t *labels, double *s
     else { ProfScope _ps(KID_LOSS_STATS, s, (double)B * V * (4.0 * K + 1)); hipLaunchKernelGGL(loss_stats_kernel<8>, dim3((int)gx, B), dim3(256), 0, s, probs, labels, stats, K, V); }
     HNO_CHECK_LAUNCH();
     { ProfScope _ps(KID_LOSS_FINALIZE, s); hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const double *)stats, coef, loss, B, K, V, kind, param); }
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+// the statistics through per-workgroup rows (no atomics, no clear kernel, bit-reproducible): workspace of hno_loss_workspace_doubles
+// doubles; its first B K 4 doubles hold the reduced statistics afterwards (what hno_loss_fwd leaves in `stats`)
+static int loss_rows(int B, long long V) {
+    long long gq = (V / 4 + 255) / 256;
+    static const int env = getenv("HNO_LOSS_ROWS") ? atoi(getenv("HNO_LOSS_ROWS")) : 0;
+    const long long cap = env > 0 ? env : 512;
+    if (gq > cap) gq = cap;
+    (void)B;
+    return (int)gq;
+}
+
+extern "C" size_t hno_loss_workspace_doubles(int B, int K, long long V) {
+    if (B <= 0 || K <= 0 || V <= 0) return 0;
+    return (size_t)B * K * 4 * (1 + (size_t)(V % 4 == 0 ? 1024 : 0));      // room for up to 1 024 rows per sample
+}
+
+extern "C" int hno_loss_fwd_ws(const float *probs, const uint8_t *labels, double *workspace, size_t workspace_doubles, float *coef,
+                               float *loss, int B, int K, long long V, int kind, float param, void *stream) {
+    HNO_REQUIRE(probs && labels && workspace && coef && loss && B > 0 && K > 0 && V > 0, "hno_loss_fwd_ws: bad argument");
+    HNO_REQUIRE(kind >= 0 && kind <= 2, "hno_loss_fwd_ws: kind must be 0 (PCC), 1 (Dice) or 2 (ExpDice)");
+    if (K > 8) return fail(HNO_ELIMIT, "hno_loss_fwd_ws: K=%d classes (max 8)", K);
+    const bool vec = V % 4 == 0 && ((size_t)labels & 3) == 0 && ((size_t)probs & 15) == 0 && !(debug_flags() & 16);
+    int gq = loss_rows(B, V);
+    if (gq > 1024) gq = 1024;
+    if (!vec || workspace_doubles < (size_t)B * K * 4 * (1 + (size_t)gq))
+        return hno_loss_fwd(probs, labels, workspace, coef, loss, B, K, V, kind, param, stream);      // the accumulating form
+    hipStream_t s = (hipStream_t)stream;
+    double *rows = workspace + (size_t)B * K * 4;
+    {
+        ProfScope _ps(KID_LOSS_STATS, s, (double)B * V * (4.0 * K + 1));
+        if (K <= 4) hipLaunchKernelGGL((loss_stats_vec_kernel<4, true>), dim3(gq, B), dim3(256), 0, s, probs, labels, rows, K, V);
+        else hipLaunchKernelGGL((loss_stats_vec_kernel<8, true>), dim3(gq, B), dim3(256), 0, s, probs, labels, rows, K, V);
+    }
+    HNO_CHECK_LAUNCH();
+    {
+        ProfScope _ps2(KID_LOSS_FINALIZE, s);
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const double *)workspace, coef, loss, B, K, V, kind, param,
+                           (const double *)rows, gq, workspace);
+    }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }

@@ -1699,11 +1699,12 @@ class SegLossFn(_HnoFunction):
         B, K = probs.shape[:2]
         V = _flat_v(probs)
         assert labels_u8.numel() == B * V
-        stats = torch.empty(B * K * 4, device=probs.device, dtype=torch.float64)
+        nws = _lib.lib().hno_loss_workspace_doubles(B, K, V)
+        stats = torch.empty(nws, device=probs.device, dtype=torch.float64)
         coef = torch.empty((B, K, 4), device=probs.device, dtype=torch.float32)
         loss = torch.empty((), device=probs.device, dtype=torch.float32)
-        check(_lib.lib().hno_loss_fwd(ptr(probs), ptr(labels_u8), ptr(stats), ptr(coef), ptr(loss), B, K, V, kind,
-                                      float(param), stream_ptr()), 'hno_loss_fwd')
+        check(_lib.lib().hno_loss_fwd_ws(ptr(probs), ptr(labels_u8), ptr(stats), nws, ptr(coef), ptr(loss), B, K, V, kind,
+                                         float(param), stream_ptr()), 'hno_loss_fwd_ws')
         ctx.save_for_backward(probs, labels_u8, coef)
         ctx.mark_non_differentiable(coef)
         ctx.set_materialize_grads(False)      # no zero tensor (a fill kernel per step) for the coefficient output's gradient
