@@ -446,6 +446,20 @@ def test_head_on_channel_padded_logits(pkg):
     assert bool((torch.empty(0, device='cuda').set_(res[1][1].untyped_storage(), 0, (2 * K, ld))[:, 33 ** 3:] == 0).all())
 
 
+def test_loss_is_bit_reproducible(pkg):
+    """Round 3: the loss statistics are summed through per-workgroup rows in a fixed order (no double atomics): the same inputs give the
+    same bits, run after run, at the benchmark's size."""
+    from multimodal_3d_image_segmentation_amd import ops
+    torch.manual_seed(11)
+    probs = torch.softmax(torch.randn(2, 4, 128, 128, 128, device='cuda'), dim=1)
+    lab = torch.randint(0, 4, (2, 128, 128, 128), device='cuda').to(torch.uint8)
+    for kind, param in ((0, 0.0), (1, 0.0), (2, 0.3)):
+        l0, c0 = ops.SegLossFn.apply(probs, lab, kind, param)
+        for _ in range(5):
+            l1, c1 = ops.SegLossFn.apply(probs, lab, kind, param)
+            assert bool(l1 == l0) and bool((c1 == c0).all())
+
+
 def test_losses_vs_golden(pkg):
     from multimodal_3d_image_segmentation_amd.nets import custom_losses as CL
     g = load_golden('g5_losses.npz')
