@@ -289,8 +289,8 @@ __device__ __forceinline__ int kept_pos(int k, int m, int full = 0) {
 // MFMA phases so HBM latency hides behind compute.  MAXE == 0: generic row-by-row path.
 // The folds x[n] +- x[N-n] (axis W) and T[n1] +- T[N1-n1] (axis H) are cheap in-place LDS passes
 // (a wave per row, no integer division), so the MFMA loops read plain pre-folded operands.
-template <int MAXE>
-__global__ __launch_bounds__(256) void dht_fwd_plane_kernel(const float *__restrict__ x, const float *__restrict__ xact,
+template <int MAXE, int NTH = 256>
+__global__ __launch_bounds__(NTH) void dht_fwd_plane_kernel(const float *__restrict__ x, const float *__restrict__ xact,
                                                             float *__restrict__ Y, DhtArgs a) {
     extern __shared__ float lds[];
     const DhtPlan &p = a.p;
@@ -301,28 +301,28 @@ __global__ __launch_bounds__(256) void dht_fwd_plane_kernel(const float *__restr
     const float *cosW = tabW, *sinW = tabW + a2.KT * a2.KcP * 16;
     const float *cosH = tabH, *sinH = tabH + a1.KT * a1.KcP * 16;
     // tables: contiguous in the plan buffer as cosF | sinF per axis
-    for (int i = tid; i < a2.KT * (a2.KcP + a2.KsP) * 16; i += 256) tabW[i] = p.tables[a2.cosF + i];
-    for (int i = tid; i < a1.KT * (a1.KcP + a1.KsP) * 16; i += 256) tabH[i] = p.tables[a1.cosF + i];
+    for (int i = tid; i < a2.KT * (a2.KcP + a2.KsP) * 16; i += NTH) tabW[i] = p.tables[a2.cosF + i];
+    for (int i = tid; i < a1.KT * (a1.KcP + a1.KsP) * 16; i += NTH) tabH[i] = p.tables[a1.cosF + i];
     // zero the padding of xs once (rows >= N1, columns >= N2): never overwritten below
-    for (int i = tid; i < (p.MP1 - N1) * p.lda2; i += 256) xs[N1 * p.lda2 + i] = 0.f;
+    for (int i = tid; i < (p.MP1 - N1) * p.lda2; i += NTH) xs[N1 * p.lda2 + i] = 0.f;
     const int padc = p.lda2 - N2;
-    for (int i = tid; i < N1 * padc; i += 256) xs[(i / padc) * p.lda2 + N2 + (i % padc)] = 0.f;
+    for (int i = tid; i < N1 * padc; i += NTH) xs[(i / padc) * p.lda2 + N2 + (i % padc)] = 0.f;
     // T rows >= N1 are reduction padding for axis H: keep them zero (stage W never stores there)
-    for (int i = tid; i < (p.TP - N1) * p.ldt; i += 256) T[N1 * p.ldt + i] = 0.f;
+    for (int i = tid; i < (p.TP - N1) * p.ldt; i += NTH) T[N1 * p.ldt + i] = 0.f;
 
     const int planes = a.BC * p.ax[0].N;
     const size_t plane_elems = (size_t)N1 * N2;
     const int MT1 = p.MP1 / 16;
     constexpr int NE = MAXE > 0 ? MAXE : 1;
     float rx[NE], ru[NE];
-    // (row, col) of element tid + 256 * j, advanced incrementally
-    const int r0 = tid / N2, c0 = tid - r0 * N2, dr = 256 / N2, dc = 256 - dr * N2;
+    // (row, col) of element tid + NTH * j, advanced incrementally
+    const int r0 = tid / N2, c0 = tid - r0 * N2, dr = NTH / N2, dc = NTH - dr * N2;
     auto fetch = [&](int plane) {
         const float *xp = x + (size_t)plane * plane_elems;
         const float *up = xact ? xact + (size_t)plane * plane_elems : nullptr;
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
-            const unsigned e = tid + 256u * j;
+            const unsigned e = tid + (unsigned)NTH * j;
             const bool in = e < plane_elems;
             rx[j] = in ? xp[e] : 0.f;
             ru[j] = (in && up) ? up[e] : 0.f;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void dht_fwd_plane_kernel(const float *__restr
             int r = r0, c = c0;
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
-                if (tid + 256u * j < plane_elems) xs[r * p.lda2 + c] = xact ? rx[j] * act_grad_from_out(ru[j], a.act) : rx[j];
+                if (tid + (unsigned)NTH * j < plane_elems) xs[r * p.lda2 + c] = xact ? rx[j] * act_grad_from_out(ru[j], a.act) : rx[j];
                 r += dr;
                 c += dc;
                 if (c >= N2) {
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void dht_fwd_plane_kernel(const float *__restr
         } else {
             const float *xp = x + (size_t)plane * plane_elems;
             const float *up = xact ? xact + (size_t)plane * plane_elems : nullptr;
-            for (int r = wave; r < N1; r += 4)
+            for (int r = wave; r < N1; r += (NTH / 64))
                 for (int c = lane; c < N2; c += 64) {
                     float v = xp[(size_t)r * N2 + c];
                     if (up) v *= act_grad_from_out(up[(size_t)r * N2 + c], a.act);
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void dht_fwd_plane_kernel(const float *__restr
         }
         __syncthreads();
         // ---- fold along W in place (division-free: a wave per row, lanes over columns)
-        for (int r = wave; r < N1; r += 4) {
+        for (int r = wave; r < N1; r += (NTH / 64)) {
             float *row = xs + r * p.lda2;
             for (int c = 1 + lane; c <= a2.Js; c += 64) {
                 const float va = row[c], vb = row[N2 - c];
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void dht_fwd_plane_kernel(const float *__restr
         __syncthreads();
         // ---- axis W: T[n1][k2]: cos part -> columns [0,KP2), sin part -> [KP2, 2KP2)
         const int ntaskW = (a.dbg & 1) ? 0 : MT1 * a2.KT;
-        for (int t = wave; t < ntaskW; t += 4) {
+        for (int t = wave; t < ntaskW; t += (NTH / 64)) {
             const int kt = t % a2.KT, mt = t / a2.KT;
             f32x4 accC = {0.f, 0.f, 0.f, 0.f}, accS = accC;
             const float *rows = xs + mt * 16 * p.lda2;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void dht_fwd_plane_kernel(const float *__restr
         }
         __syncthreads();
         // ---- fold T along n1 in place (a wave per row pair, lanes over the 2*KP2 columns)
-        for (int c = 1 + wave; c <= a1.Js; c += 4) {
+        for (int c = 1 + wave; c <= a1.Js; c += (NTH / 64)) {
             float *ra_ = T + c * p.ldt, *rb_ = T + (N1 - c) * p.ldt;
             for (int col = lane; col < 2 * a2.KP; col += 64) {
                 const float va = ra_[col], vb = rb_[col];
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void dht_fwd_plane_kernel(const float *__restr
         // ---- axis H: rows = T columns (Ac | As), reduce over n1, outputs k1 in 0..m1 (+/-)
         float *Yp = Y + (size_t)plane * (2 * p.CP);
         const int ntaskH = (a.dbg & 2) ? 0 : a2.KT * a1.KT * 2;
-        for (int t = wave; t < ntaskH; t += 4) {
+        for (int t = wave; t < ntaskH; t += (NTH / 64)) {
             const int part = t & 1, kt1 = (t >> 1) % a1.KT, kt2 = (t >> 1) / a1.KT;
             const float *Tc = T + kt2 * 16;             // Ac columns of this k2 tile
             const float *Ts = T + a2.KP + kt2 * 16;     // As columns
@@ -1639,8 +1639,8 @@ __global__ __launch_bounds__(64) void dht_inv_d_kernel(const float *__restrict__
 // done while the axis-H operands are read.  The axis-W result goes to an LDS image of the output
 // plane, and a final flat pass applies scale / residual / activation with fully coalesced
 // loads and stores.
-template <int MAXE>
-__global__ __launch_bounds__(256) void dht_inv_plane_kernel(const float *__restrict__ E, const float *__restrict__ addend,
+template <int MAXE, int NTH = 256>
+__global__ __launch_bounds__(NTH) void dht_inv_plane_kernel(const float *__restrict__ E, const float *__restrict__ addend,
                                                             float *__restrict__ out, DhtArgs a) {
     extern __shared__ float lds[];
     const DhtPlan &p = a.p;
@@ -1651,9 +1651,9 @@ __global__ __launch_bounds__(256) void dht_inv_plane_kernel(const float *__restr
     float *Es = lds + p.i_Es, *Ed = lds + p.i_Ed, *FR = lds + p.i_FR, *FI = lds + p.i_FI, *O = lds + p.i_O;
     const float *cosH = tabH, *sinH = tabH + a1.NT * a1.KmP * 16;
     const float *cosW = tabW, *sinW = tabW + a2.NT * a2.KmP * 16;
-    for (int i = tid; i < 2 * a1.NT * a1.KmP * 16; i += 256) tabH[i] = p.tables[a1.cosI + i];
-    for (int i = tid; i < 2 * a2.NT * a2.KmP * 16; i += 256) tabW[i] = p.tables[a2.cosI + i];
-    for (int i = tid; i < (p.MP1 - N1) * p.ldF; i += 256) {
+    for (int i = tid; i < 2 * a1.NT * a1.KmP * 16; i += NTH) tabH[i] = p.tables[a1.cosI + i];
+    for (int i = tid; i < 2 * a2.NT * a2.KmP * 16; i += NTH) tabW[i] = p.tables[a2.cosI + i];
+    for (int i = tid; i < (p.MP1 - N1) * p.ldF; i += NTH) {
         FR[N1 * p.ldF + i] = 0.f;
         FI[N1 * p.ldF + i] = 0.f;
     }
@@ -1667,13 +1667,13 @@ __global__ __launch_bounds__(256) void dht_inv_plane_kernel(const float *__restr
     constexpr int NI = 4;                     // entries per thread held in registers (nitem <= 1024)
     constexpr int NE = MAXE > 0 ? MAXE : 1;
     float ea[NI], eb[NI], ra[NE];
-    const int r0 = tid / N2, c0 = tid - r0 * N2, dr = 256 / N2, dc = 256 - dr * N2;
+    const int r0 = tid / N2, c0 = tid - r0 * N2, dr = NTH / N2, dc = NTH - dr * N2;
     // item i -> (k1 = i / rows, row = i % rows); rows is a multiple of 32
     auto fetch_e = [&](int plane) {
         const float *Ep = E + (size_t)plane * ne;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int i = tid + 256 * j;
+            const int i = tid + NTH * j;
             const int k1 = i / rows, row = i - k1 * rows;
             const int part = row / a2.KP, k2 = row - part * a2.KP;
             const bool ok = i < nitem && k1 <= m1;
@@ -1688,14 +1688,14 @@ __global__ __launch_bounds__(256) void dht_inv_plane_kernel(const float *__restr
         // ---- Es[row][k1] = E[+k1] + E[-k1], Ed = E[+k1] - E[-k1] (k1 = 0: E[0], 0) from the prefetched pairs
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int i = tid + 256 * j;
+            const int i = tid + NTH * j;
             if (i < nitem) {
                 const int k1 = i / rows, row = i - k1 * rows;
                 Es[row * p.ldE + k1] = ea[j] + eb[j];
                 Ed[row * p.ldE + k1] = (k1 >= 1 && k1 <= m1) ? ea[j] - eb[j] : 0.f;
             }
         }
-        for (int i = tid + 256 * NI; i < nitem; i += 256) {  // only for very large mode counts
+        for (int i = tid + NTH * NI; i < nitem; i += NTH) {  // only for very large mode counts
             const float *Ep = E + (size_t)plane * ne;
             const int k1 = i / rows, row = i - k1 * rows;
             const int part = row / a2.KP, k2 = row - part * a2.KP;
@@ -1715,14 +1715,14 @@ __global__ __launch_bounds__(256) void dht_inv_plane_kernel(const float *__restr
         if (MAXE > 0 && ad) {
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
-                const unsigned e = tid + 256u * j;
+                const unsigned e = tid + (unsigned)NTH * j;
                 ra[j] = e < plane_elems ? ad[e] : 0.f;
             }
         }
         __syncthreads();
         // ---- axis H: F[n1][k2] = sum_k1 E[k1][k2] e^{+i th k1 n1}
         const int ntaskH = (a.dbg & 1) ? 0 : a1.NT * a2.KT * 2;
-        for (int t = wave; t < ntaskH; t += 4) {
+        for (int t = wave; t < ntaskH; t += (NTH / 64)) {
             const int part = t & 1, kt2 = (t >> 1) % a2.KT, nt1 = (t >> 1) / a2.KT;
             const int rR = kt2 * 16, rI = a2.KP + kt2 * 16;
             const float *bc = cosH + nt1 * a1.KmP * 16, *bs = sinH + nt1 * a1.KmP * 16;
@@ -1748,7 +1748,7 @@ __global__ __launch_bounds__(256) void dht_inv_plane_kernel(const float *__restr
         __syncthreads();
         // ---- axis W: O[n1][n2] = sum_k2 FR cos - FI sin ; mirror n2 -> N2 - n2 gets +
         const int ntaskW = MT1 * a2.NT;
-        for (int t = wave; t < ntaskW; t += 4) {
+        for (int t = wave; t < ntaskW; t += (NTH / 64)) {
             const int nt2 = t % a2.NT, mt = t / a2.NT;
             f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = acc1;
             if (!(a.dbg & 2))
@@ -1775,7 +1775,7 @@ __global__ __launch_bounds__(256) void dht_inv_plane_kernel(const float *__restr
                 int r = r0, c = c0;
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
-                    const unsigned e = tid + 256u * j;
+                    const unsigned e = tid + (unsigned)NTH * j;
                     if (e < plane_elems) {
                         float v = a.scale * O[r * p.ldo + c];
                         if (ad) v += ra[j];
@@ -1789,7 +1789,7 @@ __global__ __launch_bounds__(256) void dht_inv_plane_kernel(const float *__restr
                     }
                 }
             } else {
-                for (int r = wave; r < N1; r += 4)
+                for (int r = wave; r < N1; r += (NTH / 64))
                     for (int c = lane; c < N2; c += 64) {
                         float v = a.scale * O[r * p.ldo + c];
                         if (ad) v += ad[(size_t)r * N2 + c];
@@ -2468,6 +2468,17 @@ static int check_sizes(int BC, int N0, int N1, int N2, int m0, int m1, int m2, i
 
 static const size_t kMaxLds = 160 * 1024;
 
+// Waves per plane of the generic plane kernels on planes above 5 120 elements (121 x 121 at the published inference size).  Those
+// kernels are bound by instruction issue and latency, not by LDS capacity (two planes per CU either way): measured single-image
+// inference at 240 x 240 x 155, GPU forward 4.26 ms with 4 waves per plane, 3.14 with 8, 2.82 with 16 (default).
+// HNO_GENERIC_WAVES=4 / 8 select the others (A/B).
+static int generic_waves() {
+    static const int v = getenv("HNO_GENERIC_WAVES") ? atoi(getenv("HNO_GENERIC_WAVES")) : 16;
+    return v;
+}
+static bool generic_waves8() { return generic_waves() == 8; }
+static bool generic_waves16() { return generic_waves() != 8 && generic_waves() != 4; }
+
 // HNO_INV_PLANE: "spec" = 1 (round-2 kernel: a workgroup per plane, axis-H result through LDS), default 0 = item kernel.  A/B aid.
 static int inv_plane_variant() {
     static const int v = [] {
@@ -2534,6 +2545,8 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel<32, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel<16, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         attr_done = true;
     }
     const int planes = BC * N0;
@@ -2620,9 +2633,12 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
         if (launched) {
         } else if (pe <= 256 * 20)
             hipLaunchKernelGGL(dht_fwd_plane_kernel<20>, dim3(grid), dim3(256), lds, s, x, x_act_out, (float *)workspace, a);
-        else if (pe <= 256 * 64)
-            hipLaunchKernelGGL(dht_fwd_plane_kernel<64>, dim3(grid), dim3(256), lds, s, x, x_act_out, (float *)workspace, a);
-        else
+        else if (pe <= 256 * 64) {
+            // large planes: sixteen waves per plane (generic_waves)
+            if (generic_waves16()) hipLaunchKernelGGL((dht_fwd_plane_kernel<16, 1024>), dim3(grid), dim3(1024), lds, s, x, x_act_out, (float *)workspace, a);
+            else if (generic_waves8()) hipLaunchKernelGGL((dht_fwd_plane_kernel<32, 512>), dim3(grid), dim3(512), lds, s, x, x_act_out, (float *)workspace, a);
+            else hipLaunchKernelGGL(dht_fwd_plane_kernel<64>, dim3(grid), dim3(256), lds, s, x, x_act_out, (float *)workspace, a);
+        } else
             hipLaunchKernelGGL(dht_fwd_plane_kernel<0>, dim3(grid), dim3(256), lds, s, x, x_act_out, (float *)workspace, a);
     }
     if (planes_only) {
@@ -2677,6 +2693,8 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel<32, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel<16, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         attr_done = true;
     }
     const Axis &a0 = plan->ax[0];
@@ -2765,8 +2783,11 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
         if (launched) {
         } else if (pe <= 256 * 20)
             hipLaunchKernelGGL(dht_inv_plane_kernel<20>, dim3(grid), dim3(256), lds, s, (const float *)workspace, addend, out, a);
-        else if (pe <= 256 * 64)
-            hipLaunchKernelGGL(dht_inv_plane_kernel<64>, dim3(grid), dim3(256), lds, s, (const float *)workspace, addend, out, a);
+        else if (pe <= 256 * 64) {
+            if (generic_waves16()) hipLaunchKernelGGL((dht_inv_plane_kernel<16, 1024>), dim3(grid), dim3(1024), lds, s, (const float *)workspace, addend, out, a);
+            else if (generic_waves8()) hipLaunchKernelGGL((dht_inv_plane_kernel<32, 512>), dim3(grid), dim3(512), lds, s, (const float *)workspace, addend, out, a);
+            else hipLaunchKernelGGL(dht_inv_plane_kernel<64>, dim3(grid), dim3(256), lds, s, (const float *)workspace, addend, out, a);
+        }
         else
             hipLaunchKernelGGL(dht_inv_plane_kernel<0>, dim3(grid), dim3(256), lds, s, (const float *)workspace, addend, out, a);
     }

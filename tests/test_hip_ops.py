@@ -234,6 +234,26 @@ def test_channel_padded_activations_match_contiguous(pkg, n, monkeypatch):
         assert rel_err(g1.cpu().numpy(), g0.cpu().numpy()) < 2e-5
 
 
+def test_generic_plane_kernels_on_large_planes_vs_float64(pkg, monkeypatch):
+    """121 x 121 planes (the working grid of the reference's published 240 x 240 x 155 inference size) run the generic plane kernels
+    with sixteen waves per plane (round 3; 61 x 61 x 40 and the other small odd grids of the goldens keep four): TransformCrop and
+    PadInverse with residual + activation against the float64 dense formulation, and against the four-wave form."""
+    from multimodal_3d_image_segmentation_amd import ops
+    torch.manual_seed(12)
+    sp, modes = (12, 121, 121), (5, 14, 14)
+    x = torch.randn(2, 3, *sp, device='cuda')
+    z = torch.randn(2, 3, 10, 28, 28, device='cuda')
+    add = torch.randn(2, 3, *sp, device='cuda')
+    y = ops.dht3_crop_raw(x, modes, 1.0 / np.prod(sp))
+    u = ops.pad_idht3_raw(z, sp, 0.5, add, ops.ACT_SELU)
+    for bc in ((0, 0), (1, 2)):
+        assert rel_err(y[bc].cpu().numpy(), O().dht_crop_dense(x[bc].cpu().double()[None, None], modes)[0, 0].numpy()) < 5e-6
+        want = F.selu(0.5 * O().pad_idht_dense(z[bc].cpu().double()[None, None], sp)[0, 0] + add[bc].cpu().double())
+        assert rel_err(u[bc].cpu().numpy(), want.numpy()) < 5e-6
+    # round trip at this size: crop(pad_inverse(z)) == z
+    assert rel_err(ops.dht3_crop_raw(ops.pad_idht3_raw(z, sp, 1.0), modes, 1.0 / np.prod(sp)).cpu().numpy(), z.cpu().numpy()) < 1e-5
+
+
 def test_dht_roundtrip_property_full_size(pkg):
     """Size-independent property at the benchmark size: crop(pad_inverse(z)) * 1 == z (the kept
     modes of an inverse transform of a band-limited spectrum are the spectrum itself) and linearity."""
