@@ -2476,6 +2476,13 @@ static int generic_waves() {
     static const int v = getenv("HNO_GENERIC_WAVES") ? atoi(getenv("HNO_GENERIC_WAVES")) : 16;
     return v;
 }
+// planes of up to 5 120 elements outside the 65 / 61 / 33 specialisations: eight waves per plane above 2 800 elements (measured on the
+// HNOSeg-XS step: 57 x 57 planes (112^3 inputs) 3.10 -> 2.90 ms with 8 waves, 3.35 with 16; 49 x 49 (96^3) 2.55 / 2.54 / 2.95);
+// HNO_GENERIC_WAVES_MID = 4 / 8 / 16 forces one form (A/B)
+static int generic_waves_mid(int pe = 0) {
+    static const int v = getenv("HNO_GENERIC_WAVES_MID") ? atoi(getenv("HNO_GENERIC_WAVES_MID")) : 0;
+    return v ? v : (pe > 2800 ? 8 : 4);
+}
 static bool generic_waves8() { return generic_waves() == 8; }
 static bool generic_waves16() { return generic_waves() != 8 && generic_waves() != 4; }
 
@@ -2547,6 +2554,8 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel<32, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel<16, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel<10, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel<5, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         attr_done = true;
     }
     const int planes = BC * N0;
@@ -2631,8 +2640,11 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
         HNO_SPEC(8, 8, 8, 8)   // 61 x 61 planes (120 x 120 inputs)
 #undef HNO_SPEC
         if (launched) {
-        } else if (pe <= 256 * 20)
-            hipLaunchKernelGGL(dht_fwd_plane_kernel<20>, dim3(grid), dim3(256), lds, s, x, x_act_out, (float *)workspace, a);
+        } else if (pe <= 256 * 20) {
+            if (generic_waves_mid(pe) == 8) hipLaunchKernelGGL((dht_fwd_plane_kernel<10, 512>), dim3(grid), dim3(512), lds, s, x, x_act_out, (float *)workspace, a);
+            else if (generic_waves_mid(pe) == 16) hipLaunchKernelGGL((dht_fwd_plane_kernel<5, 1024>), dim3(grid), dim3(1024), lds, s, x, x_act_out, (float *)workspace, a);
+            else hipLaunchKernelGGL(dht_fwd_plane_kernel<20>, dim3(grid), dim3(256), lds, s, x, x_act_out, (float *)workspace, a);
+        }
         else if (pe <= 256 * 64) {
             // large planes: sixteen waves per plane (generic_waves)
             if (generic_waves16()) hipLaunchKernelGGL((dht_fwd_plane_kernel<16, 1024>), dim3(grid), dim3(1024), lds, s, x, x_act_out, (float *)workspace, a);
@@ -2695,6 +2707,8 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel<32, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel<16, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel<10, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel<5, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         attr_done = true;
     }
     const Axis &a0 = plan->ax[0];
@@ -2781,8 +2795,11 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
         HNO_SPEC(4, 4, 1, 1, 4)    // 33 x 33 planes: positions 1..16
 #undef HNO_SPEC
         if (launched) {
-        } else if (pe <= 256 * 20)
-            hipLaunchKernelGGL(dht_inv_plane_kernel<20>, dim3(grid), dim3(256), lds, s, (const float *)workspace, addend, out, a);
+        } else if (pe <= 256 * 20) {
+            if (generic_waves_mid(pe) == 8) hipLaunchKernelGGL((dht_inv_plane_kernel<10, 512>), dim3(grid), dim3(512), lds, s, (const float *)workspace, addend, out, a);
+            else if (generic_waves_mid(pe) == 16) hipLaunchKernelGGL((dht_inv_plane_kernel<5, 1024>), dim3(grid), dim3(1024), lds, s, (const float *)workspace, addend, out, a);
+            else hipLaunchKernelGGL(dht_inv_plane_kernel<20>, dim3(grid), dim3(256), lds, s, (const float *)workspace, addend, out, a);
+        }
         else if (pe <= 256 * 64) {
             if (generic_waves16()) hipLaunchKernelGGL((dht_inv_plane_kernel<16, 1024>), dim3(grid), dim3(1024), lds, s, (const float *)workspace, addend, out, a);
             else if (generic_waves8()) hipLaunchKernelGGL((dht_inv_plane_kernel<32, 512>), dim3(grid), dim3(512), lds, s, (const float *)workspace, addend, out, a);
