@@ -150,7 +150,7 @@ int hno_spec_mid_fourier_bwd(void *workspace, const float *W2, const float *s0, 
 int hno_idht3_planes(const void *workspace, const float *addend, int act, float *out, int BC, int N0, int N1, int N2, int m0, int m1,
                      int m2, float scale, long long ldbc, void *stream);
 /* hno_dht3_crop / hno_pad_idht3 on channel-padded activations: ldbc = stride (floats) between consecutive (b, c) volumes of x /
- * x_act_out, resp. out / addend (0 or N0 N1 N2 = contiguous; a padded stride needs the 65^3 / 33^3 kernels, else HNO_ELIMIT).
+ * x_act_out, resp. out / addend (0 or N0 N1 N2 = contiguous; N0 N1 N2 <= ldbc < N0 N1 N2 + 64).
  * The inverse zeroes the padding of `out`.  hno_dht3_ld_supported: 1 when both directions take a padded stride for this geometry. */
 int hno_dht3_ld_supported(int N0, int N1, int N2, int m0, int m1, int m2);
 int hno_dht3_crop_ld(const float *x, const float *x_act_out, int act_grad, float *out, void *workspace, int BC, int N0, int N1, int N2,

@@ -274,7 +274,25 @@ struct DhtArgs {
     // 2m + 1 + k).  Used for un-truncated transforms of odd sizes (hno_dht3_full) and for a degenerate
     // first axis (N0 = 1, m0 = 0: the 2-D transforms).  full1 / full2 are Hartley-layout only.
     int full0, full1, full2;
+    // channel-padded activations (ops.chan_stride): floats between consecutive (b, c) volumes of the spatial tensors (input of the
+    // forward, output / residual of the inverse); 0 = contiguous (N0 N1 N2)
+    unsigned ldbc;
 };
+
+// float offset of plane (bc, n0) = `plane` of a spatial tensor
+__device__ __forceinline__ size_t plane_base(const DhtArgs &a, int plane, size_t plane_elems) {
+    if (a.ldbc == 0) return (size_t)plane * plane_elems;
+    const int N0 = a.p.ax[0].N, bc = plane / N0;
+    return (size_t)bc * a.ldbc + (size_t)(plane - bc * N0) * plane_elems;
+}
+// inverse kernels: the workgroup that writes the last plane of a (b, c) volume zeroes the volume's padding
+__device__ __forceinline__ void zero_volume_padding(const DhtArgs &a, float *out, int plane, size_t plane_elems, int tid) {
+    if (a.ldbc == 0) return;
+    const int N0 = a.p.ax[0].N, bc = plane / N0;
+    if (plane - bc * N0 != N0 - 1) return;
+    const unsigned vol = (unsigned)((size_t)N0 * plane_elems), npad = a.ldbc - vol;
+    if ((unsigned)tid < npad) out[(size_t)bc * a.ldbc + vol + tid] = 0.f;
+}
 
 constexpr int round_up_c(int a, int b) { return (a + b - 1) / b * b; }
 
@@ -318,8 +336,8 @@ __global__ __launch_bounds__(NTH) void dht_fwd_plane_kernel(const float *__restr
     // (row, col) of element tid + NTH * j, advanced incrementally
     const int r0 = tid / N2, c0 = tid - r0 * N2, dr = NTH / N2, dc = NTH - dr * N2;
     auto fetch = [&](int plane) {
-        const float *xp = x + (size_t)plane * plane_elems;
-        const float *up = xact ? xact + (size_t)plane * plane_elems : nullptr;
+        const float *xp = x + plane_base(a, plane, plane_elems);
+        const float *up = xact ? xact + plane_base(a, plane, plane_elems) : nullptr;
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const unsigned e = tid + (unsigned)NTH * j;
@@ -347,8 +365,8 @@ __global__ __launch_bounds__(NTH) void dht_fwd_plane_kernel(const float *__restr
             const int next = plane + gridDim.x;
             if (next < planes) fetch(next);  // in flight during this plane's compute
         } else {
-            const float *xp = x + (size_t)plane * plane_elems;
-            const float *up = xact ? xact + (size_t)plane * plane_elems : nullptr;
+            const float *xp = x + plane_base(a, plane, plane_elems);
+            const float *up = xact ? xact + plane_base(a, plane, plane_elems) : nullptr;
             for (int r = wave; r < N1; r += (NTH / 64))
                 for (int c = lane; c < N2; c += 64) {
                     float v = xp[(size_t)r * N2 + c];
@@ -488,8 +506,8 @@ __global__ __launch_bounds__(256, 3) void dht_fwd_plane_spec_kernel(const float 
     float rx[NE], ru[HAS_ACT ? NE : 1];
     const int r0 = tid / N2, c0 = tid - r0 * N2, dr = 256 / N2, dc = 256 - dr * N2;
     auto fetch = [&](int plane) {
-        const float *xp = x + (size_t)plane * plane_elems;
-        const float *up = xact ? xact + (size_t)plane * plane_elems : nullptr;
+        const float *xp = x + plane_base(a, plane, plane_elems);
+        const float *up = xact ? xact + plane_base(a, plane, plane_elems) : nullptr;
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const unsigned e = tid + 256u * j;
@@ -754,7 +772,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void dht_fwd_plane_wave_kernel(const f
     f4v rv[NV];
     float rt[NT];
     auto fetch = [&](int plane) {
-        const float *xp = x + (size_t)plane * pe;
+        const float *xp = x + plane_base(a, plane, (size_t)pe);
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const f4u_t v = *reinterpret_cast<const f4u_t *>(xp + 4 * lane + 256 * j);
@@ -1711,7 +1729,7 @@ __global__ __launch_bounds__(NTH) void dht_inv_plane_kernel(const float *__restr
         }
         if (plane + gridDim.x < planes) fetch_e(plane + gridDim.x);
         // residual of THIS plane: issued now, consumed in the epilogue after both MFMA stages
-        const float *ad = addend ? addend + (size_t)plane * plane_elems : nullptr;
+        const float *ad = addend ? addend + plane_base(a, plane, plane_elems) : nullptr;
         if (MAXE > 0 && ad) {
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
@@ -1769,7 +1787,8 @@ __global__ __launch_bounds__(NTH) void dht_inv_plane_kernel(const float *__restr
         }
         __syncthreads();
         // ---- epilogue: out = act(scale * O + residual), flat and fully coalesced
-        float *op = out + (size_t)plane * plane_elems;
+        float *op = out + plane_base(a, plane, plane_elems);
+            zero_volume_padding(a, out, plane, plane_elems, tid);
         if (!(a.dbg & 4)) {
             if (MAXE > 0) {
                 int r = r0, c = c0;
@@ -1890,7 +1909,7 @@ __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float 
         }
         if (plane + gridDim.x < planes) fetch_e(plane + gridDim.x);
         if (HAS_ADD) {  // residual of THIS plane: consumed in the epilogue, after both MFMA stages
-            const float *ad = addend + (size_t)plane * plane_elems;
+            const float *ad = addend + plane_base(a, plane, plane_elems);
 #pragma unroll
             // elements [0, 1024 NV4) as 16-byte vectors (4 tid + 1024 jv + 0..3), the rest as scalars (tid + 256 j)
             for (int jv = 0; jv < NV4; ++jv) {
@@ -2079,7 +2098,8 @@ __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float 
             const float ap = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f;
             const float aq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
             const bool lin = a.act == HNO_ACT_NONE;
-            float *op = out + (size_t)plane * plane_elems;
+            float *op = out + plane_base(a, plane, plane_elems);
+            zero_volume_padding(a, out, plane, plane_elems, tid);
             float ov[NE];   // all LDS reads first (one wait), then the arithmetic and the stores
             typedef float f4v __attribute__((ext_vector_type(4)));
 #pragma unroll
@@ -2537,6 +2557,7 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
     a.BC = BC;
     a.scale = scale;
     a.act = x_act_out ? act_grad : HNO_ACT_NONE;
+    a.ldbc = ldbc != vol ? (unsigned)ldbc : 0u;
     a.dbg = debug_flags();
     a.stamps = (a.dbg & 64) ? debug_stamp_buffer() : nullptr;
     a.mode = mode;
@@ -2618,7 +2639,6 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
         HNO_DMA(9, 8, 2)           // 65 x 65 planes
         HNO_DMA(5, 4, 1)           // 33 x 33 planes
 #undef HNO_DMA
-        if (!launched && ldbc != vol) return fail(HNO_ELIMIT, "hno_dht3_crop: a padded volume stride needs the 65 x 65 / 33 x 33 plane kernels");
         HNO_WAVE(9, 8, 9, 8, 16)   // 65 x 65 planes
         HNO_WAVE(5, 4, 5, 4, 4)    // 33 x 33 planes
 #undef HNO_WAVE
@@ -2689,6 +2709,7 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
     a.BC = BC;
     a.scale = scale;
     a.act = act;
+    a.ldbc = ldbc != vol ? (unsigned)ldbc : 0u;
     a.dbg = debug_flags();
     a.stamps = (a.dbg & 64) ? debug_stamp_buffer() : nullptr;
     a.mode = mode;
@@ -2775,7 +2796,6 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
         HNO_ITEM(2, 65, 4, 2)      // 65 x 65 planes, modes (., 14, 14)
         HNO_ITEM(1, 33, 4, 1)      // 33 x 33 planes
 #undef HNO_ITEM
-        if (!launched && ldbc != vol) return fail(HNO_ELIMIT, "hno_pad_idht3: a padded volume stride needs the 65 x 65 / 33 x 33 plane kernels");
 #define HNO_SPEC(KM1, KM2, NT1, NT2, NFULL)                                                                               \
     if (!launched && spec_ok && b1.KmP == 4 * KM1 && b2.KmP == 4 * KM2 && (b1.J + 15) / 16 == NT1 &&                      \
         (b2.J + 15) / 16 == NT2 && pe / 256 == NFULL) {                                                                   \
@@ -2828,25 +2848,17 @@ extern "C" int hno_idht3_planes(const void *workspace, const float *addend, int 
     return dht_inverse_launch(nullptr, addend, act, out, (void *)workspace, BC, N0, N1, N2, m0, m1, m2, scale, stream, 0, 1, 0, true, ldbc);
 }
 
-// 1 when both plane kernels that understand a padded volume stride (dht_fwd_plane_dma_kernel, dht_inv_item_kernel) serve this
-// geometry: the host side only hands out channel-padded activations when this says so.
+// 1 when the transforms take a padded volume stride for this geometry: every plane kernel does (the 65 x 65 / 33 x 33 kernels through
+// their stride argument, the generic / specialised workgroup-per-plane kernels through DhtArgs.ldbc); 0 only for sizes the transform
+// itself refuses.  The host side asks before it hands out channel-padded activations.
 extern "C" int hno_dht3_ld_supported(int N0, int N1, int N2, int m0, int m1, int m2) {
-    if (N0 < 1 || N1 < 16 || N2 < 16 || m0 < 0 || m1 < 1 || m2 < 1) return 0;
+    if (N0 < 1 || N1 < 1 || N2 < 1 || m0 < 0 || m1 < 1 || m2 < 1) return 0;
     const DhtPlan *plan;
     if (get_plan(N0, N1, N2, m0, m1, m2, &plan)) {
         set_error("");
         return 0;
     }
-    const Axis &b1 = plan->ax[1], &b2 = plan->ax[2];
-    const int pe = N1 * N2, dbg = debug_flags();
-    if (dbg & (16 | 512)) return 0;
-    if (fwd_plane_variant() == 1 || inv_plane_variant() == 1) return 0;
-    if (!(pe <= 256 * 20 && b1.KT == 1 && b2.KT == 1 && 2 * plan->CP <= 1024)) return 0;
-    const int NP = plan->NP1;
-    if (!((NP == 2 && N1 == 65 && N2 == 65) || (NP == 1 && N1 == 33 && N2 == 33))) return 0;
-    const bool fwd = (N2 & 1) && b2.KcP == (NP == 2 ? 36 : 20) && b2.KsP == (NP == 2 ? 32 : 16) && b2.Js == b2.KsP;
-    const bool inv = b1.KmP == 16 && b2.KmP <= 16 && (b2.J + 15) / 16 == (NP == 2 ? 2 : 1);
-    return fwd && inv ? 1 : 0;
+    return sizeof(float) * plan->f_lds_floats <= kMaxLds && sizeof(float) * plan->i_lds_floats <= kMaxLds ? 1 : 0;
 }
 
 extern "C" int hno_dht3_crop_ld(const float *x, const float *x_act_out, int act_grad, float *out, void *workspace, int BC, int N0, int N1,

@@ -1412,19 +1412,33 @@ def test_limits_fail_loudly(pkg):
     with pytest.raises(Err):                           # the fused branch backward is built for 24 + 24 -> 24 only
         t = torch.randn(1, 8, 4, 4, 4, device='cuda')
         ops.pwconv_bwd_branch_raw(t, t, t, t, torch.randn(8, 16, device='cuda'), torch.randn(8, 8, device='cuda'), ops.ACT_SELU, ops.ACT_SELU)
-    # round 3: a padded channel stride is only understood by the 65 x 65 / 33 x 33 plane kernels; other grids refuse it, and the host
-    # side never hands them one (padded_ok); the fused spectral middle refuses configurations it was not built for
+    # round 3: every plane kernel takes a padded channel stride (the 65 x 65 / 33 x 33 kernels as an argument, the others through
+    # DhtArgs.ldbc): same numbers as on the contiguous tensor, padding of the inverse's output zeroed; a stride that is not the padded one
+    # is refused; the fused spectral middle refuses configurations it was not built for
     L = pkg._lib.lib()
-    assert L.hno_dht3_ld_supported(65, 65, 65, 10, 14, 14) == 1 and L.hno_dht3_ld_supported(33, 33, 33, 10, 14, 14) == 1
-    assert L.hno_dht3_ld_supported(61, 61, 61, 10, 14, 14) == 0 and L.hno_dht3_ld_supported(24, 24, 24, 4, 4, 4) == 0
-    assert not ops.padded_ok((61, 61, 61), (10, 14, 14)) and not ops.padded_ok((64, 64, 64), (10, 14, 14))
-    V, ld = 21 ** 3, ops._pad_ld(21 ** 3)
-    xp = ops.to_layout(torch.randn(1, 2, 21, 21, 21, device='cuda'), ld)
-    assert ops.chan_stride(xp) == ld
-    with pytest.raises(Err):
-        ops.dht3_crop_raw(xp, (4, 4, 4), 1.0)
-    with pytest.raises(Err):
-        ops.pad_idht3_raw(torch.randn(1, 2, 8, 8, 8, device='cuda'), (21, 21, 21), 1.0, None, ops.ACT_NONE, ld=ld)
+    for sp in ((65, 65, 65), (33, 33, 33), (61, 61, 61), (24, 24, 24), (21, 19, 23)):
+        assert L.hno_dht3_ld_supported(*sp, 4, 4, 4) == 1
+    assert ops.padded_ok((61, 61, 61), (10, 14, 14)) and not ops.padded_ok((64, 64, 64), (10, 14, 14))      # 64^3 rows are aligned as they are
+    for sp, m in (((21, 21, 21), (4, 4, 4)), ((12, 61, 61), (5, 14, 14)), ((9, 40, 37), (3, 7, 9))):
+        V, ld = int(np.prod(sp)), ops._pad_ld(np.prod(sp))
+        xc = torch.randn(2, 3, *sp, device='cuda')
+        xp = ops.to_layout(xc, ld)
+        assert ops.chan_stride(xp) == ld
+        assert bool((ops.dht3_crop_raw(xp, m, 1.0) == ops.dht3_crop_raw(xc, m, 1.0)).all())
+        zc = torch.randn(2, 3, 2 * m[0], 2 * m[1], 2 * m[2], device='cuda')
+        ad = torch.randn_like(xc)
+        want = ops.pad_idht3_raw(zc, sp, 0.5, ad, ops.ACT_SELU)
+        got = ops.pad_idht3_raw(zc, sp, 0.5, ops.to_layout(ad, ld), ops.ACT_SELU, ld=ld)
+        assert ops.chan_stride(got) == ld and bool((got == want).all())
+        assert bool((torch.empty(0, device='cuda').set_(got.untyped_storage(), 0, (6, ld))[:, V:] == 0).all())
+        # the activation-gradient input of the forward transform (backward of PadInverse with activation) on padded operands
+        u = torch.randn_like(xc)
+        assert bool((ops.dht3_crop_raw(xp, m, 1.0, ops.to_layout(u, ld), ops.ACT_SELU) == ops.dht3_crop_raw(xc, m, 1.0, u, ops.ACT_SELU)).all())
+    with pytest.raises(Err):          # a stride that is not the padded one
+        ws = torch.empty(L.hno_dht3_workspace_bytes(6, 21, 21, 21, 4, 4, 4) // 4, device='cuda')
+        out = torch.empty(2, 3, 8, 8, 8, device='cuda')
+        pkg._lib.check(L.hno_dht3_crop_ld(pkg._lib.ptr(torch.randn(6 * 21 ** 3 + 4096, device='cuda')), None, 0, pkg._lib.ptr(out), pkg._lib.ptr(ws),
+                                          6, 21, 21, 21, 4, 4, 4, 1.0, 21 ** 3 + 500, pkg._lib.stream_ptr()), 'x')
     assert L.hno_spec_mid_supported(24, 65, 10, 14, 14, 3) == 1 and L.hno_spec_mid_supported(16, 65, 10, 14, 14, 3) == 0
     assert L.hno_spec_mid_supported(24, 61, 10, 14, 14, 3) == 0 and L.hno_spec_mid_supported(24, 65, 10, 14, 14, 5) == 0
     assert not ops.spectral_chain_supported(torch.empty(1, 16, 65, 65, 65, device='cuda'), (10, 14, 14), 3)
