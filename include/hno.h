@@ -126,7 +126,7 @@ int hno_specmix_shared_bwd(const float *g, const float *z0, const float *zs, con
  * computes what hno_dht3_crop -> hno_specmix_layers_fwd -> hno_pad_idht3 compute.  The workspace (hno_dht3_workspace_bytes) is
  * transformed in place.  zs: (L + 1, B, C, 2 m0, 2 m1, 2 m2) = cropped spectrum z0 followed by the L layer outputs (what
  * the backward needs).  hno_spec_mid_supported says whether the fused kernels exist for a configuration (24 channels, N0 in
- * {65, 33}, m0 = 10, m1, m2 <= 15); callers use the three-kernel path otherwise.  ldbc: stride (floats) between consecutive (b, c)
+ * {33, 41, 49, 57, 65, 73, 81, 97} -- the working grids of 64^3 ... 192^3 inputs --, m0 = 10, m1, m2 <= 15); callers use the three-kernel path otherwise.  ldbc: stride (floats) between consecutive (b, c)
  * volumes of x / out / addend (0 = N0 N1 N2, contiguous). */
 int hno_spec_mid_supported(int C, int N0, int m0, int m1, int m2, int L);
 int hno_dht3_planes(const float *x, void *workspace, int BC, int N0, int N1, int N2, int m0, int m1, int m2, long long ldbc,

@@ -58,11 +58,11 @@ __global__ __launch_bounds__(512, BWD ? 1 : 2) void spec_mid_kernel(MidArgs a) {
     constexpr int C = 24, NK = 12, J = N0 / 2, K0 = M0 + 1;
     constexpr int KC = (J + 1 + 3) / 4;               // k-steps of the forward D step (n = 0 .. 4 KC - 1)
     constexpr int KI = (K0 + 3) / 4;                   // k-steps of the inverse D step (k0 = 0 .. 4 KI - 1)
-    constexpr int NMT = J / 16;                        // 16-row output tiles of the inverse D step (n = 1 .. 16 NMT)
+    constexpr int NMT = (J + 15) / 16;                 // 16-row output tiles of the inverse D step (n = 1 .. 16 NMT; rows n > J masked)
     constexpr int NMODE = 2 * 2 * M0 * 4;              // modes of the tile: (sign of (k1, k2), o0, column)
     constexpr int NT = (NMODE + 31) / 32;             // 32-mode MFMA tiles
     constexpr int NCT = C / 2;                         // column tiles of the D steps: 2 channels x 2 parts x 4 columns
-    static_assert(J % 16 == 0 && K0 <= 16, "tile shapes");
+    static_assert((N0 & 1) && K0 <= 16 && 2 * M0 <= N0, "odd plane count, one k0 tile");
     constexpr int NPQ = C * 2 * 2 * K0 * 4, NZL = C * NT * 32;
     constexpr int GLD = 34;                            // row stride of the G / Z tiles: == 2 (mod 4), conflict-free 16x16x4 operand reads
     constexpr int TILE = 2 * 32 * GLD;                 // backward: [o][mode] and [i][mode] tiles of one wave
@@ -414,8 +414,10 @@ __global__ __launch_bounds__(512, BWD ? 1 : 2) void spec_mid_kernel(MidArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const int n = 1 + 16 * mt + 4 * q + r;
                 const float en = part ? U[r] + V[r] : U[r] - V[r], em = part ? U[r] - V[r] : U[r] + V[r];
-                dst[(size_t)n * pstride] = en;
-                dst[(size_t)(N0 - n) * pstride] = em;
+                if (n <= J) {      // (the last tile of an N0 with (N0 - 1) / 2 not a multiple of 16 is partly empty)
+                    dst[(size_t)n * pstride] = en;
+                    dst[(size_t)(N0 - n) * pstride] = em;
+                }
             }
         }
     }
@@ -444,14 +446,14 @@ struct MidFArgs {
 template <int N0, int M0, bool BWD>
 __global__ __launch_bounds__(512, 1) void spec_mid_fourier_kernel(MidFArgs a) {
     constexpr int C = 24, C2 = 48, NK = 24, J = N0 / 2, K0 = M0 + 1;
-    constexpr int KC = (J + 1 + 3) / 4, KI = (K0 + 3) / 4, NMT = J / 16;
+    constexpr int KC = (J + 1 + 3) / 4, KI = (K0 + 3) / 4, NMT = (J + 15) / 16;
     constexpr int S0 = 2 * M0;
     constexpr int NMODE = S0 * 4;                      // (o0, column)
     constexpr int NT = (NMODE + 31) / 32;
     constexpr int NCT = C / 2;
     constexpr int NPQ = C * 2 * 2 * K0 * 4, NZL = C2 * NT * 32;
     constexpr int GLD = 34, TILE = 2 * C2 * GLD;
-    static_assert(J % 16 == 0 && K0 <= 16, "tile shapes");
+    static_assert((N0 & 1) && K0 <= 16 && 2 * M0 <= N0, "odd plane count, one k0 tile");
     extern __shared__ float lds[];
     float *PQ = lds, *ZL = lds + NPQ, *GZ = ZL + NZL, *MINE = GZ + NT * TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -686,8 +688,10 @@ __global__ __launch_bounds__(512, 1) void spec_mid_fourier_kernel(MidFArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const int n = 1 + 16 * mt + 4 * q + r;
                 const float en = part ? U[r] + V[r] : U[r] - V[r], em = part ? U[r] - V[r] : U[r] + V[r];
-                dst[(size_t)n * pstride] = en;
-                dst[(size_t)(N0 - n) * pstride] = em;
+                if (n <= J) {      // (the last tile of an N0 with (N0 - 1) / 2 not a multiple of 16 is partly empty)
+                    dst[(size_t)n * pstride] = en;
+                    dst[(size_t)(N0 - n) * pstride] = em;
+                }
             }
         }
     }
@@ -710,7 +714,7 @@ static int mid_twiddles(int N0, int M0, const float **out) {
     // A operands of v_mfma_f32_16x16x4_f32 in lane order (lane = 16 q + i holds A[row i][k = q] of its k-step):
     //   forward D step, k-step ks: row i = k0, k = n = 4 ks + q:  cos | sin (2 pi k0 n / N0), zero for k0 > M0 or n > J
     //   inverse D step, tile mt, k-step ks: row i <-> n = 1 + 16 mt + i, k = k0 = 4 ks + q, zero for n > J or k0 > M0
-    const int J = N0 / 2, K0 = M0 + 1, KC = (J + 1 + 3) / 4, KI = (K0 + 3) / 4, NMT = J / 16;
+    const int J = N0 / 2, K0 = M0 + 1, KC = (J + 1 + 3) / 4, KI = (K0 + 3) / 4, NMT = (J + 15) / 16;
     std::vector<float> h((size_t)(2 * KC + NMT * 2 * KI) * 64, 0.f);
     const double th = 2.0 * M_PI / N0;
     for (int ks = 0; ks < KC; ++ks)
@@ -751,10 +755,19 @@ static size_t mid_lds_floats(int M0, int L, bool bwd) {
 
 using namespace hno;
 
+// plane counts N0 the fused middle kernels are instantiated for: the working grids of 64^3 ... 192^3 inputs (N0 = size / 2 + 1)
+#define HNO_MID_N0_LIST(X) X(33) X(41) X(49) X(57) X(65) X(73) X(81) X(97)
+static bool mid_n0_built(int N0) {
+#define X(n) if (N0 == n) return true;
+    HNO_MID_N0_LIST(X)
+#undef X
+    return false;
+}
+
 // 1 if the fused kernels exist for this configuration (Hartley layout, 24 channels, odd N0 in {65, 33} with m0 = 10, one k tile per
 // plane axis); the caller falls back to hno_dht3_crop / hno_specmix_layers_* / hno_pad_idht3 otherwise.
 extern "C" int hno_spec_mid_supported(int C, int N0, int m0, int m1, int m2, int L) {
-    return C == 24 && (N0 == 65 || N0 == 33) && m0 == 10 && 2 * m0 <= N0 && m1 >= 1 && m1 <= 15 && m2 >= 1 && m2 <= 15 && L >= 1 && L <= 4;
+    return C == 24 && mid_n0_built(N0) && m0 == 10 && 2 * m0 <= N0 && m1 >= 1 && m1 <= 15 && m2 >= 1 && m2 <= 15 && L >= 1 && L <= 4;
 }
 
 // workspace: the forward plane transform of x (hno_dht3_planes) on entry, the operand of the inverse plane transform
@@ -787,8 +800,9 @@ extern "C" int hno_spec_mid_fwd(void *workspace, const float *const *W_layers, f
     const size_t lds = sizeof(float) * mid_lds_floats(m0, 0, false);
     {
         ProfScope _ps(KID_SPECMIX_FWD, s, 4.0 * B * C * (2.0 * N0 * 2 * (2 * m1 + 1) * 16 + (L + 1) * 8.0 * m0 * m1 * m2));
-        if (N0 == 65) hipLaunchKernelGGL((spec_mid_kernel<65, 10, false>), grid, dim3(512), lds, s, a);
-        else hipLaunchKernelGGL((spec_mid_kernel<33, 10, false>), grid, dim3(512), lds, s, a);
+#define X(n) if (N0 == n) hipLaunchKernelGGL((spec_mid_kernel<n, 10, false>), grid, dim3(512), lds, s, a);
+        HNO_MID_N0_LIST(X)
+#undef X
     }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
@@ -828,14 +842,16 @@ extern "C" int hno_spec_mid_bwd(void *workspace, const float *const *W_layers, c
     const size_t lds = sizeof(float) * mid_lds_floats(m0, L, true);
     static bool attr_done = false;
     if (!attr_done) {
-        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)spec_mid_kernel<65, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)spec_mid_kernel<33, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define X(n) HNO_CHECK_HIP(hipFuncSetAttribute((const void *)spec_mid_kernel<n, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HNO_MID_N0_LIST(X)
+#undef X
         attr_done = true;
     }
     {
         ProfScope _ps(KID_SPECMIX_BWD, s, 4.0 * B * C * (2.0 * N0 * 2 * (2 * m1 + 1) * 16 + (L + 1) * 8.0 * m0 * m1 * m2));
-        if (N0 == 65) hipLaunchKernelGGL((spec_mid_kernel<65, 10, true>), dim3(nwg), dim3(512), lds, s, a);
-        else hipLaunchKernelGGL((spec_mid_kernel<33, 10, true>), dim3(nwg), dim3(512), lds, s, a);
+#define X(n) if (N0 == n) hipLaunchKernelGGL((spec_mid_kernel<n, 10, true>), dim3(nwg), dim3(512), lds, s, a);
+        HNO_MID_N0_LIST(X)
+#undef X
     }
     HNO_CHECK_LAUNCH();
     // bit 8 of residual: record the slab reduction for hno_flush_reduces (per-call form of hno_set_defer_reduce)
@@ -847,7 +863,7 @@ extern "C" int hno_spec_mid_bwd(void *workspace, const float *const *W_layers, c
 
 // ---- Fourier block (spec_mid_fourier_kernel) ---------------------------------------------------------------------------------------
 extern "C" int hno_spec_mid_fourier_supported(int C, int N0, int m0, int m1, int m2) {
-    return C == 24 && (N0 == 65 || N0 == 33) && m0 == 10 && 2 * m0 <= N0 && m1 >= 1 && m1 <= 15 && m2 >= 1 && m2 <= 15;
+    return C == 24 && mid_n0_built(N0) && m0 == 10 && 2 * m0 <= N0 && m1 >= 1 && m1 <= 15 && m2 >= 1 && m2 <= 15;
 }
 
 static int mid_fourier_launch(bool bwd, void *workspace, const float *W2, float *s0, float *dW2, void *slab_workspace, int B, int C, int N0,
@@ -877,16 +893,18 @@ static int mid_fourier_launch(bool bwd, void *workspace, const float *W2, float 
         return fail(HNO_ELIMIT, "hno_spec_mid_fourier_bwd: %d workgroups x %d floats exceed the slab workspace", nwg, n);
     static bool attr_done = false;
     if (!attr_done) {
-        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)spec_mid_fourier_kernel<65, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)spec_mid_fourier_kernel<33, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define X(n) HNO_CHECK_HIP(hipFuncSetAttribute((const void *)spec_mid_fourier_kernel<n, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HNO_MID_N0_LIST(X)
+#undef X
         attr_done = true;
     }
     {
         ProfScope _ps(bwd ? KID_SPECMIX_BWD : KID_SPECMIX_FWD, s, 4.0 * B * C * (2.0 * N0 * 2 * (2 * m1 + 1) * 16 + 2 * 8.0 * m0 * m1 * m2));
-        if (N0 == 65 && bwd) hipLaunchKernelGGL((spec_mid_fourier_kernel<65, 10, true>), dim3(nwg), dim3(512), lds, s, a);
-        else if (N0 == 65) hipLaunchKernelGGL((spec_mid_fourier_kernel<65, 10, false>), dim3(nwg), dim3(512), lds, s, a);
-        else if (bwd) hipLaunchKernelGGL((spec_mid_fourier_kernel<33, 10, true>), dim3(nwg), dim3(512), lds, s, a);
-        else hipLaunchKernelGGL((spec_mid_fourier_kernel<33, 10, false>), dim3(nwg), dim3(512), lds, s, a);
+#define X(n)                                                                                                                \
+    if (N0 == n && bwd) hipLaunchKernelGGL((spec_mid_fourier_kernel<n, 10, true>), dim3(nwg), dim3(512), lds, s, a);          \
+    else if (N0 == n) hipLaunchKernelGGL((spec_mid_fourier_kernel<n, 10, false>), dim3(nwg), dim3(512), lds, s, a);
+        HNO_MID_N0_LIST(X)
+#undef X
     }
     HNO_CHECK_LAUNCH();
     if (!bwd) return HNO_OK;

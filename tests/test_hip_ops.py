@@ -70,7 +70,7 @@ def test_dht_crop_pad_vs_golden_and_oracle(pkg, ci):
     assert rel_err(gz.cpu().numpy(), g[f'{k}_pad_gradz']) < TOL
 
 
-@pytest.mark.parametrize('n', [65, 33])
+@pytest.mark.parametrize('n', [65, 33, 49, 57, 41])
 def test_fused_spectral_middle_vs_three_kernel_path(pkg, n):
     """hno_dht3_planes -> hno_spec_mid_fwd -> hno_idht3_planes (round 3: the axis-D steps and the frequency-domain layers of an
     HNO-XS block in one kernel, nets/hnosegxs.py:307-329,378-410,454-494) against hno_dht3_crop -> hno_specmix_layers_fwd ->
@@ -99,7 +99,7 @@ def test_fused_spectral_middle_vs_three_kernel_path(pkg, n):
     assert rel_err(gu.cpu().numpy(), ops.pad_idht3_raw(z1[-1], (n, n, n), 1.0, None, ops.ACT_NONE).cpu().numpy()) < 2e-6
 
 
-@pytest.mark.parametrize('n', [65, 33])
+@pytest.mark.parametrize('n', [65, 33, 49, 57, 73])
 @pytest.mark.parametrize('act', ['selu', None])
 def test_fused_spectral_middle_backward_vs_three_kernel_path(pkg, n, act):
     """hno_dht3_planes -> hno_spec_mid_bwd -> hno_idht3_planes (PadInverse^T, the backward of the n_XS frequency-domain layers incl.
@@ -131,7 +131,7 @@ def test_fused_spectral_middle_backward_vs_three_kernel_path(pkg, n, act):
     assert rel_err(got.cpu().numpy(), ops.pad_idht3_raw(g_z0, sp, 1.0, None, ops.ACT_NONE).cpu().numpy()) < 2e-6
 
 
-@pytest.mark.parametrize('n', [65, 33])
+@pytest.mark.parametrize('n', [65, 33, 49, 57])
 def test_fused_fourier_middle_vs_three_kernel_path(pkg, n):
     """hno_dht3_planes -> hno_spec_mid_fourier_fwd / _bwd -> hno_idht3_planes (the D step of the rfft + crop, the complex channel mix and
     the zero pad + D step of the inverse of a FNOSeg block, nets/fourier_operator.py:117-223, in one kernel each way) against
@@ -1440,7 +1440,7 @@ def test_limits_fail_loudly(pkg):
         pkg._lib.check(L.hno_dht3_crop_ld(pkg._lib.ptr(torch.randn(6 * 21 ** 3 + 4096, device='cuda')), None, 0, pkg._lib.ptr(out), pkg._lib.ptr(ws),
                                           6, 21, 21, 21, 4, 4, 4, 1.0, 21 ** 3 + 500, pkg._lib.stream_ptr()), 'x')
     assert L.hno_spec_mid_supported(24, 65, 10, 14, 14, 3) == 1 and L.hno_spec_mid_supported(16, 65, 10, 14, 14, 3) == 0
-    assert L.hno_spec_mid_supported(24, 61, 10, 14, 14, 3) == 0 and L.hno_spec_mid_supported(24, 65, 10, 14, 14, 5) == 0
+    assert L.hno_spec_mid_supported(24, 61, 10, 14, 14, 3) == 0 and L.hno_spec_mid_supported(24, 49, 10, 14, 14, 3) == 1 and L.hno_spec_mid_supported(24, 65, 10, 14, 14, 5) == 0
     assert not ops.spectral_chain_supported(torch.empty(1, 16, 65, 65, 65, device='cuda'), (10, 14, 14), 3)
     # the repack kernel: contiguous <-> padded, padding zeroed, values untouched
     t = torch.randn(2, 3, 5, 7, 9, device='cuda')
