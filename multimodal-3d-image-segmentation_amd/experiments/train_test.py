@@ -144,7 +144,7 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
              plot_epoch_portion=None, use_autocast=False, device=None, data_parallel=None, use_graph=None):
     """Trains a model; see the reference docstring (train_test.py:48-71).  `data_parallel` is an optional
     parallel.FlatGradReplica for one-process-per-GPU training (not in the reference).  `use_graph` (not in the reference): replay
-    forward + loss + backward of recurring batch shapes from a HIP graph (CapturedStep); None = on for HNOSegXS / NeuralOperatorSeg on
+    forward + loss + backward of recurring batch shapes from a HIP graph (CapturedStep); None = on for this package's model families on
     CUDA without autocast (HNO_TRAIN_GRAPH=0 switches it off); the same kernels either way."""
     import contextlib
     import torch.distributed as dist
@@ -221,11 +221,11 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
         return float(np.mean([float(v) for v in torch.stack(losses).cpu()])) if losses else float('nan')
 
     if use_graph is None:
-        # automatic for the spectral-operator families, whose captured steps are validated against the eager ones (G8 trajectory,
-        # bench.py); other models (V-Net-DS at small grids crashed inside hipStreamEndCapture, which cannot be caught) only on request
+        # automatic for this package's four model families, whose captured steps reproduce the eager trajectories bit for bit
+        # (G8 golden, tools/dbg/graph_train_ab.py, bench.py); anything else (user modules with host-side state) only on request
         from ..nets.hnosegxs import HNOSegXS
-        from ..nets.architectures import NeuralOperatorSeg
-        use_graph = os.environ.get('HNO_TRAIN_GRAPH', '1') != '0' and isinstance(model, (HNOSegXS, NeuralOperatorSeg))
+        from ..nets.architectures import NeuralOperatorSeg, HartleyMHASeg, VNetDS
+        use_graph = os.environ.get('HNO_TRAIN_GRAPH', '1') != '0' and isinstance(model, (HNOSegXS, NeuralOperatorSeg, HartleyMHASeg, VNetDS))
     captured = None
     if use_graph and not use_autocast and next(model.parameters()).is_cuda:
         captured = CapturedStep(model, loss_fn, num_labels, label_mapping, data_parallel if world > 1 else None)
