@@ -2658,6 +2658,9 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
         HNO_SPEC(9, 8, 9, 8)   // 65 x 65 planes (128^3 inputs)
         HNO_SPEC(5, 4, 5, 4)   // 33 x 33 planes (64^3 inputs)
         HNO_SPEC(8, 8, 8, 8)   // 61 x 61 planes (120 x 120 inputs)
+        HNO_SPEC(8, 7, 8, 7)   // 57 x 57 planes (112^3 inputs)
+        HNO_SPEC(7, 6, 7, 6)   // 49 x 49 planes (96^3 inputs)
+        HNO_SPEC(6, 5, 6, 5)   // 41 x 41 planes (80^3 inputs)
 #undef HNO_SPEC
         if (launched) {
         } else if (pe <= 256 * 20) {
@@ -2813,6 +2816,9 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
         HNO_SPEC(4, 4, 2, 2, 16)   // 65 x 65 planes, modes (., 14, 14): positions 1..32
         HNO_SPEC(4, 4, 2, 2, 14)   // 61 x 61 planes: positions 1..30
         HNO_SPEC(4, 4, 1, 1, 4)    // 33 x 33 planes: positions 1..16
+        HNO_SPEC(4, 4, 2, 2, 12)   // 57 x 57 planes: positions 1..28
+        HNO_SPEC(4, 4, 2, 2, 9)    // 49 x 49 planes: positions 1..24
+        HNO_SPEC(4, 4, 2, 2, 6)    // 41 x 41 planes: positions 1..20
 #undef HNO_SPEC
         if (launched) {
         } else if (pe <= 256 * 20) {

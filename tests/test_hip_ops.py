@@ -254,6 +254,33 @@ def test_generic_plane_kernels_on_large_planes_vs_float64(pkg, monkeypatch):
     assert rel_err(ops.dht3_crop_raw(ops.pad_idht3_raw(z, sp, 1.0), modes, 1.0 / np.prod(sp)).cpu().numpy(), z.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('n', [41, 49, 57, 73])
+def test_plane_kernels_on_other_working_grids_vs_float64(pkg, n):
+    """The working grids of 80^3 / 96^3 / 112^3 / 144^3 inputs (41, 49 and 57 got instantiations of the specialised plane kernels in round 3,
+    73 runs the generic ones): TransformCrop, PadInverse with residual + activation and the activation-gradient form of the forward
+    against the float64 dense formulation, contiguous and channel-padded."""
+    from multimodal_3d_image_segmentation_amd import ops
+    torch.manual_seed(13)
+    sp, modes = (7, n, n), (3, 14, 14)
+    x = torch.randn(2, 3, *sp, device='cuda')
+    z = torch.randn(2, 3, 6, 28, 28, device='cuda')
+    add = torch.randn(2, 3, *sp, device='cuda')
+    y = ops.dht3_crop_raw(x, modes, 1.0 / np.prod(sp))
+    u = ops.pad_idht3_raw(z, sp, 0.5, add, ops.ACT_SELU)
+    ya = ops.dht3_crop_raw(x, modes, 1.0, add, ops.ACT_SELU)
+    dsel = torch.where(add.double() > 0, torch.full_like(add.double(), O().SELU_SCALE), add.double() + O().SELU_SCALE * O().SELU_ALPHA)
+    for bc in ((0, 0), (1, 2)):
+        assert rel_err(y[bc].cpu().numpy(), O().dht_crop_dense(x[bc].cpu().double()[None, None], modes)[0, 0].numpy()) < 5e-6
+        want = F.selu(0.5 * O().pad_idht_dense(z[bc].cpu().double()[None, None], sp)[0, 0] + add[bc].cpu().double())
+        assert rel_err(u[bc].cpu().numpy(), want.numpy()) < 5e-6
+        wa = O().dht_crop_dense((x[bc].cpu().double() * dsel[bc].cpu())[None, None], modes, scale=1.0)[0, 0]
+        assert rel_err(ya[bc].cpu().numpy(), wa.numpy()) < 5e-6
+    ld = ops._pad_ld(np.prod(sp))
+    if ld != int(np.prod(sp)):
+        assert bool((ops.dht3_crop_raw(ops.to_layout(x, ld), modes, 1.0 / np.prod(sp)) == y).all())
+        assert bool((ops.pad_idht3_raw(z, sp, 0.5, ops.to_layout(add, ld), ops.ACT_SELU, ld=ld) == u).all())
+
+
 def test_dht_roundtrip_property_full_size(pkg):
     """Size-independent property at the benchmark size: crop(pad_inverse(z)) * 1 == z (the kept
     modes of an inverse transform of a band-limited spectrum are the spectrum itself) and linearity."""
