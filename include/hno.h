@@ -134,19 +134,23 @@ int hno_dht3_planes(const float *x, void *workspace, int BC, int N0, int N1, int
 int hno_spec_mid_fwd(void *workspace, const float *const *W_layers, float *zs, int B, int C, int N0, int m0, int m1, int m2, int L,
                      int residual, int act, float scale, void *stream);
 /* backward of the same chain: workspace = hno_dht3_planes of the block-output gradient on entry, operand of hno_idht3_planes (which
- * yields the block-input gradient) on return; zs as written by hno_spec_mid_fwd; dW (L, C, C); slab_workspace of
- * hno_specmix_bwd_workspace_bytes(B, C, M, L) bytes; bit 8 of `residual` defers the slab reduction (hno_set_defer_reduce). */
-int hno_spec_mid_bwd(void *workspace, const float *const *W_layers, const float *zs, float *dW, void *slab_workspace, int B, int C,
-                     int N0, int m0, int m1, int m2, int L, int residual, int act, float scale, void *stream);
+ * yields the block-input gradient) on return; zs as written by hno_spec_mid_fwd; dW (L, C, C); slab_workspace of slab_bytes >=
+ * hno_spec_mid_bwd_workspace_bytes(B, C, m1, L) bytes (one slab of weight-gradient partial sums per workgroup: grows with the batch;
+ * HNO_EINVAL if smaller); bit 8 of `residual` defers the slab reduction (hno_set_defer_reduce). */
+size_t hno_spec_mid_bwd_workspace_bytes(int B, int C, int m1, int L);
+int hno_spec_mid_bwd(void *workspace, const float *const *W_layers, const float *zs, float *dW, void *slab_workspace, size_t slab_bytes,
+                     int B, int C, int N0, int m0, int m1, int m2, int L, int residual, int act, float scale, void *stream);
 /* the same for the Fourier block (FNOSeg): D step of the rfft + crop -> complex channel mix as ONE real (2C, 2C) product on [re | im]
  * channels (hno_cmix_compose) -> zero pad + D step of the inverse, and its backward.  w_fwd / w_inv: c2r weights (1, 2, 2, ... over k2)
  * on the forward / inverse D step (forward pass: 0, 1; backward pass: 1, 0).  s0 (B, 2C, 2 m0, 2 m1, m2) = what hno_rfft3_crop returns
- * (written by _fwd, read by _bwd); dW2 (2C, 2C) for hno_cmix_split_grad; slab_workspace: hno_pwconv_bwd_workspace_bytes(2C, 2C). */
+ * (written by _fwd, read by _bwd); dW2 (2C, 2C) for hno_cmix_split_grad; slab_workspace: slab_bytes >=
+ * hno_spec_mid_fourier_bwd_workspace_bytes(B, C, m1). */
 int hno_spec_mid_fourier_supported(int C, int N0, int m0, int m1, int m2);
 int hno_spec_mid_fourier_fwd(void *workspace, const float *W2, float *s0, int B, int C, int N0, int m0, int m1, int m2, float scale,
                              int w_fwd, int w_inv, void *stream);
-int hno_spec_mid_fourier_bwd(void *workspace, const float *W2, const float *s0, float *dW2, void *slab_workspace, int B, int C, int N0,
-                             int m0, int m1, int m2, float scale, int w_fwd, int w_inv, void *stream);
+size_t hno_spec_mid_fourier_bwd_workspace_bytes(int B, int C, int m1);
+int hno_spec_mid_fourier_bwd(void *workspace, const float *W2, const float *s0, float *dW2, void *slab_workspace, size_t slab_bytes, int B,
+                             int C, int N0, int m0, int m1, int m2, float scale, int w_fwd, int w_inv, void *stream);
 int hno_idht3_planes(const void *workspace, const float *addend, int act, float *out, int BC, int N0, int N1, int N2, int m0, int m1,
                      int m2, float scale, long long ldbc, void *stream);
 /* hno_dht3_crop / hno_pad_idht3 on channel-padded activations: ldbc = stride (floats) between consecutive (b, c) volumes of x /

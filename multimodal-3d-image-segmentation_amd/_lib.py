@@ -34,10 +34,12 @@ SIGNATURES = {
     'hno_spec_mid_supported': (c_int, [c_int] * 6),
     'hno_dht3_planes': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_ll, c_void_p]),
     'hno_spec_mid_fwd': (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_float, c_void_p]),
-    'hno_spec_mid_bwd': (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_float, c_void_p]),
+    'hno_spec_mid_bwd_workspace_bytes': (c_size_t, [c_int] * 4),
+    'hno_spec_mid_bwd': (c_int, [c_void_p] * 5 + [c_size_t] + [c_int] * 9 + [c_float, c_void_p]),
     'hno_spec_mid_fourier_supported': (c_int, [c_int] * 5),
     'hno_spec_mid_fourier_fwd': (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_float, c_int, c_int, c_void_p]),
-    'hno_spec_mid_fourier_bwd': (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float, c_int, c_int, c_void_p]),
+    'hno_spec_mid_fourier_bwd_workspace_bytes': (c_size_t, [c_int] * 3),
+    'hno_spec_mid_fourier_bwd': (c_int, [c_void_p] * 5 + [c_size_t] + [c_int] * 6 + [c_float, c_int, c_int, c_void_p]),
     'hno_idht3_planes': (c_int, [c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 7 + [c_float, c_ll, c_void_p]),
     'hno_dht3_ld_supported': (c_int, [c_int] * 6),
     'hno_dht3_crop_ld': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_ll, c_void_p]),

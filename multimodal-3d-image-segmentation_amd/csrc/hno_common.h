@@ -84,6 +84,8 @@ int clear_doubles(double *p, int n, hipStream_t s);
 
 // debug/ablation switches (hno_set_debug): timing-only builds of a kernel phase, results are WRONG
 int debug_flags();
+// the calling thread's current HIP device (-2 on error): kernel attributes are set once per device, not once per process
+int current_device();
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // Grid of a persistent (grid-stride) kernel: no more workgroups than are resident at once (occupancy from the

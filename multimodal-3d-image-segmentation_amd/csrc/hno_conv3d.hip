@@ -837,10 +837,10 @@ extern "C" int hno_conv3d_k3_wgrad(const float *g, const float *x, float *dW, vo
     a.nchunks = (int)nch;
     const int tiles = ((a.Cg + 31) / 32) * ((a.Cx + 31) / 32);
     const size_t lds = sizeof(float) * 4 * (32 + 96) * C3W_LD;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static int attr_done = -1;
+    if (attr_done != current_device()) {
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)c3_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
+        attr_done = current_device();
     }
     ProfScope _ps(KID_CONV3D_WGRAD, s);
     hipLaunchKernelGGL(c3_wgrad_kernel, dim3(a.nchunks, 9, tiles), dim3(256), lds, s, a);

@@ -1410,10 +1410,10 @@ extern "C" int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const
                 const bool wide = 3 * S > 128;      // staging variant (template: the batched form's registers stay out of the narrow kernels)
 #define HNO_HALO_CASE(MTv, NTv, WIDEv)                                                                                                       \
     if (bMT == MTv && bNT == NTv && wide == WIDEv) {                                                                                         \
-        static bool attr_set = false;                                                                                                        \
-        if (lds > 48 * 1024 && !attr_set) {                                                                                                  \
+        static int attr_set = -1;                                                                                                        \
+        if (lds > 48 * 1024 && attr_set != current_device()) {                                                                                             \
             HNO_CHECK_HIP(hipFuncSetAttribute((const void *)cb_halo_kernel<MTv, NTv, WIDEv>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); \
-            attr_set = true;                                                                                                                 \
+            attr_set = current_device();                                                                                                                 \
         }                                                                                                                                    \
         hipLaunchKernelGGL((cb_halo_kernel<MTv, NTv, WIDEv>), g, dim3(256), lds, s, h);                                                      \
     }
@@ -1634,10 +1634,10 @@ extern "C" size_t hno_cb_wgrad_workspace_bytes(int Cin, int Cout, int ks) {
 
 template <int TA, int TB, int TPW>
 static int wg_launch1(const CwArgs &a, dim3 grid, size_t lds, hipStream_t s) {
-    static bool attr_set = false;       // once per instantiation (not a stream operation; kept out of graph captures after warm-up)
-    if (!attr_set) {
+    static int attr_set = -1;       // once per instantiation (not a stream operation; kept out of graph captures after warm-up)
+    if (attr_set != current_device()) {
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)cb_wgrad_kernel<TA, TB, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set = current_device();
     }
     hipLaunchKernelGGL((cb_wgrad_kernel<TA, TB, TPW>), grid, dim3(256), lds, s, a);
     HNO_CHECK_LAUNCH();

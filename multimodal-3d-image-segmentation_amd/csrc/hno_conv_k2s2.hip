@@ -387,8 +387,8 @@ extern "C" int hno_conv_k2s2_fwd(const float *x, const float *W, const float *bi
         ProfScope _ps(KID_CONV_K2S2_FWD, (hipStream_t)stream, 4.0 * B * ((double)Cin * D * H * Wd + (double)Cout * a.Do * a.Ho * a.Wo));
         if (Cin <= 4) hipLaunchKernelGGL(conv_k2s2_fwd_kernel<16>, dim3((int)grid), dim3(256), 4 * 2 * 16 * 256, (hipStream_t)stream, a);
         else {
-            static bool attr = false;
-            if (!attr) { (void)hipFuncSetAttribute((const void *)conv_k2s2_fwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr = true; }
+            static int attr = -1;
+            if (attr != current_device()) { (void)hipFuncSetAttribute((const void *)conv_k2s2_fwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr = current_device(); }
             hipLaunchKernelGGL(conv_k2s2_fwd_kernel<32>, dim3((int)grid), dim3(256), 4 * 2 * 32 * 256, (hipStream_t)stream, a);
         }
     }

@@ -66,9 +66,28 @@ int clear_doubles(double *p, int n, hipStream_t s) {
     return HNO_OK;
 }
 
-// HNO_DEBUG_FLAGS=<int> presets the ablation / variant switches of hno_set_debug for a whole process (A/B runs of bench.py)
-static int g_debug_flags = getenv("HNO_DEBUG_FLAGS") ? atoi(getenv("HNO_DEBUG_FLAGS")) : 0;
+// HNO_DEBUG_FLAGS=<int> presets the ablation / variant switches of hno_set_debug for a whole process (A/B runs of the measurement
+// tools).  Several bits select TIMING-ONLY variants whose results are wrong, so the variable is honoured only together with
+// HNO_ALLOW_DEBUG_FLAGS=1 (set by tools/, never by the package) and announced on stderr; a stray HNO_DEBUG_FLAGS in a training job's
+// environment is ignored with a warning.
+static int debug_flags_from_env() {
+    const char *v = getenv("HNO_DEBUG_FLAGS");
+    if (!v || atoi(v) == 0) return 0;
+    const char *ok = getenv("HNO_ALLOW_DEBUG_FLAGS");
+    if (!ok || atoi(ok) != 1) {
+        fprintf(stderr, "libhno: HNO_DEBUG_FLAGS=%s IGNORED (measurement switch; set HNO_ALLOW_DEBUG_FLAGS=1 to enable it)\n", v);
+        return 0;
+    }
+    fprintf(stderr, "libhno: WARNING: HNO_DEBUG_FLAGS=%d is active -- ablation variants, results may be WRONG\n", atoi(v));
+    return atoi(v);
+}
+static int g_debug_flags = debug_flags_from_env();
 int debug_flags() { return g_debug_flags; }
+int current_device() {
+    int dev = -2;
+    if (hipGetDevice(&dev) != hipSuccess) return -2;
+    return dev;
+}
 
 // ---- profiler state
 static const char *kKernelNames[KID_COUNT] = {

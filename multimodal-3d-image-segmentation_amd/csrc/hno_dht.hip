@@ -2568,8 +2568,8 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
     const size_t lds = sizeof(float) * plan->f_lds_floats;
     if (lds > kMaxLds) return fail(HNO_ELIMIT, "hno_dht3_crop: plane %dx%d needs %zu B of LDS (> 160 KiB)", N1, N2, lds);
     hipStream_t s = (hipStream_t)stream;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static int attr_done = -1;
+    if (attr_done != current_device()) {
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
@@ -2577,7 +2577,7 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel<16, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel<10, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_kernel<5, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
-        attr_done = true;
+        attr_done = current_device();
     }
     const int planes = BC * N0;
     // resident workgroups: LDS-limited; a grid of exactly that size lets every workgroup prefetch
@@ -2603,10 +2603,10 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
         constexpr int NWV = 8;   /* one 8-wave workgroup per CU (4 waves per CU measured 10 % slower) */                   \
         auto kern = dht_fwd_plane_wave_kernel<KC2, KS2, KC1, KS1, NEV, NWV>;                                               \
         const size_t lds_w = sizeof(float) * NWV * (16 + ((pe + 32 + 15) & ~15));                                          \
-        static bool attr = false;                                                                                          \
-        if (!attr) {                                                                                                       \
+        static int attr = -1;                                                                                          \
+        if (attr != current_device()) {                                                                                                       \
             HNO_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds)); \
-            attr = true;                                                                                                   \
+            attr = current_device();                                                                                                   \
         }                                                                                                                  \
         const int gw = persistent_grid((const void *)kern, 64 * NWV, lds_w, (planes + NWV - 1) / NWV);                     \
         hipLaunchKernelGGL(kern, dim3(gw), dim3(64 * NWV), lds_w, s, x, (float *)workspace, a);                            \
@@ -2624,10 +2624,10 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
         auto kern = (a.dbg & 2) ? dht_fwd_plane_dma_kernel<KC2, KS2, NP, NWV, 1>                                          \
                                 : (a.dbg & 4) ? dht_fwd_plane_dma_kernel<KC2, KS2, NP, NWV, 2> : dht_fwd_plane_dma_kernel<KC2, KS2, NP, NWV, 0>; \
         const size_t lds_w = (size_t)NWV * 2 * (NP == 2 ? 10 : 5) * 1024;                                                  \
-        static bool attr = false;                                                                                          \
-        if (!attr || (a.dbg & 6)) {                                                                                        \
+        static int attr = -1;                                                                                          \
+        if (attr != current_device() || (a.dbg & 6)) {                                                                                        \
             HNO_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds)); \
-            attr = true;                                                                                                   \
+            attr = current_device();                                                                                                   \
         }                                                                                                                  \
         static const int gforce = getenv("HNO_FWD_GRID") ? atoi(getenv("HNO_FWD_GRID")) : 0;                               \
         int gw = persistent_grid((const void *)kern, 64 * NWV, lds_w, (planes + NWV - 1) / NWV);                           \
@@ -2724,8 +2724,8 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
     if (lds > kMaxLds) return fail(HNO_ELIMIT, "hno_pad_idht3: plane %dx%d needs %zu B of LDS (> 160 KiB)", N1, N2, lds);
     hipStream_t s = (hipStream_t)stream;
     if (a.dbg & 8) a.act = HNO_ACT_NONE;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static int attr_done = -1;
+    if (attr_done != current_device()) {
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
@@ -2733,7 +2733,7 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel<16, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel<10, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_plane_kernel<5, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
-        attr_done = true;
+        attr_done = current_device();
     }
     const Axis &a0 = plan->ax[0];
     const size_t ldsd = sizeof(float) * 2 * a0.NT * a0.KmP * 16;
@@ -2775,20 +2775,20 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
         const int items = planes * NP;                                                                                     \
         if (addend) {                                                                                                      \
             auto kern = dht_inv_item_kernel<NP, N2c, KM1, NT2, true, NWV>;                                                      \
-            static bool attr = false;                                                                                      \
-            if (!attr) {                                                                                                   \
+            static int attr = -1;                                                                                      \
+            if (attr != current_device()) {                                                                                                   \
                 HNO_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds)); \
-                attr = true;                                                                                               \
+                attr = current_device();                                                                                               \
             }                                                                                                              \
             const int gw = items < 256 * NWV ? (items + NWV - 1) / NWV : 256;                                              \
             hipLaunchKernelGGL(kern, dim3(gw), dim3(64 * NWV), lds_w, s, (const float *)workspace, add_al, out_al, a, shift0, \
                                items / gw, items % gw, (unsigned)ldbc);                                                    \
         } else {                                                                                                           \
             auto kern = dht_inv_item_kernel<NP, N2c, KM1, NT2, false, NWV>;                                                     \
-            static bool attr = false;                                                                                      \
-            if (!attr) {                                                                                                   \
+            static int attr = -1;                                                                                      \
+            if (attr != current_device()) {                                                                                                   \
                 HNO_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds)); \
-                attr = true;                                                                                               \
+                attr = current_device();                                                                                               \
             }                                                                                                              \
             const int gw = items < 256 * NWV ? (items + NWV - 1) / NWV : 256;                                              \
             hipLaunchKernelGGL(kern, dim3(gw), dim3(64 * NWV), lds_w, s, (const float *)workspace, add_al, out_al, a, shift0, \

@@ -880,7 +880,7 @@ extern "C" int hno_loss_fwd(const float *probs, const uint8_t *labels, double *s
 static int loss_rows(int B, long long V) {
     long long gq = (V / 4 + 255) / 256;
     static const int env = getenv("HNO_LOSS_ROWS") ? atoi(getenv("HNO_LOSS_ROWS")) : 0;
-    const long long cap = env > 0 ? env : 512;
+    const long long cap = (env > 0 && env <= 1024) ? env : 512;    // the workspace holds at most 1 024 rows per sample
     if (gq > cap) gq = cap;
     (void)B;
     return (int)gq;

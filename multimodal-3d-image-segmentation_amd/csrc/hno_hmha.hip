@@ -196,10 +196,10 @@ template <int MODE, int CKT, int CVT>
 static int hm_launch(const HmArgs &a, hipStream_t s) {
     constexpr int CMAX = 32 * (CKT > CVT ? CKT : CVT);
     const size_t lds = (size_t)4 * 2 * CMAX * HM_LD * sizeof(float);
-    static bool attr = false;
-    if (lds > 48 * 1024 && !attr) {
+    static int attr = -1;
+    if (lds > 48 * 1024 && attr != current_device()) {
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)hmha_kernel<MODE, CKT, CVT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
+        attr = current_device();
     }
     const dim3 grid((a.T + 31) / 32, a.BZ);
     hipLaunchKernelGGL((hmha_kernel<MODE, CKT, CVT>), grid, dim3(256), lds, s, a);

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void pwconv_bwd_kernel(PwBwdArgs a) {
 // With the misaligned rows of rounds 1-2 four waves were best.  HNO_PWF_WAVES=4 / 12 select the others (A/B).
 static int pwf_waves() {
     static const int v = getenv("HNO_PWF_WAVES") ? atoi(getenv("HNO_PWF_WAVES")) : 8;
-    return v;
+    return (v == 4 || v == 12) ? v : 8;      // only the built instantiations
 }
 #define PWF_FAST_WAVES 8
 #define PWF_DMA_WAVES 4      // fast forward kernel: 4 waves (one per SIMD), each with a private two-slot LDS ring
@@ -1110,11 +1110,11 @@ int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const fl
             const int nw = pwf_waves();
             int g8 = (int)((ntiles + nw - 1) / nw);
             if (g8 > 256) g8 = 256;
-            static bool attr8 = false;
-            if (!attr8) {
+            static int attr8 = -1;
+            if (attr8 != current_device()) {
                 (void)hipFuncSetAttribute((const void *)pwconv_fwd_fast_kernel<24, 24, 24, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute((const void *)pwconv_fwd_fast_kernel<24, 24, 24, false, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr8 = true;
+                attr8 = current_device();
             }
             if (nw == 8) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 24, 24, false, 8>), dim3(g8), dim3(512), (size_t)8 * 2 * 24 * 256, fs, a);
             else hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 24, 24, false, 12>), dim3(g8), dim3(768), (size_t)12 * 2 * 24 * 256, fs, a);
@@ -1209,11 +1209,11 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
             long long fgb = (ntiles + PWB_FAST_WAVES - 1) / PWB_FAST_WAVES;
             if (fgb > 512) fgb = 512;
             auto kern = bf16 ? pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 1, true> : pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 1>;
-            static bool battr = false;
-            if (!battr) {
+            static int battr = -1;
+            if (battr != current_device()) {
                 (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                battr = true;
+                battr = current_device();
             }
             const int nb = Cout * Cin + Cout + Ca * Cb + Ca;
             {
@@ -1227,8 +1227,8 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
         long long fg = (ntiles + NW - 1) / NW;
         if (fg > 512) fg = 512;   // two blocks per CU
         if (a.dbg >> 8) fg = a.dbg >> 8;
-        static bool attr_done = false;
-        if (!attr_done) {
+        static int attr_done = -1;
+        if (attr_done != current_device()) {
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 24, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1236,7 +1236,7 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<48, 48, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 0, PWB_FAST_WAVES, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_done = true;
+            attr_done = current_device();
         }
         {
             ProfScope ps(KID_PWCONV_BWD, s, 4.0 * B * (double)V * ((act != HNO_ACT_NONE ? 2 : 1) * Cout + Cin + (gxa ? Ca : 0) + (gxb ? Cb : 0)));

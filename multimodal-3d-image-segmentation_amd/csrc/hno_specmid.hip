@@ -764,6 +764,33 @@ static bool mid_n0_built(int N0) {
     return false;
 }
 
+// workgroups of the fused middle kernels: 8 x roundup8(B x ceil((2 m1 + 1) / 2)) (spec_mid_kernel's id mapping)
+static int mid_workgroups(int B, int m1) {
+    const int pairs = (2 * m1 + 1 + 1) / 2, G8 = (B * pairs + 7) & ~7;
+    return 8 * G8;
+}
+
+// the dynamic-LDS attribute of the backward instantiations is a per-DEVICE property of the loaded code object
+static bool mid_attr_needed(int family) {
+    static std::mutex m;
+    static std::map<std::pair<int, int>, bool> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return true;
+    std::lock_guard<std::mutex> lock(m);
+    bool &d = done[std::make_pair(dev, family)];
+    const bool need = !d;
+    d = true;
+    return need;
+}
+
+// slab workspaces of the backward kernels: one slab of weight-gradient partial sums per workgroup (grows with the batch)
+extern "C" size_t hno_spec_mid_bwd_workspace_bytes(int B, int C, int m1, int L) {
+    return sizeof(float) * (size_t)mid_workgroups(B, m1) * L * C * C;
+}
+extern "C" size_t hno_spec_mid_fourier_bwd_workspace_bytes(int B, int C, int m1) {
+    return sizeof(float) * (size_t)mid_workgroups(B, m1) * 4 * C * C;
+}
+
 // 1 if the fused kernels exist for this configuration (Hartley layout, 24 channels, odd N0 in {65, 33} with m0 = 10, one k tile per
 // plane axis); the caller falls back to hno_dht3_crop / hno_specmix_layers_* / hno_pad_idht3 otherwise.
 extern "C" int hno_spec_mid_supported(int C, int N0, int m0, int m1, int m2, int L) {
@@ -811,9 +838,9 @@ extern "C" int hno_spec_mid_fwd(void *workspace, const float *const *W_layers, f
 // Backward of the same chain.  workspace: the forward plane transform of the block-output gradient (hno_dht3_planes of g_u) on entry,
 // the operand of the inverse plane transform that yields the block-input gradient (hno_idht3_planes) on return.  zs: what the
 // forward wrote (z_0 .. z_L).  dW: (L, C, C) weight gradients (written, or recorded for the batched end-of-backward reduction when
-// bit 8 of `residual` is set: hno_set_defer_reduce); slab_workspace: hno_specmix_bwd_workspace_bytes(B, C, M, L) bytes.
-extern "C" int hno_spec_mid_bwd(void *workspace, const float *const *W_layers, const float *zs, float *dW, void *slab_workspace, int B,
-                                int C, int N0, int m0, int m1, int m2, int L, int residual, int act, float scale, void *stream) {
+// bit 8 of `residual` is set: hno_set_defer_reduce); slab_workspace: slab_bytes >= hno_spec_mid_bwd_workspace_bytes(B, C, m1, L).
+extern "C" int hno_spec_mid_bwd(void *workspace, const float *const *W_layers, const float *zs, float *dW, void *slab_workspace,
+                                size_t slab_bytes, int B, int C, int N0, int m0, int m1, int m2, int L, int residual, int act, float scale, void *stream) {
     HNO_REQUIRE(workspace && W_layers && zs && dW && slab_workspace && B > 0, "hno_spec_mid_bwd: bad argument");
     if (!hno_spec_mid_supported(C, N0, m0, m1, m2, L)) return fail(HNO_ELIMIT, "hno_spec_mid_bwd: unsupported configuration");
     MidArgs a = {};
@@ -836,16 +863,15 @@ extern "C" int hno_spec_mid_bwd(void *workspace, const float *const *W_layers, c
     int rc = mid_twiddles(N0, m0, &a.tw);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int pairs = (2 * m1 + 1 + 1) / 2, G8 = (B * pairs + 7) & ~7, nwg = 8 * G8, n = L * C * C;
-    if ((size_t)nwg * n * sizeof(float) > hno_pwconv_bwd_workspace_bytes(C, C))
-        return fail(HNO_ELIMIT, "hno_spec_mid_bwd: %d workgroups x %d floats exceed the slab workspace", nwg, n);
+    const int nwg = mid_workgroups(B, m1), n = L * C * C;
+    if (slab_bytes < hno_spec_mid_bwd_workspace_bytes(B, C, m1, L))
+        return fail(HNO_EINVAL, "hno_spec_mid_bwd: slab workspace of %zu bytes, hno_spec_mid_bwd_workspace_bytes() = %zu", slab_bytes,
+                    hno_spec_mid_bwd_workspace_bytes(B, C, m1, L));
     const size_t lds = sizeof(float) * mid_lds_floats(m0, L, true);
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (mid_attr_needed(0)) {   // once per device
 #define X(n) HNO_CHECK_HIP(hipFuncSetAttribute((const void *)spec_mid_kernel<n, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HNO_MID_N0_LIST(X)
 #undef X
-        attr_done = true;
     }
     {
         ProfScope _ps(KID_SPECMIX_BWD, s, 4.0 * B * C * (2.0 * N0 * 2 * (2 * m1 + 1) * 16 + (L + 1) * 8.0 * m0 * m1 * m2));
@@ -866,7 +892,8 @@ extern "C" int hno_spec_mid_fourier_supported(int C, int N0, int m0, int m1, int
     return C == 24 && mid_n0_built(N0) && m0 == 10 && 2 * m0 <= N0 && m1 >= 1 && m1 <= 15 && m2 >= 1 && m2 <= 15;
 }
 
-static int mid_fourier_launch(bool bwd, void *workspace, const float *W2, float *s0, float *dW2, void *slab_workspace, int B, int C, int N0,
+static int mid_fourier_launch(bool bwd, void *workspace, const float *W2, float *s0, float *dW2, void *slab_workspace, size_t slab_bytes,
+                              int B, int C, int N0,
                               int m0, int m1, int m2, float scale, int w_fwd, int w_inv, void *stream) {
     if (!hno_spec_mid_fourier_supported(C, N0, m0, m1, m2)) return fail(HNO_ELIMIT, "hno_spec_mid_fourier: unsupported configuration");
     MidFArgs a = {};
@@ -884,19 +911,18 @@ static int mid_fourier_launch(bool bwd, void *workspace, const float *W2, float 
     int rc = mid_twiddles(N0, m0, &a.tw);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int pairs = (2 * m1 + 1 + 1) / 2, G8 = (B * pairs + 7) & ~7, nwg = 8 * G8, n = 4 * C * C;
+    const int nwg = mid_workgroups(B, m1), n = 4 * C * C;
     const int K0 = m0 + 1, NT = (2 * m0 * 4 + 31) / 32;
     size_t lds = (size_t)C * 2 * 2 * K0 * 4 + (size_t)2 * C * NT * 32;
     if (bwd) lds += (size_t)NT * 2 * 2 * C * 34 + (size_t)NT * n;
     lds *= sizeof(float);
-    if (bwd && (size_t)nwg * n * sizeof(float) > hno_pwconv_bwd_workspace_bytes(2 * C, 2 * C))
-        return fail(HNO_ELIMIT, "hno_spec_mid_fourier_bwd: %d workgroups x %d floats exceed the slab workspace", nwg, n);
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (bwd && slab_bytes < hno_spec_mid_fourier_bwd_workspace_bytes(B, C, m1))
+        return fail(HNO_EINVAL, "hno_spec_mid_fourier_bwd: slab workspace of %zu bytes, hno_spec_mid_fourier_bwd_workspace_bytes() = %zu",
+                    slab_bytes, hno_spec_mid_fourier_bwd_workspace_bytes(B, C, m1));
+    if (bwd && mid_attr_needed(1)) {   // once per device
 #define X(n) HNO_CHECK_HIP(hipFuncSetAttribute((const void *)spec_mid_fourier_kernel<n, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HNO_MID_N0_LIST(X)
 #undef X
-        attr_done = true;
     }
     {
         ProfScope _ps(bwd ? KID_SPECMIX_BWD : KID_SPECMIX_FWD, s, 4.0 * B * C * (2.0 * N0 * 2 * (2 * m1 + 1) * 16 + 2 * 8.0 * m0 * m1 * m2));
@@ -919,15 +945,15 @@ static int mid_fourier_launch(bool bwd, void *workspace, const float *W2, float 
 extern "C" int hno_spec_mid_fourier_fwd(void *workspace, const float *W2, float *s0, int B, int C, int N0, int m0, int m1, int m2, float scale,
                                         int w_fwd, int w_inv, void *stream) {
     HNO_REQUIRE(workspace && W2 && s0 && B > 0, "hno_spec_mid_fourier_fwd: bad argument");
-    return mid_fourier_launch(false, workspace, W2, s0, nullptr, nullptr, B, C, N0, m0, m1, m2, scale, w_fwd, w_inv, stream);
+    return mid_fourier_launch(false, workspace, W2, s0, nullptr, nullptr, 0, B, C, N0, m0, m1, m2, scale, w_fwd, w_inv, stream);
 }
 
 // backward: workspace = hno_dht3_planes of the gradient of the inverse transform's output; s0 as written by the forward;
 // dW2 (2C, 2C) <- sum over modes of g s0^T (hno_cmix_split_grad turns it into the gradients of the real / imaginary weights);
-// slab_workspace: hno_pwconv_bwd_workspace_bytes(2C, 2C) bytes.  On return the workspace is the operand of hno_idht3_planes.
-extern "C" int hno_spec_mid_fourier_bwd(void *workspace, const float *W2, const float *s0, float *dW2, void *slab_workspace, int B, int C,
-                                        int N0, int m0, int m1, int m2, float scale, int w_fwd, int w_inv, void *stream) {
+// slab_workspace: slab_bytes >= hno_spec_mid_fourier_bwd_workspace_bytes(B, C, m1).  On return the workspace is the operand of hno_idht3_planes.
+extern "C" int hno_spec_mid_fourier_bwd(void *workspace, const float *W2, const float *s0, float *dW2, void *slab_workspace,
+                                        size_t slab_bytes, int B, int C, int N0, int m0, int m1, int m2, float scale, int w_fwd, int w_inv, void *stream) {
     HNO_REQUIRE(workspace && W2 && s0 && dW2 && slab_workspace && B > 0, "hno_spec_mid_fourier_bwd: bad argument");
-    return mid_fourier_launch(true, workspace, W2, const_cast<float *>(s0), dW2, slab_workspace, B, C, N0, m0, m1, m2, scale, w_fwd, w_inv,
+    return mid_fourier_launch(true, workspace, W2, const_cast<float *>(s0), dW2, slab_workspace, slab_bytes, B, C, N0, m0, m1, m2, scale, w_fwd, w_inv,
                               stream);
 }

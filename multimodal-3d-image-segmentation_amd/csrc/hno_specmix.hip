@@ -398,11 +398,11 @@ __global__ __launch_bounds__(256) void specmix_bwd_loop_kernel(MixArgs a) {
 
 template <int NK>
 static void mix_bwd_loop_dispatch(bool exact, int grid, size_t lds, hipStream_t s, const MixArgs &a) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static int attr_done = -1;
+    if (attr_done != current_device()) {
         (void)hipFuncSetAttribute((const void *)specmix_bwd_loop_kernel<NK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)specmix_bwd_loop_kernel<NK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
+        attr_done = current_device();
     }
     if (exact) hipLaunchKernelGGL((specmix_bwd_loop_kernel<NK, true>), dim3(grid), dim3(256), lds, s, a);
     else hipLaunchKernelGGL((specmix_bwd_loop_kernel<NK, false>), dim3(grid), dim3(256), lds, s, a);
@@ -420,13 +420,13 @@ static void mix_fwd_dispatch(int LT, int grid, hipStream_t s, const MixArgs &a) 
 
 template <int NK>
 static void mix_bwd_dispatch(int LT, int grid, size_t lds, hipStream_t s, const MixArgs &a) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static int attr_done = -1;
+    if (attr_done != current_device()) {
         (void)hipFuncSetAttribute((const void *)specmix_bwd_kernel<NK, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)specmix_bwd_kernel<NK, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)specmix_bwd_kernel<NK, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)specmix_bwd_kernel<NK, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
+        attr_done = current_device();
     }
     switch (LT) {
         case 1: hipLaunchKernelGGL((specmix_bwd_kernel<NK, 1>), dim3(grid), dim3(256), lds, s, a); break;

@@ -114,10 +114,20 @@ class CapturedStep:
                 return None
             dev = self.params[0].device
             ent = self._capture(x.to(dev), y.to(dev))
+            if self.dp is not None and not self.dp.all_ranks_ok(ent is not None):
+                # a capture that failed on ANY rank (graph-pool OOM, a transient HIP error) is dropped on EVERY rank: a rank that
+                # replays sends one flat all-reduce, an eager rank one per bucket -- mixed, the collectives no longer match
+                if ent is not None:
+                    ent = None
+                    if not self.entries:
+                        self.dp.set_hooks_enabled(True)
             if ent is None:
                 self.failed.add(key)
                 return None
             self.entries[key] = ent
+            if os.environ.get('HNO_TRAIN_GRAPH_QUIET', '0') == '0' and (self.dp is None or torch.distributed.get_rank(self.dp.group) == 0):
+                print(f'training(): batches of shape {tuple(x.shape)} are replayed from a HIP graph from now on '
+                      f'(module / loss hooks and host-side logic do not run in replayed steps; use_graph=False keeps every step eager)')
         graph, xs, ys, loss, grads, xst, yst, done = ent
         st = self.staged
         if st is not None and st[0] is x and st[1] is y:      # prefetched: already on the device
@@ -145,7 +155,11 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
     """Trains a model; see the reference docstring (train_test.py:48-71).  `data_parallel` is an optional
     parallel.FlatGradReplica for one-process-per-GPU training (not in the reference).  `use_graph` (not in the reference): replay
     forward + loss + backward of recurring batch shapes from a HIP graph (CapturedStep); None = on for this package's model families on
-    CUDA without autocast (HNO_TRAIN_GRAPH=0 switches it off); the same kernels either way."""
+    CUDA without autocast (HNO_TRAIN_GRAPH=0 switches it off); the same kernels either way.  What changes with replay (logged once per
+    captured shape): forward / backward hooks and any host-side logic inside the model or loss_fn do not run in replayed steps; each
+    captured shape (at most 2) keeps a private graph memory pool plus input / staging buffers for the rest of training, which eager
+    validation cannot reuse (a model close to the memory limit may prefer use_graph=False); under data_parallel the per-bucket
+    overlap hooks stay off once a shape is captured (eager fall-back steps then send their buckets after backward)."""
     import contextlib
     import torch.distributed as dist
     # use_autocast (reference :79, :154-168): forward + loss under autocast, GradScaler around backward / step, its state in

@@ -612,12 +612,13 @@ def spectral_chain_bwd_raw(g_u, z0, W, modes, act, scale_out, addend, defer=Fals
     ld = chan_stride(g_u)
     addend = to_layout(addend, ld)
     ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, N0, N1, N2, m0, m1, m2) // 4, device=g_u.device, dtype=torch.float32)
-    slab = torch.empty(L.hno_specmix_bwd_workspace_bytes(B, C, 8 * m0 * m1 * m2, Lyr) // 4, device=g_u.device, dtype=torch.float32)
+    slab = torch.empty(L.hno_spec_mid_bwd_workspace_bytes(B, C, m1, Lyr) // 4, device=g_u.device, dtype=torch.float32)
     dW = _grad_buffer_stacked(W) if not torch.is_tensor(W) else torch.empty((Lyr, C, C), device=g_u.device, dtype=torch.float32)
     g_xm = act_like(g_u)
     check(L.hno_dht3_planes(ptr(g_u), ptr(ws), B * C, N0, N1, N2, m0, m1, m2, ld or 0, stream_ptr()), 'hno_dht3_planes')
     with _DeferReduce(defer) as d:
-        check(L.hno_spec_mid_bwd(ptr(ws), _layer_ptrs(Ws), ptr(z0), ptr(dW), ptr(slab), B, C, N0, m0, m1, m2, Lyr, int(residual) | d.bit, act, 1.0,
+        check(L.hno_spec_mid_bwd(ptr(ws), _layer_ptrs(Ws), ptr(z0), ptr(dW), ptr(slab), 4 * slab.numel(), B, C, N0, m0, m1, m2, Lyr,
+                                 int(residual) | d.bit, act, 1.0,
                                  stream_ptr()), 'hno_spec_mid_bwd')
         d.keep(slab)
     check(L.hno_idht3_planes(ptr(ws), ptr(addend), ACT_NONE, ptr(g_xm), B * C, N0, N1, N2, m0, m1, m2, float(scale_out), ld or 0,
@@ -662,11 +663,12 @@ def fourier_chain_bwd_raw(p, s0, w2, modes, scale_out, addend):
     ld = chan_stride(p) or 0
     addend = to_layout(addend, ld or None)
     ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, N0, N1, N2, m0, m1, m2) // 4, device=p.device, dtype=torch.float32)
-    slab = torch.empty(L.hno_pwconv_bwd_workspace_bytes(2 * C, 2 * C) // 4, device=p.device, dtype=torch.float32)
+    slab = torch.empty(L.hno_spec_mid_fourier_bwd_workspace_bytes(B, C, m1) // 4, device=p.device, dtype=torch.float32)
     dw2 = torch.empty((2 * C, 2 * C), device=p.device, dtype=torch.float32)
     gx = act_like(p)
     check(L.hno_dht3_planes(ptr(p), ptr(ws), B * C, N0, N1, N2, m0, m1, m2, ld, stream_ptr()), 'hno_dht3_planes')
-    check(L.hno_spec_mid_fourier_bwd(ptr(ws), ptr(w2), ptr(s0), ptr(dw2), ptr(slab), B, C, N0, m0, m1, m2, 1.0, 1, 0, stream_ptr()),
+    check(L.hno_spec_mid_fourier_bwd(ptr(ws), ptr(w2), ptr(s0), ptr(dw2), ptr(slab), 4 * slab.numel(), B, C, N0, m0, m1, m2, 1.0, 1, 0,
+                                     stream_ptr()),
           'hno_spec_mid_fourier_bwd')
     check(L.hno_idht3_planes(ptr(ws), ptr(addend), ACT_NONE, ptr(gx), B * C, N0, N1, N2, m0, m1, m2, float(scale_out), ld, stream_ptr()),
           'hno_idht3_planes')

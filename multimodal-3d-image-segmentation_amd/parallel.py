@@ -46,7 +46,10 @@ class FlatGradReplica:
             self.views.append(self.flat_grad[off:off + p.numel()].view_as(p))
             self.offsets.append(off)
             off += p.numel()
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.real_world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # `world` selects the code paths (> 1: collectives, hooks, flat-buffer destinations); the averaging divisor is always the
+        # REAL group size (a forced one-rank group on a backend without AVG halved every gradient)
+        self.world = self.real_world
         if force_distributed and dist.is_initialized() and self.world == 1:
             self.world = 2       # branch selector only: the collectives still run over the real (one-rank) group
         self.forced = bool(force_distributed)
@@ -163,8 +166,8 @@ class FlatGradReplica:
             w.wait()
         if self._comm_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self._comm_stream)
-        if not self._avg:
-            self.flat_grad.mul_(1.0 / self.world)
+        if not self._avg and self.real_world > 1:
+            self.flat_grad.mul_(1.0 / self.real_world)
         # ready for the next step even if the caller does not call zero_grad() (gradient accumulation into the views)
         self._pending = [len(b[2]) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
@@ -205,8 +208,19 @@ class FlatGradReplica:
         assert self._flat_ready, 'allreduce_flat() needs finish_capture() in the captured step'
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         dist.all_reduce(self.flat_grad, op=op, group=self.group)      # synchronous form: the compute stream waits for the collective
-        if not self._avg:
-            self.flat_grad.mul_(1.0 / self.world)
+        if not self._avg and self.real_world > 1:
+            self.flat_grad.mul_(1.0 / self.real_world)
+
+    def all_ranks_ok(self, ok):
+        """True iff `ok` holds on EVERY rank (one MIN all-reduce of a flag).  Decisions that change the sequence of collectives a
+        rank issues -- e.g. whether a step was captured into a graph (one flat all-reduce) or runs eagerly (one all-reduce per
+        bucket) -- must be taken by all ranks together, or the job hangs / reduces mismatched buffers."""
+        if self.real_world == 1 or not dist.is_initialized():
+            return bool(ok)
+        on_gpu = self.device.type == 'cuda' and dist.get_backend(self.group) == 'nccl'
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if on_gpu else 'cpu')
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag.item()))
 
     def close(self):
         for h in self._hooks:

@@ -70,7 +70,7 @@ def test_dht_crop_pad_vs_golden_and_oracle(pkg, ci):
     assert rel_err(gz.cpu().numpy(), g[f'{k}_pad_gradz']) < TOL
 
 
-@pytest.mark.parametrize('n', [65, 33, 49, 57, 41])
+@pytest.mark.parametrize('n', [65, 33, 49, 57, 41, 73, 81, 97])
 def test_fused_spectral_middle_vs_three_kernel_path(pkg, n):
     """hno_dht3_planes -> hno_spec_mid_fwd -> hno_idht3_planes (round 3: the axis-D steps and the frequency-domain layers of an
     HNO-XS block in one kernel, nets/hnosegxs.py:307-329,378-410,454-494) against hno_dht3_crop -> hno_specmix_layers_fwd ->
@@ -99,7 +99,7 @@ def test_fused_spectral_middle_vs_three_kernel_path(pkg, n):
     assert rel_err(gu.cpu().numpy(), ops.pad_idht3_raw(z1[-1], (n, n, n), 1.0, None, ops.ACT_NONE).cpu().numpy()) < 2e-6
 
 
-@pytest.mark.parametrize('n', [65, 33, 49, 57, 73])
+@pytest.mark.parametrize('n', [65, 33, 41, 49, 57, 73, 81, 97])
 @pytest.mark.parametrize('act', ['selu', None])
 def test_fused_spectral_middle_backward_vs_three_kernel_path(pkg, n, act):
     """hno_dht3_planes -> hno_spec_mid_bwd -> hno_idht3_planes (PadInverse^T, the backward of the n_XS frequency-domain layers incl.
@@ -131,7 +131,105 @@ def test_fused_spectral_middle_backward_vs_three_kernel_path(pkg, n, act):
     assert rel_err(got.cpu().numpy(), ops.pad_idht3_raw(g_z0, sp, 1.0, None, ops.ACT_NONE).cpu().numpy()) < 2e-6
 
 
-@pytest.mark.parametrize('n', [65, 33, 49, 57])
+MID_SIZES = [33, 41, 49, 57, 65, 73, 81, 97]      # HNO_MID_N0_LIST of csrc/hno_specmid.hip: every instantiation is run below
+
+
+@pytest.mark.parametrize('n', MID_SIZES)
+def test_fused_spectral_middle_vs_float64_dense_chain(pkg, n):
+    """Every built plane count of the fused spectral middle (incl. 81 and 97, whose last 16-row tile of the inverse D step is partly
+    masked), forward AND backward, against the float64 dense chain: oracle.dht_crop_dense -> L x z <- selu((W + I) z) ->
+    oracle.pad_idht_dense (nets/hnosegxs.py:378-410, 307-329, 454-494) and its transposes (the backward of PadInverse is
+    TransformCrop x N^3 and vice versa); the layer stack is differentiated by autograd in float64.  Bars relative to max: the
+    transforms' own 5e-6 on z0, 2e-5 after three SELU layers."""
+    from multimodal_3d_image_segmentation_amd import ops
+    torch.manual_seed(40 + n)
+    modes, sp, C, B = (10, 14, 14), (n, n, n), 24, (2 if n <= 65 else 1)
+    x = torch.randn(B, C, n, n, n, device='cuda')
+    g_u, add = torch.randn_like(x), torch.randn_like(x)
+    Ws = [torch.randn(C, C, device='cuda') * 0.2 for _ in range(3)]
+    assert ops.spectral_chain_supported(x, modes, 3)
+    f0, fs, fu = ops.spectral_chain_fwd_raw(x, Ws, modes, ops.ACT_SELU, 1.0 / n ** 3, ops.ACT_SELU)
+    assert ops.spectral_chain_bwd_ok(x, modes, f0, fs)
+    got, dW = ops.spectral_chain_bwd_raw(g_u, f0, Ws, modes, ops.ACT_SELU, 1.0 / n ** 3, add)
+    # float64 chain on the CPU
+    W64 = [w.cpu().double().requires_grad_(True) for w in Ws]
+    z0 = O().dht_crop_dense(x.cpu().double(), modes).requires_grad_(True)
+    zl, zall = z0, []
+    eye = torch.eye(C, dtype=torch.float64)
+    for w in W64:
+        zl = F.selu(torch.einsum('oi,bidhw->bodhw', w + eye, zl))
+        zall.append(zl)
+    u = F.selu(O().pad_idht_dense(zl.detach(), sp))
+    assert rel_err(f0.cpu().numpy(), z0.detach().numpy()) < 5e-6
+    for l in range(3):
+        assert rel_err(fs[l].cpu().numpy(), zall[l].detach().numpy()) < 2e-5
+    assert rel_err(fu.cpu().numpy(), u.numpy()) < 2e-5
+    g_zl = O().dht_crop_dense(g_u.cpu().double(), modes, scale=1.0)          # PadInverse^T
+    grads = torch.autograd.grad(zl, [z0] + W64, g_zl)
+    want = O().pad_idht_dense(grads[0], sp, 1.0 / n ** 3) + add.cpu().double()   # TransformCrop^T + skip gradient
+    assert rel_err(got.cpu().numpy(), want.numpy()) < 2e-5
+    for l in range(3):
+        assert rel_err(dW[l].cpu().numpy(), grads[1 + l].numpy()) < 2e-5
+
+
+@pytest.mark.parametrize('n,B', [(33, 3), (33, 4), (33, 9), (65, 3)])
+def test_fused_spectral_middle_backward_at_larger_batches(pkg, n, B):
+    """The backward's slab workspace grows with the batch (one slab per workgroup: hno_spec_mid_bwd_workspace_bytes); round 3's
+    version failed at B >= 3.  Fused vs three-kernel path, Hartley (3 layers) and Fourier."""
+    from multimodal_3d_image_segmentation_amd import ops
+    torch.manual_seed(50 + B)
+    modes, sp, C, a = (10, 14, 14), (n, n, n), 24, ops.ACT_SELU
+    x = torch.randn(B, C, n, n, n, device='cuda')
+    g_u, add = torch.randn_like(x), torch.randn_like(x)
+    Ws = [torch.randn(C, C, device='cuda') * 0.2 for _ in range(3)]
+    z0, zs, _ = ops.spectral_chain_fwd_raw(x, Ws, modes, a, 1.0 / n ** 3, a)
+    g_z0, dW = ops.specmix_bwd_raw(ops.dht3_crop_raw(g_u, modes, 1.0), z0, zs, Ws, 1, a)
+    want = ops.pad_idht3_raw(g_z0, sp, 1.0 / n ** 3, add, ops.ACT_NONE)
+    got, dW2 = ops.spectral_chain_bwd_raw(g_u, z0, Ws, modes, a, 1.0 / n ** 3, add)
+    assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 2e-6
+    assert rel_err(dW2.cpu().numpy(), dW.cpu().numpy()) < 1e-5
+    if B > 4 and n > 33:
+        return
+    wr, wi = torch.randn(C, C, device='cuda') * 0.2, torch.randn(C, C, device='cuda') * 0.2
+    w2 = torch.empty(2 * C, 2 * C, device='cuda')
+    pkg._lib.check(pkg._lib.lib().hno_cmix_compose(pkg._lib.ptr(wr), pkg._lib.ptr(wi), pkg._lib.ptr(w2), C, C, pkg._lib.stream_ptr()), 'c')
+    s0 = ops.rfft3_crop_raw(x, modes, 1.0 / n ** 3, False)
+    gs0, _, dw2, _ = ops.pwconv_bwd_raw(ops.rfft3_crop_raw(g_u, modes, 1.0, True), None, s0, None, w2, ops.ACT_NONE, False)
+    gx = ops.irfft3_pad_raw(gs0, sp, 1.0 / n ** 3, False, add, ops.ACT_NONE)
+    fgx, fdw2 = ops.fourier_chain_bwd_raw(g_u, s0, w2, modes, 1.0 / n ** 3, add)
+    assert rel_err(fgx.cpu().numpy(), gx.cpu().numpy()) < 2e-6
+    assert rel_err(fdw2.cpu().numpy(), dw2.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('n', MID_SIZES)
+def test_fused_fourier_middle_vs_float64_operator(pkg, n):
+    """Every built plane count of the Fourier block's fused middle against the float64 oracle of the reference operator
+    (oracle.fourier_operator = nets/fourier_operator.py:148-211: rfftn(norm='forward') -> complex mix -> zero pad -> unscaled irfftn):
+    block output selu(op(x) + addend), and through autograd in float64 the input gradient and both weight gradients."""
+    from multimodal_3d_image_segmentation_amd import ops
+    torch.manual_seed(60 + n)
+    modes, C, B = (10, 14, 14), 24, (2 if n <= 49 else 1)
+    L = pkg._lib.lib()
+    x = torch.randn(B, C, n, n, n, device='cuda')
+    add, p = torch.randn_like(x), torch.randn_like(x)
+    wr, wi = torch.randn(C, C, device='cuda') * 0.2, torch.randn(C, C, device='cuda') * 0.2
+    w2 = torch.empty(2 * C, 2 * C, device='cuda')
+    pkg._lib.check(L.hno_cmix_compose(pkg._lib.ptr(wr), pkg._lib.ptr(wi), pkg._lib.ptr(w2), C, C, pkg._lib.stream_ptr()), 'compose')
+    assert ops.fourier_chain_supported(x, modes)
+    s0, y = ops.fourier_chain_fwd_raw(x, w2, modes, 1.0 / n ** 3, add, ops.ACT_SELU)
+    gx, dw2 = ops.fourier_chain_bwd_raw(p, s0, w2, modes, 1.0 / n ** 3, add)
+    dwr, dwi = torch.empty_like(wr), torch.empty_like(wi)
+    pkg._lib.check(L.hno_cmix_split_grad(pkg._lib.ptr(dw2), pkg._lib.ptr(dwr), pkg._lib.ptr(dwi), C, C, pkg._lib.stream_ptr()), 'split')
+    x64 = x.cpu().double().requires_grad_(True)
+    wr64, wi64 = wr.cpu().double().requires_grad_(True), wi.cpu().double().requires_grad_(True)
+    op = O().fourier_operator(x64, wr64, wi64, modes)
+    assert rel_err(y.cpu().numpy(), F.selu(op.detach() + add.cpu().double()).numpy()) < 1e-5
+    g = torch.autograd.grad(op, [x64, wr64, wi64], p.cpu().double())
+    assert rel_err(gx.cpu().numpy(), (g[0] + add.cpu().double()).numpy()) < 1e-5
+    assert rel_err(dwr.cpu().numpy(), g[1].numpy()) < 2e-5 and rel_err(dwi.cpu().numpy(), g[2].numpy()) < 2e-5
+
+
+@pytest.mark.parametrize('n', [65, 33, 49, 57, 41, 73, 81, 97])
 def test_fused_fourier_middle_vs_three_kernel_path(pkg, n):
     """hno_dht3_planes -> hno_spec_mid_fourier_fwd / _bwd -> hno_idht3_planes (the D step of the rfft + crop, the complex channel mix and
     the zero pad + D step of the inverse of a FNOSeg block, nets/fourier_operator.py:117-223, in one kernel each way) against
@@ -232,6 +330,34 @@ def test_channel_padded_activations_match_contiguous(pkg, n, monkeypatch):
     for g0, g1 in zip(res[0][2], res[1][2]):
         assert bool(torch.isfinite(g1).all())
         assert rel_err(g1.cpu().numpy(), g0.cpu().numpy()) < 2e-5
+
+
+@pytest.mark.parametrize('family', ['hnosegxs', 'fnoseg', 'hnoseg'])
+def test_model_step_at_batch_4_fused_vs_three_kernel_middle(pkg, family, monkeypatch):
+    """a batch-4 training step must run through the fused spectral middle (its backward needs one weight-gradient slab
+    per workgroup, and the workgroup count grows with the batch) and give the gradients of the three-kernel path (HNO_FUSED_MID=0),
+    which the G6 / G7 goldens pin.  64^3 inputs -> 33^3 working grid, benchmark channel count and modes."""
+    from multimodal_3d_image_segmentation_amd import ops
+    from multimodal_3d_image_segmentation_amd.nets.hnosegxs import HNOSegXS
+    from multimodal_3d_image_segmentation_amd.nets.architectures import NeuralOperatorSeg
+    img = torch.randn(4, 4, 64, 64, 64, device='cuda', generator=torch.Generator('cuda').manual_seed(5))
+    lab = torch.randint(0, 4, (4, 1, 64, 64, 64), device='cuda', generator=torch.Generator('cuda').manual_seed(6)).to(torch.uint8)
+    res = []
+    for flag in ('0', '1'):
+        monkeypatch.setenv('HNO_FUSED_MID', flag)
+        torch.manual_seed(21)
+        if family == 'hnosegxs':
+            net = HNOSegXS(4, 4, 24, [3, 3, 3], (10, 14, 14), device='cuda')
+        else:
+            net = NeuralOperatorSeg(4, 4, 24, 3, (10, 14, 14), 'Fourier' if family == 'fnoseg' else 'Hartley', device='cuda')
+        probs = net(img)
+        loss, _ = ops.SegLossFn.apply(probs, lab, 0, 0.0)
+        loss.backward()
+        res.append((probs.detach(), float(loss), [p.grad.clone() for p in net.parameters()]))
+    assert rel_err(res[1][0].cpu().numpy(), res[0][0].cpu().numpy()) < 1e-5 and abs(res[0][1] - res[1][1]) < 1e-6
+    for g0, g1 in zip(res[0][2], res[1][2]):
+        assert bool(torch.isfinite(g1).all())
+        assert rel_err(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-4
 
 
 def test_generic_plane_kernels_on_large_planes_vs_float64(pkg, monkeypatch):

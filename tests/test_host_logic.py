@@ -180,6 +180,11 @@ for replay in range(2):                                  # a "replay" refills th
     for p, want in zip(net.parameters(), ref):
         assert torch.allclose(p.grad, want, atol=1e-6), replay
 rep2.set_hooks_enabled(True)
+# ---- decisions that change a rank's collective sequence are taken together (ADVICE round 3): a capture that fails on ONE rank
+#      must be dropped on every rank
+assert rep2.all_ranks_ok(True) is True
+assert rep2.all_ranks_ok(rank == 0) is False             # rank 1 "failed": both ranks learn it
+assert rep2.all_ranks_ok(False) is False
 # overlap=False: nothing is sent before allreduce_grads
 rep3 = FlatGradReplica(torch.nn.Linear(4, 4), overlap=False)
 rep3.zero_grad()
@@ -200,6 +205,46 @@ def test_flat_grad_allreduce_gloo_world2(tmp_path):
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert res.stdout.count('ok') == 2
+
+
+FORCED_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+dist.init_process_group('gloo')
+from multimodal_3d_image_segmentation_amd.parallel import FlatGradReplica
+# ADVICE round 3: force_distributed on a ONE-rank group of a backend without ReduceOp.AVG (gloo) must not halve the gradients:
+# `world` = 2 only selects the code paths, the divisor is the real group size
+net = torch.nn.Linear(3, 2)
+rep = FlatGradReplica(net, broadcast=False, force_distributed=True)
+assert rep.world == 2 and rep.real_world == 1 and not rep._avg
+rep.zero_grad()
+net(torch.ones(4, 3)).sum().backward()
+want = [p.grad.clone() for p in net.parameters()]
+rep.allreduce_grads()
+for p, w in zip(net.parameters(), want):
+    assert torch.equal(p.grad, w), (p.grad, w)
+rep.set_hooks_enabled(False)
+rep.zero_grad()
+net(torch.ones(4, 3)).sum().backward()
+rep.finish_capture()
+rep.allreduce_flat()
+for p, w in zip(net.parameters(), want):
+    assert torch.equal(p.grad, w)
+assert rep.all_ranks_ok(True) and not rep.all_ranks_ok(False)
+dist.destroy_process_group()
+print('ok')
+'''
+
+
+def test_forced_one_rank_replica_keeps_gradients(tmp_path):
+    script = tmp_path / 'forced_worker.py'
+    script.write_text(FORCED_WORKER)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
+           '--master-port', '29519', str(script), ROOT]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert res.stdout.count('ok') == 1
 
 
 def test_image_transform_random_stream_matches_reference():

@@ -36,8 +36,8 @@ wp = ops._layer_ptrs(Ws)
 ws = torch.randn(L.hno_dht3_workspace_bytes(B * C, N, N, N, *modes) // 4, device=dev)
 zall = torch.randn((4, B, C, 20, 28, 28), device=dev)
 dW = torch.empty(3, C, C, device=dev)
-slab = torch.empty(L.hno_specmix_bwd_workspace_bytes(B, C, 8 * 10 * 14 * 14, 3) // 4, device=dev)
-call = lambda: L.hno_spec_mid_bwd(P(ws), wp, P(zall), P(dW), P(slab), B, C, N, *modes, 3, 1, 1, 1.0, S())
+slab = torch.empty(L.hno_spec_mid_bwd_workspace_bytes(B, C, modes[1], 3) // 4, device=dev)
+call = lambda: L.hno_spec_mid_bwd(P(ws), wp, P(zall), P(dW), P(slab), 4 * slab.numel(), B, C, N, *modes, 3, 1, 1, 1.0, S())
 for dbg, name in ((0, 'full'), (16, 'return at top'), (32, 'return after phase 1'), (64, 'return before phase 4'), (64 + 2, 'before phase 4, no layers'), (2, 'no layers'), (4, 'no inverse D')):
     L.hno_set_debug(dbg)
     print(f'hno_spec_mid_bwd alone [{name}]: {timeit(call):.1f} us (incl. the slab reduction launch)')
