@@ -56,6 +56,14 @@ struct ProfScope {
 // same-address atomic contention that made the first version of these kernels 10x slower.
 int reduce_partials_launch(const float *partials, int nblocks, int n, float *dst0, int n0, float *dst1,
                            hipStream_t stream, int cols = 0, int ldd = 0, bool allow_defer = true);   // allow_defer = false: callers that reuse the slab workspace for several rounds   // cols/ldd: dst0 is a sub-block with row stride ldd
+// record lists of other translation units behind hno_set_defer_reduce / hno_flush_reduces (hno_core.hip)
+struct DeferredFamily {
+    int (*pending)();
+    int (*discard)();
+    int (*flush)(hipStream_t);
+};
+void register_deferred_family(const DeferredFamily &f);
+bool defer_reduce_enabled();
 
 // wave-private accumulator fragments -> one slab per block.  `scratch` is >= nwaves * n floats of LDS.
 // frag(idx) semantic: each wave calls store(idx, value) for the elements it owns; all 4 waves own

@@ -68,6 +68,13 @@ struct CbArgs {
     int ks, stride, pad, frac;
     int ntaps, nq2;            // ks^3, padded chunk count
     int ksplit;                // gridDim.z slices of the chunk range
+    // stride-2 fractional gather (ConvTranspose forward, input gradient of a strided conv) by PARITY CLASS: an output voxel
+    // (od, oh, ow) only meets the taps with t = (o + pad) mod 2 per axis -- 1 or 2 of 3 per axis, 27 / 8 taps on average.  With the
+    // voxels of a workgroup taken from ONE class (od % 2, oh % 2, ow % 2) the valid taps are workgroup-uniform and the others are
+    // not visited at all (round 3 multiplied zeros for them: 8x the flops; decode_layers.0.0 228 us).  cls_blk0[c]: first
+    // blockIdx.x of class c (class c = 4 pz + 2 py + px; c = 8: end).
+    int cls;
+    int cls_blk0[9];
 };
 
 // One wave = MT tiles of 32 consecutive output voxels (flattened d,h,w of one sample) x NT tiles of 32 output channels.
@@ -80,26 +87,46 @@ __global__ __launch_bounds__(256) void cb_gather_kernel(CbArgs a) {
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.z / a.ksplit, kz = blockIdx.z % a.ksplit;
     const int Vo = a.Do * a.Ho * a.Wo;
-    const int v0 = (blockIdx.x * 4 + wave) * 32 * MT;
     const int n0 = blockIdx.y * 32 * NT;
     const int Cin = a.Ca + a.Cb, nC8 = Cin >> 3, nCa8 = a.Ca >> 3;
     const size_t Vi = (size_t)a.Di * a.Hi * a.Wi;
     const bf16_t *xa = a.xa + (size_t)b * Vi * a.Ca;
     const bf16_t *xb = a.xb ? a.xb + (size_t)b * Vi * a.Cb : nullptr;
-    const bool wave_active = v0 < Vo;
+    // parity-class mode: this workgroup's class, the class's sub-grid and its valid taps (all workgroup-uniform)
+    int cls = 0, blk_local = blockIdx.x, pz = 0, py = 0, px = 0, Dc = a.Do, Hc = a.Ho, Wc = a.Wo;
+    unsigned long long tap_list = 0;      // 5 bits per valid tap
+    int ntl = a.ntaps;
+    if (a.cls) {
+        while (cls < 7 && (int)blockIdx.x >= a.cls_blk0[cls + 1]) ++cls;
+        blk_local = blockIdx.x - a.cls_blk0[cls];
+        pz = cls >> 2; py = (cls >> 1) & 1; px = cls & 1;
+        Dc = (a.Do + 1 - pz) >> 1; Hc = (a.Ho + 1 - py) >> 1; Wc = (a.Wo + 1 - px) >> 1;
+        ntl = 0;
+        for (int td = (pz + a.pad) & 1; td < a.ks; td += 2)
+            for (int th = (py + a.pad) & 1; th < a.ks; th += 2)
+                for (int tw = (px + a.pad) & 1; tw < a.ks; tw += 2) {
+                    tap_list |= (unsigned long long)((td * a.ks + th) * a.ks + tw) << (5 * ntl);
+                    ++ntl;
+                }
+    }
+    const int Vc = a.cls ? Dc * Hc * Wc : Vo;
+    const int v0 = (blk_local * 4 + wave) * 32 * MT;
+    const bool wave_active = v0 < Vc;
 
-    int od[MT], oh[MT], ow[MT];
+    int od[MT], oh[MT], ow[MT], lin[MT];      // lin: flattened output voxel of this lane's voxel (-1: none)
     bool vok[MT];
-    const int HWo = a.Ho * a.Wo;
+    const int HWc = Hc * Wc;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int v = v0 + 32 * m + r;
-        vok[m] = v < Vo;
+        vok[m] = v < Vc;
         const int vv = vok[m] ? v : 0;
-        od[m] = vv / HWo;
-        const int rem = vv - od[m] * HWo;
-        oh[m] = rem / a.Wo;
-        ow[m] = rem - oh[m] * a.Wo;
+        od[m] = vv / HWc;
+        const int rem = vv - od[m] * HWc;
+        oh[m] = rem / Wc;
+        ow[m] = rem - oh[m] * Wc;
+        if (a.cls) { od[m] = 2 * od[m] + pz; oh[m] = 2 * oh[m] + py; ow[m] = 2 * ow[m] + px; }
+        lin[m] = vok[m] ? (od[m] * a.Ho + oh[m]) * a.Wo + ow[m] : -1;
     }
     f32x16b acc[MT][NT];
 #pragma unroll
@@ -109,20 +136,26 @@ __global__ __launch_bounds__(256) void cb_gather_kernel(CbArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
-    // chunk range of this K slice (whole K-steps)
-    const int nsteps = a.nq2 >> 1;
+    // chunk range of this K slice (whole K-steps).  Virtual chunk qv = tap index x nC8 + c8 over the taps this workgroup visits
+    // (all of them, or the class's valid ones); the packed weights are addressed by the real q = tap x nC8 + c8.
+    const int nqv = ntl * nC8;
+    const int nsteps = (nqv + 1) >> 1;
     const int s_lo = (int)((long long)nsteps * kz / a.ksplit), s_hi = (int)((long long)nsteps * (kz + 1) / a.ksplit);
     if (wave_active && s_lo < s_hi) {
-        int q = 2 * s_lo + h;
-        int tap = q / nC8, c8 = q - tap * nC8;
+        int qv = 2 * s_lo + h;
+        int tapi = qv / nC8, c8 = qv - tapi * nC8;
+        int tap = 0, q = 0;
         long long off[MT];    // element offset of the tap's input voxel (channel 0) in a tensor with 1 channel; < 0: padding
-        auto set_tap = [&](int t) {
+        auto set_tap = [&](int ti) {
+            const bool live = ti < ntl;
+            const int t = a.cls ? (int)((tap_list >> (5 * (live ? ti : 0))) & 31) : (live ? ti : 0);
+            tap = t;
             const int ks2 = a.ks * a.ks;
             const int td = t / ks2, th = (t / a.ks) % a.ks, tw = t % a.ks;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 int zi, yi, xi;
-                bool ok = vok[m] && t < a.ntaps;
+                bool ok = vok[m] && live;
                 if (!a.frac) {
                     zi = a.stride * od[m] - a.pad + td;
                     yi = a.stride * oh[m] - a.pad + th;
@@ -142,14 +175,15 @@ __global__ __launch_bounds__(256) void cb_gather_kernel(CbArgs a) {
                 off[m] = ok ? ((long long)zi * a.Hi + yi) * a.Wi + xi : -1;
             }
         };
-        set_tap(tap);
+        set_tap(tapi);
+        q = tap * nC8 + c8;
         const uint4 zero4 = make_uint4(0, 0, 0, 0);
         auto load_a = [&](int m) -> uint4 {
             if (off[m] < 0) return zero4;
             const bf16_t *p = c8 < nCa8 ? xa + (size_t)off[m] * a.Ca + c8 * 8 : xb + (size_t)off[m] * a.Cb + (c8 - nCa8) * 8;
             return *reinterpret_cast<const uint4 *>(p);
         };
-        auto load_b = [&](int n) -> uint4 {
+        auto load_b = [&](int n) -> uint4 {      // (a chunk past the last tap multiplies zero activations: any finite weights do)
             return *reinterpret_cast<const uint4 *>(a.w + ((size_t)q * a.CoP + n0 + 32 * n + r) * 8);
         };
         uint4 av[MT], bv[NT];
@@ -161,14 +195,14 @@ __global__ __launch_bounds__(256) void cb_gather_kernel(CbArgs a) {
             uint4 an[MT], bn[NT];
             const bool more = s + 1 < s_hi;
             if (more) {     // next K-step's operands are in flight during this step's MFMAs
-                q += 2;
                 c8 += 2;
                 if (c8 >= nC8) {
                     c8 -= nC8;
-                    ++tap;
-                    if (c8 >= nC8) { c8 -= nC8; ++tap; }      // nC8 == 1
-                    set_tap(tap);
+                    ++tapi;
+                    if (c8 >= nC8) { c8 -= nC8; ++tapi; }      // nC8 == 1
+                    set_tap(tapi);
                 }
+                q = tap * nC8 + c8;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) an[m] = load_a(m);
 #pragma unroll
@@ -188,9 +222,15 @@ __global__ __launch_bounds__(256) void cb_gather_kernel(CbArgs a) {
             }
         }
     }
-    // epilogue.  C/D: column (lane & 31) = output channel, rows (i & 3) + 8 (i >> 2) + 4 h = voxels of the tile
+    // epilogue.  C/D: column (lane & 31) = output channel, rows (i & 3) + 8 (i >> 2) + 4 h = voxels of the tile; the flattened
+    // output voxel of row j is what lane j computed for its own voxel (lin)
     float ssum = 0.f, ssq = 0.f;
     if (wave_active) {
+        int vrow[MT][16];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) vrow[m][i] = __shfl(lin[m], (i & 3) + 8 * (i >> 2) + 4 * h);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int ch = n0 + 32 * n + r;
@@ -200,8 +240,8 @@ __global__ __launch_bounds__(256) void cb_gather_kernel(CbArgs a) {
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int v = v0 + 32 * m + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (v >= Vo) continue;
+                    const int v = vrow[m][i];
+                    if (v < 0) continue;
                     const float val = acc[m][n][i] + bias;
                     if (a.part) {
                         a.part[(((size_t)kz * a.B + b) * Vo + v) * a.Cout + ch] = val;
@@ -1344,7 +1384,10 @@ extern "C" int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const
     a.ntaps = ks * ks * ks;
     const int nq = a.ntaps * ((Ca + Cb) / 8);
     a.nq2 = (nq + 1) & ~1;
-    const int nsteps = a.nq2 / 2;
+    // stride-2 fractional gather: by parity class (CbArgs.cls); a class visits 1, 2, 4 or 8 of the 27 taps (ks = 3) -- the split over K
+    // is chosen for the average class
+    a.cls = (mode == 1 && stride == 2 && !(debug_flags() & 2048)) ? 1 : 0;
+    const int nsteps = a.cls ? (((a.ntaps + 7) / 8) * ((Ca + Cb) / 8) + 1) / 2 : a.nq2 / 2;
     const int kz = cb_pick_ksplit(B, Cout, Vo, nsteps);
     a.ksplit = kz;
     const size_t part_bytes = kz > 1 ? (size_t)kz * B * Vo * Cout * sizeof(float) : 0;
@@ -1440,16 +1483,29 @@ extern "C" int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const
     }
     {
         ProfScope _ps(KID_CB_CONV, s, flops);
+        // workgroups along x: 128 MT voxels each; in class mode per parity class (a workgroup never mixes classes)
+        auto grid_x = [&](int MT) -> unsigned {
+            const int per = 4 * 32 * MT;
+            if (!a.cls) return (unsigned)((Vo + per - 1) / per);
+            int n = 0;
+            for (int c = 0; c < 8; ++c) {
+                a.cls_blk0[c] = n;
+                const long long vc = (long long)((Do + 1 - (c >> 2)) >> 1) * ((Ho + 1 - ((c >> 1) & 1)) >> 1) * ((Wo + 1 - (c & 1)) >> 1);
+                n += (int)((vc + per - 1) / per);
+            }
+            a.cls_blk0[8] = n;
+            return (unsigned)n;
+        };
         if (Cout <= 32) {
-            const dim3 g((unsigned)((Vo + 4 * 32 * 4 - 1) / (4 * 32 * 4)), 1, B * kz);
+            const dim3 g(grid_x(4), 1, B * kz);
             hipLaunchKernelGGL((cb_gather_kernel<4, 1>), g, dim3(256), 0, s, a);
             nblk_stats = g.x * g.y;
         } else if (Cout <= 64) {
-            const dim3 g((unsigned)((Vo + 4 * 32 * 2 - 1) / (4 * 32 * 2)), 1, B * kz);
+            const dim3 g(grid_x(2), 1, B * kz);
             hipLaunchKernelGGL((cb_gather_kernel<2, 2>), g, dim3(256), 0, s, a);
             nblk_stats = g.x * g.y;
         } else {
-            const dim3 g((unsigned)((Vo + 4 * 32 * 2 - 1) / (4 * 32 * 2)), (Cout + 95) / 96, B * kz);
+            const dim3 g(grid_x(2), (Cout + 95) / 96, B * kz);
             hipLaunchKernelGGL((cb_gather_kernel<2, 3>), g, dim3(256), 0, s, a);
             nblk_stats = g.x * g.y;
         }

@@ -280,13 +280,34 @@ extern "C" int hno_set_defer_reduce(int on) {
     g_defer_reduce = on != 0;
     return was;
 }
-extern "C" int hno_pending_reduces(void) { return (int)g_deferred.size(); }
-extern "C" int hno_discard_reduces(void) {   // forget recorded reductions (a backward pass that was aborted by an exception)
-    const int n = (int)g_deferred.size();
-    g_deferred.clear();
+// other translation units (the bf16 convolution path's weight-gradient and GroupNorm reductions) keep their own record lists and
+// hook them in here: hno_pending_reduces / hno_discard_reduces / hno_flush_reduces cover every family
+static std::vector<DeferredFamily> &deferred_families() {
+    static std::vector<DeferredFamily> v;
+    return v;
+}
+void register_deferred_family(const DeferredFamily &f) { deferred_families().push_back(f); }
+bool defer_reduce_enabled() { return g_defer_reduce; }
+
+extern "C" int hno_pending_reduces(void) {
+    int n = (int)g_deferred.size();
+    for (const DeferredFamily &f : deferred_families()) n += f.pending();
     return n;
 }
-extern "C" int hno_flush_reduces(void *stream) { return flush_reduces((hipStream_t)stream); }
+extern "C" int hno_discard_reduces(void) {   // forget recorded reductions (a backward pass that was aborted by an exception)
+    int n = (int)g_deferred.size();
+    g_deferred.clear();
+    for (const DeferredFamily &f : deferred_families()) n += f.discard();
+    return n;
+}
+extern "C" int hno_flush_reduces(void *stream) {
+    int rc = flush_reduces((hipStream_t)stream);
+    for (const DeferredFamily &f : deferred_families()) {
+        const int r = f.flush((hipStream_t)stream);
+        if (rc == HNO_OK) rc = r;
+    }
+    return rc;
+}
 extern "C" const char *hno_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" int hno_selftest_gemm(const float *A, const float *Bm, float *C, int M, int N, int K, void *stream) {

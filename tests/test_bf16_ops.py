@@ -56,6 +56,14 @@ CONV_CASES = [
     (1, 48, 0, 96, (5, 6, 5), 3, 1, False),
     (1, 24, 0, 24, (9, 11, 13), 3, 2, False),       # strided down-convolution
     (1, 48, 0, 24, (5, 6, 7), 3, 2, True),          # ConvTranspose3d k3 s2 p1 op1
+    # round 4: stride-2 fractional gathers run by parity class (only the 1 / 2 / 4 / 8 valid taps of a class are visited): transposed
+    # convolutions of every channel tiling incl. split-K, and input gradients of strided convolutions on odd and even grids
+    (1, 96, 0, 48, (5, 6, 7), 3, 2, True),
+    (1, 192, 0, 96, (3, 4, 3), 3, 2, True),
+    (2, 48, 0, 24, (4, 3, 18), 3, 2, True),
+    (2, 48, 0, 48, (9, 10, 7), 3, 2, False),
+    (1, 96, 0, 96, (7, 9, 5), 3, 2, False),
+    (1, 192, 0, 192, (6, 4, 5), 3, 2, False),
     (1, 8, 0, 24, (10, 12, 8), 2, 2, False),        # conv_in (input channels padded 4 -> 8)
     (2, 48, 0, 24, (6, 7, 9), 1, 1, False),         # 1x1x1 residual conv
     (1, 192, 0, 384, (3, 4, 3), 3, 1, False),       # deep level: split-K over taps
