@@ -286,8 +286,10 @@ static std::vector<DeferredFamily> &deferred_families() {
     static std::vector<DeferredFamily> v;
     return v;
 }
+namespace hno {
 void register_deferred_family(const DeferredFamily &f) { deferred_families().push_back(f); }
 bool defer_reduce_enabled() { return g_defer_reduce; }
+}  // namespace hno
 
 extern "C" int hno_pending_reduces(void) {
     int n = (int)g_deferred.size();

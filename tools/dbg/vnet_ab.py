@@ -10,6 +10,7 @@ model = pkg.nets.VNetDS(4, 4, 24, [1, 2, 3, 3, 3], right_leg_indexes=[0, 1, 2, 3
 x = torch.randn(1, 4, 160, 192, 128, device=dev)
 lab = pkg.ops.labels_prepare(torch.randint(0, 4, (1, 1, 160, 192, 128), device=dev).float(), 4)
 loss_fn = custom_losses.PCCLoss()
+pkg.ops.set_defer_reduce(os.environ.get('HNO_DEFER', '1') == '1')      # batched end-of-backward slab reductions, as bench.py / training() run it
 def step():
     for p in model.parameters(): p.grad = None
     with torch.autocast('cuda', dtype=torch.bfloat16):
