@@ -316,10 +316,14 @@ int hno_cb_pack_weights_multi(const void *table_dev, int nrows, long long total_
 size_t hno_cb_conv_workspace_bytes(int B, int Cin, int Cout, int Do, int Ho, int Wo, int ks);
 /* y = conv([xa ; xb]) + bias as a gather GEMM.  mode 0: in = stride * out - pad + tap (Conv3d forward, ConvTranspose3d input
  * gradient); mode 1: in = (out + pad - tap) / stride where divisible (ConvTranspose3d forward, Conv3d input gradient).
- * mean_rstd (B, 2) != NULL: GroupNorm(1, Cout) statistics of the bf16-rounded output come out of the same pass. */
+ * mean_rstd (B, 2) != NULL: GroupNorm(1, Cout) statistics of the bf16-rounded output come out of the same pass.
+ * nstat_out != NULL ("lazy statistics", round 4): mean_rstd must hold hno_cb_conv_stats_floats() floats; the per-workgroup (sum, sum of
+ * squares) partials are left behind its (B, 2) slot and their count per sample is returned instead of launching the one-workgroup
+ * finalize kernel; hno_cb_gn_apply called with that count finishes them (and stores mean / rstd into the slot for the backward). */
+size_t hno_cb_conv_stats_floats(int B, int Cout, int Do, int Ho, int Wo);
 int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const void *wpacked, const float *bias, void *y, float *mean_rstd,
                 float eps, void *workspace, size_t workspace_bytes, int mode, int B, int Cout, int Di, int Hi, int Wi, int Do, int Ho,
-                int Wo, int ks, int stride, int pad, void *stream);
+                int Wo, int ks, int stride, int pad, int *nstat_out, void *stream);
 /* upper bound of the slab workspace hno_cb_wgrad writes for a layer with these (total input, output) channel counts */
 size_t hno_cb_wgrad_workspace_bytes(int Cin, int Cout, int ks);
 /* dW (fp32, the parameter's own layout) of a Conv3d (transposed = 0: g on the output grid (Dg, Hg, Wg), x = [xa ; xb] on the
@@ -327,9 +331,12 @@ size_t hno_cb_wgrad_workspace_bytes(int Cin, int Cout, int ks);
 int hno_cb_wgrad(const void *g, int Cg, const void *xa, int Ca, const void *xb, int Cb, float *dW, void *workspace,
                  size_t workspace_bytes, int transposed, int B, int Dx, int Hx, int Wx, int Dg, int Hg, int Wg, int ks, int stride,
                  int pad, void *stream);
-/* z = act(GroupNorm(1, C)(y1)) [+ act(GroupNorm(1, C)(y2))]: the residual sum of a V-Net section fused (architectures.py:205-224) */
+/* z = act(GroupNorm(1, C)(y1)) [+ act(GroupNorm(1, C)(y2))]: the residual sum of a V-Net section fused (architectures.py:205-224).
+ * nstat1 / nstat2 > 0: mr holds the producing hno_cb_conv's lazy statistics (partials behind the (B, 2) slot): finished here with
+ * `eps`, (mean, rstd) stored into the slot; 0: mr already holds (mean, rstd). */
 int hno_cb_gn_apply(const void *y1, const float *mr1, const float *gamma1, const float *beta1, const void *y2, const float *mr2,
-                    const float *gamma2, const float *beta2, void *z, int B, int C, long long V, int act, void *stream);
+                    const float *gamma2, const float *beta2, void *z, int B, int C, long long V, int act, int nstat1, int nstat2,
+                    float eps, void *stream);
 size_t hno_cb_gn_bwd_workspace_bytes(int B, int C);
 /* dy_colsum (C floats, may be NULL): sum over samples and voxels of dy per channel = the bias gradient of the convolution that produced
  * y, obtained from the per-channel reductions the backward already makes (no pass over dy: see cb_gn_bwd_apply_kernel). */

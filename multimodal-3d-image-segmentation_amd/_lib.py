@@ -80,11 +80,12 @@ SIGNATURES = {
     'hno_cb_pack_row_chunks': (c_ll, [c_void_p]),
     'hno_cb_pack_weights_multi': (c_int, [c_void_p, c_int, c_ll, c_void_p]),
     'hno_cb_conv_workspace_bytes': (c_size_t, [c_int] * 7),
+    'hno_cb_conv_stats_floats': (c_size_t, [c_int] * 5),
     'hno_cb_conv': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_size_t]
-                    + [c_int] * 12 + [c_void_p]),
+                    + [c_int] * 12 + [ctypes.POINTER(c_int), c_void_p]),
     'hno_cb_wgrad_workspace_bytes': (c_size_t, [c_int] * 3),
     'hno_cb_wgrad': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t] + [c_int] * 11 + [c_void_p]),
-    'hno_cb_gn_apply': (c_int, [c_void_p] * 9 + [c_int, c_int, c_ll, c_int, c_void_p]),
+    'hno_cb_gn_apply': (c_int, [c_void_p] * 9 + [c_int, c_int, c_ll, c_int, c_int, c_int, c_float, c_void_p]),
     'hno_cb_gn_bwd_workspace_bytes': (c_size_t, [c_int] * 2),
     'hno_cb_gn_bwd': (c_int, [c_void_p] * 10 + [c_int, c_int, c_ll, c_int, c_int, c_void_p]),
     'hno_cb_pack_input': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_ll, c_void_p]),

@@ -532,15 +532,14 @@ __global__ __launch_bounds__(256) void cb_splitk_finish_kernel(const float *__re
     }
 }
 
-// (sum, sumsq) partials -> (mean, rstd) per sample; fp64 accumulation, fixed order
-__global__ __launch_bounds__(256) void cb_gn_finalize_kernel(const float *__restrict__ part, int nblk, double count, float eps,
-                                                            float *__restrict__ mr) {
-    const int b = blockIdx.x;
-    __shared__ double sh[512];
+// (sum, sumsq) partials -> (mean, rstd) of one sample; fp64 accumulation, fixed order (256 threads; `sh` = 512 doubles of LDS).
+// Every thread returns the same pair.
+__device__ __forceinline__ void cb_gn_finalize_block(const float *__restrict__ part, int nblk, double count, float eps, double *sh,
+                                                     float &mean_out, float &rstd_out) {
     double s = 0.0, q = 0.0;
     for (int i = threadIdx.x; i < nblk; i += 256) {
-        s += (double)part[((size_t)b * nblk + i) * 2];
-        q += (double)part[((size_t)b * nblk + i) * 2 + 1];
+        s += (double)part[(size_t)i * 2];
+        q += (double)part[(size_t)i * 2 + 1];
     }
     sh[threadIdx.x] = s;
     sh[256 + threadIdx.x] = q;
@@ -552,12 +551,22 @@ __global__ __launch_bounds__(256) void cb_gn_finalize_kernel(const float *__rest
         }
         __syncthreads();
     }
+    const double mean = sh[0] / count;
+    double var = sh[256] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_out = (float)mean;
+    rstd_out = (float)(1.0 / sqrt(var + (double)eps));
+    __syncthreads();      // sh may be reused
+}
+__global__ __launch_bounds__(256) void cb_gn_finalize_kernel(const float *__restrict__ part, int nblk, double count, float eps,
+                                                            float *__restrict__ mr) {
+    const int b = blockIdx.x;
+    __shared__ double sh[512];
+    float mean, rstd;
+    cb_gn_finalize_block(part + (size_t)b * nblk * 2, nblk, count, eps, sh, mean, rstd);
     if (threadIdx.x == 0) {
-        const double mean = sh[0] / count;
-        double var = sh[256] / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        mr[2 * b] = (float)mean;
-        mr[2 * b + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        mr[2 * b] = mean;
+        mr[2 * b + 1] = rstd;
     }
 }
 
@@ -576,10 +585,29 @@ __global__ __launch_bounds__(256) void cb_gn_apply_kernel(const bf16_t *__restri
                                                          const float *__restrict__ b1, const bf16_t *__restrict__ y2,
                                                          const float *__restrict__ mr2, const float *__restrict__ g2,
                                                          const float *__restrict__ b2, bf16_t *__restrict__ z, int C, long long per_sample,
-                                                         int act) {
+                                                         int act, int nstat1, int nstat2, float eps, int B) {
     const int b = blockIdx.y;
-    const float m1 = mr1[2 * b], r1 = mr1[2 * b + 1];
-    const float m2 = y2 ? mr2[2 * b] : 0.f, r2 = y2 ? mr2[2 * b + 1] : 0.f;
+    // nstat > 0: the producing convolution left its (sum, sum of squares) partials behind the (B, 2) slot of mr (hno_cb_conv with
+    // nstat_out): every workgroup reduces them itself in the finalize kernel's order (all agree bit for bit; one dependent ~5 us
+    // launch per layer less), workgroup x = 0 of each sample stores (mean, rstd) for the backward kernels
+    __shared__ double fin[512];
+    float m1, r1, m2 = 0.f, r2 = 0.f;
+    if (nstat1 > 0) {
+        cb_gn_finalize_block(mr1 + 2 * B + (size_t)b * nstat1 * 2, nstat1, (double)per_sample, eps, fin, m1, r1);
+        if (blockIdx.x == 0 && threadIdx.x == 0) { const_cast<float *>(mr1)[2 * b] = m1; const_cast<float *>(mr1)[2 * b + 1] = r1; }
+    } else {
+        m1 = mr1[2 * b];
+        r1 = mr1[2 * b + 1];
+    }
+    if (y2) {
+        if (nstat2 > 0) {
+            cb_gn_finalize_block(mr2 + 2 * B + (size_t)b * nstat2 * 2, nstat2, (double)per_sample, eps, fin, m2, r2);
+            if (blockIdx.x == 0 && threadIdx.x == 0) { const_cast<float *>(mr2)[2 * b] = m2; const_cast<float *>(mr2)[2 * b + 1] = r2; }
+        } else {
+            m2 = mr2[2 * b];
+            r2 = mr2[2 * b + 1];
+        }
+    }
     const long long n8 = per_sample >> 3;
     const int C8 = C >> 3;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
@@ -1367,9 +1395,17 @@ extern "C" size_t hno_cb_conv_workspace_bytes(int B, int Cin, int Cout, int Do, 
 // mode 1: fractional gather in = (out + pad - tap) / stride (ConvTranspose forward, input gradient of a conv).
 // wpacked: from hno_cb_pack_weights with the matching role.  Cin = Ca + Cb GEMM input channels, Cout GEMM output channels.
 // mean_rstd (B, 2) non-null: GroupNorm(1, Cout) statistics of the rounded output are produced in the same pass.
+// nstat_out non-null ("lazy statistics"): mean_rstd must hold hno_cb_conv_stats_floats() floats; the (sum, sum of squares) partials
+// are left behind its (B, 2) slot, their count per sample is returned, and hno_cb_gn_apply (nstat > 0) finishes them -- no finalize launch.
+extern "C" size_t hno_cb_conv_stats_floats(int B, int Cout, int Do, int Ho, int Wo) {
+    const long long Vo = (long long)Do * Ho * Wo;
+    return (size_t)2 * B + (size_t)B * (((Vo + 63) / 64) * ((Cout + 31) / 32) + (size_t)Do * Ho * ((Cout + 31) / 32) + 4096) * 2;
+}
 extern "C" int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const void *wpacked, const float *bias, void *y,
                            float *mean_rstd, float eps, void *workspace, size_t workspace_bytes, int mode, int B, int Cout,
-                           int Di, int Hi, int Wi, int Do, int Ho, int Wo, int ks, int stride, int pad, void *stream) {
+                           int Di, int Hi, int Wi, int Do, int Ho, int Wo, int ks, int stride, int pad, int *nstat_out, void *stream) {
+    const bool lazy = nstat_out != nullptr && mean_rstd != nullptr;
+    if (nstat_out) *nstat_out = 0;
     HNO_REQUIRE(xa && wpacked && y && workspace && B > 0 && Cout > 0 && Ca > 0 && Cb >= 0, "hno_cb_conv: bad argument");
     HNO_REQUIRE((mode == 0 || mode == 1) && (stride == 1 || stride == 2) && ks >= 1 && ks <= 3, "hno_cb_conv: bad mode / stride / kernel");
     HNO_REQUIRE(Cb == 0 || xb, "hno_cb_conv: second input missing");
@@ -1393,7 +1429,7 @@ extern "C" int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const
     const size_t part_bytes = kz > 1 ? (size_t)kz * B * Vo * Cout * sizeof(float) : 0;
     HNO_REQUIRE(workspace_bytes >= hno_cb_conv_workspace_bytes(B, Ca + Cb, Cout, Do, Ho, Wo, ks), "hno_cb_conv: workspace too small");
     a.part = kz > 1 ? (float *)workspace : nullptr;
-    float *stats = (float *)((char *)workspace + ((part_bytes + 255) & ~(size_t)255));
+    float *stats = lazy ? mean_rstd + 2 * B : (float *)((char *)workspace + ((part_bytes + 255) & ~(size_t)255));
     a.stats = mean_rstd ? stats : nullptr;
     int nblk_stats;
     const double flops = 2.0 * B * Vo * (double)Cout * a.ntaps * (Ca + Cb);
@@ -1444,7 +1480,7 @@ extern "C" int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const
             if (h.npos < 3 * (bTH + 2) * S) h.npos = 3 * (bTH + 2) * S;
             h.ksplit = bKS;
             h.part = bKS > 1 ? (float *)workspace : nullptr;
-            float *hstats = (float *)((char *)workspace + ((part_need + 255) & ~(size_t)255));
+            float *hstats = lazy ? mean_rstd + 2 * B : (float *)((char *)workspace + ((part_need + 255) & ~(size_t)255));
             h.stats = mean_rstd ? hstats : nullptr;
             const size_t lds = (size_t)h.npos * 48 + 96 * sizeof(int2);
             const dim3 g((unsigned)(B * Do * h.nbands), (Cout + 32 * bNT - 1) / (32 * bNT), bKS);
@@ -1474,7 +1510,9 @@ extern "C" int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const
                 HNO_CHECK_LAUNCH();
                 nstat = gx;
             }
-            if (mean_rstd) {
+            if (lazy) {
+                *nstat_out = nstat;
+            } else if (mean_rstd) {
                 hipLaunchKernelGGL(cb_gn_finalize_kernel, dim3(B), dim3(256), 0, s, (const float *)hstats, nstat, (double)Vo * Cout, eps, mean_rstd);
                 HNO_CHECK_LAUNCH();
             }
@@ -1519,7 +1557,9 @@ extern "C" int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const
         HNO_CHECK_LAUNCH();
         nblk_stats = gx;
     }
-    if (mean_rstd) {
+    if (lazy) {
+        *nstat_out = nblk_stats;
+    } else if (mean_rstd) {
         hipLaunchKernelGGL(cb_gn_finalize_kernel, dim3(B), dim3(256), 0, s, (const float *)stats, nblk_stats, (double)Vo * Cout, eps, mean_rstd);
         HNO_CHECK_LAUNCH();
     }
@@ -1528,7 +1568,7 @@ extern "C" int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const
 
 extern "C" int hno_cb_gn_apply(const void *y1, const float *mr1, const float *gamma1, const float *beta1, const void *y2,
                                const float *mr2, const float *gamma2, const float *beta2, void *z, int B, int C, long long V, int act,
-                               void *stream) {
+                               int nstat1, int nstat2, float eps, void *stream) {
     HNO_REQUIRE(y1 && mr1 && gamma1 && beta1 && z && B > 0 && C > 0 && V > 0, "hno_cb_gn_apply: bad argument");
     HNO_REQUIRE(!y2 || (mr2 && gamma2 && beta2), "hno_cb_gn_apply: second branch incomplete");
     if (C % 8) return fail(HNO_ELIMIT, "hno_cb_gn_apply: C = %d must be a multiple of 8", C);
@@ -1536,8 +1576,10 @@ extern "C" int hno_cb_gn_apply(const void *y1, const float *mr1, const float *ga
     const long long per_sample = V * C;
     if (per_sample >= (1ll << 34)) return fail(HNO_ELIMIT, "hno_cb_gn_apply: %lld elements per sample exceed the kernel's 32-bit item index", per_sample);
     ProfScope _ps(KID_CB_GN, s, (double)B * per_sample * (y2 ? 6.0 : 4.0));
-    hipLaunchKernelGGL(cb_gn_apply_kernel, dim3(gsz(per_sample / 8, 256, 2048), B), dim3(256), 0, s, (const bf16_t *)y1, mr1, gamma1, beta1,
-                       (const bf16_t *)y2, mr2, gamma2, beta2, (bf16_t *)z, C, per_sample, act);
+    // (lazy statistics: every workgroup re-reads the partials, so fewer, longer-running workgroups)
+    const int cap = (nstat1 > 512 || nstat2 > 512) ? 1024 : 2048;
+    hipLaunchKernelGGL(cb_gn_apply_kernel, dim3(gsz(per_sample / 8, 256, cap), B), dim3(256), 0, s, (const bf16_t *)y1, mr1, gamma1, beta1,
+                       (const bf16_t *)y2, mr2, gamma2, beta2, (bf16_t *)z, C, per_sample, act, nstat1, nstat2, eps, B);
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }

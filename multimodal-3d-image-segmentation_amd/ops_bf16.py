@@ -12,6 +12,8 @@ from ._lib import check, ptr, stream_ptr
 from .ops import _HnoFunction, _need_gpu, _m, ACT_NONE
 
 BF16 = torch.bfloat16
+import os as _os
+_LAZY_STATS = _os.environ.get('HNO_LAZY_STATS', '1') != '0'     # A/B switch: GroupNorm statistics finished by gn_apply (round 4)
 
 
 def _ws(nbytes, device):
@@ -116,8 +118,10 @@ class PackedWeights:
         return e[1], e[2]
 
 
-def conv_raw(xa, xb, wpacked, bias, Cout, out_spatial, mode, ks, stride, pad, want_stats, eps=1e-5):
-    """gather GEMM; -> (y (B, Do, Ho, Wo, Cout) bf16, mean_rstd (B, 2) fp32 or None)"""
+def conv_raw(xa, xb, wpacked, bias, Cout, out_spatial, mode, ks, stride, pad, want_stats, eps=1e-5, lazy=False):
+    """gather GEMM; -> (y (B, Do, Ho, Wo, Cout) bf16, mean_rstd (B, 2) fp32 or None[, nstat]).  lazy: the statistics are left as
+    per-workgroup partials behind the (B, 2) slot (same storage) and their count is returned as a third value; gn_apply_raw(...,
+    nstat=) finishes them -- one dependent launch per layer less."""
     _need_gpu(xa, xb)
     xa = _cl(xa)
     B, Di, Hi, Wi, Ca = xa.shape
@@ -129,11 +133,21 @@ def conv_raw(xa, xb, wpacked, bias, Cout, out_spatial, mode, ks, stride, pad, wa
     Do, Ho, Wo = (int(v) for v in out_spatial)
     L = _lib.lib()
     y = torch.empty((B, Do, Ho, Wo, Cout), device=xa.device, dtype=BF16)
-    mr = torch.empty((B, 2), device=xa.device, dtype=torch.float32) if want_stats else None
+    lazy = bool(lazy and want_stats)
+    mr = nstat = None
+    if lazy:
+        import ctypes
+        full = torch.empty(L.hno_cb_conv_stats_floats(B, Cout, Do, Ho, Wo), device=xa.device, dtype=torch.float32)
+        mr = full[:2 * B].view(B, 2)            # (mean, rstd) slot, written by gn_apply; the partials follow in the same storage
+        nstat = ctypes.c_int(0)
+    elif want_stats:
+        mr = torch.empty((B, 2), device=xa.device, dtype=torch.float32)
     nws = L.hno_cb_conv_workspace_bytes(B, Ca + Cb, Cout, Do, Ho, Wo, ks)
     ws = _ws(nws, xa.device)
     check(L.hno_cb_conv(ptr(xa), Ca, ptr(xb), Cb, ptr(wpacked), ptr(_f32(bias)), ptr(y), ptr(mr), float(eps), ptr(ws), nws, mode, B, Cout,
-                        Di, Hi, Wi, Do, Ho, Wo, ks, stride, pad, stream_ptr()), 'hno_cb_conv')
+                        Di, Hi, Wi, Do, Ho, Wo, ks, stride, pad, nstat, stream_ptr()), 'hno_cb_conv')
+    if lazy:
+        return y, mr, int(nstat.value)
     return y, mr
 
 
@@ -162,13 +176,13 @@ def colsum_raw(g):
     return out
 
 
-def gn_apply_raw(y1, mr1, g1, b1, act, y2=None, mr2=None, g2=None, b2=None):
+def gn_apply_raw(y1, mr1, g1, b1, act, y2=None, mr2=None, g2=None, b2=None, nstat1=0, nstat2=0, eps=1e-5):
     y1 = _cl(y1)
     B, C = y1.shape[0], y1.shape[4]
     V = y1.shape[1] * y1.shape[2] * y1.shape[3]
     z = torch.empty_like(y1)
     check(_lib.lib().hno_cb_gn_apply(ptr(y1), ptr(mr1), ptr(_f32(g1)), ptr(_f32(b1)), ptr(y2), ptr(mr2), ptr(_f32(g2)), ptr(_f32(b2)), ptr(z),
-                                     B, C, V, act, stream_ptr()), 'hno_cb_gn_apply')
+                                     B, C, V, act, int(nstat1), int(nstat2), float(eps), stream_ptr()), 'hno_cb_gn_apply')
     return z
 
 
@@ -235,13 +249,15 @@ class ConvFn(_HnoFunction):
     bias gradient = column sums."""
 
     @staticmethod
-    def meta(xa, xb, W, bias, ks, stride, transposed, want_stats, eps):
+    def meta(xa, xb, W, bias, ks, stride, transposed, want_stats, eps, lazy=False):
         Cout = W.shape[1] if transposed else W.shape[0]
         osz = _out_spatial(tuple(xa.shape[1:4]), ks, stride, transposed)
-        return _m((xa.shape[0],) + osz + (Cout,), BF16), (_m((xa.shape[0], 2)) if want_stats else None)
+        out = _m((xa.shape[0],) + osz + (Cout,), BF16), (_m((xa.shape[0], 2)) if want_stats else None)
+        return out + (0,) if (lazy and want_stats) else out
 
     @staticmethod
-    def forward(ctx, xa, xb, W, bias, ks, stride, transposed, want_stats, eps):
+    def forward(ctx, xa, xb, W, bias, ks, stride, transposed, want_stats, eps, lazy=False):
+        """lazy (with want_stats): -> (y, mean_rstd, nstat): the statistics are unfinished partials (conv_raw) for GNActFn"""
         _need_gpu(xa, xb, W, bias)
         Ca = xa.shape[4]
         Cb = xb.shape[4] if xb is not None else 0
@@ -259,17 +275,18 @@ class ConvFn(_HnoFunction):
             wp, ctx.wpd = pack_weights_both(W, transposed, Cin, Cout, ks)
         else:
             wp, ctx.wpd = pack_weights(W, 2 if transposed else 0, Cin, Cout, ks), None
-        y, mr = conv_raw(xa, xb, wp, bias, Cout, osz, 1 if transposed else 0, ks, stride, pad, want_stats, eps)
+        res = conv_raw(xa, xb, wp, bias, Cout, osz, 1 if transposed else 0, ks, stride, pad, want_stats, eps, lazy=lazy)
+        y, mr = res[0], res[1]
         ctx.save_for_backward(xa, xb, W)
         ctx.cfg = (ks, stride, bool(transposed), pad, bias is not None, Ca, Cb, Cout)
         ctx.mark_non_differentiable(*([mr] if mr is not None else []))
         ctx.set_materialize_grads(False)      # no zero tensor (one fill kernel per layer) for the statistics output's gradient
-        return y, mr
+        return res
 
     @staticmethod
-    def backward(ctx, gy, _gmr):
+    def backward(ctx, gy, _gmr=None, _gn=None):
         if gy is None:
-            return (None,) * 9
+            return (None,) * 10
         xa, xb, W = ctx.saved_tensors
         ks, stride, transposed, pad, has_bias, Ca, Cb, Cout = ctx.cfg
         # left by GNActFn.backward: the column sums of this very tensor -- valid only while nobody wrote into it (the autograd engine
@@ -294,7 +311,7 @@ class ConvFn(_HnoFunction):
         if has_bias:
             db = cs if (cs is not None and cs.numel() == Cout) else colsum_raw(gy)
             _stats['colsum_fused' if db is cs else 'colsum_pass'] += 1
-        return gxa, gxb, dW, db, None, None, None, None, None
+        return gxa, gxb, dW, db, None, None, None, None, None, None
 
 
 class GNActFn(_HnoFunction):
@@ -302,13 +319,14 @@ class GNActFn(_HnoFunction):
     (nets/nets_utils.py:127-133; the two-branch form is the residual sum of a V-Net section, architectures.py:205-224)."""
 
     @staticmethod
-    def meta(y1, mr1, g1, b1, act, y2=None, mr2=None, g2=None, b2=None):
+    def meta(y1, mr1, g1, b1, act, y2=None, mr2=None, g2=None, b2=None, nstat1=0, nstat2=0, eps=1e-5):
         return _m(y1.shape, BF16)
 
     @staticmethod
-    def forward(ctx, y1, mr1, g1, b1, act, y2=None, mr2=None, g2=None, b2=None):
+    def forward(ctx, y1, mr1, g1, b1, act, y2=None, mr2=None, g2=None, b2=None, nstat1=0, nstat2=0, eps=1e-5):
+        """nstat > 0: mr holds ConvFn's lazy statistics (finished by the kernel, which also stores mean / rstd for the backward)"""
         _need_gpu(y1, y2)
-        z = gn_apply_raw(y1, mr1, g1, b1, act, y2, mr2, g2, b2)
+        z = gn_apply_raw(y1, mr1, g1, b1, act, y2, mr2, g2, b2, nstat1, nstat2, eps)
         ctx.save_for_backward(y1, mr1, g1, b1, y2, mr2, g2, b2)
         ctx.act = act
         return z
@@ -325,7 +343,7 @@ class GNActFn(_HnoFunction):
         if y2 is not None:
             dy2, dg2, db2, cs2 = gn_bwd_raw(dz, y2, mr2, g2, b2, ctx.act, colsum=True)
             dy2._hno_colsum = (cs2, dy2._version)
-        return dy1, None, dg1, db1, None, dy2, None, dg2, db2
+        return dy1, None, dg1, db1, None, dy2, None, dg2, db2, None, None, None
 
 
 class PackInputFn(_HnoFunction):
@@ -381,9 +399,14 @@ def conv_norm_act(layer, xa, xb=None, residual=None):
     if Cin_w < Cin_x:          # first layer: image channels were padded to a multiple of 8 (zero channels, zero weights)
         assert not transposed and xb is None
         W = torch.nn.functional.pad(W, (0, 0, 0, 0, 0, 0, 0, Cin_x - Cin_w))
-    y, mr = ConvFn.apply(xa, xb, W, b, ks, stride, transposed, norm is not None, norm.eps if norm is not None else 1e-5)
+    eps = norm.eps if norm is not None else 1e-5
+    nstat = 0
+    if norm is not None and not xa.is_meta and _LAZY_STATS:      # lazy statistics: GNActFn's kernel finishes them (no finalize launch)
+        y, mr, nstat = ConvFn.apply(xa, xb, W, b, ks, stride, transposed, True, eps, True)
+    else:
+        y, mr = ConvFn.apply(xa, xb, W, b, ks, stride, transposed, norm is not None, eps)
     if isinstance(residual, str):
-        return y, mr, norm
+        return y, mr, norm, nstat
     if norm is None:           # SNN configuration (SELU, no normalisation): identity statistics and affine
         dev = y.device
         mr = torch.tensor([[0.0, 1.0]] * y.shape[0], device=dev)
@@ -391,15 +414,15 @@ def conv_norm_act(layer, xa, xb=None, residual=None):
     else:
         g, bt = norm.weight, norm.bias
     if residual is None:
-        return GNActFn.apply(y, mr, g, bt, act)
-    y2, mr2, norm2 = residual
+        return GNActFn.apply(y, mr, g, bt, act, None, None, None, None, nstat, 0, eps)
+    y2, mr2, norm2, nstat2 = residual
     if norm2 is None:
         dev = y.device
         mr2 = torch.tensor([[0.0, 1.0]] * y.shape[0], device=dev)
         g2, b2 = torch.ones(y.shape[4], device=dev), torch.zeros(y.shape[4], device=dev)
     else:
         g2, b2 = norm2.weight, norm2.bias
-    return GNActFn.apply(y, mr, g, bt, act, y2, mr2, g2, b2)
+    return GNActFn.apply(y, mr, g, bt, act, y2, mr2, g2, b2, nstat, nstat2, eps)
 
 
 def pointwise_to_f32(x, weight, bias, out_channels):
