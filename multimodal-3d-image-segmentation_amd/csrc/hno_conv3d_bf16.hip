@@ -919,6 +919,9 @@ struct CwArgs {
     int slide, nseg;             // slide = 1: items are runs of output planes, the input planes slide through a 3-slot ring
 };
 
+// 16 bytes of zeros in global memory: the source of every LDS-DMA piece that lies outside its tensor
+__device__ __attribute__((aligned(16))) unsigned int g_cb_zero16[4] = {0u, 0u, 0u, 0u};
+
 // ds_read_b64_tr_b16 through the compiler builtin (it then places the lgkmcnt waits itself).  Per 16-lane group: lane 4q + p
 // supplies the address of row q, columns 4p .. 4p+3 of a 4 x 16 block; lane i receives column i of the 4 rows.
 __device__ __forceinline__ s16x4 lds_tr_read(const bf16_t *p) {
@@ -934,8 +937,8 @@ __global__ __launch_bounds__(256) void cb_wgrad_kernel(CwArgs a) {
     const int gpos = a.TH * a.Sg;                          // G image positions (rounded up to 32 below)
     const int gpos32 = (gpos + 31) & ~31;
     const int xpos = a.xpos;                               // X image positions incl. slack on both ends (host: wg_plan)
-    bf16_t *gi = reinterpret_cast<bf16_t *>(smem);                         // [gpos32][PG]
-    bf16_t *xi = gi + (size_t)gpos32 * PG;                                 // [xpos][PX], position 0 = slack
+    bf16_t *gi = reinterpret_cast<bf16_t *>(smem);                         // 2 x [gpos32][PG] (double buffer)
+    bf16_t *xi = gi + (size_t)2 * gpos32 * PG;                             // [xpos][PX], position 0 = slack
     const int xorg = a.Sx + 32;                                            // image position of (plane 0, row 0, col -pad.. see below)
     f32x4 acc[TPW][TA][TB];
 #pragma unroll
@@ -948,153 +951,200 @@ __global__ __launch_bounds__(256) void cb_wgrad_kernel(CwArgs a) {
     const int co0 = a.co0 + (gridDim.y > 1 ? (int)(blockIdx.y / a.nci) * a.CO : 0);
     const int ci0 = a.ci0 + (gridDim.y > 1 ? (int)(blockIdx.y % a.nci) * a.CI : 0);
     const int grp = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
-    // the whole X image once: the slack positions behind the last plane are read (against zeros of G) and never staged again
+    // the whole X image once: the slack positions around the plane slots are read (against zeros of G) and never staged
     for (int i = threadIdx.x; i < xpos * (PX >> 3); i += 256) reinterpret_cast<uint4 *>(xi)[i] = make_uint4(0, 0, 0, 0);
-    // stage input plane `id` (rows ih0 .. ih0 + xrows - 1, columns -pad .. Sx - pad - 1) into plane slot `slot`: one wave per image
-    // row (the row's validity is wave-uniform), a lane per position, 16-byte loads of the channel block; out of range -> zero
+    __syncthreads();
+    // ---- staging by LDS-DMA (round 4).  Round 3 staged through registers between two barriers: stage, sync, multiply, sync -- the
+    // two phases ADD (48 -> 24 layer at 81 x 97 x 65: staging alone 98 us, K loop alone 105 us, both 184 us; tools/bench_cb_conv.py).
+    // Now the images of step n + 1 are requested (global_load_lds_dwordx4: 64 lanes x 16 bytes -> 1 KiB of contiguous LDS, no
+    // registers) before the K loop of step n runs, into the other G buffer and the free plane slot(s).  An image is a flat array of
+    // 16-byte pieces [position][channel block / 8]; piece f of a plane slot is (row f / (Sx LPP), column, channel piece); pieces outside
+    // the tensor (spatial padding, pad channels) come from a 16-byte block of zeros in global memory (a DMA cannot mask).
+    const unsigned gi_b = (unsigned)(size_t)gi, xi_b = (unsigned)(size_t)xi;    // LDS byte addresses
+    const bf16_t *zsrc = reinterpret_cast<const bf16_t *>(g_cb_zero16);
+    auto dma16 = [&](const bf16_t *src, unsigned dst_wave) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst_wave) : "memory");
+    };
+    // one wave per image row (row validity and the row's base address are wave-uniform: scalar arithmetic), a lane per 16-byte piece:
+    // per DMA instruction a lane spends ~10 VALU operations on its address (the first version decoded a flat piece index with two
+    // runtime divisions per piece: the address arithmetic of a step cost as much as its K loop)
     auto stage_plane = [&](int b, int id, int ih0, int slot) {
+        constexpr int LPP = TB * 2;
         const int c8n = (a.CI + 7) >> 3;
         const bool pok = id >= 0 && id < a.Di;
+        const int npr = a.Sx * LPP;                                   // pieces per image row
+        const unsigned dst0 = xi_b + (unsigned)(xorg + slot * a.xrows * a.Sx) * (PX * 2);
         for (int rr = wave; rr < a.xrows; rr += 4) {
             const int ih = ih0 + rr;
             const bool rok = pok && ih >= 0 && ih < a.Hi;
             const size_t vrow = (((size_t)b * a.Di + (rok ? id : 0)) * a.Hi + (rok ? ih : 0)) * a.Wi;
-            bf16_t *drow = xi + ((size_t)xorg + (size_t)(slot * a.xrows + rr) * a.Sx) * PX;
-            for (int cc0 = 0; cc0 < a.Sx; cc0 += 128) {          // two positions per lane and pass, all their loads in flight
-                uint4 v[2][TB * 2];
-                bool okk[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int cc = cc0 + lane + 64 * u;
-                    const int iw = cc - a.pad;
-                    okk[u] = rok && cc < a.Sx && iw >= 0 && iw < a.Wi;
-#pragma unroll
-                    for (int c8 = 0; c8 < TB * 2; ++c8) {
-                        const int ch = ci0 + c8 * 8;
-                        const bool ok = okk[u] && c8 < c8n;
-                        const bf16_t *ptr = !ok ? a.xa : (ch < a.Ca ? a.xa + (vrow + iw) * a.Ca + ch : a.xb + (vrow + iw) * a.Cb + (ch - a.Ca));
-                        v[u][c8] = *reinterpret_cast<const uint4 *>(ptr);
-                        if (!ok) v[u][c8] = make_uint4(0, 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int cc = cc0 + lane + 64 * u;
-                    if (cc < a.Sx)
-#pragma unroll
-                        for (int c8 = 0; c8 < TB * 2; ++c8) *reinterpret_cast<uint4 *>(drow + (size_t)cc * PX + c8 * 8) = v[u][c8];
-                }
+            const bf16_t *ra = a.xa + vrow * a.Ca + ci0, *rb = a.xb ? a.xb + vrow * a.Cb + (ci0 - a.Ca) : a.xa;
+            const unsigned drow = dst0 + (unsigned)(rr * a.Sx) * (PX * 2);
+            for (int f0 = 0; f0 < npr; f0 += 64) {
+                const int f = f0 + lane;
+                const int cc = f / LPP, piece = f - cc * LPP;
+                const int iw = cc - a.pad, ch = ci0 + piece * 8;
+                const bool ok = rok && iw >= 0 && iw < a.Wi && piece < c8n;
+                const bf16_t *src = !ok ? zsrc : (ch < a.Ca ? ra + (size_t)iw * a.Ca + piece * 8 : rb + (size_t)iw * a.Cb + piece * 8);
+                if (f < npr) dma16(src, __builtin_amdgcn_readfirstlane(drow + (unsigned)f0 * 16u));
             }
         }
     };
-    auto stage_g = [&](int b, int od, int oh0) {
+    auto stage_g = [&](int b, int od, int oh0, int buf) {
+        constexpr int LPG = TA * 2;
         const int c8n = (a.CO + 7) >> 3;
-        const int rows_img = gpos32 / a.Sg + 1;
+        const int npr = a.Sg * LPG;
+        const int rows_img = (gpos32 + a.Sg - 1) / a.Sg;              // image rows incl. the (partial) rounding row: all zero beyond TH
+        const unsigned dst0 = gi_b + (unsigned)buf * (unsigned)(gpos32 * PG * 2);
         for (int hh = wave; hh < rows_img; hh += 4) {
             const int oh = oh0 + hh;
             const bool rok = hh < a.TH && oh < a.Ho;
             const size_t vrow = (((size_t)b * a.Do + od) * a.Ho + (rok ? oh : 0)) * a.Wo;
-            for (int ww0 = 0; ww0 < a.Sg; ww0 += 128) {
-                uint4 v[2][TA * 2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int ww = ww0 + lane + 64 * u;
-#pragma unroll
-                    for (int c8 = 0; c8 < TA * 2; ++c8) {
-                        const bool ok = rok && ww < a.Wo && c8 < c8n;
-                        v[u][c8] = *reinterpret_cast<const uint4 *>(ok ? a.g + (vrow + ww) * a.Cg + co0 + c8 * 8 : a.g);
-                        if (!ok) v[u][c8] = make_uint4(0, 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int ww = ww0 + lane + 64 * u;
-                    const int p = hh * a.Sg + ww;
-                    if (ww < a.Sg && p < gpos32)
-#pragma unroll
-                        for (int c8 = 0; c8 < TA * 2; ++c8) *reinterpret_cast<uint4 *>(gi + (size_t)p * PG + c8 * 8) = v[u][c8];
-                }
+            const bf16_t *rg = a.g + vrow * a.Cg + co0;
+            const unsigned drow = dst0 + (unsigned)(hh * a.Sg) * (PG * 2);
+            const int nrow = (gpos32 - hh * a.Sg) * LPG < npr ? (gpos32 - hh * a.Sg) * LPG : npr;     // the last row stops at gpos32
+            for (int f0 = 0; f0 < nrow; f0 += 64) {
+                const int f = f0 + lane;
+                const int ww = f / LPG, piece = f - ww * LPG;
+                const bool ok = rok && ww < a.Wo && piece < c8n;
+                const bf16_t *src = ok ? rg + (size_t)ww * a.Cg + piece * 8 : zsrc;
+                if (f < nrow) dma16(src, __builtin_amdgcn_readfirstlane(drow + (unsigned)f0 * 16u));
             }
         }
     };
-    // work items.  slide = 1 (3x3x3, stride 1): an item is (b, band, a run of consecutive output planes); the three input planes
-    // of a run live in a ring of plane slots and every step stages ONE new plane (the first version staged all three planes of
-    // every (od, band): 155 of 254 us on the largest layer).  slide = 0: an item is one (b, od, band).
+    // work items.  slide = 1 (3x3x3, stride 1): an item is (b, band, a run of consecutive output planes); the input planes of a run
+    // live in a ring of FOUR plane slots (plane id in slot (id + 1) & 3) and every step requests ONE new plane -- the plane of the
+    // NEXT step.  slide = 0: an item is one (b, od, band) with its ks input planes in one of two slot sets.
     const long long nwork = a.slide ? (long long)a.B * a.nbands * a.nseg : (long long)a.B * a.Do * a.nbands;
-    for (long long wk = blockIdx.x; wk < nwork; wk += gridDim.x) {
-        int b, band, od_lo, od_hi;
+    // a step = (work item wk, output plane od); item -> (b, band, od_lo, od_hi).  Plain integers: a struct with a bool went through scratch
+    int c_b = 0, c_band = 0, c_od = 0, c_lo = 0, c_hi = 0;
+    long long c_wk = blockIdx.x;
+    auto decode = [&](long long wk, int &sb, int &sband, int &slo, int &shi) -> bool {
+        if (wk >= nwork) return false;
         if (a.slide) {
             const int seg = (int)(wk % a.nseg);
-            band = (int)((wk / a.nseg) % a.nbands);
-            b = (int)(wk / ((long long)a.nseg * a.nbands));
-            od_lo = (int)((long long)a.Do * seg / a.nseg);
-            od_hi = (int)((long long)a.Do * (seg + 1) / a.nseg);
+            sband = (int)((wk / a.nseg) % a.nbands);
+            sb = (int)(wk / ((long long)a.nseg * a.nbands));
+            slo = (int)((long long)a.Do * seg / a.nseg);
+            shi = (int)((long long)a.Do * (seg + 1) / a.nseg);
         } else {
-            band = (int)(wk % a.nbands);
-            od_lo = (int)((wk / a.nbands) % a.Do);
-            od_hi = od_lo + 1;
-            b = (int)(wk / ((long long)a.nbands * a.Do));
+            sband = (int)(wk % a.nbands);
+            slo = (int)((wk / a.nbands) % a.Do);
+            shi = slo + 1;
+            sb = (int)(wk / ((long long)a.nbands * a.Do));
         }
-        const int oh0 = band * a.TH;
-        const int ih0 = a.stride * oh0 - a.pad;
-      for (int od = od_lo; od < od_hi; ++od) {
-        __syncthreads();   // previous step's reads are done
-        if (!(a.dbg & 512)) {
-            stage_g(b, od, oh0);
-            if (a.slide) {
-                // input planes od - 1, od, od + 1 live in slots (plane + 1) % 3
-                if (od == od_lo) { stage_plane(b, od - 1, ih0, od % 3); stage_plane(b, od, ih0, (od + 1) % 3); }
-                stage_plane(b, od + 1, ih0, (od + 2) % 3);
-            } else {
-                for (int pl = 0; pl < a.xplanes; ++pl) stage_plane(b, a.stride * od - a.pad + pl, ih0, pl);
-            }
+        return true;        // (nseg <= Do on the host: no empty runs)
+    };
+    // request the images of a step (G into buffer `par`; X: the planes the step needs that are not in the ring yet)
+    auto request = [&](int sb, int sband, int sod, int slo, int par) {
+        const int oh0 = sband * a.TH, ih0 = a.stride * oh0 - a.pad;
+        stage_g(sb, sod, oh0, par);
+        if (a.slide) {
+            if (sod == slo) { stage_plane(sb, sod - 1, ih0, sod & 3); stage_plane(sb, sod, ih0, (sod + 1) & 3); }
+            stage_plane(sb, sod + 1, ih0, (sod + 2) & 3);
+        } else {
+            for (int pl = 0; pl < a.xplanes; ++pl) stage_plane(sb, a.stride * sod - a.pad + pl, ih0, par * a.xplanes + pl);
         }
-        const int slot_rot = a.slide ? od % 3 : 0;         // input plane od - 1 + td sits in slot (od + td) % 3
-        __syncthreads();
-        if (a.dbg & 1024) continue;
-        // ---- K loop over the band's positions, 32 per step (v_mfma_f32_16x16x32_bf16: lane group grp holds k = 8 grp .. 8 grp + 7)
-        for (int p0 = 0; p0 < gpos32; p0 += 32) {
-            // A operand = G^T: rows = output channels (16 per tile), k = positions.  Two transposed reads per tile:
-            // positions p0 + 8 grp + {0..3} and + {4..7}; lane 4q+p supplies row q, channels 4p..4p+3 of the tile
-            s16x4 af[TA][2];
+    };
+    bool c_valid = decode(c_wk, c_b, c_band, c_lo, c_hi);
+    c_od = c_lo;
+    int par = 0;
+    if (c_valid && !(a.dbg & 512)) request(c_b, c_band, c_od, c_lo, par);
+    while (c_valid) {
+        int n_b = c_b, n_band = c_band, n_od = c_od + 1, n_lo = c_lo, n_hi = c_hi;
+        long long n_wk = c_wk;
+        bool n_valid = true;
+        if (n_od >= n_hi) {
+            n_wk = c_wk + gridDim.x;
+            n_valid = decode(n_wk, n_b, n_band, n_lo, n_hi);
+            n_od = n_lo;
+        }
+        // a new run needs three fresh planes: they do not fit beside the three the current step reads -> requested after its K loop
+        const bool early = n_valid && !(a.slide && n_od == n_lo);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's requests for `cur` have landed ...
+        __syncthreads();                                       // ... everybody's have, and everybody is done with the previous step
+        if (early && !(a.dbg & 512)) request(n_b, n_band, n_od, n_lo, par ^ 1);
+        const bf16_t *gcur = gi + (size_t)par * gpos32 * PG;
+        const int od = c_od;
+        {
+        const int slot_rot = 0;
+        (void)slot_rot;
+        if (!(a.dbg & 1024)) {
+        // ---- K loop over the band's positions, 32 per step (v_mfma_f32_16x16x32_bf16: lane group grp holds k = 8 grp .. 8 grp + 7).
+        // Round 4: software-pipelined and branch-free.  The first version read a tap's six B fragments, waited for them and multiplied,
+        // tap after tap, behind a wave-uniform `tap < ntaps` branch per tap (ISA: s_cbranch_execz + s_waitcnt lgkmcnt(0) in front of
+        // every group of 9 MFMAs: ~100 cycles of exposed LDS latency per 144 MFMA cycles with one wave per SIMD -- the weight gradient
+        // ran at half the forward rate).  Now the fragments of step (p0, t + 1) are requested BEFORE the MFMAs of step (p0, t); a wave
+        // whose last tap does not exist (27 taps over 4 waves) multiplies a clamped tap and drops the result at the slab store.
+        int boff[TPW];        // wave-uniform LDS element offset of tap t's X window (position 0 of the band)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            int tap = wave + 4 * t;
+            tap = tap < a.ntaps ? tap : a.ntaps - 1;
+            const int ks2 = a.ks * a.ks;
+            const int td = tap / ks2, th = (tap / a.ks) % a.ks, tw = tap % a.ks;
+            const int slot = a.slide ? ((od + td) & 3) : par * a.xplanes + td;      // input plane od - 1 + td sits in slot (od + td) & 3
+            boff[t] = (xorg + (slot * a.xrows + th) * a.Sx + tw) * PX;
+        }
+        const int a_lane = (8 * grp + lq) * PG + 4 * lp;                 // + (p0 + 4 u) PG + 16 i
+        const int b_lane = a.stride * (8 * grp + lq) * PX + 4 * lp;      // + boff[t] + stride (p0 + 4 u) PX + 16 j
+        auto load_a = [&](int p0, s16x4 (&af)[TA][2]) {
 #pragma unroll
             for (int i = 0; i < TA; ++i)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int pos = p0 + 8 * grp + 4 * u + lq;
-                    af[i][u] = lds_tr_read(gi + (pos * PG + 16 * i + 4 * lp));
-                }
+                for (int u = 0; u < 2; ++u) af[i][u] = lds_tr_read(gcur + (a_lane + (p0 + 4 * u) * PG + 16 * i));
+        };
+        auto load_b = [&](int p0, int off, s16x4 (&bf)[TB][2]) {
+#pragma unroll
+            for (int j = 0; j < TB; ++j)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) bf[j][u] = lds_tr_read(xi + (b_lane + off + a.stride * (p0 + 4 * u) * PX + 16 * j));
+        };
+        s16x4 af[TA][2], bcur[TB][2];
+        load_a(0, af);
+        load_b(0, boff[0], bcur);
+        for (int p0 = 0; p0 < gpos32; p0 += 32) {
+            const int pn = p0 + 32 < gpos32 ? p0 + 32 : p0;      // (the last step re-requests its own fragments: harmless)
+            s16x4 an[TA][2];
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
-                const int tap = wave + 4 * t;
-                if (tap < a.ntaps) {            // wave-uniform
-                    const int ks2 = a.ks * a.ks;
-                    const int td = tap / ks2, th = (tap / a.ks) % a.ks, tw = tap % a.ks;
-                    int slot = td + slot_rot;
-                    slot = slot >= 3 ? slot - 3 : slot;
-                    const int base = xorg + (slot * a.xrows + th) * a.Sx + tw;
-                    s16x4 bfr[TB][2];
-#pragma unroll
-                    for (int j = 0; j < TB; ++j)
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const int pos = base + a.stride * (p0 + 8 * grp + 4 * u + lq);
-                            bfr[j][u] = lds_tr_read(xi + (pos * PX + 16 * j + 4 * lp));
-                        }
-#pragma unroll
-                    for (int i = 0; i < TA; ++i)
-#pragma unroll
-                        for (int j = 0; j < TB; ++j) {
-                            typedef short s16x8 __attribute__((ext_vector_type(8)));
-                            const s16x8 av = {af[i][0][0], af[i][0][1], af[i][0][2], af[i][0][3], af[i][1][0], af[i][1][1], af[i][1][2], af[i][1][3]};
-                            const s16x8 bv = {bfr[j][0][0], bfr[j][0][1], bfr[j][0][2], bfr[j][0][3], bfr[j][1][0], bfr[j][1][1], bfr[j][1][2], bfr[j][1][3]};
-                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
-                                                                                   acc[t][i][j], 0, 0, 0);
-                        }
+                s16x4 bn[TB][2];
+                if (t + 1 < TPW) {
+                    load_b(p0, boff[t + 1], bn);
+                } else {
+                    load_a(pn, an);
+                    load_b(pn, boff[0], bn);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TA; ++i)
+#pragma unroll
+                    for (int j = 0; j < TB; ++j) {
+                        typedef short s16x8 __attribute__((ext_vector_type(8)));
+                        const s16x8 av = {af[i][0][0], af[i][0][1], af[i][0][2], af[i][0][3], af[i][1][0], af[i][1][1], af[i][1][2], af[i][1][3]};
+                        const s16x8 bv = {bcur[j][0][0], bcur[j][0][1], bcur[j][0][2], bcur[j][0][3], bcur[j][1][0], bcur[j][1][1], bcur[j][1][2], bcur[j][1][3]};
+                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                                               acc[t][i][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < TB; ++j)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) bcur[j][u] = bn[j][u];
             }
+#pragma unroll
+            for (int i = 0; i < TA; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) af[i][u] = an[i][u];
         }
-      }
+        }
+        }
+        if (n_valid && !early) {
+            __syncthreads();                                   // everybody has left the K loop: the ring may be refilled
+            if (!(a.dbg & 512)) request(n_b, n_band, n_od, n_lo, par ^ 1);
+        }
+        c_valid = n_valid; c_wk = n_wk; c_b = n_b; c_band = n_band; c_od = n_od; c_lo = n_lo; c_hi = n_hi;
+        par ^= 1;
     }
     // ---- slab: [tap][CO][CI] for this block.  C/D of 16x16x32: column (lane & 15) = input channel, rows 4 (lane >> 4) + e = output channel
     float *dst = a.slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * a.ntaps * a.CO * a.CI;
@@ -1687,19 +1737,22 @@ WgPlan wg_plan(int B, int Do, int Ho, int Wo, int ks, int stride, int pad, int P
     // (row stride * hh + th, column stride * ww + tw) when the X rows have the SAME pitch S >= stride * (Wo - 1) + ks
     p.Sg = stride * (Wo - 1) + ks;
     p.Sx = p.Sg;
+    // plane slots of the X image: a ring of 4 when the input planes slide (3x3x3, stride 1: three in use + the next one on its way),
+    // two sets of ks otherwise (LDS-DMA double buffering, cb_wgrad_kernel); the G band is double-buffered too
+    const int nslot = (ks == 3 && stride == 1) ? 4 : 2 * ks;
     int best = 1;
     for (int th = 1; th <= Ho; ++th) {
         const int xrows = stride * (th - 1) + ks;
         const int gpos32 = (th * p.Sg + 31) & ~31;
-        const int xpos = ks * xrows * p.Sx + 2 * p.Sx + 64 + stride * 32;
-        const size_t bytes = ((size_t)gpos32 * PG + (size_t)xpos * PX) * 2;
+        const int xpos = nslot * xrows * p.Sx + 2 * p.Sx + 64 + stride * 32;
+        const size_t bytes = ((size_t)2 * gpos32 * PG + (size_t)xpos * PX) * 2;
         if (bytes <= cap || th == 1) best = th; else break;
     }
     p.TH = best;
     p.xrows = stride * (best - 1) + ks;
     p.gpos32 = (best * p.Sg + 31) & ~31;
-    p.xpos = ks * p.xrows * p.Sx + 2 * p.Sx + 64 + stride * 32;
-    p.lds = ((size_t)p.gpos32 * PG + (size_t)p.xpos * PX) * 2;
+    p.xpos = nslot * p.xrows * p.Sx + 2 * p.Sx + 64 + stride * 32;
+    p.lds = ((size_t)2 * p.gpos32 * PG + (size_t)p.xpos * PX) * 2;
     // workgroups per channel block: ~one per CU over all channel blocks.  Every workgroup writes a slab of ntaps x 48 x 48 floats
     // that the reduce kernel reads back: with 512 / ny (>= 8) workgroups the slabs of a 384 x 384 layer were 127 MB, more traffic
     // than everything else in that layer
