@@ -375,10 +375,14 @@ int hno_bmm(const float *A, const float *B, float *C, int batch, int M, int N, i
  * q, k (BZ, Ck, T); v, out, dout (BZ, Cv, T); Ck, Cv <= 128 (hno_hmha_supported).  Replaces nets/hartley_mha.py:196-201
  * (einsum 'bzcq,bzck->bzqk' / sqrt(C), attention activation -- SELU, not softmax --, einsum 'bzqk,bzck->bzcq') and its backward. */
 int hno_hmha_supported(int Ck, int Cv);
-int hno_hmha_fwd(const float *q, const float *k, const float *v, float *out, int BZ, int Ck, int Cv, int T, float alpha, int act,
-                 void *stream);
-int hno_hmha_bwd(const float *q, const float *k, const float *v, const float *dout, float *dq, float *dk, float *dv, int BZ, int Ck,
+/* workspace (hno_hmha_workspace_bytes; round 4): the streamed side is split over several workgroups that share every fetched tile
+ * among four owner waves; each split writes a partial result there and a small kernel adds them in a fixed order.  workspace = NULL
+ * (or too small) runs the round-2 kernels, which need none. */
+size_t hno_hmha_workspace_bytes(int BZ, int Ck, int Cv, int T);
+int hno_hmha_fwd(const float *q, const float *k, const float *v, float *out, void *workspace, size_t workspace_bytes, int BZ, int Ck,
                  int Cv, int T, float alpha, int act, void *stream);
+int hno_hmha_bwd(const float *q, const float *k, const float *v, const float *dout, float *dq, float *dk, float *dv, void *workspace,
+                 size_t workspace_bytes, int BZ, int Ck, int Cv, int T, float alpha, int act, void *stream);
 
 /* ------------------------------------------------------------------- elementwise helpers
  * y = act(x) ; gx = g * act'(y) (y = saved output) ; out = a + b.  Used where the reference applies an

@@ -96,8 +96,9 @@ SIGNATURES = {
     'hno_permode_bwd': (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_void_p]),
     'hno_bmm': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_float, c_void_p]),
     'hno_hmha_supported': (c_int, [c_int, c_int]),
-    'hno_hmha_fwd': (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_float, c_int, c_void_p]),
-    'hno_hmha_bwd': (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_int, c_void_p]),
+    'hno_hmha_workspace_bytes': (c_size_t, [c_int] * 4),
+    'hno_hmha_fwd': (c_int, [c_void_p] * 5 + [c_size_t] + [c_int] * 4 + [c_float, c_int, c_void_p]),
+    'hno_hmha_bwd': (c_int, [c_void_p] * 8 + [c_size_t] + [c_int] * 4 + [c_float, c_int, c_void_p]),
     'hno_act_fwd': (c_int, [c_void_p, c_void_p, c_ll, c_int, c_void_p]),
     'hno_act_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p]),
     'hno_bias_act': (c_int, [c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_void_p]),

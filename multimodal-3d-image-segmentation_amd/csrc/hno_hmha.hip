@@ -18,6 +18,9 @@
 //                                                                          dV += dOut (x) act(G);   dK += Q (x) dS
 // with dS = alpha * H * act'(G).  The 4 waves of a workgroup own the SAME 32 tokens and split the streamed range; their
 // accumulators are added in a fixed order through LDS at the end (no atomics, no workspace).
+#include <stdlib.h>
+#include <type_traits>
+
 #include "hno_common.h"
 
 namespace hno {
@@ -192,6 +195,299 @@ __global__ __launch_bounds__(256) void hmha_kernel(HmArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same products with SHARED streamed tiles and two waves per SIMD.
+//
+// hmha_kernel above gives a workgroup's 4 waves the SAME 32 owned tokens and lets each stream its own quarter of the other side
+// through a wave-private LDS tile: every wave fetches and stages whole tiles (192 loads + 192 LDS stores per 96 MFMAs), runs alone on
+// its SIMD (101 KB of LDS per workgroup) and nothing overlaps its address arithmetic and activation with its MFMAs: 45 TFLOP/s =
+// 29 % of the fp32 matrix rate (DESIGN lesson 32).  Here
+//   * the 4 waves of a workgroup own DIFFERENT 32-token tiles (128 tokens) and stream the SAME tiles, so a tile is fetched once per
+//     workgroup -- by LDS-DMA (global_load_lds_dword: no registers, no LDS store instructions), each wave a quarter of the rows,
+//     into the other half of a double buffer while the current tile is multiplied; one barrier per streamed tile;
+//   * the streamed range is split over gridDim.y workgroups (8 for the published 4 x 96 x 1960 shape: 2 048 waves = two per SIMD,
+//     25 KB of LDS per buffer): each writes a partial result, a small kernel adds the partials in a fixed order (no atomics);
+//   * LDS image of a streamed tensor: row PAIRS [c / 2][c & 1][32 tokens] + 1 pad float (one DMA instruction fills a pair); the
+//     score product reads along tokens (conflict-free), the accumulation down channels (2-way: pairs share a bank -- 4 LDS cycles
+//     per 64-cycle MFMA).
+#define HM2_PITCH 65
+#define HM2_PITCH4 36
+template <int MODE, int CKT, int CVT, bool X4>
+__global__ __launch_bounds__(256, MODE == 2 ? 1 : 2) void hmha2_kernel(HmArgs a, float *part0, float *part1) {
+    extern __shared__ float smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int bz = blockIdx.z, nsplit = gridDim.y, e = blockIdx.y;
+    const int o0 = (blockIdx.x * 4 + wave) * 32;            // this wave's owned tokens
+    const int T = a.T, Ck = a.Ck, Cv = a.Cv;
+    constexpr int CKP = 32 * CKT, CVP = 32 * CVT, NP1 = CKP / 2, NP2 = CVP / 2, NPAIR = NP1 + NP2;
+    constexpr int BUF = X4 ? (CKP + CVP) * HM2_PITCH4 : NPAIR * HM2_PITCH;      // floats per buffer
+    constexpr int T2OFF = X4 ? CKP * HM2_PITCH4 : NP1 * HM2_PITCH;              // second tensor's image
+    constexpr int TSTEP = X4 ? 2 * HM2_PITCH4 : HM2_PITCH;                      // score operand: + t TSTEP
+    constexpr int CTSTEP = X4 ? 32 * HM2_PITCH4 : 16 * HM2_PITCH;               // accumulation operand: + ct CTSTEP + s
+    const float *Q = a.q + (size_t)bz * Ck * T, *K = a.k + (size_t)bz * Ck * T;
+    const float *V = a.v + (size_t)bz * Cv * T, *dO = MODE ? a.dout + (size_t)bz * Cv * T : nullptr;
+    // both buffers to zero once: pairs beyond the channel count are never fetched (their products meet zero fragments or land in
+    // accumulator rows that are dropped, but 0 x NaN from a previous kernel's LDS contents must not happen)
+    for (int i = threadIdx.x; i < 2 * BUF; i += 256) smem[i] = 0.f;
+    const bool active = o0 < T;                              // (wave-uniform; idle waves still stage and keep the barriers)
+    const bool own_ok = o0 + r < T;
+    float f1[CKP / 2];                                      // MODE 0, 1: Q; MODE 2: K
+    float f2[MODE ? CVP / 2 : 1];                           // MODE 1: dOut; MODE 2: V
+    {
+        const float *X1 = MODE == 2 ? K : Q;
+#pragma unroll
+        for (int t = 0; t < CKP / 2; ++t) {
+            const int c = 2 * t + h;
+            f1[t] = (c < Ck && own_ok) ? X1[(size_t)c * T + o0 + r] : 0.f;
+        }
+        if constexpr (MODE != 0) {
+            const float *X2 = MODE == 2 ? V : dO;
+#pragma unroll
+            for (int t = 0; t < CVP / 2; ++t) {
+                const int c = 2 * t + h;
+                f2[t] = (c < Cv && own_ok) ? X2[(size_t)c * T + o0 + r] : 0.f;
+            }
+        }
+    }
+    constexpr int CT1 = MODE == 1 ? CKT : CVT;
+    f32x16h acc1[CT1], acc2[MODE == 2 ? CKT : 1];
+#pragma unroll
+    for (int ct = 0; ct < CT1; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc1[ct][i] = 0.f;
+    if constexpr (MODE == 2)
+#pragma unroll
+        for (int ct = 0; ct < CKT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc2[ct][i] = 0.f;
+
+    const int ntile = (T + 31) / 32;
+    // branch-free activation (as in the pointwise kernels): act(x) = (x > 0 or linear) ? ap x : aq expm1(x); SELU, ELU or none
+    const float ap = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f;
+    const float aq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
+    const bool lin = a.act == HNO_ACT_NONE;
+    const int st_lo = (int)((long long)ntile * e / nsplit), st_hi = (int)((long long)ntile * (e + 1) / nsplit);
+    const float *S1 = MODE == 2 ? Q : K, *S2 = MODE == 2 ? dO : V;
+    const unsigned smem_b = (unsigned)(size_t)smem;
+    // request tile st into buffer `buf`.
+    //  X4 (T % 4 == 0, every row 16-byte aligned): global_load_lds_dwordx4, ONE instruction = 7 rows x (8 data + 1 pad) 16-byte slots
+    //     (lane 63 off) = rows of 36 floats in LDS: 14 instructions per 96-row tensor instead of 48 (a DMA instruction costs its wave
+    //     60-180 issue cycles beside MFMAs); reads along tokens are conflict-free, reads down channels 4-way (8 banks) -- 8 LDS cycles
+    //     per 64-cycle MFMA.  Tokens beyond T re-read the row's last four (their score rows are masked below).
+    //  else: global_load_lds_dword, one instruction = a row PAIR [c / 2][c & 1][32 tokens] + 1 pad float; the odd row of a last half
+    //     pair re-reads its even row (dropped / zero-fragment rows).
+    const int l9 = lane / 9, q9 = lane - 9 * l9;
+    auto request = [&](int st, int buf) {
+        if constexpr (X4) {
+            const int tok = st * 32 + 4 * (q9 < 8 ? q9 : 7);
+            const unsigned tokoff = (unsigned)(tok + 4 <= T ? tok : T - 4) * 4u;
+            constexpr int NI1 = (CKP + 6) / 7, NI2 = (CVP + 6) / 7;
+            for (int n = wave; n < NI1 + NI2; n += 4) {
+                const bool first = n < NI1;                      // wave-uniform
+                const int n7 = 7 * (first ? n : n - NI1), c = n7 + l9, C = first ? Ck : Cv;
+                const float *base = first ? S1 : S2;
+                const unsigned off = (unsigned)(c < C ? c : 0) * (unsigned)T * 4u + tokoff;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(smem_b + (unsigned)(buf * BUF + (first ? 0 : T2OFF) + n7 * HM2_PITCH4) * 4u);
+                if (lane < 63 && c < C)
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(dst) : "memory");
+            }
+        } else {
+            const int tokc = st * 32 + r < T ? st * 32 + r : T - 1;
+            for (int j = wave; j < NPAIR; j += 4) {
+                const bool first = j < NP1;
+                const int c0 = 2 * (first ? j : j - NP1), C = first ? Ck : Cv;
+                if (c0 >= C) continue;                           // wave-uniform
+                const float *base = (first ? S1 : S2) + (size_t)c0 * T;
+                const unsigned off = (unsigned)(((c0 + 1 < C && h) ? T : 0) + tokc) * 4u;
+                dma_row_pair(base, off, __builtin_amdgcn_readfirstlane(smem_b + (unsigned)(buf * BUF + j * HM2_PITCH) * 4u));
+            }
+        }
+    };
+    __syncthreads();                                         // the zero fill is done before the first DMA lands
+    if (st_lo < st_hi) request(st_lo, 0);
+    for (int st = st_lo; st < st_hi; ++st) {
+        const int buf = (st - st_lo) & 1;
+        dma_wait<0>();                                       // this wave's pieces of tile st have landed ...
+        __syncthreads();                                     // ... everybody's have, and everybody is done with tile st - 1
+        if (st + 1 < st_hi) request(st + 1, buf ^ 1);
+        if (!active) continue;
+        const float *t1 = smem + buf * BUF, *t2 = t1 + T2OFF;
+        // score operands (+ t TSTEP): channel 2 t + h, token r;  accumulation operands (+ ct CTSTEP + s): channel 32 ct + r, token s
+        const int rowo = X4 ? h * HM2_PITCH4 + r : h * 32 + r;
+        const int colo = X4 ? r * HM2_PITCH4 : (r >> 1) * HM2_PITCH + (r & 1) * 32;
+        const float *row1 = t1 + rowo, *row2 = t2 + rowo, *col1 = t1 + colo, *col2 = t2 + colo;
+        // LDS operands are requested a chunk ahead of the MFMAs that use them (the compiler's own order was read, wait, two MFMAs,
+        // read, wait, ...: an exposed LDS round trip per pair)
+        auto score = [&](f32x16h &Gm, const float *row, const float *frag, auto nn) {
+            constexpr int N = decltype(nn)::value, CH = 8, NCH = N / CH;
+            static_assert(N % CH == 0, "whole chunks");
+            float cur[CH], nxt[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) cur[u] = row[u * TSTEP];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (c + 1 < NCH) {
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) nxt[u] = row[((c + 1) * CH + u) * TSTEP];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < CH; ++u) Gm = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[u], frag[c * CH + u], Gm, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < CH; ++u) cur[u] = nxt[u];
+            }
+        };
+        f32x16h G;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) G[i] = 0.f;
+        score(G, row1, f1, std::integral_constant<int, CKP / 2>{});
+        const int sbase = st * 32 + 4 * h;
+        f32x16h P;                                           // act(alpha G), rows of tokens beyond T zero
+        if (lin) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) P[i] = sbase + (i & 3) + 8 * (i >> 2) < T ? a.alpha * G[i] : 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const f32x2 y = selu_like_pk(f32x2{a.alpha * G[i], a.alpha * G[i + 1]}, ap, aq);
+                P[i] = sbase + (i & 3) + 8 * (i >> 2) < T ? y[0] : 0.f;
+                P[i + 1] = sbase + ((i + 1) & 3) + 8 * ((i + 1) >> 2) < T ? y[1] : 0.f;
+            }
+        }
+        auto accumulate = [&](f32x16h *acc, const float *col, const f32x16h &Pm, auto ctn) {
+            constexpr int CT = decltype(ctn)::value, IS = 2;         // chunks of IS k-steps (IS x CT operands)
+            float cur[IS][CT], nxt[IS][CT];
+            auto ld = [&](float (&d)[IS][CT], int i0) {
+#pragma unroll
+                for (int u = 0; u < IS; ++u) {
+                    const int i = i0 + u, sidx = (i & 3) + 8 * (i >> 2) + 4 * h;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) d[u][ct] = col[ct * CTSTEP + sidx];
+                }
+            };
+            ld(cur, 0);
+#pragma unroll
+            for (int i0 = 0; i0 < 16; i0 += IS) {
+                if (i0 + IS < 16) ld(nxt, i0 + IS);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < IS; ++u)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[u][ct], Pm[i0 + u], acc[ct], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < IS; ++u)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) cur[u][ct] = nxt[u][ct];
+            }
+        };
+        if constexpr (MODE == 0) {
+            accumulate(acc1, col2, P, std::integral_constant<int, CVT>{});          // out += V (x) P
+        } else {
+            f32x16h H;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) H[i] = 0.f;
+            score(H, row2, f2, std::integral_constant<int, CVP / 2>{});
+            f32x16h dS;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                // act'(x) from the output y = act(x): SELU-like: y > 0 ? ap : y + aq (branch-free; masked rows have P = 0, H finite)
+                const float gr = (lin || P[i] > 0.f) ? ap : P[i] + aq;
+                const float d = a.alpha * H[i] * gr;
+                dS[i] = sbase + (i & 3) + 8 * (i >> 2) < T ? d : 0.f;
+            }
+            if constexpr (MODE == 1) {
+                accumulate(acc1, col1, dS, std::integral_constant<int, CKT>{});     // dQ += K (x) dS^T
+            } else {
+                accumulate(acc1, col2, P, std::integral_constant<int, CVT>{});      // dV += dOut (x) P
+                accumulate(acc2, col1, dS, std::integral_constant<int, CKT>{});     // dK += Q (x) dS
+            }
+        }
+    }
+    // ---- this wave's partial tiles: register i of tile ct = channel 32 ct + (i & 3) + 8 (i >> 2) + 4 h, lane column = token o0 + r
+    if (active && own_ok) {
+        const int C1 = MODE == 1 ? Ck : Cv;
+        float *d0 = part0 + (((size_t)e * a.BZ + bz) * C1) * T + o0 + r;
+#pragma unroll
+        for (int ct = 0; ct < CT1; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = 32 * ct + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (c < C1) d0[(size_t)c * T] = acc1[ct][i];
+            }
+        if constexpr (MODE == 2) {
+            float *d1 = part1 + (((size_t)e * a.BZ + bz) * Ck) * T + o0 + r;
+#pragma unroll
+            for (int ct = 0; ct < CKT; ++ct)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int c = 32 * ct + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (c < Ck) d1[(size_t)c * T] = acc2[ct][i];
+                }
+        }
+    }
+}
+
+// out[i] = part[0][i] + part[1][i] + ... (fixed order), n floats per partial
+__global__ __launch_bounds__(256) void hm_sum_partials_kernel(const float *__restrict__ part, float *__restrict__ out, long long n, int nsplit) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float s = part[i];
+        for (int e = 1; e < nsplit; ++e) s += part[(size_t)e * n + i];
+        out[i] = s;
+    }
+}
+
+template <int MODE, int CKT, int CVT, bool X4>
+static int hm2_launch_x(const HmArgs &a, float *workspace, hipStream_t s);
+
+// stream splits so that the launch has ~2 waves per SIMD (2 048 waves) without making a split shorter than two tiles
+static int hm2_nsplit(int BZ, int T) {
+    const int nblk = (T + 127) / 128, ntile = (T + 31) / 32;
+    static const int force = getenv("HNO_HM_NSPLIT") ? atoi(getenv("HNO_HM_NSPLIT")) : 0;     // tuning aid
+    int n = (2048 + nblk * 4 * BZ - 1) / (nblk * 4 * BZ);
+    if (n > 8) n = 8;
+    if (force > 0 && force <= 16) n = force;
+    if (n > ntile / 2) n = ntile / 2;
+    return n < 1 ? 1 : n;
+}
+
+template <int MODE, int CKT, int CVT>
+static int hm2_launch(const HmArgs &a, float *workspace, hipStream_t s) {
+    if (a.T % 4 == 0 && a.T >= 4 && !(debug_flags() & 32768)) return hm2_launch_x<MODE, CKT, CVT, true>(a, workspace, s);
+    return hm2_launch_x<MODE, CKT, CVT, false>(a, workspace, s);
+}
+
+template <int MODE, int CKT, int CVT, bool X4>
+static int hm2_launch_x(const HmArgs &a, float *workspace, hipStream_t s) {
+    constexpr int NPAIR = 16 * (CKT + CVT);
+    const size_t lds = (size_t)2 * (X4 ? 32 * (CKT + CVT) * HM2_PITCH4 : NPAIR * HM2_PITCH) * sizeof(float);
+    static int attr = -1;
+    if (lds > 48 * 1024 && attr != current_device()) {
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)hmha2_kernel<MODE, CKT, CVT, X4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = current_device();
+    }
+    const int nsplit = hm2_nsplit(a.BZ, a.T);
+    const dim3 grid((a.T + 127) / 128, nsplit, a.BZ);
+    const int C1 = MODE == 1 ? a.Ck : a.Cv;
+    const long long n0 = (long long)a.BZ * C1 * a.T, n1 = (long long)a.BZ * a.Ck * a.T;
+    // one split: the partial IS the result
+    float *p0 = nsplit == 1 ? a.out0 : workspace, *p1 = nsplit == 1 ? a.out1 : workspace + (size_t)nsplit * n0;
+    hipLaunchKernelGGL((hmha2_kernel<MODE, CKT, CVT, X4>), grid, dim3(256), lds, s, a, p0, p1);
+    HNO_CHECK_LAUNCH();
+    if (nsplit > 1) {
+        const int g0 = (int)((n0 + 255) / 256 < 2048 ? (n0 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(hm_sum_partials_kernel, dim3(g0), dim3(256), 0, s, (const float *)p0, a.out0, n0, nsplit);
+        if (MODE == 2) {
+            const int g1 = (int)((n1 + 255) / 256 < 2048 ? (n1 + 255) / 256 : 2048);
+            hipLaunchKernelGGL(hm_sum_partials_kernel, dim3(g1), dim3(256), 0, s, (const float *)p1, a.out1, n1, nsplit);
+        }
+        HNO_CHECK_LAUNCH();
+    }
+    return HNO_OK;
+}
+
 template <int MODE, int CKT, int CVT>
 static int hm_launch(const HmArgs &a, hipStream_t s) {
     constexpr int CMAX = 32 * (CKT > CVT ? CKT : CVT);
@@ -208,8 +504,14 @@ static int hm_launch(const HmArgs &a, hipStream_t s) {
 }
 
 template <int MODE>
-static int hm_dispatch(const HmArgs &a, hipStream_t s) {
+static int hm_dispatch(const HmArgs &a, hipStream_t s, float *workspace = nullptr) {
     const int kt = (a.Ck + 31) / 32, vt = (a.Cv + 31) / 32;
+    if (workspace && !(debug_flags() & 16384) && (a.act == HNO_ACT_NONE || a.act == HNO_ACT_SELU || a.act == HNO_ACT_ELU)) {      // shared-tile kernels (round 4); debug flag 16384: the round-2 kernels (A/B)
+        if (kt == 1 && vt == 1) return hm2_launch<MODE, 1, 1>(a, workspace, s);
+        if (kt <= 2 && vt <= 2) return hm2_launch<MODE, 2, 2>(a, workspace, s);
+        if (kt == 3 && vt == 3) return hm2_launch<MODE, 3, 3>(a, workspace, s);
+        if (kt <= 4 && vt <= 4) return hm2_launch<MODE, 4, 4>(a, workspace, s);
+    }
     if (kt == 1 && vt == 1) return hm_launch<MODE, 1, 1>(a, s);
     if (kt == 2 && vt == 2) return hm_launch<MODE, 2, 2>(a, s);
     if (kt == 3 && vt == 3) return hm_launch<MODE, 3, 3>(a, s);
@@ -226,19 +528,28 @@ using namespace hno;
 extern "C" int hno_hmha_supported(int Ck, int Cv) { return Ck > 0 && Cv > 0 && Ck <= 128 && Cv <= 128; }
 
 // out (BZ, Cv, T) = V att^T with att = act(alpha Q^T K); q, k (BZ, Ck, T), v (BZ, Cv, T)
-extern "C" int hno_hmha_fwd(const float *q, const float *k, const float *v, float *out, int BZ, int Ck, int Cv, int T, float alpha,
-                            int act, void *stream) {
+// workspace of the shared-tile kernels: partial results of the stream splits, (forward) nsplit x BZ x Cv x T floats,
+// (backward) nsplit x BZ x (Ck + Cv) x T; NULL selects the round-2 kernels (no workspace)
+extern "C" size_t hno_hmha_workspace_bytes(int BZ, int Ck, int Cv, int T) {
+    if (BZ <= 0 || Ck <= 0 || Cv <= 0 || T <= 0) return 0;
+    return sizeof(float) * (size_t)hm2_nsplit(BZ, T) * BZ * (size_t)(Ck + Cv) * T;
+}
+
+extern "C" int hno_hmha_fwd(const float *q, const float *k, const float *v, float *out, void *workspace, size_t workspace_bytes, int BZ,
+                            int Ck, int Cv, int T, float alpha, int act, void *stream) {
+    if (workspace && workspace_bytes < hno_hmha_workspace_bytes(BZ, Ck, Cv, T)) workspace = nullptr;
     HNO_REQUIRE(q && k && v && out && BZ > 0 && Ck > 0 && Cv > 0 && T > 0, "hno_hmha_fwd: bad argument");
     HmArgs a = {};
     a.q = q; a.k = k; a.v = v; a.out0 = out; a.BZ = BZ; a.Ck = Ck; a.Cv = Cv; a.T = T; a.alpha = alpha; a.act = act;
     hipStream_t s = (hipStream_t)stream;
     ProfScope _ps(KID_HMHA, s, 2.0 * BZ * (double)T * T * (Ck + Cv));
-    return hm_dispatch<0>(a, s);
+    return hm_dispatch<0>(a, s, (float *)workspace);
 }
 
 // gradients of hno_hmha_fwd by recomputation: dq, dk (BZ, Ck, T), dv (BZ, Cv, T) from dout (BZ, Cv, T)
-extern "C" int hno_hmha_bwd(const float *q, const float *k, const float *v, const float *dout, float *dq, float *dk, float *dv, int BZ,
-                            int Ck, int Cv, int T, float alpha, int act, void *stream) {
+extern "C" int hno_hmha_bwd(const float *q, const float *k, const float *v, const float *dout, float *dq, float *dk, float *dv,
+                            void *workspace, size_t workspace_bytes, int BZ, int Ck, int Cv, int T, float alpha, int act, void *stream) {
+    if (workspace && workspace_bytes < hno_hmha_workspace_bytes(BZ, Ck, Cv, T)) workspace = nullptr;
     HNO_REQUIRE(q && k && v && dout && dq && dk && dv && BZ > 0 && Ck > 0 && Cv > 0 && T > 0, "hno_hmha_bwd: bad argument");
     HmArgs a = {};
     a.q = q; a.k = k; a.v = v; a.dout = dout; a.BZ = BZ; a.Ck = Ck; a.Cv = Cv; a.T = T; a.alpha = alpha; a.act = act;
@@ -246,11 +557,11 @@ extern "C" int hno_hmha_bwd(const float *q, const float *k, const float *v, cons
     {
         ProfScope _ps(KID_HMHA, s, 2.0 * BZ * (double)T * T * (2.0 * Ck + Cv));
         a.out0 = dq;
-        const int rc = hm_dispatch<1>(a, s);
+        const int rc = hm_dispatch<1>(a, s, (float *)workspace);
         if (rc != HNO_OK) return rc;
     }
     ProfScope _ps(KID_HMHA, s, 2.0 * BZ * (double)T * T * (2.0 * Ck + 2.0 * Cv));
     a.out0 = dv;
     a.out1 = dk;
-    return hm_dispatch<2>(a, s);
+    return hm_dispatch<2>(a, s, (float *)workspace);
 }

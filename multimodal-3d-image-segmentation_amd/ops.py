@@ -1126,7 +1126,9 @@ class HartleyAttentionFn(_HnoFunction):
         Cv = v.shape[2]
         assert k.shape == q.shape and v.shape[:2] == q.shape[:2] and v.shape[3] == T
         out = torch.empty_like(v)
-        check(_lib.lib().hno_hmha_fwd(ptr(q), ptr(k), ptr(v), ptr(out), B * Z, Ck, Cv, T, float(alpha), act, stream_ptr()), 'hno_hmha_fwd')
+        ws = torch.empty(_lib.lib().hno_hmha_workspace_bytes(B * Z, Ck, Cv, T) // 4, device=q.device, dtype=torch.float32)
+        check(_lib.lib().hno_hmha_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(ws), 4 * ws.numel(), B * Z, Ck, Cv, T, float(alpha), act,
+                                      stream_ptr()), 'hno_hmha_fwd')
         ctx.save_for_backward(q, k, v)
         ctx.cfg = (float(alpha), act)
         return out
@@ -1138,8 +1140,9 @@ class HartleyAttentionFn(_HnoFunction):
         g = _f32c(g)
         B, Z, Ck, T = q.shape
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        check(_lib.lib().hno_hmha_bwd(ptr(q), ptr(k), ptr(v), ptr(g), ptr(dq), ptr(dk), ptr(dv), B * Z, Ck, v.shape[2], T, alpha, act,
-                                      stream_ptr()), 'hno_hmha_bwd')
+        ws = torch.empty(_lib.lib().hno_hmha_workspace_bytes(B * Z, Ck, v.shape[2], T) // 4, device=q.device, dtype=torch.float32)
+        check(_lib.lib().hno_hmha_bwd(ptr(q), ptr(k), ptr(v), ptr(g), ptr(dq), ptr(dk), ptr(dv), ptr(ws), 4 * ws.numel(), B * Z, Ck,
+                                      v.shape[2], T, alpha, act, stream_ptr()), 'hno_hmha_bwd')
         return dq, dk, dv, None, None
 
 
