@@ -186,17 +186,21 @@ def dp_path_secondary(headline_ms):
     `--dp-path`), next to the headline: ms per step, the ratio, and the host time the step's launches take."""
     import subprocess
     out = {}
-    try:
-        res = subprocess.run([sys.executable, os.path.abspath(__file__), '--dp-path', '--steps', '30', '--warmup', '5', '--no-secondary',
-                              '--no-cpu-baseline', '--no-kernel-profile'], capture_output=True, text=True, timeout=600)
-        line = [ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1]
-        d = json.loads(line)
-        out['dp_path_1rank_ms_per_step'] = d['ms_per_step']
-        out['dp_path_1rank_over_headline'] = round(d['ms_per_step'] / headline_ms, 4)
-        out['dp_path_1rank_host_us_per_step'] = d['config'].get('host_us_per_step')
-        out['dp_path_1rank_launch'] = d['config'].get('launch')
-    except Exception as exc:
-        out['dp_path_1rank_ms_per_step'] = f'failed: {exc!r}'[:200]
+    # two forms: the default (replay + one eager flat all-reduce + one eager Adamax launch) and, round 4, the whole step as ONE graph
+    # replay (HNO_DP_CAPTURE_ALLREDUCE=1: the collective and the device-stepped Adamax are nodes of the graph)
+    for key, env in (('dp_path_1rank', {}), ('dp_path_1rank_one_replay', {'HNO_DP_CAPTURE_ALLREDUCE': '1'})):
+        try:
+            res = subprocess.run([sys.executable, os.path.abspath(__file__), '--dp-path', '--steps', '30', '--warmup', '5', '--no-secondary',
+                                  '--no-cpu-baseline', '--no-kernel-profile'], capture_output=True, text=True, timeout=600,
+                                 env=dict(os.environ, **env))
+            line = [ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1]
+            d = json.loads(line)
+            out[f'{key}_ms_per_step'] = d['ms_per_step']
+            out[f'{key}_over_headline'] = round(d['ms_per_step'] / headline_ms, 4)
+            out[f'{key}_host_us_per_step'] = d['config'].get('host_us_per_step')
+            out[f'{key}_launch'] = d['config'].get('launch')
+        except Exception as exc:
+            out[f'{key}_ms_per_step'] = f'failed: {exc!r}'[:200]
     return out
 
 
@@ -288,6 +292,10 @@ def main():
     # HNO_DP_CAPTURE_ALLREDUCE=1: also capture the gradient all-reduce into the graph (measured on one rank only; the default keeps it an
     # eager launch behind the replay because a capture of RCCL collectives across several GPUs could not be tested from here)
     capture_allreduce = distributed and os.environ.get('HNO_DP_CAPTURE_ALLREDUCE', '0') == '1'
+    # round 4: Adamax with its step counter / learning rate on the device (optim.Adamax.device_stepped): the update has no per-step host
+    # argument and is captured behind backward -- a step is ONE graph replay.  With replicas it has to follow the all-reduce, so it is
+    # part of the graph only when the collective is (HNO_DP_CAPTURE_ALLREDUCE=1); otherwise it stays one eager launch behind it.
+    opt_in_graph = os.environ.get('HNO_BENCH_OPT_IN_GRAPH', '1') == '1' and opt.device_stepped(None) and (not distributed or capture_allreduce)
     if not args.no_graph:
         try:
             torch.cuda.synchronize()
@@ -304,6 +312,8 @@ def main():
                         rep.finish_capture()
                         if capture_allreduce:      # the collective becomes a node of the graph (RCCL kernels are capturable)
                             rep.allreduce_flat()
+                    if opt_in_graph:
+                        opt.step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
         except Exception as exc:   # capture unsupported on this stack: run eagerly and say so
@@ -322,7 +332,8 @@ def main():
         graph.replay()
         if distributed and not capture_allreduce:
             rep.allreduce_flat()
-        opt.step()
+        if not opt_in_graph:
+            opt.step()
         host_s[0] += time.perf_counter() - t_h
         return static_loss
 
@@ -389,7 +400,7 @@ def main():
                                    "synthetic 4-modal 128^3 fp32, step = fwd + PCC loss + bwd + grad all-reduce + Adamax",
                        'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
                        'launch': ('hip-graph replay (fwd+loss+bwd)' + ((' + one flat gradient all-reduce ' + ('inside the graph' if capture_allreduce else 'behind the replay')) if distributed else '')
-                                  + ' + eager Adamax') if graph is not None else
+                                  + (' + Adamax inside the graph (device-side step counter): one replay per step' if opt_in_graph else ' + eager Adamax')) if graph is not None else
                                  ('eager; gradient buckets all-reduced from backward hooks on a comm stream' if distributed else 'eager'),
                        'grad_buckets': len(rep.buckets) if distributed else 0,
                        'dp_path_on_one_rank': bool(args.dp_path and world == 1),

@@ -436,6 +436,14 @@ int hno_labels_prepare(const float *labels_f32, const int *remap_from, const int
 int hno_adamax_chunk_rows(void);
 int hno_adamax_multi(const void *table, int n_chunks, float lr, float beta1, float beta2, float eps,
                      float weight_decay, long long step, float grad_scale, void *stream);
+/* Device-stepped form (round 4): step counter, learning-rate schedule and bias correction live in `state`, a DEVICE array of
+ * hno_adamax_state_doubles() (= 9) doubles { step, lr of the next update, base_lr, eta_min, T_cur, T_i, T_mult, schedule (0 constant,
+ * 1 CosineAnnealingWarmRestarts stepped per optimizer step: experiments/run.py:92-103, train_test.py:173-174), clr (scratch) }.
+ * A one-thread kernel advances the state, then the update runs with lr / (1 - beta1^step) read from it: no host value changes from
+ * step to step, so the call can be captured into the training step's HIP graph (one graph replay per step and rank). */
+int hno_adamax_state_doubles(void);
+int hno_adamax_multi_dev(const void *table, int n_chunks, void *state, float beta1, float beta2, float eps, float weight_decay,
+                         float grad_scale, void *stream);
 
 /* ------------------------------------------------------------------ input pipeline
  * hno_zscore_modalities: x, out (C, V): per modality c, v = clip(x) if has_clip; statistics over v != mask_val if

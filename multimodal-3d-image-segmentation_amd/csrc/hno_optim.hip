@@ -34,9 +34,66 @@ __global__ __launch_bounds__(256) void adamax_multi_kernel(const AdamaxChunk *__
     }
 }
 
+// ---- device-stepped form (round 4): the step counter, the learning-rate schedule and the bias correction live in a small device
+// state, so the launch has NO per-step host argument and the update can be captured into the training step's HIP graph (a rank's
+// whole step is then one graph replay).  state (doubles; integers are exact):
+//   [0] step (optimizer steps taken)   [1] lr (of the NEXT update)   [2] base_lr   [3] eta_min   [4] T_cur   [5] T_i   [6] T_mult
+//   [7] schedule: 0 = constant lr, 1 = CosineAnnealingWarmRestarts stepped once per optimizer step (experiments/run.py:92-103,
+//       train_test.py:173-174)          [8] clr = lr / (1 - beta1^step) of the CURRENT update (written by the tick kernel)
+// tick (one thread, in front of the update): step += 1; clr from the current lr; then the scheduler's step() for the next update, as
+// torch.optim.lr_scheduler.CosineAnnealingWarmRestarts.step() does it: T_cur += 1; if T_cur >= T_i: T_cur -= T_i, T_i *= T_mult;
+// lr = eta_min + (base_lr - eta_min) (1 + cos(pi T_cur / T_i)) / 2, all in double.
+__global__ void adamax_tick_kernel(double *st, double beta1) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double step = st[0] + 1.0;
+    st[0] = step;
+    st[8] = (double)(float)st[1] / (1.0 - pow(beta1, step));      // (the eager entry point takes lr as a float: same rounding)
+    if (st[7] == 1.0) {
+        double T_cur = st[4] + 1.0, T_i = st[5];
+        if (T_cur >= T_i) {
+            T_cur -= T_i;
+            T_i *= st[6];
+        }
+        st[4] = T_cur;
+        st[5] = T_i;
+        st[1] = st[3] + (st[2] - st[3]) * (1.0 + cos(M_PI * T_cur / T_i)) / 2.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void adamax_multi_dev_kernel(const AdamaxChunk *__restrict__ table, const double *__restrict__ st, float beta1,
+                                                               float beta2, float eps, float wd, float gscale) {
+    const AdamaxChunk c = table[blockIdx.x];
+    const float clr = (float)st[8];
+    for (int i = threadIdx.x; i < c.n; i += 256) {
+        const float p = c.p[i];
+        const float g = fmaf(wd, p, c.g[i] * gscale);
+        float m = c.m[i];
+        m = fmaf(1.f - beta1, g - m, m);
+        const float u = fmaxf(beta2 * c.u[i], fabsf(g) + eps);
+        c.m[i] = m;
+        c.u[i] = u;
+        c.p[i] = p - clr * (m / u);
+    }
+}
+
 }  // namespace hno
 
 using namespace hno;
+
+extern "C" int hno_adamax_state_doubles(void) { return 9; }
+
+// one Adamax step driven by the device state (see above); capturable: no host value changes from step to step
+extern "C" int hno_adamax_multi_dev(const void *table, int n_chunks, void *state, float beta1, float beta2, float eps, float weight_decay,
+                                    float grad_scale, void *stream) {
+    HNO_REQUIRE(table && n_chunks > 0 && state, "hno_adamax_multi_dev: bad argument");
+    HNO_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "hno_adamax_multi_dev: bad hyper-parameter");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adamax_tick_kernel, dim3(1), dim3(64), 0, s, (double *)state, (double)beta1);
+    hipLaunchKernelGGL(adamax_multi_dev_kernel, dim3(n_chunks), dim3(256), 0, s, (const AdamaxChunk *)table, (const double *)state, beta1, beta2,
+                       eps, weight_decay, grad_scale);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
 
 extern "C" int hno_adamax_chunk_rows(void) { return (int)(sizeof(AdamaxChunk) / sizeof(long long)); }
 

@@ -32,9 +32,19 @@ class CapturedStep:
     an epoch then simply runs eagerly).  After a replay every parameter's ``.grad`` is the buffer the graph wrote, whatever eager
     steps did in between.  Not used with autocast (GradScaler's inf checks synchronise) or on CPU tensors."""
 
-    def __init__(self, model, loss_fn, num_labels, label_mapping=None, data_parallel=None, max_shapes=2):
+    def __init__(self, model, loss_fn, num_labels, label_mapping=None, data_parallel=None, max_shapes=2, optimizer=None):
+        """optimizer: a device-stepped optim.Adamax (``optimizer.device_stepped(scheduler)``): its update (and the scheduler's step)
+        is captured behind backward -- and behind the gradient all-reduce, which is then captured too -- so a step of a rank is ONE
+        graph replay; ``steps_optimizer`` tells the caller not to step again."""
         self.model, self.loss_fn, self.num_labels, self.label_mapping = model, loss_fn, num_labels, label_mapping
         self.dp, self.max_shapes = data_parallel, max_shapes
+        self.optimizer = optimizer if (optimizer is not None and getattr(optimizer, 'is_device_stepped', False)) else None
+        # the optimizer can only follow the all-reduce: with replicas the collective has to be part of the graph as well
+        self.capture_allreduce = data_parallel is not None and (self.optimizer is not None
+                                                                 or os.environ.get('HNO_DP_CAPTURE_ALLREDUCE', '0') == '1')
+        if data_parallel is not None and os.environ.get('HNO_DP_CAPTURE_ALLREDUCE', '') == '0':
+            self.capture_allreduce, self.optimizer = False, None
+        self.steps_optimizer = self.optimizer is not None
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.entries, self.seen, self.failed = {}, {}, set()
         self.copy_stream, self.staged = None, None
@@ -63,6 +73,10 @@ class CapturedStep:
                     ops.backward_from(loss)
                     if self.dp is not None:
                         self.dp.finish_capture()
+                        if self.capture_allreduce:
+                            self.dp.allreduce_flat()
+                    if self.optimizer is not None:
+                        self.optimizer.step()
             cur.wait_stream(side)
             torch.cuda.synchronize()
         except Exception as exc:        # capture not possible for this model / shape: stay eager
@@ -144,7 +158,7 @@ class CapturedStep:
         graph.replay()
         for p, g in zip(self.params, grads):
             p.grad = g
-        if self.dp is not None:
+        if self.dp is not None and not self.capture_allreduce:
             self.dp.allreduce_flat()
         return loss
 
@@ -242,7 +256,12 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
         use_graph = os.environ.get('HNO_TRAIN_GRAPH', '1') != '0' and isinstance(model, (HNOSegXS, NeuralOperatorSeg, HartleyMHASeg, VNetDS))
     captured = None
     if use_graph and not use_autocast and next(model.parameters()).is_cuda:
-        captured = CapturedStep(model, loss_fn, num_labels, label_mapping, data_parallel if world > 1 else None)
+        # our Adamax moves its step counter, the learning rate and the per-batch cosine schedule onto the device, so that the update
+        # is part of the captured step (HNO_TRAIN_GRAPH_OPT=0: keep optimizer and scheduler eager behind the replay)
+        if os.environ.get('HNO_TRAIN_GRAPH_OPT', '1') != '0' and hasattr(optimizer, 'device_stepped'):
+            optimizer.device_stepped(scheduler)
+        captured = CapturedStep(model, loss_fn, num_labels, label_mapping, data_parallel if world > 1 else None, optimizer=optimizer)
+    dev_opt = getattr(optimizer, 'is_device_stepped', False)      # the tick kernel advances the schedule: no scheduler.step()
 
     for epoch in range(start_epoch, num_epochs):
         model.train()
@@ -256,8 +275,9 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
                 if loss is not None:          # forward + loss + backward replayed; gradients (reduced over ranks) are in place
                     step_stats['replayed'] += 1
                     losses.append(loss.detach().clone())
-                    optimizer.step()
-                    if scheduler is not None:
+                    if not captured.steps_optimizer:
+                        optimizer.step()
+                    if scheduler is not None and not dev_opt:
                         scheduler.step()
                     nxt = next(flow_it, None)       # the host prepares the next batch and starts its PCIe copy while the GPU works
                     if nxt is not None:
@@ -285,13 +305,15 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
                 if data_parallel is not None:
                     data_parallel.allreduce_grads()
                 optimizer.step()
-            if scheduler is not None:
+            if scheduler is not None and not dev_opt:
                 scheduler.step()
             # no reference to this step's autograd graph survives the iteration: a live loss tensor keeps the AccumulateGrad nodes
             # of the eager step alive, and a capture that follows then dies inside hipStreamEndCapture (DESIGN lesson 22)
             y_pred = loss = None
             nxt = next(flow_it, None)
         train_loss = mean_loss(losses)
+        if dev_opt:
+            optimizer.sync_from_device()       # step counters, lr and the scheduler's position back on the host objects
         log('', '-------------------------', f'Epoch: {epoch}', f'train_loss: {train_loss}')
 
         model.eval()

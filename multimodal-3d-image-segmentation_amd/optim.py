@@ -31,6 +31,79 @@ class Adamax(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_scale = float(grad_scale)   # e.g. 1 / world after a SUM all-reduce
         self._tables = {}                     # pointer signature -> (device table, rows)
+        self._dev = None                      # device-stepped mode: (state tensor, scheduler or None)
+
+    # ---- device-stepped mode: the whole update is capturable into a HIP graph ------------------------------------------------
+    def device_stepped(self, scheduler=None):
+        """Move the step counter, the learning rate and (optionally) a per-step ``CosineAnnealingWarmRestarts`` schedule (the
+        reference's: experiments/run.py:92-103, stepped per batch by train_test.py:173-174) into a 9-double device state.  From now on
+        ``step()`` launches hno_adamax_multi_dev: no host value changes from step to step, so the update can sit inside the captured
+        training step (``CapturedStep``) and a rank's whole step is one graph replay.  Callers then do NOT call ``scheduler.step()``
+        (the tick kernel advances the schedule); ``sync_from_device()`` -- called by ``state_dict()`` -- writes the counters, the
+        learning rate and the scheduler's T_cur / T_i / last_epoch back to the host objects, so checkpoints keep torch's layout.
+        -> True if the mode was entered (one parameter group, one common step count, supported scheduler)."""
+        if self._dev is not None:
+            return True
+        if len(self.param_groups) != 1:
+            return False
+        group = self.param_groups[0]
+        params = [p for p in group['params']]
+        if not params or not all(p.is_cuda for p in params):
+            return False
+        steps = {float(self.state[p]['step']) for p in params if len(self.state[p])}
+        if len(steps) > 1:
+            return False
+        step = steps.pop() if steps else 0.0
+        st = [step, float(group['lr']), float(group['lr']), 0.0, 0.0, 1.0, 1.0, 0.0, 0.0]
+        if scheduler is not None:
+            from torch.optim.lr_scheduler import CosineAnnealingWarmRestarts
+            if type(scheduler) is not CosineAnnealingWarmRestarts or scheduler.optimizer is not self or len(scheduler.base_lrs) != 1:
+                return False
+            st[2], st[3] = float(scheduler.base_lrs[0]), float(scheduler.eta_min)
+            st[4], st[5], st[6], st[7] = float(scheduler.T_cur), float(scheduler.T_i), float(scheduler.T_mult), 1.0
+        assert _lib.lib().hno_adamax_state_doubles() == len(st)
+        self._dev = (torch.tensor(st, dtype=torch.float64, device=params[0].device), scheduler)
+        # scheduler.last_epoch counts its step() calls; it normally equals the optimizer's step count (both stepped once per batch)
+        self._sched_offset = int(scheduler.last_epoch) - int(step) if scheduler is not None else 0
+        self._reserve_tables()
+        return True
+
+    @property
+    def is_device_stepped(self):
+        return self._dev is not None
+
+    def sync_from_device(self):
+        """device state -> host objects (one small device-to-host copy): per-parameter ``step`` counters, the group's ``lr`` and the
+        scheduler's position, exactly what the eager optimizer + scheduler.step() sequence would hold after the same number of steps."""
+        if self._dev is None:
+            return
+        state, sched = self._dev
+        v = state.cpu().tolist()
+        group = self.param_groups[0]
+        for p in group['params']:
+            if len(self.state[p]):
+                self.state[p]['step'] = torch.tensor(float(v[0]), dtype=torch.float32)
+        group['lr'] = v[1]
+        if sched is not None:
+            sched.T_cur, sched.T_i = (int(v[4]) if float(v[4]).is_integer() else v[4]), int(v[5])
+            sched._last_lr = [v[1]]
+            # last_epoch counts scheduler.step() calls (one per optimizer step since the scheduler was created at step 0)
+            sched.last_epoch = int(v[0]) + self._sched_offset
+
+    def leave_device_stepped(self):
+        self.sync_from_device()
+        self._dev = None
+
+    def state_dict(self):
+        self.sync_from_device()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        was = self._dev
+        self._dev = None
+        super().load_state_dict(state_dict)
+        if was is not None:          # re-enter the mode on the loaded counters (the caller reloads the scheduler first)
+            self.device_stepped(was[1])
 
     def _init_state(self, group):
         """exp_avg / exp_inf of a group live in two flat buffers (views per parameter)."""
@@ -59,11 +132,33 @@ class Adamax(torch.optim.Optimizer):
                 rows.append([p.data_ptr() + 4 * off, g.data_ptr() + 4 * off, m.data_ptr() + 4 * off, u.data_ptr() + 4 * off,
                              min(_CHUNK, n - off)])
         assert _lib.lib().hno_adamax_chunk_rows() == 5
-        table = torch.tensor(rows, dtype=torch.int64).to(tensors[0][0].device)
-        if len(self._tables) > 8:
+        dev = tensors[0][0].device
+        if torch.cuda.is_current_stream_capturing():
+            # inside a HIP-graph capture nothing may be allocated or pinned: take a (pinned host, device) buffer pair set aside by
+            # device_stepped(); the copy becomes a node of the graph that re-reads the pinned rows at every replay, so a pair is
+            # written once and never reused
+            pool = getattr(self, '_table_pool', [])
+            if not pool or pool[-1][0].shape[0] < len(rows):
+                raise _lib.HnoError('optim.Adamax: no pre-allocated table left for a captured step (run this batch shape eagerly)')
+            host, table = pool.pop()
+            host[:len(rows)] = torch.tensor(rows, dtype=torch.int64)
+            table.copy_(host, non_blocking=True)
+            self._table_keep = getattr(self, '_table_keep', []) + [host]
+        else:
+            table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        if len(self._tables) > 8 and not torch.cuda.is_current_stream_capturing():
             self._tables.clear()
         self._tables[key] = (table, len(rows))
         return self._tables[key]
+
+    def _reserve_tables(self, count=4):
+        """(pinned host, device) buffer pairs for chunk tables built inside graph captures (gradient addresses of a captured step are
+        only known while it is being captured)"""
+        params = self.param_groups[0]['params']
+        nrows = sum(-(-p.numel() // _CHUNK) for p in params)
+        dev = params[0].device
+        self._table_pool = [(torch.zeros((nrows, 5), dtype=torch.int64).pin_memory(), torch.zeros((nrows, 5), dtype=torch.int64, device=dev))
+                            for _ in range(count)]
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -85,6 +180,9 @@ class Adamax(torch.optim.Optimizer):
                     raise _lib.HnoError('the fused Adamax needs contiguous fp32 parameters and gradients on the GPU '
                                         '(there is no CPU fallback)')
                 st = self.state[p]
+                if self._dev is not None:
+                    by_step.setdefault(0, []).append((p, p.grad, st['exp_avg'], st['exp_inf']))
+                    continue
                 for k in ('exp_avg', 'exp_inf'):   # e.g. after load_state_dict from a CPU checkpoint
                     if st[k].device != p.device or st[k].dtype != torch.float32 or not st[k].is_contiguous():
                         st[k] = st[k].to(device=p.device, dtype=torch.float32).contiguous()
@@ -97,6 +195,11 @@ class Adamax(torch.optim.Optimizer):
             beta1, beta2 = group['betas']
             for t, tensors in by_step.items():
                 table, nrows = self._table(tensors)
+                if self._dev is not None:
+                    check(L.hno_adamax_multi_dev(table.data_ptr(), nrows, self._dev[0].data_ptr(), float(beta1), float(beta2),
+                                                 float(group['eps']), float(group['weight_decay']), self.grad_scale, stream_ptr()),
+                          'hno_adamax_multi_dev')
+                    continue
                 check(L.hno_adamax_multi(table.data_ptr(), nrows, float(group['lr']), float(beta1), float(beta2),
                                          float(group['eps']), float(group['weight_decay']), t, self.grad_scale,
                                          stream_ptr()), 'hno_adamax_multi')

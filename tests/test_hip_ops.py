@@ -1727,6 +1727,41 @@ for i in range(3):
     for p, want in zip(model.parameters(), ref2):
         assert lo <= p.grad.data_ptr() < hi
         assert float((p.grad - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-12
+# ---- round 4: the whole step of a rank as ONE graph replay: forward + loss + backward + flat RCCL all-reduce + device-stepped Adamax
+#      (step counter, learning rate and cosine schedule on the device) captured together; against the eager optimizer + scheduler
+import copy
+from multimodal_3d_image_segmentation_amd import optim as hopt
+from torch.optim.lr_scheduler import CosineAnnealingWarmRestarts
+w0 = copy.deepcopy(model.state_dict())
+def run(captured):
+    model.load_state_dict(w0)
+    for p in model.parameters():
+        p.grad = None
+    opt = hopt.Adamax(model.parameters(), lr=5e-3)
+    sched = CosineAnnealingWarmRestarts(opt, T_0=7, eta_min=1e-3)
+    cap2 = None
+    if captured:
+        assert opt.device_stepped(sched)
+        cap2 = CapturedStep(model, loss_fn, 3, None, rep, optimizer=opt)
+        assert cap2.steps_optimizer and cap2.capture_allreduce
+    for i in range(9):                               # 9 steps over a restart of the schedule (T_0 = 7)
+        l = cap2.step(xh, labf) if captured else None
+        if l is None:                                # eager step (always for the reference run; first occurrence of the shape else)
+            rep.zero_grad()
+            loss_fn(model(x), ops.labels_prepare(labf.cuda(), 3)).backward()
+            rep.allreduce_grads()
+            opt.step()
+            if not captured:
+                sched.step()
+    torch.cuda.synchronize()
+    sd = opt.state_dict()
+    return [p.detach().clone() for p in model.parameters()], opt.param_groups[0]['lr'], sched.state_dict(), float(sd['state'][0]['step'])
+pe, lre, sde, ste = run(False)
+pc, lrc, sdc, stc = run(True)
+assert ste == stc == 9.0 and abs(lre - lrc) < 1e-15, (ste, stc, lre, lrc)
+assert all(sde[k] == sdc[k] for k in ('T_cur', 'T_i', 'last_epoch')), (sde, sdc)
+for a, b in zip(pc, pe):
+    assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-9
 rep.close()
 dist.destroy_process_group()
 print('ok nccl1')
