@@ -53,8 +53,13 @@ __device__ __forceinline__ int mid_chan(int ks, int h) { return (ks & 3) + 8 * (
 // matrix-core work.  Twiddles are the A operands (registers, loaded once in lane order).
 //   forward : rows k0 = 0..15, K = n (folded: f[n] = v[n] + v[N0 - n] against cos, d[n] = v[n] - v[N0 - n] against sin), 9 k-steps
 //   inverse : rows n = 1 + 16 mt + i, K = k0 (3 k-steps); n = 0 is the plain sum of the cosine coefficients
+// waves per workgroup of the Hartley kernel.  Round 3 ran 8: the 12 column tiles of the two D steps then took two passes on four of the
+// waves (phase 1 ended when the two-tile waves did).  12 waves = one tile each, three waves per SIMD; one workgroup per CU either way
+// (232 workgroups at the benchmark size).
+#define MID_NW 12
 template <int N0, int M0, bool BWD>
-__global__ __launch_bounds__(512, BWD ? 1 : 2) void spec_mid_kernel(MidArgs a) {
+__global__ __launch_bounds__(64 * MID_NW, 1) void spec_mid_kernel(MidArgs a) {
+    constexpr int NW = MID_NW, NTH = 64 * NW;          // waves per workgroup: one D-step column tile per wave (NCT = 12)
     constexpr int C = 24, NK = 12, J = N0 / 2, K0 = M0 + 1;
     constexpr int KC = (J + 1 + 3) / 4;               // k-steps of the forward D step (n = 0 .. 4 KC - 1)
     constexpr int KI = (K0 + 3) / 4;                   // k-steps of the inverse D step (k0 = 0 .. 4 KI - 1)
@@ -66,9 +71,11 @@ __global__ __launch_bounds__(512, BWD ? 1 : 2) void spec_mid_kernel(MidArgs a) {
     constexpr int NPQ = C * 2 * 2 * K0 * 4, NZL = C * NT * 32;
     constexpr int GLD = 34;                            // row stride of the G / Z tiles: == 2 (mod 4), conflict-free 16x16x4 operand reads
     constexpr int TILE = 2 * 32 * GLD;                 // backward: [o][mode] and [i][mode] tiles of one wave
+    constexpr int WLD = 25, NWL = 4 * 32 * WLD;        // layer weights in LDS: [l][row 32][25] (odd pitch: conflict-free both ways)
     extern __shared__ float lds[];
-    float *PQ = lds;                                   // [c][part][P | Q][k0][column]
-    float *ZL = lds + NPQ;                             // [c][mode]: output of the last layer (backward: gradient of the first layer's input)
+    float *WL = lds;                                   // W'_l = W_l + residual identity, rows >= C zero
+    float *PQ = lds + NWL;                             // [c][part][P | Q][k0][column]
+    float *ZL = PQ + NPQ;                              // [c][mode]: output of the last layer (backward: gradient of the first layer's input)
     float *GZ = ZL + NZL;                              // backward: NT tiles
     float *MINE = GZ + NT * TILE;                      // backward: per-wave weight-gradient fragments [wave][l][o][i]
     if (a.dbg & 16) return;
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(512, BWD ? 1 : 2) void spec_mid_kernel(MidArgs a) {
     const int b = gidx / pairs, k1s = 2 * (gidx - b * pairs) + (w8 >> 2), kt2 = w8 & 3;
     if (b >= a.B || k1s >= K1S) {
         if (BWD)
-            for (int i = tid; i < a.L * C * C; i += 512) a.partials[(size_t)blockIdx.x * (a.L * C * C) + i] = 0.f;
+            for (int i = tid; i < a.L * C * C; i += NTH) a.partials[(size_t)blockIdx.x * (a.L * C * C) + i] = 0.f;
         return;
     }
     const int k1 = k1s - m1;
@@ -108,46 +115,34 @@ __global__ __launch_bounds__(512, BWD ? 1 : 2) void spec_mid_kernel(MidArgs a) {
                 tsI[mt][ks] = tb[(2 * KC + (mt * 2 + 1) * KI + ks) * 64];
             }
     }
-    // ---------------- layer weights as the A operand of the 32x32x2 MFMA: lane (row cl, k-slot half h) holds W'[cl][chan(ks, h)].
-    // Rows >= C of the 32-row tile are zero: they LOAD row 0 and select it away -- a load under a lane condition compiles to a branch
-    // with its own vmcnt(0), i.e. twelve dependent L2 round trips per layer (3 us per layer, seen in the ISA).  The first layer's
-    // weights are requested here, ahead of the forward D step.
+    // ---------------- layer weights as the A operand of the 32x32x2 MFMA: lane (row cl, k-slot half h) holds W'[cl][chan(ks, h)]
+    // (backward: the transpose, W'[chan(ks, h)][cl]).  Round 4: all layers' weights go to LDS once, at the top, by every wave together,
+    // as W' = W + residual identity with rows >= C zero.  Round 3 fetched a layer's weights from global memory one layer ahead -- and
+    // the compiler's wait for them (vmcnt counts loads AND stores, in order) also waited for the twelve scattered stores of the layer
+    // output issued in between: ~1 600 cycles of exposed store latency per layer (in-kernel stamps; 3 of the forward's 21 us).  LDS
+    // reads are counted separately (lgkmcnt), so the stores now leave and nobody waits for them.
     const int h = lane >> 5, cl = lane & 31;
-    const bool wrow = cl < C;
-    const unsigned wl = (unsigned)(wrow ? cl : 0) * C + 4 * h;
-    const int dsel = cl - 4 * h;
-    const float res = a.residual ? 1.f : 0.f;
-    auto load_w_raw = [&](const float *Wp, float (&w)[NK]) {
-#pragma unroll
-        for (int ks = 0; ks < NK; ++ks) w[ks] = Wp[wl + (ks & 3) + 8 * (ks >> 2)];
-    };
-    auto fin_w = [&](const float (&raw)[NK], float (&w)[NK]) {
+    // forward: W'[cl][chan(ks, h)];  backward: W'[chan(ks, h)][cl] (cl >= C: rows of zeros above -> read column cl of a zero... see below)
+    auto read_w = [&](int l, float (&w)[NK]) {
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
-            const int row = (ks & 3) + 8 * (ks >> 2);
-            w[ks] = wrow ? raw[ks] + ((dsel == row) ? res : 0.f) : 0.f;
+            const int ch = mid_chan(ks, h);
+            if (BWD) {
+                const float v = WL[(l * 32 + ch) * WLD + (cl < C ? cl : 0)];
+                w[ks] = cl < C ? v : 0.f;
+            } else {
+                w[ks] = WL[(l * 32 + cl) * WLD + ch];
+            }
         }
     };
-    // backward: A operand of g <- W'^T g: lane (row cl = input channel, k-slot half h) holds W'[chan(ks, h)][cl]
-    const unsigned wlt = 4u * h * C + (unsigned)(wrow ? cl : 0);
-    auto load_wt_raw = [&](const float *Wp, float (&w)[NK]) {
-#pragma unroll
-        for (int ks = 0; ks < NK; ++ks) w[ks] = Wp[wlt + ((ks & 3) + 8 * (ks >> 2)) * C];
-    };
-    auto wsel = [&](int l) -> const float * { return l == 0 ? a.W[0] : (l == 1 ? a.W[1] : (l == 2 ? a.W[2] : a.W[3])); };
-    float wraw[NK];
-    if (wave < NT) {
-        if (BWD) load_wt_raw(wsel(a.L - 1), wraw);
-        else load_w_raw(a.W[0], wraw);
-    }
     // ---------------- phase 1: forward D step.  A wave owns the column tiles wave and wave + 8; the loads of BOTH are issued before the
     //                  first product (one memory round trip per wave instead of two: the columns come from another XCD's writes)
     {
-        constexpr int TPW = (NCT + 7) / 8;
+        constexpr int TPW = (NCT + NW - 1) / NW;
         float va[TPW][KC], vb[TPW][KC];
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
-            const int t = wave + 8 * u;
+            const int t = wave + NW * u;
             const int c = 2 * (t < NCT ? t : 0) + cloc;
             const float *src = a.ws + ((size_t)(b * C + c) * N0) * pstride + (size_t)part * CP + k1s * 16 + kt2 * 4 + j;
 #pragma unroll
@@ -158,9 +153,34 @@ __global__ __launch_bounds__(512, BWD ? 1 : 2) void spec_mid_kernel(MidArgs a) {
                 vb[u][ks] = (a.dbg & 8) ? 1.f : src[(size_t)(mir ? N0 - n : 0) * pstride];
             }
         }
+        // (the weights' trip to LDS rides behind the column loads just issued: one round trip, not two)
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            // all of a thread's (<= 6) weight elements are requested before the first one is stored (a load followed by its LDS
+            // store is one exposed round trip per element)
+            const float res = a.residual ? 1.f : 0.f;
+            constexpr int NWE = (4 * 32 * C + NTH - 1) / NTH;
+            float wv[NWE];
+            const int nwl = a.L * 32 * C;
+#pragma unroll
+            for (int e = 0; e < NWE; ++e) {
+                const int i = tid + NTH * e;
+                const int l = i / (32 * C), rem = i - l * (32 * C), row = rem / C, col = rem - row * C;
+                const int ls = i < nwl ? l : 0;          // (elements beyond the last layer read W[0][0]: a.W[l >= L] is NULL)
+                const float *Wp = ls == 0 ? a.W[0] : (ls == 1 ? a.W[1] : (ls == 2 ? a.W[2] : a.W[3]));
+                wv[e] = Wp[i < nwl ? (row < C ? row : 0) * C + col : 0];
+            }
+#pragma unroll
+            for (int e = 0; e < NWE; ++e) {
+                const int i = tid + NTH * e;
+                const int l = i / (32 * C), rem = i - l * (32 * C), row = rem / C, col = rem - row * C;
+                if (i < nwl) WL[(l * 32 + row) * WLD + col] = row < C ? wv[e] + (row == col ? res : 0.f) : 0.f;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
-            const int t = wave + 8 * u;
+            const int t = wave + NW * u;
             if (t >= NCT) break;
             const int c = 2 * t + cloc;
             f32x4 P = {0.f, 0.f, 0.f, 0.f}, Q = P;
@@ -220,7 +240,7 @@ __global__ __launch_bounds__(512, BWD ? 1 : 2) void spec_mid_kernel(MidArgs a) {
         const float aq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
         const bool lin = a.act == HNO_ACT_NONE;
         float w[NK];
-        fin_w(wraw, w);      // (residual identity on the diagonal, zero rows >= C: the same for W' and W'^T)
+        read_w(BWD ? a.L - 1 : 0, w);      // (written before the barrier behind phase 1)
         if (BWD) {
             // ---- backward of the layer stack on this wave's 32 modes; z holds the incoming gradient (the cropped spectrum of g_u).
             // Saved activations come from zs (z_0 .. z_L; loads unconditional at offset 0 for unkept positions and selected away),
@@ -240,11 +260,8 @@ __global__ __launch_bounds__(512, BWD ? 1 : 2) void spec_mid_kernel(MidArgs a) {
             HNO_STAMP(a.stamps, 3);
 #pragma unroll 1
             for (int l = ((a.dbg & 2) ? -1 : a.L - 1); l >= 0; --l) {
-                float zn[NK], nraw[NK];
-                if (l > 0) {
-                    load_z(ob + (size_t)(l - 1) * layer, zn);
-                    load_wt_raw(wsel(l - 1), nraw);
-                }
+                float zn[NK];
+                if (l > 0) load_z(ob + (size_t)(l - 1) * layer, zn);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < NK; ++ks) {
@@ -298,7 +315,7 @@ __global__ __launch_bounds__(512, BWD ? 1 : 2) void spec_mid_kernel(MidArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (l > 0) {
-                    fin_w(nraw, w);
+                    read_w(l - 1, w);
 #pragma unroll
                     for (int ks = 0; ks < NK; ++ks) zi[ks] = zn[ks];
                 }
@@ -314,8 +331,6 @@ __global__ __launch_bounds__(512, BWD ? 1 : 2) void spec_mid_kernel(MidArgs a) {
             // the next layer's weights are requested before this layer's products and finished (residual identity, zero rows) after
             // its activation: the loads are in flight behind the MFMAs instead of in front of them
             HNO_STAMP(a.stamps, 4 + 4 * l);
-            float nraw[NK];
-            if (l + 1 < a.L) load_w_raw(l == 0 ? a.W[1] : (l == 1 ? a.W[2] : a.W[3]), nraw);
             __builtin_amdgcn_sched_barrier(0);
             f32x16 acc;
 #pragma unroll
@@ -348,7 +363,7 @@ __global__ __launch_bounds__(512, BWD ? 1 : 2) void spec_mid_kernel(MidArgs a) {
             }
             HNO_STAMP(a.stamps, 7 + 4 * l);
             __builtin_amdgcn_sched_barrier(0);
-            if (l + 1 < a.L) fin_w(nraw, w);
+            if (l + 1 < a.L) read_w(l + 1, w);
         }
         }
 #pragma unroll
@@ -360,7 +375,7 @@ __global__ __launch_bounds__(512, BWD ? 1 : 2) void spec_mid_kernel(MidArgs a) {
     if (BWD) {   // the NT waves' weight-gradient fragments -> this workgroup's slab (fixed order: bit-reproducible)
         const int nslab = a.L * C * C;
         float *slab = a.partials + (size_t)blockIdx.x * nslab;
-        for (int i = tid; i < nslab; i += 512) {
+        for (int i = tid; i < nslab; i += NTH) {
             float sum = 0.f;
 #pragma unroll
             for (int wv = 0; wv < NT; ++wv) sum += MINE[wv * nslab + i];
@@ -369,7 +384,7 @@ __global__ __launch_bounds__(512, BWD ? 1 : 2) void spec_mid_kernel(MidArgs a) {
     }
     if (a.dbg & 64) return;
     // ---------------- phase 4: pad + inverse D step
-    for (int t = wave; t < NCT; t += 8) {
+    for (int t = wave; t < NCT; t += NW) {
         if (a.dbg & 4) break;
         const int c = 2 * t + cloc;
         // z(+-, kappa) of this channel and column; positions outside the kept block are zero
@@ -746,7 +761,7 @@ static int mid_twiddles(int N0, int M0, const float **out) {
 // dynamic LDS of spec_mid_kernel (floats): PQ + ZL (+ backward: NT G / Z tiles and NT x L x C x C weight-gradient fragments)
 static size_t mid_lds_floats(int M0, int L, bool bwd) {
     const int C = 24, K0 = M0 + 1, NT = (2 * 2 * M0 * 4 + 31) / 32;
-    size_t n = (size_t)C * 2 * 2 * K0 * 4 + (size_t)C * NT * 32;
+    size_t n = (size_t)4 * 32 * 25 + (size_t)C * 2 * 2 * K0 * 4 + (size_t)C * NT * 32;      // layer weights + PQ + ZL
     if (bwd) n += (size_t)NT * 2 * 32 * 34 + (size_t)NT * L * C * C;
     return n;
 }
@@ -827,7 +842,7 @@ extern "C" int hno_spec_mid_fwd(void *workspace, const float *const *W_layers, f
     const size_t lds = sizeof(float) * mid_lds_floats(m0, 0, false);
     {
         ProfScope _ps(KID_SPECMIX_FWD, s, 4.0 * B * C * (2.0 * N0 * 2 * (2 * m1 + 1) * 16 + (L + 1) * 8.0 * m0 * m1 * m2));
-#define X(n) if (N0 == n) hipLaunchKernelGGL((spec_mid_kernel<n, 10, false>), grid, dim3(512), lds, s, a);
+#define X(n) if (N0 == n) hipLaunchKernelGGL((spec_mid_kernel<n, 10, false>), grid, dim3(64 * MID_NW), lds, s, a);
         HNO_MID_N0_LIST(X)
 #undef X
     }
@@ -875,7 +890,7 @@ extern "C" int hno_spec_mid_bwd(void *workspace, const float *const *W_layers, c
     }
     {
         ProfScope _ps(KID_SPECMIX_BWD, s, 4.0 * B * C * (2.0 * N0 * 2 * (2 * m1 + 1) * 16 + (L + 1) * 8.0 * m0 * m1 * m2));
-#define X(n) if (N0 == n) hipLaunchKernelGGL((spec_mid_kernel<n, 10, true>), dim3(nwg), dim3(512), lds, s, a);
+#define X(n) if (N0 == n) hipLaunchKernelGGL((spec_mid_kernel<n, 10, true>), dim3(nwg), dim3(64 * MID_NW), lds, s, a);
         HNO_MID_N0_LIST(X)
 #undef X
     }
