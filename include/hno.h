@@ -202,6 +202,13 @@ int hno_pwconv_bwd(const float *gy, const float *y, const float *xa, int Ca, con
 int hno_pwconv_fwd_branch(const float *s, const float *xb, const float *Wbr, const float *bbr, const float *W,
                           const float *bias, float *y, float *out, int B, int Ca, int Cb, int Cout, long long V,
                           int act, void *stream);
+/* Two chained pointwise layers in one pass (round 4): xi = act(Wc [u ; t] + bc), xn = act(Wm [xi ; k] + bm) -- the conv_concat that
+ * ends HNO-XS block i and the mapping_conv over cat[block output, U-Net skip] that opens decoder block i + 1 (nets/hnosegxs.py:161-162,
+ * 253-255, 274-275).  xi is written for the backward but never read back: 5 activation streams instead of 6.  (B, 24, V) tensors
+ * (V may be the channel stride of channel-padded activations), Wc / Wm (24, 48); other widths: HNO_ELIMIT (callers run the two layers). */
+int hno_pwconv_fwd_chain_supported(int C);
+int hno_pwconv_fwd_chain(const float *u, const float *t, const float *k, const float *Wc, const float *bc, const float *Wm,
+                         const float *bm, float *xi, float *xn, int B, int C, long long V, int act, void *stream);
 size_t hno_pwconv_bwd_branch_workspace_bytes(int Ca, int Cb, int Cout);
 int hno_pwconv_bwd_branch(const float *gy, const float *y, const float *xa, int Ca, const float *xb, int Cb,
                           const float *W, const float *Wbr, float *p_out, float *gxb, float *dflat, void *workspace,

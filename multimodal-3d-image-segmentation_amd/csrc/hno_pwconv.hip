@@ -641,6 +641,143 @@ __global__ __launch_bounds__(64 * PWF_DMA_WAVES) void pwconv_fwd_branch_kernel(P
     }
 }
 
+// ---- two chained pointwise layers in one pass (round 4): the concat convolution that ends HNO-XS block i and the mapping convolution
+// that opens block i + 1 (decoder blocks, nets/hnosegxs.py:253-279 with the U-Net concatenation of :161-162):
+//   xi = act(Wc [u ; t] + bc)         u: the block's transformed branch (PadInverse output), t: the block's input
+//   xn = act(Wm [xi ; k] + bm)        k: the U-Net skip tensor of block i + 1
+// xi is written (the backward of both layers needs it) but not read back: the first product's accumulator registers are the B
+// operand of the second product's xi part (k-slot r of lane half h = channel (r & 3) + 8 (r >> 2) + 4 h, matched by the order in which
+// the xi columns of Wm are loaded).  Reads u, t, k; writes xi, xn: 5 streams of 24 channels instead of 6 for the two layers apart
+// (pwconv_fwd_fast_kernel twice: 2 x (48 in + 24 out)).  Same DMA ring as pwconv_fwd_fast_kernel, three tensors per tile.
+struct PwChainArgs {
+    const float *u, *t, *k, *Wc, *bc, *Wm, *bm;
+    float *xi, *xn;
+    int B;
+    unsigned V;
+    int act;
+    int dbg;
+};
+
+template <int C, int NWV>
+__global__ __launch_bounds__(64 * NWV) void pwconv_fwd_chain_kernel(PwChainArgs a) {
+    static_assert(C % 8 == 0 && C <= 32, "one 32-row tile per product");
+    constexpr int NW = NWV, NK = C / 2, CIN = 2 * C, NDMA = 3 * NK;
+    extern __shared__ float pwf_ring[];      // NW x 2 slots x NDMA x 64 floats
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, c = lane & 31;
+    const unsigned V = a.V;
+    // A operands (row c = output channel): first product over [u ; t] in B-operand row pairs (channels 2 ks + h); second product: the xi
+    // part in accumulator-register order, the k part in row pairs
+    float wcu[NK], wct[NK], wmx[NK], wmk[NK], b1[NK], b2[NK];
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        wcu[ks] = c < C ? a.Wc[(size_t)c * CIN + 2 * ks + h] : 0.f;
+        wct[ks] = c < C ? a.Wc[(size_t)c * CIN + C + 2 * ks + h] : 0.f;
+        wmk[ks] = c < C ? a.Wm[(size_t)c * CIN + C + 2 * ks + h] : 0.f;
+        const int ch = (ks & 3) + 8 * (ks >> 2) + 4 * h;
+        wmx[ks] = c < C ? a.Wm[(size_t)c * CIN + ch] : 0.f;
+        b1[ks] = a.bc ? a.bc[ch] : 0.f;
+        b2[ks] = a.bm ? a.bm[ch] : 0.f;
+    }
+    const float ap = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f;
+    const float aq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
+    const bool lin = a.act == HNO_ACT_NONE;
+    const unsigned tiles_per_b = (V + 31) / 32;
+    const unsigned ntiles = tiles_per_b * a.B;
+    const unsigned hoffV = h ? V : 0u, hoff4V = h ? 4u * V : 0u;
+    static_assert(NDMA <= 63, "the DMA of one tile must fit the vmcnt counter");
+    float *ring = pwf_ring + wave * (2 * NDMA * 64);
+    const unsigned ring_b = (unsigned)(size_t)ring;
+    const unsigned stride = gridDim.x * NW;
+    auto issue = [&](unsigned t, int slot) {
+        const unsigned b = t / tiles_per_b;
+        const unsigned v = (t - b * tiles_per_b) * 32 + c;
+        const unsigned boff = (hoffV + (v < V ? v : 0u)) * 4u;
+        const float *u_b = a.u + (size_t)b * C * V, *t_b = a.t + (size_t)b * C * V, *k_b = a.k + (size_t)b * C * V;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) dma_row_pair(u_b + (size_t)(2 * ks) * V, boff, __builtin_amdgcn_readfirstlane(ring_b + (slot * NDMA + ks) * 256));
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) dma_row_pair(t_b + (size_t)(2 * ks) * V, boff, __builtin_amdgcn_readfirstlane(ring_b + (slot * NDMA + NK + ks) * 256));
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) dma_row_pair(k_b + (size_t)(2 * ks) * V, boff, __builtin_amdgcn_readfirstlane(ring_b + (slot * NDMA + 2 * NK + ks) * 256));
+    };
+    unsigned t = blockIdx.x * NW + wave;
+    if (t < ntiles) issue(t, 0);
+    for (int slot = 0; t < ntiles; t += stride, slot ^= 1) {
+        if (t + stride < ntiles) {
+            issue(t + stride, slot ^ 1);
+            dma_wait<NDMA>();
+        } else {
+            dma_wait<0>();
+        }
+        const unsigned b = t / tiles_per_b;
+        const unsigned v0 = (t - b * tiles_per_b) * 32, v = v0 + c;
+        const bool vin = v < V, full = v0 + 32 <= V;      // `full` is wave-uniform
+        const float *sl = ring + slot * NDMA * 64 + lane;
+        float uv[NK], tv[NK], kv[NK];
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            uv[ks] = sl[ks * 64];
+            tv[ks] = sl[(NK + ks) * 64];
+            kv[ks] = sl[(2 * NK + ks) * 64];
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) acc = mfma32(wcu[ks], uv[ks], acc);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) acc = mfma32(wct[ks], tv[ks], acc);
+        float xi[NK];
+#pragma unroll
+        for (int r = 0; r < NK; ++r) xi[r] = acc[r] + b1[r];
+        if (!lin) {             // no branch per register (see pwconv_fwd_fast_kernel)
+#pragma unroll
+            for (int r = 0; r < NK; ++r) {
+                float e = neg_expm1(xi[r]);
+                asm volatile("" : "+v"(e));
+                xi[r] = xi[r] > 0.f ? ap * xi[r] : aq * e;
+            }
+        }
+        float *xi_l = a.xi + (size_t)b * C * V + (hoff4V + v);
+        if (full) {
+#pragma unroll
+            for (int r = 0; r < NK; ++r) xi_l[(size_t)((r & 3) + 8 * (r >> 2)) * V] = xi[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < NK; ++r)
+                if (vin) xi_l[(size_t)((r & 3) + 8 * (r >> 2)) * V] = xi[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < NK; ++r) acc = mfma32(wmx[r], xi[r], acc);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) acc = mfma32(wmk[ks], kv[ks], acc);
+        float xn[NK];
+#pragma unroll
+        for (int r = 0; r < NK; ++r) xn[r] = acc[r] + b2[r];
+        if (!lin) {
+#pragma unroll
+            for (int r = 0; r < NK; ++r) {
+                float e = neg_expm1(xn[r]);
+                asm volatile("" : "+v"(e));
+                xn[r] = xn[r] > 0.f ? ap * xn[r] : aq * e;
+            }
+        }
+        float *xn_l = a.xn + (size_t)b * C * V + (hoff4V + v);
+        if (full) {
+#pragma unroll
+            for (int r = 0; r < NK; ++r) xn_l[(size_t)((r & 3) + 8 * (r >> 2)) * V] = xn[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < NK; ++r)
+                if (vin) xn_l[(size_t)((r & 3) + 8 * (r >> 2)) * V] = xn[r];
+        }
+    }
+}
+
 #define PWB_FAST_WAVES 4   // 256-thread blocks, two per CU (512 slabs): measured best of {4, 8, 12} waves x {256, 512, 1024} blocks
 template <int COUT, int CA, int CB, int NW = PWB_FAST_WAVES, int BR = 0, bool BF16 = false>   // compile-time channel counts: every address select folds
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kernel(PwBwdArgs a) {   // 2 blocks per CU: a 256-register budget, all in VGPRs (no AGPR copies)
@@ -1370,6 +1507,40 @@ extern "C" int hno_pwconv_fwd_branch(const float *s_in, const float *x, const fl
     const size_t fl = (size_t)PWF_DMA_WAVES * 2 * (12 + 12) * 256;
     if (bf16) hipLaunchKernelGGL((pwconv_fwd_branch_kernel<24, 24, 24, true>), dim3((int)grid), dim3(64 * PWF_DMA_WAVES), fl, fs, a);
     else hipLaunchKernelGGL((pwconv_fwd_branch_kernel<24, 24, 24>), dim3((int)grid), dim3(64 * PWF_DMA_WAVES), fl, fs, a);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+// xi = act(Wc [u ; t] + bc), xn = act(Wm [xi ; k] + bm): conv_concat of one HNO-XS block and mapping_conv of the next in one pass
+// (pwconv_fwd_chain_kernel).  All tensors (B, 24, V) fp32 (V = the channel stride of channel-padded activations); Wc, Wm (24, 48).
+extern "C" int hno_pwconv_fwd_chain_supported(int C) { return C == 24; }
+extern "C" int hno_pwconv_fwd_chain(const float *u, const float *t, const float *k, const float *Wc, const float *bc, const float *Wm,
+                                    const float *bm, float *xi, float *xn, int B, int C, long long V, int act, void *stream) {
+    HNO_REQUIRE(u && t && k && Wc && Wm && xi && xn && B > 0 && V > 0, "hno_pwconv_fwd_chain: bad argument");
+    if (C != 24) return fail(HNO_ELIMIT, "hno_pwconv_fwd_chain: only 24-channel blocks are built (got %d)", C);
+    if (V * 8 >= (1ll << 32) || ((V + 31) / 32) * B >= (1ll << 31))
+        return fail(HNO_ELIMIT, "hno_pwconv_fwd_chain: V=%lld voxels per channel exceeds the 32-bit offset range", V);
+    PwChainArgs a;
+    a.u = u; a.t = t; a.k = k; a.Wc = Wc; a.bc = bc; a.Wm = Wm; a.bm = bm; a.xi = xi; a.xn = xn;
+    a.B = B; a.V = (unsigned)V; a.act = act & 0xfff; a.dbg = debug_flags();
+    const long long ntiles = ((V + 31) / 32) * B;
+    static const int nw_env = getenv("HNO_PWCHAIN_WAVES") ? atoi(getenv("HNO_PWCHAIN_WAVES")) : 8;      // tuning aid: 4 or 8
+    const int nw = nw_env == 4 ? 4 : 8;
+    long long grid = (ntiles + nw - 1) / nw;
+    const long long cap = nw == 4 ? 512 : 256;
+    if (grid > cap) grid = cap;
+    if (debug_flags() >> 8) grid = debug_flags() >> 8;
+    hipStream_t fs = (hipStream_t)stream;
+    ProfScope ps(KID_PWCONV_FWD, fs, 4.0 * B * (double)V * 5 * C);
+    const size_t fl = (size_t)nw * 2 * 36 * 256;
+    static int attr = -1;
+    if (attr != current_device()) {
+        (void)hipFuncSetAttribute((const void *)pwconv_fwd_chain_kernel<24, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)pwconv_fwd_chain_kernel<24, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = current_device();
+    }
+    if (nw == 8) hipLaunchKernelGGL((pwconv_fwd_chain_kernel<24, 8>), dim3((int)grid), dim3(512), fl, fs, a);
+    else hipLaunchKernelGGL((pwconv_fwd_chain_kernel<24, 4>), dim3((int)grid), dim3(256), fl, fs, a);
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }

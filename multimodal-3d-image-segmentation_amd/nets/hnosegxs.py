@@ -13,6 +13,8 @@ the reference does not exist here.
 from functools import partial
 from typing import Union
 
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -132,20 +134,35 @@ class HNOXSBlock(nn.Module):
                 and self.conv_concat is not None and self.conv_concat.normalization is None
                 and (self.mapping_conv is None or self.mapping_conv.normalization is None))
 
-    def forward(self, x, skip=None, passthrough=False):
+    def chain_ok(self, nxt, x):
+        """conv_concat of this block and mapping_conv of `nxt` can run as one pass (ops.XSBlockFn with nmap_*): both blocks are the
+        fused node, 24 -> 24 channels with a 48 -> 24 mapping, fp32 (not under autocast), same activation"""
+        from .. import ops_bf16
+        return (x.ndim == 5 and x.is_cuda and self._fused_ok() and nxt._fused_ok() and nxt.mapping_conv is not None
+                and self.conv_concat.op.out_channels == 24 and tuple(nxt.mapping_conv.op.weight.shape[:2]) == (24, 48)
+                and self.activation is nxt.activation and not ops_bf16.autocast_bf16()
+                and os.environ.get('HNO_PW_CHAIN', '1') != '0')
+
+    def forward(self, x, skip=None, passthrough=False, chain_to=None, next_skip=None, premapped=False):
         """`skip` is the U-Net skip tensor the reference concatenates in HNOSegXS.forward (:161-162);
         passing it separately lets the mapping conv read both tensors without a torch.cat.
         passthrough=True additionally returns the block INPUT (an alias) for use as a later block's skip, which
-        routes that block's skip gradient through this block's backward (see ops.XSBlockFn)."""
+        routes that block's skip gradient through this block's backward (see ops.XSBlockFn).
+        chain_to / next_skip (round 4): the next block and its skip tensor: this block returns the next block's MAPPED input
+        (conv_concat and the next mapping_conv in one pass); that block is then called with premapped=True."""
         if x.ndim == 5 and self._fused_ok():
             # standard configuration: the whole block is one autograd node (ops.XSBlockFn)
             act = ops.act_id(self.activation)
-            mc = self.mapping_conv.op if self.mapping_conv is not None else None
+            mc = self.mapping_conv.op if (self.mapping_conv is not None and not premapped) else None
             assert mc is not None or skip is None
             cc = self.conv_concat.op
+            nm = chain_to.mapping_conv.op if chain_to is not None else None
             return ops.XSBlockFn.apply(x, skip, mc.weight if mc is not None else None, mc.bias if mc is not None else None,
                                        cc.weight, cc.bias, self.transform_crop.num_modes, act, passthrough,
+                                       nm.weight if nm is not None else None, nm.bias if nm is not None else None,
+                                       next_skip if nm is not None else None,
                                        *[b.op.weight for b in self.conv_blocks])
+        assert chain_to is None and not premapped
         if passthrough:   # unfused configurations: plain autograd accumulates the two gradients of x
             return self.forward(x, skip), x
         if self.mapping_conv is not None:
@@ -253,14 +270,27 @@ class HNOSegXS(nn.Module):
         if self.use_deep_supervision:
             ds.append(x)
         nb = len(self.num_transform_blocks)
+        premapped = False
         for i, layer in enumerate(self.layers):
             skip = enc[nb - 1 - i] if (self.use_unet_skip and i > nb // 2) else None
             # the output of block i - 1 (this block's input) is a later block's skip: take the alias from this block
             feeds_skip = self.use_unet_skip and 0 <= i - 1 < nb // 2 and (nb - 1 - (i - 1)) > nb // 2
+            # decoder blocks: the next block's mapping_conv over cat[this block's output, its U-Net skip] is chained to this block's
+            # conv_concat (one pass over the activations instead of two) when nobody else reads this block's output
+            nxt = self.layers[i + 1] if i + 1 < nb else None
+            nskip = enc.get(nb - 1 - (i + 1)) if (nxt is not None and self.use_unet_skip and i + 1 > nb // 2) else None
+            chain = (nxt is not None and nskip is not None and not self.use_deep_supervision and not (self.use_unet_skip and i < nb // 2)
+                     and not (feeds_skip and torch.is_grad_enabled()) and layer.chain_ok(nxt, x))
+            if premapped:
+                skip = None
             if feeds_skip and torch.is_grad_enabled():
-                x, enc[i - 1] = layer(x, skip, passthrough=True)
+                assert not chain
+                x, enc[i - 1] = layer(x, skip, passthrough=True, premapped=premapped)
+            elif chain:
+                x = layer(x, skip, chain_to=nxt, next_skip=nskip, premapped=premapped)
             else:
-                x = layer(x, skip)
+                x = layer(x, skip, premapped=premapped)
+            premapped = chain
             if self.use_deep_supervision:
                 ds.append(x)
             if self.use_unet_skip and i < nb // 2:

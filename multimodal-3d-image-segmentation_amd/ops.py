@@ -1467,18 +1467,21 @@ class XSBlockFn(_HnoFunction):
     of materialising both and adding them."""
 
     @staticmethod
-    def meta(x, skip, map_w, map_b, cat_w, cat_b, modes, act, passthrough, *mix_ws):
+    def meta(x, skip, map_w, map_b, cat_w, cat_b, modes, act, passthrough, nmap_w, nmap_b, nskip, *mix_ws):
         out = _m((x.shape[0], cat_w.shape[0]) + tuple(x.shape[2:]))
         return (out, x) if passthrough else out
 
     @staticmethod
-    def forward(ctx, x, skip, map_w, map_b, cat_w, cat_b, modes, act, passthrough, *mix_ws):
+    def forward(ctx, x, skip, map_w, map_b, cat_w, cat_b, modes, act, passthrough, nmap_w, nmap_b, nskip, *mix_ws):
         """passthrough: also return the block input `x` as a second output.  A later block that takes this
         tensor as its U-Net skip then sends its gradient HERE instead of to a second consumer edge of `x`, and
         the backward below folds it into the store of the concat-path gradient -- autograd's separate
         accumulation kernel (3 x 158 MB of traffic per step in HNOSeg-XS) disappears."""
-        ctx.leaf_params = _leaf_params(ctx, map_w, map_b, cat_w, cat_b, *mix_ws)
-        map_w, map_b, cat_w, cat_b = (_f32c(t) for t in (map_w, map_b, cat_w, cat_b))
+        # nmap_w / nmap_b / nskip (round 4): the mapping_conv of the NEXT (decoder) block and its U-Net skip tensor.  The block then
+        # returns xn = act(Wm [out ; nskip] + bm) instead of its own output: conv_concat and the next mapping_conv run as ONE pass
+        # (hno_pwconv_fwd_chain / hno_pwconv_bwd_chain) and the next block is called without a mapping convolution.
+        ctx.leaf_params = _leaf_params(ctx, map_w, map_b, cat_w, cat_b, nmap_w, nmap_b, *mix_ws)
+        map_w, map_b, cat_w, cat_b, nmap_w, nmap_b = (_f32c(t) for t in (map_w, map_b, cat_w, cat_b, nmap_w, nmap_b))
         mix_ws = [_f32c(w) for w in mix_ws]
         spatial = tuple(x.shape[2:])
         if len(modes) == 2:                      # 2-D model on a (B, C, 1, H, W) view
@@ -1499,25 +1502,48 @@ class XSBlockFn(_HnoFunction):
             z0 = dht3_crop_raw(xm, modes, 1.0 / n3)
             zs = specmix_fwd_raw(z0, mix_ws, 1, act)
             u = pad_idht3_raw(zs[-1], spatial, 1.0, None, act, ld=chan_stride(xm))
-        out = pwconv_fwd_raw(u, xm, cat_w, cat_b, act, bf)
-        ctx.save_for_backward(x, skip, map_w, xm if has_map else None, z0, zs, u, cat_w, out, map_b, cat_b, *mix_ws)
+        chained = nmap_w is not None
+        xn = None
+        if chained:
+            assert not passthrough and not bf and nskip is not None
+            nskip = to_layout(_f32a(nskip), chan_stride(xm))
+            out, xn = act_like(xm), act_like(xm)
+            check(_lib.lib().hno_pwconv_fwd_chain(ptr(u), ptr(xm), ptr(nskip), ptr(cat_w), ptr(cat_b), ptr(nmap_w), ptr(nmap_b), ptr(out), ptr(xn),
+                                                  x.shape[0], int(cat_w.shape[0]), chan_stride(xm) or _flat_v(xm), act, stream_ptr()),
+                  'hno_pwconv_fwd_chain')
+        else:
+            out = pwconv_fwd_raw(u, xm, cat_w, cat_b, act, bf)
+        ctx.chain = chained
+        # (the chained tensors go through save_for_backward like the others: an output kept on ctx directly would be a reference cycle)
+        ctx.save_for_backward(x, skip, map_w, xm if has_map else None, z0, zs, u, cat_w, out, map_b, cat_b,
+                              nmap_w, nmap_b, nskip if chained else None, xn, *mix_ws)
         ctx.cfg = (has_map, modes, act, spatial, n3, map_b is not None, cat_b is not None, bool(passthrough))
         ctx.set_materialize_grads(False)
+        if chained:
+            return xn
         if passthrough:
             return out, x.view_as(x)
         return out
 
     @staticmethod
     def backward(ctx, g_out, g_pass=None):
-        x, skip, map_w, xm, z0, zs, u, cat_w, out, map_b, cat_b, *mix_ws = ctx.saved_tensors
+        x, skip, map_w, xm, z0, zs, u, cat_w, out, map_b, cat_b, nmap_w, nmap_b, nskip, xn, *mix_ws = ctx.saved_tensors
         has_map, modes, act, spatial, n3, map_has_b, cat_has_b, passthrough = ctx.cfg
         if not has_map:
             xm = x
         # weight gradients of leaves with .grad None are not read before backward ends: their slab reductions are batched
-        lp = ctx.leaf_params and _release_use(map_w, map_b, cat_w, cat_b, *mix_ws)
+        lp = ctx.leaf_params and _release_use(map_w, map_b, cat_w, cat_b, nmap_w, nmap_b, *mix_ws)
         late_cat, late_mix, late_map = lp and _deferrable(cat_w, cat_b), lp and _deferrable(*mix_ws), lp and _deferrable(map_w, map_b)
         if g_out is None:
             raise _lib.HnoError('XSBlockFn.backward: no gradient for the block output')
+        d_nmap_w = d_nmap_b = g_nskip = None
+        if ctx.chain:
+            # g_out is the gradient of xn = act(Wm [out ; nskip] + bm): through the next block's mapping convolution first
+            late_nmap = lp and _deferrable(nmap_w, nmap_b)
+            g_out, g_nskip, d_nmap_w, d_nmap_b = pwconv_bwd_raw(to_layout(g_out, chan_stride(xn)), xn, out, nskip, nmap_w, act, nmap_b is not None,
+                                                               True, True, defer=late_nmap, bias=nmap_b, bf16=False)
+            if g_nskip is not None:
+                g_nskip._hno_private = True      # fresh buffer of ours: the encoder block that owns the skip may accumulate into it
         # The passthrough gradient is accumulated IN PLACE into the buffer autograd handed us only when that buffer is
         # provably private: produced by our own mapping-conv backward below (tagged), i.e. not summed by the engine, not
         # captured by a hook, not shared with another consumer.  Anything else takes the out-of-place add.
@@ -1547,7 +1573,7 @@ class XSBlockFn(_HnoFunction):
             g_xm = pad_idht3_raw(g_z0, spatial, 1.0 / n3, g_skipin, ACT_NONE, ld=ld)    # TransformCrop^T + skip gradient
         d_mix = tuple(d_mix.unbind(0))
         if not has_map:
-            return (g_xm, None, None, None, d_cat_w, d_cat_b, None, None, None) + d_mix
+            return (g_xm, None, None, None, d_cat_w, d_cat_b, None, None, None, d_nmap_w, d_nmap_b, g_nskip) + d_mix
         g_x, g_skip, d_map_w, d_map_b = pwconv_bwd_raw(g_xm, xm, x, skip, map_w, act, map_has_b,
                                                        ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                                        accumulate_into=(g_pass, None) if private else None,
@@ -1556,7 +1582,7 @@ class XSBlockFn(_HnoFunction):
             g_x = plus_pass(g_x)
         if g_skip is not None:
             g_skip._hno_private = True          # fresh buffer of ours: a later consumer may accumulate into it
-        return (g_x, g_skip, d_map_w, d_map_b, d_cat_w, d_cat_b, None, None, None) + d_mix
+        return (g_x, g_skip, d_map_w, d_map_b, d_cat_w, d_cat_b, None, None, None, d_nmap_w, d_nmap_b, g_nskip) + d_mix
 
 
 class ConvK2S2Fn(_HnoFunction):
