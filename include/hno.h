@@ -209,6 +209,14 @@ int hno_pwconv_fwd_branch(const float *s, const float *xb, const float *Wbr, con
 int hno_pwconv_fwd_chain_supported(int C);
 int hno_pwconv_fwd_chain(const float *u, const float *t, const float *k, const float *Wc, const float *bc, const float *Wm,
                          const float *bm, float *xi, float *xn, int B, int C, long long V, int act, void *stream);
+/* backward of the pair in one pass: gn = gradient of xn -> gu (times xa_act'(u): u is the output of that activation), gt, gk and
+ * grads = [dWm (24, 48) | dbm (24) | dWc (24, 48) | dbc (24)] in one flat buffer.  9 activation streams instead of 12: the gradient
+ * between the two layers never reaches memory.  workspace: hno_pwconv_bwd_chain_workspace_bytes(C); bit 8 of xa_act defers the slab
+ * reduction (hno_set_defer_reduce). */
+size_t hno_pwconv_bwd_chain_workspace_bytes(int C);
+int hno_pwconv_bwd_chain(const float *gn, const float *xn, const float *xi, const float *k, const float *u, const float *t,
+                         const float *Wm, const float *Wc, float *gu, float *gt, float *gk, float *grads, void *workspace, int B, int C,
+                         long long V, int act, int xa_act, void *stream);
 size_t hno_pwconv_bwd_branch_workspace_bytes(int Ca, int Cb, int Cout);
 int hno_pwconv_bwd_branch(const float *gy, const float *y, const float *xa, int Ca, const float *xb, int Cb,
                           const float *W, const float *Wbr, float *p_out, float *gxb, float *dflat, void *workspace,

@@ -1184,6 +1184,239 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kern
     }
 }
 
+// ---- backward of the two chained pointwise layers (pwconv_fwd_chain_kernel) in one pass:
+//   g1 = gn * act'(xn)                                 gradient of the mapping convolution's pre-activation
+//   [gxi ; gk] = Wm^T g1                               gk: gradient of the U-Net skip tensor (stored)
+//   p  = gxi * act'(xi)                                gradient of the concat convolution's pre-activation -- stays in registers
+//   [gu ; gt] = Wc^T p,  gu *= xa_act'(u)              (the activation of PadInverse's output is applied to u by its producer)
+//   dWm += g1 [xi ; k]^T, dbm += sum g1;   dWc += p [u ; t]^T, dbc += sum p
+// The two layers apart (pwconv_bwd_fast_kernel twice) move 12 streams of 24 channels -- gn, xn, xi, k -> gxi, gk and gxi, xi, u, t ->
+// gu, gt --, this kernel 9: the gradient between the layers never reaches memory and xi is read once.  Structure as the fast kernel:
+// the four x tensors of the NEXT tile arrive by LDS-DMA into the other slot of a two-slot ring (row pairs, PWB_XP apart) while this
+// tile is multiplied, gn / xn are register-prefetched right behind them (the compiler's wait for those retires the DMAs: in-order
+// return), dgrads on 32x32x2 with the weights as A operands, weight gradients on 16x16x4 over wave-private LDS tiles (g1 then p in ONE
+// [channel][voxel] tile), one slab of partial sums per workgroup.
+struct PwChainBwdArgs {
+    const float *gn, *xn, *xi, *k, *u, *t;    // (B, C, V)
+    const float *Wm, *Wc;                      // (C, 2C)
+    float *gu, *gt, *gk;                       // (B, C, V)
+    float *partials;                           // per workgroup: [dWm C x 2C | dbm C | dWc C x 2C | dbc C]
+    int B;
+    unsigned V;
+    int act, xa_act, dbg;
+};
+
+template <int C, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void pwconv_bwd_chain_kernel(PwChainBwdArgs a) {
+    static_assert(C == 24, "accumulator-row bookkeeping below is written for 24 channels");
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, c = lane & 31;
+    constexpr int CIN = 2 * C, NK = C / 2, NPAIR = 4 * NK;            // row pairs per slot: xi, k, u, t
+    constexpr int XS = NPAIR * PWB_XP;                                // floats per slot
+    constexpr int WAVE_FLOATS = 32 * PWB_LD + 2 * XS;
+    float *G = lds + (size_t)wave * WAVE_FLOATS;                      // [o][v]: g1, later p
+    float *X = G + 32 * PWB_LD;                                       // two slots of [pair][row & 1][v]
+    const unsigned V = a.V;
+    // A operands of the two input-gradient products.  First: Wm^T, rows i = 32 ic + c, k-slots = output channels 2 ks + h (g1 sits in
+    // registers as row pairs).  Second: Wc^T, rows i, k-slot r of lane half h = channel (r & 3) + 8 (r >> 2) + 4 h (p sits in the first
+    // product's accumulator registers).
+    float wm[2][NK], wc[2][NK];
+#pragma unroll
+    for (int ic = 0; ic < 2; ++ic)
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const int i = ic * 32 + c;
+            wm[ic][ks] = i < CIN ? a.Wm[(size_t)(2 * ks + h) * CIN + i] : 0.f;
+            wc[ic][ks] = i < CIN ? a.Wc[(size_t)((ks & 3) + 8 * (ks >> 2) + 4 * h) * CIN + i] : 0.f;
+        }
+    for (int i = lane; i < WAVE_FLOATS; i += 64) G[i] = 0.f;
+    float dbm[NK], dbc[NK];
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) dbm[ks] = dbc[ks] = 0.f;
+    f32x4 dwm[2][3], dwc[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) dwm[m][n] = dwc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float dp = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f, dq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
+    const bool lin = a.act == HNO_ACT_NONE;
+    const float xp = a.xa_act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f, xq = a.xa_act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
+    const bool xact = a.xa_act != HNO_ACT_NONE;
+    const unsigned tiles_per_b = (V + 31) / 32;
+    const unsigned ntiles = tiles_per_b * a.B;
+    const unsigned ngroups = (ntiles + NW - 1) / NW;
+    const unsigned hoffV = h ? V : 0u, hoff4V = h ? 4u * V : 0u;
+    const float *ga = G + (lane & 15) * PWB_LD + (lane >> 4);
+    const float *xbp = X + ((lane & 15) >> 1) * PWB_XP + (lane & 1) * 32 + (lane >> 4);      // + slot XS + tensor-pair offset + n 8 XP + 4 ks
+    const unsigned x_lds = (unsigned)(size_t)X;
+    float pg[NK], py[NK];
+    auto fetch = [&](unsigned grp, int slot) {
+        const unsigned t = grp * NW + wave;
+        const bool live = t < ntiles;
+        const unsigned b = live ? t / tiles_per_b : 0u;
+        const unsigned v = live ? (t - b * tiles_per_b) * 32 + c : 0u;
+        const unsigned off = hoffV + ((live && v < V) ? v : 0u);
+        const size_t bo = (size_t)b * C * V;
+        const float *srcs[4] = {a.xi + bo, a.k + bo, a.u + bo, a.t + bo};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < NK; ++j)
+                dma_row_pair(srcs[q] + (size_t)(2 * j) * V, off * 4u, __builtin_amdgcn_readfirstlane(x_lds + (slot * XS + (q * NK + j) * PWB_XP) * 4));
+        // register loads issued BEHIND the DMAs: the wait hipcc places in front of their first use retires the DMAs too (in-order return)
+        const float *gn_b = a.gn + bo, *xn_b = a.xn + bo;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) pg[ks] = (gn_b + (size_t)(2 * ks) * V)[off];
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) py[ks] = (xn_b + (size_t)(2 * ks) * V)[off];
+    };
+    if (blockIdx.x < ngroups) fetch(blockIdx.x, 0);
+    int slot = 0;
+    for (unsigned grp = blockIdx.x; grp < ngroups; grp += gridDim.x, slot ^= 1) {
+        const float *Xc = X + slot * XS;
+        const unsigned t = grp * NW + wave;
+        const bool live = t < ntiles;
+        const unsigned b = live ? t / tiles_per_b : 0u;
+        const unsigned v = live ? (t - b * tiles_per_b) * 32 + c : 0u;
+        const bool vin = live && v < V;
+        // ---- g1 = gn act'(xn): B operand of the first product (registers), A operand of dWm (LDS tile)
+        float g[NK];
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const float gv = pg[ks] * ((lin || py[ks] > 0.f) ? dp : py[ks] + dq);
+            g[ks] = vin ? gv : 0.f;
+            G[(2 * ks + h) * PWB_LD + c] = g[ks];
+            dbm[ks] += g[ks];
+        }
+        if (grp + gridDim.x < ngroups) fetch(grp + gridDim.x, slot ^ 1);
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) acc0 = mfma32(wm[0][ks], g[ks], acc0);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) acc1 = mfma32(wm[1][ks], g[ks], acc1);
+        // rows of [gxi ; gk]: acc0 registers 0..11 = gxi rows (r & 3) + 8 (r >> 2) + 4 h; registers 12..15 = gk rows 0..7; acc1 registers
+        // 0..7 = gk rows 8..23
+        float xo[NK];
+#pragma unroll
+        for (int r = 0; r < NK; ++r) {
+            const int irow = (r & 3) + 8 * (r >> 2);
+            xo[r] = Xc[((irow >> 1) + 2 * h) * PWB_XP + (irow & 1) * 32 + c];                    // xi: pairs 0 .. NK - 1
+        }
+        float *gk_l = a.gk + (size_t)b * C * V + (hoff4V + v);
+        if (vin) {
+#pragma unroll
+            for (int r = 12; r < 16; ++r) gk_l[(size_t)((r & 3) + 8 * (r >> 2) - 24) * V] = acc0[r];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) gk_l[(size_t)(8 + (r & 3) + 8 * (r >> 2)) * V] = acc1[r];
+        }
+        // the wave's LDS reads of g1 (weight gradient of the mapping layer) before the tile is overwritten with p
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 2
+        for (int ks = 0; ks < 8; ++ks) {
+            float av[2], bv[3];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) av[m] = ga[m * 16 * PWB_LD + ks * 4];
+#pragma unroll
+            for (int n = 0; n < 3; ++n) bv[n] = xbp[slot * XS + n * 8 * PWB_XP + ks * 4];          // [xi ; k]: pairs 0 .. 2 NK - 1
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) dwm[m][n] = mfma16(av[m], bv[n], dwm[m][n]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- p = gxi act'(xi): stays in acc0[0..11] (B operand of the second product), copy to the LDS tile for dWc
+        float pr[NK];
+#pragma unroll
+        for (int r = 0; r < NK; ++r) {
+            const int irow = (r & 3) + 8 * (r >> 2);
+            const float pv = vin ? acc0[r] * ((lin || xo[r] > 0.f) ? dp : xo[r] + dq) : 0.f;
+            pr[r] = pv;
+            G[(irow + 4 * h) * PWB_LD + c] = pv;
+            dbc[r] += pv;
+        }
+        f32x16 acc2, acc3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = acc3[r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < NK; ++r) acc2 = mfma32(wc[0][r], pr[r], acc2);
+#pragma unroll
+        for (int r = 0; r < NK; ++r) acc3 = mfma32(wc[1][r], pr[r], acc3);
+        float uo[NK];
+        if (xact) {
+#pragma unroll
+            for (int r = 0; r < NK; ++r) {
+                const int irow = (r & 3) + 8 * (r >> 2);
+                uo[r] = Xc[(2 * NK + (irow >> 1) + 2 * h) * PWB_XP + (irow & 1) * 32 + c];          // u: pairs 2 NK .. 3 NK - 1
+            }
+        }
+        float *gu_l = a.gu + (size_t)b * C * V + (hoff4V + v), *gt_l = a.gt + (size_t)b * C * V + (hoff4V + v);
+        if (vin) {
+#pragma unroll
+            for (int r = 0; r < NK; ++r) {
+                float gv = acc2[r];
+                if (xact) gv *= uo[r] > 0.f ? xp : uo[r] + xq;
+                gu_l[(size_t)((r & 3) + 8 * (r >> 2)) * V] = gv;
+            }
+#pragma unroll
+            for (int r = 12; r < 16; ++r) gt_l[(size_t)((r & 3) + 8 * (r >> 2) - 24) * V] = acc2[r];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) gt_l[(size_t)(8 + (r & 3) + 8 * (r >> 2)) * V] = acc3[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 2
+        for (int ks = 0; ks < 8; ++ks) {
+            float av[2], bv[3];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) av[m] = ga[m * 16 * PWB_LD + ks * 4];
+#pragma unroll
+            for (int n = 0; n < 3; ++n) bv[n] = xbp[slot * XS + (2 * NK + n * 8) * PWB_XP + ks * 4];   // [u ; t]: pairs 2 NK .. 4 NK - 1
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) dwc[m][n] = mfma16(av[m], bv[n], dwc[m][n]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    {
+        constexpr int n1 = C * CIN + C, n = 2 * n1;
+        __syncthreads();
+        float *mine = lds + (size_t)wave * n;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int nn = 0; nn < 3; ++nn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = m * 16 + (lane >> 4) * 4 + r, i = nn * 16 + (lane & 15);
+                    if (o < C) {
+                        mine[o * CIN + i] = dwm[m][nn][r];
+                        mine[n1 + o * CIN + i] = dwc[m][nn][r];
+                    }
+                }
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            float s1 = dbm[ks], s2 = dbc[ks];
+            for (int off2 = 16; off2 >= 1; off2 >>= 1) {
+                s1 += __shfl_xor(s1, off2);
+                s2 += __shfl_xor(s2, off2);
+            }
+            if (c == 0) {
+                mine[C * CIN + 2 * ks + h] = s1;                                       // g1 rows are pairs 2 ks + h
+                mine[n1 + C * CIN + (ks & 3) + 8 * (ks >> 2) + 4 * h] = s2;             // p rows are accumulator rows
+            }
+        }
+        block_sum_to_slab(lds, n, a.partials + (size_t)blockIdx.x * n, threadIdx.x, NW);
+    }
+}
+
 // dynamic LDS of pwconv_bwd_fast_kernel<COUT, CA, CB, NW, BR>: per wave G (rows of 16) + x (ring of two DMA slots, or one padded tile with
 // the fused branch) + P; never less than the slab staging of its epilogue
 template <int COUT, int CA, int CB, int BR>
@@ -1543,6 +1776,46 @@ extern "C" int hno_pwconv_fwd_chain(const float *u, const float *t, const float 
     else hipLaunchKernelGGL((pwconv_fwd_chain_kernel<24, 4>), dim3((int)grid), dim3(256), fl, fs, a);
     HNO_CHECK_LAUNCH();
     return HNO_OK;
+}
+
+// backward of hno_pwconv_fwd_chain in one pass (pwconv_bwd_chain_kernel): gn = gradient of xn; -> gu, gt, gk and
+// grads = [dWm (C, 2C) | dbm (C) | dWc (C, 2C) | dbc (C)] (one flat buffer).  xa_act: activation whose output u is (its derivative is
+// applied to gu), as hno_pwconv_bwd's.  workspace: hno_pwconv_bwd_chain_workspace_bytes(C).  bit 8 of xa_act: defer the slab reduction.
+extern "C" size_t hno_pwconv_bwd_chain_workspace_bytes(int C) { return sizeof(float) * 256 * 2 * ((size_t)C * 2 * C + C); }
+extern "C" int hno_pwconv_bwd_chain(const float *gn, const float *xn, const float *xi, const float *k, const float *u, const float *t,
+                                    const float *Wm, const float *Wc, float *gu, float *gt, float *gk, float *grads, void *workspace,
+                                    int B, int C, long long V, int act, int xa_act, void *stream) {
+    HNO_REQUIRE(gn && xn && xi && k && u && t && Wm && Wc && gu && gt && gk && grads && workspace && B > 0 && V > 0,
+                "hno_pwconv_bwd_chain: bad argument");
+    if (C != 24) return fail(HNO_ELIMIT, "hno_pwconv_bwd_chain: only 24-channel blocks are built (got %d)", C);
+    if (V * 8 >= (1ll << 32) || ((V + 31) / 32) * B >= (1ll << 31))
+        return fail(HNO_ELIMIT, "hno_pwconv_bwd_chain: V=%lld voxels per channel exceeds the 32-bit offset range", V);
+    const int defer_bit = (xa_act >> 8) & 1;
+    PwChainBwdArgs a;
+    a.gn = gn; a.xn = xn; a.xi = xi; a.k = k; a.u = u; a.t = t; a.Wm = Wm; a.Wc = Wc; a.gu = gu; a.gt = gt; a.gk = gk;
+    a.partials = (float *)workspace; a.B = B; a.V = (unsigned)V; a.act = act & 0xfff; a.xa_act = xa_act & 0xff; a.dbg = debug_flags();
+    constexpr int NW = 4;
+    const long long ntiles = ((V + 31) / 32) * B, ngroups = (ntiles + NW - 1) / NW;
+    int grid = (int)(ngroups < 256 ? ngroups : 256);          // one 4-wave workgroup per CU (35 KB of LDS per wave)
+    hipStream_t s = (hipStream_t)stream;
+    const size_t per_wave = (size_t)(32 * PWB_LD + 2 * 48 * PWB_XP) * sizeof(float);
+    const int n = 2 * (C * 2 * C + C);
+    size_t ldsb = NW * per_wave;
+    if (ldsb < (size_t)NW * n * sizeof(float)) ldsb = (size_t)NW * n * sizeof(float);
+    static int attr = -1;
+    if (attr != current_device()) {
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)pwconv_bwd_chain_kernel<24, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = current_device();
+    }
+    {
+        ProfScope ps(KID_PWCONV_BWD, s, 4.0 * B * (double)V * 9 * C);
+        hipLaunchKernelGGL((pwconv_bwd_chain_kernel<24, NW>), dim3(grid), dim3(64 * NW), ldsb, s, a);
+        HNO_CHECK_LAUNCH();
+    }
+    const int prev = hno_set_defer_reduce(0);
+    struct Restore { int v; ~Restore() { hno_set_defer_reduce(v); } } restore{prev};
+    hno_set_defer_reduce(defer_bit ? 1 : prev);
+    return reduce_partials_launch(a.partials, grid, n, grads, n, nullptr, s);
 }
 
 extern "C" size_t hno_pwconv_bwd_branch_workspace_bytes(int Ca, int Cb, int Cout) {

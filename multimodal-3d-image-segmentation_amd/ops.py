@@ -1537,11 +1537,31 @@ class XSBlockFn(_HnoFunction):
         if g_out is None:
             raise _lib.HnoError('XSBlockFn.backward: no gradient for the block output')
         d_nmap_w = d_nmap_b = g_nskip = None
+        chain_fused = False
         if ctx.chain:
-            # g_out is the gradient of xn = act(Wm [out ; nskip] + bm): through the next block's mapping convolution first
+            # g_out is the gradient of xn = act(Wm [out ; nskip] + bm).  One pass through both pointwise layers (hno_pwconv_bwd_chain:
+            # the gradient between them never reaches memory); HNO_PW_CHAIN_BWD=0: the two layers apart (A/B)
             late_nmap = lp and _deferrable(nmap_w, nmap_b)
-            g_out, g_nskip, d_nmap_w, d_nmap_b = pwconv_bwd_raw(to_layout(g_out, chan_stride(xn)), xn, out, nskip, nmap_w, act, nmap_b is not None,
-                                                               True, True, defer=late_nmap, bias=nmap_b, bf16=False)
+            ld_n = chan_stride(xn)
+            C = int(cat_w.shape[0])
+            if os.environ.get('HNO_PW_CHAIN_BWD', '1') != '0' and g_pass is None and chan_stride(u) == ld_n == chan_stride(xm):
+                L = _lib.lib()
+                gn = to_layout(g_out, ld_n)
+                g_u, g_skipin, g_nskip = act_like(u), act_like(xm), act_like(nskip)
+                n1 = C * 2 * C + C
+                flat = torch.empty(2 * n1, device=u.device, dtype=torch.float32)
+                ws = torch.empty(L.hno_pwconv_bwd_chain_workspace_bytes(C) // 4, device=u.device, dtype=torch.float32)
+                with _DeferReduce(late_nmap and late_cat) as d:
+                    check(L.hno_pwconv_bwd_chain(ptr(gn), ptr(xn), ptr(out), ptr(nskip), ptr(u), ptr(xm), ptr(nmap_w), ptr(cat_w), ptr(g_u), ptr(g_skipin),
+                                                 ptr(g_nskip), ptr(flat), ptr(ws), x.shape[0], C, ld_n or _flat_v(xn), act, act | d.bit, stream_ptr()),
+                          'hno_pwconv_bwd_chain')
+                    d.keep(ws)
+                d_nmap_w, d_nmap_b = flat[:C * 2 * C].view_as(nmap_w), (flat[C * 2 * C:n1] if nmap_b is not None else None)
+                d_cat_w, d_cat_b = flat[n1:n1 + C * 2 * C].view_as(cat_w), (flat[n1 + C * 2 * C:] if cat_has_b else None)
+                chain_fused = True
+            else:
+                g_out, g_nskip, d_nmap_w, d_nmap_b = pwconv_bwd_raw(to_layout(g_out, ld_n), xn, out, nskip, nmap_w, act, nmap_b is not None,
+                                                                   True, True, defer=late_nmap, bias=nmap_b, bf16=False)
             if g_nskip is not None:
                 g_nskip._hno_private = True      # fresh buffer of ours: the encoder block that owns the skip may accumulate into it
         # The passthrough gradient is accumulated IN PLACE into the buffer autograd handed us only when that buffer is
@@ -1561,8 +1581,9 @@ class XSBlockFn(_HnoFunction):
         # a mapping conv the block input IS xm: the passthrough gradient is accumulated into the concat-path
         # gradient by the same kernel (gxb += ...).
         fuse_pass = private and not has_map
-        g_u, g_skipin, d_cat_w, d_cat_b = pwconv_bwd_raw(to_layout(g_out, ld), out, u, xm, cat_w, act, cat_has_b, xa_act=act,
-                                                         accumulate_into=(None, g_pass) if fuse_pass else None, defer=late_cat, bias=cat_b, bf16=ctx.bf16)
+        if not chain_fused:
+            g_u, g_skipin, d_cat_w, d_cat_b = pwconv_bwd_raw(to_layout(g_out, ld), out, u, xm, cat_w, act, cat_has_b, xa_act=act,
+                                                             accumulate_into=(None, g_pass) if fuse_pass else None, defer=late_cat, bias=cat_b, bf16=ctx.bf16)
         if g_pass is not None and not has_map and not fuse_pass:
             g_skipin = plus_pass(g_skipin)
         if spectral_chain_bwd_ok(xm, modes, z0, zs):     # PadInverse^T, the layers' backward and TransformCrop^T + skip gradient
