@@ -38,3 +38,23 @@ def two():
     a = ops.pwconv_fwd_raw(u, t, Wc, bc, ops.ACT_SELU)
     return ops.pwconv_fwd_raw(a, k, Wm, bm, ops.ACT_SELU)
 print(f'two layers {timeit(two):.1f} us, chained {timeit(chain):.1f} us')
+
+# ---- backward
+gn = mk()
+def two_bwd():
+    g_xi, g_k, dwm, dbm = ops.pwconv_bwd_raw(gn, xn_ref, xi_ref, k, Wm, ops.ACT_SELU, True)
+    g_u, g_t, dwc, dbc = ops.pwconv_bwd_raw(g_xi, xi_ref, u, t, Wc, ops.ACT_SELU, True, xa_act=ops.ACT_SELU)
+    return g_u, g_t, g_k, dwm, dbm, dwc, dbc
+ref = two_bwd()
+g_u, g_t, g_k = ops.act_like(u), ops.act_like(u), ops.act_like(u)
+n1 = C * 2 * C + C
+flat = torch.empty(2 * n1, device=dev)
+ws = torch.empty(L.hno_pwconv_bwd_chain_workspace_bytes(C) // 4, device=dev)
+def chain_bwd():
+    pkg._lib.check(L.hno_pwconv_bwd_chain(P(gn), P(xn_ref), P(xi_ref), P(k), P(u), P(t), P(Wm), P(Wc), P(g_u), P(g_t), P(g_k), P(flat), P(ws),
+                                          B, C, ld, ops.ACT_SELU, ops.ACT_SELU, S()), 'chain bwd')
+chain_bwd(); torch.cuda.synchronize()
+rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+print('gu', rel(g_u, ref[0]), 'gt', rel(g_t, ref[1]), 'gk', rel(g_k, ref[2]), 'dWm', rel(flat[:C * 2 * C].view(C, 2 * C), ref[3]), 'dbm', rel(flat[C * 2 * C:n1], ref[4]),
+      'dWc', rel(flat[n1:n1 + C * 2 * C].view(C, 2 * C), ref[5]), 'dbc', rel(flat[n1 + C * 2 * C:], ref[6]))
+print(f'backward: two layers {timeit(two_bwd):.1f} us, chained {timeit(chain_bwd):.1f} us')
