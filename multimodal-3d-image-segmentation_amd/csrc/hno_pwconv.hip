@@ -1757,8 +1757,9 @@ extern "C" int hno_pwconv_fwd_chain(const float *u, const float *t, const float 
     a.u = u; a.t = t; a.k = k; a.Wc = Wc; a.bc = bc; a.Wm = Wm; a.bm = bm; a.xi = xi; a.xn = xn;
     a.B = B; a.V = (unsigned)V; a.act = act & 0xfff; a.dbg = debug_flags();
     const long long ntiles = ((V + 31) / 32) * B;
-    static const int nw_env = getenv("HNO_PWCHAIN_WAVES") ? atoi(getenv("HNO_PWCHAIN_WAVES")) : 8;      // tuning aid: 4 or 8
-    const int nw = nw_env == 4 ? 4 : 8;
+    // two 4-wave workgroups per CU (63.3 us at 2 x 24 x 65^3) or one of 8 waves (67.7 us): HNO_PWCHAIN_WAVES=8 selects the latter (A/B)
+    static const int nw_env = getenv("HNO_PWCHAIN_WAVES") ? atoi(getenv("HNO_PWCHAIN_WAVES")) : 4;
+    const int nw = nw_env == 8 ? 8 : 4;
     long long grid = (ntiles + nw - 1) / nw;
     const long long cap = nw == 4 ? 512 : 256;
     if (grid > cap) grid = cap;
