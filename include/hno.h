@@ -206,17 +206,19 @@ int hno_pwconv_fwd_branch(const float *s, const float *xb, const float *Wbr, con
  * ends HNO-XS block i and the mapping_conv over cat[block output, U-Net skip] that opens decoder block i + 1 (nets/hnosegxs.py:161-162,
  * 253-255, 274-275).  xi is written for the backward but never read back: 5 activation streams instead of 6.  (B, 24, V) tensors
  * (V may be the channel stride of channel-padded activations), Wc / Wm (24, 48); other widths: HNO_ELIMIT (callers run the two layers). */
-int hno_pwconv_fwd_chain_supported(int C);
+int hno_pwconv_fwd_chain_supported(int C, int C2, int has_k);
+/* C2 = 24 with k: the next block's mapping_conv (act2 = act);  C2 = 4, k = bm = NULL: the model's conv_out (nets/hnosegxs.py:178, 24 ->
+ * out_channels, no bias, act2 none) behind the LAST block's conv_concat; xn (B, C2, V), Wm (C2, 48 or 24) */
 int hno_pwconv_fwd_chain(const float *u, const float *t, const float *k, const float *Wc, const float *bc, const float *Wm,
-                         const float *bm, float *xi, float *xn, int B, int C, long long V, int act, void *stream);
+                         const float *bm, float *xi, float *xn, int B, int C, int C2, long long V, int act, int act2, void *stream);
 /* backward of the pair in one pass: gn = gradient of xn -> gu (times xa_act'(u): u is the output of that activation), gt, gk and
- * grads = [dWm (24, 48) | dbm (24) | dWc (24, 48) | dbc (24)] in one flat buffer.  9 activation streams instead of 12: the gradient
- * between the two layers never reaches memory.  workspace: hno_pwconv_bwd_chain_workspace_bytes(C); bit 8 of xa_act defers the slab
- * reduction (hno_set_defer_reduce). */
+ * grads = [dWm (C2, 48 | 24) | dbm (C2) | dWc (24, 48) | dbc (24)] in one flat buffer.  9 activation streams instead of 12 (5 + 2 x 4 ch
+ * instead of 8 for the conv_out form): the gradient between the two layers never reaches memory.  k / gk NULL for the conv_out form.
+ * workspace: hno_pwconv_bwd_chain_workspace_bytes(C); bit 8 of xa_act defers the slab reduction (hno_set_defer_reduce). */
 size_t hno_pwconv_bwd_chain_workspace_bytes(int C);
 int hno_pwconv_bwd_chain(const float *gn, const float *xn, const float *xi, const float *k, const float *u, const float *t,
                          const float *Wm, const float *Wc, float *gu, float *gt, float *gk, float *grads, void *workspace, int B, int C,
-                         long long V, int act, int xa_act, void *stream);
+                         int C2, long long V, int act, int act2, int xa_act, void *stream);
 size_t hno_pwconv_bwd_branch_workspace_bytes(int Ca, int Cb, int Cout);
 int hno_pwconv_bwd_branch(const float *gy, const float *y, const float *xa, int Ca, const float *xb, int Cb,
                           const float *W, const float *Wbr, float *p_out, float *gxb, float *dflat, void *workspace,

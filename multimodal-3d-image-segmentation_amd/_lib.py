@@ -51,10 +51,10 @@ SIGNATURES = {
     'hno_pwconv_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_int, c_int, c_void_p]),
     'hno_pwconv_fwd_branch': (c_int, [c_void_p] * 8 + [c_int] * 4 + [c_ll, c_int, c_void_p]),
-    'hno_pwconv_fwd_chain_supported': (c_int, [c_int]),
-    'hno_pwconv_fwd_chain': (c_int, [c_void_p] * 9 + [c_int, c_int, c_ll, c_int, c_void_p]),
+    'hno_pwconv_fwd_chain_supported': (c_int, [c_int] * 3),
+    'hno_pwconv_fwd_chain': (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_ll, c_int, c_int, c_void_p]),
     'hno_pwconv_bwd_chain_workspace_bytes': (c_size_t, [c_int]),
-    'hno_pwconv_bwd_chain': (c_int, [c_void_p] * 13 + [c_int, c_int, c_ll, c_int, c_int, c_void_p]),
+    'hno_pwconv_bwd_chain': (c_int, [c_void_p] * 13 + [c_int, c_int, c_int, c_ll, c_int, c_int, c_int, c_void_p]),
     'hno_pwconv_bwd_branch_workspace_bytes': (c_size_t, [c_int] * 3),
     'hno_pwconv_bwd_branch': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 6 + [c_int, c_int, c_ll, c_int, c_int, c_void_p]),
     'hno_cmix_compose': (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p]),

@@ -654,14 +654,17 @@ struct PwChainArgs {
     float *xi, *xn;
     int B;
     unsigned V;
-    int act;
+    int act, act2;
     int dbg;
 };
 
-template <int C, int NWV>
+// C2 / HASK: the second layer has C2 output channels and (HASK) a second input k of C channels.  <24, 24, true>: the next block's
+// mapping_conv; <24, 4, false>: the model's conv_out (24 -> out_channels, no bias, no activation: a.act2) behind the LAST block.
+template <int C, int NWV, int C2 = C, bool HASK = true>
 __global__ __launch_bounds__(64 * NWV) void pwconv_fwd_chain_kernel(PwChainArgs a) {
-    static_assert(C % 8 == 0 && C <= 32, "one 32-row tile per product");
-    constexpr int NW = NWV, NK = C / 2, CIN = 2 * C, NDMA = 3 * NK;
+    static_assert(C % 8 == 0 && C <= 32 && C2 <= 32 && (C2 % 8 == 0 || C2 == 4), "one 32-row tile per product");
+    constexpr int NW = NWV, NK = C / 2, CIN = 2 * C, NDMA = (HASK ? 3 : 2) * NK, CIN2 = HASK ? 2 * C : C;
+    constexpr int NR2 = C2 >= 8 ? C2 / 2 : C2;        // accumulator registers of the second product that hold rows < C2 (C2 = 4: rows 0..3, h = 0 lanes)
     extern __shared__ float pwf_ring[];      // NW x 2 slots x NDMA x 64 floats
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -674,15 +677,17 @@ __global__ __launch_bounds__(64 * NWV) void pwconv_fwd_chain_kernel(PwChainArgs 
     for (int ks = 0; ks < NK; ++ks) {
         wcu[ks] = c < C ? a.Wc[(size_t)c * CIN + 2 * ks + h] : 0.f;
         wct[ks] = c < C ? a.Wc[(size_t)c * CIN + C + 2 * ks + h] : 0.f;
-        wmk[ks] = c < C ? a.Wm[(size_t)c * CIN + C + 2 * ks + h] : 0.f;
+        wmk[ks] = (HASK && c < C2) ? a.Wm[(size_t)c * CIN2 + C + 2 * ks + h] : 0.f;
         const int ch = (ks & 3) + 8 * (ks >> 2) + 4 * h;
-        wmx[ks] = c < C ? a.Wm[(size_t)c * CIN + ch] : 0.f;
+        wmx[ks] = c < C2 ? a.Wm[(size_t)c * CIN2 + ch] : 0.f;
         b1[ks] = a.bc ? a.bc[ch] : 0.f;
-        b2[ks] = a.bm ? a.bm[ch] : 0.f;
+        b2[ks] = (a.bm && ch < C2) ? a.bm[ch] : 0.f;
     }
     const float ap = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f;
     const float aq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
     const bool lin = a.act == HNO_ACT_NONE;
+    const float ap2 = a.act2 == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f, aq2 = a.act2 == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
+    const bool lin2 = a.act2 == HNO_ACT_NONE;
     const unsigned tiles_per_b = (V + 31) / 32;
     const unsigned ntiles = tiles_per_b * a.B;
     const unsigned hoffV = h ? V : 0u, hoff4V = h ? 4u * V : 0u;
@@ -694,13 +699,15 @@ __global__ __launch_bounds__(64 * NWV) void pwconv_fwd_chain_kernel(PwChainArgs 
         const unsigned b = t / tiles_per_b;
         const unsigned v = (t - b * tiles_per_b) * 32 + c;
         const unsigned boff = (hoffV + (v < V ? v : 0u)) * 4u;
-        const float *u_b = a.u + (size_t)b * C * V, *t_b = a.t + (size_t)b * C * V, *k_b = a.k + (size_t)b * C * V;
+        const float *u_b = a.u + (size_t)b * C * V, *t_b = a.t + (size_t)b * C * V, *k_b = HASK ? a.k + (size_t)b * C * V : a.u;
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) dma_row_pair(u_b + (size_t)(2 * ks) * V, boff, __builtin_amdgcn_readfirstlane(ring_b + (slot * NDMA + ks) * 256));
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) dma_row_pair(t_b + (size_t)(2 * ks) * V, boff, __builtin_amdgcn_readfirstlane(ring_b + (slot * NDMA + NK + ks) * 256));
+        if constexpr (HASK) {
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks) dma_row_pair(k_b + (size_t)(2 * ks) * V, boff, __builtin_amdgcn_readfirstlane(ring_b + (slot * NDMA + 2 * NK + ks) * 256));
+            for (int ks = 0; ks < NK; ++ks) dma_row_pair(k_b + (size_t)(2 * ks) * V, boff, __builtin_amdgcn_readfirstlane(ring_b + (slot * NDMA + 2 * NK + ks) * 256));
+        }
     };
     unsigned t = blockIdx.x * NW + wave;
     if (t < ntiles) issue(t, 0);
@@ -720,7 +727,7 @@ __global__ __launch_bounds__(64 * NWV) void pwconv_fwd_chain_kernel(PwChainArgs 
         for (int ks = 0; ks < NK; ++ks) {
             uv[ks] = sl[ks * 64];
             tv[ks] = sl[(NK + ks) * 64];
-            kv[ks] = sl[(2 * NK + ks) * 64];
+            kv[ks] = HASK ? sl[(2 * NK + ks) * 64] : 0.f;
         }
         f32x16 acc;
 #pragma unroll
@@ -753,28 +760,26 @@ __global__ __launch_bounds__(64 * NWV) void pwconv_fwd_chain_kernel(PwChainArgs 
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int r = 0; r < NK; ++r) acc = mfma32(wmx[r], xi[r], acc);
+        if constexpr (HASK) {
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks) acc = mfma32(wmk[ks], kv[ks], acc);
-        float xn[NK];
+            for (int ks = 0; ks < NK; ++ks) acc = mfma32(wmk[ks], kv[ks], acc);
+        }
+        float xn[NR2];
 #pragma unroll
-        for (int r = 0; r < NK; ++r) xn[r] = acc[r] + b2[r];
-        if (!lin) {
+        for (int r = 0; r < NR2; ++r) xn[r] = acc[r] + b2[r];
+        if (!lin2) {
 #pragma unroll
-            for (int r = 0; r < NK; ++r) {
+            for (int r = 0; r < NR2; ++r) {
                 float e = neg_expm1(xn[r]);
                 asm volatile("" : "+v"(e));
-                xn[r] = xn[r] > 0.f ? ap * xn[r] : aq * e;
+                xn[r] = xn[r] > 0.f ? ap2 * xn[r] : aq2 * e;
             }
         }
-        float *xn_l = a.xn + (size_t)b * C * V + (hoff4V + v);
-        if (full) {
+        float *xn_l = a.xn + (size_t)b * C2 * V + (hoff4V + v);
+        const bool hok = C2 >= 8 || h == 0;           // C2 = 4: the rows live on the h = 0 lanes only
 #pragma unroll
-            for (int r = 0; r < NK; ++r) xn_l[(size_t)((r & 3) + 8 * (r >> 2)) * V] = xn[r];
-        } else {
-#pragma unroll
-            for (int r = 0; r < NK; ++r)
-                if (vin) xn_l[(size_t)((r & 3) + 8 * (r >> 2)) * V] = xn[r];
-        }
+        for (int r = 0; r < NR2; ++r)
+            if (vin && hok) xn_l[(size_t)((r & 3) + 8 * (r >> 2)) * V] = xn[r];
     }
 }
 
@@ -1203,17 +1208,21 @@ struct PwChainBwdArgs {
     float *partials;                           // per workgroup: [dWm C x 2C | dbm C | dWc C x 2C | dbc C]
     int B;
     unsigned V;
-    int act, xa_act, dbg;
+    int act, act2, xa_act, dbg;
 };
 
-template <int C, int NW>
+// C2 / HASK as pwconv_fwd_chain_kernel's: <24, NW, 24, true> mapping_conv behind conv_concat; <24, NW, 4, false> the model's conv_out
+// (no second input, no bias; its activation a.act2 is none) behind the last block's conv_concat.
+template <int C, int NW, int C2 = C, bool HASK = true>
 __global__ __launch_bounds__(64 * NW, 1) void pwconv_bwd_chain_kernel(PwChainBwdArgs a) {
     static_assert(C == 24, "accumulator-row bookkeeping below is written for 24 channels");
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, c = lane & 31;
-    constexpr int CIN = 2 * C, NK = C / 2, NPAIR = 4 * NK;            // row pairs per slot: xi, k, u, t
+    constexpr int CIN = 2 * C, NK = C / 2, NT = HASK ? 4 : 3, NPAIR = NT * NK;   // row pairs per slot: xi, (k,) u, t
+    constexpr int CIN2 = HASK ? 2 * C : C, NK2 = C2 / 2, UP = (HASK ? 2 : 1) * NK;   // second layer: inputs, k-slots of g1; first pair of u
+    constexpr int MT2 = (C2 + 15) / 16, NTI2 = (CIN2 + 15) / 16;      // weight-gradient tiles of the second layer
     constexpr int XS = NPAIR * PWB_XP;                                // floats per slot
     constexpr int WAVE_FLOATS = 32 * PWB_LD + 2 * XS;
     float *G = lds + (size_t)wave * WAVE_FLOATS;                      // [o][v]: g1, later p
@@ -1222,24 +1231,32 @@ __global__ __launch_bounds__(64 * NW, 1) void pwconv_bwd_chain_kernel(PwChainBwd
     // A operands of the two input-gradient products.  First: Wm^T, rows i = 32 ic + c, k-slots = output channels 2 ks + h (g1 sits in
     // registers as row pairs).  Second: Wc^T, rows i, k-slot r of lane half h = channel (r & 3) + 8 (r >> 2) + 4 h (p sits in the first
     // product's accumulator registers).
-    float wm[2][NK], wc[2][NK];
+    float wm[2][NK2], wc[2][NK];
 #pragma unroll
-    for (int ic = 0; ic < 2; ++ic)
+    for (int ic = 0; ic < 2; ++ic) {
+        const int i = ic * 32 + c;
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks) {
-            const int i = ic * 32 + c;
-            wm[ic][ks] = i < CIN ? a.Wm[(size_t)(2 * ks + h) * CIN + i] : 0.f;
-            wc[ic][ks] = i < CIN ? a.Wc[(size_t)((ks & 3) + 8 * (ks >> 2) + 4 * h) * CIN + i] : 0.f;
-        }
+        for (int ks = 0; ks < NK2; ++ks) wm[ic][ks] = i < CIN2 ? a.Wm[(size_t)(2 * ks + h) * CIN2 + i] : 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) wc[ic][ks] = i < CIN ? a.Wc[(size_t)((ks & 3) + 8 * (ks >> 2) + 4 * h) * CIN + i] : 0.f;
+    }
     for (int i = lane; i < WAVE_FLOATS; i += 64) G[i] = 0.f;
-    float dbm[NK], dbc[NK];
+    float dbm[NK2], dbc[NK];
 #pragma unroll
-    for (int ks = 0; ks < NK; ++ks) dbm[ks] = dbc[ks] = 0.f;
-    f32x4 dwm[2][3], dwc[2][3];
+    for (int ks = 0; ks < NK2; ++ks) dbm[ks] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) dbc[ks] = 0.f;
+    f32x4 dwm[MT2][NTI2], dwc[2][3];
+#pragma unroll
+    for (int m = 0; m < MT2; ++m)
+#pragma unroll
+        for (int n = 0; n < NTI2; ++n) dwm[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 3; ++n) dwm[m][n] = dwc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < 3; ++n) dwc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float dp2 = a.act2 == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f, dq2 = a.act2 == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
+    const bool lin2 = a.act2 == HNO_ACT_NONE;
     const float dp = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f, dq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
     const bool lin = a.act == HNO_ACT_NONE;
     const float xp = a.xa_act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f, xq = a.xa_act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
@@ -1251,7 +1268,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pwconv_bwd_chain_kernel(PwChainBwd
     const float *ga = G + (lane & 15) * PWB_LD + (lane >> 4);
     const float *xbp = X + ((lane & 15) >> 1) * PWB_XP + (lane & 1) * 32 + (lane >> 4);      // + slot XS + tensor-pair offset + n 8 XP + 4 ks
     const unsigned x_lds = (unsigned)(size_t)X;
-    float pg[NK], py[NK];
+    float pg[NK2], py[NK2] = {};
     auto fetch = [&](unsigned grp, int slot) {
         const unsigned t = grp * NW + wave;
         const bool live = t < ntiles;
@@ -1259,18 +1276,21 @@ __global__ __launch_bounds__(64 * NW, 1) void pwconv_bwd_chain_kernel(PwChainBwd
         const unsigned v = live ? (t - b * tiles_per_b) * 32 + c : 0u;
         const unsigned off = hoffV + ((live && v < V) ? v : 0u);
         const size_t bo = (size_t)b * C * V;
-        const float *srcs[4] = {a.xi + bo, a.k + bo, a.u + bo, a.t + bo};
+        const float *srcs[4] = {a.xi + bo, HASK ? a.k + bo : a.u + bo, HASK ? a.u + bo : a.t + bo, a.t + bo};
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NT; ++q)
 #pragma unroll
             for (int j = 0; j < NK; ++j)
                 dma_row_pair(srcs[q] + (size_t)(2 * j) * V, off * 4u, __builtin_amdgcn_readfirstlane(x_lds + (slot * XS + (q * NK + j) * PWB_XP) * 4));
         // register loads issued BEHIND the DMAs: the wait hipcc places in front of their first use retires the DMAs too (in-order return)
-        const float *gn_b = a.gn + bo, *xn_b = a.xn + bo;
+        const size_t bo2 = (size_t)b * C2 * V;
+        const float *gn_b = a.gn + bo2, *xn_b = a.xn + bo2;
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks) pg[ks] = (gn_b + (size_t)(2 * ks) * V)[off];
+        for (int ks = 0; ks < NK2; ++ks) pg[ks] = (gn_b + (size_t)(2 * ks) * V)[off];
+        if (!lin2) {
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks) py[ks] = (xn_b + (size_t)(2 * ks) * V)[off];
+            for (int ks = 0; ks < NK2; ++ks) py[ks] = (xn_b + (size_t)(2 * ks) * V)[off];
+        }
     };
     if (blockIdx.x < ngroups) fetch(blockIdx.x, 0);
     int slot = 0;
@@ -1282,10 +1302,10 @@ __global__ __launch_bounds__(64 * NW, 1) void pwconv_bwd_chain_kernel(PwChainBwd
         const unsigned v = live ? (t - b * tiles_per_b) * 32 + c : 0u;
         const bool vin = live && v < V;
         // ---- g1 = gn act'(xn): B operand of the first product (registers), A operand of dWm (LDS tile)
-        float g[NK];
+        float g[NK2];
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks) {
-            const float gv = pg[ks] * ((lin || py[ks] > 0.f) ? dp : py[ks] + dq);
+        for (int ks = 0; ks < NK2; ++ks) {
+            const float gv = pg[ks] * ((lin2 || py[ks] > 0.f) ? dp2 : py[ks] + dq2);
             g[ks] = vin ? gv : 0.f;
             G[(2 * ks + h) * PWB_LD + c] = g[ks];
             dbm[ks] += g[ks];
@@ -1295,9 +1315,11 @@ __global__ __launch_bounds__(64 * NW, 1) void pwconv_bwd_chain_kernel(PwChainBwd
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks) acc0 = mfma32(wm[0][ks], g[ks], acc0);
+        for (int ks = 0; ks < NK2; ++ks) acc0 = mfma32(wm[0][ks], g[ks], acc0);
+        if constexpr (HASK) {
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks) acc1 = mfma32(wm[1][ks], g[ks], acc1);
+            for (int ks = 0; ks < NK2; ++ks) acc1 = mfma32(wm[1][ks], g[ks], acc1);
+        }
         // rows of [gxi ; gk]: acc0 registers 0..11 = gxi rows (r & 3) + 8 (r >> 2) + 4 h; registers 12..15 = gk rows 0..7; acc1 registers
         // 0..7 = gk rows 8..23
         float xo[NK];
@@ -1306,8 +1328,8 @@ __global__ __launch_bounds__(64 * NW, 1) void pwconv_bwd_chain_kernel(PwChainBwd
             const int irow = (r & 3) + 8 * (r >> 2);
             xo[r] = Xc[((irow >> 1) + 2 * h) * PWB_XP + (irow & 1) * 32 + c];                    // xi: pairs 0 .. NK - 1
         }
-        float *gk_l = a.gk + (size_t)b * C * V + (hoff4V + v);
-        if (vin) {
+        float *gk_l = HASK ? a.gk + (size_t)b * C * V + (hoff4V + v) : nullptr;
+        if (HASK && vin) {
 #pragma unroll
             for (int r = 12; r < 16; ++r) gk_l[(size_t)((r & 3) + 8 * (r >> 2) - 24) * V] = acc0[r];
 #pragma unroll
@@ -1318,15 +1340,15 @@ __global__ __launch_bounds__(64 * NW, 1) void pwconv_bwd_chain_kernel(PwChainBwd
         __builtin_amdgcn_wave_barrier();
 #pragma unroll 2
         for (int ks = 0; ks < 8; ++ks) {
-            float av[2], bv[3];
+            float av[MT2], bv[NTI2];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) av[m] = ga[m * 16 * PWB_LD + ks * 4];
+            for (int m = 0; m < MT2; ++m) av[m] = ga[m * 16 * PWB_LD + ks * 4];
 #pragma unroll
-            for (int n = 0; n < 3; ++n) bv[n] = xbp[slot * XS + n * 8 * PWB_XP + ks * 4];          // [xi ; k]: pairs 0 .. 2 NK - 1
+            for (int n = 0; n < NTI2; ++n) bv[n] = xbp[slot * XS + n * 8 * PWB_XP + ks * 4];       // [xi (; k)]: pairs 0 ..; columns >= CIN2 dropped below
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MT2; ++m)
 #pragma unroll
-                for (int n = 0; n < 3; ++n) dwm[m][n] = mfma16(av[m], bv[n], dwm[m][n]);
+                for (int n = 0; n < NTI2; ++n) dwm[m][n] = mfma16(av[m], bv[n], dwm[m][n]);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1352,7 +1374,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pwconv_bwd_chain_kernel(PwChainBwd
 #pragma unroll
             for (int r = 0; r < NK; ++r) {
                 const int irow = (r & 3) + 8 * (r >> 2);
-                uo[r] = Xc[(2 * NK + (irow >> 1) + 2 * h) * PWB_XP + (irow & 1) * 32 + c];          // u: pairs 2 NK .. 3 NK - 1
+                uo[r] = Xc[(UP + (irow >> 1) + 2 * h) * PWB_XP + (irow & 1) * 32 + c];          // u: pairs UP .. UP + NK - 1
             }
         }
         float *gu_l = a.gu + (size_t)b * C * V + (hoff4V + v), *gt_l = a.gt + (size_t)b * C * V + (hoff4V + v);
@@ -1376,7 +1398,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pwconv_bwd_chain_kernel(PwChainBwd
 #pragma unroll
             for (int m = 0; m < 2; ++m) av[m] = ga[m * 16 * PWB_LD + ks * 4];
 #pragma unroll
-            for (int n = 0; n < 3; ++n) bv[n] = xbp[slot * XS + (2 * NK + n * 8) * PWB_XP + ks * 4];   // [u ; t]: pairs 2 NK .. 4 NK - 1
+            for (int n = 0; n < 3; ++n) bv[n] = xbp[slot * XS + (UP + n * 8) * PWB_XP + ks * 4];   // [u ; t]: pairs UP .. UP + 2 NK - 1
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1386,9 +1408,18 @@ __global__ __launch_bounds__(64 * NW, 1) void pwconv_bwd_chain_kernel(PwChainBwd
         __builtin_amdgcn_wave_barrier();
     }
     {
-        constexpr int n1 = C * CIN + C, n = 2 * n1;
+        constexpr int n1 = C2 * CIN2 + C2, n = n1 + C * CIN + C;            // [dWm | dbm | dWc | dbc]
         __syncthreads();
         float *mine = lds + (size_t)wave * n;
+#pragma unroll
+        for (int m = 0; m < MT2; ++m)
+#pragma unroll
+            for (int nn = 0; nn < NTI2; ++nn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = m * 16 + (lane >> 4) * 4 + r, i = nn * 16 + (lane & 15);
+                    if (o < C2 && i < CIN2) mine[o * CIN2 + i] = dwm[m][nn][r];
+                }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1396,22 +1427,19 @@ __global__ __launch_bounds__(64 * NW, 1) void pwconv_bwd_chain_kernel(PwChainBwd
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int o = m * 16 + (lane >> 4) * 4 + r, i = nn * 16 + (lane & 15);
-                    if (o < C) {
-                        mine[o * CIN + i] = dwm[m][nn][r];
-                        mine[n1 + o * CIN + i] = dwc[m][nn][r];
-                    }
+                    if (o < C) mine[n1 + o * CIN + i] = dwc[m][nn][r];
                 }
 #pragma unroll
+        for (int ks = 0; ks < NK2; ++ks) {
+            float s1 = dbm[ks];
+            for (int off2 = 16; off2 >= 1; off2 >>= 1) s1 += __shfl_xor(s1, off2);
+            if (c == 0) mine[C2 * CIN2 + 2 * ks + h] = s1;                              // g1 rows are pairs 2 ks + h
+        }
+#pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
-            float s1 = dbm[ks], s2 = dbc[ks];
-            for (int off2 = 16; off2 >= 1; off2 >>= 1) {
-                s1 += __shfl_xor(s1, off2);
-                s2 += __shfl_xor(s2, off2);
-            }
-            if (c == 0) {
-                mine[C * CIN + 2 * ks + h] = s1;                                       // g1 rows are pairs 2 ks + h
-                mine[n1 + C * CIN + (ks & 3) + 8 * (ks >> 2) + 4 * h] = s2;             // p rows are accumulator rows
-            }
+            float s2 = dbc[ks];
+            for (int off2 = 16; off2 >= 1; off2 >>= 1) s2 += __shfl_xor(s2, off2);
+            if (c == 0) mine[n1 + C * CIN + (ks & 3) + 8 * (ks >> 2) + 4 * h] = s2;    // p rows are accumulator rows
         }
         block_sum_to_slab(lds, n, a.partials + (size_t)blockIdx.x * n, threadIdx.x, NW);
     }
@@ -1746,34 +1774,39 @@ extern "C" int hno_pwconv_fwd_branch(const float *s_in, const float *x, const fl
 
 // xi = act(Wc [u ; t] + bc), xn = act(Wm [xi ; k] + bm): conv_concat of one HNO-XS block and mapping_conv of the next in one pass
 // (pwconv_fwd_chain_kernel).  All tensors (B, 24, V) fp32 (V = the channel stride of channel-padded activations); Wc, Wm (24, 48).
-extern "C" int hno_pwconv_fwd_chain_supported(int C) { return C == 24; }
+extern "C" int hno_pwconv_fwd_chain_supported(int C, int C2, int has_k) { return C == 24 && ((C2 == 24 && has_k) || (C2 == 4 && !has_k)); }
+// C2 = 24 with k (mapping_conv of the next block, activation act2 = act) or C2 = 4 without k (conv_out behind the last block: Wm (4, 24),
+// bm NULL, act2 none); xn (B, C2, V)
 extern "C" int hno_pwconv_fwd_chain(const float *u, const float *t, const float *k, const float *Wc, const float *bc, const float *Wm,
-                                    const float *bm, float *xi, float *xn, int B, int C, long long V, int act, void *stream) {
-    HNO_REQUIRE(u && t && k && Wc && Wm && xi && xn && B > 0 && V > 0, "hno_pwconv_fwd_chain: bad argument");
-    if (C != 24) return fail(HNO_ELIMIT, "hno_pwconv_fwd_chain: only 24-channel blocks are built (got %d)", C);
+                                    const float *bm, float *xi, float *xn, int B, int C, int C2, long long V, int act, int act2, void *stream) {
+    HNO_REQUIRE(u && t && Wc && Wm && xi && xn && B > 0 && V > 0, "hno_pwconv_fwd_chain: bad argument");
+    if (!hno_pwconv_fwd_chain_supported(C, C2, k != nullptr))
+        return fail(HNO_ELIMIT, "hno_pwconv_fwd_chain: 24 -> 24 (with a second input) and 24 -> 4 (without) are built (got %d -> %d)", C, C2);
     if (V * 8 >= (1ll << 32) || ((V + 31) / 32) * B >= (1ll << 31))
         return fail(HNO_ELIMIT, "hno_pwconv_fwd_chain: V=%lld voxels per channel exceeds the 32-bit offset range", V);
     PwChainArgs a;
     a.u = u; a.t = t; a.k = k; a.Wc = Wc; a.bc = bc; a.Wm = Wm; a.bm = bm; a.xi = xi; a.xn = xn;
-    a.B = B; a.V = (unsigned)V; a.act = act & 0xfff; a.dbg = debug_flags();
+    a.B = B; a.V = (unsigned)V; a.act = act & 0xfff; a.act2 = act2 & 0xfff; a.dbg = debug_flags();
     const long long ntiles = ((V + 31) / 32) * B;
     // two 4-wave workgroups per CU (63.3 us at 2 x 24 x 65^3) or one of 8 waves (67.7 us): HNO_PWCHAIN_WAVES=8 selects the latter (A/B)
     static const int nw_env = getenv("HNO_PWCHAIN_WAVES") ? atoi(getenv("HNO_PWCHAIN_WAVES")) : 4;
-    const int nw = nw_env == 8 ? 8 : 4;
+    const int nw = (nw_env == 8 && C2 == 24) ? 8 : 4;
     long long grid = (ntiles + nw - 1) / nw;
     const long long cap = nw == 4 ? 512 : 256;
     if (grid > cap) grid = cap;
     if (debug_flags() >> 8) grid = debug_flags() >> 8;
     hipStream_t fs = (hipStream_t)stream;
-    ProfScope ps(KID_PWCONV_FWD, fs, 4.0 * B * (double)V * 5 * C);
-    const size_t fl = (size_t)nw * 2 * 36 * 256;
+    ProfScope ps(KID_PWCONV_FWD, fs, 4.0 * B * (double)V * ((k ? 4 : 3) * C + C2));
+    const size_t fl = (size_t)nw * 2 * (k ? 36 : 24) * 256;
     static int attr = -1;
     if (attr != current_device()) {
         (void)hipFuncSetAttribute((const void *)pwconv_fwd_chain_kernel<24, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)pwconv_fwd_chain_kernel<24, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)pwconv_fwd_chain_kernel<24, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = current_device();
     }
-    if (nw == 8) hipLaunchKernelGGL((pwconv_fwd_chain_kernel<24, 8>), dim3((int)grid), dim3(512), fl, fs, a);
+    if (C2 == 4) hipLaunchKernelGGL((pwconv_fwd_chain_kernel<24, 4, 4, false>), dim3((int)grid), dim3(256), fl, fs, a);
+    else if (nw == 8) hipLaunchKernelGGL((pwconv_fwd_chain_kernel<24, 8>), dim3((int)grid), dim3(512), fl, fs, a);
     else hipLaunchKernelGGL((pwconv_fwd_chain_kernel<24, 4>), dim3((int)grid), dim3(256), fl, fs, a);
     HNO_CHECK_LAUNCH();
     return HNO_OK;
@@ -1783,34 +1816,41 @@ extern "C" int hno_pwconv_fwd_chain(const float *u, const float *t, const float 
 // grads = [dWm (C, 2C) | dbm (C) | dWc (C, 2C) | dbc (C)] (one flat buffer).  xa_act: activation whose output u is (its derivative is
 // applied to gu), as hno_pwconv_bwd's.  workspace: hno_pwconv_bwd_chain_workspace_bytes(C).  bit 8 of xa_act: defer the slab reduction.
 extern "C" size_t hno_pwconv_bwd_chain_workspace_bytes(int C) { return sizeof(float) * 256 * 2 * ((size_t)C * 2 * C + C); }
+// grads: C2 = 24: [dWm (24, 48) | dbm (24) | dWc (24, 48) | dbc (24)];  C2 = 4 (k, gk NULL): [dWm (4, 24) | dbm (4, unused) | dWc | dbc]
 extern "C" int hno_pwconv_bwd_chain(const float *gn, const float *xn, const float *xi, const float *k, const float *u, const float *t,
                                     const float *Wm, const float *Wc, float *gu, float *gt, float *gk, float *grads, void *workspace,
-                                    int B, int C, long long V, int act, int xa_act, void *stream) {
-    HNO_REQUIRE(gn && xn && xi && k && u && t && Wm && Wc && gu && gt && gk && grads && workspace && B > 0 && V > 0,
-                "hno_pwconv_bwd_chain: bad argument");
-    if (C != 24) return fail(HNO_ELIMIT, "hno_pwconv_bwd_chain: only 24-channel blocks are built (got %d)", C);
+                                    int B, int C, int C2, long long V, int act, int act2, int xa_act, void *stream) {
+    HNO_REQUIRE(gn && xi && u && t && Wm && Wc && gu && gt && grads && workspace && B > 0 && V > 0, "hno_pwconv_bwd_chain: bad argument");
+    HNO_REQUIRE((k != nullptr) == (gk != nullptr), "hno_pwconv_bwd_chain: k and gk go together");
+    HNO_REQUIRE((act2 & 0xfff) == HNO_ACT_NONE || xn, "hno_pwconv_bwd_chain: xn needed for the second layer's activation gradient");
+    if (!hno_pwconv_fwd_chain_supported(C, C2, k != nullptr))
+        return fail(HNO_ELIMIT, "hno_pwconv_bwd_chain: 24 -> 24 (with a second input) and 24 -> 4 (without) are built (got %d -> %d)", C, C2);
     if (V * 8 >= (1ll << 32) || ((V + 31) / 32) * B >= (1ll << 31))
         return fail(HNO_ELIMIT, "hno_pwconv_bwd_chain: V=%lld voxels per channel exceeds the 32-bit offset range", V);
     const int defer_bit = (xa_act >> 8) & 1;
     PwChainBwdArgs a;
-    a.gn = gn; a.xn = xn; a.xi = xi; a.k = k; a.u = u; a.t = t; a.Wm = Wm; a.Wc = Wc; a.gu = gu; a.gt = gt; a.gk = gk;
-    a.partials = (float *)workspace; a.B = B; a.V = (unsigned)V; a.act = act & 0xfff; a.xa_act = xa_act & 0xff; a.dbg = debug_flags();
+    a.gn = gn; a.xn = xn ? xn : gn; a.xi = xi; a.k = k; a.u = u; a.t = t; a.Wm = Wm; a.Wc = Wc; a.gu = gu; a.gt = gt; a.gk = gk;
+    a.partials = (float *)workspace; a.B = B; a.V = (unsigned)V; a.act = act & 0xfff; a.act2 = act2 & 0xfff; a.xa_act = xa_act & 0xff;
+    a.dbg = debug_flags();
     constexpr int NW = 4;
     const long long ntiles = ((V + 31) / 32) * B, ngroups = (ntiles + NW - 1) / NW;
-    int grid = (int)(ngroups < 256 ? ngroups : 256);          // one 4-wave workgroup per CU (35 KB of LDS per wave)
+    int grid = (int)(ngroups < 256 ? ngroups : 256);          // one 4-wave workgroup per CU (30 KB of LDS per wave)
     hipStream_t s = (hipStream_t)stream;
-    const size_t per_wave = (size_t)(32 * PWB_LD + 2 * 48 * PWB_XP) * sizeof(float);
-    const int n = 2 * (C * 2 * C + C);
+    const int nt = k ? 4 : 3, cin2 = k ? 2 * C : C;
+    const size_t per_wave = (size_t)(32 * PWB_LD + 2 * nt * 12 * PWB_XP) * sizeof(float);
+    const int n = C2 * cin2 + C2 + C * 2 * C + C;
     size_t ldsb = NW * per_wave;
     if (ldsb < (size_t)NW * n * sizeof(float)) ldsb = (size_t)NW * n * sizeof(float);
     static int attr = -1;
     if (attr != current_device()) {
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)pwconv_bwd_chain_kernel<24, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)pwconv_bwd_chain_kernel<24, NW, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = current_device();
     }
     {
-        ProfScope ps(KID_PWCONV_BWD, s, 4.0 * B * (double)V * 9 * C);
-        hipLaunchKernelGGL((pwconv_bwd_chain_kernel<24, NW>), dim3(grid), dim3(64 * NW), ldsb, s, a);
+        ProfScope ps(KID_PWCONV_BWD, s, 4.0 * B * (double)V * ((k ? 7 : 5) * C + 2 * C2));
+        if (C2 == 4) hipLaunchKernelGGL((pwconv_bwd_chain_kernel<24, NW, 4, false>), dim3(grid), dim3(64 * NW), ldsb, s, a);
+        else hipLaunchKernelGGL((pwconv_bwd_chain_kernel<24, NW>), dim3(grid), dim3(64 * NW), ldsb, s, a);
         HNO_CHECK_LAUNCH();
     }
     const int prev = hno_set_defer_reduce(0);

@@ -156,11 +156,12 @@ class HNOXSBlock(nn.Module):
             mc = self.mapping_conv.op if (self.mapping_conv is not None and not premapped) else None
             assert mc is not None or skip is None
             cc = self.conv_concat.op
-            nm = chain_to.mapping_conv.op if chain_to is not None else None
+            # chain_to: the next HNOXSBlock (its mapping_conv is chained) or the model's conv_out (nn.Conv3d: the logits are returned)
+            nm = chain_to.mapping_conv.op if isinstance(chain_to, HNOXSBlock) else chain_to
             return ops.XSBlockFn.apply(x, skip, mc.weight if mc is not None else None, mc.bias if mc is not None else None,
                                        cc.weight, cc.bias, self.transform_crop.num_modes, act, passthrough,
                                        nm.weight if nm is not None else None, nm.bias if nm is not None else None,
-                                       next_skip if nm is not None else None,
+                                       next_skip if isinstance(chain_to, HNOXSBlock) else None,
                                        *[b.op.weight for b in self.conv_blocks])
         assert chain_to is None and not premapped
         if passthrough:   # unfused configurations: plain autograd accumulates the two gradients of x
@@ -288,6 +289,10 @@ class HNOSegXS(nn.Module):
                 x, enc[i - 1] = layer(x, skip, passthrough=True, premapped=premapped)
             elif chain:
                 x = layer(x, skip, chain_to=nxt, next_skip=nskip, premapped=premapped)
+            elif i == nb - 1 and nb > 1 and self._head_chain_ok(layer, x):
+                # the last block hands back the low-resolution logits: its conv_concat and conv_out run as one pass
+                logits = layer(x, skip, chain_to=self.conv_out, premapped=premapped)
+                return self._head_logits(logits, image_size)
             else:
                 x = layer(x, skip, premapped=premapped)
             premapped = chain
@@ -296,6 +301,14 @@ class HNOSegXS(nn.Module):
             if self.use_unet_skip and i < nb // 2:
                 enc[i] = x
         return self._head(ds if ds else [x], image_size)
+
+    def _head_chain_ok(self, layer, x):
+        """the last block's conv_concat and conv_out (24 -> 4, no bias) can run as one pass (ops.XSBlockFn with the conv_out weight)"""
+        from .. import ops_bf16
+        return (x.ndim == 5 and x.is_cuda and layer._fused_ok() and not self.use_deep_supervision and self.conv_out.bias is None
+                and layer.conv_concat.op.out_channels == 24 and tuple(self.conv_out.weight.shape[:2]) == (4, 24)
+                and not ops_bf16.autocast_bf16() and os.environ.get('HNO_PW_CHAIN', '1') != '0'
+                and os.environ.get('HNO_PW_CHAIN_HEAD', '1') != '0')
 
     def _head(self, feats, image_size):
         """conv_out at LOW resolution (it commutes with the per-channel trilinear interpolation),
@@ -309,6 +322,9 @@ class HNOSegXS(nn.Module):
                 part = ops.PwConvFn.apply(f, None, w[:, c0:c0 + f.shape[1]].contiguous(), None, ops.ACT_NONE)
                 logits = part if logits is None else ops.AddFn.apply(logits, part)
                 c0 += f.shape[1]
+        return self._head_logits(logits, image_size)
+
+    def _head_logits(self, logits, image_size):
         if self.use_resize:
             y = ops.head_output(logits, image_size, self._softmax, self._out_act)
         else:

@@ -1505,12 +1505,19 @@ class XSBlockFn(_HnoFunction):
         chained = nmap_w is not None
         xn = None
         if chained:
-            assert not passthrough and not bf and nskip is not None
-            nskip = to_layout(_f32a(nskip), chan_stride(xm))
-            out, xn = act_like(xm), act_like(xm)
+            # nskip given: the next block's mapping_conv (24 + 24 -> 24, same activation); nskip None: the model's conv_out behind the
+            # last block (24 -> out_channels, no bias, no activation): xn are the low-resolution logits
+            assert not passthrough and not bf
+            C2 = int(nmap_w.shape[0])
+            act2 = act if nskip is not None else ACT_NONE
+            if nskip is not None:
+                nskip = to_layout(_f32a(nskip), chan_stride(xm))
+            out = act_like(xm)
+            xn = act_like(xm) if nskip is not None else act_empty(x.shape[0], C2, spatial, x.device, chan_stride(xm))
             check(_lib.lib().hno_pwconv_fwd_chain(ptr(u), ptr(xm), ptr(nskip), ptr(cat_w), ptr(cat_b), ptr(nmap_w), ptr(nmap_b), ptr(out), ptr(xn),
-                                                  x.shape[0], int(cat_w.shape[0]), chan_stride(xm) or _flat_v(xm), act, stream_ptr()),
+                                                  x.shape[0], int(cat_w.shape[0]), C2, chan_stride(xm) or _flat_v(xm), act, act2, stream_ptr()),
                   'hno_pwconv_fwd_chain')
+            ctx.act2 = act2
         else:
             out = pwconv_fwd_raw(u, xm, cat_w, cat_b, act, bf)
         ctx.chain = chained
@@ -1542,26 +1549,31 @@ class XSBlockFn(_HnoFunction):
             # g_out is the gradient of xn = act(Wm [out ; nskip] + bm).  One pass through both pointwise layers (hno_pwconv_bwd_chain:
             # the gradient between them never reaches memory); HNO_PW_CHAIN_BWD=0: the two layers apart (A/B)
             late_nmap = lp and _deferrable(nmap_w, nmap_b)
-            ld_n = chan_stride(xn)
+            ld_n = chan_stride(xm)
             C = int(cat_w.shape[0])
-            if os.environ.get('HNO_PW_CHAIN_BWD', '1') != '0' and g_pass is None and chan_stride(u) == ld_n == chan_stride(xm):
+            if os.environ.get('HNO_PW_CHAIN_BWD', '1') != '0' and g_pass is None and chan_stride(u) == ld_n == chan_stride(xn):
                 L = _lib.lib()
                 gn = to_layout(g_out, ld_n)
-                g_u, g_skipin, g_nskip = act_like(u), act_like(xm), act_like(nskip)
-                n1 = C * 2 * C + C
-                flat = torch.empty(2 * n1, device=u.device, dtype=torch.float32)
+                C2, has_k = int(nmap_w.shape[0]), nskip is not None
+                cin2 = 2 * C if has_k else C
+                g_u, g_skipin = act_like(u), act_like(xm)
+                g_nskip = act_like(nskip) if has_k else None
+                n1 = C2 * cin2 + C2
+                flat = torch.empty(n1 + C * 2 * C + C, device=u.device, dtype=torch.float32)
                 ws = torch.empty(L.hno_pwconv_bwd_chain_workspace_bytes(C) // 4, device=u.device, dtype=torch.float32)
                 with _DeferReduce(late_nmap and late_cat) as d:
-                    check(L.hno_pwconv_bwd_chain(ptr(gn), ptr(xn), ptr(out), ptr(nskip), ptr(u), ptr(xm), ptr(nmap_w), ptr(cat_w), ptr(g_u), ptr(g_skipin),
-                                                 ptr(g_nskip), ptr(flat), ptr(ws), x.shape[0], C, ld_n or _flat_v(xn), act, act | d.bit, stream_ptr()),
-                          'hno_pwconv_bwd_chain')
+                    check(L.hno_pwconv_bwd_chain(ptr(gn), ptr(xn) if ctx.act2 != ACT_NONE else None, ptr(out), ptr(nskip), ptr(u), ptr(xm), ptr(nmap_w),
+                                                 ptr(cat_w), ptr(g_u), ptr(g_skipin), ptr(g_nskip), ptr(flat), ptr(ws), x.shape[0], C, C2,
+                                                 ld_n or _flat_v(xm), act, ctx.act2, act | d.bit, stream_ptr()), 'hno_pwconv_bwd_chain')
                     d.keep(ws)
-                d_nmap_w, d_nmap_b = flat[:C * 2 * C].view_as(nmap_w), (flat[C * 2 * C:n1] if nmap_b is not None else None)
+                d_nmap_w, d_nmap_b = flat[:C2 * cin2].view_as(nmap_w), (flat[C2 * cin2:n1] if nmap_b is not None else None)
                 d_cat_w, d_cat_b = flat[n1:n1 + C * 2 * C].view_as(cat_w), (flat[n1 + C * 2 * C:] if cat_has_b else None)
                 chain_fused = True
             else:
-                g_out, g_nskip, d_nmap_w, d_nmap_b = pwconv_bwd_raw(to_layout(g_out, ld_n), xn, out, nskip, nmap_w, act, nmap_b is not None,
-                                                                   True, True, defer=late_nmap, bias=nmap_b, bf16=False)
+                g_out, g_nskip, d_nmap_w, d_nmap_b = pwconv_bwd_raw(to_layout(g_out, ld_n), xn if ctx.act2 != ACT_NONE else None, out, nskip,
+                                                                   nmap_w.reshape(nmap_w.shape[0], -1), ctx.act2, nmap_b is not None,
+                                                                   True, nskip is not None, defer=late_nmap, bias=nmap_b, bf16=False)
+                d_nmap_w = d_nmap_w.view_as(nmap_w)
             if g_nskip is not None:
                 g_nskip._hno_private = True      # fresh buffer of ours: the encoder block that owns the skip may accumulate into it
         # The passthrough gradient is accumulated IN PLACE into the buffer autograd handed us only when that buffer is

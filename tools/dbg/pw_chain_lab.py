@@ -16,7 +16,7 @@ xi_ref = ops.pwconv_fwd_raw(u, t, Wc, bc, ops.ACT_SELU)
 xn_ref = ops.pwconv_fwd_raw(xi_ref, k, Wm, bm, ops.ACT_SELU)
 xi, xn = ops.act_like(u), ops.act_like(u)
 def chain():
-    pkg._lib.check(L.hno_pwconv_fwd_chain(P(u), P(t), P(k), P(Wc), P(bc), P(Wm), P(bm), P(xi), P(xn), B, C, ld, ops.ACT_SELU, S()), 'chain')
+    pkg._lib.check(L.hno_pwconv_fwd_chain(P(u), P(t), P(k), P(Wc), P(bc), P(Wm), P(bm), P(xi), P(xn), B, C, C, ld, ops.ACT_SELU, ops.ACT_SELU, S()), 'chain')
 chain(); torch.cuda.synchronize()
 print('xi equal', bool((xi == xi_ref).all()), 'xn max rel', float((xn - xn_ref).abs().max() / xn_ref.abs().max()))
 def timeit(fn, n=10, reps=5):
@@ -52,7 +52,7 @@ flat = torch.empty(2 * n1, device=dev)
 ws = torch.empty(L.hno_pwconv_bwd_chain_workspace_bytes(C) // 4, device=dev)
 def chain_bwd():
     pkg._lib.check(L.hno_pwconv_bwd_chain(P(gn), P(xn_ref), P(xi_ref), P(k), P(u), P(t), P(Wm), P(Wc), P(g_u), P(g_t), P(g_k), P(flat), P(ws),
-                                          B, C, ld, ops.ACT_SELU, ops.ACT_SELU, S()), 'chain bwd')
+                                          B, C, C, ld, ops.ACT_SELU, ops.ACT_SELU, ops.ACT_SELU, S()), 'chain bwd')
 chain_bwd(); torch.cuda.synchronize()
 rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
 print('gu', rel(g_u, ref[0]), 'gt', rel(g_t, ref[1]), 'gk', rel(g_k, ref[2]), 'dWm', rel(flat[:C * 2 * C].view(C, 2 * C), ref[3]), 'dbm', rel(flat[C * 2 * C:n1], ref[4]),
