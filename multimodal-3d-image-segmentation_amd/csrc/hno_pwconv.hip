@@ -1213,8 +1213,12 @@ struct PwChainBwdArgs {
 
 // C2 / HASK as pwconv_fwd_chain_kernel's: <24, NW, 24, true> mapping_conv behind conv_concat; <24, NW, 4, false> the model's conv_out
 // (no second input, no bias; its activation a.act2 is none) behind the last block's conv_concat.
-template <int C, int NW, int C2 = C, bool HASK = true>
-__global__ __launch_bounds__(64 * NW, 1) void pwconv_bwd_chain_kernel(PwChainBwdArgs a) {
+// SLOTS: 2 = the next tile's x rows land in the other ring slot while this tile is multiplied (30.5 KB of LDS per wave: four waves per
+// CU, one per SIMD -- nothing overlaps a wave's VALU / scalar work and waits with MFMAs: 38 % MFMA-busy, 128 us); 1 = one slot, the next
+// tile requested when this one's LDS reads are done (17.4 KB: eight waves per CU, two workgroups of four -- the partner wave on the
+// SIMD computes while this one waits for its rows).
+template <int C, int NW, int C2 = C, bool HASK = true, int SLOTS = 2>
+__global__ __launch_bounds__(64 * NW, SLOTS == 1 ? 2 : 1) void pwconv_bwd_chain_kernel(PwChainBwdArgs a) {
     static_assert(C == 24, "accumulator-row bookkeeping below is written for 24 channels");
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63;
@@ -1224,7 +1228,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pwconv_bwd_chain_kernel(PwChainBwd
     constexpr int CIN2 = HASK ? 2 * C : C, NK2 = C2 / 2, UP = (HASK ? 2 : 1) * NK;   // second layer: inputs, k-slots of g1; first pair of u
     constexpr int MT2 = (C2 + 15) / 16, NTI2 = (CIN2 + 15) / 16;      // weight-gradient tiles of the second layer
     constexpr int XS = NPAIR * PWB_XP;                                // floats per slot
-    constexpr int WAVE_FLOATS = 32 * PWB_LD + 2 * XS;
+    constexpr int WAVE_FLOATS = 32 * PWB_LD + SLOTS * XS;
     float *G = lds + (size_t)wave * WAVE_FLOATS;                      // [o][v]: g1, later p
     float *X = G + 32 * PWB_LD;                                       // two slots of [pair][row & 1][v]
     const unsigned V = a.V;
@@ -1294,7 +1298,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pwconv_bwd_chain_kernel(PwChainBwd
     };
     if (blockIdx.x < ngroups) fetch(blockIdx.x, 0);
     int slot = 0;
-    for (unsigned grp = blockIdx.x; grp < ngroups; grp += gridDim.x, slot ^= 1) {
+    for (unsigned grp = blockIdx.x; grp < ngroups; grp += gridDim.x, slot ^= (SLOTS - 1)) {
         const float *Xc = X + slot * XS;
         const unsigned t = grp * NW + wave;
         const bool live = t < ntiles;
@@ -1310,7 +1314,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pwconv_bwd_chain_kernel(PwChainBwd
             G[(2 * ks + h) * PWB_LD + c] = g[ks];
             dbm[ks] += g[ks];
         }
-        if (grp + gridDim.x < ngroups) fetch(grp + gridDim.x, slot ^ 1);
+        if (SLOTS == 2 && grp + gridDim.x < ngroups) fetch(grp + gridDim.x, slot ^ 1);
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
@@ -1406,6 +1410,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pwconv_bwd_chain_kernel(PwChainBwd
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (SLOTS == 1 && grp + gridDim.x < ngroups) fetch(grp + gridDim.x, 0);      // (this tile's LDS reads are done)
     }
     {
         constexpr int n1 = C2 * CIN2 + C2, n = n1 + C * CIN + C;            // [dWm | dbm | dWc | dbc]
@@ -1815,7 +1820,7 @@ extern "C" int hno_pwconv_fwd_chain(const float *u, const float *t, const float 
 // backward of hno_pwconv_fwd_chain in one pass (pwconv_bwd_chain_kernel): gn = gradient of xn; -> gu, gt, gk and
 // grads = [dWm (C, 2C) | dbm (C) | dWc (C, 2C) | dbc (C)] (one flat buffer).  xa_act: activation whose output u is (its derivative is
 // applied to gu), as hno_pwconv_bwd's.  workspace: hno_pwconv_bwd_chain_workspace_bytes(C).  bit 8 of xa_act: defer the slab reduction.
-extern "C" size_t hno_pwconv_bwd_chain_workspace_bytes(int C) { return sizeof(float) * 256 * 2 * ((size_t)C * 2 * C + C); }
+extern "C" size_t hno_pwconv_bwd_chain_workspace_bytes(int C) { return sizeof(float) * 512 * 2 * ((size_t)C * 2 * C + C); }
 // grads: C2 = 24: [dWm (24, 48) | dbm (24) | dWc (24, 48) | dbc (24)];  C2 = 4 (k, gk NULL): [dWm (4, 24) | dbm (4, unused) | dWc | dbc]
 extern "C" int hno_pwconv_bwd_chain(const float *gn, const float *xn, const float *xi, const float *k, const float *u, const float *t,
                                     const float *Wm, const float *Wc, float *gu, float *gt, float *gk, float *grads, void *workspace,
@@ -1833,11 +1838,14 @@ extern "C" int hno_pwconv_bwd_chain(const float *gn, const float *xn, const floa
     a.partials = (float *)workspace; a.B = B; a.V = (unsigned)V; a.act = act & 0xfff; a.act2 = act2 & 0xfff; a.xa_act = xa_act & 0xff;
     a.dbg = debug_flags();
     constexpr int NW = 4;
+    static const int slots_env = getenv("HNO_PWCHAIN_SLOTS") ? atoi(getenv("HNO_PWCHAIN_SLOTS")) : 1;     // A/B: 2 = double-buffered ring
+    const int slots = slots_env == 2 ? 2 : 1;
     const long long ntiles = ((V + 31) / 32) * B, ngroups = (ntiles + NW - 1) / NW;
-    int grid = (int)(ngroups < 256 ? ngroups : 256);          // one 4-wave workgroup per CU (30 KB of LDS per wave)
+    const int cap = slots == 1 ? 512 : 256;                   // two 4-wave workgroups per CU (17 KB of LDS per wave) / one (30 KB)
+    int grid = (int)(ngroups < cap ? ngroups : cap);
     hipStream_t s = (hipStream_t)stream;
     const int nt = k ? 4 : 3, cin2 = k ? 2 * C : C;
-    const size_t per_wave = (size_t)(32 * PWB_LD + 2 * nt * 12 * PWB_XP) * sizeof(float);
+    const size_t per_wave = (size_t)(32 * PWB_LD + slots * nt * 12 * PWB_XP) * sizeof(float);
     const int n = C2 * cin2 + C2 + C * 2 * C + C;
     size_t ldsb = NW * per_wave;
     if (ldsb < (size_t)NW * n * sizeof(float)) ldsb = (size_t)NW * n * sizeof(float);
@@ -1845,11 +1853,15 @@ extern "C" int hno_pwconv_bwd_chain(const float *gn, const float *xn, const floa
     if (attr != current_device()) {
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)pwconv_bwd_chain_kernel<24, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)pwconv_bwd_chain_kernel<24, NW, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)pwconv_bwd_chain_kernel<24, NW, 24, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)pwconv_bwd_chain_kernel<24, NW, 4, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = current_device();
     }
     {
         ProfScope ps(KID_PWCONV_BWD, s, 4.0 * B * (double)V * ((k ? 7 : 5) * C + 2 * C2));
-        if (C2 == 4) hipLaunchKernelGGL((pwconv_bwd_chain_kernel<24, NW, 4, false>), dim3(grid), dim3(64 * NW), ldsb, s, a);
+        if (C2 == 4 && slots == 1) hipLaunchKernelGGL((pwconv_bwd_chain_kernel<24, NW, 4, false, 1>), dim3(grid), dim3(64 * NW), ldsb, s, a);
+        else if (C2 == 4) hipLaunchKernelGGL((pwconv_bwd_chain_kernel<24, NW, 4, false>), dim3(grid), dim3(64 * NW), ldsb, s, a);
+        else if (slots == 1) hipLaunchKernelGGL((pwconv_bwd_chain_kernel<24, NW, 24, true, 1>), dim3(grid), dim3(64 * NW), ldsb, s, a);
         else hipLaunchKernelGGL((pwconv_bwd_chain_kernel<24, NW>), dim3(grid), dim3(64 * NW), ldsb, s, a);
         HNO_CHECK_LAUNCH();
     }
