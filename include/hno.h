@@ -437,6 +437,21 @@ int hno_loss_fwd_ws(const float *probs, const uint8_t *labels, double *workspace
 int hno_loss_bwd(const float *probs, const uint8_t *labels, const float *coef, const float *gscale,
                  float *g_probs, int B, int K, long long V, void *stream);
 
+/* Round 4: the softmax head and the loss in one pass each way (nets/hnosegxs.py:174-180 + nets/custom_losses.py:17-133; in the
+ * reference's loop `loss_fn(model(x), y)`, experiments/train_test.py:154-160).
+ *   hno_uphead_loss_fwd: trilinear upsampling of the low-resolution logits + softmax -> probs, and the loss sums taken from the
+ *     probabilities while they are in registers (no second pass over probs); coef / loss as hno_loss_fwd_ws leaves them.
+ *     workspace: hno_uphead_loss_workspace_doubles(B, K) doubles.  Shapes: hno_uphead_loss_supported (even W <= 128, w <= 128, K <= 8).
+ *   hno_upsoftmax_loss_bwd: the head's backward with d loss / d probs = gscale (alpha t + beta p + gamma) evaluated from coef and
+ *     the labels in place of hno_loss_bwd's tensor; workspace of hno_upsoftmax_bwd_workspace_bytes (0 = not covered -> HNO_ELIMIT). */
+int hno_uphead_loss_supported(int B, int K, int d, int h, int w, int D, int H, int W);
+size_t hno_uphead_loss_workspace_doubles(int B, int K);
+int hno_uphead_loss_fwd(const float *logits_lr, const unsigned char *labels, float *probs, double *workspace, size_t workspace_doubles,
+                        float *coef, float *loss, int B, int K, int d, int h, int w, int D, int H, int W, long long ldlr, int kind,
+                        float param, void *stream);
+int hno_upsoftmax_loss_bwd(const float *probs, const unsigned char *labels, const float *coef, const float *gscale, float *g_lr,
+                           void *workspace, int B, int K, int d, int h, int w, int D, int H, int W, long long ldlr, void *stream);
+
 /* float labels (B,1,...) -> uint8 class indices with optional remap table (256 entries,
  * NULL = identity); one-hot output optional (NULL to skip). experiments/utils.py:74-119 */
 int hno_labels_prepare(const float *labels_f32, const int *remap_from, const int *remap_to, int n_remap,

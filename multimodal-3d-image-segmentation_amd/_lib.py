@@ -113,6 +113,10 @@ SIGNATURES = {
     'hno_loss_workspace_doubles': (c_size_t, [c_int, c_int, c_ll]),
     'hno_loss_fwd_ws': (c_int, [c_void_p] * 3 + [c_size_t, c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_float, c_void_p]),
     'hno_loss_bwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_ll, c_void_p]),
+    'hno_uphead_loss_supported': (c_int, [c_int] * 8),
+    'hno_uphead_loss_workspace_doubles': (c_size_t, [c_int, c_int]),
+    'hno_uphead_loss_fwd': (c_int, [c_void_p] * 4 + [c_size_t, c_void_p, c_void_p] + [c_int] * 8 + [c_ll, c_int, c_float, c_void_p]),
+    'hno_upsoftmax_loss_bwd': (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_ll, c_void_p]),
     'hno_labels_prepare': (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 2 + [c_int, c_int, c_ll, c_void_p]),
     'hno_adamax_chunk_rows': (c_int, []),
     'hno_adamax_multi': (c_int, [c_void_p, c_int] + [c_float] * 5 + [c_ll, c_float, c_void_p]),

@@ -146,6 +146,162 @@ __global__ __launch_bounds__(256) void uphead_seg_kernel(UpArgs a, unsigned char
     }
 }
 
+// Row form of the head (round 4): a wave owns whole output rows (W <= 128: lane l holds x = 2 l, 2 l + 1) and interpolates in SOURCE
+// space first -- the y / z blend of the four source rows is done once per source column (lanes = source columns, 4 coalesced loads +
+// 3 fma per class) and parked in a wave-private LDS row; every output voxel then takes its two x taps from LDS.  The voxel form above
+// gathers 8 values and blends 7 times per (voxel, class): ~200 VALU instructions per voxel, which is what bounded it (36 us for 76 MB);
+// this form needs ~45.  (Blending y / z before x instead of x first changes the rounding, not the result: <= 2 ulp.)
+// STATS: the four loss sums per (sample, class) -- sum p, sum p^2, sum p t, sum t (nets/custom_losses.py:17-41, 73-90) -- are taken from
+// the probabilities while they are in registers (the separate statistics pass re-read all 67 MB): fp32 per lane over the wave's <= 16
+// rows, then fp64 across lanes, waves and workgroups in a fixed order; row [b][workgroup][K * 4] of `rows` goes to loss_finalize_kernel.
+#define UPR_WAVES 8
+#define UPR_PITCH 132          // w + 1 <= 129 source columns (+ the duplicated last one) per class
+
+// byte offsets are formed in 32 bits and added to a wave-uniform base: the loads and stores then take the (SGPR base + VGPR offset)
+// address form -- 64-bit per-lane address arithmetic was a third of this kernel's instructions
+__device__ __forceinline__ float ld_off(const float *base, unsigned byte_off) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
+template <int KMAX, bool STATS, bool EXACT>      // EXACT: K == KMAX at compile time (no per-class branches)
+__global__ __launch_bounds__(64 * UPR_WAVES) void uphead_rows_kernel(UpArgs a, const uint8_t *__restrict__ lab, double *__restrict__ rows) {
+    constexpr int NT = 64 * UPR_WAVES, NS = KMAX * 4;
+    // the y / z-blended source rows of the waves; the statistics' cross-lane stage reuses the space afterwards
+    constexpr int NV = UPR_WAVES * KMAX * UPR_PITCH, NR = STATS ? NS * NT : 1;
+    __shared__ float lds[NV > NR ? NV : NR];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y, K = EXACT ? KMAX : a.K, W = a.W, w = a.w;
+    const size_t V = (size_t)a.D * a.H * W;
+    const int nrow = a.D * a.H;
+    float *Vw = lds + wave * (KMAX * UPR_PITCH);
+    // x taps of this lane's two voxels (the same for every row)
+    const int x0 = 2 * lane;
+    const bool in = x0 < W;                                   // W is even: both voxels or none
+    const Lin le = lin_coord(in ? x0 : 0, a.sw, w), lo = lin_coord(in ? x0 + 1 : 0, a.sw, w);
+    // source columns of this lane: lane and lane + 64, clamped to w - 1.  Lanes beyond the row thus hold the LAST column, and writing
+    // every lane's value unconditionally leaves Vw[w] = Vw[w - 1]: the tap i1 = i0 + 1 is always readable (torch clamps i1 to w - 1)
+    const bool two = w >= 64;
+    const unsigned j1b = 4u * (unsigned)(lane < w ? lane : w - 1), j2b = 4u * (unsigned)(lane + 64 < w ? lane + 64 : w - 1);
+    const unsigned xb = 8u * (unsigned)lane;
+    float sp[KMAX], sp2[KMAX], spt[KMAX];
+    int st[KMAX];                                             // label counts of the WAVE (scalar: popcount of the compare masks)
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { sp[k] = sp2[k] = spt[k] = 0.f; st[k] = 0; }
+    // rows of this workgroup and of this wave: even split at row granularity (the grid is sized to the residency of the chip)
+    const int wg0 = (int)((long long)nrow * blockIdx.x / gridDim.x), wg1 = (int)((long long)nrow * (blockIdx.x + 1) / gridDim.x);
+    const int r0 = wg0 + (wg1 - wg0) * wave / UPR_WAVES, r1 = wg0 + (wg1 - wg0) * (wave + 1) / UPR_WAVES;
+    float raw1[KMAX][4], raw2[KMAX][4];
+    unsigned l2n = 0;
+    Lin lz, ly;
+    auto request = [&](int r) {                               // the four source rows of output row r (wave-uniform offsets)
+        const int z = r / a.H, y = r - z * a.H;
+        lz = lin_coord(z, a.sd, a.d);
+        ly = lin_coord(y, a.sh, a.h);
+        const unsigned o00 = 4u * (((unsigned)lz.i0 * a.h + ly.i0) * w), o01 = 4u * (((unsigned)lz.i0 * a.h + ly.i1) * w);
+        const unsigned o10 = 4u * (((unsigned)lz.i1 * a.h + ly.i0) * w), o11 = 4u * (((unsigned)lz.i1 * a.h + ly.i1) * w);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) {
+                const float *s = a.lr + ((size_t)b * K + k) * a.ldlr;
+                raw1[k][0] = ld_off(s, o00 + j1b); raw1[k][1] = ld_off(s, o01 + j1b);
+                raw1[k][2] = ld_off(s, o10 + j1b); raw1[k][3] = ld_off(s, o11 + j1b);
+                if (two) {
+                    raw2[k][0] = ld_off(s, o00 + j2b); raw2[k][1] = ld_off(s, o01 + j2b);
+                    raw2[k][2] = ld_off(s, o10 + j2b); raw2[k][3] = ld_off(s, o11 + j2b);
+                }
+            }
+        if (STATS && in)
+            l2n = *reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(lab + (size_t)b * V + (size_t)r * W) + 2u * (unsigned)lane);
+    };
+    if (r0 < r1) request(r0);
+    for (int r = r0; r < r1; ++r) {
+        // ---- y / z blend per source column -> LDS
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) {
+                float *vs = Vw + k * UPR_PITCH;
+                vs[lane] = lz.w0 * (ly.w0 * raw1[k][0] + ly.w1 * raw1[k][1]) + lz.w1 * (ly.w0 * raw1[k][2] + ly.w1 * raw1[k][3]);
+                if (two) vs[lane + 64] = lz.w0 * (ly.w0 * raw2[k][0] + ly.w1 * raw2[k][1]) + lz.w1 * (ly.w0 * raw2[k][2] + ly.w1 * raw2[k][3]);
+            }
+        const unsigned l2 = l2n;
+        if (r + 1 < r1) request(r + 1);                       // in flight under the taps, the softmax and the stores of this row
+        // ---- x taps, softmax, store
+        float pe[KMAX], po[KMAX];
+        float me = -3.0e38f, mo = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            pe[k] = po[k] = 0.f;
+            if (k < K) {
+                const float *vs = Vw + k * UPR_PITCH;
+                pe[k] = le.w0 * vs[le.i0] + le.w1 * vs[le.i0 + 1];
+                po[k] = lo.w0 * vs[lo.i0] + lo.w1 * vs[lo.i0 + 1];
+                me = fmaxf(me, pe[k]);
+                mo = fmaxf(mo, po[k]);
+            }
+        }
+        if (a.softmax) {
+            // e^x = exp2(x log2 e) on the hardware exp2: the rounded product costs |x| 2^-24 relative, i.e. < 3e-8 absolute on e^x for x <= 0
+            float se = 0.f, so = 0.f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < K) {
+                    pe[k] = __builtin_amdgcn_exp2f((pe[k] - me) * 1.44269504f);
+                    po[k] = __builtin_amdgcn_exp2f((po[k] - mo) * 1.44269504f);
+                    se += pe[k];
+                    so += po[k];
+                }
+            float ie = __builtin_amdgcn_rcpf(se), io = __builtin_amdgcn_rcpf(so);
+            ie = fmaf(fmaf(-se, ie, 1.f), ie, ie);
+            io = fmaf(fmaf(-so, io, 1.f), io, io);
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                pe[k] *= ie;
+                po[k] *= io;
+            }
+        }
+        if (in) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < K) {
+                    float *orow = a.out + ((size_t)b * K + k) * V + (size_t)r * W;          // wave-uniform
+                    *reinterpret_cast<float2 *>(reinterpret_cast<char *>(orow) + xb) = make_float2(pe[k], po[k]);
+                }
+        }
+        if constexpr (STATS) {
+            const int l0 = in ? (int)(l2 & 255) : -1, l1 = in ? (int)(l2 >> 8) : -1;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < K) {
+                    const bool te = l0 == k, to = l1 == k;
+                    sp[k] += pe[k] + po[k];
+                    sp2[k] = fmaf(pe[k], pe[k], fmaf(po[k], po[k], sp2[k]));
+                    spt[k] += (te ? pe[k] : 0.f) + (to ? po[k] : 0.f);
+                    st[k] += __builtin_popcountll(__ballot(te)) + __builtin_popcountll(__ballot(to));
+                }
+        }
+    }
+    if constexpr (STATS) {
+        __syncthreads();                                      // every wave is done with its rows of `lds`
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            lds[(k * 4 + 0) * NT + threadIdx.x] = in ? sp[k] : 0.f;
+            lds[(k * 4 + 1) * NT + threadIdx.x] = in ? sp2[k] : 0.f;
+            lds[(k * 4 + 2) * NT + threadIdx.x] = spt[k];
+            lds[(k * 4 + 3) * NT + threadIdx.x] = lane == 0 ? (float)st[k] : 0.f;       // <= 2 * 64 * rows of the wave: exact
+        }
+        __syncthreads();
+        constexpr int NSP = KMAX <= 2 ? 8 : (KMAX <= 4 ? 16 : 32), TPS = NT / NSP;     // threads per statistic (a power of two <= 64)
+        const int sidx = threadIdx.x / TPS, t = threadIdx.x - sidx * TPS;
+        double acc = 0.0;
+        if (sidx < NS) {
+#pragma unroll 4
+            for (int i = 0; i < NSP; ++i) acc += (double)lds[sidx * NT + t + i * TPS];
+        }
+        for (int off = TPS / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+        if (t == 0 && sidx < K * 4) rows[((size_t)b * gridDim.x + blockIdx.x) * (K * 4) + sidx] = acc;
+    }
+}
+
 // Inference head: argmax over channels of the upsampled logits, written as uint8 class labels.  softmax is
 // monotone, so the probabilities (67 MB per 2 volumes, and their trip over PCIe in the reference's testing loop,
 // experiments/train_test.py:398-408) are never formed.  Ties resolve to the lowest index like numpy.argmax.
@@ -271,9 +427,12 @@ struct UpBwdArgs {
     float sd, sh, sw;
     int softmax, nsplit, dbg;
     unsigned ldlr;     // channel stride of the low-resolution gradient (padding zeroed by upsoftmax_bwd_d_kernel)
+    // LG form: the gradient of the probabilities is not read but evaluated from the loss coefficients (loss_bwd_kernel's expression)
+    const uint8_t *lab;
+    const float *coef, *gscale;
 };
 
-template <int KMAX, int NC, int NI>   // NI: (row, quad) items per thread, UPB_ROWS * W / 4 <= NI * UPB_THREADS
+template <int KMAX, int NC, int NI, bool LG = false>   // NI: (row, quad) items per thread, UPB_ROWS * W / 4 <= NI * UPB_THREADS
 __global__ __launch_bounds__(UPB_THREADS) void upsoftmax_bwd_plane_kernel(UpBwdArgs a) {
     extern __shared__ float stage[];   // [2][UPB_ROWS][K][W]
     const int tid = threadIdx.x;
@@ -311,6 +470,20 @@ __global__ __launch_bounds__(UPB_THREADS) void upsoftmax_bwd_plane_kernel(UpBwdA
     const int nitem = UPB_ROWS * QW;               // (row, quad) items per batch
     typedef float f4 __attribute__((ext_vector_type(4)));
     f4 gq[NI][KMAX], pq[NI][KMAX];
+    unsigned labq[NI];
+    float al[KMAX], be[KMAX], ga[KMAX];
+    if constexpr (LG) {
+        const float gs = a.gscale ? *a.gscale : 1.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            al[k] = be[k] = ga[k] = 0.f;
+            if (k < K) {
+                al[k] = gs * a.coef[((size_t)b * K + k) * 4 + 1];
+                be[k] = gs * a.coef[((size_t)b * K + k) * 4 + 2];
+                ga[k] = gs * a.coef[((size_t)b * K + k) * 4 + 3];
+            }
+        }
+    }
     auto fetch = [&](int hbase) {
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
@@ -319,11 +492,12 @@ __global__ __launch_bounds__(UPB_THREADS) void upsoftmax_bwd_plane_kernel(UpBwdA
             const int hh = hbase + r;
             if (item >= nitem || (a.dbg & 2)) continue;
             const size_t off = ((size_t)z * H + (hh <= hb ? hh : ha)) * W + 4 * q;
+            if constexpr (LG) labq[it] = *reinterpret_cast<const unsigned *>(a.lab + (size_t)b * V + off);
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) {
                 if (k < K) {
-                    gq[it][k] = *reinterpret_cast<const f4 *>(a.gp + ((size_t)b * K + k) * V + off);
-                    if (a.softmax) pq[it][k] = *reinterpret_cast<const f4 *>(a.p + ((size_t)b * K + k) * V + off);
+                    if constexpr (!LG) gq[it][k] = *reinterpret_cast<const f4 *>(a.gp + ((size_t)b * K + k) * V + off);
+                    if (a.softmax || LG) pq[it][k] = *reinterpret_cast<const f4 *>(a.p + ((size_t)b * K + k) * V + off);
                 }
             }
         }
@@ -341,6 +515,17 @@ __global__ __launch_bounds__(UPB_THREADS) void upsoftmax_bwd_plane_kernel(UpBwdA
             const int item = tid + it * UPB_THREADS;
             if (item < nitem) {
                 const int r = item / QW, q = item - r * QW;
+                if constexpr (LG) {     // d loss / d p = alpha t + beta p + gamma, as loss_bwd_kernel writes it
+                    const int l0 = labq[it] & 255, l1 = (labq[it] >> 8) & 255, l2 = (labq[it] >> 16) & 255, l3 = labq[it] >> 24;
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k)
+                        if (k < K) {
+                            gq[it][k].x = (l0 == k ? al[k] : 0.f) + be[k] * pq[it][k].x + ga[k];
+                            gq[it][k].y = (l1 == k ? al[k] : 0.f) + be[k] * pq[it][k].y + ga[k];
+                            gq[it][k].z = (l2 == k ? al[k] : 0.f) + be[k] * pq[it][k].z + ga[k];
+                            gq[it][k].w = (l3 == k ? al[k] : 0.f) + be[k] * pq[it][k].w + ga[k];
+                        }
+                }
                 f4 dot = {0.f, 0.f, 0.f, 0.f};
                 if (a.softmax) {
 #pragma unroll
@@ -708,6 +893,39 @@ static int up_set_ld(UpArgs &a, long long ldlr) {
     return HNO_OK;
 }
 
+static bool uprows_ok(int K, int d, int h, int w, int D, int H, int W) {
+    (void)d; (void)h; (void)D; (void)H;
+    return K <= 8 && W % 2 == 0 && W <= 128 && w <= 127 && w >= 2;   // (w = 128 would need the duplicated column at index 128)
+}
+
+template <bool STATS>
+static void uprows_launch(const UpArgs &a, int gx, int B, hipStream_t s, const uint8_t *labels, double *rows) {
+    const dim3 g(gx, B), blk(64 * UPR_WAVES);
+    switch (a.K) {
+        case 2: hipLaunchKernelGGL((uphead_rows_kernel<2, STATS, true>), g, blk, 0, s, a, labels, rows); break;
+        case 3: hipLaunchKernelGGL((uphead_rows_kernel<3, STATS, true>), g, blk, 0, s, a, labels, rows); break;
+        case 4: hipLaunchKernelGGL((uphead_rows_kernel<4, STATS, true>), g, blk, 0, s, a, labels, rows); break;
+        case 1: hipLaunchKernelGGL((uphead_rows_kernel<4, STATS, false>), g, blk, 0, s, a, labels, rows); break;
+        default: hipLaunchKernelGGL((uphead_rows_kernel<8, STATS, false>), g, blk, 0, s, a, labels, rows); break;
+    }
+}
+
+// workgroups per sample of the row kernel (= rows of the statistics workspace per sample, <= 1 024): two 8-wave workgroups per CU
+// are resident (registers), so the grid is 512 workgroups when there are rows enough (HNO_UPR_WGS overrides: A/B); rows_per_wave -> the longest fp32 run of a lane
+static int uprows_plan(int B, int D, int H, bool stats, int &rows_per_wave) {
+    const long long nrow = (long long)D * H;
+    static const int env = getenv("HNO_UPR_WGS") ? atoi(getenv("HNO_UPR_WGS")) : 0;
+    const int chip = env >= 64 && env <= 8192 ? env : 512;
+    long long gx = (chip + B - 1) / B;
+    const long long most = (nrow + UPR_WAVES - 1) / UPR_WAVES;       // at least one row per wave
+    if (gx > most) gx = most;
+    if (gx > 1024) gx = 1024;
+    if (gx < 1) gx = 1;
+    (void)stats;
+    rows_per_wave = (int)((nrow + gx * UPR_WAVES - 1) / (gx * UPR_WAVES)) + 1;
+    return (int)gx;
+}
+
 // ldlr: floats between consecutive (b, k) volumes of logits_lr (0 = d h w; a channel-padded stride: ops.chan_stride)
 extern "C" int hno_upsoftmax_fwd_ld(const float *logits_lr, float *probs, int B, int K, int d, int h, int w,
                                     int D, int H, int W, int softmax, long long ldlr, void *stream) {
@@ -720,7 +938,11 @@ extern "C" int hno_upsoftmax_fwd_ld(const float *logits_lr, float *probs, int B,
     a.lr = logits_lr; a.out = probs;
     ProfScope _ps(KID_UPSOFTMAX_FWD, (hipStream_t)stream, 4.0 * B * K * ((double)d * h * w + (double)D * H * W));
     const long long items = (long long)B * D * H * ((W + 63) / 64);
-    if (items < (1ll << 31) && (long long)d * h * w < (1ll << 31) && !(debug_flags() & 16)) {
+    if (uprows_ok(K, d, h, w, D, H, W) && (long long)D * H * W < (1ll << 31) && !(debug_flags() & (16 | 65536))) {
+        int rpw;
+        const int gx = uprows_plan(B, D, H, false, rpw);
+        uprows_launch<false>(a, gx, B, (hipStream_t)stream, nullptr, nullptr);
+    } else if (items < (1ll << 31) && (long long)d * h * w < (1ll << 31) && !(debug_flags() & 16)) {
         long long grid = (items + 3) / 4;
         if (grid > 8192) grid = 8192;
         if (debug_flags() >> 8) grid = debug_flags() >> 8;
@@ -730,6 +952,54 @@ extern "C" int hno_upsoftmax_fwd_ld(const float *logits_lr, float *probs, int B,
         const int grid = grid1d((size_t)B * D * H * W);
         if (K <= 4) hipLaunchKernelGGL(upsoftmax_fwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL(upsoftmax_fwd_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+extern "C" int hno_uphead_loss_supported(int B, int K, int d, int h, int w, int D, int H, int W) {
+    if (B <= 0 || !uprows_ok(K, d, h, w, D, H, W) || (long long)D * H * W >= (1ll << 31)) return 0;
+    int rpw;
+    uprows_plan(B, D, H, true, rpw);
+    return rpw <= 64 && ((long long)D * H * W) % 4 == 0;       // fp32 sums of <= 128 probabilities per lane before the fp64 stages
+}
+
+extern "C" size_t hno_uphead_loss_workspace_doubles(int B, int K) {
+    if (B <= 0 || K <= 0) return 0;
+    return (size_t)B * K * 4 * (1 + 1024);
+}
+
+// Softmax head and loss statistics in one pass (round 4): trilinear upsampling of the low-resolution logits + softmax
+// (nets/hnosegxs.py:174-180) -> probs, and from the same registers the sums PCCLoss / DiceLoss / ExpDiceLoss need
+// (nets/custom_losses.py:17-133): coef[b][k] = {value, alpha, beta, gamma}, *loss as hno_loss_fwd_ws leaves them.
+extern "C" int hno_uphead_loss_fwd(const float *logits_lr, const unsigned char *labels, float *probs, double *workspace,
+                                   size_t workspace_doubles, float *coef, float *loss, int B, int K, int d, int h, int w, int D, int H, int W,
+                                   long long ldlr, int kind, float param, void *stream) {
+    HNO_REQUIRE(logits_lr && labels && probs && workspace && coef && loss, "hno_uphead_loss_fwd: null pointer");
+    HNO_REQUIRE(kind >= 0 && kind <= 2, "hno_uphead_loss_fwd: kind must be 0 (PCC), 1 (Dice) or 2 (ExpDice)");
+    HNO_REQUIRE(((size_t)labels & 1) == 0, "hno_uphead_loss_fwd: labels must be 2-byte aligned");
+    if (!hno_uphead_loss_supported(B, K, d, h, w, D, H, W)) return fail(HNO_ELIMIT, "hno_uphead_loss_fwd: shape not covered");
+    HNO_REQUIRE(workspace_doubles >= hno_uphead_loss_workspace_doubles(B, K), "hno_uphead_loss_fwd: workspace too small");
+    UpArgs a = {};
+    int rc = up_fill(a, B, K, d, h, w, D, H, W, 1);
+    if (rc) return rc;
+    rc = up_set_ld(a, ldlr);
+    if (rc) return rc;
+    a.lr = logits_lr; a.out = probs;
+    hipStream_t s = (hipStream_t)stream;
+    int rpw;
+    const int gx = uprows_plan(B, D, H, true, rpw);
+    double *rows = workspace + (size_t)B * K * 4;
+    const long long V = (long long)D * H * W;
+    {
+        ProfScope _ps(KID_UPSOFTMAX_FWD, s, 4.0 * B * K * ((double)d * h * w + (double)V) + (double)B * V);
+        uprows_launch<true>(a, gx, B, s, labels, rows);
+    }
+    HNO_CHECK_LAUNCH();
+    {
+        ProfScope _ps2(KID_LOSS_FINALIZE, s);
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const double *)workspace, coef, loss, B, K, V, kind, param,
+                           (const double *)rows, gx, workspace);
     }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
@@ -784,9 +1054,11 @@ extern "C" size_t hno_upsoftmax_bwd_workspace_bytes(int B, int K, int d, int h, 
 }
 
 // ldlr: floats between consecutive (b, k) volumes of g_lr (0 = d h w; channel-padded: the padding is zeroed)
-extern "C" int hno_upsoftmax_bwd_ld(const float *g_probs, const float *probs, float *g_lr, void *workspace, int B, int K, int d,
-                                    int h, int w, int D, int H, int W, int softmax, long long ldlr, void *stream) {
-    HNO_REQUIRE(g_probs && g_lr && (probs || !softmax), "hno_upsoftmax_bwd: null pointer");
+static int upsoftmax_bwd_impl(const float *g_probs, const float *probs, float *g_lr, void *workspace, int B, int K, int d,
+                              int h, int w, int D, int H, int W, int softmax, long long ldlr, void *stream, const uint8_t *lab,
+                              const float *coef, const float *gscale) {
+    const bool lg = lab != nullptr;
+    HNO_REQUIRE((g_probs || lg) && g_lr && (probs || !(softmax || lg)), "hno_upsoftmax_bwd: null pointer");
     UpArgs a = {};
     int rc = up_fill(a, B, K, d, h, w, D, H, W, softmax);
     if (rc) return rc;
@@ -797,8 +1069,11 @@ extern "C" int hno_upsoftmax_bwd_ld(const float *g_probs, const float *probs, fl
     a.gp = g_probs; a.p = probs; a.out = g_lr;
     hipStream_t s = (hipStream_t)stream;
     const double abytes = 4.0 * B * K * ((double)d * h * w + (softmax ? 2.0 : 1.0) * D * H * W);
-    if (workspace && upb_separable_ok(K, d, h, w, D, H, W) && (!(debug_flags() & 16) || a.ldlr != (unsigned)((long long)d * h * w))) {
+    if (lg && !(workspace && upb_separable_ok(K, d, h, w, D, H, W)))
+        return fail(HNO_ELIMIT, "hno_upsoftmax_loss_bwd: shape not covered by the separable form");
+    if (workspace && upb_separable_ok(K, d, h, w, D, H, W) && (lg || !(debug_flags() & 16) || a.ldlr != (unsigned)((long long)d * h * w))) {
         UpBwdArgs u = {};
+        u.lab = lab; u.coef = coef; u.gscale = gscale;
         u.gp = g_probs; u.p = probs; u.T = (float *)workspace; u.out = g_lr;
         u.B = B; u.K = K; u.d = d; u.h = h; u.w = w; u.D = D; u.H = H; u.W = W;
         u.sd = a.sd; u.sh = a.sh; u.sw = a.sw; u.softmax = softmax;
@@ -816,7 +1091,12 @@ extern "C" int hno_upsoftmax_bwd_ld(const float *g_probs, const float *probs, fl
             const dim3 g(planes * nsplit), blk(UPB_THREADS);
             const bool ni1 = UPB_ROWS * (W / 4) <= UPB_THREADS;
             u.dbg = debug_flags();
-            if (K <= 4 && nc <= 1 && ni1) hipLaunchKernelGGL((upsoftmax_bwd_plane_kernel<4, 1, 1>), g, blk, lds, s, u);
+            if (lg) {
+                if (K <= 4 && nc <= 1 && ni1) hipLaunchKernelGGL((upsoftmax_bwd_plane_kernel<4, 1, 1, true>), g, blk, lds, s, u);
+                else if (K <= 4) hipLaunchKernelGGL((upsoftmax_bwd_plane_kernel<4, UPB_NC, 2, true>), g, blk, lds, s, u);
+                else if (nc <= 1 && ni1) hipLaunchKernelGGL((upsoftmax_bwd_plane_kernel<8, 1, 1, true>), g, blk, lds, s, u);
+                else hipLaunchKernelGGL((upsoftmax_bwd_plane_kernel<8, UPB_NC, 2, true>), g, blk, lds, s, u);
+            } else if (K <= 4 && nc <= 1 && ni1) hipLaunchKernelGGL((upsoftmax_bwd_plane_kernel<4, 1, 1>), g, blk, lds, s, u);
             else if (K <= 4) hipLaunchKernelGGL((upsoftmax_bwd_plane_kernel<4, UPB_NC, 2>), g, blk, lds, s, u);
             else if (nc <= 1 && ni1) hipLaunchKernelGGL((upsoftmax_bwd_plane_kernel<8, 1, 1>), g, blk, lds, s, u);
             else hipLaunchKernelGGL((upsoftmax_bwd_plane_kernel<8, UPB_NC, 2>), g, blk, lds, s, u);
@@ -836,6 +1116,22 @@ extern "C" int hno_upsoftmax_bwd_ld(const float *g_probs, const float *probs, fl
     else { ProfScope _ps(KID_UPSOFTMAX_BWD, s, abytes); hipLaunchKernelGGL(upsoftmax_bwd_kernel<8>, dim3(grid), dim3(256), 0, s, a); }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
+}
+
+extern "C" int hno_upsoftmax_bwd_ld(const float *g_probs, const float *probs, float *g_lr, void *workspace, int B, int K, int d,
+                                    int h, int w, int D, int H, int W, int softmax, long long ldlr, void *stream) {
+    return upsoftmax_bwd_impl(g_probs, probs, g_lr, workspace, B, K, d, h, w, D, H, W, softmax, ldlr, stream, nullptr, nullptr, nullptr);
+}
+
+// Backward of (softmax head -> PCC / Dice / ExpDice loss) in one pass (round 4): d loss / d probs = gscale (alpha t + beta p + gamma) is
+// evaluated from `coef` (what hno_loss_fwd / hno_uphead_loss_fwd left there) and the labels inside the head's backward instead of being
+// written by hno_loss_bwd (67 MB per 2 x 4 x 128^3 batch) and read back.  Separable form only (hno_upsoftmax_bwd_workspace_bytes > 0),
+// else HNO_ELIMIT: the caller then runs hno_loss_bwd + hno_upsoftmax_bwd_ld.
+extern "C" int hno_upsoftmax_loss_bwd(const float *probs, const unsigned char *labels, const float *coef, const float *gscale, float *g_lr,
+                                      void *workspace, int B, int K, int d, int h, int w, int D, int H, int W, long long ldlr, void *stream) {
+    HNO_REQUIRE(probs && labels && coef && g_lr, "hno_upsoftmax_loss_bwd: null pointer");
+    HNO_REQUIRE(((size_t)labels & 3) == 0, "hno_upsoftmax_loss_bwd: labels must be 4-byte aligned");
+    return upsoftmax_bwd_impl(nullptr, probs, g_lr, workspace, B, K, d, h, w, D, H, W, 1, ldlr, stream, labels, coef, gscale);
 }
 
 extern "C" int hno_upsoftmax_bwd(const float *g_probs, const float *probs, float *g_lr, void *workspace, int B, int K, int d,

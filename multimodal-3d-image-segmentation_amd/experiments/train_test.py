@@ -16,6 +16,7 @@ from os.path import join
 import numpy as np
 import torch
 
+from .. import ops
 from ..ops import backward_from
 from .utils import labels_to_u8, save_model_summary
 
@@ -64,7 +65,10 @@ class CapturedStep:
                 graph = torch.cuda.CUDAGraph()
                 # thread_local: a collective library's watchdog thread may poll events while we capture
                 with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
-                    loss = self.loss_fn(self.model(xs), labels_to_u8(ys, self.num_labels, self.label_mapping))
+                    lab = labels_to_u8(ys, self.num_labels, self.label_mapping)
+                    with ops.expected_loss(lab, self.loss_fn):       # the head takes the loss sums in its own pass
+                        y_pred = self.model(xs)
+                    loss = self.loss_fn(y_pred, lab)
                     if self.dp is not None:
                         self.dp.zero_grad()
                     else:
@@ -287,7 +291,8 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
             x, y = x.to(device), y.to(device)
             y = labels_to_u8(y, num_labels, label_mapping)
             with autocast():
-                y_pred = model(x)
+                with ops.expected_loss(y, loss_fn):
+                    y_pred = model(x)
                 loss = loss_fn(y_pred, y)
             losses.append(loss.detach())          # no host sync inside the step
             if data_parallel is not None:
@@ -323,7 +328,9 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
                 x, y = x.to(device), y.to(device)
                 y = labels_to_u8(y, num_labels, label_mapping)
                 with autocast():
-                    losses.append(loss_fn(model(x), y).detach())
+                    with ops.expected_loss(y, loss_fn):
+                        y_pred = model(x)
+                    losses.append(loss_fn(y_pred, y).detach())
         valid_loss = mean_loss(losses)
         if world > 1:               # same number on every rank: they must agree on best_epoch / min_loss
             t = torch.tensor([valid_loss if losses else 0.0, 1.0 if losses else 0.0], dtype=torch.float64,

@@ -20,7 +20,11 @@ def _labels_u8(y_pred, y_true):
 
 def _run(y_pred, y_true, kind, param=0.0):
     assert y_pred.ndim in (3, 4, 5)
-    return ops.SegLossFn.apply(y_pred, _labels_u8(y_pred, y_true), ops.LOSS_KINDS[kind], param)
+    lab = _labels_u8(y_pred, y_true)
+    done = ops.precomputed_loss(y_pred, lab, ops.LOSS_KINDS[kind], param)      # the head took the sums already (ops.expected_loss)
+    if done is not None:
+        return done
+    return ops.SegLossFn.apply(y_pred, lab, ops.LOSS_KINDS[kind], param)
 
 
 def corrcoef(y_pred, y_true):
@@ -36,6 +40,7 @@ def dice_coef(y_pred, y_true):
 
 class PCCLoss(Module):
     """mean(1 - (r + 1) / 2) (reference :44-70)."""
+    hno_loss_spec = ('pcc', 0.0)
 
     @staticmethod
     def forward(y_pred, y_true):
@@ -44,6 +49,7 @@ class PCCLoss(Module):
 
 class DiceLoss(Module):
     """mean(1 - dice) (reference :93-111)."""
+    hno_loss_spec = ('dice', 0.0)
 
     @staticmethod
     def forward(y_pred, y_true):
@@ -56,6 +62,10 @@ class ExpDiceLoss(Module):
     def __init__(self, exp=0.3):
         super().__init__()
         self.exp = exp
+
+    @property
+    def hno_loss_spec(self):
+        return 'expdice', self.exp
 
     def forward(self, y_pred, y_true):
         return _run(y_pred, y_true, 'expdice', self.exp)[0]

@@ -1739,12 +1739,109 @@ def output_act(output_activation):
     raise NotImplementedError(f'output activation {output_activation!r} is not provided by the HIP path (softmax, sigmoid or None)')
 
 
+@contextlib.contextmanager
+def expected_loss(labels_u8, loss_fn):
+    """``with ops.expected_loss(labels_u8, loss_fn): y = model(x)`` followed by ``loss_fn(y, labels_u8)`` -- the reference's step
+    (experiments/train_test.py:154-160) with one hint: the output head learns which loss is about to be applied to its probabilities and
+    takes the loss sums while they are in registers (hno_uphead_loss_fwd), and the backward evaluates d loss / d probs inside the head's
+    backward (hno_upsoftmax_loss_bwd) instead of writing and re-reading it.  The hint changes no result and no protocol: the head hands
+    the finished loss to ``nets.custom_losses`` on the probabilities tensor, which uses it only for the same labels and loss; any other
+    use of the probabilities takes the separate kernels as before.  Losses without ``hno_loss_spec`` (or ``HNO_HEAD_LOSS=0``) ignore it."""
+    spec = getattr(loss_fn, 'hno_loss_spec', None)
+    prev = getattr(_HEAD_MODE, 'loss', None)
+    ok = (spec is not None and torch.is_tensor(labels_u8) and labels_u8.dtype == torch.uint8 and labels_u8.is_cuda
+          and labels_u8.is_contiguous() and os.environ.get('HNO_HEAD_LOSS', '1') != '0')
+    _HEAD_MODE.loss = (labels_u8, LOSS_KINDS[spec[0]], float(spec[1])) if ok else None
+    try:
+        yield
+    finally:
+        _HEAD_MODE.loss = prev
+
+
+def precomputed_loss(y_pred, labels_u8, kind, param):
+    """(loss, coef) the head left on its output for exactly this (labels, loss), else None"""
+    hit = getattr(y_pred, '_hno_loss', None)
+    if hit is None:
+        return None
+    lab, k, p, loss, coef = hit
+    if k == kind and p == float(param) and lab.data_ptr() == labels_u8.data_ptr() and lab.numel() == labels_u8.numel():
+        return loss, coef
+    return None
+
+
 def head_output(logits_lr, size, softmax, out_act=ACT_NONE):
     """Output head shared by all model families: probabilities (training / evaluation) or labels (label_output())."""
     if getattr(_HEAD_MODE, 'labels', False):
         return up_argmax(logits_lr, size)      # arg max of the logits == arg max after softmax / sigmoid
+    hint = getattr(_HEAD_MODE, 'loss', None)
+    if hint is not None and softmax and out_act == ACT_NONE and logits_lr.is_cuda and logits_lr.ndim == 5:
+        lab, kind, param = hint
+        B, K, d, h, w = logits_lr.shape
+        D, H, W = (int(v) for v in size)
+        if lab.numel() == B * D * H * W and _lib.lib().hno_uphead_loss_supported(B, K, d, h, w, D, H, W):
+            y, loss, coef = HeadLossFn.apply(logits_lr, lab, size, kind, param)
+            y._hno_loss = (lab, kind, param, loss, coef)
+            return y
     y = UpSoftmaxFn.apply(logits_lr, size, softmax)
     return ActFn.apply(y, out_act) if out_act != ACT_NONE else y
+
+
+class HeadLossFn(_HnoFunction):
+    """Softmax head + PCC / Dice / ExpDice loss as one autograd node with outputs (probs, loss, coef): forward hno_uphead_loss_fwd,
+    backward hno_upsoftmax_loss_bwd when only the loss sends a gradient (the training step); a gradient arriving at the probabilities
+    as well is added to the loss's and takes the separate kernels."""
+
+    @staticmethod
+    def meta(logits_lr, labels_u8, size, kind, param):
+        return _m(tuple(logits_lr.shape[:2]) + tuple(size)), _m(()), _m(tuple(logits_lr.shape[:2]) + (4,))
+
+    @staticmethod
+    def forward(ctx, logits_lr, labels_u8, size, kind, param):
+        lr = _f32a(logits_lr)
+        _need_gpu(lr, labels_u8)
+        B, K, d, h, w = lr.shape
+        D, H, W = (int(s) for s in size)
+        L = _lib.lib()
+        probs = torch.empty((B, K, D, H, W), device=lr.device, dtype=torch.float32)
+        nws = L.hno_uphead_loss_workspace_doubles(B, K)
+        stats = torch.empty(nws, device=lr.device, dtype=torch.float64)
+        coef = torch.empty((B, K, 4), device=lr.device, dtype=torch.float32)
+        loss = torch.empty((), device=lr.device, dtype=torch.float32)
+        ld = chan_stride(lr)
+        check(L.hno_uphead_loss_fwd(ptr(lr), ptr(labels_u8), ptr(probs), ptr(stats), nws, ptr(coef), ptr(loss), B, K, d, h, w, D, H, W,
+                                    ld or 0, kind, float(param), stream_ptr()), 'hno_uphead_loss_fwd')
+        ctx.lr_shape, ctx.lr_ld = tuple(lr.shape), ld
+        ctx.save_for_backward(probs, labels_u8, coef)
+        ctx.mark_non_differentiable(coef)
+        ctx.set_materialize_grads(False)
+        return probs, loss, coef
+
+    @staticmethod
+    def backward(ctx, g_probs, g_loss, _gcoef):
+        if g_probs is None and g_loss is None:
+            return None, None, None, None, None
+        probs, labels_u8, coef = ctx.saved_tensors
+        B, K, d, h, w = ctx.lr_shape
+        D, H, W = probs.shape[2:]
+        L = _lib.lib()
+        nws = L.hno_upsoftmax_bwd_workspace_bytes(B, K, d, h, w, D, H, W)
+        ws = torch.empty(nws // 4, device=probs.device, dtype=torch.float32) if nws else None
+        ld = ctx.lr_ld if nws else None
+        g_lr = act_empty(B, K, (d, h, w), probs.device, ld)
+        if g_loss is not None:
+            g_loss = _f32c(g_loss).reshape(1)
+        if g_probs is None and nws and labels_u8.data_ptr() % 4 == 0:
+            check(L.hno_upsoftmax_loss_bwd(ptr(probs), ptr(labels_u8), ptr(coef), ptr(g_loss), ptr(g_lr), ptr(ws), B, K, d, h, w, D, H, W,
+                                           ld or 0, stream_ptr()), 'hno_upsoftmax_loss_bwd')
+            return g_lr, None, None, None, None
+        g = _f32c(g_probs) if g_probs is not None else None
+        if g_loss is not None:
+            gl = torch.empty_like(probs)
+            check(L.hno_loss_bwd(ptr(probs), ptr(labels_u8), ptr(coef), ptr(g_loss), ptr(gl), B, K, _flat_v(probs), stream_ptr()), 'hno_loss_bwd')
+            g = gl if g is None else g + gl
+        check(L.hno_upsoftmax_bwd_ld(ptr(g), ptr(probs), ptr(g_lr), ptr(ws), B, K, d, h, w, D, H, W, 1, ld or 0, stream_ptr()),
+              'hno_upsoftmax_bwd')
+        return g_lr, None, None, None, None
 
 
 class SegLossFn(_HnoFunction):

@@ -5,6 +5,7 @@ fp32 logits and gradients.  Individual ops are held to tighter bounds where the 
 allows; the bound used is written next to each assert.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -623,6 +624,95 @@ def test_head_on_channel_padded_logits(pkg):
     assert ops.chan_stride(res[1][1]) == ld and ops.chan_stride(res[0][1]) is None
     assert bool((res[0][0] == res[1][0]).all()) and bool((res[0][1] == res[1][1]).all()) and bool((res[0][2] == res[1][2]).all())
     assert bool((torch.empty(0, device='cuda').set_(res[1][1].untyped_storage(), 0, (2 * K, ld))[:, 33 ** 3:] == 0).all())
+
+
+@pytest.mark.parametrize('lr,hr,K', [((5, 6, 7), (10, 12, 14), 4), ((33, 33, 33), (64, 64, 64), 4), ((65, 65, 65), (128, 128, 128), 4),
+                                     ((10, 12, 14), (16, 20, 24), 5), ((6, 9, 70), (11, 17, 128), 8), ((7, 30, 9), (13, 60, 16), 3),
+                                     ((5, 6, 7), (9, 11, 13), 4)])      # the last one: odd W, not covered -> the separate kernels
+@pytest.mark.parametrize('kind,param', [(0, 0.0), (1, 0.0), (2, 0.3)])
+def test_head_and_loss_in_one_pass(pkg, lr, hr, K, kind, param):
+    """Round 4: hno_uphead_loss_fwd / hno_upsoftmax_loss_bwd (ops.HeadLossFn) against the separate head and loss kernels, and both
+    against torch in float64: probabilities, loss, coefficients and the gradient of the low-resolution logits."""
+    from multimodal_3d_image_segmentation_amd import ops
+    torch.manual_seed(3)
+    x = torch.randn((2, K) + lr, dtype=torch.float32)
+    lab = torch.randint(0, K, (2,) + hr).to(torch.uint8)
+    xd = x.cuda().requires_grad_(True)
+    labd = lab.cuda()
+    probs_s = ops.UpSoftmaxFn.apply(xd, hr, True)
+    loss_s, coef_s = ops.SegLossFn.apply(probs_s, labd, kind, param)
+    (g_s,) = torch.autograd.grad(loss_s, [xd], retain_graph=True)
+    L = pkg._lib.lib()
+    covered = bool(L.hno_uphead_loss_supported(2, K, *lr, *hr))
+    assert covered == (hr[2] % 2 == 0)
+    if covered:
+        probs_f, loss_f, coef_f = ops.HeadLossFn.apply(xd, labd, hr, kind, param)
+        (g_f,) = torch.autograd.grad(loss_f, [xd], retain_graph=True)
+        assert bool((probs_f == probs_s).all())                       # the same row kernel with and without the sums
+        assert abs(float(loss_f) - float(loss_s)) < 2e-6
+        assert rel_err(coef_f.cpu().numpy(), coef_s.cpu().numpy()) < 1e-5
+        assert rel_err(g_f.cpu().numpy(), g_s.cpu().numpy()) < 1e-5
+        # a gradient arriving at the probabilities as well: added to the loss's (separate kernels)
+        cot = torch.randn_like(probs_f)
+        (g_b,) = torch.autograd.grad(loss_f * 3.0 + (probs_f * cot).sum(), [xd])
+        (g_r,) = torch.autograd.grad(loss_s * 3.0 + (probs_s * cot).sum(), [xd])
+        assert rel_err(g_b.cpu().numpy(), g_r.cpu().numpy()) < 1e-5
+    # float64 reference
+    x64 = x.double().requires_grad_(True)
+    up = F.interpolate(x64, size=hr, mode='trilinear')
+    p64 = F.softmax(up, dim=1)
+    t = F.one_hot(lab.long(), K).permute(0, 4, 1, 2, 3).double()
+    pf, tf = p64.flatten(2), t.flatten(2)
+    if kind == 0:
+        pc, tc = pf - pf.mean(-1, keepdim=True), tf - tf.mean(-1, keepdim=True)
+        r = (pc * tc).sum(-1) / torch.sqrt((pc * pc).sum(-1) * (tc * tc).sum(-1) + 1e-7)
+        ref = (1 - (r + 1) / 2).mean()
+    else:
+        dice = 2 * (pf * tf).sum(-1) / (pf.sum(-1) + tf.sum(-1) + 1e-7)
+        ref = (1 - dice).mean() if kind == 1 else ((-torch.log(dice.clamp(1e-7, 1 - 1e-7))) ** param).mean()
+    (g64,) = torch.autograd.grad(ref, [x64])
+    got_loss, got_g = (loss_f, g_f) if covered else (loss_s, g_s)
+    assert abs(float(got_loss) - float(ref)) < 2e-6
+    assert rel_err(got_g.cpu().numpy(), g64.numpy()) < 2e-5
+
+
+def test_expected_loss_protocol(pkg):
+    """ops.expected_loss: the model's head hands the finished loss to nets.custom_losses only for the same labels and loss; anything
+    else runs the separate kernels.  Same loss and same parameter gradients either way (HNOSeg-XS, 2 x 2 x 32^3)."""
+    from multimodal_3d_image_segmentation_amd import ops
+    from multimodal_3d_image_segmentation_amd.nets import custom_losses as CL
+    torch.manual_seed(5)
+    model = pkg.nets.HNOSegXS(2, 3, 8, [1, 1], (4, 4, 4)).cuda()
+    x = torch.randn(2, 2, 32, 32, 32, device='cuda')
+    lab = torch.randint(0, 3, (2, 32, 32, 32), device='cuda').to(torch.uint8)
+    other = torch.randint(0, 3, (2, 32, 32, 32), device='cuda').to(torch.uint8)
+    params = [p for p in model.parameters() if p.requires_grad]
+    for loss_fn in (CL.PCCLoss(), CL.DiceLoss(), CL.ExpDiceLoss(0.3)):
+        y0 = model(x)
+        assert not hasattr(y0, '_hno_loss')
+        l0 = loss_fn(y0, lab)
+        g0 = torch.autograd.grad(l0, params)
+        with ops.expected_loss(lab, loss_fn):
+            y1 = model(x)
+        assert hasattr(y1, '_hno_loss')
+        l1 = loss_fn(y1, lab)
+        assert l1 is y1._hno_loss[3]                                   # taken from the head
+        g1 = torch.autograd.grad(l1, params, retain_graph=True)
+        assert abs(float(l1) - float(l0)) < 2e-6
+        num = sum(float(((a - b) ** 2).sum()) for a, b in zip(g1, g0)) ** 0.5
+        den = sum(float((b ** 2).sum()) for b in g0) ** 0.5
+        assert num / den < 2e-5
+        l2 = loss_fn(y1, other)                                        # other labels: the separate loss kernels on the same tensor
+        assert l2 is not y1._hno_loss[3]
+        assert abs(float(l2) - float(loss_fn(y0, other))) < 2e-6
+        l3 = CL.DiceLoss()(y1, lab) if not isinstance(loss_fn, CL.DiceLoss) else CL.PCCLoss()(y1, lab)      # another loss: separate
+        assert l3 is not y1._hno_loss[3]
+    os.environ['HNO_HEAD_LOSS'] = '0'
+    try:
+        with ops.expected_loss(lab, CL.PCCLoss()):
+            assert not hasattr(model(x), '_hno_loss')
+    finally:
+        del os.environ['HNO_HEAD_LOSS']
 
 
 def test_loss_is_bit_reproducible(pkg):

@@ -32,7 +32,9 @@ for name in which:
     def step():
         for p in model.parameters(): p.grad = None
         with ac():
-            loss = loss_fn(model(x), lab)
+            with pkg.ops.expected_loss(lab, loss_fn):
+                y = model(x)
+            loss = loss_fn(y, lab)
         loss.backward(); return loss
     try:
         step(); step()

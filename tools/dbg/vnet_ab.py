@@ -14,7 +14,9 @@ pkg.ops.set_defer_reduce(os.environ.get('HNO_DEFER', '1') == '1')      # batched
 def step():
     for p in model.parameters(): p.grad = None
     with torch.autocast('cuda', dtype=torch.bfloat16):
-        loss = loss_fn(model(x), lab)
+        with pkg.ops.expected_loss(lab, loss_fn):
+            y = model(x)
+        loss = loss_fn(y, lab)
     loss.backward()
 for flag in [int(a) for a in sys.argv[1:]] or [0]:
     L.hno_set_debug(flag)
