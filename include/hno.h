@@ -247,6 +247,19 @@ int hno_conv_k2s2_bwd(const float *gy, const float *y, const float *x, const flo
                       float *dbias, void *workspace, int B, int Cin, int Cout, int D, int H, int Wd, int act,
                       long long ldy, void *stream);
 
+/* Round 4: the stem of HNOSeg-XS in one pass each way -- conv_in = Conv3d(k 2, s 2, p 1) + bias + act followed by conv1 = Conv3d(k 1) +
+ * bias + act1 (nets/hnosegxs.py:102-108, 151-152).  Forward: y1 only (conv_in's output stays in the matrix-core accumulators and is not
+ * written).  Backward: recomputes conv_in's output from the image tile it reads anyway; grads = [dW_in (C0 x Cin x 8) | db_in (C0) |
+ * dW1 (C1 x C0) | db1 (C1)]; workspace of hno_conv_k2s2_chain_bwd_workspace_bytes; bit 8 of act1 defers the slab reduction.
+ * Cin <= 4, C0, C1 <= 32 (hno_conv_k2s2_chain_supported). */
+int hno_conv_k2s2_chain_supported(int Cin, int C0, int C1);
+size_t hno_conv_k2s2_chain_bwd_workspace_bytes(int Cin, int C0, int C1);
+int hno_conv_k2s2_chain_fwd(const float *x, const float *W, const float *bias, const float *W1, const float *bias1, float *y1, int B, int Cin,
+                            int C0, int C1, int D, int H, int Wd, int act, int act1, long long ldy, void *stream);
+int hno_conv_k2s2_chain_bwd(const float *gy1, const float *y1, const float *x, const float *W, const float *bias, const float *W1, float *grads,
+                            void *workspace, int B, int Cin, int C0, int C1, int D, int H, int Wd, int act, int act1, long long ldy,
+                            void *stream);
+
 /* ------------------------------------------------- output head: upsample + channel softmax
  * probs[b, c, :] = softmax_c( trilinear(logits_lr[b, c], size=(D,H,W), align_corners=False) )
  * logits_lr is (B, K, d, h, w).  Together with hno_pwconv_fwd(conv_out) at LOW resolution

@@ -61,6 +61,10 @@ SIGNATURES = {
     'hno_cmix_split_grad': (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p]),
     'hno_conv_k2s2_fwd': (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_ll, c_void_p]),
     'hno_conv_k2s2_bwd': (c_int, [c_void_p] * 8 + [c_int] * 7 + [c_ll, c_void_p]),
+    'hno_conv_k2s2_chain_supported': (c_int, [c_int] * 3),
+    'hno_conv_k2s2_chain_bwd_workspace_bytes': (c_size_t, [c_int] * 3),
+    'hno_conv_k2s2_chain_fwd': (c_int, [c_void_p] * 6 + [c_int] * 9 + [c_ll, c_void_p]),
+    'hno_conv_k2s2_chain_bwd': (c_int, [c_void_p] * 8 + [c_int] * 9 + [c_ll, c_void_p]),
     'hno_upsoftmax_fwd': (c_int, [c_void_p] * 2 + [c_int] * 9 + [c_void_p]),
     'hno_up_argmax': (c_int, [c_void_p] * 2 + [c_int] * 8 + [c_void_p]),
     'hno_upsoftmax_bwd_workspace_bytes': (c_size_t, [c_int] * 8),

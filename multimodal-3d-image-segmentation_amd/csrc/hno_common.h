@@ -140,6 +140,12 @@ __device__ __forceinline__ f32x2 selu_like_pk(f32x2 x, float ap, float aq) {
     const f32x2 pos = x * f32x2{ap, ap}, neg = neg_expm1_pk(x) * f32x2{aq, aq};
     return f32x2{x[0] > 0.f ? pos[0] : neg[0], x[1] > 0.f ? pos[1] : neg[1]};
 }
+// byte offsets are formed in 32 bits and added to a wave-uniform base: the loads and stores then take the (SGPR base + VGPR offset)
+// address form -- 64-bit per-lane address arithmetic was a third of the head kernel's instructions
+__device__ __forceinline__ float ld_off(const float *base, unsigned byte_off) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
 __device__ __forceinline__ float act_apply(float x, int act) {
     if (act == HNO_ACT_SELU) return x > 0.f ? HNO_SELU_SCALE * x : (HNO_SELU_SCALE * HNO_SELU_ALPHA) * neg_expm1(x);
     if (act == HNO_ACT_ELU) return x > 0.f ? x : neg_expm1(x);

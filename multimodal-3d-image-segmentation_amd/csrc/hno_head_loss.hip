@@ -157,12 +157,6 @@ __global__ __launch_bounds__(256) void uphead_seg_kernel(UpArgs a, unsigned char
 #define UPR_WAVES 8
 #define UPR_PITCH 132          // w + 1 <= 129 source columns (+ the duplicated last one) per class
 
-// byte offsets are formed in 32 bits and added to a wave-uniform base: the loads and stores then take the (SGPR base + VGPR offset)
-// address form -- 64-bit per-lane address arithmetic was a third of this kernel's instructions
-__device__ __forceinline__ float ld_off(const float *base, unsigned byte_off) {
-    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
-}
-
 template <int KMAX, bool STATS, bool EXACT>      // EXACT: K == KMAX at compile time (no per-class branches)
 __global__ __launch_bounds__(64 * UPR_WAVES) void uphead_rows_kernel(UpArgs a, const uint8_t *__restrict__ lab, double *__restrict__ rows) {
     constexpr int NT = 64 * UPR_WAVES, NS = KMAX * 4;

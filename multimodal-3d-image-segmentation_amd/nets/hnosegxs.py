@@ -265,9 +265,14 @@ class HNOSegXS(nn.Module):
 
     def _forward5(self, x, image_size):
         ds, enc = [], {}
-        if self.use_resize:
-            x = self.conv_in(x)
-        x = self.conv1(x)
+        if self._stem_chain_ok(x):
+            # conv_in and conv1 as one pass (ops.StemChainFn): conv_in's output is not written, the backward recomputes it
+            x = ops.StemChainFn.apply(x, self.conv_in.op.weight, self.conv_in.op.bias, self.conv1.op.weight, self.conv1.op.bias,
+                                      ops.act_id(self.conv_in.activation))
+        else:
+            if self.use_resize:
+                x = self.conv_in(x)
+            x = self.conv1(x)
         if self.use_deep_supervision:
             ds.append(x)
         nb = len(self.num_transform_blocks)
@@ -301,6 +306,13 @@ class HNOSegXS(nn.Module):
             if self.use_unet_skip and i < nb // 2:
                 enc[i] = x
         return self._head(ds if ds else [x], image_size)
+
+    def _stem_chain_ok(self, x):
+        from .. import ops_bf16
+        return (self.use_resize and x.ndim == 5 and x.is_cuda and self.conv_in.normalization is None and self.conv1.normalization is None
+                and self.conv_in.activation is self.conv1.activation and not ops_bf16.autocast_bf16()
+                and os.environ.get('HNO_STEM_CHAIN', '1') != '0'
+                and ops.StemChainFn.supported(x, self.conv_in.op.weight, self.conv1.op.weight))
 
     def _head_chain_ok(self, layer, x):
         """the last block's conv_concat and conv_out (24 -> 4, no bias) can run as one pass (ops.XSBlockFn with the conv_out weight)"""

@@ -1658,6 +1658,63 @@ class ConvK2S2Fn(_HnoFunction):
         return None, dW, db, None
 
 
+class StemChainFn(_HnoFunction):
+    """conv_in = Conv3d(k 2, s 2, p 1) + bias + act and conv1 = Conv3d(k 1) + bias + act of HNOSeg-XS (nets/hnosegxs.py:102-108, 151-152) as
+    one pass each way (hno_conv_k2s2_chain_fwd / _bwd): conv_in's output is neither written nor saved -- the backward recomputes its tile
+    from the image it reads for conv_in's weight gradient anyway."""
+
+    @staticmethod
+    def meta(x, W, bias, W1, bias1, act):
+        return _m((x.shape[0], W1.shape[0]) + tuple(v // 2 + 1 for v in x.shape[2:]))
+
+    @staticmethod
+    def supported(x, W, W1):
+        return (x.ndim == 5 and x.is_cuda and tuple(W.shape[2:]) == (2, 2, 2) and W1.shape[1] == W.shape[0]
+                and all(v == 1 for v in W1.shape[2:])
+                and bool(_lib.lib().hno_conv_k2s2_chain_supported(int(W.shape[1]), int(W.shape[0]), int(W1.shape[0]))))
+
+    @staticmethod
+    def forward(ctx, x, W, bias, W1, bias1, act):
+        ctx.leaf_params = _leaf_params(ctx, W, bias, W1, bias1)
+        x, W, bias, W1, bias1 = _f32c(x), _f32c(W), _f32c(bias), _f32c(W1), _f32c(bias1)
+        _need_gpu(x, W, W1)
+        B, Cin, D, H, Wd = x.shape
+        C0, C1 = int(W.shape[0]), int(W1.shape[0])
+        so = (D // 2 + 1, H // 2 + 1, Wd // 2 + 1)
+        ld = _pad_ld(np.prod(so)) if (getattr(_PAD, 'on', False) and so[0] > 1 and int(np.prod(so)) % 32) else None
+        y1 = act_empty(B, C1, so, x.device, ld)
+        check(_lib.lib().hno_conv_k2s2_chain_fwd(ptr(x), ptr(W), ptr(bias), ptr(W1), ptr(bias1), ptr(y1), B, Cin, C0, C1, D, H, Wd, act, act,
+                                                 ld or 0, stream_ptr()), 'hno_conv_k2s2_chain_fwd')
+        ctx.save_for_backward(x, W, bias, W1, bias1, y1)
+        ctx.act = act
+        return y1
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, W, bias, W1, bias1, y1 = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise _lib.HnoError('conv_in input gradient is not implemented (the image needs none)')
+        lp = ctx.leaf_params and _release_use(W, bias, W1, bias1)
+        late = lp and _deferrable(W, bias, W1, bias1)
+        ld = chan_stride(y1)
+        gy = to_layout(gy, ld)
+        B, Cin, D, H, Wd = x.shape
+        C0, C1 = int(W.shape[0]), int(W1.shape[0])
+        L = _lib.lib()
+        n_in, n_1 = C0 * Cin * 8, C1 * C0
+        flat = torch.empty(n_in + C0 + n_1 + C1, device=x.device, dtype=torch.float32)
+        ws = torch.empty(L.hno_conv_k2s2_chain_bwd_workspace_bytes(Cin, C0, C1) // 4, device=x.device, dtype=torch.float32)
+        with _DeferReduce(late) as d:
+            check(L.hno_conv_k2s2_chain_bwd(ptr(gy), ptr(y1), ptr(x), ptr(W), ptr(bias), ptr(W1), ptr(flat), ptr(ws), B, Cin, C0, C1, D, H, Wd,
+                                            ctx.act, ctx.act | d.bit, ld or 0, stream_ptr()), 'hno_conv_k2s2_chain_bwd')
+            d.keep(ws)
+        dW = flat[:n_in].view_as(W)
+        db = flat[n_in:n_in + C0] if bias is not None else None
+        dW1 = flat[n_in + C0:n_in + C0 + n_1].view_as(W1)
+        db1 = flat[n_in + C0 + n_1:] if bias1 is not None else None
+        return None, dW, db, dW1, db1, None
+
+
 class UpSoftmaxFn(_HnoFunction):
     """trilinear(align_corners=False) upsample of K logits + softmax over channels
     (nets/hnosegxs.py:174-180 with conv_out commuted to low resolution)."""

@@ -585,6 +585,50 @@ def test_conv_k2s2(pkg, shape, Cin, Cout):
     assert rel_err(gbd.cpu().numpy(), gb.numpy()) < 5e-6
 
 
+@pytest.mark.parametrize('shape,C0,C1,padded', [((2, 4, 16, 16, 16), 24, 24, False), ((1, 4, 32, 32, 32), 24, 24, True),
+                                                 ((2, 3, 12, 14, 130), 24, 24, False), ((2, 2, 9, 11, 13), 16, 20, False),
+                                                 ((1, 1, 8, 8, 8), 8, 32, False), ((2, 4, 128, 128, 128), 24, 24, True)])
+def test_stem_chain(pkg, shape, C0, C1, padded):
+    """Round 4: conv_in + conv1 in one pass each way (ops.StemChainFn = hno_conv_k2s2_chain_fwd / _bwd, conv_in's output recomputed in the
+    backward) against the two layers apart (ops.ConvK2S2Fn + ops.PwConvFn) and, for the small cases, against torch in float64."""
+    from multimodal_3d_image_segmentation_amd import ops
+    torch.manual_seed(0)
+    Cin = shape[1]
+    x = torch.randn(shape, dtype=torch.float64)
+    W = torch.randn(C0, Cin, 2, 2, 2, dtype=torch.float64) * 0.3
+    b = torch.randn(C0, dtype=torch.float64) * 0.1
+    W1 = torch.randn(C1, C0, 1, 1, 1, dtype=torch.float64) * 0.2
+    b1 = torch.randn(C1, dtype=torch.float64) * 0.1
+    dev = [t.float().cuda() for t in (x, W, b, W1, b1)]
+
+    def run(chain):
+        xd = dev[0]
+        ps = [t.clone().requires_grad_(True) for t in dev[1:]]
+        with ops.channel_padded(padded):
+            if chain:
+                y = ops.StemChainFn.apply(xd, ps[0], ps[1], ps[2], ps[3], ops.ACT_SELU)
+            else:
+                y = ops.PwConvFn.apply(ops.ConvK2S2Fn.apply(xd, ps[0], ps[1], ops.ACT_SELU), None, ps[2], ps[3], ops.ACT_SELU)
+            torch.manual_seed(1)
+            cot = torch.randn(tuple(y.shape), device='cuda')
+            gs = torch.autograd.grad((y * cot).sum(), ps)
+        return y.detach(), gs, cot
+    assert ops.StemChainFn.supported(dev[0], dev[1], dev[3])
+    y_c, g_c, cot = run(True)
+    y_s, g_s, _ = run(False)
+    assert (ops.chan_stride(y_c) is not None) == (padded and int(np.prod(y_c.shape[2:])) % 32 != 0)
+    assert rel_err(y_c.cpu().numpy(), y_s.cpu().numpy()) < 2e-6
+    for a, r in zip(g_c, g_s):
+        assert rel_err(a.cpu().numpy(), r.cpu().numpy()) < (2e-5 if np.prod(shape) <= 2 * 4 * 32 ** 3 else 1e-4)      # (fp32 sums over 549 250 voxels: the two orders differ by ~4e-5)
+    if np.prod(shape) <= 2 * 4 * 32 ** 3:
+        ps = [t.clone().requires_grad_(True) for t in (W, b, W1, b1)]
+        y = F.selu(F.conv3d(F.selu(F.conv3d(x, ps[0], ps[1], stride=2, padding=1)), ps[2], ps[3]))
+        gs = torch.autograd.grad((y * cot.cpu().double()).sum(), ps)
+        assert rel_err(y_c.cpu().numpy(), y.detach().numpy()) < 2e-6
+        for a, r in zip(g_c, gs):
+            assert rel_err(a.cpu().numpy(), r.numpy()) < 1e-5
+
+
 @pytest.mark.parametrize('lr,hr,K,softmax', [((5, 6, 7), (9, 11, 13), 4, True), ((33, 33, 33), (64, 64, 64), 4, True),
                                              ((4, 4, 4), (4, 4, 4), 3, True), ((6, 5, 4), (12, 9, 8), 2, False),
                                              ((65, 65, 65), (128, 128, 128), 4, True),     # benchmark head: separable backward, 4 row bands
