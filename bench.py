@@ -319,6 +319,8 @@ def main():
                         opt.step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            if opt_in_graph:
+                opt.finish_capture()           # the chunk table built during the capture -> device, once (not a copy node per replay)
         except Exception as exc:   # capture unsupported on this stack: run eagerly and say so
             print(f'[bench] HIP graph capture failed ({exc!r}); running eagerly', file=sys.stderr)
             graph = None

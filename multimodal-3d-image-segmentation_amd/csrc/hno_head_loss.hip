@@ -426,9 +426,12 @@ struct UpBwdArgs {
     const float *coef, *gscale;
 };
 
-template <int KMAX, int NC, int NI, bool LG = false>   // NI: (row, quad) items per thread, UPB_ROWS * W / 4 <= NI * UPB_THREADS
-__global__ __launch_bounds__(UPB_THREADS) void upsoftmax_bwd_plane_kernel(UpBwdArgs a) {
+// EXACT: K == KMAX and softmax at compile time (no per-class branches; the 4-class head of every BraTS configuration)
+template <int KMAX, int NC, int NI, bool LG = false, bool EXACT = false>   // NI: (row, quad) items per thread, UPB_ROWS * W / 4 <= NI * UPB_THREADS
+__global__ __launch_bounds__(UPB_THREADS) void upsoftmax_bwd_plane_kernel(UpBwdArgs a_) {
     extern __shared__ float stage[];   // [2][UPB_ROWS][K][W]
+    UpBwdArgs a = a_;
+    if constexpr (EXACT) { a.K = KMAX; a.softmax = 1; a.dbg = 0; }
     const int tid = threadIdx.x;
     if ((a.dbg & 0xe0) == 0x20) return;
     const int K = a.K, W = a.W, H = a.H, w = a.w, h = a.h;
@@ -712,7 +715,7 @@ __global__ __launch_bounds__(256) void loss_stats_vec_kernel(const float *__rest
 // coef[b][k] = {value, alpha, beta, gamma} with  dloss/dp[b,k,v] = alpha * t_v + beta * p_v + gamma
 __global__ void loss_finalize_kernel(const double *stats, float *coef, float *loss, int B, int K, long long V, int kind,
                                      float param, const double *rows = nullptr, int nrows = 0, double *stats_out = nullptr) {
-    __shared__ double part[256];
+    __shared__ double part[1024];
     if (rows) {   // per-workgroup rows [b][nrows][K * 4] -> stats_out[b][K * 4], every sum in the same fixed order on every run:
                   // n = K * 4 consecutive threads read one row (coalesced), G = 256 / n rows per pass; the G partial sums of a
                   // statistic are then added in order
@@ -992,7 +995,7 @@ extern "C" int hno_uphead_loss_fwd(const float *logits_lr, const unsigned char *
     HNO_CHECK_LAUNCH();
     {
         ProfScope _ps2(KID_LOSS_FINALIZE, s);
-        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const double *)workspace, coef, loss, B, K, V, kind, param,
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, s, (const double *)workspace, coef, loss, B, K, V, kind, param,
                            (const double *)rows, gx, workspace);
     }
     HNO_CHECK_LAUNCH();
@@ -1085,7 +1088,10 @@ static int upsoftmax_bwd_impl(const float *g_probs, const float *probs, float *g
             const dim3 g(planes * nsplit), blk(UPB_THREADS);
             const bool ni1 = UPB_ROWS * (W / 4) <= UPB_THREADS;
             u.dbg = debug_flags();
-            if (lg) {
+            const bool exact = K == 4 && softmax && !u.dbg && nc <= 1 && ni1;
+            if (exact && lg) hipLaunchKernelGGL((upsoftmax_bwd_plane_kernel<4, 1, 1, true, true>), g, blk, lds, s, u);
+            else if (exact) hipLaunchKernelGGL((upsoftmax_bwd_plane_kernel<4, 1, 1, false, true>), g, blk, lds, s, u);
+            else if (lg) {
                 if (K <= 4 && nc <= 1 && ni1) hipLaunchKernelGGL((upsoftmax_bwd_plane_kernel<4, 1, 1, true>), g, blk, lds, s, u);
                 else if (K <= 4) hipLaunchKernelGGL((upsoftmax_bwd_plane_kernel<4, UPB_NC, 2, true>), g, blk, lds, s, u);
                 else if (nc <= 1 && ni1) hipLaunchKernelGGL((upsoftmax_bwd_plane_kernel<8, 1, 1, true>), g, blk, lds, s, u);

@@ -39,15 +39,17 @@ __global__ __launch_bounds__(256) void adamax_multi_kernel(const AdamaxChunk *__
 // whole step is then one graph replay).  state (doubles; integers are exact):
 //   [0] step (optimizer steps taken)   [1] lr (of the NEXT update)   [2] base_lr   [3] eta_min   [4] T_cur   [5] T_i   [6] T_mult
 //   [7] schedule: 0 = constant lr, 1 = CosineAnnealingWarmRestarts stepped once per optimizer step (experiments/run.py:92-103,
-//       train_test.py:173-174)          [8] clr = lr / (1 - beta1^step) of the CURRENT update (written by the tick kernel)
-// tick (one thread, in front of the update): step += 1; clr from the current lr; then the scheduler's step() for the next update, as
+//       train_test.py:173-174)          [8] clr = lr / (1 - beta1^(step + 1)) of the NEXT update          [9] ticket counter (bits)
+//
+// The state is advanced by the LAST workgroup of the update kernel itself (a ticket counter behind the doubles; round 4b: a separate
+// one-thread kernel in front of the update cost a 5 us launch per step): every workgroup reads clr = st[8] at its start, takes a ticket
+// when its stores are done, and the holder of the last ticket does   step += 1;   the scheduler's step() for the next update, as
 // torch.optim.lr_scheduler.CosineAnnealingWarmRestarts.step() does it: T_cur += 1; if T_cur >= T_i: T_cur -= T_i, T_i *= T_mult;
-// lr = eta_min + (base_lr - eta_min) (1 + cos(pi T_cur / T_i)) / 2, all in double.
-__global__ void adamax_tick_kernel(double *st, double beta1) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// lr = eta_min + (base_lr - eta_min) (1 + cos(pi T_cur / T_i)) / 2, all in double;   st[8] = (float) lr / (1 - beta1^(step + 1)) for the
+// NEXT update (the host writes the first one: optim.Adamax.device_stepped);   ticket counter = 0.
+__device__ __forceinline__ void adamax_advance(double *st, double beta1) {
     const double step = st[0] + 1.0;
     st[0] = step;
-    st[8] = (double)(float)st[1] / (1.0 - pow(beta1, step));      // (the eager entry point takes lr as a float: same rounding)
     if (st[7] == 1.0) {
         double T_cur = st[4] + 1.0, T_i = st[5];
         if (T_cur >= T_i) {
@@ -58,9 +60,10 @@ __global__ void adamax_tick_kernel(double *st, double beta1) {
         st[5] = T_i;
         st[1] = st[3] + (st[2] - st[3]) * (1.0 + cos(M_PI * T_cur / T_i)) / 2.0;
     }
+    st[8] = (double)(float)st[1] / (1.0 - pow(beta1, step + 1.0));      // (the eager entry point takes lr as a float: same rounding)
 }
 
-__global__ __launch_bounds__(256) void adamax_multi_dev_kernel(const AdamaxChunk *__restrict__ table, const double *__restrict__ st, float beta1,
+__global__ __launch_bounds__(256) void adamax_multi_dev_kernel(const AdamaxChunk *__restrict__ table, double *st, float beta1,
                                                                float beta2, float eps, float wd, float gscale) {
     const AdamaxChunk c = table[blockIdx.x];
     const float clr = (float)st[8];
@@ -74,13 +77,23 @@ __global__ __launch_bounds__(256) void adamax_multi_dev_kernel(const AdamaxChunk
         c.u[i] = u;
         c.p[i] = p - clr * (m / u);
     }
+    __syncthreads();                                       // (every thread of this workgroup has read clr)
+    if (threadIdx.x == 0) {
+        unsigned *ticket = reinterpret_cast<unsigned *>(st + 9);
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {      // all workgroups are past their read of st[8]
+            adamax_advance(st, (double)beta1);
+            *ticket = 0u;
+            __threadfence();
+        }
+    }
 }
 
 }  // namespace hno
 
 using namespace hno;
 
-extern "C" int hno_adamax_state_doubles(void) { return 9; }
+extern "C" int hno_adamax_state_doubles(void) { return 10; }   // 9 doubles + the ticket counter
 
 // one Adamax step driven by the device state (see above); capturable: no host value changes from step to step
 extern "C" int hno_adamax_multi_dev(const void *table, int n_chunks, void *state, float beta1, float beta2, float eps, float weight_decay,
@@ -88,8 +101,7 @@ extern "C" int hno_adamax_multi_dev(const void *table, int n_chunks, void *state
     HNO_REQUIRE(table && n_chunks > 0 && state, "hno_adamax_multi_dev: bad argument");
     HNO_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "hno_adamax_multi_dev: bad hyper-parameter");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(adamax_tick_kernel, dim3(1), dim3(64), 0, s, (double *)state, (double)beta1);
-    hipLaunchKernelGGL(adamax_multi_dev_kernel, dim3(n_chunks), dim3(256), 0, s, (const AdamaxChunk *)table, (const double *)state, beta1, beta2,
+    hipLaunchKernelGGL(adamax_multi_dev_kernel, dim3(n_chunks), dim3(256), 0, s, (const AdamaxChunk *)table, (double *)state, beta1, beta2,
                        eps, weight_decay, grad_scale);
     HNO_CHECK_LAUNCH();
     return HNO_OK;

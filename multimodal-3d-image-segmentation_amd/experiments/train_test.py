@@ -83,6 +83,8 @@ class CapturedStep:
                         self.optimizer.step()
             cur.wait_stream(side)
             torch.cuda.synchronize()
+            if self.optimizer is not None:
+                self.optimizer.finish_capture()      # chunk tables built during the capture -> device, once
         except Exception as exc:        # capture not possible for this model / shape: stay eager
             if os.environ.get('HNO_TRAIN_GRAPH_DEBUG'):
                 import traceback

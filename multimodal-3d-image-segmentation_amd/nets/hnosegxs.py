@@ -309,7 +309,9 @@ class HNOSegXS(nn.Module):
 
     def _stem_chain_ok(self, x):
         from .. import ops_bf16
-        return (self.use_resize and x.ndim == 5 and x.is_cuda and self.conv_in.normalization is None and self.conv1.normalization is None
+        hooked = any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks for m in (self.conv_in, self.conv1))
+        return (self.use_resize and not hooked      # (the two modules' own forward() is bypassed: hooks on them keep the layers apart)
+                and x.ndim == 5 and x.is_cuda and self.conv_in.normalization is None and self.conv1.normalization is None
                 and self.conv_in.activation is self.conv1.activation and not ops_bf16.autocast_bf16()
                 and os.environ.get('HNO_STEM_CHAIN', '1') != '0'
                 and ops.StemChainFn.supported(x, self.conv_in.op.weight, self.conv1.op.weight))

@@ -205,6 +205,26 @@ def _grad_buffer_stacked(params):
     return torch.empty((len(params),) + tuple(p0.shape), device=p0.device, dtype=torch.float32)
 
 
+def _grad_buffer_concat(params):
+    """one flat fp32 buffer for the gradients of `params` laid end to end in this order: the registered destinations themselves when
+    they lie back to back like that in the flat gradient buffer (consecutive parameters of consecutive modules do), else fresh."""
+    n = sum(p.numel() for p in params)
+    if _grad_dest:
+        vs = [_grad_dest.get(p.data_ptr()) for p in params]
+        if all(v is not None and p.grad is None and tuple(v.shape) == tuple(p.shape) and p.data_ptr() not in _dest_written
+               for v, p in zip(vs, params)):
+            off, ok = vs[0].data_ptr(), True
+            for v in vs:
+                ok = ok and v.data_ptr() == off
+                off += v.numel() * 4
+            if ok:
+                _dest_written.update(p.data_ptr() for p in params)
+                base = vs[0]._base if vs[0]._base is not None else vs[0]
+                o = (vs[0].data_ptr() - base.data_ptr()) // 4
+                return base.reshape(-1)[o:o + n]
+    return torch.empty(n, device=params[0].device, dtype=torch.float32)
+
+
 # ------------------------------------------------------------------------- raw launchers
 def _block0(N0, m0):
     """size of the kept block along the first axis: a degenerate axis (N0 = 1, m0 = 0; 2-D data viewed as
@@ -1695,14 +1715,19 @@ class StemChainFn(_HnoFunction):
         if ctx.needs_input_grad[0]:
             raise _lib.HnoError('conv_in input gradient is not implemented (the image needs none)')
         lp = ctx.leaf_params and _release_use(W, bias, W1, bias1)
-        late = lp and _deferrable(W, bias, W1, bias1)
+        late = lp and _deferrable(W, bias, W1, bias1) and os.environ.get('HNO_STEM_DEFER', '1') != '0'
         ld = chan_stride(y1)
         gy = to_layout(gy, ld)
         B, Cin, D, H, Wd = x.shape
         C0, C1 = int(W.shape[0]), int(W1.shape[0])
         L = _lib.lib()
         n_in, n_1 = C0 * Cin * 8, C1 * C0
-        flat = torch.empty(n_in + C0 + n_1 + C1, device=x.device, dtype=torch.float32)
+        # [dW_in | db_in | dW1 | db1] is the order of the four parameters in the model: the kernel's output IS their run of the flat
+        # gradient buffer when one is registered (data-parallel replicas)
+        if bias is not None and bias1 is not None:
+            flat = _grad_buffer_concat([W, bias, W1, bias1])
+        else:
+            flat = torch.empty(n_in + C0 + n_1 + C1, device=x.device, dtype=torch.float32)
         ws = torch.empty(L.hno_conv_k2s2_chain_bwd_workspace_bytes(Cin, C0, C1) // 4, device=x.device, dtype=torch.float32)
         with _DeferReduce(late) as d:
             check(L.hno_conv_k2s2_chain_bwd(ptr(gy), ptr(y1), ptr(x), ptr(W), ptr(bias), ptr(W1), ptr(flat), ptr(ws), B, Cin, C0, C1, D, H, Wd,

@@ -61,6 +61,11 @@ class Adamax(torch.optim.Optimizer):
                 return False
             st[2], st[3] = float(scheduler.base_lrs[0]), float(scheduler.eta_min)
             st[4], st[5], st[6], st[7] = float(scheduler.T_cur), float(scheduler.T_i), float(scheduler.T_mult), 1.0
+        # [8]: lr / (1 - beta1^(step + 1)) of the first update (the kernel's last workgroup writes the following ones), lr rounded to fp32 as
+        # the eager entry point receives it; [9]: the kernel's ticket counter
+        import numpy as np
+        st[8] = float(np.float32(st[1])) / (1.0 - float(np.float32(group['betas'][0])) ** (step + 1.0))     # (beta1 reaches the kernels as a float)
+        st.append(0.0)
         assert _lib.lib().hno_adamax_state_doubles() == len(st)
         self._dev = (torch.tensor(st, dtype=torch.float64, device=params[0].device), scheduler)
         # scheduler.last_epoch counts its step() calls; it normally equals the optimizer's step count (both stepped once per batch)
@@ -142,14 +147,24 @@ class Adamax(torch.optim.Optimizer):
                 raise _lib.HnoError('optim.Adamax: no pre-allocated table left for a captured step (run this batch shape eagerly)')
             host, table = pool.pop()
             host[:len(rows)] = torch.tensor(rows, dtype=torch.int64)
-            table.copy_(host, non_blocking=True)
-            self._table_keep = getattr(self, '_table_keep', []) + [host]
+            # the rows reach the device ONCE, after the capture (finish_capture): a copy node inside the graph would move the same
+            # 8 KB again at every replay (4.7 us per step in the kernel trace of round 4)
+            self._unfilled = getattr(self, '_unfilled', []) + [(host, table)]
         else:
             table = torch.tensor(rows, dtype=torch.int64).to(dev)
         if len(self._tables) > 8 and not torch.cuda.is_current_stream_capturing():
             self._tables.clear()
         self._tables[key] = (table, len(rows))
         return self._tables[key]
+
+    def finish_capture(self):
+        """after a graph capture that contained step(): copy the chunk tables built during the capture to the device (synchronous; the
+        captured launch reads them at every replay).  MUST run before the first replay -- CapturedStep and bench.py call it."""
+        for host, table in getattr(self, '_unfilled', []):
+            table.copy_(host)
+        self._unfilled = []
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
 
     def _reserve_tables(self, count=4):
         """(pinned host, device) buffer pairs for chunk tables built inside graph captures (gradient addresses of a captured step are
@@ -167,6 +182,8 @@ class Adamax(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         L = _lib.lib()
+        if getattr(self, '_unfilled', None) and not torch.cuda.is_current_stream_capturing():
+            self.finish_capture()
         for group in self.param_groups:
             self._init_state(group)
             by_step = {}
