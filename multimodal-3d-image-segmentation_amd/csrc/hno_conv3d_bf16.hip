@@ -641,10 +641,13 @@ __global__ __launch_bounds__(256) void cb_gn_apply_kernel(const bf16_t *__restri
 // backward, pass 1: with u = gamma xhat + beta, t = dz act'(u):  per (block, channel) partial sums of t and t xhat.
 // Each block owns a contiguous run of voxels of ONE sample; thread t of 256 handles channel group (t % C8) of voxel
 // (t / C8) + k * (256 / C8) ... the partials go through LDS to one slab row per block: [b][blk][2][C].
+// kpart[b][blk] = (sum_c gamma_c S1_c, sum_c gamma_c S2_c) of this workgroup's rows: what pass 2 needs of pass 1 is only their sum over
+// the workgroups (k1, k2), so pass 2 adds these up itself and the per-channel sums (pass 1b) move into ONE of its workgroups -- no launch
+// between the two streaming passes (round 4b; the finalize launch was 39 x 7.2 us of a V-Net-DS step)
 __global__ __launch_bounds__(256) void cb_gn_bwd_reduce_kernel(const bf16_t *__restrict__ dz, const bf16_t *__restrict__ y,
                                                               const float *__restrict__ mr, const float *__restrict__ gamma,
                                                               const float *__restrict__ beta, float *__restrict__ slab, int C, long long V,
-                                                              int act) {
+                                                              int act, float *__restrict__ kpart) {
     extern __shared__ float lds[];    // [256][24]
     const int b = blockIdx.y, nblk = gridDim.x;
     const float mean = mr[2 * b], rstd = mr[2 * b + 1];
@@ -695,18 +698,40 @@ __global__ __launch_bounds__(256) void cb_gn_bwd_reduce_kernel(const bf16_t *__r
         for (int t = g8; t < S; t += C8) acc += lds[t * 24 + which * 8 + j];
         dst[i] = acc;
     }
+    if (kpart) {
+        float q1 = 0.f, q2 = 0.f;
+        for (int i = threadIdx.x; i < 2 * C; i += 256) {       // (re-summed from LDS in the same order: bit-identical to dst[i])
+            const int which = i / C, c = i - which * C, g8 = c >> 3, j = c & 7;
+            float acc = 0.f;
+            for (int t = g8; t < S; t += C8) acc += lds[t * 24 + which * 8 + j];
+            if (which == 0) q1 = fmaf(gamma[c], acc, q1);
+            else q2 = fmaf(gamma[c], acc, q2);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            q1 += __shfl_xor(q1, o);
+            q2 += __shfl_xor(q2, o);
+        }
+        if ((threadIdx.x & 63) == 0) { lds[(threadIdx.x >> 6) * 2] = q1; lds[(threadIdx.x >> 6) * 2 + 1] = q2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float *kp = kpart + ((size_t)b * nblk + blockIdx.x) * 2;
+            kp[0] = (lds[0] + lds[2]) + (lds[4] + lds[6]);
+            kp[1] = (lds[1] + lds[3]) + (lds[5] + lds[7]);
+        }
+    }
 }
 
 // pass 1b: slabs -> dgamma[c], dbeta[c] (summed over samples and blocks, fixed order) and gS[b][which][c] = gamma_c S_which[b][c].
 // One workgroup per 8 channels: thread (slice = t >> 3, j = t & 7) sums every 32nd slab row of channel 8 blockIdx.x + j,
 // the 32 slices are then added in order.  (A single-workgroup version of this kernel -- 256 dependent loads per thread --
 // cost 0.2-0.5 ms per call, 10 ms of the 18 ms V-Net step.)
-__global__ __launch_bounds__(256) void cb_gn_bwd_finalize_kernel(const float *__restrict__ slab, const float *__restrict__ gamma, int B, int nblk,
-                                                                int C, float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                                float *__restrict__ gS, int accumulate) {
-    __shared__ float sh[3][32][8];
+__device__ __forceinline__ void cb_gn_bwd_finalize_group(const float *__restrict__ slab, const float *__restrict__ gamma, int B, int nblk,
+                                                         int C, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                         float *__restrict__ gS, int accumulate, int group, float (*sh)[32][8]) {
     const int j = threadIdx.x & 7, slice = threadIdx.x >> 3;
-    const int c = blockIdx.x * 8 + j;
+    const int c = group * 8 + j;
     float dg = 0.f, db = 0.f;
     for (int b = 0; b < B; ++b) {
         float s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -737,20 +762,74 @@ __global__ __launch_bounds__(256) void cb_gn_bwd_finalize_kernel(const float *__
     }
 }
 
+__global__ __launch_bounds__(256) void cb_gn_bwd_finalize_kernel(const float *__restrict__ slab, const float *__restrict__ gamma, int B, int nblk,
+                                                                int C, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                                float *__restrict__ gS, int accumulate) {
+    __shared__ float sh[3][32][8];
+    cb_gn_bwd_finalize_group(slab, gamma, B, nblk, C, dgamma, dbeta, gS, accumulate, blockIdx.x, sh);
+}
+
 // pass 2: dy = rstd (gamma t - k1 - xhat k2), bf16 channels-last
 __global__ __launch_bounds__(256) void cb_gn_bwd_apply_kernel(const bf16_t *__restrict__ dz, const bf16_t *__restrict__ y, const float *__restrict__ mr,
                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
                                                              const float *__restrict__ gS, bf16_t *__restrict__ dy, int C, long long per_sample,
-                                                             int act, float *__restrict__ dcolsum, int B) {
+                                                             int act, float *__restrict__ dcolsum, int B, const float *__restrict__ kpart,
+                                                             int nblk, const float *__restrict__ slab, float *__restrict__ dgamma,
+                                                             float *__restrict__ dbeta, float *__restrict__ gS_w, int accumulate) {
     const int b = blockIdx.y;
+    // pass 1b (kpart form): workgroup g of sample 0 owns channel group g (8 channels): their sums over samples and slab rows -> dgamma,
+    // dbeta, gS and -- per channel independent -- the convolution's bias gradient.  (All groups in ONE workgroup made that workgroup the
+    // kernel's long pole on the deep levels: 48 groups x two barriers and a global round trip each = 0.7 ms per step.)
+    if (kpart && blockIdx.y == 0 && (int)blockIdx.x < (C >> 3)) {
+        __shared__ float sh[3][32][8];
+        __shared__ float kq[2][64];
+        const float inv_n0 = 1.0f / (float)per_sample, Vf0 = (float)(per_sample / C);
+        for (int grp = blockIdx.x; grp < (C >> 3); grp += gridDim.x) {
+            __syncthreads();
+            cb_gn_bwd_finalize_group(slab, gamma, B, nblk, C, dgamma, dbeta, gS_w, accumulate, grp, sh);
+            __syncthreads();                               // this workgroup's own gS writes are read back below
+            if (dcolsum) {
+                float colsum = 0.f;
+                for (int bb = 0; bb < B; ++bb) {
+                    // k1, k2 of sample bb: wave 0 adds the kpart rows in a fixed order
+                    if (threadIdx.x < 64) {
+                        float a1 = 0.f, a2 = 0.f;
+                        for (int k = threadIdx.x; k < nblk; k += 64) {
+                            a1 += kpart[((size_t)bb * nblk + k) * 2];
+                            a2 += kpart[((size_t)bb * nblk + k) * 2 + 1];
+                        }
+                        kq[0][threadIdx.x] = a1;
+                        kq[1][threadIdx.x] = a2;
+                    }
+                    __syncthreads();
+                    if (threadIdx.x < 8) {
+                        float q1 = 0.f, q2 = 0.f;
+                        for (int t = 0; t < 64; ++t) { q1 += kq[0][t]; q2 += kq[1][t]; }
+                        const int c = grp * 8 + threadIdx.x;
+                        colsum += mr[2 * bb + 1] * (gS_w[((size_t)bb * 4) * C + c] - Vf0 * (q1 * inv_n0) - (q2 * inv_n0) * gS_w[((size_t)bb * 4 + 2) * C + c]);
+                    }
+                    __syncthreads();
+                }
+                if (threadIdx.x < 8) dcolsum[grp * 8 + threadIdx.x] = colsum;
+            }
+        }
+        __syncthreads();
+    }
     // k1 = sum_c gS[b][0][c] / N, k2 = sum_c gS[b][1][c] / N: every workgroup re-reduces the <= 2 x 2048 values itself (fixed
     // order, so all workgroups agree bit for bit) instead of waiting for one more tiny launch
     __shared__ float kred[2][256];
     {
         float a1 = 0.f, a2 = 0.f;
-        for (int c = threadIdx.x; c < C; c += 256) {
-            a1 += gS[((size_t)b * 4) * C + c];
-            a2 += gS[((size_t)b * 4 + 1) * C + c];
+        if (kpart) {
+            for (int k = threadIdx.x; k < nblk; k += 256) {
+                a1 += kpart[((size_t)b * nblk + k) * 2];
+                a2 += kpart[((size_t)b * nblk + k) * 2 + 1];
+            }
+        } else {
+            for (int c = threadIdx.x; c < C; c += 256) {
+                a1 += gS[((size_t)b * 4) * C + c];
+                a2 += gS[((size_t)b * 4 + 1) * C + c];
+            }
         }
         kred[0][threadIdx.x] = a1;
         kred[1][threadIdx.x] = a2;
@@ -768,7 +847,7 @@ __global__ __launch_bounds__(256) void cb_gn_bwd_apply_kernel(const bf16_t *__re
     // Column sums of dy = the bias gradient of the convolution that produced y, without another pass over dy:
     //   sum_v dy[c][v] = rstd (gamma_c S1_c - V k1 - k2 S3_c),  S1 = sum_v t, S3 = sum_v xhat  (both already reduced per channel).
     // Workgroup (0, 0) does it for every sample (k1, k2 of the other samples re-reduced the same way), fixed order.
-    if (dcolsum && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (dcolsum && !kpart && blockIdx.x == 0 && blockIdx.y == 0) {
         const float Vf = (float)(per_sample / C);
         for (int c = threadIdx.x; c < C; c += 256) dcolsum[c] = 0.f;
         for (int bb = 0; bb < B; ++bb) {
@@ -1636,7 +1715,7 @@ extern "C" int hno_cb_gn_apply(const void *y1, const float *mr1, const float *ga
 
 #define CB_GN_BWD_BLOCKS 1024     // upper bound; small tensors use fewer (>= 64 voxels per workgroup)
 extern "C" size_t hno_cb_gn_bwd_workspace_bytes(int B, int C) {
-    return ((size_t)B * CB_GN_BWD_BLOCKS * 3 * C + 4 * (size_t)B * C + 2 * (size_t)(B > 8 ? B : 8)) * sizeof(float) + 256;
+    return ((size_t)B * CB_GN_BWD_BLOCKS * 3 * C + 4 * (size_t)B * C + 2 * (size_t)(B > 8 ? B : 8) + 2 * (size_t)B * CB_GN_BWD_BLOCKS) * sizeof(float) + 256;
 }
 
 // backward of z = act(gamma (y - mean) rstd + beta) w.r.t. y, gamma, beta.  accumulate != 0: dgamma / dbeta += .
@@ -1655,16 +1734,19 @@ extern "C" int hno_cb_gn_bwd(const void *dz, const void *y, const float *mr, con
     if (nblk < 1) nblk = 1;
     {
         ProfScope _ps(KID_CB_GN, s, (double)B * V * C * 4.0);
+        static const bool apart = getenv("HNO_GN_FINALIZE_LAUNCH") && atoi(getenv("HNO_GN_FINALIZE_LAUNCH")) == 1;      // A/B: pass 1b as its own launch
+        float *kpart = apart ? nullptr : gS + 4 * (size_t)B * C + 2 * (size_t)(B > 8 ? B : 8);
         hipLaunchKernelGGL(cb_gn_bwd_reduce_kernel, dim3(nblk, B), dim3(256), 256 * 24 * sizeof(float), s, (const bf16_t *)dz, (const bf16_t *)y, mr, gamma,
-                           beta, slab, C, V, act);
+                           beta, slab, C, V, act, kpart);
         HNO_CHECK_LAUNCH();
-    }
-    hipLaunchKernelGGL(cb_gn_bwd_finalize_kernel, dim3(C / 8), dim3(256), 0, s, (const float *)slab, gamma, B, nblk, C, dgamma, dbeta, gS, accumulate);
-    HNO_CHECK_LAUNCH();
-    {
-        ProfScope _ps(KID_CB_GN, s, (double)B * V * C * 6.0);
+        if (apart) {
+            hipLaunchKernelGGL(cb_gn_bwd_finalize_kernel, dim3(C / 8), dim3(256), 0, s, (const float *)slab, gamma, B, nblk, C, dgamma, dbeta, gS, accumulate);
+            HNO_CHECK_LAUNCH();
+        }
+        ProfScope _ps2(KID_CB_GN, s, (double)B * V * C * 6.0);
         hipLaunchKernelGGL(cb_gn_bwd_apply_kernel, dim3(gsz(V * C / 8, 256, 2048), B), dim3(256), 0, s, (const bf16_t *)dz, (const bf16_t *)y, mr, gamma,
-                           beta, (const float *)gS, (bf16_t *)dy, C, V * C, act, dy_colsum, B);
+                           beta, (const float *)gS, (bf16_t *)dy, C, V * C, act, dy_colsum, B, (const float *)kpart, nblk, (const float *)slab, dgamma,
+                           dbeta, gS, accumulate);
         HNO_CHECK_LAUNCH();
     }
     return HNO_OK;

@@ -407,7 +407,7 @@ class VNetDS(nn.Module):
             assert all(a >= b for a, b in zip(up.shape[1:4], (d, hh, w)))
             lo = [(a - b) // 2 for a, b in zip(up.shape[1:4], (d, hh, w))]      # spatial_padcrop: the extra element goes high
             if tuple(up.shape[1:4]) != (d, hh, w):
-                up = up[:, lo[0]:lo[0] + d, lo[1]:lo[1] + hh, lo[2]:lo[2] + w, :].contiguous()
+                up = ob.CropHighFn.apply(up, lo, (d, hh, w)) if (not up.is_meta and os.environ.get('HNO_VNET_GLUE', '1') != '0') else up[:, lo[0]:lo[0] + d, lo[1]:lo[1] + hh, lo[2]:lo[2] + w, :].contiguous()
             h, _ = section(list(layers)[1:], up, enc[i], self.num_blocks[i])    # the concat is fused into the convolutions
             if i in self.right_leg_indexes:
                 legs[i] = h
@@ -419,9 +419,13 @@ class VNetDS(nn.Module):
             w = op.weight.reshape(op.weight.shape[0], -1)
             ref_size = tuple(legs[0].shape[1:4])
             acc, c0 = None, 0
+            wlegs = ob.LegWeightsFn.apply(w, tuple(t.shape[4] for t in legs.values())) if (not x.is_meta and os.environ.get('HNO_VNET_GLUE', '1') != '0') else None
             for idx, (key, t) in enumerate(legs.items()):   # insertion order = concat order of the reference
                 c = t.shape[4]
-                part = ob.pointwise_to_f32(t, w[:, c0:c0 + c], op.bias if idx == 0 else None, w.shape[0])
+                if wlegs is not None:
+                    part = ob.pointwise_to_f32(t, wlegs[idx], op.bias if idx == 0 else None, w.shape[0], padded=True)
+                else:
+                    part = ob.pointwise_to_f32(t, w[:, c0:c0 + c], op.bias if idx == 0 else None, w.shape[0])
                 if tuple(part.shape[2:]) != ref_size:
                     part = ops.NearestUpFn.apply(part, ref_size)
                 acc = part if acc is None else ops.AddFn.apply(acc, part)

@@ -425,7 +425,58 @@ def conv_norm_act(layer, xa, xb=None, residual=None):
     return GNActFn.apply(y, mr, g, bt, act, y2, mr2, g2, b2, nstat, nstat2, eps)
 
 
-def pointwise_to_f32(x, weight, bias, out_channels):
+class CropHighFn(torch.autograd.Function):
+    """x[:, lo0:lo0 + d, lo1:lo1 + h, lo2:lo2 + w, :] of a channels-last tensor as ONE node: a Python slice over three axes is three
+    autograd nodes whose backward each fills and copies a full-size tensor (6 kernels per decoder level and step in the V-Net trace);
+    here the backward is one zero fill and one copy."""
+
+    @staticmethod
+    def forward(ctx, x, lo, size):
+        ctx.lo, ctx.size, ctx.shape = tuple(lo), tuple(size), tuple(x.shape)
+        (a, b, c), (d, h, w) = ctx.lo, ctx.size
+        return x[:, a:a + d, b:b + h, c:c + w, :].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        (a, b, c), (d, h, w) = ctx.lo, ctx.size
+        gx = torch.zeros(ctx.shape, device=g.device, dtype=g.dtype)
+        gx[:, a:a + d, b:b + h, c:c + w, :] = g
+        return gx, None, None
+
+
+class LegWeightsFn(torch.autograd.Function):
+    """The (K, C_total) weight of the deep-supervision 1x1x1 convolution over the concatenated legs (nets/architectures.py:474-476),
+    handed out as one contiguous (8, C_leg) matrix per leg (K rows padded to the 8 the bf16 GEMM needs).  One node: per-leg column
+    slices + F.pad were ~3 kernels per leg forward and, through autograd's slice / pad backward, a zero-filled (K, C_total) tensor
+    and an accumulation per leg backward (14 launches); the backward here is one concatenation."""
+
+    @staticmethod
+    def forward(ctx, w, sizes):
+        K, Ct = w.shape
+        ctx.K = K
+        wp = torch.zeros((K + (-K) % 8, Ct), device=w.device, dtype=w.dtype)
+        wp[:K] = w
+        out, c0 = [], 0
+        for c in sizes:
+            out.append(wp[:, c0:c0 + c].contiguous())
+            c0 += c
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return torch.cat(grads, dim=1)[:ctx.K], None
+
+
+def pointwise_to_f32(x, weight, bias, out_channels, padded=False):
+    """padded: `weight` already has its rows padded to a multiple of 8 (LegWeightsFn)"""
+    if padded:
+        b = torch.nn.functional.pad(bias, (0, weight.shape[0] - bias.shape[0])) if bias is not None else None
+        y, _ = ConvFn.apply(x, None, weight.reshape(weight.shape[0], weight.shape[1], 1, 1, 1), b, 1, 1, False, False, 1e-5)
+        return UnpackFn.apply(y, out_channels)
+    return _pointwise_to_f32(x, weight, bias, out_channels)
+
+
+def _pointwise_to_f32(x, weight, bias, out_channels):
     """1x1x1 conv of a channels-last bf16 tensor to a few (< 8) output channels, returned as fp32 NCDHW: where the bf16
     body hands over to the fp32 head (deep-supervision legs, conv_out).  The output channels are padded to 8 for the GEMM."""
     w2 = weight.reshape(weight.shape[0], -1)

@@ -26,5 +26,5 @@ for e in prof.events():
     if e.name.startswith('aten::') and e.name.split('::')[1] in ('fill_', 'zero_', 'copy_', 'add', 'add_', 'cat', 'mul', 'sum', 'clone'):
         st = [s for s in (e.stack or []) if 'multimodal' in s or 'tools/' in s]
         agg[(e.name, str(e.input_shapes)[:70], st[0][-70:] if st else '?')] += 1
-for (k, n) in agg.most_common(30):
+for (k, n) in agg.most_common(60):
     print(f'x{n:3d} {k[0]:14s} {k[1]:72s} {k[2]}')
