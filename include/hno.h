@@ -414,6 +414,12 @@ int hno_hmha_fwd(const float *q, const float *k, const float *v, float *out, voi
 int hno_hmha_bwd(const float *q, const float *k, const float *v, const float *dout, float *dq, float *dk, float *dv, void *workspace,
                  size_t workspace_bytes, int BZ, int Ck, int Cv, int T, float alpha, int act, void *stream);
 
+/* Round 4b: grouping3d / ungrouping3d (nets/hartley_mha.py:473-524) as one permutation kernel.  full: (B, C0 + C1 + C2, d, h, w), the
+ * stacked q / k / v projections (or one tensor: C1 = C2 = 0); p_s: (B, C_s pd ph pw, (d / pd)(h / ph)(w / pw)) contiguous, NULL = skipped
+ * (inverse: that channel range of `full` is zero-filled).  inverse = 0: full -> parts (grouping3d); 1: parts -> full (ungrouping3d). */
+int hno_patch_group3(float *full, float *p0, float *p1, float *p2, int B, int C0, int C1, int C2, int d, int h, int w, int pd, int ph,
+                     int pw, int inverse, void *stream);
+
 /* ------------------------------------------------------------------- elementwise helpers
  * y = act(x) ; gx = g * act'(y) (y = saved output) ; out = a + b.  Used where the reference applies an
  * activation or a residual add that no neighbouring kernel can absorb (nets/architectures.py:529-546). */

@@ -107,6 +107,7 @@ SIGNATURES = {
     'hno_hmha_workspace_bytes': (c_size_t, [c_int] * 4),
     'hno_hmha_fwd': (c_int, [c_void_p] * 5 + [c_size_t] + [c_int] * 4 + [c_float, c_int, c_void_p]),
     'hno_hmha_bwd': (c_int, [c_void_p] * 8 + [c_size_t] + [c_int] * 4 + [c_float, c_int, c_void_p]),
+    'hno_patch_group3': (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p]),
     'hno_act_fwd': (c_int, [c_void_p, c_void_p, c_ll, c_int, c_void_p]),
     'hno_act_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p]),
     'hno_bias_act': (c_int, [c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_void_p]),

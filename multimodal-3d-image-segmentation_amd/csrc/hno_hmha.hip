@@ -565,3 +565,60 @@ extern "C" int hno_hmha_bwd(const float *q, const float *k, const float *v, cons
     a.out1 = dk;
     return hm_dispatch<2>(a, s, (float *)workspace);
 }
+
+// ---- patch grouping (round 4b): grouping3d / ungrouping3d of the reference (nets/hartley_mha.py:473-524) as ONE permutation kernel.
+// In the model the q / k / v projections come out of one stacked pointwise convolution as (B, Z Kq + Z Kk + Z Kv, d, h, w); attention wants
+// three contiguous (B, Z, K P, T) tensors with P = pd ph pw patch voxels folded into the channels and T = (d / pd)(h / ph)(w / pw) tokens:
+//   dst_s[b][(cg P + ((i ph + j) pw + l))][(td nh + th) nw + tw] = src[b][c0_s + cg][td pd + i][th ph + j][tw pw + l]
+// As torch ops that was split + 3 x (reshape, permute, copy) forward and the mirror image plus a concatenation backward: ~20 ATen launches
+// of ~5 us per attention block and direction (1.7 ms of the 11.8 ms HartleyMHASeg step).  inverse = 1: the other direction (the gradient
+// of the grouped tensors back into the stacked layout, and ungrouping3d of the attention output).
+struct PgArgs {
+    float *full;               // (B, Ctot, d, h, w)
+    float *part[3];            // (B, C_s P, T) each
+    int cend[3];               // exclusive end channel of each part in the stacked tensor
+    int B, Ctot, d, h, w, pd, ph, pw, inverse;
+};
+
+__global__ __launch_bounds__(256) void patch_group_kernel(PgArgs a) {
+    // blockIdx.y = (b, stacked channel c): everything about the channel is workgroup-uniform; a thread owns tokens and walks the P patch
+    // voxels of each (consecutive lanes = consecutive tokens: contiguous in the grouped tensor, pw floats apart in the full one)
+    const int nd = a.d / a.pd, nh = a.h / a.ph, nw = a.w / a.pw;
+    const int P = a.pd * a.ph * a.pw, T = nd * nh * nw;
+    const int b = blockIdx.y / a.Ctot, c = blockIdx.y - b * a.Ctot;
+    const int s = c < a.cend[0] ? 0 : (c < a.cend[1] ? 1 : 2);
+    const int c0 = s == 0 ? 0 : a.cend[s - 1], Cs = a.cend[s] - c0;
+    float *part = a.part[s];
+    if (!part && !a.inverse) return;
+    float *fullc = a.full + (size_t)blockIdx.y * a.d * a.h * a.w;
+    float *partc = part ? part + ((size_t)b * Cs + (c - c0)) * P * T : nullptr;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < T; t += gridDim.x * 256) {
+        const int tw = t % nw, r = t / nw, th = r % nh, td = r / nh;
+        const unsigned base = ((unsigned)(td * a.pd) * a.h + th * a.ph) * a.w + tw * a.pw;
+        int pi = 0;
+        for (int i = 0; i < a.pd; ++i)
+            for (int j = 0; j < a.ph; ++j)
+                for (int l = 0; l < a.pw; ++l, ++pi) {
+                    const unsigned fo = base + ((unsigned)i * a.h + j) * a.w + l;
+                    if (a.inverse) fullc[fo] = partc ? partc[(size_t)pi * T + t] : 0.f;
+                    else partc[(size_t)pi * T + t] = fullc[fo];
+                }
+    }
+}
+
+extern "C" int hno_patch_group3(float *full, float *p0, float *p1, float *p2, int B, int C0, int C1, int C2, int d, int h, int w, int pd,
+                                int ph, int pw, int inverse, void *stream) {
+    HNO_REQUIRE(full && B > 0 && C0 > 0 && C1 >= 0 && C2 >= 0 && d > 0 && h > 0 && w > 0, "hno_patch_group3: bad argument");
+    HNO_REQUIRE(pd > 0 && ph > 0 && pw > 0 && d % pd == 0 && h % ph == 0 && w % pw == 0, "hno_patch_group3: the patch must divide the grid");
+    PgArgs a = {};
+    a.full = full; a.part[0] = p0; a.part[1] = p1; a.part[2] = p2;
+    a.cend[0] = C0; a.cend[1] = C0 + C1; a.cend[2] = C0 + C1 + C2;
+    a.B = B; a.Ctot = C0 + C1 + C2; a.d = d; a.h = h; a.w = w; a.pd = pd; a.ph = ph; a.pw = pw; a.inverse = inverse;
+    const int T = (d / pd) * (h / ph) * (w / pw);
+    HNO_REQUIRE((long long)B * a.Ctot <= 65535 && (long long)d * h * w < (1ll << 31), "hno_patch_group3: too many channels / voxels");
+    int gx = (T + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(patch_group_kernel, dim3((unsigned)gx, (unsigned)(B * a.Ctot)), dim3(256), 0, (hipStream_t)stream, a);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}

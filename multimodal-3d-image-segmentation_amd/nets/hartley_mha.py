@@ -7,6 +7,7 @@ output projection, zero pad + unscaled inverse transform (hno_pad_idht3).  SELU,
 default attention activation, so no online normalisation is needed.
 """
 import math
+import os
 from typing import Union
 
 import numpy as np
@@ -144,11 +145,18 @@ class HartleyMultiHeadAttention(Module):
             q = ops.PwConvFn.apply(q_src, None, wq, bq, ops.ACT_NONE)
             k = ops.PwConvFn.apply(k_src, None, wk, bk, ops.ACT_NONE)
             v = ops.PwConvFn.apply(v_src, None, wv, bv, ops.ACT_NONE)
-        q, k, v = (t.reshape(t.shape[0], Z, t.shape[1] // Z, *fsp) for t in (q, k, v))   # (B, Z, K, d, h, w)
-        if patch is not None:
-            q, k, v = (grouping3d(t, patch) for t in (q, k, v))
-        freq_shape = tuple(q.shape[3:])
-        q, k, v = (t.reshape(t.shape[0], Z, t.shape[2], -1).contiguous() for t in (q, k, v))   # (B, Z, C', T)
+        # split + grouping3d + the (B, Z, C', T) copies as one permutation launch each way when the three projections are one tensor
+        one_pass = (patch is not None and q_src is k_src and k_src is v_src and (y.is_cuda or y.is_meta)
+                    and os.environ.get('HNO_MHA_GROUP', '1') != '0')
+        if one_pass:
+            q, k, v = ops.PatchGroupQKVFn.apply(y, Z, wq.shape[0] // Z, wk.shape[0] // Z, wv.shape[0] // Z, tuple(patch))
+            freq_shape = tuple(a // b for a, b in zip(fsp, patch))
+        else:
+            q, k, v = (t.reshape(t.shape[0], Z, t.shape[1] // Z, *fsp) for t in (q, k, v))   # (B, Z, K, d, h, w)
+            if patch is not None:
+                q, k, v = (grouping3d(t, patch) for t in (q, k, v))
+            freq_shape = tuple(q.shape[3:])
+            q, k, v = (t.reshape(t.shape[0], Z, t.shape[2], -1).contiguous() for t in (q, k, v))   # (B, Z, C', T)
         alpha = 1.0 / math.sqrt(k.shape[2])
         if q.is_meta or (q.shape[3] == k.shape[3] and ops.hmha_supported(q.shape[2], v.shape[2])):
             # fused: QK^T -> scale -> activation -> .V in one kernel each way, the (T, T) matrix is never written
@@ -158,10 +166,13 @@ class HartleyMultiHeadAttention(Module):
             if act_att != ops.ACT_NONE:
                 att = ops.ActFn.apply(att, act_att)
             out = ops.BmmFn.apply(v, att, False, True, 1.0)                                     # (B, Z, C', Tq)
-        out = out.reshape(out.shape[0], Z, out.shape[2], *freq_shape)
-        if patch is not None:
-            out = ungrouping3d(out, self.value_dim, patch)
-        out = out.reshape(out.shape[0], Z * self.value_dim, *out.shape[3:]).contiguous()
+        if one_pass:
+            out = ops.PatchUngroupFn.apply(out, Z, self.value_dim, tuple(patch), fsp)
+        else:
+            out = out.reshape(out.shape[0], Z, out.shape[2], *freq_shape)
+            if patch is not None:
+                out = ungrouping3d(out, self.value_dim, patch)
+            out = out.reshape(out.shape[0], Z * self.value_dim, *out.shape[3:]).contiguous()
         out = ops.PwConvFn.apply(out, None, self.weight_out, bo, ops.ACT_NONE)                 # 'oi,bidhw->bodhw' (+ bias_out)
         if not self.use_transform:
             assert addend is None and act == ops.ACT_NONE

@@ -1166,6 +1166,73 @@ class HartleyAttentionFn(_HnoFunction):
         return dq, dk, dv, None, None
 
 
+class PatchGroupQKVFn(_HnoFunction):
+    """The stacked q / k / v projections (B, Z Kq + Z Kk + Z Kv, d, h, w) -> three contiguous (B, Z, K P, T) attention operands:
+    reference's split + reshape + grouping3d (nets/hartley_mha.py:180-190, 473-498) as ONE permutation launch each way
+    (hno_patch_group3) instead of ~10 ATen copies forward and as many plus a concatenation backward."""
+
+    @staticmethod
+    def meta(y, Z, Kq, Kk, Kv, patch):
+        B, _, d, h, w = y.shape
+        P = int(np.prod(patch))
+        T = (d // patch[0]) * (h // patch[1]) * (w // patch[2])
+        return tuple(_m((B, Z, K * P, T)) for K in (Kq, Kk, Kv))
+
+    @staticmethod
+    def forward(ctx, y, Z, Kq, Kk, Kv, patch):
+        y = _f32c(y)
+        _need_gpu(y)
+        B, Ct, d, h, w = y.shape
+        assert Ct == Z * (Kq + Kk + Kv)
+        pd, ph, pw = (int(v) for v in patch)
+        P, T = pd * ph * pw, (d // pd) * (h // ph) * (w // pw)
+        outs = [torch.empty((B, Z, K * P, T), device=y.device, dtype=torch.float32) for K in (Kq, Kk, Kv)]
+        check(_lib.lib().hno_patch_group3(ptr(y), ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), B, Z * Kq, Z * Kk, Z * Kv, d, h, w, pd, ph, pw, 0,
+                                          stream_ptr()), 'hno_patch_group3')
+        ctx.cfg = (tuple(y.shape), Z, Kq, Kk, Kv, (pd, ph, pw))
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, gq, gk, gv):
+        shape, Z, Kq, Kk, Kv, (pd, ph, pw) = ctx.cfg
+        B, Ct, d, h, w = shape
+        gs = [None if g is None else _f32c(g) for g in (gq, gk, gv)]
+        dev = next(g for g in gs if g is not None).device
+        gy = torch.empty(shape, device=dev, dtype=torch.float32)
+        check(_lib.lib().hno_patch_group3(ptr(gy), ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), B, Z * Kq, Z * Kk, Z * Kv, d, h, w, pd, ph, pw, 1,
+                                          stream_ptr()), 'hno_patch_group3')
+        return gy, None, None, None, None, None
+
+
+class PatchUngroupFn(_HnoFunction):
+    """ungrouping3d of the attention output (B, Z, V P, T) -> (B, Z V, d, h, w) (nets/hartley_mha.py:501-524) as one launch each way."""
+
+    @staticmethod
+    def meta(x, Z, V, patch, grid):
+        return _m((x.shape[0], Z * V) + tuple(grid))
+
+    @staticmethod
+    def forward(ctx, x, Z, V, patch, grid):
+        x = _f32c(x)
+        _need_gpu(x)
+        B = x.shape[0]
+        d, h, w = (int(v) for v in grid)
+        pd, ph, pw = (int(v) for v in patch)
+        out = torch.empty((B, Z * V, d, h, w), device=x.device, dtype=torch.float32)
+        check(_lib.lib().hno_patch_group3(ptr(out), ptr(x), None, None, B, Z * V, 0, 0, d, h, w, pd, ph, pw, 1, stream_ptr()), 'hno_patch_group3')
+        ctx.cfg = (tuple(x.shape), Z, V, (pd, ph, pw), (d, h, w))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, Z, V, (pd, ph, pw), (d, h, w) = ctx.cfg
+        g = _f32c(g)
+        gx = torch.empty(shape, device=g.device, dtype=torch.float32)
+        check(_lib.lib().hno_patch_group3(ptr(g), ptr(gx), None, None, shape[0], Z * V, 0, 0, d, h, w, pd, ph, pw, 0, stream_ptr()), 'hno_patch_group3')
+        return gx, None, None, None, None
+
+
 def hmha_supported(Ck, Cv):
     return bool(_lib.lib().hno_hmha_supported(int(Ck), int(Cv)))
 
