@@ -420,6 +420,18 @@ int hno_hmha_bwd(const float *q, const float *k, const float *v, const float *do
 int hno_patch_group3(float *full, float *p0, float *p1, float *p2, int B, int C0, int C1, int C2, int d, int h, int w, int pd, int ph,
                      int pw, int inverse, void *stream);
 
+/* Round 4b: the fused attention with the stream splits' partial results left unsummed -- hno_hmha_nsplit(BZ, T) slices of (BZ, C, T) floats
+ * per output -- and the permutation that adds them in slice order while it ungroups (parts -> full only).  Saves the partial-sum launches
+ * (4 per attention block and step). */
+int hno_hmha_nsplit(int BZ, int T);
+int hno_hmha_parts_supported(int Ck, int Cv, int act);
+int hno_hmha_fwd_parts(const float *q, const float *k, const float *v, float *out_parts, int BZ, int Ck, int Cv, int T, float alpha, int act,
+                       void *stream);
+int hno_hmha_bwd_parts(const float *q, const float *k, const float *v, const float *dout, float *dq_parts, float *dk_parts, float *dv_parts,
+                       int BZ, int Ck, int Cv, int T, float alpha, int act, void *stream);
+int hno_patch_group3_sum(float *full, const float *p0, const float *p1, const float *p2, int nsum, int B, int C0, int C1, int C2, int d, int h,
+                         int w, int pd, int ph, int pw, void *stream);
+
 /* ------------------------------------------------------------------- elementwise helpers
  * y = act(x) ; gx = g * act'(y) (y = saved output) ; out = a + b.  Used where the reference applies an
  * activation or a residual add that no neighbouring kernel can absorb (nets/architectures.py:529-546). */

@@ -33,6 +33,7 @@ struct HmArgs {
     int BZ, Ck, Cv, T;
     float alpha;
     int act;
+    int keep_parts;                  // out0 / out1 are [nsplit] slices of partial results, left unsummed (the consumer adds them in order)
 };
 
 // LDS tile of a streamed tensor: [C][33] floats (row c, 32 tokens + 1 pad: reads down a column are conflict-free)
@@ -473,10 +474,10 @@ static int hm2_launch_x(const HmArgs &a, float *workspace, hipStream_t s) {
     const int C1 = MODE == 1 ? a.Ck : a.Cv;
     const long long n0 = (long long)a.BZ * C1 * a.T, n1 = (long long)a.BZ * a.Ck * a.T;
     // one split: the partial IS the result
-    float *p0 = nsplit == 1 ? a.out0 : workspace, *p1 = nsplit == 1 ? a.out1 : workspace + (size_t)nsplit * n0;
+    float *p0 = (nsplit == 1 || a.keep_parts) ? a.out0 : workspace, *p1 = (nsplit == 1 || a.keep_parts) ? a.out1 : workspace + (size_t)nsplit * n0;
     hipLaunchKernelGGL((hmha2_kernel<MODE, CKT, CVT, X4>), grid, dim3(256), lds, s, a, p0, p1);
     HNO_CHECK_LAUNCH();
-    if (nsplit > 1) {
+    if (nsplit > 1 && !a.keep_parts) {
         const int g0 = (int)((n0 + 255) / 256 < 2048 ? (n0 + 255) / 256 : 2048);
         hipLaunchKernelGGL(hm_sum_partials_kernel, dim3(g0), dim3(256), 0, s, (const float *)p0, a.out0, n0, nsplit);
         if (MODE == 2) {
@@ -512,6 +513,7 @@ static int hm_dispatch(const HmArgs &a, hipStream_t s, float *workspace = nullpt
         if (kt == 3 && vt == 3) return hm2_launch<MODE, 3, 3>(a, workspace, s);
         if (kt <= 4 && vt <= 4) return hm2_launch<MODE, 4, 4>(a, workspace, s);
     }
+    if (a.keep_parts) return fail(HNO_ELIMIT, "hno_hmha_*_parts: shape / activation not covered by the shared-tile kernels");
     if (kt == 1 && vt == 1) return hm_launch<MODE, 1, 1>(a, s);
     if (kt == 2 && vt == 2) return hm_launch<MODE, 2, 2>(a, s);
     if (kt == 3 && vt == 3) return hm_launch<MODE, 3, 3>(a, s);
@@ -566,6 +568,45 @@ extern "C" int hno_hmha_bwd(const float *q, const float *k, const float *v, cons
     return hm_dispatch<2>(a, s, (float *)workspace);
 }
 
+// ---- the stream splits' partial results left unsummed (round 4b): hno_hmha_nsplit(BZ, T) slices of BZ x C x T floats each, which the
+// consumer adds in slice order while it reads them anyway (hno_patch_group3_sum) -- hm_sum_partials_kernel was 4 launches of ~7 us per
+// attention block and step.  hno_hmha_parts_supported: the shapes / activations the shared-tile kernels serve.
+extern "C" int hno_hmha_nsplit(int BZ, int T) { return BZ > 0 && T > 0 ? hm2_nsplit(BZ, T) : 0; }
+
+extern "C" int hno_hmha_parts_supported(int Ck, int Cv, int act) {
+    return hno_hmha_supported(Ck, Cv) && (act == HNO_ACT_NONE || act == HNO_ACT_SELU || act == HNO_ACT_ELU) && !(debug_flags() & 16384);
+}
+
+extern "C" int hno_hmha_fwd_parts(const float *q, const float *k, const float *v, float *out_parts, int BZ, int Ck, int Cv, int T, float alpha,
+                                  int act, void *stream) {
+    HNO_REQUIRE(q && k && v && out_parts && BZ > 0 && Ck > 0 && Cv > 0 && T > 0, "hno_hmha_fwd_parts: bad argument");
+    if (!hno_hmha_parts_supported(Ck, Cv, act)) return fail(HNO_ELIMIT, "hno_hmha_fwd_parts: not covered");
+    HmArgs a = {};
+    a.q = q; a.k = k; a.v = v; a.out0 = out_parts; a.BZ = BZ; a.Ck = Ck; a.Cv = Cv; a.T = T; a.alpha = alpha; a.act = act; a.keep_parts = 1;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope _ps(KID_HMHA, s, 2.0 * BZ * (double)T * T * (Ck + Cv));
+    return hm_dispatch<0>(a, s, out_parts);
+}
+
+extern "C" int hno_hmha_bwd_parts(const float *q, const float *k, const float *v, const float *dout, float *dq_parts, float *dk_parts,
+                                  float *dv_parts, int BZ, int Ck, int Cv, int T, float alpha, int act, void *stream) {
+    HNO_REQUIRE(q && k && v && dout && dq_parts && dk_parts && dv_parts && BZ > 0 && Ck > 0 && Cv > 0 && T > 0, "hno_hmha_bwd_parts: bad argument");
+    if (!hno_hmha_parts_supported(Ck, Cv, act)) return fail(HNO_ELIMIT, "hno_hmha_bwd_parts: not covered");
+    HmArgs a = {};
+    a.q = q; a.k = k; a.v = v; a.dout = dout; a.BZ = BZ; a.Ck = Ck; a.Cv = Cv; a.T = T; a.alpha = alpha; a.act = act; a.keep_parts = 1;
+    hipStream_t s = (hipStream_t)stream;
+    {
+        ProfScope _ps(KID_HMHA, s, 2.0 * BZ * (double)T * T * (2.0 * Ck + Cv));
+        a.out0 = dq_parts;
+        const int rc = hm_dispatch<1>(a, s, dq_parts);
+        if (rc != HNO_OK) return rc;
+    }
+    ProfScope _ps(KID_HMHA, s, 2.0 * BZ * (double)T * T * (2.0 * Ck + 2.0 * Cv));
+    a.out0 = dv_parts;
+    a.out1 = dk_parts;
+    return hm_dispatch<2>(a, s, dv_parts);
+}
+
 // ---- patch grouping (round 4b): grouping3d / ungrouping3d of the reference (nets/hartley_mha.py:473-524) as ONE permutation kernel.
 // In the model the q / k / v projections come out of one stacked pointwise convolution as (B, Z Kq + Z Kk + Z Kv, d, h, w); attention wants
 // three contiguous (B, Z, K P, T) tensors with P = pd ph pw patch voxels folded into the channels and T = (d / pd)(h / ph)(w / pw) tokens:
@@ -578,6 +619,7 @@ struct PgArgs {
     float *part[3];            // (B, C_s P, T) each
     int cend[3];               // exclusive end channel of each part in the stacked tensor
     int B, Ctot, d, h, w, pd, ph, pw, inverse;
+    int nsum;                  // inverse only: every part is `nsum` slices (B C_s P T floats apart) that are added in order
 };
 
 __global__ __launch_bounds__(256) void patch_group_kernel(PgArgs a) {
@@ -600,20 +642,44 @@ __global__ __launch_bounds__(256) void patch_group_kernel(PgArgs a) {
             for (int j = 0; j < a.ph; ++j)
                 for (int l = 0; l < a.pw; ++l, ++pi) {
                     const unsigned fo = base + ((unsigned)i * a.h + j) * a.w + l;
-                    if (a.inverse) fullc[fo] = partc ? partc[(size_t)pi * T + t] : 0.f;
-                    else partc[(size_t)pi * T + t] = fullc[fo];
+                    if (a.inverse) {
+                        float v = 0.f;
+                        if (partc) {
+                            v = partc[(size_t)pi * T + t];
+                            const size_t slice = (size_t)a.B * Cs * P * T;
+                            for (int e = 1; e < a.nsum; ++e) v += partc[(size_t)e * slice + (size_t)pi * T + t];
+                        }
+                        fullc[fo] = v;
+                    } else {
+                        partc[(size_t)pi * T + t] = fullc[fo];
+                    }
                 }
     }
 }
 
+static int patch_group_launch(float *full, float *p0, float *p1, float *p2, int B, int C0, int C1, int C2, int d, int h, int w, int pd,
+                              int ph, int pw, int inverse, int nsum, void *stream);
+
 extern "C" int hno_patch_group3(float *full, float *p0, float *p1, float *p2, int B, int C0, int C1, int C2, int d, int h, int w, int pd,
                                 int ph, int pw, int inverse, void *stream) {
+    return patch_group_launch(full, p0, p1, p2, B, C0, C1, C2, d, h, w, pd, ph, pw, inverse, 1, stream);
+}
+
+// parts -> full with every part given as `nsum` partial slices (hno_hmha_*_parts) that are added in slice order on the way
+extern "C" int hno_patch_group3_sum(float *full, const float *p0, const float *p1, const float *p2, int nsum, int B, int C0, int C1, int C2,
+                                    int d, int h, int w, int pd, int ph, int pw, void *stream) {
+    HNO_REQUIRE(nsum >= 1 && nsum <= 64, "hno_patch_group3_sum: bad slice count");
+    return patch_group_launch(full, (float *)p0, (float *)p1, (float *)p2, B, C0, C1, C2, d, h, w, pd, ph, pw, 1, nsum, stream);
+}
+
+static int patch_group_launch(float *full, float *p0, float *p1, float *p2, int B, int C0, int C1, int C2, int d, int h, int w, int pd,
+                              int ph, int pw, int inverse, int nsum, void *stream) {
     HNO_REQUIRE(full && B > 0 && C0 > 0 && C1 >= 0 && C2 >= 0 && d > 0 && h > 0 && w > 0, "hno_patch_group3: bad argument");
     HNO_REQUIRE(pd > 0 && ph > 0 && pw > 0 && d % pd == 0 && h % ph == 0 && w % pw == 0, "hno_patch_group3: the patch must divide the grid");
     PgArgs a = {};
     a.full = full; a.part[0] = p0; a.part[1] = p1; a.part[2] = p2;
     a.cend[0] = C0; a.cend[1] = C0 + C1; a.cend[2] = C0 + C1 + C2;
-    a.B = B; a.Ctot = C0 + C1 + C2; a.d = d; a.h = h; a.w = w; a.pd = pd; a.ph = ph; a.pw = pw; a.inverse = inverse;
+    a.B = B; a.Ctot = C0 + C1 + C2; a.d = d; a.h = h; a.w = w; a.pd = pd; a.ph = ph; a.pw = pw; a.inverse = inverse; a.nsum = nsum;
     const int T = (d / pd) * (h / ph) * (w / pw);
     HNO_REQUIRE((long long)B * a.Ctot <= 65535 && (long long)d * h * w < (1ll << 31), "hno_patch_group3: too many channels / voxels");
     int gx = (T + 255) / 256;

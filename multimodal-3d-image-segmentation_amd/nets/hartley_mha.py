@@ -148,6 +148,18 @@ class HartleyMultiHeadAttention(Module):
         # split + grouping3d + the (B, Z, C', T) copies as one permutation launch each way when the three projections are one tensor
         one_pass = (patch is not None and q_src is k_src and k_src is v_src and (y.is_cuda or y.is_meta)
                     and os.environ.get('HNO_MHA_GROUP', '1') != '0')
+        Kq, Kv = wq.shape[0] // Z, wv.shape[0] // Z
+        if (one_pass and wk.shape[0] == wq.shape[0] and os.environ.get('HNO_MHA_GROUP', '1') != '2'
+                and (y.is_meta or ops.GroupedAttentionFn.supported(Z, Kq, Kv, tuple(patch), act_att))):
+            # grouping, attention and ungrouping as one node: the attention's partial sums are added by the ungrouping permutation
+            out = ops.GroupedAttentionFn.apply(y, Z, Kq, Kv, tuple(patch), 1.0 / math.sqrt(Kq * int(np.prod(patch))), act_att)
+            out = ops.PwConvFn.apply(out, None, self.weight_out, bo, ops.ACT_NONE)
+            if not self.use_transform:
+                assert addend is None and act == ops.ACT_NONE
+                return out
+            if addend is None:
+                return ops.PadIdhtFn.apply(out, spatial, 1.0, act)
+            return ops.PadIdhtAddFn.apply(out, addend, spatial, 1.0, act)
         if one_pass:
             q, k, v = ops.PatchGroupQKVFn.apply(y, Z, wq.shape[0] // Z, wk.shape[0] // Z, wv.shape[0] // Z, tuple(patch))
             freq_shape = tuple(a // b for a, b in zip(fsp, patch))

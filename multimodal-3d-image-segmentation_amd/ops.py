@@ -1233,6 +1233,62 @@ class PatchUngroupFn(_HnoFunction):
         return gx, None, None, None, None
 
 
+class GroupedAttentionFn(_HnoFunction):
+    """Stacked q / k / v projections (B, Z (2 Kq + Kv), d, h, w) -> attention output (B, Z Kv, d, h, w): grouping3d, the fused attention
+    and ungrouping3d (nets/hartley_mha.py:180-216, 473-524) as one autograd node.  The attention kernels leave the partial results of
+    their stream splits unsummed (hno_hmha_fwd_parts / _bwd_parts) and the ungrouping permutation adds them in slice order while it
+    reads them (hno_patch_group3_sum): 3 launches forward and 4 backward per block instead of 4 + 7 (and ~40 as torch ops)."""
+
+    @staticmethod
+    def meta(y, Z, Kq, Kv, patch, alpha, act):
+        return _m((y.shape[0], Z * Kv) + tuple(y.shape[2:]))
+
+    @staticmethod
+    def supported(Z, Kq, Kv, patch, act):
+        P = int(np.prod(patch))
+        return bool(_lib.lib().hno_hmha_parts_supported(Kq * P, Kv * P, act))
+
+    @staticmethod
+    def forward(ctx, y, Z, Kq, Kv, patch, alpha, act):
+        y = _f32c(y)
+        _need_gpu(y)
+        L = _lib.lib()
+        B, Ct, d, h, w = y.shape
+        assert Ct == Z * (2 * Kq + Kv)
+        pd, ph, pw = (int(v) for v in patch)
+        P, T = pd * ph * pw, (d // pd) * (h // ph) * (w // pw)
+        q, k = (torch.empty((B, Z, Kq * P, T), device=y.device, dtype=torch.float32) for _ in range(2))
+        v = torch.empty((B, Z, Kv * P, T), device=y.device, dtype=torch.float32)
+        check(L.hno_patch_group3(ptr(y), ptr(q), ptr(k), ptr(v), B, Z * Kq, Z * Kq, Z * Kv, d, h, w, pd, ph, pw, 0, stream_ptr()), 'hno_patch_group3')
+        ns = L.hno_hmha_nsplit(B * Z, T)
+        parts = torch.empty((ns, B, Z, Kv * P, T), device=y.device, dtype=torch.float32)
+        check(L.hno_hmha_fwd_parts(ptr(q), ptr(k), ptr(v), ptr(parts), B * Z, Kq * P, Kv * P, T, float(alpha), act, stream_ptr()), 'hno_hmha_fwd_parts')
+        out = torch.empty((B, Z * Kv, d, h, w), device=y.device, dtype=torch.float32)
+        check(L.hno_patch_group3_sum(ptr(out), ptr(parts), None, None, ns, B, Z * Kv, 0, 0, d, h, w, pd, ph, pw, stream_ptr()), 'hno_patch_group3_sum')
+        ctx.save_for_backward(q, k, v)
+        ctx.cfg = (tuple(y.shape), Z, Kq, Kv, (pd, ph, pw), float(alpha), act, ns)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v = ctx.saved_tensors
+        shape, Z, Kq, Kv, (pd, ph, pw), alpha, act, ns = ctx.cfg
+        B, Ct, d, h, w = shape
+        P, T = pd * ph * pw, q.shape[3]
+        L = _lib.lib()
+        g = _f32c(g)
+        dout = torch.empty_like(v)
+        check(L.hno_patch_group3(ptr(g), ptr(dout), None, None, B, Z * Kv, 0, 0, d, h, w, pd, ph, pw, 0, stream_ptr()), 'hno_patch_group3')
+        dq, dk = (torch.empty((ns,) + tuple(q.shape), device=g.device, dtype=torch.float32) for _ in range(2))
+        dv = torch.empty((ns,) + tuple(v.shape), device=g.device, dtype=torch.float32)
+        check(L.hno_hmha_bwd_parts(ptr(q), ptr(k), ptr(v), ptr(dout), ptr(dq), ptr(dk), ptr(dv), B * Z, Kq * P, Kv * P, T, alpha, act, stream_ptr()),
+              'hno_hmha_bwd_parts')
+        gy = torch.empty(shape, device=g.device, dtype=torch.float32)
+        check(L.hno_patch_group3_sum(ptr(gy), ptr(dq), ptr(dk), ptr(dv), ns, B, Z * Kq, Z * Kq, Z * Kv, d, h, w, pd, ph, pw, stream_ptr()),
+              'hno_patch_group3_sum')
+        return gy, None, None, None, None, None, None
+
+
 def hmha_supported(Ck, Cv):
     return bool(_lib.lib().hno_hmha_supported(int(Ck), int(Cv)))
 

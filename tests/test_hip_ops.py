@@ -1103,6 +1103,31 @@ def test_patch_grouping_is_the_reference_permutation(pkg, B, Z, Kq, Kv, grid, pa
     assert bool((torch.autograd.grad((u * cot).sum(), [o])[0] == torch.autograd.grad((ur * cot).sum(), [o])[0]).all())
 
 
+@pytest.mark.parametrize('B,Z,Kq,Kv,grid,patch,act', [(1, 16, 3, 3, (20, 28, 28), (2, 2, 2), 'selu'), (2, 2, 4, 2, (4, 6, 8), (2, 2, 2), 'selu'),
+                                                       (1, 3, 2, 5, (6, 6, 9), (3, 2, 3), None), (2, 4, 3, 3, (8, 12, 12), (2, 2, 2), 'elu')])
+def test_grouped_attention_is_the_three_ops(pkg, B, Z, Kq, Kv, grid, patch, act):
+    """Round 4b: ops.GroupedAttentionFn (grouping + fused attention with unsummed stream-split partials + summing ungrouping) against
+    PatchGroupQKVFn -> HartleyAttentionFn -> PatchUngroupFn: the partial results are added in the same order, so bit-identical."""
+    from multimodal_3d_image_segmentation_amd import ops
+    torch.manual_seed(2)
+    a = ops.act_id(getattr(F, act) if act else None)
+    if not ops.GroupedAttentionFn.supported(Z, Kq, Kv, patch, a):
+        pytest.skip('shape not served by the shared-tile kernels')
+    alpha = 1.0 / np.sqrt(Kq * np.prod(patch))
+    res = []
+    for fused in (True, False):
+        y = (torch.randn((B, Z * (2 * Kq + Kv)) + grid, device='cuda', generator=torch.Generator('cuda').manual_seed(7)) * 0.5).requires_grad_(True)
+        if fused:
+            o = ops.GroupedAttentionFn.apply(y, Z, Kq, Kv, patch, alpha, a)
+        else:
+            q, k, v = ops.PatchGroupQKVFn.apply(y, Z, Kq, Kq, Kv, patch)
+            o = ops.PatchUngroupFn.apply(ops.HartleyAttentionFn.apply(q, k, v, alpha, a), Z, Kv, patch, grid)
+        cot = torch.randn(tuple(o.shape), device='cuda', generator=torch.Generator('cuda').manual_seed(8))
+        (g,) = torch.autograd.grad((o * cot).sum(), [y])
+        res.append((o.detach(), g))
+    assert bool((res[0][0] == res[1][0]).all()) and bool((res[0][1] == res[1][1]).all())
+
+
 @pytest.mark.parametrize('ci', range(len(MHA_CASES)))
 def test_hartley_mha_vs_golden(pkg, ci):
     from multimodal_3d_image_segmentation_amd.nets.hartley_mha import HartleyMultiHeadAttention
