@@ -8,6 +8,8 @@
 // Since kw is the lowest bit of k and the two lane halves of one MFMA operand register are
 // k and k+1, one operand load reads x[2w-1] (half 0) and x[2w] (half 1) for 32 consecutive
 // w: a single contiguous 256-byte run per instruction, no LDS, no wasted sector halves.
+#include <stdlib.h>
+
 #include "hno_common.h"
 
 namespace hno {
@@ -729,6 +731,11 @@ extern "C" int hno_conv_k2s2_bwd(const float *gy, const float *y, const float *x
     return reduce_partials_launch(a.partials, (int)grid, Cout * Cin * 8 + Cout, dW, Cout * Cin * 8, dbias, s);
 }
 
+static bool k2_fixed_off() {      // HNO_STEM_FIXED=0: the generic chained kernels also for the 4 -> 24 -> 24 / SELU stem (A/B)
+    static const bool off = getenv("HNO_STEM_FIXED") && atoi(getenv("HNO_STEM_FIXED")) == 0;
+    return off;
+}
+
 // ---- chained stem (round 4): conv_in + conv1 of HNOSeg-XS (nets/hnosegxs.py:102-108, 151-152) in one pass each way
 extern "C" int hno_conv_k2s2_chain_supported(int Cin, int C0, int C1) {
     return Cin >= 1 && Cin <= 4 && C0 >= 1 && C0 <= 32 && C1 >= 1 && C1 <= 32;
@@ -756,7 +763,7 @@ extern "C" int hno_conv_k2s2_chain_fwd(const float *x, const float *W, const flo
     const long long ntiles = (long long)B * a.Do * a.tiles_per_slab;
     if (ntiles >= (1ll << 31) || (long long)Cin * D * H * Wd >= (1ll << 29) || 32ll * a.Do * a.Ho * a.Wo >= (1ll << 29))
         return fail(HNO_ELIMIT, "hno_conv_k2s2_chain_fwd: image of %d x %d x %d x %d exceeds the 32-bit offset range", Cin, D, H, Wd);
-    const bool fixed = Cin == 4 && C0 == 24 && C1 == 24 && act == HNO_ACT_SELU && act1 == HNO_ACT_SELU && !(debug_flags() & 131072);
+    const bool fixed = Cin == 4 && C0 == 24 && C1 == 24 && act == HNO_ACT_SELU && act1 == HNO_ACT_SELU && !k2_fixed_off();
     long long grid = (ntiles + 3) / 4;
     const long long cap = fixed ? 1024 : 768;      // 120 / 164 registers: four / three 4-wave workgroups per CU are resident
     if (grid > cap) grid = cap;
@@ -796,7 +803,7 @@ extern "C" int hno_conv_k2s2_chain_bwd(const float *gy1, const float *y1, const 
     hipStream_t s = (hipStream_t)stream;
     {
         ProfScope _ps(KID_CONV_K2S2_BWD, s, 4.0 * B * ((double)Cin * D * H * Wd + 2.0 * C1 * a.Do * a.Ho * a.Wo));
-        if (Cin == 4 && C0 == 24 && C1 == 24 && act == HNO_ACT_SELU && act1 == HNO_ACT_SELU && !(debug_flags() & 131072)) {
+        if (Cin == 4 && C0 == 24 && C1 == 24 && act == HNO_ACT_SELU && act1 == HNO_ACT_SELU && !k2_fixed_off()) {
             static int attr = -1;
             if (attr != current_device()) { (void)hipFuncSetAttribute((const void *)conv_k2s2_chain_bwd_kernel<12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = current_device(); }
             hipLaunchKernelGGL((conv_k2s2_chain_bwd_kernel<12, true>), dim3((int)grid), dim3(256), lds, s, a);

@@ -935,7 +935,8 @@ extern "C" int hno_upsoftmax_fwd_ld(const float *logits_lr, float *probs, int B,
     a.lr = logits_lr; a.out = probs;
     ProfScope _ps(KID_UPSOFTMAX_FWD, (hipStream_t)stream, 4.0 * B * K * ((double)d * h * w + (double)D * H * W));
     const long long items = (long long)B * D * H * ((W + 63) / 64);
-    if (uprows_ok(K, d, h, w, D, H, W) && (long long)D * H * W < (1ll << 31) && !(debug_flags() & (16 | 65536))) {
+    static const bool rows_off = getenv("HNO_HEAD_ROWS") && atoi(getenv("HNO_HEAD_ROWS")) == 0;      // A/B: the voxel-form kernel
+    if (uprows_ok(K, d, h, w, D, H, W) && (long long)D * H * W < (1ll << 31) && !(debug_flags() & 16) && !rows_off) {
         int rpw;
         const int gx = uprows_plan(B, D, H, false, rpw);
         uprows_launch<false>(a, gx, B, (hipStream_t)stream, nullptr, nullptr);

@@ -1983,7 +1983,7 @@ def head_output(logits_lr, size, softmax, out_act=ACT_NONE):
         lab, kind, param = hint
         B, K, d, h, w = logits_lr.shape
         D, H, W = (int(v) for v in size)
-        if lab.numel() == B * D * H * W and _lib.lib().hno_uphead_loss_supported(B, K, d, h, w, D, H, W):
+        if lab.numel() == B * D * H * W and lab.data_ptr() % 4 == 0 and _lib.lib().hno_uphead_loss_supported(B, K, d, h, w, D, H, W):
             y, loss, coef = HeadLossFn.apply(logits_lr, lab, size, kind, param)
             y._hno_loss = (lab, kind, param, loss, coef)
             return y
