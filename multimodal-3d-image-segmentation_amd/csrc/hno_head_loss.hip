@@ -721,6 +721,31 @@ __global__ void loss_finalize_kernel(const double *stats, float *coef, float *lo
                   // statistic are then added in order
         const int n = K * 4, G = (int)blockDim.x / n;
         const int g = threadIdx.x / n, i = threadIdx.x - g * n;
+        if (B > 1 && B <= G) {     // all samples in ONE pass: G / B groups of n threads per sample (round 4b: the loop over samples below
+                                   // paid a global round trip and two barriers per sample)
+            const int Gb = G / B, b = g / Gb, gg = g - b * Gb;
+            double acc = 0.0;
+            if (b < B) {
+                const double *rb = rows + (size_t)b * nrows * n + i;
+                int w = gg;
+                for (; w + 3 * Gb < nrows; w += 4 * Gb) {
+                    double v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = rb[(size_t)(w + u * Gb) * n];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc += v[u];
+                }
+                for (; w < nrows; w += Gb) acc += rb[(size_t)w * n];
+            }
+            part[threadIdx.x] = acc;
+            __syncthreads();
+            if (b < B && gg == 0) {
+                double t = 0.0;
+                for (int u = 0; u < Gb; ++u) t += part[(b * Gb + u) * n + i];
+                stats_out[b * n + i] = t;
+            }
+            __syncthreads();
+        } else
         for (int b = 0; b < B; ++b) {
             double acc = 0.0;
             if (g < G) {
@@ -790,11 +815,12 @@ __global__ void loss_finalize_kernel(const double *stats, float *coef, float *lo
     }
     part[threadIdx.x] = local;
     __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
-        __syncthreads();
+    if (threadIdx.x == 0) {       // at most min(B K, blockDim) threads hold a term: added in index order (a 10-level tree of barriers before)
+        const int nt = B * K < (int)blockDim.x ? B * K : (int)blockDim.x;
+        double t = 0.0;
+        for (int j = 0; j < nt; ++j) t += part[j];
+        *loss = (float)(t * inv_bk);
     }
-    if (threadIdx.x == 0) *loss = (float)(part[0] * inv_bk);
 }
 
 template <int KMAX>
@@ -837,6 +863,24 @@ __global__ __launch_bounds__(256) void labels_kernel(const float *__restrict__ l
             const size_t b = idx / V, v = idx % V;
             for (int k = 0; k < K; ++k) onehot[(b * K + k) * V + v] = (l == k) ? 1.f : 0.f;
         }
+    }
+}
+
+// class map only, four voxels per thread (16-byte loads, one 32-bit store): the per-voxel form above moves 21 MB in 8.4 us
+__global__ __launch_bounds__(256) void labels4_kernel(const float *__restrict__ lf, const int *rfrom, const int *rto, int nmap,
+                                                     unsigned *__restrict__ lu4, size_t nquad) {
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nquad; q += (size_t)gridDim.x * 256) {
+        const float4 f = reinterpret_cast<const float4 *>(lf)[q];
+        const int orig[4] = {(int)f.x, (int)f.y, (int)f.z, (int)f.w};     // y.to(dtype=int) truncates (experiments/utils.py:86)
+        unsigned out = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int l = orig[e];
+            for (int j = 0; j < nmap; ++j)
+                if (orig[e] == rfrom[j]) l = rto[j];  // every key matched against the ORIGINAL label
+            out |= (unsigned)(l & 255) << (8 * e);
+        }
+        lu4[q] = out;
     }
 }
 
@@ -1232,8 +1276,16 @@ extern "C" int hno_labels_prepare(const float *labels_f32, const int *remap_from
                                   uint8_t *labels_u8, float *onehot, int B, int K, long long V, void *stream) {
     HNO_REQUIRE(labels_f32 && (labels_u8 || onehot) && B > 0 && V > 0, "hno_labels_prepare: bad argument");
     HNO_REQUIRE(n_remap == 0 || (remap_from && remap_to), "hno_labels_prepare: remap tables missing");
-    { ProfScope _ps(KID_LABELS, (hipStream_t)stream); hipLaunchKernelGGL(labels_kernel, dim3(grid1d((size_t)B * V)), dim3(256), 0, (hipStream_t)stream, labels_f32,
-                       remap_from, remap_to, n_remap, labels_u8, onehot, K, V, B); }
+    const size_t total = (size_t)B * V;
+    if (!onehot && total % 4 == 0 && ((size_t)labels_f32 & 15) == 0 && ((size_t)labels_u8 & 3) == 0) {
+        ProfScope _ps(KID_LABELS, (hipStream_t)stream);
+        hipLaunchKernelGGL(labels4_kernel, dim3(grid1d(total / 4)), dim3(256), 0, (hipStream_t)stream, labels_f32, remap_from, remap_to, n_remap,
+                           (unsigned *)labels_u8, total / 4);
+    } else {
+        ProfScope _ps(KID_LABELS, (hipStream_t)stream);
+        hipLaunchKernelGGL(labels_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, labels_f32, remap_from, remap_to, n_remap, labels_u8,
+                           onehot, K, V, B);
+    }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }
