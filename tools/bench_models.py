@@ -22,7 +22,9 @@ which = sys.argv[1:] or list(CASES)
 import contextlib
 for name in which:
     bf16 = name.endswith(':bf16')
-    ctor, shape = CASES[name.split(':')[0]]
+    ctor, shape = CASES[name.split(':')[0].split('@')[0]]
+    if '@' in name:      # name@N: cubic inputs of edge N instead of the configuration's size (e.g. hnosegxs_cfg2@96)
+        shape = tuple(shape[:2]) + (int(name.split(':')[0].split('@')[1]),) * 3
     ac = (lambda: torch.autocast('cuda', dtype=torch.bfloat16)) if bf16 else contextlib.nullcontext
     torch.manual_seed(0)
     model = ctor().cuda()

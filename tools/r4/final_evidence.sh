@@ -24,7 +24,7 @@ PY
 # V-Net-DS cfg4 bf16, HartleyMHASeg, every model family
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/vnet -- python3 tools/dbg/vnet_ab.py 0 > $O/vnet.log 2>&1
 python3 tools/dbg/hmha_one.py > $O/hmha.log 2>&1
-python3 tools/bench_models.py fnoseg_cfg3 fnoseg_cfg3:bf16 hnoseg hartleymha vnetds_cfg4:bf16 vnetds_cfg4 fno_individual > $O/models.jsonl 2> /dev/null
+python3 tools/bench_models.py fnoseg_cfg3 fnoseg_cfg3:bf16 hnoseg hartleymha vnetds_cfg4:bf16 vnetds_cfg4 fno_individual hnosegxs_cfg2@96 hnosegxs_cfg2@112 hnosegxs_cfg2@80 > $O/models.jsonl 2> /dev/null
 python3 tools/bench_infer.py > $O/inference.jsonl 2>/dev/null
 python3 tools/bench_cb_conv.py 0 > $O/bf16_conv_layers.txt 2>/dev/null
 find $O -name "*agent_info.csv" -delete; find $O -name "*kernel_trace.csv" -delete
