@@ -8,7 +8,7 @@ import csv, glob
 fn = glob.glob('gpurun_out/seq/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(fn)), key=lambda r: int(r['Start_Timestamp']))
 # last replay: take the last N kernels where N = kernels per step (find the last labels_kernel)
-idx = [i for i, r in enumerate(rows) if 'labels_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'labels' in r['Kernel_Name'] and 'kernel' in r['Kernel_Name']]
 a, b = idx[-2], idx[-1]
 t0 = int(rows[a]['Start_Timestamp'])
 prev_end = t0
