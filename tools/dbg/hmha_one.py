@@ -19,3 +19,10 @@ for flag in (16384, 0):
     print('round-2 kernels' if flag else 'shared-tile kernels', end=': ')
 fl = 2.0 * BZ * T * T * 2 * C
 print(f'hmha fwd {tf:.1f} us ({fl / tf / 1e6:.1f} TFLOP/s), bwd {tb:.1f} us ({fl * 3.5 / tb / 1e6:.1f} TFLOP/s)')
+# round 4b: the stream splits' partial results left to the consumer (ops.GroupedAttentionFn: the ungrouping permutation adds them)
+L.hno_set_debug(0)
+ns = L.hno_hmha_nsplit(BZ, T)
+po = torch.empty(ns, BZ, C, T, device=dev); pq = torch.empty_like(po); pk = torch.empty_like(po); pv = torch.empty_like(po)
+tf = timeit(lambda: L.hno_hmha_fwd_parts(P(q), P(k), P(v), P(po), BZ, C, C, T, 0.1, 1, S()))
+tb = timeit(lambda: L.hno_hmha_bwd_parts(P(q), P(k), P(v), P(do), P(pq), P(pk), P(pv), BZ, C, C, T, 0.1, 1, S()))
+print(f'partials form ({ns} splits, summed by the consumer): hmha fwd {tf:.1f} us ({fl / tf / 1e6:.1f} TFLOP/s), bwd {tb:.1f} us ({fl * 3.5 / tb / 1e6:.1f} TFLOP/s)')
