@@ -24,6 +24,97 @@ from .utils import labels_to_u8, save_model_summary
 step_stats = {'replayed': 0, 'eager': 0}     # training steps by launch form (read by the tests)
 
 
+class SampleSplit:
+    """The two halves of a batch as two concurrent forward + loss + backward passes on two streams of the capturing graph (round 4b).
+
+    The samples of a batch are independent (no batch statistics anywhere in these models) and the losses are means over (sample, class),
+    so loss = (loss_A + loss_B) / 2 and every gradient is the sum of the halves' gradients.  Run one after the other the halves gain
+    nothing; run on two streams INSIDE one captured graph the latency-bound kernels of one half (the fused spectral middles, the small
+    reductions: ~0.4 ms of the 2.4 ms HNOSeg-XS step keep three quarters of the chip idle) execute under the bandwidth-bound kernels of
+    the other: 2.41 -> 2.32 ms measured with two independent models (tools/dbg/two_stream.py, DESIGN lesson 57).
+    The second half runs through a TWIN of the model -- a deep copy whose parameters and buffers alias the model's storage, so it always
+    computes with the current weights but collects its gradients in its own ``.grad`` tensors; one multi-tensor add joins them.
+    Only used inside captured steps (CapturedStep / bench.py); eager steps run the whole batch as before.  HNO_SPLIT_STREAMS=0: off."""
+
+    _streams = {}
+
+    def __init__(self, model):
+        import copy
+        self.model = model
+        self.twin = copy.deepcopy(model)
+        for p, q in zip(model.parameters(), self.twin.parameters()):
+            q.data = p.data
+        for a, b in zip(model.buffers(), self.twin.buffers()):
+            b.data = a.data
+        self.twin.train(model.training)
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.tparams = [q for q in self.twin.parameters() if q.requires_grad]
+        dev = self.params[0].device
+        self.half = torch.full((), 0.5, device=dev, dtype=torch.float32)
+        # one pair of streams per device for every split of the process: the gradient-accumulation nodes autograd keeps per parameter
+        # remember the stream they were created on, and a node that outlives one capture must not name a stream the next capture does
+        # not know (a stream outside the capture being waited on inside it ends the capture with a crash)
+        key = (dev.type, dev.index)
+        if key not in SampleSplit._streams:
+            SampleSplit._streams[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        self.streams = SampleSplit._streams[key]
+
+    @staticmethod
+    def usable(model, loss_fn, x):
+        if os.environ.get('HNO_SPLIT_STREAMS', '1') == '0' or not (torch.is_tensor(x) and x.is_cuda) or x.shape[0] < 2 or x.shape[0] % 2:
+            return False
+        if getattr(loss_fn, 'hno_loss_spec', None) is None:      # a mean over (sample, class): halves average exactly
+            return False
+        norm = (torch.nn.modules.batchnorm._BatchNorm,)
+        return not any(isinstance(m, norm) for m in model.modules()) and all(p.is_cuda for p in model.parameters())
+
+    def aliased(self):
+        """the twin still shares the model's storage (a model moved or re-materialised after the split was built does not)"""
+        return all(p.data_ptr() == q.data_ptr() for p, q in zip(self.model.parameters(), self.twin.parameters()))
+
+    def fwd_bwd(self, x, lab_u8, loss_fn, zero_grad=None):
+        """enqueue both halves (call with the capturing stream current) -> the batch loss; model parameters' .grad = full gradients.
+        Only inside a stream capture: there every tensor of the step lives in the graph's private pool until the capture ends; eager,
+        the caching allocator's per-stream reuse and autograd's stream bookkeeping for accumulation nodes that outlive a pass made the
+        same sequence fault once in a few runs (a memory access fault after unrelated graph tests in the same process), unexplained."""
+        if not torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('SampleSplit.fwd_bwd is for captured steps only (CapturedStep / bench.py)')
+        cur = torch.cuda.current_stream()
+        h = x.shape[0] // 2
+        losses = []
+        for m, s, sl in ((self.model, self.streams[0], slice(0, h)), (self.twin, self.streams[1], slice(h, x.shape[0]))):
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                xb, lb = x[sl], lab_u8[sl]
+                with ops.expected_loss(lb, loss_fn):
+                    y = m(xb)
+                losses.append(loss_fn(y, lb))
+        if zero_grad is not None:
+            zero_grad()
+        else:
+            for p in self.params:
+                p.grad = None
+        for q in self.tparams:
+            q.grad = None
+        for l, s in zip(losses, self.streams):
+            s.wait_stream(cur)          # zero_grad may have launched on the capturing stream (a replica clears its flat gradient buffer)
+            with torch.cuda.stream(s):
+                torch.autograd.backward(l, grad_tensors=self.half)
+        cur.wait_stream(self.streams[0])
+        cur.wait_stream(self.streams[1])
+        pairs = [(p, q) for p, q in zip(self.params, self.tparams) if q.grad is not None]
+        for p, q in pairs:
+            if p.grad is None:
+                p.grad = q.grad
+        both = [(p.grad, q.grad) for p, q in pairs if p.grad is not q.grad]
+        if both:
+            torch._foreach_add_([a for a, _ in both], [b for _, b in both])
+        # (detached: a loss that keeps its autograd graph alive keeps the halves' accumulation nodes alive across captures)
+        l0, l1 = losses[0].detach(), losses[1].detach()
+        del losses
+        return torch.add(l0, l1).mul_(0.5)
+
+
 class CapturedStep:
     """forward + loss + backward of one batch shape as a HIP graph -- the step bench.py replays, for `training()`.
 
@@ -49,6 +140,7 @@ class CapturedStep:
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.entries, self.seen, self.failed = {}, {}, set()
         self.copy_stream, self.staged = None, None
+        self.split = None
 
     def _capture(self, x, y):
         from .. import ops
@@ -66,15 +158,21 @@ class CapturedStep:
                 # thread_local: a collective library's watchdog thread may poll events while we capture
                 with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
                     lab = labels_to_u8(ys, self.num_labels, self.label_mapping)
-                    with ops.expected_loss(lab, self.loss_fn):       # the head takes the loss sums in its own pass
-                        y_pred = self.model(xs)
-                    loss = self.loss_fn(y_pred, lab)
-                    if self.dp is not None:
-                        self.dp.zero_grad()
+                    if SampleSplit.usable(self.model, self.loss_fn, xs):
+                        # the two halves of the batch on two streams of this graph (SampleSplit)
+                        if self.split is None or not self.split.aliased():
+                            self.split = SampleSplit(self.model)
+                        loss = self.split.fwd_bwd(xs, lab, self.loss_fn, zero_grad=self.dp.zero_grad if self.dp is not None else None)
                     else:
-                        for p in self.params:
-                            p.grad = None
-                    ops.backward_from(loss)
+                        with ops.expected_loss(lab, self.loss_fn):       # the head takes the loss sums in its own pass
+                            y_pred = self.model(xs)
+                        loss = self.loss_fn(y_pred, lab)
+                        if self.dp is not None:
+                            self.dp.zero_grad()
+                        else:
+                            for p in self.params:
+                                p.grad = None
+                        ops.backward_from(loss)
                     if self.dp is not None:
                         self.dp.finish_capture()
                         if self.capture_allreduce:

@@ -256,3 +256,77 @@ def test_training_with_autocast_and_grad_scaler(tmp_path):
                 checkpoint_epoch=2, is_print=False, use_autocast=True, device='cuda')
     tl, _ = tt.get_losses_from_file(os.path.join(tmp_path / 'bf16', 'stdout.txt'))
     assert len(tl) == 6 and tl[:4] == losses['bf16']
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('loss_name', ['pcc', 'dice', 'expdice'])
+def test_sample_split_gives_the_batch_gradients(loss_name):
+    """Round 4b: experiments.train_test.SampleSplit -- the two halves of a batch as two concurrent passes (model and its storage-aliasing
+    twin) on two streams of a captured graph.  Loss and every gradient equal the whole-batch pass (means over (sample, class): the halves
+    average exactly); the twin follows in-place weight updates (every replay computes with the current weights); a model whose storage
+    moved is detected; outside a capture the split refuses to run."""
+    import multimodal_3d_image_segmentation_amd as pkg
+    from multimodal_3d_image_segmentation_amd import ops
+    from multimodal_3d_image_segmentation_amd.experiments import train_test as tt
+    from multimodal_3d_image_segmentation_amd.nets import custom_losses as CL
+    loss_fn = {'pcc': CL.PCCLoss(), 'dice': CL.DiceLoss(), 'expdice': CL.ExpDiceLoss(0.3)}[loss_name]
+    torch.manual_seed(3)
+    model = pkg.nets.HNOSegXS(4, 4, 24, [1, 1, 1, 1], (4, 6, 6)).cuda()
+    x = torch.randn(4, 4, 32, 32, 32, device='cuda')
+    lab = torch.randint(0, 4, (4, 32, 32, 32), device='cuda').to(torch.uint8)
+    assert tt.SampleSplit.usable(model, loss_fn, x) and not tt.SampleSplit.usable(model, loss_fn, x[:3]) and not tt.SampleSplit.usable(model, torch.nn.MSELoss(), x)
+    params = [p for p in model.parameters()]
+
+    def whole():
+        for p in params:
+            p.grad = None
+        with ops.expected_loss(lab, loss_fn):
+            y = model(x)
+        l = loss_fn(y, lab)
+        l.backward()
+        out = float(l.detach()), [p.grad.clone() for p in params]
+        for p in params:
+            p.grad = None
+        del y, l
+        return out
+    l0, g0 = whole()
+    whole()                                                        # (every kernel attribute / table of the half-batch shapes exists)
+    split = tt.SampleSplit(model)
+    assert split.aliased()
+    with pytest.raises(RuntimeError):
+        split.fwd_bwd(x, lab, loss_fn)
+    # the half-batch shapes once eagerly through the model (tables and kernel attributes are created at first use, not capturable)
+    with torch.no_grad():
+        model(x[:2])
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    prev = ops.set_defer_reduce(True)
+    try:
+        with torch.cuda.stream(side):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
+                loss = split.fwd_bwd(x, lab, loss_fn)
+    finally:
+        ops.set_defer_reduce(prev)
+    torch.cuda.current_stream().wait_stream(side)
+    grads = [p.grad for p in params]
+
+    def check(lref, gref):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert abs(float(loss) - lref) < 2e-6
+        num = sum(float(((a - g) ** 2).sum()) for a, g in zip(grads, gref)) ** 0.5
+        den = sum(float((g ** 2).sum()) for g in gref) ** 0.5
+        assert num / den < 2e-5, num / den
+        for a, g in zip(grads, gref):
+            assert rel_err(a.cpu().numpy(), g.cpu().numpy()) < 2e-4
+    check(l0, g0)
+    check(l0, g0)
+    with torch.no_grad():                                          # in-place updates reach the twin: it shares the storage
+        for p in params:
+            p.mul_(1.01)
+    l2, g2 = whole()
+    check(l2, g2)
+    params[0].data = params[0].data.clone()                        # a re-materialised parameter does not: detected
+    assert not split.aliased()
