@@ -41,7 +41,23 @@ class SampleSplit:
     def __init__(self, model):
         import copy
         self.model = model
-        self.twin = copy.deepcopy(model)
+        # tensor hooks stay with the model (a data-parallel replica's post-accumulate hooks would be deep-copied together with the
+        # replica they point to, and the twin's backward would then launch that copy's bucket all-reduces)
+        stash = []
+        for p in model.parameters():
+            stash.append((p, getattr(p, '_post_accumulate_grad_hooks', None), getattr(p, '_backward_hooks', None)))
+            if stash[-1][1] is not None:
+                p._post_accumulate_grad_hooks = None
+            if stash[-1][2] is not None:
+                p._backward_hooks = None
+        try:
+            self.twin = copy.deepcopy(model)
+        finally:
+            for p, post, back in stash:
+                if post is not None:
+                    p._post_accumulate_grad_hooks = post
+                if back is not None:
+                    p._backward_hooks = back
         for p, q in zip(model.parameters(), self.twin.parameters()):
             q.data = p.data
         for a, b in zip(model.buffers(), self.twin.buffers()):
@@ -145,6 +161,9 @@ class CapturedStep:
     def _capture(self, x, y):
         from .. import ops
         xs, ys = x.clone(), y.clone()
+        if SampleSplit.usable(self.model, self.loss_fn, xs):
+            with torch.no_grad():      # tables / kernel attributes of the half-batch shapes are created at first use: not capturable
+                self.model(xs[:xs.shape[0] // 2])
         cur = torch.cuda.current_stream()
         torch.cuda.synchronize()
         if self.dp is not None:

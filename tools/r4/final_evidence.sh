@@ -17,7 +17,7 @@ import csv, glob, sys
 o = sys.argv[1]
 fn = glob.glob(o + '/graph/**/*kernel_stats.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(fn)))
-n = [int(r['Calls']) for r in rows if 'loss_finalize' in r['Name']][0]
+n = [int(r['Calls']) for r in rows if 'labels' in r['Name'] and 'kernel' in r['Name']][0]      # (one label conversion per step; loss_finalize runs once per half-batch)
 open(o + '/graph_steps.txt', 'w').write(f'{n} steps in kernel_stats_bench_graph_replay.csv (python tools/kstats.py <file> {n})\n')
 print('graph steps', n)
 PY
