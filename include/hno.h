@@ -212,7 +212,7 @@ int hno_pwconv_fwd_chain_supported(int C, int C2, int has_k);
 int hno_pwconv_fwd_chain(const float *u, const float *t, const float *k, const float *Wc, const float *bc, const float *Wm,
                          const float *bm, float *xi, float *xn, int B, int C, int C2, long long V, int act, int act2, void *stream);
 /* backward of the pair in one pass: gn = gradient of xn -> gu (times xa_act'(u): u is the output of that activation), gt, gk and
- * grads = [dWm (C2, 48 | 24) | dbm (C2) | dWc (24, 48) | dbc (24)] in one flat buffer.  9 activation streams instead of 12 (5 + 2 x 4 ch
+ * grads = [dWc (24, 48) | dbc (24) | dWm (C2, 48 | 24) | dbm (C2; not written in the C2 = 4 form)] in one flat buffer (the parameters' order in the model).  9 activation streams instead of 12 (5 + 2 x 4 ch
  * instead of 8 for the conv_out form): the gradient between the two layers never reaches memory.  k / gk NULL for the conv_out form.
  * workspace: hno_pwconv_bwd_chain_workspace_bytes(C); bit 8 of xa_act defers the slab reduction (hno_set_defer_reduce). */
 size_t hno_pwconv_bwd_chain_workspace_bytes(int C);

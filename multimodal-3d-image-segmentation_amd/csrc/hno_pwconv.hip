@@ -1205,7 +1205,7 @@ struct PwChainBwdArgs {
     const float *gn, *xn, *xi, *k, *u, *t;    // (B, C, V)
     const float *Wm, *Wc;                      // (C, 2C)
     float *gu, *gt, *gk;                       // (B, C, V)
-    float *partials;                           // per workgroup: [dWm C x 2C | dbm C | dWc C x 2C | dbc C]
+    float *partials;                           // per workgroup: [dWc C x 2C | dbc C | dWm C2 x CIN2 | dbm C2]
     int B;
     unsigned V;
     int act, act2, xa_act, dbg;
@@ -1413,7 +1413,9 @@ __global__ __launch_bounds__(64 * NW, SLOTS == 1 ? 2 : 1) void pwconv_bwd_chain_
         if (SLOTS == 1 && grp + gridDim.x < ngroups) fetch(grp + gridDim.x, 0);      // (this tile's LDS reads are done)
     }
     {
-        constexpr int n1 = C2 * CIN2 + C2, n = n1 + C * CIN + C;            // [dWm | dbm | dWc | dbc]
+        // slab [dWc | dbc | dWm | dbm]: the order of the four parameters in the model (conv_concat of block i, mapping_conv of block i + 1 /
+        // conv_out), so that under a data-parallel replica the reduced slab IS their run of the flat gradient buffer
+        constexpr int nc = C * CIN + C, n = nc + C2 * CIN2 + C2;
         __syncthreads();
         float *mine = lds + (size_t)wave * n;
 #pragma unroll
@@ -1423,7 +1425,7 @@ __global__ __launch_bounds__(64 * NW, SLOTS == 1 ? 2 : 1) void pwconv_bwd_chain_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int o = m * 16 + (lane >> 4) * 4 + r, i = nn * 16 + (lane & 15);
-                    if (o < C2 && i < CIN2) mine[o * CIN2 + i] = dwm[m][nn][r];
+                    if (o < C2 && i < CIN2) mine[nc + o * CIN2 + i] = dwm[m][nn][r];
                 }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -1432,19 +1434,19 @@ __global__ __launch_bounds__(64 * NW, SLOTS == 1 ? 2 : 1) void pwconv_bwd_chain_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int o = m * 16 + (lane >> 4) * 4 + r, i = nn * 16 + (lane & 15);
-                    if (o < C) mine[n1 + o * CIN + i] = dwc[m][nn][r];
+                    if (o < C) mine[o * CIN + i] = dwc[m][nn][r];
                 }
 #pragma unroll
         for (int ks = 0; ks < NK2; ++ks) {
             float s1 = dbm[ks];
             for (int off2 = 16; off2 >= 1; off2 >>= 1) s1 += __shfl_xor(s1, off2);
-            if (c == 0) mine[C2 * CIN2 + 2 * ks + h] = s1;                              // g1 rows are pairs 2 ks + h
+            if (c == 0) mine[nc + C2 * CIN2 + 2 * ks + h] = s1;                         // g1 rows are pairs 2 ks + h
         }
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
             float s2 = dbc[ks];
             for (int off2 = 16; off2 >= 1; off2 >>= 1) s2 += __shfl_xor(s2, off2);
-            if (c == 0) mine[n1 + C * CIN + (ks & 3) + 8 * (ks >> 2) + 4 * h] = s2;    // p rows are accumulator rows
+            if (c == 0) mine[C * CIN + (ks & 3) + 8 * (ks >> 2) + 4 * h] = s2;         // p rows are accumulator rows
         }
         block_sum_to_slab(lds, n, a.partials + (size_t)blockIdx.x * n, threadIdx.x, NW);
     }
@@ -1818,10 +1820,11 @@ extern "C" int hno_pwconv_fwd_chain(const float *u, const float *t, const float 
 }
 
 // backward of hno_pwconv_fwd_chain in one pass (pwconv_bwd_chain_kernel): gn = gradient of xn; -> gu, gt, gk and
-// grads = [dWm (C, 2C) | dbm (C) | dWc (C, 2C) | dbc (C)] (one flat buffer).  xa_act: activation whose output u is (its derivative is
+// grads = [dWc (C, 2C) | dbc (C) | dWm (C2, CIN2) | dbm (C2)] (one flat buffer: the parameters' order in the model).  xa_act: activation whose output u is (its derivative is
 // applied to gu), as hno_pwconv_bwd's.  workspace: hno_pwconv_bwd_chain_workspace_bytes(C).  bit 8 of xa_act: defer the slab reduction.
 extern "C" size_t hno_pwconv_bwd_chain_workspace_bytes(int C) { return sizeof(float) * 512 * 2 * ((size_t)C * 2 * C + C); }
-// grads: C2 = 24: [dWm (24, 48) | dbm (24) | dWc (24, 48) | dbc (24)];  C2 = 4 (k, gk NULL): [dWm (4, 24) | dbm (4, unused) | dWc | dbc]
+// grads: C2 = 24: [dWc (24, 48) | dbc (24) | dWm (24, 48) | dbm (24)];  C2 = 4 (k, gk NULL): [dWc | dbc | dWm (4, 24)] -- dbm is not written
+// (conv_out has no bias): the buffer ends behind dWm
 extern "C" int hno_pwconv_bwd_chain(const float *gn, const float *xn, const float *xi, const float *k, const float *u, const float *t,
                                     const float *Wm, const float *Wc, float *gu, float *gt, float *gk, float *grads, void *workspace,
                                     int B, int C, int C2, long long V, int act, int act2, int xa_act, void *stream) {
@@ -1868,7 +1871,7 @@ extern "C" int hno_pwconv_bwd_chain(const float *gn, const float *xn, const floa
     const int prev = hno_set_defer_reduce(0);
     struct Restore { int v; ~Restore() { hno_set_defer_reduce(v); } } restore{prev};
     hno_set_defer_reduce(defer_bit ? 1 : prev);
-    return reduce_partials_launch(a.partials, grid, n, grads, n, nullptr, s);
+    return reduce_partials_launch(a.partials, grid, n, grads, k ? n : n - C2, nullptr, s);
 }
 
 extern "C" size_t hno_pwconv_bwd_branch_workspace_bytes(int Ca, int Cb, int Cout) {

@@ -1701,16 +1701,24 @@ class XSBlockFn(_HnoFunction):
                 cin2 = 2 * C if has_k else C
                 g_u, g_skipin = act_like(u), act_like(xm)
                 g_nskip = act_like(nskip) if has_k else None
-                n1 = C2 * cin2 + C2
-                flat = torch.empty(n1 + C * 2 * C + C, device=u.device, dtype=torch.float32)
+                # [dWc | dbc | dWm | dbm]: the four parameters' order in the model -- under a data-parallel replica the kernel's output IS
+                # their run of the flat gradient buffer (conv_out has no bias: its form ends behind dWm)
+                nc = C * 2 * C + C
+                nm = C2 * cin2 + (C2 if has_k else 0)
+                plist = [cat_w, cat_b, nmap_w] + ([nmap_b] if has_k else [])
+                if cat_has_b and all(t is not None for t in plist):
+                    flat = _grad_buffer_concat(plist)
+                else:
+                    flat = torch.empty(nc + nm, device=u.device, dtype=torch.float32)
                 ws = torch.empty(L.hno_pwconv_bwd_chain_workspace_bytes(C) // 4, device=u.device, dtype=torch.float32)
                 with _DeferReduce(late_nmap and late_cat) as d:
                     check(L.hno_pwconv_bwd_chain(ptr(gn), ptr(xn) if ctx.act2 != ACT_NONE else None, ptr(out), ptr(nskip), ptr(u), ptr(xm), ptr(nmap_w),
                                                  ptr(cat_w), ptr(g_u), ptr(g_skipin), ptr(g_nskip), ptr(flat), ptr(ws), x.shape[0], C, C2,
                                                  ld_n or _flat_v(xm), act, ctx.act2, act | d.bit, stream_ptr()), 'hno_pwconv_bwd_chain')
                     d.keep(ws)
-                d_nmap_w, d_nmap_b = flat[:C2 * cin2].view_as(nmap_w), (flat[C2 * cin2:n1] if nmap_b is not None else None)
-                d_cat_w, d_cat_b = flat[n1:n1 + C * 2 * C].view_as(cat_w), (flat[n1 + C * 2 * C:] if cat_has_b else None)
+                d_cat_w, d_cat_b = flat[:C * 2 * C].view_as(cat_w), (flat[C * 2 * C:nc] if cat_has_b else None)
+                d_nmap_w = flat[nc:nc + C2 * cin2].view_as(nmap_w)
+                d_nmap_b = flat[nc + C2 * cin2:nc + C2 * cin2 + C2] if (nmap_b is not None and has_k) else None
                 chain_fused = True
             else:
                 g_out, g_nskip, d_nmap_w, d_nmap_b = pwconv_bwd_raw(to_layout(g_out, ld_n), xn if ctx.act2 != ACT_NONE else None, out, nskip,

@@ -55,6 +55,7 @@ def chain_bwd():
                                           B, C, C, ld, ops.ACT_SELU, ops.ACT_SELU, ops.ACT_SELU, S()), 'chain bwd')
 chain_bwd(); torch.cuda.synchronize()
 rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
-print('gu', rel(g_u, ref[0]), 'gt', rel(g_t, ref[1]), 'gk', rel(g_k, ref[2]), 'dWm', rel(flat[:C * 2 * C].view(C, 2 * C), ref[3]), 'dbm', rel(flat[C * 2 * C:n1], ref[4]),
-      'dWc', rel(flat[n1:n1 + C * 2 * C].view(C, 2 * C), ref[5]), 'dbc', rel(flat[n1 + C * 2 * C:], ref[6]))
+# grads = [dWc | dbc | dWm | dbm]
+print('gu', rel(g_u, ref[0]), 'gt', rel(g_t, ref[1]), 'gk', rel(g_k, ref[2]), 'dWm', rel(flat[n1:n1 + C * 2 * C].view(C, 2 * C), ref[3]), 'dbm', rel(flat[n1 + C * 2 * C:], ref[4]),
+      'dWc', rel(flat[:C * 2 * C].view(C, 2 * C), ref[5]), 'dbc', rel(flat[C * 2 * C:n1], ref[6]))
 print(f'backward: two layers {timeit(two_bwd):.1f} us, chained {timeit(chain_bwd):.1f} us')
