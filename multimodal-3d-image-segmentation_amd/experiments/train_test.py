@@ -177,14 +177,14 @@ class CapturedStep:
                 # thread_local: a collective library's watchdog thread may poll events while we capture
                 with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
                     lab = labels_to_u8(ys, self.num_labels, self.label_mapping)
-                    if self.split is not False and SampleSplit.usable(self.model, self.loss_fn, xs):
+                    use_split = self.split is not False and SampleSplit.usable(self.model, self.loss_fn, xs)
+                    if use_split and (self.split is None or not self.split.aliased()):
                         # the two halves of the batch on two streams of this graph (SampleSplit)
-                        if self.split is None or not self.split.aliased():
-                            try:
-                                self.split = SampleSplit(self.model)
-                            except Exception:            # a model that cannot be deep-copied: one pass over the batch
-                                self.split = False
-                    if self.split:
+                        try:
+                            self.split = SampleSplit(self.model)
+                        except Exception:                # a model that cannot be deep-copied: one pass over the batch
+                            self.split, use_split = False, False
+                    if use_split:
                         loss = self.split.fwd_bwd(xs, lab, self.loss_fn, zero_grad=self.dp.zero_grad if self.dp is not None else None)
                     else:
                         with ops.expected_loss(lab, self.loss_fn):       # the head takes the loss sums in its own pass
