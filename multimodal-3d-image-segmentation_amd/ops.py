@@ -1846,7 +1846,7 @@ class StemChainFn(_HnoFunction):
         if ctx.needs_input_grad[0]:
             raise _lib.HnoError('conv_in input gradient is not implemented (the image needs none)')
         lp = ctx.leaf_params and _release_use(W, bias, W1, bias1)
-        late = lp and _deferrable(W, bias, W1, bias1) and os.environ.get('HNO_STEM_DEFER', '1') != '0'
+        late = lp and _deferrable(W, bias, W1, bias1)
         ld = chan_stride(y1)
         gy = to_layout(gy, ld)
         B, Cin, D, H, Wd = x.shape
