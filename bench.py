@@ -139,18 +139,18 @@ def secondary_configs(pkg, dev):
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        # fp32 steps of an even batch: the two half-batches on two streams of the graph, as training()'s CapturedStep runs them
+        # steps of an even batch: the two half-batches on two streams of the graph, as training()'s CapturedStep runs them
         from multimodal_3d_image_segmentation_amd.experiments.train_test import SampleSplit
-        sp = SampleSplit(model) if (not bf16 and SampleSplit.usable(model, loss_fn, x)) else None
+        sp = SampleSplit(model) if SampleSplit.usable(model, loss_fn, x) else None
         if sp is not None:
-            with torch.no_grad():
+            with torch.no_grad(), ac():
                 model(x[:shape[0] // 2])          # (tables / kernel attributes of the half-batch shapes: not capturable)
             torch.cuda.synchronize()
         with torch.cuda.stream(side):
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr, stream=side):
                 if sp is not None:
-                    sp.fwd_bwd(x, lab, loss_fn)
+                    sp.fwd_bwd(x, lab, loss_fn, autocast=ac if bf16 else None)
                 else:
                     step()
         torch.cuda.current_stream().wait_stream(side)

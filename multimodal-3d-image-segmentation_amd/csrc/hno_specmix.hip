@@ -106,7 +106,9 @@ __global__ __launch_bounds__(64) void specmix_fwd_loop_kernel(MixArgs a) {
     const float aq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
     const bool lin = a.act == HNO_ACT_NONE;
     const float res = a.residual ? 1.f : 0.f;
-    const unsigned wl = (unsigned)c * C + 4 * h;       // lane part of the weight offset
+    // lane part of the weight offset.  Lanes c >= C (EXACT skips the guards) feed output rows that are never stored: they re-read row C - 1
+    // instead of running up to (32 - C) rows past the end of W (a fault when W ends its allocator segment)
+    const unsigned wl = (unsigned)(c < C ? c : C - 1) * C + 4 * h;
     const int dsel = c - 4 * h;                         // diagonal: c == row(ks) + 4h
     const unsigned tiles_per_b = (M + 31) / 32, ntiles = tiles_per_b * a.B;
     const size_t sample = (size_t)C * M, layer = sample * a.B;
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(256) void specmix_bwd_loop_kernel(MixArgs a) {
     const float dq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
     const bool lin = a.act == HNO_ACT_NONE;
     const float res = a.residual ? 1.f : 0.f;
-    const unsigned wlt = 4u * h * C + c;   // lane part of W^T: W[(row + 4h) * C + c]
+    const unsigned wlt = 4u * h * C + (c < C ? c : C - 1);   // lane part of W^T: W[(row + 4h) * C + c] (lanes c >= C: unused, kept inside W)
     const int dsel = c - 4 * h;
     const unsigned tiles_per_b = (M + 31) / 32, ntiles = tiles_per_b * a.B;
     const size_t sample = (size_t)C * M, layer = sample * a.B;

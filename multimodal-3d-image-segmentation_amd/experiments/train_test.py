@@ -8,6 +8,7 @@ Changed on purpose: labels go to the loss kernels as uint8 class maps (no one-ho
 per-batch `loss.item()` host synchronisation (reference :162) is deferred to the end of the epoch.
 Out of scope: torchview graph rendering, matplotlib plots.
 """
+import contextlib
 import os
 import re
 import time
@@ -34,7 +35,8 @@ class SampleSplit:
     the other: 2.41 -> 2.32 ms measured with two independent models (tools/dbg/two_stream.py, DESIGN lesson 57).
     The second half runs through a TWIN of the model -- a deep copy whose parameters and buffers alias the model's storage, so it always
     computes with the current weights but collects its gradients in its own ``.grad`` tensors; one multi-tensor add joins them.
-    Only used inside captured steps (CapturedStep / bench.py); eager steps run the whole batch as before.  HNO_SPLIT_STREAMS=0: off."""
+    Only used inside captured steps (CapturedStep / bench.py); eager steps run the whole batch as before.  Model classes opt in
+    (``hno_sample_split``: HNOSegXS); HNO_SPLIT_STREAMS=1 / 0 forces it on / off for every model."""
 
     _streams = {}
 
@@ -77,7 +79,12 @@ class SampleSplit:
 
     @staticmethod
     def usable(model, loss_fn, x):
-        if os.environ.get('HNO_SPLIT_STREAMS', '1') == '0' or not (torch.is_tensor(x) and x.is_cuda) or x.shape[0] < 2 or x.shape[0] % 2:
+        # measured per model family: HNOSeg-XS gains 2-6 % (its latency-bound fused middles hide under the other half's bandwidth-bound
+        # kernels), FNOSeg loses 1 % -- so a model class opts in (``hno_sample_split = True``); HNO_SPLIT_STREAMS=1 / 0 forces it on / off
+        env = os.environ.get('HNO_SPLIT_STREAMS', '')
+        if env == '0' or (env != '1' and not getattr(model, 'hno_sample_split', False)):
+            return False
+        if not (torch.is_tensor(x) and x.is_cuda) or x.shape[0] < 2 or x.shape[0] % 2:
             return False
         if getattr(loss_fn, 'hno_loss_spec', None) is None:      # a mean over (sample, class): halves average exactly
             return False
@@ -88,7 +95,7 @@ class SampleSplit:
         """the twin still shares the model's storage (a model moved or re-materialised after the split was built does not)"""
         return all(p.data_ptr() == q.data_ptr() for p, q in zip(self.model.parameters(), self.twin.parameters()))
 
-    def fwd_bwd(self, x, lab_u8, loss_fn, zero_grad=None):
+    def fwd_bwd(self, x, lab_u8, loss_fn, zero_grad=None, autocast=None):
         """enqueue both halves (call with the capturing stream current) -> the batch loss; model parameters' .grad = full gradients.
         Only inside a stream capture: there every tensor of the step lives in the graph's private pool until the capture ends; eager,
         the caching allocator's per-stream reuse and autograd's stream bookkeeping for accumulation nodes that outlive a pass made the
@@ -100,7 +107,7 @@ class SampleSplit:
         losses = []
         for m, s, sl in ((self.model, self.streams[0], slice(0, h)), (self.twin, self.streams[1], slice(h, x.shape[0]))):
             s.wait_stream(cur)
-            with torch.cuda.stream(s):
+            with torch.cuda.stream(s), (autocast() if autocast is not None else contextlib.nullcontext()):
                 xb, lb = x[sl], lab_u8[sl]
                 with ops.expected_loss(lb, loss_fn):
                     y = m(xb)

@@ -193,6 +193,8 @@ class HNOXSBlock(nn.Module):
 class HNOSegXS(nn.Module):
     """HNOSeg-XS (reference :20-182).  See the reference docstring for the arguments; they are
     identical here."""
+    # captured training steps run the two halves of an even batch as two concurrent passes (experiments.train_test.SampleSplit)
+    hno_sample_split = True
 
     def __init__(self, in_channels, out_channels, filters, num_transform_blocks, num_modes, weights_type='shared',
                  use_resize=True, use_deep_supervision=False, use_unet_skip=True, use_block_concat=True,

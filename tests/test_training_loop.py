@@ -275,6 +275,8 @@ def test_sample_split_gives_the_batch_gradients(loss_name):
     x = torch.randn(4, 4, 32, 32, 32, device='cuda')
     lab = torch.randint(0, 4, (4, 32, 32, 32), device='cuda').to(torch.uint8)
     assert tt.SampleSplit.usable(model, loss_fn, x) and not tt.SampleSplit.usable(model, loss_fn, x[:3]) and not tt.SampleSplit.usable(model, torch.nn.MSELoss(), x)
+    other = pkg.nets.NeuralOperatorSeg(4, 4, 24, 2, (4, 6, 6), 'Fourier').cuda()      # a family that has not opted in (measured: no gain)
+    assert not tt.SampleSplit.usable(other, loss_fn, x)
     params = [p for p in model.parameters()]
 
     def whole():
