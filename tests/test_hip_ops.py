@@ -828,6 +828,37 @@ def test_specmix_stack(pkg, C, L, residual, shape):
         assert rel_err(a.cpu().numpy(), b.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('C', [16, 24])
+def test_specmix_weights_at_the_end_of_an_allocation(pkg, C):
+    """The guard-free (C == 16 / 24, M % 32 == 0) instantiations of the mixing kernels read the weights with all 32 lanes of a half
+    wave: lanes >= C must stay inside W.  (Round 4: they ran up to 32 - C rows past it, which faulted whenever W closed an allocator
+    segment with nothing mapped behind it -- an abort of the first process on a fresh box.)  W is placed as the last bytes of a
+    buffer that is a segment of its own (>= 10 MB allocations are not pooled); results must equal the ordinary placement exactly."""
+    from multimodal_3d_image_segmentation_amd import ops
+    torch.manual_seed(1)
+    L = 3
+    z = torch.randn(2, C, 4, 4, 6, device='cuda', requires_grad=True)
+    W = [(torch.randn(C, C, device='cuda') * 0.2).requires_grad_(True) for _ in range(L)]
+    cot = torch.randn(2, C, 4, 4, 6, device='cuda')
+    out = ops.SpecMixFn.apply(z, 1, ops.ACT_SELU, *W)
+    ref = torch.autograd.grad((out * cot).sum(), [z] + W)
+    for l in range(L):
+        seg = torch.empty(5 * 2 ** 20 + 0, device='cuda')                      # 20 MiB: a multiple of the 2 MiB segment rounding
+        with torch.no_grad():
+            tail = seg[-C * C:].view(C, C)
+            tail.copy_(W[l])
+        Wt = list(W)
+        Wt[l] = tail.requires_grad_(True)
+        assert Wt[l].data_ptr() + 4 * C * C == seg.data_ptr() + 4 * seg.numel()
+        out2 = ops.SpecMixFn.apply(z, 1, ops.ACT_SELU, *Wt)
+        got = torch.autograd.grad((out2 * cot).sum(), [z] + Wt)
+        torch.cuda.synchronize()
+        assert torch.equal(out2, out)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+        del seg, tail, Wt, out2, got
+
+
 @pytest.mark.parametrize('tag', ['64', 'odd'])
 def test_hnosegxs_full_model_vs_reference_golden(pkg, tag):
     """Logits (softmax outputs), loss and ALL 28 248 parameter gradients of HNOSeg-XS against the
