@@ -785,7 +785,7 @@ __global__ __launch_bounds__(64 * NWV) void pwconv_fwd_chain_kernel(PwChainArgs 
 
 #define PWB_FAST_WAVES 4   // 256-thread blocks, two per CU (512 slabs): measured best of {4, 8, 12} waves x {256, 512, 1024} blocks
 template <int COUT, int CA, int CB, int NW = PWB_FAST_WAVES, int BR = 0, bool BF16 = false>   // compile-time channel counts: every address select folds
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pwconv_bwd_fast_kernel(PwBwdArgs a) {   // 2 blocks per CU: a 256-register budget, all in VGPRs (no AGPR copies)
+__global__ __launch_bounds__(64 * NW, (NW == 4 && COUT <= 48) ? 2 : 1) void pwconv_bwd_fast_kernel(PwBwdArgs a) {   // 2 blocks per CU: a 256-register budget, all in VGPRs (no AGPR copies); COUT = 144: one block, 512 registers
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1480,7 +1480,10 @@ int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const fl
     HNO_REQUIRE(Cb == 0 || xb, "hno_pwconv_fwd: xb is NULL but Cb > 0");
     if (V * 8 >= (1ll << 32) || ((V + 31) / 32) * B >= (1ll << 31))
         return fail(HNO_ELIMIT, "hno_pwconv_fwd: V=%lld voxels per channel exceeds the 32-bit offset range", V);
-    if (B == 1 && Ca == 12 && Cb == 0 && Cout > 48 && Cout % 48 == 0 && !residual) {
+    // 144 <- 12 in one launch (five 32-row output tiles per wave; see pwconv_bwd_launch): the three thirds cost three latency-bound launches
+    static const bool wide144 = !(getenv("HNO_PW_WIDE144") && atoi(getenv("HNO_PW_WIDE144")) == 0);
+    const bool one_launch_144 = wide144 && Cout == 144 && !bf16;
+    if (B == 1 && Ca == 12 && Cb == 0 && Cout > 48 && Cout % 48 == 0 && !residual && !one_launch_144) {
         // HartleyMHASeg's fused q / k / v projection (12 -> 144 on the kept spectrum): three launches of the 12 -> 48 fast kernel on
         // output-channel thirds instead of five of the generic one (one sample: the thirds are contiguous blocks of y)
         for (int o0 = 0; o0 < Cout; o0 += 48) {
@@ -1531,6 +1534,7 @@ int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const fl
         else if (Ca == 12 && Cb == 12 && Cout == 12) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<12, 12, 12>), dim3(fgrid), fb, fl, fs, a);
         else if (Ca == 12 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<12, 0, 4>), dim3(fgrid), fb, fl, fs, a);
         else if (Ca == 12 && Cb == 0 && Cout == 48) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<12, 0, 48>), dim3(fgrid), fb, fl, fs, a);     // a third of the attention's q / k / v projection
+        else if (Ca == 12 && Cb == 0 && Cout == 144 && one_launch_144) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<12, 0, 144>), dim3(fgrid), fb, fl, fs, a);   // the stacked projection
         else if (Ca == 48 && Cb == 0 && Cout == 12) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<48, 0, 12>), dim3(fgrid), fb, fl, fs, a);     // attention output projection
         else done = false;
         if (done) {
@@ -1572,7 +1576,12 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
     const int Cin = Ca + Cb;
     if (V * 8 >= (1ll << 32) || ((V + 31) / 32) * B >= (1ll << 31))
         return fail(HNO_ELIMIT, "hno_pwconv_bwd: V=%lld voxels per channel exceeds the 32-bit offset range", V);
-    if (B == 1 && Ca == 12 && Cb == 0 && Cout > 48 && Cout % 48 == 0 && !residual && !Wbr) {
+    // 144 <- 12 (the stacked q / k / v projection of HartleyMHASeg): one launch of the 144-row instantiation (round 4c) instead of three
+    // 48-row launches + three slab reductions that serialise on the accumulated input gradient (3 x 15.5 us -> one launch; at 490 tiles the
+    // launch has fewer workgroups than the chip has CUs, so the 512-register single-block form costs no occupancy).  HNO_PW_WIDE144=0: thirds
+    static const bool wide144 = !(getenv("HNO_PW_WIDE144") && atoi(getenv("HNO_PW_WIDE144")) == 0);
+    const bool one_launch_144 = wide144 && Cout == 144 && !bf16 && ((V + 31) / 32 + PWB_FAST_WAVES - 1) / PWB_FAST_WAVES <= 512;
+    if (B == 1 && Ca == 12 && Cb == 0 && Cout > 48 && Cout % 48 == 0 && !residual && !Wbr && !one_launch_144) {
         // see pwconv_fwd_launch: output-channel thirds on the 48 <- 12 fast kernel; the input gradient accumulates over the thirds
         // each third keeps its own slab region (a deferred slab reduction reads it after the next third has run): the workspace of
         // (12, Cout) is 1024 slabs of Cout (12 + 1) floats = Cout / 48 regions of 1024 slabs of 48 (12 + 1)
@@ -1639,6 +1648,7 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<4, 24, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<48, 48, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<144, 12, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 0, PWB_FAST_WAVES, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_done = current_device();
@@ -1659,6 +1669,7 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
             else if (Ca == 12 && Cb == 12 && Cout == 12) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<12, 12, 12>), g, blk, (pwb_fast_lds_bytes<12, 12, 12, 0>(NW)), s, a);
             else if (Ca == 12 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<4, 12, 0>), g, blk, (pwb_fast_lds_bytes<4, 12, 0, 0>(NW)), s, a);
             else if (Ca == 12 && Cb == 0 && Cout == 48) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<48, 12, 0>), g, blk, (pwb_fast_lds_bytes<48, 12, 0, 0>(NW)), s, a);
+            else if (Ca == 12 && Cb == 0 && Cout == 144 && B == 1 && one_launch_144) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<144, 12, 0>), g, blk, (pwb_fast_lds_bytes<144, 12, 0, 0>(NW)), s, a);
             else if (Ca == 48 && Cb == 0 && Cout == 12) hipLaunchKernelGGL((pwconv_bwd_fast_kernel<12, 48, 0>), g, blk, (pwb_fast_lds_bytes<12, 48, 0, 0>(NW)), s, a);
             else done = false;
         }

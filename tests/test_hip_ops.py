@@ -828,6 +828,27 @@ def test_specmix_stack(pkg, C, L, residual, shape):
         assert rel_err(a.cpu().numpy(), b.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('grid', [(20, 28, 28), (5, 7, 9), (40, 40, 41)])
+def test_pwconv_stacked_qkv_projection(pkg, grid):
+    """144 <- 12 pointwise conv of one sample (HartleyMHASeg's stacked q / k / v projection, nets/hartley_mha.py): forward in output-channel
+    thirds, backward as ONE launch of the 144-row kernel while the tile count fits one wave of workgroups (round 4c; thirds beyond that --
+    the third grid), against float64."""
+    from multimodal_3d_image_segmentation_amd import ops
+    torch.manual_seed(4)
+    x = torch.randn(1, 12, *grid, dtype=torch.float64, requires_grad=True)
+    W = (torch.randn(144, 12, dtype=torch.float64) * 0.3).requires_grad_(True)
+    b = torch.randn(144, dtype=torch.float64, requires_grad=True)
+    y = torch.einsum('oi,bidhw->bodhw', W, x) + b.view(1, -1, 1, 1, 1)
+    cot = torch.randn_like(y)
+    ref = torch.autograd.grad((y * cot).sum(), [x, W, b])
+    xd, Wd, bd = (t.detach().float().cuda().requires_grad_(True) for t in (x, W, b))
+    yd = ops.PwConvFn.apply(xd, None, Wd, bd, ops.ACT_NONE)
+    assert rel_err(yd.detach().cpu().numpy(), y.detach().numpy()) < 5e-6
+    got = torch.autograd.grad((yd * cot.float().cuda()).sum(), [xd, Wd, bd])
+    for a, r in zip(got, ref):
+        assert rel_err(a.cpu().numpy(), r.numpy()) < 1e-5
+
+
 @pytest.mark.parametrize('C', [16, 24])
 def test_specmix_weights_at_the_end_of_an_allocation(pkg, C):
     """The guard-free (C == 16 / 24, M % 32 == 0) instantiations of the mixing kernels read the weights with all 32 lanes of a half
