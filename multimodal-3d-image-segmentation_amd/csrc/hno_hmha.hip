@@ -634,13 +634,18 @@ __global__ __launch_bounds__(256) void patch_group_kernel(PgArgs a) {
     if (!part && !a.inverse) return;
     float *fullc = a.full + (size_t)blockIdx.y * a.d * a.h * a.w;
     float *partc = part ? part + ((size_t)b * Cs + (c - c0)) * P * T : nullptr;
+    // gridDim.z = pd ph: one (i, j) row of the patch per workgroup (few channels: 8 x 48 workgroups of 64 dependent loads per thread were
+    // latency-bound at 1.5 TB/s); gridDim.z = 1: a thread walks the whole patch
+    const bool zs = gridDim.z > 1;
+    const int i0 = zs ? (int)blockIdx.z / a.ph : 0, i1 = zs ? i0 + 1 : a.pd;
+    const int j0 = zs ? (int)blockIdx.z - i0 * a.ph : 0, j1 = zs ? j0 + 1 : a.ph;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < T; t += gridDim.x * 256) {
         const int tw = t % nw, r = t / nw, th = r % nh, td = r / nh;
         const unsigned base = ((unsigned)(td * a.pd) * a.h + th * a.ph) * a.w + tw * a.pw;
-        int pi = 0;
-        for (int i = 0; i < a.pd; ++i)
-            for (int j = 0; j < a.ph; ++j)
-                for (int l = 0; l < a.pw; ++l, ++pi) {
+        for (int i = i0; i < i1; ++i)
+            for (int j = j0; j < j1; ++j)
+                for (int l = 0; l < a.pw; ++l) {
+                    const int pi = (i * a.ph + j) * a.pw + l;
                     const unsigned fo = base + ((unsigned)i * a.h + j) * a.w + l;
                     if (a.inverse) {
                         float v = 0.f;
@@ -684,7 +689,10 @@ static int patch_group_launch(float *full, float *p0, float *p1, float *p2, int 
     HNO_REQUIRE((long long)B * a.Ctot <= 65535 && (long long)d * h * w < (1ll << 31), "hno_patch_group3: too many channels / voxels");
     int gx = (T + 255) / 256;
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(patch_group_kernel, dim3((unsigned)gx, (unsigned)(B * a.Ctot)), dim3(256), 0, (hipStream_t)stream, a);
+    static const int split_mode = getenv("HNO_PG_SPLIT") ? atoi(getenv("HNO_PG_SPLIT")) : 1;     // 0: never, 1: below 1 024 workgroups, 2: always
+    const bool split = pd * ph > 1 && pd * ph <= 64 && (split_mode == 2 || (split_mode == 1 && (long long)gx * B * a.Ctot < 1024));
+    hipLaunchKernelGGL(patch_group_kernel, dim3((unsigned)gx, (unsigned)(B * a.Ctot), split ? (unsigned)(pd * ph) : 1u), dim3(256), 0,
+                       (hipStream_t)stream, a);
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }
