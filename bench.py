@@ -416,7 +416,8 @@ def main():
                 traffic = None
                 tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
                 if os.path.exists(tpath):
-                    traffic = json.load(open(tpath)).get(dom)
+                    tj = json.load(open(tpath))      # PMC passes of the same command (tools/make_hbm_traffic.py; profiles/README.md)
+                    traffic = tj.get('per_kernel_bytes_per_launch', tj).get(dom)
                 roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                             'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                             'algorithmic_bytes_per_launch': ab, 'avg_launch_us': round(avg_ms * 1e3, 2)}
