@@ -79,11 +79,19 @@ class SampleSplit:
 
     @staticmethod
     def usable(model, loss_fn, x):
-        # measured per model family: HNOSeg-XS gains 2-6 % (its latency-bound fused middles hide under the other half's bandwidth-bound
-        # kernels), FNOSeg loses 1 % -- so a model class opts in (``hno_sample_split = True``); HNO_SPLIT_STREAMS=1 / 0 forces it on / off
+        # measured per model family AND batch shape: HNOSeg-XS at 2 x 4 x 128^3 gains 3-6 % (its latency-bound fused middles hide under the
+        # other half's bandwidth-bound kernels); the same model at 80^3 ... 120^3 and 144^3 / 160^3 LOSES 2-10 %, FNOSeg loses 1 % -- so a
+        # model class opts in with the (batch, D, H, W) shapes it was measured to gain at (``hno_sample_split``: a collection of such tuples,
+        # or True for every shape); HNO_SPLIT_STREAMS=1 / 0 forces it on / off
         env = os.environ.get('HNO_SPLIT_STREAMS', '')
-        if env == '0' or (env != '1' and not getattr(model, 'hno_sample_split', False)):
+        if env == '0':
             return False
+        if env != '1':
+            spec = getattr(model, 'hno_sample_split', False)
+            if not spec:
+                return False
+            if spec is not True and not (torch.is_tensor(x) and (int(x.shape[0]),) + tuple(int(v) for v in x.shape[2:]) in spec):
+                return False
         if not (torch.is_tensor(x) and x.is_cuda) or x.shape[0] < 2 or x.shape[0] % 2:
             return False
         if getattr(loss_fn, 'hno_loss_spec', None) is None:      # a mean over (sample, class): halves average exactly
@@ -97,9 +105,8 @@ class SampleSplit:
 
     def fwd_bwd(self, x, lab_u8, loss_fn, zero_grad=None, autocast=None):
         """enqueue both halves (call with the capturing stream current) -> the batch loss; model parameters' .grad = full gradients.
-        Only inside a stream capture: there every tensor of the step lives in the graph's private pool until the capture ends; eager,
-        the caching allocator's per-stream reuse and autograd's stream bookkeeping for accumulation nodes that outlive a pass made the
-        same sequence fault once in a few runs (a memory access fault after unrelated graph tests in the same process), unexplained."""
+        Only inside a stream capture (there every tensor of the step lives in the graph's private pool until the capture ends): eager, the
+        two passes are launch-bound and gain nothing, and the caching allocator's per-stream reuse would need record_stream bookkeeping."""
         if not torch.cuda.is_current_stream_capturing():
             raise RuntimeError('SampleSplit.fwd_bwd is for captured steps only (CapturedStep / bench.py)')
         cur = torch.cuda.current_stream()

@@ -43,9 +43,11 @@ def test_training_matches_reference_trajectory(tmp_path):
         assert rel_err(v.cpu().numpy(), g[f'sd1::{k}']) < 2e-3, k
 
 
-def test_training_graph_replay_equals_eager(tmp_path):
+@pytest.mark.parametrize('two_streams', ['0', '1'])
+def test_training_graph_replay_equals_eager(tmp_path, monkeypatch, two_streams):
     """training() replays forward + loss + backward of recurring batch shapes from a HIP graph (CapturedStep, round 3): the same
     kernels, so the same trajectory as eager launches -- and the first batch of a shape still runs eagerly."""
+    monkeypatch.setenv('HNO_SPLIT_STREAMS', two_streams)      # captured steps as one pass / as two half-batches on two streams (SampleSplit)
     from multimodal_3d_image_segmentation_amd.experiments import train_test as tt
     g = load_golden('g8_training.npz')
     runs = {}
@@ -64,9 +66,11 @@ def test_training_graph_replay_equals_eager(tmp_path):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-4
 
 
-def test_training_graph_replay_with_ragged_last_batch(tmp_path):
+@pytest.mark.parametrize('two_streams', ['0', '1'])
+def test_training_graph_replay_with_ragged_last_batch(tmp_path, monkeypatch, two_streams):
     """Five samples in batches of two: shapes (2, ...) and (1, ...) alternate.  Each shape runs eagerly once, then from its own graph;
     gradients written by one form must never leak into a step of the other (CapturedStep re-installs .grad after every replay)."""
+    monkeypatch.setenv('HNO_SPLIT_STREAMS', two_streams)      # captured steps as one pass / as two half-batches on two streams (SampleSplit)
     import multimodal_3d_image_segmentation_amd as pkg
     from multimodal_3d_image_segmentation_amd.experiments import train_test as tt
     from multimodal_3d_image_segmentation_amd.experiments.synthetic import SyntheticInputData
@@ -260,7 +264,7 @@ def test_training_with_autocast_and_grad_scaler(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('loss_name', ['pcc', 'dice', 'expdice'])
-def test_sample_split_gives_the_batch_gradients(loss_name):
+def test_sample_split_gives_the_batch_gradients(loss_name, monkeypatch):
     """Round 4b: experiments.train_test.SampleSplit -- the two halves of a batch as two concurrent passes (model and its storage-aliasing
     twin) on two streams of a captured graph.  Loss and every gradient equal the whole-batch pass (means over (sample, class): the halves
     average exactly); the twin follows in-place weight updates (every replay computes with the current weights); a model whose storage
@@ -274,9 +278,16 @@ def test_sample_split_gives_the_batch_gradients(loss_name):
     model = pkg.nets.HNOSegXS(4, 4, 24, [1, 1, 1, 1], (4, 6, 6)).cuda()
     x = torch.randn(4, 4, 32, 32, 32, device='cuda')
     lab = torch.randint(0, 4, (4, 32, 32, 32), device='cuda').to(torch.uint8)
-    assert tt.SampleSplit.usable(model, loss_fn, x) and not tt.SampleSplit.usable(model, loss_fn, x[:3]) and not tt.SampleSplit.usable(model, torch.nn.MSELoss(), x)
+    # opt-in per model class and batch shape (measured: only HNOSeg-XS at 2 x 4 x 128^3 gains); HNO_SPLIT_STREAMS=1 forces it for this test
+    monkeypatch.delenv('HNO_SPLIT_STREAMS', raising=False)
+    big = torch.empty(2, 4, 128, 128, 128, device='cuda')
+    assert tt.SampleSplit.usable(model, loss_fn, big) and not tt.SampleSplit.usable(model, loss_fn, x)
     other = pkg.nets.NeuralOperatorSeg(4, 4, 24, 2, (4, 6, 6), 'Fourier').cuda()      # a family that has not opted in (measured: no gain)
-    assert not tt.SampleSplit.usable(other, loss_fn, x)
+    assert not tt.SampleSplit.usable(other, loss_fn, big)
+    del big
+    monkeypatch.setenv('HNO_SPLIT_STREAMS', '1')
+    assert tt.SampleSplit.usable(model, loss_fn, x) and not tt.SampleSplit.usable(model, loss_fn, x[:3]) and not tt.SampleSplit.usable(model, torch.nn.MSELoss(), x)
+    assert tt.SampleSplit.usable(other, loss_fn, x)
     params = [p for p in model.parameters()]
 
     def whole():
