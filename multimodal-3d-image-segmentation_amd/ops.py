@@ -791,6 +791,9 @@ class PadIdhtFn(_HnoFunction):
         return dht3_crop_raw(_f32c(g), ctx.modes, ctx.scale, out, ctx.act), None, None, None
 
 
+_PADADD_BWD_ONE_PRODUCT = os.environ.get('HNO_PADADD_BWD_ONE_PRODUCT', '1') != '0'
+
+
 class PadIdhtAddFn(_HnoFunction):
     """act(scale * PadInverse(z) + addend): the operator output plus the spatial conv branch, activated
     (nets/architectures.py:521-539 with HartleyOperator._call3d :243-269 feeding it)."""
@@ -811,6 +814,12 @@ class PadIdhtAddFn(_HnoFunction):
     def backward(ctx, g):
         (out,) = ctx.saved_tensors
         g = _f32c(g)
+        if ctx.act != ACT_NONE and ctx.needs_input_grad[1] and _PADADD_BWD_ONE_PRODUCT:
+            # the addend's gradient g * act'(out) is needed as a tensor anyway: transform THAT instead of letting the transform form the
+            # product again from g and out -- one input stream less, and the plain plane kernel (LDS-DMA rows) instead of the two-operand
+            # one (HartleyMHASeg: 20.1 -> 8.9 us per block)
+            ga = act_bwd_raw(g, out, ctx.act)
+            return dht3_crop_raw(ga, ctx.modes, ctx.scale), ga, None, None, None
         gz = dht3_crop_raw(g, ctx.modes, ctx.scale, out, ctx.act)
         ga = None
         if ctx.needs_input_grad[1]:
