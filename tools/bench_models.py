@@ -20,6 +20,7 @@ CASES = {
 # a case name suffixed with ':bf16' runs the step under torch.autocast('cuda', dtype=torch.bfloat16) (the bf16 matrix-core path)
 which = sys.argv[1:] or list(CASES)
 import contextlib
+import os
 for name in which:
     bf16 = name.endswith(':bf16')
     ctor, shape = CASES[name.split(':')[0].split('@')[0]]
@@ -63,7 +64,16 @@ for name in which:
         dt_split = None
         try:
             from multimodal_3d_image_segmentation_amd.experiments.train_test import SampleSplit
-            if not bf16 and SampleSplit.usable(model, loss_fn, x):
+            # measured for every shape of a family that opted in at some shape (the opt-in itself is per shape: this is how it was decided)
+            forced = dict(os.environ, HNO_SPLIT_STREAMS='1') if getattr(model, 'hno_sample_split', False) else None
+            prev_env = os.environ.get('HNO_SPLIT_STREAMS')
+            if forced: os.environ['HNO_SPLIT_STREAMS'] = '1'
+            try: can = not bf16 and SampleSplit.usable(model, loss_fn, x)
+            finally:
+                if forced:
+                    if prev_env is None: os.environ.pop('HNO_SPLIT_STREAMS', None)
+                    else: os.environ['HNO_SPLIT_STREAMS'] = prev_env
+            if can:
                 sp = SampleSplit(model)
                 def zero():
                     for p in model.parameters(): p.grad = None
