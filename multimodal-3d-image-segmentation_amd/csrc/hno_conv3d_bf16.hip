@@ -1365,7 +1365,9 @@ extern "C" int hno_cb_pack_weights_both(const float *W, void *dst_fwd, void *dst
 #define CB_PT_C0 8
 #define CB_PT_C1 32
 __global__ __launch_bounds__(256) void cb_pack_weights_tiled_kernel(const long long *__restrict__ table, int nrows) {
-    __shared__ float wt[CB_PT_C0][CB_PT_C1 * 27];
+    // + 1: in the output-major branch the eight lanes of a 16-byte chunk read the eight rows at the same column -- a row stride of
+    // 32 x 27 floats put all of them in one bank (8-way conflict on every read)
+    __shared__ float wt[CB_PT_C0][CB_PT_C1 * 27 + 1];
     int row_id = 0;
     long long first = 0;
     int g1n = 1;

@@ -1534,7 +1534,7 @@ int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const fl
         else if (Ca == 12 && Cb == 12 && Cout == 12) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<12, 12, 12>), dim3(fgrid), fb, fl, fs, a);
         else if (Ca == 12 && Cb == 0 && Cout == 4) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<12, 0, 4>), dim3(fgrid), fb, fl, fs, a);
         else if (Ca == 12 && Cb == 0 && Cout == 48) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<12, 0, 48>), dim3(fgrid), fb, fl, fs, a);     // a third of the attention's q / k / v projection
-        else if (Ca == 12 && Cb == 0 && Cout == 144 && one_launch_144) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<12, 0, 144>), dim3(fgrid), fb, fl, fs, a);   // the stacked projection
+        else if (Ca == 12 && Cb == 0 && Cout == 144 && B == 1 && one_launch_144) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<12, 0, 144>), dim3(fgrid), fb, fl, fs, a);   // the stacked projection
         else if (Ca == 48 && Cb == 0 && Cout == 12) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<48, 0, 12>), dim3(fgrid), fb, fl, fs, a);     // attention output projection
         else done = false;
         if (done) {
