@@ -169,6 +169,8 @@ def secondary_configs(pkg, dev):
         'cfg3_fnoseg_2x4x128^3_fp32_ms_per_step': (lambda: nets.NeuralOperatorSeg(4, 4, 24, 24, (10, 14, 14), 'Fourier'), (2, 4, 128, 128, 128), False),
         'cfg4_vnetds_1x4x160x192x128_bf16_autocast_ms_per_step': (lambda: nets.VNetDS(4, 4, 24, [1, 2, 3, 3, 3], right_leg_indexes=[0, 1, 2, 3, 4]), (1, 4, 160, 192, 128), True),
         'cfg4_vnetds_1x4x160x192x128_fp32_ms_per_step': (lambda: nets.VNetDS(4, 4, 24, [1, 2, 3, 3, 3], right_leg_indexes=[0, 1, 2, 3, 4]), (1, 4, 160, 192, 128), False),
+        # the attention family (reference tensorflow/experiments/config_files/config_hartleymha.ini:24-29: 12 filters, 16 blocks, 4 heads, modes 10-14-14, patch 2 x 2 x 2)
+        'hartleymha_1x4x128^3_fp32_ms_per_step': (lambda: nets.HartleyMHASeg(4, 4, 12, 16, 4, (10, 14, 14), (2, 2, 2)), (1, 4, 128, 128, 128), False),
     }
     for key, (ctor, shape, bf16) in cases.items():
         try:
