@@ -1503,8 +1503,13 @@ extern "C" int hno_cb_pack_weights(const float *W, void *dst, int role, int Cin,
 
 static int cb_pick_ksplit(int B, int Cout, long long Vo, int nsteps) {
     const long long waves = (long long)B * ((Vo + 63) / 64) * ((Cout + 95) / 96);
+    static const int ks_max = getenv("HNO_CB_KSPLIT_MAX") ? atoi(getenv("HNO_CB_KSPLIT_MAX")) : 32;     // A/B aid (1 ... 32)
+    // split K until the launch has one wave per SIMD (1 024).  Rounds 2-4 split to two (2 048): the mid levels of V-Net-DS then wrote and
+    // re-read twice the partial slabs for no gain in occupancy -- cfg4 bf16 step 7.78 -> 7.59 ms (384 ... 1 024: 7.57-7.59; 256: 7.66;
+    // 128: 7.93; capping the split depth instead hurts the deepest levels: max 16 / 8 / 4 -> 7.82 / 7.93 / 8.36)
+    static const int wave_target = getenv("HNO_CB_KSPLIT_WAVES") ? atoi(getenv("HNO_CB_KSPLIT_WAVES")) : 1024;
     int ks = 1;
-    while (waves * ks < 2048 && ks * 2 <= nsteps && ks < 32) ks *= 2;
+    while (waves * ks < wave_target && ks * 2 <= nsteps && ks < 32 && ks * 2 <= ks_max) ks *= 2;
     return ks;
 }
 
