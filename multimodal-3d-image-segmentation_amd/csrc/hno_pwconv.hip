@@ -1506,7 +1506,11 @@ int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const fl
         bool done = true;
         ProfScope ps(KID_PWCONV_FWD, fs, 4.0 * B * (double)V * (a.Cin + Cout));
         int fgrid = (int)((ntiles + PWF_DMA_WAVES - 1) / PWF_DMA_WAVES);
-        if (fgrid > 256) fgrid = 256;   // one block per CU
+        static const int fcap_env = getenv("HNO_PWF_GRID_CAP") ? atoi(getenv("HNO_PWF_GRID_CAP")) : 0;      // A/B aid
+        // 24-channel shapes (HNOSeg-XS): one block per CU measured best; the 12-channel shapes of HartleyMHASeg do half the products per
+        // tile and want two (model step 10.63 -> 10.55 ms; 1 024: 10.57)
+        const int fcap = fcap_env > 0 ? fcap_env : (Ca == 12 ? 512 : 256);
+        if (fgrid > fcap) fgrid = fcap;   // one block per CU
         if (a.dbg >> 8) fgrid = a.dbg >> 8;
         const dim3 fb(64 * PWF_DMA_WAVES);
         const size_t fl = (size_t)PWF_DMA_WAVES * 2 * (a.Cin / 2) * 256;      // the waves' DMA rings
@@ -1639,7 +1643,8 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
         }
         if (s2424 && (a.dbg & 64)) NW = 8;
         long long fg = (ntiles + NW - 1) / NW;
-        if (fg > 512) fg = 512;   // two blocks per CU
+        static const int bcap_env = getenv("HNO_PWB_GRID_CAP") ? atoi(getenv("HNO_PWB_GRID_CAP")) : 0;      // A/B aid
+        if (fg > (bcap_env > 0 ? bcap_env : 512)) fg = bcap_env > 0 ? bcap_env : 512;   // two blocks per CU
         if (a.dbg >> 8) fg = a.dbg >> 8;
         static int attr_done = -1;
         if (attr_done != current_device()) {
