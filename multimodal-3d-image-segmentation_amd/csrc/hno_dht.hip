@@ -2694,6 +2694,41 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
     return HNO_OK;
 }
 
+// HNO_ITEM_SMALL: item count up to which the inverse item kernel runs with 8 instead of 16 waves per workgroup (0: never).  A/B aid.
+static int item_small_limit() {
+    static const int v = getenv("HNO_ITEM_SMALL") ? atoi(getenv("HNO_ITEM_SMALL")) : 2048;
+    return v;
+}
+
+template <int NP, int N2c, int KM1, int NT2, int NWV>
+static int inv_item_launch(const void *workspace, const float *addend, float *out, const DhtArgs &a, unsigned shift0, int items,
+                           long long ldbc, hipStream_t s) {
+    float *out_al = out - shift0;
+    const float *add_al = addend ? addend - shift0 : nullptr;
+    const size_t lds_w = sizeof(float) * NWV * ((NP == 2 ? 2176 : round_up_c((32 * NP + 1) * N2c + 4, 64)) + 64);
+    const int gw = items < 256 * NWV ? (items + NWV - 1) / NWV : 256;
+    if (addend) {
+        auto kern = dht_inv_item_kernel<NP, N2c, KM1, NT2, true, NWV>;
+        static int attr = -1;
+        if (attr != current_device()) {
+            HNO_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+            attr = current_device();
+        }
+        hipLaunchKernelGGL(kern, dim3(gw), dim3(64 * NWV), lds_w, s, (const float *)workspace, add_al, out_al, a, shift0, items / gw, items % gw,
+                           (unsigned)ldbc);
+    } else {
+        auto kern = dht_inv_item_kernel<NP, N2c, KM1, NT2, false, NWV>;
+        static int attr = -1;
+        if (attr != current_device()) {
+            HNO_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+            attr = current_device();
+        }
+        hipLaunchKernelGGL(kern, dim3(gw), dim3(64 * NWV), lds_w, s, (const float *)workspace, add_al, out_al, a, shift0, items / gw, items % gw,
+                           (unsigned)ldbc);
+    }
+    return HNO_OK;
+}
+
 // planes_only: the workspace already holds the axis-D step's output (written by the fused spectral middle): plane kernel only
 static int dht_inverse_launch(const float *z, const float *addend, int act, float *out, void *workspace,
                               int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream,
@@ -2768,32 +2803,12 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
         b2.KT == 1 && b1.KmP == 4 * KM1 && b2.KmP <= 16 && plan->NP1 == NP && (b2.J + 15) / 16 == NT2 &&                   \
         (double)BC * ldbc < 1.0e9 && ((size_t)out & 3) == 0 && (!addend || ((size_t)addend & 15) == ((size_t)out & 15))) { \
         const unsigned shift0 = (unsigned)(((size_t)out >> 2) & 3);                                                        \
-        float *out_al = out - shift0;                                                                                      \
-        const float *add_al = addend ? addend - shift0 : nullptr;                                                          \
-        constexpr int NWV = 16;                                                                                            \
-        const size_t lds_w = sizeof(float) * NWV * ((NP == 2 ? 2176 : round_up_c((32 * NP + 1) * N2c + 4, 64)) + 64);     \
         const int items = planes * NP;                                                                                     \
-        if (addend) {                                                                                                      \
-            auto kern = dht_inv_item_kernel<NP, N2c, KM1, NT2, true, NWV>;                                                      \
-            static int attr = -1;                                                                                      \
-            if (attr != current_device()) {                                                                                                   \
-                HNO_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds)); \
-                attr = current_device();                                                                                               \
-            }                                                                                                              \
-            const int gw = items < 256 * NWV ? (items + NWV - 1) / NWV : 256;                                              \
-            hipLaunchKernelGGL(kern, dim3(gw), dim3(64 * NWV), lds_w, s, (const float *)workspace, add_al, out_al, a, shift0, \
-                               items / gw, items % gw, (unsigned)ldbc);                                                    \
-        } else {                                                                                                           \
-            auto kern = dht_inv_item_kernel<NP, N2c, KM1, NT2, false, NWV>;                                                     \
-            static int attr = -1;                                                                                      \
-            if (attr != current_device()) {                                                                                                   \
-                HNO_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds)); \
-                attr = current_device();                                                                                               \
-            }                                                                                                              \
-            const int gw = items < 256 * NWV ? (items + NWV - 1) / NWV : 256;                                              \
-            hipLaunchKernelGGL(kern, dim3(gw), dim3(64 * NWV), lds_w, s, (const float *)workspace, add_al, out_al, a, shift0, \
-                               items / gw, items % gw, (unsigned)ldbc);                                                    \
-        }                                                                                                                  \
+        /* few items (one sample of a 12-channel model: 1 560): eight waves per workgroup spread them over twice the CUs */ \
+        const int rc_item = (items <= item_small_limit())                                                                  \
+            ? inv_item_launch<NP, N2c, KM1, NT2, 8>(workspace, addend, out, a, shift0, items, ldbc, s)                      \
+            : inv_item_launch<NP, N2c, KM1, NT2, 16>(workspace, addend, out, a, shift0, items, ldbc, s);                    \
+        if (rc_item) return rc_item;                                                                                       \
         launched = true;                                                                                                   \
     }
         HNO_ITEM(2, 65, 4, 2)      // 65 x 65 planes, modes (., 14, 14)
