@@ -550,6 +550,10 @@ int hno_set_debug(int flags);
 /* with debug flag 64: clock64() stamps stored by thread 0 of workgroup 0 at the phase boundaries of the
  * instrumented kernels (tuning aid; n <= 64) */
 int hno_debug_stamps(long long *out, int n);
+/* test aid: the plane-kernel family the calling thread's last forward (inverse = 0) / inverse (1) transform launch took --
+ * 0 none yet, 1 generic (a workgroup per plane), 2 the round-2 specialised kernels, 3 the LDS-DMA forward / half-plane item inverse
+ * kernels.  The GPU tests pin the families of the benchmark shapes (a dropped instantiation falls back silently). */
+int hno_debug_last_plane_family(int inverse);
 
 /* ------------------------------------------------------------------------ self tests
  * C(MxN) = A(MxK) B(KxN) through the wave-level MFMA tile engine every kernel uses. */

@@ -144,6 +144,7 @@ SIGNATURES = {
     'hno_profile_kernel_name': (ctypes.c_char_p, [c_int]),
     'hno_debug_stamps': (c_int, [c_void_p, c_int]),
     'hno_set_debug': (c_int, [c_int]),
+    'hno_debug_last_plane_family': (c_int, [c_int]),
     'hno_selftest_gemm': (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
 }
 

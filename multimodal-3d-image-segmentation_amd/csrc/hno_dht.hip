@@ -2488,6 +2488,14 @@ static int check_sizes(int BC, int N0, int N1, int N2, int m0, int m1, int m2, i
 
 static const size_t kMaxLds = 160 * 1024;
 
+// Which plane-kernel family the last forward / inverse launch of this thread took: 0 none yet, 1 generic (workgroup per plane), 2 the
+// round-2 specialised kernels (spec / wave), 3 the LDS-DMA forward / half-plane item inverse kernels.  Test aid (tests/test_hip_ops.py
+// pins the families of the headline shapes: a refactoring that drops an instantiation falls back to a slower family with every parity
+// test still green -- round 4 lost 9 % of the headline that way for an hour).
+static thread_local int g_last_plane_family[2] = {0, 0};
+extern "C" int hno_debug_last_plane_family(int inverse) { return g_last_plane_family[inverse ? 1 : 0]; }
+
+
 // Waves per plane of the generic plane kernels on planes above 5 120 elements (121 x 121 at the published inference size).  Those
 // kernels are bound by instruction issue and latency, not by LDS capacity (two planes per CU either way): measured single-image
 // inference at 240 x 240 x 155, GPU forward 4.26 ms with 4 waves per plane, 3.14 with 8, 2.82 with 16 (default).
@@ -2595,6 +2603,7 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
         if (g_spec > 8) g_spec = 8;
         g_spec = planes < 256 * g_spec ? planes : 256 * g_spec;
         bool launched = false;
+        g_last_plane_family[0] = 1;
         // one wave per plane (no workgroup barriers): N1 = 32 g + 1, odd N2, no activation-gradient input
 #define HNO_WAVE(KC2, KS2, KC1, KS1, NEV)                                                                                  \
     if (!launched && spec_ok && !x_act_out && !(a.dbg & 512) && N1 % 32 == 1 && (N2 & 1) && b2.KcP == 4 * KC2 &&           \
@@ -2610,7 +2619,7 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
         }                                                                                                                  \
         const int gw = persistent_grid((const void *)kern, 64 * NWV, lds_w, (planes + NWV - 1) / NWV);                     \
         hipLaunchKernelGGL(kern, dim3(gw), dim3(64 * NWV), lds_w, s, x, (float *)workspace, a);                            \
-        launched = true;                                                                                                   \
+        g_last_plane_family[0] = 2; launched = true;                                                                       \
     }
         // planes by LDS-DMA, axis-W result in registers (see dht_fwd_plane_dma_kernel); HNO_FWD_PLANE=wave selects the older kernel
 #define HNO_DMA(KC2, KS2, NP)                                                                                              \
@@ -2634,7 +2643,7 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
         if (gforce > 0) gw = gforce < planes ? gforce : planes;                                                            \
         hipLaunchKernelGGL(kern, dim3(gw), dim3(64 * NWV), lds_w, s, xal, (float *)workspace, a, shift0, max_off,          \
                            planes / gw, planes % gw, (unsigned)ldbc);                                                      \
-        launched = true;                                                                                                   \
+        g_last_plane_family[0] = 3; launched = true;                                                                       \
     }
         HNO_DMA(9, 8, 2)           // 65 x 65 planes
         HNO_DMA(5, 4, 1)           // 33 x 33 planes
@@ -2653,7 +2662,7 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
             hipLaunchKernelGGL(kern, dim3(persistent_grid((const void *)kern, 256, lds_spec, planes)), dim3(256), lds_spec, \
                                s, x, x_act_out, (float *)workspace, a);                                                   \
         }                                                                                                                 \
-        launched = true;                                                                                                  \
+        g_last_plane_family[0] = 2; launched = true;                                                                      \
     }
         HNO_SPEC(9, 8, 9, 8)   // 65 x 65 planes (128^3 inputs)
         HNO_SPEC(5, 4, 5, 4)   // 33 x 33 planes (64^3 inputs)
@@ -2797,6 +2806,7 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
         if (g_spec > 8) g_spec = 8;
         g_spec = planes < 256 * g_spec ? planes : 256 * g_spec;
         bool launched = false;
+        g_last_plane_family[1] = 1;
         // one wave per half-plane item, GEMMs chained in registers (dht_inv_item_kernel); HNO_INV_PLANE=spec selects the older kernel
 #define HNO_ITEM(NP, N2c, KM1, NT2)                                                                                        \
     if (!launched && spec_ok && !(a.dbg & 512) && inv_plane_variant() != 1 && N1 == 32 * NP + 1 && N2 == N2c && b1.KT == 1 && \
@@ -2809,7 +2819,7 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
             ? inv_item_launch<NP, N2c, KM1, NT2, 8>(workspace, addend, out, a, shift0, items, ldbc, s)                      \
             : inv_item_launch<NP, N2c, KM1, NT2, 16>(workspace, addend, out, a, shift0, items, ldbc, s);                    \
         if (rc_item) return rc_item;                                                                                       \
-        launched = true;                                                                                                   \
+        g_last_plane_family[1] = 3; launched = true;                                                                       \
     }
         HNO_ITEM(2, 65, 4, 2)      // 65 x 65 planes, modes (., 14, 14)
         HNO_ITEM(1, 33, 4, 1)      // 33 x 33 planes
@@ -2826,7 +2836,7 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
             hipLaunchKernelGGL(kern, dim3(persistent_grid((const void *)kern, 256, lds_spec, planes)), dim3(256), lds_spec, \
                                s, (const float *)workspace, addend, out, a);                                              \
         }                                                                                                                 \
-        launched = true;                                                                                                  \
+        g_last_plane_family[1] = 2; launched = true;                                                                      \
     }
         HNO_SPEC(4, 4, 2, 2, 16)   // 65 x 65 planes, modes (., 14, 14): positions 1..32
         HNO_SPEC(4, 4, 2, 2, 14)   // 61 x 61 planes: positions 1..30

@@ -828,6 +828,25 @@ def test_specmix_stack(pkg, C, L, residual, shape):
         assert rel_err(a.cpu().numpy(), b.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('B,C,N,modes', [(2, 24, 65, (10, 14, 14)), (1, 24, 65, (10, 14, 14)), (1, 12, 65, (10, 14, 14)), (2, 24, 33, (10, 14, 14))])
+def test_benchmark_shapes_take_the_fast_plane_kernels(pkg, B, C, N, modes):
+    """The headline grids (65^3 after the stem of a 128^3 input; 33^3 for 64^3) must run the LDS-DMA forward and the half-plane item
+    inverse kernels (family 3 of hno_debug_last_plane_family), for the full batch, for one sample (the halves of the two-stream schedule)
+    and for the 12-channel attention model.  Every slower family computes the same numbers: a refactoring that drops an instantiation
+    keeps all parity tests green (round 4: -9 % on the headline, noticed only because the bench was re-run)."""
+    from multimodal_3d_image_segmentation_amd import ops
+    L = pkg._lib.lib()
+    x = torch.randn(B, C, N, N, N, device='cuda')
+    z = ops.dht3_crop_raw(x, modes, 1.0)
+    assert L.hno_debug_last_plane_family(0) == 3
+    y = ops.pad_idht3_raw(z, (N, N, N), 1.0)
+    assert L.hno_debug_last_plane_family(1) == 3
+    y2 = ops.pad_idht3_raw(z, (N, N, N), 1.0, x, ops.ACT_SELU)           # with addend and activation (the block's form)
+    assert L.hno_debug_last_plane_family(1) == 3
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all() and torch.isfinite(y2).all()
+
+
 @pytest.mark.parametrize('grid', [(20, 28, 28), (5, 7, 9), (40, 40, 41)])
 def test_pwconv_stacked_qkv_projection(pkg, grid):
     """144 <- 12 pointwise conv of one sample (HartleyMHASeg's stacked q / k / v projection, nets/hartley_mha.py): forward in output-channel
