@@ -87,15 +87,17 @@ def cpu_baseline(budget_s=40.0):
                       f'(torch-CPU fp32 port of the reference op sequence), {dt:.1f} s; 64^3 probe step {t64:.2f} s'}
 
 
-def launch_ranks(n):
+def launch_ranks(n, dry_run=False):
     """One child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, the same command line);
-    rank 0's stdout -- the JSON line -- passes through.  Returns the worst exit code."""
+    rank 0's stdout -- the JSON line -- passes through, the other ranks' stdout is dropped.  Returns the worst exit code.
+    dry_run: the children only initialise a gloo group and all-reduce a flat buffer (no GPU needed: the CPU suite runs this)."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()       # does not initialise the GPU runtime
-    if have < n:
-        print(f'[bench] --gpus {n} requested but only {have} GPU(s) are visible', file=sys.stderr)
-        return 2
+    if not dry_run:
+        have = torch.cuda.device_count()       # does not initialise the GPU runtime
+        if have < n:
+            print(f'[bench] --gpus {n} requested but only {have} GPU(s) are visible', file=sys.stderr)
+            return 2
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
@@ -109,6 +111,84 @@ def launch_ranks(n):
     for p in procs:
         rc = max(rc, abs(p.wait()))
     return rc
+
+
+def dry_run_rank(args):
+    """`--dry-run`: what a rank of `--gpus N` does up to and including its first collective, without a GPU -- read RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* from the environment, join a gloo group, all-reduce a flat gradient-sized buffer (HNOSeg-XS: 28 248 floats),
+    check the mean, rank 0 prints one JSON line.  `--dry-run-fail-rank R` makes rank R exit with code 3 (exit-code propagation)."""
+    import torch.distributed as dist
+    world, rank, local_rank = int(os.environ['WORLD_SIZE']), int(os.environ['RANK']), int(os.environ['LOCAL_RANK'])
+    assert os.environ.get('MASTER_ADDR') and os.environ.get('MASTER_PORT')
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with {args.gpus} ranks')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    flat = torch.full((28248,), float(rank + 1))
+    dist.all_reduce(flat)
+    flat /= world
+    ok = bool(torch.all(flat == (world + 1) / 2.0))
+    print('this line must not reach the launcher\'s stdout from ranks > 0' if rank else
+          json.dumps({'dry_run': True, 'rccl_ranks': dist.get_world_size(), 'backend': 'gloo', 'rank': rank, 'local_rank': local_rank,
+                      'master_port': int(os.environ['MASTER_PORT']), 'allreduce_ok': ok}), flush=True)
+    dist.destroy_process_group()
+    if args.dry_run_fail_rank == rank:
+        raise SystemExit(3)
+    raise SystemExit(0 if ok else 4)
+
+
+def probe_store_path():
+    """a rendezvous file every rank of THIS launch derives alone (ranks cannot talk before they have a group): the launcher's pid and
+    the master port are common to all ranks of one launch and differ between launches"""
+    import tempfile
+    return os.path.join(tempfile.gettempdir(), f"hno_probe_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}")
+
+
+def probe_captured_allreduce_child():
+    """`--probe-capture` (a child of every rank, started BEFORE the rank touches the GPU): its own RCCL group over a file store, an
+    all-reduce of a gradient-sized flat buffer CAPTURED into a HIP graph, three replays with changing inputs, results checked.  Exit 0 =
+    a collective inside a graph works across these ranks on this stack.  A mismatch inside a captured collective hangs instead of
+    raising, so this runs in a throw-away process under the parent's timeout, never in the benchmark process itself."""
+    import torch.distributed as dist
+    world, rank, local_rank = int(os.environ['WORLD_SIZE']), int(os.environ['RANK']), int(os.environ['LOCAL_RANK'])
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist.init_process_group('nccl', init_method='file://' + probe_store_path(), rank=rank, world_size=world, device_id=dev)
+    flat = torch.zeros(28248, device=dev)
+    src = torch.zeros(28248, device=dev)
+    dist.all_reduce(flat)                       # eager once: communicator set-up is not capturable
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
+            flat.copy_(src)
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+    torch.cuda.current_stream().wait_stream(side)
+    ok = True
+    for it in range(3):
+        src.fill_(float(rank + 1 + it))
+        graph.replay()
+        torch.cuda.synchronize()
+        ok = ok and bool(torch.all(flat == (world + 1) / 2.0 + it))
+    dist.destroy_process_group()
+    raise SystemExit(0 if ok else 5)
+
+
+def probe_captured_allreduce(timeout_s=150.0):
+    """-> True when the throw-away probe (above) succeeded on THIS rank within the timeout; the ranks then agree on the minimum."""
+    import subprocess
+    try:
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__), '--probe-capture'], stdout=subprocess.DEVNULL,
+                                 stderr=subprocess.DEVNULL, env=dict(os.environ))
+    except OSError:
+        return False
+    try:
+        return child.wait(timeout=timeout_s) == 0
+    except subprocess.TimeoutExpired:
+        child.kill()                            # exactly the process we started
+        child.wait()
+        return False
 
 
 def secondary_configs(pkg, dev):
@@ -139,20 +219,10 @@ def secondary_configs(pkg, dev):
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        # steps of an even batch: the two half-batches on two streams of the graph, as training()'s CapturedStep runs them
-        from multimodal_3d_image_segmentation_amd.experiments.train_test import SampleSplit
-        sp = SampleSplit(model) if SampleSplit.usable(model, loss_fn, x) else None
-        if sp is not None:
-            with torch.no_grad(), ac():
-                model(x[:shape[0] // 2])          # (tables / kernel attributes of the half-batch shapes: not capturable)
-            torch.cuda.synchronize()
         with torch.cuda.stream(side):
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr, stream=side):
-                if sp is not None:
-                    sp.fwd_bwd(x, lab, loss_fn, autocast=ac if bf16 else None)
-                else:
-                    step()
+                step()
         torch.cuda.current_stream().wait_stream(side)
         gr.replay()
         torch.cuda.synchronize()
@@ -161,9 +231,19 @@ def secondary_configs(pkg, dev):
             gr.replay()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / replays * 1e3
-        del gr, model, x, sp
+        # the step's ALGORITHMIC bytes: what every launch of one eager step declares to the profiler (DESIGN section 4's per-kernel
+        # definitions; launches that declare none count as zero, so the sum is a lower bound)
+        algo = None
+        try:
+            with pkg._lib.KernelProfile(max_records=4096) as kp:
+                step()
+            torch.cuda.synchronize()
+            algo = sum(nb for _, _, nb in kp.records)
+        except Exception:   # noqa: BLE001
+            pass
+        del gr, model, x
         torch.cuda.empty_cache()
-        return round(ms, 3)
+        return round(ms, 3), algo
     cases = {
         'cfg3_fnoseg_2x4x128^3_bf16_autocast_ms_per_step': (lambda: nets.NeuralOperatorSeg(4, 4, 24, 24, (10, 14, 14), 'Fourier'), (2, 4, 128, 128, 128), True),
         'cfg3_fnoseg_2x4x128^3_fp32_ms_per_step': (lambda: nets.NeuralOperatorSeg(4, 4, 24, 24, (10, 14, 14), 'Fourier'), (2, 4, 128, 128, 128), False),
@@ -172,11 +252,30 @@ def secondary_configs(pkg, dev):
         # the attention family (reference tensorflow/experiments/config_files/config_hartleymha.ini:24-29: 12 filters, 16 blocks, 4 heads, modes 10-14-14, patch 2 x 2 x 2)
         'hartleymha_1x4x128^3_fp32_ms_per_step': (lambda: nets.HartleyMHASeg(4, 4, 12, 16, 4, (10, 14, 14), (2, 2, 2)), (1, 4, 128, 128, 128), False),
     }
+    algo_bytes = {}
     for key, (ctor, shape, bf16) in cases.items():
         try:
-            out[key] = time_step(ctor, shape, bf16)
+            out[key], algo_bytes[key] = time_step(ctor, shape, bf16)
         except Exception as exc:   # noqa: BLE001
             out[key] = f'failed: {exc!r}'[:200]
+    # rooflines of the two other BASELINE configurations (round 5; the headline's is the top-level `roofline`):
+    # cfg3 FNOSeg is bandwidth-bound: achieved = algorithmic bytes of the step (sum over its launches, as declared to the profiler:
+    #   DESIGN section 4) / replayed step time, against the 8 TB/s HBM peak;
+    # cfg4 V-Net-DS is matrix-bound: 463 GFLOP per volume fwd + bwd (154.3 GFLOP forward [probed] x 3) / step time,
+    #   against the 2.5 PFLOP/s dense bf16 MFMA peak of MI355X_MICROARCH.md (fp32 runs: the 157 TFLOP/s fp32 matrix peak).
+    for tag, key in (('cfg3_roofline', 'cfg3_fnoseg_2x4x128^3_bf16_autocast_ms_per_step'), ('cfg3_fp32_roofline', 'cfg3_fnoseg_2x4x128^3_fp32_ms_per_step')):
+        ms, nb = out.get(key), algo_bytes.get(key)
+        if isinstance(ms, float) and nb:
+            ach = nb / (ms * 1e-3) / 1e9
+            out[tag] = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
+                        'algorithmic_bytes_per_step': nb}
+    for tag, key, peak in (('cfg4_roofline', 'cfg4_vnetds_1x4x160x192x128_bf16_autocast_ms_per_step', 2500.0),
+                           ('cfg4_fp32_roofline', 'cfg4_vnetds_1x4x160x192x128_fp32_ms_per_step', 157.0)):
+        ms = out.get(key)
+        if isinstance(ms, float):
+            ach = 0.463 / (ms * 1e-3)       # TFLOP/s
+            out[tag] = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                        'flops_per_step': 463e9}
     try:    # the reference's published metric: single-image inference at 240 x 240 x 155 incl. host copies (README.md:10: V100 < 0.24 s)
         model = nets.HNOSegXS(**MODEL_CFG).to(dev).eval()
         xh = torch.randn((1, 4, 240, 240, 155)).pin_memory()
@@ -232,18 +331,34 @@ def main():
                     help='one rank, but through the data-parallel step as N > 1 ranks run it: RCCL group of one rank, flat gradient '
                          'buffer written by the backward kernels, bucket all-reduces on the communication stream behind the graph '
                          'replay (what `secondary.dp_path_1rank_ms_per_step` reports)')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='rank plumbing only, no GPU: every rank joins a gloo group and all-reduces a flat buffer (the CPU suite runs '
+                         '`--gpus 2 --dry-run` through launch_ranks)')
+    ap.add_argument('--dry-run-fail-rank', type=int, default=-1, help='with --dry-run: this rank exits with code 3')
+    ap.add_argument('--probe-capture', action='store_true', help='internal: the throw-away child that tries an RCCL all-reduce inside a HIP graph')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.probe_capture:
+        probe_captured_allreduce_child()
     if args.gpus > 1 and world == 1 and 'RANK' not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks ourselves.  This process has not touched the GPU yet (nothing
         # above initialises HIP) and never will: the ranks are fresh child processes, this one only waits for them.
-        raise SystemExit(launch_ranks(args.gpus))
+        raise SystemExit(launch_ranks(args.gpus, dry_run=args.dry_run))
+    if args.dry_run:
+        dry_run_rank(args)
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with {args.gpus} ranks')
+    # N > 1: whether the gradient all-reduce (and with it the Adamax update) can be part of the replayed graph is TRIED, in a throw-away
+    # child of every rank, before this process touches the GPU (a captured collective that mismatches hangs; nothing can be retried in
+    # here).  HNO_DP_CAPTURE_ALLREDUCE=1 / 0 skip the probe and force / forbid the form.
+    env_cap = os.environ.get('HNO_DP_CAPTURE_ALLREDUCE', '')
+    probe_ok = None
+    if world > 1 and env_cap not in ('0', '1') and not args.no_graph:
+        probe_ok = probe_captured_allreduce()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
@@ -287,19 +402,6 @@ def main():
         pkg.ops.backward_from(loss)      # loss.backward() with a cached root gradient: autograd's ones_like fill is not part of the model
         return loss
 
-    # captured steps: the two halves of the batch as two concurrent passes on two streams of the graph (experiments.train_test.SampleSplit,
-    # as training()'s CapturedStep runs them; HNO_SPLIT_STREAMS=0: one pass over the whole batch)
-    from multimodal_3d_image_segmentation_amd.experiments.train_test import SampleSplit
-    split = SampleSplit(model) if SampleSplit.usable(model, loss_fn, x) else None
-    if split is not None:
-        with torch.no_grad():
-            model(x[:B // 2])                 # tables / kernel attributes of the half-batch shapes exist before the capture
-
-    def fwd_bwd_captured():
-        if split is None:
-            return fwd_bwd()
-        lab_u8 = pkg.ops.labels_prepare(labels, 4)
-        return split.fwd_bwd(x, lab_u8, loss_fn, zero_grad=rep.zero_grad)
 
     def eager_step():
         loss = fwd_bwd()
@@ -309,6 +411,42 @@ def main():
 
     for _ in range(max(args.warmup, 2)):   # also creates the twiddle tables / kernel attributes (not capturable)
         eager_step()
+
+    # captured steps: the two halves of the batch MAY run as two concurrent passes on two streams of the graph (experiments.train_test.
+    # SampleSplit) -- decided as training()'s CapturedStep decides it: both forms of forward + loss + backward are captured, replayed
+    # three times each, and the faster one is kept (train_test.choose_schedule; HNO_SPLIT_STREAMS=1 / 0 force the answer)
+    from multimodal_3d_image_segmentation_amd.experiments.train_test import SampleSplit, choose_schedule
+    split_mode = False if args.no_graph else SampleSplit.candidate(model, loss_fn, x)
+    split = SampleSplit(model) if split_mode else None
+    schedule_ms = None
+    if split is not None:
+        with torch.no_grad():
+            model(x[:B // 2])                 # tables / kernel attributes of the half-batch shapes exist before the capture
+
+    def fwd_bwd_split():
+        lab_u8 = pkg.ops.labels_prepare(labels, 4)
+        return split.fwd_bwd(x, lab_u8, loss_fn, zero_grad=rep.zero_grad)
+
+    if split_mode == 'measure':
+        prev_defer = pkg.ops.set_defer_reduce(True)
+        rep.set_hooks_enabled(False)
+        try:
+            use, ms_one, ms_split = choose_schedule(lambda: fwd_bwd().detach(), fwd_bwd_split,
+                                                    agree=rep.all_ranks_ok if distributed else None, what=' of bench.py')
+            schedule_ms = {'one_pass': round(ms_one, 3), 'two_streams': round(ms_split, 3)}
+        except Exception as exc:   # noqa: BLE001
+            print(f'[bench] schedule measurement failed ({exc!r}); one pass over the batch', file=sys.stderr)
+            use = False
+        pkg.ops.set_defer_reduce(prev_defer)
+        rep.set_hooks_enabled(True)
+        rep.zero_grad()
+        for q in split.tparams:
+            q.grad = None
+        if not use:
+            split = None
+
+    def fwd_bwd_captured():
+        return fwd_bwd() if split is None else fwd_bwd_split()
 
     # forward + loss + backward are captured ONCE into a HIP graph and replayed: ~120 kernel launches per step cost no host
     # time, so the GPU is never launch-bound.  Adamax stays an eager launch behind the replay.
@@ -320,7 +458,14 @@ def main():
     graph = None
     # HNO_DP_CAPTURE_ALLREDUCE=1: also capture the gradient all-reduce into the graph (measured on one rank only; the default keeps it an
     # eager launch behind the replay because a capture of RCCL collectives across several GPUs could not be tested from here)
-    capture_allreduce = distributed and os.environ.get('HNO_DP_CAPTURE_ALLREDUCE', '0') == '1'
+    # N > 1 (round 5): the one-replay form when the probe above succeeded on EVERY rank (rep.all_ranks_ok: a MIN all-reduce of the
+    # flags), else the eager collective behind the replay; --dp-path on one rank keeps the measured default (eager) unless asked
+    if env_cap in ('0', '1'):
+        capture_allreduce = distributed and env_cap == '1'
+    elif world > 1:
+        capture_allreduce = bool(rep.all_ranks_ok(bool(probe_ok)))
+    else:
+        capture_allreduce = False
     # round 4: Adamax with its step counter / learning rate on the device (optim.Adamax.device_stepped): the update has no per-step host
     # argument and is captured behind backward -- a step is ONE graph replay.  With replicas it has to follow the all-reduce, so it is
     # part of the graph only when the collective is (HNO_DP_CAPTURE_ALLREDUCE=1); otherwise it stays one eager launch behind it.
@@ -435,6 +580,12 @@ def main():
                                   + (' + Adamax inside the graph (device-side step counter): one replay per step' if opt_in_graph else ' + eager Adamax')) if graph is not None else
                                  ('eager; gradient buckets all-reduced from backward hooks on a comm stream' if distributed else 'eager'),
                        'grad_buckets': len(rep.buckets) if distributed else 0,
+                       # ranks the process group really has (the driver can check that N ranks were seen) and how the collective form was chosen
+                       'rccl_ranks': dist.get_world_size() if distributed else 1,
+                       'allreduce_in_graph': bool(capture_allreduce),
+                       'allreduce_in_graph_chosen_by': ('env HNO_DP_CAPTURE_ALLREDUCE' if env_cap in ('0', '1') else
+                                                        (f'probe on every rank (this rank: {probe_ok})' if world > 1 else 'n/a')),
+                       'schedule_measured_ms': schedule_ms,
                        'dp_path_on_one_rank': bool(args.dp_path and world == 1),
                        'host_us_per_step': None if host_us_per_step is None else round(host_us_per_step, 1),
                        # the captured step's schedule: the batch's two halves as concurrent passes on two streams of the graph

@@ -507,6 +507,13 @@ int hno_adamax_multi(const void *table, int n_chunks, float lr, float beta1, flo
 int hno_adamax_state_doubles(void);
 int hno_adamax_multi_dev(const void *table, int n_chunks, void *state, float beta1, float beta2, float eps, float weight_decay,
                          float grad_scale, void *stream);
+/* Join of two tensor sets (round 5): dst[i] = scale[i] * (a[i] + b[i]) elementwise for `count` fp32 tensors of n[i] elements; dst, a, b,
+ * n, scale are HOST arrays (device pointers / sizes), dst[i] may alias a[i] or b[i].  One launch per 64 tensors, entries passed by value
+ * in the kernel arguments: capturable into a HIP graph without a device table.  Replaces the torch._foreach_add_ / torch.lerp pair that
+ * joined the two half-batch passes of a captured training step (experiments/train_test.py SampleSplit; no reference counterpart: the
+ * reference runs the batch as one pass, train_test.py:154-170). */
+int hno_sum_pairs(void *const *dst, const void *const *a, const void *const *b, const long long *n, const float *scale, int count,
+                  void *stream);
 
 /* ------------------------------------------------------------------ input pipeline
  * hno_zscore_modalities: x, out (C, V): per modality c, v = clip(x) if has_clip; statistics over v != mask_val if
@@ -554,6 +561,10 @@ int hno_debug_stamps(long long *out, int n);
  * 0 none yet, 1 generic (a workgroup per plane), 2 the round-2 specialised kernels, 3 the LDS-DMA forward / half-plane item inverse
  * kernels.  The GPU tests pin the families of the benchmark shapes (a dropped instantiation falls back silently). */
 int hno_debug_last_plane_family(int inverse);
+/* test aid: weight-gradient slab reductions launched by this process so far -- batched = 0: one launch per slab set
+ * (reduce_partials_kernel), 1: batched end-of-backward launches (reduce_partials_multi_kernel).  The GPU tests pin the launch count of a
+ * captured training step with it (round 4's two-stream schedule silently fell back to 17 single launches per pass). */
+long long hno_debug_reduce_launches(int batched);
 
 /* ------------------------------------------------------------------------ self tests
  * C(MxN) = A(MxK) B(KxN) through the wave-level MFMA tile engine every kernel uses. */

@@ -41,7 +41,7 @@ enum KernelId {
     KID_DHT_FWD_PLANE = 0, KID_DHT_FWD_D, KID_DHT_INV_D, KID_DHT_INV_PLANE, KID_PWCONV_FWD, KID_PWCONV_BWD,
     KID_CONV_K2S2_FWD, KID_CONV_K2S2_BWD, KID_UPSOFTMAX_FWD, KID_UPSOFTMAX_BWD, KID_LOSS_STATS, KID_LOSS_FINALIZE,
     KID_LOSS_BWD, KID_LABELS, KID_SPECMIX_FWD, KID_SPECMIX_BWD, KID_REDUCE_PARTIALS, KID_UPSOFTMAX_BWD_D, KID_BMM, KID_PERMODE_FWD, KID_PERMODE_BWD, KID_CONV3D_GEMM,
-    KID_CONV3D_WGRAD, KID_GROUPNORM, KID_RESAMPLE, KID_CB_CONV, KID_CB_WGRAD, KID_CB_GN, KID_HMHA, KID_COUNT
+    KID_CONV3D_WGRAD, KID_GROUPNORM, KID_RESAMPLE, KID_CB_CONV, KID_CB_WGRAD, KID_CB_GN, KID_HMHA, KID_SPEC_MID_FWD, KID_SPEC_MID_BWD, KID_COUNT
 };
 struct ProfScope {
     int slot;
@@ -56,13 +56,6 @@ struct ProfScope {
 // same-address atomic contention that made the first version of these kernels 10x slower.
 int reduce_partials_launch(const float *partials, int nblocks, int n, float *dst0, int n0, float *dst1,
                            hipStream_t stream, int cols = 0, int ldd = 0, bool allow_defer = true);   // allow_defer = false: callers that reuse the slab workspace for several rounds   // cols/ldd: dst0 is a sub-block with row stride ldd
-// record lists of other translation units behind hno_set_defer_reduce / hno_flush_reduces (hno_core.hip)
-struct DeferredFamily {
-    int (*pending)();
-    int (*discard)();
-    int (*flush)(hipStream_t);
-};
-void register_deferred_family(const DeferredFamily &f);
 bool defer_reduce_enabled();
 
 // wave-private accumulator fragments -> one slab per block.  `scratch` is >= nwaves * n floats of LDS.
@@ -92,6 +85,11 @@ int clear_doubles(double *p, int n, hipStream_t s);
 
 // debug/ablation switches (hno_set_debug): timing-only builds of a kernel phase, results are WRONG
 int debug_flags();
+// bits 8..23 of the debug flags: a forced grid size for the launchers that have one (tuning sweeps); switches of other kernels live
+// above bit 23 (the attention A/B switches sat at bits 14 / 15 and silently forced 64 / 128-workgroup grids elsewhere)
+inline int debug_grid() { return (debug_flags() >> 8) & 0xFFFF; }
+#define HNO_DBG_HM_ROUND2 (1 << 24)   // attention: the round-2 kernels instead of the shared-tile ones (A/B)
+#define HNO_DBG_HM_PAIR (1 << 25)     // attention: the pair layout of the streamed tile even when T % 4 == 0 (A/B)
 // the calling thread's current HIP device (-2 on error): kernel attributes are set once per device, not once per process
 int current_device();
 

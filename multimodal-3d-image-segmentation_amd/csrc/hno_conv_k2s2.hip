@@ -682,7 +682,7 @@ extern "C" int hno_conv_k2s2_fwd(const float *x, const float *W, const float *bi
         return fail(HNO_ELIMIT, "hno_conv_k2s2_fwd: image of %d x %d x %d x %d exceeds the 32-bit offset range", Cin, D, H, Wd);
     long long grid = (ntiles + 3) / 4;
     if (grid > 1024) grid = 1024;   // four 4-wave workgroups per CU (measured: 256 -> 56 us, 512 -> 44, 1024 -> 40)
-    if (debug_flags() >> 8) grid = debug_flags() >> 8;
+    if (debug_grid()) grid = debug_grid();
     {
         ProfScope _ps(KID_CONV_K2S2_FWD, (hipStream_t)stream, 4.0 * B * ((double)Cin * D * H * Wd + (double)Cout * a.Do * a.Ho * a.Wo));
         if (Cin <= 4) hipLaunchKernelGGL(conv_k2s2_fwd_kernel<16>, dim3((int)grid), dim3(256), 4 * 2 * 16 * 256, (hipStream_t)stream, a);
@@ -716,7 +716,7 @@ extern "C" int hno_conv_k2s2_bwd(const float *gy, const float *y, const float *x
         return fail(HNO_ELIMIT, "hno_conv_k2s2_bwd: image of %d x %d x %d x %d exceeds the 32-bit offset range", Cin, D, H, Wd);
     long long grid = (ntiles + 3) / 4;
     if (grid > 512) grid = 512;     // two workgroups per CU (measured: 256 -> 79 us, 512 -> 61, 1024 -> 68 incl. the slab reduce)
-    if (debug_flags() >> 8) grid = debug_flags() >> 8;
+    if (debug_grid()) grid = debug_grid();
     const int kch = Cin * 8 <= 32 ? 1 : 2;
     const size_t lds = sizeof(float) * 4 * (32 * K2_LD + 2 * kch * 16 * K2_XP);
     hipStream_t s = (hipStream_t)stream;
@@ -767,7 +767,7 @@ extern "C" int hno_conv_k2s2_chain_fwd(const float *x, const float *W, const flo
     long long grid = (ntiles + 3) / 4;
     const long long cap = fixed ? 1024 : 768;      // 120 / 164 registers: four / three 4-wave workgroups per CU are resident
     if (grid > cap) grid = cap;
-    if (debug_flags() >> 8) grid = debug_flags() >> 8;
+    if (debug_grid()) grid = debug_grid();
     ProfScope _ps(KID_CONV_K2S2_FWD, (hipStream_t)stream, 4.0 * B * ((double)Cin * D * H * Wd + (double)C1 * a.Do * a.Ho * a.Wo));
     if (fixed)
         hipLaunchKernelGGL((conv_k2s2_fwd_kernel<16, true, true>), dim3((int)grid), dim3(256), 4 * 2 * 16 * 256, (hipStream_t)stream, a);
@@ -798,7 +798,7 @@ extern "C" int hno_conv_k2s2_chain_bwd(const float *gy1, const float *y1, const 
         return fail(HNO_ELIMIT, "hno_conv_k2s2_chain_bwd: image of %d x %d x %d x %d exceeds the 32-bit offset range", Cin, D, H, Wd);
     long long grid = (ntiles + 3) / 4;
     if (grid > K2_CHAIN_SLABS) grid = K2_CHAIN_SLABS;     // two workgroups per CU
-    if ((debug_flags() >> 8) && (debug_flags() >> 8) <= K2_CHAIN_SLABS) grid = debug_flags() >> 8;
+    if ((debug_grid()) && (debug_grid()) <= K2_CHAIN_SLABS) grid = debug_grid();
     const size_t lds = sizeof(float) * 4 * (2 * 32 * K2_LD + 2 * 16 * K2_XP);
     hipStream_t s = (hipStream_t)stream;
     {

@@ -95,7 +95,7 @@ static const char *kKernelNames[KID_COUNT] = {
     "pwconv_bwd_kernel", "conv_k2s2_fwd_kernel", "conv_k2s2_bwd_kernel", "upsoftmax_fwd_kernel", "upsoftmax_bwd_kernel",
     "loss_stats_kernel", "loss_finalize_kernel", "loss_bwd_kernel", "labels_kernel", "specmix_fwd_kernel", "specmix_bwd_kernel", "reduce_partials_kernel", "upsoftmax_bwd_d_kernel", "bmm_kernel", "permode_fwd_kernel", "permode_bwd_kernels",
     "conv3d_gemm_kernel", "conv3d_wgrad_kernels", "groupnorm_kernels", "resample_kernels", "cb_conv_bf16_kernel", "cb_wgrad_bf16_kernel",
-    "cb_groupnorm_bf16_kernels", "hmha_kernel"};
+    "cb_groupnorm_bf16_kernels", "hmha_kernel", "spec_mid_fwd_kernel", "spec_mid_bwd_kernel"};
 static bool g_prof_on = false;
 static std::vector<hipEvent_t> g_prof_events;  // 2 per record
 static std::vector<int> g_prof_ids;
@@ -172,6 +172,7 @@ struct ReduceBatch {
     int count;
 };
 static bool g_defer_reduce = false;
+static long long g_reduce_launches[2] = {0, 0};   // [0] single-slab-set launches, [1] batched launches (hno_debug_reduce_launches)
 static std::vector<ReduceEntry> g_deferred;
 
 __global__ __launch_bounds__(1024) void reduce_partials_multi_kernel(ReduceBatch b) {
@@ -232,6 +233,7 @@ int flush_reduces(hipStream_t stream) {
         }
         ProfScope ps(KID_REDUCE_PARTIALS, stream);
         hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(blocks), dim3(1024), 0, stream, b);
+        ++g_reduce_launches[1];
     }
     g_deferred.clear();
     HNO_CHECK_LAUNCH();
@@ -248,6 +250,7 @@ int reduce_partials_launch(const float *partials, int nblocks, int n, float *dst
     ProfScope ps(KID_REDUCE_PARTIALS, stream, 4.0 * n * ((double)nblocks + 1));
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(n, 64)), dim3(1024), 0, stream, partials, nblocks, n, dst0,
                        n0, dst1, cols, ldd);
+    ++g_reduce_launches[0];
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }
@@ -280,35 +283,21 @@ extern "C" int hno_set_defer_reduce(int on) {
     g_defer_reduce = on != 0;
     return was;
 }
-// other translation units (the bf16 convolution path's weight-gradient and GroupNorm reductions) keep their own record lists and
-// hook them in here: hno_pending_reduces / hno_discard_reduces / hno_flush_reduces cover every family
-static std::vector<DeferredFamily> &deferred_families() {
-    static std::vector<DeferredFamily> v;
-    return v;
-}
 namespace hno {
-void register_deferred_family(const DeferredFamily &f) { deferred_families().push_back(f); }
 bool defer_reduce_enabled() { return g_defer_reduce; }
 }  // namespace hno
 
+extern "C" long long hno_debug_reduce_launches(int batched) { return g_reduce_launches[batched ? 1 : 0]; }
 extern "C" int hno_pending_reduces(void) {
-    int n = (int)g_deferred.size();
-    for (const DeferredFamily &f : deferred_families()) n += f.pending();
-    return n;
+    return (int)g_deferred.size();
 }
 extern "C" int hno_discard_reduces(void) {   // forget recorded reductions (a backward pass that was aborted by an exception)
     int n = (int)g_deferred.size();
     g_deferred.clear();
-    for (const DeferredFamily &f : deferred_families()) n += f.discard();
     return n;
 }
 extern "C" int hno_flush_reduces(void *stream) {
-    int rc = flush_reduces((hipStream_t)stream);
-    for (const DeferredFamily &f : deferred_families()) {
-        const int r = f.flush((hipStream_t)stream);
-        if (rc == HNO_OK) rc = r;
-    }
-    return rc;
+    return flush_reduces((hipStream_t)stream);
 }
 extern "C" const char *hno_last_error(void) { return g_last_error.c_str(); }
 

@@ -987,7 +987,7 @@ extern "C" int hno_upsoftmax_fwd_ld(const float *logits_lr, float *probs, int B,
     } else if (items < (1ll << 31) && (long long)d * h * w < (1ll << 31) && !(debug_flags() & 16)) {
         long long grid = (items + 3) / 4;
         if (grid > 8192) grid = 8192;
-        if (debug_flags() >> 8) grid = debug_flags() >> 8;
+        if (debug_grid()) grid = debug_grid();
         if (K <= 4) hipLaunchKernelGGL((uphead_seg_kernel<4, false>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a, nullptr);
         else hipLaunchKernelGGL((uphead_seg_kernel<8, false>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a, nullptr);
     } else {
@@ -1066,7 +1066,7 @@ extern "C" int hno_up_argmax_ld(const float *logits_lr, unsigned char *labels, i
     if (items < (1ll << 31) && (long long)d * h * w < (1ll << 31) && !(debug_flags() & 16)) {
         long long grid = (items + 3) / 4;
         if (grid > 8192) grid = 8192;
-        if (debug_flags() >> 8) grid = debug_flags() >> 8;
+        if (debug_grid()) grid = debug_grid();
         if (K <= 4) hipLaunchKernelGGL((uphead_seg_kernel<4, true>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a, labels);
         else hipLaunchKernelGGL((uphead_seg_kernel<8, true>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a, labels);
     } else {
@@ -1123,7 +1123,7 @@ static int upsoftmax_bwd_impl(const float *g_probs, const float *probs, float *g
         const int planes = B * D;
         int nsplit = (1024 + planes - 1) / planes;
         if (nsplit > h / 8) nsplit = h / 8;
-        if (debug_flags() >> 8) nsplit = debug_flags() >> 8;
+        if (debug_grid()) nsplit = debug_grid();
         if (nsplit < 1) nsplit = 1;
         u.nsplit = nsplit;
         const size_t lds = sizeof(float) * 2 * UPB_ROWS * (size_t)K * W;
@@ -1197,7 +1197,7 @@ extern "C" int hno_loss_fwd(const float *probs, const uint8_t *labels, double *s
     if (V % 4 == 0 && ((size_t)labels & 3) == 0 && ((size_t)probs & 15) == 0 && !(debug_flags() & 16)) {
         long long gq = (V / 4 + 255) / 256;
         if (gq > 256) gq = 256;   // measured (stats + finalize): 128 -> 37 us, 256 -> 29, 512 -> 32, 2048 -> 67 (atomic contention)
-        if (debug_flags() >> 8) gq = debug_flags() >> 8;
+        if (debug_grid()) gq = debug_grid();
         ProfScope _ps(KID_LOSS_STATS, s, (double)B * V * (4.0 * K + 1));
         if (K <= 4) hipLaunchKernelGGL(loss_stats_vec_kernel<4>, dim3((int)gq, B), dim3(256), 0, s, probs, labels, stats, K, V);
         else hipLaunchKernelGGL(loss_stats_vec_kernel<8>, dim3((int)gq, B), dim3(256), 0, s, probs, labels, stats, K, V);

@@ -456,7 +456,7 @@ static int hm2_nsplit(int BZ, int T) {
 
 template <int MODE, int CKT, int CVT>
 static int hm2_launch(const HmArgs &a, float *workspace, hipStream_t s) {
-    if (a.T % 4 == 0 && a.T >= 4 && !(debug_flags() & 32768)) return hm2_launch_x<MODE, CKT, CVT, true>(a, workspace, s);
+    if (a.T % 4 == 0 && a.T >= 4 && !(debug_flags() & HNO_DBG_HM_PAIR)) return hm2_launch_x<MODE, CKT, CVT, true>(a, workspace, s);
     return hm2_launch_x<MODE, CKT, CVT, false>(a, workspace, s);
 }
 
@@ -507,7 +507,7 @@ static int hm_launch(const HmArgs &a, hipStream_t s) {
 template <int MODE>
 static int hm_dispatch(const HmArgs &a, hipStream_t s, float *workspace = nullptr) {
     const int kt = (a.Ck + 31) / 32, vt = (a.Cv + 31) / 32;
-    if (workspace && !(debug_flags() & 16384) && (a.act == HNO_ACT_NONE || a.act == HNO_ACT_SELU || a.act == HNO_ACT_ELU)) {      // shared-tile kernels (round 4); debug flag 16384: the round-2 kernels (A/B)
+    if (workspace && !(debug_flags() & HNO_DBG_HM_ROUND2) && (a.act == HNO_ACT_NONE || a.act == HNO_ACT_SELU || a.act == HNO_ACT_ELU)) {      // shared-tile kernels (round 4); debug flag HNO_DBG_HM_ROUND2 (1 << 24): the round-2 kernels (A/B)
         if (kt == 1 && vt == 1) return hm2_launch<MODE, 1, 1>(a, workspace, s);
         if (kt <= 2 && vt <= 2) return hm2_launch<MODE, 2, 2>(a, workspace, s);
         if (kt == 3 && vt == 3) return hm2_launch<MODE, 3, 3>(a, workspace, s);
@@ -574,7 +574,7 @@ extern "C" int hno_hmha_bwd(const float *q, const float *k, const float *v, cons
 extern "C" int hno_hmha_nsplit(int BZ, int T) { return BZ > 0 && T > 0 ? hm2_nsplit(BZ, T) : 0; }
 
 extern "C" int hno_hmha_parts_supported(int Ck, int Cv, int act) {
-    return hno_hmha_supported(Ck, Cv) && (act == HNO_ACT_NONE || act == HNO_ACT_SELU || act == HNO_ACT_ELU) && !(debug_flags() & 16384);
+    return hno_hmha_supported(Ck, Cv) && (act == HNO_ACT_NONE || act == HNO_ACT_SELU || act == HNO_ACT_ELU) && !(debug_flags() & HNO_DBG_HM_ROUND2);
 }
 
 extern "C" int hno_hmha_fwd_parts(const float *q, const float *k, const float *v, float *out_parts, int BZ, int Ck, int Cv, int T, float alpha,

@@ -89,6 +89,36 @@ __global__ __launch_bounds__(256) void adamax_multi_dev_kernel(const AdamaxChunk
     }
 }
 
+
+// ---- the join of two gradient sets (round 5): dst_i = scale_i * (a_i + b_i) for up to 64 tensors per launch -----------------------
+// A captured step that runs the two halves of its batch as two passes (experiments.train_test.SampleSplit) ends with the halves'
+// gradients in two tensor sets and two loss scalars.  torch._foreach_add_ + torch.lerp did the join in round 4: two ATen launches in a
+// step that otherwise consists of libhno kernels only.  The tensors' addresses are known only while the step is being captured (nothing
+// may be allocated there), so the entries travel BY VALUE in the kernel arguments (2 KB for 64 entries) and become part of the graph node.
+#define HNO_MAX_PAIRS 64
+struct PairEntry {
+    float *dst;
+    const float *a, *b;
+    int n, first_block;
+    float scale;
+    int pad_;
+};
+struct PairBatch {
+    PairEntry e[HNO_MAX_PAIRS];
+    int count;
+};
+__global__ __launch_bounds__(256) void sum_pairs_kernel(PairBatch pb) {
+    int ei = 0;
+    while (ei + 1 < pb.count && (int)blockIdx.x >= pb.e[ei + 1].first_block) ++ei;   // block-uniform search
+    const PairEntry &e = pb.e[ei];
+    const int i0 = ((int)blockIdx.x - e.first_block) * 1024 + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = i0 + 256 * j;
+        if (i < e.n) e.dst[i] = e.scale * (e.a[i] + e.b[i]);
+    }
+}
+
 }  // namespace hno
 
 using namespace hno;
@@ -118,6 +148,32 @@ extern "C" int hno_adamax_multi(const void *table, int n_chunks, float lr, float
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(adamax_multi_kernel, dim3(n_chunks), dim3(256), 0, s, (const AdamaxChunk *)table, clr, beta1, beta2, eps,
                        weight_decay, grad_scale);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+// dst[i] = scale[i] * (a[i] + b[i]) elementwise for `count` fp32 tensors of n[i] elements (HOST arrays of device pointers / sizes);
+// dst may alias a or b.  One launch per 64 tensors; capturable (no device table: the entries are kernel arguments).
+extern "C" int hno_sum_pairs(void *const *dst, const void *const *a, const void *const *b, const long long *n, const float *scale,
+                             int count, void *stream) {
+    HNO_REQUIRE(dst && a && b && n && scale && count > 0, "hno_sum_pairs: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    int i = 0;
+    while (i < count) {
+        PairBatch pb;
+        pb.count = 0;
+        int blocks = 0;
+        while (i < count && pb.count < HNO_MAX_PAIRS) {
+            HNO_REQUIRE(dst[i] && a[i] && b[i] && n[i] >= 0 && n[i] < (1ll << 31) - 1024, "hno_sum_pairs: bad entry");
+            if (n[i] == 0) { ++i; continue; }
+            PairEntry e{(float *)dst[i], (const float *)a[i], (const float *)b[i], (int)n[i], blocks, scale[i], 0};
+            blocks += ceil_div((int)n[i], 1024);
+            pb.e[pb.count++] = e;
+            ++i;
+        }
+        if (pb.count == 0) break;
+        hipLaunchKernelGGL(sum_pairs_kernel, dim3(blocks), dim3(256), 0, s, pb);
+    }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }

@@ -1785,7 +1785,7 @@ extern "C" int hno_pwconv_fwd_branch(const float *s_in, const float *x, const fl
     const long long ntiles = ((V + 31) / 32) * B;
     long long grid = (ntiles + PWF_DMA_WAVES - 1) / PWF_DMA_WAVES;
     if (grid > 512) grid = 512;   // two 4-wave blocks per CU (each wave one tile ahead through its LDS ring; 256: 62 us, 512: 57)
-    if (debug_flags() >> 8) grid = debug_flags() >> 8;
+    if (debug_grid()) grid = debug_grid();
     hipStream_t fs = (hipStream_t)stream;
     ProfScope ps(KID_PWCONV_FWD, fs, 4.0 * B * (double)V * (2 * Ca + Cb + Cout));
     const size_t fl = (size_t)PWF_DMA_WAVES * 2 * (12 + 12) * 256;
@@ -1817,7 +1817,7 @@ extern "C" int hno_pwconv_fwd_chain(const float *u, const float *t, const float 
     long long grid = (ntiles + nw - 1) / nw;
     const long long cap = nw == 4 ? 512 : 256;
     if (grid > cap) grid = cap;
-    if (debug_flags() >> 8) grid = debug_flags() >> 8;
+    if (debug_grid()) grid = debug_grid();
     hipStream_t fs = (hipStream_t)stream;
     ProfScope ps(KID_PWCONV_FWD, fs, 4.0 * B * (double)V * ((k ? 4 : 3) * C + C2));
     const size_t fl = (size_t)nw * 2 * (k ? 36 : 24) * 256;

@@ -841,7 +841,7 @@ extern "C" int hno_spec_mid_fwd(void *workspace, const float *const *W_layers, f
     const dim3 grid(8 * G8);
     const size_t lds = sizeof(float) * mid_lds_floats(m0, 0, false);
     {
-        ProfScope _ps(KID_SPECMIX_FWD, s, 4.0 * B * C * (2.0 * N0 * 2 * (2 * m1 + 1) * 16 + (L + 1) * 8.0 * m0 * m1 * m2));
+        ProfScope _ps(KID_SPEC_MID_FWD, s, 4.0 * B * C * (2.0 * N0 * 2 * (2 * m1 + 1) * 16 + (L + 1) * 8.0 * m0 * m1 * m2));
 #define X(n) if (N0 == n) hipLaunchKernelGGL((spec_mid_kernel<n, 10, false>), grid, dim3(64 * MID_NW), lds, s, a);
         HNO_MID_N0_LIST(X)
 #undef X
@@ -889,7 +889,7 @@ extern "C" int hno_spec_mid_bwd(void *workspace, const float *const *W_layers, c
 #undef X
     }
     {
-        ProfScope _ps(KID_SPECMIX_BWD, s, 4.0 * B * C * (2.0 * N0 * 2 * (2 * m1 + 1) * 16 + (L + 1) * 8.0 * m0 * m1 * m2));
+        ProfScope _ps(KID_SPEC_MID_BWD, s, 4.0 * B * C * (2.0 * N0 * 2 * (2 * m1 + 1) * 16 + (L + 1) * 8.0 * m0 * m1 * m2));
 #define X(n) if (N0 == n) hipLaunchKernelGGL((spec_mid_kernel<n, 10, true>), dim3(nwg), dim3(64 * MID_NW), lds, s, a);
         HNO_MID_N0_LIST(X)
 #undef X
@@ -940,7 +940,7 @@ static int mid_fourier_launch(bool bwd, void *workspace, const float *W2, float 
 #undef X
     }
     {
-        ProfScope _ps(bwd ? KID_SPECMIX_BWD : KID_SPECMIX_FWD, s, 4.0 * B * C * (2.0 * N0 * 2 * (2 * m1 + 1) * 16 + 2 * 8.0 * m0 * m1 * m2));
+        ProfScope _ps(bwd ? KID_SPEC_MID_BWD : KID_SPEC_MID_FWD, s, 4.0 * B * C * (2.0 * N0 * 2 * (2 * m1 + 1) * 16 + 2 * 8.0 * m0 * m1 * m2));
 #define X(n)                                                                                                                \
     if (N0 == n && bwd) hipLaunchKernelGGL((spec_mid_fourier_kernel<n, 10, true>), dim3(nwg), dim3(512), lds, s, a);          \
     else if (N0 == n) hipLaunchKernelGGL((spec_mid_fourier_kernel<n, 10, false>), dim3(nwg), dim3(512), lds, s, a);

@@ -11,6 +11,7 @@ Out of scope: torchview graph rendering, matplotlib plots.
 import contextlib
 import os
 import re
+import sys
 import time
 from os.path import join
 
@@ -23,6 +24,7 @@ from .utils import labels_to_u8, save_model_summary
 
 
 step_stats = {'replayed': 0, 'eager': 0}     # training steps by launch form (read by the tests)
+last_run = {}                                # what the last training() call did: device-stepped optimizer, measured schedules (tests, logs)
 
 
 class SampleSplit:
@@ -34,14 +36,20 @@ class SampleSplit:
     reductions: ~0.4 ms of the 2.4 ms HNOSeg-XS step keep three quarters of the chip idle) execute under the bandwidth-bound kernels of
     the other: 2.41 -> 2.32 ms measured with two independent models (tools/dbg/two_stream.py, DESIGN lesson 57).
     The second half runs through a TWIN of the model -- a deep copy whose parameters and buffers alias the model's storage, so it always
-    computes with the current weights but collects its gradients in its own ``.grad`` tensors; one multi-tensor add joins them.
-    Only used inside captured steps (CapturedStep / bench.py); eager steps run the whole batch as before.  Model classes opt in
-    (``hno_sample_split``: HNOSegXS); HNO_SPLIT_STREAMS=1 / 0 forces it on / off for every model."""
+    computes with the current weights but collects its gradients in its own ``.grad`` tensors; ONE libhno launch (ops.sum_pairs) joins
+    the gradient sets and averages the two losses.
+    Only used inside captured steps (CapturedStep / bench.py); eager steps run the whole batch as before.  Whether a captured step takes
+    this schedule is MEASURED when the step is captured (``choose_schedule``: both forms are captured, replayed three times each, the
+    faster one is kept) for model classes that name themselves candidates (``hno_sample_split = 'measure'``: HNOSegXS);
+    HNO_SPLIT_STREAMS=1 / 0 forces it on / off for every model.  Build it OUTSIDE the capture (its deep copy and constants are not part
+    of the step)."""
 
     _streams = {}
 
     def __init__(self, model):
         import copy
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('build a SampleSplit before the capture: its copies would become nodes of the graph')
         self.model = model
         # tensor hooks stay with the model (a data-parallel replica's post-accumulate hooks would be deep-copied together with the
         # replica they point to, and the twin's backward would then launch that copy's bucket all-reduces)
@@ -62,6 +70,7 @@ class SampleSplit:
                     p._backward_hooks = back
         for p, q in zip(model.parameters(), self.twin.parameters()):
             q.data = p.data
+            q.grad = None
         for a, b in zip(model.buffers(), self.twin.buffers()):
             b.data = a.data
         self.twin.train(model.training)
@@ -69,6 +78,7 @@ class SampleSplit:
         self.tparams = [q for q in self.twin.parameters() if q.requires_grad]
         dev = self.params[0].device
         self.half = torch.full((), 0.5, device=dev, dtype=torch.float32)
+        self.outputs = None
         # one pair of streams per device for every split of the process: the gradient-accumulation nodes autograd keeps per parameter
         # remember the stream they were created on, and a node that outlives one capture must not name a stream the next capture does
         # not know (a stream outside the capture being waited on inside it ends the capture with a crash)
@@ -76,42 +86,50 @@ class SampleSplit:
         if key not in SampleSplit._streams:
             SampleSplit._streams[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
         self.streams = SampleSplit._streams[key]
+        torch.cuda.synchronize(dev)
 
     @staticmethod
-    def usable(model, loss_fn, x):
-        # measured per model family AND batch shape: HNOSeg-XS at 2 x 4 x 128^3 gains 3-6 % (its latency-bound fused middles hide under the
-        # other half's bandwidth-bound kernels); the same model at 80^3 ... 120^3 and 144^3 / 160^3 LOSES 2-10 %, FNOSeg loses 1 % -- so a
-        # model class opts in with the (batch, D, H, W) shapes it was measured to gain at (``hno_sample_split``: a collection of such tuples,
-        # or True for every shape); HNO_SPLIT_STREAMS=1 / 0 forces it on / off
+    def candidate(model, loss_fn, x):
+        """-> False, 'force' or 'measure'.  The schedule is possible for an even batch of independent samples under a loss that is a mean
+        over (sample, class); it is WANTED when HNO_SPLIT_STREAMS=1 ('force'), or when the model class names itself a candidate
+        (``hno_sample_split``: True = 'force', 'measure' = let choose_schedule() time both forms of the step at capture time).  Round 4
+        carried a list of shapes measured by hand (HNOSeg-XS gains 3-6 % at 2 x 4 x 128^3 and loses 2-10 % at 80^3 ... 160^3; FNOSeg loses
+        1 %): a constant in model code, replaced by the measurement."""
         env = os.environ.get('HNO_SPLIT_STREAMS', '')
         if env == '0':
             return False
-        if env != '1':
-            spec = getattr(model, 'hno_sample_split', False)
-            if not spec:
-                return False
-            if spec is not True and not (torch.is_tensor(x) and (int(x.shape[0]),) + tuple(int(v) for v in x.shape[2:]) in spec):
-                return False
+        spec = 'force' if env == '1' else getattr(model, 'hno_sample_split', False)
+        if spec is True:
+            spec = 'force'
+        if spec not in ('force', 'measure'):
+            return False
         if not (torch.is_tensor(x) and x.is_cuda) or x.shape[0] < 2 or x.shape[0] % 2:
             return False
         if getattr(loss_fn, 'hno_loss_spec', None) is None:      # a mean over (sample, class): halves average exactly
             return False
         norm = (torch.nn.modules.batchnorm._BatchNorm,)
-        return not any(isinstance(m, norm) for m in model.modules()) and all(p.is_cuda for p in model.parameters())
+        if any(isinstance(m, norm) for m in model.modules()) or not all(p.is_cuda for p in model.parameters()):
+            return False
+        return spec
+
+    @staticmethod
+    def usable(model, loss_fn, x):
+        return bool(SampleSplit.candidate(model, loss_fn, x))
 
     def aliased(self):
         """the twin still shares the model's storage (a model moved or re-materialised after the split was built does not)"""
         return all(p.data_ptr() == q.data_ptr() for p, q in zip(self.model.parameters(), self.twin.parameters()))
 
-    def fwd_bwd(self, x, lab_u8, loss_fn, zero_grad=None, autocast=None):
+    def fwd_bwd(self, x, lab_u8, loss_fn, zero_grad=None, autocast=None, keep_outputs=False):
         """enqueue both halves (call with the capturing stream current) -> the batch loss; model parameters' .grad = full gradients.
         Only inside a stream capture (there every tensor of the step lives in the graph's private pool until the capture ends): eager, the
-        two passes are launch-bound and gain nothing, and the caching allocator's per-stream reuse would need record_stream bookkeeping."""
+        two passes are launch-bound and gain nothing, and the caching allocator's per-stream reuse would need record_stream bookkeeping.
+        keep_outputs: leave the halves' (detached) model outputs in ``self.outputs`` (tests read them after a replay)."""
         if not torch.cuda.is_current_stream_capturing():
             raise RuntimeError('SampleSplit.fwd_bwd is for captured steps only (CapturedStep / bench.py)')
         cur = torch.cuda.current_stream()
         h = x.shape[0] // 2
-        losses = []
+        losses, outs = [], []
         for m, s, sl in ((self.model, self.streams[0], slice(0, h)), (self.twin, self.streams[1], slice(h, x.shape[0]))):
             s.wait_stream(cur)
             with torch.cuda.stream(s), (autocast() if autocast is not None else contextlib.nullcontext()):
@@ -119,6 +137,10 @@ class SampleSplit:
                 with ops.expected_loss(lb, loss_fn):
                     y = m(xb)
                 losses.append(loss_fn(y, lb))
+                if keep_outputs:
+                    outs.append(y.detach())
+                del y
+        self.outputs = outs if keep_outputs else None
         if zero_grad is not None:
             zero_grad()
         else:
@@ -136,13 +158,53 @@ class SampleSplit:
         for p, q in pairs:
             if p.grad is None:
                 p.grad = q.grad
-        both = [(p.grad, q.grad) for p, q in pairs if p.grad is not q.grad]
-        if both:
-            torch._foreach_add_([a for a, _ in both], [b for _, b in both])
         # (detached: a loss that keeps its autograd graph alive keeps the halves' accumulation nodes alive across captures)
-        l0, l1 = losses[0].detach(), losses[1].detach()
+        l0, l1 = losses[0].detach().float().contiguous(), losses[1].detach().float().contiguous()
         del losses
-        return torch.lerp(l0, l1, 0.5)          # the mean of the halves' losses in one launch (two scalar kernels sat on the step's tail)
+        loss = torch.empty_like(l0)
+        # the join: every gradient of the model += its twin's, loss = (l0 + l1) / 2 -- ONE libhno launch (round 4: torch._foreach_add_ +
+        # torch.lerp, the only two ATen kernels of the step)
+        ops.sum_pairs([(p.grad, p.grad, q.grad, 1.0) for p, q in pairs if p.grad is not q.grad] + [(loss, l0, l1, 0.5)])
+        return loss
+
+
+def choose_schedule(run_one, run_split, replays=3, agree=None, what=''):
+    """Measure, do not guess: capture the step's forward + loss + backward in both forms -- one pass over the batch (``run_one()``) and
+    the two half-batches on two streams (``run_split()``) -- into two temporary graphs, replay each once untimed and ``replays`` times
+    timed (HIP events), free them, and return (use_split, ms_one, ms_split).  Nothing but forward / loss / backward may be in the
+    closures (no optimizer, no collective: the replays must not change any state but gradients, which the caller resets).
+    ``agree``: a callable flag -> flag that makes ranks agree (FlatGradReplica.all_ranks_ok): a rank-local timing decision would give
+    the ranks different graphs."""
+    times = []
+    for fn in (run_one, run_split):
+        cur = torch.cuda.current_stream()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
+                out = fn()
+            del out
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        graph.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(replays):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1) / replays)
+        del graph
+    use = times[1] < times[0]
+    if agree is not None:
+        use = bool(agree(use))
+    if os.environ.get('HNO_TRAIN_GRAPH_QUIET', '0') == '0':
+        print(f'[hno] captured step{what}: one pass over the batch {times[0]:.3f} ms, two half-batches on two streams {times[1]:.3f} ms '
+              f'-> {"two streams" if use else "one pass"}', file=sys.stderr, flush=True)
+    return use, times[0], times[1]
 
 
 class CapturedStep:
@@ -157,59 +219,83 @@ class CapturedStep:
     def __init__(self, model, loss_fn, num_labels, label_mapping=None, data_parallel=None, max_shapes=2, optimizer=None):
         """optimizer: a device-stepped optim.Adamax (``optimizer.device_stepped(scheduler)``): its update (and the scheduler's step)
         is captured behind backward -- and behind the gradient all-reduce, which is then captured too -- so a step of a rank is ONE
-        graph replay; ``steps_optimizer`` tells the caller not to step again."""
+        graph replay; ``steps_optimizer`` tells the caller not to step again.
+        With replicas over SEVERAL ranks the collective is captured only on request (HNO_DP_CAPTURE_ALLREDUCE=1): a collective inside
+        a graph has never run on more than one GPU from this pool, and a mismatch there hangs instead of raising (ADVICE round 4);
+        the default is the measured form -- replay, then one eager flat all-reduce, then the eager Adamax launch."""
         self.model, self.loss_fn, self.num_labels, self.label_mapping = model, loss_fn, num_labels, label_mapping
         self.dp, self.max_shapes = data_parallel, max_shapes
         self.optimizer = optimizer if (optimizer is not None and getattr(optimizer, 'is_device_stepped', False)) else None
+        env = os.environ.get('HNO_DP_CAPTURE_ALLREDUCE', '')
+        multi_rank = data_parallel is not None and getattr(data_parallel, 'real_world', 1) > 1
         # the optimizer can only follow the all-reduce: with replicas the collective has to be part of the graph as well
-        self.capture_allreduce = data_parallel is not None and (self.optimizer is not None
-                                                                 or os.environ.get('HNO_DP_CAPTURE_ALLREDUCE', '0') == '1')
-        if data_parallel is not None and os.environ.get('HNO_DP_CAPTURE_ALLREDUCE', '') == '0':
-            self.capture_allreduce, self.optimizer = False, None
+        self.capture_allreduce = data_parallel is not None and (env == '1' or (env != '0' and not multi_rank and self.optimizer is not None))
+        if data_parallel is not None and not self.capture_allreduce:
+            self.optimizer = None
         self.steps_optimizer = self.optimizer is not None
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.entries, self.seen, self.failed = {}, {}, set()
         self.copy_stream, self.staged = None, None
         self.split = None
+        self.keep_outputs = False
+        self.schedule = {}          # batch-shape key -> ('one pass' | 'two streams', ms_one, ms_split)
+
+    def _fwd_bwd(self, xs, ys, use_split):
+        """the step's forward + loss + backward, enqueued on the current (capturing) stream -> loss"""
+        from .. import ops
+        lab = labels_to_u8(ys, self.num_labels, self.label_mapping)
+        if use_split:
+            return self.split.fwd_bwd(xs, lab, self.loss_fn, zero_grad=self.dp.zero_grad if self.dp is not None else None,
+                                      keep_outputs=self.keep_outputs)
+        with ops.expected_loss(lab, self.loss_fn):       # the head takes the loss sums in its own pass
+            y_pred = self.model(xs)
+        loss = self.loss_fn(y_pred, lab)
+        if self.keep_outputs:
+            self.outputs = [y_pred.detach()]
+        if self.dp is not None:
+            self.dp.zero_grad()
+        else:
+            for p in self.params:
+                p.grad = None
+        ops.backward_from(loss)
+        return loss.detach()
 
     def _capture(self, x, y):
         from .. import ops
         xs, ys = x.clone(), y.clone()
-        if SampleSplit.usable(self.model, self.loss_fn, xs):
-            with torch.no_grad():      # tables / kernel attributes of the half-batch shapes are created at first use: not capturable
-                self.model(xs[:xs.shape[0] // 2])
+        mode = SampleSplit.candidate(self.model, self.loss_fn, xs)
+        if mode:
+            # the twin, its constants and the half-batch shapes' tables / kernel attributes exist BEFORE the capture (none of it is
+            # capturable; round 4 built the twin inside the capture: its copies were replayed with every step -- ADVICE round 4)
+            try:
+                if self.split is None or not self.split.aliased():
+                    self.split = SampleSplit(self.model)
+                with torch.no_grad():
+                    self.model(xs[:xs.shape[0] // 2])
+            except Exception:                # a model that cannot be deep-copied: one pass over the batch
+                self.split, mode = None, False
         cur = torch.cuda.current_stream()
         torch.cuda.synchronize()
         if self.dp is not None:
             self.dp.set_hooks_enabled(False)
         prev = ops.set_defer_reduce(True)      # inside a captured step nothing reads a gradient before backward ends
-        side = torch.cuda.Stream()
-        side.wait_stream(cur)
+        key = (tuple(x.shape), x.dtype, tuple(y.shape), y.dtype)
         try:
+            use_split = mode == 'force'
+            if mode == 'measure':
+                use_split, ms_one, ms_split = choose_schedule(lambda: self._fwd_bwd(xs, ys, False), lambda: self._fwd_bwd(xs, ys, True),
+                                                              agree=self.dp.all_ranks_ok if self.dp is not None else None,
+                                                              what=f' for batches of shape {tuple(x.shape)}')
+                self.schedule[key] = ('two streams' if use_split else 'one pass', ms_one, ms_split)
+                for p in self.params + self.split.tparams:      # the temporary graphs' gradient buffers are gone
+                    p.grad = None
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
             with torch.cuda.stream(side):
                 graph = torch.cuda.CUDAGraph()
                 # thread_local: a collective library's watchdog thread may poll events while we capture
                 with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
-                    lab = labels_to_u8(ys, self.num_labels, self.label_mapping)
-                    use_split = self.split is not False and SampleSplit.usable(self.model, self.loss_fn, xs)
-                    if use_split and (self.split is None or not self.split.aliased()):
-                        # the two halves of the batch on two streams of this graph (SampleSplit)
-                        try:
-                            self.split = SampleSplit(self.model)
-                        except Exception:                # a model that cannot be deep-copied: one pass over the batch
-                            self.split, use_split = False, False
-                    if use_split:
-                        loss = self.split.fwd_bwd(xs, lab, self.loss_fn, zero_grad=self.dp.zero_grad if self.dp is not None else None)
-                    else:
-                        with ops.expected_loss(lab, self.loss_fn):       # the head takes the loss sums in its own pass
-                            y_pred = self.model(xs)
-                        loss = self.loss_fn(y_pred, lab)
-                        if self.dp is not None:
-                            self.dp.zero_grad()
-                        else:
-                            for p in self.params:
-                                p.grad = None
-                        ops.backward_from(loss)
+                    loss = self._fwd_bwd(xs, ys, use_split)
                     if self.dp is not None:
                         self.dp.finish_capture()
                         if self.capture_allreduce:
@@ -225,6 +311,7 @@ class CapturedStep:
                 import traceback
                 traceback.print_exc()
             ops.set_defer_reduce(prev)
+            self.split = None           # (a twin whose gradients point into a dropped graph's pool must not be reused)
             if self.dp is not None:
                 self.dp.set_hooks_enabled(True)
             return None
@@ -274,6 +361,7 @@ class CapturedStep:
                 # replays sends one flat all-reduce, an eager rank one per bucket -- mixed, the collectives no longer match
                 if ent is not None:
                     ent = None
+                    self.split = None
                     if not self.entries:
                         self.dp.set_hooks_enabled(True)
             if ent is None:
@@ -395,12 +483,12 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
         from ..nets.hnosegxs import HNOSegXS
         from ..nets.architectures import NeuralOperatorSeg, HartleyMHASeg, VNetDS
         use_graph = os.environ.get('HNO_TRAIN_GRAPH', '1') != '0' and isinstance(model, (HNOSegXS, NeuralOperatorSeg, HartleyMHASeg, VNetDS))
-    captured = None
+    captured, entered_dev_opt = None, False
     if use_graph and not use_autocast and next(model.parameters()).is_cuda:
         # our Adamax moves its step counter, the learning rate and the per-batch cosine schedule onto the device, so that the update
         # is part of the captured step (HNO_TRAIN_GRAPH_OPT=0: keep optimizer and scheduler eager behind the replay)
-        if os.environ.get('HNO_TRAIN_GRAPH_OPT', '1') != '0' and hasattr(optimizer, 'device_stepped'):
-            optimizer.device_stepped(scheduler)
+        if os.environ.get('HNO_TRAIN_GRAPH_OPT', '1') != '0' and hasattr(optimizer, 'device_stepped') and not optimizer.is_device_stepped:
+            entered_dev_opt = optimizer.device_stepped(scheduler)
         captured = CapturedStep(model, loss_fn, num_labels, label_mapping, data_parallel if world > 1 else None, optimizer=optimizer)
     dev_opt = getattr(optimizer, 'is_device_stepped', False)      # the tick kernel advances the schedule: no scheduler.step()
 
@@ -490,6 +578,13 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
                     save_checkpoint(chkpt_path, epoch, model, optimizer, scheduler, min_loss, best_epoch, scaler)
                 log('Best checkpoint saved.')
     end_time = time.time()
+    last_run.clear()
+    last_run.update(device_stepped_optimizer=bool(dev_opt), schedules=dict(captured.schedule) if captured is not None else {})
+    if entered_dev_opt:
+        # the mode was entered for THIS run's captured steps: hand the caller's optimizer and scheduler back in torch's own stepping
+        # form (a later scheduler.step() / eager loop would otherwise diverge from the device counters)
+        captured = None
+        optimizer.leave_device_stepped()
 
     if best_epoch is None and is_main:  # num_epochs == 0, i.e. no training
         torch.save(model.state_dict(), model_path)

@@ -193,9 +193,10 @@ class HNOXSBlock(nn.Module):
 class HNOSegXS(nn.Module):
     """HNOSeg-XS (reference :20-182).  See the reference docstring for the arguments; they are
     identical here."""
-    # captured training steps of these (batch, D, H, W) shapes run the two halves of the batch as two concurrent passes
-    # (experiments.train_test.SampleSplit): measured +3-6 % at the BraTS training shape, -2 ... -10 % at 80^3 ... 120^3, 144^3 and 160^3
-    hno_sample_split = frozenset({(2, 128, 128, 128)})
+    # a captured training step of this family MAY run the two halves of its batch as two concurrent passes (experiments.train_test.
+    # SampleSplit): whether it does is measured per batch shape when the step is captured (train_test.choose_schedule: both forms are
+    # captured and replayed, the faster is kept; by hand in round 4: +3-6 % at the BraTS training shape, -2 ... -10 % at 80^3 ... 160^3)
+    hno_sample_split = 'measure'
 
     def __init__(self, in_channels, out_channels, filters, num_transform_blocks, num_modes, weights_type='shared',
                  use_resize=True, use_deep_supervision=False, use_unet_skip=True, use_block_concat=True,

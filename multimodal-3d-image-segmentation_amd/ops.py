@@ -426,10 +426,11 @@ def pwconv_bwd_branch_raw(gy, y, xa, xb, W, Wbr, act, xa_act, defer=False, bf16=
 # pass ends -- the weight is a leaf with .grad None, has no tensor / post-accumulate hooks, and feeds exactly ONE live
 # autograd node (a module applied twice, or tied weights, would make AccumulateGrad sum two unreduced tensors).
 import os as _os
+import weakref as _weakref
 _DEFER_ENABLED = bool(int(_os.environ.get('HNO_DEFER_REDUCE', '0')))
 _defer_state = {'active': False, 'keep': [], 'task': None, 'stream': None}
 _stats = {'pass_fused': 0, 'pass_unfused': 0}     # counters read by the tests
-_param_uses = {}     # id(parameter) -> [live autograd nodes holding it, poisoned]
+_param_uses = {}     # id(parameter) -> [weak references to the live autograd nodes (ctx) holding it, poisoned]
 
 
 def set_defer_reduce(on=True):
@@ -472,19 +473,27 @@ def _defer_drop_stale():
         _defer_reset()
 
 
-def _note_use(*weights):
-    """forward-time: these parameters are held by one more live autograd node"""
+def _note_use(ctx, *weights):
+    """forward-time: these parameters are held by one more live autograd node.  The node is remembered through a weak reference to
+    its ctx: a forward that never gets a backward (torch.no_grad() -- ctx.needs_input_grad is True there too --, validation passes,
+    an exception before backward) leaves no trace once its outputs are gone.  (Round 4 counted uses instead: one no_grad forward of a
+    model -- the half-batch warm-up in front of a capture, any validation epoch -- left every parameter "held twice" for good, and
+    the model's passes reduced their slabs one launch at a time from then on.)"""
     if not _DEFER_ENABLED:
         return
+    ref = _weakref.ref(ctx)
     for w in weights:
         if w is not None and w.requires_grad:
-            e = _param_uses.setdefault(id(w), [0, False])
-            e[0] += 1
-            if e[0] > 1:
+            e = _param_uses.setdefault(id(w), [[], False])
+            e[0] = [r for r in e[0] if r() is not None]
+            if not e[0]:
+                e[1] = False
+            e[0].append(ref)
+            if len(e[0]) > 1:
                 e[1] = True
 
 
-def _release_use(*weights):
+def _release_use(ctx, *weights):
     """backward-time: -> True when every one of these parameters fed only this node since it was last idle"""
     ok = True
     for w in weights:
@@ -494,9 +503,12 @@ def _release_use(*weights):
         if e is None:
             ok = False
             continue
-        ok = ok and not e[1]
-        e[0] -= 1
-        if e[0] <= 0:
+        live = [r for r in e[0] if r() is not None and r() is not ctx]
+        if len(live) + 1 != len(e[0]):          # dead nodes dropped: were they what poisoned the entry?
+            e[1] = e[1] and len(live) > 0
+        ok = ok and not e[1] and not live
+        e[0] = live
+        if not live:
             del _param_uses[id(w)]
     return ok
 
@@ -520,7 +532,7 @@ def _leaf_params(ctx, *ts):
     ctx.needs_input_grad is the signal) the parameters are counted as held by one more live node (_note_use)."""
     ok = all(t is None or (t.is_leaf and t.dtype == torch.float32 and t.is_contiguous()) for t in ts)
     if ok and ctx is not None and any(ctx.needs_input_grad):
-        _note_use(*ts)
+        _note_use(ctx, *ts)
         return True
     return False
 
@@ -1458,7 +1470,7 @@ class PwConvFn(_HnoFunction):
             db = _chan_sum(g) if ctx.has_bias else None
             return gxa, None, dW, db, None
         gxa, gxb, dW, db = pwconv_bwd_raw(_f32a(gy), y, xa, xb, W, ctx.act, ctx.has_bias, ctx.needs_input_grad[0],
-                                          ctx.needs_input_grad[1], defer=ctx.leaf_params and _release_use(W, bias) and _deferrable(W, bias),
+                                          ctx.needs_input_grad[1], defer=ctx.leaf_params and _release_use(ctx, W, bias) and _deferrable(W, bias),
                                           bias=bias, bf16=getattr(ctx, 'bf16', False))
         return gxa, gxb, dW, db, None
 
@@ -1566,7 +1578,7 @@ class NOBlockFn(_HnoFunction):
     def backward(ctx, g_out):
         x, br_w, cat_w, w, s0, s1, y, out, br_b, cat_b, *op_ws = ctx.saved_tensors
         fourier, modes, act, spatial, n3, br_has_b, cat_has_b = ctx.cfg
-        late = ctx.leaf_params and _release_use(br_w, br_b, cat_w, cat_b, *op_ws) and _deferrable(br_w, br_b, cat_w, cat_b, *op_ws)   # (the Fourier mix reads its dW2 at once: never late)
+        late = ctx.leaf_params and _release_use(ctx, br_w, br_b, cat_w, cat_b, *op_ws) and _deferrable(br_w, br_b, cat_w, cat_b, *op_ws)   # (the Fourier mix reads its dW2 at once: never late)
         d_br_w = d_br_b = None
         if br_w is not None and tuple(cat_w.shape[:2]) == (24, 48) and tuple(br_w.shape[:2]) == (24, 24):
             # one pass: p = d loss / d (s + x2) = g_y * act'(y); g_x = concat-path gradient + Wbr^T p; all four parameter gradients
@@ -1691,7 +1703,7 @@ class XSBlockFn(_HnoFunction):
         if not has_map:
             xm = x
         # weight gradients of leaves with .grad None are not read before backward ends: their slab reductions are batched
-        lp = ctx.leaf_params and _release_use(map_w, map_b, cat_w, cat_b, nmap_w, nmap_b, *mix_ws)
+        lp = ctx.leaf_params and _release_use(ctx, map_w, map_b, cat_w, cat_b, nmap_w, nmap_b, *mix_ws)
         late_cat, late_mix, late_map = lp and _deferrable(cat_w, cat_b), lp and _deferrable(*mix_ws), lp and _deferrable(map_w, map_b)
         if g_out is None:
             raise _lib.HnoError('XSBlockFn.backward: no gradient for the block output')
@@ -1854,7 +1866,7 @@ class StemChainFn(_HnoFunction):
         x, W, bias, W1, bias1, y1 = ctx.saved_tensors
         if ctx.needs_input_grad[0]:
             raise _lib.HnoError('conv_in input gradient is not implemented (the image needs none)')
-        lp = ctx.leaf_params and _release_use(W, bias, W1, bias1)
+        lp = ctx.leaf_params and _release_use(ctx, W, bias, W1, bias1)
         late = lp and _deferrable(W, bias, W1, bias1)
         ld = chan_stride(y1)
         gy = to_layout(gy, ld)
@@ -2122,6 +2134,24 @@ def backward_from(loss):
     if one is None:
         one = _ones[key] = torch.ones((), device=loss.device, dtype=loss.dtype)
     loss.backward(gradient=one.expand_as(loss) if loss.dim() else one)
+
+
+def sum_pairs(entries):
+    """entries: (dst, a, b, scale) of contiguous fp32 GPU tensors with equal element counts; dst = scale * (a + b), elementwise, for ALL
+    entries in one launch per 64 tensors (hno_sum_pairs).  Capturable: the addresses travel in the kernel arguments.  Used for the join of
+    the two half-batch passes of a captured training step (gradients: dst = a, scale 1; the loss: scale 0.5)."""
+    import ctypes
+    if not entries:
+        return
+    n = len(entries)
+    for d, a, b, _ in entries:
+        _need_gpu(d, a, b)
+        assert d.dtype == a.dtype == b.dtype == torch.float32 and d.numel() == a.numel() == b.numel()
+        assert d.is_contiguous() and a.is_contiguous() and b.is_contiguous()
+    vp = ctypes.c_void_p * n
+    check(_lib.lib().hno_sum_pairs(vp(*[e[0].data_ptr() for e in entries]), vp(*[e[1].data_ptr() for e in entries]),
+                                   vp(*[e[2].data_ptr() for e in entries]), (ctypes.c_longlong * n)(*[e[0].numel() for e in entries]),
+                                   (ctypes.c_float * n)(*[float(e[3]) for e in entries]), n, stream_ptr()), 'hno_sum_pairs')
 
 
 def labels_prepare(labels, num_classes, mapping=None, want_onehot=False):

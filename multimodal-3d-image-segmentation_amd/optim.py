@@ -30,7 +30,9 @@ class Adamax(torch.optim.Optimizer):
             raise ValueError(f'Invalid weight_decay value: {weight_decay}')
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_scale = float(grad_scale)   # e.g. 1 / world after a SUM all-reduce
-        self._tables = {}                     # pointer signature -> (device table, rows)
+        self._tables = {}                     # pointer signature -> (device table, rows); eager-built entries may be evicted
+        self._captured_tables = {}            # the same for tables built inside a graph capture: a graph reads them at every replay,
+                                              # so they live as long as the optimizer (evicting one was a use-after-free)
         self._dev = None                      # device-stepped mode: (state tensor, scheduler or None)
 
     # ---- device-stepped mode: the whole update is capturable into a HIP graph ------------------------------------------------
@@ -70,7 +72,8 @@ class Adamax(torch.optim.Optimizer):
         self._dev = (torch.tensor(st, dtype=torch.float64, device=params[0].device), scheduler)
         # scheduler.last_epoch counts its step() calls; it normally equals the optimizer's step count (both stepped once per batch)
         self._sched_offset = int(scheduler.last_epoch) - int(step) if scheduler is not None else 0
-        self._reserve_tables()
+        if not getattr(self, '_table_pool', None):
+            self._reserve_tables()
         return True
 
     @property
@@ -104,11 +107,27 @@ class Adamax(torch.optim.Optimizer):
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
+        """In device-stepped mode the loaded values are copied INTO the existing device state and moment buffers: graphs captured
+        before the load keep reading the addresses they were captured with."""
         was = self._dev
+        old = {}
+        if was is not None:
+            for p in self.param_groups[0]['params']:
+                if len(self.state[p]):
+                    old[p] = (self.state[p].get('exp_avg'), self.state[p].get('exp_inf'))
         self._dev = None
         super().load_state_dict(state_dict)
         if was is not None:          # re-enter the mode on the loaded counters (the caller reloads the scheduler first)
-            self.device_stepped(was[1])
+            with torch.no_grad():
+                for p, bufs in old.items():
+                    st = self.state[p]
+                    for k, buf in zip(('exp_avg', 'exp_inf'), bufs):
+                        if buf is not None and k in st and torch.is_tensor(st[k]) and st[k].shape == buf.shape:
+                            buf.copy_(st[k])
+                            st[k] = buf
+            if self.device_stepped(was[1]) and self._dev[0] is not was[0]:
+                was[0].copy_(self._dev[0])
+                self._dev = (was[0], self._dev[1])
 
     def _init_state(self, group):
         """exp_avg / exp_inf of a group live in two flat buffers (views per parameter)."""
@@ -127,7 +146,7 @@ class Adamax(torch.optim.Optimizer):
 
     def _table(self, tensors):
         key = tuple(t.data_ptr() for quad in tensors for t in quad)
-        hit = self._tables.get(key)
+        hit = self._captured_tables.get(key) or self._tables.get(key)
         if hit is not None:
             return hit
         rows = []
@@ -150,9 +169,10 @@ class Adamax(torch.optim.Optimizer):
             # the rows reach the device ONCE, after the capture (finish_capture): a copy node inside the graph would move the same
             # 8 KB again at every replay (4.7 us per step in the kernel trace of round 4)
             self._unfilled = getattr(self, '_unfilled', []) + [(host, table)]
-        else:
-            table = torch.tensor(rows, dtype=torch.int64).to(dev)
-        if len(self._tables) > 8 and not torch.cuda.is_current_stream_capturing():
+            self._captured_tables[key] = (table, len(rows))
+            return self._captured_tables[key]
+        table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        if len(self._tables) > 8:
             self._tables.clear()
         self._tables[key] = (table, len(rows))
         return self._tables[key]

@@ -332,13 +332,24 @@ def test_deferred_reduction_guards():
         ops._param_uses.clear()
         class Ctx:                                       # what autograd hands Function.forward
             needs_input_grad = (True, False)
-        ctx = Ctx()
-        assert ops._leaf_params(ctx, w, v)               # node 1 holds w and v
-        assert ops._leaf_params(ctx, w)                  # node 2 holds w again (module applied twice / tied weights)
-        assert ops._release_use(w) is False              # backward of node 2: w is shared -> reduce immediately
-        assert ops._release_use(w, v) is False           # backward of node 1: still poisoned for this pass
+        n1, n2 = Ctx(), Ctx()
+        assert ops._leaf_params(n1, w, v)                # node 1 holds w and v
+        assert ops._leaf_params(n2, w)                   # node 2 holds w again (module applied twice / tied weights)
+        assert ops._release_use(n2, w) is False          # backward of node 2: w is shared -> reduce immediately
+        assert ops._release_use(n1, w, v) is False       # backward of node 1: still poisoned for this pass
         assert not ops._param_uses                       # all uses released: the next pass starts clean
-        assert ops._leaf_params(ctx, w, v) and ops._release_use(w, v) is True
+        assert ops._leaf_params(n1, w, v) and ops._release_use(n1, w, v) is True
+        # a forward that never gets a backward (torch.no_grad(): needs_input_grad is True there as well; a validation pass) dies with
+        # its outputs and must not count -- round 4 counted it, and every later pass of the model reduced slab by slab
+        gone = Ctx()
+        assert ops._leaf_params(gone, w, v)
+        del gone
+        assert ops._leaf_params(n1, w, v) and ops._release_use(n1, w, v) is True and not ops._param_uses
+        gone = Ctx()                                     # ... also when it ran between a forward and its backward
+        assert ops._leaf_params(n1, w, v) and ops._leaf_params(gone, w, v)
+        del gone
+        assert ops._release_use(n1, w, v) is True and not ops._param_uses
+        ctx = n1
         assert ops._deferrable(w, None, v)
         h = w.register_hook(lambda g: g)
         assert not ops._deferrable(w)                    # a tensor hook would read the unreduced gradient
@@ -397,3 +408,23 @@ def test_test_flow_is_never_sharded():
     fl = r.get_test_flow()
     assert len(fl) == 3 and fl._epoch_order().tolist() == [0, 1, 2, 3, 4]
     assert r.get_valid_flow()._epoch_order().tolist() == [1, 3]
+
+
+def test_traffic_file_keys_are_profiler_kernel_names():
+    """bench.py looks the dominant kernel family's measured HBM traffic up in profiles/hbm_traffic.json BY THE PROFILER'S NAME of the
+    family; a key the profiler never reports (round 4: spec_mid_* in the file, specmix_* from the profiler) makes `roofline.traffic` null
+    without a word.  Every key of the file must be a name hno_profile_kernel_name() can return."""
+    import json
+    import multimodal_3d_image_segmentation_amd as pkg
+    L = pkg._lib.lib()
+    names = set()
+    for i in range(256):
+        n = L.hno_profile_kernel_name(i)
+        if not n or n == b'?':
+            break
+        names.add(n.decode())
+    assert {'spec_mid_fwd_kernel', 'spec_mid_bwd_kernel', 'pwconv_bwd_kernel', 'dht_fwd_plane_kernel'} <= names
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tj = json.load(open(os.path.join(root, 'profiles', 'hbm_traffic.json')))
+    keys = set(tj.get('per_kernel_bytes_per_launch', tj))
+    assert keys and keys <= names, keys - names

@@ -118,7 +118,7 @@ def test_training_with_optimizer_and_schedule_inside_the_captured_step(tmp_path,
         model, opt, sched, data, loss_fn = setup()
         before = dict(tt.step_stats)
         tt.training(model, data, str(tmp_path / tag), loss_fn, opt, sched, num_epochs=TRAIN_CASE['epochs'], use_graph=True, **kw)
-        assert opt.is_device_stepped == (flag == '1')
+        assert tt.last_run['device_stepped_optimizer'] == (flag == '1') and not opt.is_device_stepped      # (training() leaves the mode it entered)
         assert tt.step_stats['replayed'] - before['replayed'] > 0
         tl, vl = tt.get_losses_from_file(os.path.join(tmp_path / tag, 'stdout.txt'))
         assert np.abs(np.array(tl) - g['train_loss']).max() < 2e-5 and np.abs(np.array(vl) - g['valid_loss']).max() < 2e-5
@@ -278,14 +278,16 @@ def test_sample_split_gives_the_batch_gradients(loss_name, monkeypatch):
     model = pkg.nets.HNOSegXS(4, 4, 24, [1, 1, 1, 1], (4, 6, 6)).cuda()
     x = torch.randn(4, 4, 32, 32, 32, device='cuda')
     lab = torch.randint(0, 4, (4, 32, 32, 32), device='cuda').to(torch.uint8)
-    # opt-in per model class and batch shape (measured: only HNOSeg-XS at 2 x 4 x 128^3 gains); HNO_SPLIT_STREAMS=1 forces it for this test
+    # a model class names itself a CANDIDATE ('measure': CapturedStep / bench.py time both forms when the step is captured and keep the
+    # faster, test_captured_step_measures_its_schedule); HNO_SPLIT_STREAMS=1 / 0 force it on / off for every model
     monkeypatch.delenv('HNO_SPLIT_STREAMS', raising=False)
-    big = torch.empty(2, 4, 128, 128, 128, device='cuda')
-    assert tt.SampleSplit.usable(model, loss_fn, big) and not tt.SampleSplit.usable(model, loss_fn, x)
-    other = pkg.nets.NeuralOperatorSeg(4, 4, 24, 2, (4, 6, 6), 'Fourier').cuda()      # a family that has not opted in (measured: no gain)
-    assert not tt.SampleSplit.usable(other, loss_fn, big)
-    del big
+    assert tt.SampleSplit.candidate(model, loss_fn, x) == 'measure'
+    other = pkg.nets.NeuralOperatorSeg(4, 4, 24, 2, (4, 6, 6), 'Fourier').cuda()      # a family that is no candidate (measured: no gain)
+    assert tt.SampleSplit.candidate(other, loss_fn, x) is False
+    monkeypatch.setenv('HNO_SPLIT_STREAMS', '0')
+    assert tt.SampleSplit.candidate(model, loss_fn, x) is False
     monkeypatch.setenv('HNO_SPLIT_STREAMS', '1')
+    assert tt.SampleSplit.candidate(model, loss_fn, x) == 'force' and tt.SampleSplit.candidate(other, loss_fn, x) == 'force'
     assert tt.SampleSplit.usable(model, loss_fn, x) and not tt.SampleSplit.usable(model, loss_fn, x[:3]) and not tt.SampleSplit.usable(model, torch.nn.MSELoss(), x)
     assert tt.SampleSplit.usable(other, loss_fn, x)
     params = [p for p in model.parameters()]
@@ -343,3 +345,72 @@ def test_sample_split_gives_the_batch_gradients(loss_name, monkeypatch):
     check(l2, g2)
     params[0].data = params[0].data.clone()                        # a re-materialised parameter does not: detected
     assert not split.aliased()
+
+
+def test_captured_step_measures_its_schedule(monkeypatch):
+    """Round 5: whether a captured step runs its batch as one pass or as two half-batches on two streams is MEASURED when the step is
+    captured (train_test.choose_schedule: both forms captured, replayed, the faster kept) -- round 4 carried a hand-measured list of
+    shapes in model code.  Whatever wins, the replayed step gives the eager step's loss and gradients, its weight-gradient slabs are
+    reduced by batched launches only (round 4's split silently fell back to 17 single launches per pass), and a forced answer
+    (HNO_SPLIT_STREAMS) skips the measurement."""
+    import multimodal_3d_image_segmentation_amd as pkg
+    from multimodal_3d_image_segmentation_amd import ops, _lib
+    from multimodal_3d_image_segmentation_amd.experiments import train_test as tt
+    from multimodal_3d_image_segmentation_amd.nets import custom_losses as CL
+    monkeypatch.delenv('HNO_SPLIT_STREAMS', raising=False)
+    monkeypatch.setenv('HNO_TRAIN_GRAPH_QUIET', '1')
+    torch.manual_seed(5)
+    model = pkg.nets.HNOSegXS(4, 4, 24, [1, 1, 1, 1], (4, 6, 6)).cuda()
+    loss_fn = CL.PCCLoss()
+    x = torch.randn(2, 4, 32, 32, 32, device='cuda')
+    y = torch.randint(0, 4, (2, 1, 32, 32, 32), device='cuda').float()
+    params = [p for p in model.parameters()]
+
+    def eager():
+        lab = ops.labels_prepare(y, 4)
+        for p in params:
+            p.grad = None
+        with ops.expected_loss(lab, loss_fn):
+            out = model(x)
+        l = loss_fn(out, lab)
+        l.backward()
+        res = float(l.detach()), [p.grad.clone() for p in params]
+        for p in params:
+            p.grad = None
+        del out, l
+        return res
+    l_ref, g_ref = eager()
+    with torch.no_grad():            # a validation-style pass in between must not disturb the batched reduction (round-4 bug)
+        model(x)
+    L = _lib.lib()
+    for forced in (None, '1', '0'):
+        if forced is None:
+            monkeypatch.delenv('HNO_SPLIT_STREAMS', raising=False)
+        else:
+            monkeypatch.setenv('HNO_SPLIT_STREAMS', forced)
+        cap = tt.CapturedStep(model, loss_fn, 4)
+        assert cap.step(x, y) is None                      # first sighting of a shape: the caller runs it eagerly
+        single0, multi0 = L.hno_debug_reduce_launches(0), L.hno_debug_reduce_launches(1)
+        loss = cap.step(x, y)                              # second: measured (or forced), captured, replayed
+        assert loss is not None
+        torch.cuda.synchronize()
+        key = next(iter(cap.entries))
+        if forced is None:
+            form, ms_one, ms_split = cap.schedule[key]
+            assert ms_one > 0 and ms_split > 0 and form == ('two streams' if ms_split < ms_one else 'one pass')
+            passes = 1 + 2 + (2 if form == 'two streams' else 1)      # both trial captures + the kept one
+        else:
+            assert not cap.schedule
+            passes = 2 if forced == '1' else 1
+        # every backward pass that was enqueued reduced ALL its slab sets in one batched launch
+        assert L.hno_debug_reduce_launches(0) == single0
+        assert L.hno_debug_reduce_launches(1) - multi0 == passes
+        assert abs(float(loss) - l_ref) < 2e-6
+        for p, g in zip(params, g_ref):
+            assert rel_err(p.grad.cpu().numpy(), g.cpu().numpy()) < 2e-4
+        loss2 = cap.step(x, y)
+        torch.cuda.synchronize()
+        assert abs(float(loss2) - l_ref) < 2e-6
+        del cap
+        for p in params:
+            p.grad = None

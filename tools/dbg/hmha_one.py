@@ -12,7 +12,7 @@ def timeit(f, n=20):
     e0.record()
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / n * 1e3
-for flag in (16384, 0):
+for flag in (1 << 24, 0):
     L.hno_set_debug(flag)
     tf = timeit(lambda: L.hno_hmha_fwd(P(q), P(k), P(v), P(out), P(ws), WB, BZ, C, C, T, 0.1, 1, S()))
     tb = timeit(lambda: L.hno_hmha_bwd(P(q), P(k), P(v), P(do), P(dq), P(dk), P(dv), P(ws), WB, BZ, C, C, T, 0.1, 1, S()))
