@@ -57,6 +57,8 @@ struct ProfScope {
 int reduce_partials_launch(const float *partials, int nblocks, int n, float *dst0, int n0, float *dst1,
                            hipStream_t stream, int cols = 0, int ldd = 0, bool allow_defer = true);   // allow_defer = false: callers that reuse the slab workspace for several rounds   // cols/ldd: dst0 is a sub-block with row stride ldd
 bool defer_reduce_enabled();
+// layout of the plane kernels' intermediate around the fused spectral middle (hno_dht.hip: DhtArgs.zl; HNO_MID_ZLAYOUT=0 keeps the old one)
+bool mid_zlayout();
 
 // wave-private accumulator fragments -> one slab per block.  `scratch` is >= nwaves * n floats of LDS.
 // frag(idx) semantic: each wave calls store(idx, value) for the elements it owns; all 4 waves own

@@ -277,7 +277,19 @@ struct DhtArgs {
     // channel-padded activations (ops.chan_stride): floats between consecutive (b, c) volumes of the spatial tensors (input of the
     // forward, output / residual of the inverse); 0 = contiguous (N0 N1 N2)
     unsigned ldbc;
+    // layout of the intermediate (the plane kernels' output / input).  0: [plane][part][k1 position][k2] -- what the axis-D kernels read
+    // and write.  1 (round 5, planes-only launches around the fused spectral middle): [k1 position][k2 / 4][plane][part][4] -- the
+    // 16-byte pieces a middle workgroup (sample, k1, four k2 columns) needs of all planes and channels lie in ONE contiguous run
+    // instead of one 128-byte line each (its D steps: 20.4 -> 16 us forward, 27.8 -> 23.3 us backward at the benchmark size)
+    int zl;
+    unsigned zplanes;   // BC * N0
 };
+
+// float offset of element (part, k1 position `row` in [0, K1S), column k2) of intermediate plane `plane`
+__device__ __forceinline__ size_t ymid(const DhtArgs &a, int plane, int part, int row, int k2) {
+    if (a.zl) return ((size_t)(row * (a.p.ax[2].KP >> 2) + (k2 >> 2)) * a.zplanes + (size_t)plane) * 8 + part * 4 + (k2 & 3);
+    return (size_t)plane * (2 * a.p.CP) + (size_t)(part * a.p.K1S + row) * a.p.ax[2].KP + k2;
+}
 
 // float offset of plane (bc, n0) = `plane` of a spatial tensor
 __device__ __forceinline__ size_t plane_base(const DhtArgs &a, int plane, size_t plane_elems) {
@@ -441,10 +453,10 @@ __global__ __launch_bounds__(NTH) void dht_fwd_plane_kernel(const float *__restr
                     }
                 }
                 const int k2 = kt2 * 16 + (lane >> 4) * 4;
-                float *dstp = Yp + (size_t)(part * p.K1S + (a1.m + k1)) * a2.KP + k2;
+                float *dstp = Y + ymid(a, plane, part, a1.m + k1, k2);
                 *reinterpret_cast<f32x4 *>(dstp) = vp;
                 if (k1 >= 1) {
-                    float *dstm = Yp + (size_t)(part * p.K1S + (a1.m - k1)) * a2.KP + k2;
+                    float *dstm = Y + ymid(a, plane, part, a1.m - k1, k2);
                     *reinterpret_cast<f32x4 *>(dstm) = vm;
                 }
             }
@@ -665,8 +677,8 @@ __global__ __launch_bounds__(256, 3) void dht_fwd_plane_spec_kernel(const float 
                     }
                 }
                 const int k2 = q * 4;
-                *reinterpret_cast<f32x4 *>(Yp + (size_t)(part * p.K1S + (a1.m + k1)) * a2.KP + k2) = vp;
-                if (k1 >= 1) *reinterpret_cast<f32x4 *>(Yp + (size_t)(part * p.K1S + (a1.m - k1)) * a2.KP + k2) = vm;
+                *reinterpret_cast<f32x4 *>(Y + ymid(a, plane, part, a1.m + k1, k2)) = vp;
+                if (k1 >= 1) *reinterpret_cast<f32x4 *>(Y + ymid(a, plane, part, a1.m - k1, k2)) = vm;
             }
         }
     }
@@ -984,11 +996,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void dht_fwd_plane_wave_kernel(const f
                     vm1[r] = qA[r] - pB[r];
                 }
                 const int k2 = q * 4;
-                *reinterpret_cast<f32x4 *>(Yp + (size_t)(a1.m + k1) * a2.KP + k2) = vp0;
-                *reinterpret_cast<f32x4 *>(Yp + (size_t)(p.K1S + (a1.m + k1)) * a2.KP + k2) = vp1;
+                *reinterpret_cast<f32x4 *>(Y + ymid(a, plane, 0, a1.m + k1, k2)) = vp0;
+                *reinterpret_cast<f32x4 *>(Y + ymid(a, plane, 1, a1.m + k1, k2)) = vp1;
                 if (k1 >= 1) {
-                    *reinterpret_cast<f32x4 *>(Yp + (size_t)(a1.m - k1) * a2.KP + k2) = vm0;
-                    *reinterpret_cast<f32x4 *>(Yp + (size_t)(p.K1S + (a1.m - k1)) * a2.KP + k2) = vm1;
+                    *reinterpret_cast<f32x4 *>(Y + ymid(a, plane, 0, a1.m - k1, k2)) = vm0;
+                    *reinterpret_cast<f32x4 *>(Y + ymid(a, plane, 1, a1.m - k1, k2)) = vm1;
                 }
             }
         }
@@ -1375,11 +1387,23 @@ __global__ __launch_bounds__(64 * NWV, 2) void dht_fwd_plane_dma_kernel(const fl
                 }
                 const int k2 = q * 4;
                 // write-through stores: the 11.6 MB of Y would otherwise sit dirty in the L2s until the end-of-kernel write-back
-                store16_wt(Yp + (size_t)(a1.m + k1) * a2.KP + k2, vp0);
-                store16_wt(Yp + (size_t)(p.K1S + (a1.m + k1)) * a2.KP + k2, vp1);
+                if (a.zl == 1) {   // plain stores: the XCD's L2 merges the 32-byte pieces of neighbouring planes into lines (write-through
+                                   // pieces, HNO_MID_ZLAYOUT=2, cost this kernel 4.4 us: 19.3 against 23.7 us per launch in the step)
+                    float *d0 = Y + ymid(a, plane, 0, a1.m + k1, k2);
+                    *reinterpret_cast<f32x4 *>(d0) = vp0;
+                    *reinterpret_cast<f32x4 *>(d0 + 4) = vp1;
+                    if (k1 >= 1) {
+                        float *d1 = Y + ymid(a, plane, 0, a1.m - k1, k2);
+                        *reinterpret_cast<f32x4 *>(d1) = vm0;
+                        *reinterpret_cast<f32x4 *>(d1 + 4) = vm1;
+                    }
+                } else {
+                store16_wt(Y + ymid(a, plane, 0, a1.m + k1, k2), vp0);
+                store16_wt(Y + ymid(a, plane, 1, a1.m + k1, k2), vp1);
                 if (k1 >= 1) {
-                    store16_wt(Yp + (size_t)(a1.m - k1) * a2.KP + k2, vm0);
-                    store16_wt(Yp + (size_t)(p.K1S + (a1.m - k1)) * a2.KP + k2, vm1);
+                    store16_wt(Y + ymid(a, plane, 0, a1.m - k1, k2), vm0);
+                    store16_wt(Y + ymid(a, plane, 1, a1.m - k1, k2), vm1);
+                }
                 }
             }
         }
@@ -1696,8 +1720,8 @@ __global__ __launch_bounds__(NTH) void dht_inv_plane_kernel(const float *__restr
             const int part = row / a2.KP, k2 = row - part * a2.KP;
             const bool ok = i < nitem && k1 <= m1;
             const int kc = ok ? k1 : 0;
-            ea[j] = ok ? Ep[(size_t)(part * p.K1S + (m1 + kc)) * a2.KP + k2] : 0.f;
-            eb[j] = (ok && k1 >= 1) ? Ep[(size_t)(part * p.K1S + (m1 - kc)) * a2.KP + k2] : 0.f;
+            ea[j] = ok ? E[ymid(a, plane, part, m1 + kc, k2)] : 0.f;
+            eb[j] = (ok && k1 >= 1) ? E[ymid(a, plane, part, m1 - kc, k2)] : 0.f;
         }
     };
     if (blockIdx.x < planes) fetch_e(blockIdx.x);
@@ -1719,8 +1743,8 @@ __global__ __launch_bounds__(NTH) void dht_inv_plane_kernel(const float *__restr
             const int part = row / a2.KP, k2 = row - part * a2.KP;
             float sv = 0.f, dv = 0.f;
             if (k1 <= m1) {
-                const float va = Ep[(size_t)(part * p.K1S + (m1 + k1)) * a2.KP + k2];
-                const float vb = k1 >= 1 ? Ep[(size_t)(part * p.K1S + (m1 - k1)) * a2.KP + k2] : 0.f;
+                const float va = E[ymid(a, plane, part, m1 + k1, k2)];
+                const float vb = k1 >= 1 ? E[ymid(a, plane, part, m1 - k1, k2)] : 0.f;
                 sv = va + vb;
                 dv = k1 >= 1 ? va - vb : 0.f;
             }
@@ -1892,7 +1916,11 @@ __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float 
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int e = tid + 256 * j;
-            re[j] = e < ne ? Ep[e] : 0.f;
+            if (a.zl) {      // the LDS image keeps the [part][k1 position][16] order (this kernel needs one k2 tile: KP == 16)
+                const int es = e < ne ? e : 0, part = es / p.CP, rem = es - part * p.CP;
+                re[j] = e < ne ? E[ymid(a, plane, part, rem >> 4, rem & 15)] : 0.f;
+            } else
+                re[j] = e < ne ? Ep[e] : 0.f;
         }
     };
     HNO_STAMP(a.stamps, 0);
@@ -2224,10 +2252,19 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const f
             const int k1 = 4 * ks + q;
             const bool ok = k1 <= m1;
             const int rp = ok ? m1 + k1 : m1, rm = ok ? m1 - k1 : m1;
-            erp[ks] = Ep[rp * 16 + l15];
-            erm[ks] = Ep[rm * 16 + l15];
-            eip[ks] = Ep[p.CP + rp * 16 + l15];
-            eim[ks] = Ep[p.CP + rm * 16 + l15];
+            if (a.zl) {
+                const size_t op = ((size_t)(rp * 4 + (l15 >> 2)) * a.zplanes + pl) * 8 + (l15 & 3);
+                const size_t om = ((size_t)(rm * 4 + (l15 >> 2)) * a.zplanes + pl) * 8 + (l15 & 3);
+                erp[ks] = E[op];
+                erm[ks] = E[om];
+                eip[ks] = E[op + 4];
+                eim[ks] = E[om + 4];
+            } else {
+                erp[ks] = Ep[rp * 16 + l15];
+                erm[ks] = Ep[rm * 16 + l15];
+                eip[ks] = Ep[p.CP + rp * 16 + l15];
+                eim[ks] = Ep[p.CP + rm * 16 + l15];
+            }
         }
     };
     HNO_STAMP(a.stamps, 21);
@@ -2536,6 +2573,16 @@ static int fwd_plane_variant() {
     return v;
 }
 
+// HNO_MID_ZLAYOUT=0: the planes-only launches and the fused middle keep the [plane][part][k1][k2] intermediate (A/B aid; read once)
+bool mid_zlayout() {
+    static const bool v = !(getenv("HNO_MID_ZLAYOUT") && atoi(getenv("HNO_MID_ZLAYOUT")) == 0);
+    return v;
+}
+static int mid_zlayout_store() {   // 1: plain stores in the forward plane kernel; 2 (A/B): write-through stores as in the old layout
+    static const int v = (getenv("HNO_MID_ZLAYOUT") && atoi(getenv("HNO_MID_ZLAYOUT")) == 2) ? 2 : 1;
+    return v;
+}
+
 }  // namespace hno
 
 using namespace hno;
@@ -2573,6 +2620,8 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
     a.full0 = full & 1;
     a.full1 = (full >> 1) & 1;
     a.full2 = (full >> 2) & 1;
+    a.zl = planes_only && mid_zlayout() ? mid_zlayout_store() : 0;
+    a.zplanes = (unsigned)(BC * N0);
     const size_t lds = sizeof(float) * plan->f_lds_floats;
     if (lds > kMaxLds) return fail(HNO_ELIMIT, "hno_dht3_crop: plane %dx%d needs %zu B of LDS (> 160 KiB)", N1, N2, lds);
     hipStream_t s = (hipStream_t)stream;
@@ -2764,6 +2813,8 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
     a.full0 = full & 1;
     a.full1 = (full >> 1) & 1;
     a.full2 = (full >> 2) & 1;
+    a.zl = planes_only && mid_zlayout() ? 1 : 0;
+    a.zplanes = (unsigned)(BC * N0);
     const size_t lds = sizeof(float) * plan->i_lds_floats;
     if (lds > kMaxLds) return fail(HNO_ELIMIT, "hno_pad_idht3: plane %dx%d needs %zu B of LDS (> 160 KiB)", N1, N2, lds);
     hipStream_t s = (hipStream_t)stream;

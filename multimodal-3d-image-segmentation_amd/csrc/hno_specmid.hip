@@ -42,6 +42,7 @@ struct MidArgs {
     float *partials;           // backward: one slab of L x C x C weight-gradient partial sums per workgroup
     long long *stamps;         // phase stamps of workgroup 0, wave 0 (debug flag 1024)
     int dbg;                   // timing aids (results wrong): 1 = no forward D arithmetic, 2 = no layers, 4 = no inverse D step, 8 = no loads
+    int zl;                    // layout of ws (hno_dht.hip, DhtArgs.zl): 1 = [k1 position][k2 tile][plane][part][4]
 };
 
 __device__ __forceinline__ int mid_chan(int ks, int h) { return (ks & 3) + 8 * (ks >> 2) + 4 * h; }
@@ -95,7 +96,13 @@ __global__ __launch_bounds__(64 * MID_NW, 1) void spec_mid_kernel(MidArgs a) {
         return;
     }
     const int k1 = k1s - m1;
-    const size_t pstride = (size_t)2 * CP;            // floats per n0 plane
+    // intermediate layout (hno_dht.hip, DhtArgs.zl): 0 = [plane][part][k1 position][16], 1 = [k1 position][k2 tile][plane][part][4]
+    const size_t pstride = a.zl ? (size_t)8 : (size_t)2 * CP;            // floats per n0 plane
+    // float offset of (channel c, plane 0, part, column j) of this workgroup's columns
+    auto col_base = [&](int c, int part_, int j_) -> size_t {
+        if (a.zl) return ((size_t)(k1s * 4 + kt2) * ((size_t)a.B * C * N0) + (size_t)(b * C + c) * N0) * 8 + part_ * 4 + j_;
+        return ((size_t)(b * C + c) * N0) * ((size_t)2 * CP) + (size_t)part_ * CP + k1s * 16 + kt2 * 4 + j_;
+    };
     // column of the D-step tiles held by this lane: j = column of the k2 tile, re / im part, channel within the pair
     const int j = l15 & 3, part = (l15 >> 2) & 1, cloc = l15 >> 3;
     // twiddle A operands in lane order: forward cos / sin [ks], inverse cos / sin [mt][ks]
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(64 * MID_NW, 1) void spec_mid_kernel(MidArgs a) {
         for (int u = 0; u < TPW; ++u) {
             const int t = wave + NW * u;
             const int c = 2 * (t < NCT ? t : 0) + cloc;
-            const float *src = a.ws + ((size_t)(b * C + c) * N0) * pstride + (size_t)part * CP + k1s * 16 + kt2 * 4 + j;
+            const float *src = a.ws + col_base(c, part, j);
 #pragma unroll
             for (int ks = 0; ks < KC; ++ks) {
                 const int n = 4 * ks + q;
@@ -407,7 +414,7 @@ __global__ __launch_bounds__(64 * MID_NW, 1) void spec_mid_kernel(MidArgs a) {
             gs[ks] = in ? (part ? pi + mi_ : pr + mr) : 0.f;
             gd[ks] = in ? (part ? pr - mr : pi - mi_) : 0.f;
         }
-        float *dst = a.ws + ((size_t)(b * C + c) * N0) * pstride + (size_t)part * CP + k1s * 16 + kt2 * 4 + j;
+        float *dst = a.ws + col_base(c, part, j);
         {   // n = 0: cos = 1, sin = 0 -> the plain sum of the cosine coefficients over k0 = over (ks, q)
             float u0 = gs[0];
 #pragma unroll
@@ -456,6 +463,7 @@ struct MidFArgs {
     float scale;               // of the forward D step
     int w_fwd, w_inv;          // c2r weights (2 for k2 > 0) on the forward / inverse D step
     int dbg;
+    int zl;                    // layout of ws, as MidArgs.zl
 };
 
 template <int N0, int M0, bool BWD>
@@ -483,7 +491,11 @@ __global__ __launch_bounds__(512, 1) void spec_mid_fourier_kernel(MidFArgs a) {
         return;
     }
     const int k1 = k1s - m1;
-    const size_t pstride = (size_t)2 * CP;
+    const size_t pstride = a.zl ? (size_t)8 : (size_t)2 * CP;      // (layouts of ws: see spec_mid_kernel)
+    auto col_base = [&](int c, int part_, int j_) -> size_t {
+        if (a.zl) return ((size_t)(k1s * 4 + kt2) * ((size_t)a.B * C * N0) + (size_t)(b * C + c) * N0) * 8 + part_ * 4 + j_;
+        return ((size_t)(b * C + c) * N0) * ((size_t)2 * CP) + (size_t)part_ * CP + k1s * 16 + kt2 * 4 + j_;
+    };
     const int j = l15 & 3, part = (l15 >> 2) & 1, cloc = l15 >> 3;
     float tcF[KC], tsF[KC], tcI[NMT][KI], tsI[NMT][KI];
     {
@@ -528,7 +540,7 @@ __global__ __launch_bounds__(512, 1) void spec_mid_fourier_kernel(MidFArgs a) {
         for (int u = 0; u < TPW; ++u) {
             const int t = wave + 8 * u;
             const int c = 2 * (t < NCT ? t : 0) + cloc;
-            const float *src = a.ws + ((size_t)(b * C + c) * N0) * pstride + (size_t)part * CP + k1s * 16 + kt2 * 4 + j;
+            const float *src = a.ws + col_base(c, part, j);
 #pragma unroll
             for (int ks = 0; ks < KC; ++ks) {
                 const int n = 4 * ks + q;
@@ -682,7 +694,7 @@ __global__ __launch_bounds__(512, 1) void spec_mid_fourier_kernel(MidFArgs a) {
             gs[ks] = in ? (part ? pi + mi_ : pr + mr) : 0.f;
             gd[ks] = in ? (part ? pr - mr : pi - mi_) : 0.f;
         }
-        float *dst = a.ws + ((size_t)(b * C + c) * N0) * pstride + (size_t)part * CP + k1s * 16 + kt2 * 4 + j;
+        float *dst = a.ws + col_base(c, part, j);
         {
             float u0 = gs[0];
 #pragma unroll
@@ -833,6 +845,7 @@ extern "C" int hno_spec_mid_fwd(void *workspace, const float *const *W_layers, f
     a.m2 = m2;
     a.scale = scale;
     a.dbg = debug_flags();
+    a.zl = mid_zlayout() ? 1 : 0;
     a.stamps = (a.dbg & 1024) ? debug_stamp_buffer() : nullptr;
     int rc = mid_twiddles(N0, m0, &a.tw);
     if (rc) return rc;
@@ -874,6 +887,7 @@ extern "C" int hno_spec_mid_bwd(void *workspace, const float *const *W_layers, c
     a.m2 = m2;
     a.scale = scale;
     a.dbg = debug_flags();
+    a.zl = mid_zlayout() ? 1 : 0;
     a.stamps = (a.dbg & 1024) ? debug_stamp_buffer() : nullptr;
     int rc = mid_twiddles(N0, m0, &a.tw);
     if (rc) return rc;
@@ -923,6 +937,7 @@ static int mid_fourier_launch(bool bwd, void *workspace, const float *W2, float 
     a.w_fwd = w_fwd;
     a.w_inv = w_inv;
     a.dbg = debug_flags();
+    a.zl = mid_zlayout() ? 1 : 0;
     int rc = mid_twiddles(N0, m0, &a.tw);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;

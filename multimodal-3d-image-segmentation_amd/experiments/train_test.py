@@ -168,14 +168,16 @@ class SampleSplit:
         return loss
 
 
-def choose_schedule(run_one, run_split, replays=3, agree=None, what=''):
+def choose_schedule(run_one, run_split, replays=5, rounds=3, agree=None, what=''):
     """Measure, do not guess: capture the step's forward + loss + backward in both forms -- one pass over the batch (``run_one()``) and
-    the two half-batches on two streams (``run_split()``) -- into two temporary graphs, replay each once untimed and ``replays`` times
-    timed (HIP events), free them, and return (use_split, ms_one, ms_split).  Nothing but forward / loss / backward may be in the
-    closures (no optimizer, no collective: the replays must not change any state but gradients, which the caller resets).
+    the two half-batches on two streams (``run_split()``) -- into two temporary graphs, warm both up, time ``rounds`` alternating bursts
+    of ``replays`` replays each (HIP events; the minimum per form: clocks and caches settle during the first bursts -- a single cold burst
+    of three replays read 2.49 ms for both forms of a step whose steady state is 2.35 / 2.27 ms), free the graphs, and return
+    (use_split, ms_one, ms_split).  Nothing but forward / loss / backward may be in the closures (no optimizer, no collective: the
+    replays must not change any state but gradients, which the caller resets).
     ``agree``: a callable flag -> flag that makes ranks agree (FlatGradReplica.all_ranks_ok): a rank-local timing decision would give
     the ranks different graphs."""
-    times = []
+    graphs = []
     for fn in (run_one, run_split):
         cur = torch.cuda.current_stream()
         torch.cuda.synchronize()
@@ -188,16 +190,22 @@ def choose_schedule(run_one, run_split, replays=3, agree=None, what=''):
             del out
         cur.wait_stream(side)
         torch.cuda.synchronize()
-        graph.replay()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(replays):
+        graphs.append(graph)
+    for graph in graphs:
+        for _ in range(3):
             graph.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        times.append(e0.elapsed_time(e1) / replays)
-        del graph
+    torch.cuda.synchronize()
+    times = [float('inf'), float('inf')]
+    for _ in range(rounds):
+        for i, graph in enumerate(graphs):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(replays):
+                graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            times[i] = min(times[i], e0.elapsed_time(e1) / replays)
+    del graphs, graph
     use = times[1] < times[0]
     if agree is not None:
         use = bool(agree(use))
