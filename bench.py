@@ -226,15 +226,19 @@ def secondary_configs(pkg, dev):
         torch.cuda.current_stream().wait_stream(side)
         gr.replay()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(replays):
-            gr.replay()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / replays * 1e3
+        ms = float('inf')
+        for _ in range(3):       # the best of three bursts (one burst of ten once read 10.6 ms for a 7.6 ms step on a box of the pool)
+            t0 = time.perf_counter()
+            for _ in range(replays):
+                gr.replay()
+            torch.cuda.synchronize()
+            ms = min(ms, (time.perf_counter() - t0) / replays * 1e3)
         # the step's ALGORITHMIC bytes: what every launch of one eager step declares to the profiler (DESIGN section 4's per-kernel
         # definitions; launches that declare none count as zero, so the sum is a lower bound)
         algo = None
         try:
+            if os.environ.get('HNO_BENCH_SEC_NOALGO'):
+                raise RuntimeError('skipped')
             with pkg._lib.KernelProfile(max_records=4096) as kp:
                 step()
             torch.cuda.synchronize()
