@@ -182,7 +182,12 @@ __global__ __launch_bounds__(64 * UPR_WAVES) void uphead_rows_kernel(UpArgs a, c
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) { sp[k] = sp2[k] = spt[k] = 0.f; st[k] = 0; }
     // rows of this workgroup and of this wave: even split at row granularity (the grid is sized to the residency of the chip)
-    const int wg0 = (int)((long long)nrow * blockIdx.x / gridDim.x), wg1 = (int)((long long)nrow * (blockIdx.x + 1) / gridDim.x);
+    // XCD-aware row ranges (round 5): workgroups go to the 8 XCDs round-robin, and an output row reads the four source rows its
+    // neighbours in y AND in z read too.  With consecutive ranges on consecutive workgroups every XCD touched every source slice and
+    // fetched it into its own L2: 128.6 MB of traffic for 80 MB of algorithmic bytes (profiles/hbm_traffic.json, round 4).  Workgroup
+    // i now takes range (i % 8) * (G / 8) + i / 8: one XCD owns a contiguous eighth of the rows of a sample.
+    const unsigned G = gridDim.x, bx = (G & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (G >> 3) + (blockIdx.x >> 3);
+    const int wg0 = (int)((long long)nrow * bx / G), wg1 = (int)((long long)nrow * (bx + 1) / G);
     const int r0 = wg0 + (wg1 - wg0) * wave / UPR_WAVES, r1 = wg0 + (wg1 - wg0) * (wave + 1) / UPR_WAVES;
     float raw1[KMAX][4], raw2[KMAX][4];
     unsigned l2n = 0;
