@@ -108,15 +108,10 @@ struct PairBatch {
     int count;
 };
 __global__ __launch_bounds__(256) void sum_pairs_kernel(PairBatch pb) {
-    int ei = 0;
-    while (ei + 1 < pb.count && (int)blockIdx.x >= pb.e[ei + 1].first_block) ++ei;   // block-uniform search
-    const PairEntry &e = pb.e[ei];
-    const int i0 = ((int)blockIdx.x - e.first_block) * 1024 + threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = i0 + 256 * j;
-        if (i < e.n) e.dst[i] = e.scale * (e.a[i] + e.b[i]);
-    }
+    // one workgroup per tensor (the tensors of a model are small: the largest of HNOSeg-XS has 1 152 elements).  The first version mapped
+    // 1 024-element blocks to entries by a linear search through the kernel arguments: 13.8 us for 28 k elements, all of it the search.
+    const PairEntry &e = pb.e[blockIdx.x];
+    for (int i = threadIdx.x; i < e.n; i += 256) e.dst[i] = e.scale * (e.a[i] + e.b[i]);
 }
 
 }  // namespace hno
@@ -158,22 +153,22 @@ extern "C" int hno_sum_pairs(void *const *dst, const void *const *a, const void 
                              int count, void *stream) {
     HNO_REQUIRE(dst && a && b && n && scale && count > 0, "hno_sum_pairs: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    int i = 0;
-    while (i < count) {
-        PairBatch pb;
+    constexpr long long CHUNK = 1 << 16;      // elements per workgroup: large tensors become several entries
+    PairBatch pb;
+    pb.count = 0;
+    auto flush = [&]() {
+        if (pb.count) hipLaunchKernelGGL(sum_pairs_kernel, dim3(pb.count), dim3(256), 0, s, pb);
         pb.count = 0;
-        int blocks = 0;
-        while (i < count && pb.count < HNO_MAX_PAIRS) {
-            HNO_REQUIRE(dst[i] && a[i] && b[i] && n[i] >= 0 && n[i] < (1ll << 31) - 1024, "hno_sum_pairs: bad entry");
-            if (n[i] == 0) { ++i; continue; }
-            PairEntry e{(float *)dst[i], (const float *)a[i], (const float *)b[i], (int)n[i], blocks, scale[i], 0};
-            blocks += ceil_div((int)n[i], 1024);
-            pb.e[pb.count++] = e;
-            ++i;
+    };
+    for (int i = 0; i < count; ++i) {
+        HNO_REQUIRE(dst[i] && a[i] && b[i] && n[i] >= 0, "hno_sum_pairs: bad entry");
+        for (long long off = 0; off < n[i]; off += CHUNK) {
+            const long long m = n[i] - off < CHUNK ? n[i] - off : CHUNK;
+            pb.e[pb.count++] = PairEntry{(float *)dst[i] + off, (const float *)a[i] + off, (const float *)b[i] + off, (int)m, 0, scale[i], 0};
+            if (pb.count == HNO_MAX_PAIRS) flush();
         }
-        if (pb.count == 0) break;
-        hipLaunchKernelGGL(sum_pairs_kernel, dim3(blocks), dim3(256), 0, s, pb);
     }
+    flush();
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }

@@ -1907,6 +1907,30 @@ def test_small_helper_kernels(pkg):
     assert rel_err(out[:, 5:].cpu().numpy(), yc.imag.cpu().numpy()) < 1e-5
 
 
+def test_sum_pairs_joins_tensor_sets(pkg):
+    """ops.sum_pairs (hno_sum_pairs, round 5): dst = scale * (a + b) for a list of tensors in one launch per 64 entries -- the join of the
+    two half-batch passes of a captured step (gradients in place, the loss with scale 0.5).  Sizes from one element to several chunks,
+    more than 64 tensors, dst aliasing a; bit-exact against the same fp32 arithmetic in torch."""
+    from multimodal_3d_image_segmentation_amd import ops
+    torch.manual_seed(0)
+    sizes = [1, 7, 256, 1152, 4096, 65536, 65537, 200001] + [24 * 24] * 70
+    a = [torch.randn(n, device='cuda') for n in sizes]
+    b = [torch.randn(n, device='cuda') for n in sizes]
+    want = [(x + y) for x, y in zip(a, b)]
+    l0, l1 = torch.tensor(0.25, device='cuda'), torch.tensor(0.75, device='cuda')
+    loss = torch.empty((), device='cuda')
+    ops.sum_pairs([(x, x, y, 1.0) for x, y in zip(a, b)] + [(loss, l0, l1, 0.5)])
+    torch.cuda.synchronize()
+    for x, w in zip(a, want):
+        assert torch.equal(x, w)
+    assert float(loss) == 0.5
+    out, u, v = torch.empty(1000, device='cuda'), torch.randn(1000, device='cuda'), torch.randn(1000, device='cuda')
+    ops.sum_pairs([(out, u, v, 2.0)])
+    assert torch.equal(out, 2.0 * (u + v))
+    with pytest.raises(AssertionError):
+        ops.sum_pairs([(out, a[0], b[0], 1.0)])
+
+
 def test_limits_fail_loudly(pkg):
     """Sizes outside the fused kernels' limits raise (HNO_ELIMIT / HNO_EINVAL) -- never a silent fallback."""
     from multimodal_3d_image_segmentation_amd import ops
