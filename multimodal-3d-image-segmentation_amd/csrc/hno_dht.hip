@@ -283,6 +283,7 @@ struct DhtArgs {
     // instead of one 128-byte line each (its D steps: 20.4 -> 16 us forward, 27.8 -> 23.3 us backward at the benchmark size)
     int zl;
     unsigned zplanes;   // BC * N0
+    int inv_prefetch;   // inverse item kernel: operands of the next item requested one item ahead (HNO_INV_PREFETCH)
 };
 
 // float offset of element (part, k1 position `row` in [0, K1S), column k2) of intermediate plane `plane`
@@ -2271,6 +2272,8 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const f
     // (Staggering the four waves of a SIMD by n x 1 024 cycles -- one computes while the others store -- was measured: 34.7 us at
     // n = 0, 35.3 / 36.1 / 38.2 at n = 1 / 3 / 8 without residual; with residual 38.5 -> 36.9 at n = 3.  Not kept.)
     int it = 0;
+    const bool pf = a.inv_prefetch != 0;     // the next item's operands are requested as soon as this item's are folded
+    if (pf && t < t_end) load_e(t);
     for (; t < t_end; t += NWV, ++it) {
         HNO_STAMP(a.stamps, 24 + it * 6);
         const int plane = NP == 2 ? (t >> 1) : t;
@@ -2289,7 +2292,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const f
         const int c1_r0 = 49, c1_lo = 1112;
         const unsigned fA = f0 + (unsigned)(c0_r0 * N2), fC = f0 + 49u * N2;
         const unsigned shA = fA & 3u, shC = fC & 3u;
-        load_e(t);
+        if (!pf) load_e(t);
         // ---- folds of the +-k1 rows
         float sR[KM1], dR[KM1], sI[KM1], dI[KM1];
 #pragma unroll
@@ -2300,6 +2303,8 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const f
             sI[ks] = ok ? eip[ks] + eim[ks] : 0.f;
             dI[ks] = ok ? eip[ks] - eim[ks] : 0.f;
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (pf && t + NWV < t_end) load_e(t + NWV);
         __builtin_amdgcn_sched_barrier(0);
         if (a.stamps) asm volatile("s_nop 0" ::"v"(sR[0]), "v"(dI[KM1 - 1]));
         if (HAS_ADD) {
@@ -2622,6 +2627,7 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
     a.full2 = (full >> 2) & 1;
     a.zl = planes_only && mid_zlayout() ? mid_zlayout_store() : 0;
     a.zplanes = (unsigned)(BC * N0);
+    a.inv_prefetch = 0;
     const size_t lds = sizeof(float) * plan->f_lds_floats;
     if (lds > kMaxLds) return fail(HNO_ELIMIT, "hno_dht3_crop: plane %dx%d needs %zu B of LDS (> 160 KiB)", N1, N2, lds);
     hipStream_t s = (hipStream_t)stream;
@@ -2815,6 +2821,7 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
     a.full2 = (full >> 2) & 1;
     a.zl = planes_only && mid_zlayout() ? 1 : 0;
     a.zplanes = (unsigned)(BC * N0);
+    { static const int pfv = getenv("HNO_INV_PREFETCH") ? atoi(getenv("HNO_INV_PREFETCH")) : 1; a.inv_prefetch = pfv; }   // (round 5: -0.7 us per launch of the residual variant on a box where operand latency is long; HNO_INV_PREFETCH=0: A/B)
     const size_t lds = sizeof(float) * plan->i_lds_floats;
     if (lds > kMaxLds) return fail(HNO_ELIMIT, "hno_pad_idht3: plane %dx%d needs %zu B of LDS (> 160 KiB)", N1, N2, lds);
     hipStream_t s = (hipStream_t)stream;
