@@ -539,6 +539,56 @@ def g7v_vnet_models():
     save('g7v_vnet_models.npz', **out)
 
 
+# ------------------------- G15: BASELINE cfg3 (FNOSeg, 24 Fourier blocks) at its REAL volume size, fp32 and under bf16 autocast
+def g15_cfg3_full_size():
+    """The reference's NeuralOperatorSeg(4, 4, 24, 24, (10, 14, 14), 'Fourier') (config_fnoseg.ini:46-52) on one (1, 4, 128^3) formula
+    volume: 4 096 sampled outputs, output sum, loss and all 71 184 parameter gradients, in fp32, under
+    torch.autocast('cpu', bfloat16) (train_test.py:154-160) and with the reference run in float64.  Until round 5 the full-size cfg3 test compared the bf16 kernels with the
+    repo's own fp32 kernels only; with this fixture it is anchored to the reference at the benchmark's own size.  A batch of 2 is the same
+    volume stacked (PCC is a mean over (b, c))."""
+    torch.manual_seed(0)
+    model = nets.NeuralOperatorSeg(4, 4, 24, 24, (10, 14, 14), 'Fourier')
+    out = {}
+    for k, v in model.state_dict().items():
+        out[f'sd::{k}'] = v.detach().numpy().copy()
+    shape = (1, 4, 128, 128, 128)
+    x = T(formula_tensor(shape, 7))
+    lab = formula_labels((1, 1) + shape[2:], 4, 5)
+    onehot = torch.movedim(torch.nn.functional.one_hot(T(lab)[:, 0].long(), 4).float(), -1, 1)
+    idx = None
+    for tag in ('f32', 'bf16'):
+        model.zero_grad()
+        if tag == 'bf16':
+            with torch.autocast(device_type='cpu', dtype=torch.bfloat16):
+                y = model(x)
+                loss = custom_losses.PCCLoss()(y, onehot)
+        else:
+            y = model(x)
+            loss = custom_losses.PCCLoss()(y, onehot)
+        loss.backward()
+        if idx is None:
+            idx = sample_indices(y.numel(), 4096, 2)
+            out['shape'], out['y_idx'] = np.array(shape), idx
+        out[f'{tag}::y'] = y.detach().float().numpy().ravel()[idx]
+        out[f'{tag}::y_sum'] = np.array(y.detach().double().sum().item())
+        out[f'{tag}::loss'] = loss.detach().float().numpy()
+        for k, p in model.named_parameters():
+            out[f'{tag}::grad::{k}'] = p.grad.detach().float().numpy().copy()
+        del y, loss
+    # ... and with the reference run in float64: the truth both fp32 evaluations (the reference's and the kernels') are measured against
+    import copy
+    m64 = copy.deepcopy(model).double()
+    m64.zero_grad()
+    y64 = m64(x.double())
+    loss64 = custom_losses.PCCLoss()(y64, onehot.double())
+    loss64.backward()
+    out['f64::y'] = y64.detach().numpy().ravel()[idx].astype(np.float32)
+    out['f64::loss'] = loss64.detach().numpy()
+    for k, p in m64.named_parameters():
+        out[f'f64::grad::{k}'] = p.grad.detach().numpy().astype(np.float32)
+    save('g15_cfg3_full_size.npz', **out)
+
+
 # ------------------------- G7b: the reference under torch.autocast(bfloat16) (train_test.py:154-160), beside its fp32 run
 def g7b_bf16_models():
     """What `use_autocast` does to each model family on the reference itself (CPU autocast, bfloat16: convolutions take bf16
@@ -652,7 +702,7 @@ def g14_testing():
 
 if __name__ == '__main__':
     ALL = [g1_dht, g2_crop_pad, g3_operators, g4_mha, g5_losses, g6_hnosegxs, g6_128, g6s_small_models, g6b_xsblock_branch, g7_noseg_models,
-           g7v_vnet_models, g7b_bf16_models, g9_misc, g10_two_d, g11_input, g12_mha_bias, g13_models_2d, g8_training, g14_testing]
+           g7v_vnet_models, g7b_bf16_models, g15_cfg3_full_size, g9_misc, g10_two_d, g11_input, g12_mha_bias, g13_models_2d, g8_training, g14_testing]
     only = set(sys.argv[2:])   # e.g. `make_golden.py /root/reference g10_two_d` regenerates one fixture
     for fn in ALL:
         if not only or fn.__name__ in only:

@@ -250,6 +250,29 @@ def test_noseg_models_oracle(name):
         assert rel_err(_np(p.grad), g[f'{name}::grad::{k}']) < 1e-4, k
 
 
+def test_cfg3_full_size_oracle():
+    """BASELINE cfg3 at its real volume size (golden G15: the reference's FNOSeg, 24 Fourier blocks, on one 4 x 128^3 volume): the oracle's
+    fp32 outputs, loss and all 71 184 gradients against the reference's fp32 run.  (~30 s of CPU time: the largest case of the CPU suite.)"""
+    g = load_golden('g15_cfg3_full_size.npz')
+    params = {k[4:]: T(g[k]).requires_grad_(True) for k in g.files if k.startswith('sd::')}
+    shape = tuple(int(v) for v in g['shape'])
+    x = T(formula_tensor(shape, 7))
+    lab = T(formula_labels((1, 1) + shape[2:], 4, 5))
+    y = O.neural_operator_seg_forward(params, x, 24, (10, 14, 14), 'Fourier')
+    loss = O.pcc_loss(y, O.to_categorical(lab, 4))
+    loss.backward()
+    assert rel_err(_np(y).ravel()[g['y_idx']], g['f32::y']) < 2e-5
+    assert abs(float(y.detach().double().sum()) - float(g['f32::y_sum'])) / float(g['f32::y_sum']) < 1e-6
+    assert abs(float(loss.detach()) - float(g['f32::loss'])) < 1e-6
+    num = den = 0.0
+    for k, p in params.items():
+        if f'f32::grad::{k}' in g.files:
+            ref = g[f'f32::grad::{k}'].astype(np.float64)
+            num += ((_np(p.grad).astype(np.float64) - ref) ** 2).sum()
+            den += (ref ** 2).sum()
+    assert den > 0 and np.sqrt(num / den) < 1e-4
+
+
 from _inputs import MHA_CASES  # noqa: E402
 
 
