@@ -589,6 +589,62 @@ def g15_cfg3_full_size():
     save('g15_cfg3_full_size.npz', **out)
 
 
+# ------------------------- G16: BASELINE cfg4 (V-Net-DS, 22.5 M parameters) at its REAL volume size, fp32 / bf16 autocast / float64
+def g16_cfg4_full_size():
+    """The reference's VNetDS(4, 4, 24, [1, 2, 3, 3, 3], right_leg_indexes=[0..4]) (config_vnet-ds.ini:46-51) on one (1, 4, 160, 192, 128)
+    formula volume: 4 096 sampled outputs, output sum, loss, and of the gradients (22.5 M values: too many to store) per parameter tensor
+    its L2 norm and 512 sampled elements -- in fp32, under torch.autocast('cpu', bfloat16) and with the reference run in float64.  The
+    weights are the constructor's under torch.manual_seed(0) (this package's constructors draw the same values: RNG-identical init); the
+    fixture holds per-tensor sums and 8 sampled values so that the test can prove it before it compares anything."""
+    import copy
+    torch.manual_seed(0)
+    model = nets.VNetDS(4, 4, 24, [1, 2, 3, 3, 3], right_leg_indexes=[0, 1, 2, 3, 4])
+    out = {}
+    names = [k for k, _ in model.named_parameters()]
+    out['param_names'] = np.array(names)
+    out['param_sum'] = np.array([float(p.detach().double().sum()) for _, p in model.named_parameters()])
+    out['param_head'] = np.stack([np.resize(p.detach().numpy().ravel()[:8], 8) for _, p in model.named_parameters()])
+    shape = (1, 4, 160, 192, 128)
+    x = T(formula_tensor(shape, 9))
+    lab = formula_labels((1, 1) + shape[2:], 4, 3)
+    onehot = torch.movedim(torch.nn.functional.one_hot(T(lab)[:, 0].long(), 4).float(), -1, 1)
+    idx = None
+    gidx = {k: sample_indices(p.numel(), 512, 5) for k, p in model.named_parameters()}
+
+    def record(tag, m, y, loss):
+        nonlocal idx
+        if idx is None:
+            idx = sample_indices(y.numel(), 4096, 2)
+            out['shape'], out['y_idx'] = np.array(shape), idx
+        out[f'{tag}::y'] = y.detach().float().numpy().ravel()[idx]
+        out[f'{tag}::y_sum'] = np.array(y.detach().double().sum().item())
+        out[f'{tag}::loss'] = np.array(float(loss.detach()))
+        out[f'{tag}::grad_norm'] = np.array([float(p.grad.detach().double().norm()) for _, p in m.named_parameters()])
+        out[f'{tag}::grad_samples'] = np.concatenate([p.grad.detach().float().numpy().ravel()[gidx[k]] for k, p in m.named_parameters()])
+    out['grad_sample_counts'] = np.array([len(gidx[k]) for k in names])
+    for tag in ('f32', 'bf16'):
+        model.zero_grad()
+        if tag == 'bf16':
+            with torch.autocast(device_type='cpu', dtype=torch.bfloat16):
+                y = model(x)
+                loss = custom_losses.PCCLoss()(y, onehot)
+        else:
+            y = model(x)
+            loss = custom_losses.PCCLoss()(y, onehot)
+        loss.backward()
+        record(tag, model, y, loss)
+        del y, loss
+    m64 = nets.VNetDS(4, 4, 24, [1, 2, 3, 3, 3], right_leg_indexes=[0, 1, 2, 3, 4])     # (the model keeps activations as attributes: no deepcopy)
+    m64.load_state_dict(model.state_dict())
+    m64 = m64.double()
+    m64.zero_grad()
+    y64 = m64(x.double())
+    loss64 = custom_losses.PCCLoss()(y64, onehot.double())
+    loss64.backward()
+    record('f64', m64, y64, loss64)
+    save('g16_cfg4_full_size.npz', **out)
+
+
 # ------------------------- G7b: the reference under torch.autocast(bfloat16) (train_test.py:154-160), beside its fp32 run
 def g7b_bf16_models():
     """What `use_autocast` does to each model family on the reference itself (CPU autocast, bfloat16: convolutions take bf16
@@ -702,7 +758,7 @@ def g14_testing():
 
 if __name__ == '__main__':
     ALL = [g1_dht, g2_crop_pad, g3_operators, g4_mha, g5_losses, g6_hnosegxs, g6_128, g6s_small_models, g6b_xsblock_branch, g7_noseg_models,
-           g7v_vnet_models, g7b_bf16_models, g15_cfg3_full_size, g9_misc, g10_two_d, g11_input, g12_mha_bias, g13_models_2d, g8_training, g14_testing]
+           g7v_vnet_models, g7b_bf16_models, g15_cfg3_full_size, g16_cfg4_full_size, g9_misc, g10_two_d, g11_input, g12_mha_bias, g13_models_2d, g8_training, g14_testing]
     only = set(sys.argv[2:])   # e.g. `make_golden.py /root/reference g10_two_d` regenerates one fixture
     for fn in ALL:
         if not only or fn.__name__ in only:
