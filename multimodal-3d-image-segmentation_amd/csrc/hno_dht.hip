@@ -283,7 +283,6 @@ struct DhtArgs {
     // instead of one 128-byte line each (its D steps: 20.4 -> 16 us forward, 27.8 -> 23.3 us backward at the benchmark size)
     int zl;
     unsigned zplanes;   // BC * N0
-    int inv_prefetch;   // inverse item kernel: operands of the next item requested one item ahead (HNO_INV_PREFETCH)
 };
 
 // float offset of element (part, k1 position `row` in [0, K1S), column k2) of intermediate plane `plane`
@@ -1050,7 +1049,7 @@ __device__ __forceinline__ void store16_wt(float *ptr, f32x4 v) {
 }
 
 // ABL: timing ablations (results wrong): 1 = a VALU op in place of every MFMA, 2 = no LDS operand reads
-template <int KC2, int KS2, int NP, int NWV, int ABL = 0>
+template <int KC2, int KS2, int NP, int NWV, int ABL = 0, int ZL = 0>   // ZL: DhtArgs.zl at compile time (0 rows, 1 z-layout / plain stores, 2 z-layout / write-through)
 __global__ __launch_bounds__(64 * NWV, 2) void dht_fwd_plane_dma_kernel(const float *__restrict__ xal, float *__restrict__ Y, DhtArgs a,
                                                                         unsigned shift0, unsigned max_off, int pl_base, int pl_rem,
                                                                         unsigned ldbc) {
@@ -1169,6 +1168,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void dht_fwd_plane_dma_kernel(const fl
     __builtin_amdgcn_sched_barrier(0);
     HNO_STAMP(a.stamps, 22);
     const bool q0 = q == 0;
+    // z-layout: float offsets of this lane's two 32-byte pieces (rows m +- k1, k2 tile q) of plane 0; a plane adds 8 floats
+    const size_t zoff_p = ((size_t)((a1.m + (l15 <= a1.m ? l15 : 0)) * 4 + q) * a.zplanes) * 8;
+    const size_t zoff_m = ((size_t)((a1.m - (l15 <= a1.m ? l15 : 0)) * 4 + q) * a.zplanes) * 8;
     // plane rows of item (plane, X) in its slot: row r of the plane at rowsP + r N2 (rows of the tile) / rowsM + r N2 (mirror rows)
     auto item_rows = [&](int pl, int X, int slot, const float *&rowsP, const float *&rowsM) {
         const unsigned g0 = plane_f0(pl);
@@ -1387,24 +1389,32 @@ __global__ __launch_bounds__(64 * NWV, 2) void dht_fwd_plane_dma_kernel(const fl
                     vm1[r] = qA[r] - pB[r];
                 }
                 const int k2 = q * 4;
-                // write-through stores: the 11.6 MB of Y would otherwise sit dirty in the L2s until the end-of-kernel write-back
-                if (a.zl == 1) {   // plain stores: the XCD's L2 merges the 32-byte pieces of neighbouring planes into lines (write-through
-                                   // pieces, HNO_MID_ZLAYOUT=2, cost this kernel 4.4 us: 19.3 against 23.7 us per launch in the step)
-                    float *d0 = Y + ymid(a, plane, 0, a1.m + k1, k2);
+                if constexpr (ZL == 1) {
+                    // z-layout, plain stores: the XCD's L2 merges the 32-byte pieces of neighbouring planes into lines (write-through
+                    // pieces, HNO_MID_ZLAYOUT=2, cost this kernel 4.4 us: 19.3 against 23.7 us per launch in the step)
+                    float *d0 = Y + zoff_p + (size_t)plane * 8, *d1 = Y + zoff_m + (size_t)plane * 8;
                     *reinterpret_cast<f32x4 *>(d0) = vp0;
                     *reinterpret_cast<f32x4 *>(d0 + 4) = vp1;
                     if (k1 >= 1) {
-                        float *d1 = Y + ymid(a, plane, 0, a1.m - k1, k2);
                         *reinterpret_cast<f32x4 *>(d1) = vm0;
                         *reinterpret_cast<f32x4 *>(d1 + 4) = vm1;
                     }
+                } else if constexpr (ZL == 2) {
+                    float *d0 = Y + zoff_p + (size_t)plane * 8, *d1 = Y + zoff_m + (size_t)plane * 8;
+                    store16_wt(d0, vp0);
+                    store16_wt(d0 + 4, vp1);
+                    if (k1 >= 1) {
+                        store16_wt(d1, vm0);
+                        store16_wt(d1 + 4, vm1);
+                    }
                 } else {
-                store16_wt(Y + ymid(a, plane, 0, a1.m + k1, k2), vp0);
-                store16_wt(Y + ymid(a, plane, 1, a1.m + k1, k2), vp1);
-                if (k1 >= 1) {
-                    store16_wt(Y + ymid(a, plane, 0, a1.m - k1, k2), vm0);
-                    store16_wt(Y + ymid(a, plane, 1, a1.m - k1, k2), vm1);
-                }
+                    // write-through stores: the 11.6 MB of Y would otherwise sit dirty in the L2s until the end-of-kernel write-back
+                    store16_wt(Y + ymid(a, plane, 0, a1.m + k1, k2), vp0);
+                    store16_wt(Y + ymid(a, plane, 1, a1.m + k1, k2), vp1);
+                    if (k1 >= 1) {
+                        store16_wt(Y + ymid(a, plane, 0, a1.m - k1, k2), vm0);
+                        store16_wt(Y + ymid(a, plane, 1, a1.m - k1, k2), vm1);
+                    }
                 }
             }
         }
@@ -2179,7 +2189,8 @@ __global__ __launch_bounds__(256, 3) void dht_inv_plane_spec_kernel(const float 
 //     group of a chunk are written element-wise;
 //   * twelve waves per CU (three per SIMD): while one wave's MFMAs hold the matrix pipe the others run their epilogues.
 // Requires N1 = 32 NP + 1 (NP = 1, 2), N2 = 16 NT2 * 2 + 1, one k tile per axis, out (and addend) 4-byte aligned with equal 16-byte phase.
-template <int NP, int N2c, int KM1, int NT2, bool HAS_ADD, int NWV>
+template <int NP, int N2c, int KM1, int NT2, bool HAS_ADD, int NWV, bool ZL>   // ZL: layout of the intermediate (DhtArgs.zl) at compile time:
+// as a run-time branch per operand load it grew the kernel from 5.6 to 9.0 KB and put a wait behind every load of the row-layout path
 __global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const float *__restrict__ E, const float *__restrict__ add_al,
                                                               float *__restrict__ out_al, DhtArgs a, unsigned shift0, int it_base,
                                                               int it_rem, unsigned ldbc) {
@@ -2253,7 +2264,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const f
             const int k1 = 4 * ks + q;
             const bool ok = k1 <= m1;
             const int rp = ok ? m1 + k1 : m1, rm = ok ? m1 - k1 : m1;
-            if (a.zl) {
+            if constexpr (ZL) {
                 const size_t op = ((size_t)(rp * 4 + (l15 >> 2)) * a.zplanes + pl) * 8 + (l15 & 3);
                 const size_t om = ((size_t)(rm * 4 + (l15 >> 2)) * a.zplanes + pl) * 8 + (l15 & 3);
                 erp[ks] = E[op];
@@ -2272,7 +2283,9 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dht_inv_item_kernel(const f
     // (Staggering the four waves of a SIMD by n x 1 024 cycles -- one computes while the others store -- was measured: 34.7 us at
     // n = 0, 35.3 / 36.1 / 38.2 at n = 1 / 3 / 8 without residual; with residual 38.5 -> 36.9 at n = 3.  Not kept.)
     int it = 0;
-    const bool pf = a.inv_prefetch != 0;     // the next item's operands are requested as soon as this item's are folded
+    // the next item's operands are requested as soon as this item's are folded (round 5: -0.7 us per launch of the residual variant on
+    // boxes where the operand round trip is long)
+    constexpr bool pf = true;
     if (pf && t < t_end) load_e(t);
     for (; t < t_end; t += NWV, ++it) {
         HNO_STAMP(a.stamps, 24 + it * 6);
@@ -2627,7 +2640,6 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
     a.full2 = (full >> 2) & 1;
     a.zl = planes_only && mid_zlayout() ? mid_zlayout_store() : 0;
     a.zplanes = (unsigned)(BC * N0);
-    a.inv_prefetch = 0;
     const size_t lds = sizeof(float) * plan->f_lds_floats;
     if (lds > kMaxLds) return fail(HNO_ELIMIT, "hno_dht3_crop: plane %dx%d needs %zu B of LDS (> 160 KiB)", N1, N2, lds);
     hipStream_t s = (hipStream_t)stream;
@@ -2686,11 +2698,17 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
         const unsigned max_off = (unsigned)((((size_t)shift0 + (size_t)(BC - 1) * ldbc + (size_t)vol) * 4 - 1) & ~(size_t)15); \
         constexpr int NWV = 8;                                                                                             \
         auto kern = (a.dbg & 2) ? dht_fwd_plane_dma_kernel<KC2, KS2, NP, NWV, 1>                                          \
-                                : (a.dbg & 4) ? dht_fwd_plane_dma_kernel<KC2, KS2, NP, NWV, 2> : dht_fwd_plane_dma_kernel<KC2, KS2, NP, NWV, 0>; \
+                                : (a.dbg & 4) ? dht_fwd_plane_dma_kernel<KC2, KS2, NP, NWV, 2>                            \
+                                : a.zl == 1 ? dht_fwd_plane_dma_kernel<KC2, KS2, NP, NWV, 0, 1>                           \
+                                : a.zl == 2 ? dht_fwd_plane_dma_kernel<KC2, KS2, NP, NWV, 0, 2> : dht_fwd_plane_dma_kernel<KC2, KS2, NP, NWV, 0>; \
         const size_t lds_w = (size_t)NWV * 2 * (NP == 2 ? 10 : 5) * 1024;                                                  \
         static int attr = -1;                                                                                          \
         if (attr != current_device() || (a.dbg & 6)) {                                                                                        \
             HNO_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds)); \
+            /* (every layout variant of this size: the selection above changes from launch to launch) */                  \
+            HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_dma_kernel<KC2, KS2, NP, NWV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds)); \
+            HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_dma_kernel<KC2, KS2, NP, NWV, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds)); \
+            HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_plane_dma_kernel<KC2, KS2, NP, NWV, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds)); \
             attr = current_device();                                                                                                   \
         }                                                                                                                  \
         static const int gforce = getenv("HNO_FWD_GRID") ? atoi(getenv("HNO_FWD_GRID")) : 0;                               \
@@ -2764,6 +2782,10 @@ static int item_small_limit() {
     return v;
 }
 
+template <int NP, int N2c, int KM1, int NT2, int NWV, bool ZL>
+static int inv_item_launch_z(const void *workspace, const float *add_al, float *out_al, const DhtArgs &a, unsigned shift0, int items,
+                             long long ldbc, hipStream_t s, size_t lds_w, int gw);
+
 template <int NP, int N2c, int KM1, int NT2, int NWV>
 static int inv_item_launch(const void *workspace, const float *addend, float *out, const DhtArgs &a, unsigned shift0, int items,
                            long long ldbc, hipStream_t s) {
@@ -2771,8 +2793,16 @@ static int inv_item_launch(const void *workspace, const float *addend, float *ou
     const float *add_al = addend ? addend - shift0 : nullptr;
     const size_t lds_w = sizeof(float) * NWV * ((NP == 2 ? 2176 : round_up_c((32 * NP + 1) * N2c + 4, 64)) + 64);
     const int gw = items < 256 * NWV ? (items + NWV - 1) / NWV : 256;
+    if (a.zl) return inv_item_launch_z<NP, N2c, KM1, NT2, NWV, true>(workspace, add_al, out_al, a, shift0, items, ldbc, s, lds_w, gw);
+    return inv_item_launch_z<NP, N2c, KM1, NT2, NWV, false>(workspace, add_al, out_al, a, shift0, items, ldbc, s, lds_w, gw);
+}
+
+template <int NP, int N2c, int KM1, int NT2, int NWV, bool ZL>
+static int inv_item_launch_z(const void *workspace, const float *add_al, float *out_al, const DhtArgs &a, unsigned shift0, int items,
+                             long long ldbc, hipStream_t s, size_t lds_w, int gw) {
+    const float *addend = add_al;
     if (addend) {
-        auto kern = dht_inv_item_kernel<NP, N2c, KM1, NT2, true, NWV>;
+        auto kern = dht_inv_item_kernel<NP, N2c, KM1, NT2, true, NWV, ZL>;
         static int attr = -1;
         if (attr != current_device()) {
             HNO_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
@@ -2781,7 +2811,7 @@ static int inv_item_launch(const void *workspace, const float *addend, float *ou
         hipLaunchKernelGGL(kern, dim3(gw), dim3(64 * NWV), lds_w, s, (const float *)workspace, add_al, out_al, a, shift0, items / gw, items % gw,
                            (unsigned)ldbc);
     } else {
-        auto kern = dht_inv_item_kernel<NP, N2c, KM1, NT2, false, NWV>;
+        auto kern = dht_inv_item_kernel<NP, N2c, KM1, NT2, false, NWV, ZL>;
         static int attr = -1;
         if (attr != current_device()) {
             HNO_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
@@ -2821,7 +2851,6 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
     a.full2 = (full >> 2) & 1;
     a.zl = planes_only && mid_zlayout() ? 1 : 0;
     a.zplanes = (unsigned)(BC * N0);
-    { static const int pfv = getenv("HNO_INV_PREFETCH") ? atoi(getenv("HNO_INV_PREFETCH")) : 1; a.inv_prefetch = pfv; }   // (round 5: -0.7 us per launch of the residual variant on a box where operand latency is long; HNO_INV_PREFETCH=0: A/B)
     const size_t lds = sizeof(float) * plan->i_lds_floats;
     if (lds > kMaxLds) return fail(HNO_ELIMIT, "hno_pad_idht3: plane %dx%d needs %zu B of LDS (> 160 KiB)", N1, N2, lds);
     hipStream_t s = (hipStream_t)stream;

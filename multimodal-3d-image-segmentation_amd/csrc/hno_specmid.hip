@@ -58,7 +58,7 @@ __device__ __forceinline__ int mid_chan(int ks, int h) { return (ks & 3) + 8 * (
 // waves (phase 1 ended when the two-tile waves did).  12 waves = one tile each, three waves per SIMD; one workgroup per CU either way
 // (232 workgroups at the benchmark size).
 #define MID_NW 12
-template <int N0, int M0, bool BWD>
+template <int N0, int M0, bool BWD, bool ZLAY>   // ZLAY: layout of the intermediate (MidArgs.zl) at compile time: plane stride 8 floats -> immediate offsets
 __global__ __launch_bounds__(64 * MID_NW, 1) void spec_mid_kernel(MidArgs a) {
     constexpr int NW = MID_NW, NTH = 64 * NW;          // waves per workgroup: one D-step column tile per wave (NCT = 12)
     constexpr int C = 24, NK = 12, J = N0 / 2, K0 = M0 + 1;
@@ -97,10 +97,10 @@ __global__ __launch_bounds__(64 * MID_NW, 1) void spec_mid_kernel(MidArgs a) {
     }
     const int k1 = k1s - m1;
     // intermediate layout (hno_dht.hip, DhtArgs.zl): 0 = [plane][part][k1 position][16], 1 = [k1 position][k2 tile][plane][part][4]
-    const size_t pstride = a.zl ? (size_t)8 : (size_t)2 * CP;            // floats per n0 plane
+    const size_t pstride = ZLAY ? (size_t)8 : (size_t)2 * CP;            // floats per n0 plane
     // float offset of (channel c, plane 0, part, column j) of this workgroup's columns
     auto col_base = [&](int c, int part_, int j_) -> size_t {
-        if (a.zl) return ((size_t)(k1s * 4 + kt2) * ((size_t)a.B * C * N0) + (size_t)(b * C + c) * N0) * 8 + part_ * 4 + j_;
+        if constexpr (ZLAY) return ((size_t)(k1s * 4 + kt2) * ((size_t)a.B * C * N0) + (size_t)(b * C + c) * N0) * 8 + part_ * 4 + j_;
         return ((size_t)(b * C + c) * N0) * ((size_t)2 * CP) + (size_t)part_ * CP + k1s * 16 + kt2 * 4 + j_;
     };
     // column of the D-step tiles held by this lane: j = column of the k2 tile, re / im part, channel within the pair
@@ -466,7 +466,7 @@ struct MidFArgs {
     int zl;                    // layout of ws, as MidArgs.zl
 };
 
-template <int N0, int M0, bool BWD>
+template <int N0, int M0, bool BWD, bool ZLAY>
 __global__ __launch_bounds__(512, 1) void spec_mid_fourier_kernel(MidFArgs a) {
     constexpr int C = 24, C2 = 48, NK = 24, J = N0 / 2, K0 = M0 + 1;
     constexpr int KC = (J + 1 + 3) / 4, KI = (K0 + 3) / 4, NMT = (J + 15) / 16;
@@ -491,9 +491,9 @@ __global__ __launch_bounds__(512, 1) void spec_mid_fourier_kernel(MidFArgs a) {
         return;
     }
     const int k1 = k1s - m1;
-    const size_t pstride = a.zl ? (size_t)8 : (size_t)2 * CP;      // (layouts of ws: see spec_mid_kernel)
+    const size_t pstride = ZLAY ? (size_t)8 : (size_t)2 * CP;      // (layouts of ws: see spec_mid_kernel)
     auto col_base = [&](int c, int part_, int j_) -> size_t {
-        if (a.zl) return ((size_t)(k1s * 4 + kt2) * ((size_t)a.B * C * N0) + (size_t)(b * C + c) * N0) * 8 + part_ * 4 + j_;
+        if constexpr (ZLAY) return ((size_t)(k1s * 4 + kt2) * ((size_t)a.B * C * N0) + (size_t)(b * C + c) * N0) * 8 + part_ * 4 + j_;
         return ((size_t)(b * C + c) * N0) * ((size_t)2 * CP) + (size_t)part_ * CP + k1s * 16 + kt2 * 4 + j_;
     };
     const int j = l15 & 3, part = (l15 >> 2) & 1, cloc = l15 >> 3;
@@ -855,7 +855,7 @@ extern "C" int hno_spec_mid_fwd(void *workspace, const float *const *W_layers, f
     const size_t lds = sizeof(float) * mid_lds_floats(m0, 0, false);
     {
         ProfScope _ps(KID_SPEC_MID_FWD, s, 4.0 * B * C * (2.0 * N0 * 2 * (2 * m1 + 1) * 16 + (L + 1) * 8.0 * m0 * m1 * m2));
-#define X(n) if (N0 == n) hipLaunchKernelGGL((spec_mid_kernel<n, 10, false>), grid, dim3(64 * MID_NW), lds, s, a);
+#define X(n) if (N0 == n) { if (a.zl) hipLaunchKernelGGL((spec_mid_kernel<n, 10, false, true>), grid, dim3(64 * MID_NW), lds, s, a); else hipLaunchKernelGGL((spec_mid_kernel<n, 10, false, false>), grid, dim3(64 * MID_NW), lds, s, a); }
         HNO_MID_N0_LIST(X)
 #undef X
     }
@@ -898,13 +898,13 @@ extern "C" int hno_spec_mid_bwd(void *workspace, const float *const *W_layers, c
                     hno_spec_mid_bwd_workspace_bytes(B, C, m1, L));
     const size_t lds = sizeof(float) * mid_lds_floats(m0, L, true);
     if (mid_attr_needed(0)) {   // once per device
-#define X(n) HNO_CHECK_HIP(hipFuncSetAttribute((const void *)spec_mid_kernel<n, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define X(n) HNO_CHECK_HIP(hipFuncSetAttribute((const void *)spec_mid_kernel<n, 10, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); HNO_CHECK_HIP(hipFuncSetAttribute((const void *)spec_mid_kernel<n, 10, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HNO_MID_N0_LIST(X)
 #undef X
     }
     {
         ProfScope _ps(KID_SPEC_MID_BWD, s, 4.0 * B * C * (2.0 * N0 * 2 * (2 * m1 + 1) * 16 + (L + 1) * 8.0 * m0 * m1 * m2));
-#define X(n) if (N0 == n) hipLaunchKernelGGL((spec_mid_kernel<n, 10, true>), dim3(nwg), dim3(64 * MID_NW), lds, s, a);
+#define X(n) if (N0 == n) { if (a.zl) hipLaunchKernelGGL((spec_mid_kernel<n, 10, true, true>), dim3(nwg), dim3(64 * MID_NW), lds, s, a); else hipLaunchKernelGGL((spec_mid_kernel<n, 10, true, false>), dim3(nwg), dim3(64 * MID_NW), lds, s, a); }
         HNO_MID_N0_LIST(X)
 #undef X
     }
@@ -950,15 +950,17 @@ static int mid_fourier_launch(bool bwd, void *workspace, const float *W2, float 
         return fail(HNO_EINVAL, "hno_spec_mid_fourier_bwd: slab workspace of %zu bytes, hno_spec_mid_fourier_bwd_workspace_bytes() = %zu",
                     slab_bytes, hno_spec_mid_fourier_bwd_workspace_bytes(B, C, m1));
     if (bwd && mid_attr_needed(1)) {   // once per device
-#define X(n) HNO_CHECK_HIP(hipFuncSetAttribute((const void *)spec_mid_fourier_kernel<n, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define X(n) HNO_CHECK_HIP(hipFuncSetAttribute((const void *)spec_mid_fourier_kernel<n, 10, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); HNO_CHECK_HIP(hipFuncSetAttribute((const void *)spec_mid_fourier_kernel<n, 10, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HNO_MID_N0_LIST(X)
 #undef X
     }
     {
         ProfScope _ps(bwd ? KID_SPEC_MID_BWD : KID_SPEC_MID_FWD, s, 4.0 * B * C * (2.0 * N0 * 2 * (2 * m1 + 1) * 16 + 2 * 8.0 * m0 * m1 * m2));
 #define X(n)                                                                                                                \
-    if (N0 == n && bwd) hipLaunchKernelGGL((spec_mid_fourier_kernel<n, 10, true>), dim3(nwg), dim3(512), lds, s, a);          \
-    else if (N0 == n) hipLaunchKernelGGL((spec_mid_fourier_kernel<n, 10, false>), dim3(nwg), dim3(512), lds, s, a);
+    if (N0 == n && bwd && a.zl) hipLaunchKernelGGL((spec_mid_fourier_kernel<n, 10, true, true>), dim3(nwg), dim3(512), lds, s, a);          \
+    else if (N0 == n && bwd) hipLaunchKernelGGL((spec_mid_fourier_kernel<n, 10, true, false>), dim3(nwg), dim3(512), lds, s, a);          \
+    else if (N0 == n && a.zl) hipLaunchKernelGGL((spec_mid_fourier_kernel<n, 10, false, true>), dim3(nwg), dim3(512), lds, s, a);          \
+    else if (N0 == n) hipLaunchKernelGGL((spec_mid_fourier_kernel<n, 10, false, false>), dim3(nwg), dim3(512), lds, s, a);
         HNO_MID_N0_LIST(X)
 #undef X
     }
