@@ -137,9 +137,12 @@ def dry_run_rank(args):
 
 
 def probe_store_path():
-    """a rendezvous file every rank of THIS launch derives alone (ranks cannot talk before they have a group): the launcher's pid and
-    the master port are common to all ranks of one launch and differ between launches"""
+    """a rendezvous file every rank of THIS launch derives alone (ranks cannot talk before they have a group): the launcher's pid (the
+    parent of every RANK: torchrun's agent, or launch_ranks) and the master port are common to all ranks of one launch and differ between
+    launches.  Computed by the rank and handed to its probe child in HNO_PROBE_STORE (the child's own parent is the rank)."""
     import tempfile
+    if os.environ.get('HNO_PROBE_STORE'):
+        return os.environ['HNO_PROBE_STORE']
     return os.path.join(tempfile.gettempdir(), f"hno_probe_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}")
 
 
@@ -180,7 +183,7 @@ def probe_captured_allreduce(timeout_s=150.0):
     import subprocess
     try:
         child = subprocess.Popen([sys.executable, os.path.abspath(__file__), '--probe-capture'], stdout=subprocess.DEVNULL,
-                                 stderr=subprocess.DEVNULL, env=dict(os.environ))
+                                 stderr=subprocess.DEVNULL, env=dict(os.environ, HNO_PROBE_STORE=probe_store_path()))
     except OSError:
         return False
     try:

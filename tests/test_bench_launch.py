@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -37,3 +39,14 @@ def test_rank_count_mismatch_is_refused():
     res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], capture_output=True, text=True,
                          timeout=120, env=env)
     assert res.returncode != 0 and 'WORLD_SIZE=3' in (res.stderr + res.stdout)
+
+
+@pytest.mark.gpu
+def test_captured_allreduce_probe_on_one_rank(tmp_path):
+    """The throw-away child `bench.py --gpus N` starts on every rank before it touches the GPU (`--probe-capture`): its own RCCL group over
+    a file store, an all-reduce captured into a HIP graph, three checked replays.  On the one-GPU box: a group of one rank -- the code path,
+    the file-store rendezvous handed over in HNO_PROBE_STORE and the exit code, not the multi-GPU behaviour (no such hardware here)."""
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29917',
+               HNO_PROBE_STORE=str(tmp_path / 'store'), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--probe-capture'], capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, (res.returncode, res.stderr[-2000:])
