@@ -354,6 +354,14 @@ size_t hno_cb_conv_stats_floats(int B, int Cout, int Do, int Ho, int Wo);
 int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const void *wpacked, const float *bias, void *y, float *mean_rstd,
                 float eps, void *workspace, size_t workspace_bytes, int mode, int B, int Cout, int Di, int Hi, int Wi, int Do, int Ho,
                 int Wo, int ks, int stride, int pad, int *nstat_out, void *stream);
+/* hno_cb_conv with its output channels written to TWO tensors (round 5): channels [0, c_split) to y (B, Do, Ho, Wo, c_split), the others
+ * to y2 (B, Do, Ho, Wo, Cout - c_split); c_split a multiple of 8.  No statistics.  The input gradient of a two-input convolution -- the
+ * reference's Conv3d over torch.cat([x, skip]) in the V-Net decoder (nets/architectures.py:226-252) -- is the gradient of both inputs;
+ * autograd's split of the concatenated gradient (two strided copies per convolution) never happens. */
+int hno_cb_conv_split(const void *xa, int Ca, const void *xb, int Cb, const void *wpacked, const float *bias, void *y, void *y2, int c_split,
+                      void *workspace, size_t workspace_bytes, int mode, int B, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                      int ks, int stride, int pad, void *stream);
+
 /* upper bound of the slab workspace hno_cb_wgrad writes for a layer with these (total input, output) channel counts */
 size_t hno_cb_wgrad_workspace_bytes(int Cin, int Cout, int ks);
 /* dW (fp32, the parameter's own layout) of a Conv3d (transposed = 0: g on the output grid (Dg, Hg, Wg), x = [xa ; xb] on the

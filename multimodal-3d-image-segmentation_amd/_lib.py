@@ -91,6 +91,7 @@ SIGNATURES = {
     'hno_cb_conv_stats_floats': (c_size_t, [c_int] * 5),
     'hno_cb_conv': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_size_t]
                     + [c_int] * 12 + [ctypes.POINTER(c_int), c_void_p]),
+    'hno_cb_conv_split': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t] + [c_int] * 12 + [c_void_p]),
     'hno_cb_wgrad_workspace_bytes': (c_size_t, [c_int] * 3),
     'hno_cb_wgrad': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t] + [c_int] * 11 + [c_void_p]),
     'hno_cb_gn_apply': (c_int, [c_void_p] * 9 + [c_int, c_int, c_ll, c_int, c_int, c_int, c_float, c_void_p]),

@@ -61,6 +61,8 @@ struct CbArgs {
     const bf16_t *w;           // packed weights
     const float *bias;         // fp32 per output channel or null
     bf16_t *y;                 // channels-last output (null when split-K writes partials)
+    bf16_t *y2;                // round 5: second output tensor for channels >= csplit (the two inputs of a decoder convolution get their
+    int csplit;                // gradients as two contiguous tensors: no channel-split copies behind the input-gradient GEMM); 0: one output
     float *part;               // split-K: fp32 partials [z][b][v][Cout]
     float *stats;              // per-block (sum, sum of squares) of the ROUNDED outputs: [b][gridDim.x * gridDim.y][2], or null
     int B, Cout, CoP;
@@ -247,7 +249,8 @@ __global__ __launch_bounds__(256) void cb_gather_kernel(CbArgs a) {
                         a.part[(((size_t)kz * a.B + b) * Vo + v) * a.Cout + ch] = val;
                     } else {
                         const bf16_t o = f2bf(val);
-                        a.y[((size_t)b * Vo + v) * a.Cout + ch] = o;
+                        if (a.csplit && ch >= a.csplit) a.y2[((size_t)b * Vo + v) * (a.Cout - a.csplit) + (ch - a.csplit)] = o;
+                        else a.y[((size_t)b * Vo + v) * (a.csplit ? a.csplit : a.Cout) + ch] = o;
                         const float f = bf2f(o);
                         ssum += f;
                         ssq = fmaf(f, f, ssq);
@@ -289,7 +292,8 @@ struct ChArgs {
     int Ca, Cb;
     const bf16_t *w;
     const float *bias;
-    bf16_t *y;
+    bf16_t *y, *y2;           // y2 / csplit: as CbArgs
+    int csplit;
     float *stats;
     int B, Cout, CoP, D, H, W;
     int TH, S, nbands, npos;
@@ -451,7 +455,9 @@ __global__ __launch_bounds__(256) void cb_halo_kernel(ChArgs a) {
         const int hh = p / S, ww = p - hh * S;
         const int oh = oh0 + hh;
         const bool pok = hh < a.TH && oh < a.H && ww < a.W;
-        bf16_t *yrow = a.y + (((size_t)b * a.D + od) * plane + (size_t)(pok ? oh : 0) * a.W + (pok ? ww : 0)) * a.Cout;
+        const size_t ypos = ((size_t)b * a.D + od) * plane + (size_t)(pok ? oh : 0) * a.W + (pok ? ww : 0);
+        bf16_t *yrow = a.y + ypos * (a.csplit ? a.csplit : a.Cout);
+        bf16_t *yrow2 = a.csplit ? a.y2 + ypos * (a.Cout - a.csplit) - a.csplit : nullptr;      // (indexed by the GEMM's channel ch >= csplit)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -477,7 +483,7 @@ __global__ __launch_bounds__(256) void cb_halo_kernel(ChArgs a) {
                     ssum += f;
                     ssq = fmaf(f, f, ssq);
                 }
-                *reinterpret_cast<uint2 *>(yrow + ch) = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
+                *reinterpret_cast<uint2 *>(((a.csplit && ch >= a.csplit) ? yrow2 : yrow) + ch) = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
             }
     }
     if (a.stats && !a.part) {
@@ -501,7 +507,8 @@ __global__ __launch_bounds__(256) void cb_halo_kernel(ChArgs a) {
 
 // split-K finish: y = bf16(sum_z part[z] ) (bias was added by slice 0), + GroupNorm partial statistics
 __global__ __launch_bounds__(256) void cb_splitk_finish_kernel(const float *__restrict__ part, bf16_t *__restrict__ y, float *__restrict__ stats,
-                                                              int ksplit, long long per_sample, int B) {
+                                                              int ksplit, long long per_sample, int B, bf16_t *__restrict__ y2 = nullptr,
+                                                              int csplit = 0, int Cout = 0) {
     const int b = blockIdx.y;
     const size_t slice = (size_t)B * per_sample;
     float ssum = 0.f, ssq = 0.f;
@@ -509,7 +516,14 @@ __global__ __launch_bounds__(256) void cb_splitk_finish_kernel(const float *__re
         float s = 0.f;
         for (int z = 0; z < ksplit; ++z) s += part[(size_t)z * slice + (size_t)b * per_sample + i];
         const bf16_t o = f2bf(s);
-        y[(size_t)b * per_sample + i] = o;
+        if (csplit) {      // two output tensors (CbArgs.csplit)
+            const long long v = i / Cout;
+            const int ch = (int)(i - v * Cout);
+            const size_t vb = (size_t)b * (per_sample / Cout) + v;
+            if (ch >= csplit) y2[vb * (Cout - csplit) + (ch - csplit)] = o;
+            else y[vb * csplit + ch] = o;
+        } else
+            y[(size_t)b * per_sample + i] = o;
         const float f = bf2f(o);
         ssum += f;
         ssq = fmaf(f, f, ssq);
@@ -1537,9 +1551,11 @@ extern "C" size_t hno_cb_conv_stats_floats(int B, int Cout, int Do, int Ho, int 
     const long long Vo = (long long)Do * Ho * Wo;
     return (size_t)2 * B + (size_t)B * (((Vo + 63) / 64) * ((Cout + 31) / 32) + (size_t)Do * Ho * ((Cout + 31) / 32) + 4096) * 2;
 }
-extern "C" int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const void *wpacked, const float *bias, void *y,
-                           float *mean_rstd, float eps, void *workspace, size_t workspace_bytes, int mode, int B, int Cout,
-                           int Di, int Hi, int Wi, int Do, int Ho, int Wo, int ks, int stride, int pad, int *nstat_out, void *stream) {
+static int cb_conv_impl(const void *xa, int Ca, const void *xb, int Cb, const void *wpacked, const float *bias, void *y,
+                        float *mean_rstd, float eps, void *workspace, size_t workspace_bytes, int mode, int B, int Cout,
+                        int Di, int Hi, int Wi, int Do, int Ho, int Wo, int ks, int stride, int pad, int *nstat_out, void *stream,
+                        void *y2, int c_split) {
+    HNO_REQUIRE(c_split == 0 || (y2 && c_split > 0 && c_split < Cout && c_split % 8 == 0), "hno_cb_conv_split: bad channel split");
     const bool lazy = nstat_out != nullptr && mean_rstd != nullptr;
     if (nstat_out) *nstat_out = 0;
     HNO_REQUIRE(xa && wpacked && y && workspace && B > 0 && Cout > 0 && Ca > 0 && Cb >= 0, "hno_cb_conv: bad argument");
@@ -1551,7 +1567,7 @@ extern "C" int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const
     hipStream_t s = (hipStream_t)stream;
     CbArgs a = {};
     a.xa = (const bf16_t *)xa; a.xb = (const bf16_t *)xb; a.Ca = Ca; a.Cb = Cb; a.w = (const bf16_t *)wpacked; a.bias = bias;
-    a.y = (bf16_t *)y; a.B = B; a.Cout = Cout; a.CoP = (Cout + 31) / 32 * 32;
+    a.y = (bf16_t *)y; a.y2 = (bf16_t *)y2; a.csplit = c_split; a.B = B; a.Cout = Cout; a.CoP = (Cout + 31) / 32 * 32;
     a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.ks = ks; a.stride = stride; a.pad = pad; a.frac = mode;
     a.ntaps = ks * ks * ks;
     const int nq = a.ntaps * ((Ca + Cb) / 8);
@@ -1609,7 +1625,7 @@ extern "C" int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const
         const size_t stat_need = (size_t)B * ((size_t)Do * ((Ho + (bTH ? bTH : 1) - 1) / (bTH ? bTH : 1)) * ((Cout + 32 * (bNT ? bNT : 1) - 1) / (32 * (bNT ? bNT : 1))) + 1024) * 2 * sizeof(float);
         if (bMT && ((part_need + 255) & ~(size_t)255) + stat_need <= workspace_bytes) {
             ChArgs h = {};
-            h.xa = a.xa; h.xb = a.xb; h.Ca = Ca; h.Cb = Cb; h.w = a.w; h.bias = bias; h.y = a.y;
+            h.xa = a.xa; h.xb = a.xb; h.Ca = Ca; h.Cb = Cb; h.w = a.w; h.bias = bias; h.y = a.y; h.y2 = a.y2; h.csplit = a.csplit;
             h.B = B; h.Cout = Cout; h.CoP = a.CoP; h.D = Do; h.H = Ho; h.W = Wo; h.TH = bTH; h.S = S; h.flip = mode; h.dbg = debug_flags();
             h.nbands = (Ho + bTH - 1) / bTH;
             h.npos = (2 * (bTH + 2) + 2) * S + 2 + 4 * bMT * 32 + 8;
@@ -1642,7 +1658,7 @@ extern "C" int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const
                 const long long per_sample = Vo * Cout;
                 const int gx = gsz(per_sample, 256, 1024);
                 hipLaunchKernelGGL(cb_splitk_finish_kernel, dim3(gx, B), dim3(256), 0, s, (const float *)h.part, (bf16_t *)y, mean_rstd ? hstats : nullptr,
-                                   bKS, per_sample, B);
+                                   bKS, per_sample, B, a.y2, a.csplit, Cout);
                 HNO_CHECK_LAUNCH();
                 nstat = gx;
             }
@@ -1689,7 +1705,7 @@ extern "C" int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const
         const long long per_sample = Vo * Cout;
         const int gx = gsz(per_sample, 256, 1024);
         hipLaunchKernelGGL(cb_splitk_finish_kernel, dim3(gx, B), dim3(256), 0, s, (const float *)a.part, (bf16_t *)y, mean_rstd ? stats : nullptr, kz,
-                           per_sample, B);
+                           per_sample, B, a.y2, a.csplit, Cout);
         HNO_CHECK_LAUNCH();
         nblk_stats = gx;
     }
@@ -1700,6 +1716,24 @@ extern "C" int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const
         HNO_CHECK_LAUNCH();
     }
     return HNO_OK;
+}
+
+extern "C" int hno_cb_conv(const void *xa, int Ca, const void *xb, int Cb, const void *wpacked, const float *bias, void *y,
+                           float *mean_rstd, float eps, void *workspace, size_t workspace_bytes, int mode, int B, int Cout,
+                           int Di, int Hi, int Wi, int Do, int Ho, int Wo, int ks, int stride, int pad, int *nstat_out, void *stream) {
+    return cb_conv_impl(xa, Ca, xb, Cb, wpacked, bias, y, mean_rstd, eps, workspace, workspace_bytes, mode, B, Cout, Di, Hi, Wi, Do, Ho, Wo, ks,
+                        stride, pad, nstat_out, stream, nullptr, 0);
+}
+
+// The same GEMM with its output channels written to TWO tensors: channels [0, c_split) to y (B, Do, Ho, Wo, c_split), the rest to y2
+// (B, Do, Ho, Wo, Cout - c_split).  The input gradient of a two-input convolution (the decoder's fused concat) is the gradient of both
+// inputs: written apart, the consumers need no channel-split copies (16 ATen copies per V-Net-DS step in round 4).
+extern "C" int hno_cb_conv_split(const void *xa, int Ca, const void *xb, int Cb, const void *wpacked, const float *bias, void *y, void *y2,
+                                 int c_split, void *workspace, size_t workspace_bytes, int mode, int B, int Cout, int Di, int Hi, int Wi,
+                                 int Do, int Ho, int Wo, int ks, int stride, int pad, void *stream) {
+    HNO_REQUIRE(y2 && c_split > 0, "hno_cb_conv_split: bad argument");
+    return cb_conv_impl(xa, Ca, xb, Cb, wpacked, bias, y, nullptr, 1e-5f, workspace, workspace_bytes, mode, B, Cout, Di, Hi, Wi, Do, Ho, Wo, ks,
+                        stride, pad, nullptr, stream, y2, c_split);
 }
 
 extern "C" int hno_cb_gn_apply(const void *y1, const float *mr1, const float *gamma1, const float *beta1, const void *y2,

@@ -151,6 +151,23 @@ def conv_raw(xa, xb, wpacked, bias, Cout, out_spatial, mode, ks, stride, pad, wa
     return y, mr
 
 
+def conv_split_raw(x, wpacked, Cout, c_split, out_spatial, mode, ks, stride, pad):
+    """conv_raw without statistics whose output channels go to TWO contiguous tensors: [0, c_split) and [c_split, Cout)
+    (hno_cb_conv_split): the input gradient of a two-input convolution, one tensor per input."""
+    _need_gpu(x)
+    x = _cl(x)
+    B, Di, Hi, Wi, Ca = x.shape
+    Do, Ho, Wo = (int(v) for v in out_spatial)
+    L = _lib.lib()
+    ya = torch.empty((B, Do, Ho, Wo, c_split), device=x.device, dtype=BF16)
+    yb = torch.empty((B, Do, Ho, Wo, Cout - c_split), device=x.device, dtype=BF16)
+    nws = L.hno_cb_conv_workspace_bytes(B, Ca, Cout, Do, Ho, Wo, ks)
+    ws = _ws(nws, x.device)
+    check(L.hno_cb_conv_split(ptr(x), Ca, None, 0, ptr(wpacked), None, ptr(ya), ptr(yb), int(c_split), ptr(ws), nws, mode, B, Cout,
+                              Di, Hi, Wi, Do, Ho, Wo, ks, stride, pad, stream_ptr()), 'hno_cb_conv_split')
+    return ya, yb
+
+
 def wgrad_raw(g, xa, xb, w_shape, transposed, ks, stride, pad, param=None):
     """dW (fp32, parameter layout).  conv: g on the output grid, x = [xa ; xb] its input.  transposed: x the ConvTranspose input."""
     g, xa = _cl(g), _cl(xa)
@@ -301,11 +318,14 @@ class ConvFn(_HnoFunction):
             # (two graphs alive, a validation forward in between, gradient accumulation) packs its own operand from the saved weights
             stale = ctx.wp_owner is not None and ctx.wp_owner[0].generation != ctx.wp_owner[1]
             wp = ctx.wpd if (ctx.wpd is not None and not stale) else pack_weights(W, 3 if transposed else 1, Cin, Cout, ks)
-            gx, _ = conv_raw(gy, None, wp, None, Cin, tuple(xa.shape[1:4]), 0 if transposed else 1, ks, stride, pad, False)
-            if xb is None:
-                gxa = gx
-            else:   # split of the channel axis of a channels-last tensor (index op; only the decoder's two-input convs)
-                gxa, gxb = gx[..., :Ca], gx[..., Ca:]      # views: the consumers (crop backward, gradient sums, .contiguous() of the next op) copy at most once
+            if xb is None or _os.environ.get('HNO_CB_SPLIT', '1') == '0':
+                gx, _ = conv_raw(gy, None, wp, None, Cin, tuple(xa.shape[1:4]), 0 if transposed else 1, ks, stride, pad, False)
+                if xb is None:
+                    gxa = gx
+                else:   # (A/B: views of one tensor; the consumers copy)
+                    gxa, gxb = gx[..., :Ca], gx[..., Ca:]
+            else:   # round 5: the two inputs' gradients leave the GEMM as two contiguous tensors (the decoder's two-input convolutions)
+                gxa, gxb = conv_split_raw(gy, wp, Cin, Ca, tuple(xa.shape[1:4]), 0 if transposed else 1, ks, stride, pad)
         dW = wgrad_raw(gy, xa, xb, W.shape, transposed, ks, stride, pad, param=W if W.is_leaf else None)
         db = None
         if has_bias:
