@@ -505,6 +505,15 @@ def main():
             rep.set_hooks_enabled(True)
             if distributed:
                 pkg.ops.set_defer_reduce(False)
+        if world > 1 and not rep.all_ranks_ok(graph is not None) and graph is not None:
+            # a capture that failed on ANY rank is dropped on EVERY rank: a replaying rank sends one flat all-reduce (possibly inside its
+            # graph), an eager rank one per bucket -- mixed, the collectives no longer match and the job hangs
+            print('[bench] HIP graph capture failed on another rank; running eagerly', file=sys.stderr)
+            graph = None
+            rep.set_hooks_enabled(True)
+            pkg.ops.set_defer_reduce(False)
+        if graph is None and opt_in_graph:
+            opt_in_graph = False              # (the update then runs as an eager launch behind backward; still device-stepped)
 
     host_s = [0.0]
 
