@@ -2,3 +2,4 @@
 PAT=${1:-"plain run|dht_|spec_mid|sum of kernel"}
 bash tools/r5/prof_step.sh r05_tree_a | grep -E "$PAT"
 (cd _r4 && GRAFT_REPO_ROOT=$PWD bash tools/r5/prof_step.sh r05_tree_b | grep -E "$PAT")
+rm -rf gpurun_out/r05_tree_b; cp -r _r4/gpurun_out/r05_tree_b gpurun_out/r05_tree_b 2>/dev/null
