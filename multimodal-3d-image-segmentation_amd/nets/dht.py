@@ -42,7 +42,9 @@ def _dht3_long_axis0(x4, scale):
     with H2 the 2-D transform of every (N1, N2) plane (the plane kernels, first axis degenerate) and the first-axis sums two batched
     fp32 matrix-core GEMMs (hno_bmm); the frequency reversal is a flip + roll of H2 (data movement only)."""
     lead, N0, N1, N2 = x4.shape
-    h2 = ops.DhtFullFn.apply(x4.reshape(1, lead * N0, 1, N1, N2), 1.0).reshape(lead, N0, N1, N2)
+    step = max(1, _MAX_BC // N0)               # (b * c planes per launch: grid.y)
+    parts = [ops.DhtFullFn.apply(x4[i:i + step].reshape(1, -1, 1, N1, N2), 1.0).reshape(-1, N0, N1, N2) for i in range(0, lead, step)]
+    h2 = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
     rev = torch.roll(torch.flip(h2, dims=(2, 3)), shifts=(1, 1), dims=(2, 3))
     c, s = _cos_sin(N0, x4.device)
     cb, sb = c.expand(lead, N0, N0).contiguous(), s.expand(lead, N0, N0).contiguous()
