@@ -140,6 +140,19 @@ __device__ __forceinline__ f32x2 selu_like_pk(f32x2 x, float ap, float aq) {
     const f32x2 pos = x * f32x2{ap, ap}, neg = neg_expm1_pk(x) * f32x2{aq, aq};
     return f32x2{x[0] > 0.f ? pos[0] : neg[0], x[1] > 0.f ? pos[1] : neg[1]};
 }
+// the activation over N accumulator registers (N even), pairs on the packed pipe; the empty asm keeps the compiler from
+// sinking the computation into a branch per register
+template <int N>
+__device__ __forceinline__ void selu_like_regs(float *v, float ap, float aq) {
+    static_assert(N % 2 == 0, "register pairs");
+#pragma unroll
+    for (int r = 0; r < N; r += 2) {
+        f32x2 y = selu_like_pk(f32x2{v[r], v[r + 1]}, ap, aq);
+        asm volatile("" : "+v"(y));
+        v[r] = y[0];
+        v[r + 1] = y[1];
+    }
+}
 // byte offsets are formed in 32 bits and added to a wave-uniform base: the loads and stores then take the (SGPR base + VGPR offset)
 // address form -- 64-bit per-lane address arithmetic was a third of the head kernel's instructions
 __device__ __forceinline__ float ld_off(const float *base, unsigned byte_off) {

@@ -445,12 +445,8 @@ __global__ __launch_bounds__(64 * NWV) void pwconv_fwd_fast_kernel(PwArgs a) {
                     val[r] = x;
                 }
                 if (!lin) {
-#pragma unroll
-                    for (int r = 0; r < (ot == OT - 1 ? NRL : 16); ++r) {
-                        float e = neg_expm1(val[r]);
-                        asm volatile("" : "+v"(e));             // keeps the compiler from sinking the computation into a branch
-                        val[r] = val[r] > 0.f ? ap * val[r] : aq * e;
-                    }
+                    if (ot == OT - 1) selu_like_regs<NRL>(val, ap, aq);
+                    else selu_like_regs<16>(val, ap, aq);
                 }
                 float *y_l = y_b + (hoff4V + v);
                 if (full) {
@@ -589,12 +585,7 @@ __global__ __launch_bounds__(64 * PWF_DMA_WAVES) void pwconv_fwd_branch_kernel(P
             yv[r] = BF16 ? bf16_round(acc[r] + bb[r]) + sv[r] : acc[r] + sv[r] + bb[r];
         }
         if (!lin) {             // no branch per register (see pwconv_fwd_fast_kernel)
-#pragma unroll
-            for (int r = 0; r < RA; ++r) {
-                float e = neg_expm1(yv[r]);
-                asm volatile("" : "+v"(e));
-                yv[r] = yv[r] > 0.f ? ap * yv[r] : aq * e;
-            }
+            selu_like_regs<RA>(yv, ap, aq);
         }
         if (full) {
 #pragma unroll
@@ -625,12 +616,7 @@ __global__ __launch_bounds__(64 * PWF_DMA_WAVES) void pwconv_fwd_branch_kernel(P
             if constexpr (BF16) ov[r] = bf16_round(ov[r]);
         }
         if (!lin) {
-#pragma unroll
-            for (int r = 0; r < RO; ++r) {
-                float e = neg_expm1(ov[r]);
-                asm volatile("" : "+v"(e));
-                ov[r] = ov[r] > 0.f ? ap * ov[r] : aq * e;
-            }
+            selu_like_regs<RO>(ov, ap, aq);
         }
 #pragma unroll
         for (int r = 0; r < RO; ++r) {
@@ -740,12 +726,7 @@ __global__ __launch_bounds__(64 * NWV) void pwconv_fwd_chain_kernel(PwChainArgs 
 #pragma unroll
         for (int r = 0; r < NK; ++r) xi[r] = acc[r] + b1[r];
         if (!lin) {             // no branch per register (see pwconv_fwd_fast_kernel)
-#pragma unroll
-            for (int r = 0; r < NK; ++r) {
-                float e = neg_expm1(xi[r]);
-                asm volatile("" : "+v"(e));
-                xi[r] = xi[r] > 0.f ? ap * xi[r] : aq * e;
-            }
+            selu_like_regs<NK>(xi, ap, aq);
         }
         float *xi_l = a.xi + (size_t)b * C * V + (hoff4V + v);
         if (full) {
@@ -768,12 +749,7 @@ __global__ __launch_bounds__(64 * NWV) void pwconv_fwd_chain_kernel(PwChainArgs 
 #pragma unroll
         for (int r = 0; r < NR2; ++r) xn[r] = acc[r] + b2[r];
         if (!lin2) {
-#pragma unroll
-            for (int r = 0; r < NR2; ++r) {
-                float e = neg_expm1(xn[r]);
-                asm volatile("" : "+v"(e));
-                xn[r] = xn[r] > 0.f ? ap2 * xn[r] : aq2 * e;
-            }
+            selu_like_regs<NR2>(xn, ap2, aq2);
         }
         float *xn_l = a.xn + (size_t)b * C2 * V + (hoff4V + v);
         const bool hok = C2 >= 8 || h == 0;           // C2 = 4: the rows live on the h = 0 lanes only
