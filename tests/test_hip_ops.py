@@ -414,6 +414,43 @@ def test_plane_kernels_on_other_working_grids_vs_float64(pkg, n):
         assert bool((ops.pad_idht3_raw(z, sp, 0.5, ops.to_layout(add, ld), ops.ACT_SELU, ld=ld) == u).all())
 
 
+@pytest.mark.parametrize('n1,n2', [(41, 41), (49, 49), (57, 57), (73, 73), (81, 81), (97, 97), (121, 78)])
+def test_item_plane_kernels_general_sizes_vs_float64(pkg, n1, n2):
+    """The item plane kernels for plane sizes other than 65 / 33 (hno_dht_items.hip, round 5; 121 x 78 = the planes of the reference's
+    published inference size 240 x 240 x 155, README.md:10): partial last item (Js1 not a multiple of 16), an even N2 (its middle column
+    is its own mirror), three and four items per plane.  TransformCrop and PadInverse (plain, and with residual + SELU) against the float64
+    dense formulation, contiguous and channel-padded, at an odd plane count so that workgroups start at every item number; the family
+    that ran is pinned (4), and HNO_ITEMS=0's older kernels give the same numbers to rounding."""
+    from multimodal_3d_image_segmentation_amd import ops
+    L = pkg._lib.lib()
+    torch.manual_seed(17)
+    sp, modes = (5, n1, n2), (2, 14, 14)
+    x = torch.randn(2, 3, *sp, device='cuda')
+    z = torch.randn(2, 3, 4, 28, 28, device='cuda')
+    add = torch.randn(2, 3, *sp, device='cuda')
+    y = ops.dht3_crop_raw(x, modes, 1.0 / np.prod(sp))
+    assert L.hno_debug_last_plane_family(0) == 4
+    u0 = ops.pad_idht3_raw(z, sp, 0.5)
+    assert L.hno_debug_last_plane_family(1) == 4
+    u = ops.pad_idht3_raw(z, sp, 0.5, add, ops.ACT_SELU)
+    assert L.hno_debug_last_plane_family(1) == 4
+    for bc in ((0, 0), (1, 2)):
+        assert rel_err(y[bc].cpu().numpy(), O().dht_crop_dense(x[bc].cpu().double()[None, None], modes)[0, 0].numpy()) < 5e-6
+        lin = 0.5 * O().pad_idht_dense(z[bc].cpu().double()[None, None], sp)[0, 0]
+        assert rel_err(u0[bc].cpu().numpy(), lin.numpy()) < 5e-6
+        assert rel_err(u[bc].cpu().numpy(), F.selu(lin + add[bc].cpu().double()).numpy()) < 5e-6
+    ld = ops._pad_ld(np.prod(sp))
+    if ld != int(np.prod(sp)):
+        assert bool((ops.dht3_crop_raw(ops.to_layout(x, ld), modes, 1.0 / np.prod(sp)) == y).all())
+        assert bool((ops.pad_idht3_raw(z, sp, 0.5, ops.to_layout(add, ld), ops.ACT_SELU, ld=ld) == u).all())
+    # a misaligned base address (a view one float into a buffer): the DMA source ranges start below the data
+    buf = torch.zeros(x.numel() + 3, device='cuda')
+    for sh in (1, 3):
+        xv = buf[sh:sh + x.numel()].view_as(x)
+        xv.copy_(x)
+        assert bool((ops.dht3_crop_raw(xv, modes, 1.0 / np.prod(sp)) == y).all())
+
+
 def test_dht_roundtrip_property_full_size(pkg):
     """Size-independent property at the benchmark size: crop(pad_inverse(z)) * 1 == z (the kept
     modes of an inverse transform of a band-limited spectrum are the spectrum itself) and linearity."""
