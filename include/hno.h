@@ -208,7 +208,8 @@ int hno_pwconv_fwd_branch(const float *s, const float *xb, const float *Wbr, con
  * (V may be the channel stride of channel-padded activations), Wc / Wm (24, 48); other widths: HNO_ELIMIT (callers run the two layers). */
 int hno_pwconv_fwd_chain_supported(int C, int C2, int has_k);
 /* C2 = 24 with k: the next block's mapping_conv (act2 = act);  C2 = 4, k = bm = NULL: the model's conv_out (nets/hnosegxs.py:178, 24 ->
- * out_channels, no bias, act2 none) behind the LAST block's conv_concat; xn (B, C2, V), Wm (C2, 48 or 24) */
+ * out_channels, no bias, act2 none) behind the LAST block's conv_concat; xn (B, C2, V), Wm (C2, 48 or 24).  xi NULL: the first layer's
+ * output is not stored (inference: only the backward reads it) */
 int hno_pwconv_fwd_chain(const float *u, const float *t, const float *k, const float *Wc, const float *bc, const float *Wm,
                          const float *bm, float *xi, float *xn, int B, int C, int C2, long long V, int act, int act2, void *stream);
 /* backward of the pair in one pass: gn = gradient of xn -> gu (times xa_act'(u): u is the output of that activation), gt, gk and

@@ -729,7 +729,8 @@ __global__ __launch_bounds__(64 * NWV) void pwconv_fwd_chain_kernel(PwChainArgs 
             selu_like_regs<NK>(xi, ap, aq);
         }
         float *xi_l = a.xi + (size_t)b * C * V + (hoff4V + v);
-        if (full) {
+        if (!a.xi) {            // inference: nobody reads the first layer's output (the backward would)
+        } else if (full) {
 #pragma unroll
             for (int r = 0; r < NK; ++r) xi_l[(size_t)((r & 3) + 8 * (r >> 2)) * V] = xi[r];
         } else {
@@ -1778,7 +1779,7 @@ extern "C" int hno_pwconv_fwd_chain_supported(int C, int C2, int has_k) { return
 // bm NULL, act2 none); xn (B, C2, V)
 extern "C" int hno_pwconv_fwd_chain(const float *u, const float *t, const float *k, const float *Wc, const float *bc, const float *Wm,
                                     const float *bm, float *xi, float *xn, int B, int C, int C2, long long V, int act, int act2, void *stream) {
-    HNO_REQUIRE(u && t && Wc && Wm && xi && xn && B > 0 && V > 0, "hno_pwconv_fwd_chain: bad argument");
+    HNO_REQUIRE(u && t && Wc && Wm && xn && B > 0 && V > 0, "hno_pwconv_fwd_chain: bad argument");   // xi NULL: not stored (inference)
     if (!hno_pwconv_fwd_chain_supported(C, C2, k != nullptr))
         return fail(HNO_ELIMIT, "hno_pwconv_fwd_chain: 24 -> 24 (with a second input) and 24 -> 4 (without) are built (got %d -> %d)", C, C2);
     if (V * 8 >= (1ll << 32) || ((V + 31) / 32) * B >= (1ll << 31))
@@ -1795,7 +1796,7 @@ extern "C" int hno_pwconv_fwd_chain(const float *u, const float *t, const float 
     if (grid > cap) grid = cap;
     if (debug_grid()) grid = debug_grid();
     hipStream_t fs = (hipStream_t)stream;
-    ProfScope ps(KID_PWCONV_FWD, fs, 4.0 * B * (double)V * ((k ? 4 : 3) * C + C2));
+    ProfScope ps(KID_PWCONV_FWD, fs, 4.0 * B * (double)V * ((k ? 3 : 2) * C + (xi ? C : 0) + C2));
     const size_t fl = (size_t)nw * 2 * (k ? 36 : 24) * 256;
     static int attr = -1;
     if (attr != current_device()) {

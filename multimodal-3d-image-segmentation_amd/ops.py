@@ -1676,7 +1676,8 @@ class XSBlockFn(_HnoFunction):
             act2 = act if nskip is not None else ACT_NONE
             if nskip is not None:
                 nskip = to_layout(_f32a(nskip), chan_stride(xm))
-            out = act_like(xm)
+            # the concat convolution's output is read by the backward only: not stored when no input wants a gradient (inference)
+            out = act_like(xm) if any(ctx.needs_input_grad) else None
             xn = act_like(xm) if nskip is not None else act_empty(x.shape[0], C2, spatial, x.device, chan_stride(xm))
             check(_lib.lib().hno_pwconv_fwd_chain(ptr(u), ptr(xm), ptr(nskip), ptr(cat_w), ptr(cat_b), ptr(nmap_w), ptr(nmap_b), ptr(out), ptr(xn),
                                                   x.shape[0], int(cat_w.shape[0]), C2, chan_stride(xm) or _flat_v(xm), act, act2, stream_ptr()),

@@ -896,6 +896,26 @@ def test_specmix_stack(pkg, C, L, residual, shape):
         assert rel_err(a.cpu().numpy(), b.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('size', [(48, 40, 36), (64, 64, 64)])
+def test_hnosegxs_inference_forward_equals_the_training_forward(pkg, size):
+    """Under no_grad the chained pointwise kernel of the decoder blocks does not store its first layer's output (only the backward reads
+    it: hno_pwconv_fwd_chain with xi NULL, round 5): the probabilities must be bit-identical to the forward of a training step, eval()
+    or not (nets/hnosegxs.py has no mode-dependent layer)."""
+    nets = pkg.nets
+    torch.manual_seed(21)
+    model = nets.HNOSegXS(4, 4, 24, [3] * 8, (10, 14, 14)).cuda()
+    x = torch.randn((1, 4) + size, device='cuda')
+    y_train = model(x)
+    assert y_train.requires_grad
+    with torch.no_grad():
+        y_inf = model(x)
+        y_eval = model.eval()(x)
+    assert not y_inf.requires_grad
+    assert bool((y_inf == y_train.detach()).all()) and bool((y_eval == y_inf).all())
+    y_train.sum().backward()             # the training forward kept what its backward needs
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
 @pytest.mark.parametrize('B,C,N,modes', [(2, 24, 65, (10, 14, 14)), (1, 24, 65, (10, 14, 14)), (1, 12, 65, (10, 14, 14)), (2, 24, 33, (10, 14, 14))])
 def test_benchmark_shapes_take_the_fast_plane_kernels(pkg, B, C, N, modes):
     """The headline grids (65^3 after the stem of a 128^3 input; 33^3 for 64^3) must run the LDS-DMA forward and the half-plane item
