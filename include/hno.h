@@ -568,7 +568,8 @@ int hno_set_debug(int flags);
 int hno_debug_stamps(long long *out, int n);
 /* test aid: the plane-kernel family the calling thread's last forward (inverse = 0) / inverse (1) transform launch took --
  * 0 none yet, 1 generic (a workgroup per plane), 2 the round-2 specialised kernels, 3 the LDS-DMA forward / half-plane item inverse
- * kernels.  The GPU tests pin the families of the benchmark shapes (a dropped instantiation falls back silently). */
+ * kernels of the 65 / 33 planes, 4 the item kernels for other plane sizes (hno_dht_items.hip, round 5).  The GPU tests pin the
+ * families of the benchmark shapes and of the inference grid (a dropped instantiation falls back silently). */
 int hno_debug_last_plane_family(int inverse);
 /* test aid: weight-gradient slab reductions launched by this process so far -- batched = 0: one launch per slab set
  * (reduce_partials_kernel), 1: batched end-of-backward launches (reduce_partials_multi_kernel).  The GPU tests pin the launch count of a
