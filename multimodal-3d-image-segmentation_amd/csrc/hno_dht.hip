@@ -2627,11 +2627,8 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
                            planes / gw, planes % gw, (unsigned)ldbc);                                                      \
         g_last_plane_family[0] = 3; launched = true;                                                                       \
     }
-        HNO_DMA(9, 8, 2)           // 65 x 65 planes
-        HNO_DMA(5, 4, 1)           // 33 x 33 planes
-#undef HNO_DMA
-        // other plane sizes with an item kernel (hno_dht_items.hip); HNO_ITEMS=0 keeps the older kernels (A/B)
-        if (!launched && !x_act_out && !(a.dbg & (512 | 16)) && items_enabled()) {
+        // plane sizes with an item kernel of hno_dht_items.hip (65 x 65 too: 17.8 against 18.9 us); HNO_ITEMS=0 keeps the older kernels (A/B)
+        if (!launched && !x_act_out && !(a.dbg & (512 | 16)) && items_enabled() && fwd_plane_variant() != 1) {
             const int rc_items = fwd_items_launch(x, (float *)workspace, a, BC, ldbc, s);
             if (rc_items < 0) return rc_items;
             if (rc_items > 0) {
@@ -2639,6 +2636,9 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
                 launched = true;
             }
         }
+        HNO_DMA(9, 8, 2)           // 65 x 65 planes
+        HNO_DMA(5, 4, 1)           // 33 x 33 planes
+#undef HNO_DMA
         HNO_WAVE(9, 8, 9, 8, 16)   // 65 x 65 planes
         HNO_WAVE(5, 4, 5, 4, 4)    // 33 x 33 planes
 #undef HNO_WAVE
@@ -2826,10 +2826,8 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
         if (rc_item) return rc_item;                                                                                       \
         g_last_plane_family[1] = 3; launched = true;                                                                       \
     }
-        HNO_ITEM(2, 65, 4, 2)      // 65 x 65 planes, modes (., 14, 14)
-        HNO_ITEM(1, 33, 4, 1)      // 33 x 33 planes
-#undef HNO_ITEM
-        if (!launched && !(a.dbg & (512 | 16)) && items_enabled()) {
+        // (65 x 65 with a residual stays with dht_inv_item_kernel: 30.1 against 30.6 us; without one the item kernel runs 24.2 against 25.4)
+        if (!launched && !(a.dbg & (512 | 16)) && items_enabled() && inv_plane_variant() != 1 && !(addend && N1 == 65 && N2 == 65)) {
             const int rc_items = inv_items_launch(workspace, addend, out, a, BC, ldbc, s);
             if (rc_items < 0) return rc_items;
             if (rc_items > 0) {
@@ -2837,6 +2835,9 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
                 launched = true;
             }
         }
+        HNO_ITEM(2, 65, 4, 2)      // 65 x 65 planes, modes (., 14, 14)
+        HNO_ITEM(1, 33, 4, 1)      // 33 x 33 planes
+#undef HNO_ITEM
 #define HNO_SPEC(KM1, KM2, NT1, NT2, NFULL)                                                                               \
     if (!launched && spec_ok && b1.KmP == 4 * KM1 && b2.KmP == 4 * KM2 && (b1.J + 15) / 16 == NT1 &&                      \
         (b2.J + 15) / 16 == NT2 && pe / 256 == NFULL) {                                                                   \
