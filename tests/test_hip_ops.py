@@ -482,6 +482,24 @@ def test_item_plane_kernels_general_sizes_vs_float64(pkg, n1, n2):
         assert bool((ops.dht3_crop_raw(xv, modes, 1.0 / np.prod(sp)) == y).all())
 
 
+@pytest.mark.parametrize('n1,n2,modes,chans', [(49, 49, (1, 6, 9), 1), (121, 78, (1, 6, 9), 2), (81, 81, (1, 15, 15), 1), (65, 65, (1, 12, 3), 1)])
+def test_item_plane_kernels_other_mode_counts_and_few_planes(pkg, n1, n2, modes, chans):
+    """Fewer kept modes than the (14, 14) the item kernels were tuned on (the inverse one is built for 12..15 modes along H and falls back
+    below that; the forward one takes any count up to 15), and fewer planes (3 or 6) than a workgroup has waves: against the float64
+    dense formulation."""
+    from multimodal_3d_image_segmentation_amd import ops
+    torch.manual_seed(23)
+    sp = (3, n1, n2)
+    x = torch.randn(1, chans, *sp, device='cuda')
+    z = torch.randn(1, chans, 2 * modes[0], 2 * modes[1], 2 * modes[2], device='cuda')
+    y = ops.dht3_crop_raw(x, modes, 1.0 / np.prod(sp))
+    u = ops.pad_idht3_raw(z, sp, 0.5, x, ops.ACT_SELU)
+    for c in range(chans):
+        assert rel_err(y[0, c].cpu().numpy(), O().dht_crop_dense(x[0, c].cpu().double()[None, None], modes)[0, 0].numpy()) < 5e-6
+        want = F.selu(0.5 * O().pad_idht_dense(z[0, c].cpu().double()[None, None], sp)[0, 0] + x[0, c].cpu().double())
+        assert rel_err(u[0, c].cpu().numpy(), want.numpy()) < 5e-6
+
+
 def test_dht_roundtrip_property_full_size(pkg):
     """Size-independent property at the benchmark size: crop(pad_inverse(z)) * 1 == z (the kept
     modes of an inverse transform of a band-limited spectrum are the spectrum itself) and linearity."""
