@@ -7,7 +7,7 @@ reads (MI355X_MICROARCH.md, HBM section); both counters are in KB."""
 import csv, json, sys, collections, re
 
 GROUPS = {
-    'pwconv_bwd_kernel': ['pwconv_bwd'], 'pwconv_fwd_kernel': ['pwconv_fwd'], 'dht_fwd_plane_kernel': ['dht_fwd_plane'],
+    'pwconv_bwd_kernel': ['pwconv_bwd'], 'pwconv_fwd_kernel': ['pwconv_fwd'], 'dht_fwd_plane_kernel': ['dht_fwd_plane', 'dht_fwd_items'],
     'dht_inv_plane_kernel': ['dht_inv_plane', 'dht_inv_item'], 'spec_mid_fwd_kernel': ['spec_mid_kernel<65, 10, false', 'spec_mid_kernel<33, 10, false'], 'spec_mid_bwd_kernel': ['spec_mid_kernel<65, 10, true', 'spec_mid_kernel<33, 10, true'], 'dht_fwd_d_kernel': ['dht_fwd_d'], 'dht_inv_d_kernel': ['dht_inv_d'],
     'specmix_fwd_kernel': ['specmix_fwd'], 'specmix_bwd_kernel': ['specmix_bwd'], 'reduce_partials_kernel': ['reduce_partials'],
     'conv_k2s2_fwd_kernel': ['conv_k2s2_fwd'], 'conv_k2s2_bwd_kernel': ['conv_k2s2_bwd', 'conv_k2s2_chain_bwd'], 'upsoftmax_fwd_kernel': ['upsoftmax_fwd', 'uphead_seg', 'uphead_rows'],
