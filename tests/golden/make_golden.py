@@ -756,9 +756,47 @@ def g14_testing():
     save('g14_testing.npz', **out)
 
 
+# ------------------------- G17: the reference's published inference size (README.md:10: 240 x 240 x 155 BraTS images), HNOSeg-XS forward
+def g17_inference_full_size():
+    """The reference's HNOSegXS(4, 4, 24, [3] * 8, (10, 14, 14)) (config_hnoseg_xs.ini) in eval mode under no_grad on one
+    (1, 4, 240, 240, 155) formula volume -- the working grid is 121 x 121 x 78: 121 planes of 121 x 78, an even last axis, four partial
+    row-pair tiles per plane: the shapes the round-5 item plane kernels were written for.  8 192 sampled probabilities, their sum per
+    class, the arg-max labels at the samples with the top-2 margin (experiments/train_test.py:383-426 takes the arg max on the host),
+    the label histogram; fp32 and with the reference run in float64."""
+    torch.manual_seed(0)
+    model = nets.HNOSegXS(4, 4, 24, [3] * 8, (10, 14, 14)).eval()
+    out = {}
+    for k, v in model.state_dict().items():
+        out[f'sd::{k}'] = v.detach().numpy().copy()
+    shape = (1, 4, 240, 240, 155)
+    x = T(formula_tensor(shape, 9))
+    idx = None
+    for tag in ('f32', 'f64'):
+        m = model if tag == 'f32' else None
+        if m is None:
+            m = nets.HNOSegXS(4, 4, 24, [3] * 8, (10, 14, 14)).double().eval()
+            m.load_state_dict({k: v.double() for k, v in model.state_dict().items()})
+        with torch.no_grad():
+            y = m(x if tag == 'f32' else x.double())
+        assert tuple(y.shape) == (1, 4) + shape[2:]
+        if idx is None:
+            idx = sample_indices(int(np.prod(shape[2:])), 8192, 3)       # voxel indices (all four classes of a voxel are kept)
+            out['shape'], out['vox_idx'] = np.array(shape), idx
+        probs = y.detach().double().reshape(4, -1)
+        out[f'{tag}::probs'] = probs[:, idx].float().numpy()
+        out[f'{tag}::class_sums'] = probs.sum(1).numpy()
+        lab = probs.argmax(0)
+        out[f'{tag}::labels'] = lab[idx].numpy().astype(np.uint8)
+        out[f'{tag}::hist'] = torch.bincount(lab, minlength=4).numpy()
+        top2 = probs[:, idx].topk(2, dim=0).values
+        out[f'{tag}::margin'] = (top2[0] - top2[1]).float().numpy()
+        del y, probs
+    save('g17_inference_full_size.npz', **out)
+
+
 if __name__ == '__main__':
     ALL = [g1_dht, g2_crop_pad, g3_operators, g4_mha, g5_losses, g6_hnosegxs, g6_128, g6s_small_models, g6b_xsblock_branch, g7_noseg_models,
-           g7v_vnet_models, g7b_bf16_models, g15_cfg3_full_size, g16_cfg4_full_size, g9_misc, g10_two_d, g11_input, g12_mha_bias, g13_models_2d, g8_training, g14_testing]
+           g7v_vnet_models, g7b_bf16_models, g15_cfg3_full_size, g16_cfg4_full_size, g9_misc, g10_two_d, g11_input, g12_mha_bias, g13_models_2d, g8_training, g14_testing, g17_inference_full_size]
     only = set(sys.argv[2:])   # e.g. `make_golden.py /root/reference g10_two_d` regenerates one fixture
     for fn in ALL:
         if not only or fn.__name__ in only:

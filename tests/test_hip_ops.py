@@ -914,6 +914,50 @@ def test_specmix_stack(pkg, C, L, residual, shape):
         assert rel_err(a.cpu().numpy(), b.numpy()) < 1e-5
 
 
+def test_inference_full_size_vs_reference_golden(pkg):
+    """The reference's published inference size (README.md:10, experiments/train_test.py:383-426): HNOSeg-XS in eval mode under no_grad
+    on one 4 x 240 x 240 x 155 volume against golden G17 (the reference's own fp32 and float64 runs at that size).  The working grid is
+    121 x 121 x 78: item plane kernels for 121 x 78 planes (four items per plane, the last one partial, an even row length), the fused
+    middle for 121 planes, the chained pointwise kernel without its first layer's store.  Probabilities: bars below; class map produced on
+    the GPU (ops.label_output): equal to the reference's arg max wherever its top-2 margin exceeds 1e-4 (all 8 192 samples), label
+    histogram within 0.1 %."""
+    from multimodal_3d_image_segmentation_amd import ops
+    g = load_golden('g17_inference_full_size.npz')
+    model = pkg.nets.HNOSegXS(4, 4, 24, [3] * 8, (10, 14, 14))
+    model.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd::')})
+    model = model.cuda().eval()
+    shape = tuple(int(v) for v in g['shape'])
+    x = T(formula_tensor(shape, 9))
+    L = pkg._lib.lib()
+    with torch.no_grad():
+        y = model(x)
+        assert L.hno_debug_last_plane_family(0) == 4 and L.hno_debug_last_plane_family(1) == 4
+        with ops.label_output():
+            lab = model(x)
+    assert tuple(y.shape) == shape[:1] + (4,) + shape[2:] and lab.dtype == torch.uint8
+    idx = torch.from_numpy(g['vox_idx']).cuda()
+    probs = y.reshape(4, -1)
+    got = probs[:, idx].cpu().numpy()
+    ref_own = rel_err(g['f32::probs'], g['f64::probs'])
+    l2 = lambda a, b: float(np.sqrt(((a.astype(np.float64) - b) ** 2).sum() / (b.astype(np.float64) ** 2).sum()))
+    print(f'inference 240x240x155: vs reference fp32 {rel_err(got, g["f32::probs"]):.2e}, vs its float64 run {rel_err(got, g["f64::probs"]):.2e} '
+          f'(reference fp32 vs float64: {ref_own:.2e}); L2 {l2(got, g["f64::probs"]):.2e} (reference {l2(g["f32::probs"], g["f64::probs"]):.2e})')
+    # Bars.  In L2 the probabilities are within north_star's 1e-4 of the reference by an order of magnitude (7e-6).  In the max norm the
+    # reference's OWN fp32 run is 6.9e-5 from its float64 run at this size (24 SELU layers, softmax), so two correct fp32 evaluations can
+    # differ by the sum of their errors: the kernels are held to 2x the reference's own error against the float64 truth (measured 1.7x)
+    # and to 3x against its fp32 run (measured 2.2x) -- the convention of the 128^3 headline test, not widened.
+    assert l2(got, g['f32::probs']) < 1e-4 and l2(got, g['f64::probs']) < 2.0 * l2(g['f32::probs'], g['f64::probs'])
+    assert rel_err(got, g['f64::probs']) < 2.0 * ref_own
+    assert rel_err(got, g['f32::probs']) < 3.0 * ref_own
+    sums = probs.double().sum(1).cpu().numpy()
+    assert np.abs(sums - g['f32::class_sums']).max() / g['f32::class_sums'].max() < 1e-5
+    labels = lab.reshape(-1)[idx].cpu().numpy()
+    sure = g['f32::margin'] > 1e-4
+    assert np.array_equal(labels[sure], g['f32::labels'][sure])
+    hist = torch.bincount(lab.reshape(-1).long(), minlength=4).cpu().numpy()
+    assert np.abs(hist - g['f32::hist']).sum() < 1e-3 * hist.sum()
+
+
 @pytest.mark.parametrize('size', [(48, 40, 36), (64, 64, 64)])
 def test_hnosegxs_inference_forward_equals_the_training_forward(pkg, size):
     """Under no_grad the chained pointwise kernel of the decoder blocks does not store its first layer's output (only the backward reads

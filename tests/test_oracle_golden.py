@@ -273,6 +273,24 @@ def test_cfg3_full_size_oracle():
     assert den > 0 and np.sqrt(num / den) < 1e-4
 
 
+def test_inference_full_size_oracle():
+    """The reference's published inference size (README.md:10; golden G17: its HNOSeg-XS in eval mode on one 4 x 240 x 240 x 155 volume,
+    working grid 121 x 121 x 78): the oracle's probabilities and arg-max labels against the reference's fp32 run.  (~25 s of CPU time.)"""
+    g = load_golden('g17_inference_full_size.npz')
+    params = {k[4:]: T(g[k]) for k in g.files if k.startswith('sd::')}
+    shape = tuple(int(v) for v in g['shape'])
+    x = T(formula_tensor(shape, 9))
+    with torch.no_grad():
+        y = O.hnosegxs_forward(params, x, [3] * 8, (10, 14, 14))
+    probs = y.double().reshape(4, -1)
+    idx = g['vox_idx']
+    assert rel_err(probs[:, idx].float().numpy(), g['f32::probs']) < 2e-5
+    assert np.abs(probs.sum(1).numpy() - g['f32::class_sums']).max() / g['f32::class_sums'].max() < 1e-6
+    lab = probs.argmax(0)[idx].numpy()
+    sure = g['f32::margin'] > 1e-4
+    assert sure.mean() > 0.9 and np.array_equal(lab[sure], g['f32::labels'][sure])
+
+
 def test_cfg4_full_size_oracle():
     """BASELINE cfg4 at its real volume size (golden G16: the reference's V-Net-DS on one 4 x 160 x 192 x 128 volume): the oracle's fp32
     outputs, loss and sampled gradients against the reference's fp32 run, on the weights the constructor draws under seed 0 (proved equal to
