@@ -1488,7 +1488,7 @@ int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const fl
         // tile and want two (model step 10.63 -> 10.55 ms; 1 024: 10.57)
         const int fcap = fcap_env > 0 ? fcap_env : (Ca == 12 ? 512 : 256);
         if (fgrid > fcap) fgrid = fcap;   // one block per CU
-        if (a.dbg >> 8) fgrid = a.dbg >> 8;
+        if (debug_grid()) fgrid = debug_grid();
         const dim3 fb(64 * PWF_DMA_WAVES);
         const size_t fl = (size_t)PWF_DMA_WAVES * 2 * (a.Cin / 2) * 256;      // the waves' DMA rings
         if (bf16 && Ca == 24 && Cb == 0 && Cout == 24) hipLaunchKernelGGL((pwconv_fwd_fast_kernel<24, 0, 24, true>), dim3(fgrid), fb, fl, fs, a);
@@ -1622,7 +1622,7 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
         long long fg = (ntiles + NW - 1) / NW;
         static const int bcap_env = getenv("HNO_PWB_GRID_CAP") ? atoi(getenv("HNO_PWB_GRID_CAP")) : 0;      // A/B aid
         if (fg > (bcap_env > 0 ? bcap_env : 512)) fg = bcap_env > 0 ? bcap_env : 512;   // two blocks per CU
-        if (a.dbg >> 8) fg = a.dbg >> 8;
+        if (debug_grid()) fg = debug_grid();
         static int attr_done = -1;
         if (attr_done != current_device()) {
             (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
