@@ -47,7 +47,7 @@ struct MidArgs {
 
 __device__ __forceinline__ int mid_chan(int ks, int h) { return (ks & 3) + 8 * (ks >> 2) + 4 * h; }
 
-// N0: planes (odd), M0: kept modes along D (frequencies k0 = 0..M0 are computed; +M0 itself is not kept, -M0 is)
+// N0: planes (odd, or even since round 5), M0: kept modes along D (frequencies k0 = 0..M0 are computed; +M0 itself is not kept, -M0 is)
 //
 // Both D steps are small GEMMs on v_mfma_f32_16x16x4_f32 whose 16 COLUMNS are (column j of the tile, re / im part, 2 channels): the
 // N dimension of the MFMA is filled by batching over parts and channels, not by widening the k2 tile, so 4-column tiles cost no
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64 * MID_NW, 1) void spec_mid_kernel(MidArgs a) {
     constexpr int NMODE = 2 * 2 * M0 * 4;              // modes of the tile: (sign of (k1, k2), o0, column)
     constexpr int NT = (NMODE + 31) / 32;             // 32-mode MFMA tiles
     constexpr int NCT = C / 2;                         // column tiles of the D steps: 2 channels x 2 parts x 4 columns
-    static_assert((N0 & 1) && K0 <= 16 && 2 * M0 <= N0, "odd plane count, one k0 tile");
+    static_assert(K0 <= 16 && 2 * M0 <= N0, "one k0 tile");      // (an even N0: the plane N0 / 2 is its own mirror -- see mid_twiddles)
     constexpr int NPQ = C * 2 * 2 * K0 * 4, NZL = C * NT * 32;
     constexpr int GLD = 34;                            // row stride of the G / Z tiles: == 2 (mod 4), conflict-free 16x16x4 operand reads
     constexpr int TILE = 2 * 32 * GLD;                 // backward: [o][mode] and [i][mode] tiles of one wave
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(64 * MID_NW, 1) void spec_mid_kernel(MidArgs a) {
                 const float en = part ? U[r] + V[r] : U[r] - V[r], em = part ? U[r] - V[r] : U[r] + V[r];
                 if (n <= J) {      // (the last tile of an N0 with (N0 - 1) / 2 not a multiple of 16 is partly empty)
                     dst[(size_t)n * pstride] = en;
-                    dst[(size_t)(N0 - n) * pstride] = em;
+                    if ((N0 & 1) || 2 * n != N0) dst[(size_t)(N0 - n) * pstride] = em;      // (even N0: plane N0 / 2 is its own mirror)
                 }
             }
         }
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(512, 1) void spec_mid_fourier_kernel(MidFArgs a) {
     constexpr int NCT = C / 2;
     constexpr int NPQ = C * 2 * 2 * K0 * 4, NZL = C2 * NT * 32;
     constexpr int GLD = 34, TILE = 2 * C2 * GLD;
-    static_assert((N0 & 1) && K0 <= 16 && 2 * M0 <= N0, "odd plane count, one k0 tile");
+    static_assert(K0 <= 16 && 2 * M0 <= N0, "one k0 tile");      // (an even N0: the plane N0 / 2 is its own mirror -- see mid_twiddles)
     extern __shared__ float lds[];
     float *PQ = lds, *ZL = lds + NPQ, *GZ = ZL + NZL, *MINE = GZ + NT * TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(512, 1) void spec_mid_fourier_kernel(MidFArgs a) {
                 const float en = part ? U[r] + V[r] : U[r] - V[r], em = part ? U[r] - V[r] : U[r] + V[r];
                 if (n <= J) {      // (the last tile of an N0 with (N0 - 1) / 2 not a multiple of 16 is partly empty)
                     dst[(size_t)n * pstride] = en;
-                    dst[(size_t)(N0 - n) * pstride] = em;
+                    if ((N0 & 1) || 2 * n != N0) dst[(size_t)(N0 - n) * pstride] = em;      // (even N0: plane N0 / 2 is its own mirror)
                 }
             }
         }
@@ -749,7 +749,8 @@ static int mid_twiddles(int N0, int M0, const float **out) {
             const int k0 = ln & 15, n = 4 * ks + (ln >> 4);
             if (k0 > M0 || n > J) continue;
             const double ang = th * (double)((long long)k0 * n % N0);
-            h[(size_t)ks * 64 + ln] = (float)cos(ang);
+            // (the forward D step folds v[n] + v[N0 - n]: the plane N0 / 2 of an even N0 is its own mirror and would count twice)
+            h[(size_t)ks * 64 + ln] = (float)(cos(ang) * (2 * n == N0 ? 0.5 : 1.0));
             h[(size_t)(KC + ks) * 64 + ln] = (float)sin(ang);
         }
     for (int mt = 0; mt < NMT; ++mt)
@@ -782,8 +783,9 @@ static size_t mid_lds_floats(int M0, int L, bool bwd) {
 
 using namespace hno;
 
+// (78: the depth of a 155 x 240 x 240 volume in the reference's (z, y, x) array order, experiments/utils.py:270 -- an even plane count)
 // plane counts N0 the fused middle kernels are instantiated for: the working grids of 64^3 ... 192^3 and 240^3 inputs (N0 = size / 2 + 1)
-#define HNO_MID_N0_LIST(X) X(33) X(41) X(49) X(57) X(65) X(73) X(81) X(97) X(105) X(113) X(121)
+#define HNO_MID_N0_LIST(X) X(33) X(41) X(49) X(57) X(65) X(73) X(78) X(81) X(97) X(105) X(113) X(121)
 static bool mid_n0_built(int N0) {
 #define X(n) if (N0 == n) return true;
     HNO_MID_N0_LIST(X)
@@ -818,7 +820,7 @@ extern "C" size_t hno_spec_mid_fourier_bwd_workspace_bytes(int B, int C, int m1)
     return sizeof(float) * (size_t)mid_workgroups(B, m1) * 4 * C * C;
 }
 
-// 1 if the fused kernels exist for this configuration (Hartley layout, 24 channels, odd N0 in {65, 33} with m0 = 10, one k tile per
+// 1 if the fused kernels exist for this configuration (Hartley layout, 24 channels, N0 in HNO_MID_N0_LIST with m0 = 10, one k tile per
 // plane axis); the caller falls back to hno_dht3_crop / hno_specmix_layers_* / hno_pad_idht3 otherwise.
 extern "C" int hno_spec_mid_supported(int C, int N0, int m0, int m1, int m2, int L) {
     return C == 24 && mid_n0_built(N0) && m0 == 10 && 2 * m0 <= N0 && m1 >= 1 && m1 <= 15 && m2 >= 1 && m2 <= 15 && L >= 1 && L <= 4;

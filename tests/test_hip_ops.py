@@ -100,6 +100,37 @@ def test_fused_spectral_middle_vs_three_kernel_path(pkg, n):
     assert rel_err(gu.cpu().numpy(), ops.pad_idht3_raw(z1[-1], (n, n, n), 1.0, None, ops.ACT_NONE).cpu().numpy()) < 2e-6
 
 
+def test_fused_spectral_middle_on_the_inference_grid_zyx(pkg):
+    """The same volume in the array order the reference's loader produces (experiments/utils.py:270: sitk.GetArrayFromImage -> (z, y, x) =
+    (155, 240, 240)): working grid 78 x 121 x 121 -- an EVEN plane count through the fused middle (plane 39 is its own mirror in the D
+    steps), 121 x 121 planes through the item kernels -- against the three-kernel path, forward and backward."""
+    from multimodal_3d_image_segmentation_amd import ops
+    L = pkg._lib.lib()
+    torch.manual_seed(6)
+    modes, sp = (10, 14, 14), (78, 121, 121)
+    sc = 1.0 / float(np.prod(sp))
+    x = torch.randn(1, 24, *sp, device='cuda')
+    Ws = [torch.randn(24, 24, device='cuda') * 0.2 for _ in range(3)]
+    assert ops.spectral_chain_supported(x, modes, 3)
+    z0 = ops.dht3_crop_raw(x, modes, sc)
+    zs = ops.specmix_fwd_raw(z0, Ws, 1, ops.ACT_SELU)
+    u = ops.pad_idht3_raw(zs[-1], sp, 1.0, x, ops.ACT_SELU)
+    f0, fs, fu = ops.spectral_chain_fwd_raw(x, Ws, modes, ops.ACT_SELU, sc, ops.ACT_SELU, addend=x)
+    assert L.hno_debug_last_plane_family(0) == 4 and L.hno_debug_last_plane_family(1) == 4
+    assert rel_err(f0.cpu().numpy(), z0.cpu().numpy()) < 1e-6
+    for l in range(3):
+        assert rel_err(fs[l].cpu().numpy(), zs[l].cpu().numpy()) < 1e-6
+    assert rel_err(fu.cpu().numpy(), u.cpu().numpy()) < 2e-6
+    g_u, add = torch.randn_like(x), torch.randn_like(x)
+    g_zl = ops.dht3_crop_raw(g_u, modes, 1.0)
+    g_z0, dW = ops.specmix_bwd_raw(g_zl, z0, zs, Ws, 1, ops.ACT_SELU)
+    want = ops.pad_idht3_raw(g_z0, sp, sc, add, ops.ACT_NONE)
+    got, dW2 = ops.spectral_chain_bwd_raw(g_u, f0, Ws, modes, ops.ACT_SELU, sc, add)
+    assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 2e-6
+    for l in range(3):
+        assert rel_err(dW2[l].cpu().numpy(), dW[l].cpu().numpy()) < 1e-5
+
+
 def test_fused_spectral_middle_on_the_inference_grid(pkg):
     """The working grid of the reference's published inference size (240 x 240 x 155 -> 121 x 121 x 78, README.md:10): 121 planes of
     121 x 78 through the item plane kernels and the fused middle (one sample), forward and backward, against the three-kernel path."""
@@ -163,7 +194,7 @@ def test_fused_spectral_middle_backward_vs_three_kernel_path(pkg, n, act):
     assert rel_err(got.cpu().numpy(), ops.pad_idht3_raw(g_z0, sp, 1.0, None, ops.ACT_NONE).cpu().numpy()) < 2e-6
 
 
-MID_SIZES = [33, 41, 49, 57, 65, 73, 81, 97, 105, 113, 121]      # HNO_MID_N0_LIST of csrc/hno_specmid.hip: every instantiation is run below
+MID_SIZES = [33, 41, 49, 57, 65, 73, 78, 81, 97, 105, 113, 121]      # HNO_MID_N0_LIST of csrc/hno_specmid.hip: every instantiation is run below
 
 
 @pytest.mark.parametrize('n', MID_SIZES)
@@ -261,7 +292,7 @@ def test_fused_fourier_middle_vs_float64_operator(pkg, n):
     assert rel_err(dwr.cpu().numpy(), g[1].numpy()) < 2e-5 and rel_err(dwi.cpu().numpy(), g[2].numpy()) < 2e-5
 
 
-@pytest.mark.parametrize('n', [65, 33, 49, 57, 41, 73, 81, 97, 121])
+@pytest.mark.parametrize('n', [65, 33, 49, 57, 41, 73, 78, 81, 97, 121])
 def test_fused_fourier_middle_vs_three_kernel_path(pkg, n):
     """hno_dht3_planes -> hno_spec_mid_fourier_fwd / _bwd -> hno_idht3_planes (the D step of the rfft + crop, the complex channel mix and
     the zero pad + D step of the inverse of a FNOSeg block, nets/fourier_operator.py:117-223, in one kernel each way) against
@@ -2130,7 +2161,7 @@ def test_limits_fail_loudly(pkg):
         pkg._lib.check(L.hno_dht3_crop_ld(pkg._lib.ptr(torch.randn(6 * 21 ** 3 + 4096, device='cuda')), None, 0, pkg._lib.ptr(out), pkg._lib.ptr(ws),
                                           6, 21, 21, 21, 4, 4, 4, 1.0, 21 ** 3 + 500, pkg._lib.stream_ptr()), 'x')
     assert L.hno_spec_mid_supported(24, 65, 10, 14, 14, 3) == 1 and L.hno_spec_mid_supported(16, 65, 10, 14, 14, 3) == 0
-    assert L.hno_spec_mid_supported(24, 61, 10, 14, 14, 3) == 0 and L.hno_spec_mid_supported(24, 49, 10, 14, 14, 3) == 1 and L.hno_spec_mid_supported(24, 121, 10, 14, 14, 3) == 1 and L.hno_spec_mid_supported(24, 65, 10, 14, 14, 5) == 0
+    assert L.hno_spec_mid_supported(24, 61, 10, 14, 14, 3) == 0 and L.hno_spec_mid_supported(24, 49, 10, 14, 14, 3) == 1 and L.hno_spec_mid_supported(24, 121, 10, 14, 14, 3) == 1 and L.hno_spec_mid_supported(24, 78, 10, 14, 14, 3) == 1 and L.hno_spec_mid_supported(24, 65, 10, 14, 14, 5) == 0
     assert not ops.spectral_chain_supported(torch.empty(1, 16, 65, 65, 65, device='cuda'), (10, 14, 14), 3)
     # the repack kernel: contiguous <-> padded, padding zeroed, values untouched
     t = torch.randn(2, 3, 5, 7, 9, device='cuda')

@@ -37,7 +37,7 @@ bash tools/r5/cfg3_ab.sh > $O/ab_zlayout_cfg3.txt 2>&1
 # the other families
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/vnet -- python3 tools/dbg/vnet_ab.py 0 > $O/vnet.log 2>&1
 python3 tools/bench_models.py fnoseg_cfg3 fnoseg_cfg3:bf16 hnoseg hartleymha vnetds_cfg4:bf16 vnetds_cfg4 fno_individual hnosegxs_cfg2@96 hnosegxs_cfg2@112 hnosegxs_cfg2@80 > $O/models.jsonl 2> /dev/null
-python3 tools/bench_infer.py > $O/inference.jsonl 2>/dev/null
+python3 tools/bench_infer.py > $O/inference.jsonl 2>/dev/null; python3 tools/bench_infer.py --size 155 240 240 >> $O/inference.jsonl 2>/dev/null
 for m in fnoseg hnoseg vnetds; do python3 tools/bench_infer.py --model $m >> $O/inference.jsonl 2>/dev/null; done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/infer -o run -- python3 tools/bench_infer.py --samples 8 > /dev/null 2>&1
 # same-box A/B of the item plane kernels for general sizes (and of 65 x 65 through them): headline, other image sizes, inference
