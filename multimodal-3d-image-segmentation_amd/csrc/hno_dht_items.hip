@@ -634,7 +634,7 @@ static const size_t kLdsMax = 160 * 1024;
 // 73.5 with 4; the smaller cubes differ by < 3 %.  65 x 65 (the benchmark's planes): the forward kernel with SEVEN waves runs 17.8 us
 // where dht_fwd_plane_dma_kernel (eight) runs 18.9 in the same step (6: 18.5, 5: 18.2, 4: 18.3); the inverse without residual 24.2
 // against dht_inv_item_kernel's 25.4 (with residual 30.6 against 30.1: that one stays with the older kernel, see dht_inverse_launch).
-#define HNO_ITEM_SIZES(X) X(65, 65, 7, 12) X(121, 78, 4, 12) X(41, 41, 8, 12) X(49, 49, 8, 12) X(57, 57, 8, 12) X(73, 73, 6, 12) X(81, 81, 4, 12) X(97, 97, 4, 12) X(105, 105, 4, 8) X(113, 113, 4, 8) X(121, 121, 4, 8) X(129, 129, 4, 8)
+#define HNO_ITEM_SIZES(X) X(65, 65, 7, 12) X(121, 78, 4, 12) X(41, 41, 8, 12) X(49, 49, 8, 12) X(57, 57, 8, 12) X(73, 73, 6, 12) X(81, 81, 4, 12) X(89, 89, 4, 12) X(97, 97, 4, 12) X(105, 105, 4, 8) X(113, 113, 4, 8) X(121, 121, 4, 8) X(129, 129, 4, 8)
 
 template <int N1, int N2, int NWV>
 static int fwd_items_launch_t(const float *xal, float *ws, const DhtArgs &a, unsigned shift0, unsigned max_off, int planes, unsigned ldbc,

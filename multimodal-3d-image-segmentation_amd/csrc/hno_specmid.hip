@@ -785,7 +785,7 @@ using namespace hno;
 
 // (78: the depth of a 155 x 240 x 240 volume in the reference's (z, y, x) array order, experiments/utils.py:270 -- an even plane count)
 // plane counts N0 the fused middle kernels are instantiated for: the working grids of 64^3 ... 256^3 inputs (N0 = size / 2 + 1)
-#define HNO_MID_N0_LIST(X) X(33) X(41) X(49) X(57) X(65) X(73) X(78) X(81) X(97) X(105) X(113) X(121) X(129)
+#define HNO_MID_N0_LIST(X) X(33) X(41) X(49) X(57) X(65) X(73) X(78) X(81) X(89) X(97) X(105) X(113) X(121) X(129)
 static bool mid_n0_built(int N0) {
 #define X(n) if (N0 == n) return true;
     HNO_MID_N0_LIST(X)
