@@ -629,12 +629,12 @@ __global__ __launch_bounds__(64 * NWV, (NWV + 3) / 4) void dht_inv_items_kernel(
 static const size_t kLdsMax = 160 * 1024;
 
 // plane sizes the item kernels are built for: (N1, N2, waves per workgroup forward, inverse) -- the cubic working grids of 80^3 ... 256^3
-// inputs and the 121 x 78 planes of 240 x 240 x 155 images (from 105 up the forward kernel's registers overflow into AGPRs, no scratch).
+// inputs, the 121 x 78 planes of 240 x 240 x 155 images and the 97 x 65 planes of 160 x 192 x 128 volumes (BASELINE cfg4's size) (from 105 up the forward kernel's registers overflow into AGPRs, no scratch).
 // Waves per workgroup are measured: forward 121 x 78 26.9 us with 4, 30.0 with 6, 31.2 with 7; inverse 45.4 us with 12, 50.0 with 8,
 // 73.5 with 4; the smaller cubes differ by < 3 %.  65 x 65 (the benchmark's planes): the forward kernel with SEVEN waves runs 17.8 us
 // where dht_fwd_plane_dma_kernel (eight) runs 18.9 in the same step (6: 18.5, 5: 18.2, 4: 18.3); the inverse without residual 24.2
 // against dht_inv_item_kernel's 25.4 (with residual 30.6 against 30.1: that one stays with the older kernel, see dht_inverse_launch).
-#define HNO_ITEM_SIZES(X) X(65, 65, 7, 12) X(121, 78, 4, 12) X(41, 41, 8, 12) X(49, 49, 8, 12) X(57, 57, 8, 12) X(73, 73, 6, 12) X(81, 81, 4, 12) X(89, 89, 4, 12) X(97, 97, 4, 12) X(105, 105, 4, 8) X(113, 113, 4, 8) X(121, 121, 4, 8) X(129, 129, 4, 8)
+#define HNO_ITEM_SIZES(X) X(65, 65, 7, 12) X(121, 78, 4, 12) X(97, 65, 6, 12) X(41, 41, 8, 12) X(49, 49, 8, 12) X(57, 57, 8, 12) X(73, 73, 6, 12) X(81, 81, 4, 12) X(89, 89, 4, 12) X(97, 97, 4, 12) X(105, 105, 4, 8) X(113, 113, 4, 8) X(121, 121, 4, 8) X(129, 129, 4, 8)
 
 template <int N1, int N2, int NWV>
 static int fwd_items_launch_t(const float *xal, float *ws, const DhtArgs &a, unsigned shift0, unsigned max_off, int planes, unsigned ldbc,
