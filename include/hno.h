@@ -231,6 +231,9 @@ int hno_pwconv_bwd_branch(const float *gy, const float *y, const float *xa, int 
  * dW2[re,im]. */
 int hno_cmix_compose(const float *w_real, const float *w_imag, float *w2, int Co, int Ci, void *stream);
 int hno_cmix_split_grad(const float *dw2, float *dw_real, float *dw_imag, int Co, int Ci, void *stream);
+/* defer != 0 and deferred slab reductions on (hno_set_defer_reduce): the split is recorded and launched by hno_flush_reduces behind the
+ * reduction that writes dw2 (hno_spec_mid_fourier_bwd with bit 8 of w_fwd set) -- one kernel for all blocks of a backward pass */
+int hno_cmix_split_grad_ex(const float *dw2, float *dw_real, float *dw_imag, int Co, int Ci, int defer, void *stream);
 
 /* ------------------------------------------- strided 2x2x2 'resize' convolution (conv_in)
  * Conv3d(Cin -> Cout, kernel 2, stride 2, padding 1) + bias + act: (B,Cin,D,H,W) ->

@@ -59,6 +59,8 @@ int reduce_partials_launch(const float *partials, int nblocks, int n, float *dst
 bool defer_reduce_enabled();
 // layout of the plane kernels' intermediate around the fused spectral middle (hno_dht.hip: DhtArgs.zl; HNO_MID_ZLAYOUT=0 keeps the old one)
 bool mid_zlayout();
+// records the real / imaginary split of a Fourier block's weight gradient for hno_flush_reduces (hno_core.hip); false: launch it now
+bool cmix_split_defer(const float *dw2, float *dwr, float *dwi, int Co, int Ci, bool allow_defer);
 
 // wave-private accumulator fragments -> one slab per block.  `scratch` is >= nwaves * n floats of LDS.
 // frag(idx) semantic: each wave calls store(idx, value) for the elements it owns; all 4 waves own

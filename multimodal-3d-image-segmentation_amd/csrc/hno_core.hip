@@ -219,6 +219,59 @@ __global__ __launch_bounds__(1024) void reduce_partials_multi_kernel(ReduceBatch
     }
 }
 
+// ---- deferred real / imaginary split of a Fourier block's weight gradient (hno_cmix_split_grad): it reads the dW2 a deferred slab
+// reduction writes, so it is recorded with it and launched -- ONE kernel for all blocks -- right behind the batched reduction
+// (FNOSeg: 24 single reductions + 24 splits of ~5 us each per step before round 5)
+struct SplitEntry {
+    const float *dw2;
+    float *dwr, *dwi;
+    int Co, Ci, first_block;
+};
+struct SplitBatch {
+    SplitEntry e[HNO_MAX_DEFERRED];
+    int count;
+};
+static std::vector<SplitEntry> g_deferred_splits;
+
+// dWr = dW2[re, re] + dW2[im, im];  dWi = dW2[im, re] - dW2[re, im]   (one entry per block range; cmix_split_kernel's arithmetic)
+__global__ __launch_bounds__(256) void cmix_split_multi_kernel(SplitBatch b) {
+    int ei = 0;
+    while (ei + 1 < b.count && (int)blockIdx.x >= b.e[ei + 1].first_block) ++ei;
+    const SplitEntry &e = b.e[ei];
+    const int Co = e.Co, Ci = e.Ci, idx = ((int)blockIdx.x - e.first_block) * 256 + (int)threadIdx.x;
+    if (idx >= Co * Ci) return;
+    const int o = idx / Ci, i = idx - o * Ci;
+    const float rr = e.dw2[(size_t)o * 2 * Ci + i], ri = e.dw2[(size_t)o * 2 * Ci + Ci + i];
+    const float ir = e.dw2[(size_t)(o + Co) * 2 * Ci + i], ii = e.dw2[(size_t)(o + Co) * 2 * Ci + Ci + i];
+    e.dwr[idx] = rr + ii;
+    e.dwi[idx] = ir - ri;
+}
+
+// -> true when the split was recorded (deferred reductions are on and the caller allows it); false: the caller launches it now
+bool cmix_split_defer(const float *dw2, float *dwr, float *dwi, int Co, int Ci, bool allow_defer) {
+    if (!(g_defer_reduce && allow_defer)) return false;
+    g_deferred_splits.push_back(SplitEntry{dw2, dwr, dwi, Co, Ci, 0});
+    return true;
+}
+
+static int flush_splits(hipStream_t stream) {
+    size_t i = 0;
+    while (i < g_deferred_splits.size()) {
+        SplitBatch b;
+        b.count = 0;
+        int blocks = 0;
+        while (i < g_deferred_splits.size() && b.count < HNO_MAX_DEFERRED) {
+            SplitEntry e = g_deferred_splits[i++];
+            e.first_block = blocks;
+            blocks += ceil_div(e.Co * e.Ci, 256);
+            b.e[b.count++] = e;
+        }
+        hipLaunchKernelGGL(cmix_split_multi_kernel, dim3(blocks), dim3(256), 0, stream, b);
+    }
+    g_deferred_splits.clear();
+    return HNO_OK;
+}
+
 int flush_reduces(hipStream_t stream) {
     size_t i = 0;
     while (i < g_deferred.size()) {
@@ -236,6 +289,7 @@ int flush_reduces(hipStream_t stream) {
         ++g_reduce_launches[1];
     }
     g_deferred.clear();
+    flush_splits(stream);        // (they read what the reductions just wrote: same stream, behind them)
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }
@@ -294,6 +348,7 @@ extern "C" int hno_pending_reduces(void) {
 extern "C" int hno_discard_reduces(void) {   // forget recorded reductions (a backward pass that was aborted by an exception)
     int n = (int)g_deferred.size();
     g_deferred.clear();
+    g_deferred_splits.clear();
     return n;
 }
 extern "C" int hno_flush_reduces(void *stream) {

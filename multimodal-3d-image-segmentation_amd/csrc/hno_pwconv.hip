@@ -1889,6 +1889,19 @@ extern "C" int hno_cmix_compose(const float *w_real, const float *w_imag, float 
     return HNO_OK;
 }
 
+// defer != 0: when deferred slab reductions are on (hno_set_defer_reduce) the split is recorded and runs in hno_flush_reduces, behind the
+// reduction that writes dw2 (which must then have been called with its own defer bit: hno_spec_mid_fourier_bwd, bit 8 of w_fwd)
+extern "C" int hno_cmix_split_grad_ex(const float *dw2, float *dw_real, float *dw_imag, int Co, int Ci, int defer, void *stream) {
+    HNO_REQUIRE(dw2 && dw_real && dw_imag && Co > 0 && Ci > 0, "hno_cmix_split_grad: bad argument");
+    if (defer) {
+        const int prev = hno_set_defer_reduce(1);
+        const bool rec = cmix_split_defer(dw2, dw_real, dw_imag, Co, Ci, true);
+        hno_set_defer_reduce(prev);
+        if (rec) return HNO_OK;
+    }
+    return hno_cmix_split_grad(dw2, dw_real, dw_imag, Co, Ci, stream);
+}
+
 extern "C" int hno_cmix_split_grad(const float *dw2, float *dw_real, float *dw_imag, int Co, int Ci, void *stream) {
     HNO_REQUIRE(dw2 && dw_real && dw_imag && Co > 0 && Ci > 0, "hno_cmix_split_grad: bad argument");
     hipLaunchKernelGGL(cmix_split_kernel, dim3(ceil_div(Co * Ci, 256)), dim3(256), 0, (hipStream_t)stream, dw2, dw_real, dw_imag, Co, Ci);

@@ -936,7 +936,8 @@ static int mid_fourier_launch(bool bwd, void *workspace, const float *W2, float 
     a.m1 = m1;
     a.m2 = m2;
     a.scale = scale;
-    a.w_fwd = w_fwd;
+    const bool defer = ((w_fwd >> 8) & 1) != 0;
+    a.w_fwd = w_fwd & 0xff;
     a.w_inv = w_inv;
     a.dbg = debug_flags();
     a.zl = mid_zlayout() ? 1 : 0;
@@ -968,8 +969,11 @@ static int mid_fourier_launch(bool bwd, void *workspace, const float *W2, float 
     }
     HNO_CHECK_LAUNCH();
     if (!bwd) return HNO_OK;
-    const int prev = hno_set_defer_reduce(0);      // the caller splits dW2 into its real / imaginary parts right away: reduce now
+    // bit 8 of w_fwd: record the slab reduction for hno_flush_reduces (the caller then records the real / imaginary split behind it:
+    // hno_cmix_split_grad_ex); without it the caller splits dW2 right away: reduce now
+    const int prev = hno_set_defer_reduce(0);
     struct Restore { int v; ~Restore() { hno_set_defer_reduce(v); } } restore{prev};
+    hno_set_defer_reduce(defer ? 1 : 0);
     return reduce_partials_launch(a.partials, nwg, n, dW2, n, nullptr, s);
 }
 

@@ -685,9 +685,10 @@ def fourier_chain_fwd_raw(x, w2, modes, scale_fwd, addend, inv_act):
     return s0, y
 
 
-def fourier_chain_bwd_raw(p, s0, w2, modes, scale_out, addend):
+def fourier_chain_bwd_raw(p, s0, w2, modes, scale_out, addend, defer=False):
     """backward of the same chain: p = gradient of the inverse transform's (pre-activation) output -> (gx, dW2 (2C, 2C)); the gradients
-    of the spectra never reach memory."""
+    of the spectra never reach memory.  defer: dW2's slab reduction joins the batched end-of-backward reduction (the caller then
+    defers the real / imaginary split likewise: cmix_split_grad_raw)."""
     _need_gpu(p, addend)
     B, C, N0, N1, N2 = p.shape
     m0, m1, m2 = modes
@@ -699,9 +700,11 @@ def fourier_chain_bwd_raw(p, s0, w2, modes, scale_out, addend):
     dw2 = torch.empty((2 * C, 2 * C), device=p.device, dtype=torch.float32)
     gx = act_like(p)
     check(L.hno_dht3_planes(ptr(p), ptr(ws), B * C, N0, N1, N2, m0, m1, m2, ld, stream_ptr()), 'hno_dht3_planes')
-    check(L.hno_spec_mid_fourier_bwd(ptr(ws), ptr(w2), ptr(s0), ptr(dw2), ptr(slab), 4 * slab.numel(), B, C, N0, m0, m1, m2, 1.0, 1, 0,
-                                     stream_ptr()),
-          'hno_spec_mid_fourier_bwd')
+    with _DeferReduce(defer) as d:
+        check(L.hno_spec_mid_fourier_bwd(ptr(ws), ptr(w2), ptr(s0), ptr(dw2), ptr(slab), 4 * slab.numel(), B, C, N0, m0, m1, m2, 1.0, 1 | d.bit, 0,
+                                         stream_ptr()),
+              'hno_spec_mid_fourier_bwd')
+        d.keep(slab, dw2)
     check(L.hno_idht3_planes(ptr(ws), ptr(addend), ACT_NONE, ptr(gx), B * C, N0, N1, N2, m0, m1, m2, float(scale_out), ld, stream_ptr()),
           'hno_idht3_planes')
     return gx, dw2
@@ -1578,7 +1581,7 @@ class NOBlockFn(_HnoFunction):
     def backward(ctx, g_out):
         x, br_w, cat_w, w, s0, s1, y, out, br_b, cat_b, *op_ws = ctx.saved_tensors
         fourier, modes, act, spatial, n3, br_has_b, cat_has_b = ctx.cfg
-        late = ctx.leaf_params and _release_use(ctx, br_w, br_b, cat_w, cat_b, *op_ws) and _deferrable(br_w, br_b, cat_w, cat_b, *op_ws)   # (the Fourier mix reads its dW2 at once: never late)
+        late = ctx.leaf_params and _release_use(ctx, br_w, br_b, cat_w, cat_b, *op_ws) and _deferrable(br_w, br_b, cat_w, cat_b, *op_ws)
         d_br_w = d_br_b = None
         if br_w is not None and tuple(cat_w.shape[:2]) == (24, 48) and tuple(br_w.shape[:2]) == (24, 24):
             # one pass: p = d loss / d (s + x2) = g_y * act'(y); g_x = concat-path gradient + Wbr^T p; all four parameter gradients
@@ -1598,13 +1601,16 @@ class NOBlockFn(_HnoFunction):
             Co, Ci = w.shape[0] // 2, w.shape[1] // 2
             fused = Co == Ci == x.shape[1] and fourier_chain_supported(x, modes) and os.environ.get('HNO_FUSED_MID_BWD', '1') != '0'
             if fused:
-                gx, dw2 = fourier_chain_bwd_raw(p, s0, w, modes, 1.0 / n3, g_x)
+                gx, dw2 = fourier_chain_bwd_raw(p, s0, w, modes, 1.0 / n3, g_x, defer=late)
             else:
                 gs1 = rfft3_crop_raw(p, modes, 1.0, True)
                 gs0, _, dw2, _ = pwconv_bwd_raw(gs1, None, s0, None, w, ACT_NONE, False)
             dwr = torch.empty((Co, Ci), device=x.device, dtype=torch.float32)
             dwi = torch.empty_like(dwr)
-            check(_lib.lib().hno_cmix_split_grad(ptr(dw2), ptr(dwr), ptr(dwi), Co, Ci, stream_ptr()), 'hno_cmix_split_grad')
+            # (round 5: with the fused middle the reduction of dW2 and this split join the batched end-of-backward launches)
+            with _DeferReduce(late and fused) as d:
+                check(_lib.lib().hno_cmix_split_grad_ex(ptr(dw2), ptr(dwr), ptr(dwi), Co, Ci, 1 if d.on else 0, stream_ptr()), 'hno_cmix_split_grad')
+                d.keep(dw2)
             if not fused:
                 gx = irfft3_pad_raw(gs0, spatial, 1.0 / n3, False, g_x, ACT_NONE, ld=chan_stride(x))
             d_ops = (dwr, dwi)

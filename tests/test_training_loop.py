@@ -347,6 +347,48 @@ def test_sample_split_gives_the_batch_gradients(loss_name, monkeypatch):
     assert not split.aliased()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('transform', ['Fourier', 'Hartley'])
+def test_neural_operator_seg_backward_batches_every_reduction(transform):
+    """FNOSeg / HNOSeg with deferred reductions on (what bench.py and the captured step of training() run): ONE batched slab reduction
+    per backward pass -- until round 5 every Fourier block reduced its dW2 on its own (24 launches per cfg3 step) because the real /
+    imaginary split read it at once; the split is recorded behind the reduction now and runs as ONE kernel for all blocks
+    (hno_cmix_split_grad_ex).  Gradients equal the undeferred pass bit for bit."""
+    import multimodal_3d_image_segmentation_amd as pkg
+    from multimodal_3d_image_segmentation_amd import ops, _lib
+    from multimodal_3d_image_segmentation_amd.nets import custom_losses as CL
+    torch.manual_seed(9)
+    model = pkg.nets.NeuralOperatorSeg(4, 4, 24, 3, (10, 14, 14), transform).cuda()
+    loss_fn = CL.PCCLoss()
+    x = torch.randn(1, 4, 64, 64, 64, device='cuda')
+    y = torch.randint(0, 4, (1, 1, 64, 64, 64), device='cuda').float()
+    params = list(model.parameters())
+    L = _lib.lib()
+
+    def run(defer):
+        prev = ops.set_defer_reduce(defer)
+        try:
+            lab = ops.labels_prepare(y, 4)
+            for p in params:
+                p.grad = None
+            out = model(x)
+            l = loss_fn(out, lab)
+            s0, m0 = L.hno_debug_reduce_launches(0), L.hno_debug_reduce_launches(1)
+            l.backward()
+            torch.cuda.synchronize()
+            counts = L.hno_debug_reduce_launches(0) - s0, L.hno_debug_reduce_launches(1) - m0
+            return float(l.detach()), [p.grad.clone() for p in params], counts
+        finally:
+            ops.set_defer_reduce(prev)
+    l0, g0, c0 = run(False)
+    l1, g1, c1 = run(True)
+    assert c0[1] == 0 and c0[0] >= 3                       # undeferred: a launch per slab set
+    assert c1[1] == 1 and c1[0] <= 1, c1                   # deferred: one batched launch (the stride-2 stem convolution keeps its own)
+    assert l0 == l1
+    for a, b in zip(g0, g1):
+        assert bool((a == b).all())
+
+
 def test_captured_step_measures_its_schedule(monkeypatch):
     """Round 5: whether a captured step runs its batch as one pass or as two half-batches on two streams is MEASURED when the step is
     captured (train_test.choose_schedule: both forms captured, replayed, the faster kept) -- round 4 carried a hand-measured list of
