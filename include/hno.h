@@ -230,6 +230,8 @@ int hno_pwconv_bwd_branch(const float *gy, const float *y, const float *xa, int 
  * hno_pwconv_fwd / hno_pwconv_bwd; hno_cmix_split_grad turns dW2 into dWr = dW2[re,re] + dW2[im,im], dWi = dW2[im,re] -
  * dW2[re,im]. */
 int hno_cmix_compose(const float *w_real, const float *w_imag, float *w2, int Co, int Ci, void *stream);
+/* the same for n <= 64 pairs of equal shape in one launch: w2_all (n, 2Co, 2Ci) (all Fourier blocks of a model, once per forward pass) */
+int hno_cmix_compose_multi(const float *const *w_real, const float *const *w_imag, float *w2_all, int n, int Co, int Ci, void *stream);
 int hno_cmix_split_grad(const float *dw2, float *dw_real, float *dw_imag, int Co, int Ci, void *stream);
 /* defer != 0 and deferred slab reductions on (hno_set_defer_reduce): the split is recorded and launched by hno_flush_reduces behind the
  * reduction that writes dw2 (hno_spec_mid_fourier_bwd with bit 8 of w_fwd set) -- one kernel for all blocks of a backward pass */

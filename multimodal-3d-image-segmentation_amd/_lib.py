@@ -58,6 +58,7 @@ SIGNATURES = {
     'hno_pwconv_bwd_branch_workspace_bytes': (c_size_t, [c_int] * 3),
     'hno_pwconv_bwd_branch': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 6 + [c_int, c_int, c_ll, c_int, c_int, c_void_p]),
     'hno_cmix_compose': (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p]),
+    'hno_cmix_compose_multi': (c_int, [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p]),
     'hno_cmix_split_grad': (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p]),
     'hno_cmix_split_grad_ex': (c_int, [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p]),
     'hno_conv_k2s2_fwd': (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_ll, c_void_p]),

@@ -1730,6 +1730,22 @@ __global__ void cmix_compose_kernel(const float *__restrict__ wr, const float *_
     }
 }
 
+// the same for up to 64 blocks in one launch: blockIdx.y = block of the model (FNOSeg: 24 launches of ~4 us per forward pass -> 1)
+struct CmixBatch {
+    const float *wr[64], *wi[64];
+};
+__global__ void cmix_compose_multi_kernel(CmixBatch b, float *__restrict__ w2_all, int Co, int Ci) {
+    const int n = 4 * Co * Ci;
+    const float *wr = b.wr[blockIdx.y], *wi = b.wi[blockIdx.y];
+    float *w2 = w2_all + (size_t)blockIdx.y * n;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const int o = e / (2 * Ci), i = e - o * 2 * Ci;
+        const int oo = o < Co ? o : o - Co, ii = i < Ci ? i : i - Ci;
+        const float r = wr[oo * Ci + ii], im = wi[oo * Ci + ii];
+        w2[e] = (o < Co) == (i < Ci) ? r : (o < Co ? -im : im);
+    }
+}
+
 // dWr = dW2[re, re] + dW2[im, im];  dWi = dW2[im, re] - dW2[re, im]
 __global__ void cmix_split_kernel(const float *__restrict__ dw2, float *__restrict__ dwr, float *__restrict__ dwi, int Co, int Ci) {
     const int n = Co * Ci;
@@ -1880,6 +1896,20 @@ extern "C" int hno_pwconv_bwd_branch(const float *gy, const float *y, const floa
     struct Restore { int v; ~Restore() { hno_set_defer_reduce(v); } } restore{prev};
     hno_set_defer_reduce(((xa_act >> 8) & 1) ? 1 : prev);
     return pwconv_bwd_launch(gy, y, xa, Ca, xb, Cb, W, p_out, gxb, dflat, nullptr, workspace, B, Cout, V, act, 0, stream, xa_act & 0xff, 0, Wbr);
+}
+
+// n <= 64 weight pairs of equal shape -> w2_all (n, 2Co, 2Ci) in one launch
+extern "C" int hno_cmix_compose_multi(const float *const *w_real, const float *const *w_imag, float *w2_all, int n, int Co, int Ci, void *stream) {
+    HNO_REQUIRE(w_real && w_imag && w2_all && n > 0 && n <= 64 && Co > 0 && Ci > 0, "hno_cmix_compose_multi: bad argument (1 <= n <= 64)");
+    CmixBatch b = {};
+    for (int i = 0; i < n; ++i) {
+        HNO_REQUIRE(w_real[i] && w_imag[i], "hno_cmix_compose_multi: weight %d is NULL", i);
+        b.wr[i] = w_real[i];
+        b.wi[i] = w_imag[i];
+    }
+    hipLaunchKernelGGL(cmix_compose_multi_kernel, dim3(ceil_div(4 * Co * Ci, 256), n), dim3(256), 0, (hipStream_t)stream, b, w2_all, Co, Ci);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
 }
 
 extern "C" int hno_cmix_compose(const float *w_real, const float *w_imag, float *w2, int Co, int Ci, void *stream) {

@@ -41,6 +41,9 @@ class _TransBlock(nn.Module):
             return None
         fourier = isinstance(op, FourierOperator)
         op_ws = (op.weight_real, op.weight_imag) if fourier else (op.weight,)
+        w2 = getattr(self, '_w2_pre', None)          # composed by the model for all its blocks at once (_TransSeg._forward5)
+        if fourier and w2 is not None:
+            op_ws = op_ws + (w2,)
         br = self.conv_branch
         cc = self.conv_concat.op
         return ops.NOBlockFn.apply(x, fourier, tuple(op.num_modes), act, None if br is None else br.weight,
@@ -159,10 +162,25 @@ class _TransSeg(nn.Module):
         x = self.conv1(x)
         if self.use_deep_supervision:
             tensors.append(x)
-        for layer in self.layers:
-            x = layer(x)
-            if self.use_deep_supervision:
-                tensors.append(x)
+        # the complex weights of all fusable Fourier blocks in their composed real form, ONE launch per forward pass (round 5: each block
+        # ran its own hno_cmix_compose: 24 launches of ~4 us in FNOSeg's forward chain)
+        fblocks = [l for l in self.layers if isinstance(l, _TransBlock) and isinstance(l.op, FourierOperator) and x.ndim == 5
+                   and l._fusable(ops.act_id(l.activation))]
+        w2_all = None
+        if len(fblocks) > 1 and x.is_cuda:
+            with torch.no_grad():
+                w2_all = ops.cmix_compose_all([(l.op.weight_real, l.op.weight_imag) for l in fblocks])
+        try:
+            if w2_all is not None:
+                for l, w2 in zip(fblocks, w2_all.unbind(0)):
+                    l._w2_pre = w2
+            for layer in self.layers:
+                x = layer(x)
+                if self.use_deep_supervision:
+                    tensors.append(x)
+        finally:
+            for l in fblocks:
+                l._w2_pre = None
         if tensors:
             from .deep_supervision import conv_over_concat
             x = conv_over_concat(self.conv_ds, tensors)

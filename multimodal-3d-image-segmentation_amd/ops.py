@@ -658,6 +658,25 @@ def spectral_chain_bwd_raw(g_u, z0, W, modes, act, scale_out, addend, defer=Fals
     return g_xm, dW
 
 
+def cmix_compose_all(pairs):
+    """[(wr, wi), ...] of equal shape (Co, Ci) -> (n, 2Co, 2Ci): the composed real forms W2 = [[wr, -wi], [wi, wr]] of all Fourier blocks
+    of a model in ONE launch (hno_cmix_compose_multi); None when the pairs do not qualify (the blocks then compose their own)."""
+    import ctypes
+    if not pairs or len(pairs) > 64:
+        return None
+    shp = tuple(pairs[0][0].shape)
+    for wr, wi in pairs:
+        if not (wr.is_cuda and wi.is_cuda and wr.dtype == wi.dtype == torch.float32 and wr.is_contiguous() and wi.is_contiguous()
+                and tuple(wr.shape) == tuple(wi.shape) == shp and len(shp) == 2):
+            return None
+    Co, Ci = shp
+    out = torch.empty((len(pairs), 2 * Co, 2 * Ci), device=pairs[0][0].device, dtype=torch.float32)
+    arr = ctypes.c_void_p * len(pairs)
+    check(_lib.lib().hno_cmix_compose_multi(arr(*[w.data_ptr() for w, _ in pairs]), arr(*[w.data_ptr() for _, w in pairs]), ptr(out),
+                                           len(pairs), Co, Ci, stream_ptr()), 'hno_cmix_compose_multi')
+    return out
+
+
 def fourier_chain_supported(x, modes):
     """fused middle of the Fourier block (hno_spec_mid_fourier_*): 24 channels on 65^3 / 33^3 grids; HNO_FUSED_MID=0 switches it off."""
     if os.environ.get('HNO_FUSED_MID', '1') == '0' or x.dim() != 5:
@@ -1528,6 +1547,11 @@ class NOBlockFn(_HnoFunction):
 
     @staticmethod
     def forward(ctx, x, fourier, modes, act, br_w, br_b, cat_w, cat_b, *op_ws):
+        # op_ws: (weight,) of a Hartley operator; (weight_real, weight_imag[, w2]) of a Fourier operator -- w2: their composed real form
+        # when the model built it for all its blocks at once (ops.cmix_compose_all; not a parameter: no gradient)
+        w_pre = op_ws[2] if (fourier and len(op_ws) == 3) else None
+        ctx.n_ops = len(op_ws)
+        op_ws = op_ws[:2] if fourier else op_ws
         ctx.leaf_params = _leaf_params(ctx, br_w, br_b, cat_w, cat_b, *op_ws)
         br_w, br_b, cat_w, cat_b = (_f32c(t) for t in (br_w, br_b, cat_w, cat_b))
         op_ws = [_f32c(w) for w in op_ws]
@@ -1548,8 +1572,11 @@ class NOBlockFn(_HnoFunction):
         if fourier:
             wr, wi = op_ws
             Co, Ci = wr.shape
-            w = torch.empty((2 * Co, 2 * Ci), device=x.device, dtype=torch.float32)
-            check(_lib.lib().hno_cmix_compose(ptr(wr), ptr(wi), ptr(w), Co, Ci, stream_ptr()), 'hno_cmix_compose')
+            if w_pre is not None and tuple(w_pre.shape) == (2 * Co, 2 * Ci) and w_pre.is_contiguous():
+                w = w_pre
+            else:
+                w = torch.empty((2 * Co, 2 * Ci), device=x.device, dtype=torch.float32)
+                check(_lib.lib().hno_cmix_compose(ptr(wr), ptr(wi), ptr(w), Co, Ci, stream_ptr()), 'hno_cmix_compose')
             if Co == Ci == x.shape[1] and fourier_chain_supported(x, modes):
                 s0, y = fourier_chain_fwd_raw(x, w, modes, 1.0 / n3, x2, inv_act)
             else:
@@ -1623,7 +1650,7 @@ class NOBlockFn(_HnoFunction):
                 gs0, _, dw, _ = pwconv_bwd_raw(gs1, s1, s0, None, w, ACT_SELU, False, defer=late)
                 gx = pad_idht3_raw(gs0, spatial, 1.0 / n3, g_x, ACT_NONE, ld=chan_stride(x))
             d_ops = (dw,)
-        return (gx, None, None, None, d_br_w, d_br_b, d_cat_w, d_cat_b) + d_ops
+        return (gx, None, None, None, d_br_w, d_br_b, d_cat_w, d_cat_b) + d_ops + (None,) * (ctx.n_ops - len(d_ops))
 
 
 class XSBlockFn(_HnoFunction):
