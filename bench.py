@@ -340,6 +340,7 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=2, help='per-GPU batch (BASELINE config: 2)')
+    ap.add_argument('--bursts', type=int, default=5, help='the timed region of --steps steps is repeated this often; the median burst is reported')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a HIP graph')
@@ -548,14 +549,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
+    # The timed region is EXACTLY --steps steps between two fences (barrier + synchronize).  It is repeated --bursts times back to back
+    # and the MEDIAN burst is reported (verdict round 5, item 7: one 45 ms burst on a pool whose boxes and clocks wander is a coin
+    # toss); every burst's time is in config.ms_per_step_bursts, so the single-burst number the contract describes is there too
+    # (the first entry).  For N > 1 each burst's time is the MAX over ranks, taken before the median.
+    burst_dt = []
     host_s[0] = 0.0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    host_us_per_step = host_s[0] / args.steps * 1e6 if graph is not None else None
+    for _ in range(max(1, args.bursts)):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        fence()
+        burst_dt.append(time.perf_counter() - t0)
+    if world > 1:
+        tmax = torch.tensor(burst_dt, device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        burst_dt = [float(v) for v in tmax.tolist()]
+    dt = sorted(burst_dt)[(len(burst_dt) - 1) // 2]       # median (the lower one of an even count)
+    host_us_per_step = host_s[0] / (args.steps * len(burst_dt)) * 1e6 if graph is not None else None
     # per-kernel HIP-event durations: a few eager steps of the same workload right after the timed
     # region (events cannot be recorded inside a graph replay)
     prof = None
@@ -566,10 +578,6 @@ def main():
             for _ in range(prof_steps):
                 eager_step()
         fence()
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
     value = world * B * args.steps / dt
 
     if rank == 0:
@@ -593,6 +601,8 @@ def main():
                     traffic = tj.get('per_kernel_bytes_per_launch', tj).get(dom)
                 roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                             'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                            # PMC counters need rocprofv3 around the process: the number is the committed PMC pass of this command
+                            'traffic_source': 'profiles/hbm_traffic.json (static: rocprofv3 --pmc passes of this command, tools/make_hbm_traffic.py)' if traffic is not None else None,
                             'algorithmic_bytes_per_launch': ab, 'avg_launch_us': round(avg_ms * 1e3, 2)}
         out = {
             'metric': 'volumes/sec fwd+bwd, HNOSeg-XS 4-modal 128^3',
@@ -612,6 +622,9 @@ def main():
                        'allreduce_in_graph_chosen_by': ('env HNO_DP_CAPTURE_ALLREDUCE' if env_cap in ('0', '1') else
                                                         (f'probe on every rank (this rank: {probe_ok})' if world > 1 else 'n/a')),
                        'schedule_measured_ms': schedule_ms,
+                       # every timed burst of --steps steps, in order; ms_per_step / value are the median burst
+                       'ms_per_step_bursts': [round(v / args.steps * 1e3, 4) for v in burst_dt],
+                       'ms_per_step_min_max': [round(min(burst_dt) / args.steps * 1e3, 4), round(max(burst_dt) / args.steps * 1e3, 4)],
                        'dp_path_on_one_rank': bool(args.dp_path and world == 1),
                        'host_us_per_step': None if host_us_per_step is None else round(host_us_per_step, 1),
                        # the captured step's schedule: the batch's two halves as concurrent passes on two streams of the graph

@@ -248,8 +248,14 @@ __global__ __launch_bounds__(256) void cmix_split_multi_kernel(SplitBatch b) {
 }
 
 // -> true when the split was recorded (deferred reductions are on and the caller allows it); false: the caller launches it now
+// A split is only ever recorded BEHIND the recorded reduction that writes its dw2 (recorded with no such reduction pending
+// -- a direct C-API caller, a reduction that ran at once -- it would sit in the list until some later backward flushed it against freed memory)
 bool cmix_split_defer(const float *dw2, float *dwr, float *dwi, int Co, int Ci, bool allow_defer) {
     if (!(g_defer_reduce && allow_defer)) return false;
+    bool producer_pending = false;
+    for (const ReduceEntry &r : g_deferred)
+        if (r.dst0 == dw2 || r.dst1 == dw2) { producer_pending = true; break; }
+    if (!producer_pending) return false;
     g_deferred_splits.push_back(SplitEntry{dw2, dwr, dwi, Co, Ci, 0});
     return true;
 }
@@ -343,7 +349,7 @@ bool defer_reduce_enabled() { return g_defer_reduce; }
 
 extern "C" long long hno_debug_reduce_launches(int batched) { return g_reduce_launches[batched ? 1 : 0]; }
 extern "C" int hno_pending_reduces(void) {
-    return (int)g_deferred.size();
+    return (int)(g_deferred.size() + g_deferred_splits.size());
 }
 extern "C" int hno_discard_reduces(void) {   // forget recorded reductions (a backward pass that was aborted by an exception)
     int n = (int)g_deferred.size();

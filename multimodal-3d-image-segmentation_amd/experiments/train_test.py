@@ -168,6 +168,24 @@ class SampleSplit:
         return loss
 
 
+def vote_on_schedule(measure, agree=None):
+    """``measure()`` -> [ms_one_pass, ms_two_streams]; -> (use_split, times).  The agreement is a COLLECTIVE (a MIN all-reduce over the
+    ranks): every rank must reach it whatever happened locally.  A rank whose capture or timing raised (graph-pool OOM, a transient HIP
+    error) votes False and re-raises AFTER the vote -- were it to skip the vote, the other ranks' all-reduce would pair with this rank's
+    next, different collective and every later one would be off by one: the hang the vote exists to prevent."""
+    times, failure = [float('inf'), float('inf')], None
+    try:
+        times = list(measure())
+    except Exception as exc:        # noqa: BLE001 -- vote first, raise afterwards
+        failure = exc
+    use = failure is None and times[1] < times[0]
+    if agree is not None:
+        use = bool(agree(use))
+    if failure is not None:
+        raise failure
+    return use, times
+
+
 def choose_schedule(run_one, run_split, replays=5, rounds=3, agree=None, what=''):
     """Measure, do not guess: capture the step's forward + loss + backward in both forms -- one pass over the batch (``run_one()``) and
     the two half-batches on two streams (``run_split()``) -- into two temporary graphs, warm both up, time ``rounds`` alternating bursts
@@ -177,38 +195,38 @@ def choose_schedule(run_one, run_split, replays=5, rounds=3, agree=None, what=''
     replays must not change any state but gradients, which the caller resets).
     ``agree``: a callable flag -> flag that makes ranks agree (FlatGradReplica.all_ranks_ok): a rank-local timing decision would give
     the ranks different graphs."""
-    graphs = []
-    for fn in (run_one, run_split):
-        cur = torch.cuda.current_stream()
-        torch.cuda.synchronize()
-        side = torch.cuda.Stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
-                out = fn()
-            del out
-        cur.wait_stream(side)
-        torch.cuda.synchronize()
-        graphs.append(graph)
-    for graph in graphs:
-        for _ in range(3):
-            graph.replay()
-    torch.cuda.synchronize()
-    times = [float('inf'), float('inf')]
-    for _ in range(rounds):
-        for i, graph in enumerate(graphs):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(replays):
-                graph.replay()
-            e1.record()
+    def measure():
+        times = [float('inf'), float('inf')]
+        graphs = []
+        for fn in (run_one, run_split):
+            cur = torch.cuda.current_stream()
             torch.cuda.synchronize()
-            times[i] = min(times[i], e0.elapsed_time(e1) / replays)
-    del graphs, graph
-    use = times[1] < times[0]
-    if agree is not None:
-        use = bool(agree(use))
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
+                    out = fn()
+                del out
+            cur.wait_stream(side)
+            torch.cuda.synchronize()
+            graphs.append(graph)
+        for graph in graphs:
+            for _ in range(3):
+                graph.replay()
+        torch.cuda.synchronize()
+        for _ in range(rounds):
+            for i, graph in enumerate(graphs):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(replays):
+                    graph.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                times[i] = min(times[i], e0.elapsed_time(e1) / replays)
+        return times
+
+    use, times = vote_on_schedule(measure, agree)
     if os.environ.get('HNO_TRAIN_GRAPH_QUIET', '0') == '0':
         print(f'[hno] captured step{what}: one pass over the batch {times[0]:.3f} ms, two half-batches on two streams {times[1]:.3f} ms '
               f'-> {"two streams" if use else "one pass"}', file=sys.stderr, flush=True)
@@ -281,6 +299,11 @@ class CapturedStep:
                 with torch.no_grad():
                     self.model(xs[:xs.shape[0] // 2])
             except Exception:                # a model that cannot be deep-copied: one pass over the batch
+                self.split, mode = None, False
+        if self.dp is not None and SampleSplit.candidate(self.model, self.loss_fn, xs):
+            # whether the twin could be built is rank-local, whether choose_schedule()'s collective runs must not be: every rank of a
+            # candidate shape votes, and one rank without a twin takes the split (and the measurement) away from all of them
+            if not self.dp.all_ranks_ok(bool(mode)):
                 self.split, mode = None, False
         cur = torch.cuda.current_stream()
         torch.cuda.synchronize()

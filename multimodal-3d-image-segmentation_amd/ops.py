@@ -744,6 +744,14 @@ def specmix_bwd_raw(g, z0, zs, W, residual, act, defer=False):
 
 
 # ----------------------------------------------------------------------------- autograd
+_outer_grad = {'enabled': True}
+
+
+def backward_wanted(ctx):
+    """a backward pass can follow this forward: grad mode was on at the call AND some input requires grad"""
+    return _outer_grad['enabled'] and any(ctx.needs_input_grad)
+
+
 class _HnoFunction(torch.autograd.Function):
     """Base of every fused op.  Tensors on the ``meta`` device carry shapes only: ``apply`` then returns empty meta
     tensors of the output shapes (``cls.meta``) without touching libhno -- this is what the reference's
@@ -757,7 +765,14 @@ class _HnoFunction(torch.autograd.Function):
             return cls.meta(*args)
         if _defer_state['active']:
             _defer_drop_stale()
-        return super().apply(*args)
+        # torch.is_grad_enabled() is always False inside Function.forward and ctx.needs_input_grad reflects requires_grad, not the
+        # grad mode: the caller's grad mode is recorded here for forwards that skip work only a backward would read
+        prev = _outer_grad['enabled']
+        _outer_grad['enabled'] = torch.is_grad_enabled()
+        try:
+            return super().apply(*args)
+        finally:
+            _outer_grad['enabled'] = prev
 
     @staticmethod
     def meta(*args):
@@ -1710,7 +1725,7 @@ class XSBlockFn(_HnoFunction):
             if nskip is not None:
                 nskip = to_layout(_f32a(nskip), chan_stride(xm))
             # the concat convolution's output is read by the backward only: not stored when no input wants a gradient (inference)
-            out = act_like(xm) if any(ctx.needs_input_grad) else None
+            out = act_like(xm) if backward_wanted(ctx) else None
             xn = act_like(xm) if nskip is not None else act_empty(x.shape[0], C2, spatial, x.device, chan_stride(xm))
             check(_lib.lib().hno_pwconv_fwd_chain(ptr(u), ptr(xm), ptr(nskip), ptr(cat_w), ptr(cat_b), ptr(nmap_w), ptr(nmap_b), ptr(out), ptr(xn),
                                                   x.shape[0], int(cat_w.shape[0]), C2, chan_stride(xm) or _flat_v(xm), act, act2, stream_ptr()),

@@ -990,18 +990,29 @@ def test_inference_full_size_vs_reference_golden(pkg):
 
 
 @pytest.mark.parametrize('size', [(48, 40, 36), (64, 64, 64)])
-def test_hnosegxs_inference_forward_equals_the_training_forward(pkg, size):
+def test_hnosegxs_inference_forward_equals_the_training_forward(pkg, size, monkeypatch):
     """Under no_grad the chained pointwise kernel of the decoder blocks does not store its first layer's output (only the backward reads
     it: hno_pwconv_fwd_chain with xi NULL, round 5): the probabilities must be bit-identical to the forward of a training step, eval()
-    or not (nets/hnosegxs.py has no mode-dependent layer)."""
+    or not (nets/hnosegxs.py has no mode-dependent layer).  The model is TRAINABLE (requires_grad on every parameter, as in testing()
+    and the validation pass of training()): ctx.needs_input_grad is True there, the caller's grad mode is what decides."""
     nets = pkg.nets
     torch.manual_seed(21)
     model = nets.HNOSegXS(4, 4, 24, [3] * 8, (10, 14, 14)).cuda()
     x = torch.randn((1, 4) + size, device='cuda')
+    lib = pkg._lib.lib()
+    real, xi_args = lib.hno_pwconv_fwd_chain, []
+
+    def spy(*args):
+        xi_args.append(args[7])          # (u, t, k, Wc, bc, Wm, bm, xi, xn, ...)
+        return real(*args)
+    monkeypatch.setattr(lib, 'hno_pwconv_fwd_chain', spy)
     y_train = model(x)
     assert y_train.requires_grad
+    assert len(xi_args) == 4 and all(a for a in xi_args), xi_args          # training: the first layer's output is stored
+    del xi_args[:]
     with torch.no_grad():
         y_inf = model(x)
+        assert len(xi_args) == 4 and not any(xi_args), xi_args             # no_grad, trainable model: xi = NULL in every chained launch
         y_eval = model.eval()(x)
     assert not y_inf.requires_grad
     assert bool((y_inf == y_train.detach()).all()) and bool((y_eval == y_inf).all())
