@@ -38,6 +38,11 @@ extern "C" {
  * Tensors stay fp32 in memory.  Built for the 24- and 48-channel shapes of the BASELINE configurations (24 -> 24, 24 + 24 -> 24,
  * 24 -> 4, the fused block tail); other shapes ignore the flag and keep fp32 arithmetic.  The weight gradient keeps its fp32 tiles. */
 #define HNO_ACT_BF16 0x1000
+/* ORed in together with HNO_ACT_BF16 (round 6): the tensors torch.autocast makes bf16 ARE bf16 in memory -- a block's input and output
+ * (and the output's gradient): hno_pwconv_fwd_branch takes x and writes out as bf16 (s, y fp32); hno_pwconv_bwd_branch takes gy, y, xb as
+ * bf16 (xa and both gradient outputs fp32).  Rows are 2-byte elements with the SAME element stride V (V % 32 == 0: 64-byte aligned rows).
+ * The transforms' counterparts: hno_dht3_planes_b16 (bf16 input), hno_idht3_planes_b16 (bf16 output). */
+#define HNO_ACT_IO16 0x2000
 
 int hno_version(void);
 const char *hno_last_error(void);
@@ -153,6 +158,13 @@ int hno_spec_mid_fourier_bwd(void *workspace, const float *W2, const float *s0, 
                              int C, int N0, int m0, int m1, int m2, float scale, int w_fwd, int w_inv, void *stream);
 int hno_idht3_planes(const void *workspace, const float *addend, int act, float *out, int BC, int N0, int N1, int N2, int m0, int m1,
                      int m2, float scale, long long ldbc, void *stream);
+/* hno_dht3_planes / hno_idht3_planes for activations that are bf16 in memory (HNO_ACT_IO16): x / out hold 2-byte elements at element
+ * stride ldbc; the inverse's addend stays fp32 (and must sit at the same 4-element phase as out).  HNO_ELIMIT for plane sizes without a
+ * bf16 item kernel (built: 65 x 65, the working grid of the BASELINE configurations). */
+int hno_dht3_planes_b16(const void *x_bf16, void *workspace, int BC, int N0, int N1, int N2, int m0, int m1, int m2, long long ldbc,
+                        void *stream);
+int hno_idht3_planes_b16(const void *workspace, const float *addend, int act, void *out_bf16, int BC, int N0, int N1, int N2, int m0,
+                         int m1, int m2, float scale, long long ldbc, void *stream);
 /* hno_dht3_crop / hno_pad_idht3 on channel-padded activations: ldbc = stride (floats) between consecutive (b, c) volumes of x /
  * x_act_out, resp. out / addend (0 or N0 N1 N2 = contiguous; N0 N1 N2 <= ldbc < N0 N1 N2 + 64).
  * The inverse zeroes the padding of `out`.  hno_dht3_ld_supported: 1 when both directions take a padded stride for this geometry. */
@@ -457,6 +469,10 @@ int hno_add(const float *a, const float *b, float *out, long long n, void *strea
 /* dst[r][v] = v < V ? src[r][v] : 0 for v < ld_dst, r < rows: (b, c) volumes between the contiguous layout (ld = V) and the
  * channel-padded one (ld = V rounded up to 32 floats, padding zeroed) that the HNOSeg-XS path keeps its activations in */
 int hno_chan_restride(const float *src, float *dst, long long rows, long long V, long long ld_src, long long ld_dst, void *stream);
+/* fp32 <-> bf16 (round to nearest even) over n elements: the ends of a chain of blocks whose activations are bf16 in memory under
+ * torch.autocast (HNO_ACT_IO16) -- the reference casts at the same places (autocast's to(bfloat16) in front of nn.Conv3d) */
+int hno_cast_f32_bf16(const float *src, void *dst_bf16, long long n, void *stream);
+int hno_cast_bf16_f32(const void *src_bf16, float *dst, long long n, void *stream);
 /* out = alpha * a + beta * b (b may be NULL: out = alpha * a); the x +- x_reverse combinations of hartley_conv
  * (nets/hartley_operator.py:315-317) and gradient scaling in the data-parallel path */
 int hno_axpby(float alpha, const float *a, float beta, const float *b, float *out, long long n, void *stream);

@@ -41,6 +41,8 @@ SIGNATURES = {
     'hno_spec_mid_fourier_bwd_workspace_bytes': (c_size_t, [c_int] * 3),
     'hno_spec_mid_fourier_bwd': (c_int, [c_void_p] * 5 + [c_size_t] + [c_int] * 6 + [c_float, c_int, c_int, c_void_p]),
     'hno_idht3_planes': (c_int, [c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 7 + [c_float, c_ll, c_void_p]),
+    'hno_dht3_planes_b16': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_ll, c_void_p]),
+    'hno_idht3_planes_b16': (c_int, [c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 7 + [c_float, c_ll, c_void_p]),
     'hno_dht3_ld_supported': (c_int, [c_int] * 6),
     'hno_dht3_crop_ld': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_ll, c_void_p]),
     'hno_pad_idht3_ld': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_ll, c_void_p]),
@@ -121,6 +123,8 @@ SIGNATURES = {
     'hno_bias_act': (c_int, [c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_void_p]),
     'hno_add': (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
     'hno_chan_restride': (c_int, [c_void_p, c_void_p, c_ll, c_ll, c_ll, c_ll, c_void_p]),
+    'hno_cast_f32_bf16': (c_int, [c_void_p, c_void_p, c_ll, c_void_p]),
+    'hno_cast_bf16_f32': (c_int, [c_void_p, c_void_p, c_ll, c_void_p]),
     'hno_axpby': (c_int, [c_float, c_void_p, c_float, c_void_p, c_void_p, c_ll, c_void_p]),
     'hno_loss_fwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_ll, c_int, c_float, c_void_p]),
     'hno_loss_workspace_doubles': (c_size_t, [c_int, c_int, c_ll]),

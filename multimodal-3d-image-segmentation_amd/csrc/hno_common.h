@@ -193,6 +193,17 @@ __device__ __forceinline__ void dma_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Stagger (MI355X_MICROARCH.md, "Two waves per SIMD", item 9): waves that run the same program tile after tile tend to reach their
+// matrix, vector and memory phases together; the wave in an ODD wave slot of its SIMD sleeps `units` x 1024 cycles before its first
+// tile, so that one partner computes while the other waits.  No effect on results.
+__device__ __forceinline__ void stagger_start(int units) {
+    if (units <= 0) return;
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hw));
+    if (hw & 1u)
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
+}
+
 // ------------------------------------------------------------------ MFMA tile engine
 // v_mfma_f32_16x16x4_f32: D(16x16) += A(16x4) * B(4x16), exact fp32 FMA chain.
 //   A operand: lane l holds A[row = l & 15][k = l >> 4]

@@ -2524,7 +2524,7 @@ extern "C" size_t hno_dht3_workspace_bytes(int BC, int N0, int N1, int N2, int m
 // dht_fwd_d_kernel or of the fused spectral middle, hno_specmid.hip)
 static int dht_forward_launch(const float *x, const float *x_act_out, int act_grad, float *out, void *workspace,
                               int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream,
-                              int mode, int C, int full = 0, bool planes_only = false, long long ldbc = 0) {
+                              int mode, int C, int full = 0, bool planes_only = false, long long ldbc = 0, int elem_bytes = 4) {
     HNO_REQUIRE(x && (out || planes_only) && workspace, "hno_dht3_crop: null pointer");
     const long long vol = (long long)N0 * N1 * N2;
     if (ldbc == 0) ldbc = vol;
@@ -2564,6 +2564,16 @@ static int dht_forward_launch(const float *x, const float *x_act_out, int act_gr
         attr_done = current_device();
     }
     const int planes = BC * N0;
+    if (elem_bytes == 2) {      // bf16 planes (hno_dht3_planes_b16): the item kernel or nothing -- no fallback, no conversion pass
+        HNO_REQUIRE(planes_only && !x_act_out, "hno_dht3_planes_b16: plane transforms only");
+        ProfScope _ps(KID_DHT_FWD_PLANE, s, 2.0 * BC * (double)N0 * N1 * N2);
+        const int rc16 = items_enabled() ? fwd_items_launch(x, (float *)workspace, a, BC, ldbc, s, 2) : 0;
+        if (rc16 < 0) return rc16;
+        if (rc16 == 0) return fail(HNO_ELIMIT, "hno_dht3_planes_b16: bf16 planes are built for 65 x 65 planes (got %d x %d)", N1, N2);
+        g_last_plane_family[0] = 4;
+        HNO_CHECK_LAUNCH();
+        return HNO_OK;
+    }
     // resident workgroups: LDS-limited; a grid of exactly that size lets every workgroup prefetch
     int per_cu = (int)(kMaxLds / lds);
     if (per_cu > 8) per_cu = 8;
@@ -2744,7 +2754,7 @@ static int inv_item_launch_z(const void *workspace, const float *add_al, float *
 // planes_only: the workspace already holds the axis-D step's output (written by the fused spectral middle): plane kernel only
 static int dht_inverse_launch(const float *z, const float *addend, int act, float *out, void *workspace,
                               int BC, int N0, int N1, int N2, int m0, int m1, int m2, float scale, void *stream,
-                              int mode, int C, int full = 0, bool planes_only = false, long long ldbc = 0) {
+                              int mode, int C, int full = 0, bool planes_only = false, long long ldbc = 0, int elem_bytes = 4) {
     HNO_REQUIRE((z || planes_only) && out && workspace, "hno_pad_idht3: null pointer");
     const long long vol = (long long)N0 * N1 * N2;
     if (ldbc == 0) ldbc = vol;
@@ -2796,6 +2806,16 @@ static int dht_inverse_launch(const float *z, const float *addend, int act, floa
     }
     HNO_CHECK_LAUNCH();
     const int planes = BC * N0;
+    if (elem_bytes == 2) {      // bf16 output planes (hno_idht3_planes_b16): the item kernel or nothing
+        HNO_REQUIRE(planes_only, "hno_idht3_planes_b16: plane transforms only");
+        ProfScope _ps(KID_DHT_INV_PLANE, s, BC * (double)N0 * N1 * N2 * (addend ? 6.0 : 2.0));
+        const int rc16 = items_enabled() ? inv_items_launch(workspace, addend, (void *)out, a, BC, ldbc, s, 2) : 0;
+        if (rc16 < 0) return rc16;
+        if (rc16 == 0) return fail(HNO_ELIMIT, "hno_idht3_planes_b16: bf16 planes are built for 65 x 65 planes with output and addend at the same 4-element phase (got %d x %d)", N1, N2);
+        g_last_plane_family[1] = 4;
+        HNO_CHECK_LAUNCH();
+        return HNO_OK;
+    }
     int per_cu = (int)(kMaxLds / lds);
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
@@ -2891,6 +2911,21 @@ extern "C" int hno_dht3_planes(const float *x, void *workspace, int BC, int N0, 
 extern "C" int hno_idht3_planes(const void *workspace, const float *addend, int act, float *out, int BC, int N0, int N1, int N2, int m0,
                                 int m1, int m2, float scale, long long ldbc, void *stream) {
     return dht_inverse_launch(nullptr, addend, act, out, (void *)workspace, BC, N0, N1, N2, m0, m1, m2, scale, stream, 0, 1, 0, true, ldbc);
+}
+
+// The same pair for activations that are bf16 IN MEMORY (round 6; include/hno.h: HNO_ACT_IO16): x / out are (BC, ldbc) arrays of 2-byte
+// elements, the addend of the inverse stays fp32; workspace and arithmetic are the fp32 kernels'.  HNO_ELIMIT for plane sizes without a
+// bf16 item kernel (built: 65 x 65).
+extern "C" int hno_dht3_planes_b16(const void *x_bf16, void *workspace, int BC, int N0, int N1, int N2, int m0, int m1, int m2, long long ldbc,
+                                   void *stream) {
+    return dht_forward_launch((const float *)x_bf16, nullptr, HNO_ACT_NONE, nullptr, workspace, BC, N0, N1, N2, m0, m1, m2, 1.f, stream, 0, 1, 0, true,
+                              ldbc, 2);
+}
+
+extern "C" int hno_idht3_planes_b16(const void *workspace, const float *addend, int act, void *out_bf16, int BC, int N0, int N1, int N2, int m0,
+                                    int m1, int m2, float scale, long long ldbc, void *stream) {
+    return dht_inverse_launch(nullptr, addend, act, (float *)out_bf16, (void *)workspace, BC, N0, N1, N2, m0, m1, m2, scale, stream, 0, 1, 0, true,
+                              ldbc, 2);
 }
 
 // 1 when the transforms take a padded volume stride for this geometry: every plane kernel does (the 65 x 65 / 33 x 33 kernels through

@@ -16,7 +16,8 @@
 
 namespace hno {
 
-template <int N1, int N2>
+// ES: bytes per element of the FORWARD kernel's input planes (4: fp32, 2: bf16 -- round 6); only the DMA piece counts depend on it
+template <int N1, int N2, int ES = 4>
 struct ItemGeo {
     static_assert(N1 & 1, "odd N1");
     static constexpr int Js1 = (N1 - 1) / 2;
@@ -30,8 +31,8 @@ struct ItemGeo {
     static constexpr int p_rows(int X) { return merged(X) ? N1 - 16 * X - p_r0(X) : hi(X) + 1 - p_r0(X); }
     static constexpr int m_r0(int X) { return N1 - hi(X); }
     static constexpr int m_rows(int X) { return merged(X) ? 0 : hi(X) - 16 * X; }
-    // KiB pieces of a chunk: its rows plus the 0..3 floats between the 16-byte boundary below it and its first element
-    static constexpr int pieces_of(int rows) { return rows == 0 ? 0 : (rows * N2 * 4 + 12 + 1023) / 1024; }
+    // KiB pieces of a chunk: its rows plus the elements between the 16-byte boundary below it and its first element
+    static constexpr int pieces_of(int rows) { return rows == 0 ? 0 : (rows * N2 * ES + (16 - ES) + 1023) / 1024; }
     static constexpr int p_pieces(int X) { return pieces_of(p_rows(X)); }
     static constexpr int m_pieces(int X) { return pieces_of(m_rows(X)); }
     static constexpr int pieces(int X) { return p_pieces(X) + m_pieces(X); }
@@ -58,14 +59,22 @@ __device__ __forceinline__ void static_for(F &&f) {
 // (dht_fwd_plane_dma_kernel documents the scheme; differences: chunk geometry from ItemGeo, any number of items per plane, the slot of
 // an item is the parity of its running number, operands whose table entries are zero padding are selected away where they may lie
 // outside the wave's ring.)
-template <int N1, int N2, int NWV, int ZL>
-__global__ __launch_bounds__(64 * NWV, 1) void dht_fwd_items_kernel(const float *__restrict__ xal, float *__restrict__ Y, DhtArgs a,
+// T: float, or unsigned short = bf16 planes (the activations torch.autocast keeps in bf16: round 6).  The planes land in LDS as they lie
+// in memory; every operand read widens its halfword (bits << 16), all arithmetic is the fp32 kernel's.  shift0 / ldbc / offsets of the
+// ring are in ELEMENTS, max_off in bytes.
+template <int N1, int N2, int NWV, int ZL, typename T = float>
+__global__ __launch_bounds__(64 * NWV, 1) void dht_fwd_items_kernel(const T *__restrict__ xal, float *__restrict__ Y, DhtArgs a,
                                                                     unsigned shift0, unsigned max_off, int pl_base, int pl_rem,
                                                                     unsigned ldbc) {
-    using G = ItemGeo<N1, N2>;
+    constexpr int ES = (int)sizeof(T), EPV = 16 / ES, EPK = 1024 / ES;     // bytes per element, elements per 16 bytes / per KiB piece
+    using G = ItemGeo<N1, N2, ES>;
+    auto ldv = [](const T *q_) -> float {
+        if constexpr (ES == 4) return *q_;
+        else return __builtin_bit_cast(float, (unsigned)*q_ << 16);
+    };
     constexpr int NP = G::NP, KC2 = G::KC2, KS2 = G::KS2, Js2 = G::Js2;
     static_assert(NP >= 2, "at least two items per plane");
-    constexpr int SLOTF = G::slot_pieces() * 256;
+    constexpr int SLOTF = G::slot_pieces() * EPK;          // elements per ring slot
     extern __shared__ float lds[];
     const DhtPlan &p = a.p;
     const Axis &a1 = p.ax[1];
@@ -77,14 +86,14 @@ __global__ __launch_bounds__(64 * NWV, 1) void dht_fwd_items_kernel(const float 
         const int bc = plane / N0p;
         return shift0 + (unsigned)bc * ldbc + (unsigned)(plane - bc * N0p) * pe;
     };
-    float *ring = lds + 4 + (size_t)wave * 2 * SLOTF;      // (+ 16 bytes: an operand two floats below a chunk stays inside LDS)
+    T *ring = reinterpret_cast<T *>(lds + 4) + (size_t)wave * 2 * SLOTF;      // (+ 16 bytes: an operand two elements below a chunk stays inside LDS)
     const unsigned ring_b = (unsigned)(size_t)ring;
     const int bid = blockIdx.x;
     const int p_begin = bid * pl_base + (bid < pl_rem ? bid : pl_rem);
     const int p_end = p_begin + pl_base + (bid < pl_rem ? 1 : 0);
     auto issue_chunk = [&](int plane, int r0, int NPC, unsigned dst) {
         const unsigned f0 = plane_f0(plane) + (unsigned)(r0 * N2);
-        const unsigned boff = (f0 & ~3u) * 4u + (unsigned)lane * 16u;
+        const unsigned boff = (f0 & ~(unsigned)(EPV - 1)) * (unsigned)ES + (unsigned)lane * 16u;
         const unsigned first = __builtin_amdgcn_readfirstlane(boff);
         if (first + (unsigned)NPC * 1024u <= max_off) {
             int j = 0;
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void dht_fwd_items_kernel(const float 
     };
     auto issue_item = [&](int plane, auto Xc, int slot) {
         constexpr int X = decltype(Xc)::value;
-        const unsigned dst = ring_b + (unsigned)slot * (SLOTF * 4);
+        const unsigned dst = ring_b + (unsigned)slot * (SLOTF * ES);
         issue_chunk(plane, G::p_r0(X), G::p_pieces(X), dst);
         if constexpr (G::m_rows(X) > 0) issue_chunk(plane, G::m_r0(X), G::m_pieces(X), dst + G::p_pieces(X) * 1024);
     };
@@ -147,28 +156,28 @@ __global__ __launch_bounds__(64 * NWV, 1) void dht_fwd_items_kernel(const float 
     const size_t zoff_p = ((size_t)((a1.m + (l15 <= a1.m ? l15 : 0)) * 4 + q) * a.zplanes) * 8;
     const size_t zoff_m = ((size_t)((a1.m - (l15 <= a1.m ? l15 : 0)) * 4 + q) * a.zplanes) * 8;
     // row r of the plane in the slot of item (pl, X): rowsP + r N2 (tile rows), rowsM + r N2 (mirror rows)
-    auto item_rows = [&](int pl, auto Xc, int slot, const float *&rowsP, const float *&rowsM) {
+    auto item_rows = [&](int pl, auto Xc, int slot, const T *&rowsP, const T *&rowsM) {
         constexpr int X = decltype(Xc)::value;
         const unsigned g0 = plane_f0(pl);
-        const float *sl = ring + slot * SLOTF;
-        rowsP = sl + ((g0 + (unsigned)(G::p_r0(X) * N2)) & 3u) - G::p_r0(X) * N2;
+        const T *sl = ring + slot * SLOTF;
+        rowsP = sl + ((g0 + (unsigned)(G::p_r0(X) * N2)) & (unsigned)(EPV - 1)) - G::p_r0(X) * N2;
         if constexpr (G::merged(X)) rowsM = rowsP;
-        else rowsM = sl + G::p_pieces(X) * 256 + ((g0 + (unsigned)(G::m_r0(X) * N2)) & 3u) - G::m_r0(X) * N2;
+        else rowsM = sl + G::p_pieces(X) * EPK + ((g0 + (unsigned)(G::m_r0(X) * N2)) & (unsigned)(EPV - 1)) - G::m_r0(X) * N2;
     };
     auto read_cos = [&](int pl, auto Xc, int slot, float (&ra0)[KC2], float (&rb0)[KC2], float (&ra1)[KC2], float (&rb1)[KC2]) {
         constexpr int X = decltype(Xc)::value;
-        const float *rowsP, *rowsM;
+        const T *rowsP, *rowsM;
         item_rows(pl, Xc, slot, rowsP, rowsM);
         int rp = 1 + 16 * X + l15;
         if constexpr (16 + 16 * X > G::Js1) rp = rp < G::Js1 ? rp : G::Js1;   // partial item: surplus tile rows read the last pair again
-        const float *row0 = rowsP + rp * N2, *row1 = rowsM + (N1 - rp) * N2;
-        const float *pf0 = row0 + q, *pb0 = row0 + N2 - q - 4 * (KC2 - 1), *pf1 = row1 + q, *pb1 = row1 + N2 - q - 4 * (KC2 - 1);
+        const T *row0 = rowsP + rp * N2, *row1 = rowsM + (N1 - rp) * N2;
+        const T *pf0 = row0 + q, *pb0 = row0 + N2 - q - 4 * (KC2 - 1), *pf1 = row1 + q, *pb1 = row1 + N2 - q - 4 * (KC2 - 1);
 #pragma unroll
         for (int ks = 0; ks < KC2; ++ks) {
-            ra0[ks] = pf0[4 * ks];
-            rb0[ks] = pb0[4 * (KC2 - 1 - ks)];
-            ra1[ks] = pf1[4 * ks];
-            rb1[ks] = pb1[4 * (KC2 - 1 - ks)];
+            ra0[ks] = ldv(pf0 + 4 * ks);
+            rb0[ks] = ldv(pb0 + 4 * (KC2 - 1 - ks));
+            ra1[ks] = ldv(pf1 + 4 * ks);
+            rb1[ks] = ldv(pb1 + 4 * (KC2 - 1 - ks));
         }
     };
     float a0[KC2], b0[KC2], a1_[KC2], b1[KC2];
@@ -187,36 +196,36 @@ __global__ __launch_bounds__(64 * NWV, 1) void dht_fwd_items_kernel(const float 
             constexpr int X2 = (X + 2) % NP, D2 = (X + 2) / NP;         // the item two ahead refills this slot
             const int rf_plane = plane + D2 * NWV;
             const bool refill = rf_plane < p_end;
-            const float *rowsP, *rowsM;
+            const T *rowsP, *rowsM;
             item_rows(plane, Xc, slot, rowsP, rowsM);
             int rp = 1 + 16 * X + l15;
             if constexpr (16 + 16 * X > G::Js1) rp = rp < G::Js1 ? rp : G::Js1;
-            const float *row0 = rowsP + rp * N2, *row1 = rowsM + (N1 - rp) * N2;
+            const T *row0 = rowsP + rp * N2, *row1 = rowsM + (N1 - rp) * N2;
             float sa0[KS2], sb0[KS2], sa1[KS2], sb1[KS2];
             {
-                const float *sf0 = row0 + Js2 - q - 4 * (KS2 - 1), *sb0_ = row0 + N2 - Js2 + q;
-                const float *sf1 = row1 + Js2 - q - 4 * (KS2 - 1), *sb1_ = row1 + N2 - Js2 + q;
+                const T *sf0 = row0 + Js2 - q - 4 * (KS2 - 1), *sb0_ = row0 + N2 - Js2 + q;
+                const T *sf1 = row1 + Js2 - q - 4 * (KS2 - 1), *sb1_ = row1 + N2 - Js2 + q;
 #pragma unroll
                 for (int ks = 0; ks < KS2; ++ks) {
-                    sa0[ks] = sf0[4 * (KS2 - 1 - ks)];
-                    sb0[ks] = sb0_[4 * ks];
-                    sa1[ks] = sf1[4 * (KS2 - 1 - ks)];
-                    sb1[ks] = sb1_[4 * ks];
+                    sa0[ks] = ldv(sf0 + 4 * (KS2 - 1 - ks));
+                    sb0[ks] = ldv(sb0_ + 4 * ks);
+                    sa1[ks] = ldv(sf1 + 4 * (KS2 - 1 - ks));
+                    sb1[ks] = ldv(sb1_ + 4 * ks);
                 }
             }
             float r0a[KC2], r0b[KC2], r0c[KS2], r0d[KS2];   // row 0 (item 0 only)
             if constexpr (X == 0) {
-                const float *rz = rowsP;
-                const float *pf = rz + q, *pb = rz + N2 - q - 4 * (KC2 - 1), *sf = rz + Js2 - q - 4 * (KS2 - 1), *sb = rz + N2 - Js2 + q;
+                const T *rz = rowsP;
+                const T *pf = rz + q, *pb = rz + N2 - q - 4 * (KC2 - 1), *sf = rz + Js2 - q - 4 * (KS2 - 1), *sb = rz + N2 - Js2 + q;
 #pragma unroll
                 for (int ks = 0; ks < KC2; ++ks) {
-                    r0a[ks] = pf[4 * ks];
-                    r0b[ks] = pb[4 * (KC2 - 1 - ks)];
+                    r0a[ks] = ldv(pf + 4 * ks);
+                    r0b[ks] = ldv(pb + 4 * (KC2 - 1 - ks));
                 }
 #pragma unroll
                 for (int ks = 0; ks < KS2; ++ks) {
-                    r0c[ks] = sf[4 * (KS2 - 1 - ks)];
-                    r0d[ks] = sb[4 * ks];
+                    r0c[ks] = ldv(sf + 4 * (KS2 - 1 - ks));
+                    r0d[ks] = ldv(sb + 4 * ks);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -348,10 +357,18 @@ __global__ __launch_bounds__(64 * NWV, 1) void dht_fwd_items_kernel(const float 
 // ---- inverse: one wave per item, both GEMMs chained in registers, the item's rows through a wave-private LDS image ---------------
 // (dht_inv_item_kernel documents the scheme; differences: chunk geometry from the item number at run time -- a wave's items all have
 // the same X because NWV is a multiple of the items per plane --, partial tiles masked on store, even N2.)
-template <int N1, int N2, bool HAS_ADD, int NWV, bool ZL>
+// TO: float, or unsigned short = bf16 OUTPUT planes (round 6: the gradient of a block input that torch.autocast keeps in bf16).  The LDS
+// image, the residual (add_al, fp32) and all arithmetic are the fp32 kernel's; the epilogue rounds (nearest even) and stores four
+// elements = 8 bytes per lane.  out_al is 4-element aligned (16 bytes for fp32, 8 for bf16); shift0 / ldbc are in elements.
+template <int N1, int N2, bool HAS_ADD, int NWV, bool ZL, typename TO = float>
 __global__ __launch_bounds__(64 * NWV, (NWV + 3) / 4) void dht_inv_items_kernel(const float *__restrict__ E, const float *__restrict__ add_al,
-                                                                               float *__restrict__ out_al, DhtArgs a, unsigned shift0,
+                                                                               TO *__restrict__ out_al, DhtArgs a, unsigned shift0,
                                                                                int it_base, int it_rem, unsigned ldbc) {
+    constexpr bool O16 = sizeof(TO) == 2;
+    auto to_out = [](float v) -> TO {
+        if constexpr (O16) return __builtin_bit_cast(unsigned short, (__bf16)v);
+        else return v;
+    };
     using G = ItemGeo<N1, N2>;
     constexpr int NP = G::NP, KM1 = 4, NT2 = G::NT2, J2 = G::J2, Js2 = G::Js2, Js1 = G::Js1;
     static_assert(NWV % NP == 0, "the items of a wave share X");
@@ -442,7 +459,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV + 3) / 4) void dht_inv_items_kernel(
         const unsigned f0 = shift0 + (unsigned)bcv * ldbc + (unsigned)n0v * pe;
         if (n0v == N0p - 1 && X == 0 && ldbc > (unsigned)N0p * pe) {
             const unsigned npad = ldbc - (unsigned)N0p * pe;
-            if ((unsigned)lane < npad) out_al[shift0 + (unsigned)bcv * ldbc + (unsigned)N0p * pe + lane] = 0.f;
+            if ((unsigned)lane < npad) out_al[shift0 + (unsigned)bcv * ldbc + (unsigned)N0p * pe + lane] = to_out(0.f);
         }
         const unsigned fA = f0 + (unsigned)(c0_r0 * N2), fC = f0 + (unsigned)(c1_r0 * N2);
         const unsigned shA = fA & 3u, shC = fC & 3u;
@@ -596,7 +613,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV + 3) / 4) void dht_inv_items_kernel(
             const float *limg = obuf + (ch ? C1LO : 0);
             const unsigned sh = fch & 3u;
             const int ng = (int)((sh + n + 255u) >> 8);
-            float *gbase = out_al + (fch & ~3u) + 4 * lane;
+            TO *gbase = out_al + (fch & ~3u) + 4 * lane;
             const f32x2 sc = {HAS_ADD ? 1.f : a.scale, HAS_ADD ? 1.f : a.scale};
             f32x4 onext = *reinterpret_cast<const f32x4 *>(limg + 4 * lane);
 #pragma unroll 1
@@ -612,11 +629,16 @@ __global__ __launch_bounds__(64 * NWV, (NWV + 3) / 4) void dht_inv_items_kernel(
                 }
                 const f32x4 v = {x0[0], x0[1], x1[0], x1[1]};
                 if (e0 >= 0 && e0 + 3 < (int)n) {
-                    *reinterpret_cast<f32x4 *>(gbase + 256 * j) = v;
+                    if constexpr (O16) {
+                        typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+                        *reinterpret_cast<u16x4 *>(gbase + 256 * j) = u16x4{to_out(v[0]), to_out(v[1]), to_out(v[2]), to_out(v[3])};
+                    } else {
+                        *reinterpret_cast<f32x4 *>(gbase + 256 * j) = v;
+                    }
                 } else {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        if (e0 + c >= 0 && e0 + c < (int)n) gbase[256 * j + c] = v[c];
+                        if (e0 + c >= 0 && e0 + c < (int)n) gbase[256 * j + c] = to_out(v[c]);
                 }
             }
         }
@@ -636,71 +658,98 @@ static const size_t kLdsMax = 160 * 1024;
 // against dht_inv_item_kernel's 25.4 (with residual 30.6 against 30.1: that one stays with the older kernel, see dht_inverse_launch).
 #define HNO_ITEM_SIZES(X) X(65, 65, 7, 12) X(121, 78, 4, 12) X(97, 65, 6, 12) X(41, 41, 8, 12) X(49, 49, 8, 12) X(57, 57, 8, 12) X(73, 73, 6, 12) X(81, 81, 4, 12) X(89, 89, 4, 12) X(97, 97, 4, 12) X(105, 105, 4, 8) X(113, 113, 4, 8) X(121, 121, 4, 8) X(129, 129, 4, 8)
 
-template <int N1, int N2, int NWV>
-static int fwd_items_launch_t(const float *xal, float *ws, const DhtArgs &a, unsigned shift0, unsigned max_off, int planes, unsigned ldbc,
+template <int N1, int N2, int NWV, typename T = float>
+static int fwd_items_launch_t(const T *xal, float *ws, const DhtArgs &a, unsigned shift0, unsigned max_off, int planes, unsigned ldbc,
                               hipStream_t s) {
-    using G = ItemGeo<N1, N2>;
+    using G = ItemGeo<N1, N2, (int)sizeof(T)>;
     const size_t lds = (size_t)NWV * 2 * G::slot_pieces() * 1024 + 128;
     static_assert((size_t)NWV * 2 * G::slot_pieces() * 1024 + 128 <= 160 * 1024, "ring exceeds LDS");
     static int attr = -1;
     if (attr != current_device()) {
-        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_items_kernel<N1, N2, NWV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
-        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_items_kernel<N1, N2, NWV, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_items_kernel<N1, N2, NWV, 0, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_fwd_items_kernel<N1, N2, NWV, 1, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
         attr = current_device();
     }
     const int units = (planes + NWV - 1) / NWV;
     int gw = units < 256 ? units : 256;
-    if (a.zl) hipLaunchKernelGGL((dht_fwd_items_kernel<N1, N2, NWV, 1>), dim3(gw), dim3(64 * NWV), lds, s, xal, ws, a, shift0, max_off, planes / gw, planes % gw, ldbc);
-    else hipLaunchKernelGGL((dht_fwd_items_kernel<N1, N2, NWV, 0>), dim3(gw), dim3(64 * NWV), lds, s, xal, ws, a, shift0, max_off, planes / gw, planes % gw, ldbc);
+    if (a.zl) hipLaunchKernelGGL((dht_fwd_items_kernel<N1, N2, NWV, 1, T>), dim3(gw), dim3(64 * NWV), lds, s, xal, ws, a, shift0, max_off, planes / gw, planes % gw, ldbc);
+    else hipLaunchKernelGGL((dht_fwd_items_kernel<N1, N2, NWV, 0, T>), dim3(gw), dim3(64 * NWV), lds, s, xal, ws, a, shift0, max_off, planes / gw, planes % gw, ldbc);
     return 1;
 }
 
 // 1: launched; 0: no item kernel for this geometry (the caller falls back to the workgroup-per-plane kernels); < 0: error
-int fwd_items_launch(const float *x, float *workspace, const DhtArgs &a, int BC, long long ldbc, hipStream_t s) {
+int fwd_items_launch(const void *x, float *workspace, const DhtArgs &a, int BC, long long ldbc, hipStream_t s, int elem_bytes) {
     const DhtPlan &p = a.p;
     const int N0 = p.ax[0].N, N1 = p.ax[1].N, N2 = p.ax[2].N;
     const long long vol = (long long)N0 * N1 * N2;
-    if (p.ax[1].KT != 1 || p.ax[2].KT != 1 || (double)BC * ldbc >= 1.0e9 || ((size_t)x & 3)) return 0;
-    const unsigned shift0 = (unsigned)(((size_t)x >> 2) & 3);
-    const float *xal = x - shift0;
-    const unsigned max_off = (unsigned)((((size_t)shift0 + (size_t)(BC - 1) * ldbc + (size_t)vol) * 4 - 1) & ~(size_t)15);
+    const size_t es = (size_t)elem_bytes;
+    if (p.ax[1].KT != 1 || p.ax[2].KT != 1 || (double)BC * ldbc >= 1.0e9 || ((size_t)x & (es - 1))) return 0;
+    const unsigned shift0 = (unsigned)(((size_t)x / es) & (16 / es - 1));      // elements between the 16-byte boundary below x and x
+    const unsigned max_off = (unsigned)((((size_t)shift0 + (size_t)(BC - 1) * ldbc + (size_t)vol) * es - 1) & ~(size_t)15);
     const int planes = BC * N0;
+    if (elem_bytes == 2) {      // bf16 planes: the benchmark's 65 x 65 (FNOSeg / HNOSeg under autocast)
+        const unsigned short *xal = (const unsigned short *)x - shift0;
+        if (N1 == 65 && N2 == 65) return fwd_items_launch_t<65, 65, 7, unsigned short>(xal, workspace, a, shift0, max_off, planes, (unsigned)ldbc, s);
+        return 0;
+    }
+    const float *xal = (const float *)x - shift0;
+    // co-scheduling experiments (round 6): HNO_ITEM_FWD_WAVES=4 runs the 65 x 65 planes with four waves per workgroup (half the LDS ring: a
+    // second kernel's workgroup fits beside it on the compute unit)
+    static const int fw_env = getenv("HNO_ITEM_FWD_WAVES") ? atoi(getenv("HNO_ITEM_FWD_WAVES")) : 0;
+    if (N1 == 65 && N2 == 65 && fw_env == 4) return fwd_items_launch_t<65, 65, 4>(xal, workspace, a, shift0, max_off, planes, (unsigned)ldbc, s);
 #define X(n1, n2, wf, wi) if (N1 == n1 && N2 == n2) return fwd_items_launch_t<n1, n2, wf>(xal, workspace, a, shift0, max_off, planes, (unsigned)ldbc, s);
     HNO_ITEM_SIZES(X)
 #undef X
     return 0;
 }
 
-template <int N1, int N2, int NWV, bool HAS_ADD>
-static int inv_items_launch_t(const float *ws, const float *add_al, float *out_al, const DhtArgs &a, unsigned shift0, int items, unsigned ldbc,
+template <int N1, int N2, int NWV, bool HAS_ADD, typename TO = float>
+static int inv_items_launch_t(const float *ws, const float *add_al, TO *out_al, const DhtArgs &a, unsigned shift0, int items, unsigned ldbc,
                               hipStream_t s) {
     using G = ItemGeo<N1, N2>;
     const size_t lds = sizeof(float) * ((size_t)NWV * G::WSTRIDE + 256);
     static_assert(sizeof(float) * ((size_t)NWV * G::WSTRIDE + 256) <= 160 * 1024, "images exceed LDS");
     static int attr = -1;
     if (attr != current_device()) {
-        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_items_kernel<N1, N2, HAS_ADD, NWV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
-        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_items_kernel<N1, N2, HAS_ADD, NWV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_items_kernel<N1, N2, HAS_ADD, NWV, false, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+        HNO_CHECK_HIP(hipFuncSetAttribute((const void *)dht_inv_items_kernel<N1, N2, HAS_ADD, NWV, true, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
         attr = current_device();
     }
     // whole multiples of the items per plane per workgroup start: a wave's X must not depend on the workgroup (t_begin is arbitrary,
     // X = (t_begin + wave) % NP is taken per wave, so any split works)
     const int gw = items < 256 * NWV ? (items + NWV - 1) / NWV : 256;
-    if (a.zl) hipLaunchKernelGGL((dht_inv_items_kernel<N1, N2, HAS_ADD, NWV, true>), dim3(gw), dim3(64 * NWV), lds, s, ws, add_al, out_al, a, shift0, items / gw, items % gw, ldbc);
-    else hipLaunchKernelGGL((dht_inv_items_kernel<N1, N2, HAS_ADD, NWV, false>), dim3(gw), dim3(64 * NWV), lds, s, ws, add_al, out_al, a, shift0, items / gw, items % gw, ldbc);
+    if (a.zl) hipLaunchKernelGGL((dht_inv_items_kernel<N1, N2, HAS_ADD, NWV, true, TO>), dim3(gw), dim3(64 * NWV), lds, s, ws, add_al, out_al, a, shift0, items / gw, items % gw, ldbc);
+    else hipLaunchKernelGGL((dht_inv_items_kernel<N1, N2, HAS_ADD, NWV, false, TO>), dim3(gw), dim3(64 * NWV), lds, s, ws, add_al, out_al, a, shift0, items / gw, items % gw, ldbc);
     return 1;
 }
 
-int inv_items_launch(const void *workspace, const float *addend, float *out, const DhtArgs &a, int BC, long long ldbc, hipStream_t s) {
+int inv_items_launch(const void *workspace, const float *addend, void *out, const DhtArgs &a, int BC, long long ldbc, hipStream_t s, int elem_bytes) {
     const DhtPlan &p = a.p;
     const int N0 = p.ax[0].N, N1 = p.ax[1].N, N2 = p.ax[2].N;
-    if (p.ax[1].KT != 1 || p.ax[2].KT != 1 || p.ax[1].KmP != 16 || p.ax[2].KmP > 16 || (double)BC * ldbc >= 1.0e9 || ((size_t)out & 3) ||
-        (addend && ((size_t)addend & 15) != ((size_t)out & 15)))
+    const size_t es = (size_t)elem_bytes;
+    // the residual rows are DMA'd into an LDS image laid out at the output's 4-element phase: both tensors must share it
+    const unsigned shift0 = (unsigned)(((size_t)out / es) & 3);
+    if (p.ax[1].KT != 1 || p.ax[2].KT != 1 || p.ax[1].KmP != 16 || p.ax[2].KmP > 16 || (double)BC * ldbc >= 1.0e9 || ((size_t)out & (es - 1)) ||
+        (addend && (((size_t)addend & 3) || (unsigned)(((size_t)addend >> 2) & 3) != shift0)))
         return 0;
-    const unsigned shift0 = (unsigned)(((size_t)out >> 2) & 3);
-    float *out_al = out - shift0;
     const float *add_al = addend ? addend - shift0 : nullptr;
     const int planes = BC * N0;
+    if (elem_bytes == 2) {      // bf16 output planes: the benchmark's 65 x 65 (FNOSeg / HNOSeg under autocast)
+        unsigned short *o16 = (unsigned short *)out - shift0;
+        if (N1 == 65 && N2 == 65) {
+            const int items = planes * ItemGeo<65, 65>::NP;
+            return addend ? inv_items_launch_t<65, 65, 12, true, unsigned short>((const float *)workspace, add_al, o16, a, shift0, items, (unsigned)ldbc, s)
+                          : inv_items_launch_t<65, 65, 12, false, unsigned short>((const float *)workspace, add_al, o16, a, shift0, items, (unsigned)ldbc, s);
+        }
+        return 0;
+    }
+    float *out_al = (float *)out - shift0;
+    static const int iw_env = getenv("HNO_ITEM_INV_WAVES") ? atoi(getenv("HNO_ITEM_INV_WAVES")) : 0;      // (see fwd_items_launch)
+    if (N1 == 65 && N2 == 65 && iw_env == 6) {
+        const int items = planes * ItemGeo<65, 65>::NP;
+        return addend ? inv_items_launch_t<65, 65, 6, true>((const float *)workspace, add_al, out_al, a, shift0, items, (unsigned)ldbc, s)
+                      : inv_items_launch_t<65, 65, 6, false>((const float *)workspace, add_al, out_al, a, shift0, items, (unsigned)ldbc, s);
+    }
 #define X(n1, n2, wf, wi)                                                                                                          \
     if (N1 == n1 && N2 == n2) {                                                                                                    \
         const int items = planes * ItemGeo<n1, n2>::NP;                                                                            \

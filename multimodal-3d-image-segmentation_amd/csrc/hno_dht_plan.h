@@ -92,11 +92,11 @@ __device__ __forceinline__ int kept_pos(int k, int m, int full = 0) {
 }
 
 // ---- LDS-DMA pieces (dht_fwd_plane_dma_kernel explains the scheme)
-__device__ __forceinline__ void dma_piece16(const float *base, unsigned lane_byte_off, unsigned lds_dst) {
+__device__ __forceinline__ void dma_piece16(const void *base, unsigned lane_byte_off, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane_byte_off), "s"(base), "s"(lds_dst) : "memory");
 }
 // four consecutive KiB: the instruction offset advances the global and the LDS address alike
-__device__ __forceinline__ void dma_piece16x4(const float *base, unsigned lane_byte_off, unsigned lds_dst) {
+__device__ __forceinline__ void dma_piece16x4(const void *base, unsigned lane_byte_off, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
                  "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
                  : : "v"(lane_byte_off), "s"(base), "s"(lds_dst) : "memory");
@@ -108,6 +108,7 @@ __device__ __forceinline__ void store16_wt(float *ptr, f32x4 v) {
 }
 
 // item plane kernels for general plane sizes (hno_dht_items.hip).  1: launched; 0: no kernel for this geometry; < 0: error
-int fwd_items_launch(const float *x, float *workspace, const DhtArgs &a, int BC, long long ldbc, hipStream_t s);
-int inv_items_launch(const void *workspace, const float *addend, float *out, const DhtArgs &a, int BC, long long ldbc, hipStream_t s);
+// elem_bytes 2: the planes (forward: x; inverse: out) are bf16 in memory (round 6); the inverse's addend stays fp32
+int fwd_items_launch(const void *x, float *workspace, const DhtArgs &a, int BC, long long ldbc, hipStream_t s, int elem_bytes = 4);
+int inv_items_launch(const void *workspace, const float *addend, void *out, const DhtArgs &a, int BC, long long ldbc, hipStream_t s, int elem_bytes = 4);
 }  // namespace hno

@@ -1349,6 +1349,29 @@ extern "C" int hno_chan_restride(const float *src, float *dst, long long rows, l
     return HNO_OK;
 }
 
+// fp32 <-> bf16 over a flat extent (channel padding included): where an fp32 producer (the stem) meets the bf16 block chain of an
+// autocast run and where the chain's bf16 output meets the fp32 head (round 6: bf16 activations in memory).  n % 4 == 0 is not needed.
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float *__restrict__ src, unsigned short *__restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u)
+        dst[i] = __builtin_bit_cast(unsigned short, (__bf16)src[i]);
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const unsigned short *__restrict__ src, float *__restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u)
+        dst[i] = __builtin_bit_cast(float, (unsigned)src[i] << 16);
+}
+extern "C" int hno_cast_f32_bf16(const float *src, void *dst_bf16, long long n, void *stream) {
+    HNO_REQUIRE(src && dst_bf16 && n > 0, "hno_cast_f32_bf16: bad argument");
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid1d((size_t)n)), dim3(256), 0, (hipStream_t)stream, src, (unsigned short *)dst_bf16, (size_t)n);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+extern "C" int hno_cast_bf16_f32(const void *src_bf16, float *dst, long long n, void *stream) {
+    HNO_REQUIRE(src_bf16 && dst && n > 0, "hno_cast_bf16_f32: bad argument");
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid1d((size_t)n)), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)src_bf16, dst, (size_t)n);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
 extern "C" int hno_axpby(float alpha, const float *a, float beta, const float *b, float *out, long long n, void *stream) {
     HNO_REQUIRE(a && out && n > 0, "hno_axpby: bad argument");
     hipLaunchKernelGGL(eltwise_kernel, dim3(grid1d((size_t)n)), dim3(256), 0, (hipStream_t)stream, a, b, out, (size_t)n, 3, 0, alpha, beta);

@@ -44,6 +44,17 @@ __device__ __forceinline__ f32x16 mfma_bf(pw_bf16x8 a, pw_bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; }
+// bf16 activations IN MEMORY (round 6: the tensors torch.autocast makes bf16 -- the outputs of nn.Conv3d and what follows them
+// elementwise, i.e. the FNOSeg / HNOSeg block inputs and outputs, nets/architectures.py:521-546 under train_test.py:154-160)
+typedef unsigned short pw_u16;
+__device__ __forceinline__ float bf16_bits_to_f32(pw_u16 h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+__device__ __forceinline__ pw_u16 f32_to_bf16_bits(float x) { return __builtin_bit_cast(pw_u16, (__bf16)x); }
+// one LDS-DMA instruction = FOUR bf16 rows x 32 voxels (64 bytes each): lane l fetches dword (l & 15) of row (l >> 4)
+__device__ __forceinline__ void dma_row_quad16(const pw_u16 *base, unsigned lane_byte_off, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_byte_off), "s"(base), "s"(lds_dst) : "memory");
+}
 
 struct PwArgs {
     const float *xa, *xb, *W, *bias;
@@ -330,6 +341,11 @@ __global__ __launch_bounds__(256, 2) void pwconv_bwd_kernel(PwBwdArgs a) {
 // 8 waves = two per SIMD, so one wave's bias + SELU epilogue (~1 200 VALU cycles per tile) runs under the other's MFMA chain
 // (they do not overlap within a wave, DESIGN lesson 34): 39.0 -> 36.4 us isolated, 2.686 -> 2.667 ms per step; 12 waves: the same.
 // With the misaligned rows of rounds 1-2 four waves were best.  HNO_PWF_WAVES=4 / 12 select the others (A/B).
+// HNO_PW_STAGGER=n (A/B, round 6): odd wave slots of a SIMD start n x 1024 cycles late (stagger_start)
+static int pw_stagger() {
+    static const int v = getenv("HNO_PW_STAGGER") ? atoi(getenv("HNO_PW_STAGGER")) : 0;
+    return v < 0 ? 0 : (v > 63 ? 63 : v);
+}
 static int pwf_waves() {
     static const int v = getenv("HNO_PWF_WAVES") ? atoi(getenv("HNO_PWF_WAVES")) : 8;
     return (v == 4 || v == 12) ? v : 8;      // only the built instantiations
@@ -339,6 +355,7 @@ static int pwf_waves() {
 
 template <int CA, int CB, int COUT, bool BF16 = false, int NWV = PWF_DMA_WAVES>   // channel counts of xa / xb (both even) are compile-time: all address selects fold
 __global__ __launch_bounds__(64 * NWV) void pwconv_fwd_fast_kernel(PwArgs a) {
+    stagger_start((a.dbg >> 24) & 63);
     constexpr int NW = NWV;
     extern __shared__ float pwf_ring[];      // NW x 2 slots x NKI x 64 floats
     constexpr int NKI = (CA + CB) / 2;
@@ -489,9 +506,12 @@ struct PwBranchArgs {
     int act;
 };
 
-template <int CA, int CB, int COUT, bool BF16 = false>
+// IO16: x and out are bf16 IN MEMORY (what autocast makes of a block's input and output; s and y stay fp32 as in the reference); needs
+// BF16 arithmetic and V % 32 == 0 (channel-padded rows).  x arrives four rows per DMA instruction (dma_row_quad16).
+template <int CA, int CB, int COUT, bool BF16 = false, bool IO16 = false>
 __global__ __launch_bounds__(64 * PWF_DMA_WAVES) void pwconv_fwd_branch_kernel(PwBranchArgs a) {
     static_assert(CA % 8 == 0 && CA <= 32 && CB % 8 == 0 && COUT <= 32 && COUT % 8 == 0, "one 32-row tile per product");
+    static_assert(!IO16 || BF16, "bf16 tensors only under bf16 arithmetic");
     constexpr int NW = PWF_DMA_WAVES;
     extern __shared__ float pwf_ring[];      // NW x 2 slots x (NKX + RA) x 64 floats: see pwconv_fwd_fast_kernel
     constexpr int RA = CA / 2, RO = COUT / 2, NKX = CB / 2, CIN = CA + CB;
@@ -529,8 +549,10 @@ __global__ __launch_bounds__(64 * PWF_DMA_WAVES) void pwconv_fwd_branch_kernel(P
     const unsigned hoffV = h ? V : 0u, hoff4V = h ? 4u * V : 0u;
     // both inputs arrive by LDS-DMA one tile ahead (pwconv_fwd_fast_kernel): x as B-operand row pairs (2 ks, 2 ks + 1), s in the
     // accumulator layout (rows r' and r' + 4 per instruction); a lane reads back its own 4 bytes
-    constexpr int NDMA = NKX + RA;
+    constexpr int NXD = IO16 ? NKX / 2 : NKX;         // DMA instructions of the x rows: bf16 rows go four to an instruction
+    constexpr int NDMA = NXD + RA;
     static_assert(NDMA <= 63, "the DMA of one tile must fit the vmcnt counter");
+    static_assert(!IO16 || NKX % 2 == 0, "four bf16 rows per DMA instruction");
     float *ring = pwf_ring + wave * (2 * NDMA * 64);
     const unsigned ring_b = (unsigned)(size_t)ring;
     const unsigned stride = gridDim.x * NW;
@@ -538,14 +560,24 @@ __global__ __launch_bounds__(64 * PWF_DMA_WAVES) void pwconv_fwd_branch_kernel(P
         const unsigned b = t / tiles_per_b;
         const unsigned v = (t - b * tiles_per_b) * 32 + c;
         const unsigned vc = v < V ? v : 0u;
-        const float *x_b = a.x + (size_t)b * CB * V, *s_b = a.s + (size_t)b * CA * V;
+        const float *s_b = a.s + (size_t)b * CA * V;
+        if constexpr (IO16) {
+            const pw_u16 *x_b = reinterpret_cast<const pw_u16 *>(a.x) + (size_t)b * CB * V;
+            const unsigned v0 = (t - b * tiles_per_b) * 32;
+            const unsigned qoff = ((unsigned)(lane >> 4) * V + v0) * 2u + (unsigned)(lane & 15) * 4u;
 #pragma unroll
-        for (int ks = 0; ks < NKX; ++ks)
-            dma_row_pair(x_b + (size_t)(2 * ks) * V, (hoffV + vc) * 4u, __builtin_amdgcn_readfirstlane(ring_b + (slot * NDMA + ks) * 256));
+            for (int j = 0; j < NXD; ++j)
+                dma_row_quad16(x_b + (size_t)(4 * j) * V, qoff, __builtin_amdgcn_readfirstlane(ring_b + (slot * NDMA + j) * 256));
+        } else {
+            const float *x_b = a.x + (size_t)b * CB * V;
+#pragma unroll
+            for (int ks = 0; ks < NKX; ++ks)
+                dma_row_pair(x_b + (size_t)(2 * ks) * V, (hoffV + vc) * 4u, __builtin_amdgcn_readfirstlane(ring_b + (slot * NDMA + ks) * 256));
+        }
 #pragma unroll
         for (int r = 0; r < RA; ++r)
             dma_row_pair(s_b + (size_t)((r & 3) + 8 * (r >> 2)) * V, (hoff4V + vc) * 4u,
-                         __builtin_amdgcn_readfirstlane(ring_b + (slot * NDMA + NKX + r) * 256));
+                         __builtin_amdgcn_readfirstlane(ring_b + (slot * NDMA + NXD + r) * 256));
     };
     unsigned t = blockIdx.x * NW + wave;
     if (t < ntiles) issue(t, 0);
@@ -561,10 +593,17 @@ __global__ __launch_bounds__(64 * PWF_DMA_WAVES) void pwconv_fwd_branch_kernel(P
         const bool vin = v < V, full = v0 + 32 <= V;
         const float *sl = ring + slot * NDMA * 64 + lane;
         float xv[NKX], sv[RA];
+        if constexpr (IO16) {
+            // channel 2 ks + h of voxel c: DMA instruction ks >> 1, row 2 (ks & 1) + h of its four, halfword c
+            const pw_u16 *sx = reinterpret_cast<const pw_u16 *>(ring + slot * NDMA * 64) + h * 32 + c;
 #pragma unroll
-        for (int ks = 0; ks < NKX; ++ks) xv[ks] = sl[ks * 64];
+            for (int ks = 0; ks < NKX; ++ks) xv[ks] = bf16_bits_to_f32(sx[(ks >> 1) * 128 + (ks & 1) * 64]);
+        } else {
 #pragma unroll
-        for (int r = 0; r < RA; ++r) sv[r] = sl[(NKX + r) * 64];
+            for (int ks = 0; ks < NKX; ++ks) xv[ks] = sl[ks * 64];
+        }
+#pragma unroll
+        for (int r = 0; r < RA; ++r) sv[r] = sl[(NXD + r) * 64];
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -618,11 +657,18 @@ __global__ __launch_bounds__(64 * PWF_DMA_WAVES) void pwconv_fwd_branch_kernel(P
         if (!lin) {
             selu_like_regs<RO>(ov, ap, aq);
         }
+        if constexpr (IO16) {
+            pw_u16 *o16 = reinterpret_cast<pw_u16 *>(a.out) + (size_t)b * COUT * V + (hoff4V + v);
 #pragma unroll
-        for (int r = 0; r < RO; ++r) {
-            const float val = BF16 ? bf16_round(ov[r]) : ov[r];
-            if (full) o_l[(size_t)((r & 3) + 8 * (r >> 2)) * V] = val;
-            else if (vin) o_l[(size_t)((r & 3) + 8 * (r >> 2)) * V] = val;
+            for (int r = 0; r < RO; ++r)
+                if (full || vin) o16[(size_t)((r & 3) + 8 * (r >> 2)) * V] = f32_to_bf16_bits(ov[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < RO; ++r) {
+                const float val = BF16 ? bf16_round(ov[r]) : ov[r];
+                if (full) o_l[(size_t)((r & 3) + 8 * (r >> 2)) * V] = val;
+                else if (vin) o_l[(size_t)((r & 3) + 8 * (r >> 2)) * V] = val;
+            }
         }
     }
 }
@@ -648,6 +694,7 @@ struct PwChainArgs {
 // mapping_conv; <24, 4, false>: the model's conv_out (24 -> out_channels, no bias, no activation: a.act2) behind the LAST block.
 template <int C, int NWV, int C2 = C, bool HASK = true>
 __global__ __launch_bounds__(64 * NWV) void pwconv_fwd_chain_kernel(PwChainArgs a) {
+    stagger_start((a.dbg >> 24) & 63);
     static_assert(C % 8 == 0 && C <= 32 && C2 <= 32 && (C2 % 8 == 0 || C2 == 4), "one 32-row tile per product");
     constexpr int NW = NWV, NK = C / 2, CIN = 2 * C, NDMA = (HASK ? 3 : 2) * NK, CIN2 = HASK ? 2 * C : C;
     constexpr int NR2 = C2 >= 8 ? C2 / 2 : C2;        // accumulator registers of the second product that hold rows < C2 (C2 = 4: rows 0..3, h = 0 lanes)
@@ -761,8 +808,13 @@ __global__ __launch_bounds__(64 * NWV) void pwconv_fwd_chain_kernel(PwChainArgs 
 }
 
 #define PWB_FAST_WAVES 4   // 256-thread blocks, two per CU (512 slabs): measured best of {4, 8, 12} waves x {256, 512, 1024} blocks
-template <int COUT, int CA, int CB, int NW = PWB_FAST_WAVES, int BR = 0, bool BF16 = false>   // compile-time channel counts: every address select folds
-__global__ __launch_bounds__(64 * NW, (NW == 4 && COUT <= 48) ? 2 : 1) void pwconv_bwd_fast_kernel(PwBwdArgs a) {   // 2 blocks per CU: a 256-register budget, all in VGPRs (no AGPR copies); COUT = 144: one block, 512 registers
+// IO16 (with BR and BF16: the FNOSeg / HNOSeg block tail under autocast, round 6): gy, y (the block output and its gradient) and xb (the block
+// input) are bf16 IN MEMORY; xa (the operator + branch sum, fp32 in the reference too) and both input gradients stay fp32.  The raw
+// halfwords sit zero-extended in the prefetch registers and are widened where they are consumed (a conversion at the load would wait for it).
+template <int COUT, int CA, int CB, int NW = PWB_FAST_WAVES, int BR = 0, bool BF16 = false, bool IO16 = false>   // compile-time channel counts: every address select folds
+__global__ __launch_bounds__(64 * NW, (NW == 4 && COUT <= 48) ? 2 : 1) void pwconv_bwd_fast_kernel(PwBwdArgs a) {
+    static_assert(!IO16 || (BR == 1 && BF16), "bf16 tensors: the fused-branch block tail under bf16 arithmetic only");   // 2 blocks per CU: a 256-register budget, all in VGPRs (no AGPR copies); COUT = 144: one block, 512 registers
+    stagger_start((a.dbg >> 24) & 63);
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -877,6 +929,22 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && COUT <= 48) ? 2 : 1) void pwco
                 dma_row_pair(base, off * 4u, __builtin_amdgcn_readfirstlane(x_lds + (slot * XS + j * PWB_XP) * 4));
             }
         }
+        if constexpr (IO16) {
+            const pw_u16 *gy16 = reinterpret_cast<const pw_u16 *>(a.gy) + (size_t)b * COUT * V, *y16 = reinterpret_cast<const pw_u16 *>(a.y) + (size_t)b * COUT * V;
+            const pw_u16 *xb16 = reinterpret_cast<const pw_u16 *>(a.xb) + (size_t)b * CB * V;
+#pragma unroll
+            for (int ks = 0; ks < NKO; ++ks) pg[ks] = __builtin_bit_cast(float, (unsigned)(gy16 + (size_t)(2 * ks) * V)[off]);
+            if (!lin) {
+#pragma unroll
+                for (int ks = 0; ks < NKO; ++ks) py[ks] = __builtin_bit_cast(float, (unsigned)(y16 + (size_t)(2 * ks) * V)[off]);
+            }
+#pragma unroll
+            for (int j = 0; j < NKI; ++j) {
+                const int i0 = 2 * j;
+                if (i0 < CA) px[j] = (xa_b + (size_t)i0 * V)[off];
+                else px[j] = __builtin_bit_cast(float, (unsigned)(xb16 + (size_t)(i0 - CA) * V)[off]);
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < NKO; ++ks) pg[ks] = (gy_b + (size_t)(2 * ks) * V)[off];
         if (!lin) {
@@ -890,6 +958,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && COUT <= 48) ? 2 : 1) void pwco
                 const float *base = i0 < CA ? xa_b + (size_t)i0 * V : xb_b + (size_t)(i0 - CA) * V;
                 px[j] = base[off];
             }
+        }
         }
         if (accb) {
             const float *q_b = a.gxb + (size_t)b * CB * V + (h ? 4u * V : 0u) + ((live && v < V) ? v : 0u);
@@ -919,16 +988,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && COUT <= 48) ? 2 : 1) void pwco
         const unsigned v = live ? (t - b * tiles_per_b) * 32 + c : 0u;
         const bool vin = live && v < V;
         float g[NKO];
+        auto widen = [](float raw) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, raw) << 16); };   // zero-extended bf16 bits -> fp32
 #pragma unroll
         for (int ks = 0; ks < NKO; ++ks) {
-            const float gv = pg[ks] * ((lin || py[ks] > 0.f) ? dp : py[ks] + dq);
+            const float pgv = IO16 ? widen(pg[ks]) : pg[ks], pyv = IO16 ? widen(py[ks]) : py[ks];
+            const float gv = pgv * ((lin || pyv > 0.f) ? dp : pyv + dq);
             g[ks] = vin ? gv : 0.f;
             G[(2 * ks + h) * PWB_LD + c] = g[ks];
             db[ks] += g[ks];
         }
         if constexpr (!DMA) {
 #pragma unroll
-            for (int j = 0; j < NKI; ++j) X[(2 * j + h) * PWB_LD + c] = vin ? px[j] : 0.f;
+            for (int j = 0; j < NKI; ++j) X[(2 * j + h) * PWB_LD + c] = vin ? ((IO16 && 2 * j >= CA) ? widen(px[j]) : px[j]) : 0.f;
         }
         float qc[NQ];
 #pragma unroll
@@ -1196,6 +1267,7 @@ struct PwChainBwdArgs {
 // SIMD computes while this one waits for its rows).
 template <int C, int NW, int C2 = C, bool HASK = true, int SLOTS = 2>
 __global__ __launch_bounds__(64 * NW, SLOTS == 1 ? 2 : 1) void pwconv_bwd_chain_kernel(PwChainBwdArgs a) {
+    stagger_start((a.dbg >> 24) & 63);
     static_assert(C == 24, "accumulator-row bookkeeping below is written for 24 channels");
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63;
@@ -1474,7 +1546,7 @@ int pwconv_fwd_launch(const float *xa, int Ca, const float *xb, int Cb, const fl
     a.xa = xa; a.xb = xb; a.W = W; a.bias = bias; a.y = y;
     a.Ca = Ca; a.Cb = Cb; a.Cin = Ca + Cb; a.Cout = Cout; a.B = B; a.V = (unsigned)V; a.act = act;
     a.residual = residual;
-    a.dbg = debug_flags();
+    a.dbg = debug_flags() | (pw_stagger() << 24);
     const long long ntiles = ((V + 31) / 32) * B;
     int grid = grid_for(ntiles, 4);
     if (Ca % 4 == 0 && Cb % 4 == 0) {  // exact-size fast paths (the HNOSeg-XS shapes; 12 channels: HartleyMHASeg)
@@ -1549,7 +1621,9 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
                       int B, int Cout, long long V, int act, int residual, void *stream, int xa_act = HNO_ACT_NONE,
                       int accumulate_gx = 0, const float *Wbr = nullptr) {   // also declared in hno_specmix.hip
     const int bf16 = (act >> 12) & 1;      // HNO_ACT_BF16 (see pwconv_fwd_launch)
+    const int io16 = (act >> 13) & 1;      // HNO_ACT_IO16: gy, y, xb are bf16 tensors (fused-branch block tail only)
     act &= 0xfff;
+    HNO_REQUIRE(!io16 || Wbr, "hno_pwconv_bwd: bf16 tensors are built for the fused-branch block tail only (hno_pwconv_bwd_branch)");
     HNO_REQUIRE(workspace, "hno_pwconv_bwd: workspace of hno_pwconv_bwd_workspace_bytes() is required");
     HNO_REQUIRE(gy && xa && W && dW && Ca > 0 && Cb >= 0 && B > 0 && Cout > 0 && V > 0, "hno_pwconv_bwd: bad argument");
     HNO_REQUIRE(act == HNO_ACT_NONE || y, "hno_pwconv_bwd: saved output y needed for the activation gradient");
@@ -1580,7 +1654,7 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
     a.gxa = gxa; a.gxb = gxb; a.dW = dW; a.dbias = dbias; a.partials = (float *)workspace;
     a.Ca = Ca; a.Cb = Cb; a.Cin = Cin; a.Cout = Cout; a.B = B; a.V = (unsigned)V; a.act = act;
     a.residual = residual;
-    a.dbg = debug_flags();
+    a.dbg = debug_flags() | (pw_stagger() << 24);
     a.xa_act = xa_act;
     a.accum = accumulate_gx;
     a.Wbr = Wbr;
@@ -1603,16 +1677,21 @@ int pwconv_bwd_launch(const float *gy, const float *y, const float *xa, int Ca, 
             HNO_REQUIRE(xa_act != HNO_ACT_NONE && gxa && gxb && !residual, "hno_pwconv_bwd_branch: needs the activation of xa and both input gradients");
             long long fgb = (ntiles + PWB_FAST_WAVES - 1) / PWB_FAST_WAVES;
             if (fgb > 512) fgb = 512;
-            auto kern = bf16 ? pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 1, true> : pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 1>;
+            HNO_REQUIRE(!io16 || (bf16 && V % 32 == 0 && act != HNO_ACT_NONE), "hno_pwconv_bwd_branch: bf16 tensors need bf16 arithmetic, an activation and V %% 32 == 0");
+            auto kern = io16 ? pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 1, true, true>
+                             : bf16 ? pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 1, true> : pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 1>;
             static int battr = -1;
             if (battr != current_device()) {
                 (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)pwconv_bwd_fast_kernel<24, 24, 24, PWB_FAST_WAVES, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 battr = current_device();
             }
             const int nb = Cout * Cin + Cout + Ca * Cb + Ca;
             {
-                ProfScope ps(KID_PWCONV_BWD, s, 4.0 * B * (double)V * ((act != HNO_ACT_NONE ? 2 : 1) * Cout + Cin + Ca + Cb));
+                // algorithmic bytes: gy, y (out) and xb are 2-byte tensors with bf16 activations in memory
+                ProfScope ps(KID_PWCONV_BWD, s, B * (double)V * (io16 ? 2.0 * (2 * Cout + Cb) + 4.0 * (2 * Ca + Cb)
+                                                                      : 4.0 * ((act != HNO_ACT_NONE ? 2 : 1) * Cout + Cin + Ca + Cb)));
                 hipLaunchKernelGGL(kern, dim3((int)fgb), dim3(64 * PWB_FAST_WAVES), (pwb_fast_lds_bytes<24, 24, 24, 1>(PWB_FAST_WAVES)), s, a);
             }
             HNO_CHECK_LAUNCH();
@@ -1765,9 +1844,11 @@ using namespace hno;
 extern "C" int hno_pwconv_fwd_branch(const float *s_in, const float *x, const float *Wbr, const float *bbr, const float *W,
                                      const float *bias, float *y, float *out, int B, int Ca, int Cb, int Cout, long long V,
                                      int act, void *stream) {
-    const int bf16 = (act >> 12) & 1;
+    const int bf16 = (act >> 12) & 1, io16 = (act >> 13) & 1;      // HNO_ACT_BF16, HNO_ACT_IO16 (x and out are bf16 tensors)
     act &= 0xfff;
     HNO_REQUIRE(s_in && x && Wbr && W && y && out && B > 0 && V > 0, "hno_pwconv_fwd_branch: bad argument");
+    HNO_REQUIRE(!io16 || (bf16 && V % 32 == 0 && ((size_t)x & 63) == 0 && ((size_t)out & 63) == 0),
+                "hno_pwconv_fwd_branch: bf16 tensors need bf16 arithmetic, V %% 32 == 0 and 64-byte aligned rows");
     if (!(Ca == 24 && Cb == 24 && Cout == 24))
         return fail(HNO_ELIMIT, "hno_pwconv_fwd_branch: only the 24 + 24 -> 24 block shape is built (got %d + %d -> %d)", Ca, Cb, Cout);
     if (V * 8 >= (1ll << 32) || ((V + 31) / 32) * B >= (1ll << 31))
@@ -1780,9 +1861,10 @@ extern "C" int hno_pwconv_fwd_branch(const float *s_in, const float *x, const fl
     if (grid > 512) grid = 512;   // two 4-wave blocks per CU (each wave one tile ahead through its LDS ring; 256: 62 us, 512: 57)
     if (debug_grid()) grid = debug_grid();
     hipStream_t fs = (hipStream_t)stream;
-    ProfScope ps(KID_PWCONV_FWD, fs, 4.0 * B * (double)V * (2 * Ca + Cb + Cout));
+    ProfScope ps(KID_PWCONV_FWD, fs, B * (double)V * (4.0 * 2 * Ca + (io16 ? 2.0 : 4.0) * (Cb + Cout)));
     const size_t fl = (size_t)PWF_DMA_WAVES * 2 * (12 + 12) * 256;
-    if (bf16) hipLaunchKernelGGL((pwconv_fwd_branch_kernel<24, 24, 24, true>), dim3((int)grid), dim3(64 * PWF_DMA_WAVES), fl, fs, a);
+    if (io16) hipLaunchKernelGGL((pwconv_fwd_branch_kernel<24, 24, 24, true, true>), dim3((int)grid), dim3(64 * PWF_DMA_WAVES), fl, fs, a);
+    else if (bf16) hipLaunchKernelGGL((pwconv_fwd_branch_kernel<24, 24, 24, true>), dim3((int)grid), dim3(64 * PWF_DMA_WAVES), fl, fs, a);
     else hipLaunchKernelGGL((pwconv_fwd_branch_kernel<24, 24, 24>), dim3((int)grid), dim3(64 * PWF_DMA_WAVES), fl, fs, a);
     HNO_CHECK_LAUNCH();
     return HNO_OK;
@@ -1802,7 +1884,7 @@ extern "C" int hno_pwconv_fwd_chain(const float *u, const float *t, const float 
         return fail(HNO_ELIMIT, "hno_pwconv_fwd_chain: V=%lld voxels per channel exceeds the 32-bit offset range", V);
     PwChainArgs a;
     a.u = u; a.t = t; a.k = k; a.Wc = Wc; a.bc = bc; a.Wm = Wm; a.bm = bm; a.xi = xi; a.xn = xn;
-    a.B = B; a.V = (unsigned)V; a.act = act & 0xfff; a.act2 = act2 & 0xfff; a.dbg = debug_flags();
+    a.B = B; a.V = (unsigned)V; a.act = act & 0xfff; a.act2 = act2 & 0xfff; a.dbg = debug_flags() | (pw_stagger() << 24);
     const long long ntiles = ((V + 31) / 32) * B;
     // two 4-wave workgroups per CU (63.3 us at 2 x 24 x 65^3) or one of 8 waves (67.7 us): HNO_PWCHAIN_WAVES=8 selects the latter (A/B)
     static const int nw_env = getenv("HNO_PWCHAIN_WAVES") ? atoi(getenv("HNO_PWCHAIN_WAVES")) : 4;
@@ -1848,7 +1930,7 @@ extern "C" int hno_pwconv_bwd_chain(const float *gn, const float *xn, const floa
     PwChainBwdArgs a;
     a.gn = gn; a.xn = xn ? xn : gn; a.xi = xi; a.k = k; a.u = u; a.t = t; a.Wm = Wm; a.Wc = Wc; a.gu = gu; a.gt = gt; a.gk = gk;
     a.partials = (float *)workspace; a.B = B; a.V = (unsigned)V; a.act = act & 0xfff; a.act2 = act2 & 0xfff; a.xa_act = xa_act & 0xff;
-    a.dbg = debug_flags();
+    a.dbg = debug_flags() | (pw_stagger() << 24);
     constexpr int NW = 4;
     static const int slots_env = getenv("HNO_PWCHAIN_SLOTS") ? atoi(getenv("HNO_PWCHAIN_SLOTS")) : 1;     // A/B: 2 = double-buffered ring
     const int slots = slots_env == 2 ? 2 : 1;

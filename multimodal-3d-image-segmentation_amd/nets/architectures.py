@@ -170,6 +170,16 @@ class _TransSeg(nn.Module):
         if len(fblocks) > 1 and x.is_cuda:
             with torch.no_grad():
                 w2_all = ops.cmix_compose_all([(l.op.weight_real, l.op.weight_imag) for l in fblocks])
+        # torch.autocast(bfloat16): conv1's output and every block's input / output are bf16 tensors in the reference
+        # (experiments/train_test.py:154-160).  When every block can take and return bf16 activations (ops.noblock_io16_ok) the chain keeps
+        # them bf16 IN MEMORY, with one cast at each end; otherwise storage stays fp32 and only the convolutions' arithmetic is bf16.
+        io16 = (x.is_cuda and not self.use_deep_supervision and len(fblocks) == len(self.layers) > 0 and ops._autocast_bf16()
+                and ops.chan_stride(x) is not None
+                and all(l.conv_branch is not None and
+                        ops.noblock_io16_ok(tuple(x.shape[2:]), x.shape[1], True, tuple(l.op.num_modes), l.conv_branch.weight.shape,
+                                            l.conv_concat.op.weight.shape) for l in fblocks))
+        if io16:
+            x = ops.CastFn.apply(x, True)
         try:
             if w2_all is not None:
                 for l, w2 in zip(fblocks, w2_all.unbind(0)):
@@ -181,6 +191,8 @@ class _TransSeg(nn.Module):
         finally:
             for l in fblocks:
                 l._w2_pre = None
+        if io16:
+            x = ops.CastFn.apply(x, False)
         if tensors:
             from .deep_supervision import conv_over_concat
             x = conv_over_concat(self.conv_ds, tensors)

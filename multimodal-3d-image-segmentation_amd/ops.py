@@ -17,6 +17,7 @@ from ._lib import check, ptr, stream_ptr
 
 ACT_NONE, ACT_SELU, ACT_ELU = 0, 1, 2
 ACT_BF16 = 0x1000   # ORed into the `act` argument of the pointwise entry points: bf16 matrix-core arithmetic (autocast)
+ACT_IO16 = 0x2000   # with ACT_BF16: the block's input / output (and the output's gradient) are bf16 tensors IN MEMORY (include/hno.h)
 ACT_SIGMOID = 3     # elementwise ActFn only (model output activation); never passed to the fused conv / transform epilogues
 _ACT_IDS = {None: ACT_NONE, 'none': ACT_NONE, 'selu': ACT_SELU, 'elu': ACT_ELU}
 LOSS_KINDS = {'pcc': 0, 'dice': 1, 'expdice': 2}
@@ -110,6 +111,45 @@ def act_empty(B, C, spatial, device, ld=None):
 
 def act_like(t, C=None):
     return act_empty(t.shape[0], t.shape[1] if C is None else C, t.shape[2:], t.device, chan_stride(t))
+
+
+# ---- bf16 activations in memory (round 6).  Under torch.autocast(bfloat16) the reference's nn.Conv3d returns bf16 and everything
+# elementwise behind it stays bf16 (experiments/train_test.py:154-160): the input and output of every FNOSeg / HNOSeg block are bf16
+# tensors there.  Here they are too -- same channel-padded layout, same ELEMENT stride ld (rows of 2-byte elements, 64-byte aligned) --
+# so every pass over them moves half the bytes.  The operator output, the pre-concat activation y and all parameter gradients stay fp32
+# as in the reference.  HNO_IO16=0 keeps fp32 storage (A/B).
+def chan_stride16(t):
+    """channel stride (elements) when `t` is a channel-padded bf16 activation, else None"""
+    if t is None or t.dim() != 5 or t.dtype != torch.bfloat16 or t.is_meta:
+        return None
+    B, C, D, H, W = t.shape
+    V, st = D * H * W, t.stride()
+    ld = st[1]
+    if D < 2 or ld != _pad_ld(V) or tuple(st[2:]) != (H * W, W, 1) or (B > 1 and st[0] != C * ld):
+        return None
+    if (t.storage_offset() + B * C * ld) * 2 > t.untyped_storage().nbytes() or (t.data_ptr() & 63):
+        return None
+    return ld
+
+
+def act_empty16(B, C, spatial, device, ld):
+    """uninitialised (B, C, *spatial) bf16 activation with channel stride `ld` elements"""
+    D, H, W = (int(v) for v in spatial)
+    return torch.empty(B * C * ld, device=device, dtype=torch.bfloat16).as_strided((B, C, D, H, W), (C * ld, ld, H * W, W, 1))
+
+
+def to_bf16_layout(t, ld):
+    """`t` (fp32 or bf16, any layout) as a channel-padded bf16 activation of stride `ld`; padding zero"""
+    if chan_stride16(t) == ld:
+        return t
+    src = to_layout(t.float() if t.dtype != torch.float32 else t, ld)
+    out = act_empty16(t.shape[0], t.shape[1], t.shape[2:], t.device, ld)
+    check(_lib.lib().hno_cast_f32_bf16(ptr(src), ptr(out), _ext(src), stream_ptr()), 'hno_cast_f32_bf16')
+    return out
+
+
+def io16_enabled():
+    return os.environ.get('HNO_IO16', '1') != '0'
 
 
 def _ext(t):
@@ -393,22 +433,28 @@ def pwconv_bwd_raw(gy, y, xa, xb, W, act, has_bias, need_gxa=True, need_gxb=True
     return gxa, gxb, dW, db
 
 
-def pwconv_bwd_branch_raw(gy, y, xa, xb, W, Wbr, act, xa_act, defer=False, bf16=False):
+def pwconv_bwd_branch_raw(gy, y, xa, xb, W, Wbr, act, xa_act, defer=False, bf16=False, io16=False):
     """Backward of  act(W [xa ; xb] + b)  where xa = xa_act(s + Wbr xb + bbr): one pass (hno_pwconv_bwd_branch).
-    -> (p, gxb, dW, db, dWbr, dbbr) with p the gradient of the pre-activation sum s + Wbr xb + bbr."""
+    -> (p, gxb, dW, db, dWbr, dbbr) with p the gradient of the pre-activation sum s + Wbr xb + bbr.
+    io16: gy, y, xb are channel-padded bf16 tensors (xa's stride); p and gxb come back fp32."""
     B, Ca = xa.shape[:2]
     ld = chan_stride(xa)            # channel-padded operands: V := ld (pwconv_bwd_raw)
-    gy, y, xb = to_layout(gy, ld), to_layout(y, ld), to_layout(xb, ld)
+    if io16:
+        assert bf16 and ld is not None
+        gy, y, xb = to_bf16_layout(gy, ld), to_bf16_layout(y, ld), to_bf16_layout(xb, ld)
+    else:
+        gy, y, xb = to_layout(gy, ld), to_layout(y, ld), to_layout(xb, ld)
     Cb, Cout, V = xb.shape[1], W.shape[0], ld or _flat_v(xa)
     L = _lib.lib()
     p = act_like(xa)
-    gxb = act_like(xb)
+    gxb = act_like(xa, Cb)
     n_w, n_br = Cout * (Ca + Cb), Ca * Cb
     flat = torch.empty(n_w + Cout + n_br + Ca, device=xa.device, dtype=torch.float32)
     ws = torch.empty(L.hno_pwconv_bwd_branch_workspace_bytes(Ca, Cb, Cout) // 4, device=xa.device, dtype=torch.float32)
     with _DeferReduce(defer) as d:
         check(L.hno_pwconv_bwd_branch(ptr(gy), ptr(y), ptr(xa), Ca, ptr(xb), Cb, ptr(W), ptr(Wbr), ptr(p), ptr(gxb), ptr(flat),
-                                      ptr(ws), B, Cout, V, act | (ACT_BF16 if bf16 else 0), xa_act | d.bit, stream_ptr()), 'hno_pwconv_bwd_branch')
+                                      ptr(ws), B, Cout, V, act | (ACT_BF16 if bf16 else 0) | (ACT_IO16 if io16 else 0), xa_act | d.bit, stream_ptr()),
+              'hno_pwconv_bwd_branch')
         d.keep(ws)
     dW = flat[:n_w].view_as(W)
     db = flat[n_w:n_w + Cout]
@@ -687,27 +733,33 @@ def fourier_chain_supported(x, modes):
 
 def fourier_chain_fwd_raw(x, w2, modes, scale_fwd, addend, inv_act):
     """rfftn + mode selection -> complex channel mix (w2: the composed real (2C, 2C) form) -> zero pad + irfftn (+ addend, + activation)
-    with the fused middle: -> (s0, y) = what rfft3_crop_raw returns and irfft3_pad_raw(pwconv(s0, w2), ...) returns."""
+    with the fused middle: -> (s0, y) = what rfft3_crop_raw returns and irfft3_pad_raw(pwconv(s0, w2), ...) returns.
+    x may be a channel-padded bf16 activation (chan_stride16): its planes are read as they are (hno_dht3_planes_b16); y is fp32."""
     _need_gpu(x, addend)
     B, C, N0, N1, N2 = x.shape
     m0, m1, m2 = modes
     L = _lib.lib()
-    ld = chan_stride(x) or 0
+    x16 = chan_stride16(x)
+    ld = x16 or chan_stride(x) or 0
     addend = to_layout(addend, ld or None)
     ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, N0, N1, N2, m0, m1, m2) // 4, device=x.device, dtype=torch.float32)
     s0 = torch.empty((B, 2 * C, 2 * m0, 2 * m1, m2), device=x.device, dtype=torch.float32)
-    y = act_like(x)
-    check(L.hno_dht3_planes(ptr(x), ptr(ws), B * C, N0, N1, N2, m0, m1, m2, ld, stream_ptr()), 'hno_dht3_planes')
+    y = act_empty(B, C, (N0, N1, N2), x.device, ld or None)
+    if x16:
+        check(L.hno_dht3_planes_b16(ptr(x), ptr(ws), B * C, N0, N1, N2, m0, m1, m2, ld, stream_ptr()), 'hno_dht3_planes_b16')
+    else:
+        check(L.hno_dht3_planes(ptr(x), ptr(ws), B * C, N0, N1, N2, m0, m1, m2, ld, stream_ptr()), 'hno_dht3_planes')
     check(L.hno_spec_mid_fourier_fwd(ptr(ws), ptr(w2), ptr(s0), B, C, N0, m0, m1, m2, float(scale_fwd), 0, 1, stream_ptr()),
           'hno_spec_mid_fourier_fwd')
     check(L.hno_idht3_planes(ptr(ws), ptr(addend), inv_act, ptr(y), B * C, N0, N1, N2, m0, m1, m2, 1.0, ld, stream_ptr()), 'hno_idht3_planes')
     return s0, y
 
 
-def fourier_chain_bwd_raw(p, s0, w2, modes, scale_out, addend, defer=False):
+def fourier_chain_bwd_raw(p, s0, w2, modes, scale_out, addend, defer=False, out16=False):
     """backward of the same chain: p = gradient of the inverse transform's (pre-activation) output -> (gx, dW2 (2C, 2C)); the gradients
     of the spectra never reach memory.  defer: dW2's slab reduction joins the batched end-of-backward reduction (the caller then
-    defers the real / imaginary split likewise: cmix_split_grad_raw)."""
+    defers the real / imaginary split likewise: cmix_split_grad_raw).  out16: gx is the gradient of a bf16 block input -- written as a
+    channel-padded bf16 tensor by the inverse plane kernel's epilogue (hno_idht3_planes_b16; the addend stays fp32)."""
     _need_gpu(p, addend)
     B, C, N0, N1, N2 = p.shape
     m0, m1, m2 = modes
@@ -717,15 +769,19 @@ def fourier_chain_bwd_raw(p, s0, w2, modes, scale_out, addend, defer=False):
     ws = torch.empty(L.hno_dht3_workspace_bytes(B * C, N0, N1, N2, m0, m1, m2) // 4, device=p.device, dtype=torch.float32)
     slab = torch.empty(L.hno_spec_mid_fourier_bwd_workspace_bytes(B, C, m1) // 4, device=p.device, dtype=torch.float32)
     dw2 = torch.empty((2 * C, 2 * C), device=p.device, dtype=torch.float32)
-    gx = act_like(p)
+    gx = act_empty16(B, C, (N0, N1, N2), p.device, ld) if (out16 and ld) else act_like(p)
     check(L.hno_dht3_planes(ptr(p), ptr(ws), B * C, N0, N1, N2, m0, m1, m2, ld, stream_ptr()), 'hno_dht3_planes')
     with _DeferReduce(defer) as d:
         check(L.hno_spec_mid_fourier_bwd(ptr(ws), ptr(w2), ptr(s0), ptr(dw2), ptr(slab), 4 * slab.numel(), B, C, N0, m0, m1, m2, 1.0, 1 | d.bit, 0,
                                          stream_ptr()),
               'hno_spec_mid_fourier_bwd')
         d.keep(slab, dw2)
-    check(L.hno_idht3_planes(ptr(ws), ptr(addend), ACT_NONE, ptr(gx), B * C, N0, N1, N2, m0, m1, m2, float(scale_out), ld, stream_ptr()),
-          'hno_idht3_planes')
+    if gx.dtype == torch.bfloat16:
+        check(L.hno_idht3_planes_b16(ptr(ws), ptr(addend), ACT_NONE, ptr(gx), B * C, N0, N1, N2, m0, m1, m2, float(scale_out), ld, stream_ptr()),
+              'hno_idht3_planes_b16')
+    else:
+        check(L.hno_idht3_planes(ptr(ws), ptr(addend), ACT_NONE, ptr(gx), B * C, N0, N1, N2, m0, m1, m2, float(scale_out), ld, stream_ptr()),
+              'hno_idht3_planes')
     return gx, dw2
 
 
@@ -1544,6 +1600,52 @@ class ComplexMixFn(_HnoFunction):
         return gx, dwr, dwi
 
 
+def noblock_io16_ok(spatial, channels, fourier, modes, br_shape, cat_shape):
+    """the block can keep its input and output as bf16 tensors (autocast): the Fourier block of FNOSeg (24 channels, conv branch, concat
+    skip) on a working grid whose planes have a bf16 item kernel (65 x 65) and the fused Fourier middle"""
+    if not (io16_enabled() and fourier and len(spatial) == 3 and channels == 24 and tuple(br_shape or ()) [:2] == (24, 24)
+            and tuple(cat_shape)[:2] == (24, 48) and tuple(spatial[1:]) == (65, 65) and int(np.prod(spatial)) % 32 != 0):
+        return False
+    m = clamp_modes(tuple(modes), tuple(spatial))
+    return (os.environ.get('HNO_FUSED_MID', '1') != '0' and os.environ.get('HNO_FUSED_MID_BWD', '1') != '0'
+            and bool(_lib.lib().hno_spec_mid_fourier_supported(24, int(spatial[0]), int(m[0]), int(m[1]), int(m[2]))))
+
+
+class CastFn(_HnoFunction):
+    """fp32 <-> bf16 of a channel-padded activation, layout kept: the two ends of a chain of blocks with bf16 activations in memory --
+    what autocast's to(bfloat16) in front of the first nn.Conv3d, and type promotion behind the last one, do in the reference
+    (experiments/train_test.py:154-160).  The gradient takes the opposite cast."""
+
+    @staticmethod
+    def meta(x, to_bf16):
+        return _m(x.shape, torch.bfloat16 if to_bf16 else torch.float32)
+
+    @staticmethod
+    def _cast(x, to_bf16):
+        if to_bf16:
+            ld = chan_stride(x) if x.dtype == torch.float32 else chan_stride16(x)
+            if ld is None:
+                x = to_layout(x.float(), _pad_ld(_flat_v(x)))
+                ld = chan_stride(x)
+            return to_bf16_layout(x, ld)
+        ld = chan_stride16(x)
+        if ld is None:
+            return _f32c(x)
+        out = act_empty(x.shape[0], x.shape[1], x.shape[2:], x.device, ld)
+        check(_lib.lib().hno_cast_bf16_f32(ptr(x), ptr(out), x.shape[0] * x.shape[1] * ld, stream_ptr()), 'hno_cast_bf16_f32')
+        return out
+
+    @staticmethod
+    def forward(ctx, x, to_bf16):
+        _need_gpu(x)
+        ctx.to_bf16 = bool(to_bf16)
+        return CastFn._cast(x, ctx.to_bf16)
+
+    @staticmethod
+    def backward(ctx, g):
+        return CastFn._cast(g, not ctx.to_bf16), None
+
+
 class NOBlockFn(_HnoFunction):
     """One FNOSeg / HNOSeg block (nets/architectures.py:511-608 with shared weights, SELU, concat skip) as a single
     autograd node:
@@ -1574,14 +1676,18 @@ class NOBlockFn(_HnoFunction):
         if len(modes) == 2:                      # 2-D model on a (B, C, 1, H, W) view
             modes = (0,) + tuple(modes)
         modes = clamp_modes(modes, spatial)
-        # a channel-padded input stays padded through the block when both transform directions take the stride (XSBlockFn)
-        x = _f32a(x) if (chan_stride(x) is not None and padded_ok(spatial, modes)) else _f32c(x)
-        ld = chan_stride(x)
+        bf = _autocast_bf16()       # autocast: the spatial 1x1x1 convolutions take bf16 operands; transform and spectral mix stay fp32
+        # bf16 activations in memory (round 6): a channel-padded bf16 input stays bf16, and so does the block's output
+        io16 = (bf and chan_stride16(x) is not None and
+                noblock_io16_ok(spatial, x.shape[1], fourier, modes, None if br_w is None else br_w.shape, cat_w.shape))
+        if not io16:
+            # a channel-padded input stays padded through the block when both transform directions take the stride (XSBlockFn)
+            x = _f32a(x) if (chan_stride(x) is not None and padded_ok(spatial, modes)) else _f32c(x)
+        ld = chan_stride16(x) if io16 else chan_stride(x)
         _need_gpu(x, cat_w, *op_ws)
         n3 = float(np.prod(spatial))
         # 24 + 24 -> 24 with a conv branch: branch conv, add, activation and concat conv in one pass after the inverse
         fuse_tail = br_w is not None and tuple(cat_w.shape[:2]) == (24, 48) and tuple(br_w.shape[:2]) == (24, 24)
-        bf = _autocast_bf16()       # autocast: the spatial 1x1x1 convolutions take bf16 operands; transform and spectral mix stay fp32
         x2 = pwconv_fwd_raw(x, None, br_w, br_b, ACT_NONE, bf) if (br_w is not None and not fuse_tail) else None
         inv_act = ACT_NONE if fuse_tail else act
         if fourier:
@@ -1609,12 +1715,15 @@ class NOBlockFn(_HnoFunction):
                 s1 = pwconv_fwd_raw(s0, None, w, None, ACT_SELU)      # SELU in the frequency domain (hartley_operator.py:262-269)
                 y = pad_idht3_raw(s1, spatial, 1.0, x2, inv_act, ld=ld)
         if fuse_tail:
-            sop, y, out = y, act_like(x), act_like(x)
+            sop, y = y, act_like(y)
+            out = act_empty16(x.shape[0], 24, spatial, x.device, ld) if io16 else act_like(y)
             check(_lib.lib().hno_pwconv_fwd_branch(ptr(sop), ptr(x), ptr(br_w), ptr(br_b), ptr(cat_w), ptr(cat_b), ptr(y), ptr(out),
-                                                   x.shape[0], 24, 24, 24, ld or _flat_v(x), act | (ACT_BF16 if bf else 0), stream_ptr()), 'hno_pwconv_fwd_branch')
+                                                   x.shape[0], 24, 24, 24, ld or _flat_v(x),
+                                                   act | (ACT_BF16 if bf else 0) | (ACT_IO16 if io16 else 0), stream_ptr()), 'hno_pwconv_fwd_branch')
         else:
             out = pwconv_fwd_raw(y, x, cat_w, cat_b, act, bf)
         ctx.bf16 = bf
+        ctx.io16 = io16
         ctx.save_for_backward(x, br_w, cat_w, w, s0, s1 if not fourier else None, y, out, br_b, cat_b, *op_ws)
         ctx.cfg = (bool(fourier), modes, act, spatial, n3, br_b is not None, cat_b is not None)
         return out
@@ -1627,7 +1736,8 @@ class NOBlockFn(_HnoFunction):
         d_br_w = d_br_b = None
         if br_w is not None and tuple(cat_w.shape[:2]) == (24, 48) and tuple(br_w.shape[:2]) == (24, 24):
             # one pass: p = d loss / d (s + x2) = g_y * act'(y); g_x = concat-path gradient + Wbr^T p; all four parameter gradients
-            p, g_x, d_cat_w, d_cat_b, d_br_w, d_br_b = pwconv_bwd_branch_raw(_f32a(g_out), out, y, x, cat_w, br_w, act, act, defer=late, bf16=ctx.bf16)
+            p, g_x, d_cat_w, d_cat_b, d_br_w, d_br_b = pwconv_bwd_branch_raw(g_out if ctx.io16 else _f32a(g_out), out, y, x, cat_w, br_w, act, act,
+                                                                             defer=late, bf16=ctx.bf16, io16=ctx.io16)
             d_br_w = d_br_w.view_as(br_w)
             if not cat_has_b:
                 d_cat_b = None
@@ -1642,8 +1752,9 @@ class NOBlockFn(_HnoFunction):
         if fourier:
             Co, Ci = w.shape[0] // 2, w.shape[1] // 2
             fused = Co == Ci == x.shape[1] and fourier_chain_supported(x, modes) and os.environ.get('HNO_FUSED_MID_BWD', '1') != '0'
+            assert fused or not ctx.io16
             if fused:
-                gx, dw2 = fourier_chain_bwd_raw(p, s0, w, modes, 1.0 / n3, g_x, defer=late)
+                gx, dw2 = fourier_chain_bwd_raw(p, s0, w, modes, 1.0 / n3, g_x, defer=late, out16=ctx.io16)
             else:
                 gs1 = rfft3_crop_raw(p, modes, 1.0, True)
                 gs0, _, dw2, _ = pwconv_bwd_raw(gs1, None, s0, None, w, ACT_NONE, False)

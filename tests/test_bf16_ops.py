@@ -224,3 +224,123 @@ def test_pointwise_bf16_variants_vs_float64(shape):
     # the weight gradient multiplies g * act'(y) (y here = the bf16-rounded output) by the inputs in fp32
     assert rel_err(gs[-2].cpu().numpy(), gW64.numpy()) < 1e-2
     assert rel_err(gs[-1].cpu().numpy(), gb64.numpy()) < 1e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 6: bf16 activations IN MEMORY for the FNOSeg block chain (HNO_ACT_IO16; reference: what torch.autocast(bfloat16) makes of the
+# block inputs / outputs, experiments/train_test.py:154-160 with nets/architectures.py:521-546).  Storing a tensor whose values are
+# already bf16-representable as bf16 loses nothing, so every bf16-storage kernel is held BIT-EXACT to its fp32-storage twin.
+def _padded(ops, B, C, N, seed, bf16_values=True):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    ld = ops._pad_ld(N ** 3)
+    t = ops.act_empty(B, C, (N, N, N), 'cuda', ld)
+    t.as_strided((B * C * ld,), (1,)).zero_()
+    v = torch.randn((B, C, N, N, N), device='cuda', generator=g)
+    t.copy_(v.bfloat16().float() if bf16_values else v)
+    return t
+
+
+def test_plane_transforms_with_bf16_planes_equal_the_fp32_kernels():
+    import multimodal_3d_image_segmentation_amd as pkg
+    from multimodal_3d_image_segmentation_amd import ops
+    from multimodal_3d_image_segmentation_amd._lib import lib, ptr, check, stream_ptr
+    L = lib()
+    B, C, N, modes = 1, 24, 65, (10, 14, 14)
+    x = _padded(ops, B, C, N, 1)
+    ld = ops.chan_stride(x)
+    x16 = ops.to_bf16_layout(x, ld)
+    assert ops.chan_stride16(x16) == ld and torch.equal(x16.float(), x)
+    nws = L.hno_dht3_workspace_bytes(B * C, N, N, N, *modes) // 4
+    ws32, ws16 = torch.zeros(nws, device='cuda'), torch.zeros(nws, device='cuda')
+    check(L.hno_dht3_planes(ptr(x), ptr(ws32), B * C, N, N, N, *modes, ld, stream_ptr()), 'planes')
+    check(L.hno_dht3_planes_b16(ptr(x16), ptr(ws16), B * C, N, N, N, *modes, ld, stream_ptr()), 'planes_b16')
+    assert torch.equal(ws32, ws16)                    # same arithmetic on the same values: the intermediate is bit-identical
+    # inverse: fp32 output rounded to bf16 afterwards == bf16 output of the kernel, with and without the fp32 residual
+    add = _padded(ops, B, C, N, 2, bf16_values=False)
+    for addend in (None, add):
+        o32 = ops.act_empty(B, C, (N, N, N), 'cuda', ld)
+        o16 = ops.act_empty16(B, C, (N, N, N), 'cuda', ld)
+        check(L.hno_idht3_planes(ptr(ws32), ptr(addend), 0, ptr(o32), B * C, N, N, N, *modes, 0.5, ld, stream_ptr()), 'iplanes')
+        check(L.hno_idht3_planes_b16(ptr(ws32), ptr(addend), 0, ptr(o16), B * C, N, N, N, *modes, 0.5, ld, stream_ptr()), 'iplanes_b16')
+        assert torch.isfinite(o32).all() and float(o32.abs().max()) > 0
+        assert torch.equal(o16, o32.bfloat16()), float((o16.float() - o32).abs().max())
+        # the padding behind every channel's last voxel is written (zero): gradient padding must be exactly zero
+        flat = o16.as_strided((B * C, ld), (ld, 1))
+        assert float(flat[:, N ** 3:].float().abs().max()) == 0.0
+    # sizes without a bf16 item kernel fail loudly (no silent fp32 fallback)
+    y16 = torch.zeros(24 * 33 ** 3 + 64, device='cuda', dtype=torch.bfloat16)
+    ws = torch.zeros(L.hno_dht3_workspace_bytes(24, 33, 33, 33, *modes) // 4, device='cuda')
+    rc = L.hno_dht3_planes_b16(ptr(y16), ptr(ws), 24, 33, 33, 33, *modes, 0, stream_ptr())
+    assert rc != 0 and b'65 x 65' in L.hno_last_error()
+
+
+def test_block_tail_with_bf16_tensors_equals_fp32_storage():
+    """hno_pwconv_fwd_branch / hno_pwconv_bwd_branch with HNO_ACT_IO16 against the same calls on fp32 tensors that hold the same
+    (bf16-representable) values: y, out, p, g_x and all four parameter gradients bit for bit."""
+    from multimodal_3d_image_segmentation_amd import ops
+    from multimodal_3d_image_segmentation_amd._lib import lib, ptr, check, stream_ptr
+    L = lib()
+    B, C, N = 2, 24, 65
+    torch.manual_seed(3)
+    s, x = _padded(ops, B, C, N, 4, bf16_values=False), _padded(ops, B, C, N, 5)
+    ld = ops.chan_stride(x)
+    Wbr, bbr = torch.randn(24, 24, device='cuda') * 0.2, torch.randn(24, device='cuda') * 0.1
+    W, b = torch.randn(24, 48, device='cuda') * 0.15, torch.randn(24, device='cuda') * 0.1
+    act = ops.ACT_SELU
+    x16 = ops.to_bf16_layout(x, ld)
+    y32, o32, y16 = ops.act_like(x), ops.act_like(x), ops.act_like(x)
+    o16 = ops.act_empty16(B, C, (N, N, N), 'cuda', ld)
+    check(L.hno_pwconv_fwd_branch(ptr(s), ptr(x), ptr(Wbr), ptr(bbr), ptr(W), ptr(b), ptr(y32), ptr(o32), B, 24, 24, 24, ld, act | ops.ACT_BF16,
+                                  stream_ptr()), 'fwd32')
+    check(L.hno_pwconv_fwd_branch(ptr(s), ptr(x16), ptr(Wbr), ptr(bbr), ptr(W), ptr(b), ptr(y16), ptr(o16), B, 24, 24, 24, ld,
+                                  act | ops.ACT_BF16 | ops.ACT_IO16, stream_ptr()), 'fwd16')
+    assert torch.equal(y16, y32) and torch.equal(o16.float(), o32) and float(o32.abs().max()) > 0
+    g = _padded(ops, B, C, N, 6)                     # the gradient of a bf16 tensor is bf16
+    g.as_strided((B * C, ld), (ld, 1))[:, N ** 3:] = 0
+    g16 = ops.to_bf16_layout(g, ld)
+    r32 = ops.pwconv_bwd_branch_raw(g, o32, y32, x, W, Wbr, act, act, bf16=True)
+    r16 = ops.pwconv_bwd_branch_raw(g16, o16, y16, x16, W, Wbr, act, act, bf16=True, io16=True)
+    for name, a32, a16 in zip(('p', 'g_x', 'dW', 'db', 'dWbr', 'dbbr'), r32, r16):
+        assert a16.dtype == torch.float32 and torch.equal(a32, a16), name
+    # misuse fails loudly: bf16 tensors without bf16 arithmetic
+    rc = L.hno_pwconv_fwd_branch(ptr(s), ptr(x16), ptr(Wbr), ptr(bbr), ptr(W), ptr(b), ptr(y16), ptr(o16), B, 24, 24, 24, ld, act | ops.ACT_IO16,
+                                 stream_ptr())
+    assert rc != 0
+
+
+def test_fnoseg_chain_with_bf16_activations_in_memory(monkeypatch):
+    """A 3-block FNOSeg (the BASELINE cfg3 block) under autocast with bf16 block inputs / outputs IN MEMORY (the default) against fp32
+    storage (HNO_IO16=0): the forward is bit-identical (the stored values were bf16-representable already); the backward differs by the
+    bf16 rounding of each block-input gradient -- what the reference's autocast run does to the same tensors."""
+    import multimodal_3d_image_segmentation_amd as pkg
+    from multimodal_3d_image_segmentation_amd import ops
+    from multimodal_3d_image_segmentation_amd.nets import custom_losses
+    torch.manual_seed(11)
+    model = pkg.nets.NeuralOperatorSeg(4, 4, 24, 3, (10, 14, 14), 'Fourier').cuda()
+    x = torch.randn(1, 4, 128, 128, 128, device='cuda')
+    lab = pkg.ops.labels_prepare(torch.randint(0, 4, (1, 1, 128, 128, 128), device='cuda').float(), 4)
+    seen = []
+    real = ops.NOBlockFn.forward
+
+    def spy(ctx, xin, *a):
+        out = real(ctx, xin, *a)
+        seen.append((xin.dtype, out.dtype))
+        return out
+    monkeypatch.setattr(ops.NOBlockFn, 'forward', staticmethod(spy))
+    res = {}
+    for io in ('1', '0'):
+        monkeypatch.setenv('HNO_IO16', io)
+        del seen[:]
+        for p in model.parameters():
+            p.grad = None
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = model(x)
+            loss = custom_losses.PCCLoss()(y, lab)
+        loss.backward()
+        want = torch.bfloat16 if io == '1' else torch.float32
+        assert seen == [(want, want)] * 3, seen
+        res[io] = (y.detach().clone(), float(loss), torch.cat([p.grad.flatten() for p in model.parameters()]))
+    assert torch.equal(res['1'][0], res['0'][0]) and res['1'][1] == res['0'][1]
+    g1, g0 = res['1'][2], res['0'][2]
+    err = float((g1 - g0).norm() / g0.norm())
+    assert 0.0 < err < 2e-2, err
