@@ -2426,3 +2426,4 @@ def test_pwconv_qkv_projection_thirds(pkg):
                 assert rel_err(a.grad.cpu().numpy(), r.numpy()) < 5e-6, defer
         finally:
             ops.set_defer_reduce(False)
+

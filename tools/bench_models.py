@@ -68,7 +68,7 @@ for name in which:
             forced = dict(os.environ, HNO_SPLIT_STREAMS='1') if getattr(model, 'hno_sample_split', False) else None
             prev_env = os.environ.get('HNO_SPLIT_STREAMS')
             if forced: os.environ['HNO_SPLIT_STREAMS'] = '1'
-            try: can = not bf16 and SampleSplit.usable(model, loss_fn, x)
+            try: can = (not bf16 or os.environ.get('HNO_SPLIT_STREAMS') == '1') and SampleSplit.usable(model, loss_fn, x)
             finally:
                 if forced:
                     if prev_env is None: os.environ.pop('HNO_SPLIT_STREAMS', None)
@@ -86,7 +86,7 @@ for name in which:
                     with torch.cuda.stream(side):
                         gs = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(gs, stream=side, capture_error_mode='thread_local'):
-                            sp.fwd_bwd(x, lab, loss_fn, zero_grad=zero)
+                            sp.fwd_bwd(x, lab, loss_fn, zero_grad=zero, autocast=ac if bf16 else None)
                 finally:
                     pkg.ops.set_defer_reduce(prev)
                 torch.cuda.current_stream().wait_stream(side)
