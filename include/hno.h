@@ -471,6 +471,10 @@ int hno_add(const float *a, const float *b, float *out, long long n, void *strea
 int hno_chan_restride(const float *src, float *dst, long long rows, long long V, long long ld_src, long long ld_dst, void *stream);
 /* fp32 <-> bf16 (round to nearest even) over n elements: the ends of a chain of blocks whose activations are bf16 in memory under
  * torch.autocast (HNO_ACT_IO16) -- the reference casts at the same places (autocast's to(bfloat16) in front of nn.Conv3d) */
+/* TIMING PROBE, not a product path (csrc/hno_invpw.hip; LESSONS round 6): the memory traffic and instruction counts of a forward kernel
+ * that computes the inverse plane transform inside the pointwise kernel that consumes it -- outputs are NOT the transform's. */
+int hno_debug_invpw_fwd_probe(const float *Y, const float *t, const float *W, const float *bias, const float *TH, const float *TW,
+                              float *u, float *xi, int B, long long V, float scale, int grid, void *stream);
 int hno_cast_f32_bf16(const float *src, void *dst_bf16, long long n, void *stream);
 int hno_cast_bf16_f32(const void *src_bf16, float *dst, long long n, void *stream);
 /* out = alpha * a + beta * b (b may be NULL: out = alpha * a); the x +- x_reverse combinations of hartley_conv

@@ -124,6 +124,7 @@ SIGNATURES = {
     'hno_add': (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
     'hno_chan_restride': (c_int, [c_void_p, c_void_p, c_ll, c_ll, c_ll, c_ll, c_void_p]),
     'hno_cast_f32_bf16': (c_int, [c_void_p, c_void_p, c_ll, c_void_p]),
+    'hno_debug_invpw_fwd_probe': (c_int, [c_void_p] * 8 + [c_int, c_ll, c_float, c_int, c_void_p]),
     'hno_cast_bf16_f32': (c_int, [c_void_p, c_void_p, c_ll, c_void_p]),
     'hno_axpby': (c_int, [c_float, c_void_p, c_float, c_void_p, c_void_p, c_ll, c_void_p]),
     'hno_loss_fwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_ll, c_int, c_float, c_void_p]),

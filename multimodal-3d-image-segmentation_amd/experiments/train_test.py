@@ -242,7 +242,7 @@ class CapturedStep:
     an epoch then simply runs eagerly).  After a replay every parameter's ``.grad`` is the buffer the graph wrote, whatever eager
     steps did in between.  Not used with autocast (GradScaler's inf checks synchronise) or on CPU tensors."""
 
-    def __init__(self, model, loss_fn, num_labels, label_mapping=None, data_parallel=None, max_shapes=2, optimizer=None):
+    def __init__(self, model, loss_fn, num_labels, label_mapping=None, data_parallel=None, max_shapes=2, optimizer=None, bucketed=None):
         """optimizer: a device-stepped optim.Adamax (``optimizer.device_stepped(scheduler)``): its update (and the scheduler's step)
         is captured behind backward -- and behind the gradient all-reduce, which is then captured too -- so a step of a rank is ONE
         graph replay; ``steps_optimizer`` tells the caller not to step again.
@@ -259,6 +259,12 @@ class CapturedStep:
         if data_parallel is not None and not self.capture_allreduce:
             self.optimizer = None
         self.steps_optimizer = self.optimizer is not None
+        # bucketed (round 6): with the collective inside the graph AND a gradient worth overlapping (V-Net-DS: 90 MB), the per-bucket
+        # all-reduces are launched by the replica's post-accumulate hooks DURING the captured backward, on its communication stream --
+        # they become nodes of the graph on a side branch and overlap the rest of backward in every replay, as the eager path does.
+        # Default: when the flat gradient is at least HNO_DP_BUCKETED_BYTES (4 MB); HNOSeg-XS's 113 KB stay one flat all-reduce.
+        big = data_parallel is not None and data_parallel.flat_grad.numel() * 4 >= int(os.environ.get('HNO_DP_BUCKETED_BYTES', str(4 << 20)))
+        self.bucketed = bool(self.capture_allreduce and getattr(data_parallel, 'overlap', False) and (big if bucketed is None else bucketed))
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.entries, self.seen, self.failed = {}, {}, set()
         self.copy_stream, self.staged = None, None
@@ -289,7 +295,7 @@ class CapturedStep:
     def _capture(self, x, y):
         from .. import ops
         xs, ys = x.clone(), y.clone()
-        mode = SampleSplit.candidate(self.model, self.loss_fn, xs)
+        mode = False if self.bucketed else SampleSplit.candidate(self.model, self.loss_fn, xs)      # (the twin's gradients bypass the hooks)
         if mode:
             # the twin, its constants and the half-batch shapes' tables / kernel attributes exist BEFORE the capture (none of it is
             # capturable; round 4 built the twin inside the capture: its copies were replayed with every step -- ADVICE round 4)
@@ -308,8 +314,9 @@ class CapturedStep:
         cur = torch.cuda.current_stream()
         torch.cuda.synchronize()
         if self.dp is not None:
-            self.dp.set_hooks_enabled(False)
-        prev = ops.set_defer_reduce(True)      # inside a captured step nothing reads a gradient before backward ends
+            self.dp.set_hooks_enabled(self.bucketed)
+        # inside a captured step nothing reads a gradient before backward ends -- unless its buckets leave during backward
+        prev = ops.set_defer_reduce(not self.bucketed)
         key = (tuple(x.shape), x.dtype, tuple(y.shape), y.dtype)
         try:
             use_split = mode == 'force'
@@ -327,7 +334,12 @@ class CapturedStep:
                 # thread_local: a collective library's watchdog thread may poll events while we capture
                 with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
                     loss = self._fwd_bwd(xs, ys, use_split)
-                    if self.dp is not None:
+                    if self.dp is not None and self.bucketed:
+                        # the hooks sent the buckets on the communication stream (a side branch of the graph); what is left is
+                        # sent now, the capturing stream joins the branch
+                        self.dp.allreduce_grads()
+                        self.dp._flat_ready = True
+                    elif self.dp is not None:
                         self.dp.finish_capture()
                         if self.capture_allreduce:
                             self.dp.allreduce_flat()
@@ -347,6 +359,8 @@ class CapturedStep:
                 self.dp.set_hooks_enabled(True)
             return None
         ops.set_defer_reduce(prev)
+        if self.dp is not None and self.bucketed:
+            self.dp.set_hooks_enabled(False)
         # (data-parallel: the hooks stay off while graphs exist; eager fall-back steps send their buckets from allreduce_grads())
         # staging buffers of prefetch(): the NEXT batch crosses PCIe on the copy stream while this one is being worked on
         done = torch.cuda.Event()
