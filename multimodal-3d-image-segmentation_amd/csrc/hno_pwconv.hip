@@ -833,10 +833,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && COUT <= 48) ? 2 : 1) void pwco
     // the weight gradient (16 rows x 4 voxels per instruction) hit 64 different banks: bank = 4 (row >> 1) + 32 (row & 1) + voxel.
     constexpr bool DMA = BR == 0;
     constexpr int XS = DMA ? (rowsX / 2) * PWB_XP : rowsX * PWB_LD;   // floats per x slot
-    constexpr int WAVE_FLOATS = rowsG * PWB_LD + (DMA ? 2 : 1) * XS + rowsP * PWB_LD;
+    // WG16 (with IO16, round 6): the weight gradients' operands are bf16 tiles read eight voxels at a time for v_mfma_f32_32x32x16_bf16
+    // (6 matrix instructions and 10 ds_read_b128 per tile instead of 80 fp32 products and 72 ds_read_b32); fp32 accumulation.  What
+    // torch.autocast does to the convolutions' weight gradients (bf16 operands), with a wider accumulator.  The fp32 tile shrinks to
+    // the xa rows (their activation derivative is read back in accumulator order).
+    constexpr bool WG16 = IO16;
+    constexpr int WP = 40;                                      // halfwords between tile rows: 80 B -> conflict-free ds_read_b128
+    constexpr int WAVE_FLOATS = WG16 ? CA * PWB_LD + ((32 + 64 + 32) * WP) / 2 : rowsG * PWB_LD + (DMA ? 2 : 1) * XS + rowsP * PWB_LD;
     float *G = lds + (size_t)wave * WAVE_FLOATS;                // [o][v]
-    float *X = G + rowsG * PWB_LD;                              // [i][v] (DMA: two slots of [i / 2][i & 1][v])
+    float *X = WG16 ? G : G + rowsG * PWB_LD;                   // [i][v] (DMA: two slots of [i / 2][i & 1][v]; WG16: the xa rows only)
     float *P = X + (DMA ? 2 : 1) * XS;                          // [o][v] of the branch (BR only)
+    pw_u16 *G16 = reinterpret_cast<pw_u16 *>(G + CA * PWB_LD), *X16 = G16 + 32 * WP, *P16 = X16 + 64 * WP;      // (WG16) [row][voxel] bf16
     float wbr[BR ? RA : 1];   // A operand of the branch dgrad: Wbr^T[row = i][k-slot ks -> channel (ks & 3) + 8 (ks >> 2) + 4 h]
     if (BR) {
 #pragma unroll
@@ -887,6 +894,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && COUT <= 48) ? 2 : 1) void pwco
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NTI; ++n) dw[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x16 dw16[WG16 ? 3 : 1];      // (WG16) dW columns 0..31, dW columns 32..63, dWbr: rows o = (r & 3) + 8 (r >> 2) + 4 h, column lane & 31
+#pragma unroll
+    for (int t_ = 0; t_ < (WG16 ? 3 : 1); ++t_)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dw16[t_][r] = 0.f;
+    static_assert(!WG16 || (COUT <= 32 && CIN <= 64 && CA <= 32 && CA + 32 <= 64), "one 32-row A tile, two 32-column B tiles");
     // branch-free activation derivatives from the saved outputs: act'(y) = (y > 0 or linear) ? dp : y + dq
     const float dp = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f, dq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
     const bool lin = a.act == HNO_ACT_NONE;
@@ -994,10 +1007,22 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && COUT <= 48) ? 2 : 1) void pwco
             const float pgv = IO16 ? widen(pg[ks]) : pg[ks], pyv = IO16 ? widen(py[ks]) : py[ks];
             const float gv = pgv * ((lin || pyv > 0.f) ? dp : pyv + dq);
             g[ks] = vin ? gv : 0.f;
-            G[(2 * ks + h) * PWB_LD + c] = g[ks];
+            if constexpr (WG16) G16[(2 * ks + h) * WP + c] = f32_to_bf16_bits(g[ks]);
+            else G[(2 * ks + h) * PWB_LD + c] = g[ks];
             db[ks] += g[ks];
         }
-        if constexpr (!DMA) {
+        if constexpr (WG16) {
+#pragma unroll
+            for (int j = 0; j < NKI; ++j) {
+                if (2 * j < CA) {      // xa row (fp32): kept for its activation derivative, rounded for the weight gradient
+                    const float xv_ = vin ? px[j] : 0.f;
+                    X[(2 * j + h) * PWB_LD + c] = xv_;
+                    X16[(2 * j + h) * WP + c] = f32_to_bf16_bits(xv_);
+                } else {               // xb row: the prefetch register holds the bf16 bits as they lie in memory
+                    X16[(2 * j + h) * WP + c] = vin ? (pw_u16)__builtin_bit_cast(unsigned, px[j]) : (pw_u16)0;
+                }
+            }
+        } else if constexpr (!DMA) {
 #pragma unroll
             for (int j = 0; j < NKI; ++j) X[(2 * j + h) * PWB_LD + c] = vin ? ((IO16 && 2 * j >= CA) ? widen(px[j]) : px[j]) : 0.f;
         }
@@ -1033,7 +1058,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && COUT <= 48) ? 2 : 1) void pwco
                     }
                     if (BR && irow < CA) {   // p: B operand of the branch dgrad (k-slot r), A operand of its weight gradient
                         acc[r] = gv;
-                        P[(irow + 4 * h) * PWB_LD + c] = gv;
+                        if constexpr (WG16) P16[(irow + 4 * h) * WP + c] = f32_to_bf16_bits(vin ? gv : 0.f);
+                        else P[(irow + 4 * h) * PWB_LD + c] = gv;
                         dbb[r < RA ? r : 0] += gv;
                     }
                     if (BR && irow >= CA) gv += acc2[(r + 16 * ic - RA) & 15];
@@ -1122,7 +1148,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && COUT <= 48) ? 2 : 1) void pwco
                         float gv = acc[r];
                         if (xact) gv *= xo[r] > 0.f ? xp : xo[r] + xq;
                         acc[r] = gv;
-                        P[(irow + 4 * h) * PWB_LD + c] = gv;
+                        if constexpr (WG16) P16[(irow + 4 * h) * WP + c] = f32_to_bf16_bits(gv);
+                        else P[(irow + 4 * h) * PWB_LD + c] = gv;
                         dbb[r] += gv;
                         ga_l[(size_t)irow * V] = gv;
                     }
@@ -1170,6 +1197,21 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && COUT <= 48) ? 2 : 1) void pwco
         // has to be kept from reordering the reads above the writes
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if constexpr (WG16) {
+            // dW[o][i] += sum_v g[o][v] x[i][v]: A = rows of G16 (o = lane & 31), B = rows of X16 (i = lane & 31 (+ 32)), eight voxels
+            // 8 h + j (+ 16 per k-step) per lane; dWbr[o][i] += sum_v p[o][v] xb[i][v] with the xb rows starting at row CA of X16
+            const pw_u16 *ga16 = G16 + c * WP + 8 * h, *pa16 = P16 + c * WP + 8 * h;
+            const pw_u16 *x0 = X16 + c * WP + 8 * h, *x1 = X16 + (32 + c) * WP + 8 * h, *xbr = X16 + (CA + c) * WP + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < ((a.dbg & 2) ? 0 : 2); ++ks) {
+                const pw_bf16x8 av = *reinterpret_cast<const pw_bf16x8 *>(ga16 + 16 * ks), pv = *reinterpret_cast<const pw_bf16x8 *>(pa16 + 16 * ks);
+                const pw_bf16x8 b0 = *reinterpret_cast<const pw_bf16x8 *>(x0 + 16 * ks), b1 = *reinterpret_cast<const pw_bf16x8 *>(x1 + 16 * ks);
+                const pw_bf16x8 bb = *reinterpret_cast<const pw_bf16x8 *>(xbr + 16 * ks);
+                dw16[0] = mfma_bf(av, b0, dw16[0]);
+                dw16[1] = mfma_bf(av, b1, dw16[1]);
+                dw16[2] = mfma_bf(pv, bb, dw16[2]);
+            }
+        } else
 #pragma unroll 2
         for (int ks = 0; ks < ((a.dbg & 2) ? 0 : 8); ++ks) {
             float av[MT], bv[NTI];
@@ -1200,7 +1242,24 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && COUT <= 48) ? 2 : 1) void pwco
         constexpr int n = COUT * CIN + COUT + (BR ? CA * CB + CA : 0);
         __syncthreads();
         float *mine = lds + (size_t)wave * n;
-        if (BR) {   // slab tail: dWbr [o][i], dbbr [o]
+        if constexpr (WG16) {
+            float *mb = mine + COUT * CIN + COUT;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (o < COUT) {
+                    mine[o * CIN + c] = dw16[0][r];
+                    if (32 + c < CIN) mine[o * CIN + 32 + c] = dw16[1][r];
+                }
+                if (o < CA && c < CB) mb[o * CB + c] = dw16[2][r];
+            }
+#pragma unroll
+            for (int ks = 0; ks < RA; ++ks) {
+                float sb = dbb[ks];
+                for (int off2 = 16; off2 >= 1; off2 >>= 1) sb += __shfl_xor(sb, off2);
+                if (c == 0) mb[CA * CB + (ks & 3) + 8 * (ks >> 2) + 4 * h] = sb;
+            }
+        } else if (BR) {   // slab tail: dWbr [o][i], dbbr [o]
             float *mb = mine + COUT * CIN + COUT;
 #pragma unroll
             for (int m = 0; m < MTP; ++m)
@@ -1218,6 +1277,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && COUT <= 48) ? 2 : 1) void pwco
                 if (c == 0) mb[CA * CB + (ks & 3) + 8 * (ks >> 2) + 4 * h] = sb;
             }
         }
+        if constexpr (!WG16) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -1227,6 +1287,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && COUT <= 48) ? 2 : 1) void pwco
                     const int o = m * 16 + (lane >> 4) * 4 + r, i = nn * 16 + (lane & 15);
                     if (o < COUT && i < CIN) mine[o * CIN + i] = dw[m][nn][r];
                 }
+        }
 #pragma unroll
         for (int ks = 0; ks < NKO; ++ks) {
             float s = db[ks];

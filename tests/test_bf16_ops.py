@@ -301,7 +301,24 @@ def test_block_tail_with_bf16_tensors_equals_fp32_storage():
     r32 = ops.pwconv_bwd_branch_raw(g, o32, y32, x, W, Wbr, act, act, bf16=True)
     r16 = ops.pwconv_bwd_branch_raw(g16, o16, y16, x16, W, Wbr, act, act, bf16=True, io16=True)
     for name, a32, a16 in zip(('p', 'g_x', 'dW', 'db', 'dWbr', 'dbbr'), r32, r16):
-        assert a16.dtype == torch.float32 and torch.equal(a32, a16), name
+        assert a16.dtype == torch.float32
+        if name in ('dW', 'dWbr'):
+            # the bf16-storage kernel forms the weight gradients from bf16-rounded operands on the bf16 matrix cores with fp32
+            # accumulation -- what autocast does to the convolutions' weight gradients; held against float64 on the rounded operands
+            continue
+        assert torch.equal(a32, a16), name
+    p32, gx32, dW32, _, dWbr32, _ = r32
+    V = N ** 3
+    flat = lambda t: t.as_strided((B, t.shape[1], V), (t.shape[1] * ld, ld, 1)).double()
+    # g1 = g * act'(out); dW = sum_v g1 [y ; x]^T;  dWbr = sum_v p x^T  -- operands rounded to bf16 as the kernel rounds them
+    o64, g64 = flat(o32), flat(g)
+    g1 = (g64 * torch.where(o64 > 0, torch.full_like(o64, 1.0507009873554805), o64 + 1.0507009873554805 * 1.6732632423543772)).float().bfloat16().double()
+    yx = torch.cat([flat(y32).float().bfloat16().double(), flat(x)], dim=1)
+    dW_ref = torch.einsum('bov,biv->oi', g1, yx)
+    dWbr_ref = torch.einsum('bov,biv->oi', flat(p32).float().bfloat16().double(), flat(x))
+    assert rel_err(r16[2].cpu().numpy(), dW_ref.cpu().numpy()) < 1e-4
+    assert rel_err(r16[4].cpu().numpy(), dWbr_ref.cpu().numpy()) < 1e-4
+    assert rel_err(r16[2].cpu().numpy(), dW32.cpu().numpy()) < 1e-2 and rel_err(r16[4].cpu().numpy(), dWbr32.cpu().numpy()) < 1e-2
     # misuse fails loudly: bf16 tensors without bf16 arithmetic
     rc = L.hno_pwconv_fwd_branch(ptr(s), ptr(x16), ptr(Wbr), ptr(bbr), ptr(W), ptr(b), ptr(y16), ptr(o16), B, 24, 24, 24, ld, act | ops.ACT_IO16,
                                  stream_ptr())
