@@ -240,9 +240,11 @@ class CapturedStep:
     128^3: 3.4 ms eager, 2.65 ms replayed).  A shape is captured on its SECOND occurrence (the first runs eagerly: it creates the
     twiddle tables and kernel attributes, which cannot be captured); at most `max_shapes` shapes are kept (the ragged last batch of
     an epoch then simply runs eagerly).  After a replay every parameter's ``.grad`` is the buffer the graph wrote, whatever eager
-    steps did in between.  Not used with autocast (GradScaler's inf checks synchronise) or on CPU tensors."""
+    steps did in between.  Autocast runs (round 6): forward + loss + scaled backward are replayed, GradScaler's step / update (their inf check
+    synchronises) stay eager behind the replay.  Not used on CPU tensors."""
 
-    def __init__(self, model, loss_fn, num_labels, label_mapping=None, data_parallel=None, max_shapes=2, optimizer=None, bucketed=None):
+    def __init__(self, model, loss_fn, num_labels, label_mapping=None, data_parallel=None, max_shapes=2, optimizer=None, bucketed=None,
+                 autocast=None, scaler=None):
         """optimizer: a device-stepped optim.Adamax (``optimizer.device_stepped(scheduler)``): its update (and the scheduler's step)
         is captured behind backward -- and behind the gradient all-reduce, which is then captured too -- so a step of a rank is ONE
         graph replay; ``steps_optimizer`` tells the caller not to step again.
@@ -251,6 +253,13 @@ class CapturedStep:
         the default is the measured form -- replay, then one eager flat all-reduce, then the eager Adamax launch."""
         self.model, self.loss_fn, self.num_labels, self.label_mapping = model, loss_fn, num_labels, label_mapping
         self.dp, self.max_shapes = data_parallel, max_shapes
+        # autocast (round 6): a callable returning the autocast context (training(use_autocast=True)) -- forward and loss are captured
+        # inside it, and the backward starts from scaler.scale(loss) (the scale is a device tensor the scaler updates in place, so every
+        # replay reads the current one).  scaler.step() / update() stay eager behind the replay: their inf check is a host
+        # synchronisation, which is why round 3 left autocast runs eager altogether (FNOSeg cfg3: 7.6 ms eager, 5.2 ms replayed).
+        self.autocast, self.scaler = autocast, scaler
+        if autocast is not None:
+            optimizer = None                 # the update belongs to scaler.step()
         self.optimizer = optimizer if (optimizer is not None and getattr(optimizer, 'is_device_stepped', False)) else None
         env = os.environ.get('HNO_DP_CAPTURE_ALLREDUCE', '')
         multi_rank = data_parallel is not None and getattr(data_parallel, 'real_world', 1) > 1
@@ -279,9 +288,10 @@ class CapturedStep:
         if use_split:
             return self.split.fwd_bwd(xs, lab, self.loss_fn, zero_grad=self.dp.zero_grad if self.dp is not None else None,
                                       keep_outputs=self.keep_outputs)
-        with ops.expected_loss(lab, self.loss_fn):       # the head takes the loss sums in its own pass
-            y_pred = self.model(xs)
-        loss = self.loss_fn(y_pred, lab)
+        with (self.autocast() if self.autocast is not None else contextlib.nullcontext()):
+            with ops.expected_loss(lab, self.loss_fn):       # the head takes the loss sums in its own pass
+                y_pred = self.model(xs)
+            loss = self.loss_fn(y_pred, lab)
         if self.keep_outputs:
             self.outputs = [y_pred.detach()]
         if self.dp is not None:
@@ -289,13 +299,17 @@ class CapturedStep:
         else:
             for p in self.params:
                 p.grad = None
-        ops.backward_from(loss)
+        if self.scaler is not None:
+            self.scaler.scale(loss).backward()      # reference train_test.py:166
+        else:
+            ops.backward_from(loss)
         return loss.detach()
 
     def _capture(self, x, y):
         from .. import ops
         xs, ys = x.clone(), y.clone()
-        mode = False if self.bucketed else SampleSplit.candidate(self.model, self.loss_fn, xs)      # (the twin's gradients bypass the hooks)
+        # (bucketed: the twin's gradients bypass the hooks; autocast: one scaled loss starts the backward)
+        mode = False if (self.bucketed or self.autocast is not None) else SampleSplit.candidate(self.model, self.loss_fn, xs)
         if mode:
             # the twin, its constants and the half-batch shapes' tables / kernel attributes exist BEFORE the capture (none of it is
             # capturable; round 4 built the twin inside the capture: its copies were replayed with every step -- ADVICE round 4)
@@ -443,7 +457,7 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
     """Trains a model; see the reference docstring (train_test.py:48-71).  `data_parallel` is an optional
     parallel.FlatGradReplica for one-process-per-GPU training (not in the reference).  `use_graph` (not in the reference): replay
     forward + loss + backward of recurring batch shapes from a HIP graph (CapturedStep); None = on for this package's model families on
-    CUDA without autocast (HNO_TRAIN_GRAPH=0 switches it off); the same kernels either way.  What changes with replay (logged once per
+    CUDA (HNO_TRAIN_GRAPH=0 switches it off; autocast runs since round 6: HNO_TRAIN_GRAPH_AUTOCAST=0 keeps those eager); the same kernels either way.  What changes with replay (logged once per
     captured shape): forward / backward hooks and any host-side logic inside the model or loss_fn do not run in replayed steps; each
     captured shape (at most 2) keeps a private graph memory pool plus input / staging buffers for the rest of training, which eager
     validation cannot reuse (a model close to the memory limit may prefer use_graph=False); under data_parallel the per-bucket
@@ -529,7 +543,10 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
         from ..nets.architectures import NeuralOperatorSeg, HartleyMHASeg, VNetDS
         use_graph = os.environ.get('HNO_TRAIN_GRAPH', '1') != '0' and isinstance(model, (HNOSegXS, NeuralOperatorSeg, HartleyMHASeg, VNetDS))
     captured, entered_dev_opt = None, False
-    if use_graph and not use_autocast and next(model.parameters()).is_cuda:
+    if use_graph and use_autocast and next(model.parameters()).is_cuda and os.environ.get('HNO_TRAIN_GRAPH_AUTOCAST', '1') != '0':
+        # round 6: forward + loss + scaled backward of an autocast run replayed from a graph; scaler.step() / update() eager behind it
+        captured = CapturedStep(model, loss_fn, num_labels, label_mapping, data_parallel if world > 1 else None, autocast=autocast, scaler=scaler)
+    elif use_graph and not use_autocast and next(model.parameters()).is_cuda:
         # our Adamax moves its step counter, the learning rate and the per-batch cosine schedule onto the device, so that the update
         # is part of the captured step (HNO_TRAIN_GRAPH_OPT=0: keep optimizer and scheduler eager behind the replay)
         if os.environ.get('HNO_TRAIN_GRAPH_OPT', '1') != '0' and hasattr(optimizer, 'device_stepped') and not optimizer.is_device_stepped:
@@ -549,7 +566,10 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
                 if loss is not None:          # forward + loss + backward replayed; gradients (reduced over ranks) are in place
                     step_stats['replayed'] += 1
                     losses.append(loss.detach().clone())
-                    if not captured.steps_optimizer:
+                    if scaler is not None:               # unscale, inf check (the step's one host synchronisation), update, new scale
+                        scaler.step(optimizer)
+                        scaler.update()
+                    elif not captured.steps_optimizer:
                         optimizer.step()
                     if scheduler is not None and not dev_opt:
                         scheduler.step()

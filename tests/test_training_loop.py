@@ -243,17 +243,28 @@ def test_training_with_autocast_and_grad_scaler(tmp_path):
                                                        (torch.arange(16 ** 3).reshape(1, 16, 16, 16) % 3).float()))
         return model, opt, data
     losses = {}
-    for tag, ac in (('bf16', True), ('f32', False)):
+    for tag, ac in (('bf16', True), ('f32', False), ('bf16_eager', True)):
         model, opt, data = make()
         out = tmp_path / tag
-        tt.training(model, data, str(out), custom_losses.DiceLoss(), opt, None, num_epochs=4, selection_epoch_portion=0.5,
-                    checkpoint_epoch=2, is_print=False, use_autocast=ac, device='cuda')
+        # round 6: autocast runs replay forward + loss + scaled backward from a HIP graph too (GradScaler's step / update eager behind
+        # the replay); HNO_TRAIN_GRAPH_AUTOCAST=0 keeps them eager as rounds 3-5 did
+        if tag == 'bf16_eager':
+            os.environ['HNO_TRAIN_GRAPH_AUTOCAST'] = '0'
+        tt.step_stats.update(replayed=0, eager=0)
+        try:
+            tt.training(model, data, str(out), custom_losses.DiceLoss(), opt, None, num_epochs=4, selection_epoch_portion=0.5,
+                        checkpoint_epoch=2, is_print=False, use_autocast=ac, device='cuda')
+        finally:
+            os.environ.pop('HNO_TRAIN_GRAPH_AUTOCAST', None)
+        assert (tt.step_stats['replayed'] > 0) == (tag != 'bf16_eager'), dict(tt.step_stats)
         tl, vl = tt.get_losses_from_file(os.path.join(out, 'stdout.txt'))
         losses[tag] = tl
         ck = torch.load(os.path.join(out, 'model', 'checkpoint.pt'), weights_only=False)
         assert ('scaler_state_dict' in ck) == ac
         assert all(np.isfinite(tl)) and tl[-1] < tl[0]
     assert np.abs(np.array(losses['bf16']) - np.array(losses['f32'])).max() < 2e-2
+    # the replayed autocast run follows the eager autocast run (same kernels, same scaler trajectory)
+    assert np.abs(np.array(losses['bf16']) - np.array(losses['bf16_eager'])).max() < 1e-5, (losses['bf16'], losses['bf16_eager'])
     # resume an autocast run: the scaler state is restored with the rest of the checkpoint
     model, opt, data = make()
     tt.training(model, data, str(tmp_path / 'bf16'), custom_losses.DiceLoss(), opt, None, num_epochs=6, selection_epoch_portion=0.5,
