@@ -325,6 +325,15 @@ int hno_conv3d_k3(const float *x, const float *W, const float *bias, float *y, v
                   int act, void *stream);
 int hno_conv3d_k3_wgrad(const float *g, const float *x, float *dW, void *workspace, int transposed, int B, int Cin, int Cout,
                         int Dx, int Hx, int Wx, int Dg, int Hg, int Wg, int stride, int pad, void *stream);
+/* Convolutions of V-Net-DS with ANY odd kernel size (the reference's `kernel_size` constructor argument, nets/architectures.py:55-70):
+ * direct (untuned) kernels behind the same mode numbers as hno_conv3d_k3 -- 0 Conv3d forward (W (Cout, Cin, k, k, k), stride 1 'same' or
+ * stride 2 padding k / 2), 1 its input gradient, 2 ConvTranspose3d forward (W (Cin, Cout, k, k, k), stride 2, padding k / 2,
+ * output_padding 1), 3 its input gradient; (Di, Hi, Wi) / (Do, Ho, Wo) are the sizes of the tensor read / written.  hno_convk_wgrad
+ * writes dW in the weight's layout; bias gradients are hno_channel_sum.  k = 3 runs the implicit-GEMM kernels above. */
+int hno_convk(const float *x, const float *W, const float *bias, float *y, int mode, int B, int Cin, int Cout, int Di, int Hi, int Wi,
+              int Do, int Ho, int Wo, int k, int stride, int pad, void *stream);
+int hno_convk_wgrad(const float *g, const float *x, float *dW, int transposed, int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do,
+                    int Ho, int Wo, int k, int stride, int pad, void *stream);
 /* GroupNorm(1, C) + activation (nn.GroupNorm(1, C) after every V-Net conv, nets/nets_utils.py:165-170).
  * fwd saves mean_rstd (B,2); stats_ws: 2*B doubles.  bwd: sums_ws 2*B*C doubles, coef_ws 2*B floats. */
 int hno_groupnorm1_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean_rstd, double *stats_ws,

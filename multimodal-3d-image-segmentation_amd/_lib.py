@@ -80,6 +80,8 @@ SIGNATURES = {
     'hno_conv3d_k3_fwd_workspace_bytes': (c_size_t, [c_int] * 7),
     'hno_conv3d_k3': (c_int, [c_void_p] * 5 + [c_size_t] + [c_int] * 13 + [c_void_p]),
     'hno_conv3d_k3_wgrad': (c_int, [c_void_p] * 4 + [c_int] * 12 + [c_void_p]),
+    'hno_convk': (c_int, [c_void_p] * 4 + [c_int] * 13 + [c_void_p]),
+    'hno_convk_wgrad': (c_int, [c_void_p] * 3 + [c_int] * 13 + [c_void_p]),
     'hno_groupnorm1_fwd': (c_int, [c_void_p] * 6 + [c_int, c_int, c_ll, c_float, c_int, c_void_p]),
     'hno_groupnorm1_bwd': (c_int, [c_void_p] * 10 + [c_int, c_int, c_ll, c_int, c_void_p]),
     'hno_nearest3d': (c_int, [c_void_p] * 2 + [c_int] * 9 + [c_void_p]),

@@ -932,3 +932,119 @@ extern "C" int hno_channel_sum(const float *g, float *out, void *workspace, int 
     }
     return HNO_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Convolutions with ANY odd kernel size (round 6).  The reference's V-Net-DS takes `kernel_size` as a constructor argument
+// (nets/architectures.py:55-70, :105-155: nn.Conv3d(k, stride 1 'same' | stride 2 padding k // 2), nn.ConvTranspose3d(k, stride 2,
+// padding k // 2, output_padding 1)); the implicit-GEMM kernels above are built for 3 x 3 x 3, other sizes used to raise.  These are
+// the direct forms -- one thread per output element, one workgroup per weight-gradient element: correct for every size, not tuned
+// (the BASELINE configurations never reach them) -- so that a model the reference accepts is a model this package runs on the GPU.
+//   gather (hno_convk):  out[b, co, o] = bias[co] + sum_ci sum_t W[co * s_co + ci * s_ci][t] in[b, ci, idx(o, t)]
+//     frac 0: idx = stride * o - pad + t;   frac 1: idx = (o + pad - t) / stride where that is a whole number
+//   weight gradient (hno_convk_wgrad):  dW[cg][cx][t] = sum_b sum_o G[b, cg, o] X[b, cx, stride * o - pad + t]
+namespace hno {
+struct CkArgs {
+    const float *in, *W, *bias;
+    float *out;
+    int B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, k, stride, pad, frac, s_co, s_ci;
+};
+
+__global__ __launch_bounds__(256) void convk_gather_kernel(CkArgs a) {
+    const long long Vo = (long long)a.Do * a.Ho * a.Wo, n = (long long)a.B * a.Cout * Vo;
+    const int K3 = a.k * a.k * a.k;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const long long v = e % Vo, bc = e / Vo;
+        const int co = (int)(bc % a.Cout), b = (int)(bc / a.Cout);
+        const int ow = (int)(v % a.Wo), oh = (int)((v / a.Wo) % a.Ho), od = (int)(v / ((long long)a.Wo * a.Ho));
+        float acc = a.bias ? a.bias[co] : 0.f;
+        for (int td = 0; td < a.k; ++td) {
+            int zi = a.frac ? od + a.pad - td : a.stride * od - a.pad + td;
+            if (a.frac) { if (zi < 0 || zi % a.stride) continue; zi /= a.stride; }
+            if (zi < 0 || zi >= a.Di) continue;
+            for (int th = 0; th < a.k; ++th) {
+                int yi = a.frac ? oh + a.pad - th : a.stride * oh - a.pad + th;
+                if (a.frac) { if (yi < 0 || yi % a.stride) continue; yi /= a.stride; }
+                if (yi < 0 || yi >= a.Hi) continue;
+                for (int tw = 0; tw < a.k; ++tw) {
+                    int xi = a.frac ? ow + a.pad - tw : a.stride * ow - a.pad + tw;
+                    if (a.frac) { if (xi < 0 || xi % a.stride) continue; xi /= a.stride; }
+                    if (xi < 0 || xi >= a.Wi) continue;
+                    const int t = (td * a.k + th) * a.k + tw;
+                    const float *ip = a.in + (((size_t)b * a.Cin) * a.Di + zi) * a.Hi * a.Wi + (size_t)yi * a.Wi + xi;
+                    const float *wp = a.W + ((size_t)co * a.s_co) * K3 + t;
+                    const size_t istr = (size_t)a.Di * a.Hi * a.Wi, wstr = (size_t)a.s_ci * K3;
+                    for (int ci = 0; ci < a.Cin; ++ci) acc = fmaf(wp[ci * wstr], ip[ci * istr], acc);
+                }
+            }
+        }
+        a.out[e] = acc;
+    }
+}
+
+// one workgroup per (cg, cx, tap); fixed-order tree over the threads' partial sums: bit-reproducible
+__global__ __launch_bounds__(256) void convk_wgrad_kernel(const float *__restrict__ G, const float *__restrict__ X, float *__restrict__ dW,
+                                                          int B, int Cg, int Cx, int Dg, int Hg, int Wg, int Dx, int Hx, int Wx, int k,
+                                                          int stride, int pad) {
+    __shared__ float red[256];
+    const int K3 = k * k * k;
+    const int t = blockIdx.x % K3, cx = (blockIdx.x / K3) % Cx, cg = blockIdx.x / (K3 * Cx);
+    const int td = t / (k * k), th = (t / k) % k, tw = t % k;
+    const long long Vg = (long long)Dg * Hg * Wg, n = (long long)B * Vg;
+    float acc = 0.f;
+    for (long long e = threadIdx.x; e < n; e += 256) {
+        const int b = (int)(e / Vg);
+        const long long v = e - (long long)b * Vg;
+        const int ow = (int)(v % Wg), oh = (int)((v / Wg) % Hg), od = (int)(v / ((long long)Wg * Hg));
+        const int zi = stride * od - pad + td, yi = stride * oh - pad + th, xi = stride * ow - pad + tw;
+        if (zi < 0 || zi >= Dx || yi < 0 || yi >= Hx || xi < 0 || xi >= Wx) continue;
+        acc = fmaf(G[((size_t)b * Cg + cg) * Vg + v], X[(((size_t)b * Cx + cx) * Dx + zi) * Hx * Wx + (size_t)yi * Wx + xi], acc);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dW[((size_t)cg * Cx + cx) * K3 + t] = red[0];
+}
+}  // namespace hno
+
+// mode as hno_conv3d_k3: 0 = Conv3d forward (W (Cout, Cin, k, k, k)), 1 = its input gradient (x := gy, y := gx), 2 = ConvTranspose3d
+// forward (W (Cin, Cout, k, k, k), stride 2), 3 = its input gradient.  (Di, Hi, Wi) / (Do, Ho, Wo): sizes of the tensor read / written.
+extern "C" int hno_convk(const float *x, const float *W, const float *bias, float *y, int mode, int B, int Cin, int Cout, int Di, int Hi,
+                         int Wi, int Do, int Ho, int Wo, int k, int stride, int pad, void *stream) {
+    HNO_REQUIRE(x && W && y && B > 0 && Cin > 0 && Cout > 0 && k >= 1 && (k & 1) && mode >= 0 && mode <= 3 && (stride == 1 || stride == 2) && pad >= 0,
+                "hno_convk: bad argument (odd kernel sizes, stride 1 or 2)");
+    if ((long long)B * (Cin > Cout ? Cin : Cout) * Di * Hi * Wi >= (1ll << 40)) return fail(HNO_ELIMIT, "hno_convk: tensor too large");
+    CkArgs a;
+    a.in = x; a.W = W; a.bias = bias; a.out = y; a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
+    a.k = k; a.stride = stride; a.pad = pad;
+    // channel roles of the gather and the weight strides (in units of k^3) for the stored tensor
+    if (mode == 0) { a.Cin = Cin; a.Cout = Cout; a.frac = 0; a.s_co = Cin; a.s_ci = 1; }            // W[co][ci]
+    else if (mode == 1) { a.Cin = Cout; a.Cout = Cin; a.frac = 1; a.s_co = 1; a.s_ci = Cin; }        // gx[ci] = sum_co W[co][ci] gy[co]
+    else if (mode == 2) { a.Cin = Cin; a.Cout = Cout; a.frac = 1; a.s_co = 1; a.s_ci = Cout; }       // y[co] = sum_ci Wt[ci][co] x[ci]
+    else { a.Cin = Cout; a.Cout = Cin; a.frac = 0; a.s_co = Cout; a.s_ci = 1; }                      // gx[ci] = sum_co Wt[ci][co] gy[co]
+    const long long n = (long long)B * a.Cout * Do * Ho * Wo;
+    long long grid = (n + 255) / 256;
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(convk_gather_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+// dW in the weight's own layout.  transposed 0: Conv3d -- g (B, Cout, Do..) strided side, x (B, Cin, Di..) dense side, dW (Cout, Cin, k^3);
+// transposed 1: ConvTranspose3d -- x (B, Cin, Di..) is the strided side, g (B, Cout, Do..) the dense one, dW (Cin, Cout, k^3).
+extern "C" int hno_convk_wgrad(const float *g, const float *x, float *dW, int transposed, int B, int Cin, int Cout, int Di, int Hi, int Wi,
+                               int Do, int Ho, int Wo, int k, int stride, int pad, void *stream) {
+    HNO_REQUIRE(g && x && dW && B > 0 && Cin > 0 && Cout > 0 && k >= 1 && (k & 1) && (stride == 1 || stride == 2), "hno_convk_wgrad: bad argument");
+    const long long blocks = (long long)Cin * Cout * k * k * k;
+    if (blocks >= (1ll << 31)) return fail(HNO_ELIMIT, "hno_convk_wgrad: %lld weight elements", blocks);
+    if (!transposed)
+        hipLaunchKernelGGL(convk_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, x, dW, B, Cout, Cin, Do, Ho, Wo, Di, Hi, Wi, k,
+                           stride, pad);
+    else
+        hipLaunchKernelGGL(convk_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, g, dW, B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, k,
+                           stride, pad);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}

@@ -290,6 +290,7 @@ class VNetDS(nn.Module):
         assert isinstance(num_blocks, (list, tuple))
         self.in_channels, self.out_channels, self.num_blocks = in_channels, out_channels, num_blocks
         self.base_num_filters = base_num_filters
+        self.kernel_size = kernel_size
         self.use_resize, self.right_leg_indexes = use_resize, right_leg_indexes
         self.output_activation, self.use_residual, self.ndim = output_activation, use_residual, ndim
         if self.right_leg_indexes is None:
@@ -364,9 +365,8 @@ class VNetDS(nn.Module):
         from .. import ops_bf16
         # bf16 matrix-core path under autocast when every hidden channel count (base_num_filters 2^k) is a multiple of 8 -- the bf16
         # kernels' fragment width; other widths run the fp32 kernels (still on the GPU: autocast only ever lowers precision)
-        if ops_bf16.autocast_bf16() and self.base_num_filters % 8 == 0:
-            if x.ndim == 4:
-                raise NotImplementedError('the bf16 (autocast) path of V-Net-DS is 3-D only')
+        # (a 2-D model -- ndim = 4, Conv2d containers -- and kernel sizes other than 3 keep the fp32 kernels under autocast: round 6)
+        if ops_bf16.autocast_bf16() and self.base_num_filters % 8 == 0 and self.ndim == 5 and x.ndim == 5 and self.kernel_size == 3:
             return self._forward_bf16(x)
         if x.ndim == 4:   # 2-D model (ndim = 4): the same kernels on a (B, C, 1, H, W) view (see nets/conv3d.py for the 3x3 layers)
             return self.forward(x.unsqueeze(2)).squeeze(2)

@@ -1067,6 +1067,54 @@ class ConvT3dK3Fn(_HnoFunction):
         return gx, dW, (_chan_sum(g) if ctx.has_bias else None)
 
 
+class ConvKFn(_HnoFunction):
+    """nn.Conv3d / nn.ConvTranspose3d of ConvNormAct / ConvTransposeNormAct (nets/nets_utils.py:136-211) with ANY odd kernel size
+    (round 6: the reference's V-Net-DS takes ``kernel_size``, nets/architectures.py:55-70): the direct kernels hno_convk /
+    hno_convk_wgrad.  stride 1 ('same') or 2 with padding k // 2; the transposed form is stride 2, padding k // 2, output_padding 1."""
+
+    @staticmethod
+    def _osz(spatial, stride, transposed):
+        return tuple(2 * v for v in spatial) if transposed else tuple((v - 1) // stride + 1 for v in spatial)
+
+    @staticmethod
+    def meta(x, W, bias, stride, transposed):
+        return _m((x.shape[0], W.shape[1] if transposed else W.shape[0]) + ConvKFn._osz(tuple(x.shape[2:]), stride, transposed))
+
+    @staticmethod
+    def forward(ctx, x, W, bias, stride, transposed):
+        x, W, bias = _f32c(x), _f32c(W), _f32c(bias)
+        _need_gpu(x, W, bias)
+        k = int(W.shape[2])
+        assert tuple(W.shape[2:]) == (k, k, k) and k % 2 == 1, 'cubic kernels of odd size'
+        B, Cin = x.shape[:2]
+        Cout = W.shape[1] if transposed else W.shape[0]
+        osz = ConvKFn._osz(tuple(x.shape[2:]), stride, transposed)
+        y = torch.empty((B, Cout) + osz, device=x.device, dtype=torch.float32)
+        check(_lib.lib().hno_convk(ptr(x), ptr(W), ptr(bias), ptr(y), 2 if transposed else 0, B, Cin, Cout, *x.shape[2:], *osz, k,
+                                   2 if transposed else stride, k // 2, stream_ptr()), 'hno_convk')
+        ctx.save_for_backward(x, W)
+        ctx.cfg = (k, stride, bool(transposed), bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        k, stride, transposed, has_bias = ctx.cfg
+        g = _f32c(g)
+        B, Cin = x.shape[:2]
+        Cout = W.shape[1] if transposed else W.shape[0]
+        L, st = _lib.lib(), 2 if transposed else stride
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            check(L.hno_convk(ptr(g), ptr(W), None, ptr(gx), 3 if transposed else 1, B, Cin, Cout, *g.shape[2:], *x.shape[2:], k, st, k // 2,
+                              stream_ptr()), 'hno_convk')
+        dW = torch.empty_like(W)
+        check(L.hno_convk_wgrad(ptr(g), ptr(x), ptr(dW), 1 if transposed else 0, B, Cin, Cout, *x.shape[2:], *g.shape[2:], k, st, k // 2,
+                                stream_ptr()), 'hno_convk_wgrad')
+        return gx, dW, (_chan_sum(g) if has_bias else None), None, None
+
+
 class GroupNormActFn(_HnoFunction):
     """act(GroupNorm(1, C)(x)) (nets/nets_utils.py:127-133 with :165-170)."""
 

@@ -225,6 +225,9 @@ VNET_MODELS = {
                 (1, 2, 20, 24, 28)),
     'vnet_noresize_odd': (dict(in_channels=1, out_channels=2, base_num_filters=4, num_blocks=[1, 1], use_resize=False,
                                right_leg_indexes=None), (2, 1, 9, 11, 13)),
+    # round 6: the `kernel_size` constructor argument (nets/architectures.py:55-70) -- 5 x 5 x 5 section, down and transposed convolutions
+    'vnet_ds_k5': (dict(in_channels=2, out_channels=3, base_num_filters=4, num_blocks=[1, 1], right_leg_indexes=[0, 1], kernel_size=5),
+                   (1, 2, 16, 20, 24)),
 }
 
 

@@ -312,3 +312,15 @@ def test_vnet_cfg4_full_size_vs_reference_golden(pkg):
             assert d < 1.5 * ref['bf16'][0] and abs(float(loss.detach()) - float(g['f64::loss'])) < 2e-3
             assert e < min(5e-2, 1.5 * ref['bf16'][1]) and n < min(1e-2, 1.5 * ref['bf16'][2])      # (measured 2.4e-2 / 1.7e-3; the reference's CPU bf16 run: 0.71 / 0.18)
         del y, loss
+
+
+def test_vnet_2d_model_under_autocast_runs_the_fp32_kernels(pkg):
+    """A 2-D V-Net-DS (ndim = 4) under bf16 autocast used to raise; since round 6 it runs the fp32 kernels (autocast only ever lowers
+    precision): same output as without autocast."""
+    torch.manual_seed(4)
+    model = pkg.nets.VNetDS(2, 3, 8, [1, 1], right_leg_indexes=[0, 1], ndim=4).cuda()
+    x = torch.randn(2, 2, 32, 32, device='cuda')
+    y0 = model(x)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        y1 = model(x)
+    assert y1.dtype == torch.float32 and torch.equal(y0, y1)

@@ -2453,3 +2453,48 @@ def test_pwconv_qkv_projection_thirds(pkg):
         finally:
             ops.set_defer_reduce(False)
 
+
+
+@pytest.mark.parametrize('k,stride,transposed', [(5, 1, False), (5, 2, False), (5, 2, True), (7, 1, False), (1, 2, False)])
+def test_conv_any_odd_kernel_size_vs_float64(pkg, k, stride, transposed):
+    """Round 6: the reference's V-Net-DS takes `kernel_size` (nets/architectures.py:55-70); sizes other than 3 run the direct kernels
+    hno_convk / hno_convk_wgrad (ops.ConvKFn) -- output and all three gradients against torch's float64 convolution on the CPU."""
+    import torch.nn.functional as F
+    torch.manual_seed(k * 10 + stride + transposed)
+    B, Cin, Cout, sp = 2, 5, 7, (9, 8, 11)
+    x = torch.randn((B, Cin) + sp, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn((Cin, Cout, k, k, k) if transposed else (Cout, Cin, k, k, k), dtype=torch.float64) * 0.2).requires_grad_()
+    b = torch.randn(Cout, dtype=torch.float64, requires_grad=True)
+    ref = F.conv_transpose3d(x, w, b, stride=2, padding=k // 2, output_padding=1) if transposed else F.conv3d(x, w, b, stride=stride, padding=k // 2)
+    gref = torch.randn_like(ref)
+    ref.backward(gref)
+    xg, wg, bg = (t.detach().float().cuda().requires_grad_() for t in (x, w, b))
+    y = pkg.ops.ConvKFn.apply(xg, wg, bg, stride, transposed)
+    assert tuple(y.shape) == tuple(ref.shape)
+    y.backward(gref.float().cuda())
+    assert rel_err(y.detach().cpu().numpy(), ref.detach().numpy()) < 2e-6
+    for got, want in ((xg.grad, x.grad), (wg.grad, w.grad), (bg.grad, b.grad)):
+        assert rel_err(got.cpu().numpy(), want.numpy()) < 1e-5
+
+
+def test_vnet_with_kernel_size_5_vs_torch_modules(pkg):
+    """VNetDS(kernel_size=5) -- refused until round 6 -- against the same module tree evaluated by torch's own layers in float64 (state
+    dict copied over; the reference's VNetDS is this composition of nn.Conv3d / ConvTranspose3d / GroupNorm / ELU)."""
+    from multimodal_3d_image_segmentation_amd.nets import custom_losses
+    torch.manual_seed(2)
+    model = pkg.nets.VNetDS(2, 3, 4, [1, 1], right_leg_indexes=[0, 1], kernel_size=5).cuda()
+    x = torch.randn(1, 2, 16, 16, 16, device='cuda')
+    y = model(x)
+    assert tuple(y.shape) == (1, 3, 16, 16, 16) and torch.isfinite(y).all()
+    assert torch.allclose(y.sum(dim=1), torch.ones_like(y[:, 0]), atol=1e-5)
+    lab = pkg.ops.labels_prepare(torch.randint(0, 3, (1, 1, 16, 16, 16), device='cuda').float(), 3)
+    custom_losses.PCCLoss()(y, lab).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    # the k = 5 layers against F.conv3d on the model's own weights: first encoder convolution
+    layer = model.encode_layers['0'][0]
+    assert tuple(layer.op.weight.shape[2:]) == (5, 5, 5)
+    import torch.nn.functional as F
+    h = torch.randn(1, layer.op.weight.shape[1], 9, 9, 9, device='cuda')
+    got = pkg.ops.ConvKFn.apply(h, layer.op.weight, layer.op.bias, 1, False)
+    want = F.conv3d(h.double().cpu(), layer.op.weight.double().cpu(), layer.op.bias.double().cpu(), padding=2)
+    assert rel_err(got.detach().cpu().numpy(), want.detach().numpy()) < 2e-6
