@@ -1013,8 +1013,8 @@ __global__ __launch_bounds__(256) void convk_wgrad_kernel(const float *__restric
 // forward (W (Cin, Cout, k, k, k), stride 2), 3 = its input gradient.  (Di, Hi, Wi) / (Do, Ho, Wo): sizes of the tensor read / written.
 extern "C" int hno_convk(const float *x, const float *W, const float *bias, float *y, int mode, int B, int Cin, int Cout, int Di, int Hi,
                          int Wi, int Do, int Ho, int Wo, int k, int stride, int pad, void *stream) {
-    HNO_REQUIRE(x && W && y && B > 0 && Cin > 0 && Cout > 0 && k >= 1 && (k & 1) && mode >= 0 && mode <= 3 && (stride == 1 || stride == 2) && pad >= 0,
-                "hno_convk: bad argument (odd kernel sizes, stride 1 or 2)");
+    HNO_REQUIRE(x && W && y && B > 0 && Cin > 0 && Cout > 0 && k >= 1 && mode >= 0 && mode <= 3 && (stride == 1 || stride == 2) && pad >= 0,
+                "hno_convk: bad argument (stride 1 or 2)");
     if ((long long)B * (Cin > Cout ? Cin : Cout) * Di * Hi * Wi >= (1ll << 40)) return fail(HNO_ELIMIT, "hno_convk: tensor too large");
     CkArgs a;
     a.in = x; a.W = W; a.bias = bias; a.out = y; a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
@@ -1036,7 +1036,7 @@ extern "C" int hno_convk(const float *x, const float *W, const float *bias, floa
 // transposed 1: ConvTranspose3d -- x (B, Cin, Di..) is the strided side, g (B, Cout, Do..) the dense one, dW (Cin, Cout, k^3).
 extern "C" int hno_convk_wgrad(const float *g, const float *x, float *dW, int transposed, int B, int Cin, int Cout, int Di, int Hi, int Wi,
                                int Do, int Ho, int Wo, int k, int stride, int pad, void *stream) {
-    HNO_REQUIRE(g && x && dW && B > 0 && Cin > 0 && Cout > 0 && k >= 1 && (k & 1) && (stride == 1 || stride == 2), "hno_convk_wgrad: bad argument");
+    HNO_REQUIRE(g && x && dW && B > 0 && Cin > 0 && Cout > 0 && k >= 1 && (stride == 1 || stride == 2), "hno_convk_wgrad: bad argument");
     const long long blocks = (long long)Cin * Cout * k * k * k;
     if (blocks >= (1ll << 31)) return fail(HNO_ELIMIT, "hno_convk_wgrad: %lld weight elements", blocks);
     if (!transposed)

@@ -921,9 +921,14 @@ static int grid1d(size_t n) {
 
 using namespace hno;
 
+// kernels templated on the class-count bound: 4, 8, 16 or 32 registers per voxel
+#define HNO_KSEL(K, X) do { if ((K) <= 4) { X(4); } else if ((K) <= 8) { X(8); } else if ((K) <= 16) { X(16); } else { X(32); } } while (0)
+
 static int up_fill(UpArgs &a, int B, int K, int d, int h, int w, int D, int H, int W, int softmax) {
     HNO_REQUIRE(B > 0 && K > 0 && d > 0 && h > 0 && w > 0 && D > 0 && H > 0 && W > 0, "hno_upsoftmax: bad size");
-    if (K > 8) return fail(HNO_ELIMIT, "hno_upsoftmax: K=%d output channels (max 8)", K);
+    // (round 6: up to 32 classes -- the reference takes any out_channels; more than 8 run the plain voxel-form kernels, the row / separable
+    // forms of the 2 ... 8-class heads stay as they are)
+    if (K > 32) return fail(HNO_ELIMIT, "hno_upsoftmax: K=%d output channels (max 32)", K);
     a.B = B; a.K = K; a.d = d; a.h = h; a.w = w; a.D = D; a.H = H; a.W = W;
     a.sd = (float)d / (float)D; a.sh = (float)h / (float)H; a.sw = (float)w / (float)W;
     a.softmax = softmax;
@@ -989,7 +994,7 @@ extern "C" int hno_upsoftmax_fwd_ld(const float *logits_lr, float *probs, int B,
         int rpw;
         const int gx = uprows_plan(B, D, H, false, rpw);
         uprows_launch<false>(a, gx, B, (hipStream_t)stream, nullptr, nullptr);
-    } else if (items < (1ll << 31) && (long long)d * h * w < (1ll << 31) && !(debug_flags() & 16)) {
+    } else if (K <= 8 && items < (1ll << 31) && (long long)d * h * w < (1ll << 31) && !(debug_flags() & 16)) {
         long long grid = (items + 3) / 4;
         if (grid > 8192) grid = 8192;
         if (debug_grid()) grid = debug_grid();
@@ -997,8 +1002,9 @@ extern "C" int hno_upsoftmax_fwd_ld(const float *logits_lr, float *probs, int B,
         else hipLaunchKernelGGL((uphead_seg_kernel<8, false>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a, nullptr);
     } else {
         const int grid = grid1d((size_t)B * D * H * W);
-        if (K <= 4) hipLaunchKernelGGL(upsoftmax_fwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL(upsoftmax_fwd_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+#define X(KM) hipLaunchKernelGGL(upsoftmax_fwd_kernel<KM>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a)
+        HNO_KSEL(K, X);
+#undef X
     }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
@@ -1068,7 +1074,7 @@ extern "C" int hno_up_argmax_ld(const float *logits_lr, unsigned char *labels, i
     a.lr = logits_lr;
     ProfScope _ps(KID_UPSOFTMAX_FWD, (hipStream_t)stream, 4.0 * B * K * (double)d * h * w + (double)B * D * H * W);
     const long long items = (long long)B * D * H * ((W + 63) / 64);
-    if (items < (1ll << 31) && (long long)d * h * w < (1ll << 31) && !(debug_flags() & 16)) {
+    if (K <= 8 && items < (1ll << 31) && (long long)d * h * w < (1ll << 31) && !(debug_flags() & 16)) {
         long long grid = (items + 3) / 4;
         if (grid > 8192) grid = 8192;
         if (debug_grid()) grid = debug_grid();
@@ -1076,8 +1082,9 @@ extern "C" int hno_up_argmax_ld(const float *logits_lr, unsigned char *labels, i
         else hipLaunchKernelGGL((uphead_seg_kernel<8, true>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a, labels);
     } else {
         const int grid = grid1d((size_t)B * D * H * W);
-        if (K <= 4) hipLaunchKernelGGL(upargmax_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, labels);
-        else hipLaunchKernelGGL(upargmax_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, labels);
+#define X(KM) hipLaunchKernelGGL(upargmax_kernel<KM>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, labels)
+        HNO_KSEL(K, X);
+#undef X
     }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
@@ -1089,6 +1096,7 @@ extern "C" int hno_up_argmax(const float *logits_lr, unsigned char *labels, int 
 }
 
 static bool upb_separable_ok(int K, int d, int h, int w, int D, int H, int W) {
+    if (K > 8) return false;
     if (W % 4 != 0 || W > 4 * UPB_THREADS / UPB_ROWS * 2 || K * w > UPB_NC * UPB_THREADS) return false;
     if (w > W || h > H || d > D) return false;                       // taps bound assumes upsampling
     return (int)ceil(2.0 * W / w) + 3 <= UPB_MAXT && W >= UPB_MAXT;   // taps per low-res column (+ search margin)
@@ -1162,8 +1170,12 @@ static int upsoftmax_bwd_impl(const float *g_probs, const float *probs, float *g
         return HNO_OK;
     }
     const int grid = grid1d((size_t)B * d * h * w);
-    if (K <= 4) { ProfScope _ps(KID_UPSOFTMAX_BWD, s, abytes); hipLaunchKernelGGL(upsoftmax_bwd_kernel<4>, dim3(grid), dim3(256), 0, s, a); }
-    else { ProfScope _ps(KID_UPSOFTMAX_BWD, s, abytes); hipLaunchKernelGGL(upsoftmax_bwd_kernel<8>, dim3(grid), dim3(256), 0, s, a); }
+    {
+        ProfScope _ps(KID_UPSOFTMAX_BWD, s, abytes);
+#define X(KM) hipLaunchKernelGGL(upsoftmax_bwd_kernel<KM>, dim3(grid), dim3(256), 0, s, a)
+        HNO_KSEL(K, X);
+#undef X
+    }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }
@@ -1193,7 +1205,7 @@ extern "C" int hno_loss_fwd(const float *probs, const uint8_t *labels, double *s
                             int B, int K, long long V, int kind, float param, void *stream) {
     HNO_REQUIRE(probs && labels && stats && coef && loss && B > 0 && K > 0 && V > 0, "hno_loss_fwd: bad argument");
     HNO_REQUIRE(kind >= 0 && kind <= 2, "hno_loss_fwd: kind must be 0 (PCC), 1 (Dice) or 2 (ExpDice)");
-    if (K > 8) return fail(HNO_ELIMIT, "hno_loss_fwd: K=%d classes (max 8)", K);
+    if (K > 32) return fail(HNO_ELIMIT, "hno_loss_fwd: K=%d classes (max 32)", K);
     hipStream_t s = (hipStream_t)stream;
     {   // accumulators of the statistics kernels (see clear_doubles: not a memset node)
         const int rc = clear_doubles(stats, B * K * 4, s);
@@ -1204,8 +1216,9 @@ extern "C" int hno_loss_fwd(const float *probs, const uint8_t *labels, double *s
         if (gq > 256) gq = 256;   // measured (stats + finalize): 128 -> 37 us, 256 -> 29, 512 -> 32, 2048 -> 67 (atomic contention)
         if (debug_grid()) gq = debug_grid();
         ProfScope _ps(KID_LOSS_STATS, s, (double)B * V * (4.0 * K + 1));
-        if (K <= 4) hipLaunchKernelGGL(loss_stats_vec_kernel<4>, dim3((int)gq, B), dim3(256), 0, s, probs, labels, stats, K, V);
-        else hipLaunchKernelGGL(loss_stats_vec_kernel<8>, dim3((int)gq, B), dim3(256), 0, s, probs, labels, stats, K, V);
+#define X(KM) hipLaunchKernelGGL(loss_stats_vec_kernel<KM>, dim3((int)gq, B), dim3(256), 0, s, probs, labels, stats, K, V)
+        HNO_KSEL(K, X);
+#undef X
         HNO_CHECK_LAUNCH();
         { ProfScope _ps2(KID_LOSS_FINALIZE, s); hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const double *)stats, coef, loss, B, K, V, kind, param); }
         HNO_CHECK_LAUNCH();
@@ -1213,8 +1226,12 @@ extern "C" int hno_loss_fwd(const float *probs, const uint8_t *labels, double *s
     }
     long long gx = (V + 256 * 8 - 1) / (256 * 8);
     if (gx > 1024) gx = 1024;
-    if (K <= 4) { ProfScope _ps(KID_LOSS_STATS, s, (double)B * V * (4.0 * K + 1)); hipLaunchKernelGGL(loss_stats_kernel<4>, dim3((int)gx, B), dim3(256), 0, s, probs, labels, stats, K, V); }
-    else { ProfScope _ps(KID_LOSS_STATS, s, (double)B * V * (4.0 * K + 1)); hipLaunchKernelGGL(loss_stats_kernel<8>, dim3((int)gx, B), dim3(256), 0, s, probs, labels, stats, K, V); }
+    {
+        ProfScope _ps(KID_LOSS_STATS, s, (double)B * V * (4.0 * K + 1));
+#define X(KM) hipLaunchKernelGGL(loss_stats_kernel<KM>, dim3((int)gx, B), dim3(256), 0, s, probs, labels, stats, K, V)
+        HNO_KSEL(K, X);
+#undef X
+    }
     HNO_CHECK_LAUNCH();
     { ProfScope _ps(KID_LOSS_FINALIZE, s); hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const double *)stats, coef, loss, B, K, V, kind, param); }
     HNO_CHECK_LAUNCH();
@@ -1241,7 +1258,7 @@ extern "C" int hno_loss_fwd_ws(const float *probs, const uint8_t *labels, double
                                float *loss, int B, int K, long long V, int kind, float param, void *stream) {
     HNO_REQUIRE(probs && labels && workspace && coef && loss && B > 0 && K > 0 && V > 0, "hno_loss_fwd_ws: bad argument");
     HNO_REQUIRE(kind >= 0 && kind <= 2, "hno_loss_fwd_ws: kind must be 0 (PCC), 1 (Dice) or 2 (ExpDice)");
-    if (K > 8) return fail(HNO_ELIMIT, "hno_loss_fwd_ws: K=%d classes (max 8)", K);
+    if (K > 32) return fail(HNO_ELIMIT, "hno_loss_fwd_ws: K=%d classes (max 32)", K);
     const bool vec = V % 4 == 0 && ((size_t)labels & 3) == 0 && ((size_t)probs & 15) == 0 && !(debug_flags() & 16);
     int gq = loss_rows(B, V);
     if (gq > 1024) gq = 1024;
@@ -1251,8 +1268,9 @@ extern "C" int hno_loss_fwd_ws(const float *probs, const uint8_t *labels, double
     double *rows = workspace + (size_t)B * K * 4;
     {
         ProfScope _ps(KID_LOSS_STATS, s, (double)B * V * (4.0 * K + 1));
-        if (K <= 4) hipLaunchKernelGGL((loss_stats_vec_kernel<4, true>), dim3(gq, B), dim3(256), 0, s, probs, labels, rows, K, V);
-        else hipLaunchKernelGGL((loss_stats_vec_kernel<8, true>), dim3(gq, B), dim3(256), 0, s, probs, labels, rows, K, V);
+#define X(KM) hipLaunchKernelGGL((loss_stats_vec_kernel<KM, true>), dim3(gq, B), dim3(256), 0, s, probs, labels, rows, K, V)
+        HNO_KSEL(K, X);
+#undef X
     }
     HNO_CHECK_LAUNCH();
     {
@@ -1267,12 +1285,16 @@ extern "C" int hno_loss_fwd_ws(const float *probs, const uint8_t *labels, double
 extern "C" int hno_loss_bwd(const float *probs, const uint8_t *labels, const float *coef, const float *gscale,
                             float *g_probs, int B, int K, long long V, void *stream) {
     HNO_REQUIRE(probs && labels && coef && g_probs && B > 0 && K > 0 && V > 0, "hno_loss_bwd: bad argument");
-    if (K > 8) return fail(HNO_ELIMIT, "hno_loss_bwd: K=%d classes (max 8)", K);
+    if (K > 32) return fail(HNO_ELIMIT, "hno_loss_bwd: K=%d classes (max 32)", K);
     long long gx = (V + 256 * 4 - 1) / (256 * 4);
     if (gx > 2048) gx = 2048;
     hipStream_t s = (hipStream_t)stream;
-    if (K <= 4) { ProfScope _ps(KID_LOSS_BWD, s, (double)B * V * (8.0 * K + 1)); hipLaunchKernelGGL(loss_bwd_kernel<4>, dim3((int)gx, B), dim3(256), 0, s, probs, labels, coef, gscale, g_probs, K, V); }
-    else { ProfScope _ps(KID_LOSS_BWD, s, (double)B * V * (8.0 * K + 1)); hipLaunchKernelGGL(loss_bwd_kernel<8>, dim3((int)gx, B), dim3(256), 0, s, probs, labels, coef, gscale, g_probs, K, V); }
+    {
+        ProfScope _ps(KID_LOSS_BWD, s, (double)B * V * (8.0 * K + 1));
+#define X(KM) hipLaunchKernelGGL(loss_bwd_kernel<KM>, dim3((int)gx, B), dim3(256), 0, s, probs, labels, coef, gscale, g_probs, K, V)
+        HNO_KSEL(K, X);
+#undef X
+    }
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }

@@ -90,6 +90,11 @@ def conv_forward(op, x, act_id, xb=None):
             # kd = 0 taps read the depth padding); autograd slices the weight gradient back
             assert x.shape[2] == 1
             w = torch.stack([torch.zeros_like(w), w], dim=2)
+        if w.shape[0] > 32 or w.shape[1] > 8 or (x.requires_grad and torch.is_grad_enabled()):
+            # beyond the fast kernel's limits (<= 32 output, <= 8 input channels, no input gradient): the direct kernels (round 6) --
+            # the reference takes any `filters` / any number of modalities (nets/hnosegxs.py:46-62)
+            y = ops.ConvKFn.apply(x, w, op.bias, 2, False, 1)
+            return ops.ActFn.apply(y, act_id) if act_id != ops.ACT_NONE else y
         return ops.ConvK2S2Fn.apply(x, w, op.bias, act_id)
     from .conv3d import conv3d_forward  # general kernels (V-Net path)
     return conv3d_forward(op, x, act_id)

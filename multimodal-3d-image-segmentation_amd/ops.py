@@ -789,6 +789,11 @@ def specmix_bwd_raw(g, z0, zs, W, residual, act, defer=False):
     Ws = _mix_layers(W)
     B, C = z0.shape[:2]
     M, Lyr = _flat_v(z0), len(Ws)
+    if residual and C > 32:
+        # the kernels' residual (W + I) form is built for <= 32 channels; wider layers (the reference takes any `filters`) get W + I as an
+        # explicit matrix: d loss / d (W + I) = d loss / d W, everything else is the plain form (round 6: this used to raise)
+        eye = torch.eye(C, device=z0.device, dtype=torch.float32)
+        Ws, residual = [w + eye for w in Ws], 0
     gz0 = torch.empty_like(z0)
     dW = _grad_buffer_stacked(W) if not torch.is_tensor(W) else torch.empty((Lyr, C, C), device=z0.device, dtype=torch.float32)
     ws = torch.empty(_lib.lib().hno_specmix_bwd_workspace_bytes(B, C, M, Lyr) // 4, device=z0.device, dtype=torch.float32)
@@ -1068,51 +1073,58 @@ class ConvT3dK3Fn(_HnoFunction):
 
 
 class ConvKFn(_HnoFunction):
-    """nn.Conv3d / nn.ConvTranspose3d of ConvNormAct / ConvTransposeNormAct (nets/nets_utils.py:136-211) with ANY odd kernel size
+    """nn.Conv3d / nn.ConvTranspose3d of ConvNormAct / ConvTransposeNormAct (nets/nets_utils.py:136-211) with ANY kernel size
     (round 6: the reference's V-Net-DS takes ``kernel_size``, nets/architectures.py:55-70): the direct kernels hno_convk /
-    hno_convk_wgrad.  stride 1 ('same') or 2 with padding k // 2; the transposed form is stride 2, padding k // 2, output_padding 1."""
+    hno_convk_wgrad.  ``pad`` None = k // 2 (stride 1 'same' for odd k, the strided and transposed forms of the reference); conv_in's
+    Conv3d(k 2, s 2, p 1) beyond the fast kernel's channel limits takes pad = 1.  Transposed: stride 2, output_padding 1."""
 
     @staticmethod
-    def _osz(spatial, stride, transposed):
-        return tuple(2 * v for v in spatial) if transposed else tuple((v - 1) // stride + 1 for v in spatial)
+    def _osz(spatial, k, stride, pad, transposed):
+        if transposed:
+            return tuple((v - 1) * 2 - 2 * pad + k + 1 for v in spatial)
+        return tuple((v + 2 * pad - k) // stride + 1 for v in spatial)
 
     @staticmethod
-    def meta(x, W, bias, stride, transposed):
-        return _m((x.shape[0], W.shape[1] if transposed else W.shape[0]) + ConvKFn._osz(tuple(x.shape[2:]), stride, transposed))
+    def meta(x, W, bias, stride, transposed, pad=None):
+        k = int(W.shape[2])
+        pad = k // 2 if pad is None else pad
+        return _m((x.shape[0], W.shape[1] if transposed else W.shape[0]) + ConvKFn._osz(tuple(x.shape[2:]), k, stride, pad, transposed))
 
     @staticmethod
-    def forward(ctx, x, W, bias, stride, transposed):
+    def forward(ctx, x, W, bias, stride, transposed, pad=None):
         x, W, bias = _f32c(x), _f32c(W), _f32c(bias)
         _need_gpu(x, W, bias)
         k = int(W.shape[2])
-        assert tuple(W.shape[2:]) == (k, k, k) and k % 2 == 1, 'cubic kernels of odd size'
+        assert tuple(W.shape[2:]) == (k, k, k), 'cubic kernels'
+        pad = k // 2 if pad is None else int(pad)
         B, Cin = x.shape[:2]
         Cout = W.shape[1] if transposed else W.shape[0]
-        osz = ConvKFn._osz(tuple(x.shape[2:]), stride, transposed)
+        st = 2 if transposed else stride
+        osz = ConvKFn._osz(tuple(x.shape[2:]), k, st, pad, transposed)
         y = torch.empty((B, Cout) + osz, device=x.device, dtype=torch.float32)
-        check(_lib.lib().hno_convk(ptr(x), ptr(W), ptr(bias), ptr(y), 2 if transposed else 0, B, Cin, Cout, *x.shape[2:], *osz, k,
-                                   2 if transposed else stride, k // 2, stream_ptr()), 'hno_convk')
+        check(_lib.lib().hno_convk(ptr(x), ptr(W), ptr(bias), ptr(y), 2 if transposed else 0, B, Cin, Cout, *x.shape[2:], *osz, k, st, pad,
+                                   stream_ptr()), 'hno_convk')
         ctx.save_for_backward(x, W)
-        ctx.cfg = (k, stride, bool(transposed), bias is not None)
+        ctx.cfg = (k, st, pad, bool(transposed), bias is not None)
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, W = ctx.saved_tensors
-        k, stride, transposed, has_bias = ctx.cfg
+        k, st, pad, transposed, has_bias = ctx.cfg
         g = _f32c(g)
         B, Cin = x.shape[:2]
         Cout = W.shape[1] if transposed else W.shape[0]
-        L, st = _lib.lib(), 2 if transposed else stride
+        L = _lib.lib()
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            check(L.hno_convk(ptr(g), ptr(W), None, ptr(gx), 3 if transposed else 1, B, Cin, Cout, *g.shape[2:], *x.shape[2:], k, st, k // 2,
+            check(L.hno_convk(ptr(g), ptr(W), None, ptr(gx), 3 if transposed else 1, B, Cin, Cout, *g.shape[2:], *x.shape[2:], k, st, pad,
                               stream_ptr()), 'hno_convk')
         dW = torch.empty_like(W)
-        check(L.hno_convk_wgrad(ptr(g), ptr(x), ptr(dW), 1 if transposed else 0, B, Cin, Cout, *x.shape[2:], *g.shape[2:], k, st, k // 2,
+        check(L.hno_convk_wgrad(ptr(g), ptr(x), ptr(dW), 1 if transposed else 0, B, Cin, Cout, *x.shape[2:], *g.shape[2:], k, st, pad,
                                 stream_ptr()), 'hno_convk_wgrad')
-        return gx, dW, (_chan_sum(g) if has_bias else None), None, None
+        return gx, dW, (_chan_sum(g) if has_bias else None), None, None, None
 
 
 class GroupNormActFn(_HnoFunction):

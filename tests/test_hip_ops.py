@@ -2137,10 +2137,10 @@ def test_limits_fail_loudly(pkg):
         ops.dht3_crop_raw(torch.randn(1, 1, 8, 8, 8, device='cuda'), (5, 2, 2), 1.0)
     with pytest.raises(HnoError):                      # CPU tensors: there is no CPU path
         ops.dht3_crop_raw(torch.randn(1, 1, 8, 8, 8), (2, 2, 2), 1.0)
-    with pytest.raises(Err):                           # more than 8 classes in the fused head
-        ops.UpSoftmaxFn.apply(torch.randn(1, 9, 4, 4, 4, device='cuda'), (8, 8, 8), True)
-    with pytest.raises(Err):                           # conv_in with more than 8 input channels
-        ops.ConvK2S2Fn.apply(torch.randn(1, 9, 8, 8, 8, device='cuda'), torch.randn(4, 9, 2, 2, 2, device='cuda'), None, ops.ACT_SELU)
+    with pytest.raises(Err):                           # more than 32 classes in the head (round 6: 9 ... 32 run the voxel-form kernels)
+        ops.UpSoftmaxFn.apply(torch.randn(1, 33, 4, 4, 4, device='cuda'), (8, 8, 8), True)
+    with pytest.raises(Err):                           # the FAST conv_in kernel with more than 8 input channels (nets.conv_forward then
+        ops.ConvK2S2Fn.apply(torch.randn(1, 9, 8, 8, 8, device='cuda'), torch.randn(4, 9, 2, 2, 2, device='cuda'), None, ops.ACT_SELU)   # takes ops.ConvKFn)
     with pytest.raises(Err):                           # the fused branch backward is built for 24 + 24 -> 24 only
         t = torch.randn(1, 8, 4, 4, 4, device='cuda')
         ops.pwconv_bwd_branch_raw(t, t, t, t, torch.randn(8, 16, device='cuda'), torch.randn(8, 8, device='cuda'), ops.ACT_SELU, ops.ACT_SELU)
@@ -2498,3 +2498,111 @@ def test_vnet_with_kernel_size_5_vs_torch_modules(pkg):
     got = pkg.ops.ConvKFn.apply(h, layer.op.weight, layer.op.bias, 1, False)
     want = F.conv3d(h.double().cpu(), layer.op.weight.double().cpu(), layer.op.bias.double().cpu(), padding=2)
     assert rel_err(got.detach().cpu().numpy(), want.detach().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize('filters,in_ch', [(40, 2), (48, 3), (16, 10)])
+def test_hnosegxs_with_other_widths_vs_oracle(pkg, filters, in_ch):
+    """The reference takes any `filters` and any number of input modalities (nets/hnosegxs.py:46-62).  conv_in's fast kernel is built for
+    <= 32 output and <= 8 input channels: beyond that the direct kernels run (round 6; it used to raise), and the pointwise / spectral
+    layers take their generic paths.  One step of a small model against the CPU oracle."""
+    from multimodal_3d_image_segmentation_amd.nets import custom_losses
+    from oracle import hno_oracle as O
+    torch.manual_seed(filters + in_ch)
+    blocks, modes = [1, 2, 1, 1], (3, 4, 3)
+    model = pkg.nets.HNOSegXS(in_ch, 3, filters, blocks, modes).cuda()
+    x = torch.randn(1, in_ch, 20, 24, 16, device='cuda')
+    lab = torch.randint(0, 3, (1, 1, 20, 24, 16), device='cuda').float()
+    y = model(x)
+    loss = custom_losses.PCCLoss()(y, pkg.ops.labels_prepare(lab, 3))
+    loss.backward()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    y_ref, loss_ref, grads = O.hnosegxs_step(sd, x.cpu(), lab.cpu(), blocks, modes)
+    assert rel_err(y.detach().cpu().numpy(), y_ref.numpy()) < 1e-4
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    for k, p in model.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), grads[k].numpy()) < 2e-4, k
+
+
+def test_conv_in_input_gradient(pkg):
+    """d loss / d image through conv_in (saliency maps, adversarial inputs): the fast kernel has no input gradient and used to raise;
+    an input that requires grad takes the direct kernels (round 6) -- against torch's float64 convolution."""
+    import torch.nn.functional as F
+    torch.manual_seed(9)
+    layer = pkg.nets.nets_utils.ConvNormAct(3, 8, kernel_size=2, stride=2, use_bias=True, activation='selu').cuda()
+    x = torch.randn(2, 3, 12, 10, 14, device='cuda', requires_grad=True)
+    y = layer(x)
+    w64, b64 = layer.op.weight.detach().double().cpu().requires_grad_(), layer.op.bias.detach().double().cpu().requires_grad_()
+    x64 = x.detach().double().cpu().requires_grad_()
+    ref = F.selu(F.conv3d(x64, w64, b64, stride=2, padding=1))
+    assert tuple(y.shape) == tuple(ref.shape) and rel_err(y.detach().cpu().numpy(), ref.detach().numpy()) < 2e-6
+    cot = torch.randn_like(ref)
+    ref.backward(cot)
+    y.backward(cot.float().cuda())
+    assert rel_err(x.grad.cpu().numpy(), x64.grad.numpy()) < 1e-5
+    assert rel_err(layer.op.weight.grad.cpu().numpy(), w64.grad.numpy()) < 1e-5
+    assert rel_err(layer.op.bias.grad.cpu().numpy(), b64.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('K', [9, 14, 32])
+def test_head_and_losses_with_many_classes_vs_oracle(pkg, K):
+    """The reference takes any out_channels (nets/hnosegxs.py:46-62: conv_out + F.interpolate(trilinear) + softmax; custom_losses over any
+    channel count).  The head and loss kernels were built for <= 8 classes; 9 ... 32 run the voxel-form kernels (round 6).  Trilinear
+    upsampling + softmax + each loss, values and the gradient of the low-resolution logits, against torch in float64."""
+    import torch.nn.functional as F
+    from multimodal_3d_image_segmentation_amd.nets import custom_losses
+    torch.manual_seed(K)
+    lr = torch.randn(2, K, 7, 9, 8, dtype=torch.float64, requires_grad=True)
+    size = (12, 16, 14)
+    lab = torch.randint(0, K, (2, 1) + size)
+    onehot = torch.movedim(F.one_hot(lab[:, 0], K).double(), -1, 1)
+    for loss_name in ('PCCLoss', 'DiceLoss', 'ExpDiceLoss'):
+        lr.grad = None
+        p = F.softmax(F.interpolate(lr, size=size, mode='trilinear'), dim=1)
+        # the reference's formulas (nets/custom_losses.py:17-133) in float64
+        if loss_name == 'PCCLoss':
+            a, b = p.flatten(2), onehot.flatten(2)
+            a, b = a - a.mean(-1, keepdim=True), b - b.mean(-1, keepdim=True)
+            ref = (1 - ((a * b).sum(-1) / torch.sqrt((a * a).sum(-1) * (b * b).sum(-1) + 1e-7) + 1) * 0.5).mean()
+        else:
+            dice = 2 * (p * onehot).flatten(2).sum(-1) / ((p + onehot).flatten(2).sum(-1) + 1e-7)
+            ref = (1 - dice).mean() if loss_name == 'DiceLoss' else ((-torch.log(dice.clamp(1e-7, 1 - 1e-7))) ** 0.3).mean()
+        ref.backward()
+        lrg = lr.detach().float().cuda().requires_grad_()
+        probs = pkg.ops.head_output(lrg, size, True)
+        assert rel_err(probs.detach().cpu().numpy(), p.detach().numpy()) < 2e-6
+        loss = getattr(custom_losses, loss_name)()(probs, pkg.ops.labels_prepare(lab.float().cuda(), K))
+        loss.backward()
+        assert abs(float(loss.detach()) - float(ref.detach())) < 2e-6, loss_name
+        assert rel_err(lrg.grad.cpu().numpy(), lr.grad.numpy()) < 2e-5, loss_name
+    # inference: the arg-max head
+    with pkg.ops.label_output():
+        labels = pkg.ops.head_output(lr.detach().float().cuda(), size, True)
+    want = F.interpolate(lr.detach(), size=size, mode='trilinear').argmax(1, keepdim=True)
+    assert float((labels.cpu().long() != want).float().mean()) < 1e-3       # (ties / last-bit differences only)
+
+
+@pytest.mark.parametrize('classes', [12, 20])
+def test_hnosegxs_with_many_classes_vs_oracle(pkg, classes):
+    """A whole training step of HNOSegXS with more than 8 classes (whole-brain parcellations: the reference takes any out_channels,
+    nets/hnosegxs.py:46-62) against the CPU oracle: conv_out, the upsampling softmax head and the loss all leave their <= 8-class forms."""
+    from multimodal_3d_image_segmentation_amd.nets import custom_losses
+    from oracle import hno_oracle as O
+    torch.manual_seed(classes)
+    blocks, modes = [1, 1, 1, 1], (3, 3, 3)
+    model = pkg.nets.HNOSegXS(2, classes, 12, blocks, modes).cuda()
+    x = torch.randn(2, 2, 16, 20, 16, device='cuda')
+    lab = torch.randint(0, classes, (2, 1, 16, 20, 16), device='cuda').float()
+    u8 = pkg.ops.labels_prepare(lab, classes)
+    with pkg.ops.expected_loss(u8, custom_losses.DiceLoss()):
+        y = model(x)
+    loss = custom_losses.DiceLoss()(y, u8)
+    loss.backward()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    y_ref, loss_ref, grads = O.hnosegxs_step(sd, x.cpu(), lab.cpu(), blocks, modes, loss='dice')
+    assert rel_err(y.detach().cpu().numpy(), y_ref.numpy()) < 1e-4
+    assert abs(float(loss.detach()) - float(loss_ref)) < 1e-5
+    for k, p in model.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), grads[k].numpy()) < 2e-4, k
+    with torch.no_grad(), pkg.ops.label_output():
+        labels = model(x)
+    assert float((labels.cpu().long().reshape(-1) != y_ref.argmax(1).reshape(-1)).float().mean()) < 1e-3
