@@ -1,4 +1,4 @@
-# V-Net-DS cfg4 bf16 with the weight gradients on a side stream vs in the chain, same box: bash tools/r6/wgrad_side_ab.sh
+# RECORD of a removed experiment (LESSONS 94): V-Net-DS cfg4 bf16 with the weight gradients on a side stream vs in the chain; the HNO_WGRAD_STREAM switch left the code with it
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
