@@ -123,12 +123,15 @@ def test_conv_forward_backward_vs_float64(ob, case):
     assert rel_err(gs[-1].cpu().numpy(), gb64.numpy()) < 1e-4
 
 
+# shapes: small tensors run the one-workgroup backward (cb_gn_bwd_small_kernel: <= 262 144 elements; the two deepest V-Net levels of cfg4 are
+# the 384- and 192-channel cases), the last one the two-pass kernels
+@pytest.mark.parametrize('shape', [(2, 24, (5, 6, 7)), (1, 384, (6, 7, 5)), (1, 192, (11, 13, 9)), (2, 24, (20, 24, 30))], ids=str)
 @pytest.mark.parametrize('two', [False, True])
 @pytest.mark.parametrize('act', ['elu', 'selu'])
-def test_groupnorm_act_vs_float64(ob, two, act):
+def test_groupnorm_act_vs_float64(ob, two, act, shape):
     from multimodal_3d_image_segmentation_amd import ops
     torch.manual_seed(2)
-    B, C, sp = 2, 24, (5, 6, 7)
+    B, C, sp = shape
     aid = ops.act_id(act)
     fn = F.elu if act == 'elu' else F.selu
 
@@ -171,7 +174,8 @@ def test_groupnorm_act_vs_float64(ob, two, act):
     dy, dg, db, cs = ob.gn_bwd_raw(to_cl(cot), d1[0].detach(), d1[1], d1[2].detach(), d1[3].detach(), aid, colsum=True)
     want = gref[0].sum(dim=(0, 2, 3, 4)).numpy()
     assert rel_err(cs.cpu().numpy(), want) < 1e-4
-    assert rel_err(from_cl(dy).double().sum(dim=(0, 2, 3, 4)).numpy(), want) < BF16_TOL     # what a pass over the bf16 dy gives
+    if B * sp[0] * sp[1] * sp[2] <= 2000:      # what a pass over the bf16 dy gives (its rounding noise grows with the number of rows summed)
+        assert rel_err(from_cl(dy).double().sum(dim=(0, 2, 3, 4)).numpy(), want) < BF16_TOL
 
 
 @pytest.mark.parametrize('shape', ['24+24->24', '24->24', 'branch'])
