@@ -916,114 +916,6 @@ __global__ __launch_bounds__(256) void cb_gn_bwd_apply_kernel(const bf16_t *__re
     }
 }
 
-// The whole backward of GroupNorm(1, C) + activation for a SMALL tensor (the two deepest V-Net levels: 11 x 13 x 9 x 192 and
-// 6 x 7 x 5 x 384 elements per sample) in ONE workgroup of 1024 threads: sums, k1 / k2, dgamma / dbeta, the convolution's bias
-// gradient and dy, sample after sample.  The two-launch form above spends 21-28 us per layer there on launch and dependency latency
-// (4 workgroups reduce, one more launch applies; round 6 trace: 18 layers, 0.43 ms of the cfg4 step) for 0.2-1 MB of data.
-__global__ __launch_bounds__(1024) void cb_gn_bwd_small_kernel(const bf16_t *__restrict__ dz, const bf16_t *__restrict__ y, const float *__restrict__ mr,
-                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                              bf16_t *__restrict__ dy, float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                              float *__restrict__ dcolsum, int B, int C, long long V, int act, int accumulate) {
-    extern __shared__ float lds[];            // [1024][24] per-thread sums, then reused
-    __shared__ float chan[3][1024];           // S1, S2, S3 per channel of the current sample
-    __shared__ float red[2][16];
-    const int tid = threadIdx.x, C8 = C >> 3;
-    const int S = 1024 - 1024 % C8;
-    const int cg = tid % C8;
-    const long long items = V * C8;
-    const float inv_n = 1.0f / (float)(V * C), Vf = (float)V;
-    float gm[8], bt[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { gm[j] = gamma[cg * 8 + j]; bt[j] = beta[cg * 8 + j]; }
-    float dg_acc = 0.f, db_acc = 0.f, cs_acc = 0.f;      // of channel tid (tid < C)
-    const float gam_c = tid < C ? gamma[tid] : 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float mean = mr[2 * b], rstd = mr[2 * b + 1];
-        const size_t base = (size_t)b * V * C;
-        float s1[8], s2[8], s3[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s1[j] = s2[j] = s3[j] = 0.f;
-        if (tid < S)
-            for (long long it = tid; it < items; it += S) {
-                const size_t e = base + (size_t)it * 8;
-                const uint4 gv = *reinterpret_cast<const uint4 *>(dz + e), yv = *reinterpret_cast<const uint4 *>(y + e);
-                const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int j = 2 * k + u;
-                        const float g = bf2f((bf16_t)(u ? gw[k] >> 16 : gw[k] & 0xffff));
-                        const float xh = (bf2f((bf16_t)(u ? yw[k] >> 16 : yw[k] & 0xffff)) - mean) * rstd;
-                        const float t = g * act_grad_from_pre(fmaf(xh, gm[j], bt[j]), act);
-                        s1[j] += t;
-                        s2[j] = fmaf(t, xh, s2[j]);
-                        s3[j] += xh;
-                    }
-            }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            lds[tid * 24 + j] = s1[j];
-            lds[tid * 24 + 8 + j] = s2[j];
-            lds[tid * 24 + 16 + j] = s3[j];
-        }
-        __syncthreads();
-        for (int i = tid; i < 3 * C; i += 1024) {
-            const int which = i / C, c = i - which * C, g8 = c >> 3, j = c & 7;
-            float acc = 0.f;
-            for (int t = g8; t < S; t += C8) acc += lds[t * 24 + which * 8 + j];
-            chan[which][c] = acc;
-        }
-        __syncthreads();
-        // k1 = sum_c gamma_c S1_c / N, k2 = sum_c gamma_c S2_c / N
-        float q1 = tid < C ? gam_c * chan[0][tid] : 0.f, q2 = tid < C ? gam_c * chan[1][tid] : 0.f;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            q1 += __shfl_xor(q1, o);
-            q2 += __shfl_xor(q2, o);
-        }
-        if ((tid & 63) == 0) { red[0][tid >> 6] = q1; red[1][tid >> 6] = q2; }
-        __syncthreads();
-        float k1 = 0.f, k2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) { k1 += red[0][w]; k2 += red[1][w]; }
-        k1 *= inv_n;
-        k2 *= inv_n;
-        if (tid < C) {
-            db_acc += chan[0][tid];
-            dg_acc += chan[1][tid];
-            cs_acc += rstd * (gam_c * chan[0][tid] - Vf * k1 - k2 * chan[2][tid]);
-        }
-        if (tid < S)
-            for (long long it = tid; it < items; it += S) {
-                const size_t e = base + (size_t)it * 8;
-                const uint4 gv = *reinterpret_cast<const uint4 *>(dz + e), yv = *reinterpret_cast<const uint4 *>(y + e);
-                const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
-                unsigned out[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float res[2];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int j = 2 * k + u;
-                        const float g = bf2f((bf16_t)(u ? gw[k] >> 16 : gw[k] & 0xffff));
-                        const float xh = (bf2f((bf16_t)(u ? yw[k] >> 16 : yw[k] & 0xffff)) - mean) * rstd;
-                        const float t = g * act_grad_from_pre(fmaf(xh, gm[j], bt[j]), act);
-                        res[u] = rstd * (gm[j] * t - k1 - xh * k2);
-                    }
-                    out[k] = (unsigned)f2bf(res[0]) | ((unsigned)f2bf(res[1]) << 16);
-                }
-                *reinterpret_cast<uint4 *>(dy + e) = make_uint4(out[0], out[1], out[2], out[3]);
-            }
-        __syncthreads();          // lds, chan, red are rewritten by the next sample
-    }
-    if (tid < C) {
-        if (accumulate) { dgamma[tid] += dg_acc; dbeta[tid] += db_acc; }
-        else { dgamma[tid] = dg_acc; dbeta[tid] = db_acc; }
-        if (dcolsum) dcolsum[tid] = cs_acc;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ layout / precision
 // fp32 NCDHW (C channels) -> bf16 NDHWC with CP >= C channels (pad channels zero).  One thread = one voxel.
 __global__ __launch_bounds__(256) void cb_pack_input_kernel(const float *__restrict__ x, bf16_t *__restrict__ y, int C, int CP, long long V) {
@@ -1908,19 +1800,6 @@ extern "C" int hno_cb_gn_bwd(const void *dz, const void *y, const float *mr, con
     if (C % 8 || C > 2048) return fail(HNO_ELIMIT, "hno_cb_gn_bwd: C = %d must be a multiple of 8 (<= 2048)", C);
     if (V * C >= (1ll << 34)) return fail(HNO_ELIMIT, "hno_cb_gn_bwd: %lld elements per sample exceed the kernels' 32-bit item index", V * C);
     hipStream_t s = (hipStream_t)stream;
-    static const long long small_max = getenv("HNO_GN_BWD_SMALL") ? atoll(getenv("HNO_GN_BWD_SMALL")) : 0;      // elements; 0 = never.  MEASURED SLOWER (one CU cannot pull 1 MB twice in less than the two launches take: cfg4 7.55 -> 7.95 ms)
-    if ((long long)B * V * C <= small_max && C <= 1024) {
-        static int attr_set = -1;
-        if (attr_set != current_device()) {
-            HNO_CHECK_HIP(hipFuncSetAttribute((const void *)cb_gn_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 24 * 4));
-            attr_set = current_device();
-        }
-        ProfScope _ps(KID_CB_GN, s, (double)B * V * C * 10.0);
-        hipLaunchKernelGGL(cb_gn_bwd_small_kernel, dim3(1), dim3(1024), 1024 * 24 * sizeof(float), s, (const bf16_t *)dz, (const bf16_t *)y, mr, gamma, beta,
-                           (bf16_t *)dy, dgamma, dbeta, dy_colsum, B, C, V, act, accumulate);
-        HNO_CHECK_LAUNCH();
-        return HNO_OK;
-    }
     float *slab = (float *)workspace;
     float *gS = slab + (size_t)B * CB_GN_BWD_BLOCKS * 3 * C;
     // a streaming pass: enough workgroups to cover the latency (256 of them left one workgroup per CU: 0.9 TB/s)

@@ -123,8 +123,8 @@ def test_conv_forward_backward_vs_float64(ob, case):
     assert rel_err(gs[-1].cpu().numpy(), gb64.numpy()) < 1e-4
 
 
-# shapes: small tensors run the one-workgroup backward (cb_gn_bwd_small_kernel: <= 262 144 elements; the two deepest V-Net levels of cfg4 are
-# the 384- and 192-channel cases), the last one the two-pass kernels
+# shapes: the two deepest V-Net levels of cfg4 (384 and 192 channels: few voxels, many workgroup rows per channel group) and a tensor with
+# many voxels per workgroup
 @pytest.mark.parametrize('shape', [(2, 24, (5, 6, 7)), (1, 384, (6, 7, 5)), (1, 192, (11, 13, 9)), (2, 24, (20, 24, 30))], ids=str)
 @pytest.mark.parametrize('two', [False, True])
 @pytest.mark.parametrize('act', ['elu', 'selu'])
