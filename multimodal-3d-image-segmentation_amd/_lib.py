@@ -11,7 +11,8 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libhno.so')
+# HNO_LIB: another build of the SAME library (same-box A/B of two builds, tools/r6/lib_ab.sh); it is loaded and checked like the default
+LIB_PATH = os.environ.get('HNO_LIB') or os.path.join(_HERE, 'libhno.so')
 _lib = None
 
 c_void_p, c_int, c_float, c_ll, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong, ctypes.c_size_t
