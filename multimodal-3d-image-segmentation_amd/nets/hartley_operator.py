@@ -126,14 +126,14 @@ class HartleyOperator(Module):
                 z = hartley_mix_individual(None, self.weight, act=ops.ACT_SELU, x_full=inputs, modes=modes)
             else:
                 z = hartley_mix_individual(None, self.weight, act=ops.ACT_NONE, x_full=inputs, modes=modes)
-                z = torch.nn.functional.selu(z + self.bias)
+                z = ops.BiasActFn.apply(z, self.bias, ops.ACT_SELU)
         delta = None
         if bias is not None:
             # The reference adds the bias to the ZERO-PADDED spectrum (hartley_operator.py:262-263), so after SELU the
             # whole padded region holds the constant selu(b).  The (unscaled) inverse transform of a constant spectrum is
             # a delta at the origin, N^3 * selu(b): subtract the constant on the kept block, add the delta afterwards.
-            cb = torch.nn.functional.selu(self.bias)                       # (1, Co, 1, 1, 1)
-            z = z - cb
+            cb = torch.nn.functional.selu(self.bias)                       # (1, Co, 1, 1, 1): Co values of a parameter
+            z = ops.BiasActFn.apply(z, -cb, ops.ACT_NONE)                  # z - selu(b) on the kept block
             delta = cb.reshape(-1) * n3
         if delta is not None:   # rare switch: unfused tail so that the delta lands before the residual add / activation
             y = ops.PadIdhtFn.apply(z, spatial, 1.0, ops.ACT_NONE)

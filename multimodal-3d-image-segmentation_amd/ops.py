@@ -1488,6 +1488,35 @@ class ActFn(_HnoFunction):
         return act_bwd_raw(_f32c(g), y, ctx.act), None
 
 
+class BiasActFn(_HnoFunction):
+    """act(x + bias[c]) for a per-channel bias (hno_bias_act; the reference adds a (1, Co, 1, 1, 1) parameter to the spectrum and applies
+    SELU, nets/hartley_operator.py:262-267)."""
+
+    @staticmethod
+    def meta(x, bias, act):
+        return _m(x.shape)
+
+    @staticmethod
+    def forward(ctx, x, bias, act):
+        _need_gpu(x, bias)
+        y = _f32c(x).clone()
+        b = _f32c(bias.reshape(-1))
+        assert b.numel() == y.shape[1], 'one bias per channel'
+        check(_lib.lib().hno_bias_act(ptr(y), ptr(b), y.shape[0], y.shape[1], _flat_v(y), act, stream_ptr()), 'hno_bias_act')
+        ctx.act, ctx.bshape = act, tuple(bias.shape)
+        ctx.save_for_backward(y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = _f32c(g)
+        if ctx.act != ACT_NONE:
+            g = act_bwd_raw(g, y, ctx.act)
+        db = _chan_sum(g).reshape(ctx.bshape) if ctx.needs_input_grad[1] else None
+        return g, db, None
+
+
 class AddFn(_HnoFunction):
 
     @staticmethod
