@@ -214,8 +214,8 @@ __global__ __launch_bounds__(256) void cb_gather_kernel(CbArgs a) {
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[m]), __builtin_bit_cast(bf16x8, bv[n]),
-                                                                        acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bv[n]), __builtin_bit_cast(bf16x8, av[m]),
+                                                                        acc[m][n], 0, 0, 0);      // weights as the A operand: see the epilogue
             if (more) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) av[m] = an[m];
@@ -224,37 +224,42 @@ __global__ __launch_bounds__(256) void cb_gather_kernel(CbArgs a) {
             }
         }
     }
-    // epilogue.  C/D: column (lane & 31) = output channel, rows (i & 3) + 8 (i >> 2) + 4 h = voxels of the tile; the flattened
-    // output voxel of row j is what lane j computed for its own voxel (lin)
+    // epilogue.  C/D (weights = A, activations = B): column (lane & 31) = this lane's voxel, rows (i & 3) + 8 (i >> 2) + 4 h = output
+    // channel within the 32-channel tile: registers 4 g .. 4 g + 3 are 4 CONSECUTIVE channels 8 g + 4 h .. + 3 -- one 8-byte store each
+    // (16-byte for the fp32 split-K partials).  Until round 6 the operands were the other way round (column = channel, rows = voxels):
+    // sixteen 2-byte stores per tile and lane, the bound of the 1x1x1 / strided layers of the shallow levels (24 MB outputs at 1 TB/s)
     float ssum = 0.f, ssq = 0.f;
     if (wave_active) {
-        int vrow[MT][16];
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) {
+            const int v = lin[m];
+            if (v < 0) continue;
+            const size_t vb = (size_t)b * Vo + v;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) vrow[m][i] = __shfl(lin[m], (i & 3) + 8 * (i >> 2) + 4 * h);
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int ch = n0 + 32 * n + r;
-            if (ch >= a.Cout) continue;
-            const float bias = (a.bias && kz == 0) ? a.bias[ch] : 0.f;
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = n0 + 32 * n + 8 * g + 4 * h;
+                    if (ch >= a.Cout) continue;          // (Cout is a multiple of 8 and ch of 4: a group is all in or all out)
+                    const bool wb = a.bias && kz == 0;
+                    float val[4];
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int v = vrow[m][i];
-                    if (v < 0) continue;
-                    const float val = acc[m][n][i] + bias;
+                    for (int e = 0; e < 4; ++e) val[e] = acc[m][n][4 * g + e] + (wb ? a.bias[ch + e] : 0.f);
                     if (a.part) {
-                        a.part[(((size_t)kz * a.B + b) * Vo + v) * a.Cout + ch] = val;
-                    } else {
-                        const bf16_t o = f2bf(val);
-                        if (a.csplit && ch >= a.csplit) a.y2[((size_t)b * Vo + v) * (a.Cout - a.csplit) + (ch - a.csplit)] = o;
-                        else a.y[((size_t)b * Vo + v) * (a.csplit ? a.csplit : a.Cout) + ch] = o;
-                        const float f = bf2f(o);
+                        *reinterpret_cast<float4 *>(a.part + (((size_t)kz * a.B + b) * Vo + v) * a.Cout + ch) = make_float4(val[0], val[1], val[2], val[3]);
+                        continue;
+                    }
+                    bf16_t o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = f2bf(val[e]);
+                        const float f = bf2f(o[e]);
                         ssum += f;
                         ssq = fmaf(f, f, ssq);
                     }
+                    const uint2 packed = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
+                    if (a.csplit && ch >= a.csplit) *reinterpret_cast<uint2 *>(a.y2 + vb * (a.Cout - a.csplit) + (ch - a.csplit)) = packed;
+                    else *reinterpret_cast<uint2 *>(a.y + vb * (a.csplit ? a.csplit : a.Cout) + ch) = packed;
                 }
         }
     }
