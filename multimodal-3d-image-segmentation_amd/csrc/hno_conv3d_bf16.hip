@@ -1244,8 +1244,8 @@ __global__ __launch_bounds__(256) void cb_wgrad_kernel(CwArgs a) {
                         typedef short s16x8 __attribute__((ext_vector_type(8)));
                         const s16x8 av = {af[i][0][0], af[i][0][1], af[i][0][2], af[i][0][3], af[i][1][0], af[i][1][1], af[i][1][2], af[i][1][3]};
                         const s16x8 bv = {bcur[j][0][0], bcur[j][0][1], bcur[j][0][2], bcur[j][0][3], bcur[j][1][0], bcur[j][1][1], bcur[j][1][2], bcur[j][1][3]};
-                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
-                                                                               acc[t][i][j], 0, 0, 0);
+                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, av),
+                                                                               acc[t][i][j], 0, 0, 0);      // X rows, G columns: see the slab store
                     }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1267,7 +1267,9 @@ __global__ __launch_bounds__(256) void cb_wgrad_kernel(CwArgs a) {
         c_valid = n_valid; c_wk = n_wk; c_b = n_b; c_band = n_band; c_od = n_od; c_lo = n_lo; c_hi = n_hi;
         par ^= 1;
     }
-    // ---- slab: [tap][CO][CI] for this block.  C/D of 16x16x32: column (lane & 15) = input channel, rows 4 (lane >> 4) + e = output channel
+    // ---- slab: [tap][CO][CI] for this block.  C/D of 16x16x32 (X = A operand, G = B operand): column (lane & 15) = output channel, rows
+    // 4 (lane >> 4) + e = FOUR CONSECUTIVE input channels: one 16-byte store per tile and lane (the other orientation wrote the 250 KB
+    // slab of a workgroup with 4-byte stores, four instructions per tile)
     float *dst = a.slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * a.ntaps * a.CO * a.CI;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
@@ -1276,12 +1278,11 @@ __global__ __launch_bounds__(256) void cb_wgrad_kernel(CwArgs a) {
 #pragma unroll
         for (int i = 0; i < TA; ++i)
 #pragma unroll
-            for (int j = 0; j < TB; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int o = 16 * i + 4 * grp + e, c = 16 * j + li;
-                    if (o < a.CO && c < a.CI) dst[((size_t)tap * a.CO + o) * a.CI + c] = acc[t][i][j][e];
-                }
+            for (int j = 0; j < TB; ++j) {
+                const int o = 16 * i + li, c = 16 * j + 4 * grp;
+                if (o < a.CO && c < a.CI)       // (CI is a multiple of 8 and c of 4: the four channels are all in or all out)
+                    *reinterpret_cast<float4 *>(dst + ((size_t)tap * a.CO + o) * a.CI + c) = make_float4(acc[t][i][j][0], acc[t][i][j][1], acc[t][i][j][2], acc[t][i][j][3]);
+            }
     }
 }
 
