@@ -766,39 +766,65 @@ __global__ __launch_bounds__(256) void cb_gn_bwd_reduce_kernel(const bf16_t *__r
 }
 
 // pass 1b: slabs -> dgamma[c], dbeta[c] (summed over samples and blocks, fixed order) and gS[b][which][c] = gamma_c S_which[b][c].
-// One workgroup per 8 channels: thread (slice = t >> 3, j = t & 7) sums every 32nd slab row of channel 8 blockIdx.x + j,
-// the 32 slices are then added in order.  (A single-workgroup version of this kernel -- 256 dependent loads per thread --
-// cost 0.2-0.5 ms per call, 10 ms of the 18 ms V-Net step.)
-__device__ __forceinline__ void cb_gn_bwd_finalize_group(const float *__restrict__ slab, const float *__restrict__ gamma, int B, int nblk,
-                                                         int C, float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                         float *__restrict__ gS, int accumulate, int group, float (*sh)[32][8]) {
-    const int j = threadIdx.x & 7, slice = threadIdx.x >> 3;
-    const int c = group * 8 + j;
-    float dg = 0.f, db = 0.f;
-    for (int b = 0; b < B; ++b) {
-        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        for (int k = slice; k < nblk; k += 32) {
+// A workgroup step owns a GROUP of CH = 256 / SL channels; SL (a power of two, 32 ... 256) threads per channel each sum every SL-th
+// slab row, then a tree over the SL slices.  SL follows the number of slab rows (cb_gn_slices): with 1024 rows (the shallow levels) a
+// channel gets all 256 threads -- four rows each -- where the first form (8 channels x 32 slices whatever the row count, the slices then
+// added one after the other by 8 threads) walked 32 dependent rows per thread in C / 8 = 3 ... 6 workgroups: 11-12 us, the long pole of
+// the apply kernel it is fused into (round 6 trace).  (A single-workgroup version of this step -- 256 dependent loads per thread --
+// cost 0.2-0.5 ms per call, 10 ms of the 18 ms V-Net step, in round 2.)
+__host__ __device__ __forceinline__ int cb_gn_slices(int nblk) {
+    int sl = 32;
+    while (sl < 256 && sl < nblk) sl <<= 1;
+    return sl;
+}
+// sh: 3 * 256 floats.  Returns with (t1, t2, t3) = (S1, S2, S3) of sample b, channel c, valid in the threads with slice == 0.
+__device__ __forceinline__ void cb_gn_bwd_group_sums(const float *__restrict__ slab, int b, int nblk, int C, int c, int SL, int CH, float *sh, float &t1,
+                                                     float &t2, float &t3) {
+    const int slice = threadIdx.x / CH;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C)
+        for (int k = slice; k < nblk; k += SL) {
             const float *p = slab + ((size_t)b * nblk + k) * 3 * C;
             s1 += p[c];
             s2 += p[C + c];
             s3 += p[2 * C + c];
         }
-        sh[0][slice][j] = s1;
-        sh[1][slice][j] = s2;
-        sh[2][slice][j] = s3;
+    sh[threadIdx.x] = s1;
+    sh[256 + threadIdx.x] = s2;
+    sh[512 + threadIdx.x] = s3;
+    __syncthreads();
+    for (int o = SL >> 1; o > 0; o >>= 1) {
+        if (slice < o) {
+            sh[threadIdx.x] += sh[threadIdx.x + o * CH];
+            sh[256 + threadIdx.x] += sh[256 + threadIdx.x + o * CH];
+            sh[512 + threadIdx.x] += sh[512 + threadIdx.x + o * CH];
+        }
         __syncthreads();
-        if (slice == 0) {
-            float t1 = 0.f, t2 = 0.f, t3 = 0.f;
-            for (int q = 0; q < 32; ++q) { t1 += sh[0][q][j]; t2 += sh[1][q][j]; t3 += sh[2][q][j]; }
+    }
+    t1 = sh[threadIdx.x];
+    t2 = sh[256 + threadIdx.x];
+    t3 = sh[512 + threadIdx.x];
+    __syncthreads();          // sh is rewritten by the next sample
+}
+__device__ __forceinline__ void cb_gn_bwd_finalize_group(const float *__restrict__ slab, const float *__restrict__ gamma, int B, int nblk,
+                                                         int C, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                         float *__restrict__ gS, int accumulate, int group, float *sh) {
+    const int SL = cb_gn_slices(nblk), CH = 256 / SL;
+    const int j = threadIdx.x % CH, slice = threadIdx.x / CH;
+    const int c = group * CH + j;
+    float dg = 0.f, db = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float t1, t2, t3;
+        cb_gn_bwd_group_sums(slab, b, nblk, C, c, SL, CH, sh, t1, t2, t3);
+        if (slice == 0 && c < C) {
             db += t1;
             dg += t2;
             gS[((size_t)b * 4) * C + c] = gamma[c] * t1;
             gS[((size_t)b * 4 + 1) * C + c] = gamma[c] * t2;
             gS[((size_t)b * 4 + 2) * C + c] = t3;          // sum_v xhat[c][v]
         }
-        __syncthreads();
     }
-    if (slice == 0) {
+    if (slice == 0 && c < C) {
         if (accumulate) { dgamma[c] += dg; dbeta[c] += db; }
         else { dgamma[c] = dg; dbeta[c] = db; }
     }
@@ -807,7 +833,7 @@ __device__ __forceinline__ void cb_gn_bwd_finalize_group(const float *__restrict
 __global__ __launch_bounds__(256) void cb_gn_bwd_finalize_kernel(const float *__restrict__ slab, const float *__restrict__ gamma, int B, int nblk,
                                                                 int C, float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                                 float *__restrict__ gS, int accumulate) {
-    __shared__ float sh[3][32][8];
+    __shared__ float sh[768];
     cb_gn_bwd_finalize_group(slab, gamma, B, nblk, C, dgamma, dbeta, gS, accumulate, blockIdx.x, sh);
 }
 
@@ -819,43 +845,61 @@ __global__ __launch_bounds__(256) void cb_gn_bwd_apply_kernel(const bf16_t *__re
                                                              int nblk, const float *__restrict__ slab, float *__restrict__ dgamma,
                                                              float *__restrict__ dbeta, float *__restrict__ gS_w, int accumulate) {
     const int b = blockIdx.y;
-    // pass 1b (kpart form): workgroup g of sample 0 owns channel group g (8 channels): their sums over samples and slab rows -> dgamma,
-    // dbeta, gS and -- per channel independent -- the convolution's bias gradient.  (All groups in ONE workgroup made that workgroup the
-    // kernel's long pole on the deep levels: 48 groups x two barriers and a global round trip each = 0.7 ms per step.)
-    if (kpart && blockIdx.y == 0 && (int)blockIdx.x < (C >> 3)) {
-        __shared__ float sh[3][32][8];
-        __shared__ float kq[2][64];
-        const float inv_n0 = 1.0f / (float)per_sample, Vf0 = (float)(per_sample / C);
-        for (int grp = blockIdx.x; grp < (C >> 3); grp += gridDim.x) {
-            __syncthreads();
-            cb_gn_bwd_finalize_group(slab, gamma, B, nblk, C, dgamma, dbeta, gS_w, accumulate, grp, sh);
-            __syncthreads();                               // this workgroup's own gS writes are read back below
-            if (dcolsum) {
-                float colsum = 0.f;
+    // pass 1b (kpart form): workgroup g of sample 0 owns channel group g (cb_gn_slices: 1 ... 8 channels): their sums over samples and
+    // slab rows -> dgamma, dbeta, gS and -- per channel independent -- the convolution's bias gradient.  (All groups in ONE workgroup made that
+    // workgroup the kernel's long pole on the deep levels: 48 groups x two barriers and a global round trip each = 0.7 ms per step.)
+    {
+        const int SL = cb_gn_slices(nblk), CH = 256 / SL, ngroups = (C + CH - 1) / CH;
+        if (kpart && blockIdx.y == 0 && (int)blockIdx.x < ngroups) {
+            __shared__ float sh[768];
+            __shared__ float kq[2][256];
+            const float inv_n0 = 1.0f / (float)per_sample, Vf0 = (float)(per_sample / C);
+            const int j = threadIdx.x % CH, slice = threadIdx.x / CH;
+            for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+                const int c = grp * CH + j;
+                float dg = 0.f, db = 0.f, colsum = 0.f;
                 for (int bb = 0; bb < B; ++bb) {
-                    // k1, k2 of sample bb: wave 0 adds the kpart rows in a fixed order
-                    if (threadIdx.x < 64) {
+                    float t1, t2, t3;
+                    cb_gn_bwd_group_sums(slab, bb, nblk, C, c, SL, CH, sh, t1, t2, t3);
+                    float q1 = 0.f, q2 = 0.f;
+                    if (dcolsum) {      // k1, k2 of sample bb: all threads add the kpart rows, fixed order
                         float a1 = 0.f, a2 = 0.f;
-                        for (int k = threadIdx.x; k < nblk; k += 64) {
+                        for (int k = threadIdx.x; k < nblk; k += 256) {
                             a1 += kpart[((size_t)bb * nblk + k) * 2];
                             a2 += kpart[((size_t)bb * nblk + k) * 2 + 1];
                         }
                         kq[0][threadIdx.x] = a1;
                         kq[1][threadIdx.x] = a2;
+                        __syncthreads();
+                        for (int o = 128; o > 0; o >>= 1) {
+                            if ((int)threadIdx.x < o) {
+                                kq[0][threadIdx.x] += kq[0][threadIdx.x + o];
+                                kq[1][threadIdx.x] += kq[1][threadIdx.x + o];
+                            }
+                            __syncthreads();
+                        }
+                        q1 = kq[0][0];
+                        q2 = kq[1][0];
+                        __syncthreads();
                     }
-                    __syncthreads();
-                    if (threadIdx.x < 8) {
-                        float q1 = 0.f, q2 = 0.f;
-                        for (int t = 0; t < 64; ++t) { q1 += kq[0][t]; q2 += kq[1][t]; }
-                        const int c = grp * 8 + threadIdx.x;
-                        colsum += mr[2 * bb + 1] * (gS_w[((size_t)bb * 4) * C + c] - Vf0 * (q1 * inv_n0) - (q2 * inv_n0) * gS_w[((size_t)bb * 4 + 2) * C + c]);
+                    if (slice == 0 && c < C) {
+                        db += t1;
+                        dg += t2;
+                        const float g1 = gamma[c] * t1;
+                        gS_w[((size_t)bb * 4) * C + c] = g1;
+                        gS_w[((size_t)bb * 4 + 1) * C + c] = gamma[c] * t2;
+                        gS_w[((size_t)bb * 4 + 2) * C + c] = t3;
+                        colsum += mr[2 * bb + 1] * (g1 - Vf0 * (q1 * inv_n0) - (q2 * inv_n0) * t3);
                     }
-                    __syncthreads();
                 }
-                if (threadIdx.x < 8) dcolsum[grp * 8 + threadIdx.x] = colsum;
+                if (slice == 0 && c < C) {
+                    if (accumulate) { dgamma[c] += dg; dbeta[c] += db; }
+                    else { dgamma[c] = dg; dbeta[c] = db; }
+                    if (dcolsum) dcolsum[c] = colsum;
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
     // k1 = sum_c gS[b][0][c] / N, k2 = sum_c gS[b][1][c] / N: every workgroup re-reduces the <= 2 x 2048 values itself (fixed
     // order, so all workgroups agree bit for bit) instead of waiting for one more tiny launch
@@ -1848,7 +1892,8 @@ extern "C" int hno_cb_gn_bwd(const void *dz, const void *y, const float *mr, con
                            beta, slab, C, V, act, kpart);
         HNO_CHECK_LAUNCH();
         if (apart) {
-            hipLaunchKernelGGL(cb_gn_bwd_finalize_kernel, dim3(C / 8), dim3(256), 0, s, (const float *)slab, gamma, B, nblk, C, dgamma, dbeta, gS, accumulate);
+            hipLaunchKernelGGL(cb_gn_bwd_finalize_kernel, dim3((C + 256 / cb_gn_slices(nblk) - 1) / (256 / cb_gn_slices(nblk))), dim3(256), 0, s, (const float *)slab, gamma, B, nblk, C, dgamma, dbeta,
+                               gS, accumulate);
             HNO_CHECK_LAUNCH();
         }
         ProfScope _ps2(KID_CB_GN, s, (double)B * V * C * 6.0);
