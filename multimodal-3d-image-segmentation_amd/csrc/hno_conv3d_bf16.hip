@@ -1792,17 +1792,33 @@ static int cb_conv_impl(const void *xa, int Ca, const void *xb, int Cb, const vo
             a.cls_blk0[8] = n;
             return (unsigned)n;
         };
+        // position tiles per wave (MT): the largest that still gives the chip `mt_wgs` workgroups -- 4 x 128 voxels per workgroup left the
+        // strided 24 -> 24 convolution between the two shallow levels with 130 workgroups (58 us for 25 MB, round 6 trace)
+        static const int mt_wgs = getenv("HNO_CB_MT_WGS") ? atoi(getenv("HNO_CB_MT_WGS")) : 1536;     // A/B aid (0: the fixed shapes of rounds 2-5; cfg4 step at 0 / 768 / 1536 / 3072: 6.56 / 6.52 / 6.48 / 6.55 ms)
+        const int ny = Cout <= 64 ? 1 : (Cout + 95) / 96;
+        auto pick_mt = [&](int mt_max) {
+            int mt = mt_max;
+            while (mt > 1 && (long long)grid_x(mt) * ny * B * kz < mt_wgs) mt >>= 1;
+            return mt;
+        };
         if (Cout <= 32) {
-            const dim3 g(grid_x(4), 1, B * kz);
-            hipLaunchKernelGGL((cb_gather_kernel<4, 1>), g, dim3(256), 0, s, a);
+            const int mt = pick_mt(4);
+            const dim3 g(grid_x(mt), 1, B * kz);
+            if (mt == 4) hipLaunchKernelGGL((cb_gather_kernel<4, 1>), g, dim3(256), 0, s, a);
+            else if (mt == 2) hipLaunchKernelGGL((cb_gather_kernel<2, 1>), g, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((cb_gather_kernel<1, 1>), g, dim3(256), 0, s, a);
             nblk_stats = g.x * g.y;
         } else if (Cout <= 64) {
-            const dim3 g(grid_x(2), 1, B * kz);
-            hipLaunchKernelGGL((cb_gather_kernel<2, 2>), g, dim3(256), 0, s, a);
+            const int mt = pick_mt(2);
+            const dim3 g(grid_x(mt), 1, B * kz);
+            if (mt == 2) hipLaunchKernelGGL((cb_gather_kernel<2, 2>), g, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((cb_gather_kernel<1, 2>), g, dim3(256), 0, s, a);
             nblk_stats = g.x * g.y;
         } else {
-            const dim3 g(grid_x(2), (Cout + 95) / 96, B * kz);
-            hipLaunchKernelGGL((cb_gather_kernel<2, 3>), g, dim3(256), 0, s, a);
+            const int mt = pick_mt(2);
+            const dim3 g(grid_x(mt), (Cout + 95) / 96, B * kz);
+            if (mt == 2) hipLaunchKernelGGL((cb_gather_kernel<2, 3>), g, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((cb_gather_kernel<1, 3>), g, dim3(256), 0, s, a);
             nblk_stats = g.x * g.y;
         }
         HNO_CHECK_LAUNCH();
