@@ -1639,7 +1639,7 @@ extern "C" size_t hno_cb_conv_workspace_bytes(int B, int Cin, int Cout, int Do, 
     const int kz = cb_pick_ksplit(B, Cout, Vo, nsteps);
     size_t part = kz > 1 ? (size_t)kz * B * Vo * Cout * sizeof(float) : 0;
     if (ks == 3 && Cin % 24 == 0 && Cin >= 48) {             // the halo-tile kernel may slice the channel chunks 2 or 4 ways
-        const size_t halo_part = (size_t)4 * B * Vo * Cout * sizeof(float);
+        const size_t halo_part = (size_t)8 * B * Vo * Cout * sizeof(float);
         if (halo_part <= ((size_t)96 << 20) && halo_part > part) part = halo_part;
     }
     // statistics partials: at most one pair per 64-voxel x 32-channel block, or per finish block
@@ -1701,9 +1701,11 @@ static int cb_conv_impl(const void *xa, int Ca, const void *xb, int Cb, const vo
         const int ntmax = Cout <= 32 ? 1 : (Cout <= 64 ? 2 : 3);
         int bMT = 0, bNT = 0, bKS = 0, bTH = 0;
         double best = 0.0;
+        static const int halo_ksmax = getenv("HNO_HALO_KSMAX") ? atoi(getenv("HNO_HALO_KSMAX")) : 8;          // A/B aids (4 and 512 until round 6: cfg4 step 6.48 -> 6.43 ms)
+        static const double halo_fill = getenv("HNO_HALO_FILL") ? atof(getenv("HNO_HALO_FILL")) : 1024.0;
         for (int MT = 2; MT >= 1; --MT)
             for (int NT = ntmax; NT >= 1; --NT)
-                for (int ksp = 1; ksp <= 4 && ksp <= nchunk; ksp *= 2) {
+                for (int ksp = 1; ksp <= halo_ksmax && ksp <= nchunk; ksp *= 2) {
                     if (nchunk % ksp) continue;
                     int TH = (4 * MT * 32) / S;
                     if (TH > Ho) TH = Ho;
@@ -1711,11 +1713,11 @@ static int cb_conv_impl(const void *xa, int Ca, const void *xb, int Cb, const vo
                     const double util = (double)TH * S / (4 * MT * 32);
                     if (util < 0.6) continue;
                     const long long blocks = (long long)B * Do * ((Ho + TH - 1) / TH) * ((Cout + 32 * NT - 1) / (32 * NT)) * ksp;
-                    const double fill = blocks >= 512 ? 1.0 : (double)blocks / 512.0;
+                    const double fill = blocks >= halo_fill ? 1.0 : (double)blocks / halo_fill;
                     // shape factors fitted to a sweep of all shapes over the level-1 / level-2 layers (tools/bench_cb_conv.py with
                     // HNO_HALO_SHAPE): small bands and many workgroups win (co-resident workgroups run in lockstep, so parallelism
                     // has to come from the grid), fewer channel tiles re-stage the image, slices add the fp32 round trip
-                    const double shape = (MT == 2 ? 0.95 : 1.0) * (1.0 - 0.1 * (ntmax - NT)) * (ksp == 1 ? 1.0 : (ksp == 2 ? 0.8 : 0.65));
+                    const double shape = (MT == 2 ? 0.95 : 1.0) * (1.0 - 0.1 * (ntmax - NT)) * (ksp == 1 ? 1.0 : (ksp == 2 ? 0.8 : (ksp == 4 ? 0.65 : 0.55)));
                     const double score = fill * util * shape;
                     if (score > best) { best = score; bMT = MT; bNT = NT; bKS = ksp; bTH = TH; }
                 }
