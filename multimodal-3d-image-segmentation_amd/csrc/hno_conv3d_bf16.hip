@@ -652,6 +652,15 @@ __global__ __launch_bounds__(256) void cb_gn_apply_kernel(const bf16_t *__restri
     }
     const long long n8 = per_sample >> 3;
     const int C8 = C >> 3;
+    // gamma / beta from LDS (round 6): a thread's channel group changes from item to item, and 16 (32 with two branches) 4-byte global
+    // loads per 16-byte item were most of this kernel's memory instructions (24 us for the 49 MB of a shallow-level layer)
+    extern __shared__ float gb[];     // [4][C]: gamma1, beta1, gamma2, beta2
+    for (int c = threadIdx.x; c < C; c += 256) {
+        gb[c] = g1[c];
+        gb[C + c] = b1[c];
+        if (y2) { gb[2 * C + c] = g2[c]; gb[3 * C + c] = b2[c]; }
+    }
+    __syncthreads();
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
         const int c0 = (int)((unsigned)i % (unsigned)C8) * 8;      // i < 2^32 (host check): a 64-bit modulo per item costs more than the item
         const size_t e = (size_t)b * per_sample + (size_t)i * 8;
@@ -659,18 +668,29 @@ __global__ __launch_bounds__(256) void cb_gn_apply_kernel(const bf16_t *__restri
         uint4 v2 = make_uint4(0, 0, 0, 0);
         if (y2) v2 = *reinterpret_cast<const uint4 *>(y2 + e);
         const unsigned w1[4] = {v1.x, v1.y, v1.z, v1.w}, w2[4] = {v2.x, v2.y, v2.z, v2.w};
+        float G1[8], B1[8], G2[8], B2[8];
+        *reinterpret_cast<float4 *>(G1) = *reinterpret_cast<const float4 *>(gb + c0);
+        *reinterpret_cast<float4 *>(G1 + 4) = *reinterpret_cast<const float4 *>(gb + c0 + 4);
+        *reinterpret_cast<float4 *>(B1) = *reinterpret_cast<const float4 *>(gb + C + c0);
+        *reinterpret_cast<float4 *>(B1 + 4) = *reinterpret_cast<const float4 *>(gb + C + c0 + 4);
+        if (y2) {
+            *reinterpret_cast<float4 *>(G2) = *reinterpret_cast<const float4 *>(gb + 2 * C + c0);
+            *reinterpret_cast<float4 *>(G2 + 4) = *reinterpret_cast<const float4 *>(gb + 2 * C + c0 + 4);
+            *reinterpret_cast<float4 *>(B2) = *reinterpret_cast<const float4 *>(gb + 3 * C + c0);
+            *reinterpret_cast<float4 *>(B2 + 4) = *reinterpret_cast<const float4 *>(gb + 3 * C + c0 + 4);
+        }
         unsigned out[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float res[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int c = c0 + 2 * k + u;
+                const int j = 2 * k + u;
                 const float a1 = bf2f((bf16_t)(u ? w1[k] >> 16 : w1[k] & 0xffff));
-                float t = act_apply(fmaf((a1 - m1) * r1, g1[c], b1[c]), act);
+                float t = act_apply(fmaf((a1 - m1) * r1, G1[j], B1[j]), act);
                 if (y2) {
                     const float a2 = bf2f((bf16_t)(u ? w2[k] >> 16 : w2[k] & 0xffff));
-                    t += act_apply(fmaf((a2 - m2) * r2, g2[c], b2[c]), act);
+                    t += act_apply(fmaf((a2 - m2) * r2, G2[j], B2[j]), act);
                 }
                 res[u] = t;
             }
@@ -965,22 +985,33 @@ __global__ __launch_bounds__(256) void cb_gn_bwd_apply_kernel(const bf16_t *__re
     }
     const long long n8 = per_sample >> 3;
     const int C8 = C >> 3;
+    extern __shared__ float gb[];     // [2][C]: gamma, beta (see cb_gn_apply_kernel)
+    for (int c = threadIdx.x; c < C; c += 256) {
+        gb[c] = gamma[c];
+        gb[C + c] = beta[c];
+    }
+    __syncthreads();
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
         const int c0 = (int)((unsigned)i % (unsigned)C8) * 8;      // i < 2^32 (host check): a 64-bit modulo per item costs more than the item
         const size_t e = (size_t)b * per_sample + (size_t)i * 8;
         const uint4 gv = *reinterpret_cast<const uint4 *>(dz + e), yv = *reinterpret_cast<const uint4 *>(y + e);
         const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
+        float G[8], Bt[8];
+        *reinterpret_cast<float4 *>(G) = *reinterpret_cast<const float4 *>(gb + c0);
+        *reinterpret_cast<float4 *>(G + 4) = *reinterpret_cast<const float4 *>(gb + c0 + 4);
+        *reinterpret_cast<float4 *>(Bt) = *reinterpret_cast<const float4 *>(gb + C + c0);
+        *reinterpret_cast<float4 *>(Bt + 4) = *reinterpret_cast<const float4 *>(gb + C + c0 + 4);
         unsigned out[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float res[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int c = c0 + 2 * k + u;
+                const int j = 2 * k + u;
                 const float g = bf2f((bf16_t)(u ? gw[k] >> 16 : gw[k] & 0xffff));
                 const float xh = (bf2f((bf16_t)(u ? yw[k] >> 16 : yw[k] & 0xffff)) - mean) * rstd;
-                const float t = g * act_grad_from_pre(fmaf(xh, gamma[c], beta[c]), act);
-                res[u] = rstd * (gamma[c] * t - k1 - xh * k2);
+                const float t = g * act_grad_from_pre(fmaf(xh, G[j], Bt[j]), act);
+                res[u] = rstd * (G[j] * t - k1 - xh * k2);
             }
             out[k] = (unsigned)f2bf(res[0]) | ((unsigned)f2bf(res[1]) << 16);
         }
@@ -1865,14 +1896,14 @@ extern "C" int hno_cb_gn_apply(const void *y1, const float *mr1, const float *ga
                                int nstat1, int nstat2, float eps, void *stream) {
     HNO_REQUIRE(y1 && mr1 && gamma1 && beta1 && z && B > 0 && C > 0 && V > 0, "hno_cb_gn_apply: bad argument");
     HNO_REQUIRE(!y2 || (mr2 && gamma2 && beta2), "hno_cb_gn_apply: second branch incomplete");
-    if (C % 8) return fail(HNO_ELIMIT, "hno_cb_gn_apply: C = %d must be a multiple of 8", C);
+    if (C % 8 || C > 2048) return fail(HNO_ELIMIT, "hno_cb_gn_apply: C = %d must be a multiple of 8 (<= 2048)", C);
     hipStream_t s = (hipStream_t)stream;
     const long long per_sample = V * C;
     if (per_sample >= (1ll << 34)) return fail(HNO_ELIMIT, "hno_cb_gn_apply: %lld elements per sample exceed the kernel's 32-bit item index", per_sample);
     ProfScope _ps(KID_CB_GN, s, (double)B * per_sample * (y2 ? 6.0 : 4.0));
     // (lazy statistics: every workgroup re-reads the partials, so fewer, longer-running workgroups)
     const int cap = (nstat1 > 512 || nstat2 > 512) ? 1024 : 2048;
-    hipLaunchKernelGGL(cb_gn_apply_kernel, dim3(gsz(per_sample / 8, 256, cap), B), dim3(256), 0, s, (const bf16_t *)y1, mr1, gamma1, beta1,
+    hipLaunchKernelGGL(cb_gn_apply_kernel, dim3(gsz(per_sample / 8, 256, cap), B), dim3(256), 4 * (size_t)C * sizeof(float), s, (const bf16_t *)y1, mr1, gamma1, beta1,
                        (const bf16_t *)y2, mr2, gamma2, beta2, (bf16_t *)z, C, per_sample, act, nstat1, nstat2, eps, B);
     HNO_CHECK_LAUNCH();
     return HNO_OK;
@@ -1915,7 +1946,7 @@ extern "C" int hno_cb_gn_bwd(const void *dz, const void *y, const float *mr, con
             HNO_CHECK_LAUNCH();
         }
         ProfScope _ps2(KID_CB_GN, s, (double)B * V * C * 6.0);
-        hipLaunchKernelGGL(cb_gn_bwd_apply_kernel, dim3(gsz(V * C / 8, 256, 2048), B), dim3(256), 0, s, (const bf16_t *)dz, (const bf16_t *)y, mr, gamma,
+        hipLaunchKernelGGL(cb_gn_bwd_apply_kernel, dim3(gsz(V * C / 8, 256, 2048), B), dim3(256), 2 * (size_t)C * sizeof(float), s, (const bf16_t *)dz, (const bf16_t *)y, mr, gamma,
                            beta, (const float *)gS, (bf16_t *)dy, C, V * C, act, dy_colsum, B, (const float *)kpart, nblk, (const float *)slab, dgamma,
                            dbeta, gS, accumulate);
         HNO_CHECK_LAUNCH();
