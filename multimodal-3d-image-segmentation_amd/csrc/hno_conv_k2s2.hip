@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void conv_k2s2_bwd_kernel(K2Args a) {
 // FIXED: the HNOSeg-XS stem as every configuration of the reference builds it (4 -> 24 -> 24 channels, SELU twice) with all sizes and both
 // activations as compile-time constants: the generic form spends a third of its instructions on per-k-step / per-activation branches
 template <int KSO_MAX, bool FIXED>   // >= ceil(C1 / 2)
-__global__ __launch_bounds__(256, 2) void conv_k2s2_chain_bwd_kernel(K2Args a_) {
+__global__ __launch_bounds__(256, 2) void conv_k2s2_chain_bwd_kernel(K2Args a_, int k2_xcd_off) {
     extern __shared__ float lds[];
     K2Args a = a_;
     if constexpr (FIXED) { a.Cin = 4; a.Cout = 24; a.C1 = 24; a.act = HNO_ACT_SELU; a.act1 = HNO_ACT_SELU; }
@@ -522,9 +522,18 @@ __global__ __launch_bounds__(256, 2) void conv_k2s2_chain_bwd_kernel(K2Args a_) 
         return st;
     };
     St cur = {}, nxt = {};
-    if (blockIdx.x < ngroups) cur = fetch(blockIdx.x, 0);
+    // XCD-aware order (round 6): a tile's image rows start one float before a 128-byte line, so every row of a tile shares a line with the
+    // neighbouring tile (3 lines for 2: the 1.56x over-fetch of the round-4 PMC pass) -- and consecutive workgroups sit on different XCDs,
+    // each with its own L2.  With the group count split into 8 contiguous ranges, one per XCD (workgroup i: XCD i % 8, its (i / 8)-th
+    // worker), neighbouring tiles run on ONE XCD at about the same time and the shared line is an L2 hit.
+    const bool xcd = (gridDim.x & 7) == 0 && ngroups >= 8u * gridDim.x && !k2_xcd_off;
+    const unsigned R = (ngroups + 7) / 8, G8 = gridDim.x >> 3, xq = blockIdx.x & 7, jq = blockIdx.x >> 3;
+    const unsigned step = xcd ? G8 : gridDim.x, first = xcd ? jq : blockIdx.x;
+    const unsigned lim = xcd ? (xq * R + R <= ngroups ? R : (xq * R < ngroups ? ngroups - xq * R : 0u)) : ngroups;
+    const unsigned gbase = xcd ? xq * R : 0u;
+    if (first < lim) cur = fetch(gbase + first, 0);
     int slot = 0;
-    for (unsigned grp = blockIdx.x; grp < ngroups; grp += gridDim.x, slot ^= 1, cur = nxt) {
+    for (unsigned q = first; q < lim; q += step, slot ^= 1, cur = nxt) {
         float *Pc = P + slot * XS;
         dma_wait<0>();              // this tile's DMA and register loads are the only operations in flight (the kernel stores nothing)
         f32x16 accg, acc0;
@@ -545,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void conv_k2s2_chain_bwd_kernel(K2Args a_) 
             for (int ks = 0; ks < KS; ++ks)
                 if (!cur.ok[(ks >> 1) & 1][ks & 1]) Pc[ks * K2_XP + lane] = 0.f;
         }
-        if (grp + gridDim.x < ngroups) nxt = fetch(grp + gridDim.x, slot ^ 1);
+        if (q + step < lim) nxt = fetch(gbase + q + step, slot ^ 1);
         // conv_in's output of this tile, as the forward computed it (a lane reads back only patch elements it may have zeroed itself)
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks)
@@ -801,20 +810,21 @@ extern "C" int hno_conv_k2s2_chain_bwd(const float *gy1, const float *y1, const 
     if ((debug_grid()) && (debug_grid()) <= K2_CHAIN_SLABS) grid = debug_grid();
     const size_t lds = sizeof(float) * 4 * (2 * 32 * K2_LD + 2 * 16 * K2_XP);
     hipStream_t s = (hipStream_t)stream;
+    static const int xcd_off = getenv("HNO_K2_XCD") ? !atoi(getenv("HNO_K2_XCD")) : 0;      // A/B aid: HNO_K2_XCD=0 -> the round-robin tile order
     {
         ProfScope _ps(KID_CONV_K2S2_BWD, s, 4.0 * B * ((double)Cin * D * H * Wd + 2.0 * C1 * a.Do * a.Ho * a.Wo));
         if (Cin == 4 && C0 == 24 && C1 == 24 && act == HNO_ACT_SELU && act1 == HNO_ACT_SELU && !k2_fixed_off()) {
             static int attr = -1;
             if (attr != current_device()) { (void)hipFuncSetAttribute((const void *)conv_k2s2_chain_bwd_kernel<12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = current_device(); }
-            hipLaunchKernelGGL((conv_k2s2_chain_bwd_kernel<12, true>), dim3((int)grid), dim3(256), lds, s, a);
+            hipLaunchKernelGGL((conv_k2s2_chain_bwd_kernel<12, true>), dim3((int)grid), dim3(256), lds, s, a, xcd_off);
         } else if (C1 <= 24) {
             static int attr = -1;
             if (attr != current_device()) { (void)hipFuncSetAttribute((const void *)conv_k2s2_chain_bwd_kernel<12, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = current_device(); }
-            hipLaunchKernelGGL((conv_k2s2_chain_bwd_kernel<12, false>), dim3((int)grid), dim3(256), lds, s, a);
+            hipLaunchKernelGGL((conv_k2s2_chain_bwd_kernel<12, false>), dim3((int)grid), dim3(256), lds, s, a, xcd_off);
         } else {
             static int attr = -1;
             if (attr != current_device()) { (void)hipFuncSetAttribute((const void *)conv_k2s2_chain_bwd_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = current_device(); }
-            hipLaunchKernelGGL((conv_k2s2_chain_bwd_kernel<16, false>), dim3((int)grid), dim3(256), lds, s, a);
+            hipLaunchKernelGGL((conv_k2s2_chain_bwd_kernel<16, false>), dim3((int)grid), dim3(256), lds, s, a, xcd_off);
         }
     }
     HNO_CHECK_LAUNCH();
