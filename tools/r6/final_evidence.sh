@@ -40,10 +40,14 @@ python3 tools/bench_models.py fnoseg_cfg3 fnoseg_cfg3:bf16 hnoseg hartleymha vne
 python3 tools/bench_infer.py > $O/inference.jsonl 2>/dev/null; python3 tools/bench_infer.py --size 155 240 240 >> $O/inference.jsonl 2>/dev/null
 # the round's experiments: complementary kernels side by side, the fused inverse + pointwise probe, the block tail with bf16 tensors,
 # 64-byte against 128-byte row segments, the stagger
+if [ -z "$SKIP_EXPERIMENTS" ]; then
 python3 tools/r6/corun.py 2>/dev/null | tail -1 > $O/corun.jsonl
 python3 tools/r6/invpw_lab.py 2>/dev/null | tail -1 > $O/invpw_probe.json
 python3 tools/r6/branch_lab.py 2>/dev/null | tail -1 > $O/branch_lab.json
 SEG_B=8 ./tools/r6/seg_bench.bin > $O/seg_bench.txt 2>&1
 SPLIT=1 bash tools/r6/ab_env.sh "HNO_PW_STAGGER=0" "HNO_PW_STAGGER=2" > $O/ab_stagger.txt 2>&1
+fi
+# launch-ordered trace of one V-Net-DS cfg4 bf16 step (tools/r6/vnet_trace.sh)
+bash tools/r6/vnet_trace.sh $TAG/vnet_trace > /dev/null 2>&1; cp gpurun_out/$TAG/vnet_trace/step_trace.txt $O/vnet_step_trace.txt; rm -rf gpurun_out/$TAG/vnet_trace/prof
 find $O -name "*agent_info.csv" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*domain_stats.csv" -delete
 ls -R $O | head -70; tail -c 900 $O/bench.json
