@@ -543,13 +543,20 @@ int hno_adamax_chunk_rows(void);
 int hno_adamax_multi(const void *table, int n_chunks, float lr, float beta1, float beta2, float eps,
                      float weight_decay, long long step, float grad_scale, void *stream);
 /* Device-stepped form (round 4): step counter, learning-rate schedule and bias correction live in `state`, a DEVICE array of
- * hno_adamax_state_doubles() (= 9) doubles { step, lr of the next update, base_lr, eta_min, T_cur, T_i, T_mult, schedule (0 constant,
+ * hno_adamax_state_doubles() doubles (9 values, the kernel's ticket counter, the scheduler's tick count) { step, lr of the next update, base_lr, eta_min, T_cur, T_i, T_mult, schedule (0 constant,
  * 1 CosineAnnealingWarmRestarts stepped per optimizer step: experiments/run.py:92-103, train_test.py:173-174), clr (scratch) }.
  * A one-thread kernel advances the state, then the update runs with lr / (1 - beta1^step) read from it: no host value changes from
  * step to step, so the call can be captured into the training step's HIP graph (one graph replay per step and rank). */
 int hno_adamax_state_doubles(void);
 int hno_adamax_multi_dev(const void *table, int n_chunks, void *state, float beta1, float beta2, float eps, float weight_decay,
                          float grad_scale, void *stream);
+/* The same under torch.amp.GradScaler (round 6; experiments/train_test.py:79,154-168 drive GradScaler.step(optimizer) / update()): the
+ * optimizer declares `_step_supports_amp_scaling`, GradScaler then hands it two DEVICE scalars instead of synchronising on its inf
+ * check -- `amp_scale` (the gradients are still multiplied by it: divided here, written back unscaled) and `found_inf` (non-zero: the
+ * update is skipped, the step count stays, the schedule still ticks).  Either may be NULL.  state: hno_adamax_state_doubles() doubles,
+ * [10] = scheduler ticks. */
+int hno_adamax_multi_dev_amp(const void *table, int n_chunks, void *state, float beta1, float beta2, float eps, float weight_decay,
+                             float grad_scale, const float *amp_scale, const float *found_inf, void *stream);
 /* Join of two tensor sets (round 5): dst[i] = scale[i] * (a[i] + b[i]) elementwise for `count` fp32 tensors of n[i] elements; dst, a, b,
  * n, scale are HOST arrays (device pointers / sizes), dst[i] may alias a[i] or b[i].  One launch per 64 tensors, entries passed by value
  * in the kernel arguments: capturable into a HIP graph without a device table.  Replaces the torch._foreach_add_ / torch.lerp pair that

@@ -143,6 +143,7 @@ SIGNATURES = {
     'hno_adamax_multi': (c_int, [c_void_p, c_int] + [c_float] * 5 + [c_ll, c_float, c_void_p]),
     'hno_adamax_state_doubles': (c_int, []),
     'hno_adamax_multi_dev': (c_int, [c_void_p, c_int, c_void_p] + [c_float] * 5 + [c_void_p]),
+    'hno_adamax_multi_dev_amp': (c_int, [c_void_p, c_int, c_void_p, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     'hno_sum_pairs': (c_int, [c_void_p] * 5 + [c_int, c_void_p]),
     'hno_zscore_workspace_bytes': (c_size_t, [c_int]),
     'hno_zscore_modalities': (c_int, [c_void_p] * 4 + [c_int, c_ll, c_int, c_float, c_int, c_float, c_float, c_void_p]),

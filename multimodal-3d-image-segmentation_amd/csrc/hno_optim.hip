@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256) void adamax_multi_kernel(const AdamaxChunk *__
 //   [0] step (optimizer steps taken)   [1] lr (of the NEXT update)   [2] base_lr   [3] eta_min   [4] T_cur   [5] T_i   [6] T_mult
 //   [7] schedule: 0 = constant lr, 1 = CosineAnnealingWarmRestarts stepped once per optimizer step (experiments/run.py:92-103,
 //       train_test.py:173-174)          [8] clr = lr / (1 - beta1^(step + 1)) of the NEXT update          [9] ticket counter (bits)
+//   [10] scheduler ticks (differs from [0] only by the updates GradScaler skipped)
 //
 // The state is advanced by the LAST workgroup of the update kernel itself (a ticket counter behind the doubles; round 4b: a separate
 // one-thread kernel in front of the update cost a 5 us launch per step): every workgroup reads clr = st[8] at its start, takes a ticket
@@ -47,9 +48,12 @@ __global__ __launch_bounds__(256) void adamax_multi_kernel(const AdamaxChunk *__
 // torch.optim.lr_scheduler.CosineAnnealingWarmRestarts.step() does it: T_cur += 1; if T_cur >= T_i: T_cur -= T_i, T_i *= T_mult;
 // lr = eta_min + (base_lr - eta_min) (1 + cos(pi T_cur / T_i)) / 2, all in double;   st[8] = (float) lr / (1 - beta1^(step + 1)) for the
 // NEXT update (the host writes the first one: optim.Adamax.device_stepped);   ticket counter = 0.
-__device__ __forceinline__ void adamax_advance(double *st, double beta1) {
-    const double step = st[0] + 1.0;
+// skipped (round 6, GradScaler's found_inf): the update did not happen -- the optimizer's step count stays, the schedule still ticks (the
+// reference steps its scheduler after every batch, experiments/train_test.py:173-174, whether or not GradScaler.step() ran the optimizer)
+__device__ __forceinline__ void adamax_advance(double *st, double beta1, bool skipped = false) {
+    const double step = st[0] + (skipped ? 0.0 : 1.0);
     st[0] = step;
+    st[10] += 1.0;            // scheduler ticks (= the scheduler's last_epoch)
     if (st[7] == 1.0) {
         double T_cur = st[4] + 1.0, T_i = st[5];
         if (T_cur >= T_i) {
@@ -63,26 +67,40 @@ __device__ __forceinline__ void adamax_advance(double *st, double beta1) {
     st[8] = (double)(float)st[1] / (1.0 - pow(beta1, step + 1.0));      // (the eager entry point takes lr as a float: same rounding)
 }
 
+// amp_scale / found_inf (round 6): the two device scalars torch.amp.GradScaler hands an optimizer that declares
+// `_step_supports_amp_scaling` -- the gradients are still multiplied by *amp_scale and are divided here (by the float reciprocal taken
+// in double, the inv_scale GradScaler.unscale_ multiplies with; they are written back unscaled, as unscale_ leaves them), and a non-zero
+// *found_inf skips the whole update: no host reads either value, so GradScaler.step() / update() can sit inside the captured step.
 __global__ __launch_bounds__(256) void adamax_multi_dev_kernel(const AdamaxChunk *__restrict__ table, double *st, float beta1,
-                                                               float beta2, float eps, float wd, float gscale) {
+                                                               float beta2, float eps, float wd, float gscale,
+                                                               const float *__restrict__ amp_scale, const float *__restrict__ found_inf) {
     const AdamaxChunk c = table[blockIdx.x];
     const float clr = (float)st[8];
-    for (int i = threadIdx.x; i < c.n; i += 256) {
-        const float p = c.p[i];
-        const float g = fmaf(wd, p, c.g[i] * gscale);
-        float m = c.m[i];
-        m = fmaf(1.f - beta1, g - m, m);
-        const float u = fmaxf(beta2 * c.u[i], fabsf(g) + eps);
-        c.m[i] = m;
-        c.u[i] = u;
-        c.p[i] = p - clr * (m / u);
+    const bool skip = found_inf && *found_inf != 0.f;
+    if (!skip) {
+        const float inv = amp_scale ? (float)(1.0 / (double)*amp_scale) : 1.f;
+        for (int i = threadIdx.x; i < c.n; i += 256) {
+            const float p = c.p[i];
+            float gr = c.g[i];
+            if (amp_scale) {
+                gr *= inv;
+                const_cast<float *>(c.g)[i] = gr;
+            }
+            const float g = fmaf(wd, p, gr * gscale);
+            float m = c.m[i];
+            m = fmaf(1.f - beta1, g - m, m);
+            const float u = fmaxf(beta2 * c.u[i], fabsf(g) + eps);
+            c.m[i] = m;
+            c.u[i] = u;
+            c.p[i] = p - clr * (m / u);
+        }
     }
     __syncthreads();                                       // (every thread of this workgroup has read clr)
     if (threadIdx.x == 0) {
         unsigned *ticket = reinterpret_cast<unsigned *>(st + 9);
         __threadfence();
         if (atomicAdd(ticket, 1u) == gridDim.x - 1) {      // all workgroups are past their read of st[8]
-            adamax_advance(st, (double)beta1);
+            adamax_advance(st, (double)beta1, skip);
             *ticket = 0u;
             __threadfence();
         }
@@ -118,7 +136,7 @@ __global__ __launch_bounds__(256) void sum_pairs_kernel(PairBatch pb) {
 
 using namespace hno;
 
-extern "C" int hno_adamax_state_doubles(void) { return 10; }   // 9 doubles + the ticket counter
+extern "C" int hno_adamax_state_doubles(void) { return 11; }   // 9 doubles + the ticket counter + the scheduler's tick count
 
 // one Adamax step driven by the device state (see above); capturable: no host value changes from step to step
 extern "C" int hno_adamax_multi_dev(const void *table, int n_chunks, void *state, float beta1, float beta2, float eps, float weight_decay,
@@ -127,7 +145,19 @@ extern "C" int hno_adamax_multi_dev(const void *table, int n_chunks, void *state
     HNO_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "hno_adamax_multi_dev: bad hyper-parameter");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(adamax_multi_dev_kernel, dim3(n_chunks), dim3(256), 0, s, (const AdamaxChunk *)table, (double *)state, beta1, beta2,
-                       eps, weight_decay, grad_scale);
+                       eps, weight_decay, grad_scale, (const float *)nullptr, (const float *)nullptr);
+    HNO_CHECK_LAUNCH();
+    return HNO_OK;
+}
+
+// the same under torch.amp.GradScaler (see adamax_multi_dev_kernel): amp_scale / found_inf are DEVICE scalars (either may be NULL)
+extern "C" int hno_adamax_multi_dev_amp(const void *table, int n_chunks, void *state, float beta1, float beta2, float eps, float weight_decay,
+                                        float grad_scale, const float *amp_scale, const float *found_inf, void *stream) {
+    HNO_REQUIRE(table && n_chunks > 0 && state, "hno_adamax_multi_dev_amp: bad argument");
+    HNO_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "hno_adamax_multi_dev_amp: bad hyper-parameter");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adamax_multi_dev_kernel, dim3(n_chunks), dim3(256), 0, s, (const AdamaxChunk *)table, (double *)state, beta1, beta2,
+                       eps, weight_decay, grad_scale, amp_scale, found_inf);
     HNO_CHECK_LAUNCH();
     return HNO_OK;
 }

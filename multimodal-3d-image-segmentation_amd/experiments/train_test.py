@@ -240,8 +240,9 @@ class CapturedStep:
     128^3: 3.4 ms eager, 2.65 ms replayed).  A shape is captured on its SECOND occurrence (the first runs eagerly: it creates the
     twiddle tables and kernel attributes, which cannot be captured); at most `max_shapes` shapes are kept (the ragged last batch of
     an epoch then simply runs eagerly).  After a replay every parameter's ``.grad`` is the buffer the graph wrote, whatever eager
-    steps did in between.  Autocast runs (round 6): forward + loss + scaled backward are replayed, GradScaler's step / update (their inf check
-    synchronises) stay eager behind the replay.  Not used on CPU tensors."""
+    steps did in between.  Autocast runs (round 6): forward + loss + scaled backward are replayed; GradScaler's step / update join the
+    replay when the optimizer takes the scale and the inf flag as device tensors (optim.Adamax, device-stepped), otherwise they stay eager
+    behind it (their inf check synchronises).  Not used on CPU tensors."""
 
     def __init__(self, model, loss_fn, num_labels, label_mapping=None, data_parallel=None, max_shapes=2, optimizer=None, bucketed=None,
                  autocast=None, scaler=None):
@@ -258,8 +259,10 @@ class CapturedStep:
         # replay reads the current one).  scaler.step() / update() stay eager behind the replay: their inf check is a host
         # synchronisation, which is why round 3 left autocast runs eager altogether (FNOSeg cfg3: 7.6 ms eager, 5.2 ms replayed).
         self.autocast, self.scaler = autocast, scaler
-        if autocast is not None:
-            optimizer = None                 # the update belongs to scaler.step()
+        if autocast is not None and not (scaler is not None and getattr(optimizer, '_step_supports_amp_scaling', False)):
+            optimizer = None                 # the update belongs to an eager scaler.step()
+        # (round 6b: a device-stepped optim.Adamax takes GradScaler's scale and inf flag as device tensors, so scaler.step(optimizer) and
+        # scaler.update() have no host synchronisation and are captured behind the scaled backward: an autocast step is ONE replay too)
         self.optimizer = optimizer if (optimizer is not None and getattr(optimizer, 'is_device_stepped', False)) else None
         env = os.environ.get('HNO_DP_CAPTURE_ALLREDUCE', '')
         multi_rank = data_parallel is not None and getattr(data_parallel, 'real_world', 1) > 1
@@ -358,7 +361,11 @@ class CapturedStep:
                         if self.capture_allreduce:
                             self.dp.allreduce_flat()
                     if self.optimizer is not None:
-                        self.optimizer.step()
+                        if self.scaler is not None:
+                            self.scaler.step(self.optimizer)      # reference train_test.py:167-168
+                            self.scaler.update()
+                        else:
+                            self.optimizer.step()
             cur.wait_stream(side)
             torch.cuda.synchronize()
             if self.optimizer is not None:
@@ -544,8 +551,13 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
         use_graph = os.environ.get('HNO_TRAIN_GRAPH', '1') != '0' and isinstance(model, (HNOSegXS, NeuralOperatorSeg, HartleyMHASeg, VNetDS))
     captured, entered_dev_opt = None, False
     if use_graph and use_autocast and next(model.parameters()).is_cuda and os.environ.get('HNO_TRAIN_GRAPH_AUTOCAST', '1') != '0':
-        # round 6: forward + loss + scaled backward of an autocast run replayed from a graph; scaler.step() / update() eager behind it
-        captured = CapturedStep(model, loss_fn, num_labels, label_mapping, data_parallel if world > 1 else None, autocast=autocast, scaler=scaler)
+        # round 6: forward + loss + scaled backward of an autocast run replayed from a graph.  With our Adamax in device-stepped mode
+        # GradScaler.step() / update() join the graph (no host read of the inf check: optim.Adamax._step_supports_amp_scaling);
+        # otherwise (another optimizer, HNO_TRAIN_GRAPH_OPT=0) they stay eager behind the replay
+        if os.environ.get('HNO_TRAIN_GRAPH_OPT', '1') != '0' and hasattr(optimizer, 'device_stepped') and not optimizer.is_device_stepped:
+            entered_dev_opt = optimizer.device_stepped(scheduler)
+        captured = CapturedStep(model, loss_fn, num_labels, label_mapping, data_parallel if world > 1 else None, optimizer=optimizer,
+                                autocast=autocast, scaler=scaler)
     elif use_graph and not use_autocast and next(model.parameters()).is_cuda:
         # our Adamax moves its step counter, the learning rate and the per-batch cosine schedule onto the device, so that the update
         # is part of the captured step (HNO_TRAIN_GRAPH_OPT=0: keep optimizer and scheduler eager behind the replay)
@@ -566,10 +578,12 @@ def training(model, input_data, output_dir, loss_fn, optimizer, scheduler=None, 
                 if loss is not None:          # forward + loss + backward replayed; gradients (reduced over ranks) are in place
                     step_stats['replayed'] += 1
                     losses.append(loss.detach().clone())
-                    if scaler is not None:               # unscale, inf check (the step's one host synchronisation), update, new scale
+                    if captured.steps_optimizer:         # the update (under autocast: GradScaler's step + update) was part of the replay
+                        pass
+                    elif scaler is not None:             # unscale, inf check (a host synchronisation), update, new scale
                         scaler.step(optimizer)
                         scaler.update()
-                    elif not captured.steps_optimizer:
+                    else:
                         optimizer.step()
                     if scheduler is not None and not dev_opt:
                         scheduler.step()

@@ -28,12 +28,41 @@ class Adamax(torch.optim.Optimizer):
             raise ValueError(f'Invalid beta parameter at index 1: {betas[1]}')
         if weight_decay < 0.0:
             raise ValueError(f'Invalid weight_decay value: {weight_decay}')
+        self._amp_scale = None                # torch.amp.GradScaler's scale tensor while it drives step() (see `grad_scale` below)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self.grad_scale = float(grad_scale)   # e.g. 1 / world after a SUM all-reduce
+        self.grad_mul = float(grad_scale)     # a plain multiplier on every gradient, e.g. 1 / world after a SUM all-reduce
         self._tables = {}                     # pointer signature -> (device table, rows); eager-built entries may be evicted
         self._captured_tables = {}            # the same for tables built inside a graph capture: a graph reads them at every replay,
                                               # so they live as long as the optimizer (evicting one was a use-after-free)
         self._dev = None                      # device-stepped mode: (state tensor, scheduler or None)
+
+    # ---- torch.amp.GradScaler (round 6) ---------------------------------------------------------------------------------------
+    # An optimizer with `_step_supports_amp_scaling` gets two device tensors from GradScaler.step() -- `optimizer.grad_scale` (the
+    # gradients are still multiplied by it) and `optimizer.found_inf` -- instead of an unscale pass and a HOST read of the inf check
+    # (torch/amp/grad_scaler.py, the contract of torch's fused optimizers).  The device-stepped kernel divides, writes the gradients
+    # back unscaled and skips the update when an inf was found, so `scaler.step(optimizer); scaler.update()` of an autocast run
+    # (reference experiments/train_test.py:166-168) has no host synchronisation left and fits into the captured training step.
+    # Only in device-stepped mode: the host-stepped form would have to know about a skipped update to keep its step counters right.
+    @property
+    def _step_supports_amp_scaling(self):
+        return self._dev is not None
+
+    @property
+    def grad_scale(self):
+        if self._amp_scale is None:           # (GradScaler asks getattr(optimizer, 'grad_scale', 1) for a scale the user set: none)
+            raise AttributeError('grad_scale')
+        return self._amp_scale
+
+    @grad_scale.setter
+    def grad_scale(self, value):
+        if value is None or torch.is_tensor(value):
+            self._amp_scale = value
+        else:                                  # the meaning this attribute had before round 6: a plain multiplier
+            self.grad_mul = float(value)
+
+    @grad_scale.deleter
+    def grad_scale(self):
+        self._amp_scale = None
 
     # ---- device-stepped mode: the whole update is capturable into a HIP graph ------------------------------------------------
     def device_stepped(self, scheduler=None):
@@ -68,6 +97,9 @@ class Adamax(torch.optim.Optimizer):
         import numpy as np
         st[8] = float(np.float32(st[1])) / (1.0 - float(np.float32(group['betas'][0])) ** (step + 1.0))     # (beta1 reaches the kernels as a float)
         st.append(0.0)
+        # [10]: the scheduler's step() count (its last_epoch; normally the optimizer's step count -- both are stepped once per batch --,
+        # behind it only by the updates a GradScaler skipped)
+        st.append(float(scheduler.last_epoch) if scheduler is not None else step)
         assert _lib.lib().hno_adamax_state_doubles() == len(st)
         self._dev = (torch.tensor(st, dtype=torch.float64, device=params[0].device), scheduler)
         # scheduler.last_epoch counts its step() calls; it normally equals the optimizer's step count (both stepped once per batch)
@@ -95,8 +127,7 @@ class Adamax(torch.optim.Optimizer):
         if sched is not None:
             sched.T_cur, sched.T_i = (int(v[4]) if float(v[4]).is_integer() else v[4]), int(v[5])
             sched._last_lr = [v[1]]
-            # last_epoch counts scheduler.step() calls (one per optimizer step since the scheduler was created at step 0)
-            sched.last_epoch = int(v[0]) + self._sched_offset
+            sched.last_epoch = int(v[10])      # scheduler.step() calls so far (the kernel counts them: state [10])
 
     def leave_device_stepped(self):
         self.sync_from_device()
@@ -232,12 +263,25 @@ class Adamax(torch.optim.Optimizer):
             beta1, beta2 = group['betas']
             for t, tensors in by_step.items():
                 table, nrows = self._table(tensors)
+                amp_scale, found_inf = self._amp_scale, getattr(self, 'found_inf', None)
                 if self._dev is not None:
+                    if amp_scale is not None or found_inf is not None:      # driven by torch.amp.GradScaler
+                        for t_ in (amp_scale, found_inf):
+                            if t_ is not None and not (t_.is_cuda and t_.dtype == torch.float32 and t_.numel() == 1):
+                                raise _lib.HnoError('optim.Adamax: grad_scale / found_inf must be fp32 device scalars')
+                        check(L.hno_adamax_multi_dev_amp(table.data_ptr(), nrows, self._dev[0].data_ptr(), float(beta1), float(beta2),
+                                                         float(group['eps']), float(group['weight_decay']), self.grad_mul,
+                                                         None if amp_scale is None else amp_scale.data_ptr(),
+                                                         None if found_inf is None else found_inf.data_ptr(), stream_ptr()),
+                              'hno_adamax_multi_dev_amp')
+                        continue
                     check(L.hno_adamax_multi_dev(table.data_ptr(), nrows, self._dev[0].data_ptr(), float(beta1), float(beta2),
-                                                 float(group['eps']), float(group['weight_decay']), self.grad_scale, stream_ptr()),
+                                                 float(group['eps']), float(group['weight_decay']), self.grad_mul, stream_ptr()),
                           'hno_adamax_multi_dev')
                     continue
+                if amp_scale is not None or found_inf is not None:
+                    raise _lib.HnoError('optim.Adamax: GradScaler tensors reach step() only in device-stepped mode')
                 check(L.hno_adamax_multi(table.data_ptr(), nrows, float(group['lr']), float(beta1), float(beta2),
-                                         float(group['eps']), float(group['weight_decay']), t, self.grad_scale,
+                                         float(group['eps']), float(group['weight_decay']), t, self.grad_mul,
                                          stream_ptr()), 'hno_adamax_multi')
         return loss

@@ -1763,6 +1763,54 @@ def test_fused_adamax_matches_torch(pkg):
         Adamax(cpu_p).step()
 
 
+def test_adamax_under_grad_scaler_without_host_sync_matches_torch(pkg):
+    """The reference's autocast loop (experiments/train_test.py:166-174): scaler.scale(loss).backward(); scaler.step(optimizer);
+    scaler.update(); scheduler.step().  Our Adamax in device-stepped mode declares `_step_supports_amp_scaling`: GradScaler hands it
+    the scale and the inf flag as device tensors and never reads the flag on the host.  Against torch.optim.Adamax driven by its own
+    GradScaler on the same (GPU) gradients -- incl. a step with an inf gradient (update skipped, scale backed off, step count kept, the
+    schedule still ticks) and scale growth."""
+    from multimodal_3d_image_segmentation_amd.optim import Adamax
+    torch.manual_seed(5)
+    shapes = [(24, 48, 1, 1, 1), (24,), (5000,), (3, 7)]
+    ref_p = [torch.randn(s, device='cuda').requires_grad_(True) for s in shapes]
+    our_p = [p.detach().clone().requires_grad_(True) for p in ref_p]
+    kw = dict(lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    ref, our = torch.optim.Adamax(ref_p, **kw), Adamax(our_p, **kw)
+    sref = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(ref, T_0=4, eta_min=1e-3)
+    sour = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(our, T_0=4, eta_min=1e-3)
+    gs = dict(init_scale=1024.0, growth_interval=3)
+    scr, sco = torch.amp.GradScaler('cuda', **gs), torch.amp.GradScaler('cuda', **gs)
+    assert not our._step_supports_amp_scaling                 # host-stepped: GradScaler keeps its classic path
+    assert our.device_stepped(sour) and our._step_supports_amp_scaling
+    calls = []
+    orig_item = torch.Tensor.item
+    for it in range(9):
+        xs = [torch.randn(s, device='cuda') for s in shapes]
+        for params, opt, scaler in ((ref_p, ref, scr), (our_p, our, sco)):
+            opt.zero_grad(set_to_none=True)
+            loss = sum((p * x).sum() for p, x in zip(params, xs)) * (float('inf') if it == 4 else 1.0)
+            scaler.scale(loss).backward()
+        scr.step(ref), scr.update(), sref.step()
+        try:        # GradScaler must not read anything back for our optimizer
+            torch.Tensor.item = lambda self_, *a, **k: (calls.append(1), orig_item(self_, *a, **k))[1]
+            sco.step(our), sco.update()
+        finally:
+            torch.Tensor.item = orig_item
+        # (no sour.step(): the kernel ticks the schedule)
+        if it != 4:
+            for a, b in zip(ref_p, our_p):                   # after step() the gradients are unscaled, as GradScaler.unscale_ leaves them
+                assert rel_err(b.grad.cpu().numpy(), a.grad.cpu().numpy()) < 1e-6
+    assert not calls
+    assert not hasattr(our, 'found_inf') and our._amp_scale is None and our.grad_mul == 1.0
+    assert float(sco.get_scale()) == float(scr.get_scale())
+    our.sync_from_device()
+    for a, b in zip(ref_p, our_p):
+        assert rel_err(b.detach().cpu().numpy(), a.detach().cpu().numpy()) < 1e-6
+        assert rel_err(our.state[b]['exp_inf'].cpu().numpy(), ref.state[a]['exp_inf'].cpu().numpy()) < 1e-6
+        assert float(our.state[b]['step']) == float(ref.state[a]['step']) == 8.0       # nine batches, one skipped
+    assert sour.last_epoch == sref.last_epoch == 9 and abs(our.param_groups[0]['lr'] - ref.param_groups[0]['lr']) < 1e-12
+
+
 # --------------------------------------------------------------------- GPU-side input pipeline
 def test_zscore_modalities_vs_golden(pkg):
     from _inputs import raw_modalities
