@@ -25,7 +25,7 @@ tot = 0
 for r in seq:
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     tot += d
-    out.write('%9.1f %8.1f  %-70s grid %s/%s lds %s\n' % ((int(r['Start_Timestamp']) - t0) / 1e3, d, r['Kernel_Name'][:70], r.get('Grid_Size_X', r.get('Grid_Size')), r.get('Workgroup_Size_X', r.get('Workgroup_Size')), r.get('LDS_Block_Size', r.get('LDS_Block_Size_v', ''))))
+    out.write('%9.1f %8.1f  %-70s grid %s/%s lds %s\n' % ((int(r['Start_Timestamp']) - t0) / 1e3, d, r['Kernel_Name'][:70], str(r.get('Grid_Size_X')) + 'x' + str(r.get('Grid_Size_Y')) + 'x' + str(r.get('Grid_Size_Z')), r.get('Workgroup_Size_X', r.get('Workgroup_Size')), r.get('LDS_Block_Size', r.get('LDS_Block_Size_v', ''))))
 out.write('launches %d, sum of durations %.1f us, span %.1f us\n' % (len(seq), tot, (int(seq[-1]['End_Timestamp']) - t0) / 1e3))
 out.close()
 print(open('gpurun_out/$TAG/step_trace.txt').read()[-400:])
