@@ -185,6 +185,14 @@ __device__ __forceinline__ void dma_row_pair(const float *base, unsigned lane_by
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(lane_byte_off), "s"(base), "s"(lds_dst) : "memory");
 }
+// The same with the streaming hint `nt` (round 6, LESSONS 99): for rows that were written long ago and are read exactly once -- the saved
+// activations a backward kernel streams.  On the forward kernels' inputs (written by the previous launch) the hint costs time; on the
+// backward pointwise kernels' x rows it is worth 1.1 % of the headline step (six same-box pairs of two builds).
+__device__ __forceinline__ void dma_row_pair_nt(const float *base, unsigned lane_byte_off, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_byte_off), "s"(base), "s"(lds_dst) : "memory");
+}
 // At most N vector-memory operations stay in flight (DMA, loads and stores share one in-order counter).  N must not exceed the number
 // of operations CERTAINLY issued after the ones waited for: a larger N would let them stay in flight.
 template <int N>

@@ -939,7 +939,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && COUT <= 48) ? 2 : 1) void pwco
             for (int j = 0; j < NKI; ++j) {
                 const int i0 = 2 * j;
                 const float *base = i0 < CA ? xa_b + (size_t)i0 * V : xb_b + (size_t)(i0 - CA) * V;
-                dma_row_pair(base, off * 4u, __builtin_amdgcn_readfirstlane(x_lds + (slot * XS + j * PWB_XP) * 4));
+                dma_row_pair_nt(base, off * 4u, __builtin_amdgcn_readfirstlane(x_lds + (slot * XS + j * PWB_XP) * 4));
             }
         }
         if constexpr (IO16) {
@@ -1395,7 +1395,7 @@ __global__ __launch_bounds__(64 * NW, SLOTS == 1 ? 2 : 1) void pwconv_bwd_chain_
         for (int q = 0; q < NT; ++q)
 #pragma unroll
             for (int j = 0; j < NK; ++j)
-                dma_row_pair(srcs[q] + (size_t)(2 * j) * V, off * 4u, __builtin_amdgcn_readfirstlane(x_lds + (slot * XS + (q * NK + j) * PWB_XP) * 4));
+                dma_row_pair_nt(srcs[q] + (size_t)(2 * j) * V, off * 4u, __builtin_amdgcn_readfirstlane(x_lds + (slot * XS + (q * NK + j) * PWB_XP) * 4));
         // register loads issued BEHIND the DMAs: the wait hipcc places in front of their first use retires the DMAs too (in-order return)
         const size_t bo2 = (size_t)b * C2 * V;
         const float *gn_b = a.gn + bo2, *xn_b = a.xn + bo2;
