@@ -954,8 +954,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && COUT <= 48) ? 2 : 1) void pwco
 #pragma unroll
             for (int j = 0; j < NKI; ++j) {
                 const int i0 = 2 * j;
-                if (i0 < CA) px[j] = (xa_b + (size_t)i0 * V)[off];
-                else px[j] = __builtin_bit_cast(float, (unsigned)(xb16 + (size_t)(i0 - CA) * V)[off]);
+                // (saved activations, read once: streaming hint -- as dma_row_pair_nt in the DMA variants)
+                if (i0 < CA) px[j] = __builtin_nontemporal_load(xa_b + (size_t)i0 * V + off);
+                else px[j] = __builtin_bit_cast(float, (unsigned)__builtin_nontemporal_load(xb16 + (size_t)(i0 - CA) * V + off));
             }
         } else {
 #pragma unroll
@@ -969,7 +970,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && COUT <= 48) ? 2 : 1) void pwco
             for (int j = 0; j < NKI; ++j) {
                 const int i0 = 2 * j;
                 const float *base = i0 < CA ? xa_b + (size_t)i0 * V : xb_b + (size_t)(i0 - CA) * V;
-                px[j] = base[off];
+                px[j] = __builtin_nontemporal_load(base + off);
             }
         }
         }
