@@ -469,3 +469,26 @@ def test_traffic_file_keys_are_profiler_kernel_names():
     tj = json.load(open(os.path.join(root, 'profiles', 'hbm_traffic.json')))
     keys = set(tj.get('per_kernel_bytes_per_launch', tj))
     assert keys and keys <= names, keys - names
+
+
+def test_adamax_grad_scaler_contract_attributes():
+    """What torch.amp.GradScaler.step() does with an optimizer (torch/amp/grad_scaler.py): reads `_step_supports_amp_scaling`, then
+    getattr(optimizer, 'grad_scale', 1), sets `grad_scale` / `found_inf` to device tensors, calls step(), deletes both.  optim.Adamax
+    declares the support only in device-stepped mode; its old `grad_scale` float (a plain multiplier, 1 / world) lives on as `grad_mul`."""
+    from multimodal_3d_image_segmentation_amd.optim import Adamax
+    p = torch.zeros(3, requires_grad=True)
+    opt = Adamax([p], lr=1e-3, grad_scale=0.25)
+    assert opt.grad_mul == 0.25
+    assert opt._step_supports_amp_scaling is False              # host-stepped: GradScaler keeps its classic (synchronising) path
+    assert getattr(opt, 'grad_scale', 1) == 1                   # nothing set by a user: GradScaler multiplies its scale by 1
+    s = torch.tensor(1024.0)
+    opt.grad_scale = s
+    opt.found_inf = torch.tensor(0.0)
+    assert opt.grad_scale is s and opt.grad_mul == 0.25
+    del opt.grad_scale
+    del opt.found_inf
+    assert getattr(opt, 'grad_scale', 1) == 1 and not hasattr(opt, 'found_inf')
+    opt.grad_scale = None                                       # (GradScaler after a user's unscale_(): no scale left to divide by)
+    assert getattr(opt, 'grad_scale', 1) == 1
+    opt.grad_scale = 0.5                                        # the pre-round-6 meaning of the attribute
+    assert opt.grad_mul == 0.5
