@@ -531,6 +531,19 @@ int hno_upsoftmax_loss_bwd(const float *probs, const unsigned char *labels, cons
 int hno_labels_prepare(const float *labels_f32, const int *remap_from, const int *remap_to, int n_remap,
                        uint8_t *labels_u8, float *onehot, int B, int K, long long V, void *stream);
 
+/* ---- deep-supervision convolution over T equally wide tensors (round 6) --------------------------------------------------------------
+ * Replaces `torch.cat(tensors, dim=1)` + `conv_ds` (a k = 1 ConvNormAct, reference nets/architectures.py:341-343 and :196-199) and its
+ * backward: out[b, k, v] = bias[k] + sum_t sum_c W[t][k][c] x_t[b, c, v] in ONE launch, its backward (all T input gradients, the
+ * [T][K][C] weight gradient, the bias gradient) in one launch + one slab reduction.  x / gx: HOST arrays of T device pointers to
+ * (B, C, ld) fp32 tensors (channel stride ld >= V, padding untouched; gx entries or the array may be NULL); W: [T][K][C] -- the
+ * module's (K, T C) weight regrouped by leg.  hno_pwmulti_supported: the built shapes (K 2 ... 5, C 8 / 12 / 16 / 24, T <= 32). */
+int hno_pwmulti_supported(int T, int C, int K);
+int hno_pwmulti_fwd(const void *const *x, int T, int C, const float *W, const float *bias, float *out, int B, int K, long long V,
+                    long long ld, void *stream);
+size_t hno_pwmulti_bwd_workspace_bytes(int T, int C, int K, int B, long long V);
+int hno_pwmulti_bwd(const float *g, const void *const *x, void *const *gx, int T, int C, const float *W, float *dW, float *dbias,
+                    void *workspace, size_t workspace_bytes, int B, int K, long long V, long long ld, void *stream);
+
 /* ------------------------------------------------------------------ optimizer
  * Multi-tensor Adamax: ONE launch updates every parameter (replaces torch.optim.Adamax.step as driven by
  * experiments/run.py:89-91 / train_test.py:171; arithmetic of torch/optim/adamax.py):

@@ -143,6 +143,10 @@ SIGNATURES = {
     'hno_adamax_multi': (c_int, [c_void_p, c_int] + [c_float] * 5 + [c_ll, c_float, c_void_p]),
     'hno_adamax_state_doubles': (c_int, []),
     'hno_adamax_multi_dev': (c_int, [c_void_p, c_int, c_void_p] + [c_float] * 5 + [c_void_p]),
+    'hno_pwmulti_supported': (c_int, [c_int, c_int, c_int]),
+    'hno_pwmulti_fwd': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_ll, c_void_p]),
+    'hno_pwmulti_bwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_ll]),
+    'hno_pwmulti_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_ll, c_ll, c_void_p]),
     'hno_adamax_multi_dev_amp': (c_int, [c_void_p, c_int, c_void_p, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     'hno_sum_pairs': (c_int, [c_void_p] * 5 + [c_int, c_void_p]),
     'hno_zscore_workspace_bytes': (c_size_t, [c_int]),

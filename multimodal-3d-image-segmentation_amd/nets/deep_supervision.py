@@ -30,6 +30,18 @@ def conv_over_concat(conv_norm_act, tensors):
     w = op.weight.reshape(op.weight.shape[0], -1)
     chans = [t.shape[1] for t in tensors]
     same = len(set(chans)) == 1 and not w.is_meta
+    import os
+    if (same and len(tensors) > 1 and os.environ.get('HNO_DS_MULTI', '1') != '0' and ops.MultiPwConvFn.supported(tensors, w.shape[0])):
+        # round 6: all legs in ONE launch each way (csrc/hno_pwmulti.hip) instead of a pointwise convolution + an add per leg; the
+        # (K, T C) weight regrouped by leg -- (T, K, C) -- by one permuting copy (and one back for its gradient)
+        K, T = w.shape[0], len(tensors)
+        w_tkc = w.reshape(K, T, chans[0]).permute(1, 0, 2).contiguous()
+        acc = ops.MultiPwConvFn.apply(w_tkc, op.bias, *tensors)
+        act = ops.act_id(conv_norm_act.activation)
+        if conv_norm_act.normalization is not None:
+            from .conv3d import group_norm_act
+            return group_norm_act(acc, conv_norm_act.normalization, act)
+        return ops.ActFn.apply(acc, act) if act != ops.ACT_NONE else acc
     legs = _LegWeights.apply(w, len(tensors)) if same else None
     acc, c0 = None, 0
     for i, t in enumerate(tensors):

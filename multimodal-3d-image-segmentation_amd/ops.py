@@ -1657,6 +1657,66 @@ class PwConvFn(_HnoFunction):
         return gxa, gxb, dW, db, None
 
 
+class MultiPwConvFn(_HnoFunction):
+    """bias + sum_t W[t] x_t over T equally wide tensors: torch.cat(tensors, dim=1) + a k = 1 convolution (the reference's
+    deep-supervision head, nets/architectures.py:341-343) as ONE launch each way (hno_pwmulti_fwd / hno_pwmulti_bwd).
+
+        forward(w_tkc (T, K, C), bias (K,) or None, *tensors (B, C, ...)) -> (B, K, ...)"""
+
+    @staticmethod
+    def supported(tensors, K):
+        t0 = tensors[0]
+        if t0.is_meta:
+            return True
+        if not (t0.is_cuda and t0.dtype == torch.float32 and t0.ndim == 5):
+            return False
+        ld = chan_stride(t0)
+        same = all(t.shape == t0.shape and t.dtype == t0.dtype and t.device == t0.device and chan_stride(t) == ld
+                   and (ld is not None or t.is_contiguous()) for t in tensors)
+        return bool(same and _lib.lib().hno_pwmulti_supported(len(tensors), t0.shape[1], K))
+
+    @staticmethod
+    def meta(w, bias, *tensors):
+        return _m((tensors[0].shape[0], w.shape[1]) + tuple(tensors[0].shape[2:]))
+
+    @staticmethod
+    def forward(ctx, w, bias, *tensors):
+        import ctypes
+        _need_gpu(w, bias, *tensors)
+        w, bias = _f32c(w), _f32c(bias)
+        T, K, C = w.shape
+        t0 = tensors[0]
+        assert len(tensors) == T and t0.shape[1] == C
+        ld = chan_stride(t0)
+        V = ld or _flat_v(t0)           # channel-padded operands: the kernel runs over V := ld voxels per channel (pwconv_fwd_raw)
+        out = act_like(t0, K)
+        xs = (ctypes.c_void_p * T)(*[t.data_ptr() for t in tensors])
+        check(_lib.lib().hno_pwmulti_fwd(xs, T, C, ptr(w), ptr(bias), ptr(out), t0.shape[0], K, V, V, stream_ptr()), 'hno_pwmulti_fwd')
+        ctx.save_for_backward(w, *tensors)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        w, *tensors = ctx.saved_tensors
+        T, K, C = w.shape
+        t0 = tensors[0]
+        ld = chan_stride(t0)
+        V, B = ld or _flat_v(t0), t0.shape[0]          # (g's padding is zero: to_layout)
+        g = to_layout(_f32a(g), ld)
+        L = _lib.lib()
+        gxs = [act_like(t) if ctx.needs_input_grad[2 + i] else None for i, t in enumerate(tensors)]
+        dW = torch.empty_like(w)
+        db = torch.empty(K, device=w.device, dtype=torch.float32) if ctx.has_bias else None
+        nws = L.hno_pwmulti_bwd_workspace_bytes(T, C, K, B, V)
+        ws = torch.empty(max(nws // 4, 4), device=w.device, dtype=torch.float32)
+        xs = (ctypes.c_void_p * T)(*[t.data_ptr() for t in tensors])
+        gp = (ctypes.c_void_p * T)(*[(None if t is None else t.data_ptr()) for t in gxs])
+        check(L.hno_pwmulti_bwd(ptr(g), xs, gp, T, C, ptr(w), ptr(dW), ptr(db), ptr(ws), nws, B, K, V, V, stream_ptr()), 'hno_pwmulti_bwd')
+        return (dW, db) + tuple(gxs)
+
+
 class ComplexMixFn(_HnoFunction):
     """Complex shared-weight channel mix on the [re | im] layout (nets/fourier_operator.py:164-172):
     spec (B, 2Ci, ...) -> (B, 2Co, ...) with W = weight_real + i weight_imag, as one real pointwise conv with the

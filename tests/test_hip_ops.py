@@ -2658,3 +2658,42 @@ def test_hnosegxs_with_many_classes_vs_oracle(pkg, classes):
     with torch.no_grad(), pkg.ops.label_output():
         labels = model(x)
     assert float((labels.cpu().long().reshape(-1) != y_ref.argmax(1).reshape(-1)).float().mean()) < 1e-3
+
+
+@pytest.mark.parametrize('T,C,K,shape,padded', [(17, 12, 4, (1, 13, 11, 9), True), (3, 24, 5, (2, 6, 5, 7), False), (5, 8, 2, (2, 9, 9, 9), True),
+                                                (2, 16, 3, (1, 4, 5, 6), False)])
+def test_deep_supervision_conv_over_all_legs_vs_float64(pkg, T, C, K, shape, padded):
+    """torch.cat(tensors, dim=1) -> Conv3d(k = 1, bias) (reference nets/architectures.py:341-343) as hno_pwmulti_fwd / _bwd: outputs, all
+    input gradients, weight and bias gradients against float64; channel-padded and contiguous activations; bit-reproducible."""
+    ops = pkg.ops
+    torch.manual_seed(T + C)
+    B, sp = shape[0], shape[1:]
+    xs64 = [torch.randn((B, C) + sp, dtype=torch.float64, requires_grad=True) for _ in range(T)]
+    w64 = (torch.randn(K, T * C, dtype=torch.float64) * 0.3).requires_grad_(True)
+    b64 = torch.randn(K, dtype=torch.float64, requires_grad=True)
+    ref = F.conv3d(torch.cat(xs64, dim=1), w64.reshape(K, T * C, 1, 1, 1), b64)
+    cot = torch.randn_like(ref)
+    ref.backward(cot)
+
+    def dev(t):
+        t = t.detach().float().cuda()
+        if padded:
+            t = ops.to_layout(t, ops._pad_ld(int(np.prod(sp))))        # channel stride rounded up to 32 voxels, padding zero
+            assert ops.chan_stride(t) is not None
+        return t.requires_grad_(True)
+    xs = [dev(t) for t in xs64]
+    assert ops.MultiPwConvFn.supported(xs, K)
+    w = w64.detach().float().cuda().requires_grad_(True)
+    b = b64.detach().float().cuda().requires_grad_(True)
+    w_tkc = w.reshape(K, T, C).permute(1, 0, 2).contiguous()
+    out = ops.MultiPwConvFn.apply(w_tkc, b, *xs)
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < 2e-6
+    out.backward(cot.float().cuda())
+    for a, r in zip(xs, xs64):
+        assert rel_err(a.grad.cpu().numpy(), r.grad.numpy()) < 2e-6
+    assert rel_err(w.grad.cpu().numpy(), w64.grad.numpy()) < 1e-5
+    assert rel_err(b.grad.cpu().numpy(), b64.grad.numpy()) < 1e-5
+    g1 = w.grad.clone()
+    w.grad = None
+    ops.MultiPwConvFn.apply(w.reshape(K, T, C).permute(1, 0, 2).contiguous(), b, *xs).backward(cot.float().cuda())
+    assert torch.equal(g1, w.grad)
