@@ -900,7 +900,8 @@ extern "C" int hno_nearest3d(const float *src, float *dst, int BC, int d, int h,
     else
     {
         const double box = ((double)D / d) * ((double)H / h) * ((double)W / w);   // source voxels per low-resolution voxel
-        if (box >= 48.0) {
+        static const double wave_box = getenv("HNO_NN_WAVE_BOX") ? atof(getenv("HNO_NN_WAVE_BOX")) : 100.0;     // A/B aid (48 until round 6: the 57-voxel boxes of a V-Net leg took 61 us with a wave each; cfg4 step 6.28 -> 6.23 ms)
+        if (box >= wave_box) {
             size_t g = ((size_t)BC * d * h * w + 3) / 4;
             if (g > 16384) g = 16384;
             hipLaunchKernelGGL(nn_down_wave_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a);
