@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256) void hmha_kernel(HmArgs a) {
 //     score product reads along tokens (conflict-free), the accumulation down channels (2-way: pairs share a bank -- 4 LDS cycles
 //     per 64-cycle MFMA).
 #define HM2_PITCH 65
+#define HM_SPLIT_DEFAULT 7      // (bits: MODE 0 / 1 / 2 in split precision)
 #define HM2_PITCH4 36
 template <int MODE, int CKT, int CVT, bool X4>
 __global__ __launch_bounds__(256, MODE == 2 ? 1 : 2) void hmha2_kernel(HmArgs a, float *part0, float *part1) {
@@ -431,6 +432,328 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : 2) void hmha2_kernel(HmArgs a,
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 6: the same products in SPLIT PRECISION on the bf16 matrix cores.
+//
+// hmha2_kernel spends 6 144 matrix-pipe cycles per 32 x 32 score tile on v_mfma_f32_32x32x2_f32 (64 cycles for 4 K flops).  An fp32
+// value is x = x0 + x1 + x2 with x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1) -- 24 significant bits -- and a product
+//     a b = a0 b0 + a0 b1 + a1 b0 + a0 b2 + a1 b1 + a2 b0 + O(2^-24 |a b|)
+// is six v_mfma_f32_32x32x16_bf16 (32 cycles for 32 K flops each, fp32 accumulation; every bf16 x bf16 product is exact in fp32): 2.7x
+// fewer matrix cycles for fp32-level results (a timing probe with these instruction counts took the HartleyMHASeg step from 10.1 to
+// 7.9 ms before the cost of the splits: LESSONS 101).  The splits are VALU work, so the STREAMED tiles are split ONCE per workgroup --
+// the four waves used to read the same fp32 tile -- by the threads that stage them: global -> registers (a tile ahead of the products) ->
+// three bf16 planes in LDS, in the layout each product reads with 16- / 8-byte LDS loads:
+//     TK[term][token][channel]   the score product's A operand (8 consecutive channels of a token per lane)
+//     CT[term][channel][token]   the accumulation's A operand (2 x 4 consecutive tokens of a channel per lane, in the accumulator's
+//                                k-slot order (i & 3) + 8 (i >> 2) + 4 h, so that the score tile P is again the B operand as it lies
+//                                in the registers -- split per lane)
+// The owner's fragments are split once in the prologue.  T % 4 == 0 (16-byte token quads).
+typedef __bf16 hbf8 __attribute__((ext_vector_type(8)));
+struct HmT3 { uint4 t[3]; };            // three bf16 terms of eight values
+
+// bf16 terms by integer arithmetic: round half up in magnitude ((bits + 0x8000) & 0xffff0000: the same 2^-9 bound as the conversion
+// instruction; the term IS an fp32 number, so the remainder x - x0 is exact), the two 16-bit halves of a pair packed by ONE v_perm_b32.
+// ~7 instructions per value; the v_cvt / shift / pack sequence of the first version was ~12 and made the kernel VALU-bound.
+__device__ __forceinline__ void hm_split_pair(float a, float b, unsigned &p0, unsigned &p1, unsigned &p2) {
+    const unsigned M = 0xffff0000u;
+    const unsigned a0 = (__builtin_bit_cast(unsigned, a) + 0x8000u) & M, b0 = (__builtin_bit_cast(unsigned, b) + 0x8000u) & M;
+    p0 = __builtin_amdgcn_perm(b0, a0, 0x07060302u);
+    const float ra = a - __builtin_bit_cast(float, a0), rb = b - __builtin_bit_cast(float, b0);
+    const unsigned a1 = (__builtin_bit_cast(unsigned, ra) + 0x8000u) & M, b1 = (__builtin_bit_cast(unsigned, rb) + 0x8000u) & M;
+    p1 = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
+    const float sa = ra - __builtin_bit_cast(float, a1), sb = rb - __builtin_bit_cast(float, b1);
+    p2 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sb) + 0x8000u, __builtin_bit_cast(unsigned, sa) + 0x8000u, 0x07060302u);
+}
+__device__ __forceinline__ HmT3 hm_split8(const float (&v)[8]) {
+    HmT3 o;
+    hm_split_pair(v[0], v[1], o.t[0].x, o.t[1].x, o.t[2].x);
+    hm_split_pair(v[2], v[3], o.t[0].y, o.t[1].y, o.t[2].y);
+    hm_split_pair(v[4], v[5], o.t[0].z, o.t[1].z, o.t[2].z);
+    hm_split_pair(v[6], v[7], o.t[0].w, o.t[1].w, o.t[2].w);
+    return o;
+}
+// D (+)= A B in split precision: two accumulators (the six products alternate) keep two independent chains in the matrix pipe
+__device__ __forceinline__ void hm_mfma6(f32x16h &d0, f32x16h &d1, const HmT3 &a, const HmT3 &b) {
+#define HM_BF(x) __builtin_bit_cast(hbf8, x)
+    d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(HM_BF(a.t[0]), HM_BF(b.t[0]), d0, 0, 0, 0);
+    d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(HM_BF(a.t[0]), HM_BF(b.t[1]), d1, 0, 0, 0);
+    d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(HM_BF(a.t[1]), HM_BF(b.t[0]), d0, 0, 0, 0);
+    d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(HM_BF(a.t[0]), HM_BF(b.t[2]), d1, 0, 0, 0);
+    d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(HM_BF(a.t[1]), HM_BF(b.t[1]), d0, 0, 0, 0);
+    d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(HM_BF(a.t[2]), HM_BF(b.t[0]), d1, 0, 0, 0);
+#undef HM_BF
+}
+
+template <int MODE, int CKT, int CVT>
+__global__ __launch_bounds__(256, MODE == 0 ? 2 : 1) void hmha3_kernel(HmArgs a, float *part0, float *part1) {
+    extern __shared__ unsigned short sm16[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int bz = blockIdx.z, nsplit = gridDim.y, e = blockIdx.y;
+    const int o0 = (blockIdx.x * 4 + wave) * 32;            // this wave's owned tokens
+    const int T = a.T, Ck = a.Ck, Cv = a.Cv;
+    constexpr int CKP = 32 * CKT, CVP = 32 * CVT;
+    constexpr int NJK = CKP / 16, NJV = CVP / 16;           // 16-channel chunks of a score product
+    // LDS planes (bf16 elements).  TK rows: CP + 8 (16-byte row alignment, rows 2 banks apart per 8 channels); CT rows: 32 + 8
+    constexpr int PK1 = CKP + 8, PV1 = CVP + 8, P2 = 40;
+    // which planes a mode keeps:            S1 (K / K / Q)              S2 (V / V / dO)
+    constexpr bool S1_TK = true, S1_CT = MODE != 0, S2_TK = MODE != 0, S2_CT = MODE != 1;
+    constexpr int O_S1TK = 0;
+    constexpr int O_S1CT = O_S1TK + (S1_TK ? 3 * 32 * PK1 : 0);
+    constexpr int O_S2TK = O_S1CT + (S1_CT ? 3 * CKP * P2 : 0);
+    constexpr int O_S2CT = O_S2TK + (S2_TK ? 3 * 32 * PV1 : 0);
+    const float *Q = a.q + (size_t)bz * Ck * T, *K = a.k + (size_t)bz * Ck * T;
+    const float *V = a.v + (size_t)bz * Cv * T, *dO = MODE ? a.dout + (size_t)bz * Cv * T : nullptr;
+    const bool active = o0 < T;                              // (wave-uniform; idle waves still stage and keep the barriers)
+    const bool own_ok = o0 + r < T;
+    // ---- the owner's fragments, split once: chunk j, lane half h: channels 16 j + 8 h .. + 7 of token o0 + r
+    HmT3 f1[NJK], f2[MODE ? NJV : 1];
+    {
+        const float *X1 = MODE == 2 ? K : Q;
+#pragma unroll
+        for (int j = 0; j < NJK; ++j) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = 16 * j + 8 * h + u;
+                v[u] = (c < Ck && own_ok) ? X1[(size_t)c * T + o0 + r] : 0.f;
+            }
+            f1[j] = hm_split8(v);
+        }
+        if constexpr (MODE != 0) {
+            const float *X2 = MODE == 2 ? V : dO;
+#pragma unroll
+            for (int j = 0; j < NJV; ++j) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = 16 * j + 8 * h + u;
+                    v[u] = (c < Cv && own_ok) ? X2[(size_t)c * T + o0 + r] : 0.f;
+                }
+                f2[j] = hm_split8(v);
+            }
+        }
+    }
+    constexpr int CT1 = MODE == 1 ? CKT : CVT;
+    f32x16h acc1[CT1], acc2[MODE == 2 ? CKT : 1];      // (one chain per channel tile: the tiles' chains interleave in the matrix pipe)
+#pragma unroll
+    for (int ct = 0; ct < CT1; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc1[ct][i] = 0.f;
+    if constexpr (MODE == 2)
+#pragma unroll
+        for (int ct = 0; ct < CKT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc2[ct][i] = 0.f;
+
+    const int ntile = (T + 31) / 32;
+    const float ap = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE : 1.f;
+    const float aq = a.act == HNO_ACT_SELU ? HNO_SELU_SCALE * HNO_SELU_ALPHA : 1.f;
+    const bool lin = a.act == HNO_ACT_NONE;
+    const int st_lo = (int)((long long)ntile * e / nsplit), st_hi = (int)((long long)ntile * (e + 1) / nsplit);
+    const float *S1 = MODE == 2 ? Q : K, *S2 = MODE == 2 ? dO : V;
+    // ---- staging.  TK shape: thread (token = tid & 31, q = tid >> 5) takes 4 CT channels of its token; CT shape: item = (channel,
+    // token quad), CT items per thread.  Tokens beyond T re-read valid ones (their score rows are masked below).
+    constexpr int NV1 = 4 * CKT, NV2 = 4 * CVT;
+    float g1tk[S1_TK ? NV1 : 1], g2tk[S2_TK ? NV2 : 1];
+    float4 g1ct[S1_CT ? CKT : 1], g2ct[S2_CT ? CVT : 1];
+    const int tkt = threadIdx.x & 31, tkq = threadIdx.x >> 5;
+    auto fetch = [&](int st) {
+        const int tok = st * 32 + tkt < T ? st * 32 + tkt : T - 1;
+        if constexpr (S1_TK) {
+#pragma unroll
+            for (int u = 0; u < NV1; ++u) {
+                const int c = NV1 * tkq + u;
+                g1tk[u] = c < Ck ? S1[(size_t)c * T + tok] : 0.f;
+            }
+        }
+        if constexpr (S2_TK) {
+#pragma unroll
+            for (int u = 0; u < NV2; ++u) {
+                const int c = NV2 * tkq + u;
+                g2tk[u] = c < Cv ? S2[(size_t)c * T + tok] : 0.f;
+            }
+        }
+        if constexpr (S1_CT) {
+#pragma unroll
+            for (int n = 0; n < CKT; ++n) {
+                const int item = threadIdx.x + 256 * n, c = item >> 3, q4 = item & 7;
+                const int tk = st * 32 + 4 * q4 + 4 <= T ? st * 32 + 4 * q4 : T - 4;
+                g1ct[n] = c < Ck ? *reinterpret_cast<const float4 *>(S1 + (size_t)c * T + tk) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        if constexpr (S2_CT) {
+#pragma unroll
+            for (int n = 0; n < CVT; ++n) {
+                const int item = threadIdx.x + 256 * n, c = item >> 3, q4 = item & 7;
+                const int tk = st * 32 + 4 * q4 + 4 <= T ? st * 32 + 4 * q4 : T - 4;
+                g2ct[n] = c < Cv ? *reinterpret_cast<const float4 *>(S2 + (size_t)c * T + tk) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto put_tk = [&](const float *g, int NV, int base, int pitch) {
+        // NV consecutive channels of token tkt -> the three planes, 4-byte pairs
+#pragma unroll
+        for (int u = 0; u < NV; u += 2) {
+            unsigned p0, p1, p2;
+            hm_split_pair(g[u], g[u + 1], p0, p1, p2);
+            const int off = base + tkt * pitch + NV * tkq + u;
+            *reinterpret_cast<unsigned *>(sm16 + off) = p0;
+            *reinterpret_cast<unsigned *>(sm16 + off + 32 * pitch) = p1;
+            *reinterpret_cast<unsigned *>(sm16 + off + 64 * pitch) = p2;
+        }
+    };
+    auto put_ct = [&](const float4 *g, int CTn, int CP, int base) {
+#pragma unroll
+        for (int n = 0; n < CTn; ++n) {
+            const int item = threadIdx.x + 256 * n, c = item >> 3, q4 = item & 7;
+            unsigned a0, a1, a2, b0, b1, b2;
+            hm_split_pair(g[n].x, g[n].y, a0, a1, a2);
+            hm_split_pair(g[n].z, g[n].w, b0, b1, b2);
+            const int off = base + c * P2 + 4 * q4;
+            *reinterpret_cast<uint2 *>(sm16 + off) = make_uint2(a0, b0);
+            *reinterpret_cast<uint2 *>(sm16 + off + CP * P2) = make_uint2(a1, b1);
+            *reinterpret_cast<uint2 *>(sm16 + off + 2 * CP * P2) = make_uint2(a2, b2);
+        }
+    };
+    auto store = [&]() {
+        if constexpr (S1_TK) put_tk(g1tk, NV1, O_S1TK, PK1);
+        if constexpr (S2_TK) put_tk(g2tk, NV2, O_S2TK, PV1);
+        if constexpr (S1_CT) put_ct(g1ct, CKT, CKP, O_S1CT);
+        if constexpr (S2_CT) put_ct(g2ct, CVT, CVP, O_S2CT);
+    };
+    // operand fetches
+    auto tk_operand = [&](int base, int pitch, int j) {      // score A operand of chunk j: streamed token r, channels 16 j + 8 h .. + 7
+        HmT3 o;
+        const int off = base + r * pitch + 16 * j + 8 * h;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) o.t[t] = *reinterpret_cast<const uint4 *>(sm16 + off + t * 32 * pitch);
+        return o;
+    };
+    auto ct_operand = [&](int base, int CP, int ct, int j) {  // accumulation A operand: channel 32 ct + r, tokens 16 j + 4 h + {0..3, 8..11}
+        HmT3 o;
+        const int off = base + (32 * ct + r) * P2 + 16 * j + 4 * h;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const uint2 lo = *reinterpret_cast<const uint2 *>(sm16 + off + t * CP * P2), hi = *reinterpret_cast<const uint2 *>(sm16 + off + t * CP * P2 + 8);
+            o.t[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+        return o;
+    };
+    auto split_chunk = [&](const f32x16h &Pm, int j) {    // chunk j = registers 8 j .. 8 j + 7 (the accumulator's own k-slot order)
+        const float v[8] = {Pm[8 * j], Pm[8 * j + 1], Pm[8 * j + 2], Pm[8 * j + 3], Pm[8 * j + 4], Pm[8 * j + 5], Pm[8 * j + 6], Pm[8 * j + 7]};
+        return hm_split8(v);
+    };
+
+    if (st_lo < st_hi) {
+        fetch(st_lo);
+        store();
+    }
+    __syncthreads();
+    for (int st = st_lo; st < st_hi; ++st) {
+        if (st + 1 < st_hi) fetch(st + 1);                   // global loads in flight during this tile's products
+        if (active) {
+            f32x16h G0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) G0[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJK; ++j) {
+                const HmT3 av = tk_operand(O_S1TK, PK1, j);
+                hm_mfma6(G0, G0, av, f1[j]);
+            }
+            const int sbase = st * 32 + 4 * h;
+            f32x16h P;                                       // act(alpha G), rows of tokens beyond T zero
+            if (lin) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) P[i] = sbase + (i & 3) + 8 * (i >> 2) < T ? a.alpha * G0[i] : 0.f;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    const f32x2 y = selu_like_pk(f32x2{a.alpha * G0[i], a.alpha * G0[i + 1]}, ap, aq);
+                    P[i] = sbase + (i & 3) + 8 * (i >> 2) < T ? y[0] : 0.f;
+                    P[i + 1] = sbase + ((i + 1) & 3) + 8 * ((i + 1) >> 2) < T ? y[1] : 0.f;
+                }
+            }
+            if constexpr (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const HmT3 Pj = split_chunk(P, j);
+#pragma unroll
+                    for (int ct = 0; ct < CVT; ++ct) hm_mfma6(acc1[ct], acc1[ct], ct_operand(O_S2CT, CVP, ct, j), Pj);      // out += V (x) P
+                }
+            } else {
+                f32x16h H0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) H0[i] = 0.f;
+#pragma unroll
+                for (int j = 0; j < NJV; ++j) {
+                    const HmT3 av = tk_operand(O_S2TK, PV1, j);
+                    hm_mfma6(H0, H0, av, f2[j]);
+                }
+                f32x16h dS;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float gr = (lin || P[i] > 0.f) ? ap : P[i] + aq;
+                    const float d = a.alpha * H0[i] * gr;
+                    dS[i] = sbase + (i & 3) + 8 * (i >> 2) < T ? d : 0.f;
+                }
+                if constexpr (MODE == 1) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const HmT3 Dj = split_chunk(dS, j);
+#pragma unroll
+                        for (int ct = 0; ct < CKT; ++ct) hm_mfma6(acc1[ct], acc1[ct], ct_operand(O_S1CT, CKP, ct, j), Dj);  // dQ += K (x) dS^T
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const HmT3 Pj = split_chunk(P, j);
+#pragma unroll
+                        for (int ct = 0; ct < CVT; ++ct) hm_mfma6(acc1[ct], acc1[ct], ct_operand(O_S2CT, CVP, ct, j), Pj);  // dV += dOut (x) P
+                        const HmT3 Dj = split_chunk(dS, j);
+#pragma unroll
+                        for (int ct = 0; ct < CKT; ++ct) hm_mfma6(acc2[ct], acc2[ct], ct_operand(O_S1CT, CKP, ct, j), Dj);  // dK += Q (x) dS
+                    }
+                }
+            }
+        }
+        __syncthreads();                                     // every wave has read tile st
+        if (st + 1 < st_hi) store();
+        __syncthreads();                                     // tile st + 1 is in place
+    }
+    // ---- this wave's partial tiles (hmha2_kernel's layout)
+    if (active && own_ok) {
+        const int C1 = MODE == 1 ? Ck : Cv;
+        float *d0 = part0 + (((size_t)e * a.BZ + bz) * C1) * T + o0 + r;
+#pragma unroll
+        for (int ct = 0; ct < CT1; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = 32 * ct + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (c < C1) d0[(size_t)c * T] = acc1[ct][i];
+            }
+        if constexpr (MODE == 2) {
+            float *d1 = part1 + (((size_t)e * a.BZ + bz) * Ck) * T + o0 + r;
+#pragma unroll
+            for (int ct = 0; ct < CKT; ++ct)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int c = 32 * ct + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (c < Ck) d1[(size_t)c * T] = acc2[ct][i];
+                }
+        }
+    }
+}
+
+template <int MODE, int CKT, int CVT>
+static size_t hm3_lds_bytes() {
+    constexpr int CKP = 32 * CKT, CVP = 32 * CVT, PK1 = CKP + 8, PV1 = CVP + 8, P2 = 40;
+    size_t n = 3 * 32 * PK1;                        // S1 TK
+    if (MODE != 0) n += 3 * CKP * P2 + 3 * 32 * PV1; // S1 CT, S2 TK
+    if (MODE != 1) n += 3 * CVP * P2;                // S2 CT
+    return n * 2;
+}
+
 // out[i] = part[0][i] + part[1][i] + ... (fixed order), n floats per partial
 __global__ __launch_bounds__(256) void hm_sum_partials_kernel(const float *__restrict__ part, float *__restrict__ out, long long n, int nsplit) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -475,7 +798,18 @@ static int hm2_launch_x(const HmArgs &a, float *workspace, hipStream_t s) {
     const long long n0 = (long long)a.BZ * C1 * a.T, n1 = (long long)a.BZ * a.Ck * a.T;
     // one split: the partial IS the result
     float *p0 = (nsplit == 1 || a.keep_parts) ? a.out0 : workspace, *p1 = (nsplit == 1 || a.keep_parts) ? a.out1 : workspace + (size_t)nsplit * n0;
-    hipLaunchKernelGGL((hmha2_kernel<MODE, CKT, CVT, X4>), grid, dim3(256), lds, s, a, p0, p1);
+    // split-precision form (round 6): HNO_HM_SPLIT bit MODE (default: all three); 16-byte token quads
+    static const int split_modes = getenv("HNO_HM_SPLIT") ? atoi(getenv("HNO_HM_SPLIT")) : HM_SPLIT_DEFAULT;
+    if (X4 && CKT <= 3 && CVT <= 3 && ((split_modes >> MODE) & 1)) {      // (<= 96 grouped channels: the fragments of wider heads do not fit the registers)
+        const size_t lds3 = hm3_lds_bytes<MODE, CKT, CVT>();
+        static int attr3 = -1;
+        if (lds3 > 48 * 1024 && attr3 != current_device()) {
+            HNO_CHECK_HIP(hipFuncSetAttribute((const void *)hmha3_kernel<MODE, CKT, CVT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+            attr3 = current_device();
+        }
+        hipLaunchKernelGGL((hmha3_kernel<MODE, CKT, CVT>), grid, dim3(256), lds3, s, a, p0, p1);
+    } else
+        hipLaunchKernelGGL((hmha2_kernel<MODE, CKT, CVT, X4>), grid, dim3(256), lds, s, a, p0, p1);
     HNO_CHECK_LAUNCH();
     if (nsplit > 1 && !a.keep_parts) {
         const int g0 = (int)((n0 + 255) / 256 < 2048 ? (n0 + 255) / 256 : 2048);
