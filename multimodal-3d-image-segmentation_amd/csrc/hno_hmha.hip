@@ -558,36 +558,35 @@ __global__ __launch_bounds__(256, MODE == 0 ? 2 : 1) void hmha3_kernel(HmArgs a,
     float g1tk[S1_TK ? NV1 : 1], g2tk[S2_TK ? NV2 : 1];
     float4 g1ct[S1_CT ? CKT : 1], g2ct[S2_CT ? CVT : 1];
     const int tkt = threadIdx.x & 31, tkq = threadIdx.x >> 5;
+    // (32-bit byte offsets from the tensors' bases: a row's offset u T 4 is wave-uniform, the per-lane part is one add per load; the
+    // 64-bit index arithmetic of the first version was ~100 of the ~900 vector instructions per tile)
+    const unsigned Tb = (unsigned)T * 4u;
     auto fetch = [&](int st) {
-        const int tok = st * 32 + tkt < T ? st * 32 + tkt : T - 1;
+        const unsigned tok = (unsigned)(st * 32 + tkt < T ? st * 32 + tkt : T - 1);
         if constexpr (S1_TK) {
+            const unsigned o = (unsigned)(NV1 * tkq) * Tb + tok * 4u;
 #pragma unroll
-            for (int u = 0; u < NV1; ++u) {
-                const int c = NV1 * tkq + u;
-                g1tk[u] = c < Ck ? S1[(size_t)c * T + tok] : 0.f;
-            }
+            for (int u = 0; u < NV1; ++u) g1tk[u] = NV1 * tkq + u < Ck ? ld_off(S1, o + (unsigned)u * Tb) : 0.f;
         }
         if constexpr (S2_TK) {
+            const unsigned o = (unsigned)(NV2 * tkq) * Tb + tok * 4u;
 #pragma unroll
-            for (int u = 0; u < NV2; ++u) {
-                const int c = NV2 * tkq + u;
-                g2tk[u] = c < Cv ? S2[(size_t)c * T + tok] : 0.f;
-            }
+            for (int u = 0; u < NV2; ++u) g2tk[u] = NV2 * tkq + u < Cv ? ld_off(S2, o + (unsigned)u * Tb) : 0.f;
         }
+        const int q4 = threadIdx.x & 7;
+        const unsigned tk = (unsigned)(st * 32 + 4 * q4 + 4 <= T ? st * 32 + 4 * q4 : T - 4);
         if constexpr (S1_CT) {
 #pragma unroll
             for (int n = 0; n < CKT; ++n) {
-                const int item = threadIdx.x + 256 * n, c = item >> 3, q4 = item & 7;
-                const int tk = st * 32 + 4 * q4 + 4 <= T ? st * 32 + 4 * q4 : T - 4;
-                g1ct[n] = c < Ck ? *reinterpret_cast<const float4 *>(S1 + (size_t)c * T + tk) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int c = (threadIdx.x >> 3) + 32 * n;
+                g1ct[n] = c < Ck ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(S1) + ((unsigned)c * Tb + tk * 4u)) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         if constexpr (S2_CT) {
 #pragma unroll
             for (int n = 0; n < CVT; ++n) {
-                const int item = threadIdx.x + 256 * n, c = item >> 3, q4 = item & 7;
-                const int tk = st * 32 + 4 * q4 + 4 <= T ? st * 32 + 4 * q4 : T - 4;
-                g2ct[n] = c < Cv ? *reinterpret_cast<const float4 *>(S2 + (size_t)c * T + tk) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int c = (threadIdx.x >> 3) + 32 * n;
+                g2ct[n] = c < Cv ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(S2) + ((unsigned)c * Tb + tk * 4u)) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
@@ -662,17 +661,22 @@ __global__ __launch_bounds__(256, MODE == 0 ? 2 : 1) void hmha3_kernel(HmArgs a,
                 hm_mfma6(G0, G0, av, f1[j]);
             }
             const int sbase = st * 32 + 4 * h;
-            f32x16h P;                                       // act(alpha G), rows of tokens beyond T zero
+            const bool tail = st * 32 + 32 > T;              // (uniform) only the last tile has rows of tokens beyond T: masked to zero
+            f32x16h P;                                       // act(alpha G)
             if (lin) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) P[i] = sbase + (i & 3) + 8 * (i >> 2) < T ? a.alpha * G0[i] : 0.f;
+                for (int i = 0; i < 16; ++i) P[i] = a.alpha * G0[i];
             } else {
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) {
                     const f32x2 y = selu_like_pk(f32x2{a.alpha * G0[i], a.alpha * G0[i + 1]}, ap, aq);
-                    P[i] = sbase + (i & 3) + 8 * (i >> 2) < T ? y[0] : 0.f;
-                    P[i + 1] = sbase + ((i + 1) & 3) + 8 * ((i + 1) >> 2) < T ? y[1] : 0.f;
+                    P[i] = y[0];
+                    P[i + 1] = y[1];
                 }
+            }
+            if (tail) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) P[i] = sbase + (i & 3) + 8 * (i >> 2) < T ? P[i] : 0.f;
             }
             if constexpr (MODE == 0) {
 #pragma unroll
@@ -694,8 +698,11 @@ __global__ __launch_bounds__(256, MODE == 0 ? 2 : 1) void hmha3_kernel(HmArgs a,
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float gr = (lin || P[i] > 0.f) ? ap : P[i] + aq;
-                    const float d = a.alpha * H0[i] * gr;
-                    dS[i] = sbase + (i & 3) + 8 * (i >> 2) < T ? d : 0.f;
+                    dS[i] = a.alpha * H0[i] * gr;
+                }
+                if (tail) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) dS[i] = sbase + (i & 3) + 8 * (i >> 2) < T ? dS[i] : 0.f;
                 }
                 if constexpr (MODE == 1) {
 #pragma unroll
