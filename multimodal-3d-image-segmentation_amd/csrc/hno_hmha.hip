@@ -451,18 +451,19 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : 2) void hmha2_kernel(HmArgs a,
 typedef __bf16 hbf8 __attribute__((ext_vector_type(8)));
 struct HmT3 { uint4 t[3]; };            // three bf16 terms of eight values
 
-// bf16 terms by integer arithmetic: round half up in magnitude ((bits + 0x8000) & 0xffff0000: the same 2^-9 bound as the conversion
-// instruction; the term IS an fp32 number, so the remainder x - x0 is exact), the two 16-bit halves of a pair packed by ONE v_perm_b32.
-// ~7 instructions per value; the v_cvt / shift / pack sequence of the first version was ~12 and made the kernel VALU-bound.
+// bf16 terms by integer arithmetic.  The first two terms TRUNCATE (x & 0xffff0000: the term is an fp32 number, so the remainder x - x0
+// is exact, and the halves of a pair are packed by ONE v_perm_b32 straight from the unmasked words); the third rounds what is left
+// (half up in magnitude): |x - (x0 + x1 + x2)| <= 2^-23 |x|, unbiased.
+// ~6.5 instructions per value; the v_cvt / shift / pack sequence of the first version was ~12 and made the kernel VALU-bound.
 __device__ __forceinline__ void hm_split_pair(float a, float b, unsigned &p0, unsigned &p1, unsigned &p2) {
     const unsigned M = 0xffff0000u;
-    const unsigned a0 = (__builtin_bit_cast(unsigned, a) + 0x8000u) & M, b0 = (__builtin_bit_cast(unsigned, b) + 0x8000u) & M;
-    p0 = __builtin_amdgcn_perm(b0, a0, 0x07060302u);
-    const float ra = a - __builtin_bit_cast(float, a0), rb = b - __builtin_bit_cast(float, b0);
-    const unsigned a1 = (__builtin_bit_cast(unsigned, ra) + 0x8000u) & M, b1 = (__builtin_bit_cast(unsigned, rb) + 0x8000u) & M;
-    p1 = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
-    const float sa = ra - __builtin_bit_cast(float, a1), sb = rb - __builtin_bit_cast(float, b1);
-    p2 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sb) + 0x8000u, __builtin_bit_cast(unsigned, sa) + 0x8000u, 0x07060302u);
+    const unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+    p0 = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+    const float fa = a - __builtin_bit_cast(float, ua & M), fb = b - __builtin_bit_cast(float, ub & M);
+    const unsigned ra = __builtin_bit_cast(unsigned, fa), rb = __builtin_bit_cast(unsigned, fb);
+    p1 = __builtin_amdgcn_perm(rb, ra, 0x07060302u);
+    const float qa = fa - __builtin_bit_cast(float, ra & M), qb = fb - __builtin_bit_cast(float, rb & M);
+    p2 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, qb) + 0x8000u, __builtin_bit_cast(unsigned, qa) + 0x8000u, 0x07060302u);
 }
 __device__ __forceinline__ HmT3 hm_split8(const float (&v)[8]) {
     HmT3 o;
