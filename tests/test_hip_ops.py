@@ -2234,7 +2234,10 @@ def test_limits_fail_loudly(pkg):
 
 
 
-@pytest.mark.parametrize('shape', [(1, 2, 12, 20, 70), (2, 3, 32, 32, 64), (1, 4, 96, 96, 1960), (1, 1, 40, 100, 333)])
+# the last three shapes take the split-precision kernels (T % 4 == 0, <= 96 channels) with PARTIAL channel tiles (guarded rows of the staged
+# planes), a partial last token tile, and unequal numbers of key / value channel tiles
+@pytest.mark.parametrize('shape', [(1, 2, 12, 20, 70), (2, 3, 32, 32, 64), (1, 4, 96, 96, 1960), (1, 1, 40, 100, 333),
+                                   (1, 2, 40, 72, 100), (2, 1, 12, 20, 68), (1, 2, 96, 24, 132)])
 @pytest.mark.parametrize('act', ['selu', None])
 def test_fused_hartley_attention_vs_float64(pkg, shape, act):
     """hno_hmha_fwd / hno_hmha_bwd (QK^T -> scale -> activation -> .V without the T x T matrix) against the reference's two
