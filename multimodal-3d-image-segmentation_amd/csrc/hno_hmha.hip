@@ -1004,6 +1004,52 @@ __global__ __launch_bounds__(256) void patch_group_kernel(PgArgs a) {
     }
 }
 
+// The same permutation with FOUR consecutive tokens of one patch voxel (blockIdx.z) per thread: the grouped side moves as 16-byte
+// pieces -- parts -> full: nsum loads per thread added in slice order (the stream-split partial sums of the attention kernels: 8 slices
+// of dQ | dK | dV are 72 MB read for 9 MB written in the HartleyMHASeg step, 22.6 us per launch with one token and 64 four-byte loads per
+// thread: round 6), four scattered 4-byte stores; full -> parts: four scattered loads, one store.  T % 4 == 0, parts 16-byte aligned.
+__global__ __launch_bounds__(256) void patch_group_quad_kernel(PgArgs a) {
+    const int nd = a.d / a.pd, nh = a.h / a.ph, nw = a.w / a.pw;
+    const int P = a.pd * a.ph * a.pw, T = nd * nh * nw;
+    (void)nd;
+    const int b = blockIdx.y / a.Ctot, c = blockIdx.y - b * a.Ctot;
+    const int s = c < a.cend[0] ? 0 : (c < a.cend[1] ? 1 : 2);
+    const int c0 = s == 0 ? 0 : a.cend[s - 1], Cs = a.cend[s] - c0;
+    const float *part = a.part[s];
+    float *fullc = a.full + (size_t)blockIdx.y * a.d * a.h * a.w;
+    const int pi = blockIdx.z, l = pi % a.pw, ij = pi / a.pw, j = ij % a.ph, i = ij / a.ph;
+    const unsigned vo = ((unsigned)i * a.h + j) * a.w + l;
+    const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (t >= T) return;
+    if (!a.inverse) {       // full -> parts: four scattered loads, one 16-byte store
+        if (!part) return;
+        float vv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int tk = t + k, tw = tk % nw, r = tk / nw, th = r % nh, td = r / nh;
+            vv[k] = fullc[((unsigned)(td * a.pd) * a.h + th * a.ph) * a.w + tw * a.pw + vo];
+        }
+        *reinterpret_cast<float4 *>(a.part[s] + (((size_t)b * Cs + (c - c0)) * P + pi) * T + t) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        return;
+    }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (part) {
+        const float *src = part + (((size_t)b * Cs + (c - c0)) * P + pi) * T + t;
+        const size_t slice = (size_t)a.B * Cs * P * T;
+        v = *reinterpret_cast<const float4 *>(src);
+        for (int e = 1; e < a.nsum; ++e) {
+            const float4 u = *reinterpret_cast<const float4 *>(src + (size_t)e * slice);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+    }
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int tk = t + k, tw = tk % nw, r = tk / nw, th = r % nh, td = r / nh;
+        fullc[((unsigned)(td * a.pd) * a.h + th * a.ph) * a.w + tw * a.pw + vo] = vv[k];
+    }
+}
+
 static int patch_group_launch(float *full, float *p0, float *p1, float *p2, int B, int C0, int C1, int C2, int d, int h, int w, int pd,
                               int ph, int pw, int inverse, int nsum, void *stream);
 
@@ -1029,6 +1075,13 @@ static int patch_group_launch(float *full, float *p0, float *p1, float *p2, int 
     a.B = B; a.Ctot = C0 + C1 + C2; a.d = d; a.h = h; a.w = w; a.pd = pd; a.ph = ph; a.pw = pw; a.inverse = inverse; a.nsum = nsum;
     const int T = (d / pd) * (h / ph) * (w / pw);
     HNO_REQUIRE((long long)B * a.Ctot <= 65535 && (long long)d * h * w < (1ll << 31), "hno_patch_group3: too many channels / voxels");
+    static const int quad = getenv("HNO_PG_QUAD") ? atoi(getenv("HNO_PG_QUAD")) : 1;     // A/B aid: 0 = one token per thread
+    if (quad && T % 4 == 0 && pd * ph * pw <= 65535 && !(((size_t)p0 | (size_t)p1 | (size_t)p2) & 15)) {
+        hipLaunchKernelGGL(patch_group_quad_kernel, dim3((unsigned)((T / 4 + 255) / 256), (unsigned)(B * a.Ctot), (unsigned)(pd * ph * pw)), dim3(256), 0,
+                           (hipStream_t)stream, a);
+        HNO_CHECK_LAUNCH();
+        return HNO_OK;
+    }
     int gx = (T + 255) / 256;
     if (gx > 64) gx = 64;
     static const int split_mode = getenv("HNO_PG_SPLIT") ? atoi(getenv("HNO_PG_SPLIT")) : 1;     // 0: never, 1: below 1 024 workgroups, 2: always
