@@ -459,6 +459,7 @@ int hno_patch_group3(float *full, float *p0, float *p1, float *p2, int B, int C0
  * per output -- and the permutation that adds them in slice order while it ungroups (parts -> full only).  Saves the partial-sum launches
  * (4 per attention block and step). */
 int hno_hmha_nsplit(int BZ, int T);
+int hno_hmha_nsplit_bwd(int BZ, int Ck, int Cv, int T);   /* slices of hno_hmha_bwd_parts' outputs (<= hno_hmha_nsplit: round 6) */
 int hno_hmha_parts_supported(int Ck, int Cv, int act);
 int hno_hmha_fwd_parts(const float *q, const float *k, const float *v, float *out_parts, int BZ, int Ck, int Cv, int T, float alpha, int act,
                        void *stream);

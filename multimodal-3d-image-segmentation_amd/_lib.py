@@ -117,6 +117,7 @@ SIGNATURES = {
     'hno_hmha_bwd': (c_int, [c_void_p] * 8 + [c_size_t] + [c_int] * 4 + [c_float, c_int, c_void_p]),
     'hno_patch_group3': (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p]),
     'hno_hmha_nsplit': (c_int, [c_int, c_int]),
+    'hno_hmha_nsplit_bwd': (c_int, [c_int] * 4),
     'hno_hmha_parts_supported': (c_int, [c_int] * 3),
     'hno_hmha_fwd_parts': (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_float, c_int, c_void_p]),
     'hno_hmha_bwd_parts': (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_int, c_void_p]),

@@ -774,15 +774,34 @@ __global__ __launch_bounds__(256) void hm_sum_partials_kernel(const float *__res
 template <int MODE, int CKT, int CVT, bool X4>
 static int hm2_launch_x(const HmArgs &a, float *workspace, hipStream_t s);
 
-// stream splits so that the launch has ~2 waves per SIMD (2 048 waves) without making a split shorter than two tiles
-static int hm2_nsplit(int BZ, int T) {
+// stream splits so that the launch has `waves` waves (2 048 = two per SIMD) without making a split shorter than two tiles
+static int hm2_nsplit(int BZ, int T, int waves = 2048) {
     const int nblk = (T + 127) / 128, ntile = (T + 31) / 32;
     static const int force = getenv("HNO_HM_NSPLIT") ? atoi(getenv("HNO_HM_NSPLIT")) : 0;     // tuning aid
-    int n = (2048 + nblk * 4 * BZ - 1) / (nblk * 4 * BZ);
+    int n = (waves + nblk * 4 * BZ - 1) / (nblk * 4 * BZ);
     if (n > 8) n = 8;
     if (force > 0 && force <= 16) n = force;
     if (n > ntile / 2) n = ntile / 2;
     return n < 1 ? 1 : n;
+}
+static int hm_split_modes() {
+    static const int m = getenv("HNO_HM_SPLIT") ? atoi(getenv("HNO_HM_SPLIT")) : HM_SPLIT_DEFAULT;
+    return m;
+}
+// the split-precision kernels serve this shape in this mode (hm2_launch_x)
+static bool hm3_serves(int mode, int Ck, int Cv, int T) {
+    const int kt = (Ck + 31) / 32, vt = (Cv + 31) / 32;
+    const bool same = (kt == 1 && vt == 1) || (kt <= 2 && vt <= 2) || (kt == 3 && vt == 3);      // hm_dispatch's instantiations up to 3 tiles
+    return same && T % 4 == 0 && T >= 4 && !(debug_flags() & HNO_DBG_HM_PAIR) && ((hm_split_modes() >> mode) & 1);
+}
+// The BACKWARD split-precision kernels hold one workgroup per CU (362 / 483 registers per lane): 8 splits of the published shape are 512
+// workgroups = two rounds, each with its own prologue (the owner's fragments loaded and split) and twice the partial sums for the
+// ungrouping kernel to add.  One round (1 024 waves): dQ 89 -> 81 us, dK / dV 114 -> 105, the summing ungrouping 13.2 -> 10.4 (LESSONS
+// 107); the forward kernel (two workgroups per CU) keeps its 2 048.  HNO_HM_NSPLIT_BWD=0: as the forward.
+static int hm_nsplit_for(int mode, int BZ, int Ck, int Cv, int T) {
+    static const bool bwd_one_round = !(getenv("HNO_HM_NSPLIT_BWD") && atoi(getenv("HNO_HM_NSPLIT_BWD")) == 0);
+    if (mode != 0 && bwd_one_round && hm3_serves(1, Ck, Cv, T) && hm3_serves(2, Ck, Cv, T)) return hm2_nsplit(BZ, T, 1024);
+    return hm2_nsplit(BZ, T);
 }
 
 template <int MODE, int CKT, int CVT>
@@ -800,15 +819,14 @@ static int hm2_launch_x(const HmArgs &a, float *workspace, hipStream_t s) {
         HNO_CHECK_HIP(hipFuncSetAttribute((const void *)hmha2_kernel<MODE, CKT, CVT, X4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = current_device();
     }
-    const int nsplit = hm2_nsplit(a.BZ, a.T);
+    const int nsplit = hm_nsplit_for(MODE, a.BZ, a.Ck, a.Cv, a.T);
     const dim3 grid((a.T + 127) / 128, nsplit, a.BZ);
     const int C1 = MODE == 1 ? a.Ck : a.Cv;
     const long long n0 = (long long)a.BZ * C1 * a.T, n1 = (long long)a.BZ * a.Ck * a.T;
     // one split: the partial IS the result
     float *p0 = (nsplit == 1 || a.keep_parts) ? a.out0 : workspace, *p1 = (nsplit == 1 || a.keep_parts) ? a.out1 : workspace + (size_t)nsplit * n0;
     // split-precision form (round 6): HNO_HM_SPLIT bit MODE (default: all three); 16-byte token quads
-    static const int split_modes = getenv("HNO_HM_SPLIT") ? atoi(getenv("HNO_HM_SPLIT")) : HM_SPLIT_DEFAULT;
-    if (X4 && CKT <= 3 && CVT <= 3 && ((split_modes >> MODE) & 1)) {      // (<= 96 grouped channels: the fragments of wider heads do not fit the registers)
+    if (X4 && CKT <= 3 && CVT <= 3 && ((hm_split_modes() >> MODE) & 1)) {      // (<= 96 grouped channels: the fragments of wider heads do not fit the registers)
         const size_t lds3 = hm3_lds_bytes<MODE, CKT, CVT>();
         static int attr3 = -1;
         if (lds3 > 48 * 1024 && attr3 != current_device()) {
@@ -914,6 +932,8 @@ extern "C" int hno_hmha_bwd(const float *q, const float *k, const float *v, cons
 // consumer adds in slice order while it reads them anyway (hno_patch_group3_sum) -- hm_sum_partials_kernel was 4 launches of ~7 us per
 // attention block and step.  hno_hmha_parts_supported: the shapes / activations the shared-tile kernels serve.
 extern "C" int hno_hmha_nsplit(int BZ, int T) { return BZ > 0 && T > 0 ? hm2_nsplit(BZ, T) : 0; }
+// slices of hno_hmha_bwd_parts' three outputs (round 6: the backward kernels may take fewer splits than the forward one)
+extern "C" int hno_hmha_nsplit_bwd(int BZ, int Ck, int Cv, int T) { return BZ > 0 && Ck > 0 && Cv > 0 && T > 0 ? hm_nsplit_for(1, BZ, Ck, Cv, T) : 0; }
 
 extern "C" int hno_hmha_parts_supported(int Ck, int Cv, int act) {
     return hno_hmha_supported(Ck, Cv) && (act == HNO_ACT_NONE || act == HNO_ACT_SELU || act == HNO_ACT_ELU) && !(debug_flags() & HNO_DBG_HM_ROUND2);

@@ -1446,10 +1446,11 @@ class GroupedAttentionFn(_HnoFunction):
     @staticmethod
     def backward(ctx, g):
         q, k, v = ctx.saved_tensors
-        shape, Z, Kq, Kv, (pd, ph, pw), alpha, act, ns = ctx.cfg
+        shape, Z, Kq, Kv, (pd, ph, pw), alpha, act, _ = ctx.cfg
         B, Ct, d, h, w = shape
         P, T = pd * ph * pw, q.shape[3]
         L = _lib.lib()
+        ns = L.hno_hmha_nsplit_bwd(B * Z, Kq * P, Kv * P, T)      # (the backward kernels may take fewer stream splits than the forward one)
         g = _f32c(g)
         dout = torch.empty_like(v)
         check(L.hno_patch_group3(ptr(g), ptr(dout), None, None, B, Z * Kv, 0, 0, d, h, w, pd, ph, pw, 0, stream_ptr()), 'hno_patch_group3')
